@@ -1,0 +1,276 @@
+"""ctypes binding of libdsss.so (the C ABI declared in include/dsss.h).
+
+This is the only way Python reaches the hot path: there is no Python or CPU implementation behind it.
+If the HIP library has not been built, or no MI355X is visible, loading/creating fails loudly.
+"""
+import ctypes as C
+import os
+import subprocess
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libdsss.so")
+_LIB = None
+
+KP_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"),
+                     ("response", "<f4"), ("octave", "<i4")])
+LC_DTYPE = np.dtype([("rel", "<f8", (12,)), ("var", "<f8", (6,)), ("score", "<f8"), ("iters", "<i4"),
+                     ("_pad", "<i4"), ("err0", "<f8"), ("err1", "<f8")])
+LCEDGE_DTYPE = np.dtype([("a", "<i4"), ("b", "<i4"), ("rel", "<f8", (12,)), ("var", "<f8", (6,))])
+
+K_NAMES = ["preproc", "pyramid", "fast", "desc", "match", "scc", "lc", "pg"]
+
+
+class MaskParams(C.Structure):
+    _fields_ = [("factor", C.c_double), ("width", C.c_int32), ("r", C.c_int32), ("side", C.c_int32)]
+
+
+class OrbParams(C.Structure):
+    _fields_ = [("nfeatures", C.c_int32), ("scale", C.c_float), ("nlevels", C.c_int32),
+                ("ini_th", C.c_int32), ("min_th", C.c_int32)]
+
+
+class MatchParams(C.Structure):
+    _fields_ = [("use_l2", C.c_int32), ("radius", C.c_double), ("bound_same", C.c_int32), ("bound_diff", C.c_int32),
+                ("l2_bound", C.c_double), ("ratio", C.c_double), ("scc_iters", C.c_int32), ("pix_err", C.c_double),
+                ("merge_thr", C.c_double)]
+
+
+class PGParams(C.Structure):
+    _fields_ = [("max_iters", C.c_int32), ("rel_tol", C.c_double), ("abs_tol", C.c_double), ("lambda0", C.c_double),
+                ("lambda_factor", C.c_double), ("lambda_max", C.c_double), ("min_fidelity", C.c_double),
+                ("add_noise", C.c_int32)]
+
+
+class DsssError(RuntimeError):
+    pass
+
+
+def build(force=False):
+    """compile libdsss.so for gfx950 with hipcc (cross-compiles without a GPU)"""
+    src = os.path.join(_HERE, "csrc")
+    if force:
+        subprocess.check_call(["make", "-C", src, "-s", "clean"])
+    subprocess.check_call(["make", "-C", src, "-s", "-j4"])
+    return LIB_PATH
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(LIB_PATH):
+            raise DsssError("libdsss.so is not built (run `python -c 'import __graft_entry__ as g; g.build()'`); "
+                            "there is no CPU fallback")
+        L = C.CDLL(LIB_PATH)
+        L.dsss_strerror.restype = C.c_char_p
+        L.dsss_last_error.restype = C.c_char_p
+        L.dsss_last_error.argtypes = [C.c_void_p]
+        L.dsss_stream.restype = C.c_void_p
+        L.dsss_stream.argtypes = [C.c_void_p]
+        L.dsss_features_pack_bytes.restype = C.c_size_t
+        L.dsss_features_pack_bytes.argtypes = [C.c_void_p]
+        _LIB = L
+    return _LIB
+
+
+def _ptr(a):
+    """host numpy array, torch tensor (host or device) or raw int address -> void*"""
+    if a is None:
+        return None
+    if isinstance(a, np.ndarray):
+        assert a.flags.c_contiguous
+        return C.c_void_p(a.ctypes.data)
+    if hasattr(a, "data_ptr"):
+        assert a.is_contiguous()
+        return C.c_void_p(a.data_ptr())
+    return C.c_void_p(int(a))
+
+
+class Context:
+    """thin RAII wrapper over dsss_ctx"""
+
+    def __init__(self, max_frames, device=0):
+        self.L = lib()
+        h = C.c_void_p()
+        rc = self.L.dsss_create(int(device), int(max_frames), C.byref(h))
+        if rc != 0:
+            raise DsssError("dsss_create: %s" % self.L.dsss_strerror(rc).decode())
+        self.h = h
+        self.max_frames = max_frames
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.dsss_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc, what):
+        if rc != 0:
+            raise DsssError("%s: %s (%s)" % (what, self.L.dsss_strerror(rc).decode(),
+                                             self.L.dsss_last_error(self.h).decode()))
+
+    # ---- params
+    def default_params(self):
+        mp, op, mt, pg = MaskParams(), OrbParams(), MatchParams(), PGParams()
+        self.L.dsss_mask_params_default(C.byref(mp)); self.L.dsss_orb_params_default(C.byref(op))
+        self.L.dsss_match_params_default(C.byref(mt)); self.L.dsss_pg_params_default(C.byref(pg))
+        return mp, op, mt, pg
+
+    def set_params(self, mask=None, orb=None, match=None, pg=None):
+        self._chk(self.L.dsss_set_params(self.h, C.byref(mask) if mask else None, C.byref(orb) if orb else None,
+                                         C.byref(match) if match else None, C.byref(pg) if pg else None), "dsss_set_params")
+
+    def sync(self):
+        self._chk(self.L.dsss_sync(self.h), "dsss_sync")
+
+    # ---- frames
+    def frame_set(self, fid, raw, N, M, pose6, alt, gr):
+        pose6 = np.ascontiguousarray(pose6, np.float64); alt = np.ascontiguousarray(alt, np.float64)
+        gr = np.ascontiguousarray(gr, np.float64)
+        assert pose6.shape == (N, 6) and alt.shape == (N,) and gr.shape == (M // 2,)
+        if isinstance(raw, np.ndarray):
+            raw = np.ascontiguousarray(raw, np.float64); assert raw.shape == (N, M)
+        self._keep = getattr(self, "_keep", {}); self._keep[fid] = raw      # keep device tensors alive
+        self._chk(self.L.dsss_frame_set(self.h, fid, _ptr(raw), N, M, _ptr(pose6), _ptr(alt), _ptr(gr)), "dsss_frame_set")
+
+    def extract(self, fid):
+        n = C.c_int(0)
+        self._chk(self.L.dsss_extract(self.h, fid, C.byref(n)), "dsss_extract")
+        return n.value
+
+    def extract_many(self, ids):
+        ids = np.ascontiguousarray(ids, np.int32)
+        self._chk(self.L.dsss_extract_many(self.h, _ptr(ids), len(ids)), "dsss_extract_many")
+
+    def frame_norm(self, fid, N, M):
+        norm = np.zeros((N, M), np.uint8); mask = np.zeros((N, M), np.uint8)
+        self._chk(self.L.dsss_frame_get_norm(self.h, fid, _ptr(norm), _ptr(mask)), "dsss_frame_get_norm")
+        return norm, mask
+
+    def frame_level(self, fid, level, cap_rows, cap_cols):
+        img = np.zeros(cap_rows * cap_cols, np.uint8); r = C.c_int(0); c = C.c_int(0)
+        self._chk(self.L.dsss_frame_get_level(self.h, fid, level, _ptr(img), C.byref(r), C.byref(c)), "dsss_frame_get_level")
+        return img[:r.value * c.value].reshape(r.value, c.value).copy()
+
+    def frame_candidates(self, fid, level, cap=200000):
+        x = np.zeros(cap, np.float32); y = np.zeros(cap, np.float32); r = np.zeros(cap, np.float32); n = C.c_int(0)
+        self._chk(self.L.dsss_frame_get_candidates(self.h, fid, level, _ptr(x), _ptr(y), _ptr(r), cap, C.byref(n)), "dsss_frame_get_candidates")
+        return x[:n.value].copy(), y[:n.value].copy(), r[:n.value].copy()
+
+    def features_get(self, fid, cap=16384):
+        kps = np.zeros(cap, KP_DTYPE); desc = np.zeros((cap, 32), np.uint8); geo = np.zeros((cap, 2), np.float64)
+        n = C.c_int(0)
+        self._chk(self.L.dsss_features_get(self.h, fid, _ptr(kps), _ptr(desc), _ptr(geo), cap, C.byref(n)), "dsss_features_get")
+        return kps[:n.value].copy(), desc[:n.value].copy(), geo[:n.value].copy()
+
+    def features_set(self, fid, N, M, kps, desc, geo=None, bbox=None):
+        kps = np.ascontiguousarray(kps, KP_DTYPE); desc = np.ascontiguousarray(desc, np.uint8).reshape(-1, 32)
+        if geo is not None: geo = np.ascontiguousarray(geo, np.float64).reshape(-1, 2)
+        if bbox is not None: bbox = np.ascontiguousarray(bbox, np.float64)
+        self._chk(self.L.dsss_features_set(self.h, fid, N, M, _ptr(kps), _ptr(desc), _ptr(geo), _ptr(bbox), len(kps)), "dsss_features_set")
+
+    def frame_bbox(self, fid):
+        bb = np.zeros(4, np.float64)
+        self._chk(self.L.dsss_frame_bbox(self.h, fid, _ptr(bb)), "dsss_frame_bbox")
+        return bb
+
+    def overlap(self, a, b):
+        v = C.c_float(0)
+        self._chk(self.L.dsss_overlap(self.h, a, b, C.byref(v)), "dsss_overlap")
+        return v.value
+
+    def pack_bytes(self):
+        return int(self.L.dsss_features_pack_bytes(self.h))
+
+    def features_pack(self, fid, buf):
+        self._chk(self.L.dsss_features_pack(self.h, fid, _ptr(buf)), "dsss_features_pack")
+
+    def features_unpack(self, fid, buf):
+        self._chk(self.L.dsss_features_unpack(self.h, fid, _ptr(buf)), "dsss_features_unpack")
+
+    # ---- matcher
+    def match_pairs(self, src, tgt):
+        src = np.ascontiguousarray(src, np.int32); tgt = np.ascontiguousarray(tgt, np.int32)
+        self._chk(self.L.dsss_match_pairs(self.h, _ptr(src), _ptr(tgt), len(src)), "dsss_match_pairs")
+
+    def match_dir(self, pair, d, cap=16384):
+        nn = np.zeros(cap, np.int32); co = np.zeros(cap, np.int32)
+        hist = C.c_int(0); cnt = C.c_int(0); model = C.c_double(0)
+        self._chk(self.L.dsss_match_get_dir(self.h, pair, d, _ptr(nn), _ptr(co), cap, C.byref(hist), C.byref(cnt), C.byref(model)), "dsss_match_get_dir")
+        return nn, co, hist.value, cnt.value, model.value
+
+    def match_rows(self, pair):
+        n = C.c_int(0)
+        self._chk(self.L.dsss_match_get_rows(self.h, pair, None, 0, C.byref(n)), "dsss_match_get_rows")
+        rows = np.zeros((max(n.value, 1), 6), np.float64)
+        self._chk(self.L.dsss_match_get_rows(self.h, pair, _ptr(rows), len(rows), C.byref(n)), "dsss_match_get_rows")
+        return rows[:n.value].copy()
+
+    def match_kp7(self, pair):
+        n = C.c_int(0)
+        self._chk(self.L.dsss_match_get_kp7(self.h, pair, None, 0, C.byref(n)), "dsss_match_get_kp7")
+        out = np.zeros((max(n.value, 1), 7), np.float64)
+        self._chk(self.L.dsss_match_get_kp7(self.h, pair, _ptr(out), len(out), C.byref(n)), "dsss_match_get_kp7")
+        return out[:n.value].copy()
+
+    def match_total(self):
+        a = C.c_int(0); b = C.c_int(0)
+        self._chk(self.L.dsss_match_total(self.h, C.byref(a), C.byref(b)), "dsss_match_total")
+        return a.value, b.value
+
+    def descriptor_distance(self, fa, ia, fb, ib):
+        d = C.c_int(0)
+        self._chk(self.L.dsss_descriptor_distance(self.h, fa, ia, fb, ib, C.byref(d)), "dsss_descriptor_distance")
+        return d.value
+
+    # ---- optimizer
+    def lc_solve_all(self):
+        self._chk(self.L.dsss_lc_solve_all(self.h), "dsss_lc_solve_all")
+
+    def lc_get(self, pair):
+        n = C.c_int(0)
+        self._chk(self.L.dsss_lc_get(self.h, pair, None, 0, C.byref(n)), "dsss_lc_get")
+        out = np.zeros(max(n.value, 1), LC_DTYPE)
+        self._chk(self.L.dsss_lc_get(self.h, pair, _ptr(out), len(out), C.byref(n)), "dsss_lc_get")
+        return out[:n.value].copy()
+
+    def lc_solve(self, id_s, id_t, kp7):
+        kp7 = np.ascontiguousarray(kp7, np.float64).reshape(-1, 7)
+        out = np.zeros(max(len(kp7), 1), LC_DTYPE)
+        self._chk(self.L.dsss_lc_solve(self.h, id_s, id_t, _ptr(kp7), len(kp7), _ptr(out)), "dsss_lc_solve")
+        return out[:len(kp7)].copy()
+
+    def posegraph_select(self, nframes, cap=1 << 20):
+        edges = np.zeros(cap, LCEDGE_DTYPE); n = C.c_int(0)
+        self._chk(self.L.dsss_posegraph_select(self.h, nframes, _ptr(edges), cap, C.byref(n)), "dsss_posegraph_select")
+        return edges[:n.value].copy()
+
+    def posegraph_solve(self, nframes, total):
+        poses = np.zeros((total, 12), np.float64); rpy = np.zeros((total, 6), np.float64); stats = np.zeros(4, np.float64)
+        self._chk(self.L.dsss_posegraph_solve(self.h, nframes, _ptr(poses), _ptr(rpy), _ptr(stats)), "dsss_posegraph_solve")
+        return poses, rpy, stats
+
+    def posegraph_solve_edges(self, dr6, edges):
+        dr6 = np.ascontiguousarray(dr6, np.float64).reshape(-1, 6)
+        edges = np.ascontiguousarray(edges, LCEDGE_DTYPE)
+        poses = np.zeros((len(dr6), 12), np.float64); stats = np.zeros(4, np.float64)
+        self._chk(self.L.dsss_posegraph_solve_edges(self.h, _ptr(dr6), len(dr6), _ptr(edges), len(edges), _ptr(poses), _ptr(stats)),
+                  "dsss_posegraph_solve_edges")
+        return poses, stats
+
+    # ---- instrumentation
+    def profile(self, on=True):
+        self._chk(self.L.dsss_profile_enable(self.h, 1 if on else 0), "dsss_profile_enable")
+
+    def profile_reset(self):
+        self._chk(self.L.dsss_profile_reset(self.h), "dsss_profile_reset")
+
+    def profile_get(self):
+        ms = np.zeros(8, np.float64); n = np.zeros(8, np.int64)
+        self._chk(self.L.dsss_profile_get(self.h, _ptr(ms), _ptr(n)), "dsss_profile_get")
+        return {K_NAMES[i]: (float(ms[i]), int(n[i])) for i in range(8)}

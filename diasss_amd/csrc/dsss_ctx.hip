@@ -1,0 +1,402 @@
+// diasss_amd/csrc/dsss_ctx.hip -- context, frame registration, feature store, geo lookup, overlap.
+// Mirrors the data side of Diasss::Frame (/root/reference/src/core/frame.h:19-46, frame.cpp:18-55,126-165)
+// and Util::ComputeIntersection (/root/reference/src/util/util.cpp:13-43).
+#include "dsss_internal.h"
+#include <algorithm>
+
+extern "C" {
+
+void dsss_mask_params_default(dsss_mask_params* p) { p->factor = 2.5; p->width = 10; p->r = 6; p->side = 150; }
+void dsss_orb_params_default(dsss_orb_params* p) { p->nfeatures = 2000; p->scale = 1.2f; p->nlevels = 6; p->ini_th = 12; p->min_th = 7; }
+void dsss_match_params_default(dsss_match_params* p)
+{
+    p->use_l2 = 0; p->radius = 8; p->bound_same = 88; p->bound_diff = 80; p->l2_bound = 350; p->ratio = 0.35;
+    p->scc_iters = 1000; p->pix_err = 2.5; p->merge_thr = 2.5;
+}
+void dsss_pg_params_default(dsss_pg_params* p)
+{
+    p->max_iters = 100; p->rel_tol = 1e-5; p->abs_tol = 1e-5; p->lambda0 = 1e-5; p->lambda_factor = 10;
+    p->lambda_max = 1e5; p->min_fidelity = 1e-3; p->add_noise = 1;
+}
+
+const char* dsss_strerror(int code)
+{
+    switch (code) {
+    case DSSS_OK: return "ok";
+    case DSSS_E_NODEVICE: return "no HIP device (libdsss has no CPU fallback)";
+    case DSSS_E_ARG: return "bad argument";
+    case DSSS_E_HIP: return "HIP runtime error";
+    case DSSS_E_STATE: return "call order violated";
+    case DSSS_E_CAPACITY: return "buffer too small";
+    case DSSS_E_NUMERIC: return "numerical failure";
+    default: return "unknown error";
+    }
+}
+const char* dsss_last_error(const dsss_ctx* c) { return c ? c->err.c_str() : "null context"; }
+
+static int kcap_for(const dsss_orb_params& op) { return ((op.nfeatures + 3 * op.nlevels + 63) / 64 + 1) * 64; }
+
+int dsss_create(int device, int max_frames, dsss_ctx** out)
+{
+    if (!out || max_frames <= 0) return DSSS_E_ARG;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device < 0 || device >= ndev) return DSSS_E_NODEVICE;
+    if (hipSetDevice(device) != hipSuccess) return DSSS_E_NODEVICE;
+    dsss_ctx* c = new dsss_ctx();
+    c->device = device;
+    dsss_mask_params_default(&c->mp); dsss_orb_params_default(&c->op);
+    dsss_match_params_default(&c->mt); dsss_pg_params_default(&c->pg);
+    c->max_frames = max_frames;
+    c->frames.resize(max_frames);
+    c->kcap = kcap_for(c->op);
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return DSSS_E_HIP; }
+    hipEventCreate(&c->prof.e0); hipEventCreate(&c->prof.e1);
+    *out = c;
+    return DSSS_OK;
+}
+
+static void free_frame(dsss_frame& f)
+{
+    hipFree(f.raw_owned); hipFree(f.pose6); hipFree(f.alt); hipFree(f.gr); hipFree(f.mask);
+    for (int l = 0; l < DSSS_MAX_LEVELS; ++l) hipFree(f.lvl[l]);
+    f = dsss_frame();
+}
+
+static void free_match(dsss_ctx* c)
+{
+    hipFree(c->act_s); hipFree(c->act_t); hipFree(c->corres_nn); hipFree(c->corres);
+    hipFree(c->scc_hist); hipFree(c->scc_count); hipFree(c->scc_model);
+    hipFree(c->row_cnt); hipFree(c->kp7_cnt); hipFree(c->row_off); hipFree(c->kp7_off);
+    hipFree(c->rows6); hipFree(c->kp7); hipFree(c->kp7_pair); hipFree(c->kp7_flip);
+    c->act_s = c->act_t = nullptr; c->corres_nn = c->corres = nullptr;
+    c->scc_hist = c->scc_count = nullptr; c->scc_model = nullptr;
+    c->row_cnt = c->kp7_cnt = c->row_off = c->kp7_off = nullptr;
+    c->rows6 = c->kp7 = nullptr; c->kp7_pair = nullptr; c->kp7_flip = nullptr;
+    c->match_cap_pairs = 0; c->rows_cap = 0;
+}
+
+static void free_store(dsss_ctx* c)
+{
+    hipFree(c->kps); hipFree(c->desc); hipFree(c->geo); hipFree(c->nkp_dev); hipFree(c->rows_dev);
+    hipFree(c->cols_dev); hipFree(c->bbox_dev);
+    c->kps = nullptr; c->desc = nullptr; c->geo = nullptr; c->nkp_dev = nullptr; c->rows_dev = nullptr;
+    c->cols_dev = nullptr; c->bbox_dev = nullptr;
+}
+
+void dsss_destroy(dsss_ctx* c)
+{
+    if (!c) return;
+    hipSetDevice(c->device);
+    hipStreamSynchronize(c->stream);
+    for (auto& f : c->frames) free_frame(f);
+    free_match(c); free_store(c);
+    hipFree(c->lcs); hipFree(c->ex_scratch); hipFree(c->mt_aux);
+    if (c->ex_pinned) hipHostFree(c->ex_pinned);
+    dsss_pg_free(c);
+    hipEventDestroy(c->prof.e0); hipEventDestroy(c->prof.e1);
+    hipStreamDestroy(c->stream);
+    delete c;
+}
+
+int dsss_sync(dsss_ctx* c) { if (!c) return DSSS_E_ARG; HIPCHK(c, hipStreamSynchronize(c->stream)); return DSSS_OK; }
+void* dsss_stream(dsss_ctx* c) { return c ? (void*)c->stream : nullptr; }
+
+int dsss_set_params(dsss_ctx* c, const dsss_mask_params* mp, const dsss_orb_params* op, const dsss_match_params* mt,
+                    const dsss_pg_params* pg)
+{
+    if (!c) return DSSS_E_ARG;
+    if (mp) c->mp = *mp;
+    if (op) {
+        if (op->nlevels < 1 || op->nlevels > DSSS_MAX_LEVELS || op->nfeatures < 1 || !(op->scale > 1.0f))
+            DSSS_FAIL(c, DSSS_E_ARG, "orb params out of range");
+        int k = kcap_for(*op);
+        if (k != c->kcap) {
+            if (c->kps) { HIPCHK(c, hipStreamSynchronize(c->stream)); free_store(c); free_match(c); for (auto& f : c->frames) f.has_feat = false; }
+            c->kcap = k;
+        }
+        c->op = *op;
+    }
+    if (mt) c->mt = *mt;
+    if (pg) c->pg = *pg;
+    return DSSS_OK;
+}
+
+} // extern "C"
+
+int dsss_ensure_store(dsss_ctx* c)
+{
+    if (c->kps) return DSSS_OK;
+    size_t F = (size_t)c->max_frames, K = (size_t)c->kcap;
+    HIPCHK(c, hipMalloc(&c->kps, F * K * sizeof(dsss_kp)));
+    HIPCHK(c, hipMalloc(&c->desc, F * K * 32));
+    HIPCHK(c, hipMalloc(&c->geo, F * K * 2 * sizeof(double)));
+    HIPCHK(c, hipMalloc(&c->nkp_dev, F * sizeof(int)));
+    HIPCHK(c, hipMalloc(&c->rows_dev, F * sizeof(int)));
+    HIPCHK(c, hipMalloc(&c->cols_dev, F * sizeof(int)));
+    HIPCHK(c, hipMalloc(&c->bbox_dev, F * 4 * sizeof(double)));
+    HIPCHK(c, hipMemsetAsync(c->nkp_dev, 0, F * sizeof(int), c->stream));
+    HIPCHK(c, hipMemsetAsync(c->rows_dev, 0, F * sizeof(int), c->stream));
+    HIPCHK(c, hipMemsetAsync(c->cols_dev, 0, F * sizeof(int), c->stream));
+    HIPCHK(c, hipMemsetAsync(c->bbox_dev, 0, F * 4 * sizeof(double), c->stream));
+    HIPCHK(c, hipMemsetAsync(c->desc, 0, F * K * 32, c->stream));
+    return DSSS_OK;
+}
+
+// ---- geo bounding box: the four cv::minMaxLoc scans of the N x M geo image (FEAmatcher.cpp:71-72,
+// util.cpp:21-26) collapse to per-row extremes because x = px + g*c is monotone in g for fixed c:
+// only the smallest and largest ground range of each side can be extreme.  One wave per 64 rows.
+__global__ void geo_bbox_kernel(const double* __restrict__ pose6, const double* __restrict__ gr, int N, int M,
+                                double* __restrict__ bbox)
+{
+    __shared__ double sgmin[2], sgmax[2];
+    __shared__ double red[4][256];
+    int half = M / 2;
+    if (threadIdx.x < 2) {
+        // starboard uses gr[0..half-1]; port uses gr[min(half-col, half-1)] for col 0..half-1 = gr[1..half-1]
+        int lo = threadIdx.x == 0 ? 0 : (half > 1 ? 1 : 0);
+        double mn = gr[lo], mx = gr[lo];
+        for (int k = lo + 1; k < half; ++k) { double g = gr[k]; mn = g < mn ? g : mn; mx = g > mx ? g : mx; }
+        sgmin[threadIdx.x] = mn; sgmax[threadIdx.x] = mx;
+    }
+    __syncthreads();
+    double xmin = INFINITY, xmax = -INFINITY, ymin = INFINITY, ymax = -INFINITY;
+    for (int row = threadIdx.x; row < N; row += blockDim.x) {
+        const double* P = pose6 + (size_t)row * 6;
+        for (int side = 0; side < 2; ++side) {
+            double ang = side == 0 ? P[2] + DSSS_PI_REF / 2 : P[2] - DSSS_PI_REF / 2;
+            double s, c; dsss_sincos(ang, &s, &c);
+            for (int e = 0; e < 2; ++e) {
+                double g = e ? sgmax[side] : sgmin[side];
+                double x = (P[3] - 0.0) + g * c, y = (P[4] - 0.0) + g * s;
+                xmin = x < xmin ? x : xmin; xmax = x > xmax ? x : xmax;
+                ymin = y < ymin ? y : ymin; ymax = y > ymax ? y : ymax;
+            }
+        }
+    }
+    red[0][threadIdx.x] = xmin; red[1][threadIdx.x] = xmax; red[2][threadIdx.x] = ymin; red[3][threadIdx.x] = ymax;
+    __syncthreads();
+    for (int s = blockDim.x / 2; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) {
+            red[0][threadIdx.x] = fmin(red[0][threadIdx.x], red[0][threadIdx.x + s]);
+            red[1][threadIdx.x] = fmax(red[1][threadIdx.x], red[1][threadIdx.x + s]);
+            red[2][threadIdx.x] = fmin(red[2][threadIdx.x], red[2][threadIdx.x + s]);
+            red[3][threadIdx.x] = fmax(red[3][threadIdx.x], red[3][threadIdx.x + s]);
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x < 4) bbox[threadIdx.x] = red[threadIdx.x][0];
+}
+
+int dsss_frame_geo_bbox(dsss_ctx* c, int id)
+{
+    dsss_frame& f = c->frames[id];
+    if (!f.has_geom) DSSS_FAIL(c, DSSS_E_STATE, "frame %d has no geometry", id);
+    int rc = dsss_ensure_store(c); if (rc) return rc;
+    hipLaunchKernelGGL(geo_bbox_kernel, dim3(1), dim3(256), 0, c->stream, f.pose6, f.gr, f.N, f.M, c->bbox_dev + (size_t)id * 4);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipMemcpyAsync(f.bbox, c->bbox_dev + (size_t)id * 4, 4 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    f.has_bbox = true;
+    return DSSS_OK;
+}
+
+// geo_img sample at (int(pt.y), int(pt.x)) of every stored keypoint (FEAmatcher.cpp:81-82,89-90) without
+// materialising the 2 x N x M f64 geo image
+__global__ void kp_geo_kernel(const dsss_kp* __restrict__ kps, int n, const double* __restrict__ pose6,
+                              const double* __restrict__ gr, int M, double* __restrict__ geo)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    int row = (int)kps[i].y, col = (int)kps[i].x;
+    double x, y;
+    dsss_geo_at(pose6, gr, M, row, col, &x, &y);
+    geo[2 * i] = x; geo[2 * i + 1] = y;
+}
+
+int dsss_frame_kp_geo(dsss_ctx* c, int id, int n)
+{
+    dsss_frame& f = c->frames[id];
+    if (n <= 0) return DSSS_OK;
+    hipLaunchKernelGGL(kp_geo_kernel, dim3((n + 255) / 256), dim3(256), 0, c->stream,
+                       c->kps + (size_t)id * c->kcap, n, f.pose6, f.gr, f.M, c->geo + (size_t)id * c->kcap * 2);
+    HIPCHK(c, hipGetLastError());
+    return DSSS_OK;
+}
+
+extern "C" {
+
+int dsss_frame_set(dsss_ctx* c, int id, const double* raw, int N, int M, const double* pose6, const double* alt,
+                   const double* grange)
+{
+    if (!c) return DSSS_E_ARG;
+    if (id < 0 || id >= c->max_frames) DSSS_FAIL(c, DSSS_E_ARG, "frame id %d out of range [0,%d)", id, c->max_frames);
+    if (N <= 0 || M < 4 || (M & 1) || !pose6 || !alt || !grange) DSSS_FAIL(c, DSSS_E_ARG, "bad frame geometry N=%d M=%d", N, M);
+    HIPCHK(c, hipSetDevice(c->device));
+    int rc = dsss_ensure_store(c); if (rc) return rc;
+    dsss_frame& f = c->frames[id];
+    if (f.N != N || f.M != M) { HIPCHK(c, hipStreamSynchronize(c->stream)); free_frame(f); }
+    f.N = N; f.M = M;
+    if (!f.pose6) {
+        HIPCHK(c, hipMalloc(&f.pose6, (size_t)N * 6 * sizeof(double)));
+        HIPCHK(c, hipMalloc(&f.alt, (size_t)N * sizeof(double)));
+        HIPCHK(c, hipMalloc(&f.gr, (size_t)(M / 2) * sizeof(double)));
+    }
+    f.h_pose6.resize((size_t)N * 6); f.h_alt.resize(N); f.h_gr.resize(M / 2);
+    HIPCHK(c, hipMemcpy(f.h_pose6.data(), pose6, (size_t)N * 6 * sizeof(double), hipMemcpyDefault));
+    HIPCHK(c, hipMemcpy(f.h_alt.data(), alt, (size_t)N * sizeof(double), hipMemcpyDefault));
+    HIPCHK(c, hipMemcpy(f.h_gr.data(), grange, (size_t)(M / 2) * sizeof(double), hipMemcpyDefault));
+    HIPCHK(c, hipMemcpyAsync(f.pose6, f.h_pose6.data(), (size_t)N * 6 * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(f.alt, f.h_alt.data(), (size_t)N * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(f.gr, f.h_gr.data(), (size_t)(M / 2) * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->rows_dev + id, &f.N, sizeof(int), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->cols_dev + id, &f.M, sizeof(int), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    f.has_geom = true; f.has_feat = false; f.has_norm = false; f.nkp = 0;
+    if (raw) {
+        hipPointerAttribute_t at;
+        bool on_dev = (hipPointerGetAttributes(&at, raw) == hipSuccess) && at.type == hipMemoryTypeDevice;
+        (void)hipGetLastError();
+        if (on_dev) { f.raw = raw; }
+        else {
+            if (!f.raw_owned) HIPCHK(c, hipMalloc(&f.raw_owned, (size_t)N * M * sizeof(double)));
+            HIPCHK(c, hipMemcpy(f.raw_owned, raw, (size_t)N * M * sizeof(double), hipMemcpyHostToDevice));
+            f.raw = f.raw_owned;
+        }
+        f.has_raw = true;
+    } else f.has_raw = false;
+    return dsss_frame_geo_bbox(c, id);
+}
+
+int dsss_features_set(dsss_ctx* c, int id, int N, int M, const dsss_kp* kps, const uint8_t* desc, const double* geo,
+                      const double* bbox, int n)
+{
+    if (!c) return DSSS_E_ARG;
+    if (id < 0 || id >= c->max_frames) DSSS_FAIL(c, DSSS_E_ARG, "frame id %d out of range", id);
+    if (n < 0 || n > c->kcap) DSSS_FAIL(c, DSSS_E_CAPACITY, "%d features exceed the per-frame capacity %d", n, c->kcap);
+    if (n > 0 && (!kps || !desc)) return DSSS_E_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    int rc = dsss_ensure_store(c); if (rc) return rc;
+    dsss_frame& f = c->frames[id];
+    if (!f.has_geom) { f.N = N; f.M = M; }
+    else if (f.N != N || f.M != M) DSSS_FAIL(c, DSSS_E_ARG, "frame %d geometry mismatch", id);
+    size_t K = c->kcap;
+    if (n > 0) {
+        HIPCHK(c, hipMemcpyAsync(c->kps + id * K, kps, (size_t)n * sizeof(dsss_kp), hipMemcpyDefault, c->stream));
+        HIPCHK(c, hipMemcpyAsync(c->desc + id * K * 32, desc, (size_t)n * 32, hipMemcpyDefault, c->stream));
+    }
+    if (geo) { if (n > 0) HIPCHK(c, hipMemcpyAsync(c->geo + id * K * 2, geo, (size_t)n * 2 * sizeof(double), hipMemcpyDefault, c->stream)); }
+    else {
+        if (!f.has_geom) DSSS_FAIL(c, DSSS_E_STATE, "geo == NULL needs dsss_frame_set first");
+        rc = dsss_frame_kp_geo(c, id, n); if (rc) return rc;
+    }
+    if (bbox) {
+        HIPCHK(c, hipMemcpy(f.bbox, bbox, 4 * sizeof(double), hipMemcpyDefault));
+        HIPCHK(c, hipMemcpyAsync(c->bbox_dev + (size_t)id * 4, f.bbox, 4 * sizeof(double), hipMemcpyHostToDevice, c->stream));
+        f.has_bbox = true;
+    } else if (!f.has_bbox) DSSS_FAIL(c, DSSS_E_STATE, "bbox == NULL needs dsss_frame_set first");
+    HIPCHK(c, hipMemcpyAsync(c->nkp_dev + id, &n, sizeof(int), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->rows_dev + id, &f.N, sizeof(int), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->cols_dev + id, &f.M, sizeof(int), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    f.nkp = n; f.has_feat = true;
+    return DSSS_OK;
+}
+
+int dsss_features_get(dsss_ctx* c, int id, dsss_kp* kps, uint8_t* desc, double* geo, int cap, int* n)
+{
+    if (!c) return DSSS_E_ARG;
+    if (id < 0 || id >= c->max_frames) DSSS_FAIL(c, DSSS_E_ARG, "frame id %d out of range", id);
+    dsss_frame& f = c->frames[id];
+    if (!f.has_feat) DSSS_FAIL(c, DSSS_E_STATE, "frame %d has no features", id);
+    if (n) *n = f.nkp;
+    if (cap < f.nkp) DSSS_FAIL(c, DSSS_E_CAPACITY, "caller capacity %d < %d features", cap, f.nkp);
+    size_t K = c->kcap;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (f.nkp > 0) {
+        if (kps) HIPCHK(c, hipMemcpy(kps, c->kps + id * K, (size_t)f.nkp * sizeof(dsss_kp), hipMemcpyDeviceToHost));
+        if (desc) HIPCHK(c, hipMemcpy(desc, c->desc + id * K * 32, (size_t)f.nkp * 32, hipMemcpyDeviceToHost));
+        if (geo) HIPCHK(c, hipMemcpy(geo, c->geo + id * K * 2, (size_t)f.nkp * 2 * sizeof(double), hipMemcpyDeviceToHost));
+    }
+    return DSSS_OK;
+}
+
+int dsss_frame_bbox(dsss_ctx* c, int id, double* bbox)
+{
+    if (!c || !bbox) return DSSS_E_ARG;
+    if (id < 0 || id >= c->max_frames) DSSS_FAIL(c, DSSS_E_ARG, "frame id %d out of range", id);
+    if (!c->frames[id].has_bbox) DSSS_FAIL(c, DSSS_E_STATE, "frame %d has no bounding box", id);
+    memcpy(bbox, c->frames[id].bbox, 4 * sizeof(double));
+    return DSSS_OK;
+}
+
+// Util::ComputeIntersection (util.cpp:13-43): float arithmetic on the double extrema; host code because it is
+// 20 flops on values that already live on the host (the expensive part, the 4 minMaxLoc scans, is the bbox kernel)
+int dsss_overlap(dsss_ctx* c, int id_s, int id_t, float* iou)
+{
+    if (!c || !iou) return DSSS_E_ARG;
+    if (id_s < 0 || id_s >= c->max_frames || id_t < 0 || id_t >= c->max_frames) DSSS_FAIL(c, DSSS_E_ARG, "frame id out of range");
+    const dsss_frame &a = c->frames[id_s], &b = c->frames[id_t];
+    if (!a.has_bbox || !b.has_bbox) DSSS_FAIL(c, DSSS_E_STATE, "frames need dsss_frame_set first");
+    float output = 0.0f;
+    double sx_min = a.bbox[0], sx_max = a.bbox[1], sy_min = a.bbox[2], sy_max = a.bbox[3];
+    double tx_min = b.bbox[0], tx_max = b.bbox[1], ty_min = b.bbox[2], ty_max = b.bbox[3];
+    float x_dist_ol = (float)(std::min(sx_max, tx_max) - std::max(sx_min, tx_min));
+    float y_dist_ol = (float)(std::min(ty_max, sy_max) - std::max(sy_min, ty_min));
+    if (x_dist_ol > 0 && y_dist_ol > 0) {
+        float area_ol = x_dist_ol * y_dist_ol;
+        float area_s = (float)(std::abs(sx_max - sx_min) * std::abs(sy_max - sy_min));
+        float area_t = (float)(std::abs(tx_max - tx_min) * std::abs(ty_max - ty_min));
+        output = area_ol / (area_s + area_t - area_ol);
+    }
+    *iou = output;
+    return DSSS_OK;
+}
+
+// packed record for collectives: [int32 n, N, M, pad][bbox 4 f64][kps kcap][desc kcap*32][geo kcap*2]
+size_t dsss_features_pack_bytes(const dsss_ctx* c)
+{
+    size_t K = c->kcap;
+    return 16 + 32 + K * sizeof(dsss_kp) + K * 32 + K * 16;
+}
+int dsss_features_pack(dsss_ctx* c, int id, void* buf)
+{
+    if (!c || !buf) return DSSS_E_ARG;
+    if (id < 0 || id >= c->max_frames) DSSS_FAIL(c, DSSS_E_ARG, "frame id out of range");
+    dsss_frame& f = c->frames[id];
+    if (!f.has_feat) DSSS_FAIL(c, DSSS_E_STATE, "frame %d has no features", id);
+    size_t K = c->kcap; char* p = (char*)buf;
+    int32_t hdr[4] = { f.nkp, f.N, f.M, 0 };
+    HIPCHK(c, hipMemcpyAsync(p, hdr, 16, hipMemcpyDefault, c->stream));
+    HIPCHK(c, hipMemcpyAsync(p + 16, f.bbox, 32, hipMemcpyDefault, c->stream));
+    HIPCHK(c, hipMemcpyAsync(p + 48, c->kps + id * K, K * sizeof(dsss_kp), hipMemcpyDefault, c->stream));
+    HIPCHK(c, hipMemcpyAsync(p + 48 + K * sizeof(dsss_kp), c->desc + id * K * 32, K * 32, hipMemcpyDefault, c->stream));
+    HIPCHK(c, hipMemcpyAsync(p + 48 + K * sizeof(dsss_kp) + K * 32, c->geo + id * K * 2, K * 16, hipMemcpyDefault, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return DSSS_OK;
+}
+int dsss_features_unpack(dsss_ctx* c, int id, const void* buf)
+{
+    if (!c || !buf) return DSSS_E_ARG;
+    size_t K = c->kcap; const char* p = (const char*)buf;
+    int32_t hdr[4]; double bbox[4];
+    HIPCHK(c, hipMemcpy(hdr, p, 16, hipMemcpyDefault));
+    HIPCHK(c, hipMemcpy(bbox, p + 16, 32, hipMemcpyDefault));
+    return dsss_features_set(c, id, hdr[1], hdr[2], (const dsss_kp*)(p + 48), (const uint8_t*)(p + 48 + K * sizeof(dsss_kp)),
+                             (const double*)(p + 48 + K * sizeof(dsss_kp) + K * 32), bbox, hdr[0]);
+}
+
+int dsss_profile_enable(dsss_ctx* c, int on) { if (!c) return DSSS_E_ARG; c->prof.on = on != 0; return DSSS_OK; }
+int dsss_profile_reset(dsss_ctx* c)
+{
+    if (!c) return DSSS_E_ARG;
+    for (int i = 0; i < DSSS_K_COUNT; ++i) { c->prof.ms[i] = 0; c->prof.launches[i] = 0; }
+    return DSSS_OK;
+}
+int dsss_profile_get(dsss_ctx* c, double* ms, int64_t* launches)
+{
+    if (!c) return DSSS_E_ARG;
+    for (int i = 0; i < DSSS_K_COUNT; ++i) { if (ms) ms[i] = c->prof.ms[i]; if (launches) launches[i] = c->prof.launches[i]; }
+    return DSSS_OK;
+}
+
+} // extern "C"

@@ -1,0 +1,152 @@
+// diasss_amd/csrc/dsss_internal.h -- shared state of libdsss.so (MI355X / gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <cmath>
+#include <string>
+#include <vector>
+#include "../../include/dsss.h"
+
+#define DSSS_MAX_LEVELS 8
+#define DSSS_PI_REF 3.14159265359   // the reference's PI macro (frame.cpp:16, FEAmatcher.cpp:11, optimizer.cpp:19)
+
+struct dsss_frame {
+    int N = 0, M = 0;
+    bool has_geom = false, has_raw = false, has_feat = false, has_norm = false;
+    const double* raw = nullptr;      // device; borrowed when the caller passed a device pointer
+    double* raw_owned = nullptr;      // device; owned copy of a host image
+    double* pose6 = nullptr;          // device N x 6
+    double* alt = nullptr;            // device N
+    double* gr = nullptr;             // device M/2
+    std::vector<double> h_pose6, h_alt, h_gr;   // small host copies (pose graph, reprojection checks)
+    uint8_t* mask = nullptr;          // device N x M
+    uint8_t* lvl[DSSS_MAX_LEVELS] = {nullptr};  // image pyramid, lvl[0] = normalised image
+    int lrows[DSSS_MAX_LEVELS] = {0}, lcols[DSSS_MAX_LEVELS] = {0};
+    size_t img_cap = 0;               // bytes allocated for mask / lvl[0]
+    int nkp = 0;
+    double bbox[4] = {0, 0, 0, 0};
+    bool has_bbox = false;
+    // FAST candidates of the last extraction, per level (host, for the stage tap)
+    std::vector<float> cand_x[DSSS_MAX_LEVELS], cand_y[DSSS_MAX_LEVELS], cand_r[DSSS_MAX_LEVELS];
+};
+
+struct dsss_prof {
+    bool on = false;
+    double ms[DSSS_K_COUNT] = {0};
+    int64_t launches[DSSS_K_COUNT] = {0};
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+};
+
+struct dsss_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string err;
+    dsss_mask_params mp;
+    dsss_orb_params op;
+    dsss_match_params mt;
+    dsss_pg_params pg;
+    int max_frames = 0;
+    int kcap = 0;                       // per-frame feature capacity (multiple of 64)
+    std::vector<dsss_frame> frames;
+    // feature store, device, frame-major with stride kcap
+    dsss_kp* kps = nullptr;             // [F][kcap]
+    uint8_t* desc = nullptr;            // [F][kcap][32]
+    double* geo = nullptr;              // [F][kcap][2]
+    int* nkp_dev = nullptr;             // [F]
+    int* rows_dev = nullptr;            // [F] pings per frame
+    int* cols_dev = nullptr;            // [F]
+    double* bbox_dev = nullptr;         // [F][4]
+    // extraction scratch (grown on demand)
+    void* ex_scratch = nullptr; size_t ex_scratch_bytes = 0;
+    void* ex_pinned = nullptr; size_t ex_pinned_bytes = 0;
+    // matcher state
+    void* mt_aux = nullptr; size_t mt_aux_bytes = 0;   // per-frame pointer tables + cv::RNG stream
+    const double** d_ptrs = nullptr;                   // [3][max_frames]: alt, gr, pose6 device pointers
+    int npairs = 0, nactive = 0;
+    std::vector<int> pair_s, pair_t, pair_active;   // pair_active[p] = active index or -1
+    int* act_s = nullptr; int* act_t = nullptr;     // device [nactive]
+    int32_t* corres_nn = nullptr;       // [2*nactive][kcap]
+    int32_t* corres = nullptr;          // [2*nactive][kcap]
+    int* scc_hist = nullptr; int* scc_count = nullptr; double* scc_model = nullptr; // [2*nactive]
+    int* row_cnt = nullptr; int* kp7_cnt = nullptr; int* row_off = nullptr; int* kp7_off = nullptr; // [nactive(+1)]
+    std::vector<int> h_row_off, h_kp7_off;
+    double* rows6 = nullptr; double* kp7 = nullptr; int* kp7_pair = nullptr; uint8_t* kp7_flip = nullptr;
+    int total_rows = 0, total_kp7 = 0;
+    size_t match_cap_pairs = 0, rows_cap = 0;
+    // LC results
+    dsss_lc* lcs = nullptr; size_t lcs_cap = 0; bool has_lc = false;
+    // pose-graph scratch
+    void* pg_state = nullptr;
+    dsss_prof prof;
+};
+
+#define DSSS_FAIL(ctx, code, ...) do { char _b[512]; snprintf(_b, sizeof _b, __VA_ARGS__); (ctx)->err = _b; return (code); } while (0)
+#define HIPCHK(ctx, call) do { hipError_t _e = (call); if (_e != hipSuccess) { \
+    char _b[512]; snprintf(_b, sizeof _b, "%s:%d %s -> %s", __FILE__, __LINE__, #call, hipGetErrorString(_e)); \
+    (ctx)->err = _b; return DSSS_E_HIP; } } while (0)
+
+// kernel-family timing with HIP events on the context stream (dsss_profile_*)
+struct dsss_scope {
+    dsss_ctx* c; int k;
+    dsss_scope(dsss_ctx* c_, int k_) : c(c_), k(k_) { if (c->prof.on) hipEventRecord(c->prof.e0, c->stream); }
+    ~dsss_scope() {
+        if (c->prof.on) {
+            hipEventRecord(c->prof.e1, c->stream);
+            hipEventSynchronize(c->prof.e1);
+            float ms = 0; hipEventElapsedTime(&ms, c->prof.e0, c->prof.e1);
+            c->prof.ms[k] += ms; c->prof.launches[k] += 1;
+        }
+    }
+};
+
+int dsss_ensure_store(dsss_ctx* c);                 // allocate the feature store for the current kcap
+int dsss_frame_geo_bbox(dsss_ctx* c, int id);       // device computation of the geo bounding box
+int dsss_frame_kp_geo(dsss_ctx* c, int id, int n);  // geo lookup of the stored keypoints (frame.cpp:126-165)
+void dsss_pg_free(dsss_ctx* c);
+
+// deterministic sin/cos shared by every kernel that must agree with the oracle bit for bit:
+// Cody-Waite reduction + fdlibm kernel polynomials, plain IEEE mul/add only (library built -ffp-contract=off)
+__host__ __device__ inline void dsss_sincos(double x, double* s, double* c)
+{
+    const double invpio2 = 6.36619772367581382433e-01;
+    const double pio2_1 = 1.57079632673412561417e+00;
+    const double pio2_1t = 6.07710050650619224932e-11;
+    double k = rint(x * invpio2);
+    double r = (x - k * pio2_1) - k * pio2_1t;
+    double z = r * r;
+    double ps = 1.58969099521155010221e-10;
+    ps = ps * z + -2.50507602534068634195e-08;
+    ps = ps * z + 2.75573137070700676789e-06;
+    ps = ps * z + -1.98412698298579493134e-04;
+    ps = ps * z + 8.33333333332248946124e-03;
+    ps = ps * z + -1.66666666666666324348e-01;
+    double sr = r + (r * z) * ps;
+    double pc = -1.13596475577881948265e-11;
+    pc = pc * z + 2.08757232129817482790e-09;
+    pc = pc * z + -2.75573143513906633035e-07;
+    pc = pc * z + 2.48015872894767294178e-05;
+    pc = pc * z + -1.38888888888741095749e-03;
+    pc = pc * z + 4.16666666666666019037e-02;
+    double cr = (1.0 - 0.5 * z) + (z * z) * pc;
+    long long q = ((long long)k) & 3;
+    if (q == 0) { *s = sr; *c = cr; }
+    else if (q == 1) { *s = cr; *c = -sr; }
+    else if (q == 2) { *s = -sr; *c = -cr; }
+    else { *s = -cr; *c = sr; }
+}
+
+// Frame::GetGeoImg for one bin (frame.cpp:126-165); port column 0 clamps the one-past-the-end read
+__host__ __device__ inline void dsss_geo_at(const double* pose6, const double* gr, int M, int row, int col,
+                                            double* x, double* y)
+{
+    const double* P = pose6 + (size_t)row * 6;
+    int half = M / 2, idx; double ang;
+    if (col >= half) { idx = col - half; ang = P[2] + DSSS_PI_REF / 2; }
+    else { idx = half - col; if (idx > half - 1) idx = half - 1; ang = P[2] - DSSS_PI_REF / 2; }
+    double s, c;
+    dsss_sincos(ang, &s, &c);
+    *x = (P[3] - 0.0) + gr[idx] * c;
+    *y = (P[4] - 0.0) + gr[idx] * s;
+}

@@ -1,0 +1,150 @@
+/*
+ * include/dsss.h -- C ABI of the MI355X-native diasss hot path (libdsss.so).
+ *
+ * The reference (halajun/diasss) has no plugin/FFI layer: its boundary is the C++ API that
+ * src/diasss2.cpp compiles against (Frame, FEAmatcher, Optimizer, Util).  The host-side mirror of those
+ * classes lives in diasss_amd/host/ and calls ONLY the entry points declared here; every entry point cites
+ * the reference interface it replaces (path:line under /root/reference).
+ *
+ * Conventions
+ *   - plain C: opaque context, plain pointers and sizes, no C++/torch types;
+ *   - return 0 (DSSS_OK) or a negative DSSS_E_* code, never throws; dsss_last_error() has the detail;
+ *   - the context owns all device memory and HIP streams; one context per (host thread, device);
+ *   - every input pointer may be a HOST or a DEVICE pointer (copied with hipMemcpyDefault);
+ *     output pointers named *_host are host memory;
+ *   - frames are identified by their img_id (0..F-1), which is also the index diasss2.cpp:84 uses;
+ *   - there is NO CPU fallback: without a HIP device dsss_create fails with DSSS_E_NODEVICE.
+ */
+#ifndef DSSS_H
+#define DSSS_H
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DSSS_OK            0
+#define DSSS_E_NODEVICE   -1   /* no HIP device / hipSetDevice failed */
+#define DSSS_E_ARG        -2   /* bad argument (null, range, size) */
+#define DSSS_E_HIP        -3   /* a HIP runtime call failed */
+#define DSSS_E_STATE      -4   /* call order violated (e.g. match before features exist) */
+#define DSSS_E_CAPACITY   -5   /* a caller buffer or an internal fixed-capacity buffer is too small */
+#define DSSS_E_NUMERIC    -6   /* linear system not positive definite / non-finite value */
+
+typedef struct dsss_ctx dsss_ctx;
+
+/* cv::KeyPoint subset that the path touches (ORBextractor.cpp:840-847,1103-1109) */
+typedef struct { float x, y, size, angle, response; int32_t octave; } dsss_kp;
+
+/* hard-coded locals of the reference gathered per stage ("Config / flags") */
+typedef struct {                 /* frame.cpp:59,85-86 */
+    double factor;  int32_t width, r, side;
+} dsss_mask_params;
+typedef struct {                 /* frame.cpp:180: ORBextractor(2000, 1.2, 6, 12, 7) */
+    int32_t nfeatures; float scale; int32_t nlevels, ini_th, min_th;
+} dsss_orb_params;
+typedef struct {                 /* FEAmatcher.cpp:63-66,108-110,143-147,189-190,329 */
+    int32_t use_l2; double radius; int32_t bound_same, bound_diff; double l2_bound, ratio;
+    int32_t scc_iters; double pix_err, merge_thr;
+} dsss_match_params;
+typedef struct {                 /* GTSAM LevenbergMarquardtParams() defaults + optimizer.cpp:154-160 */
+    int32_t max_iters; double rel_tol, abs_tol, lambda0, lambda_factor, lambda_max, min_fidelity;
+    int32_t add_noise;
+} dsss_pg_params;
+typedef struct { double rel[12]; double var[6]; double score; int32_t iters; int32_t pad_; double err0, err1; } dsss_lc;
+typedef struct { int32_t a, b; double rel[12]; double var[6]; } dsss_lc_edge;
+
+void dsss_mask_params_default(dsss_mask_params*);
+void dsss_orb_params_default(dsss_orb_params*);
+void dsss_match_params_default(dsss_match_params*);
+void dsss_pg_params_default(dsss_pg_params*);
+
+/* ------------------------------------------------------------------ context */
+int  dsss_create(int device, int max_frames, dsss_ctx** out);
+void dsss_destroy(dsss_ctx*);
+const char* dsss_strerror(int code);
+const char* dsss_last_error(const dsss_ctx*);
+int  dsss_sync(dsss_ctx*);                       /* hipStreamSynchronize of the context stream */
+void* dsss_stream(dsss_ctx*);                    /* hipStream_t, for event timing by the caller */
+int  dsss_set_params(dsss_ctx*, const dsss_mask_params*, const dsss_orb_params*, const dsss_match_params*,
+                     const dsss_pg_params*);     /* NULL keeps the current (default = reference) values */
+
+/* ------------------------------------------------------------------ Frame (frame.h:19-20, frame.cpp:18-55)
+ * Frame::Frame(id, img CV_64F NxM, pose CV_64F Nx6 [roll pitch yaw x y z], altitudes[N], ground_ranges[M/2], anno)
+ * raw may stay resident in HBM (device pointer): nothing is copied back to the host.                     */
+int dsss_frame_set(dsss_ctx*, int id, const double* raw, int N, int M,
+                   const double* pose6, const double* alt, const double* grange);
+/* GetNormalizeSSS + GetFilteredMask + DetectFeature (frame.cpp:57-124,167-203) with the ORB descriptor
+ * configuration of thirdparty/ORBextractor.cpp (operator() :1049-1113).  Features stay on the device.       */
+int dsss_extract(dsss_ctx*, int id, int* n_kp_host);
+int dsss_extract_many(dsss_ctx*, const int* ids, int n);      /* same, pipelined over frames */
+/* stage taps for parity tests (host outputs; any may be NULL) */
+int dsss_frame_get_norm(dsss_ctx*, int id, uint8_t* norm_host, uint8_t* mask_host);            /* Frame::norm_img, flt_mask */
+int dsss_frame_get_level(dsss_ctx*, int id, int level, uint8_t* img_host, int* rows, int* cols);/* mvImagePyramid[level] */
+int dsss_frame_get_candidates(dsss_ctx*, int id, int level, float* x_host, float* y_host, float* resp_host,
+                              int cap, int* n);                                                /* vToDistributeKeys */
+/* Frame::kps / Frame::dst (+ the geo_img samples FEAmatcher.cpp:81-82 reads) */
+int dsss_features_get(dsss_ctx*, int id, dsss_kp* kps_host, uint8_t* desc_host, double* geo_host, int cap, int* n);
+/* import features computed elsewhere (another rank's all-gather, or a test); geo/bbox may be NULL when the
+ * frame geometry was given with dsss_frame_set (they are then recomputed on the device)                     */
+int dsss_features_set(dsss_ctx*, int id, int N, int M, const dsss_kp* kps, const uint8_t* desc,
+                      const double* geo, const double* bbox, int n);
+/* geo bounding box = the minMaxLoc pairs of FEAmatcher.cpp:71-72 / util.cpp:21-26: xmin,xmax,ymin,ymax */
+int dsss_frame_bbox(dsss_ctx*, int id, double* bbox_host);
+/* Util::ComputeIntersection (util.h:25, util.cpp:13-43) */
+int dsss_overlap(dsss_ctx*, int id_s, int id_t, float* iou_host);
+/* packed per-frame feature record for collectives (all-gather over RCCL): size and (de)serialisation */
+size_t dsss_features_pack_bytes(const dsss_ctx*);
+int dsss_features_pack(dsss_ctx*, int id, void* dev_or_host_buf);
+int dsss_features_unpack(dsss_ctx*, int id, const void* dev_or_host_buf);
+
+/* ------------------------------------------------------------------ FEAmatcher (FEAmatcher.h:20-33)
+ * One call = FEAmatcher::RobustMatching for every listed (source,target) pair, batched on the device:
+ * GeoNearNeighSearch both directions (:52-321) + ConsistentCheck (:323-405) + the rows RobustMatching appends
+ * to Frame::corres_kps (:35-45) + Optimizer::GetKpsPairs (optimizer.cpp:575-639) on those rows.
+ * Results stay on the device; the getters copy one pair out.                                               */
+int dsss_match_pairs(dsss_ctx*, const int* src_ids, const int* tgt_ids, int npairs);
+int dsss_match_get_dir(dsss_ctx*, int pair, int dir /*0: s->t, 1: t->s*/, int32_t* corres_nn_host,
+                       int32_t* corres_host, int cap, int* scc_hist, int* scc_count, double* scc_model);
+int dsss_match_get_rows(dsss_ctx*, int pair, double* rows6_host, int cap, int* nrows);   /* [id_s,id_t,y_s,x_s,y_t,x_t] */
+int dsss_match_get_kp7(dsss_ctx*, int pair, double* kp7_host, int cap, int* n);          /* Vector7 of optimizer.cpp:625 */
+int dsss_match_total(dsss_ctx*, int* total_rows, int* total_kp7);
+/* FEAmatcher::DescriptorDistance (FEAmatcher.h:33) on device-resident descriptors of two frames */
+int dsss_descriptor_distance(dsss_ctx*, int id_a, int ia, int id_b, int ib, int* dist_host);
+
+/* ------------------------------------------------------------------ Optimizer (optimizer.h:43-67)
+ * LoopClosingTFs (optimizer.cpp:641-982) for every kp pair produced by dsss_match_pairs.                   */
+int dsss_lc_solve_all(dsss_ctx*);
+int dsss_lc_get(dsss_ctx*, int pair, dsss_lc* out_host, int cap, int* n);
+/* stand-alone form (tests): kp7 given by the caller                                                         */
+int dsss_lc_solve(dsss_ctx*, int id_s, int id_t, const double* kp7, int n, dsss_lc* out_host);
+/* TrajOptimizationAll (optimizer.h:43; optimizer.cpp:101-279): LC selection + batch LM over every ping of
+ * every frame 0..nframes-1 (frames must have been given with dsss_frame_set). poses12_host: total x 12
+ * (R row-major, t); rpy6_host: total x 6 "r p y x y z" as SaveTrajactoryAll writes (:1164-1214).           */
+int dsss_posegraph_select(dsss_ctx*, int nframes, dsss_lc_edge* edges_host, int cap, int* n_edges);
+int dsss_posegraph_solve(dsss_ctx*, int nframes, double* poses12_host, double* rpy6_host, double* stats4_host);
+/* stand-alone form: explicit DR chain + edges                                                               */
+int dsss_posegraph_solve_edges(dsss_ctx*, const double* dr6, int total, const dsss_lc_edge* edges, int ne,
+                               double* poses12_host, double* stats4_host);
+
+/* ------------------------------------------------------------------ instrumentation
+ * accumulated GPU time (ms, HIP events on the context stream) and launch count per kernel family        */
+#define DSSS_K_PREPROC 0
+#define DSSS_K_PYRAMID 1
+#define DSSS_K_FAST    2
+#define DSSS_K_DESC    3
+#define DSSS_K_MATCH   4
+#define DSSS_K_SCC     5
+#define DSSS_K_LC      6
+#define DSSS_K_PG      7
+#define DSSS_K_COUNT   8
+int dsss_profile_enable(dsss_ctx*, int on);
+int dsss_profile_get(dsss_ctx*, double* ms_host /*DSSS_K_COUNT*/, int64_t* launches_host /*DSSS_K_COUNT*/);
+int dsss_profile_reset(dsss_ctx*);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DSSS_H */
