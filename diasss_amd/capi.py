@@ -11,6 +11,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libdsss.so")
 _LIB = None
+_HIP = None
 
 KP_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"),
                      ("response", "<f4"), ("octave", "<i4")])
@@ -55,12 +56,32 @@ def build(force=False):
     return LIB_PATH
 
 
+def _load_hip_runtime():
+    """libdsss.so leaves the HIP runtime symbols undefined so that ONE runtime serves the whole process.
+    PyTorch ships its own libamdhip64 (soname libamdhip64.so) next to the system one (libamdhip64.so.7); loading
+    both makes the second one see no GPU.  So: if torch is importable use the copy it loads, else the system copy."""
+    try:
+        import torch  # noqa: F401  (loads torch/lib/libamdhip64.so)
+        cand = os.path.join(os.path.dirname(torch.__file__), "lib", "libamdhip64.so")
+        if os.path.exists(cand):
+            return C.CDLL(cand, mode=C.RTLD_GLOBAL)
+    except Exception:
+        pass
+    for cand in ("/opt/rocm/lib/libamdhip64.so", "libamdhip64.so.7", "libamdhip64.so"):
+        try:
+            return C.CDLL(cand, mode=C.RTLD_GLOBAL)
+        except OSError:
+            continue
+    raise DsssError("no HIP runtime (libamdhip64) found")
+
+
 def lib():
-    global _LIB
+    global _LIB, _HIP
     if _LIB is None:
         if not os.path.exists(LIB_PATH):
             raise DsssError("libdsss.so is not built (run `python -c 'import __graft_entry__ as g; g.build()'`); "
                             "there is no CPU fallback")
+        _HIP = _load_hip_runtime()
         L = C.CDLL(LIB_PATH)
         L.dsss_strerror.restype = C.c_char_p
         L.dsss_last_error.restype = C.c_char_p

@@ -1,0 +1,727 @@
+// diasss_amd/csrc/dsss_extract.hip -- per-frame preprocessing and ORB extraction on the device (gfx950).
+// Restates Frame::GetNormalizeSSS / GetFilteredMask / DetectFeature (/root/reference/src/core/frame.cpp:57-124,
+// 167-203) and ORBextractor::operator() in its ORB-descriptor configuration
+// (/root/reference/thirdparty/ORBextractor.cpp:77-147,410-479,765-853,1034-1041,1049-1140).
+// Everything except the quadtree cull (quadtree.cpp, host) runs in HIP kernels; all of it is integer / fixed
+// point / explicitly ordered floating point, so results are bit-exact against oracle/orc_frame.c + orc_orb.c.
+#include "dsss_internal.h"
+#include <algorithm>
+
+int dsss_quadtree_cull(const float* xs, const float* ys, const float* resp, int n,
+                       int minX, int maxX, int minY, int maxY, int quota, std::vector<int>& keep);
+
+#define EDGE_T 19
+#define HALF_PATCH 15
+#define CELL_MAX 66            // FAST window: cell (ceil(width/nCols) < 60) + 6; 37 once a level is >= 900 px wide
+#define CELL_STRIDE 68
+#define CELL_CAP 1024          // strict 8-neighbour local maxima in 60 x 60 <= 30 x 30
+
+// ------------------------------------------------------------------ K1: mean / min, normalise, mask
+// Row sums in the fixed order of oracle/orc_frame.c:fixed_sum (128 strided partials -> lane pairs -> xor
+// butterfly) so that 2.5*mean is reproducible bit for bit.  One wave per ping, 16-byte loads.
+__device__ inline double wave_fixed_sum_tail(double p0, double p1)
+{
+    double v = p0 + p1;
+#pragma unroll
+    for (int k = 32; k >= 1; k >>= 1) v = v + __shfl_xor(v, k, 64);
+    return v;
+}
+
+__global__ __launch_bounds__(256) void row_reduce_kernel(const double* __restrict__ raw, int N, int M,
+                                                         double* __restrict__ rowsum, double* __restrict__ rowmin)
+{
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= N) return;
+    const double* r = raw + (size_t)row * M;
+    double p0 = 0.0, p1 = 0.0, mn = INFINITY;
+    for (int j = 2 * lane; j < M; j += 128) {
+        if (j + 1 < M) {
+            const double2 v = *reinterpret_cast<const double2*>(r + j);
+            p0 += v.x; p1 += v.y;
+            mn = v.x < mn ? v.x : mn; mn = v.y < mn ? v.y : mn;
+        } else { const double a = r[j]; p0 += a; mn = a < mn ? a : mn; }
+    }
+    const double s = wave_fixed_sum_tail(p0, p1);
+#pragma unroll
+    for (int k = 32; k >= 1; k >>= 1) { const double o = __shfl_xor(mn, k, 64); mn = o < mn ? o : mn; }
+    if (lane == 0) { rowsum[row] = s; rowmin[row] = mn; }
+}
+
+// stats[0] = mean, stats[1] = min, stats[2] = 2.5*mean (normalisation ceiling), stats[3] = mask threshold
+__global__ __launch_bounds__(64) void final_reduce_kernel(const double* __restrict__ rowsum, const double* __restrict__ rowmin,
+                                                          int N, int M, double mask_factor, double* __restrict__ stats)
+{
+    const int lane = threadIdx.x;
+    double p0 = 0.0, p1 = 0.0, mn = INFINITY;
+    for (int j = 2 * lane; j < N; j += 128) {
+        p0 += rowsum[j]; mn = rowmin[j] < mn ? rowmin[j] : mn;
+        if (j + 1 < N) { p1 += rowsum[j + 1]; mn = rowmin[j + 1] < mn ? rowmin[j + 1] : mn; }
+    }
+    const double tot = wave_fixed_sum_tail(p0, p1);
+#pragma unroll
+    for (int k = 32; k >= 1; k >>= 1) { const double o = __shfl_xor(mn, k, 64); mn = o < mn ? o : mn; }
+    if (lane == 0) {
+        const double mean = tot / ((double)N * (double)M);
+        stats[0] = mean; stats[1] = mn; stats[2] = mean * 2.5; stats[3] = mean * mask_factor;
+    }
+}
+
+// static part of Frame::GetFilteredMask (frame.cpp:104-112)
+__global__ void mask_init_kernel(uint8_t* __restrict__ mask, int N, int M, int width, int side, double sidec)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)N * M) return;
+    const int r = (int)(i / M), c = (int)(i % M);
+    bool off = (c > M / 2 - width && c < M / 2 + width) || (r < side || r > N - side) ||
+               ((double)c < sidec || (double)c > (double)M - sidec);
+    mask[i] = off ? 0 : 255;
+}
+
+// Frame::GetNormalizeSSS (frame.cpp:67-78) + the hot-pixel eraser of GetFilteredMask (:98-103).
+// 4 pixels per thread: 2 x 16-byte loads, one 4-byte store.  Erasures only ever write 0, so the scatter is race free.
+__global__ __launch_bounds__(256) void normalize_kernel(const double* __restrict__ raw, int N, int M,
+                                                        const double* __restrict__ stats, int er,
+                                                        uint8_t* __restrict__ norm, uint8_t* __restrict__ mask)
+{
+    const size_t total = (size_t)N * M;
+    const size_t i0 = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    if (i0 >= total) return;
+    const double mn = stats[1], den = stats[2] - stats[1], thr = stats[3];
+    double v[4];
+    const int cnt = (int)((total - i0) < 4 ? (total - i0) : 4);
+    if (cnt == 4 && ((reinterpret_cast<uintptr_t>(raw + i0) & 15) == 0)) {
+        const double2 a = *reinterpret_cast<const double2*>(raw + i0), b = *reinterpret_cast<const double2*>(raw + i0 + 2);
+        v[0] = a.x; v[1] = a.y; v[2] = b.x; v[3] = b.y;
+    } else for (int k = 0; k < 4; ++k) v[k] = k < cnt ? raw[i0 + k] : 0.0;
+    uint8_t q[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        double o = (v[k] - mn) / den * 255.0;
+        if (o > 255.0) o = 255.0;
+        int r = (int)rint(o);                       // convertTo(CV_8U): saturate_cast<uchar>(cvRound())
+        r = r < 0 ? 0 : (r > 255 ? 255 : r);
+        q[k] = (uint8_t)r;
+        if (k < cnt && v[k] > thr) {
+            const int pi = (int)((i0 + k) / M), pj = (int)((i0 + k) % M);
+            if (pi - er >= 0 && pj - er >= 0)       // the reference's size_t loops do not run otherwise
+                for (int x = pi - er; x < pi + er && x < N; ++x)
+                    for (int y = pj - er; y < pj + er && y < M; ++y) mask[(size_t)x * M + y] = 0;
+        }
+    }
+    if (cnt == 4 && ((i0 & 3) == 0)) *reinterpret_cast<uchar4*>(norm + i0) = make_uchar4(q[0], q[1], q[2], q[3]);
+    else for (int k = 0; k < cnt; ++k) norm[i0 + k] = q[k];
+}
+
+// ------------------------------------------------------------------ K2: cv::resize INTER_LINEAR, CV_8UC1
+// (ORBextractor.cpp:1128).  11-bit fixed point exactly as OpenCV's scalar path: see oracle/orc_orb.c.
+__device__ inline int cvfloorf_dev(float v) { const int i = (int)v; return i - (v < (float)i); }
+
+__global__ __launch_bounds__(256) void resize_kernel(const uint8_t* __restrict__ src, int sh, int sw,
+                                                     uint8_t* __restrict__ dst, int dh, int dw, double scale_x, double scale_y)
+{
+    const int dx = blockIdx.x * blockDim.x + threadIdx.x, dy = blockIdx.y;
+    if (dx >= dw || dy >= dh) return;
+    float fx = (float)((dx + 0.5) * scale_x - 0.5);
+    int sx = cvfloorf_dev(fx);
+    fx -= sx;
+    bool edge = false;
+    if (sx < 0) { fx = 0; sx = 0; }
+    if (sx + 1 >= sw) { edge = true; if (sx >= sw - 1) { fx = 0; sx = sw - 1; } }
+    const int a0 = __float2int_rn((1.f - fx) * 2048.f), a1 = __float2int_rn(fx * 2048.f);
+    float fy = (float)((dy + 0.5) * scale_y - 0.5);
+    const int sy = cvfloorf_dev(fy);
+    fy -= sy;
+    const int b0 = __float2int_rn((1.f - fy) * 2048.f), b1 = __float2int_rn(fy * 2048.f);
+    const int ya = sy < 0 ? 0 : (sy < sh ? sy : sh - 1);
+    const int yb = sy + 1 < 0 ? 0 : (sy + 1 < sh ? sy + 1 : sh - 1);
+    const uint8_t* S0 = src + (size_t)ya * sw;
+    const uint8_t* S1 = src + (size_t)yb * sw;
+    int r0, r1;
+    if (!edge) { r0 = S0[sx] * a0 + S0[sx + 1] * a1; r1 = S1[sx] * a0 + S1[sx + 1] * a1; }
+    else { r0 = S0[sx] * 2048; r1 = S1[sx] * 2048; }     // dx >= xmax in OpenCV's HResize
+    dst[(size_t)dy * dw + dx] = (uint8_t)((((b0 * (r0 >> 4)) >> 16) + ((b1 * (r1 >> 4)) >> 16) + 2) >> 2);
+}
+
+// ------------------------------------------------------------------ K3: cv::FAST 9/16 per 30-px cell
+struct fast_cell { int level, x0, y0, w, h, offx, offy, pad; };
+struct level_tab { const uint8_t* img[DSSS_MAX_LEVELS]; int cols[DSSS_MAX_LEVELS]; };
+
+__constant__ int c_ring_dx[16] = { 0, 1, 2, 3, 3, 3, 2, 1, 0, -1, -2, -3, -3, -3, -2, -1 };
+__constant__ int c_ring_dy[16] = { 3, 3, 2, 1, 0, -1, -2, -3, -3, -3, -2, -1, 0, 1, 2, 3 };
+
+// arc value A = max over the 16 arcs of 9 contiguous ring pixels of max(min(v - ring), min(ring - v));
+// corner at threshold t iff A > t, cornerScore = A - 1.  Values <= tmin are reported as 0 (never a corner, and
+// never able to suppress one), which lets the common smooth pixel leave after the opposite-pair test.
+__device__ inline int fast_arc(const uint8_t* w, int stride, int x, int y, int tmin)
+{
+    const int v = w[y * stride + x];
+    int d[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) d[k] = v - (int)w[(y + c_ring_dy[k]) * stride + (x + c_ring_dx[k])];
+    // every arc of 9 holds one pixel of each opposite pair: both inside [-tmin, tmin] => A <= tmin
+#pragma unroll
+    for (int k = 0; k < 8; ++k) if (abs(d[k]) <= tmin && abs(d[k + 8]) <= tmin) return 0;
+    int best = 0;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        int mn = d[k], mx = d[k];
+#pragma unroll
+        for (int j = 1; j < 9; ++j) { const int e = d[(k + j) & 15]; mn = e < mn ? e : mn; mx = e > mx ? e : mx; }
+        best = mn > best ? mn : best;
+        best = -mx > best ? -mx : best;
+    }
+    return best > tmin ? best : 0;
+}
+
+__device__ inline int block_scan_excl256(int v, int* total, int* s_w)
+{
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    int inc = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(inc, o, 64); if (lane >= o) inc += t; }
+    __syncthreads();
+    if (lane == 63) s_w[w] = inc;
+    __syncthreads();
+    int base = 0, tot = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { const int t = s_w[k]; if (k < w) base += t; tot += t; }
+    *total = tot;
+    return base + inc - v;
+}
+
+// one block per cell window (ORBextractor.cpp:789-816): FAST at iniThFAST, retried at minThFAST if the cell is
+// empty, non-max suppression inside the window only, keypoints emitted row-major.
+__global__ __launch_bounds__(256) void fast_cells_kernel(const fast_cell* __restrict__ cells, level_tab lv,
+                                                         int ini_th, int min_th, uint32_t* __restrict__ cand, int* __restrict__ counts)
+{
+    __shared__ uint8_t win[CELL_MAX * CELL_STRIDE];
+    __shared__ uint8_t A[CELL_MAX * CELL_STRIDE];
+    __shared__ int s_w[4];
+    __shared__ int s_n12;
+    const fast_cell c = cells[blockIdx.x];
+    const uint8_t* img = lv.img[c.level];
+    const int cols = lv.cols[c.level];
+    for (int t = threadIdx.x; t < c.w * c.h; t += 256) {
+        const int y = t / c.w, x = t - y * c.w;
+        win[y * CELL_STRIDE + x] = img[(size_t)(c.y0 + y) * cols + (c.x0 + x)];
+        A[y * CELL_STRIDE + x] = 0;
+    }
+    if (threadIdx.x == 0) s_n12 = 0;
+    __syncthreads();
+    const int ew = c.w - 6, eh = c.h - 6;
+    const int ne = (ew > 0 && eh > 0) ? ew * eh : 0;
+    const int tmin = ini_th < min_th ? ini_th : min_th;
+    for (int t = threadIdx.x; t < ne; t += 256) {
+        const int y = 3 + t / ew, x = 3 + t % ew;
+        A[y * CELL_STRIDE + x] = (uint8_t)fast_arc(win, CELL_STRIDE, x, y, tmin);
+    }
+    __syncthreads();
+    // strict 3x3 maxima; neighbours outside the evaluated range hold 0
+    int mine[15]; int nm = 0, n12 = 0;
+    for (int t = threadIdx.x; t < ne; t += 256, ++nm) {
+        const int y = 3 + t / ew, x = 3 + t % ew;
+        const int a = A[y * CELL_STRIDE + x];
+        bool mx = a > 0;
+        if (mx) {
+            mx = a > A[(y - 1) * CELL_STRIDE + x - 1] && a > A[(y - 1) * CELL_STRIDE + x] && a > A[(y - 1) * CELL_STRIDE + x + 1] &&
+                 a > A[y * CELL_STRIDE + x - 1] && a > A[y * CELL_STRIDE + x + 1] &&
+                 a > A[(y + 1) * CELL_STRIDE + x - 1] && a > A[(y + 1) * CELL_STRIDE + x] && a > A[(y + 1) * CELL_STRIDE + x + 1];
+        }
+        mine[nm] = mx ? a : 0;
+        n12 += mx && a > ini_th;
+    }
+    if (n12) atomicAdd(&s_n12, n12);
+    __syncthreads();
+    const int thr = s_n12 > 0 ? ini_th : min_th;
+    int base = 0, k = 0;
+    for (int c0 = 0; c0 < ne; c0 += 256, ++k) {
+        const int t = c0 + threadIdx.x;
+        const int a = (t < ne) ? mine[k] : 0;
+        const bool keep = a > thr;
+        int tot;
+        const int pos = block_scan_excl256(keep, &tot, s_w);
+        if (keep) {
+            const int y = 3 + t / ew, x = 3 + t % ew;
+            cand[(size_t)blockIdx.x * CELL_CAP + base + pos] = (uint32_t)x | ((uint32_t)y << 8) | ((uint32_t)(a - 1) << 16);
+        }
+        base += tot;
+    }
+    if (threadIdx.x == 0) counts[blockIdx.x] = base;
+}
+
+__global__ __launch_bounds__(256) void scan_counts_kernel(const int* __restrict__ counts, int n, int* __restrict__ offs)
+{
+    __shared__ int s_w[4];
+    int base = 0;
+    for (int c0 = 0; c0 < n; c0 += 256) {
+        const int i = c0 + threadIdx.x;
+        const int v = i < n ? counts[i] : 0;
+        int tot;
+        const int p = block_scan_excl256(v, &tot, s_w);
+        if (i < n) offs[i] = base + p;
+        base += tot;
+    }
+    if (threadIdx.x == 0) offs[n] = base;
+}
+
+// candidates in reference order with the cell offset applied (ORBextractor.cpp:820-825)
+__global__ __launch_bounds__(64) void gather_cand_kernel(const fast_cell* __restrict__ cells, const uint32_t* __restrict__ cand,
+                                                         const int* __restrict__ counts, const int* __restrict__ offs,
+                                                         float* __restrict__ xs, float* __restrict__ ys, float* __restrict__ rs, int cap)
+{
+    const fast_cell c = cells[blockIdx.x];
+    const int n = counts[blockIdx.x], o = offs[blockIdx.x];
+    for (int q = threadIdx.x; q < n; q += 64) {
+        if (o + q >= cap) return;
+        const uint32_t v = cand[(size_t)blockIdx.x * CELL_CAP + q];
+        xs[o + q] = (float)(v & 255u) + (float)c.offx;
+        ys[o + q] = (float)((v >> 8) & 255u) + (float)c.offy;
+        rs[o + q] = (float)(v >> 16);
+    }
+}
+
+// ------------------------------------------------------------------ K5 + K6 + K7: orientation, blur, rBRIEF
+struct kp_in { float x, y, resp; int level; };
+
+__constant__ signed char c_pattern[1024] = {
+#include "orb_pattern_31.inc"
+};
+__constant__ int c_umax[16] = { 15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 8, 6, 3 };   // ORBextractor.cpp:454-469
+__constant__ int c_gauss13[13] = { 1, 2, 7, 17, 31, 45, 50, 45, 31, 17, 7, 2, 1 };               // 8.8 taps, sum 256
+
+__device__ inline float fast_atan2_dev(float y, float x)        // cv::fastAtan2 (ORBextractor.cpp:103)
+{
+    const float scale = (float)(180.0 / 3.1415926535897932384626433832795);
+    const float p1 = 0.9997878412794807f * scale, p3 = -0.3258083974640975f * scale;
+    const float p5 = 0.1555786518463281f * scale, p7 = -0.04432655554792128f * scale;
+    const float eps = (float)2.2204460492503131e-16;
+    const float ax = fabsf(x), ay = fabsf(y);
+    float a, c, c2;
+    if (ax >= ay) { c = ay / (ax + eps); c2 = c * c; a = (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c; }
+    else { c = ax / (ay + eps); c2 = c * c; a = 90.f - (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c; }
+    if (x < 0) a = 180.f - a;
+    if (y < 0) a = 360.f - a;
+    return a;
+}
+
+__device__ inline int reflect101_dev(int p, int len)
+{
+    if (len == 1) return 0;
+    while (p < 0 || p >= len) { if (p < 0) p = -p; else p = 2 * len - 2 - p; }
+    return p;
+}
+
+#define PR 24                  // patch radius: 18 (rotated BRIEF reach) + 6 (blur)
+#define PW 49
+#define PS 52                  // LDS row stride of the raw patch
+#define BR 18
+#define BW 37
+#define BS 40
+
+// one wave per keypoint, four keypoints per block.  The Gaussian blur of the level clone (ORBextractor.cpp:1091-1092)
+// is evaluated only on the 37 x 37 patch the rotated pattern can reach, from a 49 x 49 LDS tile of the level image.
+__global__ __launch_bounds__(256) void orient_desc_kernel(const kp_in* __restrict__ kin, int n, level_tab lv,
+                                                          const int* __restrict__ lrows, const float* __restrict__ lscale,
+                                                          dsss_kp* __restrict__ kp_out, uint8_t* __restrict__ desc_out)
+{
+    __shared__ uint8_t sP[4][PW * PS];
+    __shared__ uint16_t sH[4][PW * BW];
+    __shared__ uint8_t sB[4][BW * BS];
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int k = blockIdx.x * 4 + wv;
+    const bool act = k < n;
+    kp_in in = act ? kin[k] : kin[0];
+    const int L = in.level;
+    const uint8_t* img = lv.img[L];
+    const int cols = lv.cols[L], rows = lrows[L];
+    const int cx = __float2int_rn(in.x), cy = __float2int_rn(in.y);
+    uint8_t* P = sP[wv]; uint16_t* H = sH[wv]; uint8_t* B = sB[wv];
+    if (act)
+        for (int t = lane; t < PW * PW; t += 64) {
+            const int py = t / PW, px = t - py * PW;
+            P[py * PS + px] = img[(size_t)reflect101_dev(cy + py - PR, rows) * cols + reflect101_dev(cx + px - PR, cols)];
+        }
+    __syncthreads();
+    // IC_Angle (ORBextractor.cpp:77-104): integer moments over the radius-15 disc
+    int m10 = 0, m01 = 0;
+    if (act)
+        for (int t = lane; t < 31 * 31; t += 64) {
+            const int v = t / 31 - HALF_PATCH, u = t % 31 - HALF_PATCH;
+            const int av = v < 0 ? -v : v;
+            if ((u < 0 ? -u : u) <= c_umax[av]) {
+                const int I = P[(v + PR) * PS + (u + PR)];
+                m10 += u * I; m01 += v * I;
+            }
+        }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) { m10 += __shfl_xor(m10, o, 64); m01 += __shfl_xor(m01, o, 64); }
+    const float angle = fast_atan2_dev((float)m01, (float)m10);
+    // separable 13-tap blur, 8.8 fixed point (own taps, see oracle/orc.h)
+    if (act)
+        for (int t = lane; t < PW * BW; t += 64) {
+            const int py = t / BW, bx = t - py * BW;                 // H(py, bx): column bx of the 37-wide band
+            int acc = 0;
+#pragma unroll
+            for (int q = 0; q < 13; ++q) acc += c_gauss13[q] * P[py * PS + (bx + q)];      // bx + (PR-BR) + q - 6 = bx + q
+            H[py * BW + bx] = (uint16_t)acc;
+        }
+    __syncthreads();
+    if (act)
+        for (int t = lane; t < BW * BW; t += 64) {
+            const int by = t / BW, bx = t - by * BW;
+            unsigned acc = 0;
+#pragma unroll
+            for (int q = 0; q < 13; ++q) acc += (unsigned)c_gauss13[q] * H[(by + q) * BW + bx];
+            B[by * BS + bx] = (uint8_t)((acc + 32768u) >> 16);
+        }
+    __syncthreads();
+    // computeOrbDescriptor (ORBextractor.cpp:108-147): 4 tests per lane
+    const float factorPI = (float)(3.1415926535897932384626433832795 / 180.f);
+    const float ang = angle * factorPI;
+    double sd, cd;
+    dsss_sincos((double)ang, &sd, &cd);
+    const float a = (float)cd, b = (float)sd;
+    unsigned nib = 0;
+    if (act) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const signed char* p = c_pattern + (lane * 4 + q) * 4;
+            const float x0 = (float)p[0], y0 = (float)p[1], x1 = (float)p[2], y1 = (float)p[3];
+            const int r0 = __float2int_rn(x0 * b + y0 * a), c0 = __float2int_rn(x0 * a - y0 * b);
+            const int r1 = __float2int_rn(x1 * b + y1 * a), c1 = __float2int_rn(x1 * a - y1 * b);
+            const int t0 = B[(r0 + BR) * BS + (c0 + BR)], t1 = B[(r1 + BR) * BS + (c1 + BR)];
+            nib |= (unsigned)(t0 < t1) << q;
+        }
+    }
+    const unsigned hi = __shfl_down(nib, 1, 64);
+    if (act && (lane & 1) == 0) desc_out[(size_t)k * 32 + (lane >> 1)] = (uint8_t)(nib | (hi << 4));
+    if (act && lane == 0) {
+        dsss_kp o;
+        const float sc = lscale[L];
+        o.x = L ? in.x * sc : in.x; o.y = L ? in.y * sc : in.y;       // keypoint->pt *= scale (:1103-1109)
+        o.size = (float)(int)(31 * sc);                              // scaledPatchSize (:837)
+        o.angle = angle; o.response = in.resp; o.octave = L;
+        kp_out[k] = o;
+    }
+}
+
+// Frame::DetectFeature tail (frame.cpp:184-195): keep kp iff mask(int(y), int(x)) != 0, order preserved;
+// also samples the geo image for the survivors (FEAmatcher.cpp:81-82).
+__global__ __launch_bounds__(256) void mask_filter_kernel(const dsss_kp* __restrict__ kin, const uint8_t* __restrict__ din, int n,
+                                                          const uint8_t* __restrict__ mask, int M,
+                                                          const double* __restrict__ pose6, const double* __restrict__ gr,
+                                                          dsss_kp* __restrict__ kout, uint8_t* __restrict__ dout,
+                                                          double* __restrict__ geo, int* __restrict__ count)
+{
+    __shared__ int s_w[4];
+    int base = 0;
+    for (int c0 = 0; c0 < n; c0 += 256) {
+        const int i = c0 + threadIdx.x;
+        dsss_kp kp; bool keep = false;
+        if (i < n) { kp = kin[i]; keep = mask[(size_t)(int)kp.y * M + (int)kp.x] != 0; }
+        int tot;
+        const int pos = block_scan_excl256(keep, &tot, s_w);
+        if (keep) {
+            const int o = base + pos;
+            kout[o] = kp;
+            const uint4* s = reinterpret_cast<const uint4*>(din + (size_t)i * 32);
+            uint4* d = reinterpret_cast<uint4*>(dout + (size_t)o * 32);
+            d[0] = s[0]; d[1] = s[1];
+            double x, y;
+            dsss_geo_at(pose6, gr, M, (int)kp.y, (int)kp.x, &x, &y);
+            geo[2 * o] = x; geo[2 * o + 1] = y;
+        }
+        base += tot;
+    }
+    if (threadIdx.x == 0) *count = base;
+}
+
+// ------------------------------------------------------------------ host orchestration
+namespace {
+
+struct level_geom {
+    int nlevels;
+    int rows[DSSS_MAX_LEVELS], cols[DSSS_MAX_LEVELS], quota[DSSS_MAX_LEVELS];
+    float sf[DSSS_MAX_LEVELS];
+    std::vector<fast_cell> cells;
+    int cell_begin[DSSS_MAX_LEVELS + 1];
+};
+
+// scale tables, level sizes and quotas of the ORBextractor ctor / ComputePyramid (ORBextractor.cpp:415-446,1119-1120)
+void build_geom(const dsss_orb_params& op, int rows, int cols, level_geom& g)
+{
+    g.nlevels = op.nlevels;
+    float inv[DSSS_MAX_LEVELS];
+    g.sf[0] = 1.0f;
+    for (int i = 1; i < op.nlevels; ++i) g.sf[i] = g.sf[i - 1] * op.scale;
+    for (int i = 0; i < op.nlevels; ++i) inv[i] = 1.0f / g.sf[i];
+    for (int l = 0; l < op.nlevels; ++l) {
+        g.cols[l] = (int)lrintf((float)cols * inv[l]);
+        g.rows[l] = (int)lrintf((float)rows * inv[l]);
+    }
+    const float factor = 1.0f / op.scale;
+    float nDesired = op.nfeatures * (1 - factor) / (1 - (float)std::pow((double)factor, (double)op.nlevels));
+    int sum = 0;
+    for (int l = 0; l < op.nlevels - 1; ++l) { g.quota[l] = (int)lrintf(nDesired); sum += g.quota[l]; nDesired *= factor; }
+    g.quota[op.nlevels - 1] = std::max(op.nfeatures - sum, 0);
+    // cell windows of ComputeKeyPointsOctTree (ORBextractor.cpp:769-806)
+    g.cells.clear();
+    for (int l = 0; l < op.nlevels; ++l) {
+        g.cell_begin[l] = (int)g.cells.size();
+        const float W = 30;
+        const int minBX = EDGE_T - 3, minBY = minBX, maxBX = g.cols[l] - EDGE_T + 3, maxBY = g.rows[l] - EDGE_T + 3;
+        const float width = (float)(maxBX - minBX), height = (float)(maxBY - minBY);
+        const int nCols = (int)(width / W), nRows = (int)(height / W);
+        if (nCols <= 0 || nRows <= 0) continue;
+        const int wCell = (int)std::ceil(width / nCols), hCell = (int)std::ceil(height / nRows);
+        for (int i = 0; i < nRows; ++i) {
+            const float iniY = (float)(minBY + i * hCell);
+            float maxY = iniY + hCell + 6;
+            if (iniY >= maxBY - 3) continue;
+            if (maxY > maxBY) maxY = (float)maxBY;
+            for (int j = 0; j < nCols; ++j) {
+                const float iniX = (float)(minBX + j * wCell);
+                float maxX = iniX + wCell + 6;
+                if (iniX >= maxBX - 6) continue;
+                if (maxX > maxBX) maxX = (float)maxBX;
+                fast_cell c;
+                c.level = l; c.x0 = (int)iniX; c.y0 = (int)iniY; c.w = (int)maxX - (int)iniX; c.h = (int)maxY - (int)iniY;
+                c.offx = j * wCell; c.offy = i * hCell; c.pad = 0;
+                if (c.w > CELL_MAX) c.w = CELL_MAX;
+                if (c.h > CELL_MAX) c.h = CELL_MAX;
+                g.cells.push_back(c);
+            }
+        }
+    }
+    g.cell_begin[op.nlevels] = (int)g.cells.size();
+}
+
+inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+} // namespace
+
+static int ensure_frame_images(dsss_ctx* c, dsss_frame& f, const level_geom& g)
+{
+    const size_t bytes = (size_t)f.N * f.M;
+    if (f.img_cap < bytes) {
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        hipFree(f.mask); f.mask = nullptr;
+        for (int l = 0; l < DSSS_MAX_LEVELS; ++l) { hipFree(f.lvl[l]); f.lvl[l] = nullptr; }
+        HIPCHK(c, hipMalloc(&f.mask, bytes));
+        f.img_cap = bytes;
+    }
+    for (int l = 0; l < g.nlevels; ++l) {
+        if (!f.lvl[l] || f.lrows[l] != g.rows[l] || f.lcols[l] != g.cols[l]) {
+            if (f.lvl[l]) { HIPCHK(c, hipStreamSynchronize(c->stream)); hipFree(f.lvl[l]); f.lvl[l] = nullptr; }
+            HIPCHK(c, hipMalloc(&f.lvl[l], (size_t)g.rows[l] * g.cols[l] + 64));
+        }
+        f.lrows[l] = g.rows[l]; f.lcols[l] = g.cols[l];
+    }
+    return DSSS_OK;
+}
+
+// scratch layout (device): rowsum[N] rowmin[N] stats[4] | cells | counts | offs | cand | xs ys rs | kp_in | kp_tmp | desc_tmp | lrows lscale
+struct ex_layout {
+    size_t rowsum, rowmin, stats, cells, counts, offs, cand, xs, ys, rs, kin, kptmp, dtmp, lrows, lscale, total;
+    int cand_cap, kcap_in;
+};
+static ex_layout make_layout(int N, int ncells, int kcap)
+{
+    ex_layout L; size_t o = 0;
+    L.cand_cap = ncells * 64 + 4096; L.kcap_in = kcap;
+    auto take = [&](size_t bytes) { size_t r = o; o = align_up(o + bytes, 256); return r; };
+    L.rowsum = take(sizeof(double) * N); L.rowmin = take(sizeof(double) * N); L.stats = take(sizeof(double) * 4);
+    L.cells = take(sizeof(fast_cell) * ncells); L.counts = take(sizeof(int) * ncells); L.offs = take(sizeof(int) * (ncells + 1));
+    L.cand = take(sizeof(uint32_t) * (size_t)ncells * CELL_CAP);
+    L.xs = take(sizeof(float) * L.cand_cap); L.ys = take(sizeof(float) * L.cand_cap); L.rs = take(sizeof(float) * L.cand_cap);
+    L.kin = take(sizeof(kp_in) * kcap); L.kptmp = take(sizeof(dsss_kp) * kcap); L.dtmp = take((size_t)32 * kcap);
+    L.lrows = take(sizeof(int) * DSSS_MAX_LEVELS); L.lscale = take(sizeof(float) * DSSS_MAX_LEVELS);
+    L.total = o;
+    return L;
+}
+
+static int extract_one(dsss_ctx* c, int id, int* n_out)
+{
+    dsss_frame& f = c->frames[id];
+    if (!f.has_geom || !f.has_raw) DSSS_FAIL(c, DSSS_E_STATE, "frame %d has no raw image (dsss_frame_set with raw != NULL first)", id);
+    const int N = f.N, M = f.M;
+    level_geom g;
+    build_geom(c->op, N, M, g);
+    for (int l = 0; l < g.nlevels; ++l)
+        if (g.rows[l] < 2 * EDGE_T + 31 || g.cols[l] < 2 * EDGE_T + 31)
+            DSSS_FAIL(c, DSSS_E_ARG, "level %d (%d x %d) too small for 30-px FAST cells", l, g.rows[l], g.cols[l]);
+    int rc = ensure_frame_images(c, f, g); if (rc) return rc;
+    rc = dsss_ensure_store(c); if (rc) return rc;
+    const int ncells = (int)g.cells.size();
+    const ex_layout L = make_layout(N, ncells, c->kcap);
+    if (c->ex_scratch_bytes < L.total) {
+        HIPCHK(c, hipStreamSynchronize(c->stream)); hipFree(c->ex_scratch); c->ex_scratch = nullptr; c->ex_scratch_bytes = 0;
+        HIPCHK(c, hipMalloc(&c->ex_scratch, L.total)); c->ex_scratch_bytes = L.total;
+    }
+    const size_t pin_bytes = sizeof(int) * (ncells + 1) + 3 * sizeof(float) * (size_t)L.cand_cap + sizeof(kp_in) * (size_t)c->kcap + 64;
+    if (c->ex_pinned_bytes < pin_bytes) {
+        HIPCHK(c, hipStreamSynchronize(c->stream)); if (c->ex_pinned) hipHostFree(c->ex_pinned); c->ex_pinned = nullptr; c->ex_pinned_bytes = 0;
+        HIPCHK(c, hipHostMalloc(&c->ex_pinned, pin_bytes, hipHostMallocDefault)); c->ex_pinned_bytes = pin_bytes;
+    }
+    char* S = (char*)c->ex_scratch;
+    double* d_rowsum = (double*)(S + L.rowsum); double* d_rowmin = (double*)(S + L.rowmin); double* d_stats = (double*)(S + L.stats);
+    fast_cell* d_cells = (fast_cell*)(S + L.cells); int* d_counts = (int*)(S + L.counts); int* d_offs = (int*)(S + L.offs);
+    uint32_t* d_cand = (uint32_t*)(S + L.cand);
+    float* d_xs = (float*)(S + L.xs); float* d_ys = (float*)(S + L.ys); float* d_rs = (float*)(S + L.rs);
+    kp_in* d_kin = (kp_in*)(S + L.kin); dsss_kp* d_kptmp = (dsss_kp*)(S + L.kptmp); uint8_t* d_dtmp = (uint8_t*)(S + L.dtmp);
+    int* d_lrows = (int*)(S + L.lrows); float* d_lscale = (float*)(S + L.lscale);
+    char* Hp = (char*)c->ex_pinned;
+    int* h_offs = (int*)Hp;
+    float* h_xs = (float*)(Hp + align_up(sizeof(int) * (ncells + 1), 64));
+    float* h_ys = h_xs + L.cand_cap; float* h_rs = h_ys + L.cand_cap;
+    kp_in* h_kin = (kp_in*)(h_rs + L.cand_cap);
+
+    HIPCHK(c, hipMemcpyAsync(d_cells, g.cells.data(), sizeof(fast_cell) * ncells, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(d_lrows, g.rows, sizeof(int) * DSSS_MAX_LEVELS, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(d_lscale, g.sf, sizeof(float) * DSSS_MAX_LEVELS, hipMemcpyHostToDevice, c->stream));
+    {   // K1
+        dsss_scope sc(c, DSSS_K_PREPROC);
+        hipLaunchKernelGGL(row_reduce_kernel, dim3((N + 3) / 4), dim3(256), 0, c->stream, f.raw, N, M, d_rowsum, d_rowmin);
+        hipLaunchKernelGGL(final_reduce_kernel, dim3(1), dim3(64), 0, c->stream, d_rowsum, d_rowmin, N, M, (double)(float)c->mp.factor, d_stats);
+        const size_t tot = (size_t)N * M;
+        hipLaunchKernelGGL(mask_init_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, c->stream, f.mask, N, M, c->mp.width, c->mp.side,
+                           (double)c->mp.side * 0.6);
+        hipLaunchKernelGGL(normalize_kernel, dim3((unsigned)((tot / 4 + 256) / 256)), dim3(256), 0, c->stream, f.raw, N, M, d_stats, c->mp.r,
+                           f.lvl[0], f.mask);
+        HIPCHK(c, hipGetLastError());
+    }
+    level_tab lv;
+    for (int l = 0; l < DSSS_MAX_LEVELS; ++l) { lv.img[l] = l < g.nlevels ? f.lvl[l] : nullptr; lv.cols[l] = l < g.nlevels ? g.cols[l] : 0; }
+    {   // K2
+        dsss_scope sc(c, DSSS_K_PYRAMID);
+        for (int l = 1; l < g.nlevels; ++l) {
+            const double sx = 1. / ((double)g.cols[l] / g.cols[l - 1]), sy = 1. / ((double)g.rows[l] / g.rows[l - 1]);
+            hipLaunchKernelGGL(resize_kernel, dim3((g.cols[l] + 255) / 256, g.rows[l]), dim3(256), 0, c->stream, f.lvl[l - 1], g.rows[l - 1],
+                               g.cols[l - 1], f.lvl[l], g.rows[l], g.cols[l], sx, sy);
+        }
+        HIPCHK(c, hipGetLastError());
+    }
+    {   // K3
+        dsss_scope sc(c, DSSS_K_FAST);
+        hipLaunchKernelGGL(fast_cells_kernel, dim3(ncells), dim3(256), 0, c->stream, d_cells, lv, c->op.ini_th, c->op.min_th, d_cand, d_counts);
+        hipLaunchKernelGGL(scan_counts_kernel, dim3(1), dim3(256), 0, c->stream, d_counts, ncells, d_offs);
+        hipLaunchKernelGGL(gather_cand_kernel, dim3(ncells), dim3(64), 0, c->stream, d_cells, d_cand, d_counts, d_offs, d_xs, d_ys, d_rs, L.cand_cap);
+        HIPCHK(c, hipGetLastError());
+    }
+    HIPCHK(c, hipMemcpyAsync(h_offs, d_offs, sizeof(int) * (ncells + 1), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    const int ncand = h_offs[ncells];
+    if (ncand > L.cand_cap) DSSS_FAIL(c, DSSS_E_CAPACITY, "%d FAST candidates exceed the staging capacity %d", ncand, L.cand_cap);
+    if (ncand > 0) {
+        HIPCHK(c, hipMemcpyAsync(h_xs, d_xs, sizeof(float) * ncand, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipMemcpyAsync(h_ys, d_ys, sizeof(float) * ncand, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipMemcpyAsync(h_rs, d_rs, sizeof(float) * ncand, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+    }
+    // K4 (host): quadtree cull per level, then keypoints in level order (ORBextractor.cpp:831-847,1082-1111)
+    int nk = 0;
+    std::vector<int> keep;
+    for (int l = 0; l < g.nlevels; ++l) {
+        const int b = h_offs[g.cell_begin[l]], e = h_offs[g.cell_begin[l + 1]];
+        f.cand_x[l].assign(h_xs + b, h_xs + e); f.cand_y[l].assign(h_ys + b, h_ys + e); f.cand_r[l].assign(h_rs + b, h_rs + e);
+        const int minB = EDGE_T - 3;
+        dsss_quadtree_cull(h_xs + b, h_ys + b, h_rs + b, e - b, minB, g.cols[l] - EDGE_T + 3, minB, g.rows[l] - EDGE_T + 3, g.quota[l], keep);
+        for (int id2 : keep) {
+            if (nk >= c->kcap) DSSS_FAIL(c, DSSS_E_CAPACITY, "more than %d keypoints", c->kcap);
+            kp_in& q = h_kin[nk++];
+            q.x = h_xs[b + id2] + minB; q.y = h_ys[b + id2] + minB; q.resp = h_rs[b + id2]; q.level = l;
+        }
+    }
+    int* d_count = c->nkp_dev + id;
+    if (nk > 0) {
+        dsss_scope sc(c, DSSS_K_DESC);
+        HIPCHK(c, hipMemcpyAsync(d_kin, h_kin, sizeof(kp_in) * nk, hipMemcpyHostToDevice, c->stream));
+        hipLaunchKernelGGL(orient_desc_kernel, dim3((nk + 3) / 4), dim3(256), 0, c->stream, d_kin, nk, lv, d_lrows, d_lscale, d_kptmp, d_dtmp);
+        hipLaunchKernelGGL(mask_filter_kernel, dim3(1), dim3(256), 0, c->stream, d_kptmp, d_dtmp, nk, f.mask, M, f.pose6, f.gr,
+                           c->kps + (size_t)id * c->kcap, c->desc + (size_t)id * c->kcap * 32, c->geo + (size_t)id * c->kcap * 2, d_count);
+        HIPCHK(c, hipGetLastError());
+        HIPCHK(c, hipMemcpyAsync(&f.nkp, d_count, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+    } else {
+        f.nkp = 0;
+        HIPCHK(c, hipMemsetAsync(d_count, 0, sizeof(int), c->stream));
+    }
+    f.has_feat = true; f.has_norm = true;
+    if (n_out) *n_out = f.nkp;
+    return DSSS_OK;
+}
+
+extern "C" {
+
+int dsss_extract(dsss_ctx* c, int id, int* n_kp)
+{
+    if (!c) return DSSS_E_ARG;
+    if (id < 0 || id >= c->max_frames) DSSS_FAIL(c, DSSS_E_ARG, "frame id %d out of range", id);
+    HIPCHK(c, hipSetDevice(c->device));
+    return extract_one(c, id, n_kp);
+}
+
+int dsss_extract_many(dsss_ctx* c, const int* ids, int n)
+{
+    if (!c || (n > 0 && !ids)) return DSSS_E_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    for (int i = 0; i < n; ++i) {
+        if (ids[i] < 0 || ids[i] >= c->max_frames) DSSS_FAIL(c, DSSS_E_ARG, "frame id %d out of range", ids[i]);
+        int rc = extract_one(c, ids[i], nullptr);
+        if (rc) return rc;
+    }
+    return DSSS_OK;
+}
+
+int dsss_host_quadtree(const float* x, const float* y, const float* resp, int n, int minX, int maxX, int minY, int maxY,
+                       int quota, int32_t* keep_idx, int* n_keep)
+{
+    if (n < 0 || (n > 0 && (!x || !y || !resp || !keep_idx)) || maxX <= minX || maxY <= minY) return DSSS_E_ARG;
+    std::vector<int> keep;
+    dsss_quadtree_cull(x, y, resp, n, minX, maxX, minY, maxY, quota, keep);
+    for (size_t i = 0; i < keep.size(); ++i) keep_idx[i] = keep[i];
+    if (n_keep) *n_keep = (int)keep.size();
+    return DSSS_OK;
+}
+
+int dsss_frame_get_norm(dsss_ctx* c, int id, uint8_t* norm, uint8_t* mask)
+{
+    if (!c) return DSSS_E_ARG;
+    if (id < 0 || id >= c->max_frames) DSSS_FAIL(c, DSSS_E_ARG, "frame id %d out of range", id);
+    dsss_frame& f = c->frames[id];
+    if (!f.has_norm) DSSS_FAIL(c, DSSS_E_STATE, "frame %d not extracted yet", id);
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (norm) HIPCHK(c, hipMemcpy(norm, f.lvl[0], (size_t)f.N * f.M, hipMemcpyDeviceToHost));
+    if (mask) HIPCHK(c, hipMemcpy(mask, f.mask, (size_t)f.N * f.M, hipMemcpyDeviceToHost));
+    return DSSS_OK;
+}
+
+int dsss_frame_get_level(dsss_ctx* c, int id, int level, uint8_t* img, int* rows, int* cols)
+{
+    if (!c) return DSSS_E_ARG;
+    if (id < 0 || id >= c->max_frames || level < 0 || level >= c->op.nlevels) DSSS_FAIL(c, DSSS_E_ARG, "frame/level out of range");
+    dsss_frame& f = c->frames[id];
+    if (!f.has_norm) DSSS_FAIL(c, DSSS_E_STATE, "frame %d not extracted yet", id);
+    if (rows) *rows = f.lrows[level];
+    if (cols) *cols = f.lcols[level];
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (img) HIPCHK(c, hipMemcpy(img, f.lvl[level], (size_t)f.lrows[level] * f.lcols[level], hipMemcpyDeviceToHost));
+    return DSSS_OK;
+}
+
+int dsss_frame_get_candidates(dsss_ctx* c, int id, int level, float* x, float* y, float* r, int cap, int* n)
+{
+    if (!c) return DSSS_E_ARG;
+    if (id < 0 || id >= c->max_frames || level < 0 || level >= c->op.nlevels) DSSS_FAIL(c, DSSS_E_ARG, "frame/level out of range");
+    dsss_frame& f = c->frames[id];
+    if (!f.has_norm) DSSS_FAIL(c, DSSS_E_STATE, "frame %d not extracted yet", id);
+    const int m = (int)f.cand_x[level].size();
+    if (n) *n = m;
+    if (cap < m) DSSS_FAIL(c, DSSS_E_CAPACITY, "caller capacity %d < %d candidates", cap, m);
+    if (x) memcpy(x, f.cand_x[level].data(), sizeof(float) * m);
+    if (y) memcpy(y, f.cand_y[level].data(), sizeof(float) * m);
+    if (r) memcpy(r, f.cand_r[level].data(), sizeof(float) * m);
+    return DSSS_OK;
+}
+
+} // extern "C"

@@ -1,0 +1,829 @@
+// diasss_amd/csrc/dsss_pg.hip -- pose-graph assembly and batch Levenberg-Marquardt solve on the device.
+// Replaces the GTSAM NonlinearFactorGraph + iSAM2 of Optimizer::TrajOptimizationAll
+// (/root/reference/src/core/optimizer.cpp:101-279): prior on X0 (:164-170), odometry BetweenFactor chain over every
+// ping of every frame (:173-200, sigmas :24-28), at most one loop-closure BetweenFactor per target ping
+// (:203-258, "last pair wins, first kp in it", score > 0, Diagonal::Variances), initial values DR o noise (:150-160).
+// LM schedule = GTSAM LevenbergMarquardtParams() defaults, same loop as oracle/orc_posegraph.c.
+//
+// Linear algebra per LM trial (all f64 on the device, host only steers):
+//   1. per-factor residuals + Jacobians, per-pose 6x6 Hessian blocks (block tridiagonal chain + LC blocks);
+//   2. Schur complement of every chain segment between two LC-touched poses ("separators") onto its end points
+//      -- segments are independent, one thread each, 6x6 block Thomas recursion;
+//   3. the reduced system over the separators (chain couplings + LC blocks) is factorised by a sparse block
+//      Cholesky: geometric nested-dissection ordering and symbolic analysis on the host (once per solve),
+//      level-scheduled left-looking numeric factorisation and triangular solves in kernels;
+//   4. back-substitution through the segments.
+#include "dsss_internal.h"
+#include "dsss_pose.h"
+#include <algorithm>
+#include <numeric>
+#include <random>
+
+// ------------------------------------------------------------------ small dense helpers (6x6 row-major)
+__device__ inline int chol6(double* A)
+{
+    for (int j = 0; j < 6; ++j) {
+        double d = A[j * 6 + j];
+        for (int k = 0; k < j; ++k) d -= A[j * 6 + k] * A[j * 6 + k];
+        if (!(d > 0) || !isfinite(d)) return -1;
+        d = sqrt(d); A[j * 6 + j] = d;
+        for (int i = j + 1; i < 6; ++i) {
+            double s = A[i * 6 + j];
+            for (int k = 0; k < j; ++k) s -= A[i * 6 + k] * A[j * 6 + k];
+            A[i * 6 + j] = s / d;
+        }
+    }
+    return 0;
+}
+// b (6 x nrhs, row-major) <- (L L^T)^-1 b
+__device__ inline void chol6_solve(const double* L, double* b, int nrhs)
+{
+    for (int c = 0; c < nrhs; ++c) {
+        for (int i = 0; i < 6; ++i) { double s = b[i * nrhs + c]; for (int k = 0; k < i; ++k) s -= L[i * 6 + k] * b[k * nrhs + c]; b[i * nrhs + c] = s / L[i * 6 + i]; }
+        for (int i = 5; i >= 0; --i) { double s = b[i * nrhs + c]; for (int k = i + 1; k < 6; ++k) s -= L[k * 6 + i] * b[k * nrhs + c]; b[i * nrhs + c] = s / L[i * 6 + i]; }
+    }
+}
+
+struct pg_weights { double prior[6], odo[6]; };
+
+// ------------------------------------------------------------------ factors
+// factor k < n: k == 0 prior on X0 (measurement DR0), else Between(X_{k-1}, X_k); factor n + e: LC edge e.
+// r = whitened residual, Ji = whitened Jacobian wrt the first pose (-W Ad(h^-1)); the Jacobian wrt the second
+// pose is W itself (BetweenFactor with GTSAM_SLOW_BUT_CORRECT_BETWEENFACTOR off, PriorFactor H = I).
+__device__ inline void factor_eval(int k, int n, const pose_t* X, const pose_t* meas, const pg_weights& W,
+                                   const int* ea, const int* eb, const pose_t* emeas, const double* ew,
+                                   double* r, double* Ji)
+{
+    double xi[6];
+    if (k == 0) {
+        pose_t d;
+        pose_between(&meas[0], &X[0], &d);
+        pose_log(&d, xi);
+        for (int a = 0; a < 6; ++a) r[a] = xi[a] * W.prior[a];
+        if (Ji) for (int a = 0; a < 36; ++a) Ji[a] = 0.0;
+        return;
+    }
+    int i, j; const pose_t* m; const double* w;
+    if (k < n) { i = k - 1; j = k; m = &meas[k]; w = W.odo; }
+    else { const int e = k - n; i = ea[e]; j = eb[e]; m = &emeas[e]; w = ew + (size_t)e * 6; }
+    pose_t h, er;
+    pose_between(&X[i], &X[j], &h);
+    pose_between(m, &h, &er);
+    pose_log(&er, xi);
+    for (int a = 0; a < 6; ++a) r[a] = xi[a] * w[a];
+    if (Ji) {
+        pose_t hi; double Ad[36];
+        pose_inverse(&h, &hi);
+        pose_adjoint(&hi, Ad);
+        for (int a = 0; a < 6; ++a) for (int b = 0; b < 6; ++b) Ji[a * 6 + b] = -Ad[a * 6 + b] * w[a];
+    }
+}
+
+// deterministic block sum: wave shuffle tree then the 4 wave sums in order
+__device__ inline double block_sum256(double v, double* s_w)
+{
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return ((s_w[0] + s_w[1]) + s_w[2]) + s_w[3];
+}
+
+__global__ __launch_bounds__(256) void pg_linearize_kernel(int n, int ne, const pose_t* __restrict__ X, const pose_t* __restrict__ meas,
+                                                           pg_weights W, const int* __restrict__ ea, const int* __restrict__ eb,
+                                                           const pose_t* __restrict__ emeas, const double* __restrict__ ew,
+                                                           double* __restrict__ r, double* __restrict__ Ji, double* __restrict__ partial)
+{
+    __shared__ double s_w[4];
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    double e2 = 0;
+    if (k < n + ne) {
+        double rr[6], J[36];
+        factor_eval(k, n, X, meas, W, ea, eb, emeas, ew, rr, Ji ? J : nullptr);
+        for (int a = 0; a < 6; ++a) { e2 += rr[a] * rr[a]; if (r) r[(size_t)k * 6 + a] = rr[a]; }
+        if (Ji) for (int a = 0; a < 36; ++a) Ji[(size_t)k * 36 + a] = J[a];
+    }
+    const double s = block_sum256(e2, s_w);
+    if (threadIdx.x == 0) partial[blockIdx.x] = s;
+}
+
+__global__ __launch_bounds__(256) void pg_final_sum_kernel(const double* __restrict__ partial, int n, double scale, double* __restrict__ out)
+{
+    __shared__ double s_w[4];
+    double acc = 0;
+    for (int i = threadIdx.x; i < n; i += 256) acc += partial[i];
+    const double s = block_sum256(acc, s_w);
+    if (threadIdx.x == 0) *out = s * scale;
+}
+
+// per-pose Hessian blocks: D (diagonal), C = H(i, i+1), g = J^T r.  LC contributions are summed over the
+// pose's incidence list in a fixed order (no atomics).
+__global__ __launch_bounds__(256) void pg_assemble_kernel(int n, pg_weights W, const double* __restrict__ r, const double* __restrict__ Ji,
+                                                          const int* __restrict__ adj_ptr, const int* __restrict__ adj_edge,
+                                                          const double* __restrict__ ew, double lambda,
+                                                          double* __restrict__ D, double* __restrict__ C, double* __restrict__ g)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    double Dd[36], Cc[36], gg[6];
+    for (int a = 0; a < 36; ++a) { Dd[a] = 0; Cc[a] = 0; }
+    for (int a = 0; a < 6; ++a) gg[a] = 0;
+    // factor i with this pose as the second variable (Jacobian W)
+    const double* w2 = i == 0 ? W.prior : W.odo;
+    for (int a = 0; a < 6; ++a) { Dd[a * 6 + a] += w2[a] * w2[a]; gg[a] += w2[a] * r[(size_t)i * 6 + a]; }
+    if (i + 1 < n) {   // factor i+1 with this pose as the first variable
+        const double* J = Ji + (size_t)(i + 1) * 36; const double* rr = r + (size_t)(i + 1) * 6;
+        for (int a = 0; a < 6; ++a) {
+            for (int b = 0; b < 6; ++b) {
+                double s = 0;
+                for (int q = 0; q < 6; ++q) s += J[q * 6 + a] * J[q * 6 + b];
+                Dd[a * 6 + b] += s;
+                Cc[a * 6 + b] = J[b * 6 + a] * W.odo[b];            // Ji^T W
+            }
+            double s = 0;
+            for (int q = 0; q < 6; ++q) s += J[q * 6 + a] * rr[q];
+            gg[a] += s;
+        }
+    }
+    for (int p = adj_ptr[i]; p < adj_ptr[i + 1]; ++p) {
+        const int code = adj_edge[p], e = code >> 1, second = code & 1;
+        const double* rr = r + (size_t)(n + e) * 6;
+        if (second) {
+            const double* w = ew + (size_t)e * 6;
+            for (int a = 0; a < 6; ++a) { Dd[a * 6 + a] += w[a] * w[a]; gg[a] += w[a] * rr[a]; }
+        } else {
+            const double* J = Ji + (size_t)(n + e) * 36;
+            for (int a = 0; a < 6; ++a) {
+                for (int b = 0; b < 6; ++b) { double s = 0; for (int q = 0; q < 6; ++q) s += J[q * 6 + a] * J[q * 6 + b]; Dd[a * 6 + b] += s; }
+                double s = 0;
+                for (int q = 0; q < 6; ++q) s += J[q * 6 + a] * rr[q];
+                gg[a] += s;
+            }
+        }
+    }
+    for (int a = 0; a < 6; ++a) Dd[a * 6 + a] += lambda;
+    for (int a = 0; a < 36; ++a) { D[(size_t)i * 36 + a] = Dd[a]; C[(size_t)i * 36 + a] = Cc[a]; }
+    for (int a = 0; a < 6; ++a) g[(size_t)i * 6 + a] = gg[a];
+}
+
+// Schur complement of the interior of segment s (poses L+1 .. R-1) onto its end points L, R.
+// Stores the Cholesky factor of every eliminated pivot (Dl), the fill block E_i = H(L, i) and the updated
+// gradient for the back-substitution; outputs the end-point corrections.
+__global__ __launch_bounds__(64) void pg_segment_kernel(int nseg, const int* __restrict__ sep_pose, const double* __restrict__ D,
+                                                        const double* __restrict__ C, const double* __restrict__ g,
+                                                        double* __restrict__ E, double* __restrict__ Dl, double* __restrict__ gi,
+                                                        double* __restrict__ segDL, double* __restrict__ segDR, double* __restrict__ segGL,
+                                                        double* __restrict__ segGR, double* __restrict__ segS, int* __restrict__ fail)
+{
+    const int s = blockIdx.x * 64 + threadIdx.x;
+    if (s >= nseg) return;
+    const int L = sep_pose[s], R = sep_pose[s + 1];
+    double DL[36], GL[6], Dn[36], Gn[6], Ei[36];
+    for (int a = 0; a < 36; ++a) DL[a] = 0;
+    for (int a = 0; a < 6; ++a) GL[a] = 0;
+    if (R == L + 1) {
+        for (int a = 0; a < 36; ++a) { segDL[(size_t)s * 36 + a] = 0; segDR[(size_t)s * 36 + a] = 0; segS[(size_t)s * 36 + a] = C[(size_t)L * 36 + a]; }
+        for (int a = 0; a < 6; ++a) { segGL[(size_t)s * 6 + a] = 0; segGR[(size_t)s * 6 + a] = 0; }
+        return;
+    }
+    for (int a = 0; a < 36; ++a) { Ei[a] = C[(size_t)L * 36 + a]; Dn[a] = D[(size_t)(L + 1) * 36 + a]; }
+    for (int a = 0; a < 6; ++a) Gn[a] = g[(size_t)(L + 1) * 6 + a];
+    for (int i = L + 1; i < R; ++i) {
+        double Li[36], XE[36], XC[36], Xg[6], Ci[36];
+        for (int a = 0; a < 36; ++a) { Li[a] = Dn[a]; Ci[a] = C[(size_t)i * 36 + a]; E[(size_t)i * 36 + a] = Ei[a]; }
+        for (int a = 0; a < 6; ++a) { Xg[a] = Gn[a]; gi[(size_t)i * 6 + a] = Gn[a]; }
+        if (chol6(Li)) { *fail = 1; return; }
+        for (int a = 0; a < 36; ++a) Dl[(size_t)i * 36 + a] = Li[a];
+        for (int a = 0; a < 6; ++a) for (int b = 0; b < 6; ++b) XE[a * 6 + b] = Ei[b * 6 + a];      // E_i^T
+        for (int a = 0; a < 36; ++a) XC[a] = Ci[a];
+        chol6_solve(Li, XE, 6); chol6_solve(Li, XC, 6); chol6_solve(Li, Xg, 1);
+        // next pivot block and its gradient (the right separator's share when i + 1 == R)
+        double Dnext[36], Gnext[6], En[36];
+        const bool last = (i + 1 == R);
+        for (int a = 0; a < 36; ++a) Dnext[a] = last ? 0.0 : D[(size_t)(i + 1) * 36 + a];
+        for (int a = 0; a < 6; ++a) Gnext[a] = last ? 0.0 : g[(size_t)(i + 1) * 6 + a];
+        for (int a = 0; a < 6; ++a) {
+            for (int b = 0; b < 6; ++b) {
+                double sLL = 0, sLn = 0, snn = 0;
+                for (int q = 0; q < 6; ++q) {
+                    sLL += Ei[a * 6 + q] * XE[q * 6 + b];
+                    sLn += Ei[a * 6 + q] * XC[q * 6 + b];
+                    snn += Ci[q * 6 + a] * XC[q * 6 + b];
+                }
+                DL[a * 6 + b] -= sLL;
+                En[a * 6 + b] = -sLn;
+                Dnext[a * 6 + b] -= snn;
+            }
+            double tL = 0, tn = 0;
+            for (int q = 0; q < 6; ++q) { tL += Ei[a * 6 + q] * Xg[q]; tn += Ci[q * 6 + a] * Xg[q]; }
+            GL[a] -= tL;
+            Gnext[a] -= tn;
+        }
+        for (int a = 0; a < 36; ++a) { Ei[a] = En[a]; Dn[a] = Dnext[a]; }
+        for (int a = 0; a < 6; ++a) Gn[a] = Gnext[a];
+    }
+    for (int a = 0; a < 36; ++a) { segDL[(size_t)s * 36 + a] = DL[a]; segDR[(size_t)s * 36 + a] = Dn[a]; segS[(size_t)s * 36 + a] = Ei[a]; }
+    for (int a = 0; a < 6; ++a) { segGL[(size_t)s * 6 + a] = GL[a]; segGR[(size_t)s * 6 + a] = Gn[a]; }
+}
+
+// reduced system: diagonal blocks, chain couplings and right-hand side (one thread per separator, chain order)
+__global__ __launch_bounds__(256) void pg_scatter_base_kernel(int ns, const int* __restrict__ sep_pose, const int* __restrict__ perm,
+                                                              const double* __restrict__ D, const double* __restrict__ g,
+                                                              const double* __restrict__ segDL, const double* __restrict__ segDR,
+                                                              const double* __restrict__ segGL, const double* __restrict__ segGR,
+                                                              const double* __restrict__ segS, const int* __restrict__ diag_pos,
+                                                              const int* __restrict__ ch_pos, double* __restrict__ Lvals, double* __restrict__ rhs)
+{
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    if (k >= ns) return;
+    const int p = sep_pose[k];
+    double* dst = Lvals + (size_t)diag_pos[k] * 36;
+    for (int a = 0; a < 36; ++a) {
+        double v = D[(size_t)p * 36 + a];
+        if (k > 0) v += segDR[(size_t)(k - 1) * 36 + a];
+        if (k + 1 < ns) v += segDL[(size_t)k * 36 + a];
+        dst[a] = v;
+    }
+    double* rr = rhs + (size_t)perm[k] * 6;
+    for (int a = 0; a < 6; ++a) {
+        double v = g[(size_t)p * 6 + a];
+        if (k > 0) v += segGR[(size_t)(k - 1) * 6 + a];
+        if (k + 1 < ns) v += segGL[(size_t)k * 6 + a];
+        rr[a] = -v;
+    }
+    if (k + 1 < ns) {      // S(k, k+1): stored as the (larger index, smaller index) block
+        const int code = ch_pos[k], pos = code >> 1, tr = code & 1;
+        double* c = Lvals + (size_t)pos * 36;
+        const double* S = segS + (size_t)k * 36;
+        for (int a = 0; a < 6; ++a) for (int b = 0; b < 6; ++b) c[a * 6 + b] = tr ? S[b * 6 + a] : S[a * 6 + b];
+    }
+}
+// LC off-diagonal blocks H(a, b) = Ji^T W (added after the chain couplings; (a,b) is unique per edge)
+__global__ __launch_bounds__(256) void pg_scatter_lc_kernel(int n, int ne, const double* __restrict__ Ji, const double* __restrict__ ew,
+                                                            const int* __restrict__ lc_pos, double* __restrict__ Lvals)
+{
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= ne) return;
+    const int code = lc_pos[e], pos = code >> 1, tr = code & 1;
+    const double* J = Ji + (size_t)(n + e) * 36; const double* w = ew + (size_t)e * 6;
+    double* c = Lvals + (size_t)pos * 36;
+    for (int a = 0; a < 6; ++a) for (int b = 0; b < 6; ++b) {
+        const double h_ab = J[b * 6 + a] * w[b];               // (Ji^T W)(a, b)
+        if (tr) c[b * 6 + a] += h_ab; else c[a * 6 + b] += h_ab;
+    }
+}
+
+// ---- sparse block Cholesky, left-looking, one workgroup per column of the current elimination-tree level.
+// Column j holds blocks L(i, j), i in rowidx[colptr[j] .. colptr[j+1]) ascending, first the diagonal.
+// rowlist(j) = columns k < j with L(j, k) != 0 and the position of that block.
+__global__ __launch_bounds__(256) void pg_factor_level_kernel(const int* __restrict__ lvcols, const int* __restrict__ colptr,
+                                                              const int* __restrict__ rowidx, const int* __restrict__ rlptr,
+                                                              const int* __restrict__ rlcol, const int* __restrict__ rlpos,
+                                                              double* __restrict__ Lvals, int* __restrict__ fail)
+{
+    __shared__ double s_Ljk[36];
+    __shared__ double s_diag[36];
+    __shared__ int s_ok;
+    const int j = lvcols[blockIdx.x];
+    const int c0 = colptr[j], m = colptr[j + 1] - c0;
+    const int t0 = rlptr[j], t1 = rlptr[j + 1];
+    // accumulate: thread per (target block q, block row r)
+    for (int base = 0; base < 6 * m; base += 256) {
+        const int idx = base + threadIdx.x;
+        const bool act = idx < 6 * m;
+        const int q = act ? idx / 6 : 0, r = idx - q * 6;
+        const int irow = rowidx[c0 + q];
+        double acc[6];
+        if (act) for (int s = 0; s < 6; ++s) acc[s] = Lvals[(size_t)(c0 + q) * 36 + r * 6 + s];
+        for (int t = t0; t < t1; ++t) {
+            const int k = rlcol[t];
+            __syncthreads();
+            if (threadIdx.x < 36) s_Ljk[threadIdx.x] = Lvals[(size_t)rlpos[t] * 36 + threadIdx.x];
+            __syncthreads();
+            if (!act) continue;
+            // find row irow in column k (rows > k ascending): binary search
+            int lo = colptr[k] + 1, hi = colptr[k + 1] - 1, pos = -1;
+            while (lo <= hi) { const int mid = (lo + hi) >> 1; const int v = rowidx[mid]; if (v == irow) { pos = mid; break; } if (v < irow) lo = mid + 1; else hi = mid - 1; }
+            if (pos < 0) continue;
+            const double* Lik = Lvals + (size_t)pos * 36 + r * 6;
+            const double a0 = Lik[0], a1 = Lik[1], a2 = Lik[2], a3 = Lik[3], a4 = Lik[4], a5 = Lik[5];
+#pragma unroll
+            for (int s = 0; s < 6; ++s)
+                acc[s] -= a0 * s_Ljk[s * 6] + a1 * s_Ljk[s * 6 + 1] + a2 * s_Ljk[s * 6 + 2] + a3 * s_Ljk[s * 6 + 3] + a4 * s_Ljk[s * 6 + 4] + a5 * s_Ljk[s * 6 + 5];
+        }
+        if (act) for (int s = 0; s < 6; ++s) Lvals[(size_t)(c0 + q) * 36 + r * 6 + s] = acc[s];
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double A[36];
+        for (int a = 0; a < 36; ++a) A[a] = Lvals[(size_t)c0 * 36 + a];
+        const int bad = chol6(A);
+        if (bad) *fail = 1;
+        s_ok = !bad;
+        for (int a = 0; a < 6; ++a) for (int b = 0; b < 6; ++b) { const double v = b <= a ? A[a * 6 + b] : 0.0; s_diag[a * 6 + b] = v; Lvals[(size_t)c0 * 36 + a * 6 + b] = v; }
+    }
+    __syncthreads();
+    if (!s_ok) return;
+    // L(i, j) = A(i, j) L_jj^-T : forward substitution along each row
+    for (int idx = 6 + threadIdx.x; idx < 6 * m; idx += 256) {
+        double* row = Lvals + (size_t)(c0 + idx / 6) * 36 + (idx % 6) * 6;
+        double x[6];
+        for (int s = 0; s < 6; ++s) { double v = row[s]; for (int c = 0; c < s; ++c) v -= x[c] * s_diag[s * 6 + c]; x[s] = v / s_diag[s * 6 + s]; }
+        for (int s = 0; s < 6; ++s) row[s] = x[s];
+    }
+}
+
+// y_j = L_jj^-1 (b_j - sum_k L(j,k) y_k): one wave per column
+__global__ __launch_bounds__(64) void pg_fwd_level_kernel(const int* __restrict__ lvcols, const int* __restrict__ colptr,
+                                                          const int* __restrict__ rlptr, const int* __restrict__ rlcol, const int* __restrict__ rlpos,
+                                                          const double* __restrict__ Lvals, double* __restrict__ x)
+{
+    const int j = lvcols[blockIdx.x];
+    const int lane = threadIdx.x;
+    double acc[6] = { 0, 0, 0, 0, 0, 0 };
+    for (int t = rlptr[j] + lane; t < rlptr[j + 1]; t += 64) {
+        const double* B = Lvals + (size_t)rlpos[t] * 36; const double* y = x + (size_t)rlcol[t] * 6;
+        for (int a = 0; a < 6; ++a) { double s = 0; for (int b = 0; b < 6; ++b) s += B[a * 6 + b] * y[b]; acc[a] += s; }
+    }
+    for (int a = 0; a < 6; ++a)
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) acc[a] += __shfl_xor(acc[a], o, 64);
+    if (lane == 0) {
+        const double* Ld = Lvals + (size_t)colptr[j] * 36;
+        double v[6];
+        for (int a = 0; a < 6; ++a) { double s = x[(size_t)j * 6 + a] - acc[a]; for (int b = 0; b < a; ++b) s -= Ld[a * 6 + b] * v[b]; v[a] = s / Ld[a * 6 + a]; }
+        for (int a = 0; a < 6; ++a) x[(size_t)j * 6 + a] = v[a];
+    }
+}
+// x_j = L_jj^-T (y_j - sum_{i > j} L(i,j)^T x_i)
+__global__ __launch_bounds__(64) void pg_bwd_level_kernel(const int* __restrict__ lvcols, const int* __restrict__ colptr,
+                                                          const int* __restrict__ rowidx, const double* __restrict__ Lvals, double* __restrict__ x)
+{
+    const int j = lvcols[blockIdx.x];
+    const int lane = threadIdx.x;
+    double acc[6] = { 0, 0, 0, 0, 0, 0 };
+    for (int p = colptr[j] + 1 + lane; p < colptr[j + 1]; p += 64) {
+        const double* B = Lvals + (size_t)p * 36; const double* xi = x + (size_t)rowidx[p] * 6;
+        for (int a = 0; a < 6; ++a) { double s = 0; for (int b = 0; b < 6; ++b) s += B[b * 6 + a] * xi[b]; acc[a] += s; }
+    }
+    for (int a = 0; a < 6; ++a)
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) acc[a] += __shfl_xor(acc[a], o, 64);
+    if (lane == 0) {
+        const double* Ld = Lvals + (size_t)colptr[j] * 36;
+        double v[6];
+        for (int a = 5; a >= 0; --a) { double s = x[(size_t)j * 6 + a] - acc[a]; for (int b = a + 1; b < 6; ++b) s -= Ld[b * 6 + a] * v[b]; v[a] = s / Ld[a * 6 + a]; }
+        for (int a = 0; a < 6; ++a) x[(size_t)j * 6 + a] = v[a];
+    }
+}
+
+__global__ __launch_bounds__(256) void pg_sep_delta_kernel(int ns, const int* __restrict__ sep_pose, const int* __restrict__ perm,
+                                                           const double* __restrict__ x, double* __restrict__ delta)
+{
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    if (k >= ns) return;
+    for (int a = 0; a < 6; ++a) delta[(size_t)sep_pose[k] * 6 + a] = x[(size_t)perm[k] * 6 + a];
+}
+
+// interiors, right to left: delta_i = D_i^-1 (-g_i - E_i^T delta_L - C_i delta_{i+1})
+__global__ __launch_bounds__(64) void pg_backsub_kernel(int nseg, const int* __restrict__ sep_pose, const double* __restrict__ C,
+                                                        const double* __restrict__ E, const double* __restrict__ Dl, const double* __restrict__ gi,
+                                                        double* __restrict__ delta)
+{
+    const int s = blockIdx.x * 64 + threadIdx.x;
+    if (s >= nseg) return;
+    const int L = sep_pose[s], R = sep_pose[s + 1];
+    double dL[6], dn[6];
+    for (int a = 0; a < 6; ++a) { dL[a] = delta[(size_t)L * 6 + a]; dn[a] = delta[(size_t)R * 6 + a]; }
+    for (int i = R - 1; i > L; --i) {
+        double b[6];
+        for (int a = 0; a < 6; ++a) {
+            double t = -gi[(size_t)i * 6 + a];
+            for (int q = 0; q < 6; ++q) { t -= E[(size_t)i * 36 + q * 6 + a] * dL[q]; t -= C[(size_t)i * 36 + a * 6 + q] * dn[q]; }
+            b[a] = t;
+        }
+        double Li[36];
+        for (int a = 0; a < 36; ++a) Li[a] = Dl[(size_t)i * 36 + a];
+        chol6_solve(Li, b, 1);
+        for (int a = 0; a < 6; ++a) { delta[(size_t)i * 6 + a] = b[a]; dn[a] = b[a]; }
+    }
+}
+
+// 0.5 * || J delta + r ||^2 over all factors (linear.error(delta))
+__global__ __launch_bounds__(256) void pg_linerr_kernel(int n, int ne, pg_weights W, const int* __restrict__ ea, const int* __restrict__ eb,
+                                                        const double* __restrict__ ew, const double* __restrict__ r, const double* __restrict__ Ji,
+                                                        const double* __restrict__ delta, double* __restrict__ partial)
+{
+    __shared__ double s_w[4];
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    double e2 = 0;
+    if (k < n + ne) {
+        int i = -1, j; const double* w;
+        if (k == 0) { j = 0; w = W.prior; }
+        else if (k < n) { i = k - 1; j = k; w = W.odo; }
+        else { i = ea[k - n]; j = eb[k - n]; w = ew + (size_t)(k - n) * 6; }
+        for (int a = 0; a < 6; ++a) {
+            double s = r[(size_t)k * 6 + a] + w[a] * delta[(size_t)j * 6 + a];
+            if (i >= 0) for (int q = 0; q < 6; ++q) s += Ji[(size_t)k * 36 + a * 6 + q] * delta[(size_t)i * 6 + q];
+            e2 += s * s;
+        }
+    }
+    const double s = block_sum256(e2, s_w);
+    if (threadIdx.x == 0) partial[blockIdx.x] = s;
+}
+
+__global__ __launch_bounds__(256) void pg_retract_kernel(int n, const pose_t* __restrict__ X, const double* __restrict__ delta, pose_t* __restrict__ Xn)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    pose_t o;
+    pose_retract(&X[i], delta + (size_t)i * 6, &o);
+    Xn[i] = o;
+}
+
+// ------------------------------------------------------------------ host: ordering + symbolic analysis
+namespace {
+
+struct sym_t {
+    int ns = 0;
+    std::vector<int> perm;                 // chain-order separator -> elimination index
+    std::vector<int> colptr, rowidx, rlptr, rlcol, rlpos, lvptr, lvcols, diag_pos, ch_pos, lc_pos;
+};
+
+// geometric nested dissection: recursive coordinate bisection with vertex separators taken from the lower half
+void nd_order(std::vector<int>& nodes, const std::vector<std::vector<int>>& adj, const std::vector<double>& cx,
+              const std::vector<double>& cy, std::vector<char>& side, std::vector<int>& order, int leaf)
+{
+    if ((int)nodes.size() <= leaf) { std::sort(nodes.begin(), nodes.end()); for (int v : nodes) order.push_back(v); return; }
+    double x0 = 1e300, x1 = -1e300, y0 = 1e300, y1 = -1e300;
+    for (int v : nodes) { x0 = std::min(x0, cx[v]); x1 = std::max(x1, cx[v]); y0 = std::min(y0, cy[v]); y1 = std::max(y1, cy[v]); }
+    const bool byx = (x1 - x0) >= (y1 - y0);
+    std::sort(nodes.begin(), nodes.end(), [&](int a, int b) {
+        const double ka = byx ? cx[a] : cy[a], kb = byx ? cx[b] : cy[b];
+        return ka != kb ? ka < kb : a < b; });
+    const size_t half = nodes.size() / 2;
+    for (size_t i = 0; i < nodes.size(); ++i) side[nodes[i]] = i < half ? 1 : 2;
+    std::vector<int> A, B, S;
+    for (size_t i = 0; i < half; ++i) {
+        const int v = nodes[i];
+        bool cut = false;
+        for (int u : adj[v]) if (side[u] == 2) { cut = true; break; }
+        (cut ? S : A).push_back(v);
+    }
+    for (size_t i = half; i < nodes.size(); ++i) B.push_back(nodes[i]);
+    for (int v : nodes) side[v] = 0;
+    if (A.empty() || B.empty()) {          // degenerate cut: fall back to index order
+        std::sort(nodes.begin(), nodes.end());
+        for (int v : nodes) order.push_back(v);
+        return;
+    }
+    nd_order(A, adj, cx, cy, side, order, leaf);
+    nd_order(B, adj, cx, cy, side, order, leaf);
+    std::sort(S.begin(), S.end());
+    for (int v : S) order.push_back(v);
+}
+
+// edges: pairs of chain-order separator indices (chain couplings first, then LC edges)
+void symbolic(int ns, const std::vector<std::pair<int, int>>& edges, int nchain, const std::vector<double>& cx,
+              const std::vector<double>& cy, bool use_nd, sym_t& S)
+{
+    S.ns = ns;
+    std::vector<std::vector<int>> adj(ns);
+    for (auto& e : edges) if (e.first != e.second) { adj[e.first].push_back(e.second); adj[e.second].push_back(e.first); }
+    for (auto& a : adj) { std::sort(a.begin(), a.end()); a.erase(std::unique(a.begin(), a.end()), a.end()); }
+    std::vector<int> order; order.reserve(ns);
+    if (use_nd) {
+        std::vector<int> nodes(ns); std::iota(nodes.begin(), nodes.end(), 0);
+        std::vector<char> side(ns, 0);
+        nd_order(nodes, adj, cx, cy, side, order, 24);
+    } else { order.resize(ns); std::iota(order.begin(), order.end(), 0); }
+    S.perm.assign(ns, 0);
+    for (int i = 0; i < ns; ++i) S.perm[order[i]] = i;
+    // column structures by merging children (elimination tree built on the fly)
+    std::vector<std::vector<int>> cols(ns), kids(ns);
+    std::vector<int> parent(ns, -1);
+    for (int j = 0; j < ns; ++j) {
+        std::vector<int>& c = cols[j];
+        const int v = order[j];
+        for (int u : adj[v]) if (S.perm[u] > j) c.push_back(S.perm[u]);
+        for (int k : kids[j]) for (size_t q = 1; q < cols[k].size(); ++q) if (cols[k][q] != j) c.push_back(cols[k][q]);
+        std::sort(c.begin(), c.end()); c.erase(std::unique(c.begin(), c.end()), c.end());
+        c.insert(c.begin(), j);
+        if (c.size() > 1) { parent[j] = c[1]; kids[c[1]].push_back(j); }
+    }
+    S.colptr.assign(ns + 1, 0);
+    for (int j = 0; j < ns; ++j) S.colptr[j + 1] = S.colptr[j] + (int)cols[j].size();
+    S.rowidx.resize(S.colptr[ns]);
+    for (int j = 0; j < ns; ++j) std::copy(cols[j].begin(), cols[j].end(), S.rowidx.begin() + S.colptr[j]);
+    // row lists (transpose of the strictly lower structure), ascending k
+    S.rlptr.assign(ns + 1, 0);
+    for (int k = 0; k < ns; ++k) for (size_t q = 1; q < cols[k].size(); ++q) S.rlptr[cols[k][q] + 1]++;
+    for (int j = 0; j < ns; ++j) S.rlptr[j + 1] += S.rlptr[j];
+    S.rlcol.resize(S.rlptr[ns]); S.rlpos.resize(S.rlptr[ns]);
+    { std::vector<int> fill(S.rlptr.begin(), S.rlptr.end() - 1);
+      for (int k = 0; k < ns; ++k) for (size_t q = 1; q < cols[k].size(); ++q) { const int j = cols[k][q]; S.rlcol[fill[j]] = k; S.rlpos[fill[j]] = S.colptr[k] + (int)q; fill[j]++; } }
+    // levels of the elimination tree
+    std::vector<int> level(ns, 0);
+    int maxl = 0;
+    for (int j = 0; j < ns; ++j) { for (int k : kids[j]) level[j] = std::max(level[j], level[k] + 1); maxl = std::max(maxl, level[j]); }
+    S.lvptr.assign(maxl + 2, 0);
+    for (int j = 0; j < ns; ++j) S.lvptr[level[j] + 1]++;
+    for (int l = 0; l <= maxl; ++l) S.lvptr[l + 1] += S.lvptr[l];
+    S.lvcols.resize(ns);
+    { std::vector<int> fill(S.lvptr.begin(), S.lvptr.end() - 1); for (int j = 0; j < ns; ++j) S.lvcols[fill[level[j]]++] = j; }
+    // where the assembled blocks go
+    auto find = [&](int row, int col) { const auto b = S.rowidx.begin() + S.colptr[col], e = S.rowidx.begin() + S.colptr[col + 1];
+                                        return (int)(std::lower_bound(b, e, row) - S.rowidx.begin()); };
+    S.diag_pos.resize(ns);
+    for (int k = 0; k < ns; ++k) S.diag_pos[k] = S.colptr[S.perm[k]];
+    S.ch_pos.assign(std::max(ns - 1, 0), 0);
+    for (int k = 0; k + 1 < ns; ++k) {
+        const int pa = S.perm[k], pb = S.perm[k + 1];          // block S(k, k+1): rows k, cols k+1
+        S.ch_pos[k] = pa > pb ? (find(pa, pb) << 1) : ((find(pb, pa) << 1) | 1);
+    }
+    S.lc_pos.resize(edges.size() - nchain);
+    for (size_t e = nchain; e < edges.size(); ++e) {
+        const int pa = S.perm[edges[e].first], pb = S.perm[edges[e].second];   // block H(a, b)
+        S.lc_pos[e - nchain] = pa > pb ? (find(pa, pb) << 1) : ((find(pb, pa) << 1) | 1);
+    }
+}
+
+struct pg_dev {
+    std::vector<void*> allocs;
+    template <typename T> int alloc(dsss_ctx* c, T** p, size_t n) { void* q = nullptr; HIPCHK(c, hipMalloc(&q, std::max<size_t>(n, 1) * sizeof(T))); allocs.push_back(q); *p = (T*)q; return DSSS_OK; }
+    template <typename T> int upload(dsss_ctx* c, T** p, const std::vector<T>& v) { int rc = alloc(c, p, v.size()); if (rc) return rc; if (!v.empty()) HIPCHK(c, hipMemcpy(*p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice)); return DSSS_OK; }
+    void release() { for (void* q : allocs) hipFree(q); allocs.clear(); }
+};
+
+} // namespace
+
+void dsss_pg_free(dsss_ctx* c) { (void)c; }
+
+// batch LM over `total` poses (dr6: host, total x 6) with `ne` LC edges (host)
+static int pg_solve_impl(dsss_ctx* c, const double* dr6, int total, const dsss_lc_edge* edges, int ne, double* poses12, double* stats4)
+{
+    const int n = total;
+    if (n < 2) DSSS_FAIL(c, DSSS_E_ARG, "pose graph needs at least 2 poses");
+    const double PI = DSSS_PI_REF;
+    pg_weights W;
+    { const double wgt1 = 0.001, wgt2 = 10;                                   // optimizer.cpp:24,28
+      const double so[6] = { wgt1 * PI / 180, wgt1 * PI / 180, 0.1 * wgt1 * wgt2 * PI / 180, wgt1 * wgt2, wgt1 * wgt2, wgt1 };
+      for (int k = 0; k < 6; ++k) { W.prior[k] = 1.0 / 0.000001; W.odo[k] = 1.0 / so[k]; } }
+    // host-side preparation: DR poses, measurements, initial values (optimizer.cpp:150-160)
+    std::vector<pose_t> DR(n), X0(n), meas(n);
+    for (int i = 0; i < n; ++i) pose_from_rodrigues(dr6 + (size_t)i * 6, &DR[i]);
+    if (c->pg.add_noise) {
+        std::default_random_engine generator;                                  // optimizer.cpp:30-31
+        std::normal_distribution<double> distribution(0.0, 1.0);
+        const double noise_xyz = 0.5, noise_rpy = 0.5 * PI / 180;
+        for (int i = 0; i < n; ++i) {
+            double z[6];
+            for (int k = 0; k < 6; ++k) z[k] = distribution(generator);
+            const double w[3] = { z[0] * noise_rpy, z[1] * noise_rpy, z[2] * noise_rpy };
+            pose_t N; so3_exp(w, N.R);
+            N.t[0] = z[3] * noise_xyz; N.t[1] = z[4] * noise_xyz; N.t[2] = z[5] * noise_xyz;
+            pose_compose(&DR[i], &N, &X0[i]);
+        }
+    } else X0 = DR;
+    meas[0] = DR[0];
+    for (int i = 1; i < n; ++i) pose_between(&DR[i - 1], &DR[i], &meas[i]);
+    std::vector<int> ea(ne), eb(ne); std::vector<pose_t> emeas(ne); std::vector<double> ew((size_t)ne * 6);
+    for (int e = 0; e < ne; ++e) {
+        ea[e] = edges[e].a; eb[e] = edges[e].b;
+        if (ea[e] < 0 || ea[e] >= n || eb[e] < 0 || eb[e] >= n || ea[e] == eb[e]) DSSS_FAIL(c, DSSS_E_ARG, "LC edge %d out of range", e);
+        for (int k = 0; k < 9; ++k) emeas[e].R[k] = edges[e].rel[k];
+        for (int k = 0; k < 3; ++k) emeas[e].t[k] = edges[e].rel[9 + k];
+        for (int k = 0; k < 6; ++k) ew[(size_t)e * 6 + k] = 1.0 / std::sqrt(edges[e].var[k]);
+    }
+    // incidence lists (edge order), separators, segments
+    std::vector<int> adj_ptr(n + 1, 0), adj_edge(2 * (size_t)ne);
+    for (int e = 0; e < ne; ++e) { adj_ptr[ea[e] + 1]++; adj_ptr[eb[e] + 1]++; }
+    for (int i = 0; i < n; ++i) adj_ptr[i + 1] += adj_ptr[i];
+    { std::vector<int> fill(adj_ptr.begin(), adj_ptr.end() - 1);
+      for (int e = 0; e < ne; ++e) { adj_edge[fill[ea[e]]++] = e << 1; adj_edge[fill[eb[e]]++] = (e << 1) | 1; } }
+    std::vector<char> is_sep(n, 0);
+    is_sep[0] = 1; is_sep[n - 1] = 1;
+    for (int e = 0; e < ne; ++e) { is_sep[ea[e]] = 1; is_sep[eb[e]] = 1; }
+    std::vector<int> sep_pose, sidx(n, -1);
+    for (int i = 0; i < n; ++i) if (is_sep[i]) { sidx[i] = (int)sep_pose.size(); sep_pose.push_back(i); }
+    const int ns = (int)sep_pose.size(), nseg = ns - 1;
+    std::vector<std::pair<int, int>> redges;
+    for (int k = 0; k + 1 < ns; ++k) redges.push_back({ k, k + 1 });
+    for (int e = 0; e < ne; ++e) redges.push_back({ sidx[ea[e]], sidx[eb[e]] });
+    std::vector<double> cx(ns), cy(ns);
+    for (int k = 0; k < ns; ++k) { cx[k] = DR[sep_pose[k]].t[0]; cy[k] = DR[sep_pose[k]].t[1]; }
+    sym_t S;
+    symbolic(ns, redges, nseg, cx, cy, true, S);
+    const int nlev = (int)S.lvptr.size() - 1;
+    const size_t nnzL = S.rowidx.size();
+
+    // device state
+    pg_dev dv;
+    int rc = DSSS_OK;
+    pose_t *d_X, *d_Xn, *d_meas, *d_emeas; int *d_ea, *d_eb, *d_adj_ptr, *d_adj_edge, *d_sep, *d_perm;
+    double *d_ew, *d_r, *d_Ji, *d_D, *d_C, *d_g, *d_delta, *d_E, *d_Dl, *d_gi, *d_sDL, *d_sDR, *d_sGL, *d_sGR, *d_sS, *d_L, *d_x, *d_part, *d_scal;
+    int *d_colptr, *d_rowidx, *d_rlptr, *d_rlcol, *d_rlpos, *d_lvcols, *d_diag, *d_ch, *d_lc, *d_fail;
+    const int nf = n + ne, nblk = (nf + 255) / 256;
+#define TRY(x) do { rc = (x); if (rc) { dv.release(); return rc; } } while (0)
+    TRY(dv.upload(c, &d_X, X0)); TRY(dv.alloc(c, &d_Xn, n)); TRY(dv.upload(c, &d_meas, meas)); TRY(dv.upload(c, &d_emeas, emeas));
+    TRY(dv.upload(c, &d_ea, ea)); TRY(dv.upload(c, &d_eb, eb)); TRY(dv.upload(c, &d_ew, ew));
+    TRY(dv.upload(c, &d_adj_ptr, adj_ptr)); TRY(dv.upload(c, &d_adj_edge, adj_edge)); TRY(dv.upload(c, &d_sep, sep_pose)); TRY(dv.upload(c, &d_perm, S.perm));
+    TRY(dv.alloc(c, &d_r, (size_t)nf * 6)); TRY(dv.alloc(c, &d_Ji, (size_t)nf * 36));
+    TRY(dv.alloc(c, &d_D, (size_t)n * 36)); TRY(dv.alloc(c, &d_C, (size_t)n * 36)); TRY(dv.alloc(c, &d_g, (size_t)n * 6)); TRY(dv.alloc(c, &d_delta, (size_t)n * 6));
+    TRY(dv.alloc(c, &d_E, (size_t)n * 36)); TRY(dv.alloc(c, &d_Dl, (size_t)n * 36)); TRY(dv.alloc(c, &d_gi, (size_t)n * 6));
+    TRY(dv.alloc(c, &d_sDL, (size_t)nseg * 36)); TRY(dv.alloc(c, &d_sDR, (size_t)nseg * 36)); TRY(dv.alloc(c, &d_sGL, (size_t)nseg * 6));
+    TRY(dv.alloc(c, &d_sGR, (size_t)nseg * 6)); TRY(dv.alloc(c, &d_sS, (size_t)nseg * 36));
+    TRY(dv.alloc(c, &d_L, nnzL * 36)); TRY(dv.alloc(c, &d_x, (size_t)ns * 6)); TRY(dv.alloc(c, &d_part, (size_t)nblk)); TRY(dv.alloc(c, &d_scal, 4)); TRY(dv.alloc(c, &d_fail, 1));
+    TRY(dv.upload(c, &d_colptr, S.colptr)); TRY(dv.upload(c, &d_rowidx, S.rowidx)); TRY(dv.upload(c, &d_rlptr, S.rlptr)); TRY(dv.upload(c, &d_rlcol, S.rlcol));
+    TRY(dv.upload(c, &d_rlpos, S.rlpos)); TRY(dv.upload(c, &d_lvcols, S.lvcols)); TRY(dv.upload(c, &d_diag, S.diag_pos)); TRY(dv.upload(c, &d_ch, S.ch_pos)); TRY(dv.upload(c, &d_lc, S.lc_pos));
+    hipStream_t st = c->stream;
+#define HCK(x) do { hipError_t _e = (x); if (_e != hipSuccess) { c->err = std::string(#x) + ": " + hipGetErrorString(_e); dv.release(); return DSSS_E_HIP; } } while (0)
+    auto error_of = [&](const pose_t* Xd, double* out) -> int {
+        hipLaunchKernelGGL(pg_linearize_kernel, dim3(nblk), dim3(256), 0, st, n, ne, Xd, d_meas, W, d_ea, d_eb, d_emeas, d_ew, (double*)nullptr, (double*)nullptr, d_part);
+        hipLaunchKernelGGL(pg_final_sum_kernel, dim3(1), dim3(256), 0, st, d_part, nblk, 0.5, d_scal);
+        HCK(hipMemcpyAsync(out, d_scal, sizeof(double), hipMemcpyDeviceToHost, st));
+        HCK(hipStreamSynchronize(st));
+        return DSSS_OK;
+    };
+    dsss_scope sc(c, DSSS_K_PG);
+    double lambda = c->pg.lambda0, err = 0, err0 = 0, cur = 0;
+    int iters = 0, nfact = 0;
+    TRY(error_of(d_X, &err));
+    err0 = err;
+    if (err > 0) do {
+        cur = err;
+        double oldLin = 0;
+        hipLaunchKernelGGL(pg_linearize_kernel, dim3(nblk), dim3(256), 0, st, n, ne, d_X, d_meas, W, d_ea, d_eb, d_emeas, d_ew, d_r, d_Ji, d_part);
+        hipLaunchKernelGGL(pg_final_sum_kernel, dim3(1), dim3(256), 0, st, d_part, nblk, 0.5, d_scal);
+        HCK(hipMemcpyAsync(&oldLin, d_scal, sizeof(double), hipMemcpyDeviceToHost, st));
+        for (;;) {
+            // ---- solve (H + lambda I) delta = -g
+            HCK(hipMemsetAsync(d_fail, 0, sizeof(int), st));
+            HCK(hipMemsetAsync(d_L, 0, nnzL * 36 * sizeof(double), st));
+            hipLaunchKernelGGL(pg_assemble_kernel, dim3((n + 255) / 256), dim3(256), 0, st, n, W, d_r, d_Ji, d_adj_ptr, d_adj_edge, d_ew, lambda, d_D, d_C, d_g);
+            hipLaunchKernelGGL(pg_segment_kernel, dim3((nseg + 63) / 64), dim3(64), 0, st, nseg, d_sep, d_D, d_C, d_g, d_E, d_Dl, d_gi, d_sDL, d_sDR, d_sGL, d_sGR, d_sS, d_fail);
+            hipLaunchKernelGGL(pg_scatter_base_kernel, dim3((ns + 255) / 256), dim3(256), 0, st, ns, d_sep, d_perm, d_D, d_g, d_sDL, d_sDR, d_sGL, d_sGR, d_sS, d_diag, d_ch, d_L, d_x);
+            if (ne > 0) hipLaunchKernelGGL(pg_scatter_lc_kernel, dim3((ne + 255) / 256), dim3(256), 0, st, n, ne, d_Ji, d_ew, d_lc, d_L);
+            for (int l = 0; l < nlev; ++l)
+                hipLaunchKernelGGL(pg_factor_level_kernel, dim3(S.lvptr[l + 1] - S.lvptr[l]), dim3(256), 0, st, d_lvcols + S.lvptr[l], d_colptr, d_rowidx, d_rlptr, d_rlcol, d_rlpos, d_L, d_fail);
+            ++nfact;
+            for (int l = 0; l < nlev; ++l)
+                hipLaunchKernelGGL(pg_fwd_level_kernel, dim3(S.lvptr[l + 1] - S.lvptr[l]), dim3(64), 0, st, d_lvcols + S.lvptr[l], d_colptr, d_rlptr, d_rlcol, d_rlpos, d_L, d_x);
+            for (int l = nlev - 1; l >= 0; --l)
+                hipLaunchKernelGGL(pg_bwd_level_kernel, dim3(S.lvptr[l + 1] - S.lvptr[l]), dim3(64), 0, st, d_lvcols + S.lvptr[l], d_colptr, d_rowidx, d_L, d_x);
+            hipLaunchKernelGGL(pg_sep_delta_kernel, dim3((ns + 255) / 256), dim3(256), 0, st, ns, d_sep, d_perm, d_x, d_delta);
+            hipLaunchKernelGGL(pg_backsub_kernel, dim3((nseg + 63) / 64), dim3(64), 0, st, nseg, d_sep, d_C, d_E, d_Dl, d_gi, d_delta);
+            hipLaunchKernelGGL(pg_linerr_kernel, dim3(nblk), dim3(256), 0, st, n, ne, W, d_ea, d_eb, d_ew, d_r, d_Ji, d_delta, d_part);
+            hipLaunchKernelGGL(pg_final_sum_kernel, dim3(1), dim3(256), 0, st, d_part, nblk, 0.5, d_scal + 1);
+            hipLaunchKernelGGL(pg_retract_kernel, dim3((n + 255) / 256), dim3(256), 0, st, n, d_X, d_delta, d_Xn);
+            hipLaunchKernelGGL(pg_linearize_kernel, dim3(nblk), dim3(256), 0, st, n, ne, d_Xn, d_meas, W, d_ea, d_eb, d_emeas, d_ew, (double*)nullptr, (double*)nullptr, d_part);
+            hipLaunchKernelGGL(pg_final_sum_kernel, dim3(1), dim3(256), 0, st, d_part, nblk, 0.5, d_scal + 2);
+            HCK(hipGetLastError());
+            double h[3]; int failed = 0;
+            HCK(hipMemcpyAsync(h, d_scal, 3 * sizeof(double), hipMemcpyDeviceToHost, st));
+            HCK(hipMemcpyAsync(&failed, d_fail, sizeof(int), hipMemcpyDeviceToHost, st));
+            HCK(hipStreamSynchronize(st));
+            const bool ok = !failed && std::isfinite(h[1]);
+            bool success = false, stop = false;
+            double newErr = 0;
+            if (ok) {
+                const double linChange = oldLin - h[1];
+                if (linChange >= 0) {
+                    newErr = h[2];
+                    const double costChange = err - newErr;
+                    if (linChange > 2.220446049250313e-16 * oldLin) success = (costChange / linChange) > c->pg.min_fidelity;
+                    if (std::fabs(costChange) < c->pg.rel_tol * err) stop = true;
+                }
+            }
+            if (success) { std::swap(d_X, d_Xn); err = newErr; lambda /= c->pg.lambda_factor; ++iters; break; }
+            else if (!stop) { lambda *= c->pg.lambda_factor; if (lambda >= c->pg.lambda_max) break; }
+            else break;
+        }
+    } while (iters < c->pg.max_iters && !((err <= 0) || ((cur - err) / cur <= c->pg.rel_tol) || ((cur - err) <= c->pg.abs_tol)) && std::isfinite(cur));
+    if (poses12) {
+        std::vector<pose_t> out(n);
+        HCK(hipMemcpy(out.data(), d_X, (size_t)n * sizeof(pose_t), hipMemcpyDeviceToHost));
+        for (int i = 0; i < n; ++i) { for (int k = 0; k < 9; ++k) poses12[(size_t)i * 12 + k] = out[i].R[k]; for (int k = 0; k < 3; ++k) poses12[(size_t)i * 12 + 9 + k] = out[i].t[k]; }
+    }
+    if (stats4) { stats4[0] = iters; stats4[1] = err0; stats4[2] = err; stats4[3] = lambda; }
+    dv.release();
+    (void)nfact;
+#undef TRY
+#undef HCK
+    return DSSS_OK;
+}
+
+// ------------------------------------------------------------------ LC selection (optimizer.cpp:203-258)
+// For target frame t, ping j: the LAST pair (s, t) in pair order holding a kp whose target ping is j wins, and
+// within it the FIRST such kp.  One 64-bit atomicMax per kp on key = (pair rank << 32) | (~index in pair).
+__global__ __launch_bounds__(256) void lc_select_kernel(const double* __restrict__ kp7, int n, const int* __restrict__ kp7_pair,
+                                                        const int* __restrict__ kp7_off, const int* __restrict__ act_t,
+                                                        const int* __restrict__ frame_off, unsigned long long* __restrict__ slot)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int p = kp7_pair[i];
+    const int t = act_t[p];
+    const int ping = (int)kp7[(size_t)i * 7 + 3];
+    const unsigned long long key = ((unsigned long long)(unsigned)(p + 1) << 32) | (unsigned long long)(0xffffffffu - (unsigned)(i - kp7_off[p]));
+    atomicMax(&slot[frame_off[t] + ping], key);
+}
+
+extern "C" {
+
+int dsss_posegraph_select(dsss_ctx* c, int nframes, dsss_lc_edge* edges, int cap, int* n_edges)
+{
+    if (!c || nframes <= 0 || nframes > c->max_frames) return DSSS_E_ARG;
+    if (!c->has_lc) DSSS_FAIL(c, DSSS_E_STATE, "dsss_lc_solve_all has not run");
+    HIPCHK(c, hipSetDevice(c->device));
+    std::vector<int> off(nframes + 1, 0);
+    for (int f = 0; f < nframes; ++f) {
+        if (!c->frames[f].has_geom) DSSS_FAIL(c, DSSS_E_STATE, "frame %d has no geometry", f);
+        off[f + 1] = off[f] + c->frames[f].N;
+    }
+    const int total = off[nframes], n = c->total_kp7;
+    int ne = 0;
+    if (n > 0) {
+        // the reference's "last pair wins" ranks pairs in (i<j) loop order == the caller's pair order, provided the
+        // active pairs were listed in that order (they are: dsss_match_pairs keeps the caller's order)
+        for (int p = 0; p < c->npairs; ++p)
+            if (c->pair_s[p] >= nframes || c->pair_t[p] >= nframes) DSSS_FAIL(c, DSSS_E_ARG, "pair %d references a frame >= nframes", p);
+        unsigned long long* d_slot = nullptr; int* d_off = nullptr;
+        HIPCHK(c, hipMalloc(&d_slot, (size_t)total * sizeof(unsigned long long)));
+        HIPCHK(c, hipMalloc(&d_off, (nframes + 1) * sizeof(int)));
+        hipError_t e = hipMemsetAsync(d_slot, 0, (size_t)total * sizeof(unsigned long long), c->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(d_off, off.data(), (nframes + 1) * sizeof(int), hipMemcpyHostToDevice, c->stream);
+        if (e == hipSuccess) {
+            hipLaunchKernelGGL(lc_select_kernel, dim3((n + 255) / 256), dim3(256), 0, c->stream, c->kp7, n, c->kp7_pair, c->kp7_off, c->act_t, d_off, d_slot);
+            e = hipGetLastError();
+        }
+        std::vector<unsigned long long> slot(total);
+        std::vector<dsss_lc> lcs(n); std::vector<double> kp7((size_t)n * 7);
+        if (e == hipSuccess) e = hipMemcpyAsync(slot.data(), d_slot, (size_t)total * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(lcs.data(), c->lcs, (size_t)n * sizeof(dsss_lc), hipMemcpyDeviceToHost, c->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(kp7.data(), c->kp7, (size_t)n * 7 * sizeof(double), hipMemcpyDeviceToHost, c->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        hipFree(d_slot); hipFree(d_off);
+        HIPCHK(c, e);
+        std::vector<int> act_s(c->nactive), act_t(c->nactive);
+        for (int p = 0; p < c->npairs; ++p) if (c->pair_active[p] >= 0) { act_s[c->pair_active[p]] = c->pair_s[p]; act_t[c->pair_active[p]] = c->pair_t[p]; }
+        for (int g = 0; g < total; ++g) {                       // ascending global target pose id == the reference's loop order
+            const unsigned long long key = slot[g];
+            if (!key) continue;
+            const int p = (int)(key >> 32) - 1, k = (int)(0xffffffffu - (unsigned)(key & 0xffffffffu));
+            const int i = c->h_kp7_off[p] + k;
+            if (!(lcs[i].score > 0)) continue;                  // :234
+            if (ne >= cap) DSSS_FAIL(c, DSSS_E_CAPACITY, "more than %d LC edges", cap);
+            dsss_lc_edge& ed = edges[ne++];
+            ed.a = off[act_s[p]] + (int)kp7[(size_t)i * 7 + 0];
+            ed.b = g;
+            memcpy(ed.rel, lcs[i].rel, sizeof ed.rel); memcpy(ed.var, lcs[i].var, sizeof ed.var);
+        }
+    }
+    if (n_edges) *n_edges = ne;
+    return DSSS_OK;
+}
+
+int dsss_posegraph_solve_edges(dsss_ctx* c, const double* dr6, int total, const dsss_lc_edge* edges, int ne, double* poses12, double* stats4)
+{
+    if (!c || !dr6 || total <= 0 || ne < 0 || (ne > 0 && !edges)) return DSSS_E_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    std::vector<double> h_dr((size_t)total * 6);
+    HIPCHK(c, hipMemcpy(h_dr.data(), dr6, h_dr.size() * sizeof(double), hipMemcpyDefault));
+    std::vector<dsss_lc_edge> h_e(ne);
+    if (ne) HIPCHK(c, hipMemcpy(h_e.data(), edges, (size_t)ne * sizeof(dsss_lc_edge), hipMemcpyDefault));
+    return pg_solve_impl(c, h_dr.data(), total, h_e.data(), ne, poses12, stats4);
+}
+
+int dsss_posegraph_solve(dsss_ctx* c, int nframes, double* poses12, double* rpy6, double* stats4)
+{
+    if (!c || nframes <= 0 || nframes > c->max_frames) return DSSS_E_ARG;
+    std::vector<double> dr;
+    for (int f = 0; f < nframes; ++f) {
+        if (!c->frames[f].has_geom) DSSS_FAIL(c, DSSS_E_STATE, "frame %d has no geometry", f);
+        dr.insert(dr.end(), c->frames[f].h_pose6.begin(), c->frames[f].h_pose6.end());
+    }
+    const int total = (int)(dr.size() / 6);
+    std::vector<dsss_lc_edge> edges((size_t)std::max(c->total_kp7, 1));
+    int ne = 0;
+    int rc = dsss_posegraph_select(c, nframes, edges.data(), (int)edges.size(), &ne);
+    if (rc) return rc;
+    std::vector<double> p12((size_t)total * 12);
+    rc = pg_solve_impl(c, dr.data(), total, edges.data(), ne, p12.data(), stats4);
+    if (rc) return rc;
+    if (poses12) memcpy(poses12, p12.data(), p12.size() * sizeof(double));
+    if (rpy6)                                                   // SaveTrajactoryAll line format (optimizer.cpp:1199-1203)
+        for (int i = 0; i < total; ++i) {
+            pose_t T;
+            for (int k = 0; k < 9; ++k) T.R[k] = p12[(size_t)i * 12 + k];
+            for (int k = 0; k < 3; ++k) T.t[k] = p12[(size_t)i * 12 + 9 + k];
+            double rpy[3];
+            pose_rpy(&T, rpy);
+            rpy6[(size_t)i * 6 + 0] = rpy[0]; rpy6[(size_t)i * 6 + 1] = rpy[1]; rpy6[(size_t)i * 6 + 2] = rpy[2];
+            rpy6[(size_t)i * 6 + 3] = T.t[0]; rpy6[(size_t)i * 6 + 4] = T.t[1]; rpy6[(size_t)i * 6 + 5] = T.t[2];
+        }
+    return DSSS_OK;
+}
+
+} // extern "C"

@@ -85,6 +85,10 @@ int dsss_frame_get_norm(dsss_ctx*, int id, uint8_t* norm_host, uint8_t* mask_hos
 int dsss_frame_get_level(dsss_ctx*, int id, int level, uint8_t* img_host, int* rows, int* cols);/* mvImagePyramid[level] */
 int dsss_frame_get_candidates(dsss_ctx*, int id, int level, float* x_host, float* y_host, float* resp_host,
                               int cap, int* n);                                                /* vToDistributeKeys */
+/* ORBextractor::DistributeOctTree (ORBextractor.cpp:539-763): HOST routine (sequential, order dependent), exposed
+ * so the CPU test-suite can check it against the oracle without a GPU.  keep_idx_host needs n entries.          */
+int dsss_host_quadtree(const float* x_host, const float* y_host, const float* resp_host, int n,
+                       int minX, int maxX, int minY, int maxY, int quota, int32_t* keep_idx_host, int* n_keep);
 /* Frame::kps / Frame::dst (+ the geo_img samples FEAmatcher.cpp:81-82 reads) */
 int dsss_features_get(dsss_ctx*, int id, dsss_kp* kps_host, uint8_t* desc_host, double* geo_host, int cap, int* n);
 /* import features computed elsewhere (another rank's all-gather, or a test); geo/bbox may be NULL when the

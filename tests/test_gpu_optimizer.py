@@ -1,0 +1,118 @@
+"""GPU parity: batched mini-LM loop-closure solve, LC selection and the pose-graph LM against the CPU oracle.
+Floating point: tolerances are written next to each assertion (north_star: 1e-6 on optimised poses)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from diasss_amd import capi
+    c = capi.Context(max_frames=8)
+    yield c
+    c.close()
+
+
+@pytest.fixture(scope="module")
+def survey(ctx, orc):
+    """3 legs, features from the oracle extractor imported into the context, all pairs matched"""
+    from diasss_amd.synth import Survey
+    F, N, M = 3, 700, 480
+    sv = Survey(F, N, M, seed=31)
+    fr = []
+    for f in range(F):
+        raw = sv.frame(f).numpy()
+        pose, alt, gr = sv.inputs(f)
+        kps, desc, _, _ = orc.detect_feature(raw)
+        ctx.frame_set(f, None, N, M, pose, alt, gr)
+        ctx.features_set(f, N, M, kps, desc)
+        fr.append(dict(N=N, M=M, pose=pose, alt=alt, gr=gr, kps=kps, desc=desc, geo=orc.geo_at_kps(pose, gr, M, kps), bb=orc.geo_bbox(pose, gr, M)))
+    src = [0, 0, 1]; tgt = [1, 2, 2]
+    ctx.match_pairs(src, tgt)
+    ctx.lc_solve_all()
+    return dict(F=F, N=N, M=M, fr=fr, src=src, tgt=tgt)
+
+
+def _oracle_lc(orc, sv):
+    out = []
+    for i, j in zip(sv["src"], sv["tgt"]):
+        a, b = sv["fr"][i], sv["fr"][j]
+        rows = orc.robust_matching(i, j, a["N"], b["N"], a["kps"], a["desc"], a["geo"], a["bb"], b["kps"], b["desc"], b["geo"], b["bb"])
+        kp7 = orc.get_kps_pairs(rows, j, a["alt"], a["gr"], b["alt"], b["gr"])
+        lcs = orc.lc_solve(kp7, a["pose"], a["alt"], a["gr"], a["M"], b["pose"], b["alt"], b["gr"], b["M"])
+        out.append((kp7, lcs))
+    return out
+
+
+def test_lc_batch_parity(ctx, orc, survey):
+    ref = _oracle_lc(orc, survey)
+    total = 0
+    for p, (kp7, lcs) in enumerate(ref):
+        g = ctx.lc_get(p)
+        assert len(g) == len(lcs)
+        if not len(g):
+            continue
+        total += len(g)
+        assert (g["iters"] == lcs["iters"]).all()                       # same LM path
+        assert np.allclose(g["rel"], lcs["rel"], rtol=0, atol=1e-9)     # relative pose: 1e-9 (rad / m)
+        assert np.allclose(g["var"], lcs["var"], rtol=1e-6, atol=1e-15)
+        assert np.allclose(g["score"], lcs["score"], rtol=0, atol=1e-6)
+        assert np.allclose(g["err1"], lcs["err1"], rtol=1e-6, atol=1e-12)
+    assert total > 50
+
+
+def test_lc_standalone_and_sticky_flip(ctx, orc, survey):
+    """dsss_lc_solve with caller kp7: pair (0,1) has opposite headings so the yaw compensation (optimizer.cpp:697-703) is active"""
+    a, b = survey["fr"][0], survey["fr"][1]
+    kp7 = ctx.match_kp7(0)
+    assert len(kp7) > 5
+    g = ctx.lc_solve(0, 1, kp7)
+    o = orc.lc_solve(kp7, a["pose"], a["alt"], a["gr"], a["M"], b["pose"], b["alt"], b["gr"], b["M"])
+    assert np.allclose(g["rel"], o["rel"], rtol=0, atol=1e-9) and (g["iters"] == o["iters"]).all()
+
+
+def test_lc_selection_and_posegraph_parity(ctx, orc, survey):
+    F, N = survey["F"], survey["N"]
+    ref = _oracle_lc(orc, survey)
+    pair_off = [0]
+    for kp7, _ in ref:
+        pair_off.append(pair_off[-1] + len(kp7))
+    kp7_all = np.concatenate([r[0] for r in ref]); lcs_all = np.concatenate([r[1] for r in ref])
+    o_edges = orc.pg_select_lc([N] * F, survey["src"], survey["tgt"], pair_off, kp7_all, lcs_all)
+    g_edges = ctx.posegraph_select(F)
+    assert len(g_edges) == len(o_edges) and len(o_edges) > 10
+    assert (g_edges["a"] == o_edges["a"]).all() and (g_edges["b"] == o_edges["b"]).all()        # selection rule is exact
+    assert np.allclose(g_edges["rel"], o_edges["rel"], atol=1e-9)
+    dr = np.concatenate([f["pose"] for f in survey["fr"]])
+    o_out, o_stats = orc.pg_solve(dr, o_edges)
+    g_out, g_rpy, g_stats = ctx.posegraph_solve(F, F * N)
+    assert g_stats[0] == o_stats[0]                                                             # same number of LM iterations
+    assert np.allclose(g_stats[2], o_stats[2], rtol=1e-6)
+    assert np.abs(g_out - o_out).max() < 1e-6                                                   # north_star: poses within 1e-6
+    assert np.abs(g_rpy[:, 3:] - o_out[:, 9:]).max() < 1e-6
+
+
+def test_posegraph_edges_api_small_cases(ctx, orc):
+    """explicit chains: no LC; one LC; LC between adjacent poses (coincides with a chain coupling); long interior segments"""
+    n = 300
+    rng = np.random.default_rng(3)
+    dr = np.zeros((n, 6)); dr[:, 3] = 0.05 * np.arange(n); dr[:, 2] = 0.01 * np.sin(np.arange(n) / 30.0)
+    dr[150:, 2] += 3.14159265359; dr[150:, 4] += 5.0; dr[150:, 3] = dr[149, 3] - 0.05 * np.arange(150)
+    def edge(a, b, dy):
+        e = np.zeros(1, orc.LCEDGE_DTYPE)
+        e["a"] = a; e["b"] = b
+        Ta = orc.Pose(); Tb = orc.Pose(); Tr = orc.Pose()
+        import ctypes as C
+        orc.lib().orc_pose_from_rodrigues(orc.dp(np.ascontiguousarray(dr[a])), C.byref(Ta))
+        orc.lib().orc_pose_from_rodrigues(orc.dp(np.ascontiguousarray(dr[b])), C.byref(Tb))
+        orc.lib().orc_pose_between(C.byref(Ta), C.byref(Tb), C.byref(Tr))
+        rel = np.concatenate([np.array(Tr.R), np.array(Tr.t)]); rel[10] += dy
+        e["rel"][0] = rel; e["var"][0] = [1e-6, 1e-6, 1e-5, 1e-3, 0.5, 1e-2]
+        return e
+    cases = [np.zeros(0, orc.LCEDGE_DTYPE), edge(20, 280, 0.3), np.concatenate([edge(10, 290, 0.2), edge(60, 240, -0.1), edge(149, 150, 0.05), edge(100, 151, 0.1)])]
+    for edges in cases:
+        o_out, o_stats = orc.pg_solve(dr, edges)
+        g_out, g_stats = ctx.posegraph_solve_edges(dr, edges)
+        assert g_stats[0] == o_stats[0]
+        assert np.abs(g_out - o_out).max() < 1e-6
