@@ -579,13 +579,19 @@ static int extract_one(dsss_ctx* c, int id, int* n_out)
     HIPCHK(c, hipMemcpyAsync(d_cells, g.cells.data(), sizeof(fast_cell) * ncells, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipMemcpyAsync(d_lrows, g.rows, sizeof(int) * DSSS_MAX_LEVELS, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipMemcpyAsync(d_lscale, g.sf, sizeof(float) * DSSS_MAX_LEVELS, hipMemcpyHostToDevice, c->stream));
+    const size_t tot = (size_t)N * M;
     {   // K1
-        dsss_scope sc(c, DSSS_K_PREPROC);
+        dsss_scope sc(c, DSSS_K_ROW_REDUCE);
         hipLaunchKernelGGL(row_reduce_kernel, dim3((N + 3) / 4), dim3(256), 0, c->stream, f.raw, N, M, d_rowsum, d_rowmin);
+    }
+    {
+        dsss_scope sc(c, DSSS_K_PRE_MISC);
         hipLaunchKernelGGL(final_reduce_kernel, dim3(1), dim3(64), 0, c->stream, d_rowsum, d_rowmin, N, M, (double)(float)c->mp.factor, d_stats);
-        const size_t tot = (size_t)N * M;
         hipLaunchKernelGGL(mask_init_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, c->stream, f.mask, N, M, c->mp.width, c->mp.side,
                            (double)c->mp.side * 0.6);
+    }
+    {
+        dsss_scope sc(c, DSSS_K_NORMALIZE);
         hipLaunchKernelGGL(normalize_kernel, dim3((unsigned)((tot / 4 + 256) / 256)), dim3(256), 0, c->stream, f.raw, N, M, d_stats, c->mp.r,
                            f.lvl[0], f.mask);
         HIPCHK(c, hipGetLastError());
@@ -602,8 +608,9 @@ static int extract_one(dsss_ctx* c, int id, int* n_out)
         HIPCHK(c, hipGetLastError());
     }
     {   // K3
-        dsss_scope sc(c, DSSS_K_FAST);
-        hipLaunchKernelGGL(fast_cells_kernel, dim3(ncells), dim3(256), 0, c->stream, d_cells, lv, c->op.ini_th, c->op.min_th, d_cand, d_counts);
+        { dsss_scope sc(c, DSSS_K_FAST);
+          hipLaunchKernelGGL(fast_cells_kernel, dim3(ncells), dim3(256), 0, c->stream, d_cells, lv, c->op.ini_th, c->op.min_th, d_cand, d_counts); }
+        dsss_scope sc(c, DSSS_K_FAST_COMPACT);
         hipLaunchKernelGGL(scan_counts_kernel, dim3(1), dim3(256), 0, c->stream, d_counts, ncells, d_offs);
         hipLaunchKernelGGL(gather_cand_kernel, dim3(ncells), dim3(64), 0, c->stream, d_cells, d_cand, d_counts, d_offs, d_xs, d_ys, d_rs, L.cand_cap);
         HIPCHK(c, hipGetLastError());
@@ -634,9 +641,10 @@ static int extract_one(dsss_ctx* c, int id, int* n_out)
     }
     int* d_count = c->nkp_dev + id;
     if (nk > 0) {
-        dsss_scope sc(c, DSSS_K_DESC);
         HIPCHK(c, hipMemcpyAsync(d_kin, h_kin, sizeof(kp_in) * nk, hipMemcpyHostToDevice, c->stream));
-        hipLaunchKernelGGL(orient_desc_kernel, dim3((nk + 3) / 4), dim3(256), 0, c->stream, d_kin, nk, lv, d_lrows, d_lscale, d_kptmp, d_dtmp);
+        { dsss_scope sc(c, DSSS_K_DESC);
+          hipLaunchKernelGGL(orient_desc_kernel, dim3((nk + 3) / 4), dim3(256), 0, c->stream, d_kin, nk, lv, d_lrows, d_lscale, d_kptmp, d_dtmp); }
+        dsss_scope sc(c, DSSS_K_FILTER);
         hipLaunchKernelGGL(mask_filter_kernel, dim3(1), dim3(256), 0, c->stream, d_kptmp, d_dtmp, nk, f.mask, M, f.pose6, f.gr,
                            c->kps + (size_t)id * c->kcap, c->desc + (size_t)id * c->kcap * 32, c->geo + (size_t)id * c->kcap * 2, d_count);
         HIPCHK(c, hipGetLastError());

@@ -411,6 +411,9 @@ int dsss_match_pairs(dsss_ctx* c, const int* src_ids, const int* tgt_ids, int np
         hipLaunchKernelGGL(scc_kernel, dim3(2 * na), dim3(256), sh, c->stream, c->act_s, c->act_t, c->nkp_dev, c->rows_dev, c->kps, (int)K,
                            d_raw, iters, c->mt.pix_err, c->corres_nn, c->corres, c->scc_hist, c->scc_count, c->scc_model);
         HIPCHK(c, hipGetLastError());
+    }
+    {
+        dsss_scope sc(c, DSSS_K_ROWS);
         hipLaunchKernelGGL(pair_rows_kernel<false>, dim3(na), dim3(256), 0, c->stream, c->act_s, c->act_t, c->nkp_dev, c->rows_dev, c->cols_dev,
                            c->kps, (int)K, c->corres, c->scc_hist, c->scc_model, c->mt.merge_thr, d_ptrs, d_ptrs + F, d_ptrs + 2 * F,
                            c->row_cnt, c->kp7_cnt, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
@@ -431,7 +434,7 @@ int dsss_match_pairs(dsss_ctx* c, const int* src_ids, const int* tgt_ids, int np
         HIPCHK(c, hipMalloc(&c->kp7_flip, c->rows_cap));
     }
     if (c->total_rows > 0) {
-        dsss_scope sc(c, DSSS_K_SCC);
+        dsss_scope sc(c, DSSS_K_ROWS);
         hipLaunchKernelGGL(pair_rows_kernel<true>, dim3(na), dim3(256), 0, c->stream, c->act_s, c->act_t, c->nkp_dev, c->rows_dev, c->cols_dev,
                            c->kps, (int)K, c->corres, c->scc_hist, c->scc_model, c->mt.merge_thr, d_ptrs, d_ptrs + F, d_ptrs + 2 * F,
                            c->row_cnt, c->kp7_cnt, c->row_off, c->kp7_off, c->rows6, c->kp7, c->kp7_pair, c->kp7_flip);

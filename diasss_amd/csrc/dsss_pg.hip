@@ -18,6 +18,7 @@
 #include <algorithm>
 #include <numeric>
 #include <random>
+#include <cstdlib>
 
 // ------------------------------------------------------------------ small dense helpers (6x6 row-major)
 __device__ inline int chol6(double* A)
@@ -277,44 +278,72 @@ __global__ __launch_bounds__(256) void pg_scatter_lc_kernel(int n, int ne, const
 // ---- sparse block Cholesky, left-looking, one workgroup per column of the current elimination-tree level.
 // Column j holds blocks L(i, j), i in rowidx[colptr[j] .. colptr[j+1]) ascending, first the diagonal.
 // rowlist(j) = columns k < j with L(j, k) != 0 and the position of that block.
-__global__ __launch_bounds__(256) void pg_factor_level_kernel(const int* __restrict__ lvcols, const int* __restrict__ colptr,
-                                                              const int* __restrict__ rowidx, const int* __restrict__ rlptr,
-                                                              const int* __restrict__ rlcol, const int* __restrict__ rlpos,
-                                                              double* __restrict__ Lvals, int* __restrict__ fail)
+// upd_map (built once per solve by pg_build_map_kernel): for update t of column j and target block q the position of
+// L(i_q, k_t) or -1; layout [mapptr[j] + t * m_j + q], so the factor kernel has no dependent index search.
+__global__ __launch_bounds__(256) void pg_build_map_kernel(int nupd, const int* __restrict__ rlrow, const int* __restrict__ rlptr,
+                                                           const int* __restrict__ rlcol, const int* __restrict__ rlpos,
+                                                           const int* __restrict__ colptr, const int* __restrict__ rowidx,
+                                                           const long long* __restrict__ mapptr, int* __restrict__ upd_map)
 {
-    __shared__ double s_Ljk[36];
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= nupd) return;
+    const int j = rlrow[e], k = rlcol[e];
+    const int c0 = colptr[j], m = colptr[j + 1] - c0;
+    int* mp = upd_map + mapptr[j] + (long long)(e - rlptr[j]) * m;
+    int q = 0;
+    for (int p = rlpos[e]; p < colptr[k + 1]; ++p) {           // rows of column k from row j downwards: a subset of column j's rows
+        const int i = rowidx[p];
+        while (q < m && rowidx[c0 + q] < i) ++q;
+        if (q < m && rowidx[c0 + q] == i) mp[q] = p;
+    }
+}
+
+#define PG_TCH 128
+// accumulate A(i,j) - sum_k L(i,k) L(j,k)^T: grid (columns of the level, 256-row chunks of the column)
+__global__ __launch_bounds__(256) void pg_factor_acc_kernel(const int* __restrict__ lvcols, const int* __restrict__ colptr,
+                                                            const int* __restrict__ rlptr, const int* __restrict__ rlpos,
+                                                            const long long* __restrict__ mapptr, const int* __restrict__ upd_map,
+                                                            double* __restrict__ Lvals)
+{
+    __shared__ double s_Ljk[PG_TCH * 36];
+    const int j = lvcols[blockIdx.x];
+    const int c0 = colptr[j], m = colptr[j + 1] - c0;
+    if ((int)blockIdx.y * 256 >= 6 * m) return;
+    const int t0 = rlptr[j], T = rlptr[j + 1] - t0;
+    if (T == 0) return;
+    const int* mp = upd_map + mapptr[j];
+    const int idx = blockIdx.y * 256 + threadIdx.x;
+    const bool act = idx < 6 * m;
+    const int q = act ? idx / 6 : 0, r = idx - q * 6;
+    double acc[6];
+    if (act) for (int s = 0; s < 6; ++s) acc[s] = Lvals[(size_t)(c0 + q) * 36 + r * 6 + s];
+    for (int tc = 0; tc < T; tc += PG_TCH) {
+        const int tn = min(PG_TCH, T - tc);
+        __syncthreads();
+        for (int x = threadIdx.x; x < tn * 36; x += 256) s_Ljk[x] = Lvals[(size_t)rlpos[t0 + tc + x / 36] * 36 + (x % 36)];
+        __syncthreads();
+        if (act)
+            for (int t = 0; t < tn; ++t) {
+                const int pos = mp[(size_t)(tc + t) * m + q];
+                if (pos < 0) continue;
+                const double* Lik = Lvals + (size_t)pos * 36 + r * 6;
+                const double* B = s_Ljk + t * 36;
+                const double a0 = Lik[0], a1 = Lik[1], a2 = Lik[2], a3 = Lik[3], a4 = Lik[4], a5 = Lik[5];
+#pragma unroll
+                for (int s = 0; s < 6; ++s)
+                    acc[s] -= a0 * B[s * 6] + a1 * B[s * 6 + 1] + a2 * B[s * 6 + 2] + a3 * B[s * 6 + 3] + a4 * B[s * 6 + 4] + a5 * B[s * 6 + 5];
+            }
+    }
+    if (act) for (int s = 0; s < 6; ++s) Lvals[(size_t)(c0 + q) * 36 + r * 6 + s] = acc[s];
+}
+// diagonal block Cholesky, then L(i, j) = A(i, j) L_jj^-T (forward substitution along each row)
+__global__ __launch_bounds__(256) void pg_factor_fin_kernel(const int* __restrict__ lvcols, const int* __restrict__ colptr,
+                                                            double* __restrict__ Lvals, int* __restrict__ fail)
+{
     __shared__ double s_diag[36];
     __shared__ int s_ok;
     const int j = lvcols[blockIdx.x];
     const int c0 = colptr[j], m = colptr[j + 1] - c0;
-    const int t0 = rlptr[j], t1 = rlptr[j + 1];
-    // accumulate: thread per (target block q, block row r)
-    for (int base = 0; base < 6 * m; base += 256) {
-        const int idx = base + threadIdx.x;
-        const bool act = idx < 6 * m;
-        const int q = act ? idx / 6 : 0, r = idx - q * 6;
-        const int irow = rowidx[c0 + q];
-        double acc[6];
-        if (act) for (int s = 0; s < 6; ++s) acc[s] = Lvals[(size_t)(c0 + q) * 36 + r * 6 + s];
-        for (int t = t0; t < t1; ++t) {
-            const int k = rlcol[t];
-            __syncthreads();
-            if (threadIdx.x < 36) s_Ljk[threadIdx.x] = Lvals[(size_t)rlpos[t] * 36 + threadIdx.x];
-            __syncthreads();
-            if (!act) continue;
-            // find row irow in column k (rows > k ascending): binary search
-            int lo = colptr[k] + 1, hi = colptr[k + 1] - 1, pos = -1;
-            while (lo <= hi) { const int mid = (lo + hi) >> 1; const int v = rowidx[mid]; if (v == irow) { pos = mid; break; } if (v < irow) lo = mid + 1; else hi = mid - 1; }
-            if (pos < 0) continue;
-            const double* Lik = Lvals + (size_t)pos * 36 + r * 6;
-            const double a0 = Lik[0], a1 = Lik[1], a2 = Lik[2], a3 = Lik[3], a4 = Lik[4], a5 = Lik[5];
-#pragma unroll
-            for (int s = 0; s < 6; ++s)
-                acc[s] -= a0 * s_Ljk[s * 6] + a1 * s_Ljk[s * 6 + 1] + a2 * s_Ljk[s * 6 + 2] + a3 * s_Ljk[s * 6 + 3] + a4 * s_Ljk[s * 6 + 4] + a5 * s_Ljk[s * 6 + 5];
-        }
-        if (act) for (int s = 0; s < 6; ++s) Lvals[(size_t)(c0 + q) * 36 + r * 6 + s] = acc[s];
-    }
-    __syncthreads();
     if (threadIdx.x == 0) {
         double A[36];
         for (int a = 0; a < 36; ++a) A[a] = Lvals[(size_t)c0 * 36 + a];
@@ -325,7 +354,6 @@ __global__ __launch_bounds__(256) void pg_factor_level_kernel(const int* __restr
     }
     __syncthreads();
     if (!s_ok) return;
-    // L(i, j) = A(i, j) L_jj^-T : forward substitution along each row
     for (int idx = 6 + threadIdx.x; idx < 6 * m; idx += 256) {
         double* row = Lvals + (size_t)(c0 + idx / 6) * 36 + (idx % 6) * 6;
         double x[6];
@@ -448,7 +476,8 @@ namespace {
 struct sym_t {
     int ns = 0;
     std::vector<int> perm;                 // chain-order separator -> elimination index
-    std::vector<int> colptr, rowidx, rlptr, rlcol, rlpos, lvptr, lvcols, diag_pos, ch_pos, lc_pos;
+    std::vector<int> colptr, rowidx, rlptr, rlcol, rlpos, rlrow, lvptr, lvcols, diag_pos, ch_pos, lc_pos;
+    std::vector<long long> mapptr;
 };
 
 // geometric nested dissection: recursive coordinate bisection with vertex separators taken from the lower half
@@ -523,6 +552,12 @@ void symbolic(int ns, const std::vector<std::pair<int, int>>& edges, int nchain,
     S.rlcol.resize(S.rlptr[ns]); S.rlpos.resize(S.rlptr[ns]);
     { std::vector<int> fill(S.rlptr.begin(), S.rlptr.end() - 1);
       for (int k = 0; k < ns; ++k) for (size_t q = 1; q < cols[k].size(); ++q) { const int j = cols[k][q]; S.rlcol[fill[j]] = k; S.rlpos[fill[j]] = S.colptr[k] + (int)q; fill[j]++; } }
+    S.rlrow.resize(S.rlptr[ns]);
+    S.mapptr.assign(ns + 1, 0);
+    for (int j = 0; j < ns; ++j) {
+        for (int t = S.rlptr[j]; t < S.rlptr[j + 1]; ++t) S.rlrow[t] = j;
+        S.mapptr[j + 1] = S.mapptr[j] + (long long)(S.rlptr[j + 1] - S.rlptr[j]) * (long long)cols[j].size();
+    }
     // levels of the elimination tree
     std::vector<int> level(ns, 0);
     int maxl = 0;
@@ -605,6 +640,11 @@ static int pg_solve_impl(dsss_ctx* c, const double* dr6, int total, const dsss_l
     std::vector<char> is_sep(n, 0);
     is_sep[0] = 1; is_sep[n - 1] = 1;
     for (int e = 0; e < ne; ++e) { is_sep[ea[e]] = 1; is_sep[eb[e]] = 1; }
+    // bound the sequential depth of the per-segment block-Thomas recursion: every PG_CHUNK-th pose is promoted to a
+    // separator as well (exact: it only moves that pose from the chain elimination into the sparse factorisation,
+    // where a pose with two chain neighbours costs O(1) fill)
+    { const char* ev = getenv("DSSS_PG_CHUNK"); const int chunk = ev ? std::max(2, atoi(ev)) : 16;
+      for (int i = 0; i < n; i += chunk) is_sep[i] = 1; }
     std::vector<int> sep_pose, sidx(n, -1);
     for (int i = 0; i < n; ++i) if (is_sep[i]) { sidx[i] = (int)sep_pose.size(); sep_pose.push_back(i); }
     const int ns = (int)sep_pose.size(), nseg = ns - 1;
@@ -617,13 +657,25 @@ static int pg_solve_impl(dsss_ctx* c, const double* dr6, int total, const dsss_l
     symbolic(ns, redges, nseg, cx, cy, true, S);
     const int nlev = (int)S.lvptr.size() - 1;
     const size_t nnzL = S.rowidx.size();
+    std::vector<int> lv_chunks(nlev, 1), lv_upd(nlev, 0);
+    for (int l = 0; l < nlev; ++l)
+        for (int q = S.lvptr[l]; q < S.lvptr[l + 1]; ++q) {
+            const int j = S.lvcols[q];
+            lv_chunks[l] = std::max(lv_chunks[l], (6 * (S.colptr[j + 1] - S.colptr[j]) + 255) / 256);
+            if (S.rlptr[j + 1] > S.rlptr[j]) lv_upd[l] = 1;
+        }
+    const bool verbose = getenv("DSSS_PG_VERBOSE") != nullptr;
+    if (verbose) {
+        int maxcol = 0; for (int j = 0; j < ns; ++j) maxcol = std::max(maxcol, S.colptr[j + 1] - S.colptr[j]);
+        fprintf(stderr, "[dsss pg] poses %d  LC edges %d  separators %d  nnz(L) blocks %zu  etree levels %d  max column %d blocks  update map %lld\n", n, ne, ns, nnzL, nlev, maxcol, S.mapptr[ns]);
+    }
 
     // device state
     pg_dev dv;
     int rc = DSSS_OK;
     pose_t *d_X, *d_Xn, *d_meas, *d_emeas; int *d_ea, *d_eb, *d_adj_ptr, *d_adj_edge, *d_sep, *d_perm;
     double *d_ew, *d_r, *d_Ji, *d_D, *d_C, *d_g, *d_delta, *d_E, *d_Dl, *d_gi, *d_sDL, *d_sDR, *d_sGL, *d_sGR, *d_sS, *d_L, *d_x, *d_part, *d_scal;
-    int *d_colptr, *d_rowidx, *d_rlptr, *d_rlcol, *d_rlpos, *d_lvcols, *d_diag, *d_ch, *d_lc, *d_fail;
+    int *d_colptr, *d_rowidx, *d_rlptr, *d_rlcol, *d_rlpos, *d_rlrow, *d_lvcols, *d_diag, *d_ch, *d_lc, *d_fail, *d_map; long long* d_mapptr;
     const int nf = n + ne, nblk = (nf + 255) / 256;
 #define TRY(x) do { rc = (x); if (rc) { dv.release(); return rc; } } while (0)
     TRY(dv.upload(c, &d_X, X0)); TRY(dv.alloc(c, &d_Xn, n)); TRY(dv.upload(c, &d_meas, meas)); TRY(dv.upload(c, &d_emeas, emeas));
@@ -637,6 +689,10 @@ static int pg_solve_impl(dsss_ctx* c, const double* dr6, int total, const dsss_l
     TRY(dv.alloc(c, &d_L, nnzL * 36)); TRY(dv.alloc(c, &d_x, (size_t)ns * 6)); TRY(dv.alloc(c, &d_part, (size_t)nblk)); TRY(dv.alloc(c, &d_scal, 4)); TRY(dv.alloc(c, &d_fail, 1));
     TRY(dv.upload(c, &d_colptr, S.colptr)); TRY(dv.upload(c, &d_rowidx, S.rowidx)); TRY(dv.upload(c, &d_rlptr, S.rlptr)); TRY(dv.upload(c, &d_rlcol, S.rlcol));
     TRY(dv.upload(c, &d_rlpos, S.rlpos)); TRY(dv.upload(c, &d_lvcols, S.lvcols)); TRY(dv.upload(c, &d_diag, S.diag_pos)); TRY(dv.upload(c, &d_ch, S.ch_pos)); TRY(dv.upload(c, &d_lc, S.lc_pos));
+    TRY(dv.upload(c, &d_rlrow, S.rlrow)); TRY(dv.upload(c, &d_mapptr, S.mapptr));
+    const long long mapsz = S.mapptr[ns];
+    if (mapsz > (1LL << 31)) { dv.release(); DSSS_FAIL(c, DSSS_E_CAPACITY, "update map of %lld entries", mapsz); }
+    TRY(dv.alloc(c, &d_map, (size_t)mapsz));
     hipStream_t st = c->stream;
 #define HCK(x) do { hipError_t _e = (x); if (_e != hipSuccess) { c->err = std::string(#x) + ": " + hipGetErrorString(_e); dv.release(); return DSSS_E_HIP; } } while (0)
     auto error_of = [&](const pose_t* Xd, double* out) -> int {
@@ -646,6 +702,9 @@ static int pg_solve_impl(dsss_ctx* c, const double* dr6, int total, const dsss_l
         HCK(hipStreamSynchronize(st));
         return DSSS_OK;
     };
+    HCK(hipMemsetAsync(d_map, 0xff, (size_t)std::max<long long>(mapsz, 1) * sizeof(int), st));
+    { const int nupd = (int)S.rlcol.size();
+      if (nupd > 0) hipLaunchKernelGGL(pg_build_map_kernel, dim3((nupd + 255) / 256), dim3(256), 0, st, nupd, d_rlrow, d_rlptr, d_rlcol, d_rlpos, d_colptr, d_rowidx, d_mapptr, d_map); }
     dsss_scope sc(c, DSSS_K_PG);
     double lambda = c->pg.lambda0, err = 0, err0 = 0, cur = 0;
     int iters = 0, nfact = 0;
@@ -665,8 +724,11 @@ static int pg_solve_impl(dsss_ctx* c, const double* dr6, int total, const dsss_l
             hipLaunchKernelGGL(pg_segment_kernel, dim3((nseg + 63) / 64), dim3(64), 0, st, nseg, d_sep, d_D, d_C, d_g, d_E, d_Dl, d_gi, d_sDL, d_sDR, d_sGL, d_sGR, d_sS, d_fail);
             hipLaunchKernelGGL(pg_scatter_base_kernel, dim3((ns + 255) / 256), dim3(256), 0, st, ns, d_sep, d_perm, d_D, d_g, d_sDL, d_sDR, d_sGL, d_sGR, d_sS, d_diag, d_ch, d_L, d_x);
             if (ne > 0) hipLaunchKernelGGL(pg_scatter_lc_kernel, dim3((ne + 255) / 256), dim3(256), 0, st, n, ne, d_Ji, d_ew, d_lc, d_L);
-            for (int l = 0; l < nlev; ++l)
-                hipLaunchKernelGGL(pg_factor_level_kernel, dim3(S.lvptr[l + 1] - S.lvptr[l]), dim3(256), 0, st, d_lvcols + S.lvptr[l], d_colptr, d_rowidx, d_rlptr, d_rlcol, d_rlpos, d_L, d_fail);
+            for (int l = 0; l < nlev; ++l) {
+                const int ncl = S.lvptr[l + 1] - S.lvptr[l];
+                if (lv_upd[l]) hipLaunchKernelGGL(pg_factor_acc_kernel, dim3(ncl, lv_chunks[l]), dim3(256), 0, st, d_lvcols + S.lvptr[l], d_colptr, d_rlptr, d_rlpos, d_mapptr, d_map, d_L);
+                hipLaunchKernelGGL(pg_factor_fin_kernel, dim3(ncl), dim3(256), 0, st, d_lvcols + S.lvptr[l], d_colptr, d_L, d_fail);
+            }
             ++nfact;
             for (int l = 0; l < nlev; ++l)
                 hipLaunchKernelGGL(pg_fwd_level_kernel, dim3(S.lvptr[l + 1] - S.lvptr[l]), dim3(64), 0, st, d_lvcols + S.lvptr[l], d_colptr, d_rlptr, d_rlcol, d_rlpos, d_L, d_x);
@@ -708,7 +770,7 @@ static int pg_solve_impl(dsss_ctx* c, const double* dr6, int total, const dsss_l
     }
     if (stats4) { stats4[0] = iters; stats4[1] = err0; stats4[2] = err; stats4[3] = lambda; }
     dv.release();
-    (void)nfact;
+    if (verbose) fprintf(stderr, "[dsss pg] LM iterations %d  factorisations %d  err %.6g -> %.6g\n", iters, nfact, err0, err);
 #undef TRY
 #undef HCK
     return DSSS_OK;

@@ -135,15 +135,20 @@ int dsss_posegraph_solve_edges(dsss_ctx*, const double* dr6, int total, const ds
 
 /* ------------------------------------------------------------------ instrumentation
  * accumulated GPU time (ms, HIP events on the context stream) and launch count per kernel family        */
-#define DSSS_K_PREPROC 0
-#define DSSS_K_PYRAMID 1
-#define DSSS_K_FAST    2
-#define DSSS_K_DESC    3
-#define DSSS_K_MATCH   4
-#define DSSS_K_SCC     5
-#define DSSS_K_LC      6
-#define DSSS_K_PG      7
-#define DSSS_K_COUNT   8
+#define DSSS_K_ROW_REDUCE   0   /* row_reduce_kernel: one f64 read of the waterfall */
+#define DSSS_K_PRE_MISC     1   /* final_reduce + mask_init */
+#define DSSS_K_NORMALIZE    2   /* normalize_kernel: f64 read, u8 write, hot-pixel scatter */
+#define DSSS_K_PYRAMID      3   /* resize_kernel x (nlevels-1) */
+#define DSSS_K_FAST         4   /* fast_cells_kernel */
+#define DSSS_K_FAST_COMPACT 5   /* scan + gather of candidates */
+#define DSSS_K_DESC         6   /* orient_desc_kernel */
+#define DSSS_K_FILTER       7   /* mask_filter_kernel */
+#define DSSS_K_MATCH        8   /* match_nn_kernel */
+#define DSSS_K_SCC          9   /* scc_kernel */
+#define DSSS_K_ROWS        10   /* pair_rows count/scan/write */
+#define DSSS_K_LC          11   /* lc_kernel */
+#define DSSS_K_PG          12   /* pose-graph LM loop (all its kernels) */
+#define DSSS_K_COUNT       16
 int dsss_profile_enable(dsss_ctx*, int on);
 int dsss_profile_get(dsss_ctx*, double* ms_host /*DSSS_K_COUNT*/, int64_t* launches_host /*DSSS_K_COUNT*/);
 int dsss_profile_reset(dsss_ctx*);
