@@ -299,26 +299,29 @@ __global__ __launch_bounds__(256) void pg_build_map_kernel(int nupd, const int* 
 }
 
 #define PG_TCH 128
-// accumulate A(i,j) - sum_k L(i,k) L(j,k)^T: grid (columns of the level, 256-row chunks of the column)
+// accumulate sum_k L(i,k) L(j,k)^T for a slice of the update list: grid (columns of the level, 256-row chunks of the
+// column, slices of the update list).  With one slice the result is subtracted from A(i,j) in place; with several
+// slices each writes its partial sum to `part` and pg_factor_fin_kernel subtracts them in slice order (deterministic).
 __global__ __launch_bounds__(256) void pg_factor_acc_kernel(const int* __restrict__ lvcols, const int* __restrict__ colptr,
                                                             const int* __restrict__ rlptr, const int* __restrict__ rlpos,
                                                             const long long* __restrict__ mapptr, const int* __restrict__ upd_map,
-                                                            double* __restrict__ Lvals)
+                                                            double* __restrict__ Lvals, double* __restrict__ part, int col_stride)
 {
     __shared__ double s_Ljk[PG_TCH * 36];
     const int j = lvcols[blockIdx.x];
     const int c0 = colptr[j], m = colptr[j + 1] - c0;
     if ((int)blockIdx.y * 256 >= 6 * m) return;
     const int t0 = rlptr[j], T = rlptr[j + 1] - t0;
-    if (T == 0) return;
+    const int nsl = gridDim.z, sl = blockIdx.z;
+    const int per = (T + nsl - 1) / nsl;
+    const int ta = sl * per, tb = min(T, ta + per);
     const int* mp = upd_map + mapptr[j];
     const int idx = blockIdx.y * 256 + threadIdx.x;
     const bool act = idx < 6 * m;
     const int q = act ? idx / 6 : 0, r = idx - q * 6;
-    double acc[6];
-    if (act) for (int s = 0; s < 6; ++s) acc[s] = Lvals[(size_t)(c0 + q) * 36 + r * 6 + s];
-    for (int tc = 0; tc < T; tc += PG_TCH) {
-        const int tn = min(PG_TCH, T - tc);
+    double acc[6] = { 0, 0, 0, 0, 0, 0 };
+    for (int tc = ta; tc < tb; tc += PG_TCH) {
+        const int tn = min(PG_TCH, tb - tc);
         __syncthreads();
         for (int x = threadIdx.x; x < tn * 36; x += 256) s_Ljk[x] = Lvals[(size_t)rlpos[t0 + tc + x / 36] * 36 + (x % 36)];
         __syncthreads();
@@ -331,19 +334,35 @@ __global__ __launch_bounds__(256) void pg_factor_acc_kernel(const int* __restric
                 const double a0 = Lik[0], a1 = Lik[1], a2 = Lik[2], a3 = Lik[3], a4 = Lik[4], a5 = Lik[5];
 #pragma unroll
                 for (int s = 0; s < 6; ++s)
-                    acc[s] -= a0 * B[s * 6] + a1 * B[s * 6 + 1] + a2 * B[s * 6 + 2] + a3 * B[s * 6 + 3] + a4 * B[s * 6 + 4] + a5 * B[s * 6 + 5];
+                    acc[s] += a0 * B[s * 6] + a1 * B[s * 6 + 1] + a2 * B[s * 6 + 2] + a3 * B[s * 6 + 3] + a4 * B[s * 6 + 4] + a5 * B[s * 6 + 5];
             }
     }
-    if (act) for (int s = 0; s < 6; ++s) Lvals[(size_t)(c0 + q) * 36 + r * 6 + s] = acc[s];
+    if (!act) return;
+    if (nsl == 1) { for (int s = 0; s < 6; ++s) Lvals[(size_t)(c0 + q) * 36 + r * 6 + s] -= acc[s]; }
+    else { double* o = part + ((size_t)blockIdx.x * nsl + sl) * col_stride + (size_t)idx * 6; for (int s = 0; s < 6; ++s) o[s] = acc[s]; }
 }
-// diagonal block Cholesky, then L(i, j) = A(i, j) L_jj^-T (forward substitution along each row)
+// (fold the partial sums,) factor the diagonal block, then L(i, j) = A(i, j) L_jj^-T along each row
 __global__ __launch_bounds__(256) void pg_factor_fin_kernel(const int* __restrict__ lvcols, const int* __restrict__ colptr,
-                                                            double* __restrict__ Lvals, int* __restrict__ fail)
+                                                            double* __restrict__ Lvals, const double* __restrict__ part, int nsl,
+                                                            int col_stride, int* __restrict__ fail)
 {
     __shared__ double s_diag[36];
     __shared__ int s_ok;
     const int j = lvcols[blockIdx.x];
     const int c0 = colptr[j], m = colptr[j + 1] - c0;
+    if (nsl > 1) {
+        for (int idx = threadIdx.x; idx < 6 * m; idx += 256) {
+            double* row = Lvals + (size_t)c0 * 36 + (size_t)idx * 6;
+            double v[6];
+            for (int s = 0; s < 6; ++s) v[s] = row[s];
+            for (int sl = 0; sl < nsl; ++sl) {
+                const double* o = part + ((size_t)blockIdx.x * nsl + sl) * col_stride + (size_t)idx * 6;
+                for (int s = 0; s < 6; ++s) v[s] -= o[s];
+            }
+            for (int s = 0; s < 6; ++s) row[s] = v[s];
+        }
+        __syncthreads();
+    }
     if (threadIdx.x == 0) {
         double A[36];
         for (int a = 0; a < 36; ++a) A[a] = Lvals[(size_t)c0 * 36 + a];
@@ -657,13 +676,21 @@ static int pg_solve_impl(dsss_ctx* c, const double* dr6, int total, const dsss_l
     symbolic(ns, redges, nseg, cx, cy, true, S);
     const int nlev = (int)S.lvptr.size() - 1;
     const size_t nnzL = S.rowidx.size();
-    std::vector<int> lv_chunks(nlev, 1), lv_upd(nlev, 0);
-    for (int l = 0; l < nlev; ++l)
+    std::vector<int> lv_chunks(nlev, 1), lv_upd(nlev, 0), lv_slices(nlev, 1);
+    size_t part2_doubles = 1;
+    for (int l = 0; l < nlev; ++l) {
+        int maxT = 0;
         for (int q = S.lvptr[l]; q < S.lvptr[l + 1]; ++q) {
             const int j = S.lvcols[q];
             lv_chunks[l] = std::max(lv_chunks[l], (6 * (S.colptr[j + 1] - S.colptr[j]) + 255) / 256);
-            if (S.rlptr[j + 1] > S.rlptr[j]) lv_upd[l] = 1;
+            maxT = std::max(maxT, S.rlptr[j + 1] - S.rlptr[j]);
         }
+        lv_upd[l] = maxT > 0;
+        const int ncl = S.lvptr[l + 1] - S.lvptr[l];
+        // few wide columns near the root: slice their update lists over more workgroups
+        if (ncl <= 64 && maxT > 48) lv_slices[l] = std::min(16, (maxT + 31) / 32);
+        if (lv_slices[l] > 1) part2_doubles = std::max(part2_doubles, (size_t)ncl * lv_slices[l] * lv_chunks[l] * 256 * 6);
+    }
     const bool verbose = getenv("DSSS_PG_VERBOSE") != nullptr;
     if (verbose) {
         int maxcol = 0; for (int j = 0; j < ns; ++j) maxcol = std::max(maxcol, S.colptr[j + 1] - S.colptr[j]);
@@ -674,7 +701,7 @@ static int pg_solve_impl(dsss_ctx* c, const double* dr6, int total, const dsss_l
     pg_dev dv;
     int rc = DSSS_OK;
     pose_t *d_X, *d_Xn, *d_meas, *d_emeas; int *d_ea, *d_eb, *d_adj_ptr, *d_adj_edge, *d_sep, *d_perm;
-    double *d_ew, *d_r, *d_Ji, *d_D, *d_C, *d_g, *d_delta, *d_E, *d_Dl, *d_gi, *d_sDL, *d_sDR, *d_sGL, *d_sGR, *d_sS, *d_L, *d_x, *d_part, *d_scal;
+    double *d_ew, *d_r, *d_Ji, *d_D, *d_C, *d_g, *d_delta, *d_E, *d_Dl, *d_gi, *d_sDL, *d_sDR, *d_sGL, *d_sGR, *d_sS, *d_L, *d_x, *d_part, *d_scal, *d_part2;
     int *d_colptr, *d_rowidx, *d_rlptr, *d_rlcol, *d_rlpos, *d_rlrow, *d_lvcols, *d_diag, *d_ch, *d_lc, *d_fail, *d_map; long long* d_mapptr;
     const int nf = n + ne, nblk = (nf + 255) / 256;
 #define TRY(x) do { rc = (x); if (rc) { dv.release(); return rc; } } while (0)
@@ -692,7 +719,7 @@ static int pg_solve_impl(dsss_ctx* c, const double* dr6, int total, const dsss_l
     TRY(dv.upload(c, &d_rlrow, S.rlrow)); TRY(dv.upload(c, &d_mapptr, S.mapptr));
     const long long mapsz = S.mapptr[ns];
     if (mapsz > (1LL << 31)) { dv.release(); DSSS_FAIL(c, DSSS_E_CAPACITY, "update map of %lld entries", mapsz); }
-    TRY(dv.alloc(c, &d_map, (size_t)mapsz));
+    TRY(dv.alloc(c, &d_map, (size_t)mapsz)); TRY(dv.alloc(c, &d_part2, part2_doubles));
     hipStream_t st = c->stream;
 #define HCK(x) do { hipError_t _e = (x); if (_e != hipSuccess) { c->err = std::string(#x) + ": " + hipGetErrorString(_e); dv.release(); return DSSS_E_HIP; } } while (0)
     auto error_of = [&](const pose_t* Xd, double* out) -> int {
@@ -726,8 +753,10 @@ static int pg_solve_impl(dsss_ctx* c, const double* dr6, int total, const dsss_l
             if (ne > 0) hipLaunchKernelGGL(pg_scatter_lc_kernel, dim3((ne + 255) / 256), dim3(256), 0, st, n, ne, d_Ji, d_ew, d_lc, d_L);
             for (int l = 0; l < nlev; ++l) {
                 const int ncl = S.lvptr[l + 1] - S.lvptr[l];
-                if (lv_upd[l]) hipLaunchKernelGGL(pg_factor_acc_kernel, dim3(ncl, lv_chunks[l]), dim3(256), 0, st, d_lvcols + S.lvptr[l], d_colptr, d_rlptr, d_rlpos, d_mapptr, d_map, d_L);
-                hipLaunchKernelGGL(pg_factor_fin_kernel, dim3(ncl), dim3(256), 0, st, d_lvcols + S.lvptr[l], d_colptr, d_L, d_fail);
+                const int stride = lv_chunks[l] * 256 * 6;
+                if (lv_upd[l]) hipLaunchKernelGGL(pg_factor_acc_kernel, dim3(ncl, lv_chunks[l], lv_slices[l]), dim3(256), 0, st, d_lvcols + S.lvptr[l], d_colptr, d_rlptr, d_rlpos,
+                                                  d_mapptr, d_map, d_L, d_part2, stride);
+                hipLaunchKernelGGL(pg_factor_fin_kernel, dim3(ncl), dim3(256), 0, st, d_lvcols + S.lvptr[l], d_colptr, d_L, d_part2, lv_upd[l] ? lv_slices[l] : 1, stride, d_fail);
             }
             ++nfact;
             for (int l = 0; l < nlev; ++l)

@@ -1,0 +1,51 @@
+// diasss_amd/host/frame.cpp -- Diasss::Frame over the C ABI (mirrors /root/reference/src/core/frame.cpp:18-55)
+#include "frame.h"
+#include "dsss_device.h"
+
+namespace Diasss
+{
+
+Frame::Frame(const int &id, const cv::Mat &mImg, const cv::Mat &mPose, const std::vector<double> &vAltt,
+             const std::vector<double> &vGrange, const cv::Mat &mAnno)
+{
+    raw_img = mImg; dr_poses = mPose; altitudes = vAltt; ground_ranges = vGrange; img_id = id; anno_kps = mAnno;
+    tf_stb = {0, 0, 0}; tf_port = {0, 0, 0};                                  // frame.cpp:38-39
+    dsss_ctx* c = Device::ctx();
+    Device::check(dsss_frame_set(c, id, mImg.ptr<double>(), mImg.rows, mImg.cols, mPose.ptr<double>(), vAltt.data(), vGrange.data()),
+                  "dsss_frame_set");
+    geo_img = GetGeoImg(mImg.rows, mImg.cols, mPose, vGrange, tf_stb, tf_port);
+    DetectFeature(norm_img, flt_mask, kps, dst);
+}
+
+void Frame::DetectFeature(const cv::Mat &, const cv::Mat &, std::vector<cv::KeyPoint> &out_kps, cv::Mat &out_dst)
+{
+    dsss_ctx* c = Device::ctx();
+    int n = 0;
+    Device::check(dsss_extract(c, img_id, &n), "dsss_extract");
+    std::vector<dsss_kp> k(n > 0 ? n : 1);
+    out_dst = cv::Mat(n, 32, CV_8U);
+    Device::check(dsss_features_get(c, img_id, k.data(), n ? out_dst.data() : nullptr, nullptr, n, &n), "dsss_features_get");
+    out_kps.clear();
+    for (int i = 0; i < n; ++i) out_kps.push_back(cv::KeyPoint(k[i].x, k[i].y, k[i].size, k[i].angle, k[i].response, k[i].octave));
+}
+
+std::vector<cv::Mat> Frame::GetGeoImg(const int &, const int &, const cv::Mat &, const std::vector<double> &,
+                                      const std::vector<double> &, const std::vector<double> &)
+{
+    double bb[4];
+    Device::check(dsss_frame_bbox(Device::ctx(), img_id, bb), "dsss_frame_bbox");
+    cv::Mat gx(1, 2, CV_64F), gy(1, 2, CV_64F);
+    gx.at<double>(0, 0) = bb[0]; gx.at<double>(0, 1) = bb[1]; gy.at<double>(0, 0) = bb[2]; gy.at<double>(0, 1) = bb[3];
+    return { gx, gy };
+}
+
+void Frame::FetchImages()
+{
+    norm_img = cv::Mat(raw_img.rows, raw_img.cols, CV_8U); flt_mask = cv::Mat(raw_img.rows, raw_img.cols, CV_8U);
+    Device::check(dsss_frame_get_norm(Device::ctx(), img_id, norm_img.data(), flt_mask.data()), "dsss_frame_get_norm");
+}
+
+cv::Mat Frame::GetNormalizeSSS(const cv::Mat &) { if (norm_img.empty()) FetchImages(); return norm_img; }
+cv::Mat Frame::GetFilteredMask(const cv::Mat &) { if (flt_mask.empty()) FetchImages(); return flt_mask; }
+
+} // namespace Diasss

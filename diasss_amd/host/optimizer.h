@@ -1,0 +1,50 @@
+// diasss_amd/host/optimizer.h -- drop-in for the in-scope part of /root/reference/src/core/optimizer.h:31-67.
+// GTSAM's Vector7 / Vector6 / Pose3 appear in the reference's public signatures (optimizer.h:12-25); GTSAM is not a
+// dependency here, so POD equivalents carry the same names inside namespace Diasss.
+#ifndef OPTIMIZER_H
+#define OPTIMIZER_H
+
+#include <array>
+#include <tuple>
+#include <vector>
+#include "frame.h"
+
+namespace Diasss
+{
+
+    typedef std::array<double, 7> Vector7;     // [ping_s, bin_s, slant_s, ping_t, bin_t, slant_t, depth]
+    typedef std::array<double, 6> Vector6;     // tangent order [rot(3), trans(3)]
+    struct Pose3 { double R[9]; double t[3]; double x() const { return t[0]; } double y() const { return t[1]; } double z() const { return t[2]; } };
+
+    class Optimizer
+    {
+
+    public:
+
+        // the reference hard-codes these as locals (optimizer.cpp:26); USE_ANNO = 1 there consumes hand annotations,
+        // the synthetic configs need the matcher's output, so the default here is 0
+        static bool USE_ANNO;
+        static bool ADD_LC;
+
+        void static TrajOptimizationAll(std::vector<Frame> &AllFrames);                                   // optimizer.h:43
+
+        std::vector<Vector7> static GetKpsPairs(const bool &USE_ANNO, const cv::Mat &kps, const int &id_s, const int &id_t,
+                                         const std::vector<double> &alts_s, const std::vector<double> &gras_s,
+                                         const std::vector<double> &alts_t, const std::vector<double> &gras_t);   // optimizer.h:45-47
+
+        std::vector<std::tuple<Pose3,Vector6,double>> static LoopClosingTFs(const std::vector<Vector7> &kps_pairs,
+                                                        const std::vector<double> &tf_stb, const std::vector<double> &tf_port,
+                                                        const int &img_id_s, const int &img_id_t,
+                                                        const std::vector<cv::Mat> &geo_s, const std::vector<cv::Mat> &geo_t,
+                                                        const std::vector<double> &alts_s, const std::vector<double> &alts_t,
+                                                        const std::vector<double> &gras_s, const std::vector<double> &gras_t,
+                                                        const cv::Mat &dr_poses_s, const cv::Mat &dr_poses_t);      // optimizer.h:61-67
+
+        // optimizer.h:73-74; poses12 = total x 12 (R row-major, t) instead of gtsam::Values
+        void static SaveTrajactoryAll(const std::vector<double> &poses12, const std::vector<std::vector<int>> &unique_id,
+                                      const std::vector<cv::Mat> &dr_poses_all);
+    };
+
+}
+
+#endif // OPTIMIZER_H
