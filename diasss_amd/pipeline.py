@@ -43,9 +43,9 @@ def merge_edges(edge_lists):
 
 
 class Pipeline:
-    def __init__(self, F, device=0, rank=0, world=1, dist=None, min_overlap=None):
+    def __init__(self, F, device=0, rank=0, world=1, dist=None, min_overlap=None, ctx=None):
         self.F, self.rank, self.world, self.dist = F, rank, world, dist
-        self.ctx = capi.Context(max_frames=F, device=device)
+        self.ctx = ctx if ctx is not None else capi.Context(max_frames=F, device=device)   # ctx injection: sharding tests
         self.min_overlap = min_overlap      # None: dense all-pairs (BASELINE configs); 0.4 reproduces diasss2.cpp:28,93
 
     def close(self):
@@ -75,13 +75,13 @@ class Pipeline:
         send = torch.zeros((per, nb), dtype=torch.uint8, device=dev)
         for k, f in enumerate(mine):
             self.ctx.features_pack(f, send[k])
-        recv = torch.empty((self.world, per, nb), dtype=torch.uint8, device=dev)
+        recv = torch.empty((self.world * per, nb), dtype=torch.uint8, device=dev)     # concatenated along dim 0
         dist.all_gather_into_tensor(recv, send)
         for r in range(self.world):
             if r == self.rank:
                 continue
             for k, f in enumerate(shard_frames(self.F, r, self.world)):
-                self.ctx.features_unpack(f, recv[r, k])
+                self.ctx.features_unpack(f, recv[r * per + k])
 
     # ---- stage 2: matching + loop-closure measurements
     def match(self):
@@ -119,9 +119,9 @@ class Pipeline:
         buf = np.zeros(mx * isz, np.uint8)
         buf[:len(edges) * isz] = edges.view(np.uint8).reshape(-1)
         send = torch.from_numpy(buf).to(dev)
-        recv = torch.empty((self.world, mx * isz), dtype=torch.uint8, device=dev)
+        recv = torch.empty(self.world * mx * isz, dtype=torch.uint8, device=dev)
         dist.all_gather_into_tensor(recv, send)
-        recv = recv.cpu().numpy()
+        recv = recv.cpu().numpy().reshape(self.world, mx * isz)
         return merge_edges([recv[r, :cnts[r] * isz].copy().view(capi.LCEDGE_DTYPE) for r in range(self.world)])
 
     def run(self, raws, poses, alts, grs):
