@@ -20,7 +20,7 @@ LC_DTYPE = np.dtype([("rel", "<f8", (12,)), ("var", "<f8", (6,)), ("score", "<f8
 LCEDGE_DTYPE = np.dtype([("a", "<i4"), ("b", "<i4"), ("rel", "<f8", (12,)), ("var", "<f8", (6,))])
 
 K_NAMES = ["row_reduce", "pre_misc", "normalize", "pyramid", "fast", "fast_compact", "desc", "filter", "match", "scc", "rows", "lc", "pg",
-           "k13", "k14", "k15"]
+           "quadtree", "k14", "k15"]
 
 
 class MaskParams(C.Structure):
@@ -295,4 +295,4 @@ class Context:
     def profile_get(self):
         ms = np.zeros(16, np.float64); n = np.zeros(16, np.int64)
         self._chk(self.L.dsss_profile_get(self.h, _ptr(ms), _ptr(n)), "dsss_profile_get")
-        return {K_NAMES[i]: (float(ms[i]), int(n[i])) for i in range(13)}
+        return {K_NAMES[i]: (float(ms[i]), int(n[i])) for i in range(14)}

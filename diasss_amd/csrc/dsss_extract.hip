@@ -5,7 +5,12 @@
 // Everything except the quadtree cull (quadtree.cpp, host) runs in HIP kernels; all of it is integer / fixed
 // point / explicitly ordered floating point, so results are bit-exact against oracle/orc_frame.c + orc_orb.c.
 #include "dsss_internal.h"
+#include "dsss_quadtree.h"
 #include <algorithm>
+#include <map>
+#include <memory>
+#include <chrono>
+#include <cstdlib>
 
 int dsss_quadtree_cull(const float* xs, const float* ys, const float* resp, int n,
                        int minX, int maxX, int minY, int maxY, int quota, std::vector<int>& keep);
@@ -192,7 +197,7 @@ __device__ inline int block_scan_excl256(int v, int* total, int* s_w)
 // one block per cell window (ORBextractor.cpp:789-816): FAST at iniThFAST, retried at minThFAST if the cell is
 // empty, non-max suppression inside the window only, keypoints emitted row-major.
 __global__ __launch_bounds__(256) void fast_cells_kernel(const fast_cell* __restrict__ cells, level_tab lv,
-                                                         int ini_th, int min_th, uint32_t* __restrict__ cand, int* __restrict__ counts)
+                                                         int ini_th, int min_th, uint32_t* __restrict__ cand, int* __restrict__ counts, int cell_cap)
 {
     __shared__ uint8_t win[CELL_MAX * CELL_STRIDE];
     __shared__ uint8_t A[CELL_MAX * CELL_STRIDE];
@@ -242,11 +247,11 @@ __global__ __launch_bounds__(256) void fast_cells_kernel(const fast_cell* __rest
         const int pos = block_scan_excl256(keep, &tot, s_w);
         if (keep) {
             const int y = 3 + t / ew, x = 3 + t % ew;
-            cand[(size_t)blockIdx.x * CELL_CAP + base + pos] = (uint32_t)x | ((uint32_t)y << 8) | ((uint32_t)(a - 1) << 16);
+            if (base + pos < cell_cap) cand[(size_t)blockIdx.x * cell_cap + base + pos] = (uint32_t)x | ((uint32_t)y << 8) | ((uint32_t)(a - 1) << 16);
         }
         base += tot;
     }
-    if (threadIdx.x == 0) counts[blockIdx.x] = base;
+    if (threadIdx.x == 0) counts[blockIdx.x] = base < cell_cap ? base : cell_cap;
 }
 
 __global__ __launch_bounds__(256) void scan_counts_kernel(const int* __restrict__ counts, int n, int* __restrict__ offs)
@@ -267,13 +272,13 @@ __global__ __launch_bounds__(256) void scan_counts_kernel(const int* __restrict_
 // candidates in reference order with the cell offset applied (ORBextractor.cpp:820-825)
 __global__ __launch_bounds__(64) void gather_cand_kernel(const fast_cell* __restrict__ cells, const uint32_t* __restrict__ cand,
                                                          const int* __restrict__ counts, const int* __restrict__ offs,
-                                                         float* __restrict__ xs, float* __restrict__ ys, float* __restrict__ rs, int cap)
+                                                         float* __restrict__ xs, float* __restrict__ ys, float* __restrict__ rs, int cap, int cell_cap)
 {
     const fast_cell c = cells[blockIdx.x];
     const int n = counts[blockIdx.x], o = offs[blockIdx.x];
     for (int q = threadIdx.x; q < n; q += 64) {
         if (o + q >= cap) return;
-        const uint32_t v = cand[(size_t)blockIdx.x * CELL_CAP + q];
+        const uint32_t v = cand[(size_t)blockIdx.x * cell_cap + q];
         xs[o + q] = (float)(v & 255u) + (float)c.offx;
         ys[o + q] = (float)((v >> 8) & 255u) + (float)c.offy;
         rs[o + q] = (float)(v >> 16);
@@ -281,7 +286,7 @@ __global__ __launch_bounds__(64) void gather_cand_kernel(const fast_cell* __rest
 }
 
 // ------------------------------------------------------------------ K5 + K6 + K7: orientation, blur, rBRIEF
-struct kp_in { float x, y, resp; int level; };
+typedef qt_kp_in kp_in;
 
 __constant__ signed char c_pattern[1024] = {
 #include "orb_pattern_31.inc"
@@ -320,7 +325,7 @@ __device__ inline int reflect101_dev(int p, int len)
 
 // one wave per keypoint, four keypoints per block.  The Gaussian blur of the level clone (ORBextractor.cpp:1091-1092)
 // is evaluated only on the 37 x 37 patch the rotated pattern can reach, from a 49 x 49 LDS tile of the level image.
-__global__ __launch_bounds__(256) void orient_desc_kernel(const kp_in* __restrict__ kin, int n, level_tab lv,
+__global__ __launch_bounds__(256) void orient_desc_kernel(const kp_in* __restrict__ kin, const int* __restrict__ n_ptr, level_tab lv,
                                                           const int* __restrict__ lrows, const float* __restrict__ lscale,
                                                           dsss_kp* __restrict__ kp_out, uint8_t* __restrict__ desc_out)
 {
@@ -329,6 +334,8 @@ __global__ __launch_bounds__(256) void orient_desc_kernel(const kp_in* __restric
     __shared__ uint8_t sB[4][BW * BS];
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int k = blockIdx.x * 4 + wv;
+    const int n = *n_ptr;
+    if (blockIdx.x * 4 >= n) return;
     const bool act = k < n;
     kp_in in = act ? kin[k] : kin[0];
     const int L = in.level;
@@ -407,13 +414,14 @@ __global__ __launch_bounds__(256) void orient_desc_kernel(const kp_in* __restric
 
 // Frame::DetectFeature tail (frame.cpp:184-195): keep kp iff mask(int(y), int(x)) != 0, order preserved;
 // also samples the geo image for the survivors (FEAmatcher.cpp:81-82).
-__global__ __launch_bounds__(256) void mask_filter_kernel(const dsss_kp* __restrict__ kin, const uint8_t* __restrict__ din, int n,
+__global__ __launch_bounds__(256) void mask_filter_kernel(const dsss_kp* __restrict__ kin, const uint8_t* __restrict__ din, const int* __restrict__ n_ptr,
                                                           const uint8_t* __restrict__ mask, int M,
                                                           const double* __restrict__ pose6, const double* __restrict__ gr,
                                                           dsss_kp* __restrict__ kout, uint8_t* __restrict__ dout,
                                                           double* __restrict__ geo, int* __restrict__ count)
 {
     __shared__ int s_w[4];
+    const int n = *n_ptr;
     int base = 0;
     for (int c0 = 0; c0 < n; c0 += 256) {
         const int i = c0 + threadIdx.x;
@@ -445,6 +453,9 @@ struct level_geom {
     float sf[DSSS_MAX_LEVELS];
     std::vector<fast_cell> cells;
     int cell_begin[DSSS_MAX_LEVELS + 1];
+    int cell_cap = 0;                     // strict local maxima possible in the largest cell
+    fast_cell* d_cells = nullptr;         // device copy (per geometry, cached)
+    int* d_lrows = nullptr; float* d_lscale = nullptr;
 };
 
 // scale tables, level sizes and quotas of the ORBextractor ctor / ComputePyramid (ORBextractor.cpp:415-446,1119-1120)
@@ -455,6 +466,7 @@ void build_geom(const dsss_orb_params& op, int rows, int cols, level_geom& g)
     g.sf[0] = 1.0f;
     for (int i = 1; i < op.nlevels; ++i) g.sf[i] = g.sf[i - 1] * op.scale;
     for (int i = 0; i < op.nlevels; ++i) inv[i] = 1.0f / g.sf[i];
+    for (int l = 0; l < DSSS_MAX_LEVELS; ++l) { g.rows[l] = 0; g.cols[l] = 0; g.quota[l] = 0; if (l >= op.nlevels) g.sf[l] = 0; }
     for (int l = 0; l < op.nlevels; ++l) {
         g.cols[l] = (int)lrintf((float)cols * inv[l]);
         g.rows[l] = (int)lrintf((float)rows * inv[l]);
@@ -466,6 +478,7 @@ void build_geom(const dsss_orb_params& op, int rows, int cols, level_geom& g)
     g.quota[op.nlevels - 1] = std::max(op.nfeatures - sum, 0);
     // cell windows of ComputeKeyPointsOctTree (ORBextractor.cpp:769-806)
     g.cells.clear();
+    int cap = 1;
     for (int l = 0; l < op.nlevels; ++l) {
         g.cell_begin[l] = (int)g.cells.size();
         const float W = 30;
@@ -489,16 +502,45 @@ void build_geom(const dsss_orb_params& op, int rows, int cols, level_geom& g)
                 c.offx = j * wCell; c.offy = i * hCell; c.pad = 0;
                 if (c.w > CELL_MAX) c.w = CELL_MAX;
                 if (c.h > CELL_MAX) c.h = CELL_MAX;
+                const int ew = std::max(c.w - 6, 0), eh = std::max(c.h - 6, 0);
+                cap = std::max(cap, ((ew + 1) / 2) * ((eh + 1) / 2));
                 g.cells.push_back(c);
             }
         }
     }
     g.cell_begin[op.nlevels] = (int)g.cells.size();
+    g.cell_cap = std::min(cap, CELL_CAP);
 }
 
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
+struct geom_key { int N, M, nf, nl, it, mt; float sc; bool operator<(const geom_key& o) const {
+    return std::tie(N, M, nf, nl, it, mt, sc) < std::tie(o.N, o.M, o.nf, o.nl, o.it, o.mt, o.sc); } };
+std::map<std::pair<dsss_ctx*, geom_key>, std::unique_ptr<level_geom>> g_geoms;   // device tables live as long as the process
+
 } // namespace
+
+static int get_geom(dsss_ctx* c, int N, int M, level_geom** out)
+{
+    geom_key k{ N, M, c->op.nfeatures, c->op.nlevels, c->op.ini_th, c->op.min_th, c->op.scale };
+    auto it = g_geoms.find({ c, k });
+    if (it == g_geoms.end()) {
+        std::unique_ptr<level_geom> g(new level_geom());
+        build_geom(c->op, N, M, *g);
+        for (int l = 0; l < g->nlevels; ++l)
+            if (g->rows[l] < 2 * EDGE_T + 31 || g->cols[l] < 2 * EDGE_T + 31)
+                DSSS_FAIL(c, DSSS_E_ARG, "level %d (%d x %d) too small for 30-px FAST cells", l, g->rows[l], g->cols[l]);
+        HIPCHK(c, hipMalloc(&g->d_cells, sizeof(fast_cell) * std::max<size_t>(g->cells.size(), 1)));
+        HIPCHK(c, hipMalloc(&g->d_lrows, sizeof(int) * DSSS_MAX_LEVELS));
+        HIPCHK(c, hipMalloc(&g->d_lscale, sizeof(float) * DSSS_MAX_LEVELS));
+        HIPCHK(c, hipMemcpy(g->d_cells, g->cells.data(), sizeof(fast_cell) * g->cells.size(), hipMemcpyHostToDevice));
+        HIPCHK(c, hipMemcpy(g->d_lrows, g->rows, sizeof(int) * DSSS_MAX_LEVELS, hipMemcpyHostToDevice));
+        HIPCHK(c, hipMemcpy(g->d_lscale, g->sf, sizeof(float) * DSSS_MAX_LEVELS, hipMemcpyHostToDevice));
+        it = g_geoms.emplace(std::make_pair(c, k), std::move(g)).first;
+    }
+    *out = it->second.get();
+    return DSSS_OK;
+}
 
 static int ensure_frame_images(dsss_ctx* c, dsss_frame& f, const level_geom& g)
 {
@@ -520,142 +562,180 @@ static int ensure_frame_images(dsss_ctx* c, dsss_frame& f, const level_geom& g)
     return DSSS_OK;
 }
 
-// scratch layout (device): rowsum[N] rowmin[N] stats[4] | cells | counts | offs | cand | xs ys rs | kp_in | kp_tmp | desc_tmp | lrows lscale
+// per-frame slot of the batch scratch (device)
 struct ex_layout {
-    size_t rowsum, rowmin, stats, cells, counts, offs, cand, xs, ys, rs, kin, kptmp, dtmp, lrows, lscale, total;
-    int cand_cap, kcap_in;
+    size_t rowsum, rowmin, stats, counts, offs, cand, xs, ys, rs, keys0, keys1, work[DSSS_MAX_LEVELS], out_idx, out_n, kin, nk, err, kptmp, dtmp, total;
+    int cand_cap, list_cap[DSSS_MAX_LEVELS], pool_cap[DSSS_MAX_LEVELS], out_cap;
 };
-static ex_layout make_layout(int N, int ncells, int kcap)
+static ex_layout make_layout(int N, const level_geom& g, int kcap)
 {
     ex_layout L; size_t o = 0;
-    L.cand_cap = ncells * 64 + 4096; L.kcap_in = kcap;
+    const int ncells = (int)g.cells.size();
+    L.cand_cap = ncells * 64 + 4096; L.out_cap = kcap;
     auto take = [&](size_t bytes) { size_t r = o; o = align_up(o + bytes, 256); return r; };
     L.rowsum = take(sizeof(double) * N); L.rowmin = take(sizeof(double) * N); L.stats = take(sizeof(double) * 4);
-    L.cells = take(sizeof(fast_cell) * ncells); L.counts = take(sizeof(int) * ncells); L.offs = take(sizeof(int) * (ncells + 1));
-    L.cand = take(sizeof(uint32_t) * (size_t)ncells * CELL_CAP);
+    L.counts = take(sizeof(int) * ncells); L.offs = take(sizeof(int) * (ncells + 1));
+    L.cand = take(sizeof(uint32_t) * (size_t)ncells * g.cell_cap);
     L.xs = take(sizeof(float) * L.cand_cap); L.ys = take(sizeof(float) * L.cand_cap); L.rs = take(sizeof(float) * L.cand_cap);
-    L.kin = take(sizeof(kp_in) * kcap); L.kptmp = take(sizeof(dsss_kp) * kcap); L.dtmp = take((size_t)32 * kcap);
-    L.lrows = take(sizeof(int) * DSSS_MAX_LEVELS); L.lscale = take(sizeof(float) * DSSS_MAX_LEVELS);
-    L.total = o;
+    L.keys0 = take(sizeof(int) * L.cand_cap); L.keys1 = take(sizeof(int) * L.cand_cap);
+    for (int l = 0; l < DSSS_MAX_LEVELS; ++l) {
+        L.list_cap[l] = 4 * g.quota[l] + 128; L.pool_cap[l] = 16 * g.quota[l] + 1024;
+        L.work[l] = l < g.nlevels ? take(sizeof(int) * ((size_t)8 * L.pool_cap[l] + (size_t)10 * L.list_cap[l])) : 0;
+    }
+    L.out_idx = take(sizeof(int) * (size_t)DSSS_MAX_LEVELS * L.out_cap); L.out_n = take(sizeof(int) * DSSS_MAX_LEVELS);
+    L.kin = take(sizeof(kp_in) * kcap); L.nk = take(sizeof(int)); L.err = take(sizeof(int));
+    L.kptmp = take(sizeof(dsss_kp) * kcap); L.dtmp = take((size_t)32 * kcap);
+    L.total = align_up(o, 4096);
     return L;
 }
 
-static int extract_one(dsss_ctx* c, int id, int* n_out)
-{
-    dsss_frame& f = c->frames[id];
-    if (!f.has_geom || !f.has_raw) DSSS_FAIL(c, DSSS_E_STATE, "frame %d has no raw image (dsss_frame_set with raw != NULL first)", id);
-    const int N = f.N, M = f.M;
-    level_geom g;
-    build_geom(c->op, N, M, g);
-    for (int l = 0; l < g.nlevels; ++l)
-        if (g.rows[l] < 2 * EDGE_T + 31 || g.cols[l] < 2 * EDGE_T + 31)
-            DSSS_FAIL(c, DSSS_E_ARG, "level %d (%d x %d) too small for 30-px FAST cells", l, g.rows[l], g.cols[l]);
-    int rc = ensure_frame_images(c, f, g); if (rc) return rc;
-    rc = dsss_ensure_store(c); if (rc) return rc;
-    const int ncells = (int)g.cells.size();
-    const ex_layout L = make_layout(N, ncells, c->kcap);
-    if (c->ex_scratch_bytes < L.total) {
-        HIPCHK(c, hipStreamSynchronize(c->stream)); hipFree(c->ex_scratch); c->ex_scratch = nullptr; c->ex_scratch_bytes = 0;
-        HIPCHK(c, hipMalloc(&c->ex_scratch, L.total)); c->ex_scratch_bytes = L.total;
-    }
-    const size_t pin_bytes = sizeof(int) * (ncells + 1) + 3 * sizeof(float) * (size_t)L.cand_cap + sizeof(kp_in) * (size_t)c->kcap + 64;
-    if (c->ex_pinned_bytes < pin_bytes) {
-        HIPCHK(c, hipStreamSynchronize(c->stream)); if (c->ex_pinned) hipHostFree(c->ex_pinned); c->ex_pinned = nullptr; c->ex_pinned_bytes = 0;
-        HIPCHK(c, hipHostMalloc(&c->ex_pinned, pin_bytes, hipHostMallocDefault)); c->ex_pinned_bytes = pin_bytes;
-    }
-    char* S = (char*)c->ex_scratch;
-    double* d_rowsum = (double*)(S + L.rowsum); double* d_rowmin = (double*)(S + L.rowmin); double* d_stats = (double*)(S + L.stats);
-    fast_cell* d_cells = (fast_cell*)(S + L.cells); int* d_counts = (int*)(S + L.counts); int* d_offs = (int*)(S + L.offs);
-    uint32_t* d_cand = (uint32_t*)(S + L.cand);
-    float* d_xs = (float*)(S + L.xs); float* d_ys = (float*)(S + L.ys); float* d_rs = (float*)(S + L.rs);
-    kp_in* d_kin = (kp_in*)(S + L.kin); dsss_kp* d_kptmp = (dsss_kp*)(S + L.kptmp); uint8_t* d_dtmp = (uint8_t*)(S + L.dtmp);
-    int* d_lrows = (int*)(S + L.lrows); float* d_lscale = (float*)(S + L.lscale);
-    char* Hp = (char*)c->ex_pinned;
-    int* h_offs = (int*)Hp;
-    float* h_xs = (float*)(Hp + align_up(sizeof(int) * (ncells + 1), 64));
-    float* h_ys = h_xs + L.cand_cap; float* h_rs = h_ys + L.cand_cap;
-    kp_in* h_kin = (kp_in*)(h_rs + L.cand_cap);
+#define EX_BATCH 64
 
-    HIPCHK(c, hipMemcpyAsync(d_cells, g.cells.data(), sizeof(fast_cell) * ncells, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipMemcpyAsync(d_lrows, g.rows, sizeof(int) * DSSS_MAX_LEVELS, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipMemcpyAsync(d_lscale, g.sf, sizeof(float) * DSSS_MAX_LEVELS, hipMemcpyHostToDevice, c->stream));
-    const size_t tot = (size_t)N * M;
-    {   // K1
-        dsss_scope sc(c, DSSS_K_ROW_REDUCE);
-        hipLaunchKernelGGL(row_reduce_kernel, dim3((N + 3) / 4), dim3(256), 0, c->stream, f.raw, N, M, d_rowsum, d_rowmin);
+// extraction of a list of frames, batched: per frame K1-K3 (+ candidate compaction), then ONE quadtree launch for the
+// whole batch (one workgroup per frame x level), then per frame K5-K7 + mask filter.  No host round trip per frame.
+static int extract_frames(dsss_ctx* c, const int* ids, int n, bool keep_taps)
+{
+    if (n <= 0) return DSSS_OK;
+    int rc = dsss_ensure_store(c); if (rc) return rc;
+    std::vector<level_geom*> G(n);
+    size_t slot_bytes = 0;
+    std::vector<ex_layout> Ls(n);
+    for (int i = 0; i < n; ++i) {
+        dsss_frame& f = c->frames[ids[i]];
+        if (!f.has_geom || !f.has_raw) DSSS_FAIL(c, DSSS_E_STATE, "frame %d has no raw image (dsss_frame_set with raw != NULL first)", ids[i]);
+        rc = get_geom(c, f.N, f.M, &G[i]); if (rc) return rc;
+        rc = ensure_frame_images(c, f, *G[i]); if (rc) return rc;
+        Ls[i] = make_layout(f.N, *G[i], c->kcap);
+        slot_bytes = std::max(slot_bytes, Ls[i].total);
     }
-    {
-        dsss_scope sc(c, DSSS_K_PRE_MISC);
-        hipLaunchKernelGGL(final_reduce_kernel, dim3(1), dim3(64), 0, c->stream, d_rowsum, d_rowmin, N, M, (double)(float)c->mp.factor, d_stats);
-        hipLaunchKernelGGL(mask_init_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, c->stream, f.mask, N, M, c->mp.width, c->mp.side,
-                           (double)c->mp.side * 0.6);
+    const int B = std::min(n, EX_BATCH);
+    const size_t tab_bytes = align_up(sizeof(qt_inst) * (size_t)B * DSSS_MAX_LEVELS, 256) + align_up(sizeof(qt_frame) * (size_t)B, 256);
+    const size_t need = slot_bytes * B + tab_bytes;
+    if (c->ex_scratch_bytes < need) {
+        HIPCHK(c, hipStreamSynchronize(c->stream)); hipFree(c->ex_scratch); c->ex_scratch = nullptr; c->ex_scratch_bytes = 0;
+        HIPCHK(c, hipMalloc(&c->ex_scratch, need)); c->ex_scratch_bytes = need;
     }
-    {
-        dsss_scope sc(c, DSSS_K_NORMALIZE);
-        hipLaunchKernelGGL(normalize_kernel, dim3((unsigned)((tot / 4 + 256) / 256)), dim3(256), 0, c->stream, f.raw, N, M, d_stats, c->mp.r,
-                           f.lvl[0], f.mask);
+    const size_t pin_need = tab_bytes + sizeof(int) * 2 * (size_t)B + 64;
+    if (c->ex_pinned_bytes < pin_need) {
+        HIPCHK(c, hipStreamSynchronize(c->stream)); if (c->ex_pinned) hipHostFree(c->ex_pinned); c->ex_pinned = nullptr; c->ex_pinned_bytes = 0;
+        HIPCHK(c, hipHostMalloc(&c->ex_pinned, pin_need, hipHostMallocDefault)); c->ex_pinned_bytes = pin_need;
+    }
+    char* S0 = (char*)c->ex_scratch;
+    qt_inst* d_inst = (qt_inst*)(S0 + slot_bytes * B);
+    qt_frame* d_fr = (qt_frame*)((char*)d_inst + align_up(sizeof(qt_inst) * (size_t)B * DSSS_MAX_LEVELS, 256));
+    qt_inst* h_inst = (qt_inst*)c->ex_pinned;
+    qt_frame* h_fr = (qt_frame*)((char*)h_inst + align_up(sizeof(qt_inst) * (size_t)B * DSSS_MAX_LEVELS, 256));
+    int* h_res = (int*)((char*)c->ex_pinned + tab_bytes);      // [B] nkp, [B] err
+    hipStream_t st = c->stream;
+
+    for (int b0 = 0; b0 < n; b0 += B) {
+        const int nb = std::min(B, n - b0);
+        int ninst = 0;
+        for (int s = 0; s < nb; ++s) {
+            const int id = ids[b0 + s];
+            dsss_frame& f = c->frames[id];
+            const level_geom& g = *G[b0 + s];
+            const ex_layout& L = Ls[b0 + s];
+            const int N = f.N, M = f.M, ncells = (int)g.cells.size();
+            char* S = S0 + slot_bytes * s;
+            double* d_rowsum = (double*)(S + L.rowsum); double* d_rowmin = (double*)(S + L.rowmin); double* d_stats = (double*)(S + L.stats);
+            int* d_counts = (int*)(S + L.counts); int* d_offs = (int*)(S + L.offs); uint32_t* d_cand = (uint32_t*)(S + L.cand);
+            float* d_xs = (float*)(S + L.xs); float* d_ys = (float*)(S + L.ys); float* d_rs = (float*)(S + L.rs);
+            int* d_err = (int*)(S + L.err);
+            HIPCHK(c, hipMemsetAsync(d_err, 0, sizeof(int), st));
+            const size_t tot = (size_t)N * M;
+            { dsss_scope sc(c, DSSS_K_ROW_REDUCE);
+              hipLaunchKernelGGL(row_reduce_kernel, dim3((N + 3) / 4), dim3(256), 0, st, f.raw, N, M, d_rowsum, d_rowmin); }
+            { dsss_scope sc(c, DSSS_K_PRE_MISC);
+              hipLaunchKernelGGL(final_reduce_kernel, dim3(1), dim3(64), 0, st, d_rowsum, d_rowmin, N, M, (double)(float)c->mp.factor, d_stats);
+              hipLaunchKernelGGL(mask_init_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, f.mask, N, M, c->mp.width, c->mp.side, (double)c->mp.side * 0.6); }
+            { dsss_scope sc(c, DSSS_K_NORMALIZE);
+              hipLaunchKernelGGL(normalize_kernel, dim3((unsigned)((tot / 4 + 256) / 256)), dim3(256), 0, st, f.raw, N, M, d_stats, c->mp.r, f.lvl[0], f.mask); }
+            level_tab lv;
+            for (int l = 0; l < DSSS_MAX_LEVELS; ++l) { lv.img[l] = l < g.nlevels ? f.lvl[l] : nullptr; lv.cols[l] = l < g.nlevels ? g.cols[l] : 0; }
+            { dsss_scope sc(c, DSSS_K_PYRAMID);
+              for (int l = 1; l < g.nlevels; ++l) {
+                  const double sx = 1. / ((double)g.cols[l] / g.cols[l - 1]), sy = 1. / ((double)g.rows[l] / g.rows[l - 1]);
+                  hipLaunchKernelGGL(resize_kernel, dim3((g.cols[l] + 255) / 256, g.rows[l]), dim3(256), 0, st, f.lvl[l - 1], g.rows[l - 1], g.cols[l - 1],
+                                     f.lvl[l], g.rows[l], g.cols[l], sx, sy);
+              } }
+            { dsss_scope sc(c, DSSS_K_FAST);
+              hipLaunchKernelGGL(fast_cells_kernel, dim3(ncells), dim3(256), 0, st, g.d_cells, lv, c->op.ini_th, c->op.min_th, d_cand, d_counts, g.cell_cap); }
+            { dsss_scope sc(c, DSSS_K_FAST_COMPACT);
+              hipLaunchKernelGGL(scan_counts_kernel, dim3(1), dim3(256), 0, st, d_counts, ncells, d_offs);
+              hipLaunchKernelGGL(gather_cand_kernel, dim3(ncells), dim3(64), 0, st, g.d_cells, d_cand, d_counts, d_offs, d_xs, d_ys, d_rs, L.cand_cap, g.cell_cap); }
+            HIPCHK(c, hipGetLastError());
+            // quadtree descriptors
+            for (int l = 0; l < g.nlevels; ++l) {
+                qt_inst& q = h_inst[ninst++];
+                q.offs = d_offs; q.cell_begin = g.cell_begin[l]; q.cell_end = g.cell_begin[l + 1];
+                q.xs = d_xs; q.ys = d_ys; q.rs = d_rs;
+                q.W = (g.cols[l] - EDGE_T + 3) - (EDGE_T - 3); q.H = (g.rows[l] - EDGE_T + 3) - (EDGE_T - 3); q.quota = g.quota[l];
+                q.keys0 = (int*)(S + L.keys0); q.keys1 = (int*)(S + L.keys1); q.work = (int*)(S + L.work[l]);
+                q.list_cap = L.list_cap[l]; q.pool_cap = L.pool_cap[l];
+                q.out_idx = (int*)(S + L.out_idx) + (size_t)l * L.out_cap; q.out_n = (int*)(S + L.out_n) + l; q.out_cap = L.out_cap;
+                q.err = d_err;
+            }
+            qt_frame& qf = h_fr[s];
+            qf.nlevels = g.nlevels; qf.out_cap = L.out_cap; qf.kcap = c->kcap; qf.min_border = EDGE_T - 3;
+            qf.out_idx = (int*)(S + L.out_idx); qf.out_n = (int*)(S + L.out_n);
+            qf.xs = d_xs; qf.ys = d_ys; qf.rs = d_rs;
+            qf.kin = (kp_in*)(S + L.kin); qf.nk = (int*)(S + L.nk); qf.err = d_err;
+        }
+        // K4 on the device for the whole batch
+        HIPCHK(c, hipMemcpyAsync(d_inst, h_inst, sizeof(qt_inst) * ninst, hipMemcpyHostToDevice, st));
+        HIPCHK(c, hipMemcpyAsync(d_fr, h_fr, sizeof(qt_frame) * nb, hipMemcpyHostToDevice, st));
+        { dsss_scope sc(c, DSSS_K_QUADTREE);
+          dsss_launch_quadtree(st, d_inst, ninst, d_fr, nb); }
         HIPCHK(c, hipGetLastError());
-    }
-    level_tab lv;
-    for (int l = 0; l < DSSS_MAX_LEVELS; ++l) { lv.img[l] = l < g.nlevels ? f.lvl[l] : nullptr; lv.cols[l] = l < g.nlevels ? g.cols[l] : 0; }
-    {   // K2
-        dsss_scope sc(c, DSSS_K_PYRAMID);
-        for (int l = 1; l < g.nlevels; ++l) {
-            const double sx = 1. / ((double)g.cols[l] / g.cols[l - 1]), sy = 1. / ((double)g.rows[l] / g.rows[l - 1]);
-            hipLaunchKernelGGL(resize_kernel, dim3((g.cols[l] + 255) / 256, g.rows[l]), dim3(256), 0, c->stream, f.lvl[l - 1], g.rows[l - 1],
-                               g.cols[l - 1], f.lvl[l], g.rows[l], g.cols[l], sx, sy);
+        for (int s = 0; s < nb; ++s) {
+            const int id = ids[b0 + s];
+            dsss_frame& f = c->frames[id];
+            const level_geom& g = *G[b0 + s];
+            const ex_layout& L = Ls[b0 + s];
+            char* S = S0 + slot_bytes * s;
+            level_tab lv;
+            for (int l = 0; l < DSSS_MAX_LEVELS; ++l) { lv.img[l] = l < g.nlevels ? f.lvl[l] : nullptr; lv.cols[l] = l < g.nlevels ? g.cols[l] : 0; }
+            kp_in* d_kin = (kp_in*)(S + L.kin); int* d_nk = (int*)(S + L.nk);
+            dsss_kp* d_kptmp = (dsss_kp*)(S + L.kptmp); uint8_t* d_dtmp = (uint8_t*)(S + L.dtmp);
+            { dsss_scope sc(c, DSSS_K_DESC);
+              hipLaunchKernelGGL(orient_desc_kernel, dim3((c->kcap + 3) / 4), dim3(256), 0, st, d_kin, d_nk, lv, g.d_lrows, g.d_lscale, d_kptmp, d_dtmp); }
+            { dsss_scope sc(c, DSSS_K_FILTER);
+              hipLaunchKernelGGL(mask_filter_kernel, dim3(1), dim3(256), 0, st, d_kptmp, d_dtmp, d_nk, f.mask, f.M, f.pose6, f.gr,
+                                 c->kps + (size_t)id * c->kcap, c->desc + (size_t)id * c->kcap * 32, c->geo + (size_t)id * c->kcap * 2, c->nkp_dev + id); }
+            HIPCHK(c, hipMemcpyAsync(&h_res[s], c->nkp_dev + id, sizeof(int), hipMemcpyDeviceToHost, st));
+            HIPCHK(c, hipMemcpyAsync(&h_res[B + s], (int*)(S + L.err), sizeof(int), hipMemcpyDeviceToHost, st));
         }
         HIPCHK(c, hipGetLastError());
-    }
-    {   // K3
-        { dsss_scope sc(c, DSSS_K_FAST);
-          hipLaunchKernelGGL(fast_cells_kernel, dim3(ncells), dim3(256), 0, c->stream, d_cells, lv, c->op.ini_th, c->op.min_th, d_cand, d_counts); }
-        dsss_scope sc(c, DSSS_K_FAST_COMPACT);
-        hipLaunchKernelGGL(scan_counts_kernel, dim3(1), dim3(256), 0, c->stream, d_counts, ncells, d_offs);
-        hipLaunchKernelGGL(gather_cand_kernel, dim3(ncells), dim3(64), 0, c->stream, d_cells, d_cand, d_counts, d_offs, d_xs, d_ys, d_rs, L.cand_cap);
-        HIPCHK(c, hipGetLastError());
-    }
-    HIPCHK(c, hipMemcpyAsync(h_offs, d_offs, sizeof(int) * (ncells + 1), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    const int ncand = h_offs[ncells];
-    if (ncand > L.cand_cap) DSSS_FAIL(c, DSSS_E_CAPACITY, "%d FAST candidates exceed the staging capacity %d", ncand, L.cand_cap);
-    if (ncand > 0) {
-        HIPCHK(c, hipMemcpyAsync(h_xs, d_xs, sizeof(float) * ncand, hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(c, hipMemcpyAsync(h_ys, d_ys, sizeof(float) * ncand, hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(c, hipMemcpyAsync(h_rs, d_rs, sizeof(float) * ncand, hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(c, hipStreamSynchronize(c->stream));
-    }
-    // K4 (host): quadtree cull per level, then keypoints in level order (ORBextractor.cpp:831-847,1082-1111)
-    int nk = 0;
-    std::vector<int> keep;
-    for (int l = 0; l < g.nlevels; ++l) {
-        const int b = h_offs[g.cell_begin[l]], e = h_offs[g.cell_begin[l + 1]];
-        f.cand_x[l].assign(h_xs + b, h_xs + e); f.cand_y[l].assign(h_ys + b, h_ys + e); f.cand_r[l].assign(h_rs + b, h_rs + e);
-        const int minB = EDGE_T - 3;
-        dsss_quadtree_cull(h_xs + b, h_ys + b, h_rs + b, e - b, minB, g.cols[l] - EDGE_T + 3, minB, g.rows[l] - EDGE_T + 3, g.quota[l], keep);
-        for (int id2 : keep) {
-            if (nk >= c->kcap) DSSS_FAIL(c, DSSS_E_CAPACITY, "more than %d keypoints", c->kcap);
-            kp_in& q = h_kin[nk++];
-            q.x = h_xs[b + id2] + minB; q.y = h_ys[b + id2] + minB; q.resp = h_rs[b + id2]; q.level = l;
+        HIPCHK(c, hipStreamSynchronize(st));         // one synchronisation per batch of up to EX_BATCH frames
+        for (int s = 0; s < nb; ++s) {
+            dsss_frame& f = c->frames[ids[b0 + s]];
+            if (h_res[B + s]) DSSS_FAIL(c, DSSS_E_CAPACITY, "frame %d: device quadtree capacity exceeded (code %d)", ids[b0 + s], h_res[B + s]);
+            f.nkp = h_res[s]; f.has_feat = true; f.has_norm = true;
+        }
+        if (keep_taps) {                             // stage tap for the parity tests: FAST candidates per level
+            for (int s = 0; s < nb; ++s) {
+                dsss_frame& f = c->frames[ids[b0 + s]];
+                const level_geom& g = *G[b0 + s];
+                const ex_layout& L = Ls[b0 + s];
+                char* S = S0 + slot_bytes * s;
+                const int ncells = (int)g.cells.size();
+                std::vector<int> offs(ncells + 1);
+                HIPCHK(c, hipMemcpy(offs.data(), S + L.offs, sizeof(int) * (ncells + 1), hipMemcpyDeviceToHost));
+                const int ncand = std::min(offs[ncells], L.cand_cap);
+                std::vector<float> xs(ncand), ys(ncand), rs(ncand);
+                if (ncand) {
+                    HIPCHK(c, hipMemcpy(xs.data(), S + L.xs, sizeof(float) * ncand, hipMemcpyDeviceToHost));
+                    HIPCHK(c, hipMemcpy(ys.data(), S + L.ys, sizeof(float) * ncand, hipMemcpyDeviceToHost));
+                    HIPCHK(c, hipMemcpy(rs.data(), S + L.rs, sizeof(float) * ncand, hipMemcpyDeviceToHost));
+                }
+                for (int l = 0; l < g.nlevels; ++l) {
+                    const int b = std::min(offs[g.cell_begin[l]], ncand), e = std::min(offs[g.cell_begin[l + 1]], ncand);
+                    f.cand_x[l].assign(xs.begin() + b, xs.begin() + e); f.cand_y[l].assign(ys.begin() + b, ys.begin() + e); f.cand_r[l].assign(rs.begin() + b, rs.begin() + e);
+                }
+            }
         }
     }
-    int* d_count = c->nkp_dev + id;
-    if (nk > 0) {
-        HIPCHK(c, hipMemcpyAsync(d_kin, h_kin, sizeof(kp_in) * nk, hipMemcpyHostToDevice, c->stream));
-        { dsss_scope sc(c, DSSS_K_DESC);
-          hipLaunchKernelGGL(orient_desc_kernel, dim3((nk + 3) / 4), dim3(256), 0, c->stream, d_kin, nk, lv, d_lrows, d_lscale, d_kptmp, d_dtmp); }
-        dsss_scope sc(c, DSSS_K_FILTER);
-        hipLaunchKernelGGL(mask_filter_kernel, dim3(1), dim3(256), 0, c->stream, d_kptmp, d_dtmp, nk, f.mask, M, f.pose6, f.gr,
-                           c->kps + (size_t)id * c->kcap, c->desc + (size_t)id * c->kcap * 32, c->geo + (size_t)id * c->kcap * 2, d_count);
-        HIPCHK(c, hipGetLastError());
-        HIPCHK(c, hipMemcpyAsync(&f.nkp, d_count, sizeof(int), hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(c, hipStreamSynchronize(c->stream));
-    } else {
-        f.nkp = 0;
-        HIPCHK(c, hipMemsetAsync(d_count, 0, sizeof(int), c->stream));
-    }
-    f.has_feat = true; f.has_norm = true;
-    if (n_out) *n_out = f.nkp;
     return DSSS_OK;
 }
 
@@ -666,19 +746,18 @@ int dsss_extract(dsss_ctx* c, int id, int* n_kp)
     if (!c) return DSSS_E_ARG;
     if (id < 0 || id >= c->max_frames) DSSS_FAIL(c, DSSS_E_ARG, "frame id %d out of range", id);
     HIPCHK(c, hipSetDevice(c->device));
-    return extract_one(c, id, n_kp);
+    int rc = extract_frames(c, &id, 1, true);
+    if (rc) return rc;
+    if (n_kp) *n_kp = c->frames[id].nkp;
+    return DSSS_OK;
 }
 
 int dsss_extract_many(dsss_ctx* c, const int* ids, int n)
 {
     if (!c || (n > 0 && !ids)) return DSSS_E_ARG;
     HIPCHK(c, hipSetDevice(c->device));
-    for (int i = 0; i < n; ++i) {
-        if (ids[i] < 0 || ids[i] >= c->max_frames) DSSS_FAIL(c, DSSS_E_ARG, "frame id %d out of range", ids[i]);
-        int rc = extract_one(c, ids[i], nullptr);
-        if (rc) return rc;
-    }
-    return DSSS_OK;
+    for (int i = 0; i < n; ++i) if (ids[i] < 0 || ids[i] >= c->max_frames) DSSS_FAIL(c, DSSS_E_ARG, "frame id %d out of range", ids[i]);
+    return extract_frames(c, ids, n, false);
 }
 
 int dsss_host_quadtree(const float* x, const float* y, const float* resp, int n, int minX, int maxX, int minY, int maxY,

@@ -1,0 +1,314 @@
+// diasss_amd/csrc/dsss_quadtree.hip -- K4: ORBextractor::DistributeOctTree on the device, one workgroup per
+// (frame, pyramid level).  Restates /root/reference/thirdparty/ORBextractor.cpp:481-763 without the std::list:
+//
+//   * a node's keypoints are a contiguous segment of a key array; DivideNode is a STABLE 4-way partition of that
+//     segment (one wave per node, ballot ranks), children living in the other of two ping-pong key buffers;
+//   * the list is an array in list order.  "push_front the non-empty children, erase the parent" over a whole pass
+//     (:606-665) gives  new list = reverse(children in creation order) ++ old leaves;  the size-ordered refinement
+//     (:676-737) processes the expandable children of the previous round by descending (size, creation order),
+//     stops at the first point where the node count reaches the quota (the reference's `break`), and gives
+//     new list = reverse(children created this round) ++ (old list minus the divided parents);
+//   * ties in the size sort use creation order (the reference compares heap addresses; same rule as the oracle and
+//     the host routine in quadtree.cpp);
+//   * nIni = max(1, round(w/h)) (the reference divides by zero for tall levels).
+// Output: the kept candidate of every node (first maximum response in key order), in list order.
+#include "dsss_internal.h"
+#include "dsss_quadtree.h"
+
+struct qnode { int x0, y0, x1, y1; int kbeg, kcnt; int buf; int leaf; };   // 32 B
+
+__device__ inline int qt_block_scan(int v, int* total, int* s_w)
+{
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    int inc = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(inc, o, 64); if (lane >= o) inc += t; }
+    __syncthreads();
+    if (lane == 63) s_w[w] = inc;
+    __syncthreads();
+    int base = 0, tot = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { const int t = s_w[k]; if (k < w) base += t; tot += t; }
+    *total = tot;
+    return base + inc - v;
+}
+
+// ExtractorNode::DivideNode (:481-537) for one node, executed by one wave: stable 4-way partition of the node's key
+// segment from its buffer into the other one; cnt[0..3] = keys of n1..n4 (top-left, top-right, bottom-left, bottom-right)
+__device__ inline void qt_divide_wave(const qnode& P, const float* __restrict__ xs, const float* __restrict__ ys,
+                                      int* __restrict__ keys0, int* __restrict__ keys1, int* cnt)
+{
+    const int lane = threadIdx.x & 63;
+    const int* src = P.buf ? keys1 : keys0;
+    int* dst = P.buf ? keys0 : keys1;
+    const float mx = (float)(P.x0 + (int)ceilf((float)(P.x1 - P.x0) / 2));
+    const float my = (float)(P.y0 + (int)ceilf((float)(P.y1 - P.y0) / 2));
+    int c0 = 0, c1 = 0, c2 = 0, c3 = 0;
+    for (int b = 0; b < P.kcnt; b += 64) {
+        const int i = b + lane;
+        int c = -1;
+        if (i < P.kcnt) { const int k = src[P.kbeg + i]; const bool left = xs[k] < mx, top = ys[k] < my; c = left ? (top ? 0 : 2) : (top ? 1 : 3); }
+        c0 += __popcll(__ballot(c == 0)); c1 += __popcll(__ballot(c == 1)); c2 += __popcll(__ballot(c == 2)); c3 += __popcll(__ballot(c == 3));
+    }
+    const int o1 = c0, o2 = c0 + c1, o3 = c0 + c1 + c2;
+    int r0 = 0, r1 = 0, r2 = 0, r3 = 0;
+    const unsigned long long below = (1ull << lane) - 1ull;
+    for (int b = 0; b < P.kcnt; b += 64) {
+        const int i = b + lane;
+        int c = -1, k = 0;
+        if (i < P.kcnt) { k = src[P.kbeg + i]; const bool left = xs[k] < mx, top = ys[k] < my; c = left ? (top ? 0 : 2) : (top ? 1 : 3); }
+        const unsigned long long m0 = __ballot(c == 0), m1 = __ballot(c == 1), m2 = __ballot(c == 2), m3 = __ballot(c == 3);
+        if (c == 0) dst[P.kbeg + r0 + __popcll(m0 & below)] = k;
+        else if (c == 1) dst[P.kbeg + o1 + r1 + __popcll(m1 & below)] = k;
+        else if (c == 2) dst[P.kbeg + o2 + r2 + __popcll(m2 & below)] = k;
+        else if (c == 3) dst[P.kbeg + o3 + r3 + __popcll(m3 & below)] = k;
+        r0 += __popcll(m0); r1 += __popcll(m1); r2 += __popcll(m2); r3 += __popcll(m3);
+    }
+    cnt[0] = c0; cnt[1] = c1; cnt[2] = c2; cnt[3] = c3;
+}
+
+__device__ inline qnode qt_child(const qnode& P, int c, const int* cnt)
+{
+    const int mx = P.x0 + (int)ceilf((float)(P.x1 - P.x0) / 2), my = P.y0 + (int)ceilf((float)(P.y1 - P.y0) / 2);
+    qnode q;
+    q.x0 = (c & 1) ? mx : P.x0; q.x1 = (c & 1) ? P.x1 : mx;
+    q.y0 = (c & 2) ? my : P.y0; q.y1 = (c & 2) ? P.y1 : my;
+    int off = 0;
+    for (int k = 0; k < c; ++k) off += cnt[k];
+    q.kbeg = P.kbeg + off; q.kcnt = cnt[c]; q.buf = P.buf ^ 1; q.leaf = cnt[c] == 1;
+    return q;
+}
+
+// work layout per instance (ints): pool (qnode x pool_cap) | listA listB parents exp order flags (cap each) | pcnt[4*cap]
+__global__ __launch_bounds__(256) void quadtree_kernel(const qt_inst* __restrict__ tab)
+{
+    __shared__ int s_w[4];
+    __shared__ int s_S, s_pool, s_np, s_nexp, s_done, s_phase2, s_t;
+    const qt_inst I = tab[blockIdx.x];
+    const int n = I.offs[I.cell_end] - I.offs[I.cell_begin];
+    const int base = I.offs[I.cell_begin];
+    const float* xs = I.xs + base; const float* ys = I.ys + base; const float* rs = I.rs + base;
+    int* out = I.out_idx; int* out_n = I.out_n;
+    if (n <= 0) { if (threadIdx.x == 0) *out_n = 0; return; }
+    const int cap = I.list_cap, pool_cap = I.pool_cap, N = I.quota;
+    int* keys0 = I.keys0 + base; int* keys1 = I.keys1 + base;        // frame-wide key arrays, this level's segment
+    qnode* pool = reinterpret_cast<qnode*>(I.work);
+    int* listA = reinterpret_cast<int*>(pool + pool_cap); int* listB = listA + cap;
+    int* parents = listB + cap; int* expv = parents + cap; int* order = expv + cap; int* flags = order + cap; int* pcnt = flags + cap;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+
+    // ---- initial nodes (:543-585)
+    int nIni = (int)roundf((float)I.W / (float)I.H);
+    if (nIni < 1) nIni = 1;
+    if (nIni > 32) nIni = 32;
+    const float hX = (float)I.W / nIni;
+    if (nIni == 1) { for (int i = threadIdx.x; i < n; i += 256) keys0[i] = i; }
+    else if (wv == 0) {                              // stable partition of 0..n-1 by root index, one wave
+        int off = 0;
+        for (int r = 0; r < nIni; ++r) {
+            int run = 0;
+            for (int b = 0; b < n; b += 64) {
+                const int i = b + lane;
+                bool in = false;
+                if (i < n) { int w = (int)(xs[i] / hX); if (w >= nIni) w = nIni - 1; in = (w == r); }
+                const unsigned long long m = __ballot(in);
+                if (in) keys0[off + run + __popcll(m & ((1ull << lane) - 1ull))] = i;
+                run += __popcll(m);
+            }
+            if (lane == 0) pcnt[r] = run;
+            off += run;
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int S = 0, off = 0;
+        for (int r = 0; r < nIni; ++r) {
+            const int c = nIni == 1 ? n : pcnt[r];
+            qnode q; q.x0 = (int)(hX * (float)r); q.x1 = (int)(hX * (float)(r + 1)); q.y0 = 0; q.y1 = I.H;
+            q.kbeg = off; q.kcnt = c; q.buf = 0; q.leaf = c == 1;
+            off += c;
+            pool[r] = q;
+            if (c > 0) listA[S++] = r;              // empty roots are erased (:581-582)
+        }
+        s_S = S; s_pool = nIni; s_done = 0; s_phase2 = 0; s_nexp = 0;
+    }
+    __syncthreads();
+    int* L = listA; int* Ln = listB;
+
+    // ---- whole-list passes (:594-672)
+    while (true) {
+        const int S = s_S;
+        // non-leaf nodes in list order -> parents[], leaves keep their relative order
+        int np = 0, nl = 0;
+        for (int b = 0; b < S; b += 256) {
+            const int i = b + threadIdx.x;
+            const int id = i < S ? L[i] : -1;
+            const int isp = (id >= 0 && !pool[id].leaf) ? 1 : 0, isl = (id >= 0 && pool[id].leaf) ? 1 : 0;
+            int tp, tl;
+            const int rp = qt_block_scan(isp, &tp, s_w), rl = qt_block_scan(isl, &tl, s_w);
+            if (isp) parents[np + rp] = id;
+            if (isl) flags[nl + rl] = id;            // flags[] doubles as the leaf list here
+            np += tp; nl += tl;
+        }
+        __syncthreads();
+        if (np == 0) break;                          // every node holds one point: size == prevSize
+        if (s_pool + 4 * np > pool_cap) { if (threadIdx.x == 0) *I.err = 1; break; }
+        for (int r = wv; r < np; r += 4) {
+            int cnt[4];
+            qt_divide_wave(pool[parents[r]], xs, ys, keys0, keys1, cnt);
+            if (lane == 0) { pcnt[4 * r] = cnt[0]; pcnt[4 * r + 1] = cnt[1]; pcnt[4 * r + 2] = cnt[2]; pcnt[4 * r + 3] = cnt[3]; }
+        }
+        __syncthreads();
+        // children in creation order: parents in list order, n1..n4, empty ones skipped
+        int Cn = 0, nexp = 0;
+        const int pool0 = s_pool;
+        for (int b = 0; b < np; b += 256) {
+            const int r = b + threadIdx.x;
+            int ne = 0, nx = 0, cnt[4] = { 0, 0, 0, 0 };
+            if (r < np) for (int c = 0; c < 4; ++c) { cnt[c] = pcnt[4 * r + c]; ne += cnt[c] > 0; nx += cnt[c] > 1; }
+            int te, tx;
+            const int qe = qt_block_scan(ne, &te, s_w), qx = qt_block_scan(nx, &tx, s_w);
+            if (r < np) {
+                const qnode P = pool[parents[r]];
+                int q = Cn + qe, x = nexp + qx;
+                for (int c = 0; c < 4; ++c) if (cnt[c] > 0) {
+                    pool[pool0 + q] = qt_child(P, c, cnt);
+                    if (cnt[c] > 1) expv[x++] = pool0 + q;
+                    ++q;
+                }
+            }
+            Cn += te; nexp += tx;
+        }
+        __syncthreads();
+        const int Snew = Cn + nl;
+        if (Snew > cap) { if (threadIdx.x == 0) *I.err = 2; break; }
+        for (int i = threadIdx.x; i < Cn; i += 256) Ln[Cn - 1 - i] = pool0 + i;      // push_front order
+        for (int i = threadIdx.x; i < nl; i += 256) Ln[Cn + i] = flags[i];
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            s_pool = pool0 + Cn; s_nexp = nexp;
+            if (Snew >= N || Snew == S) s_done = 1;
+            else if (Snew + nexp * 3 > N) s_phase2 = 1;
+            s_S = Snew;
+        }
+        { int* t = L; L = Ln; Ln = t; }
+        __syncthreads();
+        if (s_done || s_phase2) break;
+    }
+
+    // ---- size-ordered refinement (:673-738)
+    while (s_phase2 && !s_done) {
+        const int S = s_S, m = s_nexp, pool0 = s_pool;
+        if (m == 0) break;
+        if (pool0 + 4 * m > pool_cap) { if (threadIdx.x == 0) *I.err = 1; break; }
+        // processing order: descending (size, creation order)
+        for (int e = threadIdx.x; e < m; e += 256) {
+            const int id = expv[e], sz = pool[id].kcnt;
+            int rank = 0;
+            for (int f = 0; f < m; ++f) { const int id2 = expv[f], s2 = pool[id2].kcnt; rank += (s2 > sz) || (s2 == sz && id2 > id); }
+            order[rank] = id;
+        }
+        __syncthreads();
+        for (int r = wv; r < m; r += 4) {            // divide all of them; only the first t+1 take effect
+            int cnt[4];
+            qt_divide_wave(pool[order[r]], xs, ys, keys0, keys1, cnt);
+            if (lane == 0) { pcnt[4 * r] = cnt[0]; pcnt[4 * r + 1] = cnt[1]; pcnt[4 * r + 2] = cnt[2]; pcnt[4 * r + 3] = cnt[3]; }
+        }
+        if (threadIdx.x == 0) s_t = m - 1;
+        __syncthreads();
+        // running node count; the reference breaks once it reaches the quota (:730-731)
+        int run = S;
+        for (int b = 0; b < m; b += 256) {
+            const int r = b + threadIdx.x;
+            int d = 0;
+            if (r < m) { for (int c = 0; c < 4; ++c) d += pcnt[4 * r + c] > 0; d -= 1; }
+            int td;
+            const int ex = qt_block_scan(d, &td, s_w);
+            if (r < m && run + ex + d >= N) atomicMin(&s_t, r);
+            run += td;
+            __syncthreads();
+        }
+        __syncthreads();
+        const int t = s_t;                           // parents order[0..t] are divided
+        int Cn = 0, nexp = 0;
+        for (int b = 0; b <= t; b += 256) {
+            const int r = b + threadIdx.x;
+            int ne = 0, nx = 0, cnt[4] = { 0, 0, 0, 0 };
+            if (r <= t) for (int c = 0; c < 4; ++c) { cnt[c] = pcnt[4 * r + c]; ne += cnt[c] > 0; nx += cnt[c] > 1; }
+            int te, tx;
+            const int qe = qt_block_scan(ne, &te, s_w), qx = qt_block_scan(nx, &tx, s_w);
+            if (r <= t) {
+                const qnode P = pool[order[r]];
+                int q = Cn + qe, x = nexp + qx;
+                for (int c = 0; c < 4; ++c) if (cnt[c] > 0) {
+                    pool[pool0 + q] = qt_child(P, c, cnt);
+                    if (cnt[c] > 1) parents[x++] = pool0 + q;     // next round's expandables (parents[] is free here)
+                    ++q;
+                }
+                pool[order[r]].kcnt = -1;                          // erased (:728)
+            }
+            Cn += te; nexp += tx;
+        }
+        __syncthreads();
+        // new list = reverse(children) ++ old list without the divided parents
+        int kept = 0;
+        for (int b = 0; b < S; b += 256) {
+            const int i = b + threadIdx.x;
+            const int id = i < S ? L[i] : -1;
+            const int keep = (id >= 0 && pool[id].kcnt >= 0) ? 1 : 0;
+            int tk;
+            const int rk = qt_block_scan(keep, &tk, s_w);
+            if (keep) { if (Cn + kept + rk < cap) Ln[Cn + kept + rk] = id; }
+            kept += tk;
+        }
+        const int Snew = Cn + kept;
+        if (Snew > cap) { if (threadIdx.x == 0) *I.err = 2; break; }
+        for (int i = threadIdx.x; i < Cn; i += 256) Ln[Cn - 1 - i] = pool0 + i;
+        __syncthreads();
+        for (int i = threadIdx.x; i < nexp; i += 256) expv[i] = parents[i];
+        if (threadIdx.x == 0) {
+            s_pool = pool0 + Cn; s_nexp = nexp; s_S = Snew;
+            if (Snew >= N || Snew == S) s_done = 1;
+        }
+        { int* tt = L; L = Ln; Ln = tt; }
+        __syncthreads();
+    }
+    __syncthreads();
+
+    // ---- retain the best point of each node, list order (:741-760): first maximum response in key order
+    const int S = s_S;
+    for (int i = threadIdx.x; i < S; i += 256) {
+        const qnode q = pool[L[i]];
+        const int* kk = (q.buf ? keys1 : keys0) + q.kbeg;
+        int best = kk[0]; float r = rs[best];
+        for (int k = 1; k < q.kcnt; ++k) { const int c = kk[k]; const float v = rs[c]; if (v > r) { best = c; r = v; } }
+        if (i < I.out_cap) out[i] = base + best;
+    }
+    if (threadIdx.x == 0) { *out_n = S < I.out_cap ? S : I.out_cap; if (S > I.out_cap) *I.err = 3; }
+}
+
+// concatenate the kept candidates of the levels of one frame into kp_in records (ORBextractor.cpp:840-847,1082-1111)
+__global__ __launch_bounds__(256) void quadtree_collect_kernel(const qt_frame* __restrict__ tab)
+{
+    const qt_frame Fm = tab[blockIdx.x];
+    int off = 0;
+    for (int l = 0; l < Fm.nlevels; ++l) {
+        const int cnt = Fm.out_n[l];
+        const int* idx = Fm.out_idx + (size_t)l * Fm.out_cap;
+        for (int i = threadIdx.x; i < cnt; i += 256) {
+            if (off + i >= Fm.kcap) break;
+            const int c = idx[i];
+            qt_kp_in q;
+            q.x = Fm.xs[c] + (float)Fm.min_border; q.y = Fm.ys[c] + (float)Fm.min_border; q.resp = Fm.rs[c]; q.level = l;
+            Fm.kin[off + i] = q;
+        }
+        off += cnt;
+    }
+    if (threadIdx.x == 0) { if (off > Fm.kcap) { *Fm.err = 4; off = Fm.kcap; } *Fm.nk = off; }
+}
+
+void dsss_launch_quadtree(hipStream_t st, const qt_inst* d_inst, int ninst, const qt_frame* d_frames, int nframes)
+{
+    if (ninst > 0) hipLaunchKernelGGL(quadtree_kernel, dim3(ninst), dim3(256), 0, st, d_inst);
+    if (nframes > 0) hipLaunchKernelGGL(quadtree_collect_kernel, dim3(nframes), dim3(256), 0, st, d_frames);
+}

@@ -85,8 +85,9 @@ int dsss_frame_get_norm(dsss_ctx*, int id, uint8_t* norm_host, uint8_t* mask_hos
 int dsss_frame_get_level(dsss_ctx*, int id, int level, uint8_t* img_host, int* rows, int* cols);/* mvImagePyramid[level] */
 int dsss_frame_get_candidates(dsss_ctx*, int id, int level, float* x_host, float* y_host, float* resp_host,
                               int cap, int* n);                                                /* vToDistributeKeys */
-/* ORBextractor::DistributeOctTree (ORBextractor.cpp:539-763): HOST routine (sequential, order dependent), exposed
- * so the CPU test-suite can check it against the oracle without a GPU.  keep_idx_host needs n entries.          */
+/* ORBextractor::DistributeOctTree (ORBextractor.cpp:539-763) as a HOST routine: the hot path runs the device version
+ * (dsss_quadtree.hip); this one exists so the CPU test-suite can pin the list semantics against the oracle without a
+ * GPU.  keep_idx_host needs n entries.                                                                          */
 int dsss_host_quadtree(const float* x_host, const float* y_host, const float* resp_host, int n,
                        int minX, int maxX, int minY, int maxY, int quota, int32_t* keep_idx_host, int* n_keep);
 /* Frame::kps / Frame::dst (+ the geo_img samples FEAmatcher.cpp:81-82 reads) */
@@ -148,6 +149,7 @@ int dsss_posegraph_solve_edges(dsss_ctx*, const double* dr6, int total, const ds
 #define DSSS_K_ROWS        10   /* pair_rows count/scan/write */
 #define DSSS_K_LC          11   /* lc_kernel */
 #define DSSS_K_PG          12   /* pose-graph LM loop (all its kernels) */
+#define DSSS_K_QUADTREE    13   /* quadtree_kernel + collect (K4 on the device) */
 #define DSSS_K_COUNT       16
 int dsss_profile_enable(dsss_ctx*, int on);
 int dsss_profile_get(dsss_ctx*, double* ms_host /*DSSS_K_COUNT*/, int64_t* launches_host /*DSSS_K_COUNT*/);
