@@ -19,6 +19,7 @@
 #include <numeric>
 #include <random>
 #include <cstdlib>
+#include <chrono>
 
 // ------------------------------------------------------------------ small dense helpers (6x6 row-major)
 __device__ inline int chol6(double* A)
@@ -122,7 +123,7 @@ __global__ __launch_bounds__(256) void pg_final_sum_kernel(const double* __restr
 // pose's incidence list in a fixed order (no atomics).
 __global__ __launch_bounds__(256) void pg_assemble_kernel(int n, pg_weights W, const double* __restrict__ r, const double* __restrict__ Ji,
                                                           const int* __restrict__ adj_ptr, const int* __restrict__ adj_edge,
-                                                          const double* __restrict__ ew, double lambda,
+                                                          const double* __restrict__ ew, const double* __restrict__ lambda_ptr,
                                                           double* __restrict__ D, double* __restrict__ C, double* __restrict__ g)
 {
     const int i = blockIdx.x * 256 + threadIdx.x;
@@ -163,6 +164,7 @@ __global__ __launch_bounds__(256) void pg_assemble_kernel(int n, pg_weights W, c
             }
         }
     }
+    const double lambda = *lambda_ptr;
     for (int a = 0; a < 6; ++a) Dd[a * 6 + a] += lambda;
     for (int a = 0; a < 36; ++a) { D[(size_t)i * 36 + a] = Dd[a]; C[(size_t)i * 36 + a] = Cc[a]; }
     for (int a = 0; a < 6; ++a) g[(size_t)i * 6 + a] = gg[a];
@@ -305,9 +307,11 @@ __global__ __launch_bounds__(256) void pg_build_map_kernel(int nupd, const int* 
 __global__ __launch_bounds__(256) void pg_factor_acc_kernel(const int* __restrict__ lvcols, const int* __restrict__ colptr,
                                                             const int* __restrict__ rlptr, const int* __restrict__ rlpos,
                                                             const long long* __restrict__ mapptr, const int* __restrict__ upd_map,
-                                                            double* __restrict__ Lvals, double* __restrict__ part, int col_stride)
+                                                            double* __restrict__ Lvals, double* __restrict__ part, int col_stride,
+                                                            const int* __restrict__ rlcol, double* __restrict__ x)
 {
     __shared__ double s_Ljk[PG_TCH * 36];
+    __shared__ double s_yk[PG_TCH * 6];
     const int j = lvcols[blockIdx.x];
     const int c0 = colptr[j], m = colptr[j + 1] - c0;
     if ((int)blockIdx.y * 256 >= 6 * m) return;
@@ -320,11 +324,22 @@ __global__ __launch_bounds__(256) void pg_factor_acc_kernel(const int* __restric
     const bool act = idx < 6 * m;
     const int q = act ? idx / 6 : 0, r = idx - q * 6;
     double acc[6] = { 0, 0, 0, 0, 0, 0 };
+    // forward substitution fused in: the right-hand side is one more block row of the column, y_j -= sum_k L(j,k) y_k
+    const bool rhs = blockIdx.y == 0 && threadIdx.x >= 250;
+    const int rs_ = threadIdx.x - 250;
+    double accy = 0;
     for (int tc = ta; tc < tb; tc += PG_TCH) {
         const int tn = min(PG_TCH, tb - tc);
         __syncthreads();
-        for (int x = threadIdx.x; x < tn * 36; x += 256) s_Ljk[x] = Lvals[(size_t)rlpos[t0 + tc + x / 36] * 36 + (x % 36)];
+        for (int xx = threadIdx.x; xx < tn * 36; xx += 256) s_Ljk[xx] = Lvals[(size_t)rlpos[t0 + tc + xx / 36] * 36 + (xx % 36)];
+        if (blockIdx.y == 0) for (int xx = threadIdx.x; xx < tn * 6; xx += 256) s_yk[xx] = x[(size_t)rlcol[t0 + tc + xx / 6] * 6 + (xx % 6)];
         __syncthreads();
+        if (rhs)
+            for (int t = 0; t < tn; ++t) {
+                const double* yk = s_yk + t * 6;
+                const double* B = s_Ljk + t * 36 + rs_ * 6;
+                accy += B[0] * yk[0] + B[1] * yk[1] + B[2] * yk[2] + B[3] * yk[3] + B[4] * yk[4] + B[5] * yk[5];
+            }
         if (act)
             for (int t = 0; t < tn; ++t) {
                 const int pos = mp[(size_t)(tc + t) * m + q];
@@ -337,21 +352,26 @@ __global__ __launch_bounds__(256) void pg_factor_acc_kernel(const int* __restric
                     acc[s] += a0 * B[s * 6] + a1 * B[s * 6 + 1] + a2 * B[s * 6 + 2] + a3 * B[s * 6 + 3] + a4 * B[s * 6 + 4] + a5 * B[s * 6 + 5];
             }
     }
+    if (rhs) {
+        if (nsl == 1) x[(size_t)j * 6 + rs_] -= accy;
+        else part[((size_t)blockIdx.x * nsl + sl) * col_stride + (size_t)col_stride - 8 + rs_] = accy;
+    }
     if (!act) return;
     if (nsl == 1) { for (int s = 0; s < 6; ++s) Lvals[(size_t)(c0 + q) * 36 + r * 6 + s] -= acc[s]; }
     else { double* o = part + ((size_t)blockIdx.x * nsl + sl) * col_stride + (size_t)idx * 6; for (int s = 0; s < 6; ++s) o[s] = acc[s]; }
 }
-// (fold the partial sums,) factor the diagonal block, then L(i, j) = A(i, j) L_jj^-T along each row
+// (fold the partial sums,) factor the diagonal block, L(i, j) = A(i, j) L_jj^-T along each row, y_j = L_jj^-1 y_j.
+// One wave per column for narrow columns, four for wide ones (the launch picks the block size per level).
 __global__ __launch_bounds__(256) void pg_factor_fin_kernel(const int* __restrict__ lvcols, const int* __restrict__ colptr,
-                                                            double* __restrict__ Lvals, const double* __restrict__ part, int nsl,
-                                                            int col_stride, int* __restrict__ fail)
+                                                           double* __restrict__ Lvals, const double* __restrict__ part, int nsl,
+                                                           int col_stride, double* __restrict__ x, int* __restrict__ fail)
 {
     __shared__ double s_diag[36];
     __shared__ int s_ok;
     const int j = lvcols[blockIdx.x];
     const int c0 = colptr[j], m = colptr[j + 1] - c0;
     if (nsl > 1) {
-        for (int idx = threadIdx.x; idx < 6 * m; idx += 256) {
+        for (int idx = threadIdx.x; idx < 6 * m; idx += blockDim.x) {
             double* row = Lvals + (size_t)c0 * 36 + (size_t)idx * 6;
             double v[6];
             for (int s = 0; s < 6; ++s) v[s] = row[s];
@@ -360,6 +380,11 @@ __global__ __launch_bounds__(256) void pg_factor_fin_kernel(const int* __restric
                 for (int s = 0; s < 6; ++s) v[s] -= o[s];
             }
             for (int s = 0; s < 6; ++s) row[s] = v[s];
+        }
+        if (threadIdx.x < 6) {
+            double v = x[(size_t)j * 6 + threadIdx.x];
+            for (int sl = 0; sl < nsl; ++sl) v -= part[((size_t)blockIdx.x * nsl + sl) * col_stride + (size_t)col_stride - 8 + threadIdx.x];
+            x[(size_t)j * 6 + threadIdx.x] = v;
         }
         __syncthreads();
     }
@@ -370,39 +395,22 @@ __global__ __launch_bounds__(256) void pg_factor_fin_kernel(const int* __restric
         if (bad) *fail = 1;
         s_ok = !bad;
         for (int a = 0; a < 6; ++a) for (int b = 0; b < 6; ++b) { const double v = b <= a ? A[a * 6 + b] : 0.0; s_diag[a * 6 + b] = v; Lvals[(size_t)c0 * 36 + a * 6 + b] = v; }
+        if (!bad) {
+            double v[6];
+            for (int a = 0; a < 6; ++a) { double t = x[(size_t)j * 6 + a]; for (int b = 0; b < a; ++b) t -= A[a * 6 + b] * v[b]; v[a] = t / A[a * 6 + a]; }
+            for (int a = 0; a < 6; ++a) x[(size_t)j * 6 + a] = v[a];
+        }
     }
     __syncthreads();
     if (!s_ok) return;
-    for (int idx = 6 + threadIdx.x; idx < 6 * m; idx += 256) {
+    for (int idx = 6 + threadIdx.x; idx < 6 * m; idx += blockDim.x) {
         double* row = Lvals + (size_t)(c0 + idx / 6) * 36 + (idx % 6) * 6;
-        double x[6];
-        for (int s = 0; s < 6; ++s) { double v = row[s]; for (int c = 0; c < s; ++c) v -= x[c] * s_diag[s * 6 + c]; x[s] = v / s_diag[s * 6 + s]; }
-        for (int s = 0; s < 6; ++s) row[s] = x[s];
+        double xr[6];
+        for (int s = 0; s < 6; ++s) { double v = row[s]; for (int c = 0; c < s; ++c) v -= xr[c] * s_diag[s * 6 + c]; xr[s] = v / s_diag[s * 6 + s]; }
+        for (int s = 0; s < 6; ++s) row[s] = xr[s];
     }
 }
 
-// y_j = L_jj^-1 (b_j - sum_k L(j,k) y_k): one wave per column
-__global__ __launch_bounds__(64) void pg_fwd_level_kernel(const int* __restrict__ lvcols, const int* __restrict__ colptr,
-                                                          const int* __restrict__ rlptr, const int* __restrict__ rlcol, const int* __restrict__ rlpos,
-                                                          const double* __restrict__ Lvals, double* __restrict__ x)
-{
-    const int j = lvcols[blockIdx.x];
-    const int lane = threadIdx.x;
-    double acc[6] = { 0, 0, 0, 0, 0, 0 };
-    for (int t = rlptr[j] + lane; t < rlptr[j + 1]; t += 64) {
-        const double* B = Lvals + (size_t)rlpos[t] * 36; const double* y = x + (size_t)rlcol[t] * 6;
-        for (int a = 0; a < 6; ++a) { double s = 0; for (int b = 0; b < 6; ++b) s += B[a * 6 + b] * y[b]; acc[a] += s; }
-    }
-    for (int a = 0; a < 6; ++a)
-#pragma unroll
-        for (int o = 32; o >= 1; o >>= 1) acc[a] += __shfl_xor(acc[a], o, 64);
-    if (lane == 0) {
-        const double* Ld = Lvals + (size_t)colptr[j] * 36;
-        double v[6];
-        for (int a = 0; a < 6; ++a) { double s = x[(size_t)j * 6 + a] - acc[a]; for (int b = 0; b < a; ++b) s -= Ld[a * 6 + b] * v[b]; v[a] = s / Ld[a * 6 + a]; }
-        for (int a = 0; a < 6; ++a) x[(size_t)j * 6 + a] = v[a];
-    }
-}
 // x_j = L_jj^-T (y_j - sum_{i > j} L(i,j)^T x_i)
 __global__ __launch_bounds__(64) void pg_bwd_level_kernel(const int* __restrict__ lvcols, const int* __restrict__ colptr,
                                                           const int* __restrict__ rowidx, const double* __restrict__ Lvals, double* __restrict__ x)
@@ -487,6 +495,111 @@ __global__ __launch_bounds__(256) void pg_retract_kernel(int n, const pose_t* __
     pose_t o;
     pose_retract(&X[i], delta + (size_t)i * 6, &o);
     Xn[i] = o;
+}
+
+// ------------------------------------------------------------------ initial values on the device
+// std::default_random_engine (minstd_rand0, seed 1) + std::normal_distribution<double> (libstdc++ Marsaglia polar,
+// optimizer.cpp:30-31,154-158) without the sequential dependency: polar attempt a always consumes engine outputs
+// 4a+1 .. 4a+4 (two generate_canonical calls of two engine calls each), so every attempt is evaluated independently
+// after an O(log a) jump-ahead of the LCG; accepted attempts are compacted in order and each yields (y*mult, x*mult).
+__device__ inline unsigned long long minstd_pow(unsigned long long e)
+{
+    unsigned long long r = 1, b = 16807ULL;
+    const unsigned long long m = 2147483647ULL;
+    while (e) { if (e & 1) r = (r * b) % m; b = (b * b) % m; e >>= 1; }
+    return r;
+}
+#define RNG_PER_THREAD 16
+__global__ __launch_bounds__(256) void pg_rng_attempts_kernel(long long nattempts, double* __restrict__ pairs, int* __restrict__ flags)
+{
+    const long long a0 = ((long long)blockIdx.x * 256 + threadIdx.x) * RNG_PER_THREAD;
+    if (a0 >= nattempts) return;
+    const unsigned long long m = 2147483647ULL;
+    unsigned long long x = minstd_pow((unsigned long long)(4 * a0));        // state after 4*a0 engine calls (seed 1)
+    const double R = 2147483646.0;
+    for (int k = 0; k < RNG_PER_THREAD && a0 + k < nattempts; ++k) {
+        double cn[2];
+        for (int q = 0; q < 2; ++q) {
+            x = (x * 16807ULL) % m; const double e1 = (double)(x - 1);
+            x = (x * 16807ULL) % m; const double e2 = (double)(x - 1);
+            double can = (e1 + e2 * R) / (R * R);
+            if (can >= 1.0) can = 0.99999999999999988897769753748;   // nextafter(1, 0)
+            cn[q] = can;
+        }
+        const double u = 2.0 * cn[0] - 1.0, v = 2.0 * cn[1] - 1.0, r2 = u * u + v * v;
+        const bool ok = !(r2 > 1.0 || r2 == 0.0);
+        double mult = 0;
+        if (ok) mult = sqrt(-2 * log(r2) / r2);
+        pairs[2 * (a0 + k)] = v * mult; pairs[2 * (a0 + k) + 1] = u * mult;
+        flags[a0 + k] = ok ? 1 : 0;
+    }
+}
+// exclusive scan of flags in three steps (block sums, scan of block sums by one block, compaction)
+__global__ __launch_bounds__(256) void pg_flag_blocksum_kernel(const int* __restrict__ flags, long long n, int* __restrict__ bsum)
+{
+    __shared__ int s_w[4];
+    const long long i0 = (long long)blockIdx.x * 4096;
+    int acc = 0;
+    for (int k = threadIdx.x; k < 4096; k += 256) if (i0 + k < n) acc += flags[i0 + k];
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) acc += __shfl_xor(acc, o, 64);
+    if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) bsum[blockIdx.x] = s_w[0] + s_w[1] + s_w[2] + s_w[3];
+}
+__global__ __launch_bounds__(256) void pg_flag_scan_kernel(int* __restrict__ bsum, int nb, int* __restrict__ total)
+{
+    if (threadIdx.x == 0) { int run = 0; for (int i = 0; i < nb; ++i) { const int v = bsum[i]; bsum[i] = run; run += v; } *total = run; }
+}
+__global__ __launch_bounds__(256) void pg_flag_compact_kernel(const int* __restrict__ flags, const double* __restrict__ pairs, long long n,
+                                                              const int* __restrict__ bsum, long long need_pairs, double* __restrict__ normals)
+{
+    __shared__ int s_w[4];
+    __shared__ int s_run;
+    const long long i0 = (long long)blockIdx.x * 4096;
+    if (threadIdx.x == 0) s_run = bsum[blockIdx.x];
+    __syncthreads();
+    for (int c = 0; c < 4096; c += 256) {
+        const long long i = i0 + c + threadIdx.x;
+        const int f = (i < n) ? flags[i] : 0;
+        const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+        int inc = f;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(inc, o, 64); if (lane >= o) inc += t; }
+        __syncthreads();
+        if (lane == 63) s_w[w] = inc;
+        __syncthreads();
+        int base = s_run;
+        for (int k = 0; k < w; ++k) base += s_w[k];
+        const long long pos = (long long)base + inc - f;
+        if (f && pos < need_pairs) { normals[2 * pos] = pairs[2 * i]; normals[2 * pos + 1] = pairs[2 * i + 1]; }
+        __syncthreads();
+        if (threadIdx.x == 0) s_run += s_w[0] + s_w[1] + s_w[2] + s_w[3];
+        __syncthreads();
+    }
+}
+// DR poses, odometry measurements and initial estimate (optimizer.cpp:150-200)
+__global__ __launch_bounds__(256) void pg_init_kernel(int n, const double* __restrict__ dr6, const double* __restrict__ normals, int add_noise,
+                                                      pose_t* __restrict__ X, pose_t* __restrict__ meas)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const double PI = DSSS_PI_REF;
+    pose_t cur, prev, m;
+    pose_from_rodrigues(dr6 + (size_t)i * 6, &cur);
+    if (i == 0) m = cur;
+    else { pose_from_rodrigues(dr6 + (size_t)(i - 1) * 6, &prev); pose_between(&prev, &cur, &m); }
+    meas[i] = m;
+    if (add_noise) {
+        const double* z = normals + (size_t)i * 6;
+        const double noise_xyz = 0.5, noise_rpy = 0.5 * PI / 180;
+        const double w[3] = { z[0] * noise_rpy, z[1] * noise_rpy, z[2] * noise_rpy };
+        pose_t N, o;
+        so3_exp(w, N.R);
+        N.t[0] = z[3] * noise_xyz; N.t[1] = z[4] * noise_xyz; N.t[2] = z[5] * noise_xyz;
+        pose_compose(&cur, &N, &o);
+        X[i] = o;
+    } else X[i] = cur;
 }
 
 // ------------------------------------------------------------------ host: ordering + symbolic analysis
@@ -619,29 +732,14 @@ static int pg_solve_impl(dsss_ctx* c, const double* dr6, int total, const dsss_l
 {
     const int n = total;
     if (n < 2) DSSS_FAIL(c, DSSS_E_ARG, "pose graph needs at least 2 poses");
+    const auto T0 = std::chrono::steady_clock::now();
+    auto ms_since = [&](std::chrono::steady_clock::time_point t) { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t).count(); };
     const double PI = DSSS_PI_REF;
     pg_weights W;
     { const double wgt1 = 0.001, wgt2 = 10;                                   // optimizer.cpp:24,28
       const double so[6] = { wgt1 * PI / 180, wgt1 * PI / 180, 0.1 * wgt1 * wgt2 * PI / 180, wgt1 * wgt2, wgt1 * wgt2, wgt1 };
       for (int k = 0; k < 6; ++k) { W.prior[k] = 1.0 / 0.000001; W.odo[k] = 1.0 / so[k]; } }
-    // host-side preparation: DR poses, measurements, initial values (optimizer.cpp:150-160)
-    std::vector<pose_t> DR(n), X0(n), meas(n);
-    for (int i = 0; i < n; ++i) pose_from_rodrigues(dr6 + (size_t)i * 6, &DR[i]);
-    if (c->pg.add_noise) {
-        std::default_random_engine generator;                                  // optimizer.cpp:30-31
-        std::normal_distribution<double> distribution(0.0, 1.0);
-        const double noise_xyz = 0.5, noise_rpy = 0.5 * PI / 180;
-        for (int i = 0; i < n; ++i) {
-            double z[6];
-            for (int k = 0; k < 6; ++k) z[k] = distribution(generator);
-            const double w[3] = { z[0] * noise_rpy, z[1] * noise_rpy, z[2] * noise_rpy };
-            pose_t N; so3_exp(w, N.R);
-            N.t[0] = z[3] * noise_xyz; N.t[1] = z[4] * noise_xyz; N.t[2] = z[5] * noise_xyz;
-            pose_compose(&DR[i], &N, &X0[i]);
-        }
-    } else X0 = DR;
-    meas[0] = DR[0];
-    for (int i = 1; i < n; ++i) pose_between(&DR[i - 1], &DR[i], &meas[i]);
+    // DR poses, measurements and initial values are produced on the device (pg_init_kernel) further down
     std::vector<int> ea(ne), eb(ne); std::vector<pose_t> emeas(ne); std::vector<double> ew((size_t)ne * 6);
     for (int e = 0; e < ne; ++e) {
         ea[e] = edges[e].a; eb[e] = edges[e].b;
@@ -671,9 +769,13 @@ static int pg_solve_impl(dsss_ctx* c, const double* dr6, int total, const dsss_l
     for (int k = 0; k + 1 < ns; ++k) redges.push_back({ k, k + 1 });
     for (int e = 0; e < ne; ++e) redges.push_back({ sidx[ea[e]], sidx[eb[e]] });
     std::vector<double> cx(ns), cy(ns);
-    for (int k = 0; k < ns; ++k) { cx[k] = DR[sep_pose[k]].t[0]; cy[k] = DR[sep_pose[k]].t[1]; }
+    for (int k = 0; k < ns; ++k) { cx[k] = dr6[(size_t)sep_pose[k] * 6 + 3]; cy[k] = dr6[(size_t)sep_pose[k] * 6 + 4]; }
+    const double t_prep = ms_since(T0);
+    const auto T1 = std::chrono::steady_clock::now();
     sym_t S;
     symbolic(ns, redges, nseg, cx, cy, true, S);
+    const double t_sym = ms_since(T1);
+    const auto T2 = std::chrono::steady_clock::now();
     const int nlev = (int)S.lvptr.size() - 1;
     const size_t nnzL = S.rowidx.size();
     std::vector<int> lv_chunks(nlev, 1), lv_upd(nlev, 0), lv_slices(nlev, 1);
@@ -689,7 +791,7 @@ static int pg_solve_impl(dsss_ctx* c, const double* dr6, int total, const dsss_l
         const int ncl = S.lvptr[l + 1] - S.lvptr[l];
         // few wide columns near the root: slice their update lists over more workgroups
         if (ncl <= 64 && maxT > 48) lv_slices[l] = std::min(16, (maxT + 31) / 32);
-        if (lv_slices[l] > 1) part2_doubles = std::max(part2_doubles, (size_t)ncl * lv_slices[l] * lv_chunks[l] * 256 * 6);
+        if (lv_slices[l] > 1) part2_doubles = std::max(part2_doubles, (size_t)ncl * lv_slices[l] * ((size_t)lv_chunks[l] * 256 * 6 + 8));
     }
     const bool verbose = getenv("DSSS_PG_VERBOSE") != nullptr;
     if (verbose) {
@@ -705,7 +807,7 @@ static int pg_solve_impl(dsss_ctx* c, const double* dr6, int total, const dsss_l
     int *d_colptr, *d_rowidx, *d_rlptr, *d_rlcol, *d_rlpos, *d_rlrow, *d_lvcols, *d_diag, *d_ch, *d_lc, *d_fail, *d_map; long long* d_mapptr;
     const int nf = n + ne, nblk = (nf + 255) / 256;
 #define TRY(x) do { rc = (x); if (rc) { dv.release(); return rc; } } while (0)
-    TRY(dv.upload(c, &d_X, X0)); TRY(dv.alloc(c, &d_Xn, n)); TRY(dv.upload(c, &d_meas, meas)); TRY(dv.upload(c, &d_emeas, emeas));
+    TRY(dv.alloc(c, &d_X, n)); TRY(dv.alloc(c, &d_Xn, n)); TRY(dv.alloc(c, &d_meas, n)); TRY(dv.upload(c, &d_emeas, emeas));
     TRY(dv.upload(c, &d_ea, ea)); TRY(dv.upload(c, &d_eb, eb)); TRY(dv.upload(c, &d_ew, ew));
     TRY(dv.upload(c, &d_adj_ptr, adj_ptr)); TRY(dv.upload(c, &d_adj_edge, adj_edge)); TRY(dv.upload(c, &d_sep, sep_pose)); TRY(dv.upload(c, &d_perm, S.perm));
     TRY(dv.alloc(c, &d_r, (size_t)nf * 6)); TRY(dv.alloc(c, &d_Ji, (size_t)nf * 36));
@@ -713,7 +815,7 @@ static int pg_solve_impl(dsss_ctx* c, const double* dr6, int total, const dsss_l
     TRY(dv.alloc(c, &d_E, (size_t)n * 36)); TRY(dv.alloc(c, &d_Dl, (size_t)n * 36)); TRY(dv.alloc(c, &d_gi, (size_t)n * 6));
     TRY(dv.alloc(c, &d_sDL, (size_t)nseg * 36)); TRY(dv.alloc(c, &d_sDR, (size_t)nseg * 36)); TRY(dv.alloc(c, &d_sGL, (size_t)nseg * 6));
     TRY(dv.alloc(c, &d_sGR, (size_t)nseg * 6)); TRY(dv.alloc(c, &d_sS, (size_t)nseg * 36));
-    TRY(dv.alloc(c, &d_L, nnzL * 36)); TRY(dv.alloc(c, &d_x, (size_t)ns * 6)); TRY(dv.alloc(c, &d_part, (size_t)nblk)); TRY(dv.alloc(c, &d_scal, 4)); TRY(dv.alloc(c, &d_fail, 1));
+    TRY(dv.alloc(c, &d_L, nnzL * 36)); TRY(dv.alloc(c, &d_x, (size_t)ns * 6)); TRY(dv.alloc(c, &d_part, (size_t)nblk)); TRY(dv.alloc(c, &d_scal, 8)); TRY(dv.alloc(c, &d_fail, 1));
     TRY(dv.upload(c, &d_colptr, S.colptr)); TRY(dv.upload(c, &d_rowidx, S.rowidx)); TRY(dv.upload(c, &d_rlptr, S.rlptr)); TRY(dv.upload(c, &d_rlcol, S.rlcol));
     TRY(dv.upload(c, &d_rlpos, S.rlpos)); TRY(dv.upload(c, &d_lvcols, S.lvcols)); TRY(dv.upload(c, &d_diag, S.diag_pos)); TRY(dv.upload(c, &d_ch, S.ch_pos)); TRY(dv.upload(c, &d_lc, S.lc_pos));
     TRY(dv.upload(c, &d_rlrow, S.rlrow)); TRY(dv.upload(c, &d_mapptr, S.mapptr));
@@ -729,44 +831,75 @@ static int pg_solve_impl(dsss_ctx* c, const double* dr6, int total, const dsss_l
         HCK(hipStreamSynchronize(st));
         return DSSS_OK;
     };
+    {   // initial values
+        double* d_dr6; double* d_norm = nullptr;
+        TRY(dv.alloc(c, &d_dr6, (size_t)n * 6));
+        HCK(hipMemcpyAsync(d_dr6, dr6, (size_t)n * 6 * sizeof(double), hipMemcpyHostToDevice, st));
+        if (c->pg.add_noise) {
+            const long long need_pairs = 3LL * n;
+            long long natt = (long long)(need_pairs * 1.32) + 4096;          // acceptance rate pi/4
+            for (int attempt = 0;; ++attempt) {
+                double* d_pairs; int* d_flags; int* d_bsum; int* d_total;
+                const int nb = (int)((natt + 4095) / 4096);
+                TRY(dv.alloc(c, &d_pairs, (size_t)natt * 2)); TRY(dv.alloc(c, &d_flags, (size_t)natt)); TRY(dv.alloc(c, &d_bsum, (size_t)nb)); TRY(dv.alloc(c, &d_total, 1));
+                if (!d_norm) TRY(dv.alloc(c, &d_norm, (size_t)need_pairs * 2));
+                const long long nthr = (natt + RNG_PER_THREAD - 1) / RNG_PER_THREAD;
+                hipLaunchKernelGGL(pg_rng_attempts_kernel, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, st, natt, d_pairs, d_flags);
+                hipLaunchKernelGGL(pg_flag_blocksum_kernel, dim3(nb), dim3(256), 0, st, d_flags, natt, d_bsum);
+                hipLaunchKernelGGL(pg_flag_scan_kernel, dim3(1), dim3(256), 0, st, d_bsum, nb, d_total);
+                hipLaunchKernelGGL(pg_flag_compact_kernel, dim3(nb), dim3(256), 0, st, d_flags, d_pairs, natt, d_bsum, need_pairs, d_norm);
+                int total_ok = 0;
+                HCK(hipMemcpyAsync(&total_ok, d_total, sizeof(int), hipMemcpyDeviceToHost, st));
+                HCK(hipStreamSynchronize(st));
+                if (total_ok >= need_pairs) break;
+                if (attempt > 3) { dv.release(); DSSS_FAIL(c, DSSS_E_NUMERIC, "normal generator: not enough accepted attempts"); }
+                natt *= 2;
+            }
+        }
+        hipLaunchKernelGGL(pg_init_kernel, dim3((n + 255) / 256), dim3(256), 0, st, n, d_dr6, d_norm, c->pg.add_noise, d_X, d_meas);
+    }
     HCK(hipMemsetAsync(d_map, 0xff, (size_t)std::max<long long>(mapsz, 1) * sizeof(int), st));
     { const int nupd = (int)S.rlcol.size();
       if (nupd > 0) hipLaunchKernelGGL(pg_build_map_kernel, dim3((nupd + 255) / 256), dim3(256), 0, st, nupd, d_rlrow, d_rlptr, d_rlcol, d_rlpos, d_colptr, d_rowidx, d_mapptr, d_map); }
+    const double t_up = ms_since(T2);
+    const auto T3 = std::chrono::steady_clock::now();
     dsss_scope sc(c, DSSS_K_PG);
     double lambda = c->pg.lambda0, err = 0, err0 = 0, cur = 0;
     int iters = 0, nfact = 0;
     TRY(error_of(d_X, &err));
     err0 = err;
-    if (err > 0) do {
+    if (err > 0 && c->pg.max_iters > 0) do {     // NonlinearOptimizer::defaultOptimize returns before iterating when maxIterations is reached
         cur = err;
         double oldLin = 0;
         hipLaunchKernelGGL(pg_linearize_kernel, dim3(nblk), dim3(256), 0, st, n, ne, d_X, d_meas, W, d_ea, d_eb, d_emeas, d_ew, d_r, d_Ji, d_part);
         hipLaunchKernelGGL(pg_final_sum_kernel, dim3(1), dim3(256), 0, st, d_part, nblk, 0.5, d_scal);
         HCK(hipMemcpyAsync(&oldLin, d_scal, sizeof(double), hipMemcpyDeviceToHost, st));
         for (;;) {
-            // ---- solve (H + lambda I) delta = -g
-            HCK(hipMemsetAsync(d_fail, 0, sizeof(int), st));
-            HCK(hipMemsetAsync(d_L, 0, nnzL * 36 * sizeof(double), st));
-            hipLaunchKernelGGL(pg_assemble_kernel, dim3((n + 255) / 256), dim3(256), 0, st, n, W, d_r, d_Ji, d_adj_ptr, d_adj_edge, d_ew, lambda, d_D, d_C, d_g);
-            hipLaunchKernelGGL(pg_segment_kernel, dim3((nseg + 63) / 64), dim3(64), 0, st, nseg, d_sep, d_D, d_C, d_g, d_E, d_Dl, d_gi, d_sDL, d_sDR, d_sGL, d_sGR, d_sS, d_fail);
-            hipLaunchKernelGGL(pg_scatter_base_kernel, dim3((ns + 255) / 256), dim3(256), 0, st, ns, d_sep, d_perm, d_D, d_g, d_sDL, d_sDR, d_sGL, d_sGR, d_sS, d_diag, d_ch, d_L, d_x);
-            if (ne > 0) hipLaunchKernelGGL(pg_scatter_lc_kernel, dim3((ne + 255) / 256), dim3(256), 0, st, n, ne, d_Ji, d_ew, d_lc, d_L);
-            for (int l = 0; l < nlev; ++l) {
-                const int ncl = S.lvptr[l + 1] - S.lvptr[l];
-                const int stride = lv_chunks[l] * 256 * 6;
-                if (lv_upd[l]) hipLaunchKernelGGL(pg_factor_acc_kernel, dim3(ncl, lv_chunks[l], lv_slices[l]), dim3(256), 0, st, d_lvcols + S.lvptr[l], d_colptr, d_rlptr, d_rlpos,
-                                                  d_mapptr, d_map, d_L, d_part2, stride);
-                hipLaunchKernelGGL(pg_factor_fin_kernel, dim3(ncl), dim3(256), 0, st, d_lvcols + S.lvptr[l], d_colptr, d_L, d_part2, lv_upd[l] ? lv_slices[l] : 1, stride, d_fail);
+            // ---- solve (H + lambda I) delta = -g ; lambda lives in device memory
+            HCK(hipMemcpyAsync(d_scal + 3, &lambda, sizeof(double), hipMemcpyHostToDevice, st));
+            {   // (a hipGraph of this sequence costs more to instantiate than the 5 replays of one solve save: measured)
+                hipMemsetAsync(d_fail, 0, sizeof(int), st);
+                hipMemsetAsync(d_L, 0, nnzL * 36 * sizeof(double), st);
+                hipLaunchKernelGGL(pg_assemble_kernel, dim3((n + 255) / 256), dim3(256), 0, st, n, W, d_r, d_Ji, d_adj_ptr, d_adj_edge, d_ew, d_scal + 3, d_D, d_C, d_g);
+                hipLaunchKernelGGL(pg_segment_kernel, dim3((nseg + 63) / 64), dim3(64), 0, st, nseg, d_sep, d_D, d_C, d_g, d_E, d_Dl, d_gi, d_sDL, d_sDR, d_sGL, d_sGR, d_sS, d_fail);
+                hipLaunchKernelGGL(pg_scatter_base_kernel, dim3((ns + 255) / 256), dim3(256), 0, st, ns, d_sep, d_perm, d_D, d_g, d_sDL, d_sDR, d_sGL, d_sGR, d_sS, d_diag, d_ch, d_L, d_x);
+                if (ne > 0) hipLaunchKernelGGL(pg_scatter_lc_kernel, dim3((ne + 255) / 256), dim3(256), 0, st, n, ne, d_Ji, d_ew, d_lc, d_L);
+                for (int l = 0; l < nlev; ++l) {      // factorisation with the forward substitution fused in
+                    const int ncl = S.lvptr[l + 1] - S.lvptr[l];
+                    const int stride = lv_chunks[l] * 256 * 6 + 8;
+                    if (lv_upd[l]) hipLaunchKernelGGL(pg_factor_acc_kernel, dim3(ncl, lv_chunks[l], lv_slices[l]), dim3(256), 0, st, d_lvcols + S.lvptr[l], d_colptr, d_rlptr, d_rlpos,
+                                                      d_mapptr, d_map, d_L, d_part2, stride, d_rlcol, d_x);
+                    hipLaunchKernelGGL(pg_factor_fin_kernel, dim3(ncl), dim3(lv_chunks[l] > 1 ? 256 : 64), 0, st, d_lvcols + S.lvptr[l], d_colptr, d_L, d_part2, lv_upd[l] ? lv_slices[l] : 1, stride, d_x, d_fail);
+                }
+                for (int l = nlev - 1; l >= 0; --l)
+                    hipLaunchKernelGGL(pg_bwd_level_kernel, dim3(S.lvptr[l + 1] - S.lvptr[l]), dim3(64), 0, st, d_lvcols + S.lvptr[l], d_colptr, d_rowidx, d_L, d_x);
+                hipLaunchKernelGGL(pg_sep_delta_kernel, dim3((ns + 255) / 256), dim3(256), 0, st, ns, d_sep, d_perm, d_x, d_delta);
+                hipLaunchKernelGGL(pg_backsub_kernel, dim3((nseg + 63) / 64), dim3(64), 0, st, nseg, d_sep, d_C, d_E, d_Dl, d_gi, d_delta);
+                hipLaunchKernelGGL(pg_linerr_kernel, dim3(nblk), dim3(256), 0, st, n, ne, W, d_ea, d_eb, d_ew, d_r, d_Ji, d_delta, d_part);
+                hipLaunchKernelGGL(pg_final_sum_kernel, dim3(1), dim3(256), 0, st, d_part, nblk, 0.5, d_scal + 1);
             }
             ++nfact;
-            for (int l = 0; l < nlev; ++l)
-                hipLaunchKernelGGL(pg_fwd_level_kernel, dim3(S.lvptr[l + 1] - S.lvptr[l]), dim3(64), 0, st, d_lvcols + S.lvptr[l], d_colptr, d_rlptr, d_rlcol, d_rlpos, d_L, d_x);
-            for (int l = nlev - 1; l >= 0; --l)
-                hipLaunchKernelGGL(pg_bwd_level_kernel, dim3(S.lvptr[l + 1] - S.lvptr[l]), dim3(64), 0, st, d_lvcols + S.lvptr[l], d_colptr, d_rowidx, d_L, d_x);
-            hipLaunchKernelGGL(pg_sep_delta_kernel, dim3((ns + 255) / 256), dim3(256), 0, st, ns, d_sep, d_perm, d_x, d_delta);
-            hipLaunchKernelGGL(pg_backsub_kernel, dim3((nseg + 63) / 64), dim3(64), 0, st, nseg, d_sep, d_C, d_E, d_Dl, d_gi, d_delta);
-            hipLaunchKernelGGL(pg_linerr_kernel, dim3(nblk), dim3(256), 0, st, n, ne, W, d_ea, d_eb, d_ew, d_r, d_Ji, d_delta, d_part);
-            hipLaunchKernelGGL(pg_final_sum_kernel, dim3(1), dim3(256), 0, st, d_part, nblk, 0.5, d_scal + 1);
+            // X and Xn swap between trials, so these two stay outside the captured graph
             hipLaunchKernelGGL(pg_retract_kernel, dim3((n + 255) / 256), dim3(256), 0, st, n, d_X, d_delta, d_Xn);
             hipLaunchKernelGGL(pg_linearize_kernel, dim3(nblk), dim3(256), 0, st, n, ne, d_Xn, d_meas, W, d_ea, d_eb, d_emeas, d_ew, (double*)nullptr, (double*)nullptr, d_part);
             hipLaunchKernelGGL(pg_final_sum_kernel, dim3(1), dim3(256), 0, st, d_part, nblk, 0.5, d_scal + 2);
@@ -799,7 +932,8 @@ static int pg_solve_impl(dsss_ctx* c, const double* dr6, int total, const dsss_l
     }
     if (stats4) { stats4[0] = iters; stats4[1] = err0; stats4[2] = err; stats4[3] = lambda; }
     dv.release();
-    if (verbose) fprintf(stderr, "[dsss pg] LM iterations %d  factorisations %d  err %.6g -> %.6g\n", iters, nfact, err0, err);
+    if (verbose) fprintf(stderr, "[dsss pg] LM iterations %d  factorisations %d  err %.6g -> %.6g | host prep %.1f ms, symbolic %.1f ms, alloc+upload %.1f ms, LM loop %.1f ms\n",
+                         iters, nfact, err0, err, t_prep, t_sym, t_up, ms_since(T3));
 #undef TRY
 #undef HCK
     return DSSS_OK;

@@ -347,7 +347,7 @@ int orc_pg_solve(const double* dr, int total, const orc_lc_edge* edges, int ne, 
     double err = pg_error(&g, X);
     double err0 = err, cur;
     double* delta = (double*)malloc(sizeof(double) * 6 * (size_t)n);
-    if (err > 0) do {
+    if (err > 0 && p->max_iters > 0) do {
         cur = err;
         for (int k = 0; k < g.nf; ++k)
             pg_factor_eval(&g.f[k], X, g.r + (size_t)k * 6, g.Ji + (size_t)k * 36, g.Jj + (size_t)k * 36);

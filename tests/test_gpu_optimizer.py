@@ -116,3 +116,22 @@ def test_posegraph_edges_api_small_cases(ctx, orc):
         g_out, g_stats = ctx.posegraph_solve_edges(dr, edges)
         assert g_stats[0] == o_stats[0]
         assert np.abs(g_out - o_out).max() < 1e-6
+
+
+def test_initial_values_follow_libstdcxx_normal_stream(ctx, orc):
+    """max_iters = 0 returns the initial estimate DR o noise (optimizer.cpp:150-160): the device reproduces the
+    sequential minstd_rand0 + polar normal_distribution stream with a jump-ahead per attempt"""
+    n = 5000
+    rng = np.random.default_rng(4)
+    dr = np.zeros((n, 6)); dr[:, 3] = 0.05 * np.arange(n); dr[:, 2] = rng.uniform(-3, 3, n); dr[:, 5] = rng.uniform(-1, 1, n)
+    mp, op, mt, pg = ctx.default_params()
+    pg.max_iters = 0
+    ctx.set_params(pg=pg)
+    po = orc.pg_params(); po.max_iters = 0
+    g_out, _ = ctx.posegraph_solve_edges(dr, np.zeros(0, orc.LCEDGE_DTYPE))
+    o_out, _ = orc.pg_solve(dr, np.zeros(0, orc.LCEDGE_DTYPE), po)
+    pg.max_iters = 100
+    ctx.set_params(pg=pg)
+    z = np.zeros(6 * n); orc.lib().orc_normal_fill(orc.dp(z), 6 * n)
+    assert np.abs(o_out[:, 9:] - dr[:, 3:]).max() > 0.5            # noise really applied (sigma 0.5 m)
+    assert np.abs(g_out - o_out).max() < 1e-12
