@@ -301,6 +301,43 @@ __global__ __launch_bounds__(256) void pg_build_map_kernel(int nupd, const int* 
 }
 
 #define PG_TCH 128
+// acc[s] += sum_t L(i,k_t)[r][:] . L(j,k_t)[s][:] for the tn updates staged in LDS.  Updates that do not touch this
+// row (map entry -1) are masked instead of skipped, and four updates are in flight at once, so the index load and the
+// six operand loads of different updates overlap instead of forming one dependent chain per update.
+__device__ inline void pg_acc_rows(const int* __restrict__ mp, int m, int tn, const double* __restrict__ Lvals, int r,
+                                   const double* __restrict__ s_Ljk, double* acc)
+{
+    int t = 0;
+    for (; t + 4 <= tn; t += 4) {
+        int pos[4]; double a[4][6];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) pos[u] = mp[(size_t)(t + u) * m];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const double* Lik = Lvals + (size_t)(pos[u] < 0 ? 0 : pos[u]) * 36 + r * 6;
+#pragma unroll
+            for (int c = 0; c < 6; ++c) a[u][c] = Lik[c];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (pos[u] < 0) continue;
+            const double* B = s_Ljk + (t + u) * 36;
+#pragma unroll
+            for (int s = 0; s < 6; ++s)
+                acc[s] += a[u][0] * B[s * 6] + a[u][1] * B[s * 6 + 1] + a[u][2] * B[s * 6 + 2] + a[u][3] * B[s * 6 + 3] + a[u][4] * B[s * 6 + 4] + a[u][5] * B[s * 6 + 5];
+        }
+    }
+    for (; t < tn; ++t) {
+        const int pos = mp[(size_t)t * m];
+        if (pos < 0) continue;
+        const double* Lik = Lvals + (size_t)pos * 36 + r * 6;
+        const double* B = s_Ljk + t * 36;
+        const double a0 = Lik[0], a1 = Lik[1], a2 = Lik[2], a3 = Lik[3], a4 = Lik[4], a5 = Lik[5];
+#pragma unroll
+        for (int s = 0; s < 6; ++s)
+            acc[s] += a0 * B[s * 6] + a1 * B[s * 6 + 1] + a2 * B[s * 6 + 2] + a3 * B[s * 6 + 3] + a4 * B[s * 6 + 4] + a5 * B[s * 6 + 5];
+    }
+}
 // accumulate sum_k L(i,k) L(j,k)^T for a slice of the update list: grid (columns of the level, 256-row chunks of the
 // column, slices of the update list).  With one slice the result is subtracted from A(i,j) in place; with several
 // slices each writes its partial sum to `part` and pg_factor_fin_kernel subtracts them in slice order (deterministic).
@@ -341,16 +378,7 @@ __global__ __launch_bounds__(256) void pg_factor_acc_kernel(const int* __restric
                 accy += B[0] * yk[0] + B[1] * yk[1] + B[2] * yk[2] + B[3] * yk[3] + B[4] * yk[4] + B[5] * yk[5];
             }
         if (act)
-            for (int t = 0; t < tn; ++t) {
-                const int pos = mp[(size_t)(tc + t) * m + q];
-                if (pos < 0) continue;
-                const double* Lik = Lvals + (size_t)pos * 36 + r * 6;
-                const double* B = s_Ljk + t * 36;
-                const double a0 = Lik[0], a1 = Lik[1], a2 = Lik[2], a3 = Lik[3], a4 = Lik[4], a5 = Lik[5];
-#pragma unroll
-                for (int s = 0; s < 6; ++s)
-                    acc[s] += a0 * B[s * 6] + a1 * B[s * 6 + 1] + a2 * B[s * 6 + 2] + a3 * B[s * 6 + 3] + a4 * B[s * 6 + 4] + a5 * B[s * 6 + 5];
-            }
+            pg_acc_rows(mp + (size_t)tc * m + q, m, tn, Lvals, r, s_Ljk, acc);
     }
     if (rhs) {
         if (nsl == 1) x[(size_t)j * 6 + rs_] -= accy;
@@ -408,6 +436,100 @@ __global__ __launch_bounds__(256) void pg_factor_fin_kernel(const int* __restric
         double xr[6];
         for (int s = 0; s < 6; ++s) { double v = row[s]; for (int c = 0; c < s; ++c) v -= xr[c] * s_diag[s * 6 + c]; xr[s] = v / s_diag[s * 6 + s]; }
         for (int s = 0; s < 6; ++s) row[s] = xr[s];
+    }
+}
+
+// ---- bottom of the elimination tree: whole subtrees per workgroup (no grid-wide level barriers).
+// A bin is a list of columns in ascending order whose ancestors outside the bin are never its descendants, so the
+// workgroup can run them back to back with workgroup barriers only.  Same arithmetic and summation order as the
+// level-scheduled kernels.  Only columns with at most 42 blocks (6m <= 256 rows: one pass) are binned.
+__global__ __launch_bounds__(256) void pg_factor_subtree_kernel(const int* __restrict__ binptr, const int* __restrict__ bincols,
+                                                                const int* __restrict__ colptr, const int* __restrict__ rlptr,
+                                                                const int* __restrict__ rlcol, const int* __restrict__ rlpos,
+                                                                const long long* __restrict__ mapptr, const int* __restrict__ upd_map,
+                                                                double* __restrict__ Lvals, double* __restrict__ x, int* __restrict__ fail)
+{
+    __shared__ double s_Ljk[PG_TCH * 36];
+    __shared__ double s_yk[PG_TCH * 6];
+    __shared__ double s_diag[36];
+    __shared__ int s_ok;
+    for (int ci = binptr[blockIdx.x]; ci < binptr[blockIdx.x + 1]; ++ci) {
+        const int j = bincols[ci];
+        const int c0 = colptr[j], m = colptr[j + 1] - c0;
+        const int t0 = rlptr[j], T = rlptr[j + 1] - t0;
+        const int* mp = upd_map + mapptr[j];
+        const int idx = threadIdx.x;
+        const bool act = idx < 6 * m;
+        const int q = act ? idx / 6 : 0, r = idx - q * 6;
+        const bool rhs = threadIdx.x >= 250;
+        const int rs_ = threadIdx.x - 250;
+        double acc[6] = { 0, 0, 0, 0, 0, 0 }, accy = 0;
+        for (int tc = 0; tc < T; tc += PG_TCH) {
+            const int tn = min(PG_TCH, T - tc);
+            __syncthreads();
+            for (int xx = threadIdx.x; xx < tn * 36; xx += 256) s_Ljk[xx] = Lvals[(size_t)rlpos[t0 + tc + xx / 36] * 36 + (xx % 36)];
+            for (int xx = threadIdx.x; xx < tn * 6; xx += 256) s_yk[xx] = x[(size_t)rlcol[t0 + tc + xx / 6] * 6 + (xx % 6)];
+            __syncthreads();
+            if (rhs)
+                for (int t = 0; t < tn; ++t) {
+                    const double* yk = s_yk + t * 6; const double* B = s_Ljk + t * 36 + rs_ * 6;
+                    accy += B[0] * yk[0] + B[1] * yk[1] + B[2] * yk[2] + B[3] * yk[3] + B[4] * yk[4] + B[5] * yk[5];
+                }
+            if (act)
+                pg_acc_rows(mp + (size_t)tc * m + q, m, tn, Lvals, r, s_Ljk, acc);
+        }
+        if (rhs && T > 0) x[(size_t)j * 6 + rs_] -= accy;
+        if (act && T > 0) for (int s = 0; s < 6; ++s) Lvals[(size_t)(c0 + q) * 36 + r * 6 + s] -= acc[s];
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            double A[36];
+            for (int a = 0; a < 36; ++a) A[a] = Lvals[(size_t)c0 * 36 + a];
+            const int bad = chol6(A);
+            if (bad) *fail = 1;
+            s_ok = !bad;
+            for (int a = 0; a < 6; ++a) for (int b = 0; b < 6; ++b) { const double v = b <= a ? A[a * 6 + b] : 0.0; s_diag[a * 6 + b] = v; Lvals[(size_t)c0 * 36 + a * 6 + b] = v; }
+            if (!bad) {
+                double v[6];
+                for (int a = 0; a < 6; ++a) { double t = x[(size_t)j * 6 + a]; for (int b = 0; b < a; ++b) t -= A[a * 6 + b] * v[b]; v[a] = t / A[a * 6 + a]; }
+                for (int a = 0; a < 6; ++a) x[(size_t)j * 6 + a] = v[a];
+            }
+        }
+        __syncthreads();
+        if (!s_ok) return;
+        if (act && idx >= 6) {
+            double* row = Lvals + (size_t)(c0 + q) * 36 + r * 6;
+            double xr[6];
+            for (int s = 0; s < 6; ++s) { double v = row[s]; for (int c = 0; c < s; ++c) v -= xr[c] * s_diag[s * 6 + c]; xr[s] = v / s_diag[s * 6 + s]; }
+            for (int s = 0; s < 6; ++s) row[s] = xr[s];
+        }
+        __syncthreads();
+        __threadfence_block();
+    }
+}
+// backward substitution through a bin, columns in descending order, one wave per bin
+__global__ __launch_bounds__(64) void pg_bwd_subtree_kernel(const int* __restrict__ binptr, const int* __restrict__ bincols,
+                                                            const int* __restrict__ colptr, const int* __restrict__ rowidx,
+                                                            const double* __restrict__ Lvals, double* __restrict__ x)
+{
+    const int lane = threadIdx.x;
+    for (int ci = binptr[blockIdx.x + 1] - 1; ci >= binptr[blockIdx.x]; --ci) {
+        const int j = bincols[ci];
+        double acc[6] = { 0, 0, 0, 0, 0, 0 };
+        for (int p = colptr[j] + 1 + lane; p < colptr[j + 1]; p += 64) {
+            const double* B = Lvals + (size_t)p * 36; const double* xi = x + (size_t)rowidx[p] * 6;
+            for (int a = 0; a < 6; ++a) { double s = 0; for (int b = 0; b < 6; ++b) s += B[b * 6 + a] * xi[b]; acc[a] += s; }
+        }
+        for (int a = 0; a < 6; ++a)
+#pragma unroll
+            for (int o = 32; o >= 1; o >>= 1) acc[a] += __shfl_xor(acc[a], o, 64);
+        if (lane == 0) {
+            const double* Ld = Lvals + (size_t)colptr[j] * 36;
+            double v[6];
+            for (int a = 5; a >= 0; --a) { double s = x[(size_t)j * 6 + a] - acc[a]; for (int b = a + 1; b < 6; ++b) s -= Ld[b * 6 + a] * v[b]; v[a] = s / Ld[a * 6 + a]; }
+            for (int a = 0; a < 6; ++a) x[(size_t)j * 6 + a] = v[a];
+        }
+        __threadfence_block();
+        __builtin_amdgcn_s_barrier();
     }
 }
 
@@ -608,7 +730,7 @@ namespace {
 struct sym_t {
     int ns = 0;
     std::vector<int> perm;                 // chain-order separator -> elimination index
-    std::vector<int> colptr, rowidx, rlptr, rlcol, rlpos, rlrow, lvptr, lvcols, diag_pos, ch_pos, lc_pos;
+    std::vector<int> colptr, rowidx, rlptr, rlcol, rlpos, rlrow, lvptr, lvcols, diag_pos, ch_pos, lc_pos, binptr, bincols;
     std::vector<long long> mapptr;
 };
 
@@ -690,15 +812,49 @@ void symbolic(int ns, const std::vector<std::pair<int, int>>& edges, int nchain,
         for (int t = S.rlptr[j]; t < S.rlptr[j + 1]; ++t) S.rlrow[t] = j;
         S.mapptr[j + 1] = S.mapptr[j] + (long long)(S.rlptr[j + 1] - S.rlptr[j]) * (long long)cols[j].size();
     }
-    // levels of the elimination tree
-    std::vector<int> level(ns, 0);
-    int maxl = 0;
-    for (int j = 0; j < ns; ++j) { for (int k : kids[j]) level[j] = std::max(level[j], level[k] + 1); maxl = std::max(maxl, level[j]); }
+    // bottom subtrees -> bins (one workgroup each); the remaining "top" columns are level-scheduled
+    std::vector<double> sub_cost(ns, 0);
+    std::vector<char> sub_ok(ns, 0);
+    const double BIN_COST = 6000;                           // ~ update-list iterations + 20 per column: about 1 ms of one workgroup
+    for (int j = 0; j < ns; ++j) {
+        const int mj = (int)cols[j].size(), Tj = S.rlptr[j + 1] - S.rlptr[j];
+        double cst = Tj + 20.0; bool ok = mj <= 42;
+        for (int k : kids[j]) { cst += sub_cost[k]; ok = ok && sub_ok[k]; }
+        sub_cost[j] = cst; sub_ok[j] = ok && cst <= BIN_COST;
+    }
+    std::vector<int> root_of(ns, -1);                       // subtree root of every binned column
+    for (int j = ns - 1; j >= 0; --j) {
+        if (!sub_ok[j]) continue;
+        const int par = parent[j];
+        root_of[j] = (par >= 0 && sub_ok[par]) ? root_of[par] : j;
+    }
+    {   // greedy packing of whole subtrees into bins, subtrees taken in ascending root order
+        std::vector<int> roots;
+        for (int j = 0; j < ns; ++j) if (sub_ok[j] && root_of[j] == j) roots.push_back(j);
+        std::vector<int> bin_of_root(ns, -1);
+        int nbins = 0; double fill = BIN_COST + 1;
+        for (int r : roots) { if (fill + sub_cost[r] > BIN_COST) { ++nbins; fill = 0; } fill += sub_cost[r]; bin_of_root[r] = nbins - 1; }
+        S.binptr.assign(nbins + 1, 0);
+        for (int j = 0; j < ns; ++j) if (sub_ok[j]) S.binptr[bin_of_root[root_of[j]] + 1]++;
+        for (int b = 0; b < nbins; ++b) S.binptr[b + 1] += S.binptr[b];
+        S.bincols.resize(S.binptr[nbins]);
+        std::vector<int> fillp(S.binptr.begin(), S.binptr.end() - 1);
+        for (int j = 0; j < ns; ++j) if (sub_ok[j]) S.bincols[fillp[bin_of_root[root_of[j]]]++] = j;     // ascending within a bin
+    }
+    // levels of the top part of the elimination tree
+    std::vector<int> level(ns, -1);
+    int maxl = -1;
+    for (int j = 0; j < ns; ++j) {
+        if (sub_ok[j]) continue;
+        int lv = 0;
+        for (int k : kids[j]) if (!sub_ok[k]) lv = std::max(lv, level[k] + 1);
+        level[j] = lv; maxl = std::max(maxl, lv);
+    }
     S.lvptr.assign(maxl + 2, 0);
-    for (int j = 0; j < ns; ++j) S.lvptr[level[j] + 1]++;
+    for (int j = 0; j < ns; ++j) if (level[j] >= 0) S.lvptr[level[j] + 1]++;
     for (int l = 0; l <= maxl; ++l) S.lvptr[l + 1] += S.lvptr[l];
-    S.lvcols.resize(ns);
-    { std::vector<int> fill(S.lvptr.begin(), S.lvptr.end() - 1); for (int j = 0; j < ns; ++j) S.lvcols[fill[level[j]]++] = j; }
+    S.lvcols.resize(S.lvptr[maxl + 1]);
+    { std::vector<int> fill(S.lvptr.begin(), S.lvptr.end() - 1); for (int j = 0; j < ns; ++j) if (level[j] >= 0) S.lvcols[fill[level[j]]++] = j; }
     // where the assembled blocks go
     auto find = [&](int row, int col) { const auto b = S.rowidx.begin() + S.colptr[col], e = S.rowidx.begin() + S.colptr[col + 1];
                                         return (int)(std::lower_bound(b, e, row) - S.rowidx.begin()); };
@@ -796,7 +952,7 @@ static int pg_solve_impl(dsss_ctx* c, const double* dr6, int total, const dsss_l
     const bool verbose = getenv("DSSS_PG_VERBOSE") != nullptr;
     if (verbose) {
         int maxcol = 0; for (int j = 0; j < ns; ++j) maxcol = std::max(maxcol, S.colptr[j + 1] - S.colptr[j]);
-        fprintf(stderr, "[dsss pg] poses %d  LC edges %d  separators %d  nnz(L) blocks %zu  etree levels %d  max column %d blocks  update map %lld\n", n, ne, ns, nnzL, nlev, maxcol, S.mapptr[ns]);
+        fprintf(stderr, "[dsss pg] poses %d  LC edges %d  separators %d  nnz(L) blocks %zu  etree levels %d  max column %d blocks  update map %lld  bins %d (%d cols)\n", n, ne, ns, nnzL, nlev, maxcol, S.mapptr[ns], (int)S.binptr.size() - 1, (int)S.bincols.size());
     }
 
     // device state
@@ -804,7 +960,7 @@ static int pg_solve_impl(dsss_ctx* c, const double* dr6, int total, const dsss_l
     int rc = DSSS_OK;
     pose_t *d_X, *d_Xn, *d_meas, *d_emeas; int *d_ea, *d_eb, *d_adj_ptr, *d_adj_edge, *d_sep, *d_perm;
     double *d_ew, *d_r, *d_Ji, *d_D, *d_C, *d_g, *d_delta, *d_E, *d_Dl, *d_gi, *d_sDL, *d_sDR, *d_sGL, *d_sGR, *d_sS, *d_L, *d_x, *d_part, *d_scal, *d_part2;
-    int *d_colptr, *d_rowidx, *d_rlptr, *d_rlcol, *d_rlpos, *d_rlrow, *d_lvcols, *d_diag, *d_ch, *d_lc, *d_fail, *d_map; long long* d_mapptr;
+    int *d_colptr, *d_rowidx, *d_rlptr, *d_rlcol, *d_rlpos, *d_rlrow, *d_binptr, *d_bincols, *d_lvcols, *d_diag, *d_ch, *d_lc, *d_fail, *d_map; long long* d_mapptr;
     const int nf = n + ne, nblk = (nf + 255) / 256;
 #define TRY(x) do { rc = (x); if (rc) { dv.release(); return rc; } } while (0)
     TRY(dv.alloc(c, &d_X, n)); TRY(dv.alloc(c, &d_Xn, n)); TRY(dv.alloc(c, &d_meas, n)); TRY(dv.upload(c, &d_emeas, emeas));
@@ -818,7 +974,8 @@ static int pg_solve_impl(dsss_ctx* c, const double* dr6, int total, const dsss_l
     TRY(dv.alloc(c, &d_L, nnzL * 36)); TRY(dv.alloc(c, &d_x, (size_t)ns * 6)); TRY(dv.alloc(c, &d_part, (size_t)nblk)); TRY(dv.alloc(c, &d_scal, 8)); TRY(dv.alloc(c, &d_fail, 1));
     TRY(dv.upload(c, &d_colptr, S.colptr)); TRY(dv.upload(c, &d_rowidx, S.rowidx)); TRY(dv.upload(c, &d_rlptr, S.rlptr)); TRY(dv.upload(c, &d_rlcol, S.rlcol));
     TRY(dv.upload(c, &d_rlpos, S.rlpos)); TRY(dv.upload(c, &d_lvcols, S.lvcols)); TRY(dv.upload(c, &d_diag, S.diag_pos)); TRY(dv.upload(c, &d_ch, S.ch_pos)); TRY(dv.upload(c, &d_lc, S.lc_pos));
-    TRY(dv.upload(c, &d_rlrow, S.rlrow)); TRY(dv.upload(c, &d_mapptr, S.mapptr));
+    TRY(dv.upload(c, &d_rlrow, S.rlrow)); TRY(dv.upload(c, &d_mapptr, S.mapptr)); TRY(dv.upload(c, &d_binptr, S.binptr)); TRY(dv.upload(c, &d_bincols, S.bincols));
+    const int nbins = (int)S.binptr.size() - 1;
     const long long mapsz = S.mapptr[ns];
     if (mapsz > (1LL << 31)) { dv.release(); DSSS_FAIL(c, DSSS_E_CAPACITY, "update map of %lld entries", mapsz); }
     TRY(dv.alloc(c, &d_map, (size_t)mapsz)); TRY(dv.alloc(c, &d_part2, part2_doubles));
@@ -884,7 +1041,8 @@ static int pg_solve_impl(dsss_ctx* c, const double* dr6, int total, const dsss_l
                 hipLaunchKernelGGL(pg_segment_kernel, dim3((nseg + 63) / 64), dim3(64), 0, st, nseg, d_sep, d_D, d_C, d_g, d_E, d_Dl, d_gi, d_sDL, d_sDR, d_sGL, d_sGR, d_sS, d_fail);
                 hipLaunchKernelGGL(pg_scatter_base_kernel, dim3((ns + 255) / 256), dim3(256), 0, st, ns, d_sep, d_perm, d_D, d_g, d_sDL, d_sDR, d_sGL, d_sGR, d_sS, d_diag, d_ch, d_L, d_x);
                 if (ne > 0) hipLaunchKernelGGL(pg_scatter_lc_kernel, dim3((ne + 255) / 256), dim3(256), 0, st, n, ne, d_Ji, d_ew, d_lc, d_L);
-                for (int l = 0; l < nlev; ++l) {      // factorisation with the forward substitution fused in
+                if (nbins > 0) hipLaunchKernelGGL(pg_factor_subtree_kernel, dim3(nbins), dim3(256), 0, st, d_binptr, d_bincols, d_colptr, d_rlptr, d_rlcol, d_rlpos, d_mapptr, d_map, d_L, d_x, d_fail);
+                for (int l = 0; l < nlev; ++l) {      // top of the tree: level-scheduled, forward substitution fused in
                     const int ncl = S.lvptr[l + 1] - S.lvptr[l];
                     const int stride = lv_chunks[l] * 256 * 6 + 8;
                     if (lv_upd[l]) hipLaunchKernelGGL(pg_factor_acc_kernel, dim3(ncl, lv_chunks[l], lv_slices[l]), dim3(256), 0, st, d_lvcols + S.lvptr[l], d_colptr, d_rlptr, d_rlpos,
@@ -893,6 +1051,7 @@ static int pg_solve_impl(dsss_ctx* c, const double* dr6, int total, const dsss_l
                 }
                 for (int l = nlev - 1; l >= 0; --l)
                     hipLaunchKernelGGL(pg_bwd_level_kernel, dim3(S.lvptr[l + 1] - S.lvptr[l]), dim3(64), 0, st, d_lvcols + S.lvptr[l], d_colptr, d_rowidx, d_L, d_x);
+                if (nbins > 0) hipLaunchKernelGGL(pg_bwd_subtree_kernel, dim3(nbins), dim3(64), 0, st, d_binptr, d_bincols, d_colptr, d_rowidx, d_L, d_x);
                 hipLaunchKernelGGL(pg_sep_delta_kernel, dim3((ns + 255) / 256), dim3(256), 0, st, ns, d_sep, d_perm, d_x, d_delta);
                 hipLaunchKernelGGL(pg_backsub_kernel, dim3((nseg + 63) / 64), dim3(64), 0, st, nseg, d_sep, d_C, d_E, d_Dl, d_gi, d_delta);
                 hipLaunchKernelGGL(pg_linerr_kernel, dim3(nblk), dim3(256), 0, st, n, ne, W, d_ea, d_eb, d_ew, d_r, d_Ji, d_delta, d_part);
