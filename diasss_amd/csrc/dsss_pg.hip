@@ -340,19 +340,19 @@ __device__ inline void pg_acc_rows(const int* __restrict__ mp, int m, int tn, co
 }
 // accumulate sum_k L(i,k) L(j,k)^T for a slice of the update list: grid (columns of the level, 256-row chunks of the
 // column, slices of the update list).  With one slice the result is subtracted from A(i,j) in place; with several
-// slices each writes its partial sum to `part` and pg_factor_fin_kernel subtracts them in slice order (deterministic).
+// slices each writes its partial sum to `part` and the panel kernels subtract them in slice order (deterministic).
 __global__ __launch_bounds__(256) void pg_factor_acc_kernel(const int* __restrict__ lvcols, const int* __restrict__ colptr,
                                                             const int* __restrict__ rlptr, const int* __restrict__ rlpos,
                                                             const long long* __restrict__ mapptr, const int* __restrict__ upd_map,
                                                             double* __restrict__ Lvals, double* __restrict__ part, int col_stride,
-                                                            const int* __restrict__ rlcol, double* __restrict__ x)
+                                                            const int* __restrict__ rlcol, double* __restrict__ x, const int* __restrict__ tlim)
 {
     __shared__ double s_Ljk[PG_TCH * 36];
     __shared__ double s_yk[PG_TCH * 6];
     const int j = lvcols[blockIdx.x];
     const int c0 = colptr[j], m = colptr[j + 1] - c0;
     if ((int)blockIdx.y * 256 >= 6 * m) return;
-    const int t0 = rlptr[j], T = rlptr[j + 1] - t0;
+    const int t0 = rlptr[j], T = tlim[j];                  // updates from outside the column's own panel
     const int nsl = gridDim.z, sl = blockIdx.z;
     const int per = (T + nsl - 1) / nsl;
     const int ta = sl * per, tb = min(T, ta + per);
@@ -388,55 +388,192 @@ __global__ __launch_bounds__(256) void pg_factor_acc_kernel(const int* __restric
     if (nsl == 1) { for (int s = 0; s < 6; ++s) Lvals[(size_t)(c0 + q) * 36 + r * 6 + s] -= acc[s]; }
     else { double* o = part + ((size_t)blockIdx.x * nsl + sl) * col_stride + (size_t)idx * 6; for (int s = 0; s < 6; ++s) o[s] = acc[s]; }
 }
-// (fold the partial sums,) factor the diagonal block, L(i, j) = A(i, j) L_jj^-T along each row, y_j = L_jj^-1 y_j.
-// One wave per column for narrow columns, four for wide ones (the launch picks the block size per level).
-__global__ __launch_bounds__(256) void pg_factor_fin_kernel(const int* __restrict__ lvcols, const int* __restrict__ colptr,
-                                                           double* __restrict__ Lvals, const double* __restrict__ part, int nsl,
-                                                           int col_stride, double* __restrict__ x, int* __restrict__ fail)
+// ---- supernodal panels for the top of the tree.  A panel is up to PG_PW consecutive columns j0 .. j0+w-1 with nested
+// structure (struct(j+1) = struct(j) minus j), i.e. a dense trapezoid: a 6w x 6w diagonal block A11 on top of the rows
+// A21 shared by all its columns.  After the external updates (pg_factor_acc_kernel over all columns of the level at once)
+//     L11 = chol(A11), y = L11^-1 b      pg_panel_diag_kernel   one workgroup per panel, A11 in LDS
+//     L21 = A21 L11^-T                   pg_panel_trsm_kernel   one thread per scalar row of A21
+// which replaces w column-levels by one panel-level.
+#define PG_PW 16
+__device__ inline size_t pan_pos(const int* __restrict__ colptr, int j0, int qi, int c) { return (size_t)colptr[j0 + c] + (size_t)(qi - c); }
+
+__global__ __launch_bounds__(256) void pg_panel_diag_kernel(const int* __restrict__ plvpan, const int* __restrict__ pan_first, const int* __restrict__ pan_w,
+                                                            const int* __restrict__ pan_lcol0, const int* __restrict__ colptr,
+                                                            double* __restrict__ Lvals, const double* __restrict__ part, int nsl, int col_stride,
+                                                            double* __restrict__ x, int* __restrict__ fail)
 {
-    __shared__ double s_diag[36];
-    __shared__ int s_ok;
-    const int j = lvcols[blockIdx.x];
-    const int c0 = colptr[j], m = colptr[j + 1] - c0;
-    if (nsl > 1) {
-        for (int idx = threadIdx.x; idx < 6 * m; idx += blockDim.x) {
-            double* row = Lvals + (size_t)c0 * 36 + (size_t)idx * 6;
-            double v[6];
-            for (int s = 0; s < 6; ++s) v[s] = row[s];
+    // blocked right-looking Cholesky: thread (bi, bj) of a 16 x 16 grid owns the 6 x 6 block A(bi, bj) in registers;
+    // per block step k: (k,k) factors, column k solves against L_kk, the trailing blocks subtract L_ik L_jk^T.
+    __shared__ double sLkk[36];
+    __shared__ double sLcol[PG_PW][36];
+    __shared__ double sy[6];
+    __shared__ int s_bad;
+    const int p = plvpan[blockIdx.x];
+    const int j0 = pan_first[p], w = pan_w[p], lc0 = pan_lcol0[p];
+    const int bi = threadIdx.x >> 4, bj = threadIdx.x & 15;
+    const bool act = bi < w && bj <= bi;
+    double a[36], y[6];
+    if (threadIdx.x == 0) s_bad = 0;
+    if (act) {
+        const double* src = Lvals + pan_pos(colptr, j0, bi, bj) * 36;
+        for (int e = 0; e < 36; ++e) a[e] = src[e];
+        if (nsl > 1)
             for (int sl = 0; sl < nsl; ++sl) {
-                const double* o = part + ((size_t)blockIdx.x * nsl + sl) * col_stride + (size_t)idx * 6;
-                for (int s = 0; s < 6; ++s) v[s] -= o[s];
+                const double* o = part + ((size_t)(lc0 + bj) * nsl + sl) * col_stride + (size_t)(bi - bj) * 36;
+                for (int e = 0; e < 36; ++e) a[e] -= o[e];
             }
-            for (int s = 0; s < 6; ++s) row[s] = v[s];
-        }
-        if (threadIdx.x < 6) {
-            double v = x[(size_t)j * 6 + threadIdx.x];
-            for (int sl = 0; sl < nsl; ++sl) v -= part[((size_t)blockIdx.x * nsl + sl) * col_stride + (size_t)col_stride - 8 + threadIdx.x];
-            x[(size_t)j * 6 + threadIdx.x] = v;
-        }
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) {
-        double A[36];
-        for (int a = 0; a < 36; ++a) A[a] = Lvals[(size_t)c0 * 36 + a];
-        const int bad = chol6(A);
-        if (bad) *fail = 1;
-        s_ok = !bad;
-        for (int a = 0; a < 6; ++a) for (int b = 0; b < 6; ++b) { const double v = b <= a ? A[a * 6 + b] : 0.0; s_diag[a * 6 + b] = v; Lvals[(size_t)c0 * 36 + a * 6 + b] = v; }
-        if (!bad) {
-            double v[6];
-            for (int a = 0; a < 6; ++a) { double t = x[(size_t)j * 6 + a]; for (int b = 0; b < a; ++b) t -= A[a * 6 + b] * v[b]; v[a] = t / A[a * 6 + a]; }
-            for (int a = 0; a < 6; ++a) x[(size_t)j * 6 + a] = v[a];
+        if (bi == bj) {
+            for (int e = 0; e < 6; ++e) {
+                double v = x[(size_t)(j0 + bi) * 6 + e];
+                if (nsl > 1) for (int sl = 0; sl < nsl; ++sl) v -= part[((size_t)(lc0 + bi) * nsl + sl) * col_stride + (size_t)col_stride - 8 + e];
+                y[e] = v;
+            }
         }
     }
     __syncthreads();
-    if (!s_ok) return;
-    for (int idx = 6 + threadIdx.x; idx < 6 * m; idx += blockDim.x) {
-        double* row = Lvals + (size_t)(c0 + idx / 6) * 36 + (idx % 6) * 6;
-        double xr[6];
-        for (int s = 0; s < 6; ++s) { double v = row[s]; for (int c = 0; c < s; ++c) v -= xr[c] * s_diag[s * 6 + c]; xr[s] = v / s_diag[s * 6 + s]; }
-        for (int s = 0; s < 6; ++s) row[s] = xr[s];
+    for (int k = 0; k < w; ++k) {
+        if (bi == k && bj == k) {
+            if (chol6(a)) { s_bad = 1; for (int e = 0; e < 36; ++e) a[e] = (e % 7 == 0) ? 1.0 : 0.0; }
+            for (int r = 0; r < 6; ++r) for (int c2 = r + 1; c2 < 6; ++c2) a[r * 6 + c2] = 0.0;
+            for (int e = 0; e < 36; ++e) sLkk[e] = a[e];
+            for (int r = 0; r < 6; ++r) { double v = y[r]; for (int c2 = 0; c2 < r; ++c2) v -= a[r * 6 + c2] * y[c2]; y[r] = v / a[r * 6 + r]; }
+            for (int e = 0; e < 6; ++e) sy[e] = y[e];
+        }
+        __syncthreads();
+        if (act && bj == k && bi > k) {                      // X L_kk^T = A_ik, row by row
+            for (int r = 0; r < 6; ++r) {
+                double xr[6];
+                for (int s2 = 0; s2 < 6; ++s2) { double v = a[r * 6 + s2]; for (int c2 = 0; c2 < s2; ++c2) v -= xr[c2] * sLkk[s2 * 6 + c2]; xr[s2] = v / sLkk[s2 * 6 + s2]; }
+                for (int s2 = 0; s2 < 6; ++s2) a[r * 6 + s2] = xr[s2];
+            }
+            for (int e = 0; e < 36; ++e) sLcol[bi][e] = a[e];
+        }
+        __syncthreads();
+        if (act && bj > k) {                                 // A_ij -= L_ik L_jk^T
+            const double* Li = sLcol[bi]; const double* Lj = sLcol[bj];
+#pragma unroll
+            for (int r = 0; r < 6; ++r)
+#pragma unroll
+                for (int s2 = 0; s2 < 6; ++s2) {
+                    double v = 0;
+#pragma unroll
+                    for (int c2 = 0; c2 < 6; ++c2) v += Li[r * 6 + c2] * Lj[s2 * 6 + c2];
+                    a[r * 6 + s2] -= v;
+                }
+            if (bi == bj) for (int r = 0; r < 6; ++r) { double v = 0; for (int c2 = 0; c2 < 6; ++c2) v += Li[r * 6 + c2] * sy[c2]; y[r] -= v; }   // y_i -= L_ik y_k
+        }
+        __syncthreads();
     }
+    if (s_bad && threadIdx.x == 0) *fail = 1;
+    if (act) {
+        double* dst = Lvals + pan_pos(colptr, j0, bi, bj) * 36;
+        for (int e = 0; e < 36; ++e) dst[e] = a[e];
+        if (bi == bj) for (int e = 0; e < 6; ++e) x[(size_t)(j0 + bi) * 6 + e] = y[e];
+    }
+}
+
+// L21 = A21 L11^-T : one thread per scalar row below the panel's diagonal block; block column by block column, the
+// already finished part of the row is re-read from global memory (written by the same thread)
+__global__ __launch_bounds__(256) void pg_panel_trsm_kernel(const int* __restrict__ plvpan, const int* __restrict__ pan_first, const int* __restrict__ pan_w,
+                                                            const int* __restrict__ pan_lcol0, const int* __restrict__ colptr,
+                                                            double* __restrict__ Lvals, const double* __restrict__ part, int nsl, int col_stride)
+{
+    extern __shared__ double sL[];                 // L11, n x n row-major
+    const int p = plvpan[blockIdx.x];
+    const int j0 = pan_first[p], w = pan_w[p], n = 6 * w, lc0 = pan_lcol0[p];
+    const int m = colptr[j0 + 1] - colptr[j0];     // block rows of the first column
+    const int nrows = 6 * (m - w);
+    if ((int)blockIdx.y * 256 >= nrows) return;
+    for (int idx = threadIdx.x; idx < n * n; idx += 256) {
+        const int gi = idx / n, gj = idx - gi * n;
+        const int qi = gi / 6, c = gj / 6;
+        sL[idx] = (qi >= c) ? Lvals[pan_pos(colptr, j0, qi, c) * 36 + (gi % 6) * 6 + (gj % 6)] : 0.0;
+    }
+    __syncthreads();
+    const int row = blockIdx.y * 256 + threadIdx.x;
+    if (row >= nrows) return;
+    const int qi = w + row / 6, r = row % 6;       // block row index within the first column's structure
+    for (int c = 0; c < w; ++c) {
+        double* dst = Lvals + pan_pos(colptr, j0, qi, c) * 36 + r * 6;
+        double a[6];
+        for (int s = 0; s < 6; ++s) a[s] = dst[s];
+        if (nsl > 1)
+            for (int sl = 0; sl < nsl; ++sl) {
+                const double* o = part + ((size_t)(lc0 + c) * nsl + sl) * col_stride + (size_t)((qi - c) * 6 + r) * 6;
+                for (int s = 0; s < 6; ++s) a[s] -= o[s];
+            }
+        for (int cp = 0; cp < c; ++cp) {
+            const double* xr = Lvals + pan_pos(colptr, j0, qi, cp) * 36 + r * 6;
+            const double x0 = xr[0], x1 = xr[1], x2 = xr[2], x3 = xr[3], x4 = xr[4], x5 = xr[5];
+#pragma unroll
+            for (int s = 0; s < 6; ++s) {
+                const double* Lr = sL + (c * 6 + s) * n + cp * 6;
+                a[s] -= x0 * Lr[0] + x1 * Lr[1] + x2 * Lr[2] + x3 * Lr[3] + x4 * Lr[4] + x5 * Lr[5];
+            }
+        }
+        double xo[6];
+        for (int s = 0; s < 6; ++s) {
+            double v = a[s];
+            const double* Lr = sL + (c * 6 + s) * n + c * 6;
+            for (int t = 0; t < s; ++t) v -= xo[t] * Lr[t];
+            xo[s] = v / Lr[s];
+        }
+        for (int s = 0; s < 6; ++s) dst[s] = xo[s];
+    }
+}
+
+// x_panel = L11^-T (y_panel - L21^T x_below): one workgroup per panel, blocked like pg_panel_diag_kernel
+__global__ __launch_bounds__(256) void pg_panel_bwd_kernel(const int* __restrict__ plvpan, const int* __restrict__ pan_first, const int* __restrict__ pan_w,
+                                                           const int* __restrict__ colptr, const int* __restrict__ rowidx,
+                                                           const double* __restrict__ Lvals, double* __restrict__ x)
+{
+    __shared__ double s_part[256];
+    __shared__ double sz[PG_PW * 6];
+    __shared__ double sxk[6];
+    __shared__ double scontrib[PG_PW][6];
+    const int p = plvpan[blockIdx.x];
+    const int j0 = pan_first[p], w = pan_w[p], n = 6 * w;
+    const int c0 = colptr[j0], m = colptr[j0 + 1] - c0;
+    // z[gj] = y[gj] - sum over rows below of L(row, gj) x_row ; threads split the rows in 256/n groups, fixed fold order
+    const int groups = 256 / n > 0 ? 256 / n : 1;
+    {
+        const int gj = threadIdx.x % n, g = threadIdx.x / n;
+        double acc = 0;
+        if (g < groups) {
+            const int c = gj / 6, s6 = gj % 6;
+            for (int qi = w + g; qi < m; qi += groups) {
+                const double* B = Lvals + pan_pos(colptr, j0, qi, c) * 36; const double* xi = x + (size_t)rowidx[c0 + qi] * 6;
+                acc += B[s6] * xi[0] + B[6 + s6] * xi[1] + B[12 + s6] * xi[2] + B[18 + s6] * xi[3] + B[24 + s6] * xi[4] + B[30 + s6] * xi[5];
+            }
+        }
+        s_part[threadIdx.x] = acc;
+    }
+    __syncthreads();
+    for (int gj = threadIdx.x; gj < n; gj += 256) {
+        double v = x[(size_t)(j0 + gj / 6) * 6 + gj % 6];
+        for (int g = 0; g < groups; ++g) v -= s_part[g * n + gj];
+        sz[gj] = v;
+    }
+    const int bi = threadIdx.x >> 4, bj = threadIdx.x & 15;
+    const bool act = bi < w && bj <= bi;
+    double a[36];
+    if (act) { const double* src = Lvals + pan_pos(colptr, j0, bi, bj) * 36; for (int e = 0; e < 36; ++e) a[e] = src[e]; }
+    __syncthreads();
+    for (int k = w - 1; k >= 0; --k) {
+        if (bi == k && bj == k) {                            // x_k = L_kk^-T z_k
+            double v[6];
+            for (int r = 5; r >= 0; --r) { double t = sz[k * 6 + r]; for (int c2 = r + 1; c2 < 6; ++c2) t -= a[c2 * 6 + r] * v[c2]; v[r] = t / a[r * 6 + r]; }
+            for (int e = 0; e < 6; ++e) { sxk[e] = v[e]; sz[k * 6 + e] = v[e]; }
+        }
+        __syncthreads();
+        if (act && bi == k && bj < k) {                      // z_j -= L_kj^T x_k
+            for (int s2 = 0; s2 < 6; ++s2) { double v = 0; for (int r = 0; r < 6; ++r) v += a[r * 6 + s2] * sxk[r]; scontrib[bj][s2] = v; }
+        }
+        __syncthreads();
+        if (threadIdx.x < k * 6) sz[threadIdx.x] -= scontrib[threadIdx.x / 6][threadIdx.x % 6];
+        __syncthreads();
+    }
+    for (int gj = threadIdx.x; gj < n; gj += 256) x[(size_t)(j0 + gj / 6) * 6 + gj % 6] = sz[gj];
 }
 
 // ---- bottom of the elimination tree: whole subtrees per workgroup (no grid-wide level barriers).
@@ -530,28 +667,6 @@ __global__ __launch_bounds__(64) void pg_bwd_subtree_kernel(const int* __restric
         }
         __threadfence_block();
         __builtin_amdgcn_s_barrier();
-    }
-}
-
-// x_j = L_jj^-T (y_j - sum_{i > j} L(i,j)^T x_i)
-__global__ __launch_bounds__(64) void pg_bwd_level_kernel(const int* __restrict__ lvcols, const int* __restrict__ colptr,
-                                                          const int* __restrict__ rowidx, const double* __restrict__ Lvals, double* __restrict__ x)
-{
-    const int j = lvcols[blockIdx.x];
-    const int lane = threadIdx.x;
-    double acc[6] = { 0, 0, 0, 0, 0, 0 };
-    for (int p = colptr[j] + 1 + lane; p < colptr[j + 1]; p += 64) {
-        const double* B = Lvals + (size_t)p * 36; const double* xi = x + (size_t)rowidx[p] * 6;
-        for (int a = 0; a < 6; ++a) { double s = 0; for (int b = 0; b < 6; ++b) s += B[b * 6 + a] * xi[b]; acc[a] += s; }
-    }
-    for (int a = 0; a < 6; ++a)
-#pragma unroll
-        for (int o = 32; o >= 1; o >>= 1) acc[a] += __shfl_xor(acc[a], o, 64);
-    if (lane == 0) {
-        const double* Ld = Lvals + (size_t)colptr[j] * 36;
-        double v[6];
-        for (int a = 5; a >= 0; --a) { double s = x[(size_t)j * 6 + a] - acc[a]; for (int b = a + 1; b < 6; ++b) s -= Ld[b * 6 + a] * v[b]; v[a] = s / Ld[a * 6 + a]; }
-        for (int a = 0; a < 6; ++a) x[(size_t)j * 6 + a] = v[a];
     }
 }
 
@@ -731,6 +846,7 @@ struct sym_t {
     int ns = 0;
     std::vector<int> perm;                 // chain-order separator -> elimination index
     std::vector<int> colptr, rowidx, rlptr, rlcol, rlpos, rlrow, lvptr, lvcols, diag_pos, ch_pos, lc_pos, binptr, bincols;
+    std::vector<int> pan_first, pan_w, pan_lcol0, plvptr, plvpan, tlim;       // panels of the top part, panel levels
     std::vector<long long> mapptr;
 };
 
@@ -841,20 +957,46 @@ void symbolic(int ns, const std::vector<std::pair<int, int>>& edges, int nchain,
         std::vector<int> fillp(S.binptr.begin(), S.binptr.end() - 1);
         for (int j = 0; j < ns; ++j) if (sub_ok[j]) S.bincols[fillp[bin_of_root[root_of[j]]]++] = j;     // ascending within a bin
     }
-    // levels of the top part of the elimination tree
-    std::vector<int> level(ns, -1);
-    int maxl = -1;
+    // top part: supernodal panels (consecutive columns with nested structure) and their levels
+    std::vector<int> col_pan(ns, -1);
     for (int j = 0; j < ns; ++j) {
-        if (sub_ok[j]) continue;
-        int lv = 0;
-        for (int k : kids[j]) if (!sub_ok[k]) lv = std::max(lv, level[k] + 1);
-        level[j] = lv; maxl = std::max(maxl, lv);
+        if (sub_ok[j] || col_pan[j] >= 0) continue;
+        int w = 1;
+        while (w < PG_PW && j + w < ns && !sub_ok[j + w] && parent[j + w - 1] == j + w && cols[j + w].size() + 1 == cols[j + w - 1].size()) ++w;
+        const int p = (int)S.pan_first.size();
+        S.pan_first.push_back(j); S.pan_w.push_back(w);
+        for (int c = 0; c < w; ++c) col_pan[j + c] = p;
     }
-    S.lvptr.assign(maxl + 2, 0);
-    for (int j = 0; j < ns; ++j) if (level[j] >= 0) S.lvptr[level[j] + 1]++;
-    for (int l = 0; l <= maxl; ++l) S.lvptr[l + 1] += S.lvptr[l];
-    S.lvcols.resize(S.lvptr[maxl + 1]);
-    { std::vector<int> fill(S.lvptr.begin(), S.lvptr.end() - 1); for (int j = 0; j < ns; ++j) if (level[j] >= 0) S.lvcols[fill[level[j]]++] = j; }
+    const int npan = (int)S.pan_first.size();
+    std::vector<int> plevel(npan, 0);
+    int maxl = -1;
+    for (int p = 0; p < npan; ++p) {
+        int lv = 0;
+        for (int c = 0; c < S.pan_w[p]; ++c)
+            for (int k : kids[S.pan_first[p] + c]) if (!sub_ok[k] && col_pan[k] != p) lv = std::max(lv, plevel[col_pan[k]] + 1);
+        plevel[p] = lv; maxl = std::max(maxl, lv);
+    }
+    S.plvptr.assign(maxl + 2, 0);
+    for (int p = 0; p < npan; ++p) S.plvptr[plevel[p] + 1]++;
+    for (int l = 0; l <= maxl; ++l) S.plvptr[l + 1] += S.plvptr[l];
+    S.plvpan.resize(npan); S.pan_lcol0.assign(npan, 0);
+    { std::vector<int> fill(S.plvptr.begin(), S.plvptr.end() - 1); for (int p = 0; p < npan; ++p) S.plvpan[fill[plevel[p]]++] = p; }
+    // columns of each panel level, panel by panel (kernel A works on columns); lvptr/lvcols now describe panel levels
+    S.lvptr.assign(maxl + 2, 0); S.lvcols.clear();
+    for (int l = 0; l <= maxl; ++l) {
+        for (int q = S.plvptr[l]; q < S.plvptr[l + 1]; ++q) {
+            const int p = S.plvpan[q];
+            S.pan_lcol0[p] = (int)S.lvcols.size() - S.lvptr[l];
+            for (int c = 0; c < S.pan_w[p]; ++c) S.lvcols.push_back(S.pan_first[p] + c);
+        }
+        S.lvptr[l + 1] = (int)S.lvcols.size();
+    }
+    // external update count per column: rowlist entries (ascending k) that lie before the column's panel
+    S.tlim.assign(ns, 0);
+    for (int j = 0; j < ns; ++j) {
+        const int lim = col_pan[j] >= 0 ? S.pan_first[col_pan[j]] : j;
+        S.tlim[j] = (int)(std::lower_bound(S.rlcol.begin() + S.rlptr[j], S.rlcol.begin() + S.rlptr[j + 1], lim) - (S.rlcol.begin() + S.rlptr[j]));
+    }
     // where the assembled blocks go
     auto find = [&](int row, int col) { const auto b = S.rowidx.begin() + S.colptr[col], e = S.rowidx.begin() + S.colptr[col + 1];
                                         return (int)(std::lower_bound(b, e, row) - S.rowidx.begin()); };
@@ -941,18 +1083,18 @@ static int pg_solve_impl(dsss_ctx* c, const double* dr6, int total, const dsss_l
         for (int q = S.lvptr[l]; q < S.lvptr[l + 1]; ++q) {
             const int j = S.lvcols[q];
             lv_chunks[l] = std::max(lv_chunks[l], (6 * (S.colptr[j + 1] - S.colptr[j]) + 255) / 256);
-            maxT = std::max(maxT, S.rlptr[j + 1] - S.rlptr[j]);
+            maxT = std::max(maxT, S.tlim[j]);
         }
         lv_upd[l] = maxT > 0;
         const int ncl = S.lvptr[l + 1] - S.lvptr[l];
         // few wide columns near the root: slice their update lists over more workgroups
-        if (ncl <= 64 && maxT > 48) lv_slices[l] = std::min(16, (maxT + 31) / 32);
+        if (ncl <= 256 && maxT > 48) lv_slices[l] = std::min(ncl <= 64 ? 16 : 4, (maxT + 31) / 32);
         if (lv_slices[l] > 1) part2_doubles = std::max(part2_doubles, (size_t)ncl * lv_slices[l] * ((size_t)lv_chunks[l] * 256 * 6 + 8));
     }
     const bool verbose = getenv("DSSS_PG_VERBOSE") != nullptr;
     if (verbose) {
         int maxcol = 0; for (int j = 0; j < ns; ++j) maxcol = std::max(maxcol, S.colptr[j + 1] - S.colptr[j]);
-        fprintf(stderr, "[dsss pg] poses %d  LC edges %d  separators %d  nnz(L) blocks %zu  etree levels %d  max column %d blocks  update map %lld  bins %d (%d cols)\n", n, ne, ns, nnzL, nlev, maxcol, S.mapptr[ns], (int)S.binptr.size() - 1, (int)S.bincols.size());
+        fprintf(stderr, "[dsss pg] poses %d  LC edges %d  separators %d  nnz(L) blocks %zu  etree levels %d  max column %d blocks  update map %lld  bins %d (%d cols)  panels %d\n", n, ne, ns, nnzL, nlev, maxcol, S.mapptr[ns], (int)S.binptr.size() - 1, (int)S.bincols.size(), (int)S.pan_first.size());
     }
 
     // device state
@@ -960,7 +1102,7 @@ static int pg_solve_impl(dsss_ctx* c, const double* dr6, int total, const dsss_l
     int rc = DSSS_OK;
     pose_t *d_X, *d_Xn, *d_meas, *d_emeas; int *d_ea, *d_eb, *d_adj_ptr, *d_adj_edge, *d_sep, *d_perm;
     double *d_ew, *d_r, *d_Ji, *d_D, *d_C, *d_g, *d_delta, *d_E, *d_Dl, *d_gi, *d_sDL, *d_sDR, *d_sGL, *d_sGR, *d_sS, *d_L, *d_x, *d_part, *d_scal, *d_part2;
-    int *d_colptr, *d_rowidx, *d_rlptr, *d_rlcol, *d_rlpos, *d_rlrow, *d_binptr, *d_bincols, *d_lvcols, *d_diag, *d_ch, *d_lc, *d_fail, *d_map; long long* d_mapptr;
+    int *d_colptr, *d_rowidx, *d_rlptr, *d_rlcol, *d_rlpos, *d_rlrow, *d_binptr, *d_bincols, *d_pan_first, *d_pan_w, *d_pan_lcol0, *d_plvpan, *d_tlim, *d_lvcols, *d_diag, *d_ch, *d_lc, *d_fail, *d_map; long long* d_mapptr;
     const int nf = n + ne, nblk = (nf + 255) / 256;
 #define TRY(x) do { rc = (x); if (rc) { dv.release(); return rc; } } while (0)
     TRY(dv.alloc(c, &d_X, n)); TRY(dv.alloc(c, &d_Xn, n)); TRY(dv.alloc(c, &d_meas, n)); TRY(dv.upload(c, &d_emeas, emeas));
@@ -976,9 +1118,28 @@ static int pg_solve_impl(dsss_ctx* c, const double* dr6, int total, const dsss_l
     TRY(dv.upload(c, &d_rlpos, S.rlpos)); TRY(dv.upload(c, &d_lvcols, S.lvcols)); TRY(dv.upload(c, &d_diag, S.diag_pos)); TRY(dv.upload(c, &d_ch, S.ch_pos)); TRY(dv.upload(c, &d_lc, S.lc_pos));
     TRY(dv.upload(c, &d_rlrow, S.rlrow)); TRY(dv.upload(c, &d_mapptr, S.mapptr)); TRY(dv.upload(c, &d_binptr, S.binptr)); TRY(dv.upload(c, &d_bincols, S.bincols));
     const int nbins = (int)S.binptr.size() - 1;
+    TRY(dv.upload(c, &d_pan_first, S.pan_first)); TRY(dv.upload(c, &d_pan_w, S.pan_w)); TRY(dv.upload(c, &d_pan_lcol0, S.pan_lcol0)); TRY(dv.upload(c, &d_plvpan, S.plvpan)); TRY(dv.upload(c, &d_tlim, S.tlim));
+    std::vector<int> plv_n(nlev, 6), plv_rowchunks(nlev, 0);
+    for (int l = 0; l < nlev; ++l)
+        for (int q = S.plvptr[l]; q < S.plvptr[l + 1]; ++q) {
+            const int p = S.plvpan[q], j0 = S.pan_first[p], w = S.pan_w[p];
+            plv_n[l] = std::max(plv_n[l], 6 * w);
+            plv_rowchunks[l] = std::max(plv_rowchunks[l], (6 * (S.colptr[j0 + 1] - S.colptr[j0] - w) + 255) / 256);
+        }
     const long long mapsz = S.mapptr[ns];
     if (mapsz > (1LL << 31)) { dv.release(); DSSS_FAIL(c, DSSS_E_CAPACITY, "update map of %lld entries", mapsz); }
     TRY(dv.alloc(c, &d_map, (size_t)mapsz)); TRY(dv.alloc(c, &d_part2, part2_doubles));
+    {   // the panel kernels keep a 96 x 96 f64 diagonal block (73.7 KB) in LDS
+        static bool once = false;
+        if (!once) {
+            const int lds = (PG_PW * 6) * (PG_PW * 6 + 1) * (int)sizeof(double);
+            hipFuncSetAttribute((const void*)pg_panel_diag_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+            hipFuncSetAttribute((const void*)pg_panel_trsm_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+            hipFuncSetAttribute((const void*)pg_panel_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+            (void)hipGetLastError();
+            once = true;
+        }
+    }
     hipStream_t st = c->stream;
 #define HCK(x) do { hipError_t _e = (x); if (_e != hipSuccess) { c->err = std::string(#x) + ": " + hipGetErrorString(_e); dv.release(); return DSSS_E_HIP; } } while (0)
     auto error_of = [&](const pose_t* Xd, double* out) -> int {
@@ -1042,15 +1203,22 @@ static int pg_solve_impl(dsss_ctx* c, const double* dr6, int total, const dsss_l
                 hipLaunchKernelGGL(pg_scatter_base_kernel, dim3((ns + 255) / 256), dim3(256), 0, st, ns, d_sep, d_perm, d_D, d_g, d_sDL, d_sDR, d_sGL, d_sGR, d_sS, d_diag, d_ch, d_L, d_x);
                 if (ne > 0) hipLaunchKernelGGL(pg_scatter_lc_kernel, dim3((ne + 255) / 256), dim3(256), 0, st, n, ne, d_Ji, d_ew, d_lc, d_L);
                 if (nbins > 0) hipLaunchKernelGGL(pg_factor_subtree_kernel, dim3(nbins), dim3(256), 0, st, d_binptr, d_bincols, d_colptr, d_rlptr, d_rlcol, d_rlpos, d_mapptr, d_map, d_L, d_x, d_fail);
-                for (int l = 0; l < nlev; ++l) {      // top of the tree: level-scheduled, forward substitution fused in
-                    const int ncl = S.lvptr[l + 1] - S.lvptr[l];
+                for (int l = 0; l < nlev; ++l) {      // top of the tree: panel levels, forward substitution fused in
+                    const int ncl = S.lvptr[l + 1] - S.lvptr[l], npl = S.plvptr[l + 1] - S.plvptr[l];
                     const int stride = lv_chunks[l] * 256 * 6 + 8;
+                    const int nsl = lv_upd[l] ? lv_slices[l] : 1;
+                    const size_t shb = ((size_t)plv_n[l] * plv_n[l] + plv_n[l]) * sizeof(double);
                     if (lv_upd[l]) hipLaunchKernelGGL(pg_factor_acc_kernel, dim3(ncl, lv_chunks[l], lv_slices[l]), dim3(256), 0, st, d_lvcols + S.lvptr[l], d_colptr, d_rlptr, d_rlpos,
-                                                      d_mapptr, d_map, d_L, d_part2, stride, d_rlcol, d_x);
-                    hipLaunchKernelGGL(pg_factor_fin_kernel, dim3(ncl), dim3(lv_chunks[l] > 1 ? 256 : 64), 0, st, d_lvcols + S.lvptr[l], d_colptr, d_L, d_part2, lv_upd[l] ? lv_slices[l] : 1, stride, d_x, d_fail);
+                                                      d_mapptr, d_map, d_L, d_part2, stride, d_rlcol, d_x, d_tlim);
+                    hipLaunchKernelGGL(pg_panel_diag_kernel, dim3(npl), dim3(256), 0, st, d_plvpan + S.plvptr[l], d_pan_first, d_pan_w, d_pan_lcol0, d_colptr, d_L, d_part2, nsl, stride, d_x, d_fail);
+                    if (plv_rowchunks[l] > 0)
+                        hipLaunchKernelGGL(pg_panel_trsm_kernel, dim3(npl, plv_rowchunks[l]), dim3(256), (size_t)plv_n[l] * plv_n[l] * sizeof(double), st, d_plvpan + S.plvptr[l], d_pan_first, d_pan_w,
+                                           d_pan_lcol0, d_colptr, d_L, d_part2, nsl, stride);
                 }
-                for (int l = nlev - 1; l >= 0; --l)
-                    hipLaunchKernelGGL(pg_bwd_level_kernel, dim3(S.lvptr[l + 1] - S.lvptr[l]), dim3(64), 0, st, d_lvcols + S.lvptr[l], d_colptr, d_rowidx, d_L, d_x);
+                for (int l = nlev - 1; l >= 0; --l) {
+                    const size_t shb = ((size_t)plv_n[l] * plv_n[l] + plv_n[l]) * sizeof(double);
+                    hipLaunchKernelGGL(pg_panel_bwd_kernel, dim3(S.plvptr[l + 1] - S.plvptr[l]), dim3(256), 0, st, d_plvpan + S.plvptr[l], d_pan_first, d_pan_w, d_colptr, d_rowidx, d_L, d_x);
+                }
                 if (nbins > 0) hipLaunchKernelGGL(pg_bwd_subtree_kernel, dim3(nbins), dim3(64), 0, st, d_binptr, d_bincols, d_colptr, d_rowidx, d_L, d_x);
                 hipLaunchKernelGGL(pg_sep_delta_kernel, dim3((ns + 255) / 256), dim3(256), 0, st, ns, d_sep, d_perm, d_x, d_delta);
                 hipLaunchKernelGGL(pg_backsub_kernel, dim3((nseg + 63) / 64), dim3(64), 0, st, nseg, d_sep, d_C, d_E, d_Dl, d_gi, d_delta);
