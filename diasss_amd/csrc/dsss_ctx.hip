@@ -92,6 +92,7 @@ void dsss_destroy(dsss_ctx* c)
     free_match(c); free_store(c);
     hipFree(c->lcs); hipFree(c->ex_scratch); hipFree(c->mt_aux);
     if (c->ex_pinned) hipHostFree(c->ex_pinned);
+    if (c->bbox_pinned) hipHostFree(c->bbox_pinned);
     dsss_pg_free(c);
     hipEventDestroy(c->prof.e0); hipEventDestroy(c->prof.e1);
     hipStreamDestroy(c->stream);
@@ -192,11 +193,21 @@ int dsss_frame_geo_bbox(dsss_ctx* c, int id)
     dsss_frame& f = c->frames[id];
     if (!f.has_geom) DSSS_FAIL(c, DSSS_E_STATE, "frame %d has no geometry", id);
     int rc = dsss_ensure_store(c); if (rc) return rc;
+    if (!c->bbox_pinned) HIPCHK(c, hipHostMalloc((void**)&c->bbox_pinned, (size_t)c->max_frames * 4 * sizeof(double), hipHostMallocDefault));
     hipLaunchKernelGGL(geo_bbox_kernel, dim3(1), dim3(256), 0, c->stream, f.pose6, f.gr, f.N, f.M, c->bbox_dev + (size_t)id * 4);
     HIPCHK(c, hipGetLastError());
-    HIPCHK(c, hipMemcpyAsync(f.bbox, c->bbox_dev + (size_t)id * 4, 4 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->bbox_pinned + (size_t)id * 4, c->bbox_dev + (size_t)id * 4, 4 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    f.has_bbox = true; f.bbox_async = true; c->bbox_pending = true;     // host copy becomes valid in dsss_sync_bboxes
+    return DSSS_OK;
+}
+
+int dsss_sync_bboxes(dsss_ctx* c)
+{
+    if (!c->bbox_pending) return DSSS_OK;
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    f.has_bbox = true;
+    for (int f = 0; f < c->max_frames; ++f)
+        if (c->frames[f].bbox_async) { memcpy(c->frames[f].bbox, c->bbox_pinned + (size_t)f * 4, 4 * sizeof(double)); c->frames[f].bbox_async = false; }
+    c->bbox_pending = false;
     return DSSS_OK;
 }
 
@@ -250,8 +261,7 @@ int dsss_frame_set(dsss_ctx* c, int id, const double* raw, int N, int M, const d
     HIPCHK(c, hipMemcpyAsync(f.gr, f.h_gr.data(), (size_t)(M / 2) * sizeof(double), hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipMemcpyAsync(c->rows_dev + id, &f.N, sizeof(int), hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipMemcpyAsync(c->cols_dev + id, &f.M, sizeof(int), hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    f.has_geom = true; f.has_feat = false; f.has_norm = false; f.nkp = 0;
+    f.has_geom = true; f.has_feat = false; f.has_norm = false; f.nkp = 0;          // no synchronisation: the sources above live in the context
     if (raw) {
         hipPointerAttribute_t at;
         bool on_dev = (hipPointerGetAttributes(&at, raw) == hipSuccess) && at.type == hipMemoryTypeDevice;
@@ -290,6 +300,7 @@ int dsss_features_set(dsss_ctx* c, int id, int N, int M, const dsss_kp* kps, con
         rc = dsss_frame_kp_geo(c, id, n); if (rc) return rc;
     }
     if (bbox) {
+        f.bbox_async = false;
         HIPCHK(c, hipMemcpy(f.bbox, bbox, 4 * sizeof(double), hipMemcpyDefault));
         HIPCHK(c, hipMemcpyAsync(c->bbox_dev + (size_t)id * 4, f.bbox, 4 * sizeof(double), hipMemcpyHostToDevice, c->stream));
         f.has_bbox = true;
@@ -325,6 +336,7 @@ int dsss_frame_bbox(dsss_ctx* c, int id, double* bbox)
     if (!c || !bbox) return DSSS_E_ARG;
     if (id < 0 || id >= c->max_frames) DSSS_FAIL(c, DSSS_E_ARG, "frame id %d out of range", id);
     if (!c->frames[id].has_bbox) DSSS_FAIL(c, DSSS_E_STATE, "frame %d has no bounding box", id);
+    { int rc = dsss_sync_bboxes(c); if (rc) return rc; }
     memcpy(bbox, c->frames[id].bbox, 4 * sizeof(double));
     return DSSS_OK;
 }
@@ -337,6 +349,7 @@ int dsss_overlap(dsss_ctx* c, int id_s, int id_t, float* iou)
     if (id_s < 0 || id_s >= c->max_frames || id_t < 0 || id_t >= c->max_frames) DSSS_FAIL(c, DSSS_E_ARG, "frame id out of range");
     const dsss_frame &a = c->frames[id_s], &b = c->frames[id_t];
     if (!a.has_bbox || !b.has_bbox) DSSS_FAIL(c, DSSS_E_STATE, "frames need dsss_frame_set first");
+    { int rc = dsss_sync_bboxes(c); if (rc) return rc; }
     float output = 0.0f;
     double sx_min = a.bbox[0], sx_max = a.bbox[1], sy_min = a.bbox[2], sy_max = a.bbox[3];
     double tx_min = b.bbox[0], tx_max = b.bbox[1], ty_min = b.bbox[2], ty_max = b.bbox[3];
@@ -364,6 +377,7 @@ int dsss_features_pack(dsss_ctx* c, int id, void* buf)
     if (id < 0 || id >= c->max_frames) DSSS_FAIL(c, DSSS_E_ARG, "frame id out of range");
     dsss_frame& f = c->frames[id];
     if (!f.has_feat) DSSS_FAIL(c, DSSS_E_STATE, "frame %d has no features", id);
+    { int rc = dsss_sync_bboxes(c); if (rc) return rc; }
     size_t K = c->kcap; char* p = (char*)buf;
     int32_t hdr[4] = { f.nkp, f.N, f.M, 0 };
     HIPCHK(c, hipMemcpyAsync(p, hdr, 16, hipMemcpyDefault, c->stream));

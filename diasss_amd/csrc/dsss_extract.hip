@@ -589,7 +589,7 @@ static ex_layout make_layout(int N, const level_geom& g, int kcap)
     return L;
 }
 
-#define EX_BATCH 64
+#define EX_BATCH 256
 
 // extraction of a list of frames, batched: per frame K1-K3 (+ candidate compaction), then ONE quadtree launch for the
 // whole batch (one workgroup per frame x level), then per frame K5-K7 + mask filter.  No host round trip per frame.

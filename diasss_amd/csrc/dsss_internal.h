@@ -27,7 +27,7 @@ struct dsss_frame {
     size_t img_cap = 0;               // bytes allocated for mask / lvl[0]
     int nkp = 0;
     double bbox[4] = {0, 0, 0, 0};
-    bool has_bbox = false;
+    bool has_bbox = false, bbox_async = false;
     // FAST candidates of the last extraction, per level (host, for the stage tap)
     std::vector<float> cand_x[DSSS_MAX_LEVELS], cand_y[DSSS_MAX_LEVELS], cand_r[DSSS_MAX_LEVELS];
 };
@@ -58,6 +58,8 @@ struct dsss_ctx {
     int* rows_dev = nullptr;            // [F] pings per frame
     int* cols_dev = nullptr;            // [F]
     double* bbox_dev = nullptr;         // [F][4]
+    double* bbox_pinned = nullptr;      // [F][4] pinned host mirror, filled asynchronously
+    bool bbox_pending = false;          // boxes launched but not yet copied into dsss_frame::bbox
     // extraction scratch (grown on demand)
     void* ex_scratch = nullptr; size_t ex_scratch_bytes = 0;
     void* ex_pinned = nullptr; size_t ex_pinned_bytes = 0;
@@ -102,7 +104,8 @@ struct dsss_scope {
 };
 
 int dsss_ensure_store(dsss_ctx* c);                 // allocate the feature store for the current kcap
-int dsss_frame_geo_bbox(dsss_ctx* c, int id);       // device computation of the geo bounding box
+int dsss_frame_geo_bbox(dsss_ctx* c, int id);       // device computation of the geo bounding box (asynchronous)
+int dsss_sync_bboxes(dsss_ctx* c);                  // make dsss_frame::bbox valid on the host
 int dsss_frame_kp_geo(dsss_ctx* c, int id, int n);  // geo lookup of the stored keypoints (frame.cpp:126-165)
 void dsss_pg_free(dsss_ctx* c);
 

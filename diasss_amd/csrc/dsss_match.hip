@@ -341,6 +341,7 @@ int dsss_match_pairs(dsss_ctx* c, const int* src_ids, const int* tgt_ids, int np
     c->npairs = npairs; c->has_lc = false;
     c->pair_s.assign(src_ids, src_ids + npairs); c->pair_t.assign(tgt_ids, tgt_ids + npairs);
     c->pair_active.assign(npairs, -1);
+    { int rc = dsss_sync_bboxes(c); if (rc) return rc; }
     std::vector<int> as, at;
     for (int p = 0; p < npairs; ++p) {
         const int s = src_ids[p], t = tgt_ids[p];

@@ -405,6 +405,7 @@ __global__ __launch_bounds__(256) void pg_panel_diag_kernel(const int* __restric
     // blocked right-looking Cholesky: thread (bi, bj) of a 16 x 16 grid owns the 6 x 6 block A(bi, bj) in registers;
     // per block step k: (k,k) factors, column k solves against L_kk, the trailing blocks subtract L_ik L_jk^T.
     __shared__ double sLkk[36];
+    __shared__ double sRinv[6];
     __shared__ double sLcol[PG_PW][36];
     __shared__ double sy[6];
     __shared__ int s_bad;
@@ -435,15 +436,20 @@ __global__ __launch_bounds__(256) void pg_panel_diag_kernel(const int* __restric
         if (bi == k && bj == k) {
             if (chol6(a)) { s_bad = 1; for (int e = 0; e < 36; ++e) a[e] = (e % 7 == 0) ? 1.0 : 0.0; }
             for (int r = 0; r < 6; ++r) for (int c2 = r + 1; c2 < 6; ++c2) a[r * 6 + c2] = 0.0;
+            double ri[6];
+            for (int e = 0; e < 6; ++e) { ri[e] = 1.0 / a[e * 7]; sRinv[e] = ri[e]; }
             for (int e = 0; e < 36; ++e) sLkk[e] = a[e];
-            for (int r = 0; r < 6; ++r) { double v = y[r]; for (int c2 = 0; c2 < r; ++c2) v -= a[r * 6 + c2] * y[c2]; y[r] = v / a[r * 6 + r]; }
+            for (int r = 0; r < 6; ++r) { double v = y[r]; for (int c2 = 0; c2 < r; ++c2) v -= a[r * 6 + c2] * y[c2]; y[r] = v * ri[r]; }
             for (int e = 0; e < 6; ++e) sy[e] = y[e];
         }
         __syncthreads();
         if (act && bj == k && bi > k) {                      // X L_kk^T = A_ik, row by row
+#pragma unroll
             for (int r = 0; r < 6; ++r) {
                 double xr[6];
-                for (int s2 = 0; s2 < 6; ++s2) { double v = a[r * 6 + s2]; for (int c2 = 0; c2 < s2; ++c2) v -= xr[c2] * sLkk[s2 * 6 + c2]; xr[s2] = v / sLkk[s2 * 6 + s2]; }
+#pragma unroll
+                for (int s2 = 0; s2 < 6; ++s2) { double v = a[r * 6 + s2]; for (int c2 = 0; c2 < s2; ++c2) v -= xr[c2] * sLkk[s2 * 6 + c2]; xr[s2] = v * sRinv[s2]; }
+#pragma unroll
                 for (int s2 = 0; s2 < 6; ++s2) a[r * 6 + s2] = xr[s2];
             }
             for (int e = 0; e < 36; ++e) sLcol[bi][e] = a[e];
@@ -478,47 +484,59 @@ __global__ __launch_bounds__(256) void pg_panel_trsm_kernel(const int* __restric
                                                             const int* __restrict__ pan_lcol0, const int* __restrict__ colptr,
                                                             double* __restrict__ Lvals, const double* __restrict__ part, int nsl, int col_stride)
 {
-    extern __shared__ double sL[];                 // L11, n x n row-major
+    extern __shared__ double sL[];                 // L11, n x n row-major, then 1/diag [n]
     const int p = plvpan[blockIdx.x];
     const int j0 = pan_first[p], w = pan_w[p], n = 6 * w, lc0 = pan_lcol0[p];
     const int m = colptr[j0 + 1] - colptr[j0];     // block rows of the first column
     const int nrows = 6 * (m - w);
     if ((int)blockIdx.y * 256 >= nrows) return;
+    double* sR = sL + n * n;
     for (int idx = threadIdx.x; idx < n * n; idx += 256) {
         const int gi = idx / n, gj = idx - gi * n;
         const int qi = gi / 6, c = gj / 6;
-        sL[idx] = (qi >= c) ? Lvals[pan_pos(colptr, j0, qi, c) * 36 + (gi % 6) * 6 + (gj % 6)] : 0.0;
+        const double v = (qi >= c) ? Lvals[pan_pos(colptr, j0, qi, c) * 36 + (gi % 6) * 6 + (gj % 6)] : 0.0;
+        sL[idx] = v;
+        if (gi == gj) sR[gi] = 1.0 / v;
     }
     __syncthreads();
     const int row = blockIdx.y * 256 + threadIdx.x;
     if (row >= nrows) return;
     const int qi = w + row / 6, r = row % 6;       // block row index within the first column's structure
-    for (int c = 0; c < w; ++c) {
-        double* dst = Lvals + pan_pos(colptr, j0, qi, c) * 36 + r * 6;
-        double a[6];
-        for (int s = 0; s < 6; ++s) a[s] = dst[s];
-        if (nsl > 1)
-            for (int sl = 0; sl < nsl; ++sl) {
-                const double* o = part + ((size_t)(lc0 + c) * nsl + sl) * col_stride + (size_t)((qi - c) * 6 + r) * 6;
-                for (int s = 0; s < 6; ++s) a[s] -= o[s];
+    double xs[PG_PW * 6];                          // solved part of the row stays in registers (loops fully unrolled)
+#pragma unroll
+    for (int c = 0; c < PG_PW; ++c) {
+        if (c < w) {
+            double* dst = Lvals + pan_pos(colptr, j0, qi, c) * 36 + r * 6;
+            double a[6];
+#pragma unroll
+            for (int s = 0; s < 6; ++s) a[s] = dst[s];
+            if (nsl > 1)
+                for (int sl = 0; sl < nsl; ++sl) {
+                    const double* o = part + ((size_t)(lc0 + c) * nsl + sl) * col_stride + (size_t)((qi - c) * 6 + r) * 6;
+#pragma unroll
+                    for (int s = 0; s < 6; ++s) a[s] -= o[s];
+                }
+#pragma unroll
+            for (int cp = 0; cp < PG_PW; ++cp) {
+                if (cp < c) {
+#pragma unroll
+                    for (int s = 0; s < 6; ++s) {
+                        const double* Lr = sL + (c * 6 + s) * n + cp * 6;
+                        a[s] -= xs[cp * 6] * Lr[0] + xs[cp * 6 + 1] * Lr[1] + xs[cp * 6 + 2] * Lr[2] + xs[cp * 6 + 3] * Lr[3] + xs[cp * 6 + 4] * Lr[4] + xs[cp * 6 + 5] * Lr[5];
+                    }
+                }
             }
-        for (int cp = 0; cp < c; ++cp) {
-            const double* xr = Lvals + pan_pos(colptr, j0, qi, cp) * 36 + r * 6;
-            const double x0 = xr[0], x1 = xr[1], x2 = xr[2], x3 = xr[3], x4 = xr[4], x5 = xr[5];
 #pragma unroll
             for (int s = 0; s < 6; ++s) {
-                const double* Lr = sL + (c * 6 + s) * n + cp * 6;
-                a[s] -= x0 * Lr[0] + x1 * Lr[1] + x2 * Lr[2] + x3 * Lr[3] + x4 * Lr[4] + x5 * Lr[5];
+                double v = a[s];
+                const double* Lr = sL + (c * 6 + s) * n + c * 6;
+#pragma unroll
+                for (int t = 0; t < 6; ++t) if (t < s) v -= xs[c * 6 + t] * Lr[t];
+                xs[c * 6 + s] = v * sR[c * 6 + s];
             }
+#pragma unroll
+            for (int s = 0; s < 6; ++s) dst[s] = xs[c * 6 + s];
         }
-        double xo[6];
-        for (int s = 0; s < 6; ++s) {
-            double v = a[s];
-            const double* Lr = sL + (c * 6 + s) * n + c * 6;
-            for (int t = 0; t < s; ++t) v -= xo[t] * Lr[t];
-            xo[s] = v / Lr[s];
-        }
-        for (int s = 0; s < 6; ++s) dst[s] = xo[s];
     }
 }
 
@@ -1207,16 +1225,14 @@ static int pg_solve_impl(dsss_ctx* c, const double* dr6, int total, const dsss_l
                     const int ncl = S.lvptr[l + 1] - S.lvptr[l], npl = S.plvptr[l + 1] - S.plvptr[l];
                     const int stride = lv_chunks[l] * 256 * 6 + 8;
                     const int nsl = lv_upd[l] ? lv_slices[l] : 1;
-                    const size_t shb = ((size_t)plv_n[l] * plv_n[l] + plv_n[l]) * sizeof(double);
                     if (lv_upd[l]) hipLaunchKernelGGL(pg_factor_acc_kernel, dim3(ncl, lv_chunks[l], lv_slices[l]), dim3(256), 0, st, d_lvcols + S.lvptr[l], d_colptr, d_rlptr, d_rlpos,
                                                       d_mapptr, d_map, d_L, d_part2, stride, d_rlcol, d_x, d_tlim);
                     hipLaunchKernelGGL(pg_panel_diag_kernel, dim3(npl), dim3(256), 0, st, d_plvpan + S.plvptr[l], d_pan_first, d_pan_w, d_pan_lcol0, d_colptr, d_L, d_part2, nsl, stride, d_x, d_fail);
                     if (plv_rowchunks[l] > 0)
-                        hipLaunchKernelGGL(pg_panel_trsm_kernel, dim3(npl, plv_rowchunks[l]), dim3(256), (size_t)plv_n[l] * plv_n[l] * sizeof(double), st, d_plvpan + S.plvptr[l], d_pan_first, d_pan_w,
+                        hipLaunchKernelGGL(pg_panel_trsm_kernel, dim3(npl, plv_rowchunks[l]), dim3(256), ((size_t)plv_n[l] * plv_n[l] + plv_n[l]) * sizeof(double), st, d_plvpan + S.plvptr[l], d_pan_first, d_pan_w,
                                            d_pan_lcol0, d_colptr, d_L, d_part2, nsl, stride);
                 }
                 for (int l = nlev - 1; l >= 0; --l) {
-                    const size_t shb = ((size_t)plv_n[l] * plv_n[l] + plv_n[l]) * sizeof(double);
                     hipLaunchKernelGGL(pg_panel_bwd_kernel, dim3(S.plvptr[l + 1] - S.plvptr[l]), dim3(256), 0, st, d_plvpan + S.plvptr[l], d_pan_first, d_pan_w, d_colptr, d_rowidx, d_L, d_x);
                 }
                 if (nbins > 0) hipLaunchKernelGGL(pg_bwd_subtree_kernel, dim3(nbins), dim3(64), 0, st, d_binptr, d_bincols, d_colptr, d_rowidx, d_L, d_x);
