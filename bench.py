@@ -131,15 +131,16 @@ def main():
         dt = float(t.item())
 
     # ---- per-kernel timing pass (HIP events on the library's stream), outside the timed region
-    breakdown, roof = None, None
+    breakdown, roof, work = None, None, None
     if not args.no_roofline:
         pipe.ctx.profile(True); pipe.ctx.profile_reset()
         pipe.run(raws, poses, alts, grs)
         barrier()
         prof = pipe.ctx.profile_get()
         pipe.ctx.profile(False)
-        breakdown = {k: round(v[0], 3) for k, v in prof.items()}
+        breakdown = {k: round(v[0], 3) for k, v in prof.items() if v[1] > 0}
         roof = roofline(prof, wl, len(mine))
+        work = {k: ("%.3g flop" if k in FLOP_SLOTS else "%.3g B") % v[2] for k, v in prof.items() if v[1] > 0 and v[2] > 0}
     nkp = [pipe.ctx.features_get(f)[0].shape[0] for f in mine[:8]]
     tot_rows, tot_kp7 = pipe.ctx.match_total()
 
@@ -153,7 +154,7 @@ def main():
                        "kp_per_frame": int(np.mean(nkp)) if nkp else 0, "matches_rank0": tot_rows, "lc_problems_rank0": tot_kp7,
                        "pg_stats": [float(s) for s in stats] if stats is not None else None,
                        "parallelism": "frames+pairs sharded over %d rank(s), RCCL all-gather" % world},
-            "roofline": roof, "breakdown_ms": breakdown,
+            "roofline": roof, "breakdown_ms": breakdown, "work_per_step": work,
         }
         if args.cpu_frames > 0:
             out["cpu_baseline"] = cpu_baseline(sv, wl, min(args.cpu_frames, F))
@@ -163,24 +164,26 @@ def main():
         dist.destroy_process_group()
 
 
+F64_PEAK_TFLOPS = 78.6   # MI355X FP64 vector/matrix peak (AMD spec sheet; MI355X_MICROARCH.md lists no f64 MFMA row)
+
+# what bounds each timed kernel.  The streaming kernels are priced in algorithmic HBM bytes, the
+# pose-graph factorisation kernels in f64 flops against the f64 matrix peak they should eventually run at.
+FLOP_SLOTS = {"pg_acc", "pg_diag", "pg_trsm", "pg_bwd"}
+
+
 def roofline(prof, wl, n_local_frames):
-    """roofline of the kernel with the largest share of GPU time.  Algorithmic bytes per launch:
-    normalize_kernel reads the f64 waterfall once and writes the u8 image: 9*N*M bytes per frame."""
-    N, M = wl["N"], wl["M"]
-    alg = {
-        "row_reduce": 8.0 * N * M,                  # f64 read
-        "normalize": 9.0 * N * M,                   # f64 read + u8 write
-        "fast": 2.906 * N * M,                      # u8 read of the 6 pyramid levels
-    }
-    best = None
-    for k, (ms, n) in prof.items():
-        if k in alg and n > 0 and (best is None or ms > prof[best][0]):
-            best = k
-    if best is None:
+    """roofline of the single kernel with the largest accumulated GPU time (umbrella slots excluded)"""
+    cand = {k: v for k, v in prof.items() if k not in ("pg", "pg_subtree", "k19") and v[1] > 0 and v[2] > 0}
+    if not cand:
         return None
-    ms, n = prof[best]
+    best = max(cand, key=lambda k: cand[k][0])
+    ms, n, work = cand[best]
     per_launch_s = ms * 1e-3 / n
-    ach = alg[best] / per_launch_s / 1e9
+    if best in FLOP_SLOTS:
+        ach = work / n / per_launch_s / 1e12
+        return {"kernel": best, "bound": "mfma", "achieved": ach, "peak": F64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / F64_PEAK_TFLOPS,
+                "traffic": None, "launches": n, "avg_launch_us": per_launch_s * 1e6, "note": "f64; the kernel does not use MFMA yet"}
+    ach = work / n / per_launch_s / 1e9
     return {"kernel": best, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
             "traffic": None, "launches": n, "avg_launch_us": per_launch_s * 1e6}
 

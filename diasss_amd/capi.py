@@ -20,7 +20,7 @@ LC_DTYPE = np.dtype([("rel", "<f8", (12,)), ("var", "<f8", (6,)), ("score", "<f8
 LCEDGE_DTYPE = np.dtype([("a", "<i4"), ("b", "<i4"), ("rel", "<f8", (12,)), ("var", "<f8", (6,))])
 
 K_NAMES = ["row_reduce", "pre_misc", "normalize", "pyramid", "fast", "fast_compact", "desc", "filter", "match", "scc", "rows", "lc", "pg",
-           "quadtree", "k14", "k15"]
+           "quadtree", "pg_acc", "pg_diag", "pg_trsm", "pg_bwd", "pg_subtree", "k19"]
 
 
 class MaskParams(C.Structure):
@@ -293,6 +293,7 @@ class Context:
         self._chk(self.L.dsss_profile_reset(self.h), "dsss_profile_reset")
 
     def profile_get(self):
-        ms = np.zeros(16, np.float64); n = np.zeros(16, np.int64)
+        ms = np.zeros(20, np.float64); n = np.zeros(20, np.int64); wk = np.zeros(20, np.float64)
         self._chk(self.L.dsss_profile_get(self.h, _ptr(ms), _ptr(n)), "dsss_profile_get")
-        return {K_NAMES[i]: (float(ms[i]), int(n[i])) for i in range(14)}
+        self._chk(self.L.dsss_profile_get_work(self.h, _ptr(wk)), "dsss_profile_get_work")
+        return {K_NAMES[i]: (float(ms[i]), int(n[i]), float(wk[i])) for i in range(19)}

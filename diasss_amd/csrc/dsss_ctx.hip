@@ -403,7 +403,13 @@ int dsss_profile_enable(dsss_ctx* c, int on) { if (!c) return DSSS_E_ARG; c->pro
 int dsss_profile_reset(dsss_ctx* c)
 {
     if (!c) return DSSS_E_ARG;
-    for (int i = 0; i < DSSS_K_COUNT; ++i) { c->prof.ms[i] = 0; c->prof.launches[i] = 0; }
+    for (int i = 0; i < DSSS_K_COUNT; ++i) { c->prof.ms[i] = 0; c->prof.launches[i] = 0; c->prof.work[i] = 0; }
+    return DSSS_OK;
+}
+int dsss_profile_get_work(dsss_ctx* c, double* work)
+{
+    if (!c || !work) return DSSS_E_ARG;
+    for (int i = 0; i < DSSS_K_COUNT; ++i) work[i] = c->prof.work[i];
     return DSSS_OK;
 }
 int dsss_profile_get(dsss_ctx* c, double* ms, int64_t* launches)

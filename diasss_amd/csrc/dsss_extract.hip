@@ -644,22 +644,22 @@ static int extract_frames(dsss_ctx* c, const int* ids, int n, bool keep_taps)
             int* d_err = (int*)(S + L.err);
             HIPCHK(c, hipMemsetAsync(d_err, 0, sizeof(int), st));
             const size_t tot = (size_t)N * M;
-            { dsss_scope sc(c, DSSS_K_ROW_REDUCE);
+            { dsss_scope sc(c, DSSS_K_ROW_REDUCE, 8.0 * tot);
               hipLaunchKernelGGL(row_reduce_kernel, dim3((N + 3) / 4), dim3(256), 0, st, f.raw, N, M, d_rowsum, d_rowmin); }
-            { dsss_scope sc(c, DSSS_K_PRE_MISC);
+            { dsss_scope sc(c, DSSS_K_PRE_MISC, 1.0 * tot);
               hipLaunchKernelGGL(final_reduce_kernel, dim3(1), dim3(64), 0, st, d_rowsum, d_rowmin, N, M, (double)(float)c->mp.factor, d_stats);
               hipLaunchKernelGGL(mask_init_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, f.mask, N, M, c->mp.width, c->mp.side, (double)c->mp.side * 0.6); }
-            { dsss_scope sc(c, DSSS_K_NORMALIZE);
+            { dsss_scope sc(c, DSSS_K_NORMALIZE, 9.0 * tot);
               hipLaunchKernelGGL(normalize_kernel, dim3((unsigned)((tot / 4 + 256) / 256)), dim3(256), 0, st, f.raw, N, M, d_stats, c->mp.r, f.lvl[0], f.mask); }
             level_tab lv;
             for (int l = 0; l < DSSS_MAX_LEVELS; ++l) { lv.img[l] = l < g.nlevels ? f.lvl[l] : nullptr; lv.cols[l] = l < g.nlevels ? g.cols[l] : 0; }
-            { dsss_scope sc(c, DSSS_K_PYRAMID);
+            { dsss_scope sc(c, DSSS_K_PYRAMID, (1.906 + 2.74) * tot);
               for (int l = 1; l < g.nlevels; ++l) {
                   const double sx = 1. / ((double)g.cols[l] / g.cols[l - 1]), sy = 1. / ((double)g.rows[l] / g.rows[l - 1]);
                   hipLaunchKernelGGL(resize_kernel, dim3((g.cols[l] + 255) / 256, g.rows[l]), dim3(256), 0, st, f.lvl[l - 1], g.rows[l - 1], g.cols[l - 1],
                                      f.lvl[l], g.rows[l], g.cols[l], sx, sy);
               } }
-            { dsss_scope sc(c, DSSS_K_FAST);
+            { dsss_scope sc(c, DSSS_K_FAST, 2.906 * tot);
               hipLaunchKernelGGL(fast_cells_kernel, dim3(ncells), dim3(256), 0, st, g.d_cells, lv, c->op.ini_th, c->op.min_th, d_cand, d_counts, g.cell_cap); }
             { dsss_scope sc(c, DSSS_K_FAST_COMPACT);
               hipLaunchKernelGGL(scan_counts_kernel, dim3(1), dim3(256), 0, st, d_counts, ncells, d_offs);
@@ -698,7 +698,7 @@ static int extract_frames(dsss_ctx* c, const int* ids, int n, bool keep_taps)
             for (int l = 0; l < DSSS_MAX_LEVELS; ++l) { lv.img[l] = l < g.nlevels ? f.lvl[l] : nullptr; lv.cols[l] = l < g.nlevels ? g.cols[l] : 0; }
             kp_in* d_kin = (kp_in*)(S + L.kin); int* d_nk = (int*)(S + L.nk);
             dsss_kp* d_kptmp = (dsss_kp*)(S + L.kptmp); uint8_t* d_dtmp = (uint8_t*)(S + L.dtmp);
-            { dsss_scope sc(c, DSSS_K_DESC);
+            { dsss_scope sc(c, DSSS_K_DESC, (double)c->op.nfeatures * (49.0 * 49.0 + 56.0));
               hipLaunchKernelGGL(orient_desc_kernel, dim3((c->kcap + 3) / 4), dim3(256), 0, st, d_kin, d_nk, lv, g.d_lrows, g.d_lscale, d_kptmp, d_dtmp); }
             { dsss_scope sc(c, DSSS_K_FILTER);
               hipLaunchKernelGGL(mask_filter_kernel, dim3(1), dim3(256), 0, st, d_kptmp, d_dtmp, d_nk, f.mask, f.M, f.pose6, f.gr,

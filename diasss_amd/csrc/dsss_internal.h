@@ -36,6 +36,7 @@ struct dsss_prof {
     bool on = false;
     double ms[DSSS_K_COUNT] = {0};
     int64_t launches[DSSS_K_COUNT] = {0};
+    double work[DSSS_K_COUNT] = {0};      // algorithmic bytes / flops (include/dsss.h)
     hipEvent_t e0 = nullptr, e1 = nullptr;
 };
 
@@ -91,14 +92,17 @@ struct dsss_ctx {
 
 // kernel-family timing with HIP events on the context stream (dsss_profile_*)
 struct dsss_scope {
-    dsss_ctx* c; int k;
-    dsss_scope(dsss_ctx* c_, int k_) : c(c_), k(k_) { if (c->prof.on) hipEventRecord(c->prof.e0, c->stream); }
+    dsss_ctx* c; int k; hipEvent_t e0 = nullptr, e1 = nullptr;     // own event pair: scopes may nest (pose-graph solve)
+    dsss_scope(dsss_ctx* c_, int k_, double work = 0) : c(c_), k(k_) {
+        if (c->prof.on) { c->prof.work[k] += work; hipEventCreate(&e0); hipEventCreate(&e1); hipEventRecord(e0, c->stream); }
+    }
     ~dsss_scope() {
-        if (c->prof.on) {
-            hipEventRecord(c->prof.e1, c->stream);
-            hipEventSynchronize(c->prof.e1);
-            float ms = 0; hipEventElapsedTime(&ms, c->prof.e0, c->prof.e1);
+        if (e0) {
+            hipEventRecord(e1, c->stream);
+            hipEventSynchronize(e1);
+            float ms = 0; hipEventElapsedTime(&ms, e0, e1);
             c->prof.ms[k] += ms; c->prof.launches[k] += 1;
+            hipEventDestroy(e0); hipEventDestroy(e1);
         }
     }
 };

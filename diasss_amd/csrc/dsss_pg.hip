@@ -1138,6 +1138,17 @@ static int pg_solve_impl(dsss_ctx* c, const double* dr6, int total, const dsss_l
     const int nbins = (int)S.binptr.size() - 1;
     TRY(dv.upload(c, &d_pan_first, S.pan_first)); TRY(dv.upload(c, &d_pan_w, S.pan_w)); TRY(dv.upload(c, &d_pan_lcol0, S.pan_lcol0)); TRY(dv.upload(c, &d_plvpan, S.plvpan)); TRY(dv.upload(c, &d_tlim, S.tlim));
     std::vector<int> plv_n(nlev, 6), plv_rowchunks(nlev, 0);
+    std::vector<double> fl_acc(nlev, 0), fl_diag(nlev, 0), fl_trsm(nlev, 0), fl_bwd(nlev, 0);
+    for (int l = 0; l < nlev; ++l) {
+        for (int q = S.lvptr[l]; q < S.lvptr[l + 1]; ++q) {
+            const int j = S.lvcols[q];
+            for (int t = 0; t < S.tlim[j]; ++t) { const int k = S.rlcol[S.rlptr[j] + t]; fl_acc[l] += 432.0 * (S.colptr[k + 1] - S.rlpos[S.rlptr[j] + t]); }
+        }
+        for (int q = S.plvptr[l]; q < S.plvptr[l + 1]; ++q) {
+            const int p = S.plvpan[q], j0 = S.pan_first[p], w = S.pan_w[p]; const double nn = 6.0 * w, rows = 6.0 * (S.colptr[j0 + 1] - S.colptr[j0] - w);
+            fl_diag[l] += nn * nn * nn / 3.0 + nn * nn; fl_trsm[l] += rows * nn * nn; fl_bwd[l] += 2.0 * rows * nn + nn * nn;
+        }
+    }
     for (int l = 0; l < nlev; ++l)
         for (int q = S.plvptr[l]; q < S.plvptr[l + 1]; ++q) {
             const int p = S.plvpan[q], j0 = S.pan_first[p], w = S.pan_w[p];
@@ -1220,22 +1231,28 @@ static int pg_solve_impl(dsss_ctx* c, const double* dr6, int total, const dsss_l
                 hipLaunchKernelGGL(pg_segment_kernel, dim3((nseg + 63) / 64), dim3(64), 0, st, nseg, d_sep, d_D, d_C, d_g, d_E, d_Dl, d_gi, d_sDL, d_sDR, d_sGL, d_sGR, d_sS, d_fail);
                 hipLaunchKernelGGL(pg_scatter_base_kernel, dim3((ns + 255) / 256), dim3(256), 0, st, ns, d_sep, d_perm, d_D, d_g, d_sDL, d_sDR, d_sGL, d_sGR, d_sS, d_diag, d_ch, d_L, d_x);
                 if (ne > 0) hipLaunchKernelGGL(pg_scatter_lc_kernel, dim3((ne + 255) / 256), dim3(256), 0, st, n, ne, d_Ji, d_ew, d_lc, d_L);
-                if (nbins > 0) hipLaunchKernelGGL(pg_factor_subtree_kernel, dim3(nbins), dim3(256), 0, st, d_binptr, d_bincols, d_colptr, d_rlptr, d_rlcol, d_rlpos, d_mapptr, d_map, d_L, d_x, d_fail);
+                if (nbins > 0) { dsss_scope s1(c, DSSS_K_PG_SUBTREE);
+                                 hipLaunchKernelGGL(pg_factor_subtree_kernel, dim3(nbins), dim3(256), 0, st, d_binptr, d_bincols, d_colptr, d_rlptr, d_rlcol, d_rlpos, d_mapptr, d_map, d_L, d_x, d_fail); }
                 for (int l = 0; l < nlev; ++l) {      // top of the tree: panel levels, forward substitution fused in
                     const int ncl = S.lvptr[l + 1] - S.lvptr[l], npl = S.plvptr[l + 1] - S.plvptr[l];
                     const int stride = lv_chunks[l] * 256 * 6 + 8;
                     const int nsl = lv_upd[l] ? lv_slices[l] : 1;
-                    if (lv_upd[l]) hipLaunchKernelGGL(pg_factor_acc_kernel, dim3(ncl, lv_chunks[l], lv_slices[l]), dim3(256), 0, st, d_lvcols + S.lvptr[l], d_colptr, d_rlptr, d_rlpos,
-                                                      d_mapptr, d_map, d_L, d_part2, stride, d_rlcol, d_x, d_tlim);
-                    hipLaunchKernelGGL(pg_panel_diag_kernel, dim3(npl), dim3(256), 0, st, d_plvpan + S.plvptr[l], d_pan_first, d_pan_w, d_pan_lcol0, d_colptr, d_L, d_part2, nsl, stride, d_x, d_fail);
+                    if (lv_upd[l]) { dsss_scope s2(c, DSSS_K_PG_ACC, fl_acc[l]);
+                                     hipLaunchKernelGGL(pg_factor_acc_kernel, dim3(ncl, lv_chunks[l], lv_slices[l]), dim3(256), 0, st, d_lvcols + S.lvptr[l], d_colptr, d_rlptr, d_rlpos,
+                                                        d_mapptr, d_map, d_L, d_part2, stride, d_rlcol, d_x, d_tlim); }
+                    { dsss_scope s3(c, DSSS_K_PG_DIAG, fl_diag[l]);
+                      hipLaunchKernelGGL(pg_panel_diag_kernel, dim3(npl), dim3(256), 0, st, d_plvpan + S.plvptr[l], d_pan_first, d_pan_w, d_pan_lcol0, d_colptr, d_L, d_part2, nsl, stride, d_x, d_fail); }
+                    dsss_scope s4(c, DSSS_K_PG_TRSM, plv_rowchunks[l] > 0 ? fl_trsm[l] : 0.0);
                     if (plv_rowchunks[l] > 0)
                         hipLaunchKernelGGL(pg_panel_trsm_kernel, dim3(npl, plv_rowchunks[l]), dim3(256), ((size_t)plv_n[l] * plv_n[l] + plv_n[l]) * sizeof(double), st, d_plvpan + S.plvptr[l], d_pan_first, d_pan_w,
                                            d_pan_lcol0, d_colptr, d_L, d_part2, nsl, stride);
                 }
                 for (int l = nlev - 1; l >= 0; --l) {
+                    dsss_scope s5(c, DSSS_K_PG_BWD, fl_bwd[l]);
                     hipLaunchKernelGGL(pg_panel_bwd_kernel, dim3(S.plvptr[l + 1] - S.plvptr[l]), dim3(256), 0, st, d_plvpan + S.plvptr[l], d_pan_first, d_pan_w, d_colptr, d_rowidx, d_L, d_x);
                 }
-                if (nbins > 0) hipLaunchKernelGGL(pg_bwd_subtree_kernel, dim3(nbins), dim3(64), 0, st, d_binptr, d_bincols, d_colptr, d_rowidx, d_L, d_x);
+                if (nbins > 0) { dsss_scope s6(c, DSSS_K_PG_SUBTREE);
+                    hipLaunchKernelGGL(pg_bwd_subtree_kernel, dim3(nbins), dim3(64), 0, st, d_binptr, d_bincols, d_colptr, d_rowidx, d_L, d_x); }
                 hipLaunchKernelGGL(pg_sep_delta_kernel, dim3((ns + 255) / 256), dim3(256), 0, st, ns, d_sep, d_perm, d_x, d_delta);
                 hipLaunchKernelGGL(pg_backsub_kernel, dim3((nseg + 63) / 64), dim3(64), 0, st, nseg, d_sep, d_C, d_E, d_Dl, d_gi, d_delta);
                 hipLaunchKernelGGL(pg_linerr_kernel, dim3(nblk), dim3(256), 0, st, n, ne, W, d_ea, d_eb, d_ew, d_r, d_Ji, d_delta, d_part);

@@ -150,10 +150,18 @@ int dsss_posegraph_solve_edges(dsss_ctx*, const double* dr6, int total, const ds
 #define DSSS_K_LC          11   /* lc_kernel */
 #define DSSS_K_PG          12   /* pose-graph LM loop (all its kernels) */
 #define DSSS_K_QUADTREE    13   /* quadtree_kernel + collect (K4 on the device) */
-#define DSSS_K_COUNT       16
+#define DSSS_K_PG_ACC      14   /* pg_factor_acc_kernel (external block updates of the panels) */
+#define DSSS_K_PG_DIAG     15   /* pg_panel_diag_kernel */
+#define DSSS_K_PG_TRSM     16   /* pg_panel_trsm_kernel */
+#define DSSS_K_PG_BWD      17   /* pg_panel_bwd_kernel */
+#define DSSS_K_PG_SUBTREE  18   /* pg_factor_subtree_kernel + pg_bwd_subtree_kernel */
+#define DSSS_K_COUNT       20
 int dsss_profile_enable(dsss_ctx*, int on);
 int dsss_profile_get(dsss_ctx*, double* ms_host /*DSSS_K_COUNT*/, int64_t* launches_host /*DSSS_K_COUNT*/);
 int dsss_profile_reset(dsss_ctx*);
+/* algorithmic work accumulated next to the time of each slot while profiling is on: bytes for the streaming kernels
+ * (slots 0..13), f64 flops for the pose-graph factorisation kernels (slots 14..18); definitions in DESIGN.md section 4 */
+int dsss_profile_get_work(dsss_ctx*, double* work_host /*DSSS_K_COUNT*/);
 
 #ifdef __cplusplus
 }
