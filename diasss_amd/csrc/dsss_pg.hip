@@ -480,7 +480,7 @@ __global__ __launch_bounds__(256) void pg_panel_diag_kernel(const int* __restric
 
 // L21 = A21 L11^-T : one thread per scalar row below the panel's diagonal block; block column by block column, the
 // already finished part of the row is re-read from global memory (written by the same thread)
-__global__ __launch_bounds__(256) void pg_panel_trsm_kernel(const int* __restrict__ plvpan, const int* __restrict__ pan_first, const int* __restrict__ pan_w,
+__global__ __launch_bounds__(256, 1) void pg_panel_trsm_kernel(const int* __restrict__ plvpan, const int* __restrict__ pan_first, const int* __restrict__ pan_w,
                                                             const int* __restrict__ pan_lcol0, const int* __restrict__ colptr,
                                                             double* __restrict__ Lvals, const double* __restrict__ part, int nsl, int col_stride)
 {
@@ -491,12 +491,17 @@ __global__ __launch_bounds__(256) void pg_panel_trsm_kernel(const int* __restric
     const int nrows = 6 * (m - w);
     if ((int)blockIdx.y * 256 >= nrows) return;
     double* sR = sL + n * n;
-    for (int idx = threadIdx.x; idx < n * n; idx += 256) {
-        const int gi = idx / n, gj = idx - gi * n;
-        const int qi = gi / 6, c = gj / 6;
-        const double v = (qi >= c) ? Lvals[pan_pos(colptr, j0, qi, c) * 36 + (gi % 6) * 6 + (gj % 6)] : 0.0;
-        sL[idx] = v;
-        if (gi == gj) sR[gi] = 1.0 / v;
+    {   // stage L11: thread (qb, cb) copies the 6 x 6 block (qb, cb), cb <= qb (the upper blocks are never read)
+        const int qb = threadIdx.x >> 4, cb = threadIdx.x & 15;
+        if (qb < w && cb <= qb) {
+            const double* src = Lvals + pan_pos(colptr, j0, qb, cb) * 36;
+#pragma unroll
+            for (int e = 0; e < 36; ++e) sL[(qb * 6 + e / 6) * n + cb * 6 + e % 6] = src[e];
+            if (qb == cb) {
+#pragma unroll
+                for (int e = 0; e < 6; ++e) sR[qb * 6 + e] = 1.0 / src[e * 7];
+            }
+        }
     }
     __syncthreads();
     const int row = blockIdx.y * 256 + threadIdx.x;

@@ -518,7 +518,7 @@ int orc_orb_extract(const uint8_t* img, int rows, int cols, const orc_orb_params
         orc_resize_linear_u8(pyr[l - 1], lrows[l - 1], lcols[l - 1], pyr[l], lrows[l], lcols[l]);
     }
     int total = 0;
-    int capc = p->nfeatures * 40 + 1024;
+    int capc = rows * cols / 4 + 1024;      /* strict 3x3 local maxima cannot exceed one pixel in four */
     float* cx = (float*)malloc(sizeof(float) * capc);
     float* cy = (float*)malloc(sizeof(float) * capc);
     float* cr = (float*)malloc(sizeof(float) * capc);
