@@ -160,6 +160,21 @@ class Context:
         self._keep = getattr(self, "_keep", {}); self._keep[fid] = raw      # keep device tensors alive
         self._chk(self.L.dsss_frame_set(self.h, fid, _ptr(raw), N, M, _ptr(pose6), _ptr(alt), _ptr(gr)), "dsss_frame_set")
 
+    def frames_set(self, ids, raws, Ns, Ms, poses, alts, grs):
+        """dsss_frames_set: one call for many frames (arrays must be float64 C-contiguous; raws may hold None)"""
+        n = len(ids)
+        self._keep = getattr(self, "_keep", {})
+        VP = C.c_void_p * n
+        def ptrs(seq):
+            return VP(*[(_ptr(a).value if a is not None else None) for a in seq])
+        for a in list(poses) + list(alts) + list(grs):
+            assert a.dtype == np.float64 and a.flags.c_contiguous
+        for i, f in enumerate(ids):
+            self._keep[int(f)] = (raws[i], poses[i], alts[i], grs[i])
+        a_ids = np.ascontiguousarray(ids, np.int32); a_N = np.ascontiguousarray(Ns, np.int32); a_M = np.ascontiguousarray(Ms, np.int32)
+        p_raw, p_pose, p_alt, p_gr = ptrs(raws), ptrs(poses), ptrs(alts), ptrs(grs)       # locals keep the temporaries alive over the call
+        self._chk(self.L.dsss_frames_set(self.h, n, _ptr(a_ids), p_raw, _ptr(a_N), _ptr(a_M), p_pose, p_alt, p_gr), "dsss_frames_set")
+
     def extract(self, fid):
         n = C.c_int(0)
         self._chk(self.L.dsss_extract(self.h, fid, C.byref(n)), "dsss_extract")

@@ -3,6 +3,8 @@
 // and Util::ComputeIntersection (/root/reference/src/util/util.cpp:13-43).
 #include "dsss_internal.h"
 #include <algorithm>
+#include <chrono>
+#include <cstdlib>
 
 extern "C" {
 
@@ -57,7 +59,9 @@ int dsss_create(int device, int max_frames, dsss_ctx** out)
 
 static void free_frame(dsss_frame& f)
 {
-    hipFree(f.raw_owned); hipFree(f.pose6); hipFree(f.alt); hipFree(f.gr); hipFree(f.mask);
+    hipFree(f.raw_owned); hipFree(f.d_pack); hipFree(f.mask);
+    if (f.h_pack) hipHostFree(f.h_pack);
+    if (f.pack_ev) hipEventDestroy(f.pack_ev);
     for (int l = 0; l < DSSS_MAX_LEVELS; ++l) hipFree(f.lvl[l]);
     f = dsss_frame();
 }
@@ -146,9 +150,12 @@ int dsss_ensure_store(dsss_ctx* c)
 // ---- geo bounding box: the four cv::minMaxLoc scans of the N x M geo image (FEAmatcher.cpp:71-72,
 // util.cpp:21-26) collapse to per-row extremes because x = px + g*c is monotone in g for fixed c:
 // only the smallest and largest ground range of each side can be extreme.  One wave per 64 rows.
-__global__ void geo_bbox_kernel(const double* __restrict__ pose6, const double* __restrict__ gr, int N, int M,
-                                double* __restrict__ bbox)
+struct bbox_job { const double* pose6; const double* gr; int N, M, id, pad; };
+__global__ void geo_bbox_kernel(const bbox_job* __restrict__ jobs, double* __restrict__ bbox_all, int* __restrict__ rows_all, int* __restrict__ cols_all)
 {
+    const bbox_job J = jobs[blockIdx.x];
+    const double* pose6 = J.pose6; const double* gr = J.gr; const int N = J.N, M = J.M;
+    double* bbox = bbox_all + (size_t)J.id * 4; int* rows_out = rows_all + J.id; int* cols_out = cols_all + J.id;
     __shared__ double sgmin[2], sgmax[2];
     __shared__ double red[4][256];
     int half = M / 2;
@@ -186,6 +193,7 @@ __global__ void geo_bbox_kernel(const double* __restrict__ pose6, const double* 
         __syncthreads();
     }
     if (threadIdx.x < 4) bbox[threadIdx.x] = red[threadIdx.x][0];
+    if (threadIdx.x == 0) { *rows_out = N; *cols_out = M; }          // per-frame dimensions used by the matcher kernels
 }
 
 int dsss_frame_geo_bbox(dsss_ctx* c, int id)
@@ -193,20 +201,29 @@ int dsss_frame_geo_bbox(dsss_ctx* c, int id)
     dsss_frame& f = c->frames[id];
     if (!f.has_geom) DSSS_FAIL(c, DSSS_E_STATE, "frame %d has no geometry", id);
     int rc = dsss_ensure_store(c); if (rc) return rc;
-    if (!c->bbox_pinned) HIPCHK(c, hipHostMalloc((void**)&c->bbox_pinned, (size_t)c->max_frames * 4 * sizeof(double), hipHostMallocDefault));
-    hipLaunchKernelGGL(geo_bbox_kernel, dim3(1), dim3(256), 0, c->stream, f.pose6, f.gr, f.N, f.M, c->bbox_dev + (size_t)id * 4);
-    HIPCHK(c, hipGetLastError());
-    HIPCHK(c, hipMemcpyAsync(c->bbox_pinned + (size_t)id * 4, c->bbox_dev + (size_t)id * 4, 4 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-    f.has_bbox = true; f.bbox_async = true; c->bbox_pending = true;     // host copy becomes valid in dsss_sync_bboxes
+    f.has_bbox = true; f.bbox_async = true; c->bbox_pending = true;     // computed for all pending frames at once in dsss_sync_bboxes
     return DSSS_OK;
 }
 
+// one launch for every frame whose geo box is pending (one workgroup per frame), then one copy back
 int dsss_sync_bboxes(dsss_ctx* c)
 {
     if (!c->bbox_pending) return DSSS_OK;
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (!c->bbox_pinned) HIPCHK(c, hipHostMalloc((void**)&c->bbox_pinned, (size_t)c->max_frames * 4 * sizeof(double), hipHostMallocDefault));
+    std::vector<bbox_job> jobs;
     for (int f = 0; f < c->max_frames; ++f)
-        if (c->frames[f].bbox_async) { memcpy(c->frames[f].bbox, c->bbox_pinned + (size_t)f * 4, 4 * sizeof(double)); c->frames[f].bbox_async = false; }
+        if (c->frames[f].bbox_async) { const dsss_frame& fr = c->frames[f]; jobs.push_back(bbox_job{ fr.pose6, fr.gr, fr.N, fr.M, f, 0 }); }
+    if (!jobs.empty()) {
+        bbox_job* d_jobs = nullptr;
+        HIPCHK(c, hipMalloc(&d_jobs, jobs.size() * sizeof(bbox_job)));
+        hipError_t e = hipMemcpyAsync(d_jobs, jobs.data(), jobs.size() * sizeof(bbox_job), hipMemcpyHostToDevice, c->stream);
+        if (e == hipSuccess) { hipLaunchKernelGGL(geo_bbox_kernel, dim3((unsigned)jobs.size()), dim3(256), 0, c->stream, d_jobs, c->bbox_dev, c->rows_dev, c->cols_dev); e = hipGetLastError(); }
+        if (e == hipSuccess) e = hipMemcpyAsync(c->bbox_pinned, c->bbox_dev, (size_t)c->max_frames * 4 * sizeof(double), hipMemcpyDeviceToHost, c->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        hipFree(d_jobs);
+        HIPCHK(c, e);
+        for (const bbox_job& j : jobs) { memcpy(c->frames[j.id].bbox, c->bbox_pinned + (size_t)j.id * 4, 4 * sizeof(double)); c->frames[j.id].bbox_async = false; }
+    }
     c->bbox_pending = false;
     return DSSS_OK;
 }
@@ -242,25 +259,39 @@ int dsss_frame_set(dsss_ctx* c, int id, const double* raw, int N, int M, const d
     if (!c) return DSSS_E_ARG;
     if (id < 0 || id >= c->max_frames) DSSS_FAIL(c, DSSS_E_ARG, "frame id %d out of range [0,%d)", id, c->max_frames);
     if (N <= 0 || M < 4 || (M & 1) || !pose6 || !alt || !grange) DSSS_FAIL(c, DSSS_E_ARG, "bad frame geometry N=%d M=%d", N, M);
+    static const bool tv = getenv("DSSS_EX_VERBOSE") != nullptr;
+    const auto tt0 = std::chrono::steady_clock::now();
     HIPCHK(c, hipSetDevice(c->device));
     int rc = dsss_ensure_store(c); if (rc) return rc;
     dsss_frame& f = c->frames[id];
     if (f.N != N || f.M != M) { HIPCHK(c, hipStreamSynchronize(c->stream)); free_frame(f); }
     f.N = N; f.M = M;
-    if (!f.pose6) {
-        HIPCHK(c, hipMalloc(&f.pose6, (size_t)N * 6 * sizeof(double)));
-        HIPCHK(c, hipMalloc(&f.alt, (size_t)N * sizeof(double)));
-        HIPCHK(c, hipMalloc(&f.gr, (size_t)(M / 2) * sizeof(double)));
+    const size_t pack = (size_t)N * 6 + N + M / 2;
+    if (f.pack_cap < pack) {
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        hipFree(f.d_pack); if (f.h_pack) hipHostFree(f.h_pack);
+        f.d_pack = nullptr; f.h_pack = nullptr;
+        HIPCHK(c, hipMalloc(&f.d_pack, pack * sizeof(double)));
+        HIPCHK(c, hipHostMalloc((void**)&f.h_pack, pack * sizeof(double), hipHostMallocDefault));
+        f.pack_cap = pack;
     }
-    f.h_pose6.resize((size_t)N * 6); f.h_alt.resize(N); f.h_gr.resize(M / 2);
-    HIPCHK(c, hipMemcpy(f.h_pose6.data(), pose6, (size_t)N * 6 * sizeof(double), hipMemcpyDefault));
-    HIPCHK(c, hipMemcpy(f.h_alt.data(), alt, (size_t)N * sizeof(double), hipMemcpyDefault));
-    HIPCHK(c, hipMemcpy(f.h_gr.data(), grange, (size_t)(M / 2) * sizeof(double), hipMemcpyDefault));
-    HIPCHK(c, hipMemcpyAsync(f.pose6, f.h_pose6.data(), (size_t)N * 6 * sizeof(double), hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipMemcpyAsync(f.alt, f.h_alt.data(), (size_t)N * sizeof(double), hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipMemcpyAsync(f.gr, f.h_gr.data(), (size_t)(M / 2) * sizeof(double), hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipMemcpyAsync(c->rows_dev + id, &f.N, sizeof(int), hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipMemcpyAsync(c->cols_dev + id, &f.M, sizeof(int), hipMemcpyHostToDevice, c->stream));
+    f.pose6 = f.d_pack; f.alt = f.d_pack + (size_t)N * 6; f.gr = f.alt + N;
+    auto to_host = [&](double* dst, const double* src, size_t n) -> hipError_t {
+        hipPointerAttribute_t at;
+        const bool dev = (hipPointerGetAttributes(&at, src) == hipSuccess) && at.type == hipMemoryTypeDevice;
+        (void)hipGetLastError();
+        if (dev) return hipMemcpy(dst, src, n * sizeof(double), hipMemcpyDeviceToHost);
+        memcpy(dst, src, n * sizeof(double));               // plain host memory: no runtime call
+        return hipSuccess;
+    };
+    if (f.pack_ev) HIPCHK(c, hipEventSynchronize(f.pack_ev));        // the pinned staging area may still feed the previous upload
+    else HIPCHK(c, hipEventCreateWithFlags(&f.pack_ev, hipEventDisableTiming));
+    HIPCHK(c, to_host(f.h_pack, pose6, (size_t)N * 6));
+    HIPCHK(c, to_host(f.h_pack + (size_t)N * 6, alt, (size_t)N));
+    HIPCHK(c, to_host(f.h_pack + (size_t)N * 7, grange, (size_t)(M / 2)));
+    HIPCHK(c, hipMemcpyAsync(f.d_pack, f.h_pack, pack * sizeof(double), hipMemcpyHostToDevice, c->stream));   // pinned: truly asynchronous
+    HIPCHK(c, hipEventRecord(f.pack_ev, c->stream));
+    const auto tt1 = std::chrono::steady_clock::now();
     f.has_geom = true; f.has_feat = false; f.has_norm = false; f.nkp = 0;          // no synchronisation: the sources above live in the context
     if (raw) {
         hipPointerAttribute_t at;
@@ -274,7 +305,25 @@ int dsss_frame_set(dsss_ctx* c, int id, const double* raw, int N, int M, const d
         }
         f.has_raw = true;
     } else f.has_raw = false;
-    return dsss_frame_geo_bbox(c, id);
+    const auto tt2 = std::chrono::steady_clock::now();
+    rc = dsss_frame_geo_bbox(c, id);
+    if (tv && id < 3) fprintf(stderr, "[dsss frame_set %d] geometry %.1f us, raw %.1f us, bbox launch %.1f us\n", id,
+                              std::chrono::duration<double, std::micro>(tt1 - tt0).count(), std::chrono::duration<double, std::micro>(tt2 - tt1).count(),
+                              std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - tt2).count());
+    return rc;
+}
+
+int dsss_frames_set(dsss_ctx* c, int n, const int* ids, const double* const* raw, const int* N, const int* M,
+                    const double* const* pose6, const double* const* alt, const double* const* grange)
+{
+    if (!c || n < 0 || (n > 0 && (!ids || !N || !M || !pose6 || !alt || !grange))) return DSSS_E_ARG;
+    const auto t0 = std::chrono::steady_clock::now();
+    for (int i = 0; i < n; ++i) {
+        const int rc = dsss_frame_set(c, ids[i], raw ? raw[i] : nullptr, N[i], M[i], pose6[i], alt[i], grange[i]);
+        if (rc) return rc;
+    }
+    if (getenv("DSSS_EX_VERBOSE")) fprintf(stderr, "[dsss frames_set] %d frames in %.1f us\n", n, std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count());
+    return DSSS_OK;
 }
 
 int dsss_features_set(dsss_ctx* c, int id, int N, int M, const dsss_kp* kps, const uint8_t* desc, const double* geo,

@@ -166,12 +166,20 @@ __device__ inline int fast_arc(const uint8_t* w, int stride, int x, int y, int t
     // every arc of 9 holds one pixel of each opposite pair: both inside [-tmin, tmin] => A <= tmin
 #pragma unroll
     for (int k = 0; k < 8; ++k) if (abs(d[k]) <= tmin && abs(d[k + 8]) <= tmin) return 0;
+    // min / max over every window of 9 contiguous ring pixels by doubling: windows of 2, 4, 8, then one more pixel
+    int lo[16], hi[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) { const int e = d[(k + 1) & 15]; lo[k] = d[k] < e ? d[k] : e; hi[k] = d[k] > e ? d[k] : e; }
+    int lo4[16], hi4[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) { const int a = lo[(k + 2) & 15], b = hi[(k + 2) & 15]; lo4[k] = lo[k] < a ? lo[k] : a; hi4[k] = hi[k] > b ? hi[k] : b; }
     int best = 0;
 #pragma unroll
     for (int k = 0; k < 16; ++k) {
-        int mn = d[k], mx = d[k];
-#pragma unroll
-        for (int j = 1; j < 9; ++j) { const int e = d[(k + j) & 15]; mn = e < mn ? e : mn; mx = e > mx ? e : mx; }
+        int mn = lo4[k] < lo4[(k + 4) & 15] ? lo4[k] : lo4[(k + 4) & 15];
+        int mx = hi4[k] > hi4[(k + 4) & 15] ? hi4[k] : hi4[(k + 4) & 15];
+        const int e = d[(k + 8) & 15];
+        mn = e < mn ? e : mn; mx = e > mx ? e : mx;
         best = mn > best ? mn : best;
         best = -mx > best ? -mx : best;
     }

@@ -20,7 +20,10 @@ struct dsss_frame {
     double* pose6 = nullptr;          // device N x 6
     double* alt = nullptr;            // device N
     double* gr = nullptr;             // device M/2
-    std::vector<double> h_pose6, h_alt, h_gr;   // small host copies (pose graph, reprojection checks)
+    double* h_pack = nullptr;         // pinned host copy [pose6 N*6 | alt N | gr M/2] (also the pose-graph DR input)
+    double* d_pack = nullptr;         // device copy, pose6 / alt / gr point into it
+    size_t pack_cap = 0;
+    hipEvent_t pack_ev = nullptr;     // recorded after the upload of h_pack: the staging area is reusable once it fired
     uint8_t* mask = nullptr;          // device N x M
     uint8_t* lvl[DSSS_MAX_LEVELS] = {nullptr};  // image pyramid, lvl[0] = normalised image
     int lrows[DSSS_MAX_LEVELS] = {0}, lcols[DSSS_MAX_LEVELS] = {0};

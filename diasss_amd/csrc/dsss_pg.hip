@@ -1392,7 +1392,7 @@ int dsss_posegraph_solve(dsss_ctx* c, int nframes, double* poses12, double* rpy6
     std::vector<double> dr;
     for (int f = 0; f < nframes; ++f) {
         if (!c->frames[f].has_geom) DSSS_FAIL(c, DSSS_E_STATE, "frame %d has no geometry", f);
-        dr.insert(dr.end(), c->frames[f].h_pose6.begin(), c->frames[f].h_pose6.end());
+        dr.insert(dr.end(), c->frames[f].h_pack, c->frames[f].h_pack + (size_t)c->frames[f].N * 6);
     }
     const int total = (int)(dr.size() / 6);
     std::vector<dsss_lc_edge> edges((size_t)std::max(c->total_kp7, 1));

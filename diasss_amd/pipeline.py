@@ -57,8 +57,11 @@ class Pipeline:
         self.N = [p.shape[0] for p in poses]
         self.M = [2 * len(g) for g in grs]
         self.poses = poses
-        for f in range(self.F):
-            self.ctx.frame_set(f, raws[f], self.N[f], self.M[f], poses[f], alts[f], grs[f])
+        if hasattr(self.ctx, "frames_set"):
+            self.ctx.frames_set(list(range(self.F)), raws, self.N, self.M, poses, alts, grs)
+        else:
+            for f in range(self.F):
+                self.ctx.frame_set(f, raws[f], self.N[f], self.M[f], poses[f], alts[f], grs[f])
 
     def extract(self):
         mine = shard_frames(self.F, self.rank, self.world)
@@ -77,6 +80,8 @@ class Pipeline:
             self.ctx.features_pack(f, send[k])
         recv = torch.empty((self.world * per, nb), dtype=torch.uint8, device=dev)     # concatenated along dim 0
         dist.all_gather_into_tensor(recv, send)
+        if dev == "cuda":
+            torch.cuda.synchronize()      # the library reads `recv` on its own HIP stream: order it after the RCCL collective
         for r in range(self.world):
             if r == self.rank:
                 continue
@@ -121,6 +126,8 @@ class Pipeline:
         send = torch.from_numpy(buf).to(dev)
         recv = torch.empty(self.world * mx * isz, dtype=torch.uint8, device=dev)
         dist.all_gather_into_tensor(recv, send)
+        if dev == "cuda":
+            torch.cuda.synchronize()
         recv = recv.cpu().numpy().reshape(self.world, mx * isz)
         return merge_edges([recv[r, :cnts[r] * isz].copy().view(capi.LCEDGE_DTYPE) for r in range(self.world)])
 

@@ -76,6 +76,9 @@ int  dsss_set_params(dsss_ctx*, const dsss_mask_params*, const dsss_orb_params*,
  * raw may stay resident in HBM (device pointer): nothing is copied back to the host.                     */
 int dsss_frame_set(dsss_ctx*, int id, const double* raw, int N, int M,
                    const double* pose6, const double* alt, const double* grange);
+/* the same for n frames in one call (arrays of per-frame arguments; raw[i] may be NULL) */
+int dsss_frames_set(dsss_ctx*, int n, const int* ids, const double* const* raw, const int* N, const int* M,
+                    const double* const* pose6, const double* const* alt, const double* const* grange);
 /* GetNormalizeSSS + GetFilteredMask + DetectFeature (frame.cpp:57-124,167-203) with the ORB descriptor
  * configuration of thirdparty/ORBextractor.cpp (operator() :1049-1113).  Features stay on the device.       */
 int dsss_extract(dsss_ctx*, int id, int* n_kp_host);
