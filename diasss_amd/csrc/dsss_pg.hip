@@ -37,6 +37,29 @@ __device__ inline int chol6(double* A)
     }
     return 0;
 }
+// same factorisation with one reciprocal square root per pivot instead of a square root and five divisions (the
+// dependent-latency chain of the panel kernels); ri[j] = 1 / L[j][j]
+__device__ inline int chol6_fast(double* A, double* ri)
+{
+    int bad = 0;
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+        double d = A[j * 6 + j];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) if (k < j) d -= A[j * 6 + k] * A[j * 6 + k];
+        if (!(d > 0) || !isfinite(d)) { bad = 1; d = 1.0; }
+        const double r = rsqrt(d);
+        A[j * 6 + j] = d * r; ri[j] = r;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) if (i > j) {
+            double s = A[i * 6 + j];
+#pragma unroll
+            for (int k = 0; k < 6; ++k) if (k < j) s -= A[i * 6 + k] * A[j * 6 + k];
+            A[i * 6 + j] = s * r;
+        }
+    }
+    return bad;
+}
 // b (6 x nrhs, row-major) <- (L L^T)^-1 b
 __device__ inline void chol6_solve(const double* L, double* b, int nrhs)
 {
@@ -388,6 +411,34 @@ __global__ __launch_bounds__(256) void pg_factor_acc_kernel(const int* __restric
     if (nsl == 1) { for (int s = 0; s < 6; ++s) Lvals[(size_t)(c0 + q) * 36 + r * 6 + s] -= acc[s]; }
     else { double* o = part + ((size_t)blockIdx.x * nsl + sl) * col_stride + (size_t)idx * 6; for (int s = 0; s < 6; ++s) o[s] = acc[s]; }
 }
+// fold the per-slice partial sums of pg_factor_acc_kernel into the column blocks and the right-hand side, slice order
+// fixed (deterministic); keeps the serial critical paths of the panel kernels free of the nsl-fold reads
+__global__ __launch_bounds__(256) void pg_fold_kernel(const int* __restrict__ lvcols, const int* __restrict__ colptr, double* __restrict__ Lvals,
+                                                      const double* __restrict__ part, int nsl, int col_stride, double* __restrict__ x)
+{
+    const int j = lvcols[blockIdx.x];
+    const int c0 = colptr[j], m = colptr[j + 1] - c0;
+    const int idx = blockIdx.y * 256 + threadIdx.x;
+    if (idx < 6 * m) {
+        double* row = Lvals + (size_t)c0 * 36 + (size_t)idx * 6;
+        double v[6];
+#pragma unroll
+        for (int s = 0; s < 6; ++s) v[s] = row[s];
+        for (int sl = 0; sl < nsl; ++sl) {
+            const double* o = part + ((size_t)blockIdx.x * nsl + sl) * col_stride + (size_t)idx * 6;
+#pragma unroll
+            for (int s = 0; s < 6; ++s) v[s] -= o[s];
+        }
+#pragma unroll
+        for (int s = 0; s < 6; ++s) row[s] = v[s];
+    }
+    if (blockIdx.y == 0 && threadIdx.x < 6) {
+        double v = x[(size_t)j * 6 + threadIdx.x];
+        for (int sl = 0; sl < nsl; ++sl) v -= part[((size_t)blockIdx.x * nsl + sl) * col_stride + (size_t)col_stride - 8 + threadIdx.x];
+        x[(size_t)j * 6 + threadIdx.x] = v;
+    }
+}
+
 // ---- supernodal panels for the top of the tree.  A panel is up to PG_PW consecutive columns j0 .. j0+w-1 with nested
 // structure (struct(j+1) = struct(j) minus j), i.e. a dense trapezoid: a 6w x 6w diagonal block A11 on top of the rows
 // A21 shared by all its columns.  After the external updates (pg_factor_acc_kernel over all columns of the level at once)
@@ -434,10 +485,14 @@ __global__ __launch_bounds__(256) void pg_panel_diag_kernel(const int* __restric
     __syncthreads();
     for (int k = 0; k < w; ++k) {
         if (bi == k && bj == k) {
-            if (chol6(a)) { s_bad = 1; for (int e = 0; e < 36; ++e) a[e] = (e % 7 == 0) ? 1.0 : 0.0; }
-            for (int r = 0; r < 6; ++r) for (int c2 = r + 1; c2 < 6; ++c2) a[r * 6 + c2] = 0.0;
             double ri[6];
-            for (int e = 0; e < 6; ++e) { ri[e] = 1.0 / a[e * 7]; sRinv[e] = ri[e]; }
+            if (chol6_fast(a, ri)) s_bad = 1;
+#pragma unroll
+            for (int r = 0; r < 6; ++r)
+#pragma unroll
+                for (int c2 = 0; c2 < 6; ++c2) if (c2 > r) a[r * 6 + c2] = 0.0;
+#pragma unroll
+            for (int e = 0; e < 6; ++e) sRinv[e] = ri[e];
             for (int e = 0; e < 36; ++e) sLkk[e] = a[e];
             for (int r = 0; r < 6; ++r) { double v = y[r]; for (int c2 = 0; c2 < r; ++c2) v -= a[r * 6 + c2] * y[c2]; y[r] = v * ri[r]; }
             for (int e = 0; e < 6; ++e) sy[e] = y[e];
@@ -1245,12 +1300,13 @@ static int pg_solve_impl(dsss_ctx* c, const double* dr6, int total, const dsss_l
                     if (lv_upd[l]) { dsss_scope s2(c, DSSS_K_PG_ACC, fl_acc[l]);
                                      hipLaunchKernelGGL(pg_factor_acc_kernel, dim3(ncl, lv_chunks[l], lv_slices[l]), dim3(256), 0, st, d_lvcols + S.lvptr[l], d_colptr, d_rlptr, d_rlpos,
                                                         d_mapptr, d_map, d_L, d_part2, stride, d_rlcol, d_x, d_tlim); }
+                    if (nsl > 1) hipLaunchKernelGGL(pg_fold_kernel, dim3(ncl, lv_chunks[l]), dim3(256), 0, st, d_lvcols + S.lvptr[l], d_colptr, d_L, d_part2, nsl, stride, d_x);
                     { dsss_scope s3(c, DSSS_K_PG_DIAG, fl_diag[l]);
-                      hipLaunchKernelGGL(pg_panel_diag_kernel, dim3(npl), dim3(256), 0, st, d_plvpan + S.plvptr[l], d_pan_first, d_pan_w, d_pan_lcol0, d_colptr, d_L, d_part2, nsl, stride, d_x, d_fail); }
+                      hipLaunchKernelGGL(pg_panel_diag_kernel, dim3(npl), dim3(256), 0, st, d_plvpan + S.plvptr[l], d_pan_first, d_pan_w, d_pan_lcol0, d_colptr, d_L, d_part2, 1, stride, d_x, d_fail); }
                     dsss_scope s4(c, DSSS_K_PG_TRSM, plv_rowchunks[l] > 0 ? fl_trsm[l] : 0.0);
                     if (plv_rowchunks[l] > 0)
                         hipLaunchKernelGGL(pg_panel_trsm_kernel, dim3(npl, plv_rowchunks[l]), dim3(256), ((size_t)plv_n[l] * plv_n[l] + plv_n[l]) * sizeof(double), st, d_plvpan + S.plvptr[l], d_pan_first, d_pan_w,
-                                           d_pan_lcol0, d_colptr, d_L, d_part2, nsl, stride);
+                                           d_pan_lcol0, d_colptr, d_L, d_part2, 1, stride);
                 }
                 for (int l = nlev - 1; l >= 0; --l) {
                     dsss_scope s5(c, DSSS_K_PG_BWD, fl_bwd[l]);
