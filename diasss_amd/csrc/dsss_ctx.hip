@@ -53,6 +53,8 @@ int dsss_create(int device, int max_frames, dsss_ctx** out)
     c->kcap = kcap_for(c->op);
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return DSSS_E_HIP; }
     hipEventCreate(&c->prof.e0); hipEventCreate(&c->prof.e1);
+    for (int i = 0; i < 4; ++i) { hipStreamCreateWithFlags(&c->xs[i], hipStreamNonBlocking); hipEventCreateWithFlags(&c->xev[i], hipEventDisableTiming); }
+    hipEventCreateWithFlags(&c->xev_main, hipEventDisableTiming);
     *out = c;
     return DSSS_OK;
 }
@@ -99,6 +101,8 @@ void dsss_destroy(dsss_ctx* c)
     if (c->bbox_pinned) hipHostFree(c->bbox_pinned);
     dsss_pg_free(c);
     hipEventDestroy(c->prof.e0); hipEventDestroy(c->prof.e1);
+    for (int i = 0; i < 4; ++i) { if (c->xs[i]) hipStreamDestroy(c->xs[i]); if (c->xev[i]) hipEventDestroy(c->xev[i]); }
+    if (c->xev_main) hipEventDestroy(c->xev_main);
     hipStreamDestroy(c->stream);
     delete c;
 }

@@ -634,12 +634,15 @@ static int extract_frames(dsss_ctx* c, const int* ids, int n, bool keep_taps)
     qt_inst* h_inst = (qt_inst*)c->ex_pinned;
     qt_frame* h_fr = (qt_frame*)((char*)h_inst + align_up(sizeof(qt_inst) * (size_t)B * DSSS_MAX_LEVELS, 256));
     int* h_res = (int*)((char*)c->ex_pinned + tab_bytes);      // [B] nkp, [B] err
-    hipStream_t st = c->stream;
+    const hipStream_t main_st = c->stream;
+    const bool multi = !c->prof.on && n > 1;          // profiling times kernels on the main stream only
 
     for (int b0 = 0; b0 < n; b0 += B) {
         const int nb = std::min(B, n - b0);
         int ninst = 0;
+        if (multi) { HIPCHK(c, hipEventRecord(c->xev_main, main_st)); for (int q = 0; q < 4; ++q) HIPCHK(c, hipStreamWaitEvent(c->xs[q], c->xev_main, 0)); }
         for (int s = 0; s < nb; ++s) {
+            const hipStream_t st = multi ? c->xs[s & 3] : main_st;
             const int id = ids[b0 + s];
             dsss_frame& f = c->frames[id];
             const level_geom& g = *G[b0 + s];
@@ -690,13 +693,16 @@ static int extract_frames(dsss_ctx* c, const int* ids, int n, bool keep_taps)
             qf.xs = d_xs; qf.ys = d_ys; qf.rs = d_rs;
             qf.kin = (kp_in*)(S + L.kin); qf.nk = (int*)(S + L.nk); qf.err = d_err;
         }
-        // K4 on the device for the whole batch
-        HIPCHK(c, hipMemcpyAsync(d_inst, h_inst, sizeof(qt_inst) * ninst, hipMemcpyHostToDevice, st));
-        HIPCHK(c, hipMemcpyAsync(d_fr, h_fr, sizeof(qt_frame) * nb, hipMemcpyHostToDevice, st));
+        // K4 on the device for the whole batch (main stream, after every frame's FAST stage)
+        if (multi) for (int q = 0; q < 4; ++q) { HIPCHK(c, hipEventRecord(c->xev[q], c->xs[q])); HIPCHK(c, hipStreamWaitEvent(main_st, c->xev[q], 0)); }
+        HIPCHK(c, hipMemcpyAsync(d_inst, h_inst, sizeof(qt_inst) * ninst, hipMemcpyHostToDevice, main_st));
+        HIPCHK(c, hipMemcpyAsync(d_fr, h_fr, sizeof(qt_frame) * nb, hipMemcpyHostToDevice, main_st));
         { dsss_scope sc(c, DSSS_K_QUADTREE);
-          dsss_launch_quadtree(st, d_inst, ninst, d_fr, nb); }
+          dsss_launch_quadtree(main_st, d_inst, ninst, d_fr, nb); }
         HIPCHK(c, hipGetLastError());
+        if (multi) { HIPCHK(c, hipEventRecord(c->xev_main, main_st)); for (int q = 0; q < 4; ++q) HIPCHK(c, hipStreamWaitEvent(c->xs[q], c->xev_main, 0)); }
         for (int s = 0; s < nb; ++s) {
+            const hipStream_t st = multi ? c->xs[s & 3] : main_st;
             const int id = ids[b0 + s];
             dsss_frame& f = c->frames[id];
             const level_geom& g = *G[b0 + s];
@@ -715,7 +721,8 @@ static int extract_frames(dsss_ctx* c, const int* ids, int n, bool keep_taps)
             HIPCHK(c, hipMemcpyAsync(&h_res[B + s], (int*)(S + L.err), sizeof(int), hipMemcpyDeviceToHost, st));
         }
         HIPCHK(c, hipGetLastError());
-        HIPCHK(c, hipStreamSynchronize(st));         // one synchronisation per batch of up to EX_BATCH frames
+        if (multi) for (int q = 0; q < 4; ++q) { HIPCHK(c, hipEventRecord(c->xev[q], c->xs[q])); HIPCHK(c, hipStreamWaitEvent(main_st, c->xev[q], 0)); }
+        HIPCHK(c, hipStreamSynchronize(main_st));    // one synchronisation per batch of up to EX_BATCH frames
         for (int s = 0; s < nb; ++s) {
             dsss_frame& f = c->frames[ids[b0 + s]];
             if (h_res[B + s]) DSSS_FAIL(c, DSSS_E_CAPACITY, "frame %d: device quadtree capacity exceeded (code %d)", ids[b0 + s], h_res[B + s]);

@@ -46,6 +46,8 @@ struct dsss_prof {
 struct dsss_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
+    hipStream_t xs[4] = {nullptr, nullptr, nullptr, nullptr};   // extra streams: frames of one extraction batch overlap on them
+    hipEvent_t xev[4] = {nullptr, nullptr, nullptr, nullptr}; hipEvent_t xev_main = nullptr;
     std::string err;
     dsss_mask_params mp;
     dsss_orb_params op;
