@@ -917,6 +917,18 @@ __global__ __launch_bounds__(256) void pg_init_kernel(int n, const double* __res
     } else X[i] = cur;
 }
 
+// trajectory rows "r p y x y z" of SaveTrajactoryAll (optimizer.cpp:1199-1203), computed where the poses live
+__global__ __launch_bounds__(256) void pg_rpy_kernel(int n, const pose_t* __restrict__ X, double* __restrict__ rpy6)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const pose_t T = X[i];
+    double rpy[3];
+    pose_rpy(&T, rpy);
+    double* o = rpy6 + (size_t)i * 6;
+    o[0] = rpy[0]; o[1] = rpy[1]; o[2] = rpy[2]; o[3] = T.t[0]; o[4] = T.t[1]; o[5] = T.t[2];
+}
+
 // ------------------------------------------------------------------ host: ordering + symbolic analysis
 namespace {
 
@@ -1104,7 +1116,7 @@ struct pg_dev {
 void dsss_pg_free(dsss_ctx* c) { (void)c; }
 
 // batch LM over `total` poses (dr6: host, total x 6) with `ne` LC edges (host)
-static int pg_solve_impl(dsss_ctx* c, const double* dr6, int total, const dsss_lc_edge* edges, int ne, double* poses12, double* stats4)
+static int pg_solve_impl(dsss_ctx* c, const double* dr6, int total, const dsss_lc_edge* edges, int ne, double* poses12, double* stats4, double* rpy6 = nullptr)
 {
     const int n = total;
     if (n < 2) DSSS_FAIL(c, DSSS_E_ARG, "pose graph needs at least 2 poses");
@@ -1346,11 +1358,17 @@ static int pg_solve_impl(dsss_ctx* c, const double* dr6, int total, const dsss_l
             else break;
         }
     } while (iters < c->pg.max_iters && !((err <= 0) || ((cur - err) / cur <= c->pg.rel_tol) || ((cur - err) <= c->pg.abs_tol)) && std::isfinite(cur));
-    if (poses12) {
-        std::vector<pose_t> out(n);
-        HCK(hipMemcpy(out.data(), d_X, (size_t)n * sizeof(pose_t), hipMemcpyDeviceToHost));
-        for (int i = 0; i < n; ++i) { for (int k = 0; k < 9; ++k) poses12[(size_t)i * 12 + k] = out[i].R[k]; for (int k = 0; k < 3; ++k) poses12[(size_t)i * 12 + 9 + k] = out[i].t[k]; }
+    if (poses12) {      // pose_t is 12 contiguous doubles (R row-major, t): straight into the caller's buffer
+        static_assert(sizeof(pose_t) == 12 * sizeof(double), "pose_t layout");
+        HCK(hipMemcpyAsync(poses12, d_X, (size_t)n * sizeof(pose_t), hipMemcpyDeviceToHost, st));
     }
+    if (rpy6) {
+        double* d_rpy;
+        TRY(dv.alloc(c, &d_rpy, (size_t)n * 6));
+        hipLaunchKernelGGL(pg_rpy_kernel, dim3((n + 255) / 256), dim3(256), 0, st, n, d_X, d_rpy);
+        HCK(hipMemcpyAsync(rpy6, d_rpy, (size_t)n * 6 * sizeof(double), hipMemcpyDeviceToHost, st));
+    }
+    HCK(hipStreamSynchronize(st));
     if (stats4) { stats4[0] = iters; stats4[1] = err0; stats4[2] = err; stats4[3] = lambda; }
     dv.release();
     if (verbose) fprintf(stderr, "[dsss pg] LM iterations %d  factorisations %d  err %.6g -> %.6g | host prep %.1f ms, symbolic %.1f ms, alloc+upload %.1f ms, LM loop %.1f ms\n",
@@ -1455,20 +1473,8 @@ int dsss_posegraph_solve(dsss_ctx* c, int nframes, double* poses12, double* rpy6
     int ne = 0;
     int rc = dsss_posegraph_select(c, nframes, edges.data(), (int)edges.size(), &ne);
     if (rc) return rc;
-    std::vector<double> p12((size_t)total * 12);
-    rc = pg_solve_impl(c, dr.data(), total, edges.data(), ne, p12.data(), stats4);
+    rc = pg_solve_impl(c, dr.data(), total, edges.data(), ne, poses12, stats4, rpy6);
     if (rc) return rc;
-    if (poses12) memcpy(poses12, p12.data(), p12.size() * sizeof(double));
-    if (rpy6)                                                   // SaveTrajactoryAll line format (optimizer.cpp:1199-1203)
-        for (int i = 0; i < total; ++i) {
-            pose_t T;
-            for (int k = 0; k < 9; ++k) T.R[k] = p12[(size_t)i * 12 + k];
-            for (int k = 0; k < 3; ++k) T.t[k] = p12[(size_t)i * 12 + 9 + k];
-            double rpy[3];
-            pose_rpy(&T, rpy);
-            rpy6[(size_t)i * 6 + 0] = rpy[0]; rpy6[(size_t)i * 6 + 1] = rpy[1]; rpy6[(size_t)i * 6 + 2] = rpy[2];
-            rpy6[(size_t)i * 6 + 3] = T.t[0]; rpy6[(size_t)i * 6 + 4] = T.t[1]; rpy6[(size_t)i * 6 + 5] = T.t[2];
-        }
     return DSSS_OK;
 }
 
