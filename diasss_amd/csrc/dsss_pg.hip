@@ -948,10 +948,11 @@ void nd_order(std::vector<int>& nodes, const std::vector<std::vector<int>>& adj,
     double x0 = 1e300, x1 = -1e300, y0 = 1e300, y1 = -1e300;
     for (int v : nodes) { x0 = std::min(x0, cx[v]); x1 = std::max(x1, cx[v]); y0 = std::min(y0, cy[v]); y1 = std::max(y1, cy[v]); }
     const bool byx = (x1 - x0) >= (y1 - y0);
-    std::sort(nodes.begin(), nodes.end(), [&](int a, int b) {
+    const size_t half = nodes.size() / 2;
+    // split at the median of the (coordinate, index) total order; only the two halves matter, not their inner order
+    std::nth_element(nodes.begin(), nodes.begin() + half, nodes.end(), [&](int a, int b) {
         const double ka = byx ? cx[a] : cy[a], kb = byx ? cx[b] : cy[b];
         return ka != kb ? ka < kb : a < b; });
-    const size_t half = nodes.size() / 2;
     for (size_t i = 0; i < nodes.size(); ++i) side[nodes[i]] = i < half ? 1 : 2;
     std::vector<int> A, B, S;
     for (size_t i = 0; i < half; ++i) {
@@ -962,6 +963,7 @@ void nd_order(std::vector<int>& nodes, const std::vector<std::vector<int>>& adj,
     }
     for (size_t i = half; i < nodes.size(); ++i) B.push_back(nodes[i]);
     for (int v : nodes) side[v] = 0;
+    std::sort(S.begin(), S.end());
     if (A.empty() || B.empty()) {          // degenerate cut: fall back to index order
         std::sort(nodes.begin(), nodes.end());
         for (int v : nodes) order.push_back(v);
@@ -969,7 +971,6 @@ void nd_order(std::vector<int>& nodes, const std::vector<std::vector<int>>& adj,
     }
     nd_order(A, adj, cx, cy, side, order, leaf);
     nd_order(B, adj, cx, cy, side, order, leaf);
-    std::sort(S.begin(), S.end());
     for (int v : S) order.push_back(v);
 }
 
@@ -978,6 +979,10 @@ void symbolic(int ns, const std::vector<std::pair<int, int>>& edges, int nchain,
               const std::vector<double>& cy, bool use_nd, sym_t& S)
 {
     S.ns = ns;
+    const bool tv = getenv("DSSS_PG_VERBOSE") != nullptr;
+    auto tnow = [] { return std::chrono::steady_clock::now(); };
+    auto tms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+    const auto q0 = tnow();
     std::vector<std::vector<int>> adj(ns);
     for (auto& e : edges) if (e.first != e.second) { adj[e.first].push_back(e.second); adj[e.second].push_back(e.first); }
     for (auto& a : adj) { std::sort(a.begin(), a.end()); a.erase(std::unique(a.begin(), a.end()), a.end()); }
@@ -987,6 +992,7 @@ void symbolic(int ns, const std::vector<std::pair<int, int>>& edges, int nchain,
         std::vector<char> side(ns, 0);
         nd_order(nodes, adj, cx, cy, side, order, 24);
     } else { order.resize(ns); std::iota(order.begin(), order.end(), 0); }
+    const auto q1 = tnow();
     S.perm.assign(ns, 0);
     for (int i = 0; i < ns; ++i) S.perm[order[i]] = i;
     // column structures by merging children (elimination tree built on the fly)
@@ -1001,6 +1007,7 @@ void symbolic(int ns, const std::vector<std::pair<int, int>>& edges, int nchain,
         c.insert(c.begin(), j);
         if (c.size() > 1) { parent[j] = c[1]; kids[c[1]].push_back(j); }
     }
+    const auto q2 = tnow();
     S.colptr.assign(ns + 1, 0);
     for (int j = 0; j < ns; ++j) S.colptr[j + 1] = S.colptr[j] + (int)cols[j].size();
     S.rowidx.resize(S.colptr[ns]);
@@ -1018,6 +1025,7 @@ void symbolic(int ns, const std::vector<std::pair<int, int>>& edges, int nchain,
         for (int t = S.rlptr[j]; t < S.rlptr[j + 1]; ++t) S.rlrow[t] = j;
         S.mapptr[j + 1] = S.mapptr[j] + (long long)(S.rlptr[j + 1] - S.rlptr[j]) * (long long)cols[j].size();
     }
+    const auto q3 = tnow();
     // bottom subtrees -> bins (one workgroup each); the remaining "top" columns are level-scheduled
     std::vector<double> sub_cost(ns, 0);
     std::vector<char> sub_ok(ns, 0);
@@ -1087,6 +1095,7 @@ void symbolic(int ns, const std::vector<std::pair<int, int>>& edges, int nchain,
         const int lim = col_pan[j] >= 0 ? S.pan_first[col_pan[j]] : j;
         S.tlim[j] = (int)(std::lower_bound(S.rlcol.begin() + S.rlptr[j], S.rlcol.begin() + S.rlptr[j + 1], lim) - (S.rlcol.begin() + S.rlptr[j]));
     }
+    const auto q4 = tnow();
     // where the assembled blocks go
     auto find = [&](int row, int col) { const auto b = S.rowidx.begin() + S.colptr[col], e = S.rowidx.begin() + S.colptr[col + 1];
                                         return (int)(std::lower_bound(b, e, row) - S.rowidx.begin()); };
@@ -1097,6 +1106,7 @@ void symbolic(int ns, const std::vector<std::pair<int, int>>& edges, int nchain,
         const int pa = S.perm[k], pb = S.perm[k + 1];          // block S(k, k+1): rows k, cols k+1
         S.ch_pos[k] = pa > pb ? (find(pa, pb) << 1) : ((find(pb, pa) << 1) | 1);
     }
+    if (tv) fprintf(stderr, "[dsss pg symbolic] adjacency+ND %.1f ms, column structures %.1f ms, rowlists+map ptrs %.1f ms, bins+panels %.1f ms\n", tms(q0, q1), tms(q1, q2), tms(q2, q3), tms(q3, q4));
     S.lc_pos.resize(edges.size() - nchain);
     for (size_t e = nchain; e < edges.size(); ++e) {
         const int pa = S.perm[edges[e].first], pb = S.perm[edges[e].second];   // block H(a, b)
