@@ -533,21 +533,25 @@ __global__ __launch_bounds__(256) void pg_panel_diag_kernel(const int* __restric
     }
 }
 
-// L21 = A21 L11^-T : one thread per scalar row below the panel's diagonal block; block column by block column, the
-// already finished part of the row is re-read from global memory (written by the same thread)
-__global__ __launch_bounds__(256, 1) void pg_panel_trsm_kernel(const int* __restrict__ plvpan, const int* __restrict__ pan_first, const int* __restrict__ pan_w,
+// L21 = A21 L11^-T : 16 threads per scalar row, thread (row, c) owns the six values of block column c; per block step
+// the owner of column cp finishes its values against L_cp,cp and publishes them through LDS, the columns to its right
+// subtract x_cp L(c, cp)^T.  A workgroup stages L11 once and runs four groups of 16 rows through it.
+#define TRSM_ROWS 16
+__global__ __launch_bounds__(256) void pg_panel_trsm_kernel(const int* __restrict__ plvpan, const int* __restrict__ pan_first, const int* __restrict__ pan_w,
                                                             const int* __restrict__ pan_lcol0, const int* __restrict__ colptr,
                                                             double* __restrict__ Lvals, const double* __restrict__ part, int nsl, int col_stride)
 {
     extern __shared__ double sL[];                 // L11, n x n row-major, then 1/diag [n]
+    __shared__ double sxr[16][6];
     const int p = plvpan[blockIdx.x];
     const int j0 = pan_first[p], w = pan_w[p], n = 6 * w, lc0 = pan_lcol0[p];
     const int m = colptr[j0 + 1] - colptr[j0];     // block rows of the first column
     const int nrows = 6 * (m - w);
-    if ((int)blockIdx.y * 256 >= nrows) return;
+    if ((int)blockIdx.y * TRSM_ROWS >= nrows) return;
     double* sR = sL + n * n;
+    const int rr = threadIdx.x >> 4, c = threadIdx.x & 15;
     {   // stage L11: thread (qb, cb) copies the 6 x 6 block (qb, cb), cb <= qb (the upper blocks are never read)
-        const int qb = threadIdx.x >> 4, cb = threadIdx.x & 15;
+        const int qb = rr, cb = c;
         if (qb < w && cb <= qb) {
             const double* src = Lvals + pan_pos(colptr, j0, qb, cb) * 36;
 #pragma unroll
@@ -559,43 +563,50 @@ __global__ __launch_bounds__(256, 1) void pg_panel_trsm_kernel(const int* __rest
         }
     }
     __syncthreads();
-    const int row = blockIdx.y * 256 + threadIdx.x;
-    if (row >= nrows) return;
-    const int qi = w + row / 6, r = row % 6;       // block row index within the first column's structure
-    double xs[PG_PW * 6];                          // solved part of the row stays in registers (loops fully unrolled)
+    for (int g = 0; g < TRSM_ROWS / 16; ++g) {
+        const int row = blockIdx.y * TRSM_ROWS + g * 16 + rr;
+        const bool act = row < nrows && c < w;
+        const int qi = w + row / 6, r = row % 6;
+        double xv[6] = { 0, 0, 0, 0, 0, 0 };
+        double* dst = nullptr;
+        if (act) {
+            dst = Lvals + pan_pos(colptr, j0, qi, c) * 36 + r * 6;
 #pragma unroll
-    for (int c = 0; c < PG_PW; ++c) {
-        if (c < w) {
-            double* dst = Lvals + pan_pos(colptr, j0, qi, c) * 36 + r * 6;
-            double a[6];
-#pragma unroll
-            for (int s = 0; s < 6; ++s) a[s] = dst[s];
+            for (int s = 0; s < 6; ++s) xv[s] = dst[s];
             if (nsl > 1)
                 for (int sl = 0; sl < nsl; ++sl) {
                     const double* o = part + ((size_t)(lc0 + c) * nsl + sl) * col_stride + (size_t)((qi - c) * 6 + r) * 6;
 #pragma unroll
-                    for (int s = 0; s < 6; ++s) a[s] -= o[s];
+                    for (int s = 0; s < 6; ++s) xv[s] -= o[s];
+                }
+        }
+        for (int cp = 0; cp < w; ++cp) {
+            if (act && c == cp) {                  // finish block column cp of this row
+                const double* Ld = sL + (cp * 6) * n + cp * 6;
+#pragma unroll
+                for (int s = 0; s < 6; ++s) {
+                    double v = xv[s];
+#pragma unroll
+                    for (int t = 0; t < 6; ++t) if (t < s) v -= xv[t] * Ld[s * n + t];
+                    xv[s] = v * sR[cp * 6 + s];
                 }
 #pragma unroll
-            for (int cp = 0; cp < PG_PW; ++cp) {
-                if (cp < c) {
+                for (int s = 0; s < 6; ++s) sxr[rr][s] = xv[s];
+            }
+            __syncthreads();
+            if (act && c > cp) {
+                const double x0 = sxr[rr][0], x1 = sxr[rr][1], x2 = sxr[rr][2], x3 = sxr[rr][3], x4 = sxr[rr][4], x5 = sxr[rr][5];
 #pragma unroll
-                    for (int s = 0; s < 6; ++s) {
-                        const double* Lr = sL + (c * 6 + s) * n + cp * 6;
-                        a[s] -= xs[cp * 6] * Lr[0] + xs[cp * 6 + 1] * Lr[1] + xs[cp * 6 + 2] * Lr[2] + xs[cp * 6 + 3] * Lr[3] + xs[cp * 6 + 4] * Lr[4] + xs[cp * 6 + 5] * Lr[5];
-                    }
+                for (int s = 0; s < 6; ++s) {
+                    const double* Lr = sL + (c * 6 + s) * n + cp * 6;
+                    xv[s] -= x0 * Lr[0] + x1 * Lr[1] + x2 * Lr[2] + x3 * Lr[3] + x4 * Lr[4] + x5 * Lr[5];
                 }
             }
+            __syncthreads();
+        }
+        if (act) {
 #pragma unroll
-            for (int s = 0; s < 6; ++s) {
-                double v = a[s];
-                const double* Lr = sL + (c * 6 + s) * n + c * 6;
-#pragma unroll
-                for (int t = 0; t < 6; ++t) if (t < s) v -= xs[c * 6 + t] * Lr[t];
-                xs[c * 6 + s] = v * sR[c * 6 + s];
-            }
-#pragma unroll
-            for (int s = 0; s < 6; ++s) dst[s] = xs[c * 6 + s];
+            for (int s = 0; s < 6; ++s) dst[s] = xv[s];
         }
     }
 }
@@ -605,31 +616,31 @@ __global__ __launch_bounds__(256) void pg_panel_bwd_kernel(const int* __restrict
                                                            const int* __restrict__ colptr, const int* __restrict__ rowidx,
                                                            const double* __restrict__ Lvals, double* __restrict__ x)
 {
-    __shared__ double s_part[256];
     __shared__ double sz[PG_PW * 6];
     __shared__ double sxk[6];
     __shared__ double scontrib[PG_PW][6];
     const int p = plvpan[blockIdx.x];
     const int j0 = pan_first[p], w = pan_w[p], n = 6 * w;
     const int c0 = colptr[j0], m = colptr[j0 + 1] - c0;
-    // z[gj] = y[gj] - sum over rows below of L(row, gj) x_row ; threads split the rows in 256/n groups, fixed fold order
-    const int groups = 256 / n > 0 ? 256 / n : 1;
+    // z[gj] = y[gj] - sum over rows below of L(row, gj) x_row : thread (slot, c) walks block rows slot, slot+16, ... of block
+    // column c; the 16 slot sums of every scalar column are then folded in slot order (deterministic)
+    __shared__ double s_acc[16][PG_PW * 6];
     {
-        const int gj = threadIdx.x % n, g = threadIdx.x / n;
-        double acc = 0;
-        if (g < groups) {
-            const int c = gj / 6, s6 = gj % 6;
-            for (int qi = w + g; qi < m; qi += groups) {
-                const double* B = Lvals + pan_pos(colptr, j0, qi, c) * 36; const double* xi = x + (size_t)rowidx[c0 + qi] * 6;
-                acc += B[s6] * xi[0] + B[6 + s6] * xi[1] + B[12 + s6] * xi[2] + B[18 + s6] * xi[3] + B[24 + s6] * xi[4] + B[30 + s6] * xi[5];
+        const int slot = threadIdx.x >> 4, cc = threadIdx.x & 15;
+        double acc[6] = { 0, 0, 0, 0, 0, 0 };
+        if (cc < w)
+            for (int qi = w + slot; qi < m; qi += 16) {
+                const double* B = Lvals + pan_pos(colptr, j0, qi, cc) * 36; const double* xi = x + (size_t)rowidx[c0 + qi] * 6;
+                const double x0 = xi[0], x1 = xi[1], x2 = xi[2], x3 = xi[3], x4 = xi[4], x5 = xi[5];
+#pragma unroll
+                for (int s6 = 0; s6 < 6; ++s6) acc[s6] += B[s6] * x0 + B[6 + s6] * x1 + B[12 + s6] * x2 + B[18 + s6] * x3 + B[24 + s6] * x4 + B[30 + s6] * x5;
             }
-        }
-        s_part[threadIdx.x] = acc;
+        if (cc < w) for (int s6 = 0; s6 < 6; ++s6) s_acc[slot][cc * 6 + s6] = acc[s6];
     }
     __syncthreads();
     for (int gj = threadIdx.x; gj < n; gj += 256) {
         double v = x[(size_t)(j0 + gj / 6) * 6 + gj % 6];
-        for (int g = 0; g < groups; ++g) v -= s_part[g * n + gj];
+        for (int g = 0; g < 16; ++g) v -= s_acc[g][gj];
         sz[gj] = v;
     }
     const int bi = threadIdx.x >> 4, bj = threadIdx.x & 15;
@@ -1235,7 +1246,7 @@ static int pg_solve_impl(dsss_ctx* c, const double* dr6, int total, const dsss_l
         for (int q = S.plvptr[l]; q < S.plvptr[l + 1]; ++q) {
             const int p = S.plvpan[q], j0 = S.pan_first[p], w = S.pan_w[p];
             plv_n[l] = std::max(plv_n[l], 6 * w);
-            plv_rowchunks[l] = std::max(plv_rowchunks[l], (6 * (S.colptr[j0 + 1] - S.colptr[j0] - w) + 255) / 256);
+            plv_rowchunks[l] = std::max(plv_rowchunks[l], (6 * (S.colptr[j0 + 1] - S.colptr[j0] - w) + 15) / 16);
         }
     const long long mapsz = S.mapptr[ns];
     if (mapsz > (1LL << 31)) { dv.release(); DSSS_FAIL(c, DSSS_E_CAPACITY, "update map of %lld entries", mapsz); }
