@@ -446,12 +446,14 @@ __global__ __launch_bounds__(256) void pg_fold_kernel(const int* __restrict__ lv
 //     L21 = A21 L11^-T                   pg_panel_trsm_kernel   one thread per scalar row of A21
 // which replaces w column-levels by one panel-level.
 #define PG_PW 16
+#define PG_NBLK (PG_PW * (PG_PW + 1) / 2)
+#define PG_DIAG_LDS (2 * PG_NBLK * 36 * (int)sizeof(double))
 __device__ inline size_t pan_pos(const int* __restrict__ colptr, int j0, int qi, int c) { return (size_t)colptr[j0 + c] + (size_t)(qi - c); }
 
 __global__ __launch_bounds__(256) void pg_panel_diag_kernel(const int* __restrict__ plvpan, const int* __restrict__ pan_first, const int* __restrict__ pan_w,
                                                             const int* __restrict__ pan_lcol0, const int* __restrict__ colptr,
                                                             double* __restrict__ Lvals, const double* __restrict__ part, int nsl, int col_stride,
-                                                            double* __restrict__ x, int* __restrict__ fail)
+                                                            double* __restrict__ x, int* __restrict__ fail, double* __restrict__ Wsw, double* __restrict__ Wrow)
 {
     // blocked right-looking Cholesky: thread (bi, bj) of a 16 x 16 grid owns the 6 x 6 block A(bi, bj) in registers;
     // per block step k: (k,k) factors, column k solves against L_kk, the trailing blocks subtract L_ik L_jk^T.
@@ -531,94 +533,159 @@ __global__ __launch_bounds__(256) void pg_panel_diag_kernel(const int* __restric
         for (int e = 0; e < 36; ++e) dst[e] = a[e];
         if (bi == bj) for (int e = 0; e < 6; ++e) x[(size_t)(j0 + bi) * 6 + e] = y[e];
     }
-}
-
-// L21 = A21 L11^-T : 16 threads per scalar row, thread (row, c) owns the six values of block column c; per block step
-// the owner of column cp finishes its values against L_cp,cp and publishes them through LDS, the columns to its right
-// subtract x_cp L(c, cp)^T.  A workgroup stages L11 once and runs four groups of 16 rows through it.
-#define TRSM_ROWS 16
-__global__ __launch_bounds__(256) void pg_panel_trsm_kernel(const int* __restrict__ plvpan, const int* __restrict__ pan_first, const int* __restrict__ pan_w,
-                                                            const int* __restrict__ pan_lcol0, const int* __restrict__ colptr,
-                                                            double* __restrict__ Lvals, const double* __restrict__ part, int nsl, int col_stride)
-{
-    extern __shared__ double sL[];                 // L11, n x n row-major, then 1/diag [n]
-    __shared__ double sxr[16][6];
-    const int p = plvpan[blockIdx.x];
-    const int j0 = pan_first[p], w = pan_w[p], n = 6 * w, lc0 = pan_lcol0[p];
-    const int m = colptr[j0 + 1] - colptr[j0];     // block rows of the first column
-    const int nrows = 6 * (m - w);
-    if ((int)blockIdx.y * TRSM_ROWS >= nrows) return;
-    double* sR = sL + n * n;
-    const int rr = threadIdx.x >> 4, c = threadIdx.x & 15;
-    {   // stage L11: thread (qb, cb) copies the 6 x 6 block (qb, cb), cb <= qb (the upper blocks are never read)
-        const int qb = rr, cb = c;
-        if (qb < w && cb <= qb) {
-            const double* src = Lvals + pan_pos(colptr, j0, qb, cb) * 36;
+    // ---- W = L11^-1 by recursive doubling over the 6 x 6 blocks, so that the row solve below the panel and the
+    // back-substitution become products with W (pg_panel_trsm_kernel / pg_panel_bwd_kernel) instead of 16-step chains.
+    // [A 0; B C]^-1 = [A^-1 0; -C^-1 B A^-1  C^-1]; blocks packed lower-triangular, idx(i, j) = i (i + 1) / 2 + j.
+    extern __shared__ double s_dyn[];
+    double* sLb = s_dyn;
+    double* sWb = s_dyn + PG_NBLK * 36;
+    if (act) {
+        double* d = sLb + (bi * (bi + 1) / 2 + bj) * 36;
+        for (int e = 0; e < 36; ++e) d[e] = a[e];
+        if (bi == bj) {
+            double inv[36];
 #pragma unroll
-            for (int e = 0; e < 36; ++e) sL[(qb * 6 + e / 6) * n + cb * 6 + e % 6] = src[e];
-            if (qb == cb) {
+            for (int e = 0; e < 36; ++e) inv[e] = 0.0;
 #pragma unroll
-                for (int e = 0; e < 6; ++e) sR[qb * 6 + e] = 1.0 / src[e * 7];
+            for (int c2 = 0; c2 < 6; ++c2) {
+                inv[c2 * 6 + c2] = 1.0 / a[c2 * 6 + c2];
+#pragma unroll
+                for (int r = 0; r < 6; ++r) if (r > c2) {
+                    double v = 0;
+#pragma unroll
+                    for (int s2 = 0; s2 < 6; ++s2) if (s2 >= c2 && s2 < r) v += a[r * 6 + s2] * inv[s2 * 6 + c2];
+                    inv[r * 6 + c2] = -v / a[r * 6 + r];
+                }
             }
+            double* dw = sWb + (bi * (bi + 1) / 2 + bj) * 36;
+            for (int e = 0; e < 36; ++e) dw[e] = inv[e];
         }
     }
     __syncthreads();
-    for (int g = 0; g < TRSM_ROWS / 16; ++g) {
-        const int row = blockIdx.y * TRSM_ROWS + g * 16 + rr;
-        const bool act = row < nrows && c < w;
-        const int qi = w + row / 6, r = row % 6;
-        double xv[6] = { 0, 0, 0, 0, 0, 0 };
-        double* dst = nullptr;
-        if (act) {
-            dst = Lvals + pan_pos(colptr, j0, qi, c) * 36 + r * 6;
-#pragma unroll
-            for (int s = 0; s < 6; ++s) xv[s] = dst[s];
-            if (nsl > 1)
-                for (int sl = 0; sl < nsl; ++sl) {
-                    const double* o = part + ((size_t)(lc0 + c) * nsl + sl) * col_stride + (size_t)((qi - c) * 6 + r) * 6;
-#pragma unroll
-                    for (int s = 0; s < 6; ++s) xv[s] -= o[s];
-                }
+    for (int h = 1; h < w; h <<= 1) {
+        // task = (off-diagonal block of an odd h-group, pair of rows): 8h blocks x 3 row pairs <= 192 tasks
+        const int ntask = 24 * h;
+        const int t = threadIdx.x;
+        const bool on = t < ntask;
+        int tbi = 0, tbj = 0, r0 = 0, gmid = 0;
+        if (on) {
+            const int b = t / 3; r0 = 2 * (t - 3 * b);
+            const int g = b / (h * h), rem = b - g * h * h;
+            gmid = (2 * g + 1) * h;
+            tbi = gmid + rem / h; tbj = 2 * g * h + rem % h;
         }
-        for (int cp = 0; cp < w; ++cp) {
-            if (act && c == cp) {                  // finish block column cp of this row
-                const double* Ld = sL + (cp * 6) * n + cp * 6;
+        const bool run = on && tbi < w;
+        double res[12];
+        if (run) {                                           // T = B A^-1 (rows r0, r0+1 of block (tbi, tbj))
 #pragma unroll
-                for (int s = 0; s < 6; ++s) {
-                    double v = xv[s];
+            for (int e = 0; e < 12; ++e) res[e] = 0.0;
+            for (int k = tbj; k < gmid; ++k) {
+                const double* Lb = sLb + (tbi * (tbi + 1) / 2 + k) * 36 + r0 * 6;
+                const double* Wk = sWb + (k * (k + 1) / 2 + tbj) * 36;
 #pragma unroll
-                    for (int t = 0; t < 6; ++t) if (t < s) v -= xv[t] * Ld[s * n + t];
-                    xv[s] = v * sR[cp * 6 + s];
-                }
+                for (int s2 = 0; s2 < 6; ++s2) {
+                    const double l0 = Lb[s2], l1 = Lb[6 + s2];
 #pragma unroll
-                for (int s = 0; s < 6; ++s) sxr[rr][s] = xv[s];
-            }
-            __syncthreads();
-            if (act && c > cp) {
-                const double x0 = sxr[rr][0], x1 = sxr[rr][1], x2 = sxr[rr][2], x3 = sxr[rr][3], x4 = sxr[rr][4], x5 = sxr[rr][5];
-#pragma unroll
-                for (int s = 0; s < 6; ++s) {
-                    const double* Lr = sL + (c * 6 + s) * n + cp * 6;
-                    xv[s] -= x0 * Lr[0] + x1 * Lr[1] + x2 * Lr[2] + x3 * Lr[3] + x4 * Lr[4] + x5 * Lr[5];
+                    for (int c2 = 0; c2 < 6; ++c2) { res[c2] += l0 * Wk[s2 * 6 + c2]; res[6 + c2] += l1 * Wk[s2 * 6 + c2]; }
                 }
             }
-            __syncthreads();
-        }
-        if (act) {
+            double* d = sWb + (tbi * (tbi + 1) / 2 + tbj) * 36 + r0 * 6;
 #pragma unroll
-            for (int s = 0; s < 6; ++s) dst[s] = xv[s];
+            for (int e = 0; e < 12; ++e) d[e] = res[e];
+        }
+        __syncthreads();
+        if (run) {                                           // W_B = -C^-1 T
+#pragma unroll
+            for (int e = 0; e < 12; ++e) res[e] = 0.0;
+            for (int k = gmid; k <= tbi; ++k) {
+                const double* Wb = sWb + (tbi * (tbi + 1) / 2 + k) * 36 + r0 * 6;
+                const double* Tk = sWb + (k * (k + 1) / 2 + tbj) * 36;
+#pragma unroll
+                for (int s2 = 0; s2 < 6; ++s2) {
+                    const double l0 = Wb[s2], l1 = Wb[6 + s2];
+#pragma unroll
+                    for (int c2 = 0; c2 < 6; ++c2) { res[c2] -= l0 * Tk[s2 * 6 + c2]; res[6 + c2] -= l1 * Tk[s2 * 6 + c2]; }
+                }
+            }
+        }
+        __syncthreads();
+        if (run) {
+            double* d = sWb + (tbi * (tbi + 1) / 2 + tbj) * 36 + r0 * 6;
+#pragma unroll
+            for (int e = 0; e < 12; ++e) d[e] = res[e];
+        }
+        __syncthreads();
+    }
+    // W out, zero-padded to 96 x 96: row-major for the back-substitution, and in MFMA B-operand order for the row solve
+    // (tile nt = 16 output columns, k-step ks = 4 k's: lane l holds W[16 nt + (l & 15)][4 ks + (l >> 4)])
+    double* wr = Wrow + (size_t)p * (PG_PW * 6) * (PG_PW * 6);
+    double* ws = Wsw + (size_t)p * (PG_PW * 6) * (PG_PW * 6);
+    const int n = 6 * w;
+    for (int e = threadIdx.x; e < (PG_PW * 6) * (PG_PW * 6); e += 256) {
+        {   const int jr = e / (PG_PW * 6), kc = e - jr * (PG_PW * 6);
+            double v = 0.0;
+            if (jr < n && kc <= jr) { const int b1 = jr / 6, b2 = kc / 6; v = sWb[(b1 * (b1 + 1) / 2 + b2) * 36 + (jr - 6 * b1) * 6 + (kc - 6 * b2)]; }
+            wr[e] = v; }
+        {   const int lane = e & 63, ks = (e >> 6) % 24, nt = e / (64 * 24);
+            const int jr = 16 * nt + (lane & 15), kc = 4 * ks + (lane >> 4);
+            double v = 0.0;
+            if (jr < n && kc <= jr) { const int b1 = jr / 6, b2 = kc / 6; v = sWb[(b1 * (b1 + 1) / 2 + b2) * 36 + (jr - 6 * b1) * 6 + (kc - 6 * b2)]; }
+            ws[e] = v; }
+    }
+}
+
+// L21 = A21 W^T with W = L11^-1 from pg_panel_diag_kernel: a plain f64 GEMM on the matrix cores.  One wavefront per
+// 16 scalar rows: the 16 x 96 slab of A21 sits in 24 A-operand registers per lane (lane l: row l & 15, k = 4 ks + (l >> 4)),
+// W^T streams in as pre-swizzled B operands (one coalesced 512-byte load per v_mfma_f64_16x16x4_f64), and output tile nt
+// only runs the k-steps its triangular W reaches (4 nt + 4 of 24).
+typedef double pg_d4 __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void pg_panel_trsm_kernel(const int* __restrict__ plvpan, const int* __restrict__ pan_first, const int* __restrict__ pan_w,
+                                                            const int* __restrict__ colptr, double* __restrict__ Lvals, const double* __restrict__ Wsw)
+{
+    const int p = plvpan[blockIdx.x];
+    const int j0 = pan_first[p], w = pan_w[p], n = 6 * w;
+    const int m = colptr[j0 + 1] - colptr[j0];     // block rows of the first column
+    const int nrows = 6 * (m - w);
+    const int l = threadIdx.x & 63;
+    const int rowbase = ((int)blockIdx.y * 4 + (int)(threadIdx.x >> 6)) * 16;
+    if (rowbase >= nrows) return;                  // wavefront-uniform
+    const double* Wp = Wsw + (size_t)p * (PG_PW * 6) * (PG_PW * 6);
+    const int arow = rowbase + (l & 15);
+    const bool rok = arow < nrows;
+    const int qi = w + arow / 6, r = arow % 6;
+    double a[24];
+#pragma unroll
+    for (int ks = 0; ks < 24; ++ks) {
+        const int k = 4 * ks + (l >> 4), cb = k / 6, s = k - 6 * cb;
+        a[ks] = (rok && k < n) ? Lvals[((size_t)colptr[j0 + min(cb, w - 1)] + (size_t)(qi - cb)) * 36 + r * 6 + s] : 0.0;
+    }
+#pragma unroll
+    for (int nt = 0; nt < 6; ++nt) {
+        if (16 * nt < n) {                         // uniform
+            pg_d4 acc = { 0.0, 0.0, 0.0, 0.0 };
+#pragma unroll
+            for (int ks = 0; ks < 4 * nt + 4; ++ks)
+                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[ks], Wp[(nt * 24 + ks) * 64 + l], acc, 0, 0, 0);
+            const int col = 16 * nt + (l & 15);
+            if (col < n) {
+                const int cb = col / 6, s = col - 6 * cb;
+                const size_t base = (size_t)colptr[j0 + cb];
+#pragma unroll
+                for (int v = 0; v < 4; ++v) {
+                    const int row = rowbase + (l >> 4) + 4 * v;
+                    if (row < nrows) Lvals[(base + (size_t)(w + row / 6 - cb)) * 36 + (row % 6) * 6 + s] = acc[v];
+                }
+            }
         }
     }
 }
 
-// x_panel = L11^-T (y_panel - L21^T x_below): one workgroup per panel, blocked like pg_panel_diag_kernel
+// x_panel = W^T (y_panel - L21^T x_below), W = L11^-1: one workgroup per panel
 __global__ __launch_bounds__(256) void pg_panel_bwd_kernel(const int* __restrict__ plvpan, const int* __restrict__ pan_first, const int* __restrict__ pan_w,
                                                            const int* __restrict__ colptr, const int* __restrict__ rowidx,
-                                                           const double* __restrict__ Lvals, double* __restrict__ x)
+                                                           const double* __restrict__ Lvals, double* __restrict__ x, const double* __restrict__ Wrow)
 {
     __shared__ double sz[PG_PW * 6];
-    __shared__ double sxk[6];
-    __shared__ double scontrib[PG_PW][6];
     const int p = plvpan[blockIdx.x];
     const int j0 = pan_first[p], w = pan_w[p], n = 6 * w;
     const int c0 = colptr[j0], m = colptr[j0 + 1] - c0;
@@ -643,26 +710,17 @@ __global__ __launch_bounds__(256) void pg_panel_bwd_kernel(const int* __restrict
         for (int g = 0; g < 16; ++g) v -= s_acc[g][gj];
         sz[gj] = v;
     }
-    const int bi = threadIdx.x >> 4, bj = threadIdx.x & 15;
-    const bool act = bi < w && bj <= bi;
-    double a[36];
-    if (act) { const double* src = Lvals + pan_pos(colptr, j0, bi, bj) * 36; for (int e = 0; e < 36; ++e) a[e] = src[e]; }
     __syncthreads();
-    for (int k = w - 1; k >= 0; --k) {
-        if (bi == k && bj == k) {                            // x_k = L_kk^-T z_k
-            double v[6];
-            for (int r = 5; r >= 0; --r) { double t = sz[k * 6 + r]; for (int c2 = r + 1; c2 < 6; ++c2) t -= a[c2 * 6 + r] * v[c2]; v[r] = t / a[r * 6 + r]; }
-            for (int e = 0; e < 6; ++e) { sxk[e] = v[e]; sz[k * 6 + e] = v[e]; }
-        }
-        __syncthreads();
-        if (act && bi == k && bj < k) {                      // z_j -= L_kj^T x_k
-            for (int s2 = 0; s2 < 6; ++s2) { double v = 0; for (int r = 0; r < 6; ++r) v += a[r * 6 + s2] * sxk[r]; scontrib[bj][s2] = v; }
-        }
-        __syncthreads();
-        if (threadIdx.x < k * 6) sz[threadIdx.x] -= scontrib[threadIdx.x / 6][threadIdx.x % 6];
-        __syncthreads();
+    // x = L11^-T z = W^T z: x[i] = sum_{k >= i} W[k][i] z[k], ascending k (row-major W: coalesced over i)
+    if ((int)threadIdx.x < n) {
+        const int i = threadIdx.x;
+        const double* wr = Wrow + (size_t)p * (PG_PW * 6) * (PG_PW * 6);
+        double v0 = 0, v1 = 0;
+        int k = i;
+        for (; k + 1 < n; k += 2) { v0 += wr[(size_t)k * (PG_PW * 6) + i] * sz[k]; v1 += wr[(size_t)(k + 1) * (PG_PW * 6) + i] * sz[k + 1]; }
+        if (k < n) v0 += wr[(size_t)k * (PG_PW * 6) + i] * sz[k];
+        x[(size_t)(j0 + i / 6) * 6 + i % 6] = v0 + v1;
     }
-    for (int gj = threadIdx.x; gj < n; gj += 256) x[(size_t)(j0 + gj / 6) * 6 + gj % 6] = sz[gj];
 }
 
 // ---- bottom of the elimination tree: whole subtrees per workgroup (no grid-wide level barriers).
@@ -1246,18 +1304,17 @@ static int pg_solve_impl(dsss_ctx* c, const double* dr6, int total, const dsss_l
         for (int q = S.plvptr[l]; q < S.plvptr[l + 1]; ++q) {
             const int p = S.plvpan[q], j0 = S.pan_first[p], w = S.pan_w[p];
             plv_n[l] = std::max(plv_n[l], 6 * w);
-            plv_rowchunks[l] = std::max(plv_rowchunks[l], (6 * (S.colptr[j0 + 1] - S.colptr[j0] - w) + 15) / 16);
+            plv_rowchunks[l] = std::max(plv_rowchunks[l], (6 * (S.colptr[j0 + 1] - S.colptr[j0] - w) + 63) / 64);
         }
     const long long mapsz = S.mapptr[ns];
     if (mapsz > (1LL << 31)) { dv.release(); DSSS_FAIL(c, DSSS_E_CAPACITY, "update map of %lld entries", mapsz); }
     TRY(dv.alloc(c, &d_map, (size_t)mapsz)); TRY(dv.alloc(c, &d_part2, part2_doubles));
-    {   // the panel kernels keep a 96 x 96 f64 diagonal block (73.7 KB) in LDS
+    double *d_Wsw, *d_Wrow;      // per panel: W = L11^-1 (96 x 96, zero padded) in MFMA operand order and row-major
+    { const size_t npan = S.pan_first.size(); TRY(dv.alloc(c, &d_Wsw, npan * (PG_PW * 6) * (PG_PW * 6))); TRY(dv.alloc(c, &d_Wrow, npan * (PG_PW * 6) * (PG_PW * 6))); }
+    {   // pg_panel_diag_kernel keeps the packed L11 and W blocks (2 x 39 KB) in dynamic LDS
         static bool once = false;
         if (!once) {
-            const int lds = (PG_PW * 6) * (PG_PW * 6 + 1) * (int)sizeof(double);
-            hipFuncSetAttribute((const void*)pg_panel_diag_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-            hipFuncSetAttribute((const void*)pg_panel_trsm_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-            hipFuncSetAttribute((const void*)pg_panel_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+            hipFuncSetAttribute((const void*)pg_panel_diag_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, PG_DIAG_LDS);
             (void)hipGetLastError();
             once = true;
         }
@@ -1335,15 +1392,14 @@ static int pg_solve_impl(dsss_ctx* c, const double* dr6, int total, const dsss_l
                                                         d_mapptr, d_map, d_L, d_part2, stride, d_rlcol, d_x, d_tlim); }
                     if (nsl > 1) hipLaunchKernelGGL(pg_fold_kernel, dim3(ncl, lv_chunks[l]), dim3(256), 0, st, d_lvcols + S.lvptr[l], d_colptr, d_L, d_part2, nsl, stride, d_x);
                     { dsss_scope s3(c, DSSS_K_PG_DIAG, fl_diag[l]);
-                      hipLaunchKernelGGL(pg_panel_diag_kernel, dim3(npl), dim3(256), 0, st, d_plvpan + S.plvptr[l], d_pan_first, d_pan_w, d_pan_lcol0, d_colptr, d_L, d_part2, 1, stride, d_x, d_fail); }
+                      hipLaunchKernelGGL(pg_panel_diag_kernel, dim3(npl), dim3(256), PG_DIAG_LDS, st, d_plvpan + S.plvptr[l], d_pan_first, d_pan_w, d_pan_lcol0, d_colptr, d_L, d_part2, 1, stride, d_x, d_fail, d_Wsw, d_Wrow); }
                     dsss_scope s4(c, DSSS_K_PG_TRSM, plv_rowchunks[l] > 0 ? fl_trsm[l] : 0.0);
                     if (plv_rowchunks[l] > 0)
-                        hipLaunchKernelGGL(pg_panel_trsm_kernel, dim3(npl, plv_rowchunks[l]), dim3(256), ((size_t)plv_n[l] * plv_n[l] + plv_n[l]) * sizeof(double), st, d_plvpan + S.plvptr[l], d_pan_first, d_pan_w,
-                                           d_pan_lcol0, d_colptr, d_L, d_part2, 1, stride);
+                        hipLaunchKernelGGL(pg_panel_trsm_kernel, dim3(npl, plv_rowchunks[l]), dim3(256), 0, st, d_plvpan + S.plvptr[l], d_pan_first, d_pan_w, d_colptr, d_L, d_Wsw);
                 }
                 for (int l = nlev - 1; l >= 0; --l) {
                     dsss_scope s5(c, DSSS_K_PG_BWD, fl_bwd[l]);
-                    hipLaunchKernelGGL(pg_panel_bwd_kernel, dim3(S.plvptr[l + 1] - S.plvptr[l]), dim3(256), 0, st, d_plvpan + S.plvptr[l], d_pan_first, d_pan_w, d_colptr, d_rowidx, d_L, d_x);
+                    hipLaunchKernelGGL(pg_panel_bwd_kernel, dim3(S.plvptr[l + 1] - S.plvptr[l]), dim3(256), 0, st, d_plvpan + S.plvptr[l], d_pan_first, d_pan_w, d_colptr, d_rowidx, d_L, d_x, d_Wrow);
                 }
                 if (nbins > 0) { dsss_scope s6(c, DSSS_K_PG_SUBTREE);
                     hipLaunchKernelGGL(pg_bwd_subtree_kernel, dim3(nbins), dim3(64), 0, st, d_binptr, d_bincols, d_colptr, d_rowidx, d_L, d_x); }
