@@ -448,6 +448,15 @@ __global__ __launch_bounds__(256) void pg_fold_kernel(const int* __restrict__ lv
 #define PG_PW 16
 #define PG_NBLK (PG_PW * (PG_PW + 1) / 2)
 #define PG_DIAG_LDS (2 * PG_NBLK * 36 * (int)sizeof(double))
+#define PG_BWD_LDS (((PG_PW * 6) * (PG_PW * 6) + 64 * (PG_PW * 6)) * (int)sizeof(double))
+#ifdef PG_DIAG_TIMING
+__device__ unsigned long long pg_dbg[16];
+#define PGT(i) do { if (threadIdx.x == 0 && blockIdx.x == 0) { const unsigned long long _t = wall_clock64(); atomicAdd(&pg_dbg[i], _t - _tl); _tl = _t; } } while (0)
+#define PGT0() unsigned long long _tl = wall_clock64()
+#else
+#define PGT(i) do { } while (0)
+#define PGT0() do { } while (0)
+#endif
 __device__ inline size_t pan_pos(const int* __restrict__ colptr, int j0, int qi, int c) { return (size_t)colptr[j0 + c] + (size_t)(qi - c); }
 
 __global__ __launch_bounds__(256) void pg_panel_diag_kernel(const int* __restrict__ plvpan, const int* __restrict__ pan_first, const int* __restrict__ pan_w,
@@ -468,6 +477,7 @@ __global__ __launch_bounds__(256) void pg_panel_diag_kernel(const int* __restric
     const bool act = bi < w && bj <= bi;
     double a[36], y[6];
     if (threadIdx.x == 0) s_bad = 0;
+    PGT0();
     if (act) {
         const double* src = Lvals + pan_pos(colptr, j0, bi, bj) * 36;
         for (int e = 0; e < 36; ++e) a[e] = src[e];
@@ -485,6 +495,7 @@ __global__ __launch_bounds__(256) void pg_panel_diag_kernel(const int* __restric
         }
     }
     __syncthreads();
+    PGT(0);
     for (int k = 0; k < w; ++k) {
         if (bi == k && bj == k) {
             double ri[6];
@@ -500,6 +511,7 @@ __global__ __launch_bounds__(256) void pg_panel_diag_kernel(const int* __restric
             for (int e = 0; e < 6; ++e) sy[e] = y[e];
         }
         __syncthreads();
+        PGT(1);
         if (act && bj == k && bi > k) {                      // X L_kk^T = A_ik, row by row
 #pragma unroll
             for (int r = 0; r < 6; ++r) {
@@ -512,6 +524,7 @@ __global__ __launch_bounds__(256) void pg_panel_diag_kernel(const int* __restric
             for (int e = 0; e < 36; ++e) sLcol[bi][e] = a[e];
         }
         __syncthreads();
+        PGT(2);
         if (act && bj > k) {                                 // A_ij -= L_ik L_jk^T
             const double* Li = sLcol[bi]; const double* Lj = sLcol[bj];
 #pragma unroll
@@ -526,6 +539,7 @@ __global__ __launch_bounds__(256) void pg_panel_diag_kernel(const int* __restric
             if (bi == bj) for (int r = 0; r < 6; ++r) { double v = 0; for (int c2 = 0; c2 < 6; ++c2) v += Li[r * 6 + c2] * sy[c2]; y[r] -= v; }   // y_i -= L_ik y_k
         }
         __syncthreads();
+        PGT(3);
     }
     if (s_bad && threadIdx.x == 0) *fail = 1;
     if (act) {
@@ -536,6 +550,7 @@ __global__ __launch_bounds__(256) void pg_panel_diag_kernel(const int* __restric
     // ---- W = L11^-1 by recursive doubling over the 6 x 6 blocks, so that the row solve below the panel and the
     // back-substitution become products with W (pg_panel_trsm_kernel / pg_panel_bwd_kernel) instead of 16-step chains.
     // [A 0; B C]^-1 = [A^-1 0; -C^-1 B A^-1  C^-1]; blocks packed lower-triangular, idx(i, j) = i (i + 1) / 2 + j.
+    PGT(4);
     extern __shared__ double s_dyn[];
     double* sLb = s_dyn;
     double* sWb = s_dyn + PG_NBLK * 36;
@@ -547,14 +562,15 @@ __global__ __launch_bounds__(256) void pg_panel_diag_kernel(const int* __restric
 #pragma unroll
             for (int e = 0; e < 36; ++e) inv[e] = 0.0;
 #pragma unroll
+            for (int c2 = 0; c2 < 6; ++c2) inv[c2 * 6 + c2] = 1.0 / a[c2 * 6 + c2];
+#pragma unroll
             for (int c2 = 0; c2 < 6; ++c2) {
-                inv[c2 * 6 + c2] = 1.0 / a[c2 * 6 + c2];
 #pragma unroll
                 for (int r = 0; r < 6; ++r) if (r > c2) {
                     double v = 0;
 #pragma unroll
                     for (int s2 = 0; s2 < 6; ++s2) if (s2 >= c2 && s2 < r) v += a[r * 6 + s2] * inv[s2 * 6 + c2];
-                    inv[r * 6 + c2] = -v / a[r * 6 + r];
+                    inv[r * 6 + c2] = -v * inv[r * 6 + r];
                 }
             }
             double* dw = sWb + (bi * (bi + 1) / 2 + bj) * 36;
@@ -562,6 +578,7 @@ __global__ __launch_bounds__(256) void pg_panel_diag_kernel(const int* __restric
         }
     }
     __syncthreads();
+    PGT(5);
     for (int h = 1; h < w; h <<= 1) {
         // task = (off-diagonal block of an odd h-group, pair of rows): 8h blocks x 3 row pairs <= 192 tasks
         const int ntask = 24 * h;
@@ -616,22 +633,30 @@ __global__ __launch_bounds__(256) void pg_panel_diag_kernel(const int* __restric
         }
         __syncthreads();
     }
-    // W out, zero-padded to 96 x 96: row-major for the back-substitution, and in MFMA B-operand order for the row solve
-    // (tile nt = 16 output columns, k-step ks = 4 k's: lane l holds W[16 nt + (l & 15)][4 ks + (l >> 4)])
-    double* wr = Wrow + (size_t)p * (PG_PW * 6) * (PG_PW * 6);
-    double* ws = Wsw + (size_t)p * (PG_PW * 6) * (PG_PW * 6);
-    const int n = 6 * w;
-    for (int e = threadIdx.x; e < (PG_PW * 6) * (PG_PW * 6); e += 256) {
-        {   const int jr = e / (PG_PW * 6), kc = e - jr * (PG_PW * 6);
-            double v = 0.0;
-            if (jr < n && kc <= jr) { const int b1 = jr / 6, b2 = kc / 6; v = sWb[(b1 * (b1 + 1) / 2 + b2) * 36 + (jr - 6 * b1) * 6 + (kc - 6 * b2)]; }
-            wr[e] = v; }
-        {   const int lane = e & 63, ks = (e >> 6) % 24, nt = e / (64 * 24);
-            const int jr = 16 * nt + (lane & 15), kc = 4 * ks + (lane >> 4);
-            double v = 0.0;
-            if (jr < n && kc <= jr) { const int b1 = jr / 6, b2 = kc / 6; v = sWb[(b1 * (b1 + 1) / 2 + b2) * 36 + (jr - 6 * b1) * 6 + (kc - 6 * b2)]; }
-            ws[e] = v; }
+    PGT(6);
+    // W out: row-major for the back-substitution, and in MFMA B-operand order for the row solve (tile nt = 16 output
+    // columns, k-step ks = 4 k's: lane l holds W[16 nt + (l & 15)][4 ks + (l >> 4)]).  Thread (bi, bj) writes its block;
+    // everything outside the lower block triangle of the first w block rows was zeroed once by the host and stays zero.
+    if (act) {
+        double* wr = Wrow + (size_t)p * (PG_PW * 6) * (PG_PW * 6);
+        double* ws = Wsw + (size_t)p * (PG_PW * 6) * (PG_PW * 6);
+        const double* src = sWb + (bi * (bi + 1) / 2 + bj) * 36;
+        int offc[6];
+#pragma unroll
+        for (int c2 = 0; c2 < 6; ++c2) { const int kc = 6 * bj + c2; offc[c2] = (kc >> 2) * 64 + (kc & 3) * 16; }
+#pragma unroll
+        for (int r = 0; r < 6; ++r) {
+            const int jr = 6 * bi + r;
+            const int offr = (jr >> 4) * (24 * 64) + (jr & 15);
+#pragma unroll
+            for (int c2 = 0; c2 < 6; ++c2) {
+                const double v = src[r * 6 + c2];
+                wr[(size_t)jr * (PG_PW * 6) + 6 * bj + c2] = v;
+                ws[offr + offc[c2]] = v;
+            }
+        }
     }
+    PGT(7);
 }
 
 // L21 = A21 W^T with W = L11^-1 from pg_panel_diag_kernel: a plain f64 GEMM on the matrix cores.  One wavefront per
@@ -680,45 +705,58 @@ __global__ __launch_bounds__(256) void pg_panel_trsm_kernel(const int* __restric
     }
 }
 
-// x_panel = W^T (y_panel - L21^T x_below), W = L11^-1: one workgroup per panel
-__global__ __launch_bounds__(256) void pg_panel_bwd_kernel(const int* __restrict__ plvpan, const int* __restrict__ pan_first, const int* __restrict__ pan_w,
-                                                           const int* __restrict__ colptr, const int* __restrict__ rowidx,
-                                                           const double* __restrict__ Lvals, double* __restrict__ x, const double* __restrict__ Wrow)
+// x_panel = W^T (y_panel - L21^T x_below), W = L11^-1: one workgroup of 1024 threads per panel
+#define PG_BWD_SLOTS 64
+__global__ __launch_bounds__(1024) void pg_panel_bwd_kernel(const int* __restrict__ plvpan, const int* __restrict__ pan_first, const int* __restrict__ pan_w,
+                                                            const int* __restrict__ colptr, const int* __restrict__ rowidx,
+                                                            const double* __restrict__ Lvals, double* __restrict__ x, const double* __restrict__ Wrow)
 {
+    extern __shared__ double s_bw[];               // W [96 x 96] then the slot sums [PG_BWD_SLOTS][96]
     __shared__ double sz[PG_PW * 6];
+    double* sW = s_bw;
+    double* s_acc = s_bw + (PG_PW * 6) * (PG_PW * 6);
     const int p = plvpan[blockIdx.x];
     const int j0 = pan_first[p], w = pan_w[p], n = 6 * w;
     const int c0 = colptr[j0], m = colptr[j0 + 1] - c0;
-    // z[gj] = y[gj] - sum over rows below of L(row, gj) x_row : thread (slot, c) walks block rows slot, slot+16, ... of block
-    // column c; the 16 slot sums of every scalar column are then folded in slot order (deterministic)
-    __shared__ double s_acc[16][PG_PW * 6];
+    // W goes global -> registers now, -> LDS after the row sums, so its latency hides behind them
+    double wreg[9];
+    { const double* wr = Wrow + (size_t)p * (PG_PW * 6) * (PG_PW * 6);
+#pragma unroll
+      for (int e = 0; e < 9; ++e) wreg[e] = wr[e * 1024 + threadIdx.x]; }
+    // z[gj] = y[gj] - sum over rows below of L(row, gj) x_row : thread (slot, c) walks block rows slot, slot+64, ... of block
+    // column c; the slot sums of every scalar column are then folded in slot order (deterministic)
     {
         const int slot = threadIdx.x >> 4, cc = threadIdx.x & 15;
         double acc[6] = { 0, 0, 0, 0, 0, 0 };
-        if (cc < w)
-            for (int qi = w + slot; qi < m; qi += 16) {
-                const double* B = Lvals + pan_pos(colptr, j0, qi, cc) * 36; const double* xi = x + (size_t)rowidx[c0 + qi] * 6;
+        if (cc < w) {
+            const size_t cbase = (size_t)colptr[j0 + cc] - (size_t)cc;
+            for (int qi = w + slot; qi < m; qi += PG_BWD_SLOTS) {
+                const double* B = Lvals + (cbase + qi) * 36; const double* xi = x + (size_t)rowidx[c0 + qi] * 6;
                 const double x0 = xi[0], x1 = xi[1], x2 = xi[2], x3 = xi[3], x4 = xi[4], x5 = xi[5];
 #pragma unroll
                 for (int s6 = 0; s6 < 6; ++s6) acc[s6] += B[s6] * x0 + B[6 + s6] * x1 + B[12 + s6] * x2 + B[18 + s6] * x3 + B[24 + s6] * x4 + B[30 + s6] * x5;
             }
-        if (cc < w) for (int s6 = 0; s6 < 6; ++s6) s_acc[slot][cc * 6 + s6] = acc[s6];
+#pragma unroll
+            for (int s6 = 0; s6 < 6; ++s6) s_acc[slot * (PG_PW * 6) + cc * 6 + s6] = acc[s6];
+        }
     }
+#pragma unroll
+    for (int e = 0; e < 9; ++e) sW[e * 1024 + threadIdx.x] = wreg[e];
     __syncthreads();
-    for (int gj = threadIdx.x; gj < n; gj += 256) {
+    if ((int)threadIdx.x < n) {
+        const int gj = threadIdx.x;
         double v = x[(size_t)(j0 + gj / 6) * 6 + gj % 6];
-        for (int g = 0; g < 16; ++g) v -= s_acc[g][gj];
+        for (int g = 0; g < PG_BWD_SLOTS; ++g) v -= s_acc[g * (PG_PW * 6) + gj];
         sz[gj] = v;
     }
     __syncthreads();
-    // x = L11^-T z = W^T z: x[i] = sum_{k >= i} W[k][i] z[k], ascending k (row-major W: coalesced over i)
+    // x[i] = sum_{k >= i} W[k][i] z[k], ascending k, two interleaved partial sums
     if ((int)threadIdx.x < n) {
         const int i = threadIdx.x;
-        const double* wr = Wrow + (size_t)p * (PG_PW * 6) * (PG_PW * 6);
         double v0 = 0, v1 = 0;
         int k = i;
-        for (; k + 1 < n; k += 2) { v0 += wr[(size_t)k * (PG_PW * 6) + i] * sz[k]; v1 += wr[(size_t)(k + 1) * (PG_PW * 6) + i] * sz[k + 1]; }
-        if (k < n) v0 += wr[(size_t)k * (PG_PW * 6) + i] * sz[k];
+        for (; k + 1 < n; k += 2) { v0 += sW[k * (PG_PW * 6) + i] * sz[k]; v1 += sW[(k + 1) * (PG_PW * 6) + i] * sz[k + 1]; }
+        if (k < n) v0 += sW[k * (PG_PW * 6) + i] * sz[k];
         x[(size_t)(j0 + i / 6) * 6 + i % 6] = v0 + v1;
     }
 }
@@ -1310,11 +1348,13 @@ static int pg_solve_impl(dsss_ctx* c, const double* dr6, int total, const dsss_l
     if (mapsz > (1LL << 31)) { dv.release(); DSSS_FAIL(c, DSSS_E_CAPACITY, "update map of %lld entries", mapsz); }
     TRY(dv.alloc(c, &d_map, (size_t)mapsz)); TRY(dv.alloc(c, &d_part2, part2_doubles));
     double *d_Wsw, *d_Wrow;      // per panel: W = L11^-1 (96 x 96, zero padded) in MFMA operand order and row-major
-    { const size_t npan = S.pan_first.size(); TRY(dv.alloc(c, &d_Wsw, npan * (PG_PW * 6) * (PG_PW * 6))); TRY(dv.alloc(c, &d_Wrow, npan * (PG_PW * 6) * (PG_PW * 6))); }
+    { const size_t npan = S.pan_first.size(); const size_t wn = npan * (PG_PW * 6) * (PG_PW * 6); TRY(dv.alloc(c, &d_Wsw, wn)); TRY(dv.alloc(c, &d_Wrow, wn));
+      HIPCHK(c, hipMemsetAsync(d_Wsw, 0, wn * sizeof(double), c->stream)); HIPCHK(c, hipMemsetAsync(d_Wrow, 0, wn * sizeof(double), c->stream)); }
     {   // pg_panel_diag_kernel keeps the packed L11 and W blocks (2 x 39 KB) in dynamic LDS
         static bool once = false;
         if (!once) {
             hipFuncSetAttribute((const void*)pg_panel_diag_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, PG_DIAG_LDS);
+            hipFuncSetAttribute((const void*)pg_panel_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, PG_BWD_LDS);
             (void)hipGetLastError();
             once = true;
         }
@@ -1399,7 +1439,7 @@ static int pg_solve_impl(dsss_ctx* c, const double* dr6, int total, const dsss_l
                 }
                 for (int l = nlev - 1; l >= 0; --l) {
                     dsss_scope s5(c, DSSS_K_PG_BWD, fl_bwd[l]);
-                    hipLaunchKernelGGL(pg_panel_bwd_kernel, dim3(S.plvptr[l + 1] - S.plvptr[l]), dim3(256), 0, st, d_plvpan + S.plvptr[l], d_pan_first, d_pan_w, d_colptr, d_rowidx, d_L, d_x, d_Wrow);
+                    hipLaunchKernelGGL(pg_panel_bwd_kernel, dim3(S.plvptr[l + 1] - S.plvptr[l]), dim3(1024), PG_BWD_LDS, st, d_plvpan + S.plvptr[l], d_pan_first, d_pan_w, d_colptr, d_rowidx, d_L, d_x, d_Wrow);
                 }
                 if (nbins > 0) { dsss_scope s6(c, DSSS_K_PG_SUBTREE);
                     hipLaunchKernelGGL(pg_bwd_subtree_kernel, dim3(nbins), dim3(64), 0, st, d_binptr, d_bincols, d_colptr, d_rowidx, d_L, d_x); }
@@ -1448,6 +1488,11 @@ static int pg_solve_impl(dsss_ctx* c, const double* dr6, int total, const dsss_l
     HCK(hipStreamSynchronize(st));
     if (stats4) { stats4[0] = iters; stats4[1] = err0; stats4[2] = err; stats4[3] = lambda; }
     dv.release();
+#ifdef PG_DIAG_TIMING
+    { unsigned long long h[16]; hipMemcpyFromSymbol(h, HIP_SYMBOL(pg_dbg), sizeof(h)); static const char* nm[8] = { "load", "factor", "solve", "update", "store", "inv6", "levels", "W out" };
+      for (int i = 0; i < 8; ++i) fprintf(stderr, "[pg diag timing] %-8s %.1f us total (block 0 of every launch)\n", nm[i], h[i] * 0.01);
+      memset(h, 0, sizeof(h)); hipMemcpyToSymbol(HIP_SYMBOL(pg_dbg), h, sizeof(h)); }
+#endif
     if (verbose) fprintf(stderr, "[dsss pg] LM iterations %d  factorisations %d  err %.6g -> %.6g | host prep %.1f ms, symbolic %.1f ms, alloc+upload %.1f ms, LM loop %.1f ms\n",
                          iters, nfact, err0, err, t_prep, t_sym, t_up, ms_since(T3));
 #undef TRY
