@@ -20,6 +20,8 @@
 #include <random>
 #include <cstdlib>
 #include <chrono>
+#include <thread>
+#include <mutex>
 
 // ------------------------------------------------------------------ small dense helpers (6x6 row-major)
 __device__ inline int chol6(double* A)
@@ -1047,38 +1049,96 @@ struct sym_t {
     std::vector<long long> mapptr;
 };
 
-// geometric nested dissection: recursive coordinate bisection with vertex separators taken from the lower half
-void nd_order(std::vector<int>& nodes, const std::vector<std::vector<int>>& adj, const std::vector<double>& cx,
-              const std::vector<double>& cy, std::vector<char>& side, std::vector<int>& order, int leaf)
+// geometric nested dissection: recursive coordinate bisection with vertex separators taken from the lower half.
+// The order of a subtree is [A subtree][B subtree][separator]; A and B never touch, so the first PG_ND_PAR levels run
+// their two halves on two host threads, and the same tree of ranges later drives the parallel column-structure pass.
+struct nd_tree { int a = -1, b = -1, size = 0; };          // children (indices into the node pool) or -1,-1 for a leaf
+#define PG_ND_PAR 4
+struct nd_ctx {
+    const int* adj_ptr; const int* adj_idx; const double* cx; const double* cy; char* side; int leaf;
+    std::vector<nd_tree>* pool; std::mutex* mu;
+};
+int nd_order(std::vector<int>& nodes, const nd_ctx& C, std::vector<int>& order, int depth)
 {
-    if ((int)nodes.size() <= leaf) { std::sort(nodes.begin(), nodes.end()); for (int v : nodes) order.push_back(v); return; }
+    auto new_node = [&](int a, int b, int size) { std::lock_guard<std::mutex> g(*C.mu); C.pool->push_back({ a, b, size }); return (int)C.pool->size() - 1; };
+    const int total = (int)nodes.size();
+    if (total <= C.leaf) { std::sort(nodes.begin(), nodes.end()); for (int v : nodes) order.push_back(v); return depth <= PG_ND_PAR ? new_node(-1, -1, total) : -1; }
     double x0 = 1e300, x1 = -1e300, y0 = 1e300, y1 = -1e300;
-    for (int v : nodes) { x0 = std::min(x0, cx[v]); x1 = std::max(x1, cx[v]); y0 = std::min(y0, cy[v]); y1 = std::max(y1, cy[v]); }
+    for (int v : nodes) { x0 = std::min(x0, C.cx[v]); x1 = std::max(x1, C.cx[v]); y0 = std::min(y0, C.cy[v]); y1 = std::max(y1, C.cy[v]); }
     const bool byx = (x1 - x0) >= (y1 - y0);
     const size_t half = nodes.size() / 2;
     // split at the median of the (coordinate, index) total order; only the two halves matter, not their inner order
+    const double* key = byx ? C.cx : C.cy;
     std::nth_element(nodes.begin(), nodes.begin() + half, nodes.end(), [&](int a, int b) {
-        const double ka = byx ? cx[a] : cy[a], kb = byx ? cx[b] : cy[b];
+        const double ka = key[a], kb = key[b];
         return ka != kb ? ka < kb : a < b; });
-    for (size_t i = 0; i < nodes.size(); ++i) side[nodes[i]] = i < half ? 1 : 2;
+    for (size_t i = 0; i < nodes.size(); ++i) C.side[nodes[i]] = i < half ? 1 : 2;
     std::vector<int> A, B, S;
     for (size_t i = 0; i < half; ++i) {
         const int v = nodes[i];
         bool cut = false;
-        for (int u : adj[v]) if (side[u] == 2) { cut = true; break; }
+        for (int q = C.adj_ptr[v]; q < C.adj_ptr[v + 1]; ++q) if (C.side[C.adj_idx[q]] == 2) { cut = true; break; }
         (cut ? S : A).push_back(v);
     }
-    for (size_t i = half; i < nodes.size(); ++i) B.push_back(nodes[i]);
-    for (int v : nodes) side[v] = 0;
+    B.assign(nodes.begin() + half, nodes.end());
+    for (int v : nodes) C.side[v] = 0;
     std::sort(S.begin(), S.end());
     if (A.empty() || B.empty()) {          // degenerate cut: fall back to index order
         std::sort(nodes.begin(), nodes.end());
         for (int v : nodes) order.push_back(v);
-        return;
+        return depth <= PG_ND_PAR ? new_node(-1, -1, total) : -1;
     }
-    nd_order(A, adj, cx, cy, side, order, leaf);
-    nd_order(B, adj, cx, cy, side, order, leaf);
+    int na = -1, nb = -1;
+    if (depth < PG_ND_PAR && total > 2048) {
+        std::vector<int> oa;
+        std::thread th([&] { na = nd_order(A, C, oa, depth + 1); });
+        std::vector<int> ob;
+        nb = nd_order(B, C, ob, depth + 1);
+        th.join();
+        order.insert(order.end(), oa.begin(), oa.end());
+        order.insert(order.end(), ob.begin(), ob.end());
+    } else {
+        nd_order(A, C, order, PG_ND_PAR + 1);
+        nd_order(B, C, order, PG_ND_PAR + 1);
+    }
     for (int v : S) order.push_back(v);
+    return depth <= PG_ND_PAR ? new_node(na, nb, total) : -1;
+}
+
+// column structures of the range [lo, lo + size) of the elimination order described by tree node `t`, children merged
+// into parents (elimination tree built on the fly).  A column whose parent lies outside the range hands the
+// (parent, column) pair up to its caller.
+struct cs_ctx {
+    const int* adj_ptr; const int* adj_idx; const int* order; const int* perm; const std::vector<nd_tree>* pool;
+    std::vector<std::vector<int>>* cols; std::vector<std::vector<int>>* kids; int* parent;
+};
+void col_structs(const cs_ctx& C, int t, int lo, int size, std::vector<std::pair<int, int>>& up, int depth)
+{
+    const nd_tree nd = t >= 0 ? (*C.pool)[t] : nd_tree();
+    int seq_lo = lo;
+    const int hi = lo + size;
+    if (t >= 0 && nd.a >= 0 && nd.b >= 0) {
+        const int sa = (*C.pool)[nd.a].size, sb = (*C.pool)[nd.b].size;
+        std::vector<std::pair<int, int>> ua, ub;
+        std::thread th([&] { col_structs(C, nd.a, lo, sa, ua, depth + 1); });
+        col_structs(C, nd.b, lo + sa, sb, ub, depth + 1);
+        th.join();
+        for (auto* u : { &ua, &ub })
+            for (auto& e : *u) { if (e.first < hi) (*C.kids)[e.first].push_back(e.second); else up.push_back(e); }
+        seq_lo = lo + sa + sb;
+    }
+    for (int j = seq_lo; j < hi; ++j) {
+        std::vector<int>& c = (*C.cols)[j];
+        const int v = C.order[j];
+        for (int q = C.adj_ptr[v]; q < C.adj_ptr[v + 1]; ++q) { const int pu = C.perm[C.adj_idx[q]]; if (pu > j) c.push_back(pu); }
+        for (int k : (*C.kids)[j]) { const std::vector<int>& ck = (*C.cols)[k]; for (size_t q = 1; q < ck.size(); ++q) if (ck[q] != j) c.push_back(ck[q]); }
+        std::sort(c.begin(), c.end()); c.erase(std::unique(c.begin(), c.end()), c.end());
+        c.insert(c.begin(), j);
+        if (c.size() > 1) {
+            C.parent[j] = c[1];
+            if (c[1] < hi) (*C.kids)[c[1]].push_back(j); else up.push_back({ c[1], j });
+        }
+    }
 }
 
 // edges: pairs of chain-order separator indices (chain couplings first, then LC edges)
@@ -1090,29 +1150,41 @@ void symbolic(int ns, const std::vector<std::pair<int, int>>& edges, int nchain,
     auto tnow = [] { return std::chrono::steady_clock::now(); };
     auto tms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
     const auto q0 = tnow();
-    std::vector<std::vector<int>> adj(ns);
-    for (auto& e : edges) if (e.first != e.second) { adj[e.first].push_back(e.second); adj[e.second].push_back(e.first); }
-    for (auto& a : adj) { std::sort(a.begin(), a.end()); a.erase(std::unique(a.begin(), a.end()), a.end()); }
+    // adjacency in CSR form, rows sorted and deduplicated
+    std::vector<int> adj_ptr(ns + 1, 0), adj_idx;
+    {
+        for (auto& e : edges) if (e.first != e.second) { adj_ptr[e.first + 1]++; adj_ptr[e.second + 1]++; }
+        for (int i = 0; i < ns; ++i) adj_ptr[i + 1] += adj_ptr[i];
+        std::vector<int> raw(adj_ptr[ns]), fill(adj_ptr.begin(), adj_ptr.end() - 1);
+        for (auto& e : edges) if (e.first != e.second) { raw[fill[e.first]++] = e.second; raw[fill[e.second]++] = e.first; }
+        adj_idx.reserve(raw.size());
+        std::vector<int> nptr(ns + 1, 0);
+        for (int i = 0; i < ns; ++i) {
+            int* b0 = raw.data() + adj_ptr[i]; int* e0 = raw.data() + adj_ptr[i + 1];
+            std::sort(b0, e0); e0 = std::unique(b0, e0);
+            adj_idx.insert(adj_idx.end(), b0, e0);
+            nptr[i + 1] = (int)adj_idx.size();
+        }
+        adj_ptr.swap(nptr);
+    }
     std::vector<int> order; order.reserve(ns);
+    std::vector<nd_tree> pool; std::mutex mu;
+    int root = -1;
     if (use_nd) {
         std::vector<int> nodes(ns); std::iota(nodes.begin(), nodes.end(), 0);
         std::vector<char> side(ns, 0);
-        nd_order(nodes, adj, cx, cy, side, order, 24);
+        nd_ctx C{ adj_ptr.data(), adj_idx.data(), cx.data(), cy.data(), side.data(), 24, &pool, &mu };
+        root = nd_order(nodes, C, order, 0);
     } else { order.resize(ns); std::iota(order.begin(), order.end(), 0); }
     const auto q1 = tnow();
     S.perm.assign(ns, 0);
     for (int i = 0; i < ns; ++i) S.perm[order[i]] = i;
-    // column structures by merging children (elimination tree built on the fly)
     std::vector<std::vector<int>> cols(ns), kids(ns);
     std::vector<int> parent(ns, -1);
-    for (int j = 0; j < ns; ++j) {
-        std::vector<int>& c = cols[j];
-        const int v = order[j];
-        for (int u : adj[v]) if (S.perm[u] > j) c.push_back(S.perm[u]);
-        for (int k : kids[j]) for (size_t q = 1; q < cols[k].size(); ++q) if (cols[k][q] != j) c.push_back(cols[k][q]);
-        std::sort(c.begin(), c.end()); c.erase(std::unique(c.begin(), c.end()), c.end());
-        c.insert(c.begin(), j);
-        if (c.size() > 1) { parent[j] = c[1]; kids[c[1]].push_back(j); }
+    {
+        cs_ctx C{ adj_ptr.data(), adj_idx.data(), order.data(), S.perm.data(), &pool, &cols, &kids, parent.data() };
+        std::vector<std::pair<int, int>> up;
+        col_structs(C, root, 0, ns, up, 0);
     }
     const auto q2 = tnow();
     S.colptr.assign(ns + 1, 0);
