@@ -444,205 +444,232 @@ __global__ __launch_bounds__(256) void pg_fold_kernel(const int* __restrict__ lv
 // ---- supernodal panels for the top of the tree.  A panel is up to PG_PW consecutive columns j0 .. j0+w-1 with nested
 // structure (struct(j+1) = struct(j) minus j), i.e. a dense trapezoid: a 6w x 6w diagonal block A11 on top of the rows
 // A21 shared by all its columns.  After the external updates (pg_factor_acc_kernel over all columns of the level at once)
-//     L11 = chol(A11), y = L11^-1 b      pg_panel_diag_kernel   one workgroup per panel, A11 in LDS
-//     L21 = A21 L11^-T                   pg_panel_trsm_kernel   one thread per scalar row of A21
-// which replaces w column-levels by one panel-level.
+//     L11 = chol(A11), y = L11^-1 b, W = L11^-1     pg_panel_diag_kernel   one workgroup per panel, A11 dense in LDS
+//     L21 = A21 W^T                                 pg_panel_trsm_kernel   one wavefront per 16 scalar rows of A21
+// which replaces w column-levels by one panel-level; both run on the f64 matrix cores.
 #define PG_PW 16
-#define PG_NBLK (PG_PW * (PG_PW + 1) / 2)
-#define PG_DIAG_LDS (2 * PG_NBLK * 36 * (int)sizeof(double))
 #define PG_BWD_LDS (((PG_PW * 6) * (PG_PW * 6) + 64 * (PG_PW * 6)) * (int)sizeof(double))
-#ifdef PG_DIAG_TIMING
-__device__ unsigned long long pg_dbg[16];
-#define PGT(i) do { if (threadIdx.x == 0 && blockIdx.x == 0) { const unsigned long long _t = wall_clock64(); atomicAdd(&pg_dbg[i], _t - _tl); _tl = _t; } } while (0)
-#define PGT0() unsigned long long _tl = wall_clock64()
-#else
-#define PGT(i) do { } while (0)
-#define PGT0() do { } while (0)
-#endif
 __device__ inline size_t pan_pos(const int* __restrict__ colptr, int j0, int qi, int c) { return (size_t)colptr[j0 + c] + (size_t)(qi - c); }
 
+// ---- pg_panel_diag_kernel: the 6w x 6w diagonal block of a panel as a dense matrix in LDS, worked in 16 x 16 tiles.
+//   per tile step t:  A  (16 lanes) L_tt = chol(A_tt) and V_t = L_tt^-1, rows/columns held across lanes, pivots and
+//                        multipliers broadcast with v_readlane
+//                     B  L_it = A_it V_t^T for the tiles below            (v_mfma_f64_16x16x4_f64, 4 per tile)
+//                     C  A_ij -= L_it L_jt^T for the trailing tiles       (same); wavefront 0 takes tile (t+1, t+1) first
+//                        and goes straight on to step A of t+1 while wavefronts 1-3 finish the rest (look-ahead)
+//   then W = L11^-1 by recursive doubling over tiles, [A 0; B C]^-1 = [A^-1 0; -C^-1 B A^-1  C^-1], again on the matrix
+//   cores, so that the row solve below the panel and the back-substitution are plain products with W.
+// The right-hand side rides along: y_t = V_t b_t, b_i -= L_it y_t.
+#define PG_LD 98                                   // LDS row stride of the 96 x 96 images (doubles)
+#define PG_DIAG_LDS (2 * (PG_PW * 6) * PG_LD * (int)sizeof(double))
+typedef double pg_d4 __attribute__((ext_vector_type(4)));
+__device__ inline double pg_readlane(double v, int lane)
+{
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane), hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
+    return __hiloint2double(hi, lo);
+}
+// MFMA operand images of a 16 x 16 tile at (R0, C0) of a row-major LDS matrix.  "a": lane l holds [l & 15][4 ks + (l >> 4)],
+// i.e. the tile as the A operand, or its transpose as the B operand; "b": lane l holds [4 ks + (l >> 4)][l & 15].
+__device__ inline void pg_ld_a(const double* s, int R0, int C0, int l, double sign, double* f)
+{
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) f[ks] = sign * s[(R0 + (l & 15)) * PG_LD + C0 + 4 * ks + (l >> 4)];
+}
+__device__ inline void pg_ld_b(const double* s, int R0, int C0, int l, double* f)
+{
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) f[ks] = s[(R0 + 4 * ks + (l >> 4)) * PG_LD + C0 + (l & 15)];
+}
+__device__ inline pg_d4 pg_ld_c(const double* s, int R0, int C0, int l)
+{
+    pg_d4 c;
+#pragma unroll
+    for (int v = 0; v < 4; ++v) c[v] = s[(R0 + (l >> 4) + 4 * v) * PG_LD + C0 + (l & 15)];
+    return c;
+}
+__device__ inline void pg_st_c(double* s, int R0, int C0, int l, pg_d4 c)
+{
+#pragma unroll
+    for (int v = 0; v < 4; ++v) s[(R0 + (l >> 4) + 4 * v) * PG_LD + C0 + (l & 15)] = c[v];
+}
+__device__ inline pg_d4 pg_mma4(const double* a, const double* b, pg_d4 c)
+{
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) c = __builtin_amdgcn_mfma_f64_16x16x4f64(a[ks], b[ks], c, 0, 0, 0);
+    return c;
+}
+// step A for tile t, executed by lanes 0..15 of one wavefront: lane i owns row i of A_tt, then column i of V_t
+__device__ inline int pg_tile_factor(double* sA, double* sW, int t, int lane)
+{
+    double d[16], v[16], rinv[16];
+    double* row = sA + (16 * t + lane) * PG_LD + 16 * t;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) d[j] = row[j];
+    int bad = 0;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        double pj = pg_readlane(d[j], j);
+        if (!(pj > 0) || !isfinite(pj)) { bad = 1; pj = 1.0; }
+        const double r = rsqrt(pj);
+        rinv[j] = r;
+        d[j] = (lane == j ? pj : d[j]) * r;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) if (k > j) d[k] -= d[j] * pg_readlane(d[j], k);      // A_ik -= L_ij L_kj (used for i >= k)
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {                 // row i of V: lane c holds V[i][c], zero above the diagonal
+        double sacc = 0;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) if (k < i) sacc += pg_readlane(d[k], i) * v[k];
+        v[i] = lane == i ? rinv[i] : (lane < i ? -sacc * rinv[i] : 0.0);
+    }
+#pragma unroll
+    for (int j = 0; j < 16; ++j) row[j] = j <= lane ? d[j] : 0.0;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) sW[(16 * t + i) * PG_LD + 16 * t + lane] = v[i];
+    return bad;
+}
+
 __global__ __launch_bounds__(256) void pg_panel_diag_kernel(const int* __restrict__ plvpan, const int* __restrict__ pan_first, const int* __restrict__ pan_w,
-                                                            const int* __restrict__ pan_lcol0, const int* __restrict__ colptr,
-                                                            double* __restrict__ Lvals, const double* __restrict__ part, int nsl, int col_stride,
+                                                            const int* __restrict__ colptr, double* __restrict__ Lvals,
                                                             double* __restrict__ x, int* __restrict__ fail, double* __restrict__ Wsw, double* __restrict__ Wrow)
 {
-    // blocked right-looking Cholesky: thread (bi, bj) of a 16 x 16 grid owns the 6 x 6 block A(bi, bj) in registers;
-    // per block step k: (k,k) factors, column k solves against L_kk, the trailing blocks subtract L_ik L_jk^T.
-    __shared__ double sLkk[36];
-    __shared__ double sRinv[6];
-    __shared__ double sLcol[PG_PW][36];
-    __shared__ double sy[6];
+    extern __shared__ double s_dyn[];
+    __shared__ double sy[PG_PW * 6];
     __shared__ int s_bad;
+    double* sA = s_dyn;
+    double* sW = s_dyn + (PG_PW * 6) * PG_LD;
     const int p = plvpan[blockIdx.x];
-    const int j0 = pan_first[p], w = pan_w[p], lc0 = pan_lcol0[p];
+    const int j0 = pan_first[p], w = pan_w[p], n = 6 * w;
+    const int nt = (n + 15) >> 4, np = 16 * nt;
     const int bi = threadIdx.x >> 4, bj = threadIdx.x & 15;
     const bool act = bi < w && bj <= bi;
-    double a[36], y[6];
+    const int wave = threadIdx.x >> 6, l = threadIdx.x & 63;
     if (threadIdx.x == 0) s_bad = 0;
-    PGT0();
     if (act) {
         const double* src = Lvals + pan_pos(colptr, j0, bi, bj) * 36;
-        for (int e = 0; e < 36; ++e) a[e] = src[e];
-        if (nsl > 1)
-            for (int sl = 0; sl < nsl; ++sl) {
-                const double* o = part + ((size_t)(lc0 + bj) * nsl + sl) * col_stride + (size_t)(bi - bj) * 36;
-                for (int e = 0; e < 36; ++e) a[e] -= o[e];
-            }
-        if (bi == bj) {
-            for (int e = 0; e < 6; ++e) {
-                double v = x[(size_t)(j0 + bi) * 6 + e];
-                if (nsl > 1) for (int sl = 0; sl < nsl; ++sl) v -= part[((size_t)(lc0 + bi) * nsl + sl) * col_stride + (size_t)col_stride - 8 + e];
-                y[e] = v;
-            }
-        }
+#pragma unroll
+        for (int e = 0; e < 36; ++e) sA[(6 * bi + e / 6) * PG_LD + 6 * bj + e % 6] = src[e];
     }
+    for (int e = threadIdx.x; e < (np - n) * np; e += 256) {        // identity padding up to the tile boundary
+        const int i = n + e / np, c2 = e % np;
+        sA[i * PG_LD + c2] = i == c2 ? 1.0 : 0.0;
+    }
+    if ((int)threadIdx.x < np) sy[threadIdx.x] = (int)threadIdx.x < n ? x[(size_t)(j0 + threadIdx.x / 6) * 6 + threadIdx.x % 6] : 0.0;
     __syncthreads();
-    PGT(0);
-    for (int k = 0; k < w; ++k) {
-        if (bi == k && bj == k) {
-            double ri[6];
-            if (chol6_fast(a, ri)) s_bad = 1;
+    if (threadIdx.x < 16) { if (pg_tile_factor(sA, sW, 0, threadIdx.x)) s_bad = 1; }
+    __syncthreads();
+    for (int t = 0; t < nt; ++t) {
+        // ---- B: tiles below the diagonal tile, one per wavefront in turn; lanes 0..15 of wavefront 0 also finish y_t
+        for (int i = t + 1 + wave; i < nt; i += 4) {
+            double fa[4], fb[4];
+            pg_ld_a(sA, 16 * i, 16 * t, l, 1.0, fa);
+            pg_ld_a(sW, 16 * t, 16 * t, l, 1.0, fb);          // B[k][c] = V_t[c][k]
+            pg_d4 acc = { 0.0, 0.0, 0.0, 0.0 };
+            acc = pg_mma4(fa, fb, acc);
+            pg_st_c(sA, 16 * i, 16 * t, l, acc);
+        }
+        if (threadIdx.x < 16) {
+            double bb[16];
 #pragma unroll
-            for (int r = 0; r < 6; ++r)
+            for (int k = 0; k < 16; ++k) bb[k] = sy[16 * t + k];
+            double yv = 0;
 #pragma unroll
-                for (int c2 = 0; c2 < 6; ++c2) if (c2 > r) a[r * 6 + c2] = 0.0;
-#pragma unroll
-            for (int e = 0; e < 6; ++e) sRinv[e] = ri[e];
-            for (int e = 0; e < 36; ++e) sLkk[e] = a[e];
-            for (int r = 0; r < 6; ++r) { double v = y[r]; for (int c2 = 0; c2 < r; ++c2) v -= a[r * 6 + c2] * y[c2]; y[r] = v * ri[r]; }
-            for (int e = 0; e < 6; ++e) sy[e] = y[e];
+            for (int k = 0; k < 16; ++k) yv += sW[(16 * t + threadIdx.x) * PG_LD + 16 * t + k] * bb[k];
+            sy[16 * t + threadIdx.x] = yv;
         }
         __syncthreads();
-        PGT(1);
-        if (act && bj == k && bi > k) {                      // X L_kk^T = A_ik, row by row
+        // ---- C: trailing update
+        if (t + 1 < nt) {
+            if (wave == 0) {
+                double fa[4], fb[4];
+                pg_ld_a(sA, 16 * (t + 1), 16 * t, l, -1.0, fa);
+                pg_ld_a(sA, 16 * (t + 1), 16 * t, l, 1.0, fb);
+                pg_d4 acc = pg_ld_c(sA, 16 * (t + 1), 16 * (t + 1), l);
+                acc = pg_mma4(fa, fb, acc);
+                pg_st_c(sA, 16 * (t + 1), 16 * (t + 1), l, acc);
+                if (l < 16) { if (pg_tile_factor(sA, sW, t + 1, l)) s_bad = 1; }
+            } else {
+                int cnt = 0;
+                for (int i = t + 1; i < nt; ++i)
+                    for (int j = t + 1; j <= i; ++j) {
+                        if (i == t + 1 && j == t + 1) continue;
+                        if (cnt++ % 3 != wave - 1) continue;
+                        double fa[4], fb[4];
+                        pg_ld_a(sA, 16 * i, 16 * t, l, -1.0, fa);
+                        pg_ld_a(sA, 16 * j, 16 * t, l, 1.0, fb);
+                        pg_d4 acc = pg_ld_c(sA, 16 * i, 16 * j, l);
+                        acc = pg_mma4(fa, fb, acc);
+                        pg_st_c(sA, 16 * i, 16 * j, l, acc);
+                    }
+                const int i = 16 * (t + 1) + (int)threadIdx.x - 64;      // b_i -= L_it y_t
+                if (i < np) {
+                    double v = sy[i];
 #pragma unroll
-            for (int r = 0; r < 6; ++r) {
-                double xr[6];
-#pragma unroll
-                for (int s2 = 0; s2 < 6; ++s2) { double v = a[r * 6 + s2]; for (int c2 = 0; c2 < s2; ++c2) v -= xr[c2] * sLkk[s2 * 6 + c2]; xr[s2] = v * sRinv[s2]; }
-#pragma unroll
-                for (int s2 = 0; s2 < 6; ++s2) a[r * 6 + s2] = xr[s2];
-            }
-            for (int e = 0; e < 36; ++e) sLcol[bi][e] = a[e];
-        }
-        __syncthreads();
-        PGT(2);
-        if (act && bj > k) {                                 // A_ij -= L_ik L_jk^T
-            const double* Li = sLcol[bi]; const double* Lj = sLcol[bj];
-#pragma unroll
-            for (int r = 0; r < 6; ++r)
-#pragma unroll
-                for (int s2 = 0; s2 < 6; ++s2) {
-                    double v = 0;
-#pragma unroll
-                    for (int c2 = 0; c2 < 6; ++c2) v += Li[r * 6 + c2] * Lj[s2 * 6 + c2];
-                    a[r * 6 + s2] -= v;
+                    for (int k = 0; k < 16; ++k) v -= sA[i * PG_LD + 16 * t + k] * sy[16 * t + k];
+                    sy[i] = v;
                 }
-            if (bi == bj) for (int r = 0; r < 6; ++r) { double v = 0; for (int c2 = 0; c2 < 6; ++c2) v += Li[r * 6 + c2] * sy[c2]; y[r] -= v; }   // y_i -= L_ik y_k
+            }
         }
         __syncthreads();
-        PGT(3);
     }
     if (s_bad && threadIdx.x == 0) *fail = 1;
     if (act) {
         double* dst = Lvals + pan_pos(colptr, j0, bi, bj) * 36;
-        for (int e = 0; e < 36; ++e) dst[e] = a[e];
-        if (bi == bj) for (int e = 0; e < 6; ++e) x[(size_t)(j0 + bi) * 6 + e] = y[e];
+#pragma unroll
+        for (int e = 0; e < 36; ++e) dst[e] = (bi == bj && e % 6 > e / 6) ? 0.0 : sA[(6 * bi + e / 6) * PG_LD + 6 * bj + e % 6];
     }
-    // ---- W = L11^-1 by recursive doubling over the 6 x 6 blocks, so that the row solve below the panel and the
-    // back-substitution become products with W (pg_panel_trsm_kernel / pg_panel_bwd_kernel) instead of 16-step chains.
-    // [A 0; B C]^-1 = [A^-1 0; -C^-1 B A^-1  C^-1]; blocks packed lower-triangular, idx(i, j) = i (i + 1) / 2 + j.
-    PGT(4);
-    extern __shared__ double s_dyn[];
-    double* sLb = s_dyn;
-    double* sWb = s_dyn + PG_NBLK * 36;
-    if (act) {
-        double* d = sLb + (bi * (bi + 1) / 2 + bj) * 36;
-        for (int e = 0; e < 36; ++e) d[e] = a[e];
-        if (bi == bj) {
-            double inv[36];
-#pragma unroll
-            for (int e = 0; e < 36; ++e) inv[e] = 0.0;
-#pragma unroll
-            for (int c2 = 0; c2 < 6; ++c2) inv[c2 * 6 + c2] = 1.0 / a[c2 * 6 + c2];
-#pragma unroll
-            for (int c2 = 0; c2 < 6; ++c2) {
-#pragma unroll
-                for (int r = 0; r < 6; ++r) if (r > c2) {
-                    double v = 0;
-#pragma unroll
-                    for (int s2 = 0; s2 < 6; ++s2) if (s2 >= c2 && s2 < r) v += a[r * 6 + s2] * inv[s2 * 6 + c2];
-                    inv[r * 6 + c2] = -v * inv[r * 6 + r];
-                }
-            }
-            double* dw = sWb + (bi * (bi + 1) / 2 + bj) * 36;
-            for (int e = 0; e < 36; ++e) dw[e] = inv[e];
-        }
-    }
-    __syncthreads();
-    PGT(5);
-    for (int h = 1; h < w; h <<= 1) {
-        // task = (off-diagonal block of an odd h-group, pair of rows): 8h blocks x 3 row pairs <= 192 tasks
-        const int ntask = 24 * h;
-        const int t = threadIdx.x;
-        const bool on = t < ntask;
-        int tbi = 0, tbj = 0, r0 = 0, gmid = 0;
-        if (on) {
-            const int b = t / 3; r0 = 2 * (t - 3 * b);
-            const int g = b / (h * h), rem = b - g * h * h;
-            gmid = (2 * g + 1) * h;
-            tbi = gmid + rem / h; tbj = 2 * g * h + rem % h;
-        }
-        const bool run = on && tbi < w;
-        double res[12];
-        if (run) {                                           // T = B A^-1 (rows r0, r0+1 of block (tbi, tbj))
-#pragma unroll
-            for (int e = 0; e < 12; ++e) res[e] = 0.0;
-            for (int k = tbj; k < gmid; ++k) {
-                const double* Lb = sLb + (tbi * (tbi + 1) / 2 + k) * 36 + r0 * 6;
-                const double* Wk = sWb + (k * (k + 1) / 2 + tbj) * 36;
-#pragma unroll
-                for (int s2 = 0; s2 < 6; ++s2) {
-                    const double l0 = Lb[s2], l1 = Lb[6 + s2];
-#pragma unroll
-                    for (int c2 = 0; c2 < 6; ++c2) { res[c2] += l0 * Wk[s2 * 6 + c2]; res[6 + c2] += l1 * Wk[s2 * 6 + c2]; }
-                }
-            }
-            double* d = sWb + (tbi * (tbi + 1) / 2 + tbj) * 36 + r0 * 6;
-#pragma unroll
-            for (int e = 0; e < 12; ++e) d[e] = res[e];
-        }
-        __syncthreads();
-        if (run) {                                           // W_B = -C^-1 T
-#pragma unroll
-            for (int e = 0; e < 12; ++e) res[e] = 0.0;
-            for (int k = gmid; k <= tbi; ++k) {
-                const double* Wb = sWb + (tbi * (tbi + 1) / 2 + k) * 36 + r0 * 6;
-                const double* Tk = sWb + (k * (k + 1) / 2 + tbj) * 36;
-#pragma unroll
-                for (int s2 = 0; s2 < 6; ++s2) {
-                    const double l0 = Wb[s2], l1 = Wb[6 + s2];
-#pragma unroll
-                    for (int c2 = 0; c2 < 6; ++c2) { res[c2] -= l0 * Tk[s2 * 6 + c2]; res[6 + c2] -= l1 * Tk[s2 * 6 + c2]; }
-                }
+    if ((int)threadIdx.x < n) x[(size_t)(j0 + threadIdx.x / 6) * 6 + threadIdx.x % 6] = sy[threadIdx.x];
+    // ---- W = L11^-1: off-diagonal tiles by recursive doubling (the diagonal tiles V_t are in place)
+    for (int h = 1; h < nt; h <<= 1) {
+        {   int cnt = 0;                                        // T = B A^-1 into the target tiles
+            for (int g = 0; (2 * g + 1) * h < nt; ++g) {
+                const int gmid = (2 * g + 1) * h, iend = min(gmid + h, nt);
+                for (int i = gmid; i < iend; ++i)
+                    for (int j = 2 * g * h; j < gmid; ++j) {
+                        if ((cnt++ & 3) != wave) continue;
+                        pg_d4 acc = { 0.0, 0.0, 0.0, 0.0 };
+                        for (int k = j; k < gmid; ++k) {
+                            double fa[4], fb[4];
+                            pg_ld_a(sA, 16 * i, 16 * k, l, 1.0, fa);
+                            pg_ld_b(sW, 16 * k, 16 * j, l, fb);
+                            acc = pg_mma4(fa, fb, acc);
+                        }
+                        pg_st_c(sW, 16 * i, 16 * j, l, acc);
+                    }
             }
         }
         __syncthreads();
-        if (run) {
-            double* d = sWb + (tbi * (tbi + 1) / 2 + tbj) * 36 + r0 * 6;
-#pragma unroll
-            for (int e = 0; e < 12; ++e) d[e] = res[e];
+        pg_d4 r0 = { 0.0, 0.0, 0.0, 0.0 }, r1 = { 0.0, 0.0, 0.0, 0.0 };
+        int ti0 = -1, tj0 = 0, ti1 = -1, tj1 = 0;
+        {   int cnt = 0;                                        // W_B = -C^-1 T, kept in registers until every T is consumed
+            for (int g = 0; (2 * g + 1) * h < nt; ++g) {
+                const int gmid = (2 * g + 1) * h, iend = min(gmid + h, nt);
+                for (int i = gmid; i < iend; ++i)
+                    for (int j = 2 * g * h; j < gmid; ++j) {
+                        if ((cnt++ & 3) != wave) continue;
+                        pg_d4 acc = { 0.0, 0.0, 0.0, 0.0 };
+                        for (int k = gmid; k <= i; ++k) {
+                            double fa[4], fb[4];
+                            pg_ld_a(sW, 16 * i, 16 * k, l, -1.0, fa);
+                            pg_ld_b(sW, 16 * k, 16 * j, l, fb);
+                            acc = pg_mma4(fa, fb, acc);
+                        }
+                        if (ti0 < 0) { r0 = acc; ti0 = i; tj0 = j; } else { r1 = acc; ti1 = i; tj1 = j; }
+                    }
+            }
         }
         __syncthreads();
+        if (ti0 >= 0) pg_st_c(sW, 16 * ti0, 16 * tj0, l, r0);
+        if (ti1 >= 0) pg_st_c(sW, 16 * ti1, 16 * tj1, l, r1);
+        __syncthreads();
     }
-    PGT(6);
     // W out: row-major for the back-substitution, and in MFMA B-operand order for the row solve (tile nt = 16 output
     // columns, k-step ks = 4 k's: lane l holds W[16 nt + (l & 15)][4 ks + (l >> 4)]).  Thread (bi, bj) writes its block;
     // everything outside the lower block triangle of the first w block rows was zeroed once by the host and stays zero.
     if (act) {
         double* wr = Wrow + (size_t)p * (PG_PW * 6) * (PG_PW * 6);
         double* ws = Wsw + (size_t)p * (PG_PW * 6) * (PG_PW * 6);
-        const double* src = sWb + (bi * (bi + 1) / 2 + bj) * 36;
         int offc[6];
 #pragma unroll
         for (int c2 = 0; c2 < 6; ++c2) { const int kc = 6 * bj + c2; offc[c2] = (kc >> 2) * 64 + (kc & 3) * 16; }
@@ -652,20 +679,18 @@ __global__ __launch_bounds__(256) void pg_panel_diag_kernel(const int* __restric
             const int offr = (jr >> 4) * (24 * 64) + (jr & 15);
 #pragma unroll
             for (int c2 = 0; c2 < 6; ++c2) {
-                const double v = src[r * 6 + c2];
+                const double v = (bi == bj && c2 > r) ? 0.0 : sW[jr * PG_LD + 6 * bj + c2];
                 wr[(size_t)jr * (PG_PW * 6) + 6 * bj + c2] = v;
                 ws[offr + offc[c2]] = v;
             }
         }
     }
-    PGT(7);
 }
 
 // L21 = A21 W^T with W = L11^-1 from pg_panel_diag_kernel: a plain f64 GEMM on the matrix cores.  One wavefront per
 // 16 scalar rows: the 16 x 96 slab of A21 sits in 24 A-operand registers per lane (lane l: row l & 15, k = 4 ks + (l >> 4)),
 // W^T streams in as pre-swizzled B operands (one coalesced 512-byte load per v_mfma_f64_16x16x4_f64), and output tile nt
 // only runs the k-steps its triangular W reaches (4 nt + 4 of 24).
-typedef double pg_d4 __attribute__((ext_vector_type(4)));
 __global__ __launch_bounds__(256) void pg_panel_trsm_kernel(const int* __restrict__ plvpan, const int* __restrict__ pan_first, const int* __restrict__ pan_w,
                                                             const int* __restrict__ colptr, double* __restrict__ Lvals, const double* __restrict__ Wsw)
 {
@@ -1504,7 +1529,7 @@ static int pg_solve_impl(dsss_ctx* c, const double* dr6, int total, const dsss_l
                                                         d_mapptr, d_map, d_L, d_part2, stride, d_rlcol, d_x, d_tlim); }
                     if (nsl > 1) hipLaunchKernelGGL(pg_fold_kernel, dim3(ncl, lv_chunks[l]), dim3(256), 0, st, d_lvcols + S.lvptr[l], d_colptr, d_L, d_part2, nsl, stride, d_x);
                     { dsss_scope s3(c, DSSS_K_PG_DIAG, fl_diag[l]);
-                      hipLaunchKernelGGL(pg_panel_diag_kernel, dim3(npl), dim3(256), PG_DIAG_LDS, st, d_plvpan + S.plvptr[l], d_pan_first, d_pan_w, d_pan_lcol0, d_colptr, d_L, d_part2, 1, stride, d_x, d_fail, d_Wsw, d_Wrow); }
+                      hipLaunchKernelGGL(pg_panel_diag_kernel, dim3(npl), dim3(256), PG_DIAG_LDS, st, d_plvpan + S.plvptr[l], d_pan_first, d_pan_w, d_colptr, d_L, d_x, d_fail, d_Wsw, d_Wrow); }
                     dsss_scope s4(c, DSSS_K_PG_TRSM, plv_rowchunks[l] > 0 ? fl_trsm[l] : 0.0);
                     if (plv_rowchunks[l] > 0)
                         hipLaunchKernelGGL(pg_panel_trsm_kernel, dim3(npl, plv_rowchunks[l]), dim3(256), 0, st, d_plvpan + S.plvptr[l], d_pan_first, d_pan_w, d_colptr, d_L, d_Wsw);
@@ -1560,11 +1585,6 @@ static int pg_solve_impl(dsss_ctx* c, const double* dr6, int total, const dsss_l
     HCK(hipStreamSynchronize(st));
     if (stats4) { stats4[0] = iters; stats4[1] = err0; stats4[2] = err; stats4[3] = lambda; }
     dv.release();
-#ifdef PG_DIAG_TIMING
-    { unsigned long long h[16]; hipMemcpyFromSymbol(h, HIP_SYMBOL(pg_dbg), sizeof(h)); static const char* nm[8] = { "load", "factor", "solve", "update", "store", "inv6", "levels", "W out" };
-      for (int i = 0; i < 8; ++i) fprintf(stderr, "[pg diag timing] %-8s %.1f us total (block 0 of every launch)\n", nm[i], h[i] * 0.01);
-      memset(h, 0, sizeof(h)); hipMemcpyToSymbol(HIP_SYMBOL(pg_dbg), h, sizeof(h)); }
-#endif
     if (verbose) fprintf(stderr, "[dsss pg] LM iterations %d  factorisations %d  err %.6g -> %.6g | host prep %.1f ms, symbolic %.1f ms, alloc+upload %.1f ms, LM loop %.1f ms\n",
                          iters, nfact, err0, err, t_prep, t_sym, t_up, ms_since(T3));
 #undef TRY

@@ -1,5 +1,7 @@
+"""Wall-clock time of each stage of the hot path (frames, extract, match+LC, pose graph) with a device sync between
+stages; for use through gpurun:  python tools/stage_times.py C3"""
 import sys, time, os
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from diasss_amd.pipeline import Pipeline
 from diasss_amd.synth import Survey
@@ -9,7 +11,7 @@ sv = Survey(F, N, M, seed=20240601, device="cuda:0")
 raws = [sv.frame(f) for f in range(F)]
 poses = [sv.inputs(f)[0] for f in range(F)]; alts = [sv.inputs(f)[1] for f in range(F)]; grs = [sv.inputs(f)[2] for f in range(F)]
 pipe = Pipeline(F)
-for it in range(2):
+for it in range(3):
     torch.cuda.synchronize(); t0 = time.perf_counter()
     pipe.set_frames(raws, poses, alts, grs); pipe.ctx.sync(); t1 = time.perf_counter()
     pipe.extract(); pipe.ctx.sync(); t2 = time.perf_counter()
