@@ -370,17 +370,17 @@ __global__ __launch_bounds__(256) void pg_factor_acc_kernel(const int* __restric
                                                             const int* __restrict__ rlptr, const int* __restrict__ rlpos,
                                                             const long long* __restrict__ mapptr, const int* __restrict__ upd_map,
                                                             double* __restrict__ Lvals, double* __restrict__ part, int col_stride,
-                                                            const int* __restrict__ rlcol, double* __restrict__ x, const int* __restrict__ tlim)
+                                                            const int* __restrict__ rlcol, double* __restrict__ x, const int* __restrict__ tbeg, const int* __restrict__ tend)
 {
     __shared__ double s_Ljk[PG_TCH * 36];
     __shared__ double s_yk[PG_TCH * 6];
     const int j = lvcols[blockIdx.x];
     const int c0 = colptr[j], m = colptr[j + 1] - c0;
     if ((int)blockIdx.y * 256 >= 6 * m) return;
-    const int t0 = rlptr[j], T = tlim[j];                  // updates from outside the column's own panel
+    const int t0 = rlptr[j], Tb = tbeg ? tbeg[j] : 0, T = tend[j] - Tb;   // this launch's share of the updates from outside the column's own panel
     const int nsl = gridDim.z, sl = blockIdx.z;
     const int per = (T + nsl - 1) / nsl;
-    const int ta = sl * per, tb = min(T, ta + per);
+    const int ta = Tb + sl * per, tb = min(Tb + T, ta + per);
     const int* mp = upd_map + mapptr[j];
     const int idx = blockIdx.y * 256 + threadIdx.x;
     const bool act = idx < 6 * m;
@@ -1070,7 +1070,7 @@ struct sym_t {
     int ns = 0;
     std::vector<int> perm;                 // chain-order separator -> elimination index
     std::vector<int> colptr, rowidx, rlptr, rlcol, rlpos, rlrow, lvptr, lvcols, diag_pos, ch_pos, lc_pos, binptr, bincols;
-    std::vector<int> pan_first, pan_w, pan_lcol0, plvptr, plvpan, tlim;       // panels of the top part, panel levels
+    std::vector<int> pan_first, pan_w, pan_lcol0, plvptr, plvpan, tlim, tfar; // panels of the top part, panel levels
     std::vector<long long> mapptr;
 };
 
@@ -1299,6 +1299,27 @@ void symbolic(int ns, const std::vector<std::pair<int, int>>& edges, int nchain,
         const int lim = col_pan[j] >= 0 ? S.pan_first[col_pan[j]] : j;
         S.tlim[j] = (int)(std::lower_bound(S.rlcol.begin() + S.rlptr[j], S.rlcol.begin() + S.rlptr[j + 1], lim) - (S.rlcol.begin() + S.rlptr[j]));
     }
+    // look-ahead split of the external updates of every top column (panel level l): "far" sources were finished two
+    // or more levels ago (or in the subtree bins) and are accumulated on a second stream while level l-1 is still
+    // being factorised; "near" sources are the panels of level l-1.  The list is reordered [far | near | own panel].
+    S.tfar.assign(ns, 0);
+    {
+        std::vector<std::pair<int, int>> nearv;
+        for (int j = 0; j < ns; ++j) {
+            if (col_pan[j] < 0) continue;
+            const int lj = plevel[col_pan[j]], b0 = S.rlptr[j], T = S.tlim[j];
+            nearv.clear();
+            int wpos = b0;
+            for (int t = b0; t < b0 + T; ++t) {
+                const int k = S.rlcol[t];
+                const bool isnear = col_pan[k] >= 0 && plevel[col_pan[k]] == lj - 1;
+                if (isnear) nearv.push_back({ k, S.rlpos[t] });
+                else { S.rlcol[wpos] = k; S.rlpos[wpos] = S.rlpos[t]; ++wpos; }
+            }
+            S.tfar[j] = wpos - b0;
+            for (auto& e : nearv) { S.rlcol[wpos] = e.first; S.rlpos[wpos] = e.second; ++wpos; }
+        }
+    }
     const auto q4 = tnow();
     // where the assembled blocks go
     auto find = [&](int row, int col) { const auto b = S.rowidx.begin() + S.colptr[col], e = S.rowidx.begin() + S.colptr[col + 1];
@@ -1322,7 +1343,9 @@ struct pg_dev {
     std::vector<void*> allocs;
     template <typename T> int alloc(dsss_ctx* c, T** p, size_t n) { void* q = nullptr; HIPCHK(c, hipMalloc(&q, std::max<size_t>(n, 1) * sizeof(T))); allocs.push_back(q); *p = (T*)q; return DSSS_OK; }
     template <typename T> int upload(dsss_ctx* c, T** p, const std::vector<T>& v) { int rc = alloc(c, p, v.size()); if (rc) return rc; if (!v.empty()) HIPCHK(c, hipMemcpy(*p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice)); return DSSS_OK; }
-    void release() { for (void* q : allocs) hipFree(q); allocs.clear(); }
+    std::vector<hipEvent_t> events;
+    hipEvent_t event() { hipEvent_t e = nullptr; hipEventCreateWithFlags(&e, hipEventDisableTiming); events.push_back(e); return e; }
+    void release() { for (void* q : allocs) hipFree(q); allocs.clear(); for (hipEvent_t e : events) if (e) hipEventDestroy(e); events.clear(); }
 };
 
 } // namespace
@@ -1380,19 +1403,19 @@ static int pg_solve_impl(dsss_ctx* c, const double* dr6, int total, const dsss_l
     const auto T2 = std::chrono::steady_clock::now();
     const int nlev = (int)S.lvptr.size() - 1;
     const size_t nnzL = S.rowidx.size();
-    std::vector<int> lv_chunks(nlev, 1), lv_upd(nlev, 0), lv_slices(nlev, 1);
+    std::vector<int> lv_chunks(nlev, 1), lv_far(nlev, 0), lv_near(nlev, 0), lv_slices(nlev, 1);
     size_t part2_doubles = 1;
     for (int l = 0; l < nlev; ++l) {
-        int maxT = 0;
+        int maxF = 0, maxN = 0;
         for (int q = S.lvptr[l]; q < S.lvptr[l + 1]; ++q) {
             const int j = S.lvcols[q];
             lv_chunks[l] = std::max(lv_chunks[l], (6 * (S.colptr[j + 1] - S.colptr[j]) + 255) / 256);
-            maxT = std::max(maxT, S.tlim[j]);
+            maxF = std::max(maxF, S.tfar[j]); maxN = std::max(maxN, S.tlim[j] - S.tfar[j]);
         }
-        lv_upd[l] = maxT > 0;
+        lv_far[l] = maxF > 0; lv_near[l] = maxN > 0;
         const int ncl = S.lvptr[l + 1] - S.lvptr[l];
-        // few wide columns near the root: slice their update lists over more workgroups
-        if (ncl <= 256 && maxT > 48) lv_slices[l] = std::min(ncl <= 64 ? 16 : 4, (maxT + 31) / 32);
+        // few wide columns near the root: slice their (far) update lists over more workgroups
+        if (ncl <= 256 && maxF > 48) lv_slices[l] = std::min(ncl <= 64 ? 16 : 4, (maxF + 31) / 32);
         if (lv_slices[l] > 1) part2_doubles = std::max(part2_doubles, (size_t)ncl * lv_slices[l] * ((size_t)lv_chunks[l] * 256 * 6 + 8));
     }
     const bool verbose = getenv("DSSS_PG_VERBOSE") != nullptr;
@@ -1443,7 +1466,8 @@ static int pg_solve_impl(dsss_ctx* c, const double* dr6, int total, const dsss_l
         }
     const long long mapsz = S.mapptr[ns];
     if (mapsz > (1LL << 31)) { dv.release(); DSSS_FAIL(c, DSSS_E_CAPACITY, "update map of %lld entries", mapsz); }
-    TRY(dv.alloc(c, &d_map, (size_t)mapsz)); TRY(dv.alloc(c, &d_part2, part2_doubles));
+    TRY(dv.alloc(c, &d_map, (size_t)mapsz)); TRY(dv.alloc(c, &d_part2, 2 * part2_doubles));
+    int* d_tfar; TRY(dv.upload(c, &d_tfar, S.tfar));
     double *d_Wsw, *d_Wrow;      // per panel: W = L11^-1 (96 x 96, zero padded) in MFMA operand order and row-major
     { const size_t npan = S.pan_first.size(); const size_t wn = npan * (PG_PW * 6) * (PG_PW * 6); TRY(dv.alloc(c, &d_Wsw, wn)); TRY(dv.alloc(c, &d_Wrow, wn));
       HIPCHK(c, hipMemsetAsync(d_Wsw, 0, wn * sizeof(double), c->stream)); HIPCHK(c, hipMemsetAsync(d_Wrow, 0, wn * sizeof(double), c->stream)); }
@@ -1457,6 +1481,8 @@ static int pg_solve_impl(dsss_ctx* c, const double* dr6, int total, const dsss_l
         }
     }
     hipStream_t st = c->stream;
+    const bool no_ahead = getenv("DSSS_PG_NO_LOOKAHEAD") != nullptr;
+    hipEvent_t ev_bins = dv.event(), ev_far[2] = { dv.event(), dv.event() }, ev_trsm[2] = { dv.event(), dv.event() };
 #define HCK(x) do { hipError_t _e = (x); if (_e != hipSuccess) { c->err = std::string(#x) + ": " + hipGetErrorString(_e); dv.release(); return DSSS_E_HIP; } } while (0)
     auto error_of = [&](const pose_t* Xd, double* out) -> int {
         hipLaunchKernelGGL(pg_linearize_kernel, dim3(nblk), dim3(256), 0, st, n, ne, Xd, d_meas, W, d_ea, d_eb, d_emeas, d_ew, (double*)nullptr, (double*)nullptr, d_part);
@@ -1520,19 +1546,39 @@ static int pg_solve_impl(dsss_ctx* c, const double* dr6, int total, const dsss_l
                 if (ne > 0) hipLaunchKernelGGL(pg_scatter_lc_kernel, dim3((ne + 255) / 256), dim3(256), 0, st, n, ne, d_Ji, d_ew, d_lc, d_L);
                 if (nbins > 0) { dsss_scope s1(c, DSSS_K_PG_SUBTREE);
                                  hipLaunchKernelGGL(pg_factor_subtree_kernel, dim3(nbins), dim3(256), 0, st, d_binptr, d_bincols, d_colptr, d_rlptr, d_rlcol, d_rlpos, d_mapptr, d_map, d_L, d_x, d_fail); }
-                for (int l = 0; l < nlev; ++l) {      // top of the tree: panel levels, forward substitution fused in
+                // top of the tree: panel levels, forward substitution fused in.  Look-ahead: the far updates of level l
+                // (sources finished by level l-2) run on the side stream while level l-1 is being factorised; the
+                // main stream adds the near updates (level l-1) once its row solve is done.  Partial-sum buffers alternate.
+                const bool ahead = !c->prof.on && !no_ahead;
+                hipStream_t sf = ahead ? c->xs[0] : st;
+                auto launch_far = [&](int l) {
+                    if (!lv_far[l]) return;
+                    const int ncl = S.lvptr[l + 1] - S.lvptr[l], stride = lv_chunks[l] * 256 * 6 + 8;
+                    if (ahead) hipStreamWaitEvent(sf, l >= 2 ? ev_trsm[(l - 2) & 1] : ev_bins, 0);
+                    hipLaunchKernelGGL(pg_factor_acc_kernel, dim3(ncl, lv_chunks[l], lv_slices[l]), dim3(256), 0, sf, d_lvcols + S.lvptr[l], d_colptr, d_rlptr, d_rlpos,
+                                       d_mapptr, d_map, d_L, d_part2 + (size_t)(l & 1) * part2_doubles, stride, d_rlcol, d_x, (const int*)nullptr, d_tfar);
+                    if (ahead) hipEventRecord(ev_far[l & 1], sf);
+                };
+                if (ahead && nlev > 0) { hipEventRecord(ev_bins, st); launch_far(0); if (nlev > 1) launch_far(1); }
+                for (int l = 0; l < nlev; ++l) {
                     const int ncl = S.lvptr[l + 1] - S.lvptr[l], npl = S.plvptr[l + 1] - S.plvptr[l];
                     const int stride = lv_chunks[l] * 256 * 6 + 8;
-                    const int nsl = lv_upd[l] ? lv_slices[l] : 1;
-                    if (lv_upd[l]) { dsss_scope s2(c, DSSS_K_PG_ACC, fl_acc[l]);
-                                     hipLaunchKernelGGL(pg_factor_acc_kernel, dim3(ncl, lv_chunks[l], lv_slices[l]), dim3(256), 0, st, d_lvcols + S.lvptr[l], d_colptr, d_rlptr, d_rlpos,
-                                                        d_mapptr, d_map, d_L, d_part2, stride, d_rlcol, d_x, d_tlim); }
-                    if (nsl > 1) hipLaunchKernelGGL(pg_fold_kernel, dim3(ncl, lv_chunks[l]), dim3(256), 0, st, d_lvcols + S.lvptr[l], d_colptr, d_L, d_part2, nsl, stride, d_x);
+                    const int nsl = lv_far[l] ? lv_slices[l] : 1;
+                    {   dsss_scope s2(c, DSSS_K_PG_ACC, fl_acc[l]);
+                        if (!ahead) launch_far(l);
+                        else if (lv_far[l]) hipStreamWaitEvent(st, ev_far[l & 1], 0);
+                        if (lv_near[l])
+                            hipLaunchKernelGGL(pg_factor_acc_kernel, dim3(ncl, lv_chunks[l], 1), dim3(256), 0, st, d_lvcols + S.lvptr[l], d_colptr, d_rlptr, d_rlpos,
+                                               d_mapptr, d_map, d_L, d_part2, stride, d_rlcol, d_x, d_tfar, d_tlim);
+                    }
+                    if (nsl > 1) hipLaunchKernelGGL(pg_fold_kernel, dim3(ncl, lv_chunks[l]), dim3(256), 0, st, d_lvcols + S.lvptr[l], d_colptr, d_L, d_part2 + (size_t)(l & 1) * part2_doubles, nsl, stride, d_x);
                     { dsss_scope s3(c, DSSS_K_PG_DIAG, fl_diag[l]);
                       hipLaunchKernelGGL(pg_panel_diag_kernel, dim3(npl), dim3(256), PG_DIAG_LDS, st, d_plvpan + S.plvptr[l], d_pan_first, d_pan_w, d_colptr, d_L, d_x, d_fail, d_Wsw, d_Wrow); }
-                    dsss_scope s4(c, DSSS_K_PG_TRSM, plv_rowchunks[l] > 0 ? fl_trsm[l] : 0.0);
-                    if (plv_rowchunks[l] > 0)
-                        hipLaunchKernelGGL(pg_panel_trsm_kernel, dim3(npl, plv_rowchunks[l]), dim3(256), 0, st, d_plvpan + S.plvptr[l], d_pan_first, d_pan_w, d_colptr, d_L, d_Wsw);
+                    {   dsss_scope s4(c, DSSS_K_PG_TRSM, plv_rowchunks[l] > 0 ? fl_trsm[l] : 0.0);
+                        if (plv_rowchunks[l] > 0)
+                            hipLaunchKernelGGL(pg_panel_trsm_kernel, dim3(npl, plv_rowchunks[l]), dim3(256), 0, st, d_plvpan + S.plvptr[l], d_pan_first, d_pan_w, d_colptr, d_L, d_Wsw);
+                    }
+                    if (ahead && l + 2 < nlev) { hipEventRecord(ev_trsm[l & 1], st); launch_far(l + 2); }
                 }
                 for (int l = nlev - 1; l >= 0; --l) {
                     dsss_scope s5(c, DSSS_K_PG_BWD, fl_bwd[l]);
