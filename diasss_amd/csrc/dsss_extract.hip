@@ -21,6 +21,22 @@ int dsss_quadtree_cull(const float* xs, const float* ys, const float* resp, int 
 #define CELL_STRIDE 68
 #define CELL_CAP 1024          // strict 8-neighbour local maxima in 60 x 60 <= 30 x 30
 
+// ------------------------------------------------------------------ batch table
+// Every stage is ONE launch for a whole batch of frames: blockIdx.y (or .z) is the slot, and this per-slot record
+// (uploaded once per batch) carries the frame's buffers and sizes.  Frames of different sizes share a launch; the
+// grid is sized for the largest and the rest exit early.
+struct fast_cell { int level, x0, y0, w, h, offx, offy, pad; };
+struct ex_frame {
+    const double* raw; int N, M;
+    double* rowsum; double* rowmin; double* stats;
+    uint8_t* mask; uint8_t* lvl[DSSS_MAX_LEVELS]; int rows[DSSS_MAX_LEVELS], cols[DSSS_MAX_LEVELS]; int nlevels;
+    const fast_cell* cells; int ncells, cell_cap;
+    uint32_t* cand; int* counts; int* offs; float* xs; float* ys; float* rs; int cand_cap;
+    const qt_kp_in* kin; const int* nk; const int* lrows; const float* lscale; dsss_kp* kptmp; uint8_t* dtmp;
+    const double* pose6; const double* gr;
+    dsss_kp* kout; uint8_t* dout; double* geo; int* count;
+};
+
 // ------------------------------------------------------------------ K1: mean / min, normalise, mask
 // Row sums in the fixed order of oracle/orc_frame.c:fixed_sum (128 strided partials -> lane pairs -> xor
 // butterfly) so that 2.5*mean is reproducible bit for bit.  One wave per ping, 16-byte loads.
@@ -32,9 +48,11 @@ __device__ inline double wave_fixed_sum_tail(double p0, double p1)
     return v;
 }
 
-__global__ __launch_bounds__(256) void row_reduce_kernel(const double* __restrict__ raw, int N, int M,
-                                                         double* __restrict__ rowsum, double* __restrict__ rowmin)
+__global__ __launch_bounds__(256) void row_reduce_kernel(const ex_frame* __restrict__ frs)
 {
+    const ex_frame& f = frs[blockIdx.y];
+    const double* __restrict__ raw = f.raw; const int N = f.N, M = f.M;
+    double* __restrict__ rowsum = f.rowsum; double* __restrict__ rowmin = f.rowmin;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (row >= N) return;
     const double* r = raw + (size_t)row * M;
@@ -53,9 +71,11 @@ __global__ __launch_bounds__(256) void row_reduce_kernel(const double* __restric
 }
 
 // stats[0] = mean, stats[1] = min, stats[2] = 2.5*mean (normalisation ceiling), stats[3] = mask threshold
-__global__ __launch_bounds__(64) void final_reduce_kernel(const double* __restrict__ rowsum, const double* __restrict__ rowmin,
-                                                          int N, int M, double mask_factor, double* __restrict__ stats)
+__global__ __launch_bounds__(64) void final_reduce_kernel(const ex_frame* __restrict__ frs, double mask_factor)
 {
+    const ex_frame& f = frs[blockIdx.x];
+    const double* __restrict__ rowsum = f.rowsum; const double* __restrict__ rowmin = f.rowmin; double* __restrict__ stats = f.stats;
+    const int N = f.N, M = f.M;
     const int lane = threadIdx.x;
     double p0 = 0.0, p1 = 0.0, mn = INFINITY;
     for (int j = 2 * lane; j < N; j += 128) {
@@ -72,8 +92,10 @@ __global__ __launch_bounds__(64) void final_reduce_kernel(const double* __restri
 }
 
 // static part of Frame::GetFilteredMask (frame.cpp:104-112)
-__global__ void mask_init_kernel(uint8_t* __restrict__ mask, int N, int M, int width, int side, double sidec)
+__global__ void mask_init_kernel(const ex_frame* __restrict__ frs, int width, int side, double sidec)
 {
+    const ex_frame& f = frs[blockIdx.y];
+    uint8_t* __restrict__ mask = f.mask; const int N = f.N, M = f.M;
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (size_t)N * M) return;
     const int r = (int)(i / M), c = (int)(i % M);
@@ -84,10 +106,11 @@ __global__ void mask_init_kernel(uint8_t* __restrict__ mask, int N, int M, int w
 
 // Frame::GetNormalizeSSS (frame.cpp:67-78) + the hot-pixel eraser of GetFilteredMask (:98-103).
 // 4 pixels per thread: 2 x 16-byte loads, one 4-byte store.  Erasures only ever write 0, so the scatter is race free.
-__global__ __launch_bounds__(256) void normalize_kernel(const double* __restrict__ raw, int N, int M,
-                                                        const double* __restrict__ stats, int er,
-                                                        uint8_t* __restrict__ norm, uint8_t* __restrict__ mask)
+__global__ __launch_bounds__(256) void normalize_kernel(const ex_frame* __restrict__ frs, int er)
 {
+    const ex_frame& f = frs[blockIdx.y];
+    const double* __restrict__ raw = f.raw; const int N = f.N, M = f.M;
+    const double* __restrict__ stats = f.stats; uint8_t* __restrict__ norm = f.lvl[0]; uint8_t* __restrict__ mask = f.mask;
     const size_t total = (size_t)N * M;
     const size_t i0 = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
     if (i0 >= total) return;
@@ -121,11 +144,15 @@ __global__ __launch_bounds__(256) void normalize_kernel(const double* __restrict
 // (ORBextractor.cpp:1128).  11-bit fixed point exactly as OpenCV's scalar path: see oracle/orc_orb.c.
 __device__ inline int cvfloorf_dev(float v) { const int i = (int)v; return i - (v < (float)i); }
 
-__global__ __launch_bounds__(256) void resize_kernel(const uint8_t* __restrict__ src, int sh, int sw,
-                                                     uint8_t* __restrict__ dst, int dh, int dw, double scale_x, double scale_y)
+__global__ __launch_bounds__(256) void resize_kernel(const ex_frame* __restrict__ frs, int level)
 {
+    const ex_frame& f = frs[blockIdx.z];
+    if (level >= f.nlevels) return;
+    const uint8_t* __restrict__ src = f.lvl[level - 1]; uint8_t* __restrict__ dst = f.lvl[level];
+    const int sh = f.rows[level - 1], sw = f.cols[level - 1], dh = f.rows[level], dw = f.cols[level];
     const int dx = blockIdx.x * blockDim.x + threadIdx.x, dy = blockIdx.y;
     if (dx >= dw || dy >= dh) return;
+    const double scale_x = 1. / ((double)dw / sw), scale_y = 1. / ((double)dh / sh);        // cv::resize: inv_scale = dsize / ssize
     float fx = (float)((dx + 0.5) * scale_x - 0.5);
     int sx = cvfloorf_dev(fx);
     fx -= sx;
@@ -148,7 +175,6 @@ __global__ __launch_bounds__(256) void resize_kernel(const uint8_t* __restrict__
 }
 
 // ------------------------------------------------------------------ K3: cv::FAST 9/16 per 30-px cell
-struct fast_cell { int level, x0, y0, w, h, offx, offy, pad; };
 struct level_tab { const uint8_t* img[DSSS_MAX_LEVELS]; int cols[DSSS_MAX_LEVELS]; };
 
 __constant__ int c_ring_dx[16] = { 0, 1, 2, 3, 3, 3, 2, 1, 0, -1, -2, -3, -3, -3, -2, -1 };
@@ -204,16 +230,18 @@ __device__ inline int block_scan_excl256(int v, int* total, int* s_w)
 
 // one block per cell window (ORBextractor.cpp:789-816): FAST at iniThFAST, retried at minThFAST if the cell is
 // empty, non-max suppression inside the window only, keypoints emitted row-major.
-__global__ __launch_bounds__(256) void fast_cells_kernel(const fast_cell* __restrict__ cells, level_tab lv,
-                                                         int ini_th, int min_th, uint32_t* __restrict__ cand, int* __restrict__ counts, int cell_cap)
+__global__ __launch_bounds__(256) void fast_cells_kernel(const ex_frame* __restrict__ frs, int ini_th, int min_th)
 {
     __shared__ uint8_t win[CELL_MAX * CELL_STRIDE];
     __shared__ uint8_t A[CELL_MAX * CELL_STRIDE];
     __shared__ int s_w[4];
     __shared__ int s_n12;
-    const fast_cell c = cells[blockIdx.x];
-    const uint8_t* img = lv.img[c.level];
-    const int cols = lv.cols[c.level];
+    const ex_frame& f = frs[blockIdx.y];
+    if ((int)blockIdx.x >= f.ncells) return;
+    uint32_t* __restrict__ cand = f.cand; int* __restrict__ counts = f.counts; const int cell_cap = f.cell_cap;
+    const fast_cell c = f.cells[blockIdx.x];
+    const uint8_t* img = f.lvl[c.level];
+    const int cols = f.cols[c.level];
     for (int t = threadIdx.x; t < c.w * c.h; t += 256) {
         const int y = t / c.w, x = t - y * c.w;
         win[y * CELL_STRIDE + x] = img[(size_t)(c.y0 + y) * cols + (c.x0 + x)];
@@ -262,8 +290,10 @@ __global__ __launch_bounds__(256) void fast_cells_kernel(const fast_cell* __rest
     if (threadIdx.x == 0) counts[blockIdx.x] = base < cell_cap ? base : cell_cap;
 }
 
-__global__ __launch_bounds__(256) void scan_counts_kernel(const int* __restrict__ counts, int n, int* __restrict__ offs)
+__global__ __launch_bounds__(256) void scan_counts_kernel(const ex_frame* __restrict__ frs)
 {
+    const ex_frame& f = frs[blockIdx.x];
+    const int* __restrict__ counts = f.counts; int* __restrict__ offs = f.offs; const int n = f.ncells;
     __shared__ int s_w[4];
     int base = 0;
     for (int c0 = 0; c0 < n; c0 += 256) {
@@ -278,11 +308,13 @@ __global__ __launch_bounds__(256) void scan_counts_kernel(const int* __restrict_
 }
 
 // candidates in reference order with the cell offset applied (ORBextractor.cpp:820-825)
-__global__ __launch_bounds__(64) void gather_cand_kernel(const fast_cell* __restrict__ cells, const uint32_t* __restrict__ cand,
-                                                         const int* __restrict__ counts, const int* __restrict__ offs,
-                                                         float* __restrict__ xs, float* __restrict__ ys, float* __restrict__ rs, int cap, int cell_cap)
+__global__ __launch_bounds__(64) void gather_cand_kernel(const ex_frame* __restrict__ frs)
 {
-    const fast_cell c = cells[blockIdx.x];
+    const ex_frame& f = frs[blockIdx.y];
+    if ((int)blockIdx.x >= f.ncells) return;
+    const uint32_t* __restrict__ cand = f.cand; const int* __restrict__ counts = f.counts; const int* __restrict__ offs = f.offs;
+    float* __restrict__ xs = f.xs; float* __restrict__ ys = f.ys; float* __restrict__ rs = f.rs; const int cap = f.cand_cap, cell_cap = f.cell_cap;
+    const fast_cell c = f.cells[blockIdx.x];
     const int n = counts[blockIdx.x], o = offs[blockIdx.x];
     for (int q = threadIdx.x; q < n; q += 64) {
         if (o + q >= cap) return;
@@ -333,22 +365,23 @@ __device__ inline int reflect101_dev(int p, int len)
 
 // one wave per keypoint, four keypoints per block.  The Gaussian blur of the level clone (ORBextractor.cpp:1091-1092)
 // is evaluated only on the 37 x 37 patch the rotated pattern can reach, from a 49 x 49 LDS tile of the level image.
-__global__ __launch_bounds__(256) void orient_desc_kernel(const kp_in* __restrict__ kin, const int* __restrict__ n_ptr, level_tab lv,
-                                                          const int* __restrict__ lrows, const float* __restrict__ lscale,
-                                                          dsss_kp* __restrict__ kp_out, uint8_t* __restrict__ desc_out)
+__global__ __launch_bounds__(256) void orient_desc_kernel(const ex_frame* __restrict__ frs)
 {
     __shared__ uint8_t sP[4][PW * PS];
     __shared__ uint16_t sH[4][PW * BW];
     __shared__ uint8_t sB[4][BW * BS];
+    const ex_frame& f = frs[blockIdx.y];
+    const kp_in* __restrict__ kin = f.kin; const float* __restrict__ lscale = f.lscale;
+    dsss_kp* __restrict__ kp_out = f.kptmp; uint8_t* __restrict__ desc_out = f.dtmp;
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int k = blockIdx.x * 4 + wv;
-    const int n = *n_ptr;
+    const int n = *f.nk;
     if (blockIdx.x * 4 >= n) return;
     const bool act = k < n;
     kp_in in = act ? kin[k] : kin[0];
     const int L = in.level;
-    const uint8_t* img = lv.img[L];
-    const int cols = lv.cols[L], rows = lrows[L];
+    const uint8_t* img = f.lvl[L];
+    const int cols = f.cols[L], rows = f.lrows[L];
     const int cx = __float2int_rn(in.x), cy = __float2int_rn(in.y);
     uint8_t* P = sP[wv]; uint16_t* H = sH[wv]; uint8_t* B = sB[wv];
     if (act)
@@ -422,14 +455,15 @@ __global__ __launch_bounds__(256) void orient_desc_kernel(const kp_in* __restric
 
 // Frame::DetectFeature tail (frame.cpp:184-195): keep kp iff mask(int(y), int(x)) != 0, order preserved;
 // also samples the geo image for the survivors (FEAmatcher.cpp:81-82).
-__global__ __launch_bounds__(256) void mask_filter_kernel(const dsss_kp* __restrict__ kin, const uint8_t* __restrict__ din, const int* __restrict__ n_ptr,
-                                                          const uint8_t* __restrict__ mask, int M,
-                                                          const double* __restrict__ pose6, const double* __restrict__ gr,
-                                                          dsss_kp* __restrict__ kout, uint8_t* __restrict__ dout,
-                                                          double* __restrict__ geo, int* __restrict__ count)
+__global__ __launch_bounds__(256) void mask_filter_kernel(const ex_frame* __restrict__ frs)
 {
     __shared__ int s_w[4];
-    const int n = *n_ptr;
+    const ex_frame& f = frs[blockIdx.x];
+    const dsss_kp* __restrict__ kin = f.kptmp; const uint8_t* __restrict__ din = f.dtmp;
+    const uint8_t* __restrict__ mask = f.mask; const int M = f.M;
+    const double* __restrict__ pose6 = f.pose6; const double* __restrict__ gr = f.gr;
+    dsss_kp* __restrict__ kout = f.kout; uint8_t* __restrict__ dout = f.dout; double* __restrict__ geo = f.geo; int* __restrict__ count = f.count;
+    const int n = *f.nk;
     int base = 0;
     for (int c0 = 0; c0 < n; c0 += 256) {
         const int i = c0 + threadIdx.x;
@@ -599,8 +633,8 @@ static ex_layout make_layout(int N, const level_geom& g, int kcap)
 
 #define EX_BATCH 256
 
-// extraction of a list of frames, batched: per frame K1-K3 (+ candidate compaction), then ONE quadtree launch for the
-// whole batch (one workgroup per frame x level), then per frame K5-K7 + mask filter.  No host round trip per frame.
+// extraction of a list of frames, batched: every stage is one launch for the whole batch (the pyramid: one per level),
+// about twenty launches and one host synchronisation per batch of up to EX_BATCH frames.
 static int extract_frames(dsss_ctx* c, const int* ids, int n, bool keep_taps)
 {
     if (n <= 0) return DSSS_OK;
@@ -617,116 +651,109 @@ static int extract_frames(dsss_ctx* c, const int* ids, int n, bool keep_taps)
         slot_bytes = std::max(slot_bytes, Ls[i].total);
     }
     const int B = std::min(n, EX_BATCH);
-    const size_t tab_bytes = align_up(sizeof(qt_inst) * (size_t)B * DSSS_MAX_LEVELS, 256) + align_up(sizeof(qt_frame) * (size_t)B, 256);
+    const size_t inst_bytes = align_up(sizeof(qt_inst) * (size_t)B * DSSS_MAX_LEVELS, 256), qfr_bytes = align_up(sizeof(qt_frame) * (size_t)B, 256);
+    const size_t exf_bytes = align_up(sizeof(ex_frame) * (size_t)B, 256), err_bytes = align_up(sizeof(int) * (size_t)B, 256);
+    const size_t tab_bytes = inst_bytes + qfr_bytes + exf_bytes + err_bytes;
     const size_t need = slot_bytes * B + tab_bytes;
     if (c->ex_scratch_bytes < need) {
         HIPCHK(c, hipStreamSynchronize(c->stream)); hipFree(c->ex_scratch); c->ex_scratch = nullptr; c->ex_scratch_bytes = 0;
         HIPCHK(c, hipMalloc(&c->ex_scratch, need)); c->ex_scratch_bytes = need;
     }
-    const size_t pin_need = tab_bytes + sizeof(int) * 2 * (size_t)B + 64;
+    const size_t pin_need = tab_bytes + sizeof(int) * ((size_t)B + c->max_frames) + 64;
     if (c->ex_pinned_bytes < pin_need) {
         HIPCHK(c, hipStreamSynchronize(c->stream)); if (c->ex_pinned) hipHostFree(c->ex_pinned); c->ex_pinned = nullptr; c->ex_pinned_bytes = 0;
         HIPCHK(c, hipHostMalloc(&c->ex_pinned, pin_need, hipHostMallocDefault)); c->ex_pinned_bytes = pin_need;
     }
     char* S0 = (char*)c->ex_scratch;
-    qt_inst* d_inst = (qt_inst*)(S0 + slot_bytes * B);
-    qt_frame* d_fr = (qt_frame*)((char*)d_inst + align_up(sizeof(qt_inst) * (size_t)B * DSSS_MAX_LEVELS, 256));
-    qt_inst* h_inst = (qt_inst*)c->ex_pinned;
-    qt_frame* h_fr = (qt_frame*)((char*)h_inst + align_up(sizeof(qt_inst) * (size_t)B * DSSS_MAX_LEVELS, 256));
-    int* h_res = (int*)((char*)c->ex_pinned + tab_bytes);      // [B] nkp, [B] err
-    const hipStream_t main_st = c->stream;
-    const bool multi = !c->prof.on && n > 1;          // profiling times kernels on the main stream only
+    char* T0 = S0 + slot_bytes * B;                            // device tables: quadtree instances, quadtree frames, batch table, error flags
+    qt_inst* d_inst = (qt_inst*)T0;
+    qt_frame* d_fr = (qt_frame*)(T0 + inst_bytes);
+    ex_frame* d_exf = (ex_frame*)(T0 + inst_bytes + qfr_bytes);
+    int* d_errs = (int*)(T0 + inst_bytes + qfr_bytes + exf_bytes);
+    char* P0 = (char*)c->ex_pinned;                            // the same tables in pinned host memory, one upload per batch
+    qt_inst* h_inst = (qt_inst*)P0;
+    qt_frame* h_fr = (qt_frame*)(P0 + inst_bytes);
+    ex_frame* h_exf = (ex_frame*)(P0 + inst_bytes + qfr_bytes);
+    int* h_err = (int*)(P0 + tab_bytes);                       // [B] error flags, then [max_frames] keypoint counts
+    int* h_nkp = h_err + B;
+    const hipStream_t st = c->stream;
 
     for (int b0 = 0; b0 < n; b0 += B) {
         const int nb = std::min(B, n - b0);
-        int ninst = 0;
-        if (multi) { HIPCHK(c, hipEventRecord(c->xev_main, main_st)); for (int q = 0; q < 4; ++q) HIPCHK(c, hipStreamWaitEvent(c->xs[q], c->xev_main, 0)); }
+        int ninst = 0, maxN = 0, maxNM4 = 0, max_cells = 0, max_levels = 0;
+        size_t max_tot = 0;
+        int max_rows[DSSS_MAX_LEVELS] = { 0 }, max_cols[DSSS_MAX_LEVELS] = { 0 };
+        double w_tot = 0;
         for (int s = 0; s < nb; ++s) {
-            const hipStream_t st = multi ? c->xs[s & 3] : main_st;
             const int id = ids[b0 + s];
             dsss_frame& f = c->frames[id];
             const level_geom& g = *G[b0 + s];
             const ex_layout& L = Ls[b0 + s];
-            const int N = f.N, M = f.M, ncells = (int)g.cells.size();
             char* S = S0 + slot_bytes * s;
-            double* d_rowsum = (double*)(S + L.rowsum); double* d_rowmin = (double*)(S + L.rowmin); double* d_stats = (double*)(S + L.stats);
-            int* d_counts = (int*)(S + L.counts); int* d_offs = (int*)(S + L.offs); uint32_t* d_cand = (uint32_t*)(S + L.cand);
-            float* d_xs = (float*)(S + L.xs); float* d_ys = (float*)(S + L.ys); float* d_rs = (float*)(S + L.rs);
-            int* d_err = (int*)(S + L.err);
-            HIPCHK(c, hipMemsetAsync(d_err, 0, sizeof(int), st));
-            const size_t tot = (size_t)N * M;
-            { dsss_scope sc(c, DSSS_K_ROW_REDUCE, 8.0 * tot);
-              hipLaunchKernelGGL(row_reduce_kernel, dim3((N + 3) / 4), dim3(256), 0, st, f.raw, N, M, d_rowsum, d_rowmin); }
-            { dsss_scope sc(c, DSSS_K_PRE_MISC, 1.0 * tot);
-              hipLaunchKernelGGL(final_reduce_kernel, dim3(1), dim3(64), 0, st, d_rowsum, d_rowmin, N, M, (double)(float)c->mp.factor, d_stats);
-              hipLaunchKernelGGL(mask_init_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, f.mask, N, M, c->mp.width, c->mp.side, (double)c->mp.side * 0.6); }
-            { dsss_scope sc(c, DSSS_K_NORMALIZE, 9.0 * tot);
-              hipLaunchKernelGGL(normalize_kernel, dim3((unsigned)((tot / 4 + 256) / 256)), dim3(256), 0, st, f.raw, N, M, d_stats, c->mp.r, f.lvl[0], f.mask); }
-            level_tab lv;
-            for (int l = 0; l < DSSS_MAX_LEVELS; ++l) { lv.img[l] = l < g.nlevels ? f.lvl[l] : nullptr; lv.cols[l] = l < g.nlevels ? g.cols[l] : 0; }
-            { dsss_scope sc(c, DSSS_K_PYRAMID, (1.906 + 2.74) * tot);
-              for (int l = 1; l < g.nlevels; ++l) {
-                  const double sx = 1. / ((double)g.cols[l] / g.cols[l - 1]), sy = 1. / ((double)g.rows[l] / g.rows[l - 1]);
-                  hipLaunchKernelGGL(resize_kernel, dim3((g.cols[l] + 255) / 256, g.rows[l]), dim3(256), 0, st, f.lvl[l - 1], g.rows[l - 1], g.cols[l - 1],
-                                     f.lvl[l], g.rows[l], g.cols[l], sx, sy);
-              } }
-            { dsss_scope sc(c, DSSS_K_FAST, 2.906 * tot);
-              hipLaunchKernelGGL(fast_cells_kernel, dim3(ncells), dim3(256), 0, st, g.d_cells, lv, c->op.ini_th, c->op.min_th, d_cand, d_counts, g.cell_cap); }
-            { dsss_scope sc(c, DSSS_K_FAST_COMPACT);
-              hipLaunchKernelGGL(scan_counts_kernel, dim3(1), dim3(256), 0, st, d_counts, ncells, d_offs);
-              hipLaunchKernelGGL(gather_cand_kernel, dim3(ncells), dim3(64), 0, st, g.d_cells, d_cand, d_counts, d_offs, d_xs, d_ys, d_rs, L.cand_cap, g.cell_cap); }
-            HIPCHK(c, hipGetLastError());
+            ex_frame& e = h_exf[s];
+            e.raw = f.raw; e.N = f.N; e.M = f.M;
+            e.rowsum = (double*)(S + L.rowsum); e.rowmin = (double*)(S + L.rowmin); e.stats = (double*)(S + L.stats);
+            e.mask = f.mask; e.nlevels = g.nlevels;
+            for (int l = 0; l < DSSS_MAX_LEVELS; ++l) { e.lvl[l] = l < g.nlevels ? f.lvl[l] : nullptr; e.rows[l] = l < g.nlevels ? g.rows[l] : 0; e.cols[l] = l < g.nlevels ? g.cols[l] : 0; }
+            e.cells = g.d_cells; e.ncells = (int)g.cells.size(); e.cell_cap = g.cell_cap;
+            e.cand = (uint32_t*)(S + L.cand); e.counts = (int*)(S + L.counts); e.offs = (int*)(S + L.offs);
+            e.xs = (float*)(S + L.xs); e.ys = (float*)(S + L.ys); e.rs = (float*)(S + L.rs); e.cand_cap = L.cand_cap;
+            e.kin = (kp_in*)(S + L.kin); e.nk = (int*)(S + L.nk); e.lrows = g.d_lrows; e.lscale = g.d_lscale;
+            e.kptmp = (dsss_kp*)(S + L.kptmp); e.dtmp = (uint8_t*)(S + L.dtmp);
+            e.pose6 = f.pose6; e.gr = f.gr;
+            e.kout = c->kps + (size_t)id * c->kcap; e.dout = c->desc + (size_t)id * c->kcap * 32; e.geo = c->geo + (size_t)id * c->kcap * 2; e.count = c->nkp_dev + id;
+            maxN = std::max(maxN, f.N); max_tot = std::max(max_tot, (size_t)f.N * f.M); max_cells = std::max(max_cells, e.ncells); max_levels = std::max(max_levels, g.nlevels);
+            for (int l = 0; l < g.nlevels; ++l) { max_rows[l] = std::max(max_rows[l], g.rows[l]); max_cols[l] = std::max(max_cols[l], g.cols[l]); }
+            w_tot += (double)f.N * f.M;
             // quadtree descriptors
             for (int l = 0; l < g.nlevels; ++l) {
                 qt_inst& q = h_inst[ninst++];
-                q.offs = d_offs; q.cell_begin = g.cell_begin[l]; q.cell_end = g.cell_begin[l + 1];
-                q.xs = d_xs; q.ys = d_ys; q.rs = d_rs;
+                q.offs = e.offs; q.cell_begin = g.cell_begin[l]; q.cell_end = g.cell_begin[l + 1];
+                q.xs = e.xs; q.ys = e.ys; q.rs = e.rs;
                 q.W = (g.cols[l] - EDGE_T + 3) - (EDGE_T - 3); q.H = (g.rows[l] - EDGE_T + 3) - (EDGE_T - 3); q.quota = g.quota[l];
                 q.keys0 = (int*)(S + L.keys0); q.keys1 = (int*)(S + L.keys1); q.work = (int*)(S + L.work[l]);
                 q.list_cap = L.list_cap[l]; q.pool_cap = L.pool_cap[l];
                 q.out_idx = (int*)(S + L.out_idx) + (size_t)l * L.out_cap; q.out_n = (int*)(S + L.out_n) + l; q.out_cap = L.out_cap;
-                q.err = d_err;
+                q.err = d_errs + s;
             }
             qt_frame& qf = h_fr[s];
             qf.nlevels = g.nlevels; qf.out_cap = L.out_cap; qf.kcap = c->kcap; qf.min_border = EDGE_T - 3;
             qf.out_idx = (int*)(S + L.out_idx); qf.out_n = (int*)(S + L.out_n);
-            qf.xs = d_xs; qf.ys = d_ys; qf.rs = d_rs;
-            qf.kin = (kp_in*)(S + L.kin); qf.nk = (int*)(S + L.nk); qf.err = d_err;
+            qf.xs = e.xs; qf.ys = e.ys; qf.rs = e.rs;
+            qf.kin = (kp_in*)(S + L.kin); qf.nk = (int*)(S + L.nk); qf.err = d_errs + s;
         }
-        // K4 on the device for the whole batch (main stream, after every frame's FAST stage)
-        if (multi) for (int q = 0; q < 4; ++q) { HIPCHK(c, hipEventRecord(c->xev[q], c->xs[q])); HIPCHK(c, hipStreamWaitEvent(main_st, c->xev[q], 0)); }
-        HIPCHK(c, hipMemcpyAsync(d_inst, h_inst, sizeof(qt_inst) * ninst, hipMemcpyHostToDevice, main_st));
-        HIPCHK(c, hipMemcpyAsync(d_fr, h_fr, sizeof(qt_frame) * nb, hipMemcpyHostToDevice, main_st));
+        (void)maxNM4;
+        HIPCHK(c, hipMemcpyAsync(T0, P0, tab_bytes - err_bytes, hipMemcpyHostToDevice, st));
+        HIPCHK(c, hipMemsetAsync(d_errs, 0, sizeof(int) * nb, st));
+        { dsss_scope sc(c, DSSS_K_ROW_REDUCE, 8.0 * w_tot);
+          hipLaunchKernelGGL(row_reduce_kernel, dim3((maxN + 3) / 4, nb), dim3(256), 0, st, d_exf); }
+        { dsss_scope sc(c, DSSS_K_PRE_MISC, 1.0 * w_tot);
+          hipLaunchKernelGGL(final_reduce_kernel, dim3(nb), dim3(64), 0, st, d_exf, (double)(float)c->mp.factor);
+          hipLaunchKernelGGL(mask_init_kernel, dim3((unsigned)((max_tot + 255) / 256), nb), dim3(256), 0, st, d_exf, c->mp.width, c->mp.side, (double)c->mp.side * 0.6); }
+        { dsss_scope sc(c, DSSS_K_NORMALIZE, 9.0 * w_tot);
+          hipLaunchKernelGGL(normalize_kernel, dim3((unsigned)((max_tot / 4 + 256) / 256), nb), dim3(256), 0, st, d_exf, c->mp.r); }
+        { dsss_scope sc(c, DSSS_K_PYRAMID, (1.906 + 2.74) * w_tot);
+          for (int l = 1; l < max_levels; ++l)
+              hipLaunchKernelGGL(resize_kernel, dim3((max_cols[l] + 255) / 256, max_rows[l], nb), dim3(256), 0, st, d_exf, l); }
+        { dsss_scope sc(c, DSSS_K_FAST, 2.906 * w_tot);
+          hipLaunchKernelGGL(fast_cells_kernel, dim3(max_cells, nb), dim3(256), 0, st, d_exf, c->op.ini_th, c->op.min_th); }
+        { dsss_scope sc(c, DSSS_K_FAST_COMPACT);
+          hipLaunchKernelGGL(scan_counts_kernel, dim3(nb), dim3(256), 0, st, d_exf);
+          hipLaunchKernelGGL(gather_cand_kernel, dim3(max_cells, nb), dim3(64), 0, st, d_exf); }
         { dsss_scope sc(c, DSSS_K_QUADTREE);
-          dsss_launch_quadtree(main_st, d_inst, ninst, d_fr, nb); }
+          dsss_launch_quadtree(st, d_inst, ninst, d_fr, nb); }
+        { dsss_scope sc(c, DSSS_K_DESC, (double)nb * c->op.nfeatures * (49.0 * 49.0 + 56.0));
+          hipLaunchKernelGGL(orient_desc_kernel, dim3((c->kcap + 3) / 4, nb), dim3(256), 0, st, d_exf); }
+        { dsss_scope sc(c, DSSS_K_FILTER);
+          hipLaunchKernelGGL(mask_filter_kernel, dim3(nb), dim3(256), 0, st, d_exf); }
         HIPCHK(c, hipGetLastError());
-        if (multi) { HIPCHK(c, hipEventRecord(c->xev_main, main_st)); for (int q = 0; q < 4; ++q) HIPCHK(c, hipStreamWaitEvent(c->xs[q], c->xev_main, 0)); }
-        for (int s = 0; s < nb; ++s) {
-            const hipStream_t st = multi ? c->xs[s & 3] : main_st;
-            const int id = ids[b0 + s];
-            dsss_frame& f = c->frames[id];
-            const level_geom& g = *G[b0 + s];
-            const ex_layout& L = Ls[b0 + s];
-            char* S = S0 + slot_bytes * s;
-            level_tab lv;
-            for (int l = 0; l < DSSS_MAX_LEVELS; ++l) { lv.img[l] = l < g.nlevels ? f.lvl[l] : nullptr; lv.cols[l] = l < g.nlevels ? g.cols[l] : 0; }
-            kp_in* d_kin = (kp_in*)(S + L.kin); int* d_nk = (int*)(S + L.nk);
-            dsss_kp* d_kptmp = (dsss_kp*)(S + L.kptmp); uint8_t* d_dtmp = (uint8_t*)(S + L.dtmp);
-            { dsss_scope sc(c, DSSS_K_DESC, (double)c->op.nfeatures * (49.0 * 49.0 + 56.0));
-              hipLaunchKernelGGL(orient_desc_kernel, dim3((c->kcap + 3) / 4), dim3(256), 0, st, d_kin, d_nk, lv, g.d_lrows, g.d_lscale, d_kptmp, d_dtmp); }
-            { dsss_scope sc(c, DSSS_K_FILTER);
-              hipLaunchKernelGGL(mask_filter_kernel, dim3(1), dim3(256), 0, st, d_kptmp, d_dtmp, d_nk, f.mask, f.M, f.pose6, f.gr,
-                                 c->kps + (size_t)id * c->kcap, c->desc + (size_t)id * c->kcap * 32, c->geo + (size_t)id * c->kcap * 2, c->nkp_dev + id); }
-            HIPCHK(c, hipMemcpyAsync(&h_res[s], c->nkp_dev + id, sizeof(int), hipMemcpyDeviceToHost, st));
-            HIPCHK(c, hipMemcpyAsync(&h_res[B + s], (int*)(S + L.err), sizeof(int), hipMemcpyDeviceToHost, st));
-        }
-        HIPCHK(c, hipGetLastError());
-        if (multi) for (int q = 0; q < 4; ++q) { HIPCHK(c, hipEventRecord(c->xev[q], c->xs[q])); HIPCHK(c, hipStreamWaitEvent(main_st, c->xev[q], 0)); }
-        HIPCHK(c, hipStreamSynchronize(main_st));    // one synchronisation per batch of up to EX_BATCH frames
+        HIPCHK(c, hipMemcpyAsync(h_err, d_errs, sizeof(int) * nb, hipMemcpyDeviceToHost, st));
+        HIPCHK(c, hipMemcpyAsync(h_nkp, c->nkp_dev, sizeof(int) * c->max_frames, hipMemcpyDeviceToHost, st));
+        HIPCHK(c, hipStreamSynchronize(st));         // one synchronisation per batch of up to EX_BATCH frames
         for (int s = 0; s < nb; ++s) {
             dsss_frame& f = c->frames[ids[b0 + s]];
-            if (h_res[B + s]) DSSS_FAIL(c, DSSS_E_CAPACITY, "frame %d: device quadtree capacity exceeded (code %d)", ids[b0 + s], h_res[B + s]);
-            f.nkp = h_res[s]; f.has_feat = true; f.has_norm = true;
+            if (h_err[s]) DSSS_FAIL(c, DSSS_E_CAPACITY, "frame %d: device quadtree capacity exceeded (code %d)", ids[b0 + s], h_err[s]);
+            f.nkp = h_nkp[ids[b0 + s]]; f.has_feat = true; f.has_norm = true;
         }
         if (keep_taps) {                             // stage tap for the parity tests: FAST candidates per level
             for (int s = 0; s < nb; ++s) {
