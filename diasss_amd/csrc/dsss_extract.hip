@@ -181,34 +181,49 @@ __constant__ int c_ring_dx[16] = { 0, 1, 2, 3, 3, 3, 2, 1, 0, -1, -2, -3, -3, -3
 __constant__ int c_ring_dy[16] = { 3, 3, 2, 1, 0, -1, -2, -3, -3, -3, -2, -1, 0, 1, 2, 3 };
 
 // arc value A = max over the 16 arcs of 9 contiguous ring pixels of max(min(v - ring), min(ring - v));
-// corner at threshold t iff A > t, cornerScore = A - 1.  Values <= tmin are reported as 0 (never a corner, and
-// never able to suppress one), which lets the common smooth pixel leave after the opposite-pair test.
+// corner at threshold t iff A > t, cornerScore = A - 1.  Values <= tmin are reported as 0 (never a corner, and never
+// able to suppress one).  The differences are 9-bit, so two ring positions (k, k + 8) share one register and the
+// sliding min / max over 9 contiguous positions runs on packed 16-bit lanes (v_pk_min_i16 / v_pk_max_i16): windows of
+// 2, 4, 8 by doubling, then one more pixel.  Position k + 8 of a pair register is the other half of register k, so a
+// window that wraps past 15 is a half-swap.  (On speckled sonar imagery four pixels in five fail the usual
+// opposite-pair early exit at minThFAST, so there is none.)
+typedef short fast_v2 __attribute__((ext_vector_type(2)));
+__device__ inline fast_v2 fast_swap(fast_v2 a) { return __builtin_shufflevector(a, a, 1, 0); }
 __device__ inline int fast_arc(const uint8_t* w, int stride, int x, int y, int tmin)
 {
-    const int v = w[y * stride + x];
-    int d[16];
+    const short v = (short)w[y * stride + x];
+    const fast_v2 vv = { v, v };
+    fast_v2 P[16];                                   // P[j] = (d[j], d[j + 8]), j < 8; P[j + 8] = (d[j + 8], d[j])
 #pragma unroll
-    for (int k = 0; k < 16; ++k) d[k] = v - (int)w[(y + c_ring_dy[k]) * stride + (x + c_ring_dx[k])];
-    // every arc of 9 holds one pixel of each opposite pair: both inside [-tmin, tmin] => A <= tmin
-#pragma unroll
-    for (int k = 0; k < 8; ++k) if (abs(d[k]) <= tmin && abs(d[k + 8]) <= tmin) return 0;
-    // min / max over every window of 9 contiguous ring pixels by doubling: windows of 2, 4, 8, then one more pixel
-    int lo[16], hi[16];
-#pragma unroll
-    for (int k = 0; k < 16; ++k) { const int e = d[(k + 1) & 15]; lo[k] = d[k] < e ? d[k] : e; hi[k] = d[k] > e ? d[k] : e; }
-    int lo4[16], hi4[16];
-#pragma unroll
-    for (int k = 0; k < 16; ++k) { const int a = lo[(k + 2) & 15], b = hi[(k + 2) & 15]; lo4[k] = lo[k] < a ? lo[k] : a; hi4[k] = hi[k] > b ? hi[k] : b; }
-    int best = 0;
-#pragma unroll
-    for (int k = 0; k < 16; ++k) {
-        int mn = lo4[k] < lo4[(k + 4) & 15] ? lo4[k] : lo4[(k + 4) & 15];
-        int mx = hi4[k] > hi4[(k + 4) & 15] ? hi4[k] : hi4[(k + 4) & 15];
-        const int e = d[(k + 8) & 15];
-        mn = e < mn ? e : mn; mx = e > mx ? e : mx;
-        best = mn > best ? mn : best;
-        best = -mx > best ? -mx : best;
+    for (int j = 0; j < 8; ++j) {
+        const fast_v2 r = { (short)w[(y + c_ring_dy[j]) * stride + (x + c_ring_dx[j])], (short)w[(y + c_ring_dy[j + 8]) * stride + (x + c_ring_dx[j + 8])] };
+        P[j] = vv - r;
     }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) P[j + 8] = fast_swap(P[j]);
+    fast_v2 lo[12], hi[12];                          // windows of 2 starting at j (and j + 8)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { lo[j] = __builtin_elementwise_min(P[j], P[j + 1]); hi[j] = __builtin_elementwise_max(P[j], P[j + 1]); }
+#pragma unroll
+    for (int j = 8; j < 10; ++j) { lo[j] = fast_swap(lo[j - 8]); hi[j] = fast_swap(hi[j - 8]); }
+    fast_v2 lo4[12], hi4[12];                        // windows of 4
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { lo4[j] = __builtin_elementwise_min(lo[j], lo[j + 2]); hi4[j] = __builtin_elementwise_max(hi[j], hi[j + 2]); }
+#pragma unroll
+    for (int j = 8; j < 12; ++j) { lo4[j] = fast_swap(lo4[j - 8]); hi4[j] = fast_swap(hi4[j - 8]); }
+    fast_v2 bmin = { -32768, -32768 }, bmax = { 32767, 32767 };
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {                    // windows of 8, plus position j + 8 (= the other half of P[j])
+        fast_v2 mn = __builtin_elementwise_min(lo4[j], lo4[j + 4]);
+        fast_v2 mx = __builtin_elementwise_max(hi4[j], hi4[j + 4]);
+        mn = __builtin_elementwise_min(mn, P[j + 8]);
+        mx = __builtin_elementwise_max(mx, P[j + 8]);
+        bmin = __builtin_elementwise_max(bmin, mn);
+        bmax = __builtin_elementwise_min(bmax, mx);
+    }
+    int best = bmin.x > bmin.y ? bmin.x : bmin.y;
+    const int nb = bmax.x < bmax.y ? bmax.x : bmax.y;
+    best = -nb > best ? -nb : best;
     return best > tmin ? best : 0;
 }
 
@@ -242,8 +257,10 @@ __global__ __launch_bounds__(256) void fast_cells_kernel(const ex_frame* __restr
     const fast_cell c = f.cells[blockIdx.x];
     const uint8_t* img = f.lvl[c.level];
     const int cols = f.cols[c.level];
+    // t / d for t < 66 * 66 by multiplication: (t * ceil(2^20 / d)) >> 20 is exact while t * d < 2^20
+    const unsigned mg_w = ((1u << 20) + (unsigned)c.w - 1u) / (unsigned)c.w;
     for (int t = threadIdx.x; t < c.w * c.h; t += 256) {
-        const int y = t / c.w, x = t - y * c.w;
+        const int y = (int)(((unsigned)t * mg_w) >> 20), x = t - y * c.w;
         win[y * CELL_STRIDE + x] = img[(size_t)(c.y0 + y) * cols + (c.x0 + x)];
         A[y * CELL_STRIDE + x] = 0;
     }
@@ -252,15 +269,18 @@ __global__ __launch_bounds__(256) void fast_cells_kernel(const ex_frame* __restr
     const int ew = c.w - 6, eh = c.h - 6;
     const int ne = (ew > 0 && eh > 0) ? ew * eh : 0;
     const int tmin = ini_th < min_th ? ini_th : min_th;
+    const unsigned mg_e = ((1u << 20) + (unsigned)(ew > 0 ? ew : 1) - 1u) / (unsigned)(ew > 0 ? ew : 1);
     for (int t = threadIdx.x; t < ne; t += 256) {
-        const int y = 3 + t / ew, x = 3 + t % ew;
+        const int q = (int)(((unsigned)t * mg_e) >> 20);
+        const int y = 3 + q, x = 3 + t - q * ew;
         A[y * CELL_STRIDE + x] = (uint8_t)fast_arc(win, CELL_STRIDE, x, y, tmin);
     }
     __syncthreads();
     // strict 3x3 maxima; neighbours outside the evaluated range hold 0
     int mine[15]; int nm = 0, n12 = 0;
     for (int t = threadIdx.x; t < ne; t += 256, ++nm) {
-        const int y = 3 + t / ew, x = 3 + t % ew;
+        const int q = (int)(((unsigned)t * mg_e) >> 20);
+        const int y = 3 + q, x = 3 + t - q * ew;
         const int a = A[y * CELL_STRIDE + x];
         bool mx = a > 0;
         if (mx) {
@@ -282,7 +302,8 @@ __global__ __launch_bounds__(256) void fast_cells_kernel(const ex_frame* __restr
         int tot;
         const int pos = block_scan_excl256(keep, &tot, s_w);
         if (keep) {
-            const int y = 3 + t / ew, x = 3 + t % ew;
+            const int q = (int)(((unsigned)t * mg_e) >> 20);
+            const int y = 3 + q, x = 3 + t - q * ew;
             if (base + pos < cell_cap) cand[(size_t)blockIdx.x * cell_cap + base + pos] = (uint32_t)x | ((uint32_t)y << 8) | ((uint32_t)(a - 1) << 16);
         }
         base += tot;
