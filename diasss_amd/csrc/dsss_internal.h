@@ -69,6 +69,8 @@ struct dsss_ctx {
     // extraction scratch (grown on demand)
     void* ex_scratch = nullptr; size_t ex_scratch_bytes = 0;
     void* ex_pinned = nullptr; size_t ex_pinned_bytes = 0;
+    // pose-graph solver arena: device chunks kept between solves (dsss_pg.hip), bump-allocated, reset per solve
+    std::vector<std::pair<void*, size_t>> pg_chunks; size_t pg_chunk_cur = 0, pg_chunk_off = 0;
     // matcher state
     void* mt_aux = nullptr; size_t mt_aux_bytes = 0;   // per-frame pointer tables + cv::RNG stream
     const double** d_ptrs = nullptr;                   // [3][max_frames]: alt, gr, pose6 device pointers

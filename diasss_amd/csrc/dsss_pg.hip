@@ -1340,17 +1340,34 @@ void symbolic(int ns, const std::vector<std::pair<int, int>>& edges, int nchain,
 }
 
 struct pg_dev {
-    std::vector<void*> allocs;
-    template <typename T> int alloc(dsss_ctx* c, T** p, size_t n) { void* q = nullptr; HIPCHK(c, hipMalloc(&q, std::max<size_t>(n, 1) * sizeof(T))); allocs.push_back(q); *p = (T*)q; return DSSS_OK; }
+    // device memory of one solve comes from the context's arena: a few large chunks that stay allocated between solves,
+    // so a solve costs no hipMalloc / hipFree once the arena has grown to its working size
+    dsss_ctx* ctx = nullptr;
+    static constexpr size_t CHUNK = (size_t)256 << 20;
+    template <typename T> int alloc(dsss_ctx* c, T** p, size_t n) {
+        if (!ctx) { ctx = c; c->pg_chunk_cur = 0; c->pg_chunk_off = 0; }
+        const size_t bytes = (std::max<size_t>(n, 1) * sizeof(T) + 255) & ~(size_t)255;
+        for (;;) {
+            if (c->pg_chunk_cur < c->pg_chunks.size()) {
+                auto& ch = c->pg_chunks[c->pg_chunk_cur];
+                if (c->pg_chunk_off + bytes <= ch.second) { *p = (T*)((char*)ch.first + c->pg_chunk_off); c->pg_chunk_off += bytes; return DSSS_OK; }
+                ++c->pg_chunk_cur; c->pg_chunk_off = 0;
+                continue;
+            }
+            void* q = nullptr; const size_t sz = std::max(bytes, CHUNK);
+            HIPCHK(c, hipMalloc(&q, sz));
+            c->pg_chunks.push_back({ q, sz });
+        }
+    }
     template <typename T> int upload(dsss_ctx* c, T** p, const std::vector<T>& v) { int rc = alloc(c, p, v.size()); if (rc) return rc; if (!v.empty()) HIPCHK(c, hipMemcpy(*p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice)); return DSSS_OK; }
     std::vector<hipEvent_t> events;
     hipEvent_t event() { hipEvent_t e = nullptr; hipEventCreateWithFlags(&e, hipEventDisableTiming); events.push_back(e); return e; }
-    void release() { for (void* q : allocs) hipFree(q); allocs.clear(); for (hipEvent_t e : events) if (e) hipEventDestroy(e); events.clear(); }
+    void release() { if (ctx) { hipStreamSynchronize(ctx->stream); ctx->pg_chunk_cur = 0; ctx->pg_chunk_off = 0; } for (hipEvent_t e : events) if (e) hipEventDestroy(e); events.clear(); }
 };
 
 } // namespace
 
-void dsss_pg_free(dsss_ctx* c) { (void)c; }
+void dsss_pg_free(dsss_ctx* c) { for (auto& ch : c->pg_chunks) hipFree(ch.first); c->pg_chunks.clear(); c->pg_chunk_cur = 0; c->pg_chunk_off = 0; }
 
 // batch LM over `total` poses (dr6: host, total x 6) with `ne` LC edges (host)
 static int pg_solve_impl(dsss_ctx* c, const double* dr6, int total, const dsss_lc_edge* edges, int ne, double* poses12, double* stats4, double* rpy6 = nullptr)
