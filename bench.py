@@ -75,7 +75,7 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default=os.environ.get("DSSS_WORKLOAD", "C3"), choices=sorted(WORKLOADS))
-    ap.add_argument("--cpu-frames", type=int, default=3, help="frames in the CPU baseline sample (0 = skip)")
+    ap.add_argument("--cpu-frames", type=int, default=24, help="frames in the CPU baseline sample (0 = skip); 24 frames of C3 are about 10 s of one core")
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()
 
