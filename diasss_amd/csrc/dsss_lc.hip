@@ -3,7 +3,7 @@
 // (/root/reference/src/core/optimizer.cpp:641-982): graph {Prior(X1, 1e-6), Between(X1, X2; DR odometry, adaptive
 // sigmas :778), SssPoint(L1, X1), SssPoint(L1, X2)} (:773-786), GTSAM LM with default parameters (:815-822), marginal
 // covariance of X2 (:956-959), score = ini/final - 2 (:853-896).  GTSAM semantics per SURVEY.md A.2/A.3 and
-// oracle/orc_lc.c.  f64 VALU: 15 x 15 systems are far too small for MFMA; one thread per problem.
+// oracle/orc_lc.c.  f64 VALU: 15 x 15 systems are far too small for MFMA; 16 lanes per problem.
 #include "dsss_internal.h"
 #include "dsss_pose.h"
 
@@ -17,84 +17,140 @@ struct mini_prob {
 };
 struct mini_val { double L[3]; pose_t X1, X2; };
 
-__device__ static void mini_lin(const mini_prob& m, const mini_val& v, double* r, double* J)
+// ---- 16 lanes per problem, four problems per wavefront.  The pose algebra (a few hundred dependent flops) is evaluated
+// redundantly by every lane of the group; the 16 x 15 Jacobian and the 15 x 15 systems live in LDS with one row per lane,
+// and every sum keeps the element-wise order of oracle/orc_lc.c (k ascending), so results equal the one-thread version
+// bit for bit while the serial chains shrink from O(15^3) to O(15^2) and nothing spills to scratch.
+#define LG 16                  // lanes per problem
+#define LS 16                  // LDS row stride (doubles)
+struct lc_lds { double J[MR * LS]; double H[MD * LS]; double L[MD * LS]; };
+
+// whitened residual r (registers, every lane) and Jacobian J (LDS; lane `lane` clears row `lane`, lane 0 writes the entries)
+__device__ static void mini_lin(const mini_prob& m, const mini_val& v, double* r, double* J, int lane)
 {
-    if (J) for (int i = 0; i < MR * MD; ++i) J[i] = 0.0;
+    const bool wr = J && lane == 0;
+    if (J) {
+#pragma unroll
+        for (int c2 = 0; c2 < LS; ++c2) J[lane * LS + c2] = 0.0;
+        __builtin_amdgcn_wave_barrier();
+    }
     pose_t d; double xi[6];
     pose_between(&m.prior, &v.X1, &d);                     // PriorFactor: e = Logmap(prior^-1 x), H = I
     pose_log(&d, xi);
-    for (int i = 0; i < 6; ++i) { r[i] = xi[i] / m.sig_prior[i]; if (J) J[i * MD + 3 + i] = 1.0 / m.sig_prior[i]; }
+#pragma unroll
+    for (int i = 0; i < 6; ++i) { r[i] = xi[i] / m.sig_prior[i]; if (wr) J[i * LS + 3 + i] = 1.0 / m.sig_prior[i]; }
     pose_t h, e;
     pose_between(&v.X1, &v.X2, &h);                        // BetweenFactor: e = Logmap(meas^-1 h), H1 = -Ad(h^-1), H2 = I
     pose_between(&m.odo, &h, &e);
     pose_log(&e, xi);
+#pragma unroll
     for (int i = 0; i < 6; ++i) r[6 + i] = xi[i] / m.sig_odo[i];
     if (J) {
         pose_t hi; double Ad[36];
         pose_inverse(&h, &hi);
         pose_adjoint(&hi, Ad);
-        for (int i = 0; i < 6; ++i) {
-            for (int j = 0; j < 6; ++j) J[(6 + i) * MD + 3 + j] = -Ad[6 * i + j] / m.sig_odo[i];
-            J[(6 + i) * MD + 9 + i] = 1.0 / m.sig_odo[i];
+        if (wr) {
+#pragma unroll
+            for (int i = 0; i < 6; ++i) {
+#pragma unroll
+                for (int j = 0; j < 6; ++j) J[(6 + i) * LS + 3 + j] = -Ad[6 * i + j] / m.sig_odo[i];
+                J[(6 + i) * LS + 9 + i] = 1.0 / m.sig_odo[i];
+            }
         }
     }
     double ee[2], H1[6], H2[12];
     sss_factor(v.L, &v.X1, m.slant_s, 0.0, ee, J ? H1 : nullptr, H2);
+#pragma unroll
     for (int i = 0; i < 2; ++i) {
         r[12 + i] = ee[i] / m.sig_s[i];
-        if (J) {
-            for (int j = 0; j < 3; ++j) J[(12 + i) * MD + j] = H1[3 * i + j] / m.sig_s[i];
-            for (int j = 0; j < 6; ++j) J[(12 + i) * MD + 3 + j] = H2[6 * i + j] / m.sig_s[i];
+        if (wr) {
+#pragma unroll
+            for (int j = 0; j < 3; ++j) J[(12 + i) * LS + j] = H1[3 * i + j] / m.sig_s[i];
+#pragma unroll
+            for (int j = 0; j < 6; ++j) J[(12 + i) * LS + 3 + j] = H2[6 * i + j] / m.sig_s[i];
         }
     }
     sss_factor(v.L, &v.X2, m.slant_t, 0.0, ee, J ? H1 : nullptr, H2);
+#pragma unroll
     for (int i = 0; i < 2; ++i) {
         r[14 + i] = ee[i] / m.sig_t[i];
-        if (J) {
-            for (int j = 0; j < 3; ++j) J[(14 + i) * MD + j] = H1[3 * i + j] / m.sig_t[i];
-            for (int j = 0; j < 6; ++j) J[(14 + i) * MD + 9 + j] = H2[6 * i + j] / m.sig_t[i];
+        if (wr) {
+#pragma unroll
+            for (int j = 0; j < 3; ++j) J[(14 + i) * LS + j] = H1[3 * i + j] / m.sig_t[i];
+#pragma unroll
+            for (int j = 0; j < 6; ++j) J[(14 + i) * LS + 9 + j] = H2[6 * i + j] / m.sig_t[i];
         }
     }
+    if (J) __builtin_amdgcn_wave_barrier();
 }
 __device__ static double mini_err(const mini_prob& m, const mini_val& v)
 {
     double r[MR];
-    mini_lin(m, v, r, nullptr);
+    mini_lin(m, v, r, nullptr, 0);
     double s = 0;
+#pragma unroll
     for (int i = 0; i < MR; ++i) s += r[i] * r[i];
     return 0.5 * s;
 }
-__device__ static int chol15(double* A)
+// lane a < 15: row a of H = J^T J (the whole row: both triangles hold bitwise equal sums), and g[a] = (J^T r)[a]
+__device__ static double normal_eq(const double* J, const double* r, double* H, int lane)
 {
-    for (int j = 0; j < MD; ++j) {
-        double d = A[j * MD + j];
-        for (int k = 0; k < j; ++k) d -= A[j * MD + k] * A[j * MD + k];
-        if (!(d > 0) || !isfinite(d)) return -1;
-        d = sqrt(d); A[j * MD + j] = d;
-        for (int i = j + 1; i < MD; ++i) {
-            double s = A[i * MD + j];
-            for (int k = 0; k < j; ++k) s -= A[i * MD + k] * A[j * MD + k];
-            A[i * MD + j] = s / d;
+    double g = 0;
+    if (lane < MD) {
+        double ca[MR];
+#pragma unroll
+        for (int k = 0; k < MR; ++k) ca[k] = J[k * LS + lane];
+#pragma unroll
+        for (int k = 0; k < MR; ++k) g += ca[k] * r[k];
+        for (int b2 = 0; b2 < MD; ++b2) {
+            double t = 0;
+#pragma unroll
+            for (int k = 0; k < MR; ++k) t += ca[k] * J[k * LS + b2];
+            H[lane * LS + b2] = t;
         }
     }
-    return 0;
+    __builtin_amdgcn_wave_barrier();
+    return g;
 }
+// in-place lower Cholesky of A = H + lambda I into L (LDS): lane i owns row i in registers; returns 0 on success (uniform
+// over the group).  Column j: lanes i >= j subtract sum_k L(i,k) L(j,k), k ascending, exactly as the sequential form.
+__device__ static int chol15(const double* H, double lambda, double* L, int lane)
+{
+    double row[MD];
+    const int li = lane < MD ? lane : MD - 1;               // lane 15 shadows row 14 and never writes
+#pragma unroll
+    for (int j = 0; j < MD; ++j) row[j] = H[li * LS + j] + (j == li ? lambda : 0.0);
+    int bad = 0;
+#pragma unroll
+    for (int j = 0; j < MD; ++j) {
+        double sacc = row[j];
+#pragma unroll
+        for (int k = 0; k < MD; ++k) if (k < j) sacc -= row[k] * L[j * LS + k];
+        const double dj = __shfl(sacc, j, LG);              // pivot before the square root, from the diagonal lane
+        if (!(dj > 0) || !isfinite(dj)) { bad = 1; break; }
+        const double dq = sqrt(dj);
+        row[j] = li == j ? dq : sacc / dq;
+        if (lane < MD && li >= j) L[li * LS + j] = row[j];
+        __builtin_amdgcn_wave_barrier();
+    }
+    return bad;
+}
+// b <- (L L^T)^-1 b, b in registers of every lane (same values on every lane of the group), L read from LDS
 __device__ static void chol15_solve(const double* L, double* b)
 {
-    for (int i = 0; i < MD; ++i) { double s = b[i]; for (int k = 0; k < i; ++k) s -= L[i * MD + k] * b[k]; b[i] = s / L[i * MD + i]; }
-    for (int i = MD - 1; i >= 0; --i) { double s = b[i]; for (int k = i + 1; k < MD; ++k) s -= L[k * MD + i] * b[k]; b[i] = s / L[i * MD + i]; }
-}
-__device__ static void normal_eq(const double* J, const double* r, double* H, double* g)
-{
-    for (int a = 0; a < MD; ++a) {
-        double s = 0;
-        for (int k = 0; k < MR; ++k) s += J[k * MD + a] * r[k];
-        if (g) g[a] = s;
-        for (int b = 0; b <= a; ++b) {
-            double t = 0;
-            for (int k = 0; k < MR; ++k) t += J[k * MD + a] * J[k * MD + b];
-            H[a * MD + b] = t; H[b * MD + a] = t;
-        }
+#pragma unroll
+    for (int i = 0; i < MD; ++i) {
+        double sacc = b[i];
+#pragma unroll
+        for (int k = 0; k < MD; ++k) if (k < i) sacc -= L[i * LS + k] * b[k];
+        b[i] = sacc / L[i * LS + i];
+    }
+#pragma unroll
+    for (int i = MD - 1; i >= 0; --i) {
+        double sacc = b[i];
+#pragma unroll
+        for (int k = 0; k < MD; ++k) if (k > i) sacc -= L[k * LS + i] * b[k];
+        b[i] = sacc / L[i * LS + i];
     }
 }
 
@@ -107,8 +163,11 @@ __global__ __launch_bounds__(64) void lc_kernel(const double* __restrict__ kp7, 
                                                 const double* const* __restrict__ pose_ptr, const int* __restrict__ fcols,
                                                 dsss_lc* __restrict__ out)
 {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
+    __shared__ lc_lds s_all[64 / LG];
+    const int grp = threadIdx.x / LG, lane = threadIdx.x % LG;
+    const int i = blockIdx.x * (64 / LG) + grp;
+    if (i >= n) return;                                     // whole groups leave together
+    lc_lds& S = s_all[grp];
     const double PI = DSSS_PI_REF;
     const double* kp = kp7 + (size_t)i * 7;
     const int fs = kp7_pair ? act_s[kp7_pair[i]] : single_s, ft = kp7_pair ? act_t[kp7_pair[i]] : single_t;
@@ -161,30 +220,33 @@ __global__ __launch_bounds__(64) void lc_kernel(const double* __restrict__ kp7, 
     int iters = 0;
     double err = mini_err(m, v);
     const double err0 = err;
-    double r[MR], J[MR * MD], H[MD * MD], g[MD], A[MD * MD], d[MD];
+    double r[MR], d[MD];
     if (err > 0) {
         double cur;
         do {
             cur = err;
-            mini_lin(m, v, r, J);
-            normal_eq(J, r, H, g);
+            mini_lin(m, v, r, S.J, lane);
+            const double g_mine = normal_eq(S.J, r, S.H, lane);
             double oldLin = 0;
+#pragma unroll
             for (int k = 0; k < MR; ++k) oldLin += r[k] * r[k];
             oldLin *= 0.5;
             for (;;) {
-                for (int a = 0; a < MD * MD; ++a) A[a] = H[a];
-                for (int a = 0; a < MD; ++a) { A[a * MD + a] += lambda; d[a] = -g[a]; }
-                const bool ok = chol15(A) == 0;
+                const bool ok = chol15(S.H, lambda, S.L, lane) == 0;
                 bool success = false, stop = false;
                 double newErr = 0; mini_val nv;
                 if (ok) {
-                    chol15_solve(A, d);
+#pragma unroll
+                    for (int a = 0; a < MD; ++a) d[a] = -__shfl(g_mine, a, LG);
+                    chol15_solve(S.L, d);
+                    double sk = r[0];                                   // lane k: row k of J d + r
+#pragma unroll
+                    for (int k = 0; k < MR; ++k) if (k == lane) sk = r[k];
+#pragma unroll
+                    for (int a = 0; a < MD; ++a) sk += S.J[lane * LS + a] * d[a];
                     double newLin = 0;
-                    for (int k = 0; k < MR; ++k) {
-                        double s = r[k];
-                        for (int a = 0; a < MD; ++a) s += J[k * MD + a] * d[a];
-                        newLin += s * s;
-                    }
+#pragma unroll
+                    for (int k = 0; k < MR; ++k) { const double t = __shfl(sk, k, LG); newLin += t * t; }
                     newLin *= 0.5;
                     const double linChange = oldLin - newLin;
                     if (linChange >= 0) {
@@ -227,24 +289,27 @@ __global__ __launch_bounds__(64) void lc_kernel(const double* __restrict__ kp7, 
     const double x_n = gsx - lx, y_n = gsy - ly;
     const double fin = sqrt(x_n * x_n + y_n * y_n);
     o.score = ini / fin - 2;
-    // Marginals(graph, result).marginalCovariance(X2).diagonal() (:956-959)
-    mini_lin(m, v, r, J);
-    normal_eq(J, r, H, nullptr);
-    if (chol15(H) == 0) {
-        for (int c = 0; c < 6; ++c) {
-            for (int a = 0; a < MD; ++a) d[a] = 0;
-            d[9 + c] = 1;
-            chol15_solve(H, d);
-            o.var[c] = d[9 + c];
-        }
-    } else for (int c = 0; c < 6; ++c) o.var[c] = NAN;
+    // Marginals(graph, result).marginalCovariance(X2).diagonal() (:956-959): lane c < 6 solves for unit vector 9 + c
+    mini_lin(m, v, r, S.J, lane);
+    (void)normal_eq(S.J, r, S.H, lane);
+    double var_mine = NAN;
+    if (chol15(S.H, 0.0, S.L, lane) == 0) {
+#pragma unroll
+        for (int a = 0; a < MD; ++a) d[a] = (a == 9 + lane) ? 1.0 : 0.0;
+        chol15_solve(S.L, d);
+        var_mine = 0;
+#pragma unroll
+        for (int a = 9; a < MD; ++a) if (a == 9 + lane) var_mine = d[a];
+    }
+#pragma unroll
+    for (int c2 = 0; c2 < 6; ++c2) o.var[c2] = __shfl(var_mine, c2, LG);
     pose_t csi, src, rel;
     pose_inverse(&cps_s, &csi);
     pose_compose(&Tp_s, &csi, &src);
     pose_between(&src, &new_pose, &rel);                         // :958
     for (int a = 0; a < 9; ++a) o.rel[a] = rel.R[a];
     for (int a = 0; a < 3; ++a) o.rel[9 + a] = rel.t[a];
-    out[i] = o;
+    if (lane == 0) out[i] = o;
 }
 
 static int ensure_ptr_tables(dsss_ctx* c)
@@ -278,7 +343,7 @@ int dsss_lc_solve_all(dsss_ctx* c)
     }
     const int F = c->max_frames;
     dsss_scope sc(c, DSSS_K_LC);
-    hipLaunchKernelGGL(lc_kernel, dim3((n + 63) / 64), dim3(64), 0, c->stream, c->kp7, n, c->kp7_pair, c->kp7_flip, c->act_s, c->act_t,
+    hipLaunchKernelGGL(lc_kernel, dim3((n + 3) / 4), dim3(64), 0, c->stream, c->kp7, n, c->kp7_pair, c->kp7_flip, c->act_s, c->act_t,
                        0, 0, 0, c->d_ptrs, c->d_ptrs + F, c->d_ptrs + 2 * F, c->cols_dev, c->lcs);
     HIPCHK(c, hipGetLastError());
     return DSSS_OK;
@@ -314,7 +379,7 @@ int dsss_lc_solve(dsss_ctx* c, int id_s, int id_t, const double* kp7, int n, dss
     const int F = c->max_frames;
     {
         dsss_scope sc(c, DSSS_K_LC);
-        hipLaunchKernelGGL(lc_kernel, dim3((n + 63) / 64), dim3(64), 0, c->stream, d_kp7, n, (const int*)nullptr, (const uint8_t*)nullptr,
+        hipLaunchKernelGGL(lc_kernel, dim3((n + 3) / 4), dim3(64), 0, c->stream, d_kp7, n, (const int*)nullptr, (const uint8_t*)nullptr,
                            (const int*)nullptr, (const int*)nullptr, id_s, id_t, 0, c->d_ptrs, c->d_ptrs + F, c->d_ptrs + 2 * F, c->cols_dev, d_out);
     }
     hipError_t e = hipGetLastError();
