@@ -33,38 +33,96 @@ __device__ inline int qt_block_scan(int v, int* total, int* s_w)
     return base + inc - v;
 }
 
-// ExtractorNode::DivideNode (:481-537) for one node, executed by one wave: stable 4-way partition of the node's key
-// segment from its buffer into the other one; cnt[0..3] = keys of n1..n4 (top-left, top-right, bottom-left, bottom-right)
+// ExtractorNode::DivideNode (:481-537): stable 4-way partition of a node's key segment from its buffer into the other
+// one; cnt[0..3] = keys of n1..n4 (top-left, top-right, bottom-left, bottom-right).  The key -> coordinate loads are
+// dependent global loads, so a wave classifies four chunks of 64 keys per trip to keep several of them in flight.
+#define QT_ILP 4
+__device__ inline void qt_classify4(const int* __restrict__ src, int beg, int end, int b, int lane, const float* __restrict__ xs,
+                                    const float* __restrict__ ys, float mx, float my, int* c, int* k)
+{
+#pragma unroll
+    for (int u = 0; u < QT_ILP; ++u) { const int i = b + u * 64 + lane; k[u] = i < end ? src[beg + i] : -1; }
+    float x[QT_ILP], y[QT_ILP];
+#pragma unroll
+    for (int u = 0; u < QT_ILP; ++u) { x[u] = k[u] >= 0 ? xs[k[u]] : 0.f; y[u] = k[u] >= 0 ? ys[k[u]] : 0.f; }
+#pragma unroll
+    for (int u = 0; u < QT_ILP; ++u) { const bool left = x[u] < mx, top = y[u] < my; c[u] = k[u] >= 0 ? (left ? (top ? 0 : 2) : (top ? 1 : 3)) : -1; }
+}
+// counts of the four classes over keys [lo, hi) of the node (one wave)
+__device__ inline void qt_count_range(const qnode& P, const int* __restrict__ src, int lo, int hi, const float* __restrict__ xs,
+                                      const float* __restrict__ ys, float mx, float my, int* cnt)
+{
+    const int lane = threadIdx.x & 63;
+    int c0 = 0, c1 = 0, c2 = 0, c3 = 0;
+    for (int b = lo; b < hi; b += 64 * QT_ILP) {
+        int c[QT_ILP], k[QT_ILP];
+        qt_classify4(src, P.kbeg, hi, b, lane, xs, ys, mx, my, c, k);
+#pragma unroll
+        for (int u = 0; u < QT_ILP; ++u) {
+            c0 += __popcll(__ballot(c[u] == 0)); c1 += __popcll(__ballot(c[u] == 1)); c2 += __popcll(__ballot(c[u] == 2)); c3 += __popcll(__ballot(c[u] == 3));
+        }
+    }
+    cnt[0] = c0; cnt[1] = c1; cnt[2] = c2; cnt[3] = c3;
+}
+// stable scatter of keys [lo, hi) given the destination offset of each class for this range (one wave)
+__device__ inline void qt_scatter_range(const qnode& P, const int* __restrict__ src, int* __restrict__ dst, int lo, int hi,
+                                        const float* __restrict__ xs, const float* __restrict__ ys, float mx, float my, const int* off)
+{
+    const int lane = threadIdx.x & 63;
+    int r0 = off[0], r1 = off[1], r2 = off[2], r3 = off[3];
+    const unsigned long long below = (1ull << lane) - 1ull;
+    for (int b = lo; b < hi; b += 64 * QT_ILP) {
+        int c[QT_ILP], k[QT_ILP];
+        qt_classify4(src, P.kbeg, hi, b, lane, xs, ys, mx, my, c, k);
+#pragma unroll
+        for (int u = 0; u < QT_ILP; ++u) {
+            const unsigned long long m0 = __ballot(c[u] == 0), m1 = __ballot(c[u] == 1), m2 = __ballot(c[u] == 2), m3 = __ballot(c[u] == 3);
+            if (c[u] == 0) dst[P.kbeg + r0 + __popcll(m0 & below)] = k[u];
+            else if (c[u] == 1) dst[P.kbeg + r1 + __popcll(m1 & below)] = k[u];
+            else if (c[u] == 2) dst[P.kbeg + r2 + __popcll(m2 & below)] = k[u];
+            else if (c[u] == 3) dst[P.kbeg + r3 + __popcll(m3 & below)] = k[u];
+            r0 += __popcll(m0); r1 += __popcll(m1); r2 += __popcll(m2); r3 += __popcll(m3);
+        }
+    }
+}
+// one node, one wave
 __device__ inline void qt_divide_wave(const qnode& P, const float* __restrict__ xs, const float* __restrict__ ys,
                                       int* __restrict__ keys0, int* __restrict__ keys1, int* cnt)
 {
-    const int lane = threadIdx.x & 63;
     const int* src = P.buf ? keys1 : keys0;
     int* dst = P.buf ? keys0 : keys1;
     const float mx = (float)(P.x0 + (int)ceilf((float)(P.x1 - P.x0) / 2));
     const float my = (float)(P.y0 + (int)ceilf((float)(P.y1 - P.y0) / 2));
-    int c0 = 0, c1 = 0, c2 = 0, c3 = 0;
-    for (int b = 0; b < P.kcnt; b += 64) {
-        const int i = b + lane;
-        int c = -1;
-        if (i < P.kcnt) { const int k = src[P.kbeg + i]; const bool left = xs[k] < mx, top = ys[k] < my; c = left ? (top ? 0 : 2) : (top ? 1 : 3); }
-        c0 += __popcll(__ballot(c == 0)); c1 += __popcll(__ballot(c == 1)); c2 += __popcll(__ballot(c == 2)); c3 += __popcll(__ballot(c == 3));
+    qt_count_range(P, src, 0, P.kcnt, xs, ys, mx, my, cnt);
+    const int off[4] = { 0, cnt[0], cnt[0] + cnt[1], cnt[0] + cnt[1] + cnt[2] };
+    qt_scatter_range(P, src, dst, 0, P.kcnt, xs, ys, mx, my, off);
+}
+// one node, the whole workgroup (the first passes have fewer nodes than waves, and those nodes hold most of the keys):
+// every wave takes a contiguous quarter of the segment; s_cnt[wave][class] carries the counts between the two passes
+__device__ inline void qt_divide_block(const qnode& P, const float* __restrict__ xs, const float* __restrict__ ys,
+                                       int* __restrict__ keys0, int* __restrict__ keys1, int* cnt, int (*s_cnt)[4])
+{
+    const int* src = P.buf ? keys1 : keys0;
+    int* dst = P.buf ? keys0 : keys1;
+    const float mx = (float)(P.x0 + (int)ceilf((float)(P.x1 - P.x0) / 2));
+    const float my = (float)(P.y0 + (int)ceilf((float)(P.y1 - P.y0) / 2));
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int q = ((P.kcnt + 3) / 4 + 63) & ~63;
+    const int lo = min(wv * q, P.kcnt), hi = min(lo + q, P.kcnt);
+    int mine[4];
+    qt_count_range(P, src, lo, hi, xs, ys, mx, my, mine);
+    if (lane == 0) { s_cnt[wv][0] = mine[0]; s_cnt[wv][1] = mine[1]; s_cnt[wv][2] = mine[2]; s_cnt[wv][3] = mine[3]; }
+    __syncthreads();
+    int off[4], run = 0;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        int before = 0, tot = 0;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) { const int t = s_cnt[w][c]; if (w < wv) before += t; tot += t; }
+        off[c] = run + before; cnt[c] = tot; run += tot;
     }
-    const int o1 = c0, o2 = c0 + c1, o3 = c0 + c1 + c2;
-    int r0 = 0, r1 = 0, r2 = 0, r3 = 0;
-    const unsigned long long below = (1ull << lane) - 1ull;
-    for (int b = 0; b < P.kcnt; b += 64) {
-        const int i = b + lane;
-        int c = -1, k = 0;
-        if (i < P.kcnt) { k = src[P.kbeg + i]; const bool left = xs[k] < mx, top = ys[k] < my; c = left ? (top ? 0 : 2) : (top ? 1 : 3); }
-        const unsigned long long m0 = __ballot(c == 0), m1 = __ballot(c == 1), m2 = __ballot(c == 2), m3 = __ballot(c == 3);
-        if (c == 0) dst[P.kbeg + r0 + __popcll(m0 & below)] = k;
-        else if (c == 1) dst[P.kbeg + o1 + r1 + __popcll(m1 & below)] = k;
-        else if (c == 2) dst[P.kbeg + o2 + r2 + __popcll(m2 & below)] = k;
-        else if (c == 3) dst[P.kbeg + o3 + r3 + __popcll(m3 & below)] = k;
-        r0 += __popcll(m0); r1 += __popcll(m1); r2 += __popcll(m2); r3 += __popcll(m3);
-    }
-    cnt[0] = c0; cnt[1] = c1; cnt[2] = c2; cnt[3] = c3;
+    qt_scatter_range(P, src, dst, lo, hi, xs, ys, mx, my, off);
+    __syncthreads();
 }
 
 __device__ inline qnode qt_child(const qnode& P, int c, const int* cnt)
@@ -83,7 +141,8 @@ __device__ inline qnode qt_child(const qnode& P, int c, const int* cnt)
 __global__ __launch_bounds__(256) void quadtree_kernel(const qt_inst* __restrict__ tab)
 {
     __shared__ int s_w[4];
-    __shared__ int s_S, s_pool, s_np, s_nexp, s_done, s_phase2, s_t;
+    __shared__ int s_S, s_pool, s_nexp, s_done, s_phase2, s_t;
+    __shared__ int s_cnt[4][4];
     const qt_inst I = tab[blockIdx.x];
     const int n = I.offs[I.cell_end] - I.offs[I.cell_begin];
     const int base = I.offs[I.cell_begin];
@@ -153,11 +212,18 @@ __global__ __launch_bounds__(256) void quadtree_kernel(const qt_inst* __restrict
         __syncthreads();
         if (np == 0) break;                          // every node holds one point: size == prevSize
         if (s_pool + 4 * np > pool_cap) { if (threadIdx.x == 0) *I.err = 1; break; }
-        for (int r = wv; r < np; r += 4) {
-            int cnt[4];
-            qt_divide_wave(pool[parents[r]], xs, ys, keys0, keys1, cnt);
-            if (lane == 0) { pcnt[4 * r] = cnt[0]; pcnt[4 * r + 1] = cnt[1]; pcnt[4 * r + 2] = cnt[2]; pcnt[4 * r + 3] = cnt[3]; }
-        }
+        if (np < 4) {
+            for (int r = 0; r < np; ++r) {
+                int cnt[4];
+                qt_divide_block(pool[parents[r]], xs, ys, keys0, keys1, cnt, s_cnt);
+                if (threadIdx.x == 0) { pcnt[4 * r] = cnt[0]; pcnt[4 * r + 1] = cnt[1]; pcnt[4 * r + 2] = cnt[2]; pcnt[4 * r + 3] = cnt[3]; }
+            }
+        } else
+            for (int r = wv; r < np; r += 4) {
+                int cnt[4];
+                qt_divide_wave(pool[parents[r]], xs, ys, keys0, keys1, cnt);
+                if (lane == 0) { pcnt[4 * r] = cnt[0]; pcnt[4 * r + 1] = cnt[1]; pcnt[4 * r + 2] = cnt[2]; pcnt[4 * r + 3] = cnt[3]; }
+            }
         __syncthreads();
         // children in creation order: parents in list order, n1..n4, empty ones skipped
         int Cn = 0, nexp = 0;
