@@ -9,7 +9,7 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libdsss.so")
+LIB_PATH = os.environ.get("DSSS_LIB", os.path.join(_HERE, "libdsss.so"))     # DSSS_LIB: A/B runs of two builds on one box
 _LIB = None
 _HIP = None
 

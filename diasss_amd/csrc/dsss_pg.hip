@@ -302,6 +302,9 @@ __global__ __launch_bounds__(256) void pg_scatter_lc_kernel(int n, int ne, const
     }
 }
 
+// The factorisation kernels below (down to pg_sep_delta_kernel) are compared with the oracle at 1e-6 on the poses, not
+// bit for bit, so they may fuse multiply-adds; everything else in the library stays at -ffp-contract=off.
+#pragma clang fp contract(fast)
 // ---- sparse block Cholesky, left-looking, one workgroup per column of the current elimination-tree level.
 // Column j holds blocks L(i, j), i in rowidx[colptr[j] .. colptr[j+1]) ascending, first the diagonal.
 // rowlist(j) = columns k < j with L(j, k) != 0 and the position of that block.
@@ -510,7 +513,9 @@ __device__ inline int pg_tile_factor(double* sA, double* sW, int t, int lane)
     for (int j = 0; j < 16; ++j) {
         double pj = pg_readlane(d[j], j);
         if (!(pj > 0) || !isfinite(pj)) { bad = 1; pj = 1.0; }
-        const double r = rsqrt(pj);
+        double r = __builtin_amdgcn_rsq(pj);                 // v_rsq_f64 seed, two Newton steps
+        r = r * (1.5 - 0.5 * pj * r * r);
+        r = r * (1.5 - 0.5 * pj * r * r);
         rinv[j] = r;
         d[j] = (lane == j ? pj : d[j]) * r;
 #pragma unroll
@@ -882,6 +887,7 @@ __global__ __launch_bounds__(64) void pg_bwd_subtree_kernel(const int* __restric
     }
 }
 
+#pragma clang fp contract(off)
 __global__ __launch_bounds__(256) void pg_sep_delta_kernel(int ns, const int* __restrict__ sep_pose, const int* __restrict__ perm,
                                                            const double* __restrict__ x, double* __restrict__ delta)
 {

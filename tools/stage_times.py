@@ -11,7 +11,7 @@ sv = Survey(F, N, M, seed=20240601, device="cuda:0")
 raws = [sv.frame(f) for f in range(F)]
 poses = [sv.inputs(f)[0] for f in range(F)]; alts = [sv.inputs(f)[1] for f in range(F)]; grs = [sv.inputs(f)[2] for f in range(F)]
 pipe = Pipeline(F)
-for it in range(3):
+for it in range(int(sys.argv[2]) if len(sys.argv) > 2 else 3):
     torch.cuda.synchronize(); t0 = time.perf_counter()
     pipe.set_frames(raws, poses, alts, grs); pipe.ctx.sync(); t1 = time.perf_counter()
     pipe.extract(); pipe.ctx.sync(); t2 = time.perf_counter()
