@@ -371,7 +371,8 @@ int dsss_lc_solve(dsss_ctx* c, int id_s, int id_t, const double* kp7, int n, dss
     if (!c->frames[id_s].has_geom || !c->frames[id_t].has_geom) DSSS_FAIL(c, DSSS_E_STATE, "frames need dsss_frame_set first");
     if (n == 0) return DSSS_OK;
     HIPCHK(c, hipSetDevice(c->device));
-    int rc = ensure_ptr_tables(c); if (rc) return rc;
+    int rc = dsss_sync_bboxes(c); if (rc) return rc;          // also publishes the frames' N and M to the device tables
+    rc = ensure_ptr_tables(c); if (rc) return rc;
     double* d_kp7 = nullptr; dsss_lc* d_out = nullptr;
     HIPCHK(c, hipMalloc(&d_kp7, (size_t)n * 7 * sizeof(double)));
     HIPCHK(c, hipMalloc(&d_out, (size_t)n * sizeof(dsss_lc)));
