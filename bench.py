@@ -60,13 +60,30 @@ def cpu_baseline(sv, wl, n_frames):
     kp7_all = np.concatenate(kp7s) if kp7s else np.zeros((0, 7)); lcs_all = np.concatenate(lcss) if lcss else np.zeros(0, O.LC_DTYPE)
     edges = O.pg_select_lc([N] * n_frames, pair_s, pair_t, pair_off, kp7_all, lcs_all)
     dr = np.concatenate([f["pose"] for f in fr])
-    O.pg_solve(dr, edges)
+    o_poses, _ = O.pg_solve(dr, edges)
     t_rest = time.time() - t2
     t_cpu = t_extract + t_rest
     _ = t0
     return dict(value=n_frames / t_cpu, unit="frames/s", cores=1, kind="port",
                 sample="oracle (C restatement of the reference, -O3, 1 thread) on %d of %d frames of %dx%d: extraction %.1fs, "
-                       "all %d pairs + LC + pose graph %.1fs" % (n_frames, wl["F"], N, M, t_extract, n_frames * (n_frames - 1) // 2, t_rest))
+                       "all %d pairs + LC + pose graph %.1fs" % (n_frames, wl["F"], N, M, t_extract, n_frames * (n_frames - 1) // 2, t_rest)), o_poses, len(edges)
+
+
+def sample_parity(sv, n_frames, o_poses, o_edges, device):
+    """the HIP path on the CPU sample's frames against the oracle's trajectory (pose RMSE vs the oracle's batch LM)"""
+    from diasss_amd.pipeline import Pipeline
+    pipe = Pipeline(n_frames, device=device)
+    raws = [sv.frame(f) for f in range(n_frames)]
+    ins = [sv.inputs(f) for f in range(n_frames)]
+    poses, stats = pipe.run(raws, [i[0] for i in ins], [i[1] for i in ins], [i[2] for i in ins])
+    n_edges = len(pipe.ctx.posegraph_select(n_frames))
+    pipe.close()
+    dt = poses[:, 9:] - o_poses[:, 9:]
+    Rg = poses[:, :9].reshape(-1, 3, 3); Ro = o_poses[:, :9].reshape(-1, 3, 3)
+    ang = np.sqrt(((Rg - Ro) ** 2).sum((1, 2)) / 2.0)          # rotation angle of Rg^T Ro for small angles: |Rg - Ro|_F / sqrt(2)
+    return {"frames": n_frames, "poses": int(len(poses)), "lc_edges_gpu": int(n_edges), "lc_edges_oracle": int(o_edges),
+            "trans_rmse_m": float(np.sqrt((dt ** 2).sum(1).mean())), "rot_rmse_rad": float(np.sqrt((ang ** 2).mean())),
+            "max_abs_pose_entry": float(np.abs(poses - o_poses).max())}
 
 
 def main():
@@ -156,8 +173,10 @@ def main():
                        "parallelism": "frames+pairs sharded over %d rank(s), RCCL all-gather" % world},
             "roofline": roof, "breakdown_ms": breakdown, "work_per_step": work,
         }
-        if args.cpu_frames > 0:
-            out["cpu_baseline"] = cpu_baseline(sv, wl, min(args.cpu_frames, F))
+        if args.cpu_frames > 0 and world == 1:
+            nf = min(args.cpu_frames, F)
+            out["cpu_baseline"], o_poses, o_edges = cpu_baseline(sv, wl, nf)
+            out["parity_vs_oracle_on_cpu_sample"] = sample_parity(sv, nf, o_poses, o_edges, local_rank)
         print(json.dumps(out))
     pipe.close()
     if world > 1:
