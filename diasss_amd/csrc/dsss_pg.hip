@@ -1080,6 +1080,16 @@ struct sym_t {
     std::vector<long long> mapptr;
 };
 
+// host threads of the symbolic phase
+inline int sym_threads() { const unsigned hc = std::thread::hardware_concurrency(); return (int)std::min(8u, std::max(1u, hc)); }
+template <class F> void par_ranges(int n, int T, F fn)          // fn(t, lo, hi) over T contiguous ranges of [0, n)
+{
+    std::vector<std::thread> th;
+    for (int t = 1; t < T; ++t) th.emplace_back([&, t] { fn(t, (int)((long long)n * t / T), (int)((long long)n * (t + 1) / T)); });
+    fn(0, 0, (int)((long long)n / T));
+    for (auto& x : th) x.join();
+}
+
 // geometric nested dissection: recursive coordinate bisection with vertex separators taken from the lower half.
 // The order of a subtree is [A subtree][B subtree][separator]; A and B never touch, so the first PG_ND_PAR levels run
 // their two halves on two host threads, and the same tree of ranges later drives the parallel column-structure pass.
@@ -1138,16 +1148,19 @@ int nd_order(std::vector<int>& nodes, const nd_ctx& C, std::vector<int>& order, 
 
 // column structures of the range [lo, lo + size) of the elimination order described by tree node `t`, children merged
 // into parents (elimination tree built on the fly).  A column whose parent lies outside the range hands the
-// (parent, column) pair up to its caller.
+// (parent, column) pair up to its caller.  No per-column allocations: the row lists of one call go into that call's pool
+// (cref = pool, offset, length) and the children of a column are a linked list (kid_head / kid_next).
+struct cref { int pool, off, n; };
 struct cs_ctx {
     const int* adj_ptr; const int* adj_idx; const int* order; const int* perm; const std::vector<nd_tree>* pool;
-    std::vector<std::vector<int>>* cols; std::vector<std::vector<int>>* kids; int* parent;
+    std::vector<std::vector<int>>* pools; cref* cols; int* kid_head; int* kid_next; int* parent;
 };
 void col_structs(const cs_ctx& C, int t, int lo, int size, std::vector<std::pair<int, int>>& up, int depth)
 {
     const nd_tree nd = t >= 0 ? (*C.pool)[t] : nd_tree();
     int seq_lo = lo;
     const int hi = lo + size;
+    auto add_kid = [&](int par, int j) { C.kid_next[j] = C.kid_head[par]; C.kid_head[par] = j; };
     if (t >= 0 && nd.a >= 0 && nd.b >= 0) {
         const int sa = (*C.pool)[nd.a].size, sb = (*C.pool)[nd.b].size;
         std::vector<std::pair<int, int>> ua, ub;
@@ -1155,19 +1168,27 @@ void col_structs(const cs_ctx& C, int t, int lo, int size, std::vector<std::pair
         col_structs(C, nd.b, lo + sa, sb, ub, depth + 1);
         th.join();
         for (auto* u : { &ua, &ub })
-            for (auto& e : *u) { if (e.first < hi) (*C.kids)[e.first].push_back(e.second); else up.push_back(e); }
+            for (auto& e : *u) { if (e.first < hi) add_kid(e.first, e.second); else up.push_back(e); }
         seq_lo = lo + sa + sb;
     }
+    const int my_pool = t >= 0 ? t : (int)C.pools->size() - 1;
+    std::vector<int>& P = (*C.pools)[my_pool];
+    P.reserve((size_t)(hi - seq_lo) * 24);
+    std::vector<int> c;
     for (int j = seq_lo; j < hi; ++j) {
-        std::vector<int>& c = (*C.cols)[j];
+        c.clear();
         const int v = C.order[j];
         for (int q = C.adj_ptr[v]; q < C.adj_ptr[v + 1]; ++q) { const int pu = C.perm[C.adj_idx[q]]; if (pu > j) c.push_back(pu); }
-        for (int k : (*C.kids)[j]) { const std::vector<int>& ck = (*C.cols)[k]; for (size_t q = 1; q < ck.size(); ++q) if (ck[q] != j) c.push_back(ck[q]); }
+        for (int k = C.kid_head[j]; k >= 0; k = C.kid_next[k]) {
+            const cref ck = C.cols[k]; const int* d = (*C.pools)[ck.pool].data() + ck.off;
+            for (int q = 1; q < ck.n; ++q) if (d[q] != j) c.push_back(d[q]);
+        }
         std::sort(c.begin(), c.end()); c.erase(std::unique(c.begin(), c.end()), c.end());
-        c.insert(c.begin(), j);
-        if (c.size() > 1) {
-            C.parent[j] = c[1];
-            if (c[1] < hi) (*C.kids)[c[1]].push_back(j); else up.push_back({ c[1], j });
+        C.cols[j] = { my_pool, (int)P.size(), (int)c.size() + 1 };
+        P.push_back(j); P.insert(P.end(), c.begin(), c.end());
+        if (!c.empty()) {
+            C.parent[j] = c[0];
+            if (c[0] < hi) add_kid(c[0], j); else up.push_back({ c[0], j });
         }
     }
 }
@@ -1210,40 +1231,53 @@ void symbolic(int ns, const std::vector<std::pair<int, int>>& edges, int nchain,
     const auto q1 = tnow();
     S.perm.assign(ns, 0);
     for (int i = 0; i < ns; ++i) S.perm[order[i]] = i;
-    std::vector<std::vector<int>> cols(ns), kids(ns);
-    std::vector<int> parent(ns, -1);
+    std::vector<cref> cols(ns);
+    std::vector<int> parent(ns, -1), kid_head(ns, -1), kid_next(ns, -1);
+    std::vector<std::vector<int>> pools(pool.size() + 1);
     {
-        cs_ctx C{ adj_ptr.data(), adj_idx.data(), order.data(), S.perm.data(), &pool, &cols, &kids, parent.data() };
+        cs_ctx C{ adj_ptr.data(), adj_idx.data(), order.data(), S.perm.data(), &pool, &pools, cols.data(), kid_head.data(), kid_next.data(), parent.data() };
         std::vector<std::pair<int, int>> up;
         col_structs(C, root, 0, ns, up, 0);
     }
     const auto q2 = tnow();
     S.colptr.assign(ns + 1, 0);
-    for (int j = 0; j < ns; ++j) S.colptr[j + 1] = S.colptr[j] + (int)cols[j].size();
+    for (int j = 0; j < ns; ++j) S.colptr[j + 1] = S.colptr[j] + cols[j].n;
+    auto csz = [&](int j) { return S.colptr[j + 1] - S.colptr[j]; };
     S.rowidx.resize(S.colptr[ns]);
-    for (int j = 0; j < ns; ++j) std::copy(cols[j].begin(), cols[j].end(), S.rowidx.begin() + S.colptr[j]);
-    // row lists (transpose of the strictly lower structure), ascending k
+    // row lists (transpose of the strictly lower structure), ascending k.  Threads own ascending ranges of SOURCE columns
+    // with private histograms, so the entries of every target list still come out in ascending k.
+    const int T = sym_threads();
+    std::vector<std::vector<int>> hist(T, std::vector<int>(ns, 0));
+    par_ranges(ns, T, [&](int t, int lo, int hi) {
+        std::vector<int>& h = hist[t];
+        for (int k = lo; k < hi; ++k) {
+            const int* d = pools[cols[k].pool].data() + cols[k].off;
+            std::copy(d, d + cols[k].n, S.rowidx.begin() + S.colptr[k]);
+            for (int q = 1; q < cols[k].n; ++q) h[d[q]]++;
+        }
+    });
     S.rlptr.assign(ns + 1, 0);
-    for (int k = 0; k < ns; ++k) for (size_t q = 1; q < cols[k].size(); ++q) S.rlptr[cols[k][q] + 1]++;
-    for (int j = 0; j < ns; ++j) S.rlptr[j + 1] += S.rlptr[j];
-    S.rlcol.resize(S.rlptr[ns]); S.rlpos.resize(S.rlptr[ns]);
-    { std::vector<int> fill(S.rlptr.begin(), S.rlptr.end() - 1);
-      for (int k = 0; k < ns; ++k) for (size_t q = 1; q < cols[k].size(); ++q) { const int j = cols[k][q]; S.rlcol[fill[j]] = k; S.rlpos[fill[j]] = S.colptr[k] + (int)q; fill[j]++; } }
-    S.rlrow.resize(S.rlptr[ns]);
+    for (int j = 0; j < ns; ++j) { int tot = 0; for (int t = 0; t < T; ++t) { const int c = hist[t][j]; hist[t][j] = tot; tot += c; } S.rlptr[j + 1] = S.rlptr[j] + tot; }
+    S.rlcol.resize(S.rlptr[ns]); S.rlpos.resize(S.rlptr[ns]); S.rlrow.resize(S.rlptr[ns]);
+    par_ranges(ns, T, [&](int t, int lo, int hi) {
+        std::vector<int>& fill = hist[t];                       // offset of this thread's first entry inside every target list
+        for (int k = lo; k < hi; ++k)
+            for (int q = 1; q < csz(k); ++q) {
+                const int j = S.rowidx[S.colptr[k] + q], at = S.rlptr[j] + fill[j]++;
+                S.rlcol[at] = k; S.rlpos[at] = S.colptr[k] + (int)q; S.rlrow[at] = j;
+            }
+    });
     S.mapptr.assign(ns + 1, 0);
-    for (int j = 0; j < ns; ++j) {
-        for (int t = S.rlptr[j]; t < S.rlptr[j + 1]; ++t) S.rlrow[t] = j;
-        S.mapptr[j + 1] = S.mapptr[j] + (long long)(S.rlptr[j + 1] - S.rlptr[j]) * (long long)cols[j].size();
-    }
+    for (int j = 0; j < ns; ++j) S.mapptr[j + 1] = S.mapptr[j] + (long long)(S.rlptr[j + 1] - S.rlptr[j]) * (long long)csz(j);
     const auto q3 = tnow();
     // bottom subtrees -> bins (one workgroup each); the remaining "top" columns are level-scheduled
     std::vector<double> sub_cost(ns, 0);
     std::vector<char> sub_ok(ns, 0);
     const double BIN_COST = 6000;                           // ~ update-list iterations + 20 per column: about 1 ms of one workgroup
     for (int j = 0; j < ns; ++j) {
-        const int mj = (int)cols[j].size(), Tj = S.rlptr[j + 1] - S.rlptr[j];
+        const int mj = csz(j), Tj = S.rlptr[j + 1] - S.rlptr[j];
         double cst = Tj + 20.0; bool ok = mj <= 42;
-        for (int k : kids[j]) { cst += sub_cost[k]; ok = ok && sub_ok[k]; }
+        for (int k = kid_head[j]; k >= 0; k = kid_next[k]) { cst += sub_cost[k]; ok = ok && sub_ok[k]; }
         sub_cost[j] = cst; sub_ok[j] = ok && cst <= BIN_COST;
     }
     std::vector<int> root_of(ns, -1);                       // subtree root of every binned column
@@ -1270,7 +1304,7 @@ void symbolic(int ns, const std::vector<std::pair<int, int>>& edges, int nchain,
     for (int j = 0; j < ns; ++j) {
         if (sub_ok[j] || col_pan[j] >= 0) continue;
         int w = 1;
-        while (w < PG_PW && j + w < ns && !sub_ok[j + w] && parent[j + w - 1] == j + w && cols[j + w].size() + 1 == cols[j + w - 1].size()) ++w;
+        while (w < PG_PW && j + w < ns && !sub_ok[j + w] && parent[j + w - 1] == j + w && csz(j + w) + 1 == csz(j + w - 1)) ++w;
         const int p = (int)S.pan_first.size();
         S.pan_first.push_back(j); S.pan_w.push_back(w);
         for (int c = 0; c < w; ++c) col_pan[j + c] = p;
@@ -1281,7 +1315,7 @@ void symbolic(int ns, const std::vector<std::pair<int, int>>& edges, int nchain,
     for (int p = 0; p < npan; ++p) {
         int lv = 0;
         for (int c = 0; c < S.pan_w[p]; ++c)
-            for (int k : kids[S.pan_first[p] + c]) if (!sub_ok[k] && col_pan[k] != p) lv = std::max(lv, plevel[col_pan[k]] + 1);
+            for (int k = kid_head[S.pan_first[p] + c]; k >= 0; k = kid_next[k]) if (!sub_ok[k] && col_pan[k] != p) lv = std::max(lv, plevel[col_pan[k]] + 1);
         plevel[p] = lv; maxl = std::max(maxl, lv);
     }
     S.plvptr.assign(maxl + 2, 0);
@@ -1309,14 +1343,14 @@ void symbolic(int ns, const std::vector<std::pair<int, int>>& edges, int nchain,
     // or more levels ago (or in the subtree bins) and are accumulated on a second stream while level l-1 is still
     // being factorised; "near" sources are the panels of level l-1.  The list is reordered [far | near | own panel].
     S.tfar.assign(ns, 0);
-    {
+    par_ranges(ns, T, [&](int, int lo, int hi) {
         std::vector<std::pair<int, int>> nearv;
-        for (int j = 0; j < ns; ++j) {
+        for (int j = lo; j < hi; ++j) {
             if (col_pan[j] < 0) continue;
-            const int lj = plevel[col_pan[j]], b0 = S.rlptr[j], T = S.tlim[j];
+            const int lj = plevel[col_pan[j]], b0 = S.rlptr[j], Tn = S.tlim[j];
             nearv.clear();
             int wpos = b0;
-            for (int t = b0; t < b0 + T; ++t) {
+            for (int t = b0; t < b0 + Tn; ++t) {
                 const int k = S.rlcol[t];
                 const bool isnear = col_pan[k] >= 0 && plevel[col_pan[k]] == lj - 1;
                 if (isnear) nearv.push_back({ k, S.rlpos[t] });
@@ -1325,24 +1359,32 @@ void symbolic(int ns, const std::vector<std::pair<int, int>>& edges, int nchain,
             S.tfar[j] = wpos - b0;
             for (auto& e : nearv) { S.rlcol[wpos] = e.first; S.rlpos[wpos] = e.second; ++wpos; }
         }
-    }
+    });
     const auto q4 = tnow();
     // where the assembled blocks go
     auto find = [&](int row, int col) { const auto b = S.rowidx.begin() + S.colptr[col], e = S.rowidx.begin() + S.colptr[col + 1];
                                         return (int)(std::lower_bound(b, e, row) - S.rowidx.begin()); };
     S.diag_pos.resize(ns);
-    for (int k = 0; k < ns; ++k) S.diag_pos[k] = S.colptr[S.perm[k]];
     S.ch_pos.assign(std::max(ns - 1, 0), 0);
-    for (int k = 0; k + 1 < ns; ++k) {
-        const int pa = S.perm[k], pb = S.perm[k + 1];          // block S(k, k+1): rows k, cols k+1
-        S.ch_pos[k] = pa > pb ? (find(pa, pb) << 1) : ((find(pb, pa) << 1) | 1);
-    }
+    par_ranges(ns, T, [&](int, int lo, int hi) {
+        for (int k = lo; k < hi; ++k) {
+            S.diag_pos[k] = S.colptr[S.perm[k]];
+            if (k + 1 < ns) {
+                const int pa = S.perm[k], pb = S.perm[k + 1];          // block S(k, k+1): rows k, cols k+1
+                S.ch_pos[k] = pa > pb ? (find(pa, pb) << 1) : ((find(pb, pa) << 1) | 1);
+            }
+        }
+    });
     if (tv) fprintf(stderr, "[dsss pg symbolic] adjacency+ND %.1f ms, column structures %.1f ms, rowlists+map ptrs %.1f ms, bins+panels %.1f ms\n", tms(q0, q1), tms(q1, q2), tms(q2, q3), tms(q3, q4));
     S.lc_pos.resize(edges.size() - nchain);
-    for (size_t e = nchain; e < edges.size(); ++e) {
-        const int pa = S.perm[edges[e].first], pb = S.perm[edges[e].second];   // block H(a, b)
-        S.lc_pos[e - nchain] = pa > pb ? (find(pa, pb) << 1) : ((find(pb, pa) << 1) | 1);
-    }
+    par_ranges((int)(edges.size() - nchain), T, [&](int, int lo, int hi) {
+        for (int e2 = lo; e2 < hi; ++e2) {
+            const size_t e = (size_t)nchain + e2;
+            const int pa = S.perm[edges[e].first], pb = S.perm[edges[e].second];   // block H(a, b)
+            S.lc_pos[e2] = pa > pb ? (find(pa, pb) << 1) : ((find(pb, pa) << 1) | 1);
+        }
+    });
+    if (tv) fprintf(stderr, "[dsss pg symbolic] positions %.1f ms\n", tms(q4, tnow()));
 }
 
 struct pg_dev {
