@@ -1033,6 +1033,13 @@ __global__ __launch_bounds__(256) void pg_flag_compact_kernel(const int* __restr
         __syncthreads();
     }
 }
+// x, y of the separator poses (the coordinates the nested dissection bisects)
+__global__ __launch_bounds__(256) void pg_sep_xy_kernel(int ns, const int* __restrict__ sep_pose, const double* __restrict__ dr6, double* __restrict__ xy)
+{
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    if (k >= ns) return;
+    xy[2 * k] = dr6[(size_t)sep_pose[k] * 6 + 3]; xy[2 * k + 1] = dr6[(size_t)sep_pose[k] * 6 + 4];
+}
 // DR poses, odometry measurements and initial estimate (optimizer.cpp:150-200)
 __global__ __launch_bounds__(256) void pg_init_kernel(int n, const double* __restrict__ dr6, const double* __restrict__ normals, int add_noise,
                                                       pose_t* __restrict__ X, pose_t* __restrict__ meas)
@@ -1417,9 +1424,19 @@ struct pg_dev {
 
 void dsss_pg_free(dsss_ctx* c) { for (auto& ch : c->pg_chunks) hipFree(ch.first); c->pg_chunks.clear(); c->pg_chunk_cur = 0; c->pg_chunk_off = 0; }
 
-// batch LM over `total` poses (dr6: host, total x 6) with `ne` LC edges (host)
-static int pg_solve_impl(dsss_ctx* c, const double* dr6, int total, const dsss_lc_edge* edges, int ne, double* poses12, double* stats4, double* rpy6 = nullptr)
+// batch LM over `total` poses with `ne` LC edges (host).  The DR rows (total x 6) are either one host array (dr6) or,
+// with dr6 == NULL, the rows of frames 0 .. nframes-1 of the context: read on the host from the frames' pinned copies
+// (only the separator poses are looked at) and gathered on the device straight from the frames' device copies.
+static int pg_solve_impl(dsss_ctx* c, const double* dr6, int total, const dsss_lc_edge* edges, int ne, double* poses12, double* stats4, double* rpy6 = nullptr,
+                         int nframes = 0)
 {
+    std::vector<int> foff;
+    if (!dr6) { foff.assign(nframes + 1, 0); for (int f = 0; f < nframes; ++f) foff[f + 1] = foff[f] + c->frames[f].N; }
+    auto dr_row = [&](int i) -> const double* {
+        if (dr6) return dr6 + (size_t)i * 6;
+        const int f = (int)(std::upper_bound(foff.begin(), foff.end(), i) - foff.begin()) - 1;
+        return c->frames[f].h_pack + (size_t)(i - foff[f]) * 6;
+    };
     const int n = total;
     if (n < 2) DSSS_FAIL(c, DSSS_E_ARG, "pose graph needs at least 2 poses");
     const auto T0 = std::chrono::steady_clock::now();
@@ -1458,8 +1475,26 @@ static int pg_solve_impl(dsss_ctx* c, const double* dr6, int total, const dsss_l
     std::vector<std::pair<int, int>> redges;
     for (int k = 0; k + 1 < ns; ++k) redges.push_back({ k, k + 1 });
     for (int e = 0; e < ne; ++e) redges.push_back({ sidx[ea[e]], sidx[eb[e]] });
-    std::vector<double> cx(ns), cy(ns);
-    for (int k = 0; k < ns; ++k) { cx[k] = dr6[(size_t)sep_pose[k] * 6 + 3]; cy[k] = dr6[(size_t)sep_pose[k] * 6 + 4]; }
+    // device state
+    pg_dev dv;
+    int rc = DSSS_OK;
+#define TRY(x) do { rc = (x); if (rc) { dv.release(); return rc; } } while (0)
+    // DR rows on the device first: the separator coordinates for the ordering come back from there (host reads of the
+    // frames' pinned copies are slow), and the copies overlap with the rest of the host preparation
+    double* d_dr6; double* d_sxy; int* d_sep;
+    TRY(dv.alloc(c, &d_dr6, (size_t)n * 6)); TRY(dv.alloc(c, &d_sxy, (size_t)ns * 2)); TRY(dv.upload(c, &d_sep, sep_pose));
+    std::vector<double> sxy((size_t)ns * 2), cx(ns), cy(ns);
+    {
+        hipError_t e = hipSuccess;
+        if (dr6) e = hipMemcpyAsync(d_dr6, dr6, (size_t)n * 6 * sizeof(double), hipMemcpyHostToDevice, c->stream);
+        else for (int f = 0; f < nframes && e == hipSuccess; ++f)
+            e = hipMemcpyAsync(d_dr6 + (size_t)foff[f] * 6, c->frames[f].pose6, (size_t)c->frames[f].N * 6 * sizeof(double), hipMemcpyDeviceToDevice, c->stream);
+        if (e == hipSuccess) { hipLaunchKernelGGL(pg_sep_xy_kernel, dim3((ns + 255) / 256), dim3(256), 0, c->stream, ns, d_sep, d_dr6, d_sxy); e = hipGetLastError(); }
+        if (e == hipSuccess) e = hipMemcpyAsync(sxy.data(), d_sxy, sxy.size() * sizeof(double), hipMemcpyDeviceToHost, c->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);      // the library's stream does not synchronise with the null stream
+        if (e != hipSuccess) { dv.release(); HIPCHK(c, e); }
+        for (int k = 0; k < ns; ++k) { cx[k] = sxy[2 * (size_t)k]; cy[k] = sxy[2 * (size_t)k + 1]; }
+    }
     const double t_prep = ms_since(T0);
     const auto T1 = std::chrono::steady_clock::now();
     sym_t S;
@@ -1489,17 +1524,13 @@ static int pg_solve_impl(dsss_ctx* c, const double* dr6, int total, const dsss_l
         fprintf(stderr, "[dsss pg] poses %d  LC edges %d  separators %d  nnz(L) blocks %zu  etree levels %d  max column %d blocks  update map %lld  bins %d (%d cols)  panels %d\n", n, ne, ns, nnzL, nlev, maxcol, S.mapptr[ns], (int)S.binptr.size() - 1, (int)S.bincols.size(), (int)S.pan_first.size());
     }
 
-    // device state
-    pg_dev dv;
-    int rc = DSSS_OK;
-    pose_t *d_X, *d_Xn, *d_meas, *d_emeas; int *d_ea, *d_eb, *d_adj_ptr, *d_adj_edge, *d_sep, *d_perm;
+    pose_t *d_X, *d_Xn, *d_meas, *d_emeas; int *d_ea, *d_eb, *d_adj_ptr, *d_adj_edge, *d_perm;
     double *d_ew, *d_r, *d_Ji, *d_D, *d_C, *d_g, *d_delta, *d_E, *d_Dl, *d_gi, *d_sDL, *d_sDR, *d_sGL, *d_sGR, *d_sS, *d_L, *d_x, *d_part, *d_scal, *d_part2;
     int *d_colptr, *d_rowidx, *d_rlptr, *d_rlcol, *d_rlpos, *d_rlrow, *d_binptr, *d_bincols, *d_pan_first, *d_pan_w, *d_pan_lcol0, *d_plvpan, *d_tlim, *d_lvcols, *d_diag, *d_ch, *d_lc, *d_fail, *d_map; long long* d_mapptr;
     const int nf = n + ne, nblk = (nf + 255) / 256;
-#define TRY(x) do { rc = (x); if (rc) { dv.release(); return rc; } } while (0)
     TRY(dv.alloc(c, &d_X, n)); TRY(dv.alloc(c, &d_Xn, n)); TRY(dv.alloc(c, &d_meas, n)); TRY(dv.upload(c, &d_emeas, emeas));
     TRY(dv.upload(c, &d_ea, ea)); TRY(dv.upload(c, &d_eb, eb)); TRY(dv.upload(c, &d_ew, ew));
-    TRY(dv.upload(c, &d_adj_ptr, adj_ptr)); TRY(dv.upload(c, &d_adj_edge, adj_edge)); TRY(dv.upload(c, &d_sep, sep_pose)); TRY(dv.upload(c, &d_perm, S.perm));
+    TRY(dv.upload(c, &d_adj_ptr, adj_ptr)); TRY(dv.upload(c, &d_adj_edge, adj_edge)); TRY(dv.upload(c, &d_perm, S.perm));
     TRY(dv.alloc(c, &d_r, (size_t)nf * 6)); TRY(dv.alloc(c, &d_Ji, (size_t)nf * 36));
     TRY(dv.alloc(c, &d_D, (size_t)n * 36)); TRY(dv.alloc(c, &d_C, (size_t)n * 36)); TRY(dv.alloc(c, &d_g, (size_t)n * 6)); TRY(dv.alloc(c, &d_delta, (size_t)n * 6));
     TRY(dv.alloc(c, &d_E, (size_t)n * 36)); TRY(dv.alloc(c, &d_Dl, (size_t)n * 36)); TRY(dv.alloc(c, &d_gi, (size_t)n * 6));
@@ -1557,9 +1588,7 @@ static int pg_solve_impl(dsss_ctx* c, const double* dr6, int total, const dsss_l
         return DSSS_OK;
     };
     {   // initial values
-        double* d_dr6; double* d_norm = nullptr;
-        TRY(dv.alloc(c, &d_dr6, (size_t)n * 6));
-        HCK(hipMemcpyAsync(d_dr6, dr6, (size_t)n * 6 * sizeof(double), hipMemcpyHostToDevice, st));
+        double* d_norm = nullptr;
         if (c->pg.add_noise) {
             const long long need_pairs = 3LL * n;
             long long natt = (long long)(need_pairs * 1.32) + 4096;          // acceptance rate pi/4
@@ -1683,6 +1712,8 @@ static int pg_solve_impl(dsss_ctx* c, const double* dr6, int total, const dsss_l
             else break;
         }
     } while (iters < c->pg.max_iters && !((err <= 0) || ((cur - err) / cur <= c->pg.rel_tol) || ((cur - err) <= c->pg.abs_tol)) && std::isfinite(cur));
+    const auto T4 = std::chrono::steady_clock::now();
+    const double t_lm = ms_since(T3);
     if (poses12) {      // pose_t is 12 contiguous doubles (R row-major, t): straight into the caller's buffer
         static_assert(sizeof(pose_t) == 12 * sizeof(double), "pose_t layout");
         HCK(hipMemcpyAsync(poses12, d_X, (size_t)n * sizeof(pose_t), hipMemcpyDeviceToHost, st));
@@ -1696,8 +1727,8 @@ static int pg_solve_impl(dsss_ctx* c, const double* dr6, int total, const dsss_l
     HCK(hipStreamSynchronize(st));
     if (stats4) { stats4[0] = iters; stats4[1] = err0; stats4[2] = err; stats4[3] = lambda; }
     dv.release();
-    if (verbose) fprintf(stderr, "[dsss pg] LM iterations %d  factorisations %d  err %.6g -> %.6g | host prep %.1f ms, symbolic %.1f ms, alloc+upload %.1f ms, LM loop %.1f ms\n",
-                         iters, nfact, err0, err, t_prep, t_sym, t_up, ms_since(T3));
+    if (verbose) fprintf(stderr, "[dsss pg] LM iterations %d  factorisations %d  err %.6g -> %.6g | host prep %.1f ms, symbolic %.1f ms, alloc+upload %.1f ms, LM loop %.1f ms, download %.1f ms\n",
+                         iters, nfact, err0, err, t_prep, t_sym, t_up, t_lm, ms_since(T4));
 #undef TRY
 #undef HCK
     return DSSS_OK;
@@ -1719,6 +1750,61 @@ __global__ __launch_bounds__(256) void lc_select_kernel(const double* __restrict
     atomicMax(&slot[frame_off[t] + ping], key);
 }
 
+// flag of global pose g: it won a loop closure and that measurement scored > 0 (optimizer.cpp:234)
+__global__ __launch_bounds__(256) void lc_edge_flag_kernel(const unsigned long long* __restrict__ slot, int total, const int* __restrict__ kp7_off,
+                                                           const dsss_lc* __restrict__ lcs, int* __restrict__ flags)
+{
+    const int g = blockIdx.x * 256 + threadIdx.x;
+    if (g >= total) return;
+    const unsigned long long key = slot[g];
+    int f = 0;
+    if (key) {
+        const int p = (int)(key >> 32) - 1, k = (int)(0xffffffffu - (unsigned)(key & 0xffffffffu));
+        f = lcs[kp7_off[p] + k].score > 0;
+    }
+    flags[g] = f;
+}
+// edges in ascending target pose id (the reference's loop order), ordered compaction over blocks of 4096 poses
+__global__ __launch_bounds__(256) void lc_edge_compact_kernel(const int* __restrict__ flags, const int* __restrict__ bsum, const unsigned long long* __restrict__ slot,
+                                                              int total, const int* __restrict__ kp7_off, const double* __restrict__ kp7,
+                                                              const dsss_lc* __restrict__ lcs, const int* __restrict__ act_s, const int* __restrict__ frame_off,
+                                                              int cap, dsss_lc_edge* __restrict__ edges)
+{
+    __shared__ int s_w[4];
+    __shared__ int s_run;
+    const int i0 = blockIdx.x * 4096;
+    if (threadIdx.x == 0) s_run = bsum[blockIdx.x];
+    __syncthreads();
+    for (int c0 = 0; c0 < 4096; c0 += 256) {
+        const int g = i0 + c0 + threadIdx.x;
+        const int f = g < total ? flags[g] : 0;
+        const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+        int inc = f;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(inc, o, 64); if (lane >= o) inc += t; }
+        __syncthreads();
+        if (lane == 63) s_w[w] = inc;
+        __syncthreads();
+        int base = s_run;
+        for (int k = 0; k < w; ++k) base += s_w[k];
+        const int pos = base + inc - f;
+        if (f && pos < cap) {
+            const unsigned long long key = slot[g];
+            const int p = (int)(key >> 32) - 1, k = (int)(0xffffffffu - (unsigned)(key & 0xffffffffu));
+            const int i = kp7_off[p] + k;
+            dsss_lc_edge ed;
+            ed.a = frame_off[act_s[p]] + (int)kp7[(size_t)i * 7 + 0];
+            ed.b = g;
+            for (int q = 0; q < 12; ++q) ed.rel[q] = lcs[i].rel[q];
+            for (int q = 0; q < 6; ++q) ed.var[q] = lcs[i].var[q];
+            edges[pos] = ed;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) s_run += s_w[0] + s_w[1] + s_w[2] + s_w[3];
+        __syncthreads();
+    }
+}
+
 extern "C" {
 
 int dsss_posegraph_select(dsss_ctx* c, int nframes, dsss_lc_edge* edges, int cap, int* n_edges)
@@ -1738,37 +1824,31 @@ int dsss_posegraph_select(dsss_ctx* c, int nframes, dsss_lc_edge* edges, int cap
         // active pairs were listed in that order (they are: dsss_match_pairs keeps the caller's order)
         for (int p = 0; p < c->npairs; ++p)
             if (c->pair_s[p] >= nframes || c->pair_t[p] >= nframes) DSSS_FAIL(c, DSSS_E_ARG, "pair %d references a frame >= nframes", p);
-        unsigned long long* d_slot = nullptr; int* d_off = nullptr;
-        HIPCHK(c, hipMalloc(&d_slot, (size_t)total * sizeof(unsigned long long)));
-        HIPCHK(c, hipMalloc(&d_off, (nframes + 1) * sizeof(int)));
-        hipError_t e = hipMemsetAsync(d_slot, 0, (size_t)total * sizeof(unsigned long long), c->stream);
-        if (e == hipSuccess) e = hipMemcpyAsync(d_off, off.data(), (nframes + 1) * sizeof(int), hipMemcpyHostToDevice, c->stream);
-        if (e == hipSuccess) {
-            hipLaunchKernelGGL(lc_select_kernel, dim3((n + 255) / 256), dim3(256), 0, c->stream, c->kp7, n, c->kp7_pair, c->kp7_off, c->act_t, d_off, d_slot);
-            e = hipGetLastError();
-        }
-        std::vector<unsigned long long> slot(total);
-        std::vector<dsss_lc> lcs(n); std::vector<double> kp7((size_t)n * 7);
-        if (e == hipSuccess) e = hipMemcpyAsync(slot.data(), d_slot, (size_t)total * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream);
-        if (e == hipSuccess) e = hipMemcpyAsync(lcs.data(), c->lcs, (size_t)n * sizeof(dsss_lc), hipMemcpyDeviceToHost, c->stream);
-        if (e == hipSuccess) e = hipMemcpyAsync(kp7.data(), c->kp7, (size_t)n * 7 * sizeof(double), hipMemcpyDeviceToHost, c->stream);
-        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-        hipFree(d_slot); hipFree(d_off);
-        HIPCHK(c, e);
-        std::vector<int> act_s(c->nactive), act_t(c->nactive);
-        for (int p = 0; p < c->npairs; ++p) if (c->pair_active[p] >= 0) { act_s[c->pair_active[p]] = c->pair_s[p]; act_t[c->pair_active[p]] = c->pair_t[p]; }
-        for (int g = 0; g < total; ++g) {                       // ascending global target pose id == the reference's loop order
-            const unsigned long long key = slot[g];
-            if (!key) continue;
-            const int p = (int)(key >> 32) - 1, k = (int)(0xffffffffu - (unsigned)(key & 0xffffffffu));
-            const int i = c->h_kp7_off[p] + k;
-            if (!(lcs[i].score > 0)) continue;                  // :234
-            if (ne >= cap) DSSS_FAIL(c, DSSS_E_CAPACITY, "more than %d LC edges", cap);
-            dsss_lc_edge& ed = edges[ne++];
-            ed.a = off[act_s[p]] + (int)kp7[(size_t)i * 7 + 0];
-            ed.b = g;
-            memcpy(ed.rel, lcs[i].rel, sizeof ed.rel); memcpy(ed.var, lcs[i].var, sizeof ed.var);
-        }
+        // everything on the device: winner per target pose (atomicMax), score filter, ordered compaction; only the
+        // edge records come back.  Scratch comes from the solver arena (reset by the solve that follows).
+        pg_dev dv;
+        unsigned long long* d_slot; int *d_off, *d_flags, *d_bsum, *d_total; dsss_lc_edge* d_edges;
+        const int nb = (total + 4095) / 4096;
+        int rc = dv.alloc(c, &d_slot, (size_t)total); if (rc) return rc;
+        rc = dv.alloc(c, &d_off, (size_t)nframes + 1); if (rc) return rc;
+        rc = dv.alloc(c, &d_flags, (size_t)total); if (rc) return rc;
+        rc = dv.alloc(c, &d_bsum, (size_t)nb); if (rc) return rc;
+        rc = dv.alloc(c, &d_total, 1); if (rc) return rc;
+        rc = dv.alloc(c, &d_edges, (size_t)cap); if (rc) return rc;
+        hipStream_t st = c->stream;
+        HIPCHK(c, hipMemsetAsync(d_slot, 0, (size_t)total * sizeof(unsigned long long), st));
+        HIPCHK(c, hipMemcpyAsync(d_off, off.data(), (nframes + 1) * sizeof(int), hipMemcpyHostToDevice, st));
+        hipLaunchKernelGGL(lc_select_kernel, dim3((n + 255) / 256), dim3(256), 0, st, c->kp7, n, c->kp7_pair, c->kp7_off, c->act_t, d_off, d_slot);
+        hipLaunchKernelGGL(lc_edge_flag_kernel, dim3((total + 255) / 256), dim3(256), 0, st, d_slot, total, c->kp7_off, c->lcs, d_flags);
+        hipLaunchKernelGGL(pg_flag_blocksum_kernel, dim3(nb), dim3(256), 0, st, d_flags, (long long)total, d_bsum);
+        hipLaunchKernelGGL(pg_flag_scan_kernel, dim3(1), dim3(256), 0, st, d_bsum, nb, d_total);
+        hipLaunchKernelGGL(lc_edge_compact_kernel, dim3(nb), dim3(256), 0, st, d_flags, d_bsum, d_slot, total, c->kp7_off, c->kp7, c->lcs, c->act_s, d_off, cap, d_edges);
+        HIPCHK(c, hipGetLastError());
+        HIPCHK(c, hipMemcpyAsync(&ne, d_total, sizeof(int), hipMemcpyDeviceToHost, st));
+        HIPCHK(c, hipStreamSynchronize(st));
+        if (ne > cap) { dv.release(); DSSS_FAIL(c, DSSS_E_CAPACITY, "more than %d LC edges", cap); }
+        if (ne > 0) HIPCHK(c, hipMemcpy(edges, d_edges, (size_t)ne * sizeof(dsss_lc_edge), hipMemcpyDeviceToHost));
+        dv.release();
     }
     if (n_edges) *n_edges = ne;
     return DSSS_OK;
@@ -1788,18 +1868,24 @@ int dsss_posegraph_solve_edges(dsss_ctx* c, const double* dr6, int total, const 
 int dsss_posegraph_solve(dsss_ctx* c, int nframes, double* poses12, double* rpy6, double* stats4)
 {
     if (!c || nframes <= 0 || nframes > c->max_frames) return DSSS_E_ARG;
-    std::vector<double> dr;
+    const auto t0 = std::chrono::steady_clock::now();
+    auto ms = [&](std::chrono::steady_clock::time_point a) { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - a).count(); };
+    size_t total = 0;
     for (int f = 0; f < nframes; ++f) {
         if (!c->frames[f].has_geom) DSSS_FAIL(c, DSSS_E_STATE, "frame %d has no geometry", f);
-        dr.insert(dr.end(), c->frames[f].h_pack, c->frames[f].h_pack + (size_t)c->frames[f].N * 6);
+        total += (size_t)c->frames[f].N;
     }
-    const int total = (int)(dr.size() / 6);
     std::vector<dsss_lc_edge> edges((size_t)std::max(c->total_kp7, 1));
     int ne = 0;
+    const double t_dr = ms(t0);
+    const auto t1 = std::chrono::steady_clock::now();
     int rc = dsss_posegraph_select(c, nframes, edges.data(), (int)edges.size(), &ne);
     if (rc) return rc;
-    rc = pg_solve_impl(c, dr.data(), total, edges.data(), ne, poses12, stats4, rpy6);
+    const double t_sel = ms(t1);
+    const auto t2 = std::chrono::steady_clock::now();
+    rc = pg_solve_impl(c, nullptr, (int)total, edges.data(), ne, poses12, stats4, rpy6, nframes);
     if (rc) return rc;
+    if (getenv("DSSS_PG_VERBOSE")) fprintf(stderr, "[dsss pg] DR rows %.1f ms, LC selection %.1f ms, solve + download %.1f ms\n", t_dr, t_sel, ms(t2));
     return DSSS_OK;
 }
 
