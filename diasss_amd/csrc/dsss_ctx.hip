@@ -4,6 +4,8 @@
 #include "dsss_internal.h"
 #include <algorithm>
 #include <chrono>
+#include <thread>
+#include <atomic>
 #include <cstdlib>
 
 extern "C" {
@@ -95,6 +97,8 @@ void dsss_destroy(dsss_ctx* c)
     hipSetDevice(c->device);
     hipStreamSynchronize(c->stream);
     for (auto& f : c->frames) free_frame(f);
+    for (auto& G : c->gbatches) { hipFree(G.d); if (G.h) hipHostFree(G.h); if (G.ev) hipEventDestroy(G.ev); }
+    c->gbatches.clear();
     free_match(c); free_store(c);
     hipFree(c->lcs); hipFree(c->ex_scratch); hipFree(c->mt_aux);
     if (c->ex_pinned) hipHostFree(c->ex_pinned);
@@ -257,17 +261,18 @@ int dsss_frame_kp_geo(dsss_ctx* c, int id, int n)
 
 extern "C" {
 
-int dsss_frame_set(dsss_ctx* c, int id, const double* raw, int N, int M, const double* pose6, const double* alt,
-                   const double* grange)
+// dsss_frame_set in three steps so that dsss_frames_set can run the middle one (pure host copies into the pinned
+// staging areas, the bulk of the time) on several threads.
+static void release_gbatch(dsss_ctx* c, dsss_frame& f)
 {
-    if (!c) return DSSS_E_ARG;
+    if (f.gbatch >= 0) { c->gbatches[f.gbatch].refs--; f.gbatch = -1; f.pose6 = nullptr; f.alt = nullptr; f.gr = nullptr; f.h_geo = nullptr; }
+}
+static int frame_prepare(dsss_ctx* c, int id, int N, int M, const double* pose6, const double* alt, const double* grange)
+{
     if (id < 0 || id >= c->max_frames) DSSS_FAIL(c, DSSS_E_ARG, "frame id %d out of range [0,%d)", id, c->max_frames);
     if (N <= 0 || M < 4 || (M & 1) || !pose6 || !alt || !grange) DSSS_FAIL(c, DSSS_E_ARG, "bad frame geometry N=%d M=%d", N, M);
-    static const bool tv = getenv("DSSS_EX_VERBOSE") != nullptr;
-    const auto tt0 = std::chrono::steady_clock::now();
-    HIPCHK(c, hipSetDevice(c->device));
-    int rc = dsss_ensure_store(c); if (rc) return rc;
     dsss_frame& f = c->frames[id];
+    release_gbatch(c, f);
     if (f.N != N || f.M != M) { HIPCHK(c, hipStreamSynchronize(c->stream)); free_frame(f); }
     f.N = N; f.M = M;
     const size_t pack = (size_t)N * 6 + N + M / 2;
@@ -279,7 +284,14 @@ int dsss_frame_set(dsss_ctx* c, int id, const double* raw, int N, int M, const d
         HIPCHK(c, hipHostMalloc((void**)&f.h_pack, pack * sizeof(double), hipHostMallocDefault));
         f.pack_cap = pack;
     }
-    f.pose6 = f.d_pack; f.alt = f.d_pack + (size_t)N * 6; f.gr = f.alt + N;
+    f.pose6 = f.d_pack; f.alt = f.d_pack + (size_t)N * 6; f.gr = f.alt + N; f.h_geo = f.h_pack;
+    if (f.pack_ev) HIPCHK(c, hipEventSynchronize(f.pack_ev));        // the pinned staging area may still feed the previous upload
+    else HIPCHK(c, hipEventCreateWithFlags(&f.pack_ev, hipEventDisableTiming));
+    return DSSS_OK;
+}
+static hipError_t frame_fill(dsss_ctx* c, int id, double* dst_pack, const double* pose6, const double* alt, const double* grange)
+{
+    dsss_frame& f = c->frames[id];
     auto to_host = [&](double* dst, const double* src, size_t n) -> hipError_t {
         hipPointerAttribute_t at;
         const bool dev = (hipPointerGetAttributes(&at, src) == hipSuccess) && at.type == hipMemoryTypeDevice;
@@ -288,14 +300,20 @@ int dsss_frame_set(dsss_ctx* c, int id, const double* raw, int N, int M, const d
         memcpy(dst, src, n * sizeof(double));               // plain host memory: no runtime call
         return hipSuccess;
     };
-    if (f.pack_ev) HIPCHK(c, hipEventSynchronize(f.pack_ev));        // the pinned staging area may still feed the previous upload
-    else HIPCHK(c, hipEventCreateWithFlags(&f.pack_ev, hipEventDisableTiming));
-    HIPCHK(c, to_host(f.h_pack, pose6, (size_t)N * 6));
-    HIPCHK(c, to_host(f.h_pack + (size_t)N * 6, alt, (size_t)N));
-    HIPCHK(c, to_host(f.h_pack + (size_t)N * 7, grange, (size_t)(M / 2)));
-    HIPCHK(c, hipMemcpyAsync(f.d_pack, f.h_pack, pack * sizeof(double), hipMemcpyHostToDevice, c->stream));   // pinned: truly asynchronous
-    HIPCHK(c, hipEventRecord(f.pack_ev, c->stream));
-    const auto tt1 = std::chrono::steady_clock::now();
+    hipError_t e = to_host(dst_pack, pose6, (size_t)f.N * 6);
+    if (e == hipSuccess) e = to_host(dst_pack + (size_t)f.N * 6, alt, (size_t)f.N);
+    if (e == hipSuccess) e = to_host(dst_pack + (size_t)f.N * 7, grange, (size_t)(f.M / 2));
+    return e;
+}
+static int frame_submit(dsss_ctx* c, int id, const double* raw, bool own_upload)
+{
+    dsss_frame& f = c->frames[id];
+    const int N = f.N, M = f.M;
+    if (own_upload) {
+        const size_t pack = (size_t)N * 6 + N + M / 2;
+        HIPCHK(c, hipMemcpyAsync(f.d_pack, f.h_pack, pack * sizeof(double), hipMemcpyHostToDevice, c->stream));   // pinned: truly asynchronous
+        HIPCHK(c, hipEventRecord(f.pack_ev, c->stream));
+    }
     f.has_geom = true; f.has_feat = false; f.has_norm = false; f.nkp = 0;          // no synchronisation: the sources above live in the context
     if (raw) {
         hipPointerAttribute_t at;
@@ -309,22 +327,72 @@ int dsss_frame_set(dsss_ctx* c, int id, const double* raw, int N, int M, const d
         }
         f.has_raw = true;
     } else f.has_raw = false;
-    const auto tt2 = std::chrono::steady_clock::now();
-    rc = dsss_frame_geo_bbox(c, id);
-    if (tv && id < 3) fprintf(stderr, "[dsss frame_set %d] geometry %.1f us, raw %.1f us, bbox launch %.1f us\n", id,
-                              std::chrono::duration<double, std::micro>(tt1 - tt0).count(), std::chrono::duration<double, std::micro>(tt2 - tt1).count(),
-                              std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - tt2).count());
-    return rc;
+    return dsss_frame_geo_bbox(c, id);
+}
+
+int dsss_frame_set(dsss_ctx* c, int id, const double* raw, int N, int M, const double* pose6, const double* alt,
+                   const double* grange)
+{
+    if (!c) return DSSS_E_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    int rc = dsss_ensure_store(c); if (rc) return rc;
+    rc = frame_prepare(c, id, N, M, pose6, alt, grange); if (rc) return rc;
+    HIPCHK(c, frame_fill(c, id, c->frames[id].h_pack, pose6, alt, grange));
+    return frame_submit(c, id, raw, true);
 }
 
 int dsss_frames_set(dsss_ctx* c, int n, const int* ids, const double* const* raw, const int* N, const int* M,
                     const double* const* pose6, const double* const* alt, const double* const* grange)
 {
     if (!c || n < 0 || (n > 0 && (!ids || !N || !M || !pose6 || !alt || !grange))) return DSSS_E_ARG;
+    if (n == 0) return DSSS_OK;
     const auto t0 = std::chrono::steady_clock::now();
+    HIPCHK(c, hipSetDevice(c->device));
+    int rc = dsss_ensure_store(c); if (rc) return rc;
+    // the geometry of the whole call goes through ONE pinned staging area and ONE upload (200 separate 116 KB copies
+    // cost 3-4 ms of copy-engine latency at C3); the frames point into the batch's device buffer
+    std::vector<size_t> off(n + 1, 0);
     for (int i = 0; i < n; ++i) {
-        const int rc = dsss_frame_set(c, ids[i], raw ? raw[i] : nullptr, N[i], M[i], pose6[i], alt[i], grange[i]);
-        if (rc) return rc;
+        const int id = ids[i];
+        if (id < 0 || id >= c->max_frames) DSSS_FAIL(c, DSSS_E_ARG, "frame id %d out of range [0,%d)", id, c->max_frames);
+        if (N[i] <= 0 || M[i] < 4 || (M[i] & 1) || !pose6[i] || !alt[i] || !grange[i]) DSSS_FAIL(c, DSSS_E_ARG, "bad frame geometry N=%d M=%d", N[i], M[i]);
+        dsss_frame& f = c->frames[id];
+        release_gbatch(c, f);
+        if (f.N != N[i] || f.M != M[i]) { HIPCHK(c, hipStreamSynchronize(c->stream)); free_frame(f); }
+        f.N = N[i]; f.M = M[i];
+        off[i + 1] = off[i] + (((size_t)N[i] * 7 + M[i] / 2 + 63) & ~(size_t)63);
+    }
+    const size_t total = off[n];
+    int b = -1;
+    for (size_t k = 0; k < c->gbatches.size(); ++k)
+        if (c->gbatches[k].refs == 0 && c->gbatches[k].cap >= total && (b < 0 || c->gbatches[k].cap < c->gbatches[b].cap)) b = (int)k;
+    if (b < 0) {
+        for (size_t k = 0; k < c->gbatches.size() && b < 0; ++k) if (c->gbatches[k].refs == 0) b = (int)k;     // grow an idle one
+        if (b < 0) { c->gbatches.push_back(dsss_geo_batch()); b = (int)c->gbatches.size() - 1; }
+        dsss_geo_batch& G = c->gbatches[b];
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        hipFree(G.d); if (G.h) hipHostFree(G.h);
+        G.d = nullptr; G.h = nullptr; G.cap = 0;
+        HIPCHK(c, hipMalloc(&G.d, total * sizeof(double)));
+        HIPCHK(c, hipHostMalloc((void**)&G.h, total * sizeof(double), hipHostMallocDefault));
+        G.cap = total;
+        if (!G.ev) HIPCHK(c, hipEventCreateWithFlags(&G.ev, hipEventDisableTiming));
+    }
+    dsss_geo_batch& G = c->gbatches[b];
+    HIPCHK(c, hipEventSynchronize(G.ev));                   // the staging area may still feed its previous upload
+    static const int T_env = getenv("DSSS_FS_THREADS") ? atoi(getenv("DSSS_FS_THREADS")) : 0;
+    const int T = T_env > 0 ? T_env : (n >= 16 ? 4 : 1);
+    std::vector<hipError_t> errs(T, hipSuccess);
+    auto work = [&](int t) { for (int i = t; i < n; i += T) { const hipError_t e = frame_fill(c, ids[i], G.h + off[i], pose6[i], alt[i], grange[i]); if (e != hipSuccess) errs[t] = e; } };
+    { std::vector<std::thread> th; for (int t = 1; t < T; ++t) th.emplace_back(work, t); work(0); for (auto& x : th) x.join(); }
+    for (int t = 0; t < T; ++t) HIPCHK(c, errs[t]);
+    HIPCHK(c, hipMemcpyAsync(G.d, G.h, total * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipEventRecord(G.ev, c->stream));
+    for (int i = 0; i < n; ++i) {
+        dsss_frame& f = c->frames[ids[i]];
+        f.gbatch = b; G.refs++;
+        f.pose6 = G.d + off[i]; f.alt = f.pose6 + (size_t)f.N * 6; f.gr = f.alt + f.N; f.h_geo = G.h + off[i];
+        rc = frame_submit(c, ids[i], raw ? raw[i] : nullptr, false); if (rc) return rc;
     }
     if (getenv("DSSS_EX_VERBOSE")) fprintf(stderr, "[dsss frames_set] %d frames in %.1f us\n", n, std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count());
     return DSSS_OK;

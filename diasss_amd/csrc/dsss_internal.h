@@ -24,6 +24,8 @@ struct dsss_frame {
     double* d_pack = nullptr;         // device copy, pose6 / alt / gr point into it
     size_t pack_cap = 0;
     hipEvent_t pack_ev = nullptr;     // recorded after the upload of h_pack: the staging area is reusable once it fired
+    const double* h_geo = nullptr;    // host view of [pose6 | alt | gr]: h_pack, or a slice of a dsss_frames_set batch
+    int gbatch = -1;                  // batch of dsss_frames_set the geometry lives in, -1: own d_pack / h_pack
     uint8_t* mask = nullptr;          // device N x M
     uint8_t* lvl[DSSS_MAX_LEVELS] = {nullptr};  // image pyramid, lvl[0] = normalised image
     int lrows[DSSS_MAX_LEVELS] = {0}, lcols[DSSS_MAX_LEVELS] = {0};
@@ -34,6 +36,9 @@ struct dsss_frame {
     // FAST candidates of the last extraction, per level (host, for the stage tap)
     std::vector<float> cand_x[DSSS_MAX_LEVELS], cand_y[DSSS_MAX_LEVELS], cand_r[DSSS_MAX_LEVELS];
 };
+
+// geometry of a whole dsss_frames_set call: one pinned staging area, one device buffer, ONE upload
+struct dsss_geo_batch { double* d = nullptr; double* h = nullptr; size_t cap = 0; int refs = 0; hipEvent_t ev = nullptr; };
 
 struct dsss_prof {
     bool on = false;
@@ -69,6 +74,7 @@ struct dsss_ctx {
     // extraction scratch (grown on demand)
     void* ex_scratch = nullptr; size_t ex_scratch_bytes = 0;
     void* ex_pinned = nullptr; size_t ex_pinned_bytes = 0;
+    std::vector<dsss_geo_batch> gbatches;
     // pose-graph solver arena: device chunks kept between solves (dsss_pg.hip), bump-allocated, reset per solve
     std::vector<std::pair<void*, size_t>> pg_chunks; size_t pg_chunk_cur = 0, pg_chunk_off = 0;
     // matcher state

@@ -1435,7 +1435,7 @@ static int pg_solve_impl(dsss_ctx* c, const double* dr6, int total, const dsss_l
     auto dr_row = [&](int i) -> const double* {
         if (dr6) return dr6 + (size_t)i * 6;
         const int f = (int)(std::upper_bound(foff.begin(), foff.end(), i) - foff.begin()) - 1;
-        return c->frames[f].h_pack + (size_t)(i - foff[f]) * 6;
+        return c->frames[f].h_geo + (size_t)(i - foff[f]) * 6;
     };
     const int n = total;
     if (n < 2) DSSS_FAIL(c, DSSS_E_ARG, "pose graph needs at least 2 poses");
