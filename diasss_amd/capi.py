@@ -287,9 +287,11 @@ class Context:
         self._chk(self.L.dsss_posegraph_select(self.h, nframes, _ptr(edges), cap, C.byref(n)), "dsss_posegraph_select")
         return edges[:n.value].copy()
 
-    def posegraph_solve(self, nframes, total):
-        poses = np.zeros((total, 12), np.float64); rpy = np.zeros((total, 6), np.float64); stats = np.zeros(4, np.float64)
-        self._chk(self.L.dsss_posegraph_solve(self.h, nframes, _ptr(poses), _ptr(rpy), _ptr(stats)), "dsss_posegraph_solve")
+    def posegraph_solve(self, nframes, total, want_rpy=True):
+        """poses: total x 12 (R row-major, t); rpy: the reference's trajectory rows (roll pitch yaw x y z) or None"""
+        poses = np.empty((total, 12), np.float64); stats = np.zeros(4, np.float64)
+        rpy = np.empty((total, 6), np.float64) if want_rpy else None
+        self._chk(self.L.dsss_posegraph_solve(self.h, nframes, _ptr(poses), _ptr(rpy) if want_rpy else None, _ptr(stats)), "dsss_posegraph_solve")
         return poses, rpy, stats
 
     def posegraph_solve_edges(self, dr6, edges):

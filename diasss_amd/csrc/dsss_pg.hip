@@ -1280,7 +1280,7 @@ void symbolic(int ns, const std::vector<std::pair<int, int>>& edges, int nchain,
     // bottom subtrees -> bins (one workgroup each); the remaining "top" columns are level-scheduled
     std::vector<double> sub_cost(ns, 0);
     std::vector<char> sub_ok(ns, 0);
-    const double BIN_COST = 6000;                           // ~ update-list iterations + 20 per column: about 1 ms of one workgroup
+    static const double BIN_COST = getenv("DSSS_PG_BIN_COST") ? atof(getenv("DSSS_PG_BIN_COST")) : 1000;   // ~ update-list iterations + 20 per column; measured optimum at C3 (800-1500): about 0.2 ms of one workgroup
     for (int j = 0; j < ns; ++j) {
         const int mj = csz(j), Tj = S.rlptr[j + 1] - S.rlptr[j];
         double cst = Tj + 20.0; bool ok = mj <= 42;

@@ -102,7 +102,7 @@ class Pipeline:
     def optimize(self):
         total = int(sum(self.N))
         if self.world == 1:
-            poses, rpy, stats = self.ctx.posegraph_solve(self.F, total)
+            poses, _, stats = self.ctx.posegraph_solve(self.F, total, want_rpy=False)   # est_poses; the rpy rows are only for SaveTrajactoryAll
             self.n_edges = None
             return poses, stats
         edges = self.ctx.posegraph_select(self.F, cap=max(total, 1))
