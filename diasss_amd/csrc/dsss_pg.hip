@@ -373,7 +373,8 @@ __global__ __launch_bounds__(256) void pg_factor_acc_kernel(const int* __restric
                                                             const int* __restrict__ rlptr, const int* __restrict__ rlpos,
                                                             const long long* __restrict__ mapptr, const int* __restrict__ upd_map,
                                                             double* __restrict__ Lvals, double* __restrict__ part, int col_stride,
-                                                            const int* __restrict__ rlcol, double* __restrict__ x, const int* __restrict__ tbeg, const int* __restrict__ tend)
+                                                            const int* __restrict__ rlcol, double* __restrict__ x, const int* __restrict__ tbeg, const int* __restrict__ tend,
+                                                            const double* __restrict__ fold_part, int fold_nsl)
 {
     __shared__ double s_Ljk[PG_TCH * 36];
     __shared__ double s_yk[PG_TCH * 6];
@@ -408,12 +409,29 @@ __global__ __launch_bounds__(256) void pg_factor_acc_kernel(const int* __restric
         if (act)
             pg_acc_rows(mp + (size_t)tc * m + q, m, tn, Lvals, r, s_Ljk, acc);
     }
+    // an in-place launch (one slice) can also fold the partial sums another, sliced launch left for this level: slice
+    // order fixed, after this launch's own sum (same arithmetic as pg_fold_kernel running behind it)
     if (rhs) {
-        if (nsl == 1) x[(size_t)j * 6 + rs_] -= accy;
-        else part[((size_t)blockIdx.x * nsl + sl) * col_stride + (size_t)col_stride - 8 + rs_] = accy;
+        if (nsl == 1) {
+            double v = x[(size_t)j * 6 + rs_] - accy;
+            for (int s2 = 0; s2 < fold_nsl; ++s2) v -= fold_part[((size_t)blockIdx.x * fold_nsl + s2) * col_stride + (size_t)col_stride - 8 + rs_];
+            x[(size_t)j * 6 + rs_] = v;
+        } else part[((size_t)blockIdx.x * nsl + sl) * col_stride + (size_t)col_stride - 8 + rs_] = accy;
     }
     if (!act) return;
-    if (nsl == 1) { for (int s = 0; s < 6; ++s) Lvals[(size_t)(c0 + q) * 36 + r * 6 + s] -= acc[s]; }
+    if (nsl == 1) {
+        double* row = Lvals + (size_t)(c0 + q) * 36 + r * 6;
+        double v[6];
+#pragma unroll
+        for (int s = 0; s < 6; ++s) v[s] = row[s] - acc[s];
+        for (int s2 = 0; s2 < fold_nsl; ++s2) {
+            const double* o = fold_part + ((size_t)blockIdx.x * fold_nsl + s2) * col_stride + (size_t)idx * 6;
+#pragma unroll
+            for (int s = 0; s < 6; ++s) v[s] -= o[s];
+        }
+#pragma unroll
+        for (int s = 0; s < 6; ++s) row[s] = v[s];
+    }
     else { double* o = part + ((size_t)blockIdx.x * nsl + sl) * col_stride + (size_t)idx * 6; for (int s = 0; s < 6; ++s) o[s] = acc[s]; }
 }
 // fold the per-slice partial sums of pg_factor_acc_kernel into the column blocks and the right-hand side, slice order
@@ -1650,7 +1668,7 @@ static int pg_solve_impl(dsss_ctx* c, const double* dr6, int total, const dsss_l
                     const int ncl = S.lvptr[l + 1] - S.lvptr[l], stride = lv_chunks[l] * 256 * 6 + 8;
                     if (ahead) hipStreamWaitEvent(sf, l >= 2 ? ev_trsm[(l - 2) & 1] : ev_bins, 0);
                     hipLaunchKernelGGL(pg_factor_acc_kernel, dim3(ncl, lv_chunks[l], lv_slices[l]), dim3(256), 0, sf, d_lvcols + S.lvptr[l], d_colptr, d_rlptr, d_rlpos,
-                                       d_mapptr, d_map, d_L, d_part2 + (size_t)(l & 1) * part2_doubles, stride, d_rlcol, d_x, (const int*)nullptr, d_tfar);
+                                       d_mapptr, d_map, d_L, d_part2 + (size_t)(l & 1) * part2_doubles, stride, d_rlcol, d_x, (const int*)nullptr, d_tfar, (const double*)nullptr, 0);
                     if (ahead) hipEventRecord(ev_far[l & 1], sf);
                 };
                 if (ahead && nlev > 0) { hipEventRecord(ev_bins, st); launch_far(0); if (nlev > 1) launch_far(1); }
@@ -1661,11 +1679,14 @@ static int pg_solve_impl(dsss_ctx* c, const double* dr6, int total, const dsss_l
                     {   dsss_scope s2(c, DSSS_K_PG_ACC, fl_acc[l]);
                         if (!ahead) launch_far(l);
                         else if (lv_far[l]) hipStreamWaitEvent(st, ev_far[l & 1], 0);
+                        // near updates in place; the same launch folds the far slices of this level (pg_fold_kernel only
+                        // runs when a level has far slices but no near updates at all)
                         if (lv_near[l])
                             hipLaunchKernelGGL(pg_factor_acc_kernel, dim3(ncl, lv_chunks[l], 1), dim3(256), 0, st, d_lvcols + S.lvptr[l], d_colptr, d_rlptr, d_rlpos,
-                                               d_mapptr, d_map, d_L, d_part2, stride, d_rlcol, d_x, d_tfar, d_tlim);
+                                               d_mapptr, d_map, d_L, d_part2, stride, d_rlcol, d_x, d_tfar, d_tlim,
+                                               (const double*)(d_part2 + (size_t)(l & 1) * part2_doubles), nsl > 1 ? nsl : 0);
                     }
-                    if (nsl > 1) hipLaunchKernelGGL(pg_fold_kernel, dim3(ncl, lv_chunks[l]), dim3(256), 0, st, d_lvcols + S.lvptr[l], d_colptr, d_L, d_part2 + (size_t)(l & 1) * part2_doubles, nsl, stride, d_x);
+                    if (nsl > 1 && !lv_near[l]) hipLaunchKernelGGL(pg_fold_kernel, dim3(ncl, lv_chunks[l]), dim3(256), 0, st, d_lvcols + S.lvptr[l], d_colptr, d_L, d_part2 + (size_t)(l & 1) * part2_doubles, nsl, stride, d_x);
                     { dsss_scope s3(c, DSSS_K_PG_DIAG, fl_diag[l]);
                       hipLaunchKernelGGL(pg_panel_diag_kernel, dim3(npl), dim3(256), PG_DIAG_LDS, st, d_plvpan + S.plvptr[l], d_pan_first, d_pan_w, d_colptr, d_L, d_x, d_fail, d_Wsw, d_Wrow); }
                     {   dsss_scope s4(c, DSSS_K_PG_TRSM, plv_rowchunks[l] > 0 ? fl_trsm[l] : 0.0);
