@@ -148,7 +148,7 @@ def main():
         dt = float(t.item())
 
     # ---- per-kernel timing pass (HIP events on the library's stream), outside the timed region
-    breakdown, roof, work = None, None, None
+    breakdown, roof, roof_all, work = None, None, None, None
     if not args.no_roofline:
         pipe.ctx.profile(True); pipe.ctx.profile_reset()
         pipe.run(raws, poses, alts, grs)
@@ -156,7 +156,7 @@ def main():
         prof = pipe.ctx.profile_get()
         pipe.ctx.profile(False)
         breakdown = {k: round(v[0], 3) for k, v in prof.items() if v[1] > 0}
-        roof = roofline(prof, wl, len(mine))
+        roof, roof_all = roofline(prof, args.workload)
         work = {k: ("%.3g flop" if k in FLOP_SLOTS else "%.3g B") % v[2] for k, v in prof.items() if v[1] > 0 and v[2] > 0}
     nkp = [pipe.ctx.features_get(f)[0].shape[0] for f in mine[:8]]
     tot_rows, tot_kp7 = pipe.ctx.match_total()
@@ -171,7 +171,7 @@ def main():
                        "kp_per_frame": int(np.mean(nkp)) if nkp else 0, "matches_rank0": tot_rows, "lc_problems_rank0": tot_kp7,
                        "pg_stats": [float(s) for s in stats] if stats is not None else None,
                        "parallelism": "frames+pairs sharded over %d rank(s), RCCL all-gather" % world},
-            "roofline": roof, "breakdown_ms": breakdown, "work_per_step": work,
+            "roofline": roof, "roofline_all_kernels": roof_all, "breakdown_ms": breakdown, "work_per_step": work,
         }
         if args.cpu_frames > 0 and world == 1:
             nf = min(args.cpu_frames, F)
@@ -190,21 +190,54 @@ F64_PEAK_TFLOPS = 78.6   # MI355X FP64 vector/matrix peak (AMD spec sheet; MI355
 FLOP_SLOTS = {"pg_acc", "pg_diag", "pg_trsm", "pg_bwd"}
 
 
-def roofline(prof, wl, n_local_frames):
-    """roofline of the single kernel with the largest accumulated GPU time (umbrella slots excluded)"""
+# profile slot -> kernel name in the rocprofv3 tables under profiles/
+SLOT_KERNEL = {"row_reduce": "row_reduce_kernel", "normalize": "normalize_kernel", "pyramid": "resize_kernel", "fast": "fast_cells_kernel",
+               "desc": "orient_desc_kernel", "quadtree": "quadtree_kernel", "lc": "lc_kernel", "match": "match_nn_kernel",
+               "pg_acc": "pg_factor_acc_kernel", "pg_diag": "pg_panel_diag_kernel", "pg_trsm": "pg_panel_trsm_kernel", "pg_bwd": "pg_panel_bwd_kernel"}
+NOTES = {"pg_acc": "f64 VALU (fused multiply-add), bandwidth-shaped: L(i,k) is re-read once per target column; not on the matrix cores yet",
+         "pg_diag": "96 dependent pivots per panel: latency-bound; panel solve, trailing update and inverse on v_mfma_f64_16x16x4_f64",
+         "pg_trsm": "v_mfma_f64_16x16x4_f64 GEMM against the explicit panel inverse", "pg_bwd": "latency-bound matvec per panel"}
+
+
+def pmc_traffic(workload):
+    """HBM bytes per launch from the committed rocprofv3 PMC passes (FETCH_SIZE corrected x2 for gfx950, + WRITE_SIZE):
+    profiles/r01_pmc_hbm_traffic_<workload>.csv, written by tools/pmc_summary.py"""
+    path = os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic_%s.csv" % workload)
+    out = {}
+    if os.path.exists(path):
+        import csv
+        with open(path) as fh:
+            for r in csv.DictReader(fh):
+                out[r["kernel"]] = float(r["fetch_bytes_per_launch_corrected_x2"]) + float(r["write_bytes_per_launch"])
+    return out
+
+
+def one_roofline(slot, ms, n, work, traffic):
+    per_launch_s = ms * 1e-3 / n
+    tr = traffic.get(SLOT_KERNEL.get(slot, ""))
+    if slot in FLOP_SLOTS:
+        ach = work / n / per_launch_s / 1e12
+        r = {"kernel": slot, "bound": "mfma", "achieved": ach, "peak": F64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / F64_PEAK_TFLOPS}
+    else:
+        ach = work / n / per_launch_s / 1e9
+        r = {"kernel": slot, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS}
+    r.update({"traffic": tr, "launches": n, "avg_launch_us": per_launch_s * 1e6})
+    if slot in NOTES:
+        r["note"] = NOTES[slot]
+    return r
+
+
+def roofline(prof, workload):
+    """roofline of the single kernel with the largest accumulated GPU time (umbrella slots excluded), and of every other
+    kernel that has an algorithmic work figure"""
     cand = {k: v for k, v in prof.items() if k not in ("pg", "pg_subtree", "k19") and v[1] > 0 and v[2] > 0}
     if not cand:
-        return None
+        return None, None
+    traffic = pmc_traffic(workload)
     best = max(cand, key=lambda k: cand[k][0])
-    ms, n, work = cand[best]
-    per_launch_s = ms * 1e-3 / n
-    if best in FLOP_SLOTS:
-        ach = work / n / per_launch_s / 1e12
-        return {"kernel": best, "bound": "mfma", "achieved": ach, "peak": F64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / F64_PEAK_TFLOPS,
-                "traffic": None, "launches": n, "avg_launch_us": per_launch_s * 1e6, "note": "f64; the kernel does not use MFMA yet"}
-    ach = work / n / per_launch_s / 1e9
-    return {"kernel": best, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-            "traffic": None, "launches": n, "avg_launch_us": per_launch_s * 1e6}
+    allr = {k: one_roofline(k, *cand[k], traffic) for k in cand}
+    return allr[best], {k: {"achieved": round(v["achieved"], 3), "unit": v["unit"], "frac": round(v["frac"], 4), "avg_launch_us": round(v["avg_launch_us"], 1)}
+                        for k, v in allr.items()}
 
 
 if __name__ == "__main__":

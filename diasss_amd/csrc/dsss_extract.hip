@@ -748,17 +748,17 @@ static int extract_frames(dsss_ctx* c, const int* ids, int n, bool keep_taps)
         HIPCHK(c, hipMemsetAsync(d_errs, 0, sizeof(int) * nb, st));
         { dsss_scope sc(c, DSSS_K_ROW_REDUCE, 8.0 * w_tot);
           hipLaunchKernelGGL(row_reduce_kernel, dim3((maxN + 3) / 4, nb), dim3(256), 0, st, d_exf); }
-        { dsss_scope sc(c, DSSS_K_PRE_MISC, 1.0 * w_tot);
+        { dsss_scope sc(c, DSSS_K_PRE_MISC, 1.0 * w_tot, 2);
           hipLaunchKernelGGL(final_reduce_kernel, dim3(nb), dim3(64), 0, st, d_exf, (double)(float)c->mp.factor);
           hipLaunchKernelGGL(mask_init_kernel, dim3((unsigned)((max_tot + 255) / 256), nb), dim3(256), 0, st, d_exf, c->mp.width, c->mp.side, (double)c->mp.side * 0.6); }
         { dsss_scope sc(c, DSSS_K_NORMALIZE, 9.0 * w_tot);
           hipLaunchKernelGGL(normalize_kernel, dim3((unsigned)((max_tot / 4 + 256) / 256), nb), dim3(256), 0, st, d_exf, c->mp.r); }
-        { dsss_scope sc(c, DSSS_K_PYRAMID, (1.906 + 2.74) * w_tot);
+        { dsss_scope sc(c, DSSS_K_PYRAMID, (1.906 + 2.74) * w_tot, std::max(max_levels - 1, 1));
           for (int l = 1; l < max_levels; ++l)
               hipLaunchKernelGGL(resize_kernel, dim3((max_cols[l] + 255) / 256, max_rows[l], nb), dim3(256), 0, st, d_exf, l); }
         { dsss_scope sc(c, DSSS_K_FAST, 2.906 * w_tot);
           hipLaunchKernelGGL(fast_cells_kernel, dim3(max_cells, nb), dim3(256), 0, st, d_exf, c->op.ini_th, c->op.min_th); }
-        { dsss_scope sc(c, DSSS_K_FAST_COMPACT);
+        { dsss_scope sc(c, DSSS_K_FAST_COMPACT, 0, 2);
           hipLaunchKernelGGL(scan_counts_kernel, dim3(nb), dim3(256), 0, st, d_exf);
           hipLaunchKernelGGL(gather_cand_kernel, dim3(max_cells, nb), dim3(64), 0, st, d_exf); }
         { dsss_scope sc(c, DSSS_K_QUADTREE);

@@ -105,8 +105,8 @@ struct dsss_ctx {
 
 // kernel-family timing with HIP events on the context stream (dsss_profile_*)
 struct dsss_scope {
-    dsss_ctx* c; int k; hipEvent_t e0 = nullptr, e1 = nullptr;     // own event pair: scopes may nest (pose-graph solve)
-    dsss_scope(dsss_ctx* c_, int k_, double work = 0) : c(c_), k(k_) {
+    dsss_ctx* c; int k; int nl; hipEvent_t e0 = nullptr, e1 = nullptr;     // own event pair: scopes may nest (pose-graph solve)
+    dsss_scope(dsss_ctx* c_, int k_, double work = 0, int launches = 1) : c(c_), k(k_), nl(launches) {
         if (c->prof.on) { c->prof.work[k] += work; hipEventCreate(&e0); hipEventCreate(&e1); hipEventRecord(e0, c->stream); }
     }
     ~dsss_scope() {
@@ -114,7 +114,7 @@ struct dsss_scope {
             hipEventRecord(e1, c->stream);
             hipEventSynchronize(e1);
             float ms = 0; hipEventElapsedTime(&ms, e0, e1);
-            c->prof.ms[k] += ms; c->prof.launches[k] += 1;
+            c->prof.ms[k] += ms; c->prof.launches[k] += nl;
             hipEventDestroy(e0); hipEventDestroy(e1);
         }
     }

@@ -1676,7 +1676,7 @@ static int pg_solve_impl(dsss_ctx* c, const double* dr6, int total, const dsss_l
                     const int ncl = S.lvptr[l + 1] - S.lvptr[l], npl = S.plvptr[l + 1] - S.plvptr[l];
                     const int stride = lv_chunks[l] * 256 * 6 + 8;
                     const int nsl = lv_far[l] ? lv_slices[l] : 1;
-                    {   dsss_scope s2(c, DSSS_K_PG_ACC, fl_acc[l]);
+                    {   dsss_scope s2(c, DSSS_K_PG_ACC, fl_acc[l], (lv_far[l] ? 1 : 0) + (lv_near[l] ? 1 : 0));
                         if (!ahead) launch_far(l);
                         else if (lv_far[l]) hipStreamWaitEvent(st, ev_far[l & 1], 0);
                         // near updates in place; the same launch folds the far slices of this level (pg_fold_kernel only
