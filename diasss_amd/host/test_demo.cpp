@@ -1,7 +1,10 @@
 // diasss_amd/host/test_demo.cpp -- the driver loop of /root/reference/src/diasss2.cpp:83-101 against the drop-in
-// classes.  Input parsing differs: Util::LoadInputData (OpenCV FileStorage XML, util.cpp:45-213) is out of scope, so
-// frames come from the flat binary dumps written by tools/export_survey.py:
-//     <dir>/frame_%03d.bin = int32 N, int32 M, f64 raw[N*M], f64 pose[N*6], f64 alt[N], f64 gr[M/2]
+// classes.  Two input forms:
+//   test_demo --image DIR --pose DIR --altitude DIR --groundrange DIR [--annotation DIR] [--min-overlap X]
+//       the reference's own layout (diasss2.cpp:33-66) through Util::LoadInputData: OpenCV FileStorage XML / YAML + txt
+//   test_demo <dir with frame_%03d.bin> [min_overlap]
+//       flat binary dumps written by tools/export_survey.py:
+//       frame_%03d.bin = int32 N, int32 M, f64 raw[N*M], f64 pose[N*6], f64 alt[N], f64 gr[M/2]
 #include <cstdio>
 #include <iostream>
 #include <string>
@@ -14,10 +17,28 @@ using namespace Diasss;
 
 int main(int argc, char** argv)
 {
-    if (argc < 2) { std::cout << "usage: test_demo <dir with frame_%03d.bin> [min_overlap]" << std::endl; return 0; }
-    float MIN_OVERLAP = argc > 2 ? (float)atof(argv[2]) : 0.4f;                  // diasss2.cpp:28
+    if (argc < 2) { std::cout << "usage: test_demo <dir with frame_%03d.bin> [min_overlap]  |  test_demo --image D --pose D --altitude D --groundrange D [--annotation D]" << std::endl; return 0; }
+    float MIN_OVERLAP = 0.4f;                                                    // diasss2.cpp:28
     std::vector<Frame> test_frames;
-    for (int i = 0;; ++i) {
+    const bool folders = std::string(argv[1]).rfind("--", 0) == 0;
+    if (folders) {
+        std::string dI, dP, dA, dG, dN;
+        for (int a = 1; a + 1 < argc; a += 2) {
+            const std::string k = argv[a], v = argv[a + 1];
+            if (k == "--image") dI = v; else if (k == "--pose") dP = v; else if (k == "--altitude") dA = v;
+            else if (k == "--groundrange") dG = v; else if (k == "--annotation") dN = v; else if (k == "--min-overlap") MIN_OVERLAP = (float)atof(v.c_str());
+        }
+        if (dI.empty() || dP.empty() || dA.empty() || dG.empty()) { std::cout << "Please provide the image, pose, altitude and groundrange folders..." << std::endl; return 0; }
+        std::vector<cv::Mat> vmImgs, vmPoses, vmAnnos; std::vector<std::vector<double>> vvAltts, vvGranges;
+        Util::LoadInputData(dI, dP, dA, dG, dN, vmImgs, vmPoses, vvAltts, vvGranges, vmAnnos);
+        if (vmPoses.size() != vmImgs.size() || vvAltts.size() != vmImgs.size() || vvGranges.size() != vmImgs.size()) { std::cout << "folder sizes differ" << std::endl; return 1; }
+        for (size_t i = 0; i < vmImgs.size(); ++i) {                             // diasss2.cpp:83-86
+            cv::Mat anno = i < vmAnnos.size() ? vmAnnos[i] : cv::Mat();
+            test_frames.push_back(Frame((int)i, vmImgs[i], vmPoses[i], vvAltts[i], vvGranges[i], anno));
+            std::cout << "frame " << i << ": " << vmImgs[i].rows << " x " << vmImgs[i].cols << ", " << test_frames.back().kps.size() << " keypoints" << std::endl;
+        }
+    } else if (argc > 2) MIN_OVERLAP = (float)atof(argv[2]);
+    for (int i = 0; !folders; ++i) {
         char path[512];
         snprintf(path, sizeof path, "%s/frame_%03d.bin", argv[1], i);
         FILE* f = fopen(path, "rb");

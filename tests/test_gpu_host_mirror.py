@@ -44,3 +44,23 @@ def test_test_demo_end_to_end(orc, tmp_path):
     dy = np.angle(np.exp(1j * (est[:, 2] - yaw)))
     assert np.abs(dy).max() < 2e-6
     assert np.abs(drf[:, 3:] - np.concatenate([f["pose"] for f in fr])[:, 3:]).max() < 1e-8
+
+
+def test_test_demo_reference_input_layout(tmp_path):
+    """the same survey through the reference's own input layout (five folders, FileStorage XML + txt, Util::LoadInputData)
+    must give the same trajectory file as the flat dumps: the loader is exact, so the files agree to the last digit"""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import export_survey
+    F, N, M = 3, 700, 480
+    sv = export_survey.export(str(tmp_path / "frames"), F, N, M, seed=77)
+    d = export_survey.export_reference_layout(str(tmp_path / "ref"), [(sv.frame(f).numpy(),) + tuple(sv.inputs(f)) + (None,) for f in range(F)])
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "diasss_amd", "host")])
+    exe = os.path.join(ROOT, "diasss_amd", "host", "test_demo")
+    outs = []
+    for name, args in (("a", [str(tmp_path / "frames"), "0.0"]),
+                       ("b", ["--image", d["image"], "--pose", d["pose"], "--altitude", d["altitude"], "--groundrange", d["groundrange"], "--min-overlap", "0.0"])):
+        od = tmp_path / name; od.mkdir()
+        out = subprocess.run([exe] + args, env=dict(os.environ, DSSS_OUT_DIR=str(od)), capture_output=True, text=True, timeout=300)
+        assert out.returncode == 0, out.stdout + out.stderr
+        outs.append(np.loadtxt(od / "est_poses_all.txt"))
+    assert outs[0].shape == (F * N, 6) and (outs[0] == outs[1]).all()

@@ -5,6 +5,7 @@
 import ctypes as C
 import os
 import re
+import sys
 import numpy as np
 import pytest
 
@@ -54,3 +55,40 @@ def test_host_quadtree_matches_oracle(orc, seed, n, w, h, quota):
                                        16, 16 + w, 16, 16 + h, quota, k_p.ctypes.data_as(C.c_void_p), C.byref(npk))
     assert rc == 0 and npk.value == no
     assert (k_p[:no] == k_o[:no]).all()
+
+
+def test_load_input_data_reference_layout(tmp_path):
+    """Util::LoadInputData (util.cpp:45-213; SURVEY.md 8f N2): five folders, FileStorage XML and YAML matrices + text
+    columns, files in name order, exact f64 round trip -- host code only, built with g++"""
+    import subprocess
+    import numpy as np
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import export_survey as E
+    host = os.path.join(ROOT, "diasss_amd", "host")
+    subprocess.check_call(["make", "-C", host, "-s", "load_check"])
+    rng = np.random.default_rng(5)
+    for yaml in (False, True):
+        frames = []
+        for f in range(3):
+            N, M = 40 + 7 * f, 32 + 2 * f
+            raw = rng.rayleigh(1.0, (N, M)) * 10 ** rng.uniform(-3, 3)
+            raw[0, 0] = 1.0 / 3.0; raw[-1, -1] = 123456789.123456789e-7
+            pose = rng.standard_normal((N, 6)); alt = 9 + rng.standard_normal(N); gr = 0.05 * np.arange(M // 2)
+            anno = rng.integers(0, 1000, (5 + f, 7)).astype(np.int32)
+            frames.append((raw, pose, alt, gr, anno))
+        d = E.export_reference_layout(str(tmp_path / ("yaml" if yaml else "xml")), frames, yaml=yaml)
+        out = subprocess.check_output([os.path.join(host, "load_check"), d["image"], d["pose"], d["altitude"], d["groundrange"], d["annotation"]], text=True)
+        got = {}
+        for ln in out.splitlines():
+            t = ln.split()
+            if t[0] in ("@img", "@pose", "@alt", "@gr"):
+                got[(t[0][1:], int(t[1]))] = (int(t[2]), int(t[3]), float.fromhex(t[4]), float.fromhex(t[5]), float.fromhex(t[6]))
+            elif t[0] == "@anno":
+                got[("anno", int(t[1]))] = (int(t[2]), int(t[3]), int(t[4]), int(t[6]))
+        for f, (raw, pose, alt, gr, anno) in enumerate(frames):
+            for kind, a in (("img", raw), ("pose", pose), ("alt", alt), ("gr", gr)):
+                r, c, s_, first, last = got[(kind, f)]
+                assert (r, c) == ((a.shape + (1,))[:2])
+                assert first == a.reshape(-1)[0] and last == a.reshape(-1)[-1]          # exact round trip of the text form
+                assert abs(s_ - float(np.sum(a.astype(np.longdouble)))) <= 1e-9 * max(1.0, abs(s_))
+            assert got[("anno", f)] == (anno.shape[0], anno.shape[1], int(anno.sum()), 4)   # CV_32S
