@@ -43,8 +43,9 @@ def merge_edges(edge_lists):
 
 
 class Pipeline:
-    def __init__(self, F, device=0, rank=0, world=1, dist=None, min_overlap=None, ctx=None):
+    def __init__(self, F, device=0, rank=0, world=1, dist=None, min_overlap=None, ctx=None, force_collectives=False):
         self.F, self.rank, self.world, self.dist = F, rank, world, dist
+        self.collectives = world > 1 or (force_collectives and dist is not None)   # the 1-rank RCCL test drives the same code path
         self.ctx = ctx if ctx is not None else capi.Context(max_frames=F, device=device)   # ctx injection: sharding tests
         self.min_overlap = min_overlap      # None: dense all-pairs (BASELINE configs); 0.4 reproduces diasss2.cpp:28,93
 
@@ -66,7 +67,7 @@ class Pipeline:
     def extract(self):
         mine = shard_frames(self.F, self.rank, self.world)
         self.ctx.extract_many(mine)
-        if self.world > 1:
+        if self.collectives:
             self._allgather_features(mine)
 
     def _allgather_features(self, mine):
@@ -83,8 +84,8 @@ class Pipeline:
         if dev == "cuda":
             torch.cuda.synchronize()      # the library reads `recv` on its own HIP stream: order it after the RCCL collective
         for r in range(self.world):
-            if r == self.rank:
-                continue
+            if r == self.rank and self.world > 1:
+                continue                   # (a 1-rank group unpacks its own records: exercises the device-pointer path)
             for k, f in enumerate(shard_frames(self.F, r, self.world)):
                 self.ctx.features_unpack(f, recv[r * per + k])
 
@@ -101,7 +102,7 @@ class Pipeline:
     # ---- stage 3: pose graph
     def optimize(self):
         total = int(sum(self.N))
-        if self.world == 1:
+        if not self.collectives:
             poses, _, stats = self.ctx.posegraph_solve(self.F, total, want_rpy=False)   # est_poses; the rpy rows are only for SaveTrajactoryAll
             self.n_edges = None
             return poses, stats

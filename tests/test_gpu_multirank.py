@@ -57,3 +57,37 @@ def test_two_ranks_equal_single_rank():
         assert stats[0] == ref_stats[0]
         assert np.abs(out - ref).max() < 1e-9
     assert (res[0][1] == res[1][1]).all()          # replicated solve is bit-identical across ranks
+
+
+def _rccl_worker(port, q):
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    from diasss_amd.pipeline import Pipeline
+    F, raws, poses, alts, grs = _survey()
+    pipe = Pipeline(F, device=0, rank=0, world=1, dist=dist, force_collectives=True)
+    out, stats = pipe.run(raws, poses, alts, grs)
+    q.put((out, stats, pipe.n_edges))
+    pipe.close()
+    dist.destroy_process_group()
+
+
+def test_rccl_single_rank_collectives_path():
+    """backend "nccl" (RCCL) with one rank on the one GPU: the feature records and LC edges go through
+    all_gather_into_tensor on DEVICE tensors (pack / unpack with device pointers), result equal to the plain path"""
+    from diasss_amd.pipeline import Pipeline
+    F, raws, poses, alts, grs = _survey()
+    pipe = Pipeline(F, device=0)
+    ref, ref_stats = pipe.run(raws, poses, alts, grs)
+    pipe.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    pr = ctx.Process(target=_rccl_worker, args=(29700 + os.getpid() % 1000, q))
+    pr.start()
+    out, stats, n_edges = q.get(timeout=300)
+    pr.join(timeout=60)
+    assert n_edges > 10 and stats[0] == ref_stats[0]
+    assert np.abs(out - ref).max() < 1e-9
