@@ -589,6 +589,7 @@ static int get_geom(dsss_ctx* c, int N, int M, level_geom** out)
     auto it = g_geoms.find({ c, k });
     if (it == g_geoms.end()) {
         std::unique_ptr<level_geom> g(new level_geom());
+        if (N >= 65536 || M >= 65536) DSSS_FAIL(c, DSSS_E_ARG, "frames of 65536 or more pings / bins are not supported (quadtree keys pack 16-bit coordinates)");
         build_geom(c->op, N, M, *g);
         for (int l = 0; l < g->nlevels; ++l)
             if (g->rows[l] < 2 * EDGE_T + 31 || g->cols[l] < 2 * EDGE_T + 31)
@@ -640,7 +641,7 @@ static ex_layout make_layout(int N, const level_geom& g, int kcap)
     L.counts = take(sizeof(int) * ncells); L.offs = take(sizeof(int) * (ncells + 1));
     L.cand = take(sizeof(uint32_t) * (size_t)ncells * g.cell_cap);
     L.xs = take(sizeof(float) * L.cand_cap); L.ys = take(sizeof(float) * L.cand_cap); L.rs = take(sizeof(float) * L.cand_cap);
-    L.keys0 = take(sizeof(int) * L.cand_cap); L.keys1 = take(sizeof(int) * L.cand_cap);
+    L.keys0 = take(sizeof(unsigned long long) * L.cand_cap); L.keys1 = take(sizeof(unsigned long long) * L.cand_cap);
     for (int l = 0; l < DSSS_MAX_LEVELS; ++l) {
         L.list_cap[l] = 4 * g.quota[l] + 128; L.pool_cap[l] = 16 * g.quota[l] + 1024;
         L.work[l] = l < g.nlevels ? take(sizeof(int) * ((size_t)8 * L.pool_cap[l] + (size_t)10 * L.list_cap[l])) : 0;
@@ -732,7 +733,7 @@ static int extract_frames(dsss_ctx* c, const int* ids, int n, bool keep_taps)
                 q.offs = e.offs; q.cell_begin = g.cell_begin[l]; q.cell_end = g.cell_begin[l + 1];
                 q.xs = e.xs; q.ys = e.ys; q.rs = e.rs;
                 q.W = (g.cols[l] - EDGE_T + 3) - (EDGE_T - 3); q.H = (g.rows[l] - EDGE_T + 3) - (EDGE_T - 3); q.quota = g.quota[l];
-                q.keys0 = (int*)(S + L.keys0); q.keys1 = (int*)(S + L.keys1); q.work = (int*)(S + L.work[l]);
+                q.keys0 = (unsigned long long*)(S + L.keys0); q.keys1 = (unsigned long long*)(S + L.keys1); q.work = (int*)(S + L.work[l]);
                 q.list_cap = L.list_cap[l]; q.pool_cap = L.pool_cap[l];
                 q.out_idx = (int*)(S + L.out_idx) + (size_t)l * L.out_cap; q.out_n = (int*)(S + L.out_n) + l; q.out_cap = L.out_cap;
                 q.err = d_errs + s;

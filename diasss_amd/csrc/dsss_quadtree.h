@@ -9,7 +9,7 @@ struct qt_inst {                 // one (frame, level)
     int cell_begin, cell_end;    // cells of this level
     const float *xs, *ys, *rs;   // candidates of the frame, reference order
     int W, H, quota;             // maxBorderX - minBorderX, maxBorderY - minBorderY, mnFeaturesPerLevel[level]
-    int *keys0, *keys1;          // frame-wide ping-pong key arrays (candidate capacity each)
+    unsigned long long *keys0, *keys1;   // frame-wide ping-pong key arrays (candidate capacity each); key = y << 48 | x << 32 | candidate index
     int* work;                   // 8*pool_cap + 10*list_cap ints
     int list_cap, pool_cap;
     int* out_idx; int* out_n; int out_cap;

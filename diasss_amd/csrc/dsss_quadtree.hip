@@ -37,26 +37,31 @@ __device__ inline int qt_block_scan(int v, int* total, int* s_w)
 // one; cnt[0..3] = keys of n1..n4 (top-left, top-right, bottom-left, bottom-right).  The key -> coordinate loads are
 // dependent global loads, so a wave classifies four chunks of 64 keys per trip to keep several of them in flight.
 #define QT_ILP 4
-__device__ inline void qt_classify4(const int* __restrict__ src, int beg, int end, int b, int lane, const float* __restrict__ xs,
-                                    const float* __restrict__ ys, float mx, float my, int* c, int* k)
+// A key carries the candidate's coordinates (integers: FAST cell offset + position in the cell) next to its index, so
+// DivideNode streams the key segment and never gathers xs / ys:  key = y << 48 | x << 32 | index.
+typedef unsigned long long qkey;
+#define QT_NOKEY (~0ull)
+__device__ inline qkey qt_make_key(int idx, float x, float y) { return ((qkey)(unsigned)(int)y << 48) | ((qkey)((unsigned)(int)x & 0xffffu) << 32) | (qkey)(unsigned)idx; }
+__device__ inline int qt_key_idx(qkey k) { return (int)(unsigned)(k & 0xffffffffull); }
+__device__ inline void qt_classify4(const qkey* __restrict__ src, int beg, int end, int b, int lane, float mx, float my, int* c, qkey* k)
 {
 #pragma unroll
-    for (int u = 0; u < QT_ILP; ++u) { const int i = b + u * 64 + lane; k[u] = i < end ? src[beg + i] : -1; }
-    float x[QT_ILP], y[QT_ILP];
+    for (int u = 0; u < QT_ILP; ++u) { const int i = b + u * 64 + lane; k[u] = i < end ? src[beg + i] : QT_NOKEY; }
 #pragma unroll
-    for (int u = 0; u < QT_ILP; ++u) { x[u] = k[u] >= 0 ? xs[k[u]] : 0.f; y[u] = k[u] >= 0 ? ys[k[u]] : 0.f; }
-#pragma unroll
-    for (int u = 0; u < QT_ILP; ++u) { const bool left = x[u] < mx, top = y[u] < my; c[u] = k[u] >= 0 ? (left ? (top ? 0 : 2) : (top ? 1 : 3)) : -1; }
+    for (int u = 0; u < QT_ILP; ++u) {
+        const float x = (float)(int)((k[u] >> 32) & 0xffffull), y = (float)(int)(k[u] >> 48);
+        const bool left = x < mx, top = y < my;
+        c[u] = k[u] != QT_NOKEY ? (left ? (top ? 0 : 2) : (top ? 1 : 3)) : -1;
+    }
 }
 // counts of the four classes over keys [lo, hi) of the node (one wave)
-__device__ inline void qt_count_range(const qnode& P, const int* __restrict__ src, int lo, int hi, const float* __restrict__ xs,
-                                      const float* __restrict__ ys, float mx, float my, int* cnt)
+__device__ inline void qt_count_range(const qnode& P, const qkey* __restrict__ src, int lo, int hi, float mx, float my, int* cnt)
 {
     const int lane = threadIdx.x & 63;
     int c0 = 0, c1 = 0, c2 = 0, c3 = 0;
     for (int b = lo; b < hi; b += 64 * QT_ILP) {
-        int c[QT_ILP], k[QT_ILP];
-        qt_classify4(src, P.kbeg, hi, b, lane, xs, ys, mx, my, c, k);
+        int c[QT_ILP]; qkey k[QT_ILP];
+        qt_classify4(src, P.kbeg, hi, b, lane, mx, my, c, k);
 #pragma unroll
         for (int u = 0; u < QT_ILP; ++u) {
             c0 += __popcll(__ballot(c[u] == 0)); c1 += __popcll(__ballot(c[u] == 1)); c2 += __popcll(__ballot(c[u] == 2)); c3 += __popcll(__ballot(c[u] == 3));
@@ -65,15 +70,15 @@ __device__ inline void qt_count_range(const qnode& P, const int* __restrict__ sr
     cnt[0] = c0; cnt[1] = c1; cnt[2] = c2; cnt[3] = c3;
 }
 // stable scatter of keys [lo, hi) given the destination offset of each class for this range (one wave)
-__device__ inline void qt_scatter_range(const qnode& P, const int* __restrict__ src, int* __restrict__ dst, int lo, int hi,
-                                        const float* __restrict__ xs, const float* __restrict__ ys, float mx, float my, const int* off)
+__device__ inline void qt_scatter_range(const qnode& P, const qkey* __restrict__ src, qkey* __restrict__ dst, int lo, int hi,
+                                        float mx, float my, const int* off)
 {
     const int lane = threadIdx.x & 63;
     int r0 = off[0], r1 = off[1], r2 = off[2], r3 = off[3];
     const unsigned long long below = (1ull << lane) - 1ull;
     for (int b = lo; b < hi; b += 64 * QT_ILP) {
-        int c[QT_ILP], k[QT_ILP];
-        qt_classify4(src, P.kbeg, hi, b, lane, xs, ys, mx, my, c, k);
+        int c[QT_ILP]; qkey k[QT_ILP];
+        qt_classify4(src, P.kbeg, hi, b, lane, mx, my, c, k);
 #pragma unroll
         for (int u = 0; u < QT_ILP; ++u) {
             const unsigned long long m0 = __ballot(c[u] == 0), m1 = __ballot(c[u] == 1), m2 = __ballot(c[u] == 2), m3 = __ballot(c[u] == 3);
@@ -86,31 +91,29 @@ __device__ inline void qt_scatter_range(const qnode& P, const int* __restrict__ 
     }
 }
 // one node, one wave
-__device__ inline void qt_divide_wave(const qnode& P, const float* __restrict__ xs, const float* __restrict__ ys,
-                                      int* __restrict__ keys0, int* __restrict__ keys1, int* cnt)
+__device__ inline void qt_divide_wave(const qnode& P, qkey* __restrict__ keys0, qkey* __restrict__ keys1, int* cnt)
 {
-    const int* src = P.buf ? keys1 : keys0;
-    int* dst = P.buf ? keys0 : keys1;
+    const qkey* src = P.buf ? keys1 : keys0;
+    qkey* dst = P.buf ? keys0 : keys1;
     const float mx = (float)(P.x0 + (int)ceilf((float)(P.x1 - P.x0) / 2));
     const float my = (float)(P.y0 + (int)ceilf((float)(P.y1 - P.y0) / 2));
-    qt_count_range(P, src, 0, P.kcnt, xs, ys, mx, my, cnt);
+    qt_count_range(P, src, 0, P.kcnt, mx, my, cnt);
     const int off[4] = { 0, cnt[0], cnt[0] + cnt[1], cnt[0] + cnt[1] + cnt[2] };
-    qt_scatter_range(P, src, dst, 0, P.kcnt, xs, ys, mx, my, off);
+    qt_scatter_range(P, src, dst, 0, P.kcnt, mx, my, off);
 }
 // one node, the whole workgroup (the first passes have fewer nodes than waves, and those nodes hold most of the keys):
 // every wave takes a contiguous quarter of the segment; s_cnt[wave][class] carries the counts between the two passes
-__device__ inline void qt_divide_block(const qnode& P, const float* __restrict__ xs, const float* __restrict__ ys,
-                                       int* __restrict__ keys0, int* __restrict__ keys1, int* cnt, int (*s_cnt)[4])
+__device__ inline void qt_divide_block(const qnode& P, qkey* __restrict__ keys0, qkey* __restrict__ keys1, int* cnt, int (*s_cnt)[4])
 {
-    const int* src = P.buf ? keys1 : keys0;
-    int* dst = P.buf ? keys0 : keys1;
+    const qkey* src = P.buf ? keys1 : keys0;
+    qkey* dst = P.buf ? keys0 : keys1;
     const float mx = (float)(P.x0 + (int)ceilf((float)(P.x1 - P.x0) / 2));
     const float my = (float)(P.y0 + (int)ceilf((float)(P.y1 - P.y0) / 2));
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int q = ((P.kcnt + 3) / 4 + 63) & ~63;
     const int lo = min(wv * q, P.kcnt), hi = min(lo + q, P.kcnt);
     int mine[4];
-    qt_count_range(P, src, lo, hi, xs, ys, mx, my, mine);
+    qt_count_range(P, src, lo, hi, mx, my, mine);
     if (lane == 0) { s_cnt[wv][0] = mine[0]; s_cnt[wv][1] = mine[1]; s_cnt[wv][2] = mine[2]; s_cnt[wv][3] = mine[3]; }
     __syncthreads();
     int off[4], run = 0;
@@ -121,7 +124,7 @@ __device__ inline void qt_divide_block(const qnode& P, const float* __restrict__
         for (int w = 0; w < 4; ++w) { const int t = s_cnt[w][c]; if (w < wv) before += t; tot += t; }
         off[c] = run + before; cnt[c] = tot; run += tot;
     }
-    qt_scatter_range(P, src, dst, lo, hi, xs, ys, mx, my, off);
+    qt_scatter_range(P, src, dst, lo, hi, mx, my, off);
     __syncthreads();
 }
 
@@ -150,7 +153,7 @@ __global__ __launch_bounds__(256) void quadtree_kernel(const qt_inst* __restrict
     int* out = I.out_idx; int* out_n = I.out_n;
     if (n <= 0) { if (threadIdx.x == 0) *out_n = 0; return; }
     const int cap = I.list_cap, pool_cap = I.pool_cap, N = I.quota;
-    int* keys0 = I.keys0 + base; int* keys1 = I.keys1 + base;        // frame-wide key arrays, this level's segment
+    qkey* keys0 = I.keys0 + base; qkey* keys1 = I.keys1 + base;      // frame-wide key arrays, this level's segment
     qnode* pool = reinterpret_cast<qnode*>(I.work);
     int* listA = reinterpret_cast<int*>(pool + pool_cap); int* listB = listA + cap;
     int* parents = listB + cap; int* expv = parents + cap; int* order = expv + cap; int* flags = order + cap; int* pcnt = flags + cap;
@@ -161,7 +164,7 @@ __global__ __launch_bounds__(256) void quadtree_kernel(const qt_inst* __restrict
     if (nIni < 1) nIni = 1;
     if (nIni > 32) nIni = 32;
     const float hX = (float)I.W / nIni;
-    if (nIni == 1) { for (int i = threadIdx.x; i < n; i += 256) keys0[i] = i; }
+    if (nIni == 1) { for (int i = threadIdx.x; i < n; i += 256) keys0[i] = qt_make_key(i, xs[i], ys[i]); }
     else if (wv == 0) {                              // stable partition of 0..n-1 by root index, one wave
         int off = 0;
         for (int r = 0; r < nIni; ++r) {
@@ -171,7 +174,7 @@ __global__ __launch_bounds__(256) void quadtree_kernel(const qt_inst* __restrict
                 bool in = false;
                 if (i < n) { int w = (int)(xs[i] / hX); if (w >= nIni) w = nIni - 1; in = (w == r); }
                 const unsigned long long m = __ballot(in);
-                if (in) keys0[off + run + __popcll(m & ((1ull << lane) - 1ull))] = i;
+                if (in) keys0[off + run + __popcll(m & ((1ull << lane) - 1ull))] = qt_make_key(i, xs[i], ys[i]);
                 run += __popcll(m);
             }
             if (lane == 0) pcnt[r] = run;
@@ -215,13 +218,13 @@ __global__ __launch_bounds__(256) void quadtree_kernel(const qt_inst* __restrict
         if (np < 4) {
             for (int r = 0; r < np; ++r) {
                 int cnt[4];
-                qt_divide_block(pool[parents[r]], xs, ys, keys0, keys1, cnt, s_cnt);
+                qt_divide_block(pool[parents[r]], keys0, keys1, cnt, s_cnt);
                 if (threadIdx.x == 0) { pcnt[4 * r] = cnt[0]; pcnt[4 * r + 1] = cnt[1]; pcnt[4 * r + 2] = cnt[2]; pcnt[4 * r + 3] = cnt[3]; }
             }
         } else
             for (int r = wv; r < np; r += 4) {
                 int cnt[4];
-                qt_divide_wave(pool[parents[r]], xs, ys, keys0, keys1, cnt);
+                qt_divide_wave(pool[parents[r]], keys0, keys1, cnt);
                 if (lane == 0) { pcnt[4 * r] = cnt[0]; pcnt[4 * r + 1] = cnt[1]; pcnt[4 * r + 2] = cnt[2]; pcnt[4 * r + 3] = cnt[3]; }
             }
         __syncthreads();
@@ -277,7 +280,7 @@ __global__ __launch_bounds__(256) void quadtree_kernel(const qt_inst* __restrict
         __syncthreads();
         for (int r = wv; r < m; r += 4) {            // divide all of them; only the first t+1 take effect
             int cnt[4];
-            qt_divide_wave(pool[order[r]], xs, ys, keys0, keys1, cnt);
+            qt_divide_wave(pool[order[r]], keys0, keys1, cnt);
             if (lane == 0) { pcnt[4 * r] = cnt[0]; pcnt[4 * r + 1] = cnt[1]; pcnt[4 * r + 2] = cnt[2]; pcnt[4 * r + 3] = cnt[3]; }
         }
         if (threadIdx.x == 0) s_t = m - 1;
@@ -345,9 +348,9 @@ __global__ __launch_bounds__(256) void quadtree_kernel(const qt_inst* __restrict
     const int S = s_S;
     for (int i = threadIdx.x; i < S; i += 256) {
         const qnode q = pool[L[i]];
-        const int* kk = (q.buf ? keys1 : keys0) + q.kbeg;
-        int best = kk[0]; float r = rs[best];
-        for (int k = 1; k < q.kcnt; ++k) { const int c = kk[k]; const float v = rs[c]; if (v > r) { best = c; r = v; } }
+        const qkey* kk = (q.buf ? keys1 : keys0) + q.kbeg;
+        int best = qt_key_idx(kk[0]); float r = rs[best];
+        for (int k = 1; k < q.kcnt; ++k) { const int c = qt_key_idx(kk[k]); const float v = rs[c]; if (v > r) { best = c; r = v; } }
         if (i < I.out_cap) out[i] = base + best;
     }
     if (threadIdx.x == 0) { *out_n = S < I.out_cap ? S : I.out_cap; if (S > I.out_cap) *I.err = 3; }
