@@ -522,7 +522,7 @@ __device__ inline pg_d4 pg_mma4(const double* a, const double* b, pg_d4 c)
 // step A for tile t, executed by lanes 0..15 of one wavefront: lane i owns row i of A_tt, then column i of V_t
 __device__ inline int pg_tile_factor(double* sA, double* sW, int t, int lane)
 {
-    double d[16], v[16], rinv[16];
+    double d[16], v[16];
     double* row = sA + (16 * t + lane) * PG_LD + 16 * t;
 #pragma unroll
     for (int j = 0; j < 16; ++j) d[j] = row[j];
@@ -534,17 +534,17 @@ __device__ inline int pg_tile_factor(double* sA, double* sW, int t, int lane)
         double r = __builtin_amdgcn_rsq(pj);                 // v_rsq_f64 seed, two Newton steps
         r = r * (1.5 - 0.5 * pj * r * r);
         r = r * (1.5 - 0.5 * pj * r * r);
-        rinv[j] = r;
         d[j] = (lane == j ? pj : d[j]) * r;
 #pragma unroll
         for (int k = 0; k < 16; ++k) if (k > j) d[k] -= d[j] * pg_readlane(d[j], k);      // A_ik -= L_ij L_kj (used for i >= k)
-    }
+        // row j of V = L^-1 is complete data-wise now (it needs rows <= j of L): lane c holds V[j][c], zero above the
+        // diagonal; two interleaved partial sums, and the work overlaps with the next pivot's reciprocal square root
+        {
+            double s0 = 0, s1 = 0;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {                 // row i of V: lane c holds V[i][c], zero above the diagonal
-        double sacc = 0;
-#pragma unroll
-        for (int k = 0; k < 16; ++k) if (k < i) sacc += pg_readlane(d[k], i) * v[k];
-        v[i] = lane == i ? rinv[i] : (lane < i ? -sacc * rinv[i] : 0.0);
+            for (int k = 0; k < 16; ++k) if (k < j) { const double pr = pg_readlane(d[k], j) * v[k]; if (k & 1) s1 += pr; else s0 += pr; }
+            v[j] = lane == j ? r : (lane < j ? -(s0 + s1) * r : 0.0);
+        }
     }
 #pragma unroll
     for (int j = 0; j < 16; ++j) row[j] = j <= lane ? d[j] : 0.0;
