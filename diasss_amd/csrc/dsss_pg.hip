@@ -1106,7 +1106,8 @@ struct sym_t {
 };
 
 // host threads of the symbolic phase
-inline int sym_threads() { const unsigned hc = std::thread::hardware_concurrency(); return (int)std::min(8u, std::max(1u, hc)); }
+inline int sym_threads() { static const int env = getenv("DSSS_SYM_THREADS") ? atoi(getenv("DSSS_SYM_THREADS")) : 0; if (env > 0) return env;
+                          const unsigned hc = std::thread::hardware_concurrency(); return (int)std::min(4u, std::max(1u, hc)); }      // more threads do not help (serial parts dominate) and add scheduling jitter
 template <class F> void par_ranges(int n, int T, F fn)          // fn(t, lo, hi) over T contiguous ranges of [0, n)
 {
     std::vector<std::thread> th;
