@@ -17,12 +17,9 @@ from . import capi
 
 
 def all_pairs(F):
-    """the (i, j), i < j loop of diasss2.cpp:88-89"""
-    src, tgt = [], []
-    for i in range(F):
-        for j in range(i + 1, F):
-            src.append(i); tgt.append(j)
-    return np.asarray(src, np.int32), np.asarray(tgt, np.int32)
+    """the (i, j), i < j loop of diasss2.cpp:88-89, in that order"""
+    i, j = np.triu_indices(F, 1)
+    return i.astype(np.int32), j.astype(np.int32)
 
 
 def shard_frames(F, rank, world):
