@@ -287,9 +287,25 @@ class Context:
         self._chk(self.L.dsss_posegraph_select(self.h, nframes, _ptr(edges), cap, C.byref(n)), "dsss_posegraph_select")
         return edges[:n.value].copy()
 
-    def posegraph_solve(self, nframes, total, want_rpy=True):
-        """poses: total x 12 (R row-major, t); rpy: the reference's trajectory rows (roll pitch yaw x y z) or None"""
-        poses = np.empty((total, 12), np.float64); stats = np.zeros(4, np.float64)
+    def _pinned_f64(self, key, shape):
+        """page-locked output buffer (device-to-host copies into it run at PCIe speed), reused by the next call with
+        the same key and shape: copy the result if it has to outlive the next solve"""
+        cache = self.__dict__.setdefault("_pinned", {})
+        buf = cache.get((key, shape))
+        if buf is None:
+            try:
+                import torch
+                buf = torch.empty(shape, dtype=torch.float64, pin_memory=True).numpy()
+            except Exception:
+                buf = np.empty(shape, np.float64)
+            cache[(key, shape)] = buf
+        return buf
+
+    def posegraph_solve(self, nframes, total, want_rpy=True, pinned=False):
+        """poses: total x 12 (R row-major, t); rpy: the reference's trajectory rows (roll pitch yaw x y z) or None.
+        pinned=True returns views of page-locked buffers owned by this Context (overwritten by its next solve)."""
+        poses = self._pinned_f64("poses", (total, 12)) if pinned else np.empty((total, 12), np.float64)
+        stats = np.zeros(4, np.float64)
         rpy = np.empty((total, 6), np.float64) if want_rpy else None
         self._chk(self.L.dsss_posegraph_solve(self.h, nframes, _ptr(poses), _ptr(rpy) if want_rpy else None, _ptr(stats)), "dsss_posegraph_solve")
         return poses, rpy, stats

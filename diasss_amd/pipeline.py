@@ -100,7 +100,8 @@ class Pipeline:
     def optimize(self):
         total = int(sum(self.N))
         if not self.collectives:
-            poses, _, stats = self.ctx.posegraph_solve(self.F, total, want_rpy=False)   # est_poses; the rpy rows are only for SaveTrajactoryAll
+            # est_poses into a page-locked buffer of the context (valid until the next solve); the rpy rows are only for SaveTrajactoryAll
+            poses, _, stats = self.ctx.posegraph_solve(self.F, total, want_rpy=False, pinned=True)
             self.n_edges = None
             return poses, stats
         edges = self.ctx.posegraph_select(self.F, cap=max(total, 1))
