@@ -161,19 +161,26 @@ class Context:
         self._chk(self.L.dsss_frame_set(self.h, fid, _ptr(raw), N, M, _ptr(pose6), _ptr(alt), _ptr(gr)), "dsss_frame_set")
 
     def frames_set(self, ids, raws, Ns, Ms, poses, alts, grs):
-        """dsss_frames_set: one call for many frames (arrays must be float64 C-contiguous; raws may hold None)"""
+        """dsss_frames_set: one call for many frames (host arrays must be float64 C-contiguous; raws may hold None or
+        device tensors)"""
         n = len(ids)
         self._keep = getattr(self, "_keep", {})
-        VP = C.c_void_p * n
-        def ptrs(seq):
-            return VP(*[(_ptr(a).value if a is not None else None) for a in seq])
-        for a in list(poses) + list(alts) + list(grs):
-            assert a.dtype == np.float64 and a.flags.c_contiguous
+
+        def addr(a):
+            if a is None:
+                return 0
+            if isinstance(a, np.ndarray):
+                assert a.dtype == np.float64 and a.flags.c_contiguous
+                return a.__array_interface__["data"][0]
+            return _ptr(a).value or 0
+
+        def ptrs(seq):                                        # uintp array == array of void*
+            return np.fromiter((addr(a) for a in seq), np.uintp, n)
         for i, f in enumerate(ids):
             self._keep[int(f)] = (raws[i], poses[i], alts[i], grs[i])
         a_ids = np.ascontiguousarray(ids, np.int32); a_N = np.ascontiguousarray(Ns, np.int32); a_M = np.ascontiguousarray(Ms, np.int32)
-        p_raw, p_pose, p_alt, p_gr = ptrs(raws), ptrs(poses), ptrs(alts), ptrs(grs)       # locals keep the temporaries alive over the call
-        self._chk(self.L.dsss_frames_set(self.h, n, _ptr(a_ids), p_raw, _ptr(a_N), _ptr(a_M), p_pose, p_alt, p_gr), "dsss_frames_set")
+        p_raw, p_pose, p_alt, p_gr = ptrs(raws), ptrs(poses), ptrs(alts), ptrs(grs)       # locals keep the arrays alive over the call
+        self._chk(self.L.dsss_frames_set(self.h, n, _ptr(a_ids), _ptr(p_raw), _ptr(a_N), _ptr(a_M), _ptr(p_pose), _ptr(p_alt), _ptr(p_gr)), "dsss_frames_set")
 
     def extract(self, fid):
         n = C.c_int(0)
