@@ -76,7 +76,8 @@ int  dsss_set_params(dsss_ctx*, const dsss_mask_params*, const dsss_orb_params*,
  * raw may stay resident in HBM (device pointer): nothing is copied back to the host.                     */
 int dsss_frame_set(dsss_ctx*, int id, const double* raw, int N, int M,
                    const double* pose6, const double* alt, const double* grange);
-/* the same for n frames in one call (arrays of per-frame arguments; raw[i] may be NULL) */
+/* the same for n frames in one call (arrays of per-frame arguments; raw[i] may be NULL; ids distinct).  The
+ * geometry of the whole call is staged once and uploaded with ONE copy; N and M must be below 65536.          */
 int dsss_frames_set(dsss_ctx*, int n, const int* ids, const double* const* raw, const int* N, const int* M,
                     const double* const* pose6, const double* const* alt, const double* const* grange);
 /* GetNormalizeSSS + GetFilteredMask + DetectFeature (frame.cpp:57-124,167-203) with the ORB descriptor
@@ -130,6 +131,7 @@ int dsss_lc_get(dsss_ctx*, int pair, dsss_lc* out_host, int cap, int* n);
 int dsss_lc_solve(dsss_ctx*, int id_s, int id_t, const double* kp7, int n, dsss_lc* out_host);
 /* TrajOptimizationAll (optimizer.h:43; optimizer.cpp:101-279): LC selection + batch LM over every ping of
  * every frame 0..nframes-1 (frames must have been given with dsss_frame_set). poses12_host: total x 12
+ * (page-locked memory makes the download run at PCIe speed; rpy6_host may be NULL)
  * (R row-major, t); rpy6_host: total x 6 "r p y x y z" as SaveTrajactoryAll writes (:1164-1214).           */
 int dsss_posegraph_select(dsss_ctx*, int nframes, dsss_lc_edge* edges_host, int cap, int* n_edges);
 int dsss_posegraph_solve(dsss_ctx*, int nframes, double* poses12_host, double* rpy6_host, double* stats4_host);
