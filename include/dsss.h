@@ -131,8 +131,8 @@ int dsss_lc_get(dsss_ctx*, int pair, dsss_lc* out_host, int cap, int* n);
 int dsss_lc_solve(dsss_ctx*, int id_s, int id_t, const double* kp7, int n, dsss_lc* out_host);
 /* TrajOptimizationAll (optimizer.h:43; optimizer.cpp:101-279): LC selection + batch LM over every ping of
  * every frame 0..nframes-1 (frames must have been given with dsss_frame_set). poses12_host: total x 12
- * (page-locked memory makes the download run at PCIe speed; rpy6_host may be NULL)
- * (R row-major, t); rpy6_host: total x 6 "r p y x y z" as SaveTrajactoryAll writes (:1164-1214).           */
+ * (R row-major, t); rpy6_host: total x 6 "r p y x y z" as SaveTrajactoryAll writes (:1164-1214), may be NULL.
+ * Page-locked output buffers make the download run at PCIe speed.                                             */
 int dsss_posegraph_select(dsss_ctx*, int nframes, dsss_lc_edge* edges_host, int cap, int* n_edges);
 int dsss_posegraph_solve(dsss_ctx*, int nframes, double* poses12_host, double* rpy6_host, double* stats4_host);
 /* stand-alone form: explicit DR chain + edges                                                               */
