@@ -424,7 +424,21 @@ __global__ __launch_bounds__(256) void pg_factor_acc_kernel(const int* __restric
         double v[6];
 #pragma unroll
         for (int s = 0; s < 6; ++s) v[s] = row[s] - acc[s];
-        for (int s2 = 0; s2 < fold_nsl; ++s2) {
+        int s2 = 0;
+        for (; s2 + 4 <= fold_nsl; s2 += 4) {                   // four slices in flight, subtracted in slice order
+            double o[4][6];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const double* op = fold_part + ((size_t)blockIdx.x * fold_nsl + s2 + u) * col_stride + (size_t)idx * 6;
+#pragma unroll
+                for (int s = 0; s < 6; ++s) o[u][s] = op[s];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int s = 0; s < 6; ++s) v[s] -= o[u][s];
+        }
+        for (; s2 < fold_nsl; ++s2) {
             const double* o = fold_part + ((size_t)blockIdx.x * fold_nsl + s2) * col_stride + (size_t)idx * 6;
 #pragma unroll
             for (int s = 0; s < 6; ++s) v[s] -= o[s];
