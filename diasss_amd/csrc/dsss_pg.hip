@@ -397,7 +397,15 @@ __global__ __launch_bounds__(256) void pg_factor_acc_kernel(const int* __restric
     for (int tc = ta; tc < tb; tc += PG_TCH) {
         const int tn = min(PG_TCH, tb - tc);
         __syncthreads();
-        for (int xx = threadIdx.x; xx < tn * 36; xx += 256) s_Ljk[xx] = Lvals[(size_t)rlpos[t0 + tc + xx / 36] * 36 + (xx % 36)];
+        for (int x0 = threadIdx.x; x0 < tn * 36; x0 += 4 * 256) {      // four dependent (position -> block) loads in flight per thread
+            int pos[4]; double val[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { const int xx = x0 + u * 256; pos[u] = xx < tn * 36 ? rlpos[t0 + tc + xx / 36] : 0; }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { const int xx = x0 + u * 256; val[u] = xx < tn * 36 ? Lvals[(size_t)pos[u] * 36 + (xx % 36)] : 0.0; }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { const int xx = x0 + u * 256; if (xx < tn * 36) s_Ljk[xx] = val[u]; }
+        }
         if (blockIdx.y == 0) for (int xx = threadIdx.x; xx < tn * 6; xx += 256) s_yk[xx] = x[(size_t)rlcol[t0 + tc + xx / 6] * 6 + (xx % 6)];
         __syncthreads();
         if (rhs)
@@ -853,7 +861,15 @@ __global__ __launch_bounds__(256) void pg_factor_subtree_kernel(const int* __res
         for (int tc = 0; tc < T; tc += PG_TCH) {
             const int tn = min(PG_TCH, T - tc);
             __syncthreads();
-            for (int xx = threadIdx.x; xx < tn * 36; xx += 256) s_Ljk[xx] = Lvals[(size_t)rlpos[t0 + tc + xx / 36] * 36 + (xx % 36)];
+            for (int x0 = threadIdx.x; x0 < tn * 36; x0 += 4 * 256) {      // four dependent (position -> block) loads in flight per thread
+            int pos[4]; double val[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { const int xx = x0 + u * 256; pos[u] = xx < tn * 36 ? rlpos[t0 + tc + xx / 36] : 0; }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { const int xx = x0 + u * 256; val[u] = xx < tn * 36 ? Lvals[(size_t)pos[u] * 36 + (xx % 36)] : 0.0; }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { const int xx = x0 + u * 256; if (xx < tn * 36) s_Ljk[xx] = val[u]; }
+        }
             for (int xx = threadIdx.x; xx < tn * 6; xx += 256) s_yk[xx] = x[(size_t)rlcol[t0 + tc + xx / 6] * 6 + (xx % 6)];
             __syncthreads();
             if (rhs)
