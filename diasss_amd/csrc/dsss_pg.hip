@@ -1481,11 +1481,6 @@ static int pg_solve_impl(dsss_ctx* c, const double* dr6, int total, const dsss_l
 {
     std::vector<int> foff;
     if (!dr6) { foff.assign(nframes + 1, 0); for (int f = 0; f < nframes; ++f) foff[f + 1] = foff[f] + c->frames[f].N; }
-    auto dr_row = [&](int i) -> const double* {
-        if (dr6) return dr6 + (size_t)i * 6;
-        const int f = (int)(std::upper_bound(foff.begin(), foff.end(), i) - foff.begin()) - 1;
-        return c->frames[f].h_geo + (size_t)(i - foff[f]) * 6;
-    };
     const int n = total;
     if (n < 2) DSSS_FAIL(c, DSSS_E_ARG, "pose graph needs at least 2 poses");
     const auto T0 = std::chrono::steady_clock::now();
