@@ -146,3 +146,40 @@ def test_posegraph_optimum_properties_large(ctx, orc):
     assert np.isfinite(p1).all()
     R = p1[:, :9].reshape(-1, 3, 3)
     assert np.abs(np.einsum("nij,nkj->nik", R, R) - np.eye(3)).max() < 1e-9          # rotations stay orthonormal
+
+
+def test_full_size_C3_properties():
+    """BASELINE config 3 at full size (200 frames of 2000 x 1024, dense all-pairs: 19 900 pairs) has no oracle run --
+    it would take the CPU restatement minutes -- so it is held to size-independent properties: the run is reproducible
+    bit for bit, keypoints respect the detector's contract, loop-closure edges come out in the reference's order, the LM
+    error falls by many orders of magnitude and the trajectory stays on SE(3)."""
+    from diasss_amd.pipeline import Pipeline
+    from diasss_amd.synth import Survey
+    F, N, M = 200, 2000, 1024
+    sv = Survey(F, N, M, seed=20240601 + 1, device="cuda:0")
+    raws = [sv.frame(f) for f in range(F)]
+    ins = [sv.inputs(f) for f in range(F)]
+    poses, alts, grs = [i[0] for i in ins], [i[1] for i in ins], [i[2] for i in ins]
+    pipe = Pipeline(F)
+    out1, st1 = pipe.run(raws, poses, alts, grs)
+    out1 = out1.copy(); st1 = np.array(st1)
+    edges = pipe.ctx.posegraph_select(F)
+    nk = []
+    for f in (0, 1, 57, 199):
+        kps, desc, geo = pipe.ctx.features_get(f)
+        nk.append(len(kps))
+        assert 0 < len(kps) <= 2000                                           # nfeatures is an upper bound after the mask filter
+        assert (kps["x"] >= 0).all() and (kps["x"] < M).all() and (kps["y"] >= 0).all() and (kps["y"] < N).all()
+        assert (kps["octave"] >= 0).all() and (kps["octave"] < 6).all() and (kps["angle"] >= 0).all() and (kps["angle"] < 360.0001).all()
+        assert desc.any(axis=1).all() and np.isfinite(geo).all()
+    rows, kp7 = pipe.ctx.match_total()
+    assert rows > 10000 and 0 < kp7 <= rows                                  # reprojection only drops rows (nadir band, foreign target)
+    assert len(edges) > 5000 and (np.diff(edges["b"]) > 0).all()              # one edge per target ping, ascending: the reference's loop order
+    assert (edges["a"] != edges["b"]).all() and (edges["var"] > 0).all()
+    assert st1[0] >= 3 and st1[2] < 1e-6 * st1[1]                             # LM iterations, error before -> after
+    R = out1[:, :9].reshape(-1, 3, 3)
+    assert np.isfinite(out1).all() and np.abs(np.einsum("nij,nkj->nik", R, R) - np.eye(3)).max() < 1e-9
+    assert np.abs(np.linalg.det(R) - 1).max() < 1e-9
+    out2, st2 = pipe.run(raws, poses, alts, grs)                              # the whole path again: identical to the last bit
+    assert (out2 == out1).all() and (np.array(st2) == st1).all()
+    pipe.close()
