@@ -100,7 +100,8 @@ void dsss_destroy(dsss_ctx* c)
     for (auto& G : c->gbatches) { hipFree(G.d); if (G.h) hipHostFree(G.h); if (G.ev) hipEventDestroy(G.ev); }
     c->gbatches.clear();
     free_match(c); free_store(c);
-    hipFree(c->lcs); hipFree(c->ex_scratch); hipFree(c->mt_aux);
+    hipFree(c->lcs); hipFree(c->ex_scratch); hipFree(c->mt_aux); hipFree(c->tmp_dev);
+    if (c->geoms && c->geoms_free) c->geoms_free(c->geoms);
     if (c->ex_pinned) hipHostFree(c->ex_pinned);
     if (c->bbox_pinned) hipHostFree(c->bbox_pinned);
     dsss_pg_free(c);

@@ -2,7 +2,7 @@
 // Restates Frame::GetNormalizeSSS / GetFilteredMask / DetectFeature (/root/reference/src/core/frame.cpp:57-124,
 // 167-203) and ORBextractor::operator() in its ORB-descriptor configuration
 // (/root/reference/thirdparty/ORBextractor.cpp:77-147,410-479,765-853,1034-1041,1049-1140).
-// Everything except the quadtree cull (quadtree.cpp, host) runs in HIP kernels; all of it is integer / fixed
+// Everything runs in HIP kernels (the quadtree cull is dsss_quadtree.hip); all of it is integer / fixed
 // point / explicitly ordered floating point, so results are bit-exact against oracle/orc_frame.c + orc_orb.c.
 #include "dsss_internal.h"
 #include "dsss_quadtree.h"
@@ -35,6 +35,7 @@ struct ex_frame {
     const qt_kp_in* kin; const int* nk; const int* lrows; const float* lscale; dsss_kp* kptmp; uint8_t* dtmp;
     const double* pose6; const double* gr;
     dsss_kp* kout; uint8_t* dout; double* geo; int* count;
+    int* err;                      // per-slot error flag (shared with the quadtree descriptors)
 };
 
 // ------------------------------------------------------------------ K1: mean / min, normalise, mask
@@ -325,7 +326,7 @@ __global__ __launch_bounds__(256) void scan_counts_kernel(const ex_frame* __rest
         if (i < n) offs[i] = base + p;
         base += tot;
     }
-    if (threadIdx.x == 0) offs[n] = base;
+    if (threadIdx.x == 0) { offs[n] = base; if (base > f.cand_cap) *f.err = 7; }   // cannot happen with the exact bound; never silent
 }
 
 // candidates in reference order with the cell offset applied (ORBextractor.cpp:820-825)
@@ -517,8 +518,10 @@ struct level_geom {
     std::vector<fast_cell> cells;
     int cell_begin[DSSS_MAX_LEVELS + 1];
     int cell_cap = 0;                     // strict local maxima possible in the largest cell
-    fast_cell* d_cells = nullptr;         // device copy (per geometry, cached)
+    long long cand_bound = 0;             // sum over the cells of the strict local maxima each can hold: the frame can never exceed it
+    fast_cell* d_cells = nullptr;         // device copy (per geometry, cached in the context)
     int* d_lrows = nullptr; float* d_lscale = nullptr;
+    ~level_geom() { hipFree(d_cells); hipFree(d_lrows); hipFree(d_lscale); }
 };
 
 // scale tables, level sizes and quotas of the ORBextractor ctor / ComputePyramid (ORBextractor.cpp:415-446,1119-1120)
@@ -540,7 +543,7 @@ void build_geom(const dsss_orb_params& op, int rows, int cols, level_geom& g)
     for (int l = 0; l < op.nlevels - 1; ++l) { g.quota[l] = (int)lrintf(nDesired); sum += g.quota[l]; nDesired *= factor; }
     g.quota[op.nlevels - 1] = std::max(op.nfeatures - sum, 0);
     // cell windows of ComputeKeyPointsOctTree (ORBextractor.cpp:769-806)
-    g.cells.clear();
+    g.cells.clear(); g.cand_bound = 0;
     int cap = 1;
     for (int l = 0; l < op.nlevels; ++l) {
         g.cell_begin[l] = (int)g.cells.size();
@@ -567,6 +570,7 @@ void build_geom(const dsss_orb_params& op, int rows, int cols, level_geom& g)
                 if (c.h > CELL_MAX) c.h = CELL_MAX;
                 const int ew = std::max(c.w - 6, 0), eh = std::max(c.h - 6, 0);
                 cap = std::max(cap, ((ew + 1) / 2) * ((eh + 1) / 2));
+                g.cand_bound += std::min(((ew + 1) / 2) * ((eh + 1) / 2), CELL_CAP);   // no two 8-neighbours are both strict maxima
                 g.cells.push_back(c);
             }
         }
@@ -579,15 +583,18 @@ inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 struct geom_key { int N, M, nf, nl, it, mt; float sc; bool operator<(const geom_key& o) const {
     return std::tie(N, M, nf, nl, it, mt, sc) < std::tie(o.N, o.M, o.nf, o.nl, o.it, o.mt, o.sc); } };
-std::map<std::pair<dsss_ctx*, geom_key>, std::unique_ptr<level_geom>> g_geoms;   // device tables live as long as the process
+typedef std::map<geom_key, std::unique_ptr<level_geom>> geom_map;    // owned by the context (dsss_ctx::geoms), freed by dsss_destroy
+void geom_map_free(void* p) { delete static_cast<geom_map*>(p); }
 
 } // namespace
 
 static int get_geom(dsss_ctx* c, int N, int M, level_geom** out)
 {
     geom_key k{ N, M, c->op.nfeatures, c->op.nlevels, c->op.ini_th, c->op.min_th, c->op.scale };
-    auto it = g_geoms.find({ c, k });
-    if (it == g_geoms.end()) {
+    if (!c->geoms) { c->geoms = new geom_map(); c->geoms_free = geom_map_free; }
+    geom_map& geoms = *static_cast<geom_map*>(c->geoms);
+    auto it = geoms.find(k);
+    if (it == geoms.end()) {
         std::unique_ptr<level_geom> g(new level_geom());
         if (N >= 65536 || M >= 65536) DSSS_FAIL(c, DSSS_E_ARG, "frames of 65536 or more pings / bins are not supported (quadtree keys pack 16-bit coordinates)");
         build_geom(c->op, N, M, *g);
@@ -600,7 +607,7 @@ static int get_geom(dsss_ctx* c, int N, int M, level_geom** out)
         HIPCHK(c, hipMemcpy(g->d_cells, g->cells.data(), sizeof(fast_cell) * g->cells.size(), hipMemcpyHostToDevice));
         HIPCHK(c, hipMemcpy(g->d_lrows, g->rows, sizeof(int) * DSSS_MAX_LEVELS, hipMemcpyHostToDevice));
         HIPCHK(c, hipMemcpy(g->d_lscale, g->sf, sizeof(float) * DSSS_MAX_LEVELS, hipMemcpyHostToDevice));
-        it = g_geoms.emplace(std::make_pair(c, k), std::move(g)).first;
+        it = geoms.emplace(k, std::move(g)).first;
     }
     *out = it->second.get();
     return DSSS_OK;
@@ -635,7 +642,9 @@ static ex_layout make_layout(int N, const level_geom& g, int kcap)
 {
     ex_layout L; size_t o = 0;
     const int ncells = (int)g.cells.size();
-    L.cand_cap = ncells * 64 + 4096; L.out_cap = kcap;
+    // every candidate array holds the frame's true upper bound (speckled sonar data reaches 60 % of it; a fixed
+    // "typical" capacity overflowed on Rayleigh noise), so the compaction can never run past the end
+    L.cand_cap = (int)std::min<long long>(g.cand_bound + 64, 0x7fffffff); L.out_cap = kcap;
     auto take = [&](size_t bytes) { size_t r = o; o = align_up(o + bytes, 256); return r; };
     L.rowsum = take(sizeof(double) * N); L.rowmin = take(sizeof(double) * N); L.stats = take(sizeof(double) * 4);
     L.counts = take(sizeof(int) * ncells); L.offs = take(sizeof(int) * (ncells + 1));
@@ -672,7 +681,8 @@ static int extract_frames(dsss_ctx* c, const int* ids, int n, bool keep_taps)
         Ls[i] = make_layout(f.N, *G[i], c->kcap);
         slot_bytes = std::max(slot_bytes, Ls[i].total);
     }
-    const int B = std::min(n, EX_BATCH);
+    // slots of one batch share one scratch allocation: bound it (24 GB) instead of the frame count alone
+    const int B = (int)std::max<size_t>(1, std::min<size_t>(std::min(n, EX_BATCH), ((size_t)24 << 30) / std::max<size_t>(slot_bytes, 1)));
     const size_t inst_bytes = align_up(sizeof(qt_inst) * (size_t)B * DSSS_MAX_LEVELS, 256), qfr_bytes = align_up(sizeof(qt_frame) * (size_t)B, 256);
     const size_t exf_bytes = align_up(sizeof(ex_frame) * (size_t)B, 256), err_bytes = align_up(sizeof(int) * (size_t)B, 256);
     const size_t tab_bytes = inst_bytes + qfr_bytes + exf_bytes + err_bytes;
@@ -723,7 +733,7 @@ static int extract_frames(dsss_ctx* c, const int* ids, int n, bool keep_taps)
             e.kin = (kp_in*)(S + L.kin); e.nk = (int*)(S + L.nk); e.lrows = g.d_lrows; e.lscale = g.d_lscale;
             e.kptmp = (dsss_kp*)(S + L.kptmp); e.dtmp = (uint8_t*)(S + L.dtmp);
             e.pose6 = f.pose6; e.gr = f.gr;
-            e.kout = c->kps + (size_t)id * c->kcap; e.dout = c->desc + (size_t)id * c->kcap * 32; e.geo = c->geo + (size_t)id * c->kcap * 2; e.count = c->nkp_dev + id;
+            e.err = d_errs + s; e.kout = c->kps + (size_t)id * c->kcap; e.dout = c->desc + (size_t)id * c->kcap * 32; e.geo = c->geo + (size_t)id * c->kcap * 2; e.count = c->nkp_dev + id;
             maxN = std::max(maxN, f.N); max_tot = std::max(max_tot, (size_t)f.N * f.M); max_cells = std::max(max_cells, e.ncells); max_levels = std::max(max_levels, g.nlevels);
             for (int l = 0; l < g.nlevels; ++l) { max_rows[l] = std::max(max_rows[l], g.rows[l]); max_cols[l] = std::max(max_cols[l], g.cols[l]); }
             w_tot += (double)f.N * f.M;
@@ -736,7 +746,7 @@ static int extract_frames(dsss_ctx* c, const int* ids, int n, bool keep_taps)
                 q.keys0 = (unsigned long long*)(S + L.keys0); q.keys1 = (unsigned long long*)(S + L.keys1); q.work = (int*)(S + L.work[l]);
                 q.list_cap = L.list_cap[l]; q.pool_cap = L.pool_cap[l];
                 q.out_idx = (int*)(S + L.out_idx) + (size_t)l * L.out_cap; q.out_n = (int*)(S + L.out_n) + l; q.out_cap = L.out_cap;
-                q.err = d_errs + s;
+                q.err = d_errs + s; q.cand_cap = L.cand_cap;
             }
             qt_frame& qf = h_fr[s];
             qf.nlevels = g.nlevels; qf.out_cap = L.out_cap; qf.kcap = c->kcap; qf.min_border = EDGE_T - 3;
@@ -774,7 +784,7 @@ static int extract_frames(dsss_ctx* c, const int* ids, int n, bool keep_taps)
         HIPCHK(c, hipStreamSynchronize(st));         // one synchronisation per batch of up to EX_BATCH frames
         for (int s = 0; s < nb; ++s) {
             dsss_frame& f = c->frames[ids[b0 + s]];
-            if (h_err[s]) DSSS_FAIL(c, DSSS_E_CAPACITY, "frame %d: device quadtree capacity exceeded (code %d)", ids[b0 + s], h_err[s]);
+            if (h_err[s]) DSSS_FAIL(c, DSSS_E_CAPACITY, "frame %d: extraction capacity exceeded (code %d; 7 = FAST candidates, else quadtree lists)", ids[b0 + s], h_err[s]);
             f.nkp = h_nkp[ids[b0 + s]]; f.has_feat = true; f.has_norm = true;
         }
         if (keep_taps) {                             // stage tap for the parity tests: FAST candidates per level

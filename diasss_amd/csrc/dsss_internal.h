@@ -95,6 +95,9 @@ struct dsss_ctx {
     dsss_lc* lcs = nullptr; size_t lcs_cap = 0; bool has_lc = false;
     // pose-graph scratch
     void* pg_state = nullptr;
+    // per-geometry extraction tables (dsss_extract.hip owns the type; freed through geoms_free by dsss_destroy)
+    void* geoms = nullptr; void (*geoms_free)(void*) = nullptr;
+    int* tmp_dev = nullptr;             // 64 ints of device scratch for one-value results (dsss_descriptor_distance)
     dsss_prof prof;
 };
 

@@ -371,6 +371,17 @@ int dsss_lc_solve(dsss_ctx* c, int id_s, int id_t, const double* kp7, int n, dss
     if (!c->frames[id_s].has_geom || !c->frames[id_t].has_geom) DSSS_FAIL(c, DSSS_E_STATE, "frames need dsss_frame_set first");
     if (n == 0) return DSSS_OK;
     HIPCHK(c, hipSetDevice(c->device));
+    {   // caller-supplied kp7: pings and bins index altitude / ground-range tables on the device, so range-check them here
+        // (GetKpsPairs never emits |bin - M/2| < 20, optimizer.cpp:602-609; bin - M/2 == M/2 is the one-past-the-end read)
+        std::vector<double> h((size_t)n * 7);
+        HIPCHK(c, hipMemcpy(h.data(), kp7, h.size() * sizeof(double), hipMemcpyDefault));
+        const dsss_frame &fs = c->frames[id_s], &ft = c->frames[id_t];
+        for (int i = 0; i < n; ++i) {
+            const double* k = h.data() + (size_t)i * 7;
+            const bool ok = k[0] >= 0 && k[0] < fs.N && k[3] >= 0 && k[3] < ft.N && k[1] >= 1 && k[1] < fs.M && k[4] >= 1 && k[4] < ft.M;
+            if (!ok) DSSS_FAIL(c, DSSS_E_ARG, "kp7 row %d: ping/bin outside the frames (%g,%g | %g,%g)", i, k[0], k[1], k[3], k[4]);
+        }
+    }
     int rc = dsss_sync_bboxes(c); if (rc) return rc;          // also publishes the frames' N and M to the device tables
     rc = ensure_ptr_tables(c); if (rc) return rc;
     double* d_kp7 = nullptr; dsss_lc* d_out = nullptr;

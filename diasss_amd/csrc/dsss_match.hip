@@ -359,9 +359,13 @@ int dsss_match_pairs(dsss_ctx* c, const int* src_ids, const int* tgt_ids, int np
     const size_t K = c->kcap;
     if ((size_t)na > c->match_cap_pairs) {
         HIPCHK(c, hipStreamSynchronize(c->stream));
-        hipFree(c->act_s); hipFree(c->act_t); hipFree(c->corres_nn); hipFree(c->corres);
-        hipFree(c->scc_hist); hipFree(c->scc_count); hipFree(c->scc_model);
-        hipFree(c->row_cnt); hipFree(c->kp7_cnt); hipFree(c->row_off); hipFree(c->kp7_off);
+        // free + null first and publish the new capacity only after every allocation succeeded, so that a failed
+        // hipMalloc leaves the context consistent (capacity 0, null pointers: the next call starts over, dsss_destroy is safe)
+        c->match_cap_pairs = 0;
+#define DSSS_FREE0(p) do { hipFree(p); (p) = nullptr; } while (0)
+        DSSS_FREE0(c->act_s); DSSS_FREE0(c->act_t); DSSS_FREE0(c->corres_nn); DSSS_FREE0(c->corres);
+        DSSS_FREE0(c->scc_hist); DSSS_FREE0(c->scc_count); DSSS_FREE0(c->scc_model);
+        DSSS_FREE0(c->row_cnt); DSSS_FREE0(c->kp7_cnt); DSSS_FREE0(c->row_off); DSSS_FREE0(c->kp7_off);
         HIPCHK(c, hipMalloc(&c->act_s, na * sizeof(int))); HIPCHK(c, hipMalloc(&c->act_t, na * sizeof(int)));
         HIPCHK(c, hipMalloc(&c->corres_nn, 2 * (size_t)na * K * sizeof(int32_t)));
         HIPCHK(c, hipMalloc(&c->corres, 2 * (size_t)na * K * sizeof(int32_t)));
@@ -427,12 +431,14 @@ int dsss_match_pairs(dsss_ctx* c, const int* src_ids, const int* tgt_ids, int np
     HIPCHK(c, hipStreamSynchronize(c->stream));
     c->total_rows = c->h_row_off[na]; c->total_kp7 = c->h_kp7_off[na];
     if ((size_t)c->total_rows > c->rows_cap) {
-        hipFree(c->rows6); hipFree(c->kp7); hipFree(c->kp7_pair); hipFree(c->kp7_flip);
-        c->rows_cap = (size_t)c->total_rows + 1024;
-        HIPCHK(c, hipMalloc(&c->rows6, c->rows_cap * 6 * sizeof(double)));
-        HIPCHK(c, hipMalloc(&c->kp7, c->rows_cap * 7 * sizeof(double)));
-        HIPCHK(c, hipMalloc(&c->kp7_pair, c->rows_cap * sizeof(int)));
-        HIPCHK(c, hipMalloc(&c->kp7_flip, c->rows_cap));
+        const size_t want = (size_t)c->total_rows + 1024;
+        c->rows_cap = 0;
+        DSSS_FREE0(c->rows6); DSSS_FREE0(c->kp7); DSSS_FREE0(c->kp7_pair); DSSS_FREE0(c->kp7_flip);
+        HIPCHK(c, hipMalloc(&c->rows6, want * 6 * sizeof(double)));
+        HIPCHK(c, hipMalloc(&c->kp7, want * 7 * sizeof(double)));
+        HIPCHK(c, hipMalloc(&c->kp7_pair, want * sizeof(int)));
+        HIPCHK(c, hipMalloc(&c->kp7_flip, want));
+        c->rows_cap = want;
     }
     if (c->total_rows > 0) {
         dsss_scope sc(c, DSSS_K_ROWS);
@@ -509,13 +515,12 @@ int dsss_descriptor_distance(dsss_ctx* c, int id_a, int ia, int id_b, int ib, in
     if (id_a < 0 || id_a >= c->max_frames || id_b < 0 || id_b >= c->max_frames) DSSS_FAIL(c, DSSS_E_ARG, "frame id out of range");
     if (!c->frames[id_a].has_feat || !c->frames[id_b].has_feat || ia < 0 || ib < 0 || ia >= c->frames[id_a].nkp || ib >= c->frames[id_b].nkp)
         DSSS_FAIL(c, DSSS_E_ARG, "descriptor index out of range");
-    int* d_out = nullptr;
-    HIPCHK(c, hipMalloc(&d_out, sizeof(int)));
+    if (!c->tmp_dev) HIPCHK(c, hipMalloc(&c->tmp_dev, 64 * sizeof(int)));      // once per context, not per call
+    int* d_out = c->tmp_dev;
     hipLaunchKernelGGL(hamming_one_kernel, dim3(1), dim3(1), 0, c->stream, c->desc + ((size_t)id_a * c->kcap + ia) * 32,
                        c->desc + ((size_t)id_b * c->kcap + ib) * 32, d_out);
     hipError_t e = hipMemcpyAsync(dist, d_out, sizeof(int), hipMemcpyDeviceToHost, c->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-    hipFree(d_out);
     HIPCHK(c, e);
     return DSSS_OK;
 }

@@ -1497,7 +1497,11 @@ static int pg_solve_impl(dsss_ctx* c, const double* dr6, int total, const dsss_l
         if (ea[e] < 0 || ea[e] >= n || eb[e] < 0 || eb[e] >= n || ea[e] == eb[e]) DSSS_FAIL(c, DSSS_E_ARG, "LC edge %d out of range", e);
         for (int k = 0; k < 9; ++k) emeas[e].R[k] = edges[e].rel[k];
         for (int k = 0; k < 3; ++k) emeas[e].t[k] = edges[e].rel[9 + k];
-        for (int k = 0; k < 6; ++k) ew[(size_t)e * 6 + k] = 1.0 / std::sqrt(edges[e].var[k]);
+        for (int k = 0; k < 6; ++k) {
+            if (!(edges[e].var[k] > 0) || !std::isfinite(edges[e].var[k])) DSSS_FAIL(c, DSSS_E_NUMERIC, "LC edge %d: variance %d is not finite and positive", e, k);
+            ew[(size_t)e * 6 + k] = 1.0 / std::sqrt(edges[e].var[k]);
+        }
+        for (int k = 0; k < 12; ++k) if (!std::isfinite(edges[e].rel[k])) DSSS_FAIL(c, DSSS_E_NUMERIC, "LC edge %d: relative pose is not finite", e);
     }
     // incidence lists (edge order), separators, segments
     std::vector<int> adj_ptr(n + 1, 0), adj_edge(2 * (size_t)ne);
@@ -1807,7 +1811,11 @@ __global__ __launch_bounds__(256) void lc_edge_flag_kernel(const unsigned long l
     int f = 0;
     if (key) {
         const int p = (int)(key >> 32) - 1, k = (int)(0xffffffffu - (unsigned)(key & 0xffffffffu));
-        f = lcs[kp7_off[p] + k].score > 0;
+        const dsss_lc& m = lcs[kp7_off[p] + k];
+        // score > 0 (optimizer.cpp:234); a non-finite score (fin == 0) or a variance that is not finite and positive
+        // (the undamped 15x15 marginal failed: GTSAM would throw) drops the measurement instead of poisoning the batch LM
+        f = m.score > 0 && isfinite(m.score);
+        for (int q = 0; q < 6; ++q) f = f && m.var[q] > 0 && isfinite(m.var[q]);
     }
     flags[g] = f;
 }

@@ -14,6 +14,7 @@ struct qt_inst {                 // one (frame, level)
     int list_cap, pool_cap;
     int* out_idx; int* out_n; int out_cap;
     int* err;
+    int cand_cap;                // capacity of xs / ys / rs / keys0 / keys1 (candidates of the whole frame)
 };
 
 struct qt_frame {                // one frame: gathers its levels into kp_in records

@@ -147,8 +147,8 @@ __global__ __launch_bounds__(256) void quadtree_kernel(const qt_inst* __restrict
     __shared__ int s_S, s_pool, s_nexp, s_done, s_phase2, s_t;
     __shared__ int s_cnt[4][4];
     const qt_inst I = tab[blockIdx.x];
-    const int n = I.offs[I.cell_end] - I.offs[I.cell_begin];
     const int base = I.offs[I.cell_begin];
+    const int n = min(I.offs[I.cell_end], I.cand_cap) - base;         // never index past the candidate arrays (the overflow itself is flagged by scan_counts_kernel)
     const float* xs = I.xs + base; const float* ys = I.ys + base; const float* rs = I.rs + base;
     int* out = I.out_idx; int* out_n = I.out_n;
     if (n <= 0) { if (threadIdx.x == 0) *out_n = 0; return; }

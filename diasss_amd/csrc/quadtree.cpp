@@ -1,8 +1,9 @@
-// diasss_amd/csrc/quadtree.cpp -- host-side spatial culling of FAST candidates to the per-level quota.
-// Restates ORBextractor::DistributeOctTree / ExtractorNode::DivideNode
-// (/root/reference/thirdparty/ORBextractor.cpp:481-763).  The procedure is sequential and order dependent
-// (children are pushed to the FRONT of a list that is being walked; the largest nodes are split first once the
-// quota is near), so round 1 keeps it on the host; SURVEY.md 2a K4 schedules a device version later.
+// diasss_amd/csrc/quadtree.cpp -- HOST twin of the device quadtree (dsss_quadtree.hip): spatial culling of FAST
+// candidates to the per-level quota.  Restates ORBextractor::DistributeOctTree / ExtractorNode::DivideNode
+// (/root/reference/thirdparty/ORBextractor.cpp:481-763).  The hot path never calls it: extraction runs
+// quadtree_kernel on the device.  It is exported (dsss_host_quadtree) only so that the CPU test-suite can pin the
+// list-order semantics (children pushed to the FRONT of a list that is being walked; largest nodes split first once
+// the quota is near) against the oracle without a GPU.
 // Two places where the reference is undefined are pinned down exactly as in oracle/orc_orb.c:
 //   - nIni = max(1, round(width/height))      (the reference divides by zero for tall levels, :543-545)
 //   - equal-size nodes are split in creation order (the reference compares heap addresses, :684)

@@ -36,7 +36,11 @@ int orc_pg_select_lc(int F, const int* frame_rows, int npairs, const int* pair_s
                     if ((int)kp7[(size_t)q * 7 + 3] == j) { kps_id = q; pair_id = k; break; }
                 }
             }
-            if (kps_id != -1 && lcs[kps_id].score > 0) {
+            /* usable = score > 0 (:234) AND a finite score and finite positive variances: the reference's Marginals would
+             * throw on a singular 15x15 system (uncaught -> abort); both sides of the parity drop such a measurement */
+            int usable = kps_id != -1 && lcs[kps_id].score > 0 && isfinite(lcs[kps_id].score);
+            for (int c = 0; usable && c < 6; ++c) usable = lcs[kps_id].var[c] > 0 && isfinite(lcs[kps_id].var[c]);
+            if (usable) {
                 if (ne >= cap) { free(off); return ne; }
                 int id_1 = (int)kp7[(size_t)kps_id * 7 + 0], id_2 = (int)kp7[(size_t)kps_id * 7 + 3];
                 edges[ne].a = off[pair_s[pair_id]] + id_1;
