@@ -289,6 +289,27 @@ class Context:
         self._chk(self.L.dsss_lc_solve(self.h, id_s, id_t, _ptr(kp7), len(kp7), _ptr(out)), "dsss_lc_solve")
         return out[:len(kp7)].copy()
 
+    def lc_solve_pairs(self, src, tgt, kp7_list):
+        """LoopClosingTFs of many pairs in one launch from caller-built kp7 lists (dsss_lc_solve_pairs)"""
+        src = np.ascontiguousarray(src, np.int32); tgt = np.ascontiguousarray(tgt, np.int32)
+        off = np.zeros(len(src) + 1, np.int32)
+        for p, k in enumerate(kp7_list):
+            off[p + 1] = off[p] + len(k)
+        kp7 = np.ascontiguousarray(np.concatenate([np.asarray(k, np.float64).reshape(-1, 7) for k in kp7_list]) if len(kp7_list) else np.zeros((0, 7)))
+        self._chk(self.L.dsss_lc_solve_pairs(self.h, _ptr(src), _ptr(tgt), len(src), _ptr(kp7) if len(kp7) else None, _ptr(off)), "dsss_lc_solve_pairs")
+
+    def triangulate(self, id_s, id_t, kp7):
+        kp7 = np.ascontiguousarray(kp7, np.float64).reshape(-1, 7)
+        out = np.zeros((max(len(kp7), 1), 7))
+        self._chk(self.L.dsss_triangulate(self.h, id_s, id_t, _ptr(kp7), len(kp7), _ptr(out)), "dsss_triangulate")
+        return out[:len(kp7)].copy()
+
+    def triangulate_poses(self, kp7, in27):
+        kp7 = np.ascontiguousarray(kp7, np.float64).reshape(-1, 7); in27 = np.ascontiguousarray(in27, np.float64).reshape(-1, 27)
+        out = np.zeros((max(len(kp7), 1), 7))
+        self._chk(self.L.dsss_triangulate_poses(self.h, _ptr(kp7), _ptr(in27), len(kp7), _ptr(out)), "dsss_triangulate_poses")
+        return out[:len(kp7)].copy()
+
     def posegraph_select(self, nframes, cap=1 << 20):
         edges = np.zeros(cap, LCEDGE_DTYPE); n = C.c_int(0)
         self._chk(self.L.dsss_posegraph_select(self.h, nframes, _ptr(edges), cap, C.byref(n)), "dsss_posegraph_select")

@@ -312,6 +312,126 @@ __global__ __launch_bounds__(64) void lc_kernel(const double* __restrict__ kp7, 
     if (lane == 0) out[i] = o;
 }
 
+// ------------------------------------------------------------------ a21 / a23: landmark triangulation
+// LMTriaFactor (LMtriangulatefactor.cpp:10-27: residual and 2x3 Jacobian = those of SssPointFactor with the pose held
+// fixed) inside Optimizer::TriangulateOneLandmark (optimizer.cpp:984-1021): 3-DoF GTSAM LM on the landmark, point prior
+// (10, 10, |xy baseline| / 100).  Call site :907-921 (eval_2): DR poses with the sticky yaw compensation, landmark
+// initialised as in :789-795; the four consistency figures printed there are returned next to the point.
+// One thread per problem: 7 x 3 Jacobian and a 3 x 3 system in registers; same operation order as oracle/orc_lc.c.
+__device__ static void tri_lin(const pose_t& Tp_s, const pose_t& Tp_t, double slant_s, double slant_t, const double* sig_s, const double* sig_t,
+                               const double* sig_p, const double* ini, const double* p, double* r, double* J)
+{
+    double ee[2], H1[6], H2[12];
+    sss_factor(p, &Tp_s, slant_s, 0.0, ee, J ? H1 : nullptr, H2);
+    for (int i = 0; i < 2; ++i) { r[i] = ee[i] / sig_s[i]; if (J) for (int j = 0; j < 3; ++j) J[i * 3 + j] = H1[3 * i + j] / sig_s[i]; }
+    sss_factor(p, &Tp_t, slant_t, 0.0, ee, J ? H1 : nullptr, H2);
+    for (int i = 0; i < 2; ++i) { r[2 + i] = ee[i] / sig_t[i]; if (J) for (int j = 0; j < 3; ++j) J[(2 + i) * 3 + j] = H1[3 * i + j] / sig_t[i]; }
+    for (int i = 0; i < 3; ++i) { r[4 + i] = (p[i] - ini[i]) / sig_p[i]; if (J) for (int j = 0; j < 3; ++j) J[(4 + i) * 3 + j] = (i == j) ? 1.0 / sig_p[i] : 0.0; }
+}
+__device__ static int tri_chol3(double* A)
+{
+    for (int j = 0; j < 3; ++j) {
+        double d = A[j * 3 + j];
+        for (int k = 0; k < j; ++k) d -= A[j * 3 + k] * A[j * 3 + k];
+        if (!(d > 0) || !isfinite(d)) return -1;
+        d = sqrt(d); A[j * 3 + j] = d;
+        for (int i = j + 1; i < 3; ++i) { double t = A[i * 3 + j]; for (int k = 0; k < j; ++k) t -= A[i * 3 + k] * A[j * 3 + k]; A[i * 3 + j] = t / d; }
+    }
+    return 0;
+}
+__global__ __launch_bounds__(64) void tri_kernel(const double* __restrict__ kp7, int n, const double* __restrict__ pose_s, const double* __restrict__ alt_s,
+                                                 const double* __restrict__ gr_s, int Ms, const double* __restrict__ pose_t_, const double* __restrict__ alt_t,
+                                                 const double* __restrict__ gr_t, int Mt, const double* __restrict__ explicit27, double* __restrict__ out7)
+{
+    const int i = blockIdx.x * 64 + threadIdx.x;
+    if (i >= n) return;
+    const double PI = DSSS_PI_REF, thr = 2 * PI / 3;
+    int flip = 0;                                                   // sticky over the caller's list (optimizer.cpp:650,700-703)
+    if (!explicit27) for (int k = 0; k <= i; ++k) {
+        const double* q = kp7 + (size_t)k * 7;
+        if (fabs(pose_s[(size_t)(int)q[0] * 6 + 2]) > thr) flip |= 1;
+        if (fabs(pose_t_[(size_t)(int)q[3] * 6 + 2]) > thr) flip |= 2;
+    }
+    const double* kp = kp7 + (size_t)i * 7;
+    const int id_s = (int)kp[0], id_t = (int)kp[3];
+    pose_t cps_s, cps_t, Ps, Pt, Tp_s, Tp_t;
+    pose_identity(&cps_s); pose_identity(&cps_t);
+    const double flipv[3] = { 0, 0, PI };
+    if (flip & 1) so3_exp(flipv, cps_s.R);
+    if (flip & 2) so3_exp(flipv, cps_t.R);
+    double ini[3];
+    if (explicit27) {                                               // TriangulateOneLandmark with the caller's poses and start point
+        const double* q = explicit27 + (size_t)i * 27;
+        for (int k = 0; k < 9; ++k) { Tp_s.R[k] = q[k]; Tp_t.R[k] = q[12 + k]; }
+        for (int k = 0; k < 3; ++k) { Tp_s.t[k] = q[9 + k]; Tp_t.t[k] = q[21 + k]; ini[k] = q[24 + k]; }
+    } else {
+        pose_from_rodrigues(pose_s + (size_t)id_s * 6, &Ps);
+        pose_from_rodrigues(pose_t_ + (size_t)id_t * 6, &Pt);
+        pose_compose(&Ps, &cps_s, &Tp_s);
+        pose_compose(&Pt, &cps_t, &Tp_t);
+        double gsx, gsy, gtx, gty;
+        dsss_geo_at(pose_s, gr_s, Ms, id_s, (int)kp[1], &gsx, &gsy);
+        dsss_geo_at(pose_t_, gr_t, Mt, id_t, (int)kp[4], &gtx, &gty);
+        ini[0] = (gsx + gtx) / 2; ini[1] = (gsy + gty) / 2;
+        ini[2] = ((pose_s[(size_t)id_s * 6 + 5] - alt_s[id_s]) + (pose_t_[(size_t)id_t * 6 + 5] - alt_t[id_t])) / 2;
+    }
+    const double sigma_r = 0.1, alpha_bw = 0.1 * PI / 180;
+    const double sig_s[2] = { sigma_r, kp[2] * alpha_bw }, sig_t[2] = { sigma_r, kp[5] * alpha_bw };
+    const double dx = Tp_s.t[0] - Tp_t.t[0], dy = Tp_s.t[1] - Tp_t.t[1];
+    double sig_p[3] = { 10.0, 10.0, sqrt(dx * dx + dy * dy) / 100 };
+    if (sig_p[2] < 1e-9) sig_p[2] = 1e-9;
+    double p[3] = { ini[0], ini[1], ini[2] };
+    const double relTol = 1e-5, absTol = 1e-5, lamMax = 1e5, minFid = 1e-3;
+    double r[7], J[21];
+    auto err_of = [&](const double* q) { double rr[7]; tri_lin(Tp_s, Tp_t, kp[2], kp[5], sig_s, sig_t, sig_p, ini, q, rr, nullptr);
+                                         double t = 0; for (int k = 0; k < 7; ++k) t += rr[k] * rr[k]; return 0.5 * t; };
+    double lambda = 1e-5, err = err_of(p), cur;
+    int iters = 0;
+    if (err > 0) do {
+        cur = err;
+        double H[9], g[3];
+        tri_lin(Tp_s, Tp_t, kp[2], kp[5], sig_s, sig_t, sig_p, ini, p, r, J);
+        for (int a = 0; a < 3; ++a) {
+            double t = 0; for (int k = 0; k < 7; ++k) t += J[k * 3 + a] * r[k];
+            g[a] = t;
+            for (int b = 0; b < 3; ++b) { double u = 0; for (int k = 0; k < 7; ++k) u += J[k * 3 + a] * J[k * 3 + b]; H[a * 3 + b] = u; }
+        }
+        double oldLin = 0; for (int k = 0; k < 7; ++k) oldLin += r[k] * r[k];
+        oldLin *= 0.5;
+        for (;;) {
+            double A[9], d[3], np_[3] = { 0, 0, 0 };
+            for (int a = 0; a < 9; ++a) A[a] = H[a];
+            for (int a = 0; a < 3; ++a) { A[a * 3 + a] += lambda; d[a] = -g[a]; }
+            const bool ok = tri_chol3(A) == 0;
+            bool success = false, stop = false;
+            double newErr = 0;
+            if (ok) {
+                for (int a = 0; a < 3; ++a) { double t = d[a]; for (int k = 0; k < a; ++k) t -= A[a * 3 + k] * d[k]; d[a] = t / A[a * 3 + a]; }
+                for (int a = 2; a >= 0; --a) { double t = d[a]; for (int k = a + 1; k < 3; ++k) t -= A[k * 3 + a] * d[k]; d[a] = t / A[a * 3 + a]; }
+                double newLin = 0;
+                for (int k = 0; k < 7; ++k) { double t = r[k]; for (int a = 0; a < 3; ++a) t += J[k * 3 + a] * d[a]; newLin += t * t; }
+                newLin *= 0.5;
+                const double linChange = oldLin - newLin;
+                if (linChange >= 0) {
+                    for (int a = 0; a < 3; ++a) np_[a] = p[a] + d[a];
+                    newErr = err_of(np_);
+                    const double costChange = err - newErr;
+                    if (linChange > 2.220446049250313e-16 * oldLin) success = (costChange / linChange) > minFid;
+                    if (fabs(costChange) < relTol * err) stop = true;
+                }
+            }
+            if (success) { for (int a = 0; a < 3; ++a) p[a] = np_[a]; err = newErr; lambda /= 10; ++iters; break; }
+            else if (!stop) { lambda *= 10; if (lambda >= lamMax) break; }
+            else break;
+        }
+    } while (iters < 100 && !((err <= 0) || ((cur - err) / cur <= relTol) || ((cur - err) <= absTol)) && isfinite(cur));
+    double* o = out7 + (size_t)i * 7;
+    o[0] = p[0]; o[1] = p[1]; o[2] = p[2];
+    double e[2];
+    sss_factor(p, &Tp_s, kp[2], 0.0, e, nullptr, nullptr); o[3] = fabs(e[0]); o[4] = fabs(e[1]);
+    sss_factor(p, &Tp_t, kp[5], 0.0, e, nullptr, nullptr); o[5] = fabs(e[0]); o[6] = fabs(e[1]);
+}
+
 static int ensure_ptr_tables(dsss_ctx* c)
 {
     const int F = c->max_frames;
@@ -364,6 +484,78 @@ int dsss_lc_get(dsss_ctx* c, int pair, dsss_lc* out, int cap, int* nout)
     return DSSS_OK;
 }
 
+// LoopClosingTFs for the kp7 lists of MANY pairs given by the caller (what the host mirror's TrajOptimizationAll builds
+// with GetKpsPairs from corres_kps or, with USE_ANNO = 1, from anno_kps: optimizer.cpp:35-97): one upload, one launch.
+// The results stay on the device exactly as after dsss_match_pairs + dsss_lc_solve_all, so dsss_lc_get,
+// dsss_posegraph_select and dsss_posegraph_solve work on them (pair order = the caller's order = the reference's loop order).
+int dsss_lc_solve_pairs(dsss_ctx* c, const int* src_ids, const int* tgt_ids, int npairs, const double* kp7, const int* pair_off)
+{
+    if (!c || npairs < 0 || (npairs > 0 && (!src_ids || !tgt_ids || !pair_off))) return DSSS_E_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    const int n = npairs > 0 ? pair_off[npairs] : 0;
+    if (n < 0 || (n > 0 && !kp7)) return DSSS_E_ARG;
+    for (int p = 0; p < npairs; ++p) {
+        const int s = src_ids[p], t = tgt_ids[p];
+        if (s < 0 || s >= c->max_frames || t < 0 || t >= c->max_frames || s == t) DSSS_FAIL(c, DSSS_E_ARG, "pair %d: bad frame ids (%d,%d)", p, s, t);
+        if (!c->frames[s].has_geom || !c->frames[t].has_geom) DSSS_FAIL(c, DSSS_E_STATE, "pair %d: frames need dsss_frame_set first", p);
+        if (pair_off[p + 1] < pair_off[p]) DSSS_FAIL(c, DSSS_E_ARG, "pair_off is not ascending at pair %d", p);
+    }
+    int rc = dsss_sync_bboxes(c); if (rc) return rc;
+    rc = ensure_ptr_tables(c); if (rc) return rc;
+    // every listed pair is "active" here: the bookkeeping below is what dsss_match_pairs leaves behind
+    c->npairs = npairs; c->nactive = npairs; c->has_lc = false;
+    c->pair_s.assign(src_ids, src_ids + npairs); c->pair_t.assign(tgt_ids, tgt_ids + npairs);
+    c->pair_active.resize(npairs);
+    for (int p = 0; p < npairs; ++p) c->pair_active[p] = p;
+    c->h_kp7_off.assign(pair_off, pair_off + npairs + 1);
+    c->h_row_off.assign(npairs + 1, 0);
+    c->total_rows = 0; c->total_kp7 = n;
+    if (npairs == 0 || n == 0) { c->has_lc = true; return DSSS_OK; }
+    std::vector<double> h((size_t)n * 7);
+    HIPCHK(c, hipMemcpy(h.data(), kp7, h.size() * sizeof(double), hipMemcpyDefault));
+    std::vector<int> h_pair(n); std::vector<uint8_t> h_flip(n);
+    const double thr = 2 * DSSS_PI_REF / 3;                         // optimizer.cpp:697-703: sticky within one LoopClosingTFs call
+    for (int p = 0; p < npairs; ++p) {
+        const dsss_frame &fs = c->frames[src_ids[p]], &ft = c->frames[tgt_ids[p]];
+        if (!fs.h_geo || !ft.h_geo) DSSS_FAIL(c, DSSS_E_STATE, "pair %d: host copy of the DR poses missing", p);
+        uint8_t flip = 0;
+        for (int i = pair_off[p]; i < pair_off[p + 1]; ++i) {
+            const double* k = h.data() + (size_t)i * 7;
+            const bool ok = k[0] >= 0 && k[0] < fs.N && k[3] >= 0 && k[3] < ft.N && k[1] >= 1 && k[1] < fs.M && k[4] >= 1 && k[4] < ft.M;
+            if (!ok) DSSS_FAIL(c, DSSS_E_ARG, "pair %d kp7 row %d: ping/bin outside the frames", p, i - pair_off[p]);
+            if (std::fabs(fs.h_geo[(size_t)(int)k[0] * 6 + 2]) > thr) flip |= 1;
+            if (std::fabs(ft.h_geo[(size_t)(int)k[3] * 6 + 2]) > thr) flip |= 2;
+            h_pair[i] = p; h_flip[i] = flip;
+        }
+    }
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if ((size_t)npairs > c->match_cap_pairs) {
+        c->match_cap_pairs = 0;
+        hipFree(c->act_s); c->act_s = nullptr; hipFree(c->act_t); c->act_t = nullptr; hipFree(c->kp7_off); c->kp7_off = nullptr;
+        hipFree(c->corres_nn); c->corres_nn = nullptr; hipFree(c->corres); c->corres = nullptr;
+        hipFree(c->scc_hist); c->scc_hist = nullptr; hipFree(c->scc_count); c->scc_count = nullptr; hipFree(c->scc_model); c->scc_model = nullptr;
+        hipFree(c->row_cnt); c->row_cnt = nullptr; hipFree(c->kp7_cnt); c->kp7_cnt = nullptr; hipFree(c->row_off); c->row_off = nullptr;
+        HIPCHK(c, hipMalloc(&c->act_s, npairs * sizeof(int))); HIPCHK(c, hipMalloc(&c->act_t, npairs * sizeof(int)));
+        HIPCHK(c, hipMalloc(&c->kp7_off, (npairs + 1) * sizeof(int)));
+        // (the matcher's own per-pair buffers are re-created by the next dsss_match_pairs: capacity stays 0)
+    }
+    if ((size_t)n > c->rows_cap) {
+        c->rows_cap = 0;
+        hipFree(c->rows6); c->rows6 = nullptr; hipFree(c->kp7); c->kp7 = nullptr; hipFree(c->kp7_pair); c->kp7_pair = nullptr; hipFree(c->kp7_flip); c->kp7_flip = nullptr;
+        const size_t want = (size_t)n + 1024;
+        HIPCHK(c, hipMalloc(&c->rows6, want * 6 * sizeof(double))); HIPCHK(c, hipMalloc(&c->kp7, want * 7 * sizeof(double)));
+        HIPCHK(c, hipMalloc(&c->kp7_pair, want * sizeof(int))); HIPCHK(c, hipMalloc(&c->kp7_flip, want));
+        c->rows_cap = want;
+    }
+    HIPCHK(c, hipMemcpy(c->act_s, src_ids, npairs * sizeof(int), hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(c->act_t, tgt_ids, npairs * sizeof(int), hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(c->kp7_off, pair_off, (npairs + 1) * sizeof(int), hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(c->kp7, h.data(), h.size() * sizeof(double), hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(c->kp7_pair, h_pair.data(), (size_t)n * sizeof(int), hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(c->kp7_flip, h_flip.data(), (size_t)n, hipMemcpyHostToDevice));
+    return dsss_lc_solve_all(c);
+}
+
 int dsss_lc_solve(dsss_ctx* c, int id_s, int id_t, const double* kp7, int n, dsss_lc* out)
 {
     if (!c || n < 0 || (n > 0 && (!kp7 || !out))) return DSSS_E_ARG;
@@ -398,6 +590,62 @@ int dsss_lc_solve(dsss_ctx* c, int id_s, int id_t, const double* kp7, int n, dss
     if (e == hipSuccess) e = hipMemcpyAsync(out, d_out, (size_t)n * sizeof(dsss_lc), hipMemcpyDeviceToHost, c->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
     hipFree(d_kp7); hipFree(d_out);
+    HIPCHK(c, e);
+    return DSSS_OK;
+}
+
+// Optimizer::TriangulateOneLandmark for every row of the caller's kp7 list of one pair (optimizer.h:56-59, call site
+// optimizer.cpp:907-921).  out7_host: n x 7 = [x y z | |range_s err| |plane_s| |range_t err| |plane_t|].
+int dsss_triangulate(dsss_ctx* c, int id_s, int id_t, const double* kp7, int n, double* out7)
+{
+    if (!c || n < 0 || (n > 0 && (!kp7 || !out7))) return DSSS_E_ARG;
+    if (id_s < 0 || id_s >= c->max_frames || id_t < 0 || id_t >= c->max_frames) DSSS_FAIL(c, DSSS_E_ARG, "frame id out of range");
+    const dsss_frame &fs = c->frames[id_s], &ft = c->frames[id_t];
+    if (!fs.has_geom || !ft.has_geom) DSSS_FAIL(c, DSSS_E_STATE, "frames need dsss_frame_set first");
+    if (n == 0) return DSSS_OK;
+    HIPCHK(c, hipSetDevice(c->device));
+    std::vector<double> h((size_t)n * 7);
+    HIPCHK(c, hipMemcpy(h.data(), kp7, h.size() * sizeof(double), hipMemcpyDefault));
+    for (int i = 0; i < n; ++i) {
+        const double* k = h.data() + (size_t)i * 7;
+        const bool ok = k[0] >= 0 && k[0] < fs.N && k[3] >= 0 && k[3] < ft.N && k[1] >= 1 && k[1] < fs.M && k[4] >= 1 && k[4] < ft.M;
+        if (!ok) DSSS_FAIL(c, DSSS_E_ARG, "kp7 row %d: ping/bin outside the frames", i);
+    }
+    double* d_kp7 = nullptr; double* d_out = nullptr;
+    HIPCHK(c, hipMalloc(&d_kp7, h.size() * sizeof(double)));
+    hipError_t e = hipMalloc(&d_out, h.size() * sizeof(double));
+    if (e == hipSuccess) e = hipMemcpyAsync(d_kp7, h.data(), h.size() * sizeof(double), hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(tri_kernel, dim3((n + 63) / 64), dim3(64), 0, c->stream, d_kp7, n, fs.pose6, fs.alt, fs.gr, fs.M, ft.pose6, ft.alt, ft.gr, ft.M, (const double*)nullptr, d_out);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(out7, d_out, h.size() * sizeof(double), hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    hipFree(d_kp7); hipFree(d_out);
+    HIPCHK(c, e);
+    return DSSS_OK;
+}
+
+// the same with the caller's own poses: Optimizer::TriangulateOneLandmark(kps_pair, Ts_s, Ts_t, Tp_s, Tp_t, lm_ini) with
+// Ts = identity (frame.cpp:38-39).  in27: n x [Tp_s R(9) t(3) | Tp_t R(9) t(3) | lm_ini(3)]; only kp7[2], kp7[5] (slant ranges) are read.
+int dsss_triangulate_poses(dsss_ctx* c, const double* kp7, const double* in27, int n, double* out7)
+{
+    if (!c || n < 0 || (n > 0 && (!kp7 || !in27 || !out7))) return DSSS_E_ARG;
+    if (n == 0) return DSSS_OK;
+    HIPCHK(c, hipSetDevice(c->device));
+    double* d = nullptr;
+    HIPCHK(c, hipMalloc(&d, (size_t)n * (7 + 27 + 7) * sizeof(double)));
+    double* d_kp7 = d; double* d_in = d + (size_t)n * 7; double* d_out = d_in + (size_t)n * 27;
+    hipError_t e = hipMemcpyAsync(d_kp7, kp7, (size_t)n * 7 * sizeof(double), hipMemcpyDefault, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_in, in27, (size_t)n * 27 * sizeof(double), hipMemcpyDefault, c->stream);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(tri_kernel, dim3((n + 63) / 64), dim3(64), 0, c->stream, d_kp7, n, (const double*)nullptr, (const double*)nullptr, (const double*)nullptr, 0,
+                           (const double*)nullptr, (const double*)nullptr, (const double*)nullptr, 0, (const double*)d_in, d_out);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(out7, d_out, (size_t)n * 7 * sizeof(double), hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    hipFree(d);
     HIPCHK(c, e);
     return DSSS_OK;
 }

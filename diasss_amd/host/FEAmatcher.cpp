@@ -1,6 +1,9 @@
 // diasss_amd/host/FEAmatcher.cpp -- FEAmatcher over the C ABI (mirrors /root/reference/src/core/FEAmatcher.cpp:13-50)
 #include "FEAmatcher.h"
 #include "dsss_device.h"
+#include <algorithm>
+#include <cmath>
+#include <cstdlib>
 
 namespace Diasss
 {
@@ -45,6 +48,57 @@ void FEAmatcher::RobustMatching(Frame &SourceFrame, Frame &TargetFrame)
     std::vector<double> rows((size_t)n * 6);
     Device::check(dsss_match_get_rows(c, 0, rows.data(), n, &n), "dsss_match_get_rows");
     append_rows(SourceFrame, TargetFrame, rows, n);
+}
+
+std::vector<int> FEAmatcher::GeoNearNeighSearch(const int &img_id, const int &img_id_ref, const cv::Mat &, const cv::Mat &,
+                                                const std::vector<cv::KeyPoint> &kps, const cv::Mat &, const std::vector<cv::Mat> &,
+                                                const std::vector<cv::KeyPoint> &, const cv::Mat &, const std::vector<cv::Mat> &,
+                                                std::vector<std::pair<int,double>> &scc)
+{
+    dsss_ctx* c = Device::ctx();
+    const int s = img_id, t = img_id_ref;
+    Device::check(dsss_match_pairs(c, &s, &t, 1), "dsss_match_pairs");
+    std::vector<int> CorresID(kps.size(), -1);
+    int hist = 0, count = 0; double model = 0;
+    std::vector<int32_t> buf(std::max<size_t>(kps.size(), 1));
+    Device::check(dsss_match_get_dir(c, 0, 0, nullptr, buf.data(), (int)buf.size(), &hist, &count, &model), "dsss_match_get_dir");
+    for (size_t i = 0; i < kps.size(); ++i) CorresID[i] = buf[i];
+    scc.clear();
+    if (hist > 0) scc.push_back(std::make_pair(count, model));         // FEAmatcher.cpp:229-231: the last improvement is the maximum
+    return CorresID;
+}
+
+void FEAmatcher::ConsistentCheck(const Frame &SourceFrame, const Frame &TargetFrame,
+                                 const std::vector<int> &CorresID_1, const std::vector<int> &CorresID_2,
+                                 std::vector<std::pair<int,double>> &scc_1, std::vector<std::pair<int,double>> &scc_2,
+                                 std::vector<cv::KeyPoint> &SourceKeys, std::vector<cv::KeyPoint> &TargetKeys)
+{
+    const double kp_diff_thres = 2.5;                                  // FEAmatcher.cpp:329
+    std::sort(scc_1.rbegin(), scc_1.rend());
+    std::sort(scc_2.rbegin(), scc_2.rend());
+    double img_diff = 0;
+    if (SourceFrame.img_id % 2 != TargetFrame.img_id % 2) img_diff = std::abs(SourceFrame.raw_img.rows - TargetFrame.raw_img.rows);
+    // scc_x[0] of an empty vector is undefined in the reference (:344): no model on either side means no merge
+    const bool merge = !scc_1.empty() && !scc_2.empty() && std::abs(std::abs(scc_1[0].second - scc_2[0].second) - img_diff) <= kp_diff_thres;
+    auto take1 = [&](bool skip_mutual) {
+        for (size_t i = 0; i < CorresID_1.size(); i++) {
+            if (CorresID_1[i] == -1) continue;
+            if (skip_mutual && CorresID_2[CorresID_1[i]] == (int)i) continue;
+            SourceKeys.push_back(SourceFrame.kps[i]); TargetKeys.push_back(TargetFrame.kps[CorresID_1[i]]);
+        }
+    };
+    auto take2 = [&]() {
+        for (size_t i = 0; i < CorresID_2.size(); i++) {
+            if (CorresID_2[i] == -1) continue;
+            SourceKeys.push_back(SourceFrame.kps[CorresID_2[i]]); TargetKeys.push_back(TargetFrame.kps[i]);
+        }
+    };
+    if (merge) { take1(true); take2(); }
+    else {
+        const long inl_1 = (long)CorresID_1.size() - std::count(CorresID_1.begin(), CorresID_1.end(), -1);
+        const long inl_2 = (long)CorresID_2.size() - std::count(CorresID_2.begin(), CorresID_2.end(), -1);
+        if (inl_1 > inl_2) take1(false); else take2();
+    }
 }
 
 int FEAmatcher::DescriptorDistance(const cv::Mat &a, const cv::Mat &b)

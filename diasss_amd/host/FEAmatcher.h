@@ -19,6 +19,22 @@ namespace Diasss
         // batched extension: every listed (source index, target index) pair in ONE device call
         static void RobustMatchingAll(std::vector<Frame> &Frames, const std::vector<std::pair<int,int>> &Pairs);
 
+        // FEAmatcher.h:22-26 -- one direction of the geo-gated nearest-neighbour search + sliding compatibility check.
+        // The features of both frames are the device-resident ones of img_id / img_id_ref (what RobustMatching passes:
+        // the frames' own kps / dst / geo_img), so the image, keypoint and descriptor arguments only fix the sizes.
+        // scc receives the best (inlier count, model) pair -- the only entry ConsistentCheck reads after its sort.
+        static std::vector<int> GeoNearNeighSearch(const int &img_id, const int &img_id_ref,
+                                                   const cv::Mat &img, const cv::Mat &img_ref,
+                                                   const std::vector<cv::KeyPoint> &kps, const cv::Mat &dst, const std::vector<cv::Mat> &geo_img,
+                                                   const std::vector<cv::KeyPoint> &kps_ref, const cv::Mat &dst_ref, const std::vector<cv::Mat> &geo_img_ref,
+                                                   std::vector<std::pair<int,double>> &scc);
+
+        // FEAmatcher.h:28-31 -- bidirectional merge (FEAmatcher.cpp:323-405), host logic on the two CorresID vectors
+        static void ConsistentCheck(const Frame &SourceFrame, const Frame &TargetFrame,
+                                    const std::vector<int> &CorresID_1, const std::vector<int> &CorresID_2,
+                                    std::vector<std::pair<int,double>> &scc_1, std::vector<std::pair<int,double>> &scc_2,
+                                    std::vector<cv::KeyPoint> &SourceKeys, std::vector<cv::KeyPoint> &TargetKeys);
+
         // FEAmatcher.h:33 on descriptor rows (host utility; the device matcher uses v_bcnt)
         static int DescriptorDistance(const cv::Mat &a, const cv::Mat &b);
     };

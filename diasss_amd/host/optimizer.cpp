@@ -8,6 +8,8 @@
 #include <fstream>
 #include <iomanip>
 #include <iostream>
+#include <stdexcept>
+#include <algorithm>
 
 namespace Diasss
 {
@@ -68,24 +70,38 @@ std::vector<std::tuple<Pose3,Vector6,double>> Optimizer::LoopClosingTFs(const st
     return out;
 }
 
+Optimizer::Point3 Optimizer::TriangulateOneLandmark(const Vector7 &kps_pair, const Pose3 &, const Pose3 &,
+                                                    const Pose3 &Tp_s, const Pose3 &Tp_t, const Point3 &lm_ini)
+{
+    double in27[27], out7[7];
+    for (int k = 0; k < 9; ++k) { in27[k] = Tp_s.R[k]; in27[12 + k] = Tp_t.R[k]; }
+    for (int k = 0; k < 3; ++k) { in27[9 + k] = Tp_s.t[k]; in27[21 + k] = Tp_t.t[k]; in27[24 + k] = lm_ini[k]; }
+    Device::check(dsss_triangulate_poses(Device::ctx(), kps_pair.data(), in27, 1, out7), "dsss_triangulate_poses");
+    return Point3{ { out7[0], out7[1], out7[2] } };
+}
+
 void Optimizer::TrajOptimizationAll(std::vector<Frame> &AllFrames)
 {
     const size_t F = AllFrames.size();
-    // --- keypoint pairs and LC measurements of every frame pair (optimizer.cpp:35-97)
+    dsss_ctx* c = Device::ctx();
+    // --- keypoint pairs of every frame pair (optimizer.cpp:35-97): GetKpsPairs on the host from corres_kps or, with
+    //     USE_ANNO, from anno_kps; the LoopClosingTFs calls of ALL pairs then run as ONE device launch
     std::vector<std::vector<Vector7>> kps_pairs_all;
-    std::vector<std::pair<int,int>> img_pairs_ids;
-    std::vector<std::vector<std::tuple<Pose3,Vector6,double>>> lc_tf_all;
+    std::vector<int> ps, pt, pair_off(1, 0);
+    std::vector<double> kp7;
     for (size_t i = 0; i < F; i++)
         for (size_t j = i + 1; j < F; j++) {
             const cv::Mat &src = USE_ANNO ? AllFrames[i].anno_kps : AllFrames[i].corres_kps;
             kps_pairs_all.push_back(GetKpsPairs(USE_ANNO, src, AllFrames[i].img_id, AllFrames[j].img_id, AllFrames[i].altitudes,
                                                 AllFrames[i].ground_ranges, AllFrames[j].altitudes, AllFrames[j].ground_ranges));
-            img_pairs_ids.push_back(std::make_pair(AllFrames[i].img_id, AllFrames[j].img_id));
-            lc_tf_all.push_back(LoopClosingTFs(kps_pairs_all.back(), AllFrames[i].tf_stb, AllFrames[i].tf_port, AllFrames[i].img_id,
-                                               AllFrames[j].img_id, AllFrames[i].geo_img, AllFrames[j].geo_img, AllFrames[i].altitudes,
-                                               AllFrames[j].altitudes, AllFrames[i].ground_ranges, AllFrames[j].ground_ranges,
-                                               AllFrames[i].dr_poses, AllFrames[j].dr_poses));
+            ps.push_back(AllFrames[i].img_id); pt.push_back(AllFrames[j].img_id);
+            for (const Vector7 &v : kps_pairs_all.back()) kp7.insert(kp7.end(), v.begin(), v.end());
+            pair_off.push_back((int)(kp7.size() / 7));
         }
+    // the device works on frame ids 0..F-1 in AllFrames order (diasss2.cpp:84 numbers them that way)
+    for (size_t i = 0; i < F; i++)
+        if (AllFrames[i].img_id != (int)i) throw std::runtime_error("TrajOptimizationAll: AllFrames[i].img_id must equal i (diasss2.cpp:84)");
+    Device::check(dsss_lc_solve_pairs(c, ps.data(), pt.data(), (int)ps.size(), kp7.data(), pair_off.data()), "dsss_lc_solve_pairs");
     // --- unique pose ids (optimizer.cpp:101-114)
     int id_sum = 0;
     std::vector<std::vector<int>> unique_id;
@@ -94,36 +110,21 @@ void Optimizer::TrajOptimizationAll(std::vector<Frame> &AllFrames)
         for (int j = 0; j < AllFrames[i].dr_poses.rows; j++) id_tmp[j] = id_sum++;
         unique_id.push_back(id_tmp);
     }
-    // --- LC factor per target ping: last pair wins, first kp in it, score > 0 (optimizer.cpp:203-258)
-    std::vector<dsss_lc_edge> edges;
-    if (ADD_LC)
-        for (size_t i = 1; i < F; i++)
-            for (int j = 0; j < AllFrames[i].dr_poses.rows; j++) {
-                int kps_id = -1, img_pair_id = -1;
-                for (size_t k = 0; k < img_pairs_ids.size(); k++) {
-                    if (img_pairs_ids[k].second != (int)i) continue;
-                    for (size_t q = 0; q < kps_pairs_all[k].size(); q++)
-                        if ((int)kps_pairs_all[k][q][3] == j) { kps_id = (int)q; img_pair_id = (int)k; break; }
-                }
-                if (kps_id != -1 && std::get<2>(lc_tf_all[img_pair_id][kps_id]) > 0) {
-                    dsss_lc_edge e;
-                    e.a = unique_id[img_pairs_ids[img_pair_id].first][(int)kps_pairs_all[img_pair_id][kps_id][0]];
-                    e.b = unique_id[i][j];
-                    const Pose3 &T = std::get<0>(lc_tf_all[img_pair_id][kps_id]);
-                    for (int k = 0; k < 9; ++k) e.rel[k] = T.R[k];
-                    for (int k = 0; k < 3; ++k) e.rel[9 + k] = T.t[k];
-                    for (int k = 0; k < 6; ++k) e.var[k] = std::get<1>(lc_tf_all[img_pair_id][kps_id])[k];
-                    edges.push_back(e);
-                }
-            }
-    // --- batch LM over every ping (replaces the iSAM2 loop, optimizer.cpp:134-279)
-    std::vector<double> dr;
-    for (size_t i = 0; i < F; i++) dr.insert(dr.end(), AllFrames[i].dr_poses.ptr<double>(), AllFrames[i].dr_poses.ptr<double>() + (size_t)AllFrames[i].dr_poses.rows * 6);
+    // --- LC factor per target ping (last pair wins, first kp in it, score > 0: optimizer.cpp:203-258) and the batch LM over
+    //     every ping (replaces the iSAM2 loop, :134-279), both on the device
     std::vector<double> poses12((size_t)id_sum * 12);
-    double stats[4];
-    Device::check(dsss_posegraph_solve_edges(Device::ctx(), dr.data(), id_sum, edges.data(), (int)edges.size(), poses12.data(), stats),
-                  "dsss_posegraph_solve_edges");
-    std::cout << "pose graph: " << id_sum << " poses, " << edges.size() << " loop closures, " << (int)stats[0] << " LM iterations, error "
+    double stats[4] = { 0, 0, 0, 0 };
+    int n_edges = 0;
+    if (ADD_LC) {
+        Device::check(dsss_posegraph_solve(c, (int)F, poses12.data(), nullptr, stats), "dsss_posegraph_solve");
+        std::vector<dsss_lc_edge> tmp((size_t)std::max<size_t>(kp7.size() / 7, 1));
+        Device::check(dsss_posegraph_select(c, (int)F, tmp.data(), (int)tmp.size(), &n_edges), "dsss_posegraph_select");
+    } else {
+        std::vector<double> dr;
+        for (size_t i = 0; i < F; i++) dr.insert(dr.end(), AllFrames[i].dr_poses.ptr<double>(), AllFrames[i].dr_poses.ptr<double>() + (size_t)AllFrames[i].dr_poses.rows * 6);
+        Device::check(dsss_posegraph_solve_edges(c, dr.data(), id_sum, nullptr, 0, poses12.data(), stats), "dsss_posegraph_solve_edges");
+    }
+    std::cout << "pose graph: " << id_sum << " poses, " << n_edges << " loop closures, " << (int)stats[0] << " LM iterations, error "
               << stats[1] << " -> " << stats[2] << std::endl;
     size_t o = 0;
     for (size_t i = 0; i < F; i++) {

@@ -40,6 +40,11 @@ namespace Diasss
                                                         const std::vector<double> &gras_s, const std::vector<double> &gras_t,
                                                         const cv::Mat &dr_poses_s, const cv::Mat &dr_poses_t);      // optimizer.h:61-67
 
+        // optimizer.h:56-59 (3-DoF LM on one landmark, both ping poses fixed; Ts_s / Ts_t must be the identity, frame.cpp:38-39)
+        typedef std::array<double, 3> Point3;
+        Point3 static TriangulateOneLandmark(const Vector7 &kps_pair, const Pose3 &Ts_s, const Pose3 &Ts_t,
+                                             const Pose3 &Tp_s, const Pose3 &Tp_t, const Point3 &lm_ini);
+
         // optimizer.h:73-74; poses12 = total x 12 (R row-major, t) instead of gtsam::Values
         void static SaveTrajactoryAll(const std::vector<double> &poses12, const std::vector<std::vector<int>> &unique_id,
                                       const std::vector<cv::Mat> &dr_poses_all);

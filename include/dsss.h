@@ -127,8 +127,20 @@ int dsss_descriptor_distance(dsss_ctx*, int id_a, int ia, int id_b, int ib, int*
  * LoopClosingTFs (optimizer.cpp:641-982) for every kp pair produced by dsss_match_pairs.                   */
 int dsss_lc_solve_all(dsss_ctx*);
 int dsss_lc_get(dsss_ctx*, int pair, dsss_lc* out_host, int cap, int* n);
-/* stand-alone form (tests): kp7 given by the caller                                                         */
+/* stand-alone form: kp7 given by the caller (Optimizer::LoopClosingTFs of ONE pair, optimizer.h:61-67)     */
 int dsss_lc_solve(dsss_ctx*, int id_s, int id_t, const double* kp7, int n, dsss_lc* out_host);
+/* the same for the kp7 lists of MANY pairs in one launch (the pair loop of TrajOptimizationAll, optimizer.cpp:35-97,
+ * with kp7 built by the caller's GetKpsPairs from corres_kps or -- USE_ANNO = 1, optimizer.cpp:26,42-53 -- anno_kps).
+ * kp7: pair_off[npairs] x 7 (host or device); pair_off: npairs + 1 ascending offsets (host).  Results stay on the device
+ * as after dsss_match_pairs + dsss_lc_solve_all: dsss_lc_get / dsss_posegraph_select / dsss_posegraph_solve follow.     */
+int dsss_lc_solve_pairs(dsss_ctx*, const int* src_ids, const int* tgt_ids, int npairs, const double* kp7, const int* pair_off_host);
+/* LMTriaFactor + Optimizer::TriangulateOneLandmark (LMtriangulatefactor.cpp:10-27; optimizer.h:56-59, optimizer.cpp:984-1021)
+ * for every kp7 row of one pair, as LoopClosingTFs calls it (optimizer.cpp:907-921: yaw-compensated DR poses, landmark
+ * initialised as in :789-795).  out7_host: n x 7 = [x y z | |range_s err| |plane_s| |range_t err| |plane_t|]          */
+int dsss_triangulate(dsss_ctx*, int id_s, int id_t, const double* kp7, int n, double* out7_host);
+/* the same with the caller's poses and start point (the literal signature of optimizer.h:56-59, Ts = identity):
+ * in27: n x [Tp_s R(9) t(3) | Tp_t R(9) t(3) | lm_ini(3)]; of kp7 only the slant ranges [2], [5] are read          */
+int dsss_triangulate_poses(dsss_ctx*, const double* kp7, const double* in27, int n, double* out7_host);
 /* TrajOptimizationAll (optimizer.h:43; optimizer.cpp:101-279): LC selection + batch LM over every ping of
  * every frame 0..nframes-1 (frames must have been given with dsss_frame_set). poses12_host: total x 12
  * (R row-major, t); rpy6_host: total x 6 "r p y x y z" as SaveTrajactoryAll writes (:1164-1214), may be NULL.

@@ -247,6 +247,32 @@ def lc_solve(kp7, pose_s, alt_s, gr_s, Ms, pose_t, alt_t, gr_t, Mt):
     return out[:n].copy()
 
 
+def triangulate(kp7, pose_s, alt_s, gr_s, Ms, pose_t, alt_t, gr_t, Mt):
+    """orc_triangulate: n x 7 = [x y z | range_s plane_s range_t plane_t] (optimizer.cpp:907-921, 984-1021)"""
+    kp7 = np.ascontiguousarray(kp7, np.float64).reshape(-1, 7)
+    n = len(kp7)
+    out = np.zeros((max(n, 1), 7))
+    pose_s = np.ascontiguousarray(pose_s, np.float64); pose_t = np.ascontiguousarray(pose_t, np.float64)
+    alt_s = np.ascontiguousarray(alt_s, np.float64); gr_s = np.ascontiguousarray(gr_s, np.float64)
+    alt_t = np.ascontiguousarray(alt_t, np.float64); gr_t = np.ascontiguousarray(gr_t, np.float64)
+    lib().orc_triangulate(dp(kp7), n, dp(pose_s), dp(alt_s), dp(gr_s), pose_s.shape[0], Ms,
+                          dp(pose_t), dp(alt_t), dp(gr_t), pose_t.shape[0], Mt, dp(out))
+    return out[:n].copy()
+
+
+def triangulate_one(kp7, Tp_s, Tp_t, lm_ini):
+    """orc_triangulate_one with identity sensor offsets; Tp_* = 12 doubles (R row-major, t)"""
+    Ts = Pose(); Ts.R[0] = Ts.R[4] = Ts.R[8] = 1.0
+    Ps = Pose(); Pt = Pose()
+    for k in range(9):
+        Ps.R[k] = float(Tp_s[k]); Pt.R[k] = float(Tp_t[k])
+    for k in range(3):
+        Ps.t[k] = float(Tp_s[9 + k]); Pt.t[k] = float(Tp_t[9 + k])
+    kp7 = np.ascontiguousarray(kp7, np.float64); ini = np.ascontiguousarray(lm_ini, np.float64); out = np.zeros(3)
+    it = lib().orc_triangulate_one(dp(kp7), C.byref(Ts), C.byref(Ts), C.byref(Ps), C.byref(Pt), dp(ini), dp(out))
+    return out, int(it)
+
+
 def pg_select_lc(frame_rows, pair_s, pair_t, pair_off, kp7, lcs):
     frame_rows = np.ascontiguousarray(frame_rows, np.int32)
     pair_s = np.ascontiguousarray(pair_s, np.int32); pair_t = np.ascontiguousarray(pair_t, np.int32)

@@ -178,6 +178,11 @@ int orc_lc_solve(const double* kp7, int n, const double* pose6_s, const double* 
                  const double* pose6_t, const double* alt_t, const double* gr_t, int Nt, int Mt, orc_lc* out);
 
 /* ---------------------------------------------------------------- pose graph (optimizer.cpp:101-279, batch LM replaces iSAM2) */
+/* LMTriaFactor + TriangulateOneLandmark (LMtriangulatefactor.cpp:10-27, optimizer.cpp:984-1021, call site :907-921) */
+int orc_triangulate_one(const double kp7[7], const orc_pose* Ts_s, const orc_pose* Ts_t, const orc_pose* Tp_s, const orc_pose* Tp_t,
+                        const double lm_ini[3], double out[3]);
+int orc_triangulate(const double* kp7, int n, const double* pose6_s, const double* alt_s, const double* gr_s, int Ns, int Ms,
+                    const double* pose6_t, const double* alt_t, const double* gr_t, int Nt, int Mt, double* out7);
 typedef struct { int a, b; double rel[12]; double var[6]; } orc_lc_edge; /* BetweenFactor(X_a, X_b, rel, Variances(var)) */
 typedef struct {
     int max_iters; double rel_tol, abs_tol; double lambda0, lambda_factor, lambda_max; double min_fidelity;

@@ -284,3 +284,115 @@ int orc_lc_solve(const double* kp7, int n, const double* pose6_s, const double* 
     }
     return n;
 }
+
+/* ---- LMTriaFactor (LMtriangulatefactor.cpp:10-27) + Optimizer::TriangulateOneLandmark (optimizer.cpp:984-1021):
+ * 3-DoF LM on one landmark with both ping poses fixed.  The factor's residual and 2x3 Jacobian are exactly the
+ * residual and H1 of SssPointFactor (same expressions, pose held constant).  Graph: LMTriaFactor(s), LMTriaFactor(t),
+ * point prior at lm_ini with sigmas (10, 10, |xy baseline| / 100); GTSAM LM defaults.
+ * A zero baseline would make the prior a constrained model in GTSAM: clamped at 1e-9 like sig_odo above. */
+#define TROWS 7
+typedef struct { orc_pose Ts_s, Ts_t, Tp_s, Tp_t; double slant_s, slant_t, sig_s[2], sig_t[2], sig_p[3], ini[3]; } tri_t;
+static void tri_lin(const tri_t* m, const double* p, double* r, double* J /* 7 x 3 or NULL */)
+{
+    double ee[2], H1[6];
+    orc_sss_factor(p, &m->Tp_s, &m->Ts_s, m->slant_s, 0.0, ee, J ? H1 : NULL, NULL);
+    for (int i = 0; i < 2; ++i) { r[i] = ee[i] / m->sig_s[i]; if (J) for (int j = 0; j < 3; ++j) J[i * 3 + j] = H1[3 * i + j] / m->sig_s[i]; }
+    orc_sss_factor(p, &m->Tp_t, &m->Ts_t, m->slant_t, 0.0, ee, J ? H1 : NULL, NULL);
+    for (int i = 0; i < 2; ++i) { r[2 + i] = ee[i] / m->sig_t[i]; if (J) for (int j = 0; j < 3; ++j) J[(2 + i) * 3 + j] = H1[3 * i + j] / m->sig_t[i]; }
+    for (int i = 0; i < 3; ++i) { r[4 + i] = (p[i] - m->ini[i]) / m->sig_p[i]; if (J) for (int j = 0; j < 3; ++j) J[(4 + i) * 3 + j] = (i == j) ? 1.0 / m->sig_p[i] : 0.0; }
+}
+static double tri_err(const tri_t* m, const double* p)
+{
+    double r[TROWS]; tri_lin(m, p, r, NULL);
+    double s = 0; for (int i = 0; i < TROWS; ++i) s += r[i] * r[i];
+    return 0.5 * s;
+}
+int orc_triangulate_one(const double kp7[7], const orc_pose* Ts_s, const orc_pose* Ts_t, const orc_pose* Tp_s, const orc_pose* Tp_t,
+                        const double lm_ini[3], double out[3])
+{
+    const double PI = ORC_PI_REF, sigma_r = 0.1, alpha_bw = 0.1 * PI / 180;
+    tri_t m;
+    m.Ts_s = *Ts_s; m.Ts_t = *Ts_t; m.Tp_s = *Tp_s; m.Tp_t = *Tp_t;
+    m.slant_s = kp7[2]; m.slant_t = kp7[5];
+    m.sig_s[0] = sigma_r; m.sig_s[1] = kp7[2] * alpha_bw; m.sig_t[0] = sigma_r; m.sig_t[1] = kp7[5] * alpha_bw;
+    const double dx = Tp_s->t[0] - Tp_t->t[0], dy = Tp_s->t[1] - Tp_t->t[1];
+    m.sig_p[0] = 10.0; m.sig_p[1] = 10.0; m.sig_p[2] = sqrt(dx * dx + dy * dy) / 100;
+    if (m.sig_p[2] < 1e-9) m.sig_p[2] = 1e-9;
+    for (int i = 0; i < 3; ++i) m.ini[i] = lm_ini[i];
+    double p[3] = { lm_ini[0], lm_ini[1], lm_ini[2] };
+    const double relTol = 1e-5, absTol = 1e-5, lamMax = 1e5, minFid = 1e-3;
+    double lambda = 1e-5, err = tri_err(&m, p), cur;
+    int iters = 0;
+    if (err > 0) do {
+        cur = err;
+        double r[TROWS], J[TROWS * 3], H[9], g[3];
+        tri_lin(&m, p, r, J);
+        for (int a = 0; a < 3; ++a) {
+            double s = 0; for (int k = 0; k < TROWS; ++k) s += J[k * 3 + a] * r[k];
+            g[a] = s;
+            for (int b = 0; b < 3; ++b) { double t = 0; for (int k = 0; k < TROWS; ++k) t += J[k * 3 + a] * J[k * 3 + b]; H[a * 3 + b] = t; }
+        }
+        double oldLin = 0; for (int k = 0; k < TROWS; ++k) oldLin += r[k] * r[k];
+        oldLin *= 0.5;
+        for (;;) {
+            double A[9], d[3];
+            memcpy(A, H, sizeof A);
+            for (int a = 0; a < 3; ++a) { A[a * 3 + a] += lambda; d[a] = -g[a]; }
+            int ok = chol(A, 3) == 0, success = 0, stop = 0;
+            double newErr = 0, np_[3];
+            if (ok) {
+                chol_solve(A, 3, d);
+                double newLin = 0;
+                for (int k = 0; k < TROWS; ++k) { double s = r[k]; for (int a = 0; a < 3; ++a) s += J[k * 3 + a] * d[a]; newLin += s * s; }
+                newLin *= 0.5;
+                const double linChange = oldLin - newLin;
+                if (linChange >= 0) {
+                    for (int a = 0; a < 3; ++a) np_[a] = p[a] + d[a];
+                    newErr = tri_err(&m, np_);
+                    const double costChange = err - newErr;
+                    if (linChange > 2.220446049250313e-16 * oldLin) success = (costChange / linChange) > minFid;
+                    if (fabs(costChange) < relTol * err) stop = 1;
+                }
+            }
+            if (success) { for (int a = 0; a < 3; ++a) p[a] = np_[a]; err = newErr; lambda /= 10; ++iters; break; }
+            else if (!stop) { lambda *= 10; if (lambda >= lamMax) break; }
+            else break;
+        }
+    } while (iters < 100 && !((err <= 0) || ((cur - err) / cur <= relTol) || ((cur - err) <= absTol)) && isfinite(cur));
+    for (int a = 0; a < 3; ++a) out[a] = p[a];
+    return iters;
+}
+
+/* the call site in LoopClosingTFs (optimizer.cpp:907-921, eval_2): landmark triangulated from the (yaw-compensated,
+ * sticky) DR poses of both pings, initialised as in :789-795; out7 = [x y z | |range_s err| |plane_s| |range_t err| |plane_t|] */
+int orc_triangulate(const double* kp7, int n, const double* pose6_s, const double* alt_s, const double* gr_s, int Ns, int Ms,
+                    const double* pose6_t, const double* alt_t, const double* gr_t, int Nt, int Mt, double* out7)
+{
+    const double PI = ORC_PI_REF;
+    orc_pose cps_s, cps_t, ident;
+    memset(&ident, 0, sizeof ident); ident.R[0] = ident.R[4] = ident.R[8] = 1;
+    cps_s = ident; cps_t = ident;
+    const double flipv[3] = { 0, 0, PI };
+    for (int i = 0; i < n; ++i) {
+        const double* kp = kp7 + (size_t)i * 7;
+        const int id_s = (int)kp[0], id_t = (int)kp[3];
+        if (fabs(pose6_s[(size_t)id_s * 6 + 2]) > 2 * PI / 3) orc_so3_exp(flipv, cps_s.R);
+        if (fabs(pose6_t[(size_t)id_t * 6 + 2]) > 2 * PI / 3) orc_so3_exp(flipv, cps_t.R);
+        orc_pose Ps, Pt, Tp_s, Tp_t;
+        orc_pose_from_rodrigues(pose6_s + (size_t)id_s * 6, &Ps);
+        orc_pose_from_rodrigues(pose6_t + (size_t)id_t * 6, &Pt);
+        orc_pose_compose(&Ps, &cps_s, &Tp_s);
+        orc_pose_compose(&Pt, &cps_t, &Tp_t);
+        double gsx, gsy, gtx, gty, L0[3];
+        orc_geo_at(pose6_s, gr_s, Ns, Ms, id_s, (int)kp[1], &gsx, &gsy);
+        orc_geo_at(pose6_t, gr_t, Nt, Mt, id_t, (int)kp[4], &gtx, &gty);
+        L0[0] = (gsx + gtx) / 2; L0[1] = (gsy + gty) / 2;
+        L0[2] = ((pose6_s[(size_t)id_s * 6 + 5] - alt_s[id_s]) + (pose6_t[(size_t)id_t * 6 + 5] - alt_t[id_t])) / 2;
+        double* o = out7 + (size_t)i * 7;
+        orc_triangulate_one(kp, &ident, &ident, &Tp_s, &Tp_t, L0, o);
+        double e[2];
+        orc_sss_factor(o, &Tp_s, &ident, kp[2], 0.0, e, NULL, NULL); o[3] = fabs(e[0]); o[4] = fabs(e[1]);
+        orc_sss_factor(o, &Tp_t, &ident, kp[5], 0.0, e, NULL, NULL); o[5] = fabs(e[0]); o[6] = fabs(e[1]);
+    }
+    return n;
+}

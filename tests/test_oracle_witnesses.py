@@ -1,0 +1,181 @@
+"""Independent witnesses for the oracle's out-of-tree restatements (OpenCV / GTSAM are not in the image, so the oracle
+cannot be pinned against them): the same quantities computed by unrelated code that IS in the image -- scipy's matrix
+exponential / logarithm and Rotation for the Pose3 algebra, scipy.optimize.least_squares for the LM optima, a brute-force
+numpy FAST-9/16 written from the published definition, and a dense numpy Gauss-Newton for the pose graph.  Parity with the
+real libraries stays "unpinned"; these shrink the room for a wrong restatement."""
+import ctypes as C
+import numpy as np
+import scipy.linalg as sla
+from scipy.optimize import least_squares
+from scipy.spatial.transform import Rotation
+
+
+def _hat6(xi):
+    w, v = xi[:3], xi[3:]
+    X = np.zeros((4, 4))
+    X[:3, :3] = [[0, -w[2], w[1]], [w[2], 0, -w[0]], [-w[1], w[0], 0]]
+    X[:3, 3] = v
+    return X
+
+
+def _T(P):
+    M = np.eye(4); M[:3, :3] = np.array(P.R).reshape(3, 3); M[:3, 3] = P.t
+    return M
+
+
+def _pose_of(orc, M):
+    P = orc.Pose()
+    for i in range(9):
+        P.R[i] = float(M[:3, :3].flat[i])
+    for i in range(3):
+        P.t[i] = float(M[i, 3])
+    return P
+
+
+def test_pose_exp_log_vs_scipy_expm_logm(orc):
+    """Pose3::Expmap([w; v]) is the matrix exponential of the 4x4 twist; Logmap its principal logarithm"""
+    rng = np.random.default_rng(11)
+    for _ in range(100):
+        w = rng.standard_normal(3); w *= rng.uniform(1e-3, 3.0) / np.linalg.norm(w)
+        xi = np.concatenate([w, rng.uniform(-20, 20, 3)])
+        P = orc.Pose(); orc.lib().orc_pose_exp(orc.dp(np.ascontiguousarray(xi)), C.byref(P))
+        E = sla.expm(_hat6(xi))
+        assert np.abs(_T(P) - E).max() < 1e-11
+        assert np.abs(np.array(P.R).reshape(3, 3) - Rotation.from_rotvec(w).as_matrix()).max() < 1e-12
+        back = np.zeros(6); orc.lib().orc_pose_log(C.byref(P), orc.dp(back))
+        L = np.real(sla.logm(E))
+        assert np.abs(back - np.array([L[2, 1], L[0, 2], L[1, 0], L[0, 3], L[1, 3], L[2, 3]])).max() < 1e-8
+
+
+def test_adjoint_vs_matrix_conjugation(orc):
+    """AdjointMap(T) xi == vee(T hat(xi) T^-1), exactly linear (no small-angle argument)"""
+    rng = np.random.default_rng(12)
+    for _ in range(20):
+        xi0 = np.concatenate([rng.standard_normal(3), rng.uniform(-5, 5, 3)])
+        P = orc.Pose(); orc.lib().orc_pose_exp(orc.dp(np.ascontiguousarray(xi0)), C.byref(P))
+        Ad = np.zeros(36); orc.lib().orc_pose_adjoint(C.byref(P), orc.dp(Ad)); Ad = Ad.reshape(6, 6)
+        xi = rng.standard_normal(6)
+        Tm = _T(P)
+        Cj = Tm @ _hat6(xi) @ np.linalg.inv(Tm)
+        assert np.abs(Ad @ xi - np.array([Cj[2, 1], Cj[0, 2], Cj[1, 0], Cj[0, 3], Cj[1, 3], Cj[2, 3]])).max() < 1e-10
+
+
+def test_compose_between_inverse_vs_matrices(orc):
+    rng = np.random.default_rng(13)
+    for _ in range(20):
+        A = sla.expm(_hat6(rng.standard_normal(6))); B = sla.expm(_hat6(rng.standard_normal(6)))
+        PA, PB = _pose_of(orc, A), _pose_of(orc, B)
+        o = orc.Pose()
+        orc.lib().orc_pose_compose(C.byref(PA), C.byref(PB), C.byref(o)); assert np.abs(_T(o) - A @ B).max() < 1e-12
+        orc.lib().orc_pose_between(C.byref(PA), C.byref(PB), C.byref(o)); assert np.abs(_T(o) - np.linalg.inv(A) @ B).max() < 1e-12
+        orc.lib().orc_pose_inverse(C.byref(PA), C.byref(o)); assert np.abs(_T(o) - np.linalg.inv(A)).max() < 1e-12
+
+
+def _tri_residual(p, kp, Ts, Tt, ini, sig_p):
+    """LMTriaFactor x 2 + point prior, written from LMtriangulatefactor.cpp:10-27 / optimizer.cpp:984-1021 with numpy only"""
+    out = []
+    for T, slant in ((Ts, kp[2]), (Tt, kp[5])):
+        ps = T[:3, :3].T @ (p - T[:3, 3])
+        out += [(np.linalg.norm(ps) - slant) / 0.1, ps[0] / (slant * 0.1 * 3.14159265359 / 180)]
+    return np.array(out + list((p - ini) / sig_p))
+
+
+def test_triangulation_optimum_vs_scipy_least_squares(orc):
+    """the GTSAM-style LM of orc_triangulate_one stops within its 1e-5 relative tolerance of the least-squares optimum that
+    scipy finds for the same residual vector"""
+    rng = np.random.default_rng(14)
+    for _ in range(10):
+        lm = np.array([rng.uniform(-2, 2), rng.uniform(3, 8), -9.0 + rng.uniform(-0.5, 0.5)])
+        Ts = sla.expm(_hat6(np.array([0, 0, rng.uniform(-0.1, 0.1), 0, 0, 0]))); Ts[:3, 3] = [lm[0] + rng.normal(0, 0.01), 0, 0]
+        Tt = sla.expm(_hat6(np.array([0, 0, rng.uniform(-0.1, 0.1), 0, 0, 0]))); Tt[:3, 3] = [lm[0] + rng.normal(0, 0.01), 11.0, 0]
+        kp = np.array([0, 0, np.linalg.norm(lm - Ts[:3, 3]), 0, 0, np.linalg.norm(lm - Tt[:3, 3]), 0.0])
+        ini = lm + rng.normal(0, 0.2, 3)
+        sig_p = np.array([10.0, 10.0, np.hypot(*(Ts[:2, 3] - Tt[:2, 3])) / 100])
+        got, iters = orc.triangulate_one(kp, np.concatenate([Ts[:3, :3].ravel(), Ts[:3, 3]]), np.concatenate([Tt[:3, :3].ravel(), Tt[:3, 3]]), ini)
+        ref = least_squares(_tri_residual, ini, args=(kp, Ts, Tt, ini, sig_p), xtol=1e-14, ftol=1e-14, gtol=1e-14)
+        c_got = 0.5 * (_tri_residual(got, kp, Ts, Tt, ini, sig_p) ** 2).sum()
+        assert iters >= 1 and c_got <= ref.cost * (1 + 1e-4) + 1e-12
+        assert np.abs(got - ref.x).max() < 5e-3
+
+
+def _fast9_bruteforce(img, thr):
+    """corner iff >= 9 contiguous ring pixels are all > v + thr or all < v - thr; score = largest threshold that still
+    passes; strict 3x3 NMS, from the definition, no tricks"""
+    ring = [(0, 3), (1, 3), (2, 2), (3, 1), (3, 0), (3, -1), (2, -2), (1, -3), (0, -3), (-1, -3), (-2, -2), (-3, -1), (-3, 0), (-3, 1), (-2, 2), (-1, 3)]
+    H, W = img.shape
+    score = np.zeros((H, W), int)
+    I = img.astype(int)
+    for y in range(3, H - 3):
+        for x in range(3, W - 3):
+            d = np.array([I[y + dy, x + dx] - I[y, x] for dx, dy in ring])
+            best = 0
+            for s in range(16):
+                arc = d[(s + np.arange(9)) % 16]
+                best = max(best, arc.min(), (-arc).min())          # all brighter by >= arc.min(), or all darker by >= (-arc).min()
+            t = best - 1                                           # strict inequality: passes thresholds < best
+            if t >= thr:
+                score[y, x] = t
+    out = []
+    for y in range(3, H - 3):
+        for x in range(3, W - 3):
+            s = score[y, x]
+            if s and all(s > score[y + j, x + i] for j in (-1, 0, 1) for i in (-1, 0, 1) if (i or j)):
+                out.append((x, y, s))
+    return out
+
+
+def test_fast_cell_vs_bruteforce_numpy(orc):
+    """one FAST window of the oracle (cv::FAST(..., thr, true) semantics) against the brute-force definition"""
+    rng = np.random.default_rng(15)
+    lib = orc.lib()
+    for thr in (12, 7):
+        img = np.ascontiguousarray((rng.integers(0, 256, (40, 44)) // 4 * 4).astype(np.uint8))
+        cap = 4096
+        xs = np.zeros(cap, np.int32); ys = np.zeros(cap, np.int32); sc = np.zeros(cap, np.int32)
+        n = lib.orc_fast_window(orc.u8(img), img.shape[1], img.shape[0], img.shape[1], thr, orc.ip(xs), orc.ip(ys), orc.ip(sc), cap)
+        got = sorted(zip(xs[:n].tolist(), ys[:n].tolist(), sc[:n].tolist()), key=lambda t: (t[1], t[0]))
+        ref = sorted(_fast9_bruteforce(img, thr), key=lambda t: (t[1], t[0]))
+        assert len(ref) > 5 and got == ref
+
+
+def test_posegraph_vs_dense_numpy_gauss_newton(orc):
+    """the oracle's sparse LM against a dense numpy Gauss-Newton on the same factors (numeric Jacobians of the same
+    residual definitions): both reach the same optimum"""
+    n = 24
+    rng = np.random.default_rng(16)
+    dr = np.zeros((n, 6)); dr[:, 3] = 0.05 * np.arange(n); dr[:, 4] = 0.01 * np.sin(np.arange(n)); dr[:, 2] = 0.02 * np.cos(np.arange(n) / 5)
+    e = np.zeros(2, orc.LCEDGE_DTYPE)
+    for k, (a, b) in enumerate(((2, 17), (5, 22))):
+        Ta = sla.expm(_hat6(np.concatenate([dr[a, :3], [0, 0, 0]]))); Ta[:3, 3] = dr[a, 3:]
+        Tb = sla.expm(_hat6(np.concatenate([dr[b, :3], [0, 0, 0]]))); Tb[:3, 3] = dr[b, 3:]
+        rel = np.linalg.inv(Ta) @ Tb; rel[:3, 3] += rng.normal(0, 0.02, 3)
+        e["a"][k] = a; e["b"][k] = b; e["rel"][k] = np.concatenate([rel[:3, :3].ravel(), rel[:3, 3]]); e["var"][k] = [1e-6, 1e-6, 1e-5, 1e-3, 1e-3, 1e-3]
+    p = orc.pg_params(); p.add_noise = 0
+    out, stats = orc.pg_solve(dr, e, p)
+    PI = 3.14159265359
+    so = np.array([0.001 * PI / 180, 0.001 * PI / 180, 0.1 * 0.001 * 10 * PI / 180, 0.01, 0.01, 0.001])
+
+    def vee_log(M):
+        L = np.real(sla.logm(M)); return np.array([L[2, 1], L[0, 2], L[1, 0], L[0, 3], L[1, 3], L[2, 3]])
+    X0 = []
+    for i in range(n):
+        T = sla.expm(_hat6(np.concatenate([dr[i, :3], [0, 0, 0]]))); T[:3, 3] = dr[i, 3:]; X0.append(T)
+    meas = [X0[0]] + [np.linalg.inv(X0[i - 1]) @ X0[i] for i in range(1, n)]
+    rels = []
+    for k in range(2):
+        R = np.eye(4); R[:3, :3] = e["rel"][k][:9].reshape(3, 3); R[:3, 3] = e["rel"][k][9:]; rels.append(R)
+
+    def resid(x):
+        X = [X0[i] @ sla.expm(_hat6(x[6 * i:6 * i + 6])) for i in range(n)]
+        r = [vee_log(np.linalg.inv(meas[0]) @ X[0]) / 1e-6]
+        for i in range(1, n):
+            r.append(vee_log(np.linalg.inv(meas[i]) @ np.linalg.inv(X[i - 1]) @ X[i]) / so)
+        for k in range(2):
+            r.append(vee_log(np.linalg.inv(rels[k]) @ np.linalg.inv(X[e["a"][k]]) @ X[e["b"][k]]) / np.sqrt(e["var"][k]))
+        return np.concatenate(r)
+    sol = least_squares(resid, np.zeros(6 * n), xtol=1e-15, ftol=1e-15, gtol=1e-15, x_scale=1.0)
+    Xs = [X0[i] @ sla.expm(_hat6(sol.x[6 * i:6 * i + 6])) for i in range(n)]
+    ref = np.array([np.concatenate([T[:3, :3].ravel(), T[:3, 3]]) for T in Xs])
+    assert 0.5 * (resid(np.zeros(6 * n)) ** 2).sum() > 1.5 * sol.cost          # the loop closures really move the optimum off DR
+    assert np.abs(out - ref).max() < 2e-5, np.abs(out - ref).max()          # the oracle stops at GTSAM's relative tolerance 1e-5
+    assert abs(stats[2] - sol.cost) <= 1e-3 * max(sol.cost, 1e-12) + 1e-9
