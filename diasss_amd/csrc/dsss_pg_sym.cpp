@@ -1,0 +1,635 @@
+// diasss_amd/csrc/dsss_pg_sym.cpp -- ordering, symbolic factorisation, bins, fronts and schedule of the reduced pose-graph
+// system (see dsss_pg_sym.h), plus a host twin of the numeric phase for the CPU test-suite.  Plain C++, no HIP.
+#include "dsss_pg_sym.h"
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <mutex>
+#include <numeric>
+#include <thread>
+
+namespace {
+
+template <class F> void par_ranges(int n, int T, F fn)          // fn(t, lo, hi) over T contiguous ranges of [0, n)
+{
+    T = std::max(1, std::min(T, std::max(n, 1)));
+    std::vector<std::thread> th;
+    for (int t = 1; t < T; ++t) th.emplace_back([&, t] { fn(t, (int)((long long)n * t / T), (int)((long long)n * (t + 1) / T)); });
+    fn(0, 0, (int)((long long)n / T));
+    for (auto& x : th) x.join();
+}
+
+// nested dissection with vertex separators taken from the lower half.  The order of a subtree is [A][B][separator]; A and B
+// never touch, so the first PG_ND_PAR levels run their two halves on two host threads and the same tree of ranges later
+// drives the parallel column-structure pass.  While a node set spans several ranks the cut is the rank boundary (lower
+// ranks = A), so every rank's interior is one contiguous range of the order and the rank-level separators come last.
+struct nd_tree { int a = -1, b = -1, size = 0; };          // children (indices into the node pool) or -1,-1 for a leaf
+#define PG_ND_PAR 4
+struct nd_ctx {
+    const int* adj_ptr; const int* adj_idx; const double* cx; const double* cy; char* side; int leaf;
+    const int* part; char* iface;                          // rank of every node (or null); iface[v] = 1 for rank-level separator nodes
+    std::vector<nd_tree>* pool; std::mutex* mu;
+};
+int nd_order(std::vector<int>& nodes, const nd_ctx& C, std::vector<int>& order, int depth, int plo, int phi)
+{
+    auto new_node = [&](int a, int b, int size) { std::lock_guard<std::mutex> g(*C.mu); C.pool->push_back({ a, b, size }); return (int)C.pool->size() - 1; };
+    const int total = (int)nodes.size();
+    const bool by_part = C.part && phi - plo > 1;
+    if (!by_part && total <= C.leaf) { std::sort(nodes.begin(), nodes.end()); for (int v : nodes) order.push_back(v); return depth <= PG_ND_PAR ? new_node(-1, -1, total) : -1; }
+    size_t half;
+    const int pmid = (plo + phi) / 2;
+    if (by_part) {
+        half = std::stable_partition(nodes.begin(), nodes.end(), [&](int v) { return C.part[v] < pmid; }) - nodes.begin();
+    } else {
+        double x0 = 1e300, x1 = -1e300, y0 = 1e300, y1 = -1e300;
+        for (int v : nodes) { x0 = std::min(x0, C.cx[v]); x1 = std::max(x1, C.cx[v]); y0 = std::min(y0, C.cy[v]); y1 = std::max(y1, C.cy[v]); }
+        const bool byx = (x1 - x0) >= (y1 - y0);
+        half = nodes.size() / 2;
+        // split at the median of the (coordinate, index) total order; only the two halves matter, not their inner order
+        const double* key = byx ? C.cx : C.cy;
+        std::nth_element(nodes.begin(), nodes.begin() + half, nodes.end(), [&](int a, int b) {
+            const double ka = key[a], kb = key[b];
+            return ka != kb ? ka < kb : a < b; });
+    }
+    for (size_t i = 0; i < nodes.size(); ++i) C.side[nodes[i]] = i < half ? 1 : 2;
+    std::vector<int> A, B, S;
+    for (size_t i = 0; i < half; ++i) {
+        const int v = nodes[i];
+        bool cut = false;
+        for (int q = C.adj_ptr[v]; q < C.adj_ptr[v + 1]; ++q) if (C.side[C.adj_idx[q]] == 2) { cut = true; break; }
+        (cut ? S : A).push_back(v);
+    }
+    B.assign(nodes.begin() + half, nodes.end());
+    for (int v : nodes) C.side[v] = 0;
+    std::sort(S.begin(), S.end());
+    if (by_part) for (int v : S) C.iface[v] = 1;
+    if (!by_part && (A.empty() || B.empty())) {          // degenerate cut: fall back to index order
+        std::sort(nodes.begin(), nodes.end());
+        for (int v : nodes) order.push_back(v);
+        return depth <= PG_ND_PAR ? new_node(-1, -1, total) : -1;
+    }
+    int na = -1, nb = -1;
+    const int alo = plo, ahi = by_part ? pmid : phi, blo = by_part ? pmid : plo, bhi = phi;
+    if (depth < PG_ND_PAR && (total > 2048 || by_part)) {
+        std::vector<int> oa;
+        std::thread th([&] { na = nd_order(A, C, oa, depth + 1, alo, ahi); });
+        std::vector<int> ob;
+        nb = nd_order(B, C, ob, depth + 1, blo, bhi);
+        th.join();
+        order.insert(order.end(), oa.begin(), oa.end());
+        order.insert(order.end(), ob.begin(), ob.end());
+    } else {
+        nd_order(A, C, order, PG_ND_PAR + 1, alo, ahi);
+        nd_order(B, C, order, PG_ND_PAR + 1, blo, bhi);
+    }
+    for (int v : S) order.push_back(v);
+    return depth <= PG_ND_PAR ? new_node(na, nb, total) : -1;
+}
+
+// column structures of the range [lo, lo + size) of the elimination order described by tree node `t`, children merged
+// into parents (elimination tree built on the fly).  A column whose parent lies outside the range hands the
+// (parent, column) pair up to its caller.  No per-column allocations: the row lists of one call go into that call's pool
+// (cref = pool, offset, length) and the children of a column are a linked list (kid_head / kid_next).
+struct cref { int pool, off, n; };
+struct cs_ctx {
+    const int* adj_ptr; const int* adj_idx; const int* order; const int* perm; const std::vector<nd_tree>* pool;
+    std::vector<std::vector<int>>* pools; cref* cols; int* kid_head; int* kid_next; int* parent;
+};
+void col_structs(const cs_ctx& C, int t, int lo, int size, std::vector<std::pair<int, int>>& up, int depth)
+{
+    const nd_tree nd = t >= 0 ? (*C.pool)[t] : nd_tree();
+    int seq_lo = lo;
+    const int hi = lo + size;
+    auto add_kid = [&](int par, int j) { C.kid_next[j] = C.kid_head[par]; C.kid_head[par] = j; };
+    if (t >= 0 && nd.a >= 0 && nd.b >= 0) {
+        const int sa = (*C.pool)[nd.a].size, sb = (*C.pool)[nd.b].size;
+        std::vector<std::pair<int, int>> ua, ub;
+        std::thread th([&] { col_structs(C, nd.a, lo, sa, ua, depth + 1); });
+        col_structs(C, nd.b, lo + sa, sb, ub, depth + 1);
+        th.join();
+        for (auto* u : { &ua, &ub })
+            for (auto& e : *u) { if (e.first < hi) add_kid(e.first, e.second); else up.push_back(e); }
+        seq_lo = lo + sa + sb;
+    }
+    const int my_pool = t >= 0 ? t : (int)C.pools->size() - 1;
+    std::vector<int>& P = (*C.pools)[my_pool];
+    P.reserve((size_t)(hi - seq_lo) * 24);
+    std::vector<int> c;
+    for (int j = seq_lo; j < hi; ++j) {
+        c.clear();
+        const int v = C.order[j];
+        for (int q = C.adj_ptr[v]; q < C.adj_ptr[v + 1]; ++q) { const int pu = C.perm[C.adj_idx[q]]; if (pu > j) c.push_back(pu); }
+        for (int k = C.kid_head[j]; k >= 0; k = C.kid_next[k]) {
+            const cref ck = C.cols[k]; const int* d = (*C.pools)[ck.pool].data() + ck.off;
+            for (int q = 1; q < ck.n; ++q) if (d[q] != j) c.push_back(d[q]);
+        }
+        std::sort(c.begin(), c.end()); c.erase(std::unique(c.begin(), c.end()), c.end());
+        C.cols[j] = { my_pool, (int)P.size(), (int)c.size() + 1 };
+        P.push_back(j); P.insert(P.end(), c.begin(), c.end());
+        if (!c.empty()) {
+            C.parent[j] = c[0];
+            if (c[0] < hi) add_kid(c[0], j); else up.push_back({ c[0], j });
+        }
+    }
+}
+
+} // namespace
+
+void pg_symbolic(int ns, const std::vector<std::pair<int, int>>& edges, int nchain, const double* cx, const double* cy,
+                 const int* part, int nparts, const pg_sym_opts& opt, pg_sym& S)
+{
+    S = pg_sym();
+    S.ns = ns; S.nparts = std::max(1, nparts);
+    const bool tv = getenv("DSSS_PG_VERBOSE") != nullptr;
+    auto tnow = [] { return std::chrono::steady_clock::now(); };
+    auto tms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+    const auto q0 = tnow();
+    const int T = std::max(1, opt.threads);
+    // adjacency in CSR form, rows sorted and deduplicated
+    std::vector<int> adj_ptr(ns + 1, 0), adj_idx;
+    {
+        for (auto& e : edges) if (e.first != e.second) { adj_ptr[e.first + 1]++; adj_ptr[e.second + 1]++; }
+        for (int i = 0; i < ns; ++i) adj_ptr[i + 1] += adj_ptr[i];
+        std::vector<int> raw(adj_ptr[ns]), fill(adj_ptr.begin(), adj_ptr.end() - 1);
+        for (auto& e : edges) if (e.first != e.second) { raw[fill[e.first]++] = e.second; raw[fill[e.second]++] = e.first; }
+        adj_idx.reserve(raw.size());
+        std::vector<int> nptr(ns + 1, 0);
+        for (int i = 0; i < ns; ++i) {
+            int* b0 = raw.data() + adj_ptr[i]; int* e0 = raw.data() + adj_ptr[i + 1];
+            std::sort(b0, e0); e0 = std::unique(b0, e0);
+            adj_idx.insert(adj_idx.end(), b0, e0);
+            nptr[i + 1] = (int)adj_idx.size();
+        }
+        adj_ptr.swap(nptr);
+    }
+    std::vector<nd_tree> pool; std::mutex mu;
+    std::vector<char> iface(ns, 0);
+    int root = -1;
+    {
+        std::vector<int> nodes(ns); std::iota(nodes.begin(), nodes.end(), 0);
+        std::vector<char> side(ns, 0);
+        S.order.reserve(ns);
+        nd_ctx C{ adj_ptr.data(), adj_idx.data(), cx, cy, side.data(), opt.leaf, S.nparts > 1 ? part : nullptr, iface.data(), &pool, &mu };
+        root = nd_order(nodes, C, S.order, 0, 0, S.nparts);
+    }
+    const auto q1 = tnow();
+    S.perm.assign(ns, 0);
+    for (int i = 0; i < ns; ++i) S.perm[S.order[i]] = i;
+    S.col_part.assign(ns, 0);
+    for (int j = 0; j < ns; ++j) { const int v = S.order[j]; S.col_part[j] = iface[v] ? -1 : (part && S.nparts > 1 ? part[v] : 0); }
+    std::vector<cref> cols(ns);
+    S.parent.assign(ns, -1);
+    std::vector<int> kid_head(ns, -1), kid_next(ns, -1);
+    std::vector<std::vector<int>> pools(pool.size() + 1);
+    {
+        cs_ctx C{ adj_ptr.data(), adj_idx.data(), S.order.data(), S.perm.data(), &pool, &pools, cols.data(), kid_head.data(), kid_next.data(), S.parent.data() };
+        std::vector<std::pair<int, int>> up;
+        col_structs(C, root, 0, ns, up, 0);
+    }
+    const auto q2 = tnow();
+    S.colptr.assign(ns + 1, 0);
+    for (int j = 0; j < ns; ++j) S.colptr[j + 1] = S.colptr[j] + cols[j].n;
+    auto csz = [&](int j) { return S.colptr[j + 1] - S.colptr[j]; };
+    S.rowidx.resize(S.colptr[ns]);
+    S.nnzL = S.colptr[ns];
+    par_ranges(ns, T, [&](int, int lo, int hi) {
+        for (int k = lo; k < hi; ++k) { const int* d = pools[cols[k].pool].data() + cols[k].off; std::copy(d, d + cols[k].n, S.rowidx.begin() + S.colptr[k]); }
+    });
+    const std::vector<int>& parent = S.parent;
+    // ---- bottom subtrees -> bins (one workgroup each); only interior columns of one rank, at most 42 blocks per column
+    std::vector<double> sub_cost(ns, 0);
+    std::vector<char> sub_ok(ns, 0);
+    std::vector<int> nsrc(ns, 0);                          // number of source columns of every column = its count of off-diagonal blocks in row j
+    for (int k = 0; k < ns; ++k) for (int q = S.colptr[k] + 1; q < S.colptr[k + 1]; ++q) nsrc[S.rowidx[q]]++;
+    for (int j = 0; j < ns; ++j) {
+        const int mj = csz(j);
+        double cst = nsrc[j] + 20.0; bool ok = mj <= 42 && S.col_part[j] >= 0;
+        for (int k = kid_head[j]; k >= 0; k = kid_next[k]) { cst += sub_cost[k]; ok = ok && sub_ok[k]; }
+        sub_cost[j] = cst; sub_ok[j] = ok && cst <= opt.bin_cost;
+    }
+    S.binned.assign(sub_ok.begin(), sub_ok.end());
+    std::vector<int> root_of(ns, -1);                       // subtree root of every binned column
+    for (int j = ns - 1; j >= 0; --j) {
+        if (!sub_ok[j]) continue;
+        const int par = parent[j];
+        root_of[j] = (par >= 0 && sub_ok[par]) ? root_of[par] : j;
+    }
+    std::vector<int> bin_of_root(ns, -1);
+    {   // greedy packing of whole subtrees into bins, subtrees taken in ascending root order, never across ranks
+        std::vector<int> roots;
+        for (int j = 0; j < ns; ++j) if (sub_ok[j] && root_of[j] == j) roots.push_back(j);
+        int nbins = 0; double fill = opt.bin_cost + 1; int cur_part = -2;
+        for (int r : roots) {
+            if (fill + sub_cost[r] > opt.bin_cost || S.col_part[r] != cur_part) { ++nbins; fill = 0; cur_part = S.col_part[r]; S.bin_part.push_back(cur_part); }
+            fill += sub_cost[r]; bin_of_root[r] = nbins - 1;
+        }
+        S.binptr.assign(nbins + 1, 0);
+        for (int j = 0; j < ns; ++j) if (sub_ok[j]) S.binptr[bin_of_root[root_of[j]] + 1]++;
+        for (int b = 0; b < nbins; ++b) S.binptr[b + 1] += S.binptr[b];
+        S.bincols.resize(S.binptr[nbins]);
+        std::vector<int> fillp(S.binptr.begin(), S.binptr.end() - 1);
+        for (int j = 0; j < ns; ++j) if (sub_ok[j]) S.bincols[fillp[bin_of_root[root_of[j]]]++] = j;     // ascending within a bin
+        // roots that hand an update matrix up
+        S.broot_of_col.assign(ns, -1);
+        S.binroot_ptr.assign(nbins + 1, 0);
+        std::vector<int> idx_of_root(ns, -1);
+        for (int r : roots) if (csz(r) > 1) { idx_of_root[r] = (int)S.broot.size(); S.broot.push_back(r); S.broot_b.push_back(csz(r) - 1); S.binroot_ptr[bin_of_root[r] + 1]++; }
+        for (int b = 0; b < nbins; ++b) S.binroot_ptr[b + 1] += S.binroot_ptr[b];
+        S.binroot_idx.resize(S.broot.size());
+        { std::vector<int> fp(S.binroot_ptr.begin(), S.binroot_ptr.end() - 1); for (size_t i = 0; i < S.broot.size(); ++i) S.binroot_idx[fp[bin_of_root[S.broot[i]]]++] = (int)i; }
+        for (int j = 0; j < ns; ++j) if (sub_ok[j]) S.broot_of_col[j] = idx_of_root[root_of[j]];
+        S.broot_uoff.resize(S.broot.size());
+        long long o = 0;
+        for (size_t i = 0; i < S.broot.size(); ++i) { S.broot_uoff[i] = o; const long long n6 = 6LL * S.broot_b[i]; o += n6 * n6 + n6; o = (o + 31) & ~31LL; }
+        S.ubin_doubles = o;
+    }
+    // rows of a binned column beyond its subtree root, as indices into the root's boundary list
+    S.anc_first.assign(ns, 0);
+    S.anc_rel.assign(S.nnzL, -1);
+    par_ranges(ns, T, [&](int, int lo, int hi) {
+        for (int k = lo; k < hi; ++k) {
+            if (!sub_ok[k]) continue;
+            const int r = root_of[k], c0 = S.colptr[k], m = csz(k);
+            int q = 0;
+            while (q < m && S.rowidx[c0 + q] <= r) ++q;
+            S.anc_first[k] = q;
+            const int* rb = S.rowidx.data() + S.colptr[r] + 1; const int nb = csz(r) - 1;
+            int w = 0;
+            for (; q < m; ++q) { const int row = S.rowidx[c0 + q]; while (w < nb && rb[w] < row) ++w; S.anc_rel[c0 + q] = (w < nb && rb[w] == row) ? w : -1; }
+        }
+    });
+    // update lists of the binned columns (sources are binned columns of the same subtree), ascending source
+    {
+        std::vector<std::vector<int>> hist(T, std::vector<int>(ns, 0));
+        par_ranges(ns, T, [&](int t, int lo, int hi) {
+            std::vector<int>& h = hist[t];
+            for (int k = lo; k < hi; ++k) { if (!sub_ok[k]) continue; for (int q = S.colptr[k] + 1; q < S.colptr[k + 1]; ++q) { const int j = S.rowidx[q]; if (sub_ok[j]) h[j]++; } }
+        });
+        S.rlptr.assign(ns + 1, 0);
+        for (int j = 0; j < ns; ++j) { int tot = 0; for (int t = 0; t < T; ++t) { const int c = hist[t][j]; hist[t][j] = tot; tot += c; } S.rlptr[j + 1] = S.rlptr[j] + tot; }
+        S.rlcol.resize(S.rlptr[ns]); S.rlpos.resize(S.rlptr[ns]); S.rlrow.resize(S.rlptr[ns]);
+        par_ranges(ns, T, [&](int t, int lo, int hi) {
+            std::vector<int>& fill = hist[t];
+            for (int k = lo; k < hi; ++k) {
+                if (!sub_ok[k]) continue;
+                for (int q = S.colptr[k] + 1; q < S.colptr[k + 1]; ++q) {
+                    const int j = S.rowidx[q];
+                    if (!sub_ok[j]) continue;
+                    const int at = S.rlptr[j] + fill[j]++;
+                    S.rlcol[at] = k; S.rlpos[at] = q; S.rlrow[at] = j;
+                }
+            }
+        });
+        S.mapptr.assign(ns + 1, 0);
+        for (int j = 0; j < ns; ++j) S.mapptr[j + 1] = S.mapptr[j] + (long long)(S.rlptr[j + 1] - S.rlptr[j]) * (long long)csz(j);
+    }
+    const auto q3 = tnow();
+    // ---- top: supernodes of the remaining columns become fronts.  Fundamental supernodes (consecutive columns with nested
+    // structure) first; then RELAXED amalgamation along the column order: a front whose columns end where its parent's begin is
+    // merged into the parent when that adds few explicit zero blocks -- every merge removes a level of the schedule, and the
+    // levels (one dependent launch sequence each) are what the factorisation time is made of.
+    S.front_of_col.assign(ns, -1);
+    {
+        struct fnd { int c0, s, n; };                       // fundamental supernodes, ascending
+        std::vector<fnd> fund;
+        for (int j = 0; j < ns; ++j) {
+            if (sub_ok[j]) continue;
+            const bool chain = !fund.empty() && fund.back().c0 + fund.back().s == j && parent[j - 1] == j && csz(j) + 1 == csz(j - 1) && S.col_part[j] == S.col_part[j - 1];
+            if (chain) fund.back().s++;
+            else fund.push_back({ j, 1, csz(j) });
+        }
+        S.f_rowptr.assign(1, 0);
+        auto flops_of = [](double s, double n) { double f = 0; for (int j = 0; j < (int)s; ++j) { const double m = n - j - 1; f += 216.0 * (m * m + 3 * m) + 72.0; } return f; };
+        for (const fnd& g : fund) {
+            bool merged = false;
+            if (!S.f_c0.empty()) {
+                const int c = (int)S.f_c0.size() - 1;
+                const int* cr = S.f_rows.data() + S.f_rowptr[c];
+                const int sc = S.f_s[c], nc = S.f_n[c], bc = nc - sc;
+                if (S.f_c0[c] + sc == g.c0 && bc > 0 && cr[sc] >= g.c0 && cr[sc] < g.c0 + g.s && S.f_part[c] == S.col_part[g.c0]) {
+                    const double zeros = (double)(g.n - bc) * sc;                     // explicit zero blocks the merge puts into L
+                    const double f_sep = flops_of(sc, nc) + flops_of(g.s, g.n), f_mrg = flops_of(sc + g.s, sc + g.n);
+                    const bool one_panel = sc + g.s <= PG_PW;
+                    if (zeros <= opt.relax_zero_blocks || f_mrg <= f_sep * (one_panel ? opt.relax_flops_small : opt.relax_flops)) {
+                        // rows of the merged front: the child's own columns, then the parent's rows (a superset of the child's boundary)
+                        std::vector<int> rows(cr, cr + sc);
+                        rows.insert(rows.end(), S.rowidx.begin() + S.colptr[g.c0], S.rowidx.begin() + S.colptr[g.c0] + g.n);
+                        S.f_rows.resize(S.f_rowptr[c]);
+                        S.f_rows.insert(S.f_rows.end(), rows.begin(), rows.end());
+                        S.f_rowptr[c + 1] = (int)S.f_rows.size();
+                        S.f_s[c] = sc + g.s; S.f_n[c] = sc + g.n;
+                        merged = true;
+                    }
+                }
+            }
+            if (!merged) {
+                S.f_c0.push_back(g.c0); S.f_s.push_back(g.s); S.f_n.push_back(g.n); S.f_part.push_back(S.col_part[g.c0]);
+                S.f_rows.insert(S.f_rows.end(), S.rowidx.begin() + S.colptr[g.c0], S.rowidx.begin() + S.colptr[g.c0] + g.n);
+                S.f_rowptr.push_back((int)S.f_rows.size());
+            }
+        }
+        for (size_t f = 0; f < S.f_c0.size(); ++f) for (int c = 0; c < S.f_s[f]; ++c) S.front_of_col[S.f_c0[f] + c] = (int)f;
+    }
+    const int nf = (int)S.f_c0.size();
+    S.f_ld.resize(nf); S.f_off.resize(nf); S.f_roff.resize(nf); S.f_parent.assign(nf, -1);
+    {
+        long long o = 0, ro = 0;
+        for (int f = 0; f < nf; ++f) {
+            const int ld = (6 * S.f_n[f] + 15) & ~15;
+            S.f_ld[f] = ld; S.f_off[f] = o; o += (long long)ld * ld;
+            S.f_roff[f] = ro; ro += ld;
+            S.max_front_n = std::max(S.max_front_n, S.f_n[f]);
+            if (S.f_n[f] > S.f_s[f]) S.f_parent[f] = S.front_of_col[S.f_rows[S.f_rowptr[f] + S.f_s[f]]];
+            S.flops_fronts += [&] { double fl = 0; for (int j = 0; j < S.f_s[f]; ++j) { const double m = S.f_n[f] - j - 1; fl += 216.0 * (m * m + 3 * m) + 72.0; } return fl; }();
+        }
+        S.front_doubles = o; S.frhs_doubles = ro;
+    }
+    // children (bin roots first, then fronts, both ascending) and their boundary -> parent row maps
+    {
+        std::vector<int> cnt(nf + 1, 0);
+        std::vector<int> broot_front(S.broot.size());
+        for (size_t i = 0; i < S.broot.size(); ++i) { const int p = parent[S.broot[i]]; broot_front[i] = S.front_of_col[p]; cnt[broot_front[i] + 1]++; }
+        for (int f = 0; f < nf; ++f) if (S.f_parent[f] >= 0) cnt[S.f_parent[f] + 1]++;
+        S.ch_ptr.assign(nf + 1, 0);
+        for (int f = 0; f < nf; ++f) S.ch_ptr[f + 1] = S.ch_ptr[f] + cnt[f + 1];
+        const int nch = S.ch_ptr[nf];
+        S.ch_kind.resize(nch); S.ch_id.resize(nch); S.ch_relptr.resize(nch + 1);
+        std::vector<int> fp(S.ch_ptr.begin(), S.ch_ptr.end() - 1);
+        for (size_t i = 0; i < S.broot.size(); ++i) { const int at = fp[broot_front[i]]++; S.ch_kind[at] = 1; S.ch_id[at] = (int)i; }
+        for (int f = 0; f < nf; ++f) if (S.f_parent[f] >= 0) { const int at = fp[S.f_parent[f]]++; S.ch_kind[at] = 0; S.ch_id[at] = f; }
+        long long o = 0;
+        for (int c = 0; c < nch; ++c) { S.ch_relptr[c] = o; o += S.ch_kind[c] ? S.broot_b[S.ch_id[c]] : S.f_n[S.ch_id[c]] - S.f_s[S.ch_id[c]]; }
+        S.ch_relptr[nch] = o;
+        S.rel.assign(o, -1);
+        par_ranges(nf, T, [&](int, int lo, int hi) {
+            for (int f = lo; f < hi; ++f) {
+                const int* pr = S.f_rows.data() + S.f_rowptr[f]; const int pn = S.f_n[f];
+                for (int c = S.ch_ptr[f]; c < S.ch_ptr[f + 1]; ++c) {
+                    const int* cr; int cn;
+                    if (S.ch_kind[c]) { const int r = S.broot[S.ch_id[c]]; cr = S.rowidx.data() + S.colptr[r] + 1; cn = csz(r) - 1; }
+                    else { const int g = S.ch_id[c]; cr = S.f_rows.data() + S.f_rowptr[g] + S.f_s[g]; cn = S.f_n[g] - S.f_s[g]; }
+                    int w = 0;
+                    for (int q = 0; q < cn; ++q) { while (w < pn && pr[w] < cr[q]) ++w; S.rel[S.ch_relptr[c] + q] = (w < pn && pr[w] == cr[q]) ? w : -1; }
+                }
+            }
+        });
+    }
+    // ---- where the assembled blocks go
+    const int ne = (int)edges.size() - nchain, nval = ns + nchain + ne;
+    S.dest_bin.assign(nval, -1);
+    {
+        std::vector<int> v_row(nval), v_col(nval), v_tr(nval);
+        auto find = [&](int row, int col) { const auto b = S.rowidx.begin() + S.colptr[col], e = S.rowidx.begin() + S.colptr[col + 1];
+                                            return (int)(std::lower_bound(b, e, row) - S.rowidx.begin()); };
+        par_ranges(nval, T, [&](int, int lo, int hi) {
+            for (int v = lo; v < hi; ++v) {
+                int pa, pb;                                   // block H(a, b): rows of a, columns of b
+                if (v < ns) { pa = pb = S.perm[v]; }
+                else { const auto& e = edges[v - ns]; pa = S.perm[e.first]; pb = S.perm[e.second]; }
+                const int row = std::max(pa, pb), col = std::min(pa, pb), tr = (pa >= pb) ? 0 : 1;
+                v_row[v] = row; v_col[v] = col; v_tr[v] = tr;
+                if (sub_ok[col]) S.dest_bin[v] = (find(row, col) << 1) | tr;
+            }
+        });
+        std::vector<int> cnt(nf + 1, 0);
+        for (int v = 0; v < nval; ++v) if (!sub_ok[v_col[v]]) cnt[S.front_of_col[v_col[v]] + 1]++;
+        S.fa_ptr.assign(nf + 1, 0);
+        for (int f = 0; f < nf; ++f) S.fa_ptr[f + 1] = S.fa_ptr[f] + cnt[f + 1];
+        const int nfa = S.fa_ptr[nf];
+        S.fa_src.resize(nfa); S.fa_row.resize(nfa); S.fa_col.resize(nfa); S.fa_tr.resize(nfa);
+        std::vector<int> fp(S.fa_ptr.begin(), S.fa_ptr.end() - 1);
+        for (int v = 0; v < nval; ++v) {
+            if (sub_ok[v_col[v]]) continue;
+            const int f = S.front_of_col[v_col[v]], at = fp[f]++;
+            const int* pr = S.f_rows.data() + S.f_rowptr[f];
+            S.fa_src[at] = v; S.fa_col[at] = v_col[v] - S.f_c0[f]; S.fa_tr[at] = v_tr[v];
+            S.fa_row[at] = (int)(std::lower_bound(pr, pr + S.f_n[f], v_row[v]) - pr);
+        }
+        par_ranges(nf, T, [&](int, int lo, int hi) {
+            std::vector<int> idx, a, b, c2, d;
+            for (int f = lo; f < hi; ++f) {
+                const int b0 = S.fa_ptr[f], n = S.fa_ptr[f + 1] - b0;
+                idx.resize(n); std::iota(idx.begin(), idx.end(), 0);
+                std::sort(idx.begin(), idx.end(), [&](int x, int y) {
+                    if (S.fa_row[b0 + x] != S.fa_row[b0 + y]) return S.fa_row[b0 + x] < S.fa_row[b0 + y];
+                    if (S.fa_col[b0 + x] != S.fa_col[b0 + y]) return S.fa_col[b0 + x] < S.fa_col[b0 + y];
+                    return S.fa_src[b0 + x] < S.fa_src[b0 + y]; });
+                a.resize(n); b.resize(n); c2.resize(n); d.resize(n);
+                for (int i = 0; i < n; ++i) { a[i] = S.fa_src[b0 + idx[i]]; b[i] = S.fa_row[b0 + idx[i]]; c2[i] = S.fa_col[b0 + idx[i]]; d[i] = S.fa_tr[b0 + idx[i]]; }
+                for (int i = 0; i < n; ++i) { S.fa_src[b0 + i] = a[i]; S.fa_row[b0 + i] = b[i]; S.fa_col[b0 + i] = c2[i]; S.fa_tr[b0 + i] = d[i]; }
+            }
+        });
+    }
+    // ---- schedule: a front starts one level after its last child front has finished; panel steps are consecutive levels
+    S.f_level0.assign(nf, 0); S.f_npan.resize(nf); S.f_pan0.resize(nf);
+    int maxl = -1, np = 0;
+    for (int f = 0; f < nf; ++f) {
+        S.f_npan[f] = (S.f_s[f] + PG_PW - 1) / PG_PW; S.f_pan0[f] = np; np += S.f_npan[f];
+        int l0 = 0;
+        for (int c = S.ch_ptr[f]; c < S.ch_ptr[f + 1]; ++c) if (!S.ch_kind[c]) { const int g = S.ch_id[c]; l0 = std::max(l0, S.f_level0[g] + S.f_npan[g]); }
+        S.f_level0[f] = l0; maxl = std::max(maxl, l0 + S.f_npan[f] - 1);
+    }
+    S.npanels = np; S.nlev = maxl + 1;
+    S.lv_ptr.assign(S.nlev + 1, 0); S.asm_ptr.assign(S.nlev + 1, 0);
+    for (int f = 0; f < nf; ++f) { S.asm_ptr[S.f_level0[f] + 1]++; for (int k = 0; k < S.f_npan[f]; ++k) S.lv_ptr[S.f_level0[f] + k + 1]++; }
+    for (int l = 0; l < S.nlev; ++l) { S.lv_ptr[l + 1] += S.lv_ptr[l]; S.asm_ptr[l + 1] += S.asm_ptr[l]; }
+    S.lv_front.resize(np); S.lv_step.resize(np); S.asm_front.resize(nf);
+    {
+        std::vector<int> fp(S.lv_ptr.begin(), S.lv_ptr.end() - 1), fq(S.asm_ptr.begin(), S.asm_ptr.end() - 1);
+        for (int f = 0; f < nf; ++f) {
+            S.asm_front[fq[S.f_level0[f]]++] = f;
+            for (int k = 0; k < S.f_npan[f]; ++k) { const int at = fp[S.f_level0[f] + k]++; S.lv_front[at] = f; S.lv_step[at] = k; }
+        }
+    }
+    if (tv && atoi(getenv("DSSS_PG_VERBOSE")) >= 2) {      // critical path of the schedule, root first
+        int f = -1;
+        for (int g = 0; g < nf; ++g) if (S.f_level0[g] + S.f_npan[g] == S.nlev) f = g;
+        while (f >= 0) {
+            fprintf(stderr, "[dsss pg path] front %d: cols %d rows %d panels %d levels %d..%d part %d children %d\n", f, S.f_s[f], S.f_n[f], S.f_npan[f], S.f_level0[f], S.f_level0[f] + S.f_npan[f] - 1, S.f_part[f], S.ch_ptr[f + 1] - S.ch_ptr[f]);
+            int nxt = -1;
+            for (int c = S.ch_ptr[f]; c < S.ch_ptr[f + 1]; ++c) if (!S.ch_kind[c]) { const int g = S.ch_id[c]; if (S.f_level0[g] + S.f_npan[g] == S.f_level0[f]) nxt = g; }
+            f = nxt;
+        }
+    }
+    // ---- children that cross from a rank's interior into the interface
+    {
+        long long o = 0;
+        for (int f = 0; f < nf; ++f) {
+            if (S.f_part[f] >= 0) continue;
+            for (int c = S.ch_ptr[f]; c < S.ch_ptr[f + 1]; ++c) {
+                const int kind = S.ch_kind[c], id = S.ch_id[c];
+                const int cp = kind ? S.col_part[S.broot[id]] : S.f_part[id];
+                if (cp < 0) continue;
+                const long long n6 = 6LL * (kind ? S.broot_b[id] : S.f_n[id] - S.f_s[id]);
+                S.comm_kind.push_back(kind); S.comm_id.push_back(id); S.comm_part.push_back(cp); S.comm_off.push_back(o);
+                o += n6 * n6 + n6; o = (o + 31) & ~31LL;
+            }
+        }
+        S.comm_doubles = o;
+    }
+    // statistics
+    for (int j = 0; j < ns; ++j) { const double m = csz(j) - 1; S.flops_factor += 36.0 * 6.0 * (m * m + 3 * m) + 72.0; }
+    if (tv) {
+        long long zeros = 0;
+        int big = 0;
+        for (int f = 0; f < nf; ++f) { if (S.f_n[f] > 100) ++big; zeros += 0; }
+        fprintf(stderr, "[dsss pg symbolic] adjacency+ND %.1f ms, column structures %.1f ms, bins+lists %.1f ms, fronts+schedule %.1f ms | ns %d nnzL %lld bins %d (%zu cols, %zu roots, U %.1f MB) fronts %d (>100 rows: %d, max %d) panels %d levels %d front arena %.1f MB comm %.1f MB front GFLOP %.1f (column count %.1f)\n",
+                tms(q0, q1), tms(q1, q2), tms(q2, q3), tms(q3, tnow()), ns, S.nnzL, (int)S.binptr.size() - 1, S.bincols.size(), S.broot.size(), S.ubin_doubles * 8e-6,
+                nf, big, S.max_front_n, S.npanels, S.nlev, S.front_doubles * 8e-6, S.comm_doubles * 8e-6, S.flops_fronts * 1e-9, S.flops_factor * 1e-9);
+    }
+}
+
+void pg_sym_opts_env(pg_sym_opts& opt)
+{
+    if (getenv("DSSS_PG_RELAX_ZERO")) opt.relax_zero_blocks = atof(getenv("DSSS_PG_RELAX_ZERO"));
+    if (getenv("DSSS_PG_RELAX_FLOPS")) opt.relax_flops = atof(getenv("DSSS_PG_RELAX_FLOPS"));
+    if (getenv("DSSS_PG_RELAX_SMALL")) opt.relax_flops_small = atof(getenv("DSSS_PG_RELAX_SMALL"));
+}
+
+// ------------------------------------------------------------------ host twin of the numeric phase (CPU tests only)
+namespace {
+int h_chol(double* A, int n, int ld)          // in-place lower Cholesky of the leading n x n block
+{
+    for (int j = 0; j < n; ++j) {
+        double d = A[(size_t)j * ld + j];
+        for (int k = 0; k < j; ++k) d -= A[(size_t)j * ld + k] * A[(size_t)j * ld + k];
+        if (!(d > 0) || !std::isfinite(d)) return -1;
+        d = std::sqrt(d); A[(size_t)j * ld + j] = d;
+        for (int i = j + 1; i < n; ++i) { double s = A[(size_t)i * ld + j]; for (int k = 0; k < j; ++k) s -= A[(size_t)i * ld + k] * A[(size_t)j * ld + k]; A[(size_t)i * ld + j] = s / d; }
+    }
+    return 0;
+}
+} // namespace
+
+int pg_host_solve(const pg_sym& S, int ne, const std::vector<std::pair<int, int>>& edges, const double* aval, const double* rhs, double* xout)
+{
+    (void)edges; (void)ne;
+    const int ns = S.ns, nf = (int)S.f_c0.size();
+    auto csz = [&](int j) { return S.colptr[j + 1] - S.colptr[j]; };
+    std::vector<double> L((size_t)S.nnzL * 36, 0.0), x((size_t)ns * 6, 0.0), F((size_t)S.front_doubles, 0.0), R((size_t)S.frhs_doubles, 0.0), U((size_t)S.ubin_doubles, 0.0);
+    for (int k = 0; k < ns; ++k) for (int a = 0; a < 6; ++a) x[(size_t)S.perm[k] * 6 + a] = rhs[(size_t)k * 6 + a];
+    const int nval = (int)S.dest_bin.size();
+    for (int v = 0; v < nval; ++v) {
+        if (S.dest_bin[v] < 0) continue;
+        const int pos = S.dest_bin[v] >> 1, tr = S.dest_bin[v] & 1;
+        for (int a = 0; a < 6; ++a) for (int b = 0; b < 6; ++b) L[(size_t)pos * 36 + (tr ? b * 6 + a : a * 6 + b)] += aval[(size_t)v * 36 + a * 6 + b];
+    }
+    // bins, column by column (left-looking)
+    for (size_t ci = 0; ci < S.bincols.size(); ++ci) {
+        const int j = S.bincols[ci], c0 = S.colptr[j], m = csz(j);
+        for (int t = S.rlptr[j]; t < S.rlptr[j + 1]; ++t) {
+            const int k = S.rlcol[t], pj = S.rlpos[t];
+            const double* Ljk = &L[(size_t)pj * 36];
+            int q = 0;
+            for (int p = pj; p < S.colptr[k + 1]; ++p) {
+                const int i = S.rowidx[p];
+                while (q < m && S.rowidx[c0 + q] < i) ++q;
+                if (q >= m || S.rowidx[c0 + q] != i) return -2;         // structure violated
+                const double* Lik = &L[(size_t)p * 36]; double* Aij = &L[(size_t)(c0 + q) * 36];
+                for (int a = 0; a < 6; ++a) for (int b = 0; b < 6; ++b) { double s = 0; for (int c = 0; c < 6; ++c) s += Lik[a * 6 + c] * Ljk[b * 6 + c]; Aij[a * 6 + b] -= s; }
+            }
+            for (int a = 0; a < 6; ++a) { double s = 0; for (int c = 0; c < 6; ++c) s += Ljk[a * 6 + c] * x[(size_t)k * 6 + c]; x[(size_t)j * 6 + a] -= s; }
+        }
+        double* D = &L[(size_t)c0 * 36];
+        if (h_chol(D, 6, 6)) return -1;
+        for (int a = 0; a < 6; ++a) for (int b = a + 1; b < 6; ++b) D[a * 6 + b] = 0;
+        for (int a = 0; a < 6; ++a) { double s = x[(size_t)j * 6 + a]; for (int b = 0; b < a; ++b) s -= D[a * 6 + b] * x[(size_t)j * 6 + b]; x[(size_t)j * 6 + a] = s / D[a * 6 + a]; }
+        for (int q = 1; q < m; ++q) {
+            double* B = &L[(size_t)(c0 + q) * 36];
+            for (int a = 0; a < 6; ++a) for (int s6 = 0; s6 < 6; ++s6) { double v = B[a * 6 + s6]; for (int c = 0; c < s6; ++c) v -= B[a * 6 + c] * D[s6 * 6 + c]; B[a * 6 + s6] = v / D[s6 * 6 + s6]; }
+        }
+        // contribution to the update matrix of the subtree root
+        const int ri = S.broot_of_col[j];
+        if (ri >= 0) {
+            const int b6 = 6 * S.broot_b[ri]; double* Ur = &U[(size_t)S.broot_uoff[ri]]; double* gr = Ur + (size_t)b6 * b6;
+            for (int p = c0 + S.anc_first[j]; p < c0 + m; ++p) {
+                const int ia = S.anc_rel[p]; if (ia < 0) return -3;
+                const double* La = &L[(size_t)p * 36];
+                for (int a = 0; a < 6; ++a) { double s = 0; for (int c = 0; c < 6; ++c) s += La[a * 6 + c] * x[(size_t)j * 6 + c]; gr[ia * 6 + a] -= s; }
+                for (int p2 = c0 + S.anc_first[j]; p2 <= p; ++p2) {
+                    const int ib = S.anc_rel[p2]; const double* Lb = &L[(size_t)p2 * 36];
+                    for (int a = 0; a < 6; ++a) for (int b = 0; b < 6; ++b) { double s = 0; for (int c = 0; c < 6; ++c) s += La[a * 6 + c] * Lb[b * 6 + c]; Ur[(size_t)(ia * 6 + a) * b6 + ib * 6 + b] -= s; }
+                }
+            }
+        }
+    }
+    // fronts, ascending (children come first)
+    for (int f = 0; f < nf; ++f) {
+        const int ld = S.f_ld[f], s6 = 6 * S.f_s[f], n6 = 6 * S.f_n[f], c0 = S.f_c0[f];
+        double* A = &F[(size_t)S.f_off[f]]; double* r = &R[(size_t)S.f_roff[f]];
+        for (int e = S.fa_ptr[f]; e < S.fa_ptr[f + 1]; ++e) {
+            const double* B = aval + (size_t)S.fa_src[e] * 36; const int tr = S.fa_tr[e];
+            for (int a = 0; a < 6; ++a) for (int b = 0; b < 6; ++b) A[(size_t)(S.fa_row[e] * 6 + a) * ld + S.fa_col[e] * 6 + b] += tr ? B[b * 6 + a] : B[a * 6 + b];
+        }
+        for (int i = 0; i < s6; ++i) r[i] = x[(size_t)c0 * 6 + i];
+        for (int c = S.ch_ptr[f]; c < S.ch_ptr[f + 1]; ++c) {
+            const int* rl = &S.rel[S.ch_relptr[c]];
+            const double* Uc; const double* gc; int cb, cld;
+            if (S.ch_kind[c]) { const int ri = S.ch_id[c]; cb = S.broot_b[ri]; cld = 6 * cb; Uc = &U[(size_t)S.broot_uoff[ri]]; gc = Uc + (size_t)cld * cld; }
+            else { const int g = S.ch_id[c]; cb = S.f_n[g] - S.f_s[g]; cld = S.f_ld[g]; Uc = &F[(size_t)S.f_off[g]] + (size_t)(6 * S.f_s[g]) * cld + 6 * S.f_s[g]; gc = &R[(size_t)S.f_roff[g]] + 6 * S.f_s[g]; }
+            for (int i = 0; i < cb; ++i) {
+                if (rl[i] < 0) return -4;
+                for (int a = 0; a < 6; ++a) {
+                    r[rl[i] * 6 + a] += gc[i * 6 + a];
+                    for (int j2 = 0; j2 <= i; ++j2) for (int b = 0; b < 6; ++b) A[(size_t)(rl[i] * 6 + a) * ld + rl[j2] * 6 + b] += Uc[(size_t)(i * 6 + a) * cld + j2 * 6 + b];
+                }
+            }
+        }
+        if (h_chol(A, s6, ld)) return -1;
+        for (int i = 0; i < s6; ++i) { double s = r[i]; for (int k = 0; k < i; ++k) s -= A[(size_t)i * ld + k] * r[k]; r[i] = s / A[(size_t)i * ld + i]; }
+        for (int i = s6; i < n6; ++i) {
+            for (int j2 = 0; j2 < s6; ++j2) { double s = A[(size_t)i * ld + j2]; for (int k = 0; k < j2; ++k) s -= A[(size_t)i * ld + k] * A[(size_t)j2 * ld + k]; A[(size_t)i * ld + j2] = s / A[(size_t)j2 * ld + j2]; }
+            double s = 0; for (int k = 0; k < s6; ++k) s += A[(size_t)i * ld + k] * r[k];
+            r[i] -= s;
+            for (int j2 = s6; j2 <= i; ++j2) { double t = 0; for (int k = 0; k < s6; ++k) t += A[(size_t)i * ld + k] * A[(size_t)j2 * ld + k]; A[(size_t)i * ld + j2] -= t; }
+        }
+    }
+    // backward: fronts descending, then binned columns descending
+    for (int f = nf - 1; f >= 0; --f) {
+        const int ld = S.f_ld[f], s6 = 6 * S.f_s[f], n6 = 6 * S.f_n[f], c0 = S.f_c0[f];
+        const double* A = &F[(size_t)S.f_off[f]]; const double* r = &R[(size_t)S.f_roff[f]];
+        const int* rows = &S.f_rows[S.f_rowptr[f]];
+        std::vector<double> z(r, r + s6);
+        for (int i = s6; i < n6; ++i) { const double xi = x[(size_t)rows[i / 6] * 6 + i % 6]; for (int k = 0; k < s6; ++k) z[k] -= A[(size_t)i * ld + k] * xi; }
+        for (int i = s6 - 1; i >= 0; --i) { double s = z[i]; for (int k = i + 1; k < s6; ++k) s -= A[(size_t)k * ld + i] * z[k]; z[i] = s / A[(size_t)i * ld + i]; }
+        for (int i = 0; i < s6; ++i) x[(size_t)c0 * 6 + i] = z[i];
+    }
+    for (int ci = (int)S.bincols.size() - 1; ci >= 0; --ci) {
+        const int j = S.bincols[ci], c0 = S.colptr[j], m = csz(j);
+        double z[6];
+        for (int a = 0; a < 6; ++a) z[a] = x[(size_t)j * 6 + a];
+        for (int q = 1; q < m; ++q) { const double* B = &L[(size_t)(c0 + q) * 36]; const double* xi = &x[(size_t)S.rowidx[c0 + q] * 6]; for (int a = 0; a < 6; ++a) for (int b = 0; b < 6; ++b) z[a] -= B[b * 6 + a] * xi[b]; }
+        const double* D = &L[(size_t)c0 * 36];
+        for (int a = 5; a >= 0; --a) { double s = z[a]; for (int b = a + 1; b < 6; ++b) s -= D[b * 6 + a] * z[b]; z[a] = s / D[a * 6 + a]; }
+        for (int a = 0; a < 6; ++a) x[(size_t)j * 6 + a] = z[a];
+    }
+    for (int k = 0; k < ns; ++k) for (int a = 0; a < 6; ++a) xout[(size_t)k * 6 + a] = x[(size_t)S.perm[k] * 6 + a];
+    return 0;
+}
+
+// ------------------------------------------------------------------ C ABI of the host twin (CPU test-suite; include/dsss.h)
+#include "../../include/dsss.h"
+extern "C" int dsss_host_pg_solve(int ns, const int32_t* edge_a, const int32_t* edge_b, int nedges, const double* cx, const double* cy,
+                                  const int32_t* part, int nparts, const double* aval, const double* rhs, double* x, int64_t* stats8)
+{
+    if (ns < 1 || nedges < ns - 1 || !edge_a || !edge_b || !cx || !cy || (x && (!aval || !rhs))) return DSSS_E_ARG;      // x == NULL: analysis only
+    std::vector<std::pair<int, int>> edges(nedges);
+    for (int e = 0; e < nedges; ++e) {
+        edges[e] = { edge_a[e], edge_b[e] };
+        if (edge_a[e] < 0 || edge_a[e] >= ns || edge_b[e] < 0 || edge_b[e] >= ns) return DSSS_E_ARG;
+        if (e < ns - 1 && (edge_a[e] != e || edge_b[e] != e + 1)) return DSSS_E_ARG;       // the chain couplings come first
+    }
+    pg_sym S; pg_sym_opts opt;
+    if (getenv("DSSS_PG_BIN_COST")) opt.bin_cost = atof(getenv("DSSS_PG_BIN_COST"));
+    if (getenv("DSSS_PG_LEAF")) opt.leaf = atoi(getenv("DSSS_PG_LEAF"));
+    pg_sym_opts_env(opt);
+    pg_symbolic(ns, edges, ns - 1, cx, cy, part, nparts, opt, S);
+    const int rc = x ? pg_host_solve(S, nedges - (ns - 1), edges, aval, rhs, x) : 0;
+    if (stats8) {
+        stats8[0] = S.nnzL; stats8[1] = (int64_t)S.f_c0.size(); stats8[2] = S.npanels; stats8[3] = S.nlev;
+        stats8[4] = S.front_doubles; stats8[5] = S.comm_doubles; stats8[6] = (int64_t)S.bincols.size(); stats8[7] = S.max_front_n;
+    }
+    return rc == 0 ? DSSS_OK : (rc == -1 ? DSSS_E_NUMERIC : DSSS_E_STATE);
+}

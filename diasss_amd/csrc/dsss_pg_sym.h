@@ -1,0 +1,97 @@
+// diasss_amd/csrc/dsss_pg_sym.h -- host-side analysis of the reduced pose-graph system (no HIP in here).
+//
+// The reduced system of the batch LM (dsss_pg.hip) is a sparse symmetric matrix of 6x6 blocks over the "separators"
+// (LC-touched poses + a few chain poses).  This module decides how it is factorised:
+//   1. ordering     nested dissection; the first levels split by RANK PARTITION (contiguous frame blocks, one per GPU),
+//                   below that by geometry (recursive coordinate bisection of the DR positions);
+//   2. structure    column structures of L and the elimination tree;
+//   3. bottom       whole subtrees with little work are binned: one workgroup factorises a bin column by column
+//                   (left-looking, block-sparse) and leaves the UPDATE MATRIX of every subtree root for the level above;
+//   4. top          multifrontal: every fundamental supernode of the remaining columns is a dense FRONT
+//                   [ F11 (its s columns)  .  ]   assembled from the original entries and the update matrices of its children
+//                   [ F21 (boundary rows) F22 ]   (extend-add), then partially factorised in 96-column panels on the f64
+//                                                 matrix cores; F22 is its own update matrix for the parent front;
+//   5. schedule     panel steps of all fronts grouped into levels (a front starts when its children are done);
+//   6. ranks        every column belongs to one rank's interior or to the replicated INTERFACE (the partition-level
+//                   separators); the update matrices that cross from an interior into the interface are packed into one
+//                   buffer and summed over the ranks (the reduced-Hessian all-reduce).
+// Replaces GTSAM's ordering + symbolic factorisation inside ISAM2 / LevenbergMarquardtOptimizer
+// (/root/reference/src/core/optimizer.cpp:134-139, 265-279).
+#pragma once
+#include <vector>
+
+#define PG_PW 16                        // panel width in block columns (96 scalar columns)
+
+struct pg_sym {
+    int ns = 0, nparts = 1;
+    std::vector<int> perm;              // chain-order separator -> elimination index
+    std::vector<int> order;             // elimination index -> chain-order separator
+    std::vector<int> colptr, rowidx;    // block structure of L by column (ascending rows, first the diagonal)
+    std::vector<int> parent;            // elimination tree
+    std::vector<int> col_part;          // rank that eliminates the column, or -1 for interface (replicated) columns
+    // ---- bottom: bins of whole subtrees, left-looking block columns
+    std::vector<char> binned;
+    std::vector<int> binptr, bincols;   // columns of every bin, ascending
+    std::vector<int> bin_part;          // rank of every bin
+    std::vector<int> rlptr, rlcol, rlpos, rlrow;   // per target column: source columns k < j with L(j,k) != 0 and the position of that block (binned targets only)
+    std::vector<long long> mapptr;      // update map offsets (binned targets only; see pg_build_map_kernel)
+    std::vector<int> broot;             // subtree roots inside bins that have ancestors outside (they hand an update matrix up)
+    std::vector<int> broot_of_col;      // per column: index into broot of its subtree root, or -1
+    std::vector<int> broot_b;           // boundary size in blocks = |struct(root)| - 1
+    std::vector<long long> broot_uoff;  // offset (doubles) of U_root in the bin-update arena: (6b)^2 row-major, then 6b of right-hand side
+    std::vector<int> binroot_ptr, binroot_idx;     // roots per bin (CSR into broot)
+    std::vector<int> anc_first;         // per binned column: first position (within the column) whose row lies beyond its subtree root
+    std::vector<int> anc_rel;           // per L position of binned columns: index of that row in the root's boundary list, or -1
+    long long ubin_doubles = 0;
+    // ---- top: fronts
+    std::vector<int> f_c0, f_s, f_n;    // first column, number of own block columns, number of block rows (= |struct(c0)|)
+    std::vector<int> f_rowptr, f_rows;  // block rows of every front (elimination indices): its own columns first, then the boundary, ascending
+    std::vector<int> f_ld;              // leading dimension in scalars (6 n rounded up to 16)
+    std::vector<long long> f_off;       // offset (doubles) of the ld x ld front in the front arena; right-hand side at f_roff
+    std::vector<long long> f_roff;
+    std::vector<int> f_parent, f_part;  // parent front (-1 root), rank (-1 interface)
+    std::vector<int> f_level0, f_npan, f_pan0;     // first panel level, number of panel steps, first global panel id
+    std::vector<int> front_of_col;      // per column: front index or -1 (binned)
+    long long front_doubles = 0, frhs_doubles = 0;
+    // children of every front (CSR), in the fixed order the extend-add sums them: kind 0 = front, 1 = bin root
+    std::vector<int> ch_ptr, ch_kind, ch_id;
+    std::vector<long long> ch_relptr;   // offset into rel of the child's boundary -> parent row map
+    std::vector<int> rel;
+    // original entries of every front (CSR, sorted by destination row): A-value index, destination block row / column, transpose
+    std::vector<int> fa_ptr, fa_src, fa_row, fa_col, fa_tr;
+    // where the assembled blocks go: value index k in [0, ns) diagonal of separator k, [ns, 2ns-1) chain coupling k|k+1,
+    // then LC edges.  dest_bin[v] = (Lvals position << 1 | transpose) for a binned destination column, -1 for a front
+    std::vector<int> dest_bin;
+    // ---- schedule: panel steps per level, fronts to assemble per level
+    int nlev = 0, npanels = 0;
+    std::vector<int> lv_ptr, lv_front, lv_step;
+    std::vector<int> asm_ptr, asm_front;
+    // ---- ranks: children that cross from an interior front / bin root into an interface front ("comm children")
+    std::vector<int> comm_kind, comm_id, comm_part;  // the crossing children in a fixed global order
+    std::vector<long long> comm_off;    // packed offset (doubles) in the comm buffer: (6b)^2 + 6b each
+    long long comm_doubles = 0;
+    // statistics
+    double flops_factor = 0, flops_fronts = 0; long long nnzL = 0; int max_front_n = 0;
+};
+
+struct pg_sym_opts {
+    int leaf = 24;                      // nested-dissection leaf size
+    double bin_cost = 1000;             // work bound of a binned subtree
+    int threads = 4;
+    // relaxed amalgamation of a front into its parent (columns adjacent): accepted when it adds at most relax_zero_blocks
+    // zero blocks, or when the merged front costs at most relax_flops x the two separate ones (relax_flops_small while the
+    // merged front still fits one 96-column panel: such a merge removes a whole level for very little arithmetic)
+    double relax_zero_blocks = 8, relax_flops = 1.05, relax_flops_small = 1.6;
+};
+
+void pg_sym_opts_env(pg_sym_opts& opt);    // DSSS_PG_RELAX_ZERO / _FLOPS / _SMALL overrides (experiments)
+
+// edges: pairs of chain-order separator indices, the ns-1 chain couplings (k, k+1) first, then the LC edges.
+// part[k] (may be null): rank that owns separator k, non-decreasing in k.  cx, cy: DR positions of the separators.
+void pg_symbolic(int ns, const std::vector<std::pair<int, int>>& edges, int nchain, const double* cx, const double* cy,
+                 const int* part, int nparts, const pg_sym_opts& opt, pg_sym& S);
+
+// Host twin of the numeric phase, used by the CPU test-suite only (the product path is dsss_pg.hip): factorises the matrix
+// given by `aval` (36 doubles per value index, see dest_bin) and solves for `rhs` (6 per separator, chain order).  Returns 0
+// or -1 when a pivot is not positive.
+int pg_host_solve(const pg_sym& S, int ne, const std::vector<std::pair<int, int>>& edges, const double* aval, const double* rhs, double* x);

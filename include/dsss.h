@@ -151,6 +151,15 @@ int dsss_posegraph_solve(dsss_ctx*, int nframes, double* poses12_host, double* r
 int dsss_posegraph_solve_edges(dsss_ctx*, const double* dr6, int total, const dsss_lc_edge* edges, int ne,
                                double* poses12_host, double* stats4_host);
 
+/* Host twin of the pose-graph linear solve (ordering + symbolic analysis + multifrontal factorisation of the reduced
+ * system, diasss_amd/csrc/dsss_pg_sym.cpp) so that the CPU test-suite can pin the analysis the device kernels run on without
+ * a GPU; the hot path runs the numeric phase in dsss_pg.hip.  Matrix: ns block variables (6x6 blocks); value index v < ns is
+ * the diagonal block of variable v, ns + e the block H(edge_a[e], edge_b[e]); the first ns-1 edges must be the chain (e, e+1).
+ * part (may be NULL): rank of every variable, non-decreasing.  x: ns x 6.  stats8: nnz(L) blocks, fronts, panels, levels,
+ * front arena doubles, comm doubles, binned columns, largest front (block rows).                                          */
+int dsss_host_pg_solve(int ns, const int32_t* edge_a, const int32_t* edge_b, int nedges, const double* cx, const double* cy,
+                       const int32_t* part, int nparts, const double* aval36, const double* rhs6, double* x6_host, int64_t* stats8);
+
 /* ------------------------------------------------------------------ instrumentation
  * accumulated GPU time (ms, HIP events on the context stream) and launch count per kernel family        */
 #define DSSS_K_ROW_REDUCE   0   /* row_reduce_kernel: one f64 read of the waterfall */

@@ -147,7 +147,7 @@ def test_speckle_frame_candidate_capacity(orc):
         ok, od, _, _ = orc.detect_feature(raw)
         ncand = sum(len(c.frame_candidates(0, l)[0]) for l in range(6))
         assert ncand > 60000, ncand                                           # beyond the old fixed capacity (59 776)
-        assert n == len(ok) > 1000 and (d == od).all() and (k["x"] == ok["x"]).all() and (k["y"] == ok["y"]).all()
+        assert n == len(ok) > 100 and (d == od).all() and (k["x"] == ok["x"]).all() and (k["y"] == ok["y"]).all()
         c.close()
 
 

@@ -1,0 +1,107 @@
+"""CPU: the pose-graph analysis the device kernels run on (ordering with rank partitions, column structures, bins with
+update matrices, multifrontal fronts, extend-add maps, schedule -- diasss_amd/csrc/dsss_pg_sym.cpp) pinned through its host
+twin: the multifrontal solve of a random SPD block system must equal numpy's dense solve, for one rank and for a rank
+partition (where the interface columns are ordered last), for chain-only graphs, dense-ish graphs and lawn-mower-like ones."""
+import ctypes as C
+import numpy as np
+import pytest
+
+
+def _system(ns, chords, seed):
+    rng = np.random.default_rng(seed)
+    ea = list(range(ns - 1)) + [c[0] for c in chords]
+    eb = list(range(1, ns)) + [c[1] for c in chords]
+    ne = len(ea)
+    aval = np.zeros((ns + ne, 36))
+    A = np.zeros((6 * ns, 6 * ns))
+    for e in range(ne):
+        B = rng.normal(0, 0.3, (6, 6))
+        aval[ns + e] = B.ravel()
+        a, b = ea[e], eb[e]
+        A[6 * a:6 * a + 6, 6 * b:6 * b + 6] += B; A[6 * b:6 * b + 6, 6 * a:6 * a + 6] += B.T
+    deg = np.zeros(ns)
+    for a, b in zip(ea, eb):
+        deg[a] += 1; deg[b] += 1
+    for k in range(ns):
+        Q = rng.normal(0, 1, (6, 6)); D = Q @ Q.T * 0.1 + np.eye(6) * (2.5 * deg[k] + 1.0)
+        aval[k] = D.ravel(); A[6 * k:6 * k + 6, 6 * k:6 * k + 6] += D
+    rhs = rng.normal(0, 1, (ns, 6))
+    return np.array(ea, np.int32), np.array(eb, np.int32), aval, rhs, A
+
+
+def _solve(ea, eb, aval, rhs, cx, cy, part=None, nparts=1):
+    from diasss_amd import capi
+    L = capi.lib()
+    ns = len(rhs)
+    x = np.zeros((ns, 6)); st = np.zeros(8, np.int64)
+    p = lambda a: a.ctypes.data_as(C.c_void_p)
+    rc = L.dsss_host_pg_solve(ns, p(ea), p(eb), len(ea), p(cx), p(cy), p(part) if part is not None else None, nparts,
+                              p(np.ascontiguousarray(aval)), p(np.ascontiguousarray(rhs)), p(x), p(st))
+    assert rc == 0, rc
+    return x, st
+
+
+def _lawnmower(legs, per_leg, seed, density=0.5):
+    """legs x per_leg nodes on a serpentine chain, chords between neighbouring legs at the same along-track position"""
+    rng = np.random.default_rng(seed)
+    ns = legs * per_leg
+    cx = np.zeros(ns); cy = np.zeros(ns)
+    for l in range(legs):
+        for i in range(per_leg):
+            k = l * per_leg + i
+            cx[k] = i if l % 2 == 0 else per_leg - 1 - i
+            cy[k] = 3.0 * l + 0.1 * rng.standard_normal()
+    chords, used = [], set()
+    for l in range(legs):
+        for dl in (1, 2):
+            if l + dl >= legs:
+                continue
+            for i in range(per_leg):
+                if rng.uniform() > density / dl:
+                    continue
+                j = (per_leg - 1 - i if dl == 1 else i) + int(rng.integers(-1, 2))
+                j = min(max(j, 0), per_leg - 1)
+                b = (l + dl) * per_leg + j
+                if b in used:
+                    continue                                           # at most one loop closure per target node
+                used.add(b); chords.append((l * per_leg + i, b))
+    return ns, chords, cx, cy
+
+
+@pytest.mark.parametrize("case", ["chain", "random", "lawnmower", "lawnmower_big"])
+def test_host_multifrontal_solve_equals_dense(case):
+    if case == "chain":
+        ns, chords = 40, []
+        cx = np.arange(ns, dtype=float); cy = np.zeros(ns)
+    elif case == "random":
+        ns = 120
+        rng = np.random.default_rng(3)
+        chords = [(int(a), int(b)) for a, b in rng.integers(0, ns, (150, 2)) if abs(a - b) > 1]
+        chords = list({(min(a, b), max(a, b)) for a, b in chords})
+        cx = rng.uniform(0, 10, ns); cy = rng.uniform(0, 10, ns)
+    elif case == "lawnmower":
+        ns, chords, cx, cy = _lawnmower(6, 40, 5)
+    else:
+        ns, chords, cx, cy = _lawnmower(12, 90, 6)
+    ea, eb, aval, rhs, A = _system(ns, chords, 7)
+    ref = np.linalg.solve(A, rhs.ravel()).reshape(ns, 6)
+    x, st = _solve(ea, eb, aval, rhs, cx, cy)
+    assert np.abs(x - ref).max() < 1e-10 * max(1.0, np.abs(ref).max())
+    if case == "lawnmower_big":
+        assert st[1] > 3 and st[6] > 0 and st[3] >= 2            # fronts, binned columns and several levels all occur
+
+
+@pytest.mark.parametrize("nparts", [2, 3, 4, 8])
+def test_host_multifrontal_solve_with_rank_partition(nparts, monkeypatch):
+    """contiguous leg blocks per rank: interface columns last, comm children exist, same solution"""
+    monkeypatch.setenv("DSSS_PG_BIN_COST", "200")
+    legs, per_leg = 16, 50
+    ns, chords, cx, cy = _lawnmower(legs, per_leg, 9)
+    ea, eb, aval, rhs, A = _system(ns, chords, 11)
+    ref = np.linalg.solve(A, rhs.ravel()).reshape(ns, 6)
+    part = (np.arange(ns) // per_leg * nparts // legs).astype(np.int32)
+    x, st = _solve(ea, eb, aval, rhs, cx, cy, part, nparts)
+    assert np.abs(x - ref).max() < 1e-10 * max(1.0, np.abs(ref).max())
+    assert st[5] > 0                                             # update matrices cross from interiors into the interface
+    x1, st1 = _solve(ea, eb, aval, rhs, cx, cy)
+    assert np.abs(x - x1).max() < 1e-9
