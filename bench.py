@@ -247,7 +247,7 @@ def one_roofline(slot, ms, n, work, traffic):
 def roofline(prof, workload):
     """roofline of the single kernel with the largest accumulated GPU time (umbrella slots excluded), and of every other
     kernel that has an algorithmic work figure"""
-    cand = {k: v for k, v in prof.items() if k not in ("pg", "pg_subtree", "k19") and v[1] > 0 and v[2] > 0}
+    cand = {k: v for k, v in prof.items() if k not in ("pg", "pg_subtree", "pg_asm") and v[1] > 0 and v[2] > 0}
     if not cand:
         return None, None
     traffic = pmc_traffic(workload)

@@ -10,11 +10,13 @@
 //   2. Schur complement of every chain segment between two LC-touched poses ("separators") onto its end points
 //      -- segments are independent, one thread each, 6x6 block Thomas recursion;
 //   3. the reduced system over the separators (chain couplings + LC blocks) is factorised by a sparse block
-//      Cholesky: geometric nested-dissection ordering and symbolic analysis on the host (once per solve),
-//      level-scheduled left-looking numeric factorisation and triangular solves in kernels;
+//      Cholesky: nested-dissection ordering and symbolic analysis on the host (dsss_pg_sym.cpp, once per solve);
+//      small subtrees column by column inside one workgroup each, everything above them MULTIFRONTAL: dense fronts,
+//      extend-add of the children's update matrices, panel Cholesky / row solve / trailing update on the f64 matrix cores;
 //   4. back-substitution through the segments.
 #include "dsss_internal.h"
 #include "dsss_pose.h"
+#include "dsss_pg_sym.h"
 #include <algorithm>
 #include <numeric>
 #include <random>
@@ -255,18 +257,21 @@ __global__ __launch_bounds__(64) void pg_segment_kernel(int nseg, const int* __r
     for (int a = 0; a < 6; ++a) { segGL[(size_t)s * 6 + a] = GL[a]; segGR[(size_t)s * 6 + a] = Gn[a]; }
 }
 
-// reduced system: diagonal blocks, chain couplings and right-hand side (one thread per separator, chain order)
+// reduced system: diagonal blocks, chain couplings and right-hand side (one thread per separator, chain order).  Value index
+// k = diagonal block of separator k, ns + k = chain coupling S(k, k+1), 2 ns - 1 + e = LC edge e (dsss_pg_sym.h).  A value
+// whose destination column is binned goes straight into the block-sparse factor (dest >= 0: position << 1 | transpose); the
+// others go, untransposed, into the value array the fronts assemble from.
 __global__ __launch_bounds__(256) void pg_scatter_base_kernel(int ns, const int* __restrict__ sep_pose, const int* __restrict__ perm,
                                                               const double* __restrict__ D, const double* __restrict__ g,
                                                               const double* __restrict__ segDL, const double* __restrict__ segDR,
                                                               const double* __restrict__ segGL, const double* __restrict__ segGR,
-                                                              const double* __restrict__ segS, const int* __restrict__ diag_pos,
-                                                              const int* __restrict__ ch_pos, double* __restrict__ Lvals, double* __restrict__ rhs)
+                                                              const double* __restrict__ segS, const int* __restrict__ dest,
+                                                              double* __restrict__ Lvals, double* __restrict__ aval, double* __restrict__ rhs)
 {
     const int k = blockIdx.x * 256 + threadIdx.x;
     if (k >= ns) return;
     const int p = sep_pose[k];
-    double* dst = Lvals + (size_t)diag_pos[k] * 36;
+    double* dst = dest[k] >= 0 ? Lvals + (size_t)(dest[k] >> 1) * 36 : aval + (size_t)k * 36;
     for (int a = 0; a < 36; ++a) {
         double v = D[(size_t)p * 36 + a];
         if (k > 0) v += segDR[(size_t)(k - 1) * 36 + a];
@@ -280,34 +285,44 @@ __global__ __launch_bounds__(256) void pg_scatter_base_kernel(int ns, const int*
         if (k + 1 < ns) v += segGL[(size_t)k * 6 + a];
         rr[a] = -v;
     }
-    if (k + 1 < ns) {      // S(k, k+1): stored as the (larger index, smaller index) block
-        const int code = ch_pos[k], pos = code >> 1, tr = code & 1;
-        double* c = Lvals + (size_t)pos * 36;
+    if (k + 1 < ns) {      // S(k, k+1): the factor holds the (larger index, smaller index) block
+        const int code = dest[ns + k];
         const double* S = segS + (size_t)k * 36;
-        for (int a = 0; a < 6; ++a) for (int b = 0; b < 6; ++b) c[a * 6 + b] = tr ? S[b * 6 + a] : S[a * 6 + b];
+        if (code >= 0) {
+            double* c = Lvals + (size_t)(code >> 1) * 36; const int tr = code & 1;
+            for (int a = 0; a < 6; ++a) for (int b = 0; b < 6; ++b) c[a * 6 + b] = tr ? S[b * 6 + a] : S[a * 6 + b];
+        } else {
+            double* c = aval + (size_t)(ns + k) * 36;
+            for (int a = 0; a < 36; ++a) c[a] = S[a];
+        }
     }
 }
 // LC off-diagonal blocks H(a, b) = Ji^T W (added after the chain couplings; (a,b) is unique per edge)
-__global__ __launch_bounds__(256) void pg_scatter_lc_kernel(int n, int ne, const double* __restrict__ Ji, const double* __restrict__ ew,
-                                                            const int* __restrict__ lc_pos, double* __restrict__ Lvals)
+__global__ __launch_bounds__(256) void pg_scatter_lc_kernel(int n, int ne, int ns, const double* __restrict__ Ji, const double* __restrict__ ew,
+                                                            const int* __restrict__ dest, double* __restrict__ Lvals, double* __restrict__ aval)
 {
     const int e = blockIdx.x * 256 + threadIdx.x;
     if (e >= ne) return;
-    const int code = lc_pos[e], pos = code >> 1, tr = code & 1;
+    const int code = dest[2 * ns - 1 + e];
     const double* J = Ji + (size_t)(n + e) * 36; const double* w = ew + (size_t)e * 6;
-    double* c = Lvals + (size_t)pos * 36;
-    for (int a = 0; a < 6; ++a) for (int b = 0; b < 6; ++b) {
-        const double h_ab = J[b * 6 + a] * w[b];               // (Ji^T W)(a, b)
-        if (tr) c[b * 6 + a] += h_ab; else c[a * 6 + b] += h_ab;
+    if (code >= 0) {
+        double* c = Lvals + (size_t)(code >> 1) * 36; const int tr = code & 1;
+        for (int a = 0; a < 6; ++a) for (int b = 0; b < 6; ++b) {
+            const double h_ab = J[b * 6 + a] * w[b];               // (Ji^T W)(a, b)
+            if (tr) c[b * 6 + a] += h_ab; else c[a * 6 + b] += h_ab;
+        }
+    } else {
+        double* c = aval + (size_t)(2 * ns - 1 + e) * 36;
+        for (int a = 0; a < 6; ++a) for (int b = 0; b < 6; ++b) c[a * 6 + b] = J[b * 6 + a] * w[b];
     }
 }
 
 // The factorisation kernels below (down to pg_sep_delta_kernel) are compared with the oracle at 1e-6 on the poses, not
 // bit for bit, so they may fuse multiply-adds; everything else in the library stays at -ffp-contract=off.
 #pragma clang fp contract(fast)
-// ---- sparse block Cholesky, left-looking, one workgroup per column of the current elimination-tree level.
+// ---- sparse block Cholesky of the binned columns, left-looking.
 // Column j holds blocks L(i, j), i in rowidx[colptr[j] .. colptr[j+1]) ascending, first the diagonal.
-// rowlist(j) = columns k < j with L(j, k) != 0 and the position of that block.
+// rowlist(j) = binned columns k < j with L(j, k) != 0 and the position of that block.
 // upd_map (built once per solve by pg_build_map_kernel): for update t of column j and target block q the position of
 // L(i_q, k_t) or -1; layout [mapptr[j] + t * m_j + q], so the factor kernel has no dependent index search.
 __global__ __launch_bounds__(256) void pg_build_map_kernel(int nupd, const int* __restrict__ rlrow, const int* __restrict__ rlptr,
@@ -366,143 +381,83 @@ __device__ inline void pg_acc_rows(const int* __restrict__ mp, int m, int tn, co
             acc[s] += a0 * B[s * 6] + a1 * B[s * 6 + 1] + a2 * B[s * 6 + 2] + a3 * B[s * 6 + 3] + a4 * B[s * 6 + 4] + a5 * B[s * 6 + 5];
     }
 }
-// accumulate sum_k L(i,k) L(j,k)^T for a slice of the update list: grid (columns of the level, 256-row chunks of the
-// column, slices of the update list).  With one slice the result is subtracted from A(i,j) in place; with several
-// slices each writes its partial sum to `part` and the panel kernels subtract them in slice order (deterministic).
-__global__ __launch_bounds__(256) void pg_factor_acc_kernel(const int* __restrict__ lvcols, const int* __restrict__ colptr,
-                                                            const int* __restrict__ rlptr, const int* __restrict__ rlpos,
-                                                            const long long* __restrict__ mapptr, const int* __restrict__ upd_map,
-                                                            double* __restrict__ Lvals, double* __restrict__ part, int col_stride,
-                                                            const int* __restrict__ rlcol, double* __restrict__ x, const int* __restrict__ tbeg, const int* __restrict__ tend,
-                                                            const double* __restrict__ fold_part, int fold_nsl)
+// ---- multifrontal top of the tree (dsss_pg_sym.h).  A front is a dense ld x ld lower-triangular image
+//          [ F11            ]   s6 own scalar columns          assembled from the original entries + the update matrices of its
+//          [ F21   F22      ]   n6 - s6 boundary rows          children (extend-add), factorised in 96-column panel steps:
+//     pg_front_asm_kernel      zero + original entries + children, parent rows owned by workgroups, children in fixed order
+//     pg_front_diag_kernel     L11 = chol(A11), W = L11^-1, y = L11^-1 b, u = W^T y       one workgroup per panel, dense in LDS
+//     pg_front_trsm_kernel     L21 = A21 W^T, b2 -= A21 u                                  one wavefront per 16 rows
+//     pg_front_syrk_kernel     A22 -= L21 L21^T                                           64 x 64 tiles of the trailing part
+//     pg_front_bwd_kernel      x1 = W^T (y1 - L21^T x2)
+// all dense products on v_mfma_f64_16x16x4_f64.  What is left in F22 after the last panel is the front's update matrix.
+struct pg_front {
+    long long off, roff;            // front / right-hand-side arena offsets (doubles)
+    int ld, n6, s6, c0;             // leading dimension, scalar rows, own scalar columns, first column (elimination index)
+    int rowptr, pan0;               // offset of its block-row list, first global panel id
+    int ch0, ch1, fa0, fa1;         // children and original entries (CSR ranges)
+};
+struct pg_child { const double* U; const double* g; long long relptr; int cld, cb; };
+
+#define PG_ASM_RB 8                                // parent block rows owned by one workgroup of the assembly
+__device__ inline int pg_lower_bound(const int* __restrict__ a, int n, int v)
 {
-    __shared__ double s_Ljk[PG_TCH * 36];
-    __shared__ double s_yk[PG_TCH * 6];
-    const int j = lvcols[blockIdx.x];
-    const int c0 = colptr[j], m = colptr[j + 1] - c0;
-    if ((int)blockIdx.y * 256 >= 6 * m) return;
-    const int t0 = rlptr[j], Tb = tbeg ? tbeg[j] : 0, T = tend[j] - Tb;   // this launch's share of the updates from outside the column's own panel
-    const int nsl = gridDim.z, sl = blockIdx.z;
-    const int per = (T + nsl - 1) / nsl;
-    const int ta = Tb + sl * per, tb = min(Tb + T, ta + per);
-    const int* mp = upd_map + mapptr[j];
-    const int idx = blockIdx.y * 256 + threadIdx.x;
-    const bool act = idx < 6 * m;
-    const int q = act ? idx / 6 : 0, r = idx - q * 6;
-    double acc[6] = { 0, 0, 0, 0, 0, 0 };
-    // forward substitution fused in: the right-hand side is one more block row of the column, y_j -= sum_k L(j,k) y_k
-    const bool rhs = blockIdx.y == 0 && threadIdx.x >= 250;
-    const int rs_ = threadIdx.x - 250;
-    double accy = 0;
-    for (int tc = ta; tc < tb; tc += PG_TCH) {
-        const int tn = min(PG_TCH, tb - tc);
-        __syncthreads();
-        for (int x0 = threadIdx.x; x0 < tn * 36; x0 += 4 * 256) {      // four dependent (position -> block) loads in flight per thread
-            int pos[4]; double val[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) { const int xx = x0 + u * 256; pos[u] = xx < tn * 36 ? rlpos[t0 + tc + xx / 36] : 0; }
-#pragma unroll
-            for (int u = 0; u < 4; ++u) { const int xx = x0 + u * 256; val[u] = xx < tn * 36 ? Lvals[(size_t)pos[u] * 36 + (xx % 36)] : 0.0; }
-#pragma unroll
-            for (int u = 0; u < 4; ++u) { const int xx = x0 + u * 256; if (xx < tn * 36) s_Ljk[xx] = val[u]; }
-        }
-        if (blockIdx.y == 0) for (int xx = threadIdx.x; xx < tn * 6; xx += 256) s_yk[xx] = x[(size_t)rlcol[t0 + tc + xx / 6] * 6 + (xx % 6)];
-        __syncthreads();
-        if (rhs)
-            for (int t = 0; t < tn; ++t) {
-                const double* yk = s_yk + t * 6;
-                const double* B = s_Ljk + t * 36 + rs_ * 6;
-                accy += B[0] * yk[0] + B[1] * yk[1] + B[2] * yk[2] + B[3] * yk[3] + B[4] * yk[4] + B[5] * yk[5];
-            }
-        if (act)
-            pg_acc_rows(mp + (size_t)tc * m + q, m, tn, Lvals, r, s_Ljk, acc);
-    }
-    // an in-place launch (one slice) can also fold the partial sums another, sliced launch left for this level: slice
-    // order fixed, after this launch's own sum (same arithmetic as pg_fold_kernel running behind it)
-    if (rhs) {
-        if (nsl == 1) {
-            double v = x[(size_t)j * 6 + rs_] - accy;
-            for (int s2 = 0; s2 < fold_nsl; ++s2) v -= fold_part[((size_t)blockIdx.x * fold_nsl + s2) * col_stride + (size_t)col_stride - 8 + rs_];
-            x[(size_t)j * 6 + rs_] = v;
-        } else part[((size_t)blockIdx.x * nsl + sl) * col_stride + (size_t)col_stride - 8 + rs_] = accy;
-    }
-    if (!act) return;
-    if (nsl == 1) {
-        double* row = Lvals + (size_t)(c0 + q) * 36 + r * 6;
-        double v[6];
-#pragma unroll
-        for (int s = 0; s < 6; ++s) v[s] = row[s] - acc[s];
-        int s2 = 0;
-        for (; s2 + 4 <= fold_nsl; s2 += 4) {                   // four slices in flight, subtracted in slice order
-            double o[4][6];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const double* op = fold_part + ((size_t)blockIdx.x * fold_nsl + s2 + u) * col_stride + (size_t)idx * 6;
-#pragma unroll
-                for (int s = 0; s < 6; ++s) o[u][s] = op[s];
-            }
-#pragma unroll
-            for (int u = 0; u < 4; ++u)
-#pragma unroll
-                for (int s = 0; s < 6; ++s) v[s] -= o[u][s];
-        }
-        for (; s2 < fold_nsl; ++s2) {
-            const double* o = fold_part + ((size_t)blockIdx.x * fold_nsl + s2) * col_stride + (size_t)idx * 6;
-#pragma unroll
-            for (int s = 0; s < 6; ++s) v[s] -= o[s];
-        }
-#pragma unroll
-        for (int s = 0; s < 6; ++s) row[s] = v[s];
-    }
-    else { double* o = part + ((size_t)blockIdx.x * nsl + sl) * col_stride + (size_t)idx * 6; for (int s = 0; s < 6; ++s) o[s] = acc[s]; }
+    int lo = 0, hi = n;
+    while (lo < hi) { const int mid = (lo + hi) >> 1; if (a[mid] < v) lo = mid + 1; else hi = mid; }
+    return lo;
 }
-// fold the per-slice partial sums of pg_factor_acc_kernel into the column blocks and the right-hand side, slice order
-// fixed (deterministic); keeps the serial critical paths of the panel kernels free of the nsl-fold reads
-__global__ __launch_bounds__(256) void pg_fold_kernel(const int* __restrict__ lvcols, const int* __restrict__ colptr, double* __restrict__ Lvals,
-                                                      const double* __restrict__ part, int nsl, int col_stride, double* __restrict__ x)
+__global__ __launch_bounds__(256) void pg_front_asm_kernel(const int* __restrict__ fronts, const pg_front* __restrict__ FD, const pg_child* __restrict__ CH,
+                                                           const int* __restrict__ rel, const int* __restrict__ fa_src, const int* __restrict__ fa_row,
+                                                           const int* __restrict__ fa_col, const int* __restrict__ fa_tr, const double* __restrict__ aval,
+                                                           const double* __restrict__ x, double* __restrict__ F, double* __restrict__ R)
 {
-    const int j = lvcols[blockIdx.x];
-    const int c0 = colptr[j], m = colptr[j + 1] - c0;
-    const int idx = blockIdx.y * 256 + threadIdx.x;
-    if (idx < 6 * m) {
-        double* row = Lvals + (size_t)c0 * 36 + (size_t)idx * 6;
-        double v[6];
-#pragma unroll
-        for (int s = 0; s < 6; ++s) v[s] = row[s];
-        for (int sl = 0; sl < nsl; ++sl) {
-            const double* o = part + ((size_t)blockIdx.x * nsl + sl) * col_stride + (size_t)idx * 6;
-#pragma unroll
-            for (int s = 0; s < 6; ++s) v[s] -= o[s];
-        }
-#pragma unroll
-        for (int s = 0; s < 6; ++s) row[s] = v[s];
+    const pg_front fd = FD[fronts[blockIdx.x]];
+    const int nb = fd.n6 / 6, R0 = (int)blockIdx.y * PG_ASM_RB;
+    if (R0 >= nb) return;
+    const int R1 = min(nb, R0 + PG_ASM_RB), ld = fd.ld;
+    double* __restrict__ A = F + fd.off; double* __restrict__ r = R + fd.roff;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    // 1. zero the owned rows up to and including their diagonal block; right-hand side of the own columns
+    for (int row = 6 * R0 + wave; row < 6 * R1; row += 4) {
+        const int ncol = 6 * (row / 6 + 1);
+        for (int c2 = lane; c2 < ncol; c2 += 64) A[(size_t)row * ld + c2] = 0.0;
     }
-    if (blockIdx.y == 0 && threadIdx.x < 6) {
-        double v = x[(size_t)j * 6 + threadIdx.x];
-        for (int sl = 0; sl < nsl; ++sl) v -= part[((size_t)blockIdx.x * nsl + sl) * col_stride + (size_t)col_stride - 8 + threadIdx.x];
-        x[(size_t)j * 6 + threadIdx.x] = v;
+    for (int i = 6 * R0 + (int)threadIdx.x; i < 6 * R1; i += 256) r[i] = i < fd.s6 ? x[(size_t)fd.c0 * 6 + i] : 0.0;
+    __syncthreads();
+    // 2. original entries of the owned rows; entries with the same destination block (an LC edge on top of a chain coupling)
+    //    are consecutive in the list and are summed by one thread group in list order
+    {
+        const int lo = fd.fa0 + pg_lower_bound(fa_row + fd.fa0, fd.fa1 - fd.fa0, R0), hi = fd.fa0 + pg_lower_bound(fa_row + fd.fa0, fd.fa1 - fd.fa0, R1);
+        const int grp = threadIdx.x / 36, el = threadIdx.x % 36;
+        if (grp < 7)
+            for (int e = lo + grp; e < hi; e += 7) {
+                if (e > lo && fa_row[e - 1] == fa_row[e] && fa_col[e - 1] == fa_col[e]) continue;      // not the head of its run
+                const int a = el / 6, b = el % 6;
+                double v = 0;
+                for (int e2 = e; e2 < hi && fa_row[e2] == fa_row[e] && fa_col[e2] == fa_col[e]; ++e2)
+                    v += aval[(size_t)fa_src[e2] * 36 + (fa_tr[e2] ? b * 6 + a : a * 6 + b)];
+                A[(size_t)(fa_row[e] * 6 + a) * ld + fa_col[e] * 6 + b] += v;
+            }
+    }
+    __syncthreads();
+    // 3. extend-add of the children, one after the other
+    for (int c = fd.ch0; c < fd.ch1; ++c) {
+        const pg_child cd = CH[c];
+        const int* __restrict__ rl = rel + cd.relptr;
+        const int i0 = pg_lower_bound(rl, cd.cb, R0), i1 = pg_lower_bound(rl, cd.cb, R1);
+        for (int i = i0; i < i1; ++i) {
+            const int pr = rl[i], wcols = 6 * (i + 1);
+            for (int a = wave; a < 6; a += 4) {
+                const double* __restrict__ src = cd.U + (size_t)(6 * i + a) * cd.cld;
+                double* __restrict__ dst = A + (size_t)(6 * pr + a) * ld;
+                for (int cc = lane; cc < wcols; cc += 64) { const int j2 = cc / 6, b = cc - 6 * j2; dst[6 * rl[j2] + b] += src[cc]; }
+            }
+            if (threadIdx.x < 6) r[6 * pr + threadIdx.x] += cd.g[6 * i + threadIdx.x];
+        }
+        __syncthreads();
     }
 }
 
-// ---- supernodal panels for the top of the tree.  A panel is up to PG_PW consecutive columns j0 .. j0+w-1 with nested
-// structure (struct(j+1) = struct(j) minus j), i.e. a dense trapezoid: a 6w x 6w diagonal block A11 on top of the rows
-// A21 shared by all its columns.  After the external updates (pg_factor_acc_kernel over all columns of the level at once)
-//     L11 = chol(A11), y = L11^-1 b, W = L11^-1     pg_panel_diag_kernel   one workgroup per panel, A11 dense in LDS
-//     L21 = A21 W^T                                 pg_panel_trsm_kernel   one wavefront per 16 scalar rows of A21
-// which replaces w column-levels by one panel-level; both run on the f64 matrix cores.
-#define PG_PW 16
-#define PG_BWD_LDS (((PG_PW * 6) * (PG_PW * 6) + 64 * (PG_PW * 6)) * (int)sizeof(double))
-__device__ inline size_t pan_pos(const int* __restrict__ colptr, int j0, int qi, int c) { return (size_t)colptr[j0 + c] + (size_t)(qi - c); }
-
-// ---- pg_panel_diag_kernel: the 6w x 6w diagonal block of a panel as a dense matrix in LDS, worked in 16 x 16 tiles.
-//   per tile step t:  A  (16 lanes) L_tt = chol(A_tt) and V_t = L_tt^-1, rows/columns held across lanes, pivots and
-//                        multipliers broadcast with v_readlane
-//                     B  L_it = A_it V_t^T for the tiles below            (v_mfma_f64_16x16x4_f64, 4 per tile)
-//                     C  A_ij -= L_it L_jt^T for the trailing tiles       (same); wavefront 0 takes tile (t+1, t+1) first
-//                        and goes straight on to step A of t+1 while wavefronts 1-3 finish the rest (look-ahead)
-//   then W = L11^-1 by recursive doubling over tiles, [A 0; B C]^-1 = [A^-1 0; -C^-1 B A^-1  C^-1], again on the matrix
-//   cores, so that the row solve below the panel and the back-substitution are plain products with W.
-// The right-hand side rides along: y_t = V_t b_t, b_i -= L_it y_t.
+#define PG_BWD_LDS(maxn6) ((((PG_PW * 6) * (PG_PW * 6) + 10 * (PG_PW * 6) + (PG_PW * 6) + (maxn6)) + 16) * (int)sizeof(double))
 #define PG_LD 98                                   // LDS row stride of the 96 x 96 images (doubles)
 #define PG_DIAG_LDS (2 * (PG_PW * 6) * PG_LD * (int)sizeof(double))
 typedef double pg_d4 __attribute__((ext_vector_type(4)));
@@ -541,7 +496,8 @@ __device__ inline pg_d4 pg_mma4(const double* a, const double* b, pg_d4 c)
     for (int ks = 0; ks < 4; ++ks) c = __builtin_amdgcn_mfma_f64_16x16x4f64(a[ks], b[ks], c, 0, 0, 0);
     return c;
 }
-// step A for tile t, executed by lanes 0..15 of one wavefront: lane i owns row i of A_tt, then column i of V_t
+// Cholesky of the 16 x 16 diagonal tile t and its inverse V_t, executed by lanes 0..15 of one wavefront: lane i owns row i
+// of A_tt, then column i of V_t
 __device__ inline int pg_tile_factor(double* sA, double* sW, int t, int lane)
 {
     double d[16], v[16];
@@ -575,32 +531,39 @@ __device__ inline int pg_tile_factor(double* sA, double* sW, int t, int lane)
     return bad;
 }
 
-__global__ __launch_bounds__(256) void pg_panel_diag_kernel(const int* __restrict__ plvpan, const int* __restrict__ pan_first, const int* __restrict__ pan_w,
-                                                            const int* __restrict__ colptr, double* __restrict__ Lvals,
-                                                            double* __restrict__ x, int* __restrict__ fail, double* __restrict__ Wsw, double* __restrict__ Wrow)
+// panel step `step` of a front: n = min(96, s6 - 96 step) columns starting at scalar column 96 step.
+//   per tile step t:  A  (16 lanes) L_tt = chol(A_tt) and V_t = L_tt^-1
+//                     B  L_it = A_it V_t^T for the tiles below            (v_mfma_f64_16x16x4_f64, 4 per tile)
+//                     C  A_ij -= L_it L_jt^T for the trailing tiles       (same); wavefront 0 takes tile (t+1, t+1) first
+//                        and goes straight on to step A of t+1 while wavefronts 1-3 finish the rest (look-ahead)
+//   then W = L11^-1 by recursive doubling over tiles, [A 0; B C]^-1 = [A^-1 0; -C^-1 B A^-1  C^-1], again on the matrix
+//   cores, so that the row solve below the panel and the back-substitution are plain products with W.
+// The right-hand side rides along: y_t = V_t b_t, b_i -= L_it y_t; u = W^T y goes out for the row kernel.
+__global__ __launch_bounds__(256) void pg_front_diag_kernel(const int* __restrict__ it_front, const int* __restrict__ it_step, const pg_front* __restrict__ FD,
+                                                            double* __restrict__ F, double* __restrict__ R, int* __restrict__ fail,
+                                                            double* __restrict__ Wsw, double* __restrict__ Wrow, double* __restrict__ Uvec)
 {
     extern __shared__ double s_dyn[];
     __shared__ double sy[PG_PW * 6];
     __shared__ int s_bad;
     double* sA = s_dyn;
     double* sW = s_dyn + (PG_PW * 6) * PG_LD;
-    const int p = plvpan[blockIdx.x];
-    const int j0 = pan_first[p], w = pan_w[p], n = 6 * w;
+    const pg_front fd = FD[it_front[blockIdx.x]];
+    const int step = it_step[blockIdx.x], col0 = 96 * step;
+    const int n = min(96, fd.s6 - col0), w = n / 6, p = fd.pan0 + step, ld = fd.ld;
+    double* __restrict__ A = F + fd.off + (size_t)col0 * ld + col0;
+    double* __restrict__ rr = R + fd.roff + col0;
     const int nt = (n + 15) >> 4, np = 16 * nt;
     const int bi = threadIdx.x >> 4, bj = threadIdx.x & 15;
     const bool act = bi < w && bj <= bi;
     const int wave = threadIdx.x >> 6, l = threadIdx.x & 63;
     if (threadIdx.x == 0) s_bad = 0;
-    if (act) {
-        const double* src = Lvals + pan_pos(colptr, j0, bi, bj) * 36;
-#pragma unroll
-        for (int e = 0; e < 36; ++e) sA[(6 * bi + e / 6) * PG_LD + 6 * bj + e % 6] = src[e];
-    }
+    for (int i = wave; i < n; i += 4) for (int j = l; j < n; j += 64) sA[i * PG_LD + j] = A[(size_t)i * ld + j];
     for (int e = threadIdx.x; e < (np - n) * np; e += 256) {        // identity padding up to the tile boundary
         const int i = n + e / np, c2 = e % np;
         sA[i * PG_LD + c2] = i == c2 ? 1.0 : 0.0;
     }
-    if ((int)threadIdx.x < np) sy[threadIdx.x] = (int)threadIdx.x < n ? x[(size_t)(j0 + threadIdx.x / 6) * 6 + threadIdx.x % 6] : 0.0;
+    if ((int)threadIdx.x < np) sy[threadIdx.x] = (int)threadIdx.x < n ? rr[threadIdx.x] : 0.0;
     __syncthreads();
     if (threadIdx.x < 16) { if (pg_tile_factor(sA, sW, 0, threadIdx.x)) s_bad = 1; }
     __syncthreads();
@@ -659,12 +622,8 @@ __global__ __launch_bounds__(256) void pg_panel_diag_kernel(const int* __restric
         __syncthreads();
     }
     if (s_bad && threadIdx.x == 0) *fail = 1;
-    if (act) {
-        double* dst = Lvals + pan_pos(colptr, j0, bi, bj) * 36;
-#pragma unroll
-        for (int e = 0; e < 36; ++e) dst[e] = (bi == bj && e % 6 > e / 6) ? 0.0 : sA[(6 * bi + e / 6) * PG_LD + 6 * bj + e % 6];
-    }
-    if ((int)threadIdx.x < n) x[(size_t)(j0 + threadIdx.x / 6) * 6 + threadIdx.x % 6] = sy[threadIdx.x];
+    for (int i = wave; i < n; i += 4) for (int j = l; j <= i; j += 64) A[(size_t)i * ld + j] = sA[i * PG_LD + j];       // L11, lower triangle
+    if ((int)threadIdx.x < n) rr[threadIdx.x] = sy[threadIdx.x];
     // ---- W = L11^-1: off-diagonal tiles by recursive doubling (the diagonal tiles V_t are in place)
     for (int h = 1; h < nt; h <<= 1) {
         {   int cnt = 0;                                        // T = B A^-1 into the target tiles
@@ -709,6 +668,17 @@ __global__ __launch_bounds__(256) void pg_panel_diag_kernel(const int* __restric
         if (ti1 >= 0) pg_st_c(sW, 16 * ti1, 16 * tj1, l, r1);
         __syncthreads();
     }
+    // u = W^T y for the row kernel (b2 -= A21 u): u[i] = sum_{k >= i} W[k][i] y[k]
+    if ((int)threadIdx.x < PG_PW * 6) {
+        const int i = threadIdx.x;
+        double v0 = 0, v1 = 0;
+        if (i < n) {
+            int k = i;
+            for (; k + 1 < n; k += 2) { v0 += sW[k * PG_LD + i] * sy[k]; v1 += sW[(k + 1) * PG_LD + i] * sy[k + 1]; }
+            if (k < n) v0 += sW[k * PG_LD + i] * sy[k];
+        }
+        Uvec[(size_t)p * (PG_PW * 6) + i] = v0 + v1;
+    }
     // W out: row-major for the back-substitution, and in MFMA B-operand order for the row solve (tile nt = 16 output
     // columns, k-step ks = 4 k's: lane l holds W[16 nt + (l & 15)][4 ks + (l >> 4)]).  Thread (bi, bj) writes its block;
     // everything outside the lower block triangle of the first w block rows was zeroed once by the host and stays zero.
@@ -732,30 +702,36 @@ __global__ __launch_bounds__(256) void pg_panel_diag_kernel(const int* __restric
     }
 }
 
-// L21 = A21 W^T with W = L11^-1 from pg_panel_diag_kernel: a plain f64 GEMM on the matrix cores.  One wavefront per
+// L21 = A21 W^T with W = L11^-1 from pg_front_diag_kernel: a plain f64 GEMM on the matrix cores.  One wavefront per
 // 16 scalar rows: the 16 x 96 slab of A21 sits in 24 A-operand registers per lane (lane l: row l & 15, k = 4 ks + (l >> 4)),
 // W^T streams in as pre-swizzled B operands (one coalesced 512-byte load per v_mfma_f64_16x16x4_f64), and output tile nt
-// only runs the k-steps its triangular W reaches (4 nt + 4 of 24).
-__global__ __launch_bounds__(256) void pg_panel_trsm_kernel(const int* __restrict__ plvpan, const int* __restrict__ pan_first, const int* __restrict__ pan_w,
-                                                            const int* __restrict__ colptr, double* __restrict__ Lvals, const double* __restrict__ Wsw)
+// only runs the k-steps its triangular W reaches (4 nt + 4 of 24).  Forward substitution rides along: b2 -= A21 u.
+__global__ __launch_bounds__(256) void pg_front_trsm_kernel(const int* __restrict__ it_front, const int* __restrict__ it_step, const pg_front* __restrict__ FD,
+                                                            double* __restrict__ F, double* __restrict__ R, const double* __restrict__ Wsw, const double* __restrict__ Uvec)
 {
-    const int p = plvpan[blockIdx.x];
-    const int j0 = pan_first[p], w = pan_w[p], n = 6 * w;
-    const int m = colptr[j0 + 1] - colptr[j0];     // block rows of the first column
-    const int nrows = 6 * (m - w);
+    const pg_front fd = FD[it_front[blockIdx.x]];
+    const int step = it_step[blockIdx.x], col0 = 96 * step;
+    const int n = min(96, fd.s6 - col0), p = fd.pan0 + step, ld = fd.ld;
+    const int row0 = col0 + n, nrows = fd.n6 - row0;
     const int l = threadIdx.x & 63;
     const int rowbase = ((int)blockIdx.y * 4 + (int)(threadIdx.x >> 6)) * 16;
     if (rowbase >= nrows) return;                  // wavefront-uniform
     const double* Wp = Wsw + (size_t)p * (PG_PW * 6) * (PG_PW * 6);
+    const double* up = Uvec + (size_t)p * (PG_PW * 6);
     const int arow = rowbase + (l & 15);
     const bool rok = arow < nrows;
-    const int qi = w + arow / 6, r = arow % 6;
+    double* __restrict__ Arow = F + fd.off + (size_t)(row0 + arow) * ld + col0;
     double a[24];
+    double dot = 0;
 #pragma unroll
     for (int ks = 0; ks < 24; ++ks) {
-        const int k = 4 * ks + (l >> 4), cb = k / 6, s = k - 6 * cb;
-        a[ks] = (rok && k < n) ? Lvals[((size_t)colptr[j0 + min(cb, w - 1)] + (size_t)(qi - cb)) * 36 + r * 6 + s] : 0.0;
+        const int k = 4 * ks + (l >> 4);
+        a[ks] = (rok && k < n) ? Arow[k] : 0.0;
+        dot += a[ks] * up[k];
     }
+    dot += __shfl_xor(dot, 16, 64);
+    dot += __shfl_xor(dot, 32, 64);
+    if (l < 16 && rok) R[fd.roff + row0 + arow] -= dot;
 #pragma unroll
     for (int nt = 0; nt < 6; ++nt) {
         if (16 * nt < n) {                         // uniform
@@ -765,51 +741,92 @@ __global__ __launch_bounds__(256) void pg_panel_trsm_kernel(const int* __restric
                 acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[ks], Wp[(nt * 24 + ks) * 64 + l], acc, 0, 0, 0);
             const int col = 16 * nt + (l & 15);
             if (col < n) {
-                const int cb = col / 6, s = col - 6 * cb;
-                const size_t base = (size_t)colptr[j0 + cb];
 #pragma unroll
                 for (int v = 0; v < 4; ++v) {
                     const int row = rowbase + (l >> 4) + 4 * v;
-                    if (row < nrows) Lvals[(base + (size_t)(w + row / 6 - cb)) * 36 + (row % 6) * 6 + s] = acc[v];
+                    if (row < nrows) F[fd.off + (size_t)(row0 + row) * ld + col0 + col] = acc[v];
                 }
             }
         }
     }
 }
 
-// x_panel = W^T (y_panel - L21^T x_below), W = L11^-1: one workgroup of 1024 threads per panel
-#define PG_BWD_SLOTS 64
-__global__ __launch_bounds__(1024) void pg_panel_bwd_kernel(const int* __restrict__ plvpan, const int* __restrict__ pan_first, const int* __restrict__ pan_w,
-                                                            const int* __restrict__ colptr, const int* __restrict__ rowidx,
-                                                            const double* __restrict__ Lvals, double* __restrict__ x, const double* __restrict__ Wrow)
+// A22 -= L21 L21^T on the trailing part of the front (rows and columns beyond the panel): 64 x 64 output tiles of the lower
+// triangle, one wavefront per 16 rows of a tile, K = the panel's 96 columns: 24 v_mfma_f64_16x16x4_f64 per 16 x 16 block.
+__global__ __launch_bounds__(256) void pg_front_syrk_kernel(const int* __restrict__ it_front, const int* __restrict__ it_step, const pg_front* __restrict__ FD,
+                                                            double* __restrict__ F)
 {
-    extern __shared__ double s_bw[];               // W [96 x 96] then the slot sums [PG_BWD_SLOTS][96]
-    __shared__ double sz[PG_PW * 6];
+    const pg_front fd = FD[it_front[blockIdx.x]];
+    const int step = it_step[blockIdx.x], col0 = 96 * step;
+    const int n = min(96, fd.s6 - col0), ld = fd.ld;
+    const int row0 = col0 + n, nrows = fd.n6 - row0;
+    const int ntile = (nrows + 63) >> 6;
+    const int t = blockIdx.y;
+    if (t >= ntile * (ntile + 1) / 2) return;
+    int ti = (int)((sqrt(8.0 * t + 1.0) - 1.0) * 0.5);
+    while ((ti + 1) * (ti + 2) / 2 <= t) ++ti;
+    while (ti * (ti + 1) / 2 > t) --ti;
+    const int tj = t - ti * (ti + 1) / 2;
+    const int wave = threadIdx.x >> 6, l = threadIdx.x & 63;
+    const int i0 = 64 * ti + 16 * wave;
+    if (i0 >= nrows) return;
+    double* __restrict__ A = F + fd.off;
+    const int ir = i0 + (l & 15);
+    const double* __restrict__ Ai = A + (size_t)(row0 + min(ir, nrows - 1)) * ld + col0;
+    double a[24];
+#pragma unroll
+    for (int ks = 0; ks < 24; ++ks) { const int k = 4 * ks + (l >> 4); a[ks] = (ir < nrows && k < n) ? -Ai[k] : 0.0; }
+    for (int c = 0; c < 4; ++c) {
+        const int j0 = 64 * tj + 16 * c;
+        if (j0 >= nrows || j0 > i0 + 15) break;              // beyond the front, or entirely above the diagonal
+        const int jr = j0 + (l & 15);
+        const double* __restrict__ Aj = A + (size_t)(row0 + min(jr, nrows - 1)) * ld + col0;
+        double b[24];
+#pragma unroll
+        for (int ks = 0; ks < 24; ++ks) { const int k = 4 * ks + (l >> 4); b[ks] = (jr < nrows && k < n) ? Aj[k] : 0.0; }
+        pg_d4 acc;
+        double* __restrict__ Cp = A + (size_t)(row0 + i0 + (l >> 4)) * ld + row0 + j0 + (l & 15);
+#pragma unroll
+        for (int v = 0; v < 4; ++v) acc[v] = (i0 + (l >> 4) + 4 * v < nrows && jr < nrows) ? Cp[(size_t)(4 * v) * ld] : 0.0;
+#pragma unroll
+        for (int ks = 0; ks < 24; ++ks) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[ks], b[ks], acc, 0, 0, 0);
+#pragma unroll
+        for (int v = 0; v < 4; ++v) if (i0 + (l >> 4) + 4 * v < nrows && jr < nrows) Cp[(size_t)(4 * v) * ld] = acc[v];
+    }
+}
+
+// x1 = W^T (y1 - L21^T x2) for one panel: one workgroup of 1024 threads.  x2 (the rows below the panel, inside the front
+// and in its boundary) is gathered into LDS once; ten row slots accumulate the 96 column sums, folded in slot order.
+__global__ __launch_bounds__(1024) void pg_front_bwd_kernel(const int* __restrict__ it_front, const int* __restrict__ it_step, const pg_front* __restrict__ FD,
+                                                            const int* __restrict__ f_rows, const double* __restrict__ F, const double* __restrict__ R,
+                                                            double* __restrict__ x, const double* __restrict__ Wrow)
+{
+    extern __shared__ double s_bw[];               // W [96 x 96] | slot sums [10][96] | z [96] | x2 [nrows]
     double* sW = s_bw;
     double* s_acc = s_bw + (PG_PW * 6) * (PG_PW * 6);
-    const int p = plvpan[blockIdx.x];
-    const int j0 = pan_first[p], w = pan_w[p], n = 6 * w;
-    const int c0 = colptr[j0], m = colptr[j0 + 1] - c0;
-    // W goes global -> registers now, -> LDS after the row sums, so its latency hides behind them
+    double* sz = s_acc + 10 * (PG_PW * 6);
+    double* sx = sz + (PG_PW * 6);
+    const pg_front fd = FD[it_front[blockIdx.x]];
+    const int step = it_step[blockIdx.x], col0 = 96 * step;
+    const int n = min(96, fd.s6 - col0), p = fd.pan0 + step, ld = fd.ld;
+    const int row0 = col0 + n, nrows = fd.n6 - row0;
     double wreg[9];
     { const double* wr = Wrow + (size_t)p * (PG_PW * 6) * (PG_PW * 6);
 #pragma unroll
       for (int e = 0; e < 9; ++e) wreg[e] = wr[e * 1024 + threadIdx.x]; }
-    // z[gj] = y[gj] - sum over rows below of L(row, gj) x_row : thread (slot, c) walks block rows slot, slot+64, ... of block
-    // column c; the slot sums of every scalar column are then folded in slot order (deterministic)
+    for (int i = threadIdx.x; i < nrows; i += 1024) { const int g = row0 + i; sx[i] = x[(size_t)f_rows[fd.rowptr + g / 6] * 6 + g % 6]; }
+    __syncthreads();
     {
-        const int slot = threadIdx.x >> 4, cc = threadIdx.x & 15;
-        double acc[6] = { 0, 0, 0, 0, 0, 0 };
-        if (cc < w) {
-            const size_t cbase = (size_t)colptr[j0 + cc] - (size_t)cc;
-            for (int qi = w + slot; qi < m; qi += PG_BWD_SLOTS) {
-                const double* B = Lvals + (cbase + qi) * 36; const double* xi = x + (size_t)rowidx[c0 + qi] * 6;
-                const double x0 = xi[0], x1 = xi[1], x2 = xi[2], x3 = xi[3], x4 = xi[4], x5 = xi[5];
-#pragma unroll
-                for (int s6 = 0; s6 < 6; ++s6) acc[s6] += B[s6] * x0 + B[6 + s6] * x1 + B[12 + s6] * x2 + B[18 + s6] * x3 + B[24 + s6] * x4 + B[30 + s6] * x5;
+        const int slot = threadIdx.x / 96, cc = threadIdx.x - slot * 96;
+        if (slot < 10) {
+            double acc0 = 0, acc1 = 0;
+            if (cc < n) {
+                const double* __restrict__ Ab = F + fd.off + (size_t)row0 * ld + col0 + cc;
+                int i = slot;
+                for (; i + 10 < nrows; i += 20) { acc0 += Ab[(size_t)i * ld] * sx[i]; acc1 += Ab[(size_t)(i + 10) * ld] * sx[i + 10]; }
+                if (i < nrows) acc0 += Ab[(size_t)i * ld] * sx[i];
             }
-#pragma unroll
-            for (int s6 = 0; s6 < 6; ++s6) s_acc[slot * (PG_PW * 6) + cc * 6 + s6] = acc[s6];
+            s_acc[slot * (PG_PW * 6) + cc] = acc0 + acc1;
         }
     }
 #pragma unroll
@@ -817,8 +834,8 @@ __global__ __launch_bounds__(1024) void pg_panel_bwd_kernel(const int* __restric
     __syncthreads();
     if ((int)threadIdx.x < n) {
         const int gj = threadIdx.x;
-        double v = x[(size_t)(j0 + gj / 6) * 6 + gj % 6];
-        for (int g = 0; g < PG_BWD_SLOTS; ++g) v -= s_acc[g * (PG_PW * 6) + gj];
+        double v = R[fd.roff + col0 + gj];
+        for (int g = 0; g < 10; ++g) v -= s_acc[g * (PG_PW * 6) + gj];
         sz[gj] = v;
     }
     __syncthreads();
@@ -829,24 +846,36 @@ __global__ __launch_bounds__(1024) void pg_panel_bwd_kernel(const int* __restric
         int k = i;
         for (; k + 1 < n; k += 2) { v0 += sW[k * (PG_PW * 6) + i] * sz[k]; v1 += sW[(k + 1) * (PG_PW * 6) + i] * sz[k + 1]; }
         if (k < n) v0 += sW[k * (PG_PW * 6) + i] * sz[k];
-        x[(size_t)(j0 + i / 6) * 6 + i % 6] = v0 + v1;
+        x[(size_t)fd.c0 * 6 + col0 + i] = v0 + v1;
     }
 }
 
+
 // ---- bottom of the elimination tree: whole subtrees per workgroup (no grid-wide level barriers).
-// A bin is a list of columns in ascending order whose ancestors outside the bin are never its descendants, so the
-// workgroup can run them back to back with workgroup barriers only.  Same arithmetic and summation order as the
-// level-scheduled kernels.  Only columns with at most 42 blocks (6m <= 256 rows: one pass) are binned.
+// A bin is a list of columns in ascending order whose sources all lie in the same bin, so the workgroup can run them back to
+// back with workgroup barriers only (left-looking, block-sparse, update map).  Only columns with at most 42 blocks
+// (6m <= 256 rows: one pass) are binned.  Every finished column also adds its outer product over the rows BEYOND its subtree
+// root to the root's update matrix U_root (and L y to its right-hand side part): what the first front above the bin
+// extend-adds, exactly like the F22 of a child front.  One workgroup owns a bin, columns in fixed order: deterministic.
 __global__ __launch_bounds__(256) void pg_factor_subtree_kernel(const int* __restrict__ binptr, const int* __restrict__ bincols,
                                                                 const int* __restrict__ colptr, const int* __restrict__ rlptr,
                                                                 const int* __restrict__ rlcol, const int* __restrict__ rlpos,
                                                                 const long long* __restrict__ mapptr, const int* __restrict__ upd_map,
-                                                                double* __restrict__ Lvals, double* __restrict__ x, int* __restrict__ fail)
+                                                                double* __restrict__ Lvals, double* __restrict__ x, int* __restrict__ fail,
+                                                                const int* __restrict__ binroot_ptr, const int* __restrict__ binroot_idx,
+                                                                const int* __restrict__ broot_b, const long long* __restrict__ broot_uoff,
+                                                                const int* __restrict__ broot_of_col, const int* __restrict__ anc_first,
+                                                                const int* __restrict__ anc_rel, double* __restrict__ ubin)
 {
-    __shared__ double s_Ljk[PG_TCH * 36];
+    __shared__ double s_Ljk[PG_TCH * 36];          // update staging; reused for the column's ancestor blocks (42 x 36)
     __shared__ double s_yk[PG_TCH * 6];
     __shared__ double s_diag[36];
+    __shared__ double s_y[6];
     __shared__ int s_ok;
+    for (int q = binroot_ptr[blockIdx.x]; q < binroot_ptr[blockIdx.x + 1]; ++q) {        // zero the update matrices of this bin's roots
+        const int ri = binroot_idx[q]; const long long b6 = 6LL * broot_b[ri]; double* U = ubin + broot_uoff[ri];
+        for (long long e = threadIdx.x; e < b6 * b6 + b6; e += 256) U[e] = 0.0;
+    }
     for (int ci = binptr[blockIdx.x]; ci < binptr[blockIdx.x + 1]; ++ci) {
         const int j = bincols[ci];
         const int c0 = colptr[j], m = colptr[j + 1] - c0;
@@ -862,14 +891,14 @@ __global__ __launch_bounds__(256) void pg_factor_subtree_kernel(const int* __res
             const int tn = min(PG_TCH, T - tc);
             __syncthreads();
             for (int x0 = threadIdx.x; x0 < tn * 36; x0 += 4 * 256) {      // four dependent (position -> block) loads in flight per thread
-            int pos[4]; double val[4];
+                int pos[4]; double val[4];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) { const int xx = x0 + u * 256; pos[u] = xx < tn * 36 ? rlpos[t0 + tc + xx / 36] : 0; }
+                for (int u = 0; u < 4; ++u) { const int xx = x0 + u * 256; pos[u] = xx < tn * 36 ? rlpos[t0 + tc + xx / 36] : 0; }
 #pragma unroll
-            for (int u = 0; u < 4; ++u) { const int xx = x0 + u * 256; val[u] = xx < tn * 36 ? Lvals[(size_t)pos[u] * 36 + (xx % 36)] : 0.0; }
+                for (int u = 0; u < 4; ++u) { const int xx = x0 + u * 256; val[u] = xx < tn * 36 ? Lvals[(size_t)pos[u] * 36 + (xx % 36)] : 0.0; }
 #pragma unroll
-            for (int u = 0; u < 4; ++u) { const int xx = x0 + u * 256; if (xx < tn * 36) s_Ljk[xx] = val[u]; }
-        }
+                for (int u = 0; u < 4; ++u) { const int xx = x0 + u * 256; if (xx < tn * 36) s_Ljk[xx] = val[u]; }
+            }
             for (int xx = threadIdx.x; xx < tn * 6; xx += 256) s_yk[xx] = x[(size_t)rlcol[t0 + tc + xx / 6] * 6 + (xx % 6)];
             __syncthreads();
             if (rhs)
@@ -893,16 +922,39 @@ __global__ __launch_bounds__(256) void pg_factor_subtree_kernel(const int* __res
             if (!bad) {
                 double v[6];
                 for (int a = 0; a < 6; ++a) { double t = x[(size_t)j * 6 + a]; for (int b = 0; b < a; ++b) t -= A[a * 6 + b] * v[b]; v[a] = t / A[a * 6 + a]; }
-                for (int a = 0; a < 6; ++a) x[(size_t)j * 6 + a] = v[a];
+                for (int a = 0; a < 6; ++a) { x[(size_t)j * 6 + a] = v[a]; s_y[a] = v[a]; }
             }
         }
         __syncthreads();
         if (!s_ok) return;
+        const int af = anc_first[j], ta = m - af;                       // block rows beyond the subtree root (a suffix of the column)
         if (act && idx >= 6) {
             double* row = Lvals + (size_t)(c0 + q) * 36 + r * 6;
             double xr[6];
             for (int s = 0; s < 6; ++s) { double v = row[s]; for (int c = 0; c < s; ++c) v -= xr[c] * s_diag[s * 6 + c]; xr[s] = v / s_diag[s * 6 + s]; }
             for (int s = 0; s < 6; ++s) row[s] = xr[s];
+            if (q >= af) for (int s = 0; s < 6; ++s) s_Ljk[(q - af) * 36 + r * 6 + s] = xr[s];       // keep the ancestor rows for the update matrix
+        }
+        __syncthreads();
+        const int ri = broot_of_col[j];
+        if (ri >= 0 && ta > 0) {
+            const int b6 = 6 * broot_b[ri];
+            double* __restrict__ U = ubin + broot_uoff[ri];
+            double* __restrict__ g = U + (size_t)b6 * b6;
+            const int* __restrict__ arel = anc_rel + c0 + af;
+            if ((int)threadIdx.x < 6 * ta) {                            // right-hand side: g[ia] -= L_a y_j
+                const int pa = threadIdx.x / 6, a = threadIdx.x - pa * 6;
+                const double* La = s_Ljk + pa * 36 + a * 6;
+                g[arel[pa] * 6 + a] -= La[0] * s_y[0] + La[1] * s_y[1] + La[2] * s_y[2] + La[3] * s_y[3] + La[4] * s_y[4] + La[5] * s_y[5];
+            }
+            for (int pa = 0; pa < ta; ++pa) {                           // U[ia][ib] -= L_a L_b^T for the block pairs ib <= ia
+                const int ia = arel[pa];
+                for (int e = threadIdx.x; e < 36 * (pa + 1); e += 256) {
+                    const int pb = e / 36, ab = e - 36 * pb, a = ab / 6, b = ab - 6 * a;
+                    const double* La = s_Ljk + pa * 36 + a * 6; const double* Lb = s_Ljk + pb * 36 + b * 6;
+                    U[(size_t)(ia * 6 + a) * b6 + arel[pb] * 6 + b] -= La[0] * Lb[0] + La[1] * Lb[1] + La[2] * Lb[2] + La[3] * Lb[3] + La[4] * Lb[4] + La[5] * Lb[5];
+                }
+            }
         }
         __syncthreads();
         __threadfence_block();
@@ -1124,324 +1176,11 @@ __global__ __launch_bounds__(256) void pg_rpy_kernel(int n, const pose_t* __rest
     o[0] = rpy[0]; o[1] = rpy[1]; o[2] = rpy[2]; o[3] = T.t[0]; o[4] = T.t[1]; o[5] = T.t[2];
 }
 
-// ------------------------------------------------------------------ host: ordering + symbolic analysis
+// ------------------------------------------------------------------ host: device memory of one solve
 namespace {
 
-struct sym_t {
-    int ns = 0;
-    std::vector<int> perm;                 // chain-order separator -> elimination index
-    std::vector<int> colptr, rowidx, rlptr, rlcol, rlpos, rlrow, lvptr, lvcols, diag_pos, ch_pos, lc_pos, binptr, bincols;
-    std::vector<int> pan_first, pan_w, pan_lcol0, plvptr, plvpan, tlim, tfar; // panels of the top part, panel levels
-    std::vector<long long> mapptr;
-};
-
-// host threads of the symbolic phase
 inline int sym_threads() { static const int env = getenv("DSSS_SYM_THREADS") ? atoi(getenv("DSSS_SYM_THREADS")) : 0; if (env > 0) return env;
                           const unsigned hc = std::thread::hardware_concurrency(); return (int)std::min(4u, std::max(1u, hc)); }      // more threads do not help (serial parts dominate) and add scheduling jitter
-template <class F> void par_ranges(int n, int T, F fn)          // fn(t, lo, hi) over T contiguous ranges of [0, n)
-{
-    std::vector<std::thread> th;
-    for (int t = 1; t < T; ++t) th.emplace_back([&, t] { fn(t, (int)((long long)n * t / T), (int)((long long)n * (t + 1) / T)); });
-    fn(0, 0, (int)((long long)n / T));
-    for (auto& x : th) x.join();
-}
-
-// geometric nested dissection: recursive coordinate bisection with vertex separators taken from the lower half.
-// The order of a subtree is [A subtree][B subtree][separator]; A and B never touch, so the first PG_ND_PAR levels run
-// their two halves on two host threads, and the same tree of ranges later drives the parallel column-structure pass.
-struct nd_tree { int a = -1, b = -1, size = 0; };          // children (indices into the node pool) or -1,-1 for a leaf
-#define PG_ND_PAR 4
-struct nd_ctx {
-    const int* adj_ptr; const int* adj_idx; const double* cx; const double* cy; char* side; int leaf;
-    std::vector<nd_tree>* pool; std::mutex* mu;
-};
-int nd_order(std::vector<int>& nodes, const nd_ctx& C, std::vector<int>& order, int depth)
-{
-    auto new_node = [&](int a, int b, int size) { std::lock_guard<std::mutex> g(*C.mu); C.pool->push_back({ a, b, size }); return (int)C.pool->size() - 1; };
-    const int total = (int)nodes.size();
-    if (total <= C.leaf) { std::sort(nodes.begin(), nodes.end()); for (int v : nodes) order.push_back(v); return depth <= PG_ND_PAR ? new_node(-1, -1, total) : -1; }
-    double x0 = 1e300, x1 = -1e300, y0 = 1e300, y1 = -1e300;
-    for (int v : nodes) { x0 = std::min(x0, C.cx[v]); x1 = std::max(x1, C.cx[v]); y0 = std::min(y0, C.cy[v]); y1 = std::max(y1, C.cy[v]); }
-    const bool byx = (x1 - x0) >= (y1 - y0);
-    const size_t half = nodes.size() / 2;
-    // split at the median of the (coordinate, index) total order; only the two halves matter, not their inner order
-    const double* key = byx ? C.cx : C.cy;
-    std::nth_element(nodes.begin(), nodes.begin() + half, nodes.end(), [&](int a, int b) {
-        const double ka = key[a], kb = key[b];
-        return ka != kb ? ka < kb : a < b; });
-    for (size_t i = 0; i < nodes.size(); ++i) C.side[nodes[i]] = i < half ? 1 : 2;
-    std::vector<int> A, B, S;
-    for (size_t i = 0; i < half; ++i) {
-        const int v = nodes[i];
-        bool cut = false;
-        for (int q = C.adj_ptr[v]; q < C.adj_ptr[v + 1]; ++q) if (C.side[C.adj_idx[q]] == 2) { cut = true; break; }
-        (cut ? S : A).push_back(v);
-    }
-    B.assign(nodes.begin() + half, nodes.end());
-    for (int v : nodes) C.side[v] = 0;
-    std::sort(S.begin(), S.end());
-    if (A.empty() || B.empty()) {          // degenerate cut: fall back to index order
-        std::sort(nodes.begin(), nodes.end());
-        for (int v : nodes) order.push_back(v);
-        return depth <= PG_ND_PAR ? new_node(-1, -1, total) : -1;
-    }
-    int na = -1, nb = -1;
-    if (depth < PG_ND_PAR && total > 2048) {
-        std::vector<int> oa;
-        std::thread th([&] { na = nd_order(A, C, oa, depth + 1); });
-        std::vector<int> ob;
-        nb = nd_order(B, C, ob, depth + 1);
-        th.join();
-        order.insert(order.end(), oa.begin(), oa.end());
-        order.insert(order.end(), ob.begin(), ob.end());
-    } else {
-        nd_order(A, C, order, PG_ND_PAR + 1);
-        nd_order(B, C, order, PG_ND_PAR + 1);
-    }
-    for (int v : S) order.push_back(v);
-    return depth <= PG_ND_PAR ? new_node(na, nb, total) : -1;
-}
-
-// column structures of the range [lo, lo + size) of the elimination order described by tree node `t`, children merged
-// into parents (elimination tree built on the fly).  A column whose parent lies outside the range hands the
-// (parent, column) pair up to its caller.  No per-column allocations: the row lists of one call go into that call's pool
-// (cref = pool, offset, length) and the children of a column are a linked list (kid_head / kid_next).
-struct cref { int pool, off, n; };
-struct cs_ctx {
-    const int* adj_ptr; const int* adj_idx; const int* order; const int* perm; const std::vector<nd_tree>* pool;
-    std::vector<std::vector<int>>* pools; cref* cols; int* kid_head; int* kid_next; int* parent;
-};
-void col_structs(const cs_ctx& C, int t, int lo, int size, std::vector<std::pair<int, int>>& up, int depth)
-{
-    const nd_tree nd = t >= 0 ? (*C.pool)[t] : nd_tree();
-    int seq_lo = lo;
-    const int hi = lo + size;
-    auto add_kid = [&](int par, int j) { C.kid_next[j] = C.kid_head[par]; C.kid_head[par] = j; };
-    if (t >= 0 && nd.a >= 0 && nd.b >= 0) {
-        const int sa = (*C.pool)[nd.a].size, sb = (*C.pool)[nd.b].size;
-        std::vector<std::pair<int, int>> ua, ub;
-        std::thread th([&] { col_structs(C, nd.a, lo, sa, ua, depth + 1); });
-        col_structs(C, nd.b, lo + sa, sb, ub, depth + 1);
-        th.join();
-        for (auto* u : { &ua, &ub })
-            for (auto& e : *u) { if (e.first < hi) add_kid(e.first, e.second); else up.push_back(e); }
-        seq_lo = lo + sa + sb;
-    }
-    const int my_pool = t >= 0 ? t : (int)C.pools->size() - 1;
-    std::vector<int>& P = (*C.pools)[my_pool];
-    P.reserve((size_t)(hi - seq_lo) * 24);
-    std::vector<int> c;
-    for (int j = seq_lo; j < hi; ++j) {
-        c.clear();
-        const int v = C.order[j];
-        for (int q = C.adj_ptr[v]; q < C.adj_ptr[v + 1]; ++q) { const int pu = C.perm[C.adj_idx[q]]; if (pu > j) c.push_back(pu); }
-        for (int k = C.kid_head[j]; k >= 0; k = C.kid_next[k]) {
-            const cref ck = C.cols[k]; const int* d = (*C.pools)[ck.pool].data() + ck.off;
-            for (int q = 1; q < ck.n; ++q) if (d[q] != j) c.push_back(d[q]);
-        }
-        std::sort(c.begin(), c.end()); c.erase(std::unique(c.begin(), c.end()), c.end());
-        C.cols[j] = { my_pool, (int)P.size(), (int)c.size() + 1 };
-        P.push_back(j); P.insert(P.end(), c.begin(), c.end());
-        if (!c.empty()) {
-            C.parent[j] = c[0];
-            if (c[0] < hi) add_kid(c[0], j); else up.push_back({ c[0], j });
-        }
-    }
-}
-
-// edges: pairs of chain-order separator indices (chain couplings first, then LC edges)
-void symbolic(int ns, const std::vector<std::pair<int, int>>& edges, int nchain, const std::vector<double>& cx,
-              const std::vector<double>& cy, bool use_nd, sym_t& S)
-{
-    S.ns = ns;
-    const bool tv = getenv("DSSS_PG_VERBOSE") != nullptr;
-    auto tnow = [] { return std::chrono::steady_clock::now(); };
-    auto tms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
-    const auto q0 = tnow();
-    // adjacency in CSR form, rows sorted and deduplicated
-    std::vector<int> adj_ptr(ns + 1, 0), adj_idx;
-    {
-        for (auto& e : edges) if (e.first != e.second) { adj_ptr[e.first + 1]++; adj_ptr[e.second + 1]++; }
-        for (int i = 0; i < ns; ++i) adj_ptr[i + 1] += adj_ptr[i];
-        std::vector<int> raw(adj_ptr[ns]), fill(adj_ptr.begin(), adj_ptr.end() - 1);
-        for (auto& e : edges) if (e.first != e.second) { raw[fill[e.first]++] = e.second; raw[fill[e.second]++] = e.first; }
-        adj_idx.reserve(raw.size());
-        std::vector<int> nptr(ns + 1, 0);
-        for (int i = 0; i < ns; ++i) {
-            int* b0 = raw.data() + adj_ptr[i]; int* e0 = raw.data() + adj_ptr[i + 1];
-            std::sort(b0, e0); e0 = std::unique(b0, e0);
-            adj_idx.insert(adj_idx.end(), b0, e0);
-            nptr[i + 1] = (int)adj_idx.size();
-        }
-        adj_ptr.swap(nptr);
-    }
-    std::vector<int> order; order.reserve(ns);
-    std::vector<nd_tree> pool; std::mutex mu;
-    int root = -1;
-    if (use_nd) {
-        std::vector<int> nodes(ns); std::iota(nodes.begin(), nodes.end(), 0);
-        std::vector<char> side(ns, 0);
-        nd_ctx C{ adj_ptr.data(), adj_idx.data(), cx.data(), cy.data(), side.data(), 24, &pool, &mu };
-        root = nd_order(nodes, C, order, 0);
-    } else { order.resize(ns); std::iota(order.begin(), order.end(), 0); }
-    const auto q1 = tnow();
-    S.perm.assign(ns, 0);
-    for (int i = 0; i < ns; ++i) S.perm[order[i]] = i;
-    std::vector<cref> cols(ns);
-    std::vector<int> parent(ns, -1), kid_head(ns, -1), kid_next(ns, -1);
-    std::vector<std::vector<int>> pools(pool.size() + 1);
-    {
-        cs_ctx C{ adj_ptr.data(), adj_idx.data(), order.data(), S.perm.data(), &pool, &pools, cols.data(), kid_head.data(), kid_next.data(), parent.data() };
-        std::vector<std::pair<int, int>> up;
-        col_structs(C, root, 0, ns, up, 0);
-    }
-    const auto q2 = tnow();
-    S.colptr.assign(ns + 1, 0);
-    for (int j = 0; j < ns; ++j) S.colptr[j + 1] = S.colptr[j] + cols[j].n;
-    auto csz = [&](int j) { return S.colptr[j + 1] - S.colptr[j]; };
-    S.rowidx.resize(S.colptr[ns]);
-    // row lists (transpose of the strictly lower structure), ascending k.  Threads own ascending ranges of SOURCE columns
-    // with private histograms, so the entries of every target list still come out in ascending k.
-    const int T = sym_threads();
-    std::vector<std::vector<int>> hist(T, std::vector<int>(ns, 0));
-    par_ranges(ns, T, [&](int t, int lo, int hi) {
-        std::vector<int>& h = hist[t];
-        for (int k = lo; k < hi; ++k) {
-            const int* d = pools[cols[k].pool].data() + cols[k].off;
-            std::copy(d, d + cols[k].n, S.rowidx.begin() + S.colptr[k]);
-            for (int q = 1; q < cols[k].n; ++q) h[d[q]]++;
-        }
-    });
-    S.rlptr.assign(ns + 1, 0);
-    for (int j = 0; j < ns; ++j) { int tot = 0; for (int t = 0; t < T; ++t) { const int c = hist[t][j]; hist[t][j] = tot; tot += c; } S.rlptr[j + 1] = S.rlptr[j] + tot; }
-    S.rlcol.resize(S.rlptr[ns]); S.rlpos.resize(S.rlptr[ns]); S.rlrow.resize(S.rlptr[ns]);
-    par_ranges(ns, T, [&](int t, int lo, int hi) {
-        std::vector<int>& fill = hist[t];                       // offset of this thread's first entry inside every target list
-        for (int k = lo; k < hi; ++k)
-            for (int q = 1; q < csz(k); ++q) {
-                const int j = S.rowidx[S.colptr[k] + q], at = S.rlptr[j] + fill[j]++;
-                S.rlcol[at] = k; S.rlpos[at] = S.colptr[k] + (int)q; S.rlrow[at] = j;
-            }
-    });
-    S.mapptr.assign(ns + 1, 0);
-    for (int j = 0; j < ns; ++j) S.mapptr[j + 1] = S.mapptr[j] + (long long)(S.rlptr[j + 1] - S.rlptr[j]) * (long long)csz(j);
-    const auto q3 = tnow();
-    // bottom subtrees -> bins (one workgroup each); the remaining "top" columns are level-scheduled
-    std::vector<double> sub_cost(ns, 0);
-    std::vector<char> sub_ok(ns, 0);
-    static const double BIN_COST = getenv("DSSS_PG_BIN_COST") ? atof(getenv("DSSS_PG_BIN_COST")) : 1000;   // ~ update-list iterations + 20 per column; measured optimum at C3 (800-1500): about 0.2 ms of one workgroup
-    for (int j = 0; j < ns; ++j) {
-        const int mj = csz(j), Tj = S.rlptr[j + 1] - S.rlptr[j];
-        double cst = Tj + 20.0; bool ok = mj <= 42;
-        for (int k = kid_head[j]; k >= 0; k = kid_next[k]) { cst += sub_cost[k]; ok = ok && sub_ok[k]; }
-        sub_cost[j] = cst; sub_ok[j] = ok && cst <= BIN_COST;
-    }
-    std::vector<int> root_of(ns, -1);                       // subtree root of every binned column
-    for (int j = ns - 1; j >= 0; --j) {
-        if (!sub_ok[j]) continue;
-        const int par = parent[j];
-        root_of[j] = (par >= 0 && sub_ok[par]) ? root_of[par] : j;
-    }
-    {   // greedy packing of whole subtrees into bins, subtrees taken in ascending root order
-        std::vector<int> roots;
-        for (int j = 0; j < ns; ++j) if (sub_ok[j] && root_of[j] == j) roots.push_back(j);
-        std::vector<int> bin_of_root(ns, -1);
-        int nbins = 0; double fill = BIN_COST + 1;
-        for (int r : roots) { if (fill + sub_cost[r] > BIN_COST) { ++nbins; fill = 0; } fill += sub_cost[r]; bin_of_root[r] = nbins - 1; }
-        S.binptr.assign(nbins + 1, 0);
-        for (int j = 0; j < ns; ++j) if (sub_ok[j]) S.binptr[bin_of_root[root_of[j]] + 1]++;
-        for (int b = 0; b < nbins; ++b) S.binptr[b + 1] += S.binptr[b];
-        S.bincols.resize(S.binptr[nbins]);
-        std::vector<int> fillp(S.binptr.begin(), S.binptr.end() - 1);
-        for (int j = 0; j < ns; ++j) if (sub_ok[j]) S.bincols[fillp[bin_of_root[root_of[j]]]++] = j;     // ascending within a bin
-    }
-    // top part: supernodal panels (consecutive columns with nested structure) and their levels
-    std::vector<int> col_pan(ns, -1);
-    for (int j = 0; j < ns; ++j) {
-        if (sub_ok[j] || col_pan[j] >= 0) continue;
-        int w = 1;
-        while (w < PG_PW && j + w < ns && !sub_ok[j + w] && parent[j + w - 1] == j + w && csz(j + w) + 1 == csz(j + w - 1)) ++w;
-        const int p = (int)S.pan_first.size();
-        S.pan_first.push_back(j); S.pan_w.push_back(w);
-        for (int c = 0; c < w; ++c) col_pan[j + c] = p;
-    }
-    const int npan = (int)S.pan_first.size();
-    std::vector<int> plevel(npan, 0);
-    int maxl = -1;
-    for (int p = 0; p < npan; ++p) {
-        int lv = 0;
-        for (int c = 0; c < S.pan_w[p]; ++c)
-            for (int k = kid_head[S.pan_first[p] + c]; k >= 0; k = kid_next[k]) if (!sub_ok[k] && col_pan[k] != p) lv = std::max(lv, plevel[col_pan[k]] + 1);
-        plevel[p] = lv; maxl = std::max(maxl, lv);
-    }
-    S.plvptr.assign(maxl + 2, 0);
-    for (int p = 0; p < npan; ++p) S.plvptr[plevel[p] + 1]++;
-    for (int l = 0; l <= maxl; ++l) S.plvptr[l + 1] += S.plvptr[l];
-    S.plvpan.resize(npan); S.pan_lcol0.assign(npan, 0);
-    { std::vector<int> fill(S.plvptr.begin(), S.plvptr.end() - 1); for (int p = 0; p < npan; ++p) S.plvpan[fill[plevel[p]]++] = p; }
-    // columns of each panel level, panel by panel (kernel A works on columns); lvptr/lvcols now describe panel levels
-    S.lvptr.assign(maxl + 2, 0); S.lvcols.clear();
-    for (int l = 0; l <= maxl; ++l) {
-        for (int q = S.plvptr[l]; q < S.plvptr[l + 1]; ++q) {
-            const int p = S.plvpan[q];
-            S.pan_lcol0[p] = (int)S.lvcols.size() - S.lvptr[l];
-            for (int c = 0; c < S.pan_w[p]; ++c) S.lvcols.push_back(S.pan_first[p] + c);
-        }
-        S.lvptr[l + 1] = (int)S.lvcols.size();
-    }
-    // external update count per column: rowlist entries (ascending k) that lie before the column's panel
-    S.tlim.assign(ns, 0);
-    for (int j = 0; j < ns; ++j) {
-        const int lim = col_pan[j] >= 0 ? S.pan_first[col_pan[j]] : j;
-        S.tlim[j] = (int)(std::lower_bound(S.rlcol.begin() + S.rlptr[j], S.rlcol.begin() + S.rlptr[j + 1], lim) - (S.rlcol.begin() + S.rlptr[j]));
-    }
-    // look-ahead split of the external updates of every top column (panel level l): "far" sources were finished two
-    // or more levels ago (or in the subtree bins) and are accumulated on a second stream while level l-1 is still
-    // being factorised; "near" sources are the panels of level l-1.  The list is reordered [far | near | own panel].
-    S.tfar.assign(ns, 0);
-    par_ranges(ns, T, [&](int, int lo, int hi) {
-        std::vector<std::pair<int, int>> nearv;
-        for (int j = lo; j < hi; ++j) {
-            if (col_pan[j] < 0) continue;
-            const int lj = plevel[col_pan[j]], b0 = S.rlptr[j], Tn = S.tlim[j];
-            nearv.clear();
-            int wpos = b0;
-            for (int t = b0; t < b0 + Tn; ++t) {
-                const int k = S.rlcol[t];
-                const bool isnear = col_pan[k] >= 0 && plevel[col_pan[k]] == lj - 1;
-                if (isnear) nearv.push_back({ k, S.rlpos[t] });
-                else { S.rlcol[wpos] = k; S.rlpos[wpos] = S.rlpos[t]; ++wpos; }
-            }
-            S.tfar[j] = wpos - b0;
-            for (auto& e : nearv) { S.rlcol[wpos] = e.first; S.rlpos[wpos] = e.second; ++wpos; }
-        }
-    });
-    const auto q4 = tnow();
-    // where the assembled blocks go
-    auto find = [&](int row, int col) { const auto b = S.rowidx.begin() + S.colptr[col], e = S.rowidx.begin() + S.colptr[col + 1];
-                                        return (int)(std::lower_bound(b, e, row) - S.rowidx.begin()); };
-    S.diag_pos.resize(ns);
-    S.ch_pos.assign(std::max(ns - 1, 0), 0);
-    par_ranges(ns, T, [&](int, int lo, int hi) {
-        for (int k = lo; k < hi; ++k) {
-            S.diag_pos[k] = S.colptr[S.perm[k]];
-            if (k + 1 < ns) {
-                const int pa = S.perm[k], pb = S.perm[k + 1];          // block S(k, k+1): rows k, cols k+1
-                S.ch_pos[k] = pa > pb ? (find(pa, pb) << 1) : ((find(pb, pa) << 1) | 1);
-            }
-        }
-    });
-    if (tv) fprintf(stderr, "[dsss pg symbolic] adjacency+ND %.1f ms, column structures %.1f ms, rowlists+map ptrs %.1f ms, bins+panels %.1f ms\n", tms(q0, q1), tms(q1, q2), tms(q2, q3), tms(q3, q4));
-    S.lc_pos.resize(edges.size() - nchain);
-    par_ranges((int)(edges.size() - nchain), T, [&](int, int lo, int hi) {
-        for (int e2 = lo; e2 < hi; ++e2) {
-            const size_t e = (size_t)nchain + e2;
-            const int pa = S.perm[edges[e].first], pb = S.perm[edges[e].second];   // block H(a, b)
-            S.lc_pos[e2] = pa > pb ? (find(pa, pb) << 1) : ((find(pb, pa) << 1) | 1);
-        }
-    });
-    if (tv) fprintf(stderr, "[dsss pg symbolic] positions %.1f ms\n", tms(q4, tnow()));
-}
 
 struct pg_dev {
     // device memory of one solve comes from the context's arena: a few large chunks that stay allocated between solves,
@@ -1545,36 +1284,27 @@ static int pg_solve_impl(dsss_ctx* c, const double* dr6, int total, const dsss_l
     }
     const double t_prep = ms_since(T0);
     const auto T1 = std::chrono::steady_clock::now();
-    sym_t S;
-    symbolic(ns, redges, nseg, cx, cy, true, S);
+    pg_sym S;
+    { pg_sym_opts opt; opt.threads = sym_threads();
+      static const double bin_cost = getenv("DSSS_PG_BIN_COST") ? atof(getenv("DSSS_PG_BIN_COST")) : 1000;   // ~ update-list iterations + 20 per column; measured optimum at C3 (800-1500)
+      opt.bin_cost = bin_cost; pg_sym_opts_env(opt);
+      pg_symbolic(ns, redges, nseg, cx.data(), cy.data(), nullptr, 1, opt, S); }
     const double t_sym = ms_since(T1);
     const auto T2 = std::chrono::steady_clock::now();
-    const int nlev = (int)S.lvptr.size() - 1;
+    const int nlev = S.nlev, nfr = (int)S.f_c0.size(), npan = S.npanels;
     const size_t nnzL = S.rowidx.size();
-    std::vector<int> lv_chunks(nlev, 1), lv_far(nlev, 0), lv_near(nlev, 0), lv_slices(nlev, 1);
-    size_t part2_doubles = 1;
-    for (int l = 0; l < nlev; ++l) {
-        int maxF = 0, maxN = 0;
-        for (int q = S.lvptr[l]; q < S.lvptr[l + 1]; ++q) {
-            const int j = S.lvcols[q];
-            lv_chunks[l] = std::max(lv_chunks[l], (6 * (S.colptr[j + 1] - S.colptr[j]) + 255) / 256);
-            maxF = std::max(maxF, S.tfar[j]); maxN = std::max(maxN, S.tlim[j] - S.tfar[j]);
-        }
-        lv_far[l] = maxF > 0; lv_near[l] = maxN > 0;
-        const int ncl = S.lvptr[l + 1] - S.lvptr[l];
-        // few wide columns near the root: slice their (far) update lists over more workgroups
-        if (ncl <= 256 && maxF > 48) lv_slices[l] = std::min(ncl <= 64 ? 16 : 4, (maxF + 31) / 32);
-        if (lv_slices[l] > 1) part2_doubles = std::max(part2_doubles, (size_t)ncl * lv_slices[l] * ((size_t)lv_chunks[l] * 256 * 6 + 8));
-    }
+    const int nval = (int)S.dest_bin.size();
     const bool verbose = getenv("DSSS_PG_VERBOSE") != nullptr;
-    if (verbose) {
-        int maxcol = 0; for (int j = 0; j < ns; ++j) maxcol = std::max(maxcol, S.colptr[j + 1] - S.colptr[j]);
-        fprintf(stderr, "[dsss pg] poses %d  LC edges %d  separators %d  nnz(L) blocks %zu  etree levels %d  max column %d blocks  update map %lld  bins %d (%d cols)  panels %d\n", n, ne, ns, nnzL, nlev, maxcol, S.mapptr[ns], (int)S.binptr.size() - 1, (int)S.bincols.size(), (int)S.pan_first.size());
-    }
+    if (verbose)
+        fprintf(stderr, "[dsss pg] poses %d  LC edges %d  separators %d  nnz(L) blocks %zu  bins %d (%d cols)  fronts %d (largest %d block rows, arena %.0f MB)  panels %d in %d levels\n",
+                n, ne, ns, nnzL, (int)S.binptr.size() - 1, (int)S.bincols.size(), nfr, S.max_front_n, S.front_doubles * 8e-6, npan, nlev);
 
     pose_t *d_X, *d_Xn, *d_meas, *d_emeas; int *d_ea, *d_eb, *d_adj_ptr, *d_adj_edge, *d_perm;
-    double *d_ew, *d_r, *d_Ji, *d_D, *d_C, *d_g, *d_delta, *d_E, *d_Dl, *d_gi, *d_sDL, *d_sDR, *d_sGL, *d_sGR, *d_sS, *d_L, *d_x, *d_part, *d_scal, *d_part2;
-    int *d_colptr, *d_rowidx, *d_rlptr, *d_rlcol, *d_rlpos, *d_rlrow, *d_binptr, *d_bincols, *d_pan_first, *d_pan_w, *d_pan_lcol0, *d_plvpan, *d_tlim, *d_lvcols, *d_diag, *d_ch, *d_lc, *d_fail, *d_map; long long* d_mapptr;
+    double *d_ew, *d_r, *d_Ji, *d_D, *d_C, *d_g, *d_delta, *d_E, *d_Dl, *d_gi, *d_sDL, *d_sDR, *d_sGL, *d_sGR, *d_sS, *d_L, *d_x, *d_part, *d_scal;
+    double *d_F, *d_R, *d_ubin, *d_aval, *d_Wsw, *d_Wrow, *d_Uvec;
+    int *d_colptr, *d_rowidx, *d_rlptr, *d_rlcol, *d_rlpos, *d_rlrow, *d_binptr, *d_bincols, *d_dest, *d_fail, *d_map; long long* d_mapptr;
+    int *d_binroot_ptr, *d_binroot_idx, *d_broot_b, *d_broot_of_col, *d_anc_first, *d_anc_rel, *d_rel, *d_fa_src, *d_fa_row, *d_fa_col, *d_fa_tr, *d_frows, *d_lv_front, *d_lv_step, *d_asm_front;
+    long long* d_broot_uoff; pg_front* d_FD; pg_child* d_CH;
     const int nf = n + ne, nblk = (nf + 255) / 256;
     TRY(dv.alloc(c, &d_X, n)); TRY(dv.alloc(c, &d_Xn, n)); TRY(dv.alloc(c, &d_meas, n)); TRY(dv.upload(c, &d_emeas, emeas));
     TRY(dv.upload(c, &d_ea, ea)); TRY(dv.upload(c, &d_eb, eb)); TRY(dv.upload(c, &d_ew, ew));
@@ -1585,48 +1315,60 @@ static int pg_solve_impl(dsss_ctx* c, const double* dr6, int total, const dsss_l
     TRY(dv.alloc(c, &d_sDL, (size_t)nseg * 36)); TRY(dv.alloc(c, &d_sDR, (size_t)nseg * 36)); TRY(dv.alloc(c, &d_sGL, (size_t)nseg * 6));
     TRY(dv.alloc(c, &d_sGR, (size_t)nseg * 6)); TRY(dv.alloc(c, &d_sS, (size_t)nseg * 36));
     TRY(dv.alloc(c, &d_L, nnzL * 36)); TRY(dv.alloc(c, &d_x, (size_t)ns * 6)); TRY(dv.alloc(c, &d_part, (size_t)nblk)); TRY(dv.alloc(c, &d_scal, 8)); TRY(dv.alloc(c, &d_fail, 1));
+    TRY(dv.alloc(c, &d_F, (size_t)S.front_doubles)); TRY(dv.alloc(c, &d_R, (size_t)S.frhs_doubles)); TRY(dv.alloc(c, &d_ubin, (size_t)S.ubin_doubles));
+    TRY(dv.alloc(c, &d_aval, (size_t)nval * 36));
     TRY(dv.upload(c, &d_colptr, S.colptr)); TRY(dv.upload(c, &d_rowidx, S.rowidx)); TRY(dv.upload(c, &d_rlptr, S.rlptr)); TRY(dv.upload(c, &d_rlcol, S.rlcol));
-    TRY(dv.upload(c, &d_rlpos, S.rlpos)); TRY(dv.upload(c, &d_lvcols, S.lvcols)); TRY(dv.upload(c, &d_diag, S.diag_pos)); TRY(dv.upload(c, &d_ch, S.ch_pos)); TRY(dv.upload(c, &d_lc, S.lc_pos));
-    TRY(dv.upload(c, &d_rlrow, S.rlrow)); TRY(dv.upload(c, &d_mapptr, S.mapptr)); TRY(dv.upload(c, &d_binptr, S.binptr)); TRY(dv.upload(c, &d_bincols, S.bincols));
+    TRY(dv.upload(c, &d_rlpos, S.rlpos)); TRY(dv.upload(c, &d_rlrow, S.rlrow)); TRY(dv.upload(c, &d_mapptr, S.mapptr)); TRY(dv.upload(c, &d_binptr, S.binptr)); TRY(dv.upload(c, &d_bincols, S.bincols));
+    TRY(dv.upload(c, &d_dest, S.dest_bin));
+    TRY(dv.upload(c, &d_binroot_ptr, S.binroot_ptr)); TRY(dv.upload(c, &d_binroot_idx, S.binroot_idx)); TRY(dv.upload(c, &d_broot_b, S.broot_b)); TRY(dv.upload(c, &d_broot_uoff, S.broot_uoff));
+    TRY(dv.upload(c, &d_broot_of_col, S.broot_of_col)); TRY(dv.upload(c, &d_anc_first, S.anc_first)); TRY(dv.upload(c, &d_anc_rel, S.anc_rel));
+    TRY(dv.upload(c, &d_rel, S.rel)); TRY(dv.upload(c, &d_fa_src, S.fa_src)); TRY(dv.upload(c, &d_fa_row, S.fa_row)); TRY(dv.upload(c, &d_fa_col, S.fa_col)); TRY(dv.upload(c, &d_fa_tr, S.fa_tr));
+    TRY(dv.upload(c, &d_frows, S.f_rows)); TRY(dv.upload(c, &d_lv_front, S.lv_front)); TRY(dv.upload(c, &d_lv_step, S.lv_step)); TRY(dv.upload(c, &d_asm_front, S.asm_front));
     const int nbins = (int)S.binptr.size() - 1;
-    TRY(dv.upload(c, &d_pan_first, S.pan_first)); TRY(dv.upload(c, &d_pan_w, S.pan_w)); TRY(dv.upload(c, &d_pan_lcol0, S.pan_lcol0)); TRY(dv.upload(c, &d_plvpan, S.plvpan)); TRY(dv.upload(c, &d_tlim, S.tlim));
-    std::vector<int> plv_n(nlev, 6), plv_rowchunks(nlev, 0);
-    std::vector<double> fl_acc(nlev, 0), fl_diag(nlev, 0), fl_trsm(nlev, 0), fl_bwd(nlev, 0);
-    for (int l = 0; l < nlev; ++l) {
-        for (int q = S.lvptr[l]; q < S.lvptr[l + 1]; ++q) {
-            const int j = S.lvcols[q];
-            for (int t = 0; t < S.tlim[j]; ++t) { const int k = S.rlcol[S.rlptr[j] + t]; fl_acc[l] += 432.0 * (S.colptr[k + 1] - S.rlpos[S.rlptr[j] + t]); }
+    {   // front and child descriptors (the children point straight at the update matrices: F22 of a front, U of a bin root)
+        std::vector<pg_front> FD(nfr); std::vector<pg_child> CH(S.ch_kind.size());
+        for (int f = 0; f < nfr; ++f) {
+            pg_front& d = FD[f];
+            d.off = S.f_off[f]; d.roff = S.f_roff[f]; d.ld = S.f_ld[f]; d.n6 = 6 * S.f_n[f]; d.s6 = 6 * S.f_s[f]; d.c0 = S.f_c0[f];
+            d.rowptr = S.f_rowptr[f]; d.pan0 = S.f_pan0[f]; d.ch0 = S.ch_ptr[f]; d.ch1 = S.ch_ptr[f + 1]; d.fa0 = S.fa_ptr[f]; d.fa1 = S.fa_ptr[f + 1];
         }
-        for (int q = S.plvptr[l]; q < S.plvptr[l + 1]; ++q) {
-            const int p = S.plvpan[q], j0 = S.pan_first[p], w = S.pan_w[p]; const double nn = 6.0 * w, rows = 6.0 * (S.colptr[j0 + 1] - S.colptr[j0] - w);
-            fl_diag[l] += nn * nn * nn / 3.0 + nn * nn; fl_trsm[l] += rows * nn * nn; fl_bwd[l] += 2.0 * rows * nn + nn * nn;
+        for (size_t q = 0; q < CH.size(); ++q) {
+            pg_child& d = CH[q]; d.relptr = S.ch_relptr[q];
+            if (S.ch_kind[q]) { const int ri = S.ch_id[q]; d.cb = S.broot_b[ri]; d.cld = 6 * d.cb; d.U = d_ubin + S.broot_uoff[ri]; d.g = d.U + (size_t)d.cld * d.cld; }
+            else { const int gf = S.ch_id[q]; d.cb = S.f_n[gf] - S.f_s[gf]; d.cld = S.f_ld[gf]; d.U = d_F + S.f_off[gf] + (size_t)(6 * S.f_s[gf]) * d.cld + 6 * S.f_s[gf]; d.g = d_R + S.f_roff[gf] + 6 * S.f_s[gf]; }
+        }
+        TRY(dv.upload(c, &d_FD, FD)); TRY(dv.upload(c, &d_CH, CH));
+    }
+    // launch shapes and algorithmic flops of every level
+    std::vector<int> lv_asm_chunks(nlev, 0), lv_trsm_chunks(nlev, 0), lv_syrk_tiles(nlev, 0);
+    std::vector<double> fl_syrk(nlev, 0), fl_diag(nlev, 0), fl_trsm(nlev, 0), fl_bwd(nlev, 0);
+    int max_n6 = 6;
+    for (int l = 0; l < nlev; ++l) {
+        for (int q = S.asm_ptr[l]; q < S.asm_ptr[l + 1]; ++q) lv_asm_chunks[l] = std::max(lv_asm_chunks[l], (S.f_n[S.asm_front[q]] + PG_ASM_RB - 1) / PG_ASM_RB);
+        for (int q = S.lv_ptr[l]; q < S.lv_ptr[l + 1]; ++q) {
+            const int f = S.lv_front[q], k = S.lv_step[q], n6 = 6 * S.f_n[f], s6 = 6 * S.f_s[f];
+            const int w6 = std::min(96, s6 - 96 * k), nrows = n6 - 96 * k - w6, nt = (nrows + 63) / 64;
+            max_n6 = std::max(max_n6, n6);
+            lv_trsm_chunks[l] = std::max(lv_trsm_chunks[l], (nrows + 63) / 64);
+            lv_syrk_tiles[l] = std::max(lv_syrk_tiles[l], nt * (nt + 1) / 2);
+            const double nn = w6, rows = nrows;
+            fl_diag[l] += nn * nn * nn / 3.0 + nn * nn; fl_trsm[l] += rows * nn * nn; fl_bwd[l] += 2.0 * rows * nn + nn * nn; fl_syrk[l] += rows * (rows + 1) * nn;
         }
     }
-    for (int l = 0; l < nlev; ++l)
-        for (int q = S.plvptr[l]; q < S.plvptr[l + 1]; ++q) {
-            const int p = S.plvpan[q], j0 = S.pan_first[p], w = S.pan_w[p];
-            plv_n[l] = std::max(plv_n[l], 6 * w);
-            plv_rowchunks[l] = std::max(plv_rowchunks[l], (6 * (S.colptr[j0 + 1] - S.colptr[j0] - w) + 63) / 64);
-        }
     const long long mapsz = S.mapptr[ns];
     if (mapsz > (1LL << 31)) { dv.release(); DSSS_FAIL(c, DSSS_E_CAPACITY, "update map of %lld entries", mapsz); }
-    TRY(dv.alloc(c, &d_map, (size_t)mapsz)); TRY(dv.alloc(c, &d_part2, 2 * part2_doubles));
-    int* d_tfar; TRY(dv.upload(c, &d_tfar, S.tfar));
-    double *d_Wsw, *d_Wrow;      // per panel: W = L11^-1 (96 x 96, zero padded) in MFMA operand order and row-major
-    { const size_t npan = S.pan_first.size(); const size_t wn = npan * (PG_PW * 6) * (PG_PW * 6); TRY(dv.alloc(c, &d_Wsw, wn)); TRY(dv.alloc(c, &d_Wrow, wn));
+    TRY(dv.alloc(c, &d_map, (size_t)mapsz));
+    // per panel: W = L11^-1 (96 x 96, zero padded) in MFMA operand order and row-major, u = W^T y
+    { const size_t wn = (size_t)std::max(npan, 1) * (PG_PW * 6) * (PG_PW * 6); TRY(dv.alloc(c, &d_Wsw, wn)); TRY(dv.alloc(c, &d_Wrow, wn)); TRY(dv.alloc(c, &d_Uvec, (size_t)std::max(npan, 1) * (PG_PW * 6)));
       HIPCHK(c, hipMemsetAsync(d_Wsw, 0, wn * sizeof(double), c->stream)); HIPCHK(c, hipMemsetAsync(d_Wrow, 0, wn * sizeof(double), c->stream)); }
-    {   // pg_panel_diag_kernel keeps the packed L11 and W blocks (2 x 39 KB) in dynamic LDS
-        static bool once = false;
-        if (!once) {
-            hipFuncSetAttribute((const void*)pg_panel_diag_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, PG_DIAG_LDS);
-            hipFuncSetAttribute((const void*)pg_panel_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, PG_BWD_LDS);
-            (void)hipGetLastError();
-            once = true;
-        }
+    const int bwd_lds = PG_BWD_LDS(max_n6);
+    if (bwd_lds > 160 * 1024) { dv.release(); DSSS_FAIL(c, DSSS_E_CAPACITY, "front of %d scalar rows: back-substitution needs %d B of LDS", max_n6, bwd_lds); }
+    {   // pg_front_diag_kernel keeps the panel and its inverse (2 x 75 KB) in dynamic LDS, pg_front_bwd_kernel W and x2
+        hipFuncSetAttribute((const void*)pg_front_diag_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, PG_DIAG_LDS);
+        hipFuncSetAttribute((const void*)pg_front_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipGetLastError();
     }
     hipStream_t st = c->stream;
-    const bool no_ahead = getenv("DSSS_PG_NO_LOOKAHEAD") != nullptr;
-    hipEvent_t ev_bins = dv.event(), ev_far[2] = { dv.event(), dv.event() }, ev_trsm[2] = { dv.event(), dv.event() };
 #define HCK(x) do { hipError_t _e = (x); if (_e != hipSuccess) { c->err = std::string(#x) + ": " + hipGetErrorString(_e); dv.release(); return DSSS_E_HIP; } } while (0)
     auto error_of = [&](const pose_t* Xd, double* out) -> int {
         hipLaunchKernelGGL(pg_linearize_kernel, dim3(nblk), dim3(256), 0, st, n, ne, Xd, d_meas, W, d_ea, d_eb, d_emeas, d_ew, (double*)nullptr, (double*)nullptr, d_part);
@@ -1679,57 +1421,37 @@ static int pg_solve_impl(dsss_ctx* c, const double* dr6, int total, const dsss_l
         for (;;) {
             // ---- solve (H + lambda I) delta = -g ; lambda lives in device memory
             HCK(hipMemcpyAsync(d_scal + 3, &lambda, sizeof(double), hipMemcpyHostToDevice, st));
-            {   // (a hipGraph of this sequence costs more to instantiate than the 5 replays of one solve save: measured)
+            {
                 hipMemsetAsync(d_fail, 0, sizeof(int), st);
                 hipMemsetAsync(d_L, 0, nnzL * 36 * sizeof(double), st);
                 hipLaunchKernelGGL(pg_assemble_kernel, dim3((n + 255) / 256), dim3(256), 0, st, n, W, d_r, d_Ji, d_adj_ptr, d_adj_edge, d_ew, d_scal + 3, d_D, d_C, d_g);
                 hipLaunchKernelGGL(pg_segment_kernel, dim3((nseg + 63) / 64), dim3(64), 0, st, nseg, d_sep, d_D, d_C, d_g, d_E, d_Dl, d_gi, d_sDL, d_sDR, d_sGL, d_sGR, d_sS, d_fail);
-                hipLaunchKernelGGL(pg_scatter_base_kernel, dim3((ns + 255) / 256), dim3(256), 0, st, ns, d_sep, d_perm, d_D, d_g, d_sDL, d_sDR, d_sGL, d_sGR, d_sS, d_diag, d_ch, d_L, d_x);
-                if (ne > 0) hipLaunchKernelGGL(pg_scatter_lc_kernel, dim3((ne + 255) / 256), dim3(256), 0, st, n, ne, d_Ji, d_ew, d_lc, d_L);
+                hipLaunchKernelGGL(pg_scatter_base_kernel, dim3((ns + 255) / 256), dim3(256), 0, st, ns, d_sep, d_perm, d_D, d_g, d_sDL, d_sDR, d_sGL, d_sGR, d_sS, d_dest, d_L, d_aval, d_x);
+                if (ne > 0) hipLaunchKernelGGL(pg_scatter_lc_kernel, dim3((ne + 255) / 256), dim3(256), 0, st, n, ne, ns, d_Ji, d_ew, d_dest, d_L, d_aval);
                 if (nbins > 0) { dsss_scope s1(c, DSSS_K_PG_SUBTREE);
-                                 hipLaunchKernelGGL(pg_factor_subtree_kernel, dim3(nbins), dim3(256), 0, st, d_binptr, d_bincols, d_colptr, d_rlptr, d_rlcol, d_rlpos, d_mapptr, d_map, d_L, d_x, d_fail); }
-                // top of the tree: panel levels, forward substitution fused in.  Look-ahead: the far updates of level l
-                // (sources finished by level l-2) run on the side stream while level l-1 is being factorised; the
-                // main stream adds the near updates (level l-1) once its row solve is done.  Partial-sum buffers alternate.
-                const bool ahead = !c->prof.on && !no_ahead;
-                hipStream_t sf = ahead ? c->xs[0] : st;
-                auto launch_far = [&](int l) {
-                    if (!lv_far[l]) return;
-                    const int ncl = S.lvptr[l + 1] - S.lvptr[l], stride = lv_chunks[l] * 256 * 6 + 8;
-                    if (ahead) hipStreamWaitEvent(sf, l >= 2 ? ev_trsm[(l - 2) & 1] : ev_bins, 0);
-                    hipLaunchKernelGGL(pg_factor_acc_kernel, dim3(ncl, lv_chunks[l], lv_slices[l]), dim3(256), 0, sf, d_lvcols + S.lvptr[l], d_colptr, d_rlptr, d_rlpos,
-                                       d_mapptr, d_map, d_L, d_part2 + (size_t)(l & 1) * part2_doubles, stride, d_rlcol, d_x, (const int*)nullptr, d_tfar, (const double*)nullptr, 0);
-                    if (ahead) hipEventRecord(ev_far[l & 1], sf);
-                };
-                if (ahead && nlev > 0) { hipEventRecord(ev_bins, st); launch_far(0); if (nlev > 1) launch_far(1); }
+                                 hipLaunchKernelGGL(pg_factor_subtree_kernel, dim3(nbins), dim3(256), 0, st, d_binptr, d_bincols, d_colptr, d_rlptr, d_rlcol, d_rlpos, d_mapptr, d_map, d_L, d_x, d_fail,
+                                                    d_binroot_ptr, d_binroot_idx, d_broot_b, d_broot_uoff, d_broot_of_col, d_anc_first, d_anc_rel, d_ubin); }
+                // fronts, level by level: assemble the fronts that start here, then one panel step of every active front
                 for (int l = 0; l < nlev; ++l) {
-                    const int ncl = S.lvptr[l + 1] - S.lvptr[l], npl = S.plvptr[l + 1] - S.plvptr[l];
-                    const int stride = lv_chunks[l] * 256 * 6 + 8;
-                    const int nsl = lv_far[l] ? lv_slices[l] : 1;
-                    {   dsss_scope s2(c, DSSS_K_PG_ACC, fl_acc[l], (lv_far[l] ? 1 : 0) + (lv_near[l] ? 1 : 0));
-                        if (!ahead) launch_far(l);
-                        else if (lv_far[l]) hipStreamWaitEvent(st, ev_far[l & 1], 0);
-                        // near updates in place; the same launch folds the far slices of this level (pg_fold_kernel only
-                        // runs when a level has far slices but no near updates at all)
-                        if (lv_near[l])
-                            hipLaunchKernelGGL(pg_factor_acc_kernel, dim3(ncl, lv_chunks[l], 1), dim3(256), 0, st, d_lvcols + S.lvptr[l], d_colptr, d_rlptr, d_rlpos,
-                                               d_mapptr, d_map, d_L, d_part2, stride, d_rlcol, d_x, d_tfar, d_tlim,
-                                               (const double*)(d_part2 + (size_t)(l & 1) * part2_doubles), nsl > 1 ? nsl : 0);
-                    }
-                    if (nsl > 1 && !lv_near[l]) hipLaunchKernelGGL(pg_fold_kernel, dim3(ncl, lv_chunks[l]), dim3(256), 0, st, d_lvcols + S.lvptr[l], d_colptr, d_L, d_part2 + (size_t)(l & 1) * part2_doubles, nsl, stride, d_x);
+                    const int nas = S.asm_ptr[l + 1] - S.asm_ptr[l], nit = S.lv_ptr[l + 1] - S.lv_ptr[l];
+                    const int* itf = d_lv_front + S.lv_ptr[l]; const int* its = d_lv_step + S.lv_ptr[l];
+                    if (nas > 0) { dsss_scope s2(c, DSSS_K_PG_ASM);
+                        hipLaunchKernelGGL(pg_front_asm_kernel, dim3(nas, lv_asm_chunks[l]), dim3(256), 0, st, d_asm_front + S.asm_ptr[l], d_FD, d_CH, d_rel, d_fa_src, d_fa_row, d_fa_col, d_fa_tr,
+                                           d_aval, d_x, d_F, d_R); }
                     { dsss_scope s3(c, DSSS_K_PG_DIAG, fl_diag[l]);
-                      hipLaunchKernelGGL(pg_panel_diag_kernel, dim3(npl), dim3(256), PG_DIAG_LDS, st, d_plvpan + S.plvptr[l], d_pan_first, d_pan_w, d_colptr, d_L, d_x, d_fail, d_Wsw, d_Wrow); }
-                    {   dsss_scope s4(c, DSSS_K_PG_TRSM, plv_rowchunks[l] > 0 ? fl_trsm[l] : 0.0);
-                        if (plv_rowchunks[l] > 0)
-                            hipLaunchKernelGGL(pg_panel_trsm_kernel, dim3(npl, plv_rowchunks[l]), dim3(256), 0, st, d_plvpan + S.plvptr[l], d_pan_first, d_pan_w, d_colptr, d_L, d_Wsw);
+                      hipLaunchKernelGGL(pg_front_diag_kernel, dim3(nit), dim3(256), PG_DIAG_LDS, st, itf, its, d_FD, d_F, d_R, d_fail, d_Wsw, d_Wrow, d_Uvec); }
+                    if (lv_trsm_chunks[l] > 0) {
+                        { dsss_scope s4(c, DSSS_K_PG_TRSM, fl_trsm[l]);
+                          hipLaunchKernelGGL(pg_front_trsm_kernel, dim3(nit, lv_trsm_chunks[l]), dim3(256), 0, st, itf, its, d_FD, d_F, d_R, d_Wsw, d_Uvec); }
+                        { dsss_scope s5(c, DSSS_K_PG_ACC, fl_syrk[l]);
+                          hipLaunchKernelGGL(pg_front_syrk_kernel, dim3(nit, lv_syrk_tiles[l]), dim3(256), 0, st, itf, its, d_FD, d_F); }
                     }
-                    if (ahead && l + 2 < nlev) { hipEventRecord(ev_trsm[l & 1], st); launch_far(l + 2); }
                 }
                 for (int l = nlev - 1; l >= 0; --l) {
-                    dsss_scope s5(c, DSSS_K_PG_BWD, fl_bwd[l]);
-                    hipLaunchKernelGGL(pg_panel_bwd_kernel, dim3(S.plvptr[l + 1] - S.plvptr[l]), dim3(1024), PG_BWD_LDS, st, d_plvpan + S.plvptr[l], d_pan_first, d_pan_w, d_colptr, d_rowidx, d_L, d_x, d_Wrow);
+                    dsss_scope s6(c, DSSS_K_PG_BWD, fl_bwd[l]);
+                    hipLaunchKernelGGL(pg_front_bwd_kernel, dim3(S.lv_ptr[l + 1] - S.lv_ptr[l]), dim3(1024), bwd_lds, st, d_lv_front + S.lv_ptr[l], d_lv_step + S.lv_ptr[l], d_FD, d_frows, d_F, d_R, d_x, d_Wrow);
                 }
-                if (nbins > 0) { dsss_scope s6(c, DSSS_K_PG_SUBTREE);
+                if (nbins > 0) { dsss_scope s7(c, DSSS_K_PG_SUBTREE);
                     hipLaunchKernelGGL(pg_bwd_subtree_kernel, dim3(nbins), dim3(64), 0, st, d_binptr, d_bincols, d_colptr, d_rowidx, d_L, d_x); }
                 hipLaunchKernelGGL(pg_sep_delta_kernel, dim3((ns + 255) / 256), dim3(256), 0, st, ns, d_sep, d_perm, d_x, d_delta);
                 hipLaunchKernelGGL(pg_backsub_kernel, dim3((nseg + 63) / 64), dim3(64), 0, st, nseg, d_sep, d_C, d_E, d_Dl, d_gi, d_delta);

@@ -176,11 +176,12 @@ int dsss_host_pg_solve(int ns, const int32_t* edge_a, const int32_t* edge_b, int
 #define DSSS_K_LC          11   /* lc_kernel */
 #define DSSS_K_PG          12   /* pose-graph LM loop (all its kernels) */
 #define DSSS_K_QUADTREE    13   /* quadtree_kernel + collect (K4 on the device) */
-#define DSSS_K_PG_ACC      14   /* pg_factor_acc_kernel (external block updates of the panels) */
-#define DSSS_K_PG_DIAG     15   /* pg_panel_diag_kernel */
-#define DSSS_K_PG_TRSM     16   /* pg_panel_trsm_kernel */
-#define DSSS_K_PG_BWD      17   /* pg_panel_bwd_kernel */
+#define DSSS_K_PG_ACC      14   /* pg_front_syrk_kernel (trailing update of the fronts: the bulk of the factorisation flops) */
+#define DSSS_K_PG_DIAG     15   /* pg_front_diag_kernel */
+#define DSSS_K_PG_TRSM     16   /* pg_front_trsm_kernel */
+#define DSSS_K_PG_BWD      17   /* pg_front_bwd_kernel */
 #define DSSS_K_PG_SUBTREE  18   /* pg_factor_subtree_kernel + pg_bwd_subtree_kernel */
+#define DSSS_K_PG_ASM      19   /* pg_front_asm_kernel (extend-add) */
 #define DSSS_K_COUNT       20
 int dsss_profile_enable(dsss_ctx*, int on);
 int dsss_profile_get(dsss_ctx*, double* ms_host /*DSSS_K_COUNT*/, int64_t* launches_host /*DSSS_K_COUNT*/);
