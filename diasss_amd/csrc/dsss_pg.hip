@@ -398,61 +398,52 @@ struct pg_front {
 };
 struct pg_child { const double* U; const double* g; long long relptr; int cld, cb; };
 
-#define PG_ASM_RB 8                                // parent block rows owned by one workgroup of the assembly
-__device__ inline int pg_lower_bound(const int* __restrict__ a, int n, int v)
+// one workgroup per (front, block row R): zero the row up to its diagonal block, add the original entries of the row, then
+// the child rows that map onto it, children in their fixed order (the list of contributing (child, row) pairs comes from the
+// host: no searching on the device).  A thread owns a column of the child row and moves its six scalars at once.
+__global__ __launch_bounds__(256) void pg_front_asm_kernel(const int* __restrict__ it_front, const int* __restrict__ it_row, const pg_front* __restrict__ FD,
+                                                           const pg_child* __restrict__ CH, const int* __restrict__ rel, const int* __restrict__ xr_ptr,
+                                                           const int* __restrict__ xr_child, const int* __restrict__ xr_row, const int* __restrict__ fa_rowptr,
+                                                           const int* __restrict__ fa_src, const int* __restrict__ fa_col, const int* __restrict__ fa_tr,
+                                                           const double* __restrict__ aval, const double* __restrict__ x, double* __restrict__ F, double* __restrict__ R)
 {
-    int lo = 0, hi = n;
-    while (lo < hi) { const int mid = (lo + hi) >> 1; if (a[mid] < v) lo = mid + 1; else hi = mid; }
-    return lo;
-}
-__global__ __launch_bounds__(256) void pg_front_asm_kernel(const int* __restrict__ fronts, const pg_front* __restrict__ FD, const pg_child* __restrict__ CH,
-                                                           const int* __restrict__ rel, const int* __restrict__ fa_src, const int* __restrict__ fa_row,
-                                                           const int* __restrict__ fa_col, const int* __restrict__ fa_tr, const double* __restrict__ aval,
-                                                           const double* __restrict__ x, double* __restrict__ F, double* __restrict__ R)
-{
-    const pg_front fd = FD[fronts[blockIdx.x]];
-    const int nb = fd.n6 / 6, R0 = (int)blockIdx.y * PG_ASM_RB;
-    if (R0 >= nb) return;
-    const int R1 = min(nb, R0 + PG_ASM_RB), ld = fd.ld;
-    double* __restrict__ A = F + fd.off; double* __restrict__ r = R + fd.roff;
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    // 1. zero the owned rows up to and including their diagonal block; right-hand side of the own columns
-    for (int row = 6 * R0 + wave; row < 6 * R1; row += 4) {
-        const int ncol = 6 * (row / 6 + 1);
-        for (int c2 = lane; c2 < ncol; c2 += 64) A[(size_t)row * ld + c2] = 0.0;
+    const pg_front fd = FD[it_front[blockIdx.x]];
+    const int Rb = it_row[blockIdx.x], ld = fd.ld;
+    double* __restrict__ A = F + fd.off + (size_t)(6 * Rb) * ld; double* __restrict__ r = R + fd.roff + 6 * Rb;
+    const int ncol = 6 * (Rb + 1);
+    for (int cc = threadIdx.x; cc < ncol; cc += 256) {
+#pragma unroll
+        for (int a = 0; a < 6; ++a) A[(size_t)a * ld + cc] = 0.0;
     }
-    for (int i = 6 * R0 + (int)threadIdx.x; i < 6 * R1; i += 256) r[i] = i < fd.s6 ? x[(size_t)fd.c0 * 6 + i] : 0.0;
+    if (threadIdx.x < 6) { const int i = 6 * Rb + threadIdx.x; r[threadIdx.x] = i < fd.s6 ? x[(size_t)fd.c0 * 6 + i] : 0.0; }
     __syncthreads();
-    // 2. original entries of the owned rows; entries with the same destination block (an LC edge on top of a chain coupling)
-    //    are consecutive in the list and are summed by one thread group in list order
-    {
-        const int lo = fd.fa0 + pg_lower_bound(fa_row + fd.fa0, fd.fa1 - fd.fa0, R0), hi = fd.fa0 + pg_lower_bound(fa_row + fd.fa0, fd.fa1 - fd.fa0, R1);
+    {   // original entries; entries with the same destination block are consecutive and are summed by one thread group in list order
+        const int lo = fa_rowptr[fd.rowptr + Rb], hi = fa_rowptr[fd.rowptr + Rb + 1];
         const int grp = threadIdx.x / 36, el = threadIdx.x % 36;
         if (grp < 7)
             for (int e = lo + grp; e < hi; e += 7) {
-                if (e > lo && fa_row[e - 1] == fa_row[e] && fa_col[e - 1] == fa_col[e]) continue;      // not the head of its run
+                if (e > lo && fa_col[e - 1] == fa_col[e]) continue;      // not the head of its run
                 const int a = el / 6, b = el % 6;
                 double v = 0;
-                for (int e2 = e; e2 < hi && fa_row[e2] == fa_row[e] && fa_col[e2] == fa_col[e]; ++e2)
-                    v += aval[(size_t)fa_src[e2] * 36 + (fa_tr[e2] ? b * 6 + a : a * 6 + b)];
-                A[(size_t)(fa_row[e] * 6 + a) * ld + fa_col[e] * 6 + b] += v;
+                for (int e2 = e; e2 < hi && fa_col[e2] == fa_col[e]; ++e2) v += aval[(size_t)fa_src[e2] * 36 + (fa_tr[e2] ? b * 6 + a : a * 6 + b)];
+                A[(size_t)a * ld + fa_col[e] * 6 + b] += v;
             }
     }
     __syncthreads();
-    // 3. extend-add of the children, one after the other
-    for (int c = fd.ch0; c < fd.ch1; ++c) {
-        const pg_child cd = CH[c];
+    for (int q = xr_ptr[fd.rowptr + Rb]; q < xr_ptr[fd.rowptr + Rb + 1]; ++q) {
+        const pg_child cd = CH[xr_child[q]];
+        const int i = xr_row[q], wcols = 6 * (i + 1);
         const int* __restrict__ rl = rel + cd.relptr;
-        const int i0 = pg_lower_bound(rl, cd.cb, R0), i1 = pg_lower_bound(rl, cd.cb, R1);
-        for (int i = i0; i < i1; ++i) {
-            const int pr = rl[i], wcols = 6 * (i + 1);
-            for (int a = wave; a < 6; a += 4) {
-                const double* __restrict__ src = cd.U + (size_t)(6 * i + a) * cd.cld;
-                double* __restrict__ dst = A + (size_t)(6 * pr + a) * ld;
-                for (int cc = lane; cc < wcols; cc += 64) { const int j2 = cc / 6, b = cc - 6 * j2; dst[6 * rl[j2] + b] += src[cc]; }
-            }
-            if (threadIdx.x < 6) r[6 * pr + threadIdx.x] += cd.g[6 * i + threadIdx.x];
+        const double* __restrict__ src = cd.U + (size_t)(6 * i) * cd.cld;
+        for (int cc = threadIdx.x; cc < wcols; cc += 256) {
+            const int j2 = cc / 6, dcol = 6 * rl[j2] + (cc - 6 * j2);
+            double u[6], d[6];
+#pragma unroll
+            for (int a = 0; a < 6; ++a) { u[a] = src[(size_t)a * cd.cld + cc]; d[a] = A[(size_t)a * ld + dcol]; }
+#pragma unroll
+            for (int a = 0; a < 6; ++a) A[(size_t)a * ld + dcol] = d[a] + u[a];
         }
+        if (threadIdx.x < 6) r[threadIdx.x] += cd.g[6 * i + threadIdx.x];
         __syncthreads();
     }
 }
@@ -751,45 +742,60 @@ __global__ __launch_bounds__(256) void pg_front_trsm_kernel(const int* __restric
     }
 }
 
-// A22 -= L21 L21^T on the trailing part of the front (rows and columns beyond the panel): 64 x 64 output tiles of the lower
-// triangle, one wavefront per 16 rows of a tile, K = the panel's 96 columns: 24 v_mfma_f64_16x16x4_f64 per 16 x 16 block.
+// A22 -= L21 L21^T on the trailing part of the front (rows and columns beyond the panel): one workgroup per 64 x 64 tile of
+// the lower triangle (exact tile list from the host), one wavefront per 16 rows of the tile.  The 64 rows of L21 that form the
+// tile's COLUMNS are staged once in LDS (coalesced 16-byte loads, conflict-free row stride) and serve all four wavefronts
+// as MFMA B operands; every wavefront keeps its own 16 x 96 slab of L21 in 24 A-operand registers.  K = the panel's 96
+// columns: 24 v_mfma_f64_16x16x4_f64 per 16 x 16 block.
+#define PG_SYRK_LD 98
 __global__ __launch_bounds__(256) void pg_front_syrk_kernel(const int* __restrict__ it_front, const int* __restrict__ it_step, const pg_front* __restrict__ FD,
-                                                            double* __restrict__ F)
+                                                            const int* __restrict__ tile_item, const int* __restrict__ tile_ij, double* __restrict__ F)
 {
-    const pg_front fd = FD[it_front[blockIdx.x]];
-    const int step = it_step[blockIdx.x], col0 = 96 * step;
+    __shared__ double sB[64 * PG_SYRK_LD];
+    const int item = tile_item[blockIdx.x], ij = tile_ij[blockIdx.x], ti = ij >> 16, tj = ij & 0xffff;
+    const pg_front fd = FD[it_front[item]];
+    const int step = it_step[item], col0 = 96 * step;
     const int n = min(96, fd.s6 - col0), ld = fd.ld;
     const int row0 = col0 + n, nrows = fd.n6 - row0;
-    const int ntile = (nrows + 63) >> 6;
-    const int t = blockIdx.y;
-    if (t >= ntile * (ntile + 1) / 2) return;
-    int ti = (int)((sqrt(8.0 * t + 1.0) - 1.0) * 0.5);
-    while ((ti + 1) * (ti + 2) / 2 <= t) ++ti;
-    while (ti * (ti + 1) / 2 > t) --ti;
-    const int tj = t - ti * (ti + 1) / 2;
     const int wave = threadIdx.x >> 6, l = threadIdx.x & 63;
-    const int i0 = 64 * ti + 16 * wave;
-    if (i0 >= nrows) return;
     double* __restrict__ A = F + fd.off;
-    const int ir = i0 + (l & 15);
-    const double* __restrict__ Ai = A + (size_t)(row0 + min(ir, nrows - 1)) * ld + col0;
-    double a[24];
+    {   // rows 64 tj .. 64 tj + 63 of L21 -> LDS, 48 x 16 bytes per row (ld and col0 are multiples of 16 scalars, rows 16-byte aligned)
+        const double2* __restrict__ src = reinterpret_cast<const double2*>(A + (size_t)(row0 + 64 * tj) * ld + col0);
+        const int ld2 = ld >> 1, n2 = n >> 1, rows_here = min(64, nrows - 64 * tj);
+        double2 v[12];
 #pragma unroll
-    for (int ks = 0; ks < 24; ++ks) { const int k = 4 * ks + (l >> 4); a[ks] = (ir < nrows && k < n) ? -Ai[k] : 0.0; }
+        for (int u = 0; u < 12; ++u) {
+            const int e = threadIdx.x + 256 * u, rr = e / 48, c2 = e - 48 * rr;
+            v[u] = (rr < rows_here && c2 < n2) ? src[(size_t)rr * ld2 + c2] : make_double2(0.0, 0.0);
+        }
+#pragma unroll
+        for (int u = 0; u < 12; ++u) {
+            const int e = threadIdx.x + 256 * u, rr = e / 48, c2 = e - 48 * rr;
+            *reinterpret_cast<double2*>(&sB[rr * PG_SYRK_LD + 2 * c2]) = v[u];
+        }
+    }
+    const int i0 = 64 * ti + 16 * wave;
+    const int ir = i0 + (l & 15);
+    double a[24];
+    {
+        const double* __restrict__ Ai = A + (size_t)(row0 + min(ir, nrows - 1)) * ld + col0;
+#pragma unroll
+        for (int ks = 0; ks < 24; ++ks) { const int k = 4 * ks + (l >> 4); a[ks] = (ir < nrows && k < n) ? -Ai[k] : 0.0; }
+    }
+    __syncthreads();
+    if (i0 >= nrows) return;
+#pragma unroll
     for (int c = 0; c < 4; ++c) {
         const int j0 = 64 * tj + 16 * c;
-        if (j0 >= nrows || j0 > i0 + 15) break;              // beyond the front, or entirely above the diagonal
+        if (j0 >= nrows || j0 > i0 + 15) break;              // beyond the front, or entirely above the diagonal (uniform per wavefront)
         const int jr = j0 + (l & 15);
-        const double* __restrict__ Aj = A + (size_t)(row0 + min(jr, nrows - 1)) * ld + col0;
-        double b[24];
-#pragma unroll
-        for (int ks = 0; ks < 24; ++ks) { const int k = 4 * ks + (l >> 4); b[ks] = (jr < nrows && k < n) ? Aj[k] : 0.0; }
+        const double* __restrict__ sb = sB + (16 * c + (l & 15)) * PG_SYRK_LD + (l >> 4);
         pg_d4 acc;
         double* __restrict__ Cp = A + (size_t)(row0 + i0 + (l >> 4)) * ld + row0 + j0 + (l & 15);
 #pragma unroll
         for (int v = 0; v < 4; ++v) acc[v] = (i0 + (l >> 4) + 4 * v < nrows && jr < nrows) ? Cp[(size_t)(4 * v) * ld] : 0.0;
 #pragma unroll
-        for (int ks = 0; ks < 24; ++ks) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[ks], b[ks], acc, 0, 0, 0);
+        for (int ks = 0; ks < 24; ++ks) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[ks], sb[4 * ks], acc, 0, 0, 0);
 #pragma unroll
         for (int v = 0; v < 4; ++v) if (i0 + (l >> 4) + 4 * v < nrows && jr < nrows) Cp[(size_t)(4 * v) * ld] = acc[v];
     }
@@ -1303,7 +1309,7 @@ static int pg_solve_impl(dsss_ctx* c, const double* dr6, int total, const dsss_l
     double *d_ew, *d_r, *d_Ji, *d_D, *d_C, *d_g, *d_delta, *d_E, *d_Dl, *d_gi, *d_sDL, *d_sDR, *d_sGL, *d_sGR, *d_sS, *d_L, *d_x, *d_part, *d_scal;
     double *d_F, *d_R, *d_ubin, *d_aval, *d_Wsw, *d_Wrow, *d_Uvec;
     int *d_colptr, *d_rowidx, *d_rlptr, *d_rlcol, *d_rlpos, *d_rlrow, *d_binptr, *d_bincols, *d_dest, *d_fail, *d_map; long long* d_mapptr;
-    int *d_binroot_ptr, *d_binroot_idx, *d_broot_b, *d_broot_of_col, *d_anc_first, *d_anc_rel, *d_rel, *d_fa_src, *d_fa_row, *d_fa_col, *d_fa_tr, *d_frows, *d_lv_front, *d_lv_step, *d_asm_front;
+    int *d_binroot_ptr, *d_binroot_idx, *d_broot_b, *d_broot_of_col, *d_anc_first, *d_anc_rel, *d_rel, *d_fa_src, *d_fa_col, *d_fa_tr, *d_frows, *d_lv_front, *d_lv_step, *d_asm_front, *d_asm_row, *d_xr_ptr, *d_xr_child, *d_xr_row, *d_fa_rowptr, *d_tile_item, *d_tile_ij;
     long long* d_broot_uoff; pg_front* d_FD; pg_child* d_CH;
     const int nf = n + ne, nblk = (nf + 255) / 256;
     TRY(dv.alloc(c, &d_X, n)); TRY(dv.alloc(c, &d_Xn, n)); TRY(dv.alloc(c, &d_meas, n)); TRY(dv.upload(c, &d_emeas, emeas));
@@ -1322,8 +1328,9 @@ static int pg_solve_impl(dsss_ctx* c, const double* dr6, int total, const dsss_l
     TRY(dv.upload(c, &d_dest, S.dest_bin));
     TRY(dv.upload(c, &d_binroot_ptr, S.binroot_ptr)); TRY(dv.upload(c, &d_binroot_idx, S.binroot_idx)); TRY(dv.upload(c, &d_broot_b, S.broot_b)); TRY(dv.upload(c, &d_broot_uoff, S.broot_uoff));
     TRY(dv.upload(c, &d_broot_of_col, S.broot_of_col)); TRY(dv.upload(c, &d_anc_first, S.anc_first)); TRY(dv.upload(c, &d_anc_rel, S.anc_rel));
-    TRY(dv.upload(c, &d_rel, S.rel)); TRY(dv.upload(c, &d_fa_src, S.fa_src)); TRY(dv.upload(c, &d_fa_row, S.fa_row)); TRY(dv.upload(c, &d_fa_col, S.fa_col)); TRY(dv.upload(c, &d_fa_tr, S.fa_tr));
-    TRY(dv.upload(c, &d_frows, S.f_rows)); TRY(dv.upload(c, &d_lv_front, S.lv_front)); TRY(dv.upload(c, &d_lv_step, S.lv_step)); TRY(dv.upload(c, &d_asm_front, S.asm_front));
+    TRY(dv.upload(c, &d_rel, S.rel)); TRY(dv.upload(c, &d_fa_src, S.fa_src)); TRY(dv.upload(c, &d_fa_col, S.fa_col)); TRY(dv.upload(c, &d_fa_tr, S.fa_tr));
+    TRY(dv.upload(c, &d_frows, S.f_rows)); TRY(dv.upload(c, &d_lv_front, S.lv_front)); TRY(dv.upload(c, &d_lv_step, S.lv_step)); TRY(dv.upload(c, &d_asm_front, S.asmrow_front)); TRY(dv.upload(c, &d_asm_row, S.asmrow_row)); TRY(dv.upload(c, &d_xr_ptr, S.xr_ptr)); TRY(dv.upload(c, &d_xr_child, S.xr_child));
+    TRY(dv.upload(c, &d_xr_row, S.xr_row)); TRY(dv.upload(c, &d_fa_rowptr, S.fa_rowptr)); TRY(dv.upload(c, &d_tile_item, S.tile_item)); TRY(dv.upload(c, &d_tile_ij, S.tile_ij));
     const int nbins = (int)S.binptr.size() - 1;
     {   // front and child descriptors (the children point straight at the update matrices: F22 of a front, U of a bin root)
         std::vector<pg_front> FD(nfr); std::vector<pg_child> CH(S.ch_kind.size());
@@ -1340,17 +1347,15 @@ static int pg_solve_impl(dsss_ctx* c, const double* dr6, int total, const dsss_l
         TRY(dv.upload(c, &d_FD, FD)); TRY(dv.upload(c, &d_CH, CH));
     }
     // launch shapes and algorithmic flops of every level
-    std::vector<int> lv_asm_chunks(nlev, 0), lv_trsm_chunks(nlev, 0), lv_syrk_tiles(nlev, 0);
+    std::vector<int> lv_trsm_chunks(nlev, 0);
     std::vector<double> fl_syrk(nlev, 0), fl_diag(nlev, 0), fl_trsm(nlev, 0), fl_bwd(nlev, 0);
     int max_n6 = 6;
     for (int l = 0; l < nlev; ++l) {
-        for (int q = S.asm_ptr[l]; q < S.asm_ptr[l + 1]; ++q) lv_asm_chunks[l] = std::max(lv_asm_chunks[l], (S.f_n[S.asm_front[q]] + PG_ASM_RB - 1) / PG_ASM_RB);
         for (int q = S.lv_ptr[l]; q < S.lv_ptr[l + 1]; ++q) {
             const int f = S.lv_front[q], k = S.lv_step[q], n6 = 6 * S.f_n[f], s6 = 6 * S.f_s[f];
-            const int w6 = std::min(96, s6 - 96 * k), nrows = n6 - 96 * k - w6, nt = (nrows + 63) / 64;
+            const int w6 = std::min(96, s6 - 96 * k), nrows = n6 - 96 * k - w6;
             max_n6 = std::max(max_n6, n6);
             lv_trsm_chunks[l] = std::max(lv_trsm_chunks[l], (nrows + 63) / 64);
-            lv_syrk_tiles[l] = std::max(lv_syrk_tiles[l], nt * (nt + 1) / 2);
             const double nn = w6, rows = nrows;
             fl_diag[l] += nn * nn * nn / 3.0 + nn * nn; fl_trsm[l] += rows * nn * nn; fl_bwd[l] += 2.0 * rows * nn + nn * nn; fl_syrk[l] += rows * (rows + 1) * nn;
         }
@@ -1433,18 +1438,18 @@ static int pg_solve_impl(dsss_ctx* c, const double* dr6, int total, const dsss_l
                                                     d_binroot_ptr, d_binroot_idx, d_broot_b, d_broot_uoff, d_broot_of_col, d_anc_first, d_anc_rel, d_ubin); }
                 // fronts, level by level: assemble the fronts that start here, then one panel step of every active front
                 for (int l = 0; l < nlev; ++l) {
-                    const int nas = S.asm_ptr[l + 1] - S.asm_ptr[l], nit = S.lv_ptr[l + 1] - S.lv_ptr[l];
+                    const int nas = S.asmrow_ptr[l + 1] - S.asmrow_ptr[l], nit = S.lv_ptr[l + 1] - S.lv_ptr[l], ntl = S.tile_ptr[l + 1] - S.tile_ptr[l];
                     const int* itf = d_lv_front + S.lv_ptr[l]; const int* its = d_lv_step + S.lv_ptr[l];
                     if (nas > 0) { dsss_scope s2(c, DSSS_K_PG_ASM);
-                        hipLaunchKernelGGL(pg_front_asm_kernel, dim3(nas, lv_asm_chunks[l]), dim3(256), 0, st, d_asm_front + S.asm_ptr[l], d_FD, d_CH, d_rel, d_fa_src, d_fa_row, d_fa_col, d_fa_tr,
-                                           d_aval, d_x, d_F, d_R); }
+                        hipLaunchKernelGGL(pg_front_asm_kernel, dim3(nas), dim3(256), 0, st, d_asm_front + S.asmrow_ptr[l], d_asm_row + S.asmrow_ptr[l], d_FD, d_CH, d_rel, d_xr_ptr, d_xr_child, d_xr_row,
+                                           d_fa_rowptr, d_fa_src, d_fa_col, d_fa_tr, d_aval, d_x, d_F, d_R); }
                     { dsss_scope s3(c, DSSS_K_PG_DIAG, fl_diag[l]);
                       hipLaunchKernelGGL(pg_front_diag_kernel, dim3(nit), dim3(256), PG_DIAG_LDS, st, itf, its, d_FD, d_F, d_R, d_fail, d_Wsw, d_Wrow, d_Uvec); }
                     if (lv_trsm_chunks[l] > 0) {
                         { dsss_scope s4(c, DSSS_K_PG_TRSM, fl_trsm[l]);
                           hipLaunchKernelGGL(pg_front_trsm_kernel, dim3(nit, lv_trsm_chunks[l]), dim3(256), 0, st, itf, its, d_FD, d_F, d_R, d_Wsw, d_Uvec); }
                         { dsss_scope s5(c, DSSS_K_PG_ACC, fl_syrk[l]);
-                          hipLaunchKernelGGL(pg_front_syrk_kernel, dim3(nit, lv_syrk_tiles[l]), dim3(256), 0, st, itf, its, d_FD, d_F); }
+                          if (ntl > 0) hipLaunchKernelGGL(pg_front_syrk_kernel, dim3(ntl), dim3(256), 0, st, itf, its, d_FD, d_tile_item + S.tile_ptr[l], d_tile_ij + S.tile_ptr[l], d_F); }
                     }
                 }
                 for (int l = nlev - 1; l >= 0; --l) {

@@ -453,6 +453,35 @@ void pg_symbolic(int ns, const std::vector<std::pair<int, int>>& edges, int ncha
             f = nxt;
         }
     }
+    // ---- per-row views for the assembly, work items of the assembly and of the trailing update
+    {
+        const int nrows_all = S.f_rowptr[nf];
+        S.fa_rowptr.assign(nrows_all + 1, 0);
+        for (int f = 0; f < nf; ++f) for (int e = S.fa_ptr[f]; e < S.fa_ptr[f + 1]; ++e) S.fa_rowptr[S.f_rowptr[f] + S.fa_row[e] + 1]++;
+        // entries are sorted by (front, row): the CSR offsets are global positions in fa_*
+        for (int i = 0; i < nrows_all; ++i) S.fa_rowptr[i + 1] += S.fa_rowptr[i];
+        S.xr_ptr.assign(nrows_all + 1, 0);
+        for (int f = 0; f < nf; ++f)
+            for (int c = S.ch_ptr[f]; c < S.ch_ptr[f + 1]; ++c) { const long long r0 = S.ch_relptr[c], r1 = S.ch_relptr[c + 1]; for (long long q = r0; q < r1; ++q) S.xr_ptr[S.f_rowptr[f] + S.rel[q] + 1]++; }
+        for (int i = 0; i < nrows_all; ++i) S.xr_ptr[i + 1] += S.xr_ptr[i];
+        S.xr_child.resize(S.xr_ptr[nrows_all]); S.xr_row.resize(S.xr_ptr[nrows_all]);
+        std::vector<int> fp(S.xr_ptr.begin(), S.xr_ptr.end() - 1);
+        for (int f = 0; f < nf; ++f)
+            for (int c = S.ch_ptr[f]; c < S.ch_ptr[f + 1]; ++c) {                                   // children in their fixed order
+                const long long r0 = S.ch_relptr[c], r1 = S.ch_relptr[c + 1];
+                for (long long q = r0; q < r1; ++q) { const int at = fp[S.f_rowptr[f] + S.rel[q]]++; S.xr_child[at] = c; S.xr_row[at] = (int)(q - r0); }
+            }
+        S.asmrow_ptr.assign(S.nlev + 1, 0); S.tile_ptr.assign(S.nlev + 1, 0);
+        for (int l = 0; l < S.nlev; ++l) {
+            for (int q = S.asm_ptr[l]; q < S.asm_ptr[l + 1]; ++q) { const int f = S.asm_front[q]; for (int r = 0; r < S.f_n[f]; ++r) { S.asmrow_front.push_back(f); S.asmrow_row.push_back(r); } }
+            S.asmrow_ptr[l + 1] = (int)S.asmrow_front.size();
+            for (int q = S.lv_ptr[l]; q < S.lv_ptr[l + 1]; ++q) {
+                const int f = S.lv_front[q], k = S.lv_step[q], w6 = std::min(96, 6 * S.f_s[f] - 96 * k), nrows = 6 * S.f_n[f] - 96 * k - w6, nt = (nrows + 63) / 64;
+                for (int ti = 0; ti < nt; ++ti) for (int tj = 0; tj <= ti; ++tj) { S.tile_item.push_back(q - S.lv_ptr[l]); S.tile_ij.push_back((ti << 16) | tj); }
+            }
+            S.tile_ptr[l + 1] = (int)S.tile_item.size();
+        }
+    }
     // ---- children that cross from a rank's interior into the interface
     {
         long long o = 0;

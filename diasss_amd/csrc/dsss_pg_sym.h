@@ -62,10 +62,15 @@ struct pg_sym {
     // where the assembled blocks go: value index k in [0, ns) diagonal of separator k, [ns, 2ns-1) chain coupling k|k+1,
     // then LC edges.  dest_bin[v] = (Lvals position << 1 | transpose) for a binned destination column, -1 for a front
     std::vector<int> dest_bin;
+    // per front block row (index f_rowptr[f] + R): the original entries that land in it (fa_rowptr: CSR into fa_*), and the
+    // child rows that extend-add into it, in child order (xr_ptr: CSR into xr_child = index into ch_*, xr_row = child row)
+    std::vector<int> fa_rowptr, xr_ptr, xr_child, xr_row;
     // ---- schedule: panel steps per level, fronts to assemble per level
     int nlev = 0, npanels = 0;
     std::vector<int> lv_ptr, lv_front, lv_step;
     std::vector<int> asm_ptr, asm_front;
+    std::vector<int> asmrow_ptr, asmrow_front, asmrow_row;     // (front, block row) work items of the assembly per level
+    std::vector<int> tile_ptr, tile_item, tile_ij;             // (panel item within its level, ti << 16 | tj) 64 x 64 trailing-update tiles per level
     // ---- ranks: children that cross from an interior front / bin root into an interface front ("comm children")
     std::vector<int> comm_kind, comm_id, comm_part;  // the crossing children in a fixed global order
     std::vector<long long> comm_off;    // packed offset (doubles) in the comm buffer: (6b)^2 + 6b each
