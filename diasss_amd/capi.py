@@ -20,7 +20,7 @@ LC_DTYPE = np.dtype([("rel", "<f8", (12,)), ("var", "<f8", (6,)), ("score", "<f8
 LCEDGE_DTYPE = np.dtype([("a", "<i4"), ("b", "<i4"), ("rel", "<f8", (12,)), ("var", "<f8", (6,))])
 
 K_NAMES = ["row_reduce", "pre_misc", "normalize", "pyramid", "fast", "fast_compact", "desc", "filter", "match", "scc", "rows", "lc", "pg",
-           "quadtree", "pg_acc", "pg_diag", "pg_trsm", "pg_bwd", "pg_subtree", "pg_asm"]
+           "quadtree", "pg_acc", "pg_diag", "pg_trsm", "pg_bwd", "pg_subtree", "pg_asm", "pg_comm", "k21"]
 
 
 class MaskParams(C.Structure):
@@ -91,8 +91,13 @@ def lib():
         L.dsss_stream.argtypes = [C.c_void_p]
         L.dsss_features_pack_bytes.restype = C.c_size_t
         L.dsss_features_pack_bytes.argtypes = [C.c_void_p]
+        L.dsss_comm_init_callback.argtypes = [C.c_void_p, C.c_int, C.c_int, COMM_FN, C.c_void_p]
+        L.dsss_comm_frame_owner.argtypes = [C.c_void_p, C.c_int, C.c_int]
         _LIB = L
     return _LIB
+
+
+COMM_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_size_t)
 
 
 def _ptr(a):
@@ -149,6 +154,51 @@ class Context:
 
     def sync(self):
         self._chk(self.L.dsss_sync(self.h), "dsss_sync")
+
+    # ---- ranks (one process per GPU)
+    def comm_unique_id(self):
+        buf = np.zeros(128, np.uint8)
+        rc = self.L.dsss_comm_unique_id(_ptr(buf))
+        if rc != 0:
+            raise DsssError("dsss_comm_unique_id: %s" % self.L.dsss_strerror(rc).decode())
+        return buf
+
+    def comm_init_rccl(self, uid128, rank, world):
+        uid128 = np.ascontiguousarray(uid128, np.uint8); assert uid128.size == 128
+        self._chk(self.L.dsss_comm_init(self.h, _ptr(uid128), int(rank), int(world)), "dsss_comm_init")
+
+    def comm_init_callback(self, rank, world, fn):
+        """fn(op, array): op 0 = sum the float64 array over the ranks in place, op 1 = all-gather: array is (world, n) uint8
+        with this rank's row filled in"""
+        def _cb(user, op, buf, n):
+            try:
+                if op == 0:
+                    fn(0, np.ctypeslib.as_array(C.cast(buf, C.POINTER(C.c_double)), shape=(n,)))
+                else:
+                    fn(1, np.ctypeslib.as_array(C.cast(buf, C.POINTER(C.c_uint8)), shape=(world, n)))
+                return 0
+            except Exception as ex:                      # never let an exception cross the C boundary
+                import traceback; traceback.print_exc()
+                return 1
+        self._cb_keep = COMM_FN(_cb)
+        self._chk(self.L.dsss_comm_init_callback(self.h, int(rank), int(world), self._cb_keep, None), "dsss_comm_init_callback")
+
+    def comm_destroy(self):
+        self._chk(self.L.dsss_comm_destroy(self.h), "dsss_comm_destroy")
+
+    def comm_stats(self):
+        r = C.c_int(); w = C.c_int(); b = C.c_double(); n = C.c_int64()
+        self._chk(self.L.dsss_comm_stats(self.h, C.byref(r), C.byref(w), C.byref(b), C.byref(n)), "dsss_comm_stats")
+        return r.value, w.value, b.value, n.value
+
+    def frame_owner(self, nframes, frame):
+        return self.L.dsss_comm_frame_owner(self.h, int(nframes), int(frame))
+
+    def features_allgather(self, nframes):
+        self._chk(self.L.dsss_features_allgather(self.h, int(nframes)), "dsss_features_allgather")
+
+    def set_pg_partitions(self, nparts):
+        self._chk(self.L.dsss_set_pg_partitions(self.h, int(nparts)), "dsss_set_pg_partitions")
 
     # ---- frames
     def frame_set(self, fid, raw, N, M, pose6, alt, gr):

@@ -33,6 +33,7 @@ const char* dsss_strerror(int code)
     case DSSS_E_STATE: return "call order violated";
     case DSSS_E_CAPACITY: return "buffer too small";
     case DSSS_E_NUMERIC: return "numerical failure";
+    case DSSS_E_COMM: return "communicator / RCCL failure";
     default: return "unknown error";
     }
 }
@@ -104,7 +105,7 @@ void dsss_destroy(dsss_ctx* c)
     if (c->geoms && c->geoms_free) c->geoms_free(c->geoms);
     if (c->ex_pinned) hipHostFree(c->ex_pinned);
     if (c->bbox_pinned) hipHostFree(c->bbox_pinned);
-    dsss_pg_free(c);
+    dsss_pg_free(c); dsss_comm_free(c);
     hipEventDestroy(c->prof.e0); hipEventDestroy(c->prof.e1);
     for (int i = 0; i < 4; ++i) { if (c->xs[i]) hipStreamDestroy(c->xs[i]); if (c->xev[i]) hipEventDestroy(c->xev[i]); }
     if (c->xev_main) hipEventDestroy(c->xev_main);
@@ -112,6 +113,7 @@ void dsss_destroy(dsss_ctx* c)
     delete c;
 }
 
+int dsss_set_pg_partitions(dsss_ctx* c, int nparts) { if (!c || nparts < 0 || nparts > 4096) return DSSS_E_ARG; c->pg_parts = nparts; return DSSS_OK; }
 int dsss_sync(dsss_ctx* c) { if (!c) return DSSS_E_ARG; HIPCHK(c, hipStreamSynchronize(c->stream)); return DSSS_OK; }
 void* dsss_stream(dsss_ctx* c) { return c ? (void*)c->stream : nullptr; }
 
@@ -519,6 +521,42 @@ int dsss_features_unpack(dsss_ctx* c, int id, const void* buf)
     HIPCHK(c, hipMemcpy(bbox, p + 16, 32, hipMemcpyDefault));
     return dsss_features_set(c, id, hdr[1], hdr[2], (const dsss_kp*)(p + 48), (const uint8_t*)(p + 48 + K * sizeof(dsss_kp)),
                              (const double*)(p + 48 + K * sizeof(dsss_kp) + K * 32), bbox, hdr[0]);
+}
+
+int dsss_comm_frame_owner(const dsss_ctx* c, int nframes, int frame)
+{
+    const int world = c ? dsss_comm_world(c) : 1;
+    if (nframes <= 0 || frame < 0 || frame >= nframes) return -1;
+    int r = (int)(((long long)frame * world) / nframes);
+    while (r + 1 < world && (long long)nframes * (r + 1) / world <= frame) ++r;
+    while (r > 0 && (long long)nframes * r / world > frame) --r;
+    return r;
+}
+int dsss_features_allgather(dsss_ctx* c, int nframes)
+{
+    if (!c || nframes <= 0 || nframes > c->max_frames) return DSSS_E_ARG;
+    const int world = dsss_comm_world(c), rank = dsss_comm_rank(c);
+    if (world == 1) return DSSS_OK;
+    HIPCHK(c, hipSetDevice(c->device));
+    const size_t nb = dsss_features_pack_bytes(c);
+    int per = 0;
+    for (int r = 0; r < world; ++r) per = std::max(per, (int)((long long)nframes * (r + 1) / world - (long long)nframes * r / world));
+    const size_t slice = (size_t)per * nb;
+    char* d_buf = nullptr;
+    HIPCHK(c, hipMalloc(&d_buf, slice * world));
+    int rc = DSSS_OK;
+    const int f0 = (int)((long long)nframes * rank / world), f1 = (int)((long long)nframes * (rank + 1) / world);
+    for (int f = f0; f < f1 && rc == DSSS_OK; ++f) rc = dsss_features_pack(c, f, d_buf + (size_t)rank * slice + (size_t)(f - f0) * nb);
+    if (rc == DSSS_OK) rc = dsss_comm_allgather(c, d_buf, slice, c->stream);
+    if (rc == DSSS_OK && hipStreamSynchronize(c->stream) != hipSuccess) rc = DSSS_E_HIP;
+    for (int r = 0; r < world && rc == DSSS_OK; ++r) {
+        if (r == rank) continue;
+        const int g0 = (int)((long long)nframes * r / world), g1 = (int)((long long)nframes * (r + 1) / world);
+        for (int f = g0; f < g1 && rc == DSSS_OK; ++f) rc = dsss_features_unpack(c, f, d_buf + (size_t)r * slice + (size_t)(f - g0) * nb);
+    }
+    hipStreamSynchronize(c->stream);
+    hipFree(d_buf);
+    return rc;
 }
 
 int dsss_profile_enable(dsss_ctx* c, int on) { if (!c) return DSSS_E_ARG; c->prof.on = on != 0; return DSSS_OK; }

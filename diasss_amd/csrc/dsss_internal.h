@@ -40,6 +40,8 @@ struct dsss_frame {
 // geometry of a whole dsss_frames_set call: one pinned staging area, one device buffer, ONE upload
 struct dsss_geo_batch { double* d = nullptr; double* h = nullptr; size_t cap = 0; int refs = 0; hipEvent_t ev = nullptr; };
 
+struct dsss_comm;                        // dsss_comm.hip
+
 struct dsss_prof {
     bool on = false;
     double ms[DSSS_K_COUNT] = {0};
@@ -97,6 +99,8 @@ struct dsss_ctx {
     void* pg_state = nullptr;
     // per-geometry extraction tables (dsss_extract.hip owns the type; freed through geoms_free by dsss_destroy)
     void* geoms = nullptr; void (*geoms_free)(void*) = nullptr;
+    dsss_comm* comm = nullptr;          // ranks of one job (dsss_comm_init): null = single process
+    int pg_parts = 0;                   // pose-graph partitions (0: one per rank); > ranks only to exercise the interface logic on few GPUs
     int* tmp_dev = nullptr;             // 64 ints of device scratch for one-value results (dsss_descriptor_distance)
     dsss_prof prof;
 };
@@ -128,6 +132,11 @@ int dsss_frame_geo_bbox(dsss_ctx* c, int id);       // device computation of the
 int dsss_sync_bboxes(dsss_ctx* c);                  // make dsss_frame::bbox valid on the host
 int dsss_frame_kp_geo(dsss_ctx* c, int id, int n);  // geo lookup of the stored keypoints (frame.cpp:126-165)
 void dsss_pg_free(dsss_ctx* c);
+void dsss_comm_free(dsss_ctx* c);
+int dsss_comm_rank(const dsss_ctx* c);
+int dsss_comm_world(const dsss_ctx* c);
+int dsss_comm_allreduce(dsss_ctx* c, double* dev, size_t n, hipStream_t st);
+int dsss_comm_allgather(dsss_ctx* c, void* recv_dev, size_t bytes_per_rank, hipStream_t st);    // own slice in place at rank * bytes   // in-place sum over the ranks, ordered on st
 
 // deterministic sin/cos shared by every kernel that must agree with the oracle bit for bit:
 // Cody-Waite reduction + fdlibm kernel polynomials, plain IEEE mul/add only (library built -ffp-contract=off)

@@ -119,15 +119,23 @@ __device__ inline double block_sum256(double v, double* s_w)
     return ((s_w[0] + s_w[1]) + s_w[2]) + s_w[3];
 }
 
+// Ownership with several ranks (dsss_comm.hip): a rank owns the poses [mp0, mp1); chain factor k belongs to the owner of pose k,
+// LC edge (a, b) to the owner of its target pose b.  Every kernel below skips what the rank does not own; with one rank
+// [mp0, mp1) is everything.
+__device__ inline bool pg_owned_factor(int k, int n, const int* __restrict__ eb, int mp0, int mp1)
+{
+    const int p = k < n ? k : eb[k - n];
+    return p >= mp0 && p < mp1;
+}
 __global__ __launch_bounds__(256) void pg_linearize_kernel(int n, int ne, const pose_t* __restrict__ X, const pose_t* __restrict__ meas,
                                                            pg_weights W, const int* __restrict__ ea, const int* __restrict__ eb,
                                                            const pose_t* __restrict__ emeas, const double* __restrict__ ew,
-                                                           double* __restrict__ r, double* __restrict__ Ji, double* __restrict__ partial)
+                                                           double* __restrict__ r, double* __restrict__ Ji, double* __restrict__ partial, int mp0, int mp1)
 {
     __shared__ double s_w[4];
     const int k = blockIdx.x * 256 + threadIdx.x;
     double e2 = 0;
-    if (k < n + ne) {
+    if (k < n + ne && pg_owned_factor(k, n, eb, mp0, mp1)) {
         double rr[6], J[36];
         factor_eval(k, n, X, meas, W, ea, eb, emeas, ew, rr, Ji ? J : nullptr);
         for (int a = 0; a < 6; ++a) { e2 += rr[a] * rr[a]; if (r) r[(size_t)k * 6 + a] = rr[a]; }
@@ -151,17 +159,19 @@ __global__ __launch_bounds__(256) void pg_final_sum_kernel(const double* __restr
 __global__ __launch_bounds__(256) void pg_assemble_kernel(int n, pg_weights W, const double* __restrict__ r, const double* __restrict__ Ji,
                                                           const int* __restrict__ adj_ptr, const int* __restrict__ adj_edge,
                                                           const double* __restrict__ ew, const double* __restrict__ lambda_ptr,
-                                                          double* __restrict__ D, double* __restrict__ C, double* __restrict__ g)
+                                                          double* __restrict__ D, double* __restrict__ C, double* __restrict__ g,
+                                                          const int* __restrict__ eb, int mp0, int mp1)
 {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
     double Dd[36], Cc[36], gg[6];
     for (int a = 0; a < 36; ++a) { Dd[a] = 0; Cc[a] = 0; }
     for (int a = 0; a < 6; ++a) gg[a] = 0;
+    const bool own_i = i >= mp0 && i < mp1, own_next = i + 1 >= mp0 && i + 1 < mp1;
     // factor i with this pose as the second variable (Jacobian W)
     const double* w2 = i == 0 ? W.prior : W.odo;
-    for (int a = 0; a < 6; ++a) { Dd[a * 6 + a] += w2[a] * w2[a]; gg[a] += w2[a] * r[(size_t)i * 6 + a]; }
-    if (i + 1 < n) {   // factor i+1 with this pose as the first variable
+    if (own_i) for (int a = 0; a < 6; ++a) { Dd[a * 6 + a] += w2[a] * w2[a]; gg[a] += w2[a] * r[(size_t)i * 6 + a]; }
+    if (i + 1 < n && own_next) {   // factor i+1 with this pose as the first variable
         const double* J = Ji + (size_t)(i + 1) * 36; const double* rr = r + (size_t)(i + 1) * 6;
         for (int a = 0; a < 6; ++a) {
             for (int b = 0; b < 6; ++b) {
@@ -177,6 +187,7 @@ __global__ __launch_bounds__(256) void pg_assemble_kernel(int n, pg_weights W, c
     }
     for (int p = adj_ptr[i]; p < adj_ptr[i + 1]; ++p) {
         const int code = adj_edge[p], e = code >> 1, second = code & 1;
+        if (eb[e] < mp0 || eb[e] >= mp1) continue;             // the edge belongs to another rank
         const double* rr = r + (size_t)(n + e) * 6;
         if (second) {
             const double* w = ew + (size_t)e * 6;
@@ -192,7 +203,7 @@ __global__ __launch_bounds__(256) void pg_assemble_kernel(int n, pg_weights W, c
         }
     }
     const double lambda = *lambda_ptr;
-    for (int a = 0; a < 6; ++a) Dd[a * 6 + a] += lambda;
+    if (own_i) for (int a = 0; a < 6; ++a) Dd[a * 6 + a] += lambda;        // the damping of a pose is added once, by its owner
     for (int a = 0; a < 36; ++a) { D[(size_t)i * 36 + a] = Dd[a]; C[(size_t)i * 36 + a] = Cc[a]; }
     for (int a = 0; a < 6; ++a) g[(size_t)i * 6 + a] = gg[a];
 }
@@ -204,11 +215,12 @@ __global__ __launch_bounds__(64) void pg_segment_kernel(int nseg, const int* __r
                                                         const double* __restrict__ C, const double* __restrict__ g,
                                                         double* __restrict__ E, double* __restrict__ Dl, double* __restrict__ gi,
                                                         double* __restrict__ segDL, double* __restrict__ segDR, double* __restrict__ segGL,
-                                                        double* __restrict__ segGR, double* __restrict__ segS, int* __restrict__ fail)
+                                                        double* __restrict__ segGR, double* __restrict__ segS, int* __restrict__ fail, int mp0, int mp1)
 {
     const int s = blockIdx.x * 64 + threadIdx.x;
     if (s >= nseg) return;
     const int L = sep_pose[s], R = sep_pose[s + 1];
+    if (L + 1 < mp0 || L + 1 >= mp1) return;                    // a segment belongs to the owner of its poses (partitions end on a separator)
     double DL[36], GL[6], Dn[36], Gn[6], Ei[36];
     for (int a = 0; a < 36; ++a) DL[a] = 0;
     for (int a = 0; a < 6; ++a) GL[a] = 0;
@@ -266,43 +278,53 @@ __global__ __launch_bounds__(256) void pg_scatter_base_kernel(int ns, const int*
                                                               const double* __restrict__ segDL, const double* __restrict__ segDR,
                                                               const double* __restrict__ segGL, const double* __restrict__ segGR,
                                                               const double* __restrict__ segS, const int* __restrict__ dest,
-                                                              double* __restrict__ Lvals, double* __restrict__ aval, double* __restrict__ rhs)
+                                                              double* __restrict__ Lvals, double* __restrict__ aval, double* __restrict__ rhs,
+                                                              const int* __restrict__ if_slot, double* __restrict__ aval_if, double* __restrict__ x_if, int mp0, int mp1)
 {
     const int k = blockIdx.x * 256 + threadIdx.x;
     if (k >= ns) return;
     const int p = sep_pose[k];
-    double* dst = dest[k] >= 0 ? Lvals + (size_t)(dest[k] >> 1) * 36 : aval + (size_t)k * 36;
-    for (int a = 0; a < 36; ++a) {
-        double v = D[(size_t)p * 36 + a];
-        if (k > 0) v += segDR[(size_t)(k - 1) * 36 + a];
-        if (k + 1 < ns) v += segDL[(size_t)k * 36 + a];
-        dst[a] = v;
+    // segment k-1 ends in this separator, segment k starts in it; each belongs to the owner of its first interior pose
+    const bool segl = k > 0 && sep_pose[k - 1] + 1 >= mp0 && sep_pose[k - 1] + 1 < mp1, segr = k + 1 < ns && p + 1 >= mp0 && p + 1 < mp1;
+    const int code = dest[k];
+    const bool iface = code <= -2, own = p >= mp0 && p < mp1;
+    if (iface || own) {
+        // an interface separator takes a partial sum from every rank (summed by the all-reduce), an interior one is complete
+        double* dst = code >= 0 ? Lvals + (size_t)(code >> 1) * 36 : (iface ? aval_if + (size_t)(-2 - code) * 36 : aval + (size_t)k * 36);
+        for (int a = 0; a < 36; ++a) {
+            double v = D[(size_t)p * 36 + a];
+            if (segl) v += segDR[(size_t)(k - 1) * 36 + a];
+            if (segr) v += segDL[(size_t)k * 36 + a];
+            dst[a] = v;
+        }
+        double* rr = iface ? x_if + (size_t)if_slot[k] * 6 : rhs + (size_t)perm[k] * 6;
+        for (int a = 0; a < 6; ++a) {
+            double v = g[(size_t)p * 6 + a];
+            if (segl) v += segGR[(size_t)(k - 1) * 6 + a];
+            if (segr) v += segGL[(size_t)k * 6 + a];
+            rr[a] = -v;
+        }
     }
-    double* rr = rhs + (size_t)perm[k] * 6;
-    for (int a = 0; a < 6; ++a) {
-        double v = g[(size_t)p * 6 + a];
-        if (k > 0) v += segGR[(size_t)(k - 1) * 6 + a];
-        if (k + 1 < ns) v += segGL[(size_t)k * 6 + a];
-        rr[a] = -v;
-    }
-    if (k + 1 < ns) {      // S(k, k+1): the factor holds the (larger index, smaller index) block
-        const int code = dest[ns + k];
+    if (segr) {            // S(k, k+1), written by the owner of segment k: the factor holds the (larger index, smaller index) block
+        const int cc = dest[ns + k];
         const double* S = segS + (size_t)k * 36;
-        if (code >= 0) {
-            double* c = Lvals + (size_t)(code >> 1) * 36; const int tr = code & 1;
+        if (cc >= 0) {
+            double* c = Lvals + (size_t)(cc >> 1) * 36; const int tr = cc & 1;
             for (int a = 0; a < 6; ++a) for (int b = 0; b < 6; ++b) c[a * 6 + b] = tr ? S[b * 6 + a] : S[a * 6 + b];
         } else {
-            double* c = aval + (size_t)(ns + k) * 36;
+            double* c = cc <= -2 ? aval_if + (size_t)(-2 - cc) * 36 : aval + (size_t)(ns + k) * 36;
             for (int a = 0; a < 36; ++a) c[a] = S[a];
         }
     }
 }
 // LC off-diagonal blocks H(a, b) = Ji^T W (added after the chain couplings; (a,b) is unique per edge)
 __global__ __launch_bounds__(256) void pg_scatter_lc_kernel(int n, int ne, int ns, const double* __restrict__ Ji, const double* __restrict__ ew,
-                                                            const int* __restrict__ dest, double* __restrict__ Lvals, double* __restrict__ aval)
+                                                            const int* __restrict__ dest, double* __restrict__ Lvals, double* __restrict__ aval,
+                                                            double* __restrict__ aval_if, const int* __restrict__ eb, int mp0, int mp1)
 {
     const int e = blockIdx.x * 256 + threadIdx.x;
     if (e >= ne) return;
+    if (eb[e] < mp0 || eb[e] >= mp1) return;
     const int code = dest[2 * ns - 1 + e];
     const double* J = Ji + (size_t)(n + e) * 36; const double* w = ew + (size_t)e * 6;
     if (code >= 0) {
@@ -312,9 +334,43 @@ __global__ __launch_bounds__(256) void pg_scatter_lc_kernel(int n, int ne, int n
             if (tr) c[b * 6 + a] += h_ab; else c[a * 6 + b] += h_ab;
         }
     } else {
-        double* c = aval + (size_t)(2 * ns - 1 + e) * 36;
+        double* c = code <= -2 ? aval_if + (size_t)(-2 - code) * 36 : aval + (size_t)(2 * ns - 1 + e) * 36;
         for (int a = 0; a < 6; ++a) for (int b = 0; b < 6; ++b) c[a * 6 + b] = J[b * 6 + a] * w[b];
     }
+}
+
+// update matrices that cross from this rank's interior into the interface, packed (6b x 6b lower block triangle, then 6b of
+// right-hand side) into the buffer the all-reduce sums; one workgroup per (child, block row)
+struct pg_pack { const double* U; const double* g; double* dst; int cld, cb; };
+__global__ __launch_bounds__(256) void pg_comm_pack_kernel(const int* __restrict__ it_child, const int* __restrict__ it_row, const pg_pack* __restrict__ PK)
+{
+    const pg_pack pk = PK[it_child[blockIdx.x]];
+    const int i = it_row[blockIdx.x], b6 = 6 * pk.cb, wcols = 6 * (i + 1);
+    for (int cc = threadIdx.x; cc < wcols; cc += 256) {
+#pragma unroll
+        for (int a = 0; a < 6; ++a) pk.dst[(size_t)(6 * i + a) * b6 + cc] = pk.U[(size_t)(6 * i + a) * pk.cld + cc];
+    }
+    if (threadIdx.x < 6) pk.dst[(size_t)b6 * b6 + 6 * i + threadIdx.x] = pk.g[6 * i + threadIdx.x];
+}
+// interface right-hand sides out of the summed buffer into the solver's vector; three scalars + the failure flag into the
+// little buffer of the second all-reduce
+__global__ __launch_bounds__(256) void pg_comm_xif_kernel(int nif, const int* __restrict__ if_sep, const int* __restrict__ perm, const double* __restrict__ x_if, double* __restrict__ x)
+{
+    const int q = blockIdx.x * 256 + threadIdx.x;
+    if (q >= nif) return;
+    for (int a = 0; a < 6; ++a) x[(size_t)perm[if_sep[q]] * 6 + a] = x_if[(size_t)q * 6 + a];
+}
+__global__ void pg_comm_scal_kernel(const double* __restrict__ scal, const int* __restrict__ fail, double* __restrict__ red)
+{
+    if (threadIdx.x < 3) red[threadIdx.x] = scal[threadIdx.x];
+    if (threadIdx.x == 3) red[3] = (double)*fail;
+}
+__global__ __launch_bounds__(256) void pg_mask_own_kernel(int n, pose_t* __restrict__ X, int mp0, int mp1)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n || (i >= mp0 && i < mp1)) return;
+    for (int a = 0; a < 9; ++a) X[i].R[a] = 0.0;
+    for (int a = 0; a < 3; ++a) X[i].t[a] = 0.0;
 }
 
 // The factorisation kernels below (down to pg_sep_delta_kernel) are compared with the oracle at 1e-6 on the poses, not
@@ -1005,11 +1061,12 @@ __global__ __launch_bounds__(256) void pg_sep_delta_kernel(int ns, const int* __
 // interiors, right to left: delta_i = D_i^-1 (-g_i - E_i^T delta_L - C_i delta_{i+1})
 __global__ __launch_bounds__(64) void pg_backsub_kernel(int nseg, const int* __restrict__ sep_pose, const double* __restrict__ C,
                                                         const double* __restrict__ E, const double* __restrict__ Dl, const double* __restrict__ gi,
-                                                        double* __restrict__ delta)
+                                                        double* __restrict__ delta, int mp0, int mp1)
 {
     const int s = blockIdx.x * 64 + threadIdx.x;
     if (s >= nseg) return;
     const int L = sep_pose[s], R = sep_pose[s + 1];
+    if (L + 1 < mp0 || L + 1 >= mp1) return;
     double dL[6], dn[6];
     for (int a = 0; a < 6; ++a) { dL[a] = delta[(size_t)L * 6 + a]; dn[a] = delta[(size_t)R * 6 + a]; }
     for (int i = R - 1; i > L; --i) {
@@ -1029,12 +1086,12 @@ __global__ __launch_bounds__(64) void pg_backsub_kernel(int nseg, const int* __r
 // 0.5 * || J delta + r ||^2 over all factors (linear.error(delta))
 __global__ __launch_bounds__(256) void pg_linerr_kernel(int n, int ne, pg_weights W, const int* __restrict__ ea, const int* __restrict__ eb,
                                                         const double* __restrict__ ew, const double* __restrict__ r, const double* __restrict__ Ji,
-                                                        const double* __restrict__ delta, double* __restrict__ partial)
+                                                        const double* __restrict__ delta, double* __restrict__ partial, int mp0, int mp1)
 {
     __shared__ double s_w[4];
     const int k = blockIdx.x * 256 + threadIdx.x;
     double e2 = 0;
-    if (k < n + ne) {
+    if (k < n + ne && pg_owned_factor(k, n, eb, mp0, mp1)) {
         int i = -1, j; const double* w;
         if (k == 0) { j = 0; w = W.prior; }
         else if (k < n) { i = k - 1; j = k; w = W.odo; }
@@ -1228,6 +1285,17 @@ static int pg_solve_impl(dsss_ctx* c, const double* dr6, int total, const dsss_l
     if (!dr6) { foff.assign(nframes + 1, 0); for (int f = 0; f < nframes; ++f) foff[f + 1] = foff[f] + c->frames[f].N; }
     const int n = total;
     if (n < 2) DSSS_FAIL(c, DSSS_E_ARG, "pose graph needs at least 2 poses");
+    // ranks: contiguous blocks of frames (of poses when the DR chain comes without frames) per partition, contiguous partitions
+    // per rank.  A rank owns the poses [mp0, mp1): their chain factors, the LC edges that end in them, their segments.
+    const int world = dsss_comm_world(c), rank = dsss_comm_rank(c);
+    int nparts = std::max(world, c->pg_parts > 0 ? c->pg_parts : world);
+    nparts = std::min(nparts, dr6 ? std::max(1, n / 4) : std::max(1, nframes));
+    if (nparts < world) DSSS_FAIL(c, DSSS_E_ARG, "%d ranks need at least %d frames", world, world);
+    std::vector<int> pbound(nparts + 1, n);
+    for (int p = 0; p < nparts; ++p) pbound[p] = dr6 ? (int)((long long)n * p / nparts) : foff[(int)((long long)nframes * p / nparts)];
+    for (int p = 0; p < nparts; ++p) if (pbound[p + 1] <= pbound[p]) DSSS_FAIL(c, DSSS_E_ARG, "empty pose-graph partition %d", p);
+    const int part_lo = (int)((long long)nparts * rank / world), part_hi = (int)((long long)nparts * (rank + 1) / world);
+    const int mp0 = pbound[part_lo], mp1 = pbound[part_hi];
     const auto T0 = std::chrono::steady_clock::now();
     auto ms_since = [&](std::chrono::steady_clock::time_point t) { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t).count(); };
     const double PI = DSSS_PI_REF;
@@ -1262,6 +1330,7 @@ static int pg_solve_impl(dsss_ctx* c, const double* dr6, int total, const dsss_l
     // where a pose with two chain neighbours costs O(1) fill)
     { const char* ev = getenv("DSSS_PG_CHUNK"); const int chunk = ev ? std::max(2, atoi(ev)) : 16;
       for (int i = 0; i < n; i += chunk) is_sep[i] = 1; }
+    for (int p = 1; p < nparts; ++p) is_sep[pbound[p] - 1] = 1;          // a partition ends on a separator: segments never straddle ranks
     std::vector<int> sep_pose, sidx(n, -1);
     for (int i = 0; i < n; ++i) if (is_sep[i]) { sidx[i] = (int)sep_pose.size(); sep_pose.push_back(i); }
     const int ns = (int)sep_pose.size(), nseg = ns - 1;
@@ -1294,22 +1363,29 @@ static int pg_solve_impl(dsss_ctx* c, const double* dr6, int total, const dsss_l
     { pg_sym_opts opt; opt.threads = sym_threads();
       static const double bin_cost = getenv("DSSS_PG_BIN_COST") ? atof(getenv("DSSS_PG_BIN_COST")) : 1000;   // ~ update-list iterations + 20 per column; measured optimum at C3 (800-1500)
       opt.bin_cost = bin_cost; pg_sym_opts_env(opt);
-      pg_symbolic(ns, redges, nseg, cx.data(), cy.data(), nullptr, 1, opt, S); }
+      std::vector<int> part(ns);
+      for (int k = 0; k < ns; ++k) part[k] = (int)(std::upper_bound(pbound.begin(), pbound.end(), sep_pose[k]) - pbound.begin()) - 1;
+      pg_symbolic(ns, redges, nseg, cx.data(), cy.data(), nparts > 1 ? part.data() : nullptr, nparts, opt, S); }
+    // launch lists: this rank's interior fronts, then (after the all-reduce) the replicated interface fronts
+    pg_sched SO, SI;
+    pg_build_schedule(S, part_lo, part_hi, SO);
+    if (nparts > 1) pg_build_schedule(S, -1, 0, SI);
     const double t_sym = ms_since(T1);
     const auto T2 = std::chrono::steady_clock::now();
-    const int nlev = S.nlev, nfr = (int)S.f_c0.size(), npan = S.npanels;
+    const int nfr = (int)S.f_c0.size(), npan = S.npanels;
     const size_t nnzL = S.rowidx.size();
     const int nval = (int)S.dest_bin.size();
     const bool verbose = getenv("DSSS_PG_VERBOSE") != nullptr;
     if (verbose)
-        fprintf(stderr, "[dsss pg] poses %d  LC edges %d  separators %d  nnz(L) blocks %zu  bins %d (%d cols)  fronts %d (largest %d block rows, arena %.0f MB)  panels %d in %d levels\n",
-                n, ne, ns, nnzL, (int)S.binptr.size() - 1, (int)S.bincols.size(), nfr, S.max_front_n, S.front_doubles * 8e-6, npan, nlev);
+        fprintf(stderr, "[dsss pg] rank %d/%d parts %d (own %d..%d, poses %d..%d)  poses %d  LC edges %d  separators %d (interface %zu)  nnz(L) blocks %zu  bins %d (%d cols)  fronts %d (largest %d block rows, arena %.0f MB)  panels %d in %d levels  all-reduce %.1f MB\n",
+                rank, world, nparts, part_lo, part_hi, mp0, mp1, n, ne, ns, S.iface_seps.size(), nnzL, (int)S.binptr.size() - 1, (int)S.bincols.size(), nfr, S.max_front_n, S.front_doubles * 8e-6, npan, S.nlev,
+                (S.comm_doubles + 36.0 * S.comm_vals.size() + 6.0 * S.iface_seps.size()) * 8e-6);
 
     pose_t *d_X, *d_Xn, *d_meas, *d_emeas; int *d_ea, *d_eb, *d_adj_ptr, *d_adj_edge, *d_perm;
     double *d_ew, *d_r, *d_Ji, *d_D, *d_C, *d_g, *d_delta, *d_E, *d_Dl, *d_gi, *d_sDL, *d_sDR, *d_sGL, *d_sGR, *d_sS, *d_L, *d_x, *d_part, *d_scal;
     double *d_F, *d_R, *d_ubin, *d_aval, *d_Wsw, *d_Wrow, *d_Uvec;
     int *d_colptr, *d_rowidx, *d_rlptr, *d_rlcol, *d_rlpos, *d_rlrow, *d_binptr, *d_bincols, *d_dest, *d_fail, *d_map; long long* d_mapptr;
-    int *d_binroot_ptr, *d_binroot_idx, *d_broot_b, *d_broot_of_col, *d_anc_first, *d_anc_rel, *d_rel, *d_fa_src, *d_fa_col, *d_fa_tr, *d_frows, *d_lv_front, *d_lv_step, *d_asm_front, *d_asm_row, *d_xr_ptr, *d_xr_child, *d_xr_row, *d_fa_rowptr, *d_tile_item, *d_tile_ij;
+    int *d_binroot_ptr, *d_binroot_idx, *d_broot_b, *d_broot_of_col, *d_anc_first, *d_anc_rel, *d_rel, *d_fa_src, *d_fa_col, *d_fa_tr, *d_frows, *d_xr_ptr, *d_xr_child, *d_xr_row, *d_fa_rowptr;
     long long* d_broot_uoff; pg_front* d_FD; pg_child* d_CH;
     const int nf = n + ne, nblk = (nf + 255) / 256;
     TRY(dv.alloc(c, &d_X, n)); TRY(dv.alloc(c, &d_Xn, n)); TRY(dv.alloc(c, &d_meas, n)); TRY(dv.upload(c, &d_emeas, emeas));
@@ -1322,16 +1398,34 @@ static int pg_solve_impl(dsss_ctx* c, const double* dr6, int total, const dsss_l
     TRY(dv.alloc(c, &d_sGR, (size_t)nseg * 6)); TRY(dv.alloc(c, &d_sS, (size_t)nseg * 36));
     TRY(dv.alloc(c, &d_L, nnzL * 36)); TRY(dv.alloc(c, &d_x, (size_t)ns * 6)); TRY(dv.alloc(c, &d_part, (size_t)nblk)); TRY(dv.alloc(c, &d_scal, 8)); TRY(dv.alloc(c, &d_fail, 1));
     TRY(dv.alloc(c, &d_F, (size_t)S.front_doubles)); TRY(dv.alloc(c, &d_R, (size_t)S.frhs_doubles)); TRY(dv.alloc(c, &d_ubin, (size_t)S.ubin_doubles));
-    TRY(dv.alloc(c, &d_aval, (size_t)nval * 36));
+    // value array of the fronts; its tail IS the buffer the all-reduce sums: [interface values | interface right-hand sides |
+    // update matrices that cross into the interface | 8 scalars]
+    const size_t ncv = S.comm_vals.size(), nif = S.iface_seps.size();
+    const size_t comm_total = ncv * 36 + nif * 6 + (size_t)S.comm_doubles + 8;
+    TRY(dv.alloc(c, &d_aval, (size_t)nval * 36 + comm_total));
+    double* d_comm = d_aval + (size_t)nval * 36; double* d_avalif = d_comm; double* d_xif = d_comm + ncv * 36; double* d_commU = d_xif + nif * 6;
+    int *d_ifslot, *d_ifsep, *d_pk_child, *d_pk_row; pg_pack* d_PK; double* d_red;
+    { std::vector<int> ifslot(ns, -1); for (size_t q = 0; q < nif; ++q) ifslot[S.iface_seps[q]] = (int)q;
+      TRY(dv.upload(c, &d_ifslot, ifslot)); TRY(dv.upload(c, &d_ifsep, S.iface_seps)); TRY(dv.alloc(c, &d_red, 8)); }
     TRY(dv.upload(c, &d_colptr, S.colptr)); TRY(dv.upload(c, &d_rowidx, S.rowidx)); TRY(dv.upload(c, &d_rlptr, S.rlptr)); TRY(dv.upload(c, &d_rlcol, S.rlcol));
     TRY(dv.upload(c, &d_rlpos, S.rlpos)); TRY(dv.upload(c, &d_rlrow, S.rlrow)); TRY(dv.upload(c, &d_mapptr, S.mapptr)); TRY(dv.upload(c, &d_binptr, S.binptr)); TRY(dv.upload(c, &d_bincols, S.bincols));
     TRY(dv.upload(c, &d_dest, S.dest_bin));
     TRY(dv.upload(c, &d_binroot_ptr, S.binroot_ptr)); TRY(dv.upload(c, &d_binroot_idx, S.binroot_idx)); TRY(dv.upload(c, &d_broot_b, S.broot_b)); TRY(dv.upload(c, &d_broot_uoff, S.broot_uoff));
     TRY(dv.upload(c, &d_broot_of_col, S.broot_of_col)); TRY(dv.upload(c, &d_anc_first, S.anc_first)); TRY(dv.upload(c, &d_anc_rel, S.anc_rel));
     TRY(dv.upload(c, &d_rel, S.rel)); TRY(dv.upload(c, &d_fa_src, S.fa_src)); TRY(dv.upload(c, &d_fa_col, S.fa_col)); TRY(dv.upload(c, &d_fa_tr, S.fa_tr));
-    TRY(dv.upload(c, &d_frows, S.f_rows)); TRY(dv.upload(c, &d_lv_front, S.lv_front)); TRY(dv.upload(c, &d_lv_step, S.lv_step)); TRY(dv.upload(c, &d_asm_front, S.asmrow_front)); TRY(dv.upload(c, &d_asm_row, S.asmrow_row)); TRY(dv.upload(c, &d_xr_ptr, S.xr_ptr)); TRY(dv.upload(c, &d_xr_child, S.xr_child));
-    TRY(dv.upload(c, &d_xr_row, S.xr_row)); TRY(dv.upload(c, &d_fa_rowptr, S.fa_rowptr)); TRY(dv.upload(c, &d_tile_item, S.tile_item)); TRY(dv.upload(c, &d_tile_ij, S.tile_ij));
-    const int nbins = (int)S.binptr.size() - 1;
+    TRY(dv.upload(c, &d_frows, S.f_rows)); TRY(dv.upload(c, &d_xr_ptr, S.xr_ptr)); TRY(dv.upload(c, &d_xr_child, S.xr_child));
+    TRY(dv.upload(c, &d_xr_row, S.xr_row)); TRY(dv.upload(c, &d_fa_rowptr, S.fa_rowptr));
+    struct dsched { int *lv_front, *lv_step, *asm_front, *asm_row, *tile_item, *tile_ij; } DO = {}, DI = {};
+    for (int w2 = 0; w2 < 2; ++w2) {
+        const pg_sched& H = w2 ? SI : SO; dsched& Dv = w2 ? DI : DO;
+        TRY(dv.upload(c, &Dv.lv_front, H.lv_front)); TRY(dv.upload(c, &Dv.lv_step, H.lv_step)); TRY(dv.upload(c, &Dv.asm_front, H.asmrow_front)); TRY(dv.upload(c, &Dv.asm_row, H.asmrow_row));
+        TRY(dv.upload(c, &Dv.tile_item, H.tile_item)); TRY(dv.upload(c, &Dv.tile_ij, H.tile_ij));
+    }
+    // this rank's bins are one contiguous range (bins never straddle partitions, partitions are ascending in the order)
+    int bin_lo = 0, bin_hi = 0;
+    { const int nb_all = (int)S.binptr.size() - 1; while (bin_lo < nb_all && S.bin_part[bin_lo] < part_lo) ++bin_lo; bin_hi = bin_lo; while (bin_hi < nb_all && S.bin_part[bin_hi] < part_hi) ++bin_hi; }
+    const int nbins = bin_hi - bin_lo;
+    int n_pack = 0;
     {   // front and child descriptors (the children point straight at the update matrices: F22 of a front, U of a bin root)
         std::vector<pg_front> FD(nfr); std::vector<pg_child> CH(S.ch_kind.size());
         for (int f = 0; f < nfr; ++f) {
@@ -1344,22 +1438,25 @@ static int pg_solve_impl(dsss_ctx* c, const double* dr6, int total, const dsss_l
             if (S.ch_kind[q]) { const int ri = S.ch_id[q]; d.cb = S.broot_b[ri]; d.cld = 6 * d.cb; d.U = d_ubin + S.broot_uoff[ri]; d.g = d.U + (size_t)d.cld * d.cld; }
             else { const int gf = S.ch_id[q]; d.cb = S.f_n[gf] - S.f_s[gf]; d.cld = S.f_ld[gf]; d.U = d_F + S.f_off[gf] + (size_t)(6 * S.f_s[gf]) * d.cld + 6 * S.f_s[gf]; d.g = d_R + S.f_roff[gf] + 6 * S.f_s[gf]; }
         }
-        TRY(dv.upload(c, &d_FD, FD)); TRY(dv.upload(c, &d_CH, CH));
-    }
-    // launch shapes and algorithmic flops of every level
-    std::vector<int> lv_trsm_chunks(nlev, 0);
-    std::vector<double> fl_syrk(nlev, 0), fl_diag(nlev, 0), fl_trsm(nlev, 0), fl_bwd(nlev, 0);
-    int max_n6 = 6;
-    for (int l = 0; l < nlev; ++l) {
-        for (int q = S.lv_ptr[l]; q < S.lv_ptr[l + 1]; ++q) {
-            const int f = S.lv_front[q], k = S.lv_step[q], n6 = 6 * S.f_n[f], s6 = 6 * S.f_s[f];
-            const int w6 = std::min(96, s6 - 96 * k), nrows = n6 - 96 * k - w6;
-            max_n6 = std::max(max_n6, n6);
-            lv_trsm_chunks[l] = std::max(lv_trsm_chunks[l], (nrows + 63) / 64);
-            const double nn = w6, rows = nrows;
-            fl_diag[l] += nn * nn * nn / 3.0 + nn * nn; fl_trsm[l] += rows * nn * nn; fl_bwd[l] += 2.0 * rows * nn + nn * nn; fl_syrk[l] += rows * (rows + 1) * nn;
+        // children that cross from an interior into the interface are read from the summed buffer; the owner packs them there
+        std::vector<int> comm_of_front(nfr, -1), comm_of_broot(S.broot.size(), -1);
+        for (size_t q = 0; q < S.comm_kind.size(); ++q) (S.comm_kind[q] ? comm_of_broot[S.comm_id[q]] : comm_of_front[S.comm_id[q]]) = (int)q;
+        std::vector<pg_pack> PK(S.comm_kind.size()); std::vector<int> pk_child, pk_row;
+        for (int f = 0; f < nfr; ++f) {
+            if (S.f_part[f] >= 0) continue;
+            for (int q = S.ch_ptr[f]; q < S.ch_ptr[f + 1]; ++q) {
+                const int cq = S.ch_kind[q] ? comm_of_broot[S.ch_id[q]] : comm_of_front[S.ch_id[q]];
+                if (cq < 0) continue;
+                pg_child& d = CH[q];
+                pg_pack& k = PK[cq]; k.U = d.U; k.g = d.g; k.cld = d.cld; k.cb = d.cb; k.dst = d_commU + S.comm_off[cq];
+                d.U = k.dst; d.cld = 6 * d.cb; d.g = d.U + (size_t)d.cld * d.cld;
+                if (S.comm_part[cq] >= part_lo && S.comm_part[cq] < part_hi) for (int r2 = 0; r2 < d.cb; ++r2) { pk_child.push_back(cq); pk_row.push_back(r2); }
+            }
         }
+        TRY(dv.upload(c, &d_FD, FD)); TRY(dv.upload(c, &d_CH, CH)); TRY(dv.upload(c, &d_PK, PK)); TRY(dv.upload(c, &d_pk_child, pk_child)); TRY(dv.upload(c, &d_pk_row, pk_row));
+        n_pack = (int)pk_child.size();
     }
+    const int max_n6 = std::max(SO.max_n6, SI.max_n6);
     const long long mapsz = S.mapptr[ns];
     if (mapsz > (1LL << 31)) { dv.release(); DSSS_FAIL(c, DSSS_E_CAPACITY, "update map of %lld entries", mapsz); }
     TRY(dv.alloc(c, &d_map, (size_t)mapsz));
@@ -1375,11 +1472,29 @@ static int pg_solve_impl(dsss_ctx* c, const double* dr6, int total, const dsss_l
     }
     hipStream_t st = c->stream;
 #define HCK(x) do { hipError_t _e = (x); if (_e != hipSuccess) { c->err = std::string(#x) + ": " + hipGetErrorString(_e); dv.release(); return DSSS_E_HIP; } } while (0)
+    // sums over the factors are partial on every rank: one small all-reduce makes them global (and identical everywhere)
+    auto reduce_scalars = [&](double* host3, int* failed) -> int {
+        if (world > 1) {
+            hipLaunchKernelGGL(pg_comm_scal_kernel, dim3(1), dim3(64), 0, st, d_scal, d_fail, d_red);
+            int rc2 = dsss_comm_allreduce(c, d_red, 4, st); if (rc2) { dv.release(); return rc2; }
+            double h4[4];
+            HCK(hipMemcpyAsync(h4, d_red, 4 * sizeof(double), hipMemcpyDeviceToHost, st));
+            HCK(hipStreamSynchronize(st));
+            host3[0] = h4[0]; host3[1] = h4[1]; host3[2] = h4[2]; *failed = h4[3] != 0.0;
+        } else {
+            HCK(hipMemcpyAsync(host3, d_scal, 3 * sizeof(double), hipMemcpyDeviceToHost, st));
+            HCK(hipMemcpyAsync(failed, d_fail, sizeof(int), hipMemcpyDeviceToHost, st));
+            HCK(hipStreamSynchronize(st));
+        }
+        return DSSS_OK;
+    };
     auto error_of = [&](const pose_t* Xd, double* out) -> int {
-        hipLaunchKernelGGL(pg_linearize_kernel, dim3(nblk), dim3(256), 0, st, n, ne, Xd, d_meas, W, d_ea, d_eb, d_emeas, d_ew, (double*)nullptr, (double*)nullptr, d_part);
+        hipLaunchKernelGGL(pg_linearize_kernel, dim3(nblk), dim3(256), 0, st, n, ne, Xd, d_meas, W, d_ea, d_eb, d_emeas, d_ew, (double*)nullptr, (double*)nullptr, d_part, mp0, mp1);
         hipLaunchKernelGGL(pg_final_sum_kernel, dim3(1), dim3(256), 0, st, d_part, nblk, 0.5, d_scal);
-        HCK(hipMemcpyAsync(out, d_scal, sizeof(double), hipMemcpyDeviceToHost, st));
-        HCK(hipStreamSynchronize(st));
+        double h3[3]; int f0 = 0;
+        HCK(hipMemsetAsync(d_fail, 0, sizeof(int), st));
+        int rc2 = reduce_scalars(h3, &f0); if (rc2) return rc2;
+        *out = h3[0];
         return DSSS_OK;
     };
     {   // initial values
@@ -1419,60 +1534,78 @@ static int pg_solve_impl(dsss_ctx* c, const double* dr6, int total, const dsss_l
     err0 = err;
     if (err > 0 && c->pg.max_iters > 0) do {     // NonlinearOptimizer::defaultOptimize returns before iterating when maxIterations is reached
         cur = err;
-        double oldLin = 0;
-        hipLaunchKernelGGL(pg_linearize_kernel, dim3(nblk), dim3(256), 0, st, n, ne, d_X, d_meas, W, d_ea, d_eb, d_emeas, d_ew, d_r, d_Ji, d_part);
+        double oldLin = err;                                                   // linear error at delta = 0 == the error at X (same sum, already global)
+        hipLaunchKernelGGL(pg_linearize_kernel, dim3(nblk), dim3(256), 0, st, n, ne, d_X, d_meas, W, d_ea, d_eb, d_emeas, d_ew, d_r, d_Ji, d_part, mp0, mp1);
         hipLaunchKernelGGL(pg_final_sum_kernel, dim3(1), dim3(256), 0, st, d_part, nblk, 0.5, d_scal);
-        HCK(hipMemcpyAsync(&oldLin, d_scal, sizeof(double), hipMemcpyDeviceToHost, st));
         for (;;) {
             // ---- solve (H + lambda I) delta = -g ; lambda lives in device memory
             HCK(hipMemcpyAsync(d_scal + 3, &lambda, sizeof(double), hipMemcpyHostToDevice, st));
             {
                 hipMemsetAsync(d_fail, 0, sizeof(int), st);
                 hipMemsetAsync(d_L, 0, nnzL * 36 * sizeof(double), st);
-                hipLaunchKernelGGL(pg_assemble_kernel, dim3((n + 255) / 256), dim3(256), 0, st, n, W, d_r, d_Ji, d_adj_ptr, d_adj_edge, d_ew, d_scal + 3, d_D, d_C, d_g);
-                hipLaunchKernelGGL(pg_segment_kernel, dim3((nseg + 63) / 64), dim3(64), 0, st, nseg, d_sep, d_D, d_C, d_g, d_E, d_Dl, d_gi, d_sDL, d_sDR, d_sGL, d_sGR, d_sS, d_fail);
-                hipLaunchKernelGGL(pg_scatter_base_kernel, dim3((ns + 255) / 256), dim3(256), 0, st, ns, d_sep, d_perm, d_D, d_g, d_sDL, d_sDR, d_sGL, d_sGR, d_sS, d_dest, d_L, d_aval, d_x);
-                if (ne > 0) hipLaunchKernelGGL(pg_scatter_lc_kernel, dim3((ne + 255) / 256), dim3(256), 0, st, n, ne, ns, d_Ji, d_ew, d_dest, d_L, d_aval);
+                if (nparts > 1) hipMemsetAsync(d_comm, 0, comm_total * sizeof(double), st);
+                hipLaunchKernelGGL(pg_assemble_kernel, dim3((n + 255) / 256), dim3(256), 0, st, n, W, d_r, d_Ji, d_adj_ptr, d_adj_edge, d_ew, d_scal + 3, d_D, d_C, d_g, d_eb, mp0, mp1);
+                hipLaunchKernelGGL(pg_segment_kernel, dim3((nseg + 63) / 64), dim3(64), 0, st, nseg, d_sep, d_D, d_C, d_g, d_E, d_Dl, d_gi, d_sDL, d_sDR, d_sGL, d_sGR, d_sS, d_fail, mp0, mp1);
+                hipLaunchKernelGGL(pg_scatter_base_kernel, dim3((ns + 255) / 256), dim3(256), 0, st, ns, d_sep, d_perm, d_D, d_g, d_sDL, d_sDR, d_sGL, d_sGR, d_sS, d_dest, d_L, d_aval, d_x,
+                                   d_ifslot, d_avalif, d_xif, mp0, mp1);
+                if (ne > 0) hipLaunchKernelGGL(pg_scatter_lc_kernel, dim3((ne + 255) / 256), dim3(256), 0, st, n, ne, ns, d_Ji, d_ew, d_dest, d_L, d_aval, d_avalif, d_eb, mp0, mp1);
                 if (nbins > 0) { dsss_scope s1(c, DSSS_K_PG_SUBTREE);
-                                 hipLaunchKernelGGL(pg_factor_subtree_kernel, dim3(nbins), dim3(256), 0, st, d_binptr, d_bincols, d_colptr, d_rlptr, d_rlcol, d_rlpos, d_mapptr, d_map, d_L, d_x, d_fail,
-                                                    d_binroot_ptr, d_binroot_idx, d_broot_b, d_broot_uoff, d_broot_of_col, d_anc_first, d_anc_rel, d_ubin); }
+                                 hipLaunchKernelGGL(pg_factor_subtree_kernel, dim3(nbins), dim3(256), 0, st, d_binptr + bin_lo, d_bincols, d_colptr, d_rlptr, d_rlcol, d_rlpos, d_mapptr, d_map, d_L, d_x, d_fail,
+                                                    d_binroot_ptr + bin_lo, d_binroot_idx, d_broot_b, d_broot_uoff, d_broot_of_col, d_anc_first, d_anc_rel, d_ubin); }
                 // fronts, level by level: assemble the fronts that start here, then one panel step of every active front
-                for (int l = 0; l < nlev; ++l) {
-                    const int nas = S.asmrow_ptr[l + 1] - S.asmrow_ptr[l], nit = S.lv_ptr[l + 1] - S.lv_ptr[l], ntl = S.tile_ptr[l + 1] - S.tile_ptr[l];
-                    const int* itf = d_lv_front + S.lv_ptr[l]; const int* its = d_lv_step + S.lv_ptr[l];
-                    if (nas > 0) { dsss_scope s2(c, DSSS_K_PG_ASM);
-                        hipLaunchKernelGGL(pg_front_asm_kernel, dim3(nas), dim3(256), 0, st, d_asm_front + S.asmrow_ptr[l], d_asm_row + S.asmrow_ptr[l], d_FD, d_CH, d_rel, d_xr_ptr, d_xr_child, d_xr_row,
-                                           d_fa_rowptr, d_fa_src, d_fa_col, d_fa_tr, d_aval, d_x, d_F, d_R); }
-                    { dsss_scope s3(c, DSSS_K_PG_DIAG, fl_diag[l]);
-                      hipLaunchKernelGGL(pg_front_diag_kernel, dim3(nit), dim3(256), PG_DIAG_LDS, st, itf, its, d_FD, d_F, d_R, d_fail, d_Wsw, d_Wrow, d_Uvec); }
-                    if (lv_trsm_chunks[l] > 0) {
-                        { dsss_scope s4(c, DSSS_K_PG_TRSM, fl_trsm[l]);
-                          hipLaunchKernelGGL(pg_front_trsm_kernel, dim3(nit, lv_trsm_chunks[l]), dim3(256), 0, st, itf, its, d_FD, d_F, d_R, d_Wsw, d_Uvec); }
-                        { dsss_scope s5(c, DSSS_K_PG_ACC, fl_syrk[l]);
-                          if (ntl > 0) hipLaunchKernelGGL(pg_front_syrk_kernel, dim3(ntl), dim3(256), 0, st, itf, its, d_FD, d_tile_item + S.tile_ptr[l], d_tile_ij + S.tile_ptr[l], d_F); }
+                auto run_levels = [&](const pg_sched& H, const dsched& Dv) {
+                    for (int l = 0; l < H.nlev; ++l) {
+                        const int nas = H.asmrow_ptr[l + 1] - H.asmrow_ptr[l], nit = H.lv_ptr[l + 1] - H.lv_ptr[l], ntl = H.tile_ptr[l + 1] - H.tile_ptr[l];
+                        const int* itf = Dv.lv_front + H.lv_ptr[l]; const int* its = Dv.lv_step + H.lv_ptr[l];
+                        if (nas > 0) { dsss_scope s2(c, DSSS_K_PG_ASM);
+                            hipLaunchKernelGGL(pg_front_asm_kernel, dim3(nas), dim3(256), 0, st, Dv.asm_front + H.asmrow_ptr[l], Dv.asm_row + H.asmrow_ptr[l], d_FD, d_CH, d_rel, d_xr_ptr, d_xr_child, d_xr_row,
+                                               d_fa_rowptr, d_fa_src, d_fa_col, d_fa_tr, d_aval, d_x, d_F, d_R); }
+                        if (nit == 0) continue;
+                        { dsss_scope s3(c, DSSS_K_PG_DIAG, H.fl_diag[l]);
+                          hipLaunchKernelGGL(pg_front_diag_kernel, dim3(nit), dim3(256), PG_DIAG_LDS, st, itf, its, d_FD, d_F, d_R, d_fail, d_Wsw, d_Wrow, d_Uvec); }
+                        if (H.trsm_chunks[l] > 0) {
+                            { dsss_scope s4(c, DSSS_K_PG_TRSM, H.fl_trsm[l]);
+                              hipLaunchKernelGGL(pg_front_trsm_kernel, dim3(nit, H.trsm_chunks[l]), dim3(256), 0, st, itf, its, d_FD, d_F, d_R, d_Wsw, d_Uvec); }
+                            { dsss_scope s5(c, DSSS_K_PG_ACC, H.fl_syrk[l]);
+                              if (ntl > 0) hipLaunchKernelGGL(pg_front_syrk_kernel, dim3(ntl), dim3(256), 0, st, itf, its, d_FD, Dv.tile_item + H.tile_ptr[l], Dv.tile_ij + H.tile_ptr[l], d_F); }
+                        }
                     }
+                };
+                auto run_levels_bwd = [&](const pg_sched& H, const dsched& Dv) {
+                    for (int l = H.nlev - 1; l >= 0; --l) {
+                        const int nit = H.lv_ptr[l + 1] - H.lv_ptr[l];
+                        if (nit == 0) continue;
+                        dsss_scope s6(c, DSSS_K_PG_BWD, H.fl_bwd[l]);
+                        hipLaunchKernelGGL(pg_front_bwd_kernel, dim3(nit), dim3(1024), bwd_lds, st, Dv.lv_front + H.lv_ptr[l], Dv.lv_step + H.lv_ptr[l], d_FD, d_frows, d_F, d_R, d_x, d_Wrow);
+                    }
+                };
+                run_levels(SO, DO);
+                if (nparts > 1) {
+                    // the reduced Hessian on the interface: this rank's update matrices next to its share of the interface values and
+                    // right-hand sides, summed over the ranks by ONE all-reduce; then the small replicated interface factorisation
+                    if (n_pack > 0) hipLaunchKernelGGL(pg_comm_pack_kernel, dim3(n_pack), dim3(256), 0, st, d_pk_child, d_pk_row, d_PK);
+                    { dsss_scope s8(c, DSSS_K_PG_COMM, (double)comm_total * 8);
+                      int rc2 = dsss_comm_allreduce(c, d_comm, comm_total - 8, st); if (rc2) { dv.release(); return rc2; } }
+                    if (nif > 0) hipLaunchKernelGGL(pg_comm_xif_kernel, dim3(((int)nif + 255) / 256), dim3(256), 0, st, (int)nif, d_ifsep, d_perm, d_xif, d_x);
+                    run_levels(SI, DI);
+                    run_levels_bwd(SI, DI);
                 }
-                for (int l = nlev - 1; l >= 0; --l) {
-                    dsss_scope s6(c, DSSS_K_PG_BWD, fl_bwd[l]);
-                    hipLaunchKernelGGL(pg_front_bwd_kernel, dim3(S.lv_ptr[l + 1] - S.lv_ptr[l]), dim3(1024), bwd_lds, st, d_lv_front + S.lv_ptr[l], d_lv_step + S.lv_ptr[l], d_FD, d_frows, d_F, d_R, d_x, d_Wrow);
-                }
+                run_levels_bwd(SO, DO);
                 if (nbins > 0) { dsss_scope s7(c, DSSS_K_PG_SUBTREE);
-                    hipLaunchKernelGGL(pg_bwd_subtree_kernel, dim3(nbins), dim3(64), 0, st, d_binptr, d_bincols, d_colptr, d_rowidx, d_L, d_x); }
+                    hipLaunchKernelGGL(pg_bwd_subtree_kernel, dim3(nbins), dim3(64), 0, st, d_binptr + bin_lo, d_bincols, d_colptr, d_rowidx, d_L, d_x); }
                 hipLaunchKernelGGL(pg_sep_delta_kernel, dim3((ns + 255) / 256), dim3(256), 0, st, ns, d_sep, d_perm, d_x, d_delta);
-                hipLaunchKernelGGL(pg_backsub_kernel, dim3((nseg + 63) / 64), dim3(64), 0, st, nseg, d_sep, d_C, d_E, d_Dl, d_gi, d_delta);
-                hipLaunchKernelGGL(pg_linerr_kernel, dim3(nblk), dim3(256), 0, st, n, ne, W, d_ea, d_eb, d_ew, d_r, d_Ji, d_delta, d_part);
+                hipLaunchKernelGGL(pg_backsub_kernel, dim3((nseg + 63) / 64), dim3(64), 0, st, nseg, d_sep, d_C, d_E, d_Dl, d_gi, d_delta, mp0, mp1);
+                hipLaunchKernelGGL(pg_linerr_kernel, dim3(nblk), dim3(256), 0, st, n, ne, W, d_ea, d_eb, d_ew, d_r, d_Ji, d_delta, d_part, mp0, mp1);
                 hipLaunchKernelGGL(pg_final_sum_kernel, dim3(1), dim3(256), 0, st, d_part, nblk, 0.5, d_scal + 1);
             }
             ++nfact;
             // X and Xn swap between trials, so these two stay outside the captured graph
             hipLaunchKernelGGL(pg_retract_kernel, dim3((n + 255) / 256), dim3(256), 0, st, n, d_X, d_delta, d_Xn);
-            hipLaunchKernelGGL(pg_linearize_kernel, dim3(nblk), dim3(256), 0, st, n, ne, d_Xn, d_meas, W, d_ea, d_eb, d_emeas, d_ew, (double*)nullptr, (double*)nullptr, d_part);
+            hipLaunchKernelGGL(pg_linearize_kernel, dim3(nblk), dim3(256), 0, st, n, ne, d_Xn, d_meas, W, d_ea, d_eb, d_emeas, d_ew, (double*)nullptr, (double*)nullptr, d_part, mp0, mp1);
             hipLaunchKernelGGL(pg_final_sum_kernel, dim3(1), dim3(256), 0, st, d_part, nblk, 0.5, d_scal + 2);
             HCK(hipGetLastError());
             double h[3]; int failed = 0;
-            HCK(hipMemcpyAsync(h, d_scal, 3 * sizeof(double), hipMemcpyDeviceToHost, st));
-            HCK(hipMemcpyAsync(&failed, d_fail, sizeof(int), hipMemcpyDeviceToHost, st));
-            HCK(hipStreamSynchronize(st));
+            { int rc2 = reduce_scalars(h, &failed); if (rc2) return rc2; }
             const bool ok = !failed && std::isfinite(h[1]);
             bool success = false, stop = false;
             double newErr = 0;
@@ -1492,6 +1625,10 @@ static int pg_solve_impl(dsss_ctx* c, const double* dr6, int total, const dsss_l
     } while (iters < c->pg.max_iters && !((err <= 0) || ((cur - err) / cur <= c->pg.rel_tol) || ((cur - err) <= c->pg.abs_tol)) && std::isfinite(cur));
     const auto T4 = std::chrono::steady_clock::now();
     const double t_lm = ms_since(T3);
+    if (world > 1) {    // every rank holds its own poses (and the interface): zero the rest, sum -> the whole trajectory everywhere
+        hipLaunchKernelGGL(pg_mask_own_kernel, dim3((n + 255) / 256), dim3(256), 0, st, n, d_X, mp0, mp1);
+        int rc2 = dsss_comm_allreduce(c, (double*)d_X, (size_t)n * 12, st); if (rc2) { dv.release(); return rc2; }
+    }
     if (poses12) {      // pose_t is 12 contiguous doubles (R row-major, t): straight into the caller's buffer
         static_assert(sizeof(pose_t) == 12 * sizeof(double), "pose_t layout");
         HCK(hipMemcpyAsync(poses12, d_X, (size_t)n * sizeof(pose_t), hipMemcpyDeviceToHost, st));
@@ -1663,6 +1800,47 @@ int dsss_posegraph_solve(dsss_ctx* c, int nframes, double* poses12, double* rpy6
     const auto t1 = std::chrono::steady_clock::now();
     int rc = dsss_posegraph_select(c, nframes, edges.data(), (int)edges.size(), &ne);
     if (rc) return rc;
+    const int world = dsss_comm_world(c), rank = dsss_comm_rank(c);
+    if (world > 1) {
+        // every rank selected the loop closures of the pairs it matched (pairs go to the owner of the TARGET frame, so a target
+        // ping's "last pair wins" choice is rank-local): exchange them with two small all-reduces (counts, then the records in
+        // rank order = ascending target pose, the reference's loop order)
+        std::vector<double> cnt(world, 0.0); cnt[rank] = ne;
+        double* d_tmp = nullptr;
+        HIPCHK(c, hipMalloc(&d_tmp, world * sizeof(double)));
+        hipError_t e = hipMemcpyAsync(d_tmp, cnt.data(), world * sizeof(double), hipMemcpyHostToDevice, c->stream);
+        if (e == hipSuccess) { rc = dsss_comm_allreduce(c, d_tmp, world, c->stream); if (rc) { hipFree(d_tmp); return rc; } }
+        if (e == hipSuccess) e = hipMemcpyAsync(cnt.data(), d_tmp, world * sizeof(double), hipMemcpyDeviceToHost, c->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        hipFree(d_tmp);
+        HIPCHK(c, e);
+        size_t off = 0, tot = 0;
+        for (int r = 0; r < world; ++r) { if (r < rank) off += (size_t)cnt[r]; tot += (size_t)cnt[r]; }
+        std::vector<double> rec(std::max<size_t>(tot, 1) * 20, 0.0);
+        for (int i = 0; i < ne; ++i) {
+            double* q = rec.data() + (off + i) * 20;
+            q[0] = edges[i].a; q[1] = edges[i].b;
+            for (int k = 0; k < 12; ++k) q[2 + k] = edges[i].rel[k];
+            for (int k = 0; k < 6; ++k) q[14 + k] = edges[i].var[k];
+        }
+        if (tot > 0) {
+            HIPCHK(c, hipMalloc(&d_tmp, rec.size() * sizeof(double)));
+            e = hipMemcpyAsync(d_tmp, rec.data(), rec.size() * sizeof(double), hipMemcpyHostToDevice, c->stream);
+            if (e == hipSuccess) { rc = dsss_comm_allreduce(c, d_tmp, tot * 20, c->stream); if (rc) { hipFree(d_tmp); return rc; } }
+            if (e == hipSuccess) e = hipMemcpyAsync(rec.data(), d_tmp, rec.size() * sizeof(double), hipMemcpyDeviceToHost, c->stream);
+            if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+            hipFree(d_tmp);
+            HIPCHK(c, e);
+        }
+        edges.resize(std::max<size_t>(tot, 1)); ne = (int)tot;
+        for (int i = 0; i < ne; ++i) {
+            const double* q = rec.data() + (size_t)i * 20;
+            edges[i].a = (int)q[0]; edges[i].b = (int)q[1];
+            for (int k = 0; k < 12; ++k) edges[i].rel[k] = q[2 + k];
+            for (int k = 0; k < 6; ++k) edges[i].var[k] = q[14 + k];
+        }
+        std::stable_sort(edges.begin(), edges.begin() + ne, [](const dsss_lc_edge& x, const dsss_lc_edge& y) { return x.b < y.b; });
+    }
     const double t_sel = ms(t1);
     const auto t2 = std::chrono::steady_clock::now();
     rc = pg_solve_impl(c, nullptr, (int)total, edges.data(), ne, poses12, stats4, rpy6, nframes);

@@ -471,16 +471,6 @@ void pg_symbolic(int ns, const std::vector<std::pair<int, int>>& edges, int ncha
                 const long long r0 = S.ch_relptr[c], r1 = S.ch_relptr[c + 1];
                 for (long long q = r0; q < r1; ++q) { const int at = fp[S.f_rowptr[f] + S.rel[q]]++; S.xr_child[at] = c; S.xr_row[at] = (int)(q - r0); }
             }
-        S.asmrow_ptr.assign(S.nlev + 1, 0); S.tile_ptr.assign(S.nlev + 1, 0);
-        for (int l = 0; l < S.nlev; ++l) {
-            for (int q = S.asm_ptr[l]; q < S.asm_ptr[l + 1]; ++q) { const int f = S.asm_front[q]; for (int r = 0; r < S.f_n[f]; ++r) { S.asmrow_front.push_back(f); S.asmrow_row.push_back(r); } }
-            S.asmrow_ptr[l + 1] = (int)S.asmrow_front.size();
-            for (int q = S.lv_ptr[l]; q < S.lv_ptr[l + 1]; ++q) {
-                const int f = S.lv_front[q], k = S.lv_step[q], w6 = std::min(96, 6 * S.f_s[f] - 96 * k), nrows = 6 * S.f_n[f] - 96 * k - w6, nt = (nrows + 63) / 64;
-                for (int ti = 0; ti < nt; ++ti) for (int tj = 0; tj <= ti; ++tj) { S.tile_item.push_back(q - S.lv_ptr[l]); S.tile_ij.push_back((ti << 16) | tj); }
-            }
-            S.tile_ptr[l + 1] = (int)S.tile_item.size();
-        }
     }
     // ---- children that cross from a rank's interior into the interface
     {
@@ -497,6 +487,20 @@ void pg_symbolic(int ns, const std::vector<std::pair<int, int>>& edges, int ncha
             }
         }
         S.comm_doubles = o;
+        // original values of interface fronts and the interface separators
+        S.nval = nval;
+        if (S.nparts > 1) {
+            std::vector<int> slot_of(nval, -1);
+            for (int f = 0; f < nf; ++f) {
+                if (S.f_part[f] >= 0) continue;
+                for (int e = S.fa_ptr[f]; e < S.fa_ptr[f + 1]; ++e) {
+                    const int v = S.fa_src[e];
+                    if (slot_of[v] < 0) { slot_of[v] = (int)S.comm_vals.size(); S.comm_vals.push_back(v); S.dest_bin[v] = -2 - slot_of[v]; }
+                    S.fa_src[e] = nval + slot_of[v];
+                }
+            }
+            for (int k = 0; k < ns; ++k) if (S.col_part[S.perm[k]] < 0) S.iface_seps.push_back(k);
+        }
     }
     // statistics
     for (int j = 0; j < ns; ++j) { const double m = csz(j) - 1; S.flops_factor += 36.0 * 6.0 * (m * m + 3 * m) + 72.0; }
@@ -507,6 +511,33 @@ void pg_symbolic(int ns, const std::vector<std::pair<int, int>>& edges, int ncha
         fprintf(stderr, "[dsss pg symbolic] adjacency+ND %.1f ms, column structures %.1f ms, bins+lists %.1f ms, fronts+schedule %.1f ms | ns %d nnzL %lld bins %d (%zu cols, %zu roots, U %.1f MB) fronts %d (>100 rows: %d, max %d) panels %d levels %d front arena %.1f MB comm %.1f MB front GFLOP %.1f (column count %.1f)\n",
                 tms(q0, q1), tms(q1, q2), tms(q2, q3), tms(q3, tnow()), ns, S.nnzL, (int)S.binptr.size() - 1, S.bincols.size(), S.broot.size(), S.ubin_doubles * 8e-6,
                 nf, big, S.max_front_n, S.npanels, S.nlev, S.front_doubles * 8e-6, S.comm_doubles * 8e-6, S.flops_fronts * 1e-9, S.flops_factor * 1e-9);
+    }
+}
+
+void pg_build_schedule(const pg_sym& S, int part_lo, int part_hi, pg_sched& out)
+{
+    out = pg_sched();
+    out.nlev = S.nlev;
+    const int nl = S.nlev;
+    out.lv_ptr.assign(nl + 1, 0); out.asmrow_ptr.assign(nl + 1, 0); out.tile_ptr.assign(nl + 1, 0);
+    out.trsm_chunks.assign(nl, 0); out.fl_diag.assign(nl, 0); out.fl_trsm.assign(nl, 0); out.fl_syrk.assign(nl, 0); out.fl_bwd.assign(nl, 0);
+    auto sel = [&](int f) { return S.f_part[f] >= part_lo && S.f_part[f] < part_hi; };
+    for (int l = 0; l < nl; ++l) {
+        for (int q = S.asm_ptr[l]; q < S.asm_ptr[l + 1]; ++q) { const int f = S.asm_front[q]; if (!sel(f)) continue; for (int r = 0; r < S.f_n[f]; ++r) { out.asmrow_front.push_back(f); out.asmrow_row.push_back(r); } }
+        out.asmrow_ptr[l + 1] = (int)out.asmrow_front.size();
+        for (int q = S.lv_ptr[l]; q < S.lv_ptr[l + 1]; ++q) {
+            const int f = S.lv_front[q], k = S.lv_step[q];
+            if (!sel(f)) continue;
+            const int item = (int)out.lv_front.size() - out.lv_ptr[l];
+            out.lv_front.push_back(f); out.lv_step.push_back(k);
+            const int n6 = 6 * S.f_n[f], w6 = std::min(96, 6 * S.f_s[f] - 96 * k), nrows = n6 - 96 * k - w6, nt = (nrows + 63) / 64;
+            for (int ti = 0; ti < nt; ++ti) for (int tj = 0; tj <= ti; ++tj) { out.tile_item.push_back(item); out.tile_ij.push_back((ti << 16) | tj); }
+            out.max_n6 = std::max(out.max_n6, n6);
+            out.trsm_chunks[l] = std::max(out.trsm_chunks[l], (nrows + 63) / 64);
+            const double nn = w6, rows = nrows;
+            out.fl_diag[l] += nn * nn * nn / 3.0 + nn * nn; out.fl_trsm[l] += rows * nn * nn; out.fl_bwd[l] += 2.0 * rows * nn + nn * nn; out.fl_syrk[l] += rows * (rows + 1) * nn;
+        }
+        out.lv_ptr[l + 1] = (int)out.lv_front.size(); out.tile_ptr[l + 1] = (int)out.tile_item.size();
     }
 }
 
@@ -589,7 +620,8 @@ int pg_host_solve(const pg_sym& S, int ne, const std::vector<std::pair<int, int>
         const int ld = S.f_ld[f], s6 = 6 * S.f_s[f], n6 = 6 * S.f_n[f], c0 = S.f_c0[f];
         double* A = &F[(size_t)S.f_off[f]]; double* r = &R[(size_t)S.f_roff[f]];
         for (int e = S.fa_ptr[f]; e < S.fa_ptr[f + 1]; ++e) {
-            const double* B = aval + (size_t)S.fa_src[e] * 36; const int tr = S.fa_tr[e];
+            const int vsrc = S.fa_src[e] >= S.nval ? S.comm_vals[S.fa_src[e] - S.nval] : S.fa_src[e];
+            const double* B = aval + (size_t)vsrc * 36; const int tr = S.fa_tr[e];
             for (int a = 0; a < 6; ++a) for (int b = 0; b < 6; ++b) A[(size_t)(S.fa_row[e] * 6 + a) * ld + S.fa_col[e] * 6 + b] += tr ? B[b * 6 + a] : B[a * 6 + b];
         }
         for (int i = 0; i < s6; ++i) r[i] = x[(size_t)c0 * 6 + i];

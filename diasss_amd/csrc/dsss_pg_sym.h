@@ -69,15 +69,30 @@ struct pg_sym {
     int nlev = 0, npanels = 0;
     std::vector<int> lv_ptr, lv_front, lv_step;
     std::vector<int> asm_ptr, asm_front;
-    std::vector<int> asmrow_ptr, asmrow_front, asmrow_row;     // (front, block row) work items of the assembly per level
-    std::vector<int> tile_ptr, tile_item, tile_ij;             // (panel item within its level, ti << 16 | tj) 64 x 64 trailing-update tiles per level
     // ---- ranks: children that cross from an interior front / bin root into an interface front ("comm children")
     std::vector<int> comm_kind, comm_id, comm_part;  // the crossing children in a fixed global order
-    std::vector<long long> comm_off;    // packed offset (doubles) in the comm buffer: (6b)^2 + 6b each
+    std::vector<long long> comm_off;    // packed offset (doubles) in the update-matrix part of the comm buffer: (6b)^2 + 6b each
     long long comm_doubles = 0;
+    // original values whose destination is an interface front (summed over the ranks too): value index list; their
+    // dest_bin code is -2 - slot and the fronts read them at value index nval + slot.  Interface separators (chain order).
+    std::vector<int> comm_vals, iface_seps;
+    int nval = 0;
     // statistics
     double flops_factor = 0, flops_fronts = 0; long long nnzL = 0; int max_front_n = 0;
 };
+
+// launch lists of a subset of the fronts (all of them, one rank's interior, or the interface), level by level
+struct pg_sched {
+    int nlev = 0;
+    std::vector<int> lv_ptr, lv_front, lv_step;                // panel steps per level
+    std::vector<int> asmrow_ptr, asmrow_front, asmrow_row;     // (front, block row) work items of the assembly per level
+    std::vector<int> tile_ptr, tile_item, tile_ij;             // (panel item within its level, ti << 16 | tj) 64 x 64 trailing-update tiles per level
+    std::vector<int> trsm_chunks;                              // 64-row chunks below the panel, maximum over the level's items
+    std::vector<double> fl_diag, fl_trsm, fl_syrk, fl_bwd;     // algorithmic flops per level
+    int max_n6 = 6;
+};
+// part_lo <= front part < part_hi selects fronts; (-1, 0) selects the interface fronts
+void pg_build_schedule(const pg_sym& S, int part_lo, int part_hi, pg_sched& out);
 
 struct pg_sym_opts {
     int leaf = 24;                      // nested-dissection leaf size

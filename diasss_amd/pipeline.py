@@ -4,12 +4,15 @@
     for every i < j:   FEAmatcher::RobustMatching      -> dsss_match_pairs (batched, all pairs in one call)
     Optimizer::TrajOptimizationAll                     -> dsss_lc_solve_all + dsss_posegraph_solve
 
-One process per GPU.  With world_size > 1 (torch.distributed, backend nccl == RCCL on ROCm, or gloo on CPU for the
-sharding logic tests) the work is sharded as:
-    extraction   frames round-robin over ranks, then ONE all-gather of the packed per-frame feature records;
+One process per GPU.  With world_size > 1 the ranks form a communicator INSIDE the library (dsss_comm_init: RCCL over xGMI;
+torch.distributed only carries the 128-byte RCCL id to the other ranks -- or, with the gloo backend on a one-GPU test box,
+serves as the host-callback transport) and the work is sharded as:
+    extraction   contiguous blocks of frames per rank, then ONE all-gather of the packed per-frame feature records;
     matching+LC  every pair (s, t) goes to the rank that owns target frame t, so the "last pair wins" loop-closure
-                 selection (optimizer.cpp:203-231) stays rank-local; then ONE all-gather of the selected LC edges;
-    pose graph   replicated batch LM (identical on every rank).
+                 selection (optimizer.cpp:203-231) stays rank-local;
+    pose graph   every rank eliminates the poses of its own frames; ONE all-reduce per LM trial sums the reduced Hessian on
+                 the interface poses (interface blocks | Schur complements | gradient), then a small replicated interface
+                 solve and the local back-substitution (dsss_pg.hip).
 """
 import numpy as np
 
@@ -23,11 +26,21 @@ def all_pairs(F):
 
 
 def shard_frames(F, rank, world):
-    return [f for f in range(F) if f % world == rank]
+    """contiguous block of frames of a rank: [F rank / world, F (rank + 1) / world) -- dsss_comm_frame_owner"""
+    return list(range(F * rank // world, F * (rank + 1) // world))
 
 
-def shard_pairs(src, tgt, rank, world):
-    keep = (tgt % world) == rank
+def frame_owner(F, world):
+    own = np.zeros(F, np.int64)
+    for r in range(world):
+        own[F * r // world:F * (r + 1) // world] = r
+    return own
+
+
+def shard_pairs(src, tgt, rank, world, F=None):
+    """pairs whose TARGET frame this rank owns"""
+    F = int(max(src.max(initial=0), tgt.max(initial=0)) + 1) if F is None else F
+    keep = frame_owner(F, world)[tgt] == rank
     return src[keep], tgt[keep]
 
 
@@ -39,12 +52,32 @@ def merge_edges(edge_lists):
     return edges
 
 
+def make_comm(ctx, dist, rank, world):
+    """join the library's communicator: RCCL when torch.distributed runs on nccl, the host callback over gloo otherwise"""
+    import torch
+    if dist.get_backend() == "nccl":
+        uid = torch.from_numpy(ctx.comm_unique_id() if rank == 0 else np.zeros(128, np.uint8)).cuda()
+        dist.broadcast(uid, 0)
+        torch.cuda.synchronize()
+        ctx.comm_init_rccl(uid.cpu().numpy(), rank, world)
+    else:
+        def fn(op, arr):
+            t = torch.from_numpy(arr)
+            if op == 0:
+                dist.all_reduce(t)
+            else:
+                mine = t[rank].clone()
+                dist.all_gather_into_tensor(t.view(-1), mine)
+        ctx.comm_init_callback(rank, world, fn)
+
+
 class Pipeline:
     def __init__(self, F, device=0, rank=0, world=1, dist=None, min_overlap=None, ctx=None, force_collectives=False):
         self.F, self.rank, self.world, self.dist = F, rank, world, dist
-        self.collectives = world > 1 or (force_collectives and dist is not None)   # the 1-rank RCCL test drives the same code path
         self.ctx = ctx if ctx is not None else capi.Context(max_frames=F, device=device)   # ctx injection: sharding tests
         self.min_overlap = min_overlap      # None: dense all-pairs (BASELINE configs); 0.4 reproduces diasss2.cpp:28,93
+        if (world > 1 or force_collectives) and dist is not None and ctx is None:
+            make_comm(self.ctx, dist, rank, world)       # a 1-rank RCCL communicator drives the same code path
 
     def close(self):
         self.ctx.close()
@@ -62,29 +95,9 @@ class Pipeline:
                 self.ctx.frame_set(f, raws[f], self.N[f], self.M[f], poses[f], alts[f], grs[f])
 
     def extract(self):
-        mine = shard_frames(self.F, self.rank, self.world)
-        self.ctx.extract_many(mine)
-        if self.collectives:
-            self._allgather_features(mine)
-
-    def _allgather_features(self, mine):
-        import torch
-        dist = self.dist
-        nb = self.ctx.pack_bytes()
-        per = (self.F + self.world - 1) // self.world
-        dev = "cuda" if dist.get_backend() == "nccl" else "cpu"
-        send = torch.zeros((per, nb), dtype=torch.uint8, device=dev)
-        for k, f in enumerate(mine):
-            self.ctx.features_pack(f, send[k])
-        recv = torch.empty((self.world * per, nb), dtype=torch.uint8, device=dev)     # concatenated along dim 0
-        dist.all_gather_into_tensor(recv, send)
-        if dev == "cuda":
-            torch.cuda.synchronize()      # the library reads `recv` on its own HIP stream: order it after the RCCL collective
-        for r in range(self.world):
-            if r == self.rank and self.world > 1:
-                continue                   # (a 1-rank group unpacks its own records: exercises the device-pointer path)
-            for k, f in enumerate(shard_frames(self.F, r, self.world)):
-                self.ctx.features_unpack(f, recv[r * per + k])
+        self.ctx.extract_many(shard_frames(self.F, self.rank, self.world))
+        if self.world > 1:
+            self.ctx.features_allgather(self.F)      # one all-gather of the packed feature records, inside the library
 
     # ---- stage 2: matching + loop-closure measurements
     def match(self):
@@ -92,43 +105,17 @@ class Pipeline:
         if self.min_overlap is not None:
             keep = np.array([self.ctx.overlap(int(i), int(j)) > self.min_overlap for i, j in zip(src, tgt)], bool)
             src, tgt = src[keep], tgt[keep]
-        self.src, self.tgt = shard_pairs(src, tgt, self.rank, self.world)
+        self.src, self.tgt = shard_pairs(src, tgt, self.rank, self.world, self.F)
         self.ctx.match_pairs(self.src, self.tgt)
         self.ctx.lc_solve_all()
 
-    # ---- stage 3: pose graph
+    # ---- stage 3: pose graph (sharded inside the library when the context joined a communicator)
     def optimize(self):
         total = int(sum(self.N))
-        if not self.collectives:
-            # est_poses into a page-locked buffer of the context (valid until the next solve); the rpy rows are only for SaveTrajactoryAll
-            poses, _, stats = self.ctx.posegraph_solve(self.F, total, want_rpy=False, pinned=True)
-            self.n_edges = None
-            return poses, stats
-        edges = self.ctx.posegraph_select(self.F, cap=max(total, 1))
-        edges = self._allgather_edges(edges)
-        self.n_edges = len(edges)
-        dr = np.concatenate(self.poses)
-        return self.ctx.posegraph_solve_edges(dr, edges)
-
-    def _allgather_edges(self, edges):
-        import torch
-        dist = self.dist
-        dev = "cuda" if dist.get_backend() == "nccl" else "cpu"
-        cnt = torch.tensor([len(edges)], dtype=torch.int64, device=dev)
-        cnts = [torch.zeros_like(cnt) for _ in range(self.world)]
-        dist.all_gather(cnts, cnt)
-        cnts = [int(c.item()) for c in cnts]
-        mx = max(max(cnts), 1)
-        isz = capi.LCEDGE_DTYPE.itemsize
-        buf = np.zeros(mx * isz, np.uint8)
-        buf[:len(edges) * isz] = edges.view(np.uint8).reshape(-1)
-        send = torch.from_numpy(buf).to(dev)
-        recv = torch.empty(self.world * mx * isz, dtype=torch.uint8, device=dev)
-        dist.all_gather_into_tensor(recv, send)
-        if dev == "cuda":
-            torch.cuda.synchronize()
-        recv = recv.cpu().numpy().reshape(self.world, mx * isz)
-        return merge_edges([recv[r, :cnts[r] * isz].copy().view(capi.LCEDGE_DTYPE) for r in range(self.world)])
+        # est_poses into a page-locked buffer of the context (valid until the next solve); the rpy rows are only for SaveTrajactoryAll
+        poses, _, stats = self.ctx.posegraph_solve(self.F, total, want_rpy=False, pinned=True)
+        self.n_edges = None
+        return poses, stats
 
     def run(self, raws, poses, alts, grs):
         self.set_frames(raws, poses, alts, grs)

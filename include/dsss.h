@@ -32,6 +32,7 @@ extern "C" {
 #define DSSS_E_STATE      -4   /* call order violated (e.g. match before features exist) */
 #define DSSS_E_CAPACITY   -5   /* a caller buffer or an internal fixed-capacity buffer is too small */
 #define DSSS_E_NUMERIC    -6   /* linear system not positive definite / non-finite value */
+#define DSSS_E_COMM       -7   /* RCCL not available / a collective failed */
 
 typedef struct dsss_ctx dsss_ctx;
 
@@ -70,6 +71,29 @@ int  dsss_sync(dsss_ctx*);                       /* hipStreamSynchronize of the 
 void* dsss_stream(dsss_ctx*);                    /* hipStream_t, for event timing by the caller */
 int  dsss_set_params(dsss_ctx*, const dsss_mask_params*, const dsss_orb_params*, const dsss_match_params*,
                      const dsss_pg_params*);     /* NULL keeps the current (default = reference) values */
+
+/* ------------------------------------------------------------------ ranks (new: the reference is one process, one thread)
+ * One process per GPU.  A context that joined a communicator shards the pose-graph solve of dsss_posegraph_solve[_edges]:
+ * contiguous blocks of frames (poses) per rank, every rank eliminates its own block, and ONE all-reduce per LM trial sums the
+ * reduced Hessian on the interface poses ([interface blocks | Schur complements | gradient]) before the small replicated
+ * interface solve.  Every rank must make the same calls with the same frames and the same (all-gathered) LC edges.
+ * dsss_comm_init: RCCL (ncclCommInitRank with the 128-byte id of dsss_comm_unique_id, distributed by the caller's launcher);
+ * dsss_comm_init_callback: the caller sums a host buffer in place (tests on a one-GPU box, e.g. over gloo).               */
+/* op 0: in-place sum over the ranks of n doubles in host_buf.  op 1: all-gather, host_buf holds world x n bytes, the caller's
+ * own n bytes are in place at rank * n, the others are to be filled in.  Return 0 on success.                          */
+typedef int (*dsss_comm_fn)(void* user, int op, void* host_buf, size_t n);
+int dsss_comm_unique_id(void* id128_out);
+int dsss_comm_init(dsss_ctx*, const void* id128, int rank, int world);
+int dsss_comm_init_callback(dsss_ctx*, int rank, int world, dsss_comm_fn fn, void* user);
+int dsss_comm_destroy(dsss_ctx*);
+int dsss_comm_stats(dsss_ctx*, int* rank, int* world, double* allreduce_bytes, int64_t* allreduce_calls);
+/* frames are owned in contiguous blocks: rank r owns frames [nframes r / world, nframes (r+1) / world)                     */
+int dsss_comm_frame_owner(const dsss_ctx*, int nframes, int frame);
+/* after every rank extracted the frames it owns: exchange the per-frame feature records (C1 of SURVEY.md 2a, one all-gather)
+ * so that every rank holds the features of all nframes frames                                                             */
+int dsss_features_allgather(dsss_ctx*, int nframes);
+/* number of pose-graph partitions (default 0 = one per rank); more partitions than ranks only exercise the interface path */
+int dsss_set_pg_partitions(dsss_ctx*, int nparts);
 
 /* ------------------------------------------------------------------ Frame (frame.h:19-20, frame.cpp:18-55)
  * Frame::Frame(id, img CV_64F NxM, pose CV_64F Nx6 [roll pitch yaw x y z], altitudes[N], ground_ranges[M/2], anno)
@@ -182,7 +206,8 @@ int dsss_host_pg_solve(int ns, const int32_t* edge_a, const int32_t* edge_b, int
 #define DSSS_K_PG_BWD      17   /* pg_front_bwd_kernel */
 #define DSSS_K_PG_SUBTREE  18   /* pg_factor_subtree_kernel + pg_bwd_subtree_kernel */
 #define DSSS_K_PG_ASM      19   /* pg_front_asm_kernel (extend-add) */
-#define DSSS_K_COUNT       20
+#define DSSS_K_PG_COMM     20   /* the reduced-Hessian all-reduce of a trial (work = bytes) */
+#define DSSS_K_COUNT       22
 int dsss_profile_enable(dsss_ctx*, int on);
 int dsss_profile_get(dsss_ctx*, double* ms_host /*DSSS_K_COUNT*/, int64_t* launches_host /*DSSS_K_COUNT*/);
 int dsss_profile_reset(dsss_ctx*);
