@@ -913,6 +913,273 @@ __global__ __launch_bounds__(1024) void pg_front_bwd_kernel(const int* __restric
 }
 
 
+// ---- panel kernels without an explicit inverse: the whole 96 x 96 panel lives in the registers of ONE wavefront as 16 x 16
+// MFMA accumulator tiles and is factorised RIGHT-LOOKING IN BLOCKS OF FOUR COLUMNS, every rank-4 update being one
+// v_mfma_f64_16x16x4_f64 per tile (K = 4 is exactly one instruction).  Tile (T, I), T <= I, holds the symmetric matrix
+// TRANSPOSED: D[i][j] = M[16 I + j][16 T + i], i.e. lane (j = l & 15, q = l >> 4), register v holds M[16 I + j][16 T + q + 4 v].
+// In that layout the four pivot columns p_k = 16 t + 4 b + k of tile row I are register b of lanes (j, k): exactly the MFMA
+// operand layout (A: [i][k] on lane (i, k); B: [k][j] on lane (j, k)), so no data moves between the pivot solve and the update:
+//     M44 (4 x 4 pivot block)  -> 10 v_readlane pairs -> Cholesky + inverse Linv, the same scalars on every lane
+//     LP_I(j, k) = sum_{m <= k} P_I(j, m) Linv[k][m]     three lane shuffles per tile row (P = register b of tile (t, I))
+//     tile (T', I') -= LP_T' LP_I'^T                      one MFMA per tile, A = -LP_T', B = LP_I'
+// No LDS, no barriers, no explicit L11^-1: the kernels below the panel (row solve, back-substitution) repeat the same 4-column
+// steps with the stored Linv blocks.  The right-hand side rides along as row 96 of the matrix (tile row 6): the Cholesky factor
+// of the augmented matrix carries y = L11^-1 b in that row.
+#define PG_NB4 24                                   // 4-column blocks per panel
+__device__ inline double pg_rsqrt(double x)
+{
+    double r = __builtin_amdgcn_rsq(x);            // v_rsq_f64 seed, two Newton steps
+    r = r * (1.5 - 0.5 * x * r * r);
+    r = r * (1.5 - 0.5 * x * r * r);
+    return r;
+}
+// Cholesky of the 4 x 4 block m (lower, row-major 10 values m00 m10 m11 m20 m21 m22 m30 m31 m32 m33) and the inverse of its
+// factor: li = [i00 i10 i11 i20 i21 i22 i30 i31 i32 i33]
+__device__ inline int pg_chol4_inv(const double* m, double* li)
+{
+    int bad = 0;
+    double d0 = m[0]; if (!(d0 > 0) || !isfinite(d0)) { bad = 1; d0 = 1.0; }
+    const double r0 = pg_rsqrt(d0);
+    const double l10 = m[1] * r0, l20 = m[3] * r0, l30 = m[6] * r0;
+    double d1 = m[2] - l10 * l10; if (!(d1 > 0) || !isfinite(d1)) { bad = 1; d1 = 1.0; }
+    const double r1 = pg_rsqrt(d1);
+    const double l21 = (m[4] - l20 * l10) * r1, l31 = (m[7] - l30 * l10) * r1;
+    double d2 = m[5] - l20 * l20 - l21 * l21; if (!(d2 > 0) || !isfinite(d2)) { bad = 1; d2 = 1.0; }
+    const double r2 = pg_rsqrt(d2);
+    const double l32 = (m[8] - l30 * l20 - l31 * l21) * r2;
+    double d3 = m[9] - l30 * l30 - l31 * l31 - l32 * l32; if (!(d3 > 0) || !isfinite(d3)) { bad = 1; d3 = 1.0; }
+    const double r3 = pg_rsqrt(d3);
+    li[0] = r0; li[2] = r1; li[5] = r2; li[9] = r3;
+    li[1] = -(l10 * r0) * r1;
+    li[3] = -(l20 * r0 + l21 * li[1]) * r2; li[4] = -(l21 * r1) * r2;
+    li[6] = -(l30 * r0 + l31 * li[1] + l32 * li[3]) * r3; li[7] = -(l31 * r1 + l32 * li[4]) * r3; li[8] = -(l32 * r2) * r3;
+    return bad;
+}
+__device__ inline double pg_shfl(double v, int src) { return __shfl(v, src, 64); }
+
+__global__ __launch_bounds__(64) void pg_front_diag2_kernel(const int* __restrict__ it_front, const int* __restrict__ it_step, const pg_front* __restrict__ FD,
+                                                            double* __restrict__ F, double* __restrict__ R, int* __restrict__ fail, double* __restrict__ Tinv)
+{
+    const pg_front fd = FD[it_front[blockIdx.x]];
+    const int step = it_step[blockIdx.x], col0 = 96 * step;
+    const int n = min(96, fd.s6 - col0), p = fd.pan0 + step, ld = fd.ld;
+    double* __restrict__ A = F + fd.off + (size_t)col0 * ld + col0;
+    double* __restrict__ rr = R + fd.roff + col0;
+    const int l = threadIdx.x, j = l & 15, q = l >> 4;
+    pg_d4 S[6][7];                                  // S[T][I], T <= I; I = 6 is the right-hand-side row
+#pragma unroll
+    for (int T = 0; T < 6; ++T)
+#pragma unroll
+        for (int I = T; I < 7; ++I)
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                const int row = 16 * I + j, col = 16 * T + q + 4 * v;
+                double val;
+                if (I == 6) val = (j == 0 && col < n) ? rr[col] : 0.0;
+                else if (row < n && col < n) val = col <= row ? A[(size_t)row * ld + col] : A[(size_t)col * ld + row];
+                else val = row == col ? 1.0 : 0.0;               // identity padding up to 96
+                S[T][I][v] = val;
+            }
+    int bad = 0;
+    double* __restrict__ tout = Tinv + (size_t)p * PG_NB4 * 16;
+#pragma unroll
+    for (int t = 0; t < 6; ++t) {
+        if (16 * t >= n) break;                     // uniform: the rest is identity padding
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            // pivot block -> every lane
+            double m[10], li[10];
+            {
+                const double dv = S[t][t][b];
+                int e = 0;
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+#pragma unroll
+                    for (int c = 0; c <= r; ++c) m[e++] = pg_readlane(dv, (4 * b + r) + 16 * c);
+            }
+            bad |= pg_chol4_inv(m, li);
+            if (l < 16) {                                        // Linv (row-major 4 x 4, zeros above the diagonal) for the row solve and the back-substitution
+                const int r = l >> 2, c = l & 3;
+                double v = 0.0;
+                if (c <= r) { const int e = r * (r + 1) / 2 + c;
+                    v = e == 0 ? li[0] : e == 1 ? li[1] : e == 2 ? li[2] : e == 3 ? li[3] : e == 4 ? li[4] : e == 5 ? li[5] : e == 6 ? li[6] : e == 7 ? li[7] : e == 8 ? li[8] : li[9]; }
+                tout[(4 * t + b) * 16 + l] = v;
+            }
+            // coefficients of this lane's k = q: row q of Linv
+            const double c0 = q == 0 ? li[0] : q == 1 ? li[1] : q == 2 ? li[3] : li[6];
+            const double c1 = q == 1 ? li[2] : q == 2 ? li[4] : q == 3 ? li[7] : 0.0;
+            const double c2 = q == 2 ? li[5] : q == 3 ? li[8] : 0.0;
+            const double c3 = q == 3 ? li[9] : 0.0;
+            double LP[7];
+#pragma unroll
+            for (int I = 0; I < 7; ++I) {
+                if (I < t) { LP[I] = 0.0; continue; }
+                const double P = S[t][I][b];
+                double v = pg_shfl(P, j) * c0 + pg_shfl(P, j + 16) * c1 + pg_shfl(P, j + 32) * c2 + pg_shfl(P, j + 48) * c3;
+                if (I == t) { const int rj = j - 4 * b; if (rj < 0 || (rj < 4 && q > rj)) v = 0.0; }     // rows above the block; zeros of L44
+                LP[I] = v;
+                S[t][I][b] = v;                                  // the finished four columns of L (rows of tile row I)
+            }
+#pragma unroll
+            for (int T2 = t; T2 < 6; ++T2) {
+                double a = -LP[T2];
+                if (T2 == t && j < 4 * b + 4) a = 0.0;           // only the rows below the pivot block are updated
+#pragma unroll
+                for (int I2 = T2; I2 < 7; ++I2) S[T2][I2] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, LP[I2], S[T2][I2], 0, 0, 0);
+            }
+        }
+    }
+    if (bad && l == 0) *fail = 1;
+#pragma unroll
+    for (int T = 0; T < 6; ++T)
+#pragma unroll
+        for (int I = T; I < 7; ++I)
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                const int row = 16 * I + j, col = 16 * T + q + 4 * v;
+                if (I == 6) { if (j == 0 && col < n) rr[col] = S[T][I][v]; }
+                else if (row < n && col <= row) A[(size_t)row * ld + col] = S[T][I][v];
+            }
+}
+
+// L21 = A21 L11^-T for a slab of 16 rows per wavefront, by the same 4-column steps: LP = P Linv^T (three shuffles), then the
+// later columns of the slab lose LP L11[later rows][pivot columns]^T (one MFMA per 16 columns, A operand straight from L11).
+// Forward substitution rides along: b2 -= L21 y.
+__global__ __launch_bounds__(256) void pg_front_trsm2_kernel(const int* __restrict__ it_front, const int* __restrict__ it_step, const pg_front* __restrict__ FD,
+                                                             double* __restrict__ F, double* __restrict__ R, const double* __restrict__ Tinv)
+{
+    const pg_front fd = FD[it_front[blockIdx.x]];
+    const int step = it_step[blockIdx.x], col0 = 96 * step;
+    const int n = min(96, fd.s6 - col0), p = fd.pan0 + step, ld = fd.ld;
+    const int row0 = col0 + n, nrows = fd.n6 - row0;
+    const int l = threadIdx.x & 63, c = l & 15, q = l >> 4;
+    const int rowbase = ((int)blockIdx.y * 4 + (int)(threadIdx.x >> 6)) * 16;
+    if (rowbase >= nrows) return;                  // wavefront-uniform
+    const bool rok = rowbase + c < nrows;
+    double* __restrict__ Arow = F + fd.off + (size_t)(row0 + min(rowbase + c, nrows - 1)) * ld + col0;
+    const double* __restrict__ L11 = F + fd.off + (size_t)col0 * ld + col0;
+    const double* __restrict__ tin = Tinv + (size_t)p * PG_NB4 * 16;
+    pg_d4 S[6];
+#pragma unroll
+    for (int T = 0; T < 6; ++T)
+#pragma unroll
+        for (int v = 0; v < 4; ++v) { const int col = 16 * T + q + 4 * v; S[T][v] = (rok && col < n) ? Arow[col] : 0.0; }
+#pragma unroll
+    for (int t = 0; t < 6; ++t) {
+        if (16 * t >= n) break;                     // uniform: nothing beyond the panel's columns
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const double* __restrict__ li = tin + (4 * t + b) * 16 + q * 4;      // row q of Linv
+            const double c0 = li[0], c1 = li[1], c2 = li[2], c3 = li[3];
+            const double P = S[t][b];
+            const double LP = pg_shfl(P, c) * c0 + pg_shfl(P, c + 16) * c1 + pg_shfl(P, c + 32) * c2 + pg_shfl(P, c + 48) * c3;
+            S[t][b] = LP;
+#pragma unroll
+            for (int T2 = t; T2 < 6; ++T2) {
+                // A operand: L11[16 T2 + i][16 t + 4 b + k] on lane (i = c, k = q), rows beyond the pivot block only
+                const int ri = 16 * T2 + c, ck = 16 * t + 4 * b + q;
+                const double a = (ri > 16 * t + 4 * b + 3 && ri < n) ? -L11[(size_t)ri * ld + ck] : 0.0;
+                S[T2] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, LP, S[T2], 0, 0, 0);
+            }
+        }
+    }
+    const double* __restrict__ y = R + fd.roff + col0;
+    double dot = 0;
+#pragma unroll
+    for (int T = 0; T < 6; ++T)
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            const int col = 16 * T + q + 4 * v;
+            if (col < n) { if (rok) Arow[col] = S[T][v]; dot += S[T][v] * y[col]; }
+        }
+    dot += __shfl_xor(dot, 16, 64);
+    dot += __shfl_xor(dot, 32, 64);
+    if (l < 16 && rok) R[fd.roff + row0 + rowbase + c] -= dot;
+}
+
+// x1 = L11^-T (y1 - L21^T x2) for one panel: one workgroup of 1024 threads.  x2 (the rows below the panel) is gathered into LDS,
+// ten row slots accumulate the 96 column sums (folded in slot order), L11 goes global -> registers -> LDS behind them, and
+// wavefront 0 runs the block back-substitution: x_blk = Linv^T z_blk, z[earlier columns] -= L11[blk rows][columns]^T x_blk.
+#define PG_BWD2_LD 97
+__global__ __launch_bounds__(1024) void pg_front_bwd2_kernel(const int* __restrict__ it_front, const int* __restrict__ it_step, const pg_front* __restrict__ FD,
+                                                             const int* __restrict__ f_rows, const double* __restrict__ F, const double* __restrict__ R,
+                                                             double* __restrict__ x, const double* __restrict__ Tinv)
+{
+    extern __shared__ double s_bw[];               // L11 [96 x 97] | slot sums [10][96] | x2 [nrows]
+    double* sL = s_bw;
+    double* s_acc = s_bw + (PG_PW * 6) * PG_BWD2_LD;
+    double* sx = s_acc + 10 * (PG_PW * 6);
+    const pg_front fd = FD[it_front[blockIdx.x]];
+    const int step = it_step[blockIdx.x], col0 = 96 * step;
+    const int n = min(96, fd.s6 - col0), p = fd.pan0 + step, ld = fd.ld;
+    const int row0 = col0 + n, nrows = fd.n6 - row0;
+    double lreg[9];
+    { const double* __restrict__ L11 = F + fd.off + (size_t)col0 * ld + col0;
+#pragma unroll
+      for (int e = 0; e < 9; ++e) { const int id = e * 1024 + threadIdx.x, r = id / 96, cc = id - 96 * r; lreg[e] = (r < n && cc <= r) ? L11[(size_t)r * ld + cc] : 0.0; } }
+    for (int i = threadIdx.x; i < nrows; i += 1024) { const int g = row0 + i; sx[i] = x[(size_t)f_rows[fd.rowptr + g / 6] * 6 + g % 6]; }
+    __syncthreads();
+    {
+        const int slot = threadIdx.x / 96, cc = threadIdx.x - slot * 96;
+        if (slot < 10) {
+            double acc0 = 0, acc1 = 0;
+            if (cc < n) {
+                const double* __restrict__ Ab = F + fd.off + (size_t)row0 * ld + col0 + cc;
+                int i = slot;
+                for (; i + 10 < nrows; i += 20) { acc0 += Ab[(size_t)i * ld] * sx[i]; acc1 += Ab[(size_t)(i + 10) * ld] * sx[i + 10]; }
+                if (i < nrows) acc0 += Ab[(size_t)i * ld] * sx[i];
+            }
+            s_acc[slot * (PG_PW * 6) + cc] = acc0 + acc1;
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 9; ++e) { const int id = e * 1024 + threadIdx.x, r = id / 96, cc = id - 96 * r; sL[r * PG_BWD2_LD + cc] = lreg[e]; }
+    __syncthreads();
+    if (threadIdx.x >= 64) return;
+    // wavefront 0: lane c owns columns c and c + 64 of z
+    const int lane = threadIdx.x;
+    double z0, z1;
+    {
+        double v = lane < n ? R[fd.roff + col0 + lane] : 0.0;
+        if (lane < n) for (int g = 0; g < 10; ++g) v -= s_acc[g * (PG_PW * 6) + lane];
+        z0 = v;
+        const int c1 = lane + 64;
+        double w = c1 < n ? R[fd.roff + col0 + c1] : 0.0;
+        if (c1 < n) for (int g = 0; g < 10; ++g) w -= s_acc[g * (PG_PW * 6) + c1];
+        z1 = w;
+    }
+    const double* __restrict__ tin = Tinv + (size_t)p * PG_NB4 * 16;
+#pragma unroll
+    for (int blk = PG_NB4 - 1; blk >= 0; --blk) {
+        if (4 * blk >= n) continue;                 // uniform (identity padding)
+        // z of the four pivot columns -> every lane
+        double zb[4], xb[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { const int pc = 4 * blk + k; zb[k] = pc < 64 ? pg_readlane(z0, pc) : pg_readlane(z1, pc - 64); }
+        const double* __restrict__ li = tin + blk * 16;        // Linv row-major; x = Linv^T z
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { double s = 0; for (int m2 = k; m2 < 4; ++m2) s += li[m2 * 4 + k] * zb[m2]; xb[k] = s; }
+        // earlier columns lose L11[pivot rows][column] x
+        {
+            double s0 = 0;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) s0 += sL[(4 * blk + k) * PG_BWD2_LD + lane] * xb[k];
+            if (lane < 4 * blk) z0 -= s0;
+        }
+        if (4 * blk > 64) {
+            double s1 = 0;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) s1 += sL[(4 * blk + k) * PG_BWD2_LD + min(lane + 64, 95)] * xb[k];
+            if (lane + 64 < 4 * blk) z1 -= s1;
+        }
+        // the pivot columns take their solution
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { const int pc = 4 * blk + k; if (pc < 64) { if (lane == pc) z0 = xb[k]; } else if (lane == pc - 64) z1 = xb[k]; }
+    }
+    if (lane < n) x[(size_t)fd.c0 * 6 + col0 + lane] = z0;
+    if (lane + 64 < n) x[(size_t)fd.c0 * 6 + col0 + lane + 64] = z1;
+}
+
 // ---- bottom of the elimination tree: whole subtrees per workgroup (no grid-wide level barriers).
 // A bin is a list of columns in ascending order whose sources all lie in the same bin, so the workgroup can run them back to
 // back with workgroup barriers only (left-looking, block-sparse, update map).  Only columns with at most 42 blocks
@@ -1463,11 +1730,14 @@ static int pg_solve_impl(dsss_ctx* c, const double* dr6, int total, const dsss_l
     // per panel: W = L11^-1 (96 x 96, zero padded) in MFMA operand order and row-major, u = W^T y
     { const size_t wn = (size_t)std::max(npan, 1) * (PG_PW * 6) * (PG_PW * 6); TRY(dv.alloc(c, &d_Wsw, wn)); TRY(dv.alloc(c, &d_Wrow, wn)); TRY(dv.alloc(c, &d_Uvec, (size_t)std::max(npan, 1) * (PG_PW * 6)));
       HIPCHK(c, hipMemsetAsync(d_Wsw, 0, wn * sizeof(double), c->stream)); HIPCHK(c, hipMemsetAsync(d_Wrow, 0, wn * sizeof(double), c->stream)); }
-    const int bwd_lds = PG_BWD_LDS(max_n6);
+    static const bool old_panel = getenv("DSSS_PG_PANEL") && !strcmp(getenv("DSSS_PG_PANEL"), "inverse");      // A/B: the explicit-inverse panel kernels
+    double* d_Tinv; TRY(dv.alloc(c, &d_Tinv, (size_t)std::max(npan, 1) * PG_NB4 * 16));
+    const int bwd_lds = old_panel ? PG_BWD_LDS(max_n6) : (int)(((PG_PW * 6) * PG_BWD2_LD + 10 * (PG_PW * 6) + max_n6 + 16) * sizeof(double));
     if (bwd_lds > 160 * 1024) { dv.release(); DSSS_FAIL(c, DSSS_E_CAPACITY, "front of %d scalar rows: back-substitution needs %d B of LDS", max_n6, bwd_lds); }
     {   // pg_front_diag_kernel keeps the panel and its inverse (2 x 75 KB) in dynamic LDS, pg_front_bwd_kernel W and x2
         hipFuncSetAttribute((const void*)pg_front_diag_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, PG_DIAG_LDS);
         hipFuncSetAttribute((const void*)pg_front_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipFuncSetAttribute((const void*)pg_front_bwd2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipGetLastError();
     }
     hipStream_t st = c->stream;
@@ -1562,10 +1832,12 @@ static int pg_solve_impl(dsss_ctx* c, const double* dr6, int total, const dsss_l
                                                d_fa_rowptr, d_fa_src, d_fa_col, d_fa_tr, d_aval, d_x, d_F, d_R); }
                         if (nit == 0) continue;
                         { dsss_scope s3(c, DSSS_K_PG_DIAG, H.fl_diag[l]);
-                          hipLaunchKernelGGL(pg_front_diag_kernel, dim3(nit), dim3(256), PG_DIAG_LDS, st, itf, its, d_FD, d_F, d_R, d_fail, d_Wsw, d_Wrow, d_Uvec); }
+                          if (old_panel) hipLaunchKernelGGL(pg_front_diag_kernel, dim3(nit), dim3(256), PG_DIAG_LDS, st, itf, its, d_FD, d_F, d_R, d_fail, d_Wsw, d_Wrow, d_Uvec);
+                          else hipLaunchKernelGGL(pg_front_diag2_kernel, dim3(nit), dim3(64), 0, st, itf, its, d_FD, d_F, d_R, d_fail, d_Tinv); }
                         if (H.trsm_chunks[l] > 0) {
                             { dsss_scope s4(c, DSSS_K_PG_TRSM, H.fl_trsm[l]);
-                              hipLaunchKernelGGL(pg_front_trsm_kernel, dim3(nit, H.trsm_chunks[l]), dim3(256), 0, st, itf, its, d_FD, d_F, d_R, d_Wsw, d_Uvec); }
+                              if (old_panel) hipLaunchKernelGGL(pg_front_trsm_kernel, dim3(nit, H.trsm_chunks[l]), dim3(256), 0, st, itf, its, d_FD, d_F, d_R, d_Wsw, d_Uvec);
+                              else hipLaunchKernelGGL(pg_front_trsm2_kernel, dim3(nit, H.trsm_chunks[l]), dim3(256), 0, st, itf, its, d_FD, d_F, d_R, d_Tinv); }
                             { dsss_scope s5(c, DSSS_K_PG_ACC, H.fl_syrk[l]);
                               if (ntl > 0) hipLaunchKernelGGL(pg_front_syrk_kernel, dim3(ntl), dim3(256), 0, st, itf, its, d_FD, Dv.tile_item + H.tile_ptr[l], Dv.tile_ij + H.tile_ptr[l], d_F); }
                         }
@@ -1576,7 +1848,8 @@ static int pg_solve_impl(dsss_ctx* c, const double* dr6, int total, const dsss_l
                         const int nit = H.lv_ptr[l + 1] - H.lv_ptr[l];
                         if (nit == 0) continue;
                         dsss_scope s6(c, DSSS_K_PG_BWD, H.fl_bwd[l]);
-                        hipLaunchKernelGGL(pg_front_bwd_kernel, dim3(nit), dim3(1024), bwd_lds, st, Dv.lv_front + H.lv_ptr[l], Dv.lv_step + H.lv_ptr[l], d_FD, d_frows, d_F, d_R, d_x, d_Wrow);
+                        if (old_panel) hipLaunchKernelGGL(pg_front_bwd_kernel, dim3(nit), dim3(1024), bwd_lds, st, Dv.lv_front + H.lv_ptr[l], Dv.lv_step + H.lv_ptr[l], d_FD, d_frows, d_F, d_R, d_x, d_Wrow);
+                        else hipLaunchKernelGGL(pg_front_bwd2_kernel, dim3(nit), dim3(1024), bwd_lds, st, Dv.lv_front + H.lv_ptr[l], Dv.lv_step + H.lv_ptr[l], d_FD, d_frows, d_F, d_R, d_x, d_Tinv);
                     }
                 };
                 run_levels(SO, DO);
