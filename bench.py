@@ -108,6 +108,7 @@ def main():
     ap.add_argument("--workload", default=os.environ.get("DSSS_WORKLOAD", "C3"), choices=sorted(WORKLOADS))
     ap.add_argument("--cpu-frames", type=int, default=24, help="frames in the CPU baseline sample (0 = skip); 24 frames of C3 are about 10 s of one core")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--pcie-steps", type=int, default=2, help="steps of the PCIe-inclusive leg (raw frames in page-locked host memory); 0 = skip")
     args = ap.parse_args()
 
     import torch
@@ -169,11 +170,38 @@ def main():
         barrier()
         prof = pipe.ctx.profile_get()
         pipe.ctx.profile(False)
+        # mini-LM work: 3e4 flops per LM iteration and problem (+ one linearisation for the marginal covariance)
+        lc_iters = sum(int(pipe.ctx.lc_get(p)["iters"].sum()) + len(pipe.ctx.lc_get(p)) for p in range(len(pipe.src)))
+        if "lc" in prof and prof["lc"][1] > 0:
+            prof["lc"] = (prof["lc"][0], prof["lc"][1], 3e4 * lc_iters)
         breakdown = {k: round(v[0], 3) for k, v in prof.items() if v[1] > 0}
         roof, roof_all = roofline(prof, args.workload)
         work = {k: ("%.3g flop" if k in FLOP_SLOTS else "%.3g B") % v[2] for k, v in prof.items() if v[1] > 0 and v[2] > 0}
     nkp = [pipe.ctx.features_get(f)[0].shape[0] for f in mine[:8]]
     tot_rows, tot_kp7 = pipe.ctx.match_total()
+    active_pairs = sum(1 for p in range(len(pipe.src)) if pipe.ctx.pair_is_active(p))
+    if world > 1:
+        t = torch.tensor([active_pairs], dtype=torch.int64, device="cuda"); dist.all_reduce(t); active_pairs = int(t.item())
+
+    # ---- the same steps with the raw frames in page-locked HOST memory: the library streams them in under the extraction kernels
+    # (SURVEY.md 8d lists the upload inside the metric; `value` stays the HBM-resident figure, this is the PCIe-inclusive one)
+    pcie = None
+    if args.pcie_steps > 0:
+        h_raws = [None] * F
+        for f in mine:
+            h_raws[f] = raws[f].cpu().pin_memory()
+        pipe.run(h_raws, poses, alts, grs)
+        barrier()
+        t1 = time.perf_counter()
+        for _ in range(args.pcie_steps):
+            pipe.run(h_raws, poses, alts, grs)
+        barrier()
+        dt1 = time.perf_counter() - t1
+        if world > 1:
+            t = torch.tensor([dt1], dtype=torch.float64, device="cuda"); dist.all_reduce(t, op=dist.ReduceOp.MAX); dt1 = float(t.item())
+        pcie = {"value": F * args.pcie_steps / dt1, "unit": "frames/s", "ms_per_step": 1e3 * dt1 / args.pcie_steps, "steps": args.pcie_steps,
+                "bytes_per_step": float(sum(int(h_raws[f].numel()) * 8 for f in mine)), "input": "float64 frames in page-locked host memory, uploaded inside every step (double-buffered under the extraction kernels)"}
+        del h_raws
 
     if rank == 0:
         out = {
@@ -181,12 +209,17 @@ def main():
             "value": F * args.steps / dt, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "u8/int32 (extract, match) + f64 (geo gate, LM)", "data": "synthetic",
-            "config": {"workload": wl["name"], "frames": F, "pings": N, "bins": M, "pairs": F * (F - 1) // 2,
+            "config": {"workload": wl["name"], "frames": F, "pings": N, "bins": M, "pairs": F * (F - 1) // 2, "active_pairs": active_pairs,
+                       "active_pairs_note": "pairs whose geo bounding boxes intersect; the others are provably empty (FEAmatcher.cpp:84) and skipped",
+                       "input": "raw float64 frames resident in HBM before the timed region (PCIe-inclusive figure: pcie_inclusive)",
                        "kp_per_frame": int(np.mean(nkp)) if nkp else 0, "matches_rank0": tot_rows, "lc_problems_rank0": tot_kp7,
                        "pg_stats": [float(s) for s in stats] if stats is not None else None,
-                       "parallelism": "frames+pairs sharded over %d rank(s), RCCL all-gather" % world},
-            "roofline": roof, "roofline_all_kernels": roof_all, "breakdown_ms": breakdown, "work_per_step": work,
+                       "parallelism": "contiguous frame blocks over %d rank(s): RCCL all-gather of features, pairs to the owner of the target frame, pose graph sharded with one RCCL all-reduce of the reduced Hessian per LM trial" % world},
+            "roofline": roof, "roofline_all_kernels": roof_all, "breakdown_ms": breakdown, "work_per_step": work, "pcie_inclusive": pcie,
         }
+        if world > 1:
+            cs = pipe.ctx.comm_stats()
+            out["comm"] = {"allreduce_bytes_total": cs[2], "calls": cs[3]}
         if args.cpu_frames > 0 and world == 1:
             nf = min(args.cpu_frames, F)
             out["cpu_baseline"], o_poses, o_edges = cpu_baseline(sv, wl, nf)
@@ -201,31 +234,38 @@ def main():
 
 
 F64_PEAK_TFLOPS = 78.6   # MI355X FP64 vector/matrix peak (AMD spec sheet; MI355X_MICROARCH.md lists no f64 MFMA row)
+# matcher ceiling: one gate + Hamming evaluation is about 30 VALU operations (5 f64 + 8 xor + 8 popcount + compares); the chip
+# issues 256 CUs x 4 SIMDs x 32 lanes per cycle at 2.4 GHz
+MATCH_PEAK_GEVALS = 256 * 4 * 32 * 2.4 / 30.0
 
 # what bounds each timed kernel.  The streaming kernels are priced in algorithmic HBM bytes, the
 # pose-graph factorisation kernels in f64 flops against the f64 matrix peak they should eventually run at.
-FLOP_SLOTS = {"pg_acc", "pg_diag", "pg_trsm", "pg_bwd"}
+FLOP_SLOTS = {"pg_acc", "pg_diag", "pg_trsm", "pg_bwd", "lc"}
+MFMA_SLOTS = {"pg_acc", "pg_diag", "pg_trsm"}             # kernels whose flops run on v_mfma_f64_16x16x4_f64
 
 
 # profile slot -> kernel name in the rocprofv3 tables under profiles/
 SLOT_KERNEL = {"row_reduce": "row_reduce_kernel", "normalize": "normalize_kernel", "pyramid": "resize_kernel", "fast": "fast_cells_kernel",
-               "desc": "orient_desc_kernel", "quadtree": "quadtree_kernel", "lc": "lc_kernel", "match": "match_nn_kernel",
-               "pg_acc": "pg_factor_acc_kernel", "pg_diag": "pg_panel_diag_kernel", "pg_trsm": "pg_panel_trsm_kernel", "pg_bwd": "pg_panel_bwd_kernel"}
-NOTES = {"pg_acc": "f64 VALU (fused multiply-add), bandwidth-shaped: L(i,k) is re-read once per target column; not on the matrix cores yet",
-         "pg_diag": "96 dependent pivots per panel: latency-bound; panel solve, trailing update and inverse on v_mfma_f64_16x16x4_f64",
-         "pg_trsm": "v_mfma_f64_16x16x4_f64 GEMM against the explicit panel inverse", "pg_bwd": "latency-bound matvec per panel"}
+               "desc": "orient_desc_kernel", "quadtree": "quadtree_kernel", "lc": "lc_kernel", "match": "match_nn_kernel<false>",
+               "pg_acc": "pg_front_syrk_kernel", "pg_diag": "pg_front_diag2_kernel", "pg_trsm": "pg_front_trsm2_kernel", "pg_bwd": "pg_front_bwd2_kernel"}
+NOTES = {"pg_acc": "trailing update of the multifrontal fronts, 64 x 64 tiles on v_mfma_f64_16x16x4_f64 (K = one 96-column panel): the bulk of the factorisation flops; launches are short, so the matrix cores idle between levels",
+         "pg_diag": "96-column panel Cholesky in the registers of one wavefront: 24 dependent 4 x 4 pivot blocks, every rank-4 update one v_mfma_f64_16x16x4_f64 per tile; latency-bound",
+         "pg_trsm": "row solve below the panel by the same 4-column MFMA steps", "pg_bwd": "latency-bound matvec + block back-substitution per panel",
+         "match": "VALU-bound by design: (Na + Nb) x 48 B per directed pair against Na x Nb gate + popcount evaluations",
+         "lc": "f64 VALU, 16 lanes per 15-DoF problem; flops = 3e4 per LM iteration (DESIGN.md section 4) x iterations summed over the problems"}
 
 
 def pmc_traffic(workload):
-    """HBM bytes per launch from the committed rocprofv3 PMC passes (FETCH_SIZE corrected x2 for gfx950, + WRITE_SIZE):
-    profiles/r01_pmc_hbm_traffic_<workload>.csv, written by tools/pmc_summary.py"""
-    path = os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic_%s.csv" % workload)
+    """HBM bytes per launch from the committed rocprofv3 PMC passes: profiles/r02_pmc_hbm_traffic_<workload>.csv, written by
+    tools/pmc_summary.py (FETCH_SIZE x2 only for the kernels whose reads are 16-byte-per-lane streams, + WRITE_SIZE).
+    Returns kernel -> (bytes, calibrated)"""
+    path = os.path.join(ROOT, "profiles", "r02_pmc_hbm_traffic_%s.csv" % workload)
     out = {}
     if os.path.exists(path):
         import csv
         with open(path) as fh:
             for r in csv.DictReader(fh):
-                out[r["kernel"]] = float(r["fetch_bytes_per_launch_corrected_x2"]) + float(r["write_bytes_per_launch"])
+                out[r["kernel"]] = (float(r["fetch_bytes_per_launch_used"]) + float(r["write_bytes_per_launch"]), bool(int(r["fetch_calibrated_x2"])))
     return out
 
 
@@ -234,11 +274,16 @@ def one_roofline(slot, ms, n, work, traffic):
     tr = traffic.get(SLOT_KERNEL.get(slot, ""))
     if slot in FLOP_SLOTS:
         ach = work / n / per_launch_s / 1e12
-        r = {"kernel": slot, "bound": "mfma", "achieved": ach, "peak": F64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / F64_PEAK_TFLOPS}
+        r = {"kernel": slot, "bound": "mfma" if slot in MFMA_SLOTS else "valu_f64", "achieved": ach, "peak": F64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / F64_PEAK_TFLOPS}
+    elif slot == "match":
+        ach = work / n / per_launch_s / 1e9
+        r = {"kernel": slot, "bound": "valu_int", "achieved": ach, "peak": MATCH_PEAK_GEVALS, "unit": "G gate+Hamming evaluations/s", "frac": ach / MATCH_PEAK_GEVALS}
+        if tr:
+            r["hbm_GBs"] = tr[0] / per_launch_s / 1e9
     else:
         ach = work / n / per_launch_s / 1e9
         r = {"kernel": slot, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS}
-    r.update({"traffic": tr, "launches": n, "avg_launch_us": per_launch_s * 1e6})
+    r.update({"traffic": tr[0] if tr else None, "traffic_calibrated": tr[1] if tr else None, "launches": n, "avg_launch_us": per_launch_s * 1e6})
     if slot in NOTES:
         r["note"] = NOTES[slot]
     return r
@@ -247,13 +292,13 @@ def one_roofline(slot, ms, n, work, traffic):
 def roofline(prof, workload):
     """roofline of the single kernel with the largest accumulated GPU time (umbrella slots excluded), and of every other
     kernel that has an algorithmic work figure"""
-    cand = {k: v for k, v in prof.items() if k not in ("pg", "pg_subtree", "pg_asm") and v[1] > 0 and v[2] > 0}
+    cand = {k: v for k, v in prof.items() if k not in ("pg", "pg_subtree", "pg_asm", "pg_comm") and v[1] > 0 and v[2] > 0}
     if not cand:
         return None, None
     traffic = pmc_traffic(workload)
     best = max(cand, key=lambda k: cand[k][0])
     allr = {k: one_roofline(k, *cand[k], traffic) for k in cand}
-    return allr[best], {k: {"achieved": round(v["achieved"], 3), "unit": v["unit"], "frac": round(v["frac"], 4), "avg_launch_us": round(v["avg_launch_us"], 1)}
+    return allr[best], {k: {kk: (round(vv, 4) if isinstance(vv, float) else vv) for kk, vv in v.items() if kk in ("bound", "achieved", "unit", "frac", "avg_launch_us", "traffic", "traffic_calibrated", "hbm_GBs", "launches")}
                         for k, v in allr.items()}
 
 

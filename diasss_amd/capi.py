@@ -298,6 +298,12 @@ class Context:
         self._chk(self.L.dsss_match_get_dir(self.h, pair, d, _ptr(nn), _ptr(co), cap, C.byref(hist), C.byref(cnt), C.byref(model)), "dsss_match_get_dir")
         return nn, co, hist.value, cnt.value, model.value
 
+    def pair_is_active(self, pair):
+        """False for a pair whose geo bounding boxes are disjoint (provably no match; skipped before any kernel runs)"""
+        a = C.c_int(0)
+        self._chk(self.L.dsss_match_pair_active(self.h, int(pair), C.byref(a)), "dsss_match_pair_active")
+        return bool(a.value)
+
     def match_rows(self, pair):
         n = C.c_int(0)
         self._chk(self.L.dsss_match_get_rows(self.h, pair, None, 0, C.byref(n)), "dsss_match_get_rows")
@@ -404,7 +410,8 @@ class Context:
         self._chk(self.L.dsss_profile_reset(self.h), "dsss_profile_reset")
 
     def profile_get(self):
-        ms = np.zeros(20, np.float64); n = np.zeros(20, np.int64); wk = np.zeros(20, np.float64)
+        K = len(K_NAMES)                                   # == DSSS_K_COUNT (include/dsss.h)
+        ms = np.zeros(K, np.float64); n = np.zeros(K, np.int64); wk = np.zeros(K, np.float64)
         self._chk(self.L.dsss_profile_get(self.h, _ptr(ms), _ptr(n)), "dsss_profile_get")
         self._chk(self.L.dsss_profile_get_work(self.h, _ptr(wk)), "dsss_profile_get_work")
-        return {K_NAMES[i]: (float(ms[i]), int(n[i]), float(wk[i])) for i in range(19)}
+        return {K_NAMES[i]: (float(ms[i]), int(n[i]), float(wk[i])) for i in range(K) if not K_NAMES[i].startswith("k2")}

@@ -323,10 +323,17 @@ static int frame_submit(dsss_ctx* c, int id, const double* raw, bool own_upload)
         hipPointerAttribute_t at;
         bool on_dev = (hipPointerGetAttributes(&at, raw) == hipSuccess) && at.type == hipMemoryTypeDevice;
         (void)hipGetLastError();
+        f.raw_pending = false; f.raw_host = nullptr;
         if (on_dev) { f.raw = raw; }
         else {
             if (!f.raw_owned) HIPCHK(c, hipMalloc(&f.raw_owned, (size_t)N * M * sizeof(double)));
-            HIPCHK(c, hipMemcpy(f.raw_owned, raw, (size_t)N * M * sizeof(double), hipMemcpyHostToDevice));
+            const bool pinned = (hipPointerGetAttributes(&at, raw) == hipSuccess) && at.type == hipMemoryTypeHost;
+            (void)hipGetLastError();
+            // a page-locked image is not copied here: the extraction streams it in, sub-batch by sub-batch, on a copy stream while
+            // the kernels of the previous sub-batch run (the caller keeps the buffer alive until dsss_extract* returns).  Pageable
+            // memory cannot be copied asynchronously: it goes up now.
+            if (pinned) { f.raw_host = raw; f.raw_pending = true; }
+            else HIPCHK(c, hipMemcpy(f.raw_owned, raw, (size_t)N * M * sizeof(double), hipMemcpyHostToDevice));
             f.raw = f.raw_owned;
         }
         f.has_raw = true;

@@ -682,7 +682,25 @@ static int extract_frames(dsss_ctx* c, const int* ids, int n, bool keep_taps)
         slot_bytes = std::max(slot_bytes, Ls[i].total);
     }
     // slots of one batch share one scratch allocation: bound it (24 GB) instead of the frame count alone
-    const int B = (int)std::max<size_t>(1, std::min<size_t>(std::min(n, EX_BATCH), ((size_t)24 << 30) / std::max<size_t>(slot_bytes, 1)));
+    int B = (int)std::max<size_t>(1, std::min<size_t>(std::min(n, EX_BATCH), ((size_t)24 << 30) / std::max<size_t>(slot_bytes, 1)));
+    // frames whose page-locked host image has not been uploaded yet: smaller batches, the upload of batch k+1 runs on the copy
+    // stream (xs[1]) under the kernels of batch k (PCIe: 16 B per pixel against ~6 ns of kernels per pixel, so the copies set the pace)
+    bool any_pending = false;
+    for (int i = 0; i < n; ++i) any_pending = any_pending || c->frames[ids[i]].raw_pending;
+    if (any_pending) { static const int sb = getenv("DSSS_EX_UPLOAD_BATCH") ? std::max(1, atoi(getenv("DSSS_EX_UPLOAD_BATCH"))) : 8; B = std::min(B, sb); }
+    hipEvent_t up_ev[2] = { c->xev[1], c->xev[2] };
+    auto upload_batch = [&](int b0, hipEvent_t ev) -> hipError_t {
+        hipError_t e = hipSuccess;
+        for (int s2 = b0; s2 < std::min(n, b0 + B) && e == hipSuccess; ++s2) {
+            dsss_frame& f = c->frames[ids[s2]];
+            if (!f.raw_pending) continue;
+            e = hipMemcpyAsync(f.raw_owned, f.raw_host, (size_t)f.N * f.M * sizeof(double), hipMemcpyHostToDevice, c->xs[1]);
+            f.raw_pending = false;
+        }
+        if (e == hipSuccess) e = hipEventRecord(ev, c->xs[1]);
+        return e;
+    };
+    if (any_pending) HIPCHK(c, upload_batch(0, up_ev[0]));
     const size_t inst_bytes = align_up(sizeof(qt_inst) * (size_t)B * DSSS_MAX_LEVELS, 256), qfr_bytes = align_up(sizeof(qt_frame) * (size_t)B, 256);
     const size_t exf_bytes = align_up(sizeof(ex_frame) * (size_t)B, 256), err_bytes = align_up(sizeof(int) * (size_t)B, 256);
     const size_t tab_bytes = inst_bytes + qfr_bytes + exf_bytes + err_bytes;
@@ -710,8 +728,12 @@ static int extract_frames(dsss_ctx* c, const int* ids, int n, bool keep_taps)
     int* h_nkp = h_err + B;
     const hipStream_t st = c->stream;
 
-    for (int b0 = 0; b0 < n; b0 += B) {
+    for (int b0 = 0, bk = 0; b0 < n; b0 += B, ++bk) {
         const int nb = std::min(B, n - b0);
+        if (any_pending) {
+            if (b0 + B < n) HIPCHK(c, upload_batch(b0 + B, up_ev[(bk + 1) & 1]));      // next batch's images start moving now
+            HIPCHK(c, hipStreamWaitEvent(st, up_ev[bk & 1], 0));                       // this batch's images are in HBM before its kernels read them
+        }
         int ninst = 0, maxN = 0, maxNM4 = 0, max_cells = 0, max_levels = 0;
         size_t max_tot = 0;
         int max_rows[DSSS_MAX_LEVELS] = { 0 }, max_cols[DSSS_MAX_LEVELS] = { 0 };

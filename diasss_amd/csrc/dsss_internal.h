@@ -17,6 +17,8 @@ struct dsss_frame {
     bool has_geom = false, has_raw = false, has_feat = false, has_norm = false;
     const double* raw = nullptr;      // device; borrowed when the caller passed a device pointer
     double* raw_owned = nullptr;      // device; owned copy of a host image
+    const double* raw_host = nullptr; // page-locked host image whose upload is still pending (dsss_extract_many streams it in under the kernels)
+    bool raw_pending = false;
     double* pose6 = nullptr;          // device N x 6
     double* alt = nullptr;            // device N
     double* gr = nullptr;             // device M/2

@@ -400,7 +400,10 @@ int dsss_match_pairs(dsss_ctx* c, const int* src_ids, const int* tgt_ids, int np
     const dim3 grid((max_nkp + MT_TILE - 1) / MT_TILE, 2 * na);
     const double T = gate_threshold(c->mt.radius);
     {
-        dsss_scope sc(c, DSSS_K_MATCH);
+        // algorithmic work of the matcher: gate + Hamming evaluations = sum over the directed active pairs of Na x Nb
+        double evals = 0;
+        for (int a2 = 0; a2 < na; ++a2) evals += 2.0 * c->frames[as[a2]].nkp * c->frames[at[a2]].nkp;
+        dsss_scope sc(c, DSSS_K_MATCH, evals);
         if (c->mt.use_l2)
             hipLaunchKernelGGL(match_nn_kernel<true>, grid, dim3(MT_TILE), 0, c->stream, c->act_s, c->act_t, c->nkp_dev, c->desc, c->geo,
                                c->bbox_dev, (int)K, T, c->mt.bound_same, c->mt.bound_diff, c->mt.l2_bound, c->mt.ratio, c->corres_nn);
@@ -498,6 +501,14 @@ int dsss_match_get_kp7(dsss_ctx* c, int pair, double* kp7, int cap, int* nout)
     if (cap < n) DSSS_FAIL(c, DSSS_E_CAPACITY, "caller capacity %d < %d", cap, n);
     HIPCHK(c, hipStreamSynchronize(c->stream));
     HIPCHK(c, hipMemcpy(kp7, c->kp7 + (size_t)c->h_kp7_off[a] * 7, (size_t)n * 7 * sizeof(double), hipMemcpyDeviceToHost));
+    return DSSS_OK;
+}
+
+int dsss_match_pair_active(dsss_ctx* c, int pair, int* active)
+{
+    if (!c || !active) return DSSS_E_ARG;
+    if (pair < 0 || pair >= c->npairs) DSSS_FAIL(c, DSSS_E_ARG, "pair %d out of range", pair);
+    *active = c->pair_active[pair] >= 0;
     return DSSS_OK;
 }
 

@@ -1045,20 +1045,34 @@ __global__ __launch_bounds__(64) void pg_front_diag2_kernel(const int* __restric
 // L21 = A21 L11^-T for a slab of 16 rows per wavefront, by the same 4-column steps: LP = P Linv^T (three shuffles), then the
 // later columns of the slab lose LP L11[later rows][pivot columns]^T (one MFMA per 16 columns, A operand straight from L11).
 // Forward substitution rides along: b2 -= L21 y.
+#define PG_T2_LD 97
 __global__ __launch_bounds__(256) void pg_front_trsm2_kernel(const int* __restrict__ it_front, const int* __restrict__ it_step, const pg_front* __restrict__ FD,
                                                              double* __restrict__ F, double* __restrict__ R, const double* __restrict__ Tinv)
 {
+    __shared__ double sL[(PG_PW * 6) * PG_T2_LD];      // L11 of the panel (lower triangle), the A operands of every update
+    __shared__ double sT[PG_NB4 * 16];                 // the 4 x 4 inverse blocks
+    __shared__ double sY[PG_PW * 6];
     const pg_front fd = FD[it_front[blockIdx.x]];
     const int step = it_step[blockIdx.x], col0 = 96 * step;
     const int n = min(96, fd.s6 - col0), p = fd.pan0 + step, ld = fd.ld;
     const int row0 = col0 + n, nrows = fd.n6 - row0;
+    if ((int)blockIdx.y * 64 >= nrows) return;     // workgroup-uniform
+    {
+        const double* __restrict__ L11 = F + fd.off + (size_t)col0 * ld + col0;
+        double v[36];
+#pragma unroll
+        for (int e = 0; e < 36; ++e) { const int id = e * 256 + threadIdx.x, r = id / 96, cc = id - 96 * r; v[e] = (r < n && cc <= r) ? L11[(size_t)r * ld + cc] : 0.0; }
+#pragma unroll
+        for (int e = 0; e < 36; ++e) { const int id = e * 256 + threadIdx.x, r = id / 96, cc = id - 96 * r; sL[r * PG_T2_LD + cc] = v[e]; }
+        for (int e = threadIdx.x; e < PG_NB4 * 16; e += 256) sT[e] = Tinv[(size_t)p * PG_NB4 * 16 + e];
+        if (threadIdx.x < 96) sY[threadIdx.x] = (int)threadIdx.x < n ? R[fd.roff + col0 + threadIdx.x] : 0.0;
+    }
+    __syncthreads();
     const int l = threadIdx.x & 63, c = l & 15, q = l >> 4;
     const int rowbase = ((int)blockIdx.y * 4 + (int)(threadIdx.x >> 6)) * 16;
     if (rowbase >= nrows) return;                  // wavefront-uniform
     const bool rok = rowbase + c < nrows;
     double* __restrict__ Arow = F + fd.off + (size_t)(row0 + min(rowbase + c, nrows - 1)) * ld + col0;
-    const double* __restrict__ L11 = F + fd.off + (size_t)col0 * ld + col0;
-    const double* __restrict__ tin = Tinv + (size_t)p * PG_NB4 * 16;
     pg_d4 S[6];
 #pragma unroll
     for (int T = 0; T < 6; ++T)
@@ -1069,28 +1083,27 @@ __global__ __launch_bounds__(256) void pg_front_trsm2_kernel(const int* __restri
         if (16 * t >= n) break;                     // uniform: nothing beyond the panel's columns
 #pragma unroll
         for (int b = 0; b < 4; ++b) {
-            const double* __restrict__ li = tin + (4 * t + b) * 16 + q * 4;      // row q of Linv
+            const double* __restrict__ li = sT + (4 * t + b) * 16 + q * 4;      // row q of Linv
             const double c0 = li[0], c1 = li[1], c2 = li[2], c3 = li[3];
             const double P = S[t][b];
             const double LP = pg_shfl(P, c) * c0 + pg_shfl(P, c + 16) * c1 + pg_shfl(P, c + 32) * c2 + pg_shfl(P, c + 48) * c3;
             S[t][b] = LP;
 #pragma unroll
             for (int T2 = t; T2 < 6; ++T2) {
-                // A operand: L11[16 T2 + i][16 t + 4 b + k] on lane (i = c, k = q), rows beyond the pivot block only
+                // A operand: L11[16 T2 + i][16 t + 4 b + k] on lane (i = c, k = q), rows beyond the pivot block only (zero above the diagonal in sL)
                 const int ri = 16 * T2 + c, ck = 16 * t + 4 * b + q;
-                const double a = (ri > 16 * t + 4 * b + 3 && ri < n) ? -L11[(size_t)ri * ld + ck] : 0.0;
+                const double a = (T2 > t || c > 4 * b + 3) ? -sL[ri * PG_T2_LD + ck] : 0.0;
                 S[T2] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, LP, S[T2], 0, 0, 0);
             }
         }
     }
-    const double* __restrict__ y = R + fd.roff + col0;
     double dot = 0;
 #pragma unroll
     for (int T = 0; T < 6; ++T)
 #pragma unroll
         for (int v = 0; v < 4; ++v) {
             const int col = 16 * T + q + 4 * v;
-            if (col < n) { if (rok) Arow[col] = S[T][v]; dot += S[T][v] * y[col]; }
+            if (col < n) { if (rok) Arow[col] = S[T][v]; dot += S[T][v] * sY[col]; }
         }
     dot += __shfl_xor(dot, 16, 64);
     dot += __shfl_xor(dot, 32, 64);
@@ -1126,8 +1139,14 @@ __global__ __launch_bounds__(1024) void pg_front_bwd2_kernel(const int* __restri
             if (cc < n) {
                 const double* __restrict__ Ab = F + fd.off + (size_t)row0 * ld + col0 + cc;
                 int i = slot;
-                for (; i + 10 < nrows; i += 20) { acc0 += Ab[(size_t)i * ld] * sx[i]; acc1 += Ab[(size_t)(i + 10) * ld] * sx[i + 10]; }
-                if (i < nrows) acc0 += Ab[(size_t)i * ld] * sx[i];
+                for (; i + 70 < nrows; i += 80) {                  // eight loads in flight
+                    double a8[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) a8[u] = Ab[(size_t)(i + 10 * u) * ld];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) { if (u & 1) acc1 += a8[u] * sx[i + 10 * u]; else acc0 += a8[u] * sx[i + 10 * u]; }
+                }
+                for (; i < nrows; i += 10) acc0 += Ab[(size_t)i * ld] * sx[i];
             }
             s_acc[slot * (PG_PW * 6) + cc] = acc0 + acc1;
         }

@@ -144,6 +144,8 @@ int dsss_match_get_dir(dsss_ctx*, int pair, int dir /*0: s->t, 1: t->s*/, int32_
 int dsss_match_get_rows(dsss_ctx*, int pair, double* rows6_host, int cap, int* nrows);   /* [id_s,id_t,y_s,x_s,y_t,x_t] */
 int dsss_match_get_kp7(dsss_ctx*, int pair, double* kp7_host, int cap, int* n);          /* Vector7 of optimizer.cpp:625 */
 int dsss_match_total(dsss_ctx*, int* total_rows, int* total_kp7);
+/* 0 when the geo bounding boxes of the pair are disjoint: every keypoint is then skipped by FEAmatcher.cpp:84, no kernel runs */
+int dsss_match_pair_active(dsss_ctx*, int pair, int* active_host);
 /* FEAmatcher::DescriptorDistance (FEAmatcher.h:33) on device-resident descriptors of two frames */
 int dsss_descriptor_distance(dsss_ctx*, int id_a, int ia, int id_b, int ib, int* dist_host);
 
