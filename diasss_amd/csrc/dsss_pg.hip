@@ -269,6 +269,32 @@ __global__ __launch_bounds__(64) void pg_segment_kernel(int nseg, const int* __r
     for (int a = 0; a < 6; ++a) { segGL[(size_t)s * 6 + a] = GL[a]; segGR[(size_t)s * 6 + a] = Gn[a]; }
 }
 
+// the level-1 chain after pass 1: diagonal block, coupling to the next entry and gradient of every chunk end / true separator
+// (what pass 2 of pg_segment_kernel condenses; same meaning as D, C, g of the pose chain).  Partial sums on interface entries.
+__global__ __launch_bounds__(256) void pg_chain1_kernel(int ns1, const int* __restrict__ sep1, const double* __restrict__ D, const double* __restrict__ g,
+                                                        const double* __restrict__ segDL, const double* __restrict__ segDR,
+                                                        const double* __restrict__ segGL, const double* __restrict__ segGR, const double* __restrict__ segS,
+                                                        double* __restrict__ D1, double* __restrict__ C1, double* __restrict__ g1, int mp0, int mp1)
+{
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    if (k >= ns1) return;
+    const int p = sep1[k];
+    const bool segl = k > 0 && sep1[k - 1] + 1 >= mp0 && sep1[k - 1] + 1 < mp1, segr = k + 1 < ns1 && p + 1 >= mp0 && p + 1 < mp1;
+    for (int a = 0; a < 36; ++a) {
+        double v = D[(size_t)p * 36 + a];
+        if (segl) v += segDR[(size_t)(k - 1) * 36 + a];
+        if (segr) v += segDL[(size_t)k * 36 + a];
+        D1[(size_t)k * 36 + a] = v;
+        C1[(size_t)k * 36 + a] = segr ? segS[(size_t)k * 36 + a] : 0.0;
+    }
+    for (int a = 0; a < 6; ++a) {
+        double v = g[(size_t)p * 6 + a];
+        if (segl) v += segGR[(size_t)(k - 1) * 6 + a];
+        if (segr) v += segGL[(size_t)k * 6 + a];
+        g1[(size_t)k * 6 + a] = v;
+    }
+}
+
 // reduced system: diagonal blocks, chain couplings and right-hand side (one thread per separator, chain order).  Value index
 // k = diagonal block of separator k, ns + k = chain coupling S(k, k+1), 2 ns - 1 + e = LC edge e (dsss_pg_sym.h).  A value
 // whose destination column is binned goes straight into the block-sparse factor (dest >= 0: position << 1 | transpose); the
@@ -1341,7 +1367,8 @@ __global__ __launch_bounds__(256) void pg_sep_delta_kernel(int ns, const int* __
 {
     const int k = blockIdx.x * 256 + threadIdx.x;
     if (k >= ns) return;
-    for (int a = 0; a < 6; ++a) delta[(size_t)sep_pose[k] * 6 + a] = x[(size_t)perm[k] * 6 + a];
+    const int src = perm ? perm[k] : k;
+    for (int a = 0; a < 6; ++a) delta[(size_t)sep_pose[k] * 6 + a] = x[(size_t)src * 6 + a];
 }
 
 // interiors, right to left: delta_i = D_i^-1 (-g_i - E_i^T delta_L - C_i delta_{i+1})
@@ -1608,18 +1635,27 @@ static int pg_solve_impl(dsss_ctx* c, const double* dr6, int total, const dsss_l
     for (int i = 0; i < n; ++i) adj_ptr[i + 1] += adj_ptr[i];
     { std::vector<int> fill(adj_ptr.begin(), adj_ptr.end() - 1);
       for (int e = 0; e < ne; ++e) { adj_edge[fill[ea[e]]++] = e << 1; adj_edge[fill[eb[e]]++] = (e << 1) | 1; } }
-    std::vector<char> is_sep(n, 0);
-    is_sep[0] = 1; is_sep[n - 1] = 1;
-    for (int e = 0; e < ne; ++e) { is_sep[ea[e]] = 1; is_sep[eb[e]] = 1; }
-    // bound the sequential depth of the per-segment block-Thomas recursion: every PG_CHUNK-th pose is promoted to a
-    // separator as well (exact: it only moves that pose from the chain elimination into the sparse factorisation,
-    // where a pose with two chain neighbours costs O(1) fill)
+    // Two levels of chain elimination.  TRUE separators (the unknowns of the sparse factorisation): LC-touched poses, the first and
+    // the last pose, the last pose of every partition.  CHUNK ends: every PG_CHUNK-th pose as well, which bounds the sequential
+    // depth of the per-segment block-Thomas recursion (one thread per segment).  Pass 1 condenses every chunk onto its two ends
+    // (poses -> "level-1" chain of true separators + chunk ends); pass 2 condenses the runs of chunk ends between two true
+    // separators the same way (same kernel, on the level-1 chain).  Exact: only the elimination order changes.
+    std::vector<char> is_true(n, 0), is_sep(n, 0);
+    is_true[0] = 1; is_true[n - 1] = 1;
+    for (int e = 0; e < ne; ++e) { is_true[ea[e]] = 1; is_true[eb[e]] = 1; }
+    for (int p = 1; p < nparts; ++p) is_true[pbound[p] - 1] = 1;         // a partition ends on a separator: segments never straddle ranks
     { const char* ev = getenv("DSSS_PG_CHUNK"); const int chunk = ev ? std::max(2, atoi(ev)) : 16;
       for (int i = 0; i < n; i += chunk) is_sep[i] = 1; }
-    for (int p = 1; p < nparts; ++p) is_sep[pbound[p] - 1] = 1;          // a partition ends on a separator: segments never straddle ranks
-    std::vector<int> sep_pose, sidx(n, -1);
-    for (int i = 0; i < n; ++i) if (is_sep[i]) { sidx[i] = (int)sep_pose.size(); sep_pose.push_back(i); }
+    std::vector<int> sep1, sep_pose, t2, sidx(n, -1);                    // level-1 chain (poses); true separators (poses; positions in sep1)
+    for (int i = 0; i < n; ++i) {
+        if (!is_true[i] && !is_sep[i]) continue;
+        if (is_true[i]) { sidx[i] = (int)sep_pose.size(); sep_pose.push_back(i); t2.push_back((int)sep1.size()); }
+        sep1.push_back(i);
+    }
+    const int ns1 = (int)sep1.size(), nseg1 = ns1 - 1;
     const int ns = (int)sep_pose.size(), nseg = ns - 1;
+    // this rank's range of the level-1 chain (its poses are [mp0, mp1))
+    const int kp0 = (int)(std::lower_bound(sep1.begin(), sep1.end(), mp0) - sep1.begin()), kp1 = (int)(std::lower_bound(sep1.begin(), sep1.end(), mp1) - sep1.begin());
     std::vector<std::pair<int, int>> redges;
     for (int k = 0; k + 1 < ns; ++k) redges.push_back({ k, k + 1 });
     for (int e = 0; e < ne; ++e) redges.push_back({ sidx[ea[e]], sidx[eb[e]] });
@@ -1629,8 +1665,8 @@ static int pg_solve_impl(dsss_ctx* c, const double* dr6, int total, const dsss_l
 #define TRY(x) do { rc = (x); if (rc) { dv.release(); return rc; } } while (0)
     // DR rows on the device first: the separator coordinates for the ordering come back from there (host reads of the
     // frames' pinned copies are slow), and the copies overlap with the rest of the host preparation
-    double* d_dr6; double* d_sxy; int* d_sep;
-    TRY(dv.alloc(c, &d_dr6, (size_t)n * 6)); TRY(dv.alloc(c, &d_sxy, (size_t)ns * 2)); TRY(dv.upload(c, &d_sep, sep_pose));
+    double* d_dr6; double* d_sxy; int* d_sep; int* d_sep1; int* d_t2;
+    TRY(dv.alloc(c, &d_dr6, (size_t)n * 6)); TRY(dv.alloc(c, &d_sxy, (size_t)ns * 2)); TRY(dv.upload(c, &d_sep, sep_pose)); TRY(dv.upload(c, &d_sep1, sep1)); TRY(dv.upload(c, &d_t2, t2));
     std::vector<double> sxy((size_t)ns * 2), cx(ns), cy(ns);
     {
         hipError_t e = hipSuccess;
@@ -1680,8 +1716,14 @@ static int pg_solve_impl(dsss_ctx* c, const double* dr6, int total, const dsss_l
     TRY(dv.alloc(c, &d_r, (size_t)nf * 6)); TRY(dv.alloc(c, &d_Ji, (size_t)nf * 36));
     TRY(dv.alloc(c, &d_D, (size_t)n * 36)); TRY(dv.alloc(c, &d_C, (size_t)n * 36)); TRY(dv.alloc(c, &d_g, (size_t)n * 6)); TRY(dv.alloc(c, &d_delta, (size_t)n * 6));
     TRY(dv.alloc(c, &d_E, (size_t)n * 36)); TRY(dv.alloc(c, &d_Dl, (size_t)n * 36)); TRY(dv.alloc(c, &d_gi, (size_t)n * 6));
-    TRY(dv.alloc(c, &d_sDL, (size_t)nseg * 36)); TRY(dv.alloc(c, &d_sDR, (size_t)nseg * 36)); TRY(dv.alloc(c, &d_sGL, (size_t)nseg * 6));
-    TRY(dv.alloc(c, &d_sGR, (size_t)nseg * 6)); TRY(dv.alloc(c, &d_sS, (size_t)nseg * 36));
+    TRY(dv.alloc(c, &d_sDL, (size_t)nseg1 * 36)); TRY(dv.alloc(c, &d_sDR, (size_t)nseg1 * 36)); TRY(dv.alloc(c, &d_sGL, (size_t)nseg1 * 6));
+    TRY(dv.alloc(c, &d_sGR, (size_t)nseg1 * 6)); TRY(dv.alloc(c, &d_sS, (size_t)nseg1 * 36));
+    // level-1 chain (true separators + chunk ends) and its condensation onto the true separators (pass 2)
+    double *d_D1, *d_C1, *d_g1, *d_E1, *d_Dl1, *d_gi1, *d_delta1, *d_s2DL, *d_s2DR, *d_s2GL, *d_s2GR, *d_s2S;
+    TRY(dv.alloc(c, &d_D1, (size_t)ns1 * 36)); TRY(dv.alloc(c, &d_C1, (size_t)ns1 * 36)); TRY(dv.alloc(c, &d_g1, (size_t)ns1 * 6)); TRY(dv.alloc(c, &d_delta1, (size_t)ns1 * 6));
+    TRY(dv.alloc(c, &d_E1, (size_t)ns1 * 36)); TRY(dv.alloc(c, &d_Dl1, (size_t)ns1 * 36)); TRY(dv.alloc(c, &d_gi1, (size_t)ns1 * 6));
+    TRY(dv.alloc(c, &d_s2DL, (size_t)std::max(nseg, 1) * 36)); TRY(dv.alloc(c, &d_s2DR, (size_t)std::max(nseg, 1) * 36)); TRY(dv.alloc(c, &d_s2GL, (size_t)std::max(nseg, 1) * 6));
+    TRY(dv.alloc(c, &d_s2GR, (size_t)std::max(nseg, 1) * 6)); TRY(dv.alloc(c, &d_s2S, (size_t)std::max(nseg, 1) * 36));
     TRY(dv.alloc(c, &d_L, nnzL * 36)); TRY(dv.alloc(c, &d_x, (size_t)ns * 6)); TRY(dv.alloc(c, &d_part, (size_t)nblk)); TRY(dv.alloc(c, &d_scal, 8)); TRY(dv.alloc(c, &d_fail, 1));
     TRY(dv.alloc(c, &d_F, (size_t)S.front_doubles)); TRY(dv.alloc(c, &d_R, (size_t)S.frhs_doubles)); TRY(dv.alloc(c, &d_ubin, (size_t)S.ubin_doubles));
     // value array of the fronts; its tail IS the buffer the all-reduce sums: [interface values | interface right-hand sides |
@@ -1834,9 +1876,12 @@ static int pg_solve_impl(dsss_ctx* c, const double* dr6, int total, const dsss_l
                 hipMemsetAsync(d_L, 0, nnzL * 36 * sizeof(double), st);
                 if (nparts > 1) hipMemsetAsync(d_comm, 0, comm_total * sizeof(double), st);
                 hipLaunchKernelGGL(pg_assemble_kernel, dim3((n + 255) / 256), dim3(256), 0, st, n, W, d_r, d_Ji, d_adj_ptr, d_adj_edge, d_ew, d_scal + 3, d_D, d_C, d_g, d_eb, mp0, mp1);
-                hipLaunchKernelGGL(pg_segment_kernel, dim3((nseg + 63) / 64), dim3(64), 0, st, nseg, d_sep, d_D, d_C, d_g, d_E, d_Dl, d_gi, d_sDL, d_sDR, d_sGL, d_sGR, d_sS, d_fail, mp0, mp1);
-                hipLaunchKernelGGL(pg_scatter_base_kernel, dim3((ns + 255) / 256), dim3(256), 0, st, ns, d_sep, d_perm, d_D, d_g, d_sDL, d_sDR, d_sGL, d_sGR, d_sS, d_dest, d_L, d_aval, d_x,
-                                   d_ifslot, d_avalif, d_xif, mp0, mp1);
+                // pass 1: chunks of poses onto their ends; the level-1 chain; pass 2: runs of chunk ends onto the true separators
+                hipLaunchKernelGGL(pg_segment_kernel, dim3((nseg1 + 63) / 64), dim3(64), 0, st, nseg1, d_sep1, d_D, d_C, d_g, d_E, d_Dl, d_gi, d_sDL, d_sDR, d_sGL, d_sGR, d_sS, d_fail, mp0, mp1);
+                hipLaunchKernelGGL(pg_chain1_kernel, dim3((ns1 + 255) / 256), dim3(256), 0, st, ns1, d_sep1, d_D, d_g, d_sDL, d_sDR, d_sGL, d_sGR, d_sS, d_D1, d_C1, d_g1, mp0, mp1);
+                if (nseg > 0) hipLaunchKernelGGL(pg_segment_kernel, dim3((nseg + 63) / 64), dim3(64), 0, st, nseg, d_t2, d_D1, d_C1, d_g1, d_E1, d_Dl1, d_gi1, d_s2DL, d_s2DR, d_s2GL, d_s2GR, d_s2S, d_fail, kp0, kp1);
+                hipLaunchKernelGGL(pg_scatter_base_kernel, dim3((ns + 255) / 256), dim3(256), 0, st, ns, d_t2, d_perm, d_D1, d_g1, d_s2DL, d_s2DR, d_s2GL, d_s2GR, d_s2S, d_dest, d_L, d_aval, d_x,
+                                   d_ifslot, d_avalif, d_xif, kp0, kp1);
                 if (ne > 0) hipLaunchKernelGGL(pg_scatter_lc_kernel, dim3((ne + 255) / 256), dim3(256), 0, st, n, ne, ns, d_Ji, d_ew, d_dest, d_L, d_aval, d_avalif, d_eb, mp0, mp1);
                 if (nbins > 0) { dsss_scope s1(c, DSSS_K_PG_SUBTREE);
                                  hipLaunchKernelGGL(pg_factor_subtree_kernel, dim3(nbins), dim3(256), 0, st, d_binptr + bin_lo, d_bincols, d_colptr, d_rlptr, d_rlcol, d_rlpos, d_mapptr, d_map, d_L, d_x, d_fail,
@@ -1885,8 +1930,10 @@ static int pg_solve_impl(dsss_ctx* c, const double* dr6, int total, const dsss_l
                 run_levels_bwd(SO, DO);
                 if (nbins > 0) { dsss_scope s7(c, DSSS_K_PG_SUBTREE);
                     hipLaunchKernelGGL(pg_bwd_subtree_kernel, dim3(nbins), dim3(64), 0, st, d_binptr + bin_lo, d_bincols, d_colptr, d_rowidx, d_L, d_x); }
-                hipLaunchKernelGGL(pg_sep_delta_kernel, dim3((ns + 255) / 256), dim3(256), 0, st, ns, d_sep, d_perm, d_x, d_delta);
-                hipLaunchKernelGGL(pg_backsub_kernel, dim3((nseg + 63) / 64), dim3(64), 0, st, nseg, d_sep, d_C, d_E, d_Dl, d_gi, d_delta, mp0, mp1);
+                hipLaunchKernelGGL(pg_sep_delta_kernel, dim3((ns + 255) / 256), dim3(256), 0, st, ns, d_t2, d_perm, d_x, d_delta1);
+                if (nseg > 0) hipLaunchKernelGGL(pg_backsub_kernel, dim3((nseg + 63) / 64), dim3(64), 0, st, nseg, d_t2, d_C1, d_E1, d_Dl1, d_gi1, d_delta1, kp0, kp1);
+                hipLaunchKernelGGL(pg_sep_delta_kernel, dim3((ns1 + 255) / 256), dim3(256), 0, st, ns1, d_sep1, (const int*)nullptr, d_delta1, d_delta);
+                hipLaunchKernelGGL(pg_backsub_kernel, dim3((nseg1 + 63) / 64), dim3(64), 0, st, nseg1, d_sep1, d_C, d_E, d_Dl, d_gi, d_delta, mp0, mp1);
                 hipLaunchKernelGGL(pg_linerr_kernel, dim3(nblk), dim3(256), 0, st, n, ne, W, d_ea, d_eb, d_ew, d_r, d_Ji, d_delta, d_part, mp0, mp1);
                 hipLaunchKernelGGL(pg_final_sum_kernel, dim3(1), dim3(256), 0, st, d_part, nblk, 0.5, d_scal + 1);
             }
