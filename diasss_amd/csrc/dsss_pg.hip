@@ -1031,17 +1031,21 @@ __global__ __launch_bounds__(64) void pg_front_diag2_kernel(const int* __restric
                     v = e == 0 ? li[0] : e == 1 ? li[1] : e == 2 ? li[2] : e == 3 ? li[3] : e == 4 ? li[4] : e == 5 ? li[5] : e == 6 ? li[6] : e == 7 ? li[7] : e == 8 ? li[8] : li[9]; }
                 tout[(4 * t + b) * 16 + l] = v;
             }
-            // coefficients of this lane's k = q: row q of Linv
-            const double c0 = q == 0 ? li[0] : q == 1 ? li[1] : q == 2 ? li[3] : li[6];
-            const double c1 = q == 1 ? li[2] : q == 2 ? li[4] : q == 3 ? li[7] : 0.0;
-            const double c2 = q == 2 ? li[5] : q == 3 ? li[8] : 0.0;
-            const double c3 = q == 3 ? li[9] : 0.0;
+            // LP_I = P_I Linv^T without moving data between lanes: as the product Linv (4 x 4, padded to 16 x 4) x P_I^T the
+            // matrix core returns LP_I(j, k) in register 0 of lane (j, k) -- the operand layout the updates below need.
+            // A operand: lane (i, m) holds Linv[i][m] for i < 4, zero otherwise; B operand: P_I as it stands.
+            double lop;
+            {
+                const int e = j * (j + 1) / 2 + q;
+                lop = (j < 4 && q <= j) ? (e == 0 ? li[0] : e == 1 ? li[1] : e == 2 ? li[2] : e == 3 ? li[3] : e == 4 ? li[4] : e == 5 ? li[5] : e == 6 ? li[6] : e == 7 ? li[7] : e == 8 ? li[8] : li[9]) : 0.0;
+            }
             double LP[7];
 #pragma unroll
             for (int I = 0; I < 7; ++I) {
                 if (I < t) { LP[I] = 0.0; continue; }
-                const double P = S[t][I][b];
-                double v = pg_shfl(P, j) * c0 + pg_shfl(P, j + 16) * c1 + pg_shfl(P, j + 32) * c2 + pg_shfl(P, j + 48) * c3;
+                const pg_d4 zero4 = { 0.0, 0.0, 0.0, 0.0 };
+                const pg_d4 r4 = __builtin_amdgcn_mfma_f64_16x16x4f64(lop, S[t][I][b], zero4, 0, 0, 0);
+                double v = r4[0];
                 if (I == t) { const int rj = j - 4 * b; if (rj < 0 || (rj < 4 && q > rj)) v = 0.0; }     // rows above the block; zeros of L44
                 LP[I] = v;
                 S[t][I][b] = v;                                  // the finished four columns of L (rows of tile row I)
@@ -1109,10 +1113,11 @@ __global__ __launch_bounds__(256) void pg_front_trsm2_kernel(const int* __restri
         if (16 * t >= n) break;                     // uniform: nothing beyond the panel's columns
 #pragma unroll
         for (int b = 0; b < 4; ++b) {
-            const double* __restrict__ li = sT + (4 * t + b) * 16 + q * 4;      // row q of Linv
-            const double c0 = li[0], c1 = li[1], c2 = li[2], c3 = li[3];
-            const double P = S[t][b];
-            const double LP = pg_shfl(P, c) * c0 + pg_shfl(P, c + 16) * c1 + pg_shfl(P, c + 32) * c2 + pg_shfl(P, c + 48) * c3;
+            // LP = P Linv^T through the matrix core (see pg_front_diag2_kernel): A operand lane (i, m) = Linv[i][m], i < 4
+            const double lop = c < 4 ? sT[(4 * t + b) * 16 + c * 4 + q] : 0.0;
+            const pg_d4 zero4 = { 0.0, 0.0, 0.0, 0.0 };
+            const pg_d4 r4 = __builtin_amdgcn_mfma_f64_16x16x4f64(lop, S[t][b], zero4, 0, 0, 0);
+            const double LP = r4[0];
             S[t][b] = LP;
 #pragma unroll
             for (int T2 = t; T2 < 6; ++T2) {
@@ -1645,7 +1650,11 @@ static int pg_solve_impl(dsss_ctx* c, const double* dr6, int total, const dsss_l
     for (int e = 0; e < ne; ++e) { is_true[ea[e]] = 1; is_true[eb[e]] = 1; }
     for (int p = 1; p < nparts; ++p) is_true[pbound[p] - 1] = 1;         // a partition ends on a separator: segments never straddle ranks
     { const char* ev = getenv("DSSS_PG_CHUNK"); const int chunk = ev ? std::max(2, atoi(ev)) : 16;
-      for (int i = 0; i < n; i += chunk) is_sep[i] = 1; }
+      for (int i = 0; i < n; i += chunk) is_sep[i] = 1;
+      // pass 2 is sequential over the chunk ends between two true separators: a gap of more than 16 chunks (frame boundaries
+      // without keypoints reach 900 poses) gets true separators of its own every 16 chunks
+      const int run = 16 * chunk;
+      for (int i = 0, last = 0; i < n; ++i) { if (is_true[i]) last = i; else if (i - last >= run && i % chunk == 0) { is_true[i] = 1; last = i; } } }
     std::vector<int> sep1, sep_pose, t2, sidx(n, -1);                    // level-1 chain (poses); true separators (poses; positions in sep1)
     for (int i = 0; i < n; ++i) {
         if (!is_true[i] && !is_sep[i]) continue;
