@@ -1077,128 +1077,141 @@ __global__ __launch_bounds__(64) void pg_front_diag2_kernel(const int* __restric
 //     pivot wavefront (owner of tile (t, t)):  M44 -> Cholesky + inverse -> Linv into LDS                     barrier
 //     every wavefront:  LP_I = Linv x P_I^T (one MFMA) for its tile columns I >= t, LP_I into LDS              barrier
 //     every wavefront:  tile (T', I') -= LP_T' LP_I'^T for its tiles, A operand from LDS, B operand its own LP_I'
-// LDS buffers alternate between blocks, so two barriers per block order everything.  24 blocks x (one 4 x 4 Cholesky chain +
-// two barriers + a handful of MFMAs per wavefront) instead of one wavefront issuing all 416 MFMAs and every scalar of the chain.
-__global__ __launch_bounds__(256) void pg_front_diag3_kernel(const int* __restrict__ it_front, const int* __restrict__ it_step, const pg_front* __restrict__ FD,
-                                                             double* __restrict__ F, double* __restrict__ R, int* __restrict__ fail, double* __restrict__ Tinv)
+// LDS buffers alternate between blocks, so two barriers per block order everything.  The body is instantiated once per
+// wavefront index, so which tiles a wavefront owns is known at compile time: straight-line code, tiles in fixed registers.
+struct pg_d3_lds { double lp[2][7][64]; double li[2][16]; int bad; };
+template <int W>
+__device__ __forceinline__ void pg_diag3_body(pg_d3_lds& sh, double* __restrict__ A, double* __restrict__ rr, double* __restrict__ tout, int n, int ld, int l)
 {
-    __shared__ double s_lp[2][7][64];
-    __shared__ double s_li[2][16];
-    __shared__ int s_bad;
-    const pg_front fd = FD[it_front[blockIdx.x]];
-    const int step = it_step[blockIdx.x], col0 = 96 * step;
-    const int n = min(96, fd.s6 - col0), p = fd.pan0 + step, ld = fd.ld;
-    double* __restrict__ A = F + fd.off + (size_t)col0 * ld + col0;
-    double* __restrict__ rr = R + fd.roff + col0;
-    const int w = threadIdx.x >> 6, l = threadIdx.x & 63, j = l & 15, q = l >> 4;
-    if (threadIdx.x == 0) s_bad = 0;
-    // this wavefront's tile columns: I0 = w (always), I1 = w + 4 (if < 7); tiles S0[T], T <= I0 and S1[T], T <= I1
-    const int I0 = w, I1 = w + 4;
-    const bool has1 = I1 < 7;
-    pg_d4 S0[4], S1[6];
+    constexpr int I0 = W, I1 = W + 4;
+    constexpr bool has1 = I1 < 7;
+    const int j = l & 15, q = l >> 4;
+    pg_d4 S0[I0 + 1], S1[has1 ? I1 + 1 : 1];      // tiles (T, I0), T <= I0 and (T, I1), T <= min(I1, 5)
 #pragma unroll
-    for (int T = 0; T < 4; ++T)
+    for (int T = 0; T <= I0; ++T)
 #pragma unroll
         for (int v = 0; v < 4; ++v) {
             const int row = 16 * I0 + j, col = 16 * T + q + 4 * v;
-            double val = 0.0;
-            if (T <= I0) {
-                if (row < n && col < n) val = col <= row ? A[(size_t)row * ld + col] : A[(size_t)col * ld + row];
-                else val = row == col ? 1.0 : 0.0;
-            }
+            double val;
+            if (row < n && col < n) val = col <= row ? A[(size_t)row * ld + col] : A[(size_t)col * ld + row];
+            else val = row == col ? 1.0 : 0.0;
             S0[T][v] = val;
         }
+    if (has1) {
 #pragma unroll
-    for (int T = 0; T < 6; ++T)
+        for (int T = 0; T <= (I1 < 6 ? I1 : 5); ++T)
 #pragma unroll
-        for (int v = 0; v < 4; ++v) {
-            const int row = 16 * I1 + j, col = 16 * T + q + 4 * v;
-            double val = 0.0;
-            if (has1 && T <= I1) {
+            for (int v = 0; v < 4; ++v) {
+                const int row = 16 * I1 + j, col = 16 * T + q + 4 * v;
+                double val;
                 if (I1 == 6) val = (j == 0 && col < n) ? rr[col] : 0.0;
-                else if (row < n && col < n) val = A[(size_t)row * ld + col];          // T < I1 here or the diagonal tile of I1 = 4, 5
+                else if (row < n && col < n) val = col <= row ? A[(size_t)row * ld + col] : A[(size_t)col * ld + row];
                 else val = row == col ? 1.0 : 0.0;
-                if (I1 < 6 && T == I1 && row < n && col < n && col > row) val = A[(size_t)col * ld + row];
+                S1[T][v] = val;
             }
-            S1[T][v] = val;
-        }
-    double* __restrict__ tout = Tinv + (size_t)p * PG_NB4 * 16;
+    }
     __syncthreads();
     int bad = 0;
+    const pg_d4 zero4 = { 0.0, 0.0, 0.0, 0.0 };
 #pragma unroll
     for (int t = 0; t < 6; ++t) {
-        if (16 * t >= n) break;                     // uniform: the rest is identity padding
-        const int pw = t & 3;                       // owner of tile (t, t): t < 4 -> its I0 column, t >= 4 -> its I1 column
+        if (16 * t >= n) break;                     // uniform over the workgroup: the rest is identity padding
 #pragma unroll
         for (int b = 0; b < 4; ++b) {
             const int buf = b & 1;
-            if (w == pw) {
+            if ((t & 3) == W) {                     // this wavefront owns tile (t, t): S0[t] for t < 4, S1[t] for t = 4, 5
                 double m[10], li[10];
-                const double dv = t < 4 ? S0[t & 3][b] : S1[t][b];      // tile (t, t): row t of the owner's column
+                double dv;
+                if (t < 4) dv = S0[t < 4 ? (t <= I0 ? t : 0) : 0][b]; else dv = S1[has1 ? t : 0][b];
                 int e = 0;
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
 #pragma unroll
                     for (int c2 = 0; c2 <= r; ++c2) m[e++] = pg_readlane(dv, (4 * b + r) + 16 * c2);
                 bad |= pg_chol4_inv(m, li);
-                if (l < 16) {                                        // Linv row-major 4 x 4 (zeros above the diagonal): LDS for this block, global for the kernels below the panel
-                    const int r = l >> 2, c2 = l & 3;
-                    double v = 0.0;
-                    if (c2 <= r) { const int e2 = r * (r + 1) / 2 + c2;
-                        v = e2 == 0 ? li[0] : e2 == 1 ? li[1] : e2 == 2 ? li[2] : e2 == 3 ? li[3] : e2 == 4 ? li[4] : e2 == 5 ? li[5] : e2 == 6 ? li[6] : e2 == 7 ? li[7] : e2 == 8 ? li[8] : li[9]; }
-                    s_li[buf][l] = v;
-                    tout[(4 * t + b) * 16 + l] = v;
+                if (l == 0) {                        // Linv row-major 4 x 4: LDS for this block, global for the kernels below the panel
+                    double* __restrict__ to = tout + (4 * t + b) * 16;
+                    e = 0;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+#pragma unroll
+                        for (int c2 = 0; c2 < 4; ++c2) { const double v = c2 <= r ? li[e++] : 0.0; if (c2 <= r) sh.li[buf][r * 4 + c2] = v; to[r * 4 + c2] = v; }
                 }
             }
             __syncthreads();
-            // LP of this wavefront's tile columns
-            const double lop = j < 4 ? s_li[buf][j * 4 + q] : 0.0;       // A operand of Linv x P^T: lane (i, m) = Linv[i][m]
-            const pg_d4 zero4 = { 0.0, 0.0, 0.0, 0.0 };
+            const double lop = j < 4 ? sh.li[buf][j * 4 + q] : 0.0;       // A operand of Linv x P^T: lane (i, m) = Linv[i][m]
             double LP0 = 0.0, LP1 = 0.0;
             if (I0 >= t) {
-                const pg_d4 r4 = __builtin_amdgcn_mfma_f64_16x16x4f64(lop, S0[t & 3][b], zero4, 0, 0, 0);
+                const pg_d4 r4 = __builtin_amdgcn_mfma_f64_16x16x4f64(lop, S0[t <= I0 ? t : 0][b], zero4, 0, 0, 0);
                 double v = r4[0];
                 if (I0 == t) { const int rj = j - 4 * b; if (rj < 0 || (rj < 4 && q > rj)) v = 0.0; }
-                LP0 = v; S0[t & 3][b] = v;
-                s_lp[buf][I0][l] = v;
+                LP0 = v; S0[t <= I0 ? t : 0][b] = v;
+                sh.lp[buf][I0][l] = v;
             }
             if (has1 && I1 >= t) {
-                const pg_d4 r4 = __builtin_amdgcn_mfma_f64_16x16x4f64(lop, S1[t][b], zero4, 0, 0, 0);
+                const pg_d4 r4 = __builtin_amdgcn_mfma_f64_16x16x4f64(lop, S1[has1 ? t : 0][b], zero4, 0, 0, 0);
                 double v = r4[0];
                 if (I1 == t) { const int rj = j - 4 * b; if (rj < 0 || (rj < 4 && q > rj)) v = 0.0; }
-                LP1 = v; S1[t][b] = v;
-                s_lp[buf][I1][l] = v;
+                LP1 = v; S1[has1 ? t : 0][b] = v;
+                sh.lp[buf][I1][l] = v;
             }
             __syncthreads();
-            // updates of the own tiles: (T', I0) for t <= T' <= I0 and (T', I1) for t <= T' <= I1
+            // updates of the own tiles (T', I0), t <= T' <= I0, and (T', I1), t <= T' <= min(I1, 5); the operands come in first
+            double aop[6];
 #pragma unroll
             for (int T2 = t; T2 < 6; ++T2) {
-                double a = -s_lp[buf][T2][l];
-                if (T2 == t && j < 4 * b + 4) a = 0.0;           // only the rows below the pivot block are updated
-                if (T2 < 4 && T2 <= I0) S0[T2 & 3] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, LP0, S0[T2 & 3], 0, 0, 0);
-                if (has1 && T2 <= I1) S1[T2] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, LP1, S1[T2], 0, 0, 0);
+                const bool need = T2 <= I0 || (has1 && T2 <= I1);
+                aop[T2] = need ? -sh.lp[buf][T2][l] : 0.0;
+            }
+            if (j < 4 * b + 4) aop[t] = 0.0;                      // pivot tile row: only the rows below the pivot block are updated
+#pragma unroll
+            for (int T2 = t; T2 < 6; ++T2) {
+                if (T2 <= I0) S0[T2 <= I0 ? T2 : 0] = __builtin_amdgcn_mfma_f64_16x16x4f64(aop[T2], LP0, S0[T2 <= I0 ? T2 : 0], 0, 0, 0);
+                if (has1 && T2 <= I1) S1[has1 ? T2 : 0] = __builtin_amdgcn_mfma_f64_16x16x4f64(aop[T2], LP1, S1[has1 ? T2 : 0], 0, 0, 0);
             }
         }
     }
-    if (bad) s_bad = 1;
-    __syncthreads();
-    if (s_bad && threadIdx.x == 0) *fail = 1;
+    if (bad) sh.bad = 1;
 #pragma unroll
-    for (int T = 0; T < 4; ++T)
+    for (int T = 0; T <= I0; ++T)
 #pragma unroll
         for (int v = 0; v < 4; ++v) {
             const int row = 16 * I0 + j, col = 16 * T + q + 4 * v;
-            if (T <= I0 && row < n && col <= row) A[(size_t)row * ld + col] = S0[T][v];
+            if (row < n && col <= row) A[(size_t)row * ld + col] = S0[T][v];
         }
+    if (has1) {
 #pragma unroll
-    for (int T = 0; T < 6; ++T)
+        for (int T = 0; T <= (I1 < 6 ? I1 : 5); ++T)
 #pragma unroll
-        for (int v = 0; v < 4; ++v) {
-            const int row = 16 * I1 + j, col = 16 * T + q + 4 * v;
-            if (!has1 || T > I1) continue;
-            if (I1 == 6) { if (j == 0 && col < n) rr[col] = S1[T][v]; }
-            else if (row < n && col <= row) A[(size_t)row * ld + col] = S1[T][v];
-        }
+            for (int v = 0; v < 4; ++v) {
+                const int row = 16 * I1 + j, col = 16 * T + q + 4 * v;
+                if (I1 == 6) { if (j == 0 && col < n) rr[col] = S1[T][v]; }
+                else if (row < n && col <= row) A[(size_t)row * ld + col] = S1[T][v];
+            }
+    }
+}
+__global__ __launch_bounds__(256) void pg_front_diag3_kernel(const int* __restrict__ it_front, const int* __restrict__ it_step, const pg_front* __restrict__ FD,
+                                                             double* __restrict__ F, double* __restrict__ R, int* __restrict__ fail, double* __restrict__ Tinv,
+                                                             unsigned long long* __restrict__ stamps)
+{
+    __shared__ pg_d3_lds sh;
+    const unsigned long long ts0 = stamps ? __builtin_amdgcn_s_memtime() : 0;
+    const pg_front fd = FD[it_front[blockIdx.x]];
+    const int step = it_step[blockIdx.x], col0 = 96 * step;
+    const int n = min(96, fd.s6 - col0), p = fd.pan0 + step, ld = fd.ld;
+    double* __restrict__ A = F + fd.off + (size_t)col0 * ld + col0;
+    double* __restrict__ rr = R + fd.roff + col0;
+    double* __restrict__ tout = Tinv + (size_t)p * PG_NB4 * 16;
+    const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+    if (threadIdx.x == 0) sh.bad = 0;
+    if (threadIdx.x < 32) sh.li[threadIdx.x >> 4][threadIdx.x & 15] = 0.0;     // the zeros above the diagonal of Linv stay
+    if (w == 0) pg_diag3_body<0>(sh, A, rr, tout, n, ld, l);
+    else if (w == 1) pg_diag3_body<1>(sh, A, rr, tout, n, ld, l);
+    else if (w == 2) pg_diag3_body<2>(sh, A, rr, tout, n, ld, l);
+    else pg_diag3_body<3>(sh, A, rr, tout, n, ld, l);
+    __syncthreads();
+    if (sh.bad && threadIdx.x == 0) *fail = 1;
+    if (stamps && threadIdx.x == 0 && blockIdx.x == 0) { stamps[0] = ts0; stamps[1] = ts0; stamps[2] = __builtin_amdgcn_s_memtime(); stamps[3] = stamps[2]; }
 }
 
 // L21 = A21 L11^-T for a slab of 16 rows per wavefront, by the same 4-column steps: LP = P Linv^T (three shuffles), then the
@@ -1930,6 +1943,7 @@ static int pg_solve_impl(dsss_ctx* c, const double* dr6, int total, const dsss_l
     { const size_t wn = (size_t)std::max(npan, 1) * (PG_PW * 6) * (PG_PW * 6); TRY(dv.alloc(c, &d_Wsw, wn)); TRY(dv.alloc(c, &d_Wrow, wn)); TRY(dv.alloc(c, &d_Uvec, (size_t)std::max(npan, 1) * (PG_PW * 6)));
       HIPCHK(c, hipMemsetAsync(d_Wsw, 0, wn * sizeof(double), c->stream)); HIPCHK(c, hipMemsetAsync(d_Wrow, 0, wn * sizeof(double), c->stream)); }
     static const bool old_panel = getenv("DSSS_PG_PANEL") && !strcmp(getenv("DSSS_PG_PANEL"), "inverse");      // A/B: the explicit-inverse panel kernels
+    unsigned long long* d_stamps = nullptr; if (getenv("DSSS_PG_STAMPS")) TRY(dv.alloc(c, &d_stamps, 16));
     static const bool one_wave = getenv("DSSS_PG_PANEL") && !strcmp(getenv("DSSS_PG_PANEL"), "onewave");
     double* d_Tinv; TRY(dv.alloc(c, &d_Tinv, (size_t)std::max(npan, 1) * PG_NB4 * 16));
     const int bwd_lds = old_panel ? PG_BWD_LDS(max_n6) : (int)(((PG_PW * 6) * PG_BWD2_LD + 10 * (PG_PW * 6) + max_n6 + 16) * sizeof(double));
@@ -2037,7 +2051,11 @@ static int pg_solve_impl(dsss_ctx* c, const double* dr6, int total, const dsss_l
                         { dsss_scope s3(c, DSSS_K_PG_DIAG, H.fl_diag[l]);
                           if (old_panel) hipLaunchKernelGGL(pg_front_diag_kernel, dim3(nit), dim3(256), PG_DIAG_LDS, st, itf, its, d_FD, d_F, d_R, d_fail, d_Wsw, d_Wrow, d_Uvec);
                           else if (one_wave) hipLaunchKernelGGL(pg_front_diag2_kernel, dim3(nit), dim3(64), 0, st, itf, its, d_FD, d_F, d_R, d_fail, d_Tinv);
-                          else hipLaunchKernelGGL(pg_front_diag3_kernel, dim3(nit), dim3(256), 0, st, itf, its, d_FD, d_F, d_R, d_fail, d_Tinv); }
+                          else {
+                              hipLaunchKernelGGL(pg_front_diag3_kernel, dim3(nit), dim3(256), 0, st, itf, its, d_FD, d_F, d_R, d_fail, d_Tinv, d_stamps);
+                              if (d_stamps && l == H.nlev - 1) { unsigned long long hs[16]; hipMemcpyAsync(hs, d_stamps, sizeof hs, hipMemcpyDeviceToHost, st); hipStreamSynchronize(st);
+                                  fprintf(stderr, "[dsss pg stamps] diag3 last level: %llu cycles\n", hs[2] - hs[0]); }
+                          } }
                         if (H.trsm_chunks[l] > 0) {
                             { dsss_scope s4(c, DSSS_K_PG_TRSM, H.fl_trsm[l]);
                               if (old_panel) hipLaunchKernelGGL(pg_front_trsm_kernel, dim3(nit, H.trsm_chunks[l]), dim3(256), 0, st, itf, its, d_FD, d_F, d_R, d_Wsw, d_Uvec);
