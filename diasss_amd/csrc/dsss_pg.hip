@@ -208,65 +208,86 @@ __global__ __launch_bounds__(256) void pg_assemble_kernel(int n, pg_weights W, c
     for (int a = 0; a < 6; ++a) g[(size_t)i * 6 + a] = gg[a];
 }
 
-// Schur complement of the interior of segment s (poses L+1 .. R-1) onto its end points L, R.
-// Stores the Cholesky factor of every eliminated pivot (Dl), the fill block E_i = H(L, i) and the updated
-// gradient for the back-substitution; outputs the end-point corrections.
-__global__ __launch_bounds__(64) void pg_segment_kernel(int nseg, const int* __restrict__ sep_pose, const double* __restrict__ D,
+// Schur complement of the interior of segment s (poses L+1 .. R-1) onto its end points L, R (block Thomas recursion).
+// Stores the Cholesky factor of every eliminated pivot (Dl), the fill block E_i = H(L, i) and the updated gradient for the
+// back-substitution; outputs the end-point corrections.  SIXTEEN LANES PER SEGMENT (sixteen segments per workgroup): per pose the
+// thirteen right-hand sides of D_i^-1 [E_i^T | C_i | g_i] go to thirteen lanes (each factorises the 6 x 6 pivot itself: cheaper
+// than broadcasting the factor), and the products with E_i and C_i^T that follow are column-parallel as well.  One thread per
+// segment took 24 us per pose (3 000 dependent f64 operations, 512 registers and scratch); this takes well under 1 us.
+#define PG_SEG_LANES 16
+struct pg_seg_lds { double E[36], C[36], D[36], G[6], pad[14]; };
+#define PG_GROUP_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
+__global__ __launch_bounds__(256) void pg_segment_kernel(int nseg, const int* __restrict__ sep_pose, const double* __restrict__ D,
                                                         const double* __restrict__ C, const double* __restrict__ g,
                                                         double* __restrict__ E, double* __restrict__ Dl, double* __restrict__ gi,
                                                         double* __restrict__ segDL, double* __restrict__ segDR, double* __restrict__ segGL,
                                                         double* __restrict__ segGR, double* __restrict__ segS, int* __restrict__ fail, int mp0, int mp1)
 {
-    const int s = blockIdx.x * 64 + threadIdx.x;
-    if (s >= nseg) return;
+    __shared__ pg_seg_lds sh_all[256 / PG_SEG_LANES];
+    const int grp = threadIdx.x / PG_SEG_LANES, c = threadIdx.x % PG_SEG_LANES;
+    const int s = blockIdx.x * (256 / PG_SEG_LANES) + grp;
+    if (s >= nseg) return;                                      // whole groups leave together
+    pg_seg_lds& sh = sh_all[grp];
     const int L = sep_pose[s], R = sep_pose[s + 1];
     if (L + 1 < mp0 || L + 1 >= mp1) return;                    // a segment belongs to the owner of its poses (partitions end on a separator)
-    double DL[36], GL[6], Dn[36], Gn[6], Ei[36];
-    for (int a = 0; a < 36; ++a) DL[a] = 0;
-    for (int a = 0; a < 6; ++a) GL[a] = 0;
     if (R == L + 1) {
-        for (int a = 0; a < 36; ++a) { segDL[(size_t)s * 36 + a] = 0; segDR[(size_t)s * 36 + a] = 0; segS[(size_t)s * 36 + a] = C[(size_t)L * 36 + a]; }
-        for (int a = 0; a < 6; ++a) { segGL[(size_t)s * 6 + a] = 0; segGR[(size_t)s * 6 + a] = 0; }
+        for (int a = c; a < 36; a += PG_SEG_LANES) { segDL[(size_t)s * 36 + a] = 0; segDR[(size_t)s * 36 + a] = 0; segS[(size_t)s * 36 + a] = C[(size_t)L * 36 + a]; }
+        if (c < 6) { segGL[(size_t)s * 6 + c] = 0; segGR[(size_t)s * 6 + c] = 0; }
         return;
     }
-    for (int a = 0; a < 36; ++a) { Ei[a] = C[(size_t)L * 36 + a]; Dn[a] = D[(size_t)(L + 1) * 36 + a]; }
-    for (int a = 0; a < 6; ++a) Gn[a] = g[(size_t)(L + 1) * 6 + a];
+    for (int a = c; a < 36; a += PG_SEG_LANES) { sh.E[a] = C[(size_t)L * 36 + a]; sh.D[a] = D[(size_t)(L + 1) * 36 + a]; }
+    if (c < 6) sh.G[c] = g[(size_t)(L + 1) * 6 + c];
+    double accL[6] = { 0, 0, 0, 0, 0, 0 };                      // lane b < 6: column b of DL; lane 12: GL
     for (int i = L + 1; i < R; ++i) {
-        double Li[36], XE[36], XC[36], Xg[6], Ci[36];
-        for (int a = 0; a < 36; ++a) { Li[a] = Dn[a]; Ci[a] = C[(size_t)i * 36 + a]; E[(size_t)i * 36 + a] = Ei[a]; }
-        for (int a = 0; a < 6; ++a) { Xg[a] = Gn[a]; gi[(size_t)i * 6 + a] = Gn[a]; }
-        if (chol6(Li)) { *fail = 1; return; }
-        for (int a = 0; a < 36; ++a) Dl[(size_t)i * 36 + a] = Li[a];
-        for (int a = 0; a < 6; ++a) for (int b = 0; b < 6; ++b) XE[a * 6 + b] = Ei[b * 6 + a];      // E_i^T
-        for (int a = 0; a < 36; ++a) XC[a] = Ci[a];
-        chol6_solve(Li, XE, 6); chol6_solve(Li, XC, 6); chol6_solve(Li, Xg, 1);
-        // next pivot block and its gradient (the right separator's share when i + 1 == R)
-        double Dnext[36], Gnext[6], En[36];
         const bool last = (i + 1 == R);
-        for (int a = 0; a < 36; ++a) Dnext[a] = last ? 0.0 : D[(size_t)(i + 1) * 36 + a];
-        for (int a = 0; a < 6; ++a) Gnext[a] = last ? 0.0 : g[(size_t)(i + 1) * 6 + a];
+        for (int a = c; a < 36; a += PG_SEG_LANES) sh.C[a] = C[(size_t)i * 36 + a];
+        PG_GROUP_SYNC();
+        // per-step records for the back-substitution
+        for (int a = c; a < 36; a += PG_SEG_LANES) E[(size_t)i * 36 + a] = sh.E[a];
+        if (c < 6) gi[(size_t)i * 6 + c] = sh.G[c];
+        double Li[36], ri[6], y[6];
+#pragma unroll
+        for (int a = 0; a < 36; ++a) Li[a] = sh.D[a];
+        if (chol6_fast(Li, ri)) { *fail = 1; return; }          // every lane of the group sees the same pivot: they leave together
+#pragma unroll
+        for (int a = 0; a < 6; ++a)
+#pragma unroll
+            for (int b2 = 0; b2 < 6; ++b2) if (b2 > a) Li[a * 6 + b2] = 0.0;
+        // right-hand side of this lane: c < 6 row c of E (column of E^T), 6 <= c < 12 column c - 6 of C, c == 12 the gradient
+        if (c < 6) { for (int q = 0; q < 6; ++q) y[q] = sh.E[c * 6 + q]; }
+        else if (c < 12) { for (int q = 0; q < 6; ++q) y[q] = sh.C[q * 6 + (c - 6)]; }
+        else { for (int q = 0; q < 6; ++q) y[q] = sh.G[q]; }
+#pragma unroll
+        for (int a = 0; a < 6; ++a) { double t = y[a]; for (int k = 0; k < a; ++k) t -= Li[a * 6 + k] * y[k]; y[a] = t * ri[a]; }
+#pragma unroll
+        for (int a = 5; a >= 0; --a) { double t = y[a]; for (int k = a + 1; k < 6; ++k) t -= Li[k * 6 + a] * y[k]; y[a] = t * ri[a]; }
+        double eo[6], co[6];                                     // E y and C^T y
+#pragma unroll
         for (int a = 0; a < 6; ++a) {
-            for (int b = 0; b < 6; ++b) {
-                double sLL = 0, sLn = 0, snn = 0;
-                for (int q = 0; q < 6; ++q) {
-                    sLL += Ei[a * 6 + q] * XE[q * 6 + b];
-                    sLn += Ei[a * 6 + q] * XC[q * 6 + b];
-                    snn += Ci[q * 6 + a] * XC[q * 6 + b];
-                }
-                DL[a * 6 + b] -= sLL;
-                En[a * 6 + b] = -sLn;
-                Dnext[a * 6 + b] -= snn;
-            }
-            double tL = 0, tn = 0;
-            for (int q = 0; q < 6; ++q) { tL += Ei[a * 6 + q] * Xg[q]; tn += Ci[q * 6 + a] * Xg[q]; }
-            GL[a] -= tL;
-            Gnext[a] -= tn;
+            double t = 0, u = 0;
+#pragma unroll
+            for (int q = 0; q < 6; ++q) { t += sh.E[a * 6 + q] * y[q]; u += sh.C[q * 6 + a] * y[q]; }
+            eo[a] = t; co[a] = u;
         }
-        for (int a = 0; a < 36; ++a) { Ei[a] = En[a]; Dn[a] = Dnext[a]; }
-        for (int a = 0; a < 6; ++a) Gn[a] = Gnext[a];
+        if (c < 6 || c == 12) for (int a = 0; a < 6; ++a) accL[a] -= eo[a];
+        PG_GROUP_SYNC();                                         // everybody is done reading E, D, G of this step
+        if (c == 0) for (int a = 0; a < 36; ++a) sh.D[a] = Li[a];                // the factor, for the record below
+        PG_GROUP_SYNC();
+        for (int a = c; a < 36; a += PG_SEG_LANES) Dl[(size_t)i * 36 + a] = sh.D[a];
+        PG_GROUP_SYNC();
+        if (c >= 6 && c < 12) {
+            const int b2 = c - 6;
+            for (int a = 0; a < 6; ++a) {
+                sh.E[a * 6 + b2] = -eo[a];                                         // E_next = -E X_C
+                sh.D[a * 6 + b2] = (last ? 0.0 : D[(size_t)(i + 1) * 36 + a * 6 + b2]) - co[a];      // next pivot (the right separator's share when i + 1 == R)
+            }
+        } else if (c == 12) for (int a = 0; a < 6; ++a) sh.G[a] = (last ? 0.0 : g[(size_t)(i + 1) * 6 + a]) - co[a];
+        PG_GROUP_SYNC();
     }
-    for (int a = 0; a < 36; ++a) { segDL[(size_t)s * 36 + a] = DL[a]; segDR[(size_t)s * 36 + a] = Dn[a]; segS[(size_t)s * 36 + a] = Ei[a]; }
-    for (int a = 0; a < 6; ++a) { segGL[(size_t)s * 6 + a] = GL[a]; segGR[(size_t)s * 6 + a] = Gn[a]; }
+    if (c < 6) for (int a = 0; a < 6; ++a) segDL[(size_t)s * 36 + a * 6 + c] = accL[a];
+    if (c == 12) for (int a = 0; a < 6; ++a) segGL[(size_t)s * 6 + a] = accL[a];
+    for (int a = c; a < 36; a += PG_SEG_LANES) { segDR[(size_t)s * 36 + a] = sh.D[a]; segS[(size_t)s * 36 + a] = sh.E[a]; }
+    if (c < 6) segGR[(size_t)s * 6 + c] = sh.G[c];
 }
 
 // the level-1 chain after pass 1: diagonal block, coupling to the next entry and gradient of every chunk end / true separator
@@ -859,10 +880,19 @@ __global__ __launch_bounds__(256) void pg_front_syrk_kernel(const int* __restric
     const int i0 = 64 * ti + 16 * wave;
     const int ir = i0 + (l & 15);
     double a[24];
+    pg_d4 acc[4];
     {
         const double* __restrict__ Ai = A + (size_t)(row0 + min(ir, nrows - 1)) * ld + col0;
 #pragma unroll
         for (int ks = 0; ks < 24; ++ks) { const int k = 4 * ks + (l >> 4); a[ks] = (ir < nrows && k < n) ? -Ai[k] : 0.0; }
+        // the four 16 x 16 blocks of C this wavefront updates come in with the operands: one round trip to memory, not five
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int j0 = 64 * tj + 16 * c, jr = j0 + (l & 15);
+            const double* __restrict__ Cp = A + (size_t)(row0 + i0 + (l >> 4)) * ld + row0 + j0 + (l & 15);
+#pragma unroll
+            for (int v = 0; v < 4; ++v) acc[c][v] = (i0 < nrows && j0 <= i0 + 15 && i0 + (l >> 4) + 4 * v < nrows && jr < nrows) ? Cp[(size_t)(4 * v) * ld] : 0.0;
+        }
     }
     __syncthreads();
     if (i0 >= nrows) return;
@@ -872,14 +902,12 @@ __global__ __launch_bounds__(256) void pg_front_syrk_kernel(const int* __restric
         if (j0 >= nrows || j0 > i0 + 15) break;              // beyond the front, or entirely above the diagonal (uniform per wavefront)
         const int jr = j0 + (l & 15);
         const double* __restrict__ sb = sB + (16 * c + (l & 15)) * PG_SYRK_LD + (l >> 4);
-        pg_d4 acc;
         double* __restrict__ Cp = A + (size_t)(row0 + i0 + (l >> 4)) * ld + row0 + j0 + (l & 15);
+        pg_d4 r = acc[c];
 #pragma unroll
-        for (int v = 0; v < 4; ++v) acc[v] = (i0 + (l >> 4) + 4 * v < nrows && jr < nrows) ? Cp[(size_t)(4 * v) * ld] : 0.0;
+        for (int ks = 0; ks < 24; ++ks) r = __builtin_amdgcn_mfma_f64_16x16x4f64(a[ks], sb[4 * ks], r, 0, 0, 0);
 #pragma unroll
-        for (int ks = 0; ks < 24; ++ks) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[ks], sb[4 * ks], acc, 0, 0, 0);
-#pragma unroll
-        for (int v = 0; v < 4; ++v) if (i0 + (l >> 4) + 4 * v < nrows && jr < nrows) Cp[(size_t)(4 * v) * ld] = acc[v];
+        for (int v = 0; v < 4; ++v) if (i0 + (l >> 4) + 4 * v < nrows && jr < nrows) Cp[(size_t)(4 * v) * ld] = r[v];
     }
 }
 
@@ -1312,12 +1340,19 @@ __global__ __launch_bounds__(1024) void pg_front_bwd2_kernel(const int* __restri
             if (cc < n) {
                 const double* __restrict__ Ab = F + fd.off + (size_t)row0 * ld + col0 + cc;
                 int i = slot;
-                for (; i + 70 < nrows; i += 80) {                  // eight loads in flight
-                    double a8[8];
+                for (; i + 150 < nrows; i += 160) {                // sixteen loads in flight
+                    double a16[16];
 #pragma unroll
-                    for (int u = 0; u < 8; ++u) a8[u] = Ab[(size_t)(i + 10 * u) * ld];
+                    for (int u = 0; u < 16; ++u) a16[u] = Ab[(size_t)(i + 10 * u) * ld];
 #pragma unroll
-                    for (int u = 0; u < 8; ++u) { if (u & 1) acc1 += a8[u] * sx[i + 10 * u]; else acc0 += a8[u] * sx[i + 10 * u]; }
+                    for (int u = 0; u < 16; ++u) { if (u & 1) acc1 += a16[u] * sx[i + 10 * u]; else acc0 += a16[u] * sx[i + 10 * u]; }
+                }
+                for (; i + 30 < nrows; i += 40) {
+                    double a4[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) a4[u] = Ab[(size_t)(i + 10 * u) * ld];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) { if (u & 1) acc1 += a4[u] * sx[i + 10 * u]; else acc0 += a4[u] * sx[i + 10 * u]; }
                 }
                 for (; i < nrows; i += 10) acc0 += Ab[(size_t)i * ld] * sx[i];
             }
@@ -2030,9 +2065,9 @@ static int pg_solve_impl(dsss_ctx* c, const double* dr6, int total, const dsss_l
                 if (nparts > 1) hipMemsetAsync(d_comm, 0, comm_total * sizeof(double), st);
                 hipLaunchKernelGGL(pg_assemble_kernel, dim3((n + 255) / 256), dim3(256), 0, st, n, W, d_r, d_Ji, d_adj_ptr, d_adj_edge, d_ew, d_scal + 3, d_D, d_C, d_g, d_eb, mp0, mp1);
                 // pass 1: chunks of poses onto their ends; the level-1 chain; pass 2: runs of chunk ends onto the true separators
-                hipLaunchKernelGGL(pg_segment_kernel, dim3((nseg1 + 63) / 64), dim3(64), 0, st, nseg1, d_sep1, d_D, d_C, d_g, d_E, d_Dl, d_gi, d_sDL, d_sDR, d_sGL, d_sGR, d_sS, d_fail, mp0, mp1);
+                hipLaunchKernelGGL(pg_segment_kernel, dim3((nseg1 + 15) / 16), dim3(256), 0, st, nseg1, d_sep1, d_D, d_C, d_g, d_E, d_Dl, d_gi, d_sDL, d_sDR, d_sGL, d_sGR, d_sS, d_fail, mp0, mp1);
                 hipLaunchKernelGGL(pg_chain1_kernel, dim3((ns1 + 255) / 256), dim3(256), 0, st, ns1, d_sep1, d_D, d_g, d_sDL, d_sDR, d_sGL, d_sGR, d_sS, d_D1, d_C1, d_g1, mp0, mp1);
-                if (nseg > 0) hipLaunchKernelGGL(pg_segment_kernel, dim3((nseg + 63) / 64), dim3(64), 0, st, nseg, d_t2, d_D1, d_C1, d_g1, d_E1, d_Dl1, d_gi1, d_s2DL, d_s2DR, d_s2GL, d_s2GR, d_s2S, d_fail, kp0, kp1);
+                if (nseg > 0) hipLaunchKernelGGL(pg_segment_kernel, dim3((nseg + 15) / 16), dim3(256), 0, st, nseg, d_t2, d_D1, d_C1, d_g1, d_E1, d_Dl1, d_gi1, d_s2DL, d_s2DR, d_s2GL, d_s2GR, d_s2S, d_fail, kp0, kp1);
                 hipLaunchKernelGGL(pg_scatter_base_kernel, dim3((ns + 255) / 256), dim3(256), 0, st, ns, d_t2, d_perm, d_D1, d_g1, d_s2DL, d_s2DR, d_s2GL, d_s2GR, d_s2S, d_dest, d_L, d_aval, d_x,
                                    d_ifslot, d_avalif, d_xif, kp0, kp1);
                 if (ne > 0) hipLaunchKernelGGL(pg_scatter_lc_kernel, dim3((ne + 255) / 256), dim3(256), 0, st, n, ne, ns, d_Ji, d_ew, d_dest, d_L, d_aval, d_avalif, d_eb, mp0, mp1);
