@@ -26,6 +26,8 @@ int dsss_quadtree_cull(const float* xs, const float* ys, const float* resp, int 
 // (uploaded once per batch) carries the frame's buffers and sizes.  Frames of different sizes share a launch; the
 // grid is sized for the largest and the rest exit early.
 struct fast_cell { int level, x0, y0, w, h, offx, offy, pad; };
+struct resize_xtab { int sx; short a0, a1; };     // cv::resize tables: source column (sx + 1 is read only when a1 != 0), 11-bit weights
+struct resize_ytab { int ya, yb; short b0, b1; };
 struct ex_frame {
     const double* raw; int N, M;
     double* rowsum; double* rowmin; double* stats;
@@ -36,6 +38,7 @@ struct ex_frame {
     const double* pose6; const double* gr;
     dsss_kp* kout; uint8_t* dout; double* geo; int* count;
     int* err;                      // per-slot error flag (shared with the quadtree descriptors)
+    const resize_xtab* xt[DSSS_MAX_LEVELS]; const resize_ytab* yt[DSSS_MAX_LEVELS];      // per level l >= 1: tables of the resize from l - 1
 };
 
 // ------------------------------------------------------------------ K1: mean / min, normalise, mask
@@ -92,17 +95,25 @@ __global__ __launch_bounds__(64) void final_reduce_kernel(const ex_frame* __rest
     }
 }
 
-// static part of Frame::GetFilteredMask (frame.cpp:104-112)
-__global__ void mask_init_kernel(const ex_frame* __restrict__ frs, int width, int side, double sidec)
+// static part of Frame::GetFilteredMask (frame.cpp:104-112); sixteen bytes per thread, one 16-byte store (the mask buffer is
+// 256-byte aligned and the flat index of a group is a multiple of 16; a group may wrap into the next ping)
+__global__ __launch_bounds__(256) void mask_init_kernel(const ex_frame* __restrict__ frs, int width, int side, double sidec)
 {
     const ex_frame& f = frs[blockIdx.y];
     uint8_t* __restrict__ mask = f.mask; const int N = f.N, M = f.M;
-    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= (size_t)N * M) return;
-    const int r = (int)(i / M), c = (int)(i % M);
-    bool off = (c > M / 2 - width && c < M / 2 + width) || (r < side || r > N - side) ||
-               ((double)c < sidec || (double)c > (double)M - sidec);
-    mask[i] = off ? 0 : 255;
+    const size_t total = (size_t)N * M;
+    const size_t i0 = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 16;
+    if (i0 >= total) return;
+    int r = (int)(i0 / M), c = (int)(i0 - (size_t)r * M);
+    uint32_t w[4] = { 0, 0, 0, 0 };
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+        const bool off = (c > M / 2 - width && c < M / 2 + width) || (r < side || r > N - side) || ((double)c < sidec || (double)c > (double)M - sidec);
+        if (!off) w[u >> 2] |= 255u << (8 * (u & 3));
+        if (++c == M) { c = 0; ++r; }
+    }
+    if (i0 + 16 <= total) *reinterpret_cast<uint4*>(mask + i0) = make_uint4(w[0], w[1], w[2], w[3]);
+    else for (size_t u = 0; i0 + u < total; ++u) mask[i0 + u] = (uint8_t)(w[u >> 2] >> (8 * (u & 3)));
 }
 
 // Frame::GetNormalizeSSS (frame.cpp:67-78) + the hot-pixel eraser of GetFilteredMask (:98-103).
@@ -145,34 +156,37 @@ __global__ __launch_bounds__(256) void normalize_kernel(const ex_frame* __restri
 // (ORBextractor.cpp:1128).  11-bit fixed point exactly as OpenCV's scalar path: see oracle/orc_orb.c.
 __device__ inline int cvfloorf_dev(float v) { const int i = (int)v; return i - (v < (float)i); }
 
+// cv::resize(INTER_LINEAR) of one pyramid level from the previous one, OpenCV's scalar u8 path: 11-bit fixed-point weights per
+// output column / row (tables built once per geometry by resize_tables(), the same float arithmetic OpenCV uses), horizontal pass
+// in int, vertical pass with the two 16-bit shifts.  A thread produces FOUR consecutive bytes of the level (flat index, so the
+// 4-byte store is always aligned, a group may wrap into the next row) -- the one-byte-per-thread form stored at 7 % of HBM speed.
 __global__ __launch_bounds__(256) void resize_kernel(const ex_frame* __restrict__ frs, int level)
 {
-    const ex_frame& f = frs[blockIdx.z];
+    const ex_frame& f = frs[blockIdx.y];
     if (level >= f.nlevels) return;
     const uint8_t* __restrict__ src = f.lvl[level - 1]; uint8_t* __restrict__ dst = f.lvl[level];
-    const int sh = f.rows[level - 1], sw = f.cols[level - 1], dh = f.rows[level], dw = f.cols[level];
-    const int dx = blockIdx.x * blockDim.x + threadIdx.x, dy = blockIdx.y;
-    if (dx >= dw || dy >= dh) return;
-    const double scale_x = 1. / ((double)dw / sw), scale_y = 1. / ((double)dh / sh);        // cv::resize: inv_scale = dsize / ssize
-    float fx = (float)((dx + 0.5) * scale_x - 0.5);
-    int sx = cvfloorf_dev(fx);
-    fx -= sx;
-    bool edge = false;
-    if (sx < 0) { fx = 0; sx = 0; }
-    if (sx + 1 >= sw) { edge = true; if (sx >= sw - 1) { fx = 0; sx = sw - 1; } }
-    const int a0 = __float2int_rn((1.f - fx) * 2048.f), a1 = __float2int_rn(fx * 2048.f);
-    float fy = (float)((dy + 0.5) * scale_y - 0.5);
-    const int sy = cvfloorf_dev(fy);
-    fy -= sy;
-    const int b0 = __float2int_rn((1.f - fy) * 2048.f), b1 = __float2int_rn(fy * 2048.f);
-    const int ya = sy < 0 ? 0 : (sy < sh ? sy : sh - 1);
-    const int yb = sy + 1 < 0 ? 0 : (sy + 1 < sh ? sy + 1 : sh - 1);
-    const uint8_t* S0 = src + (size_t)ya * sw;
-    const uint8_t* S1 = src + (size_t)yb * sw;
-    int r0, r1;
-    if (!edge) { r0 = S0[sx] * a0 + S0[sx + 1] * a1; r1 = S1[sx] * a0 + S1[sx + 1] * a1; }
-    else { r0 = S0[sx] * 2048; r1 = S1[sx] * 2048; }     // dx >= xmax in OpenCV's HResize
-    dst[(size_t)dy * dw + dx] = (uint8_t)((((b0 * (r0 >> 4)) >> 16) + ((b1 * (r1 >> 4)) >> 16) + 2) >> 2);
+    const int sw = f.cols[level - 1], dh = f.rows[level], dw = f.cols[level];
+    const resize_xtab* __restrict__ xt = f.xt[level]; const resize_ytab* __restrict__ yt = f.yt[level];
+    const long long total = (long long)dw * dh;
+    const long long g0 = 4 * ((long long)blockIdx.x * 256 + threadIdx.x);
+    if (g0 >= total) return;
+    int dy = (int)(g0 / dw), dx = (int)(g0 - (long long)dy * dw);
+    uint32_t out = 0;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        if (g0 + u < total) {
+            const resize_xtab X = xt[dx]; const resize_ytab Y = yt[dy];
+            const uint8_t* S0 = src + (size_t)Y.ya * sw; const uint8_t* S1 = src + (size_t)Y.yb * sw;
+            int r0, r1;
+            if (X.a1) { r0 = S0[X.sx] * X.a0 + S0[X.sx + 1] * X.a1; r1 = S1[X.sx] * X.a0 + S1[X.sx + 1] * X.a1; }
+            else { r0 = S0[X.sx] * X.a0; r1 = S1[X.sx] * X.a0; }
+            const uint32_t v = (uint32_t)((((Y.b0 * (r0 >> 4)) >> 16) + ((Y.b1 * (r1 >> 4)) >> 16) + 2) >> 2) & 255u;
+            out |= v << (8 * u);
+        }
+        if (++dx == dw) { dx = 0; ++dy; }
+    }
+    if (g0 + 3 < total) *reinterpret_cast<uint32_t*>(dst + g0) = out;
+    else for (int u = 0; g0 + u < total; ++u) dst[g0 + u] = (uint8_t)(out >> (8 * u));
 }
 
 // ------------------------------------------------------------------ K3: cv::FAST 9/16 per 30-px cell
@@ -521,7 +535,8 @@ struct level_geom {
     long long cand_bound = 0;             // sum over the cells of the strict local maxima each can hold: the frame can never exceed it
     fast_cell* d_cells = nullptr;         // device copy (per geometry, cached in the context)
     int* d_lrows = nullptr; float* d_lscale = nullptr;
-    ~level_geom() { hipFree(d_cells); hipFree(d_lrows); hipFree(d_lscale); }
+    resize_xtab* d_xt[DSSS_MAX_LEVELS] = { nullptr }; resize_ytab* d_yt[DSSS_MAX_LEVELS] = { nullptr };
+    ~level_geom() { hipFree(d_cells); hipFree(d_lrows); hipFree(d_lscale); for (int l = 0; l < DSSS_MAX_LEVELS; ++l) { hipFree(d_xt[l]); hipFree(d_yt[l]); } }
 };
 
 // scale tables, level sizes and quotas of the ORBextractor ctor / ComputePyramid (ORBextractor.cpp:415-446,1119-1120)
@@ -581,6 +596,31 @@ void build_geom(const dsss_orb_params& op, int rows, int cols, level_geom& g)
 
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
+// the coefficient tables of cv::resize(INTER_LINEAR), u8 scalar path: scale = src / dst in double,
+// fx = (float)((dx + 0.5) scale - 0.5), sx = floor(fx), clamped at both ends, weights cvRound((1 - fx) 2048), cvRound(fx 2048)
+inline int cvfloorf_host(float v) { const int i = (int)v; return i - (v < (float)i); }
+void resize_tables(int sh, int sw, int dh, int dw, std::vector<resize_xtab>& xt, std::vector<resize_ytab>& yt)
+{
+    const double scale_x = 1. / ((double)dw / sw), scale_y = 1. / ((double)dh / sh);
+    xt.resize(dw); yt.resize(dh);
+    for (int dx = 0; dx < dw; ++dx) {
+        float fx = (float)((dx + 0.5) * scale_x - 0.5);
+        int sx = cvfloorf_host(fx);
+        fx -= sx;
+        if (sx < 0) { fx = 0; sx = 0; }
+        if (sx >= sw - 1) { fx = 0; sx = sw - 1; }              // dx >= xmax in OpenCV's HResize: the last source column alone
+        xt[dx].sx = sx; xt[dx].a0 = (short)lrintf((1.f - fx) * 2048.f); xt[dx].a1 = (short)lrintf(fx * 2048.f);
+    }
+    for (int dy = 0; dy < dh; ++dy) {
+        float fy = (float)((dy + 0.5) * scale_y - 0.5);
+        const int sy = cvfloorf_host(fy);
+        fy -= sy;
+        yt[dy].b0 = (short)lrintf((1.f - fy) * 2048.f); yt[dy].b1 = (short)lrintf(fy * 2048.f);
+        yt[dy].ya = sy < 0 ? 0 : (sy < sh ? sy : sh - 1);
+        yt[dy].yb = sy + 1 < 0 ? 0 : (sy + 1 < sh ? sy + 1 : sh - 1);
+    }
+}
+
 struct geom_key { int N, M, nf, nl, it, mt; float sc; bool operator<(const geom_key& o) const {
     return std::tie(N, M, nf, nl, it, mt, sc) < std::tie(o.N, o.M, o.nf, o.nl, o.it, o.mt, o.sc); } };
 typedef std::map<geom_key, std::unique_ptr<level_geom>> geom_map;    // owned by the context (dsss_ctx::geoms), freed by dsss_destroy
@@ -607,6 +647,13 @@ static int get_geom(dsss_ctx* c, int N, int M, level_geom** out)
         HIPCHK(c, hipMemcpy(g->d_cells, g->cells.data(), sizeof(fast_cell) * g->cells.size(), hipMemcpyHostToDevice));
         HIPCHK(c, hipMemcpy(g->d_lrows, g->rows, sizeof(int) * DSSS_MAX_LEVELS, hipMemcpyHostToDevice));
         HIPCHK(c, hipMemcpy(g->d_lscale, g->sf, sizeof(float) * DSSS_MAX_LEVELS, hipMemcpyHostToDevice));
+        for (int l = 1; l < g->nlevels; ++l) {                  // cv::resize(INTER_LINEAR) tables of level l from level l - 1
+            std::vector<resize_xtab> xt; std::vector<resize_ytab> yt;
+            resize_tables(g->rows[l - 1], g->cols[l - 1], g->rows[l], g->cols[l], xt, yt);
+            HIPCHK(c, hipMalloc(&g->d_xt[l], xt.size() * sizeof(resize_xtab))); HIPCHK(c, hipMalloc(&g->d_yt[l], yt.size() * sizeof(resize_ytab)));
+            HIPCHK(c, hipMemcpy(g->d_xt[l], xt.data(), xt.size() * sizeof(resize_xtab), hipMemcpyHostToDevice));
+            HIPCHK(c, hipMemcpy(g->d_yt[l], yt.data(), yt.size() * sizeof(resize_ytab), hipMemcpyHostToDevice));
+        }
         it = geoms.emplace(k, std::move(g)).first;
     }
     *out = it->second.get();
@@ -753,6 +800,7 @@ static int extract_frames(dsss_ctx* c, const int* ids, int n, bool keep_taps)
             e.cand = (uint32_t*)(S + L.cand); e.counts = (int*)(S + L.counts); e.offs = (int*)(S + L.offs);
             e.xs = (float*)(S + L.xs); e.ys = (float*)(S + L.ys); e.rs = (float*)(S + L.rs); e.cand_cap = L.cand_cap;
             e.kin = (kp_in*)(S + L.kin); e.nk = (int*)(S + L.nk); e.lrows = g.d_lrows; e.lscale = g.d_lscale;
+            for (int l = 0; l < DSSS_MAX_LEVELS; ++l) { e.xt[l] = g.d_xt[l]; e.yt[l] = g.d_yt[l]; }
             e.kptmp = (dsss_kp*)(S + L.kptmp); e.dtmp = (uint8_t*)(S + L.dtmp);
             e.pose6 = f.pose6; e.gr = f.gr;
             e.err = d_errs + s; e.kout = c->kps + (size_t)id * c->kcap; e.dout = c->desc + (size_t)id * c->kcap * 32; e.geo = c->geo + (size_t)id * c->kcap * 2; e.count = c->nkp_dev + id;
@@ -783,12 +831,12 @@ static int extract_frames(dsss_ctx* c, const int* ids, int n, bool keep_taps)
           hipLaunchKernelGGL(row_reduce_kernel, dim3((maxN + 3) / 4, nb), dim3(256), 0, st, d_exf); }
         { dsss_scope sc(c, DSSS_K_PRE_MISC, 1.0 * w_tot, 2);
           hipLaunchKernelGGL(final_reduce_kernel, dim3(nb), dim3(64), 0, st, d_exf, (double)(float)c->mp.factor);
-          hipLaunchKernelGGL(mask_init_kernel, dim3((unsigned)((max_tot + 255) / 256), nb), dim3(256), 0, st, d_exf, c->mp.width, c->mp.side, (double)c->mp.side * 0.6); }
+          hipLaunchKernelGGL(mask_init_kernel, dim3((unsigned)((max_tot / 16 + 256) / 256), nb), dim3(256), 0, st, d_exf, c->mp.width, c->mp.side, (double)c->mp.side * 0.6); }
         { dsss_scope sc(c, DSSS_K_NORMALIZE, 9.0 * w_tot);
           hipLaunchKernelGGL(normalize_kernel, dim3((unsigned)((max_tot / 4 + 256) / 256), nb), dim3(256), 0, st, d_exf, c->mp.r); }
         { dsss_scope sc(c, DSSS_K_PYRAMID, (1.906 + 2.74) * w_tot, std::max(max_levels - 1, 1));
           for (int l = 1; l < max_levels; ++l)
-              hipLaunchKernelGGL(resize_kernel, dim3((max_cols[l] + 255) / 256, max_rows[l], nb), dim3(256), 0, st, d_exf, l); }
+              hipLaunchKernelGGL(resize_kernel, dim3((unsigned)(((size_t)max_cols[l] * max_rows[l] / 4 + 256) / 256), nb), dim3(256), 0, st, d_exf, l); }
         { dsss_scope sc(c, DSSS_K_FAST, 2.906 * w_tot);
           hipLaunchKernelGGL(fast_cells_kernel, dim3(max_cells, nb), dim3(256), 0, st, d_exf, c->op.ini_th, c->op.min_th); }
         { dsss_scope sc(c, DSSS_K_FAST_COMPACT, 0, 2);
