@@ -1,0 +1,18 @@
+#!/bin/bash
+# Collects the rocprofv3 evidence of a round on the GPU box (run through gpurun from the repo root):
+#   kernel trace + stats of the default bench command, then three SEPARATE counter passes (MI355X_MICROARCH.md "HBM" / "PMC slots":
+#   FETCH_SIZE and WRITE_SIZE do not fit one pass; counters never together with --sys-trace)
+# Output under gpurun_out/<tag>_*; tools/pmc_summary.py and tools/pmc_mfma_summary.py turn them into the tables under profiles/.
+TAG=${1:-r02}
+cd /tmp && export TMPDIR=/tmp; cd "$GRAFT_REPO_ROOT"
+B="python3 bench.py --steps 3 --warmup 1 --cpu-frames 0 --pcie-steps 0"
+rocprofv3 --kernel-trace --stats -d gpurun_out/${TAG}_stats -o ${TAG} --output-format csv -- $B > gpurun_out/${TAG}_bench_under_rocprof.log 2>&1
+P="python3 bench.py --steps 1 --warmup 0 --cpu-frames 0 --no-roofline --pcie-steps 0"
+rocprofv3 --pmc FETCH_SIZE --kernel-trace -d gpurun_out/${TAG}_pmc_fetch -o f --output-format csv -- $P > gpurun_out/${TAG}_pmc_fetch.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace -d gpurun_out/${TAG}_pmc_write -o w --output-format csv -- $P > gpurun_out/${TAG}_pmc_write.log 2>&1
+rocprofv3 --pmc SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace -d gpurun_out/${TAG}_pmc_mfma -o m --output-format csv -- $P > gpurun_out/${TAG}_pmc_mfma.log 2>&1
+python3 tools/pmc_summary.py gpurun_out/${TAG}_pmc_fetch/f_counter_collection.csv gpurun_out/${TAG}_pmc_write/w_counter_collection.csv gpurun_out/${TAG}_pmc_hbm_traffic_C3.csv > gpurun_out/${TAG}_pmc_hbm.txt 2>&1
+python3 tools/pmc_mfma_summary.py gpurun_out/${TAG}_pmc_mfma/m_counter_collection.csv gpurun_out/${TAG}_pmc_mfma_C3.csv > gpurun_out/${TAG}_pmc_mfma.txt 2>&1
+# keep what travels back small: the traces stay on the box except the stats tables
+rm -f gpurun_out/${TAG}_pmc_*/?_kernel_trace.csv gpurun_out/${TAG}_stats/${TAG}_kernel_trace.csv
+ls -la gpurun_out/${TAG}_* | head -40
