@@ -215,9 +215,12 @@ __global__ __launch_bounds__(256) void pg_assemble_kernel(int n, pg_weights W, c
 // than broadcasting the factor), and the products with E_i and C_i^T that follow are column-parallel as well.  One thread per
 // segment took 24 us per pose (3 000 dependent f64 operations, 512 registers and scratch); this takes well under 1 us.
 #define PG_SEG_LANES 16
-struct pg_seg_lds { double E[36], C[36], D[36], G[6], pad[14]; };
-#define PG_GROUP_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
-__global__ __launch_bounds__(256) void pg_segment_kernel(int nseg, const int* __restrict__ sep_pose, const double* __restrict__ D,
+struct pg_seg_lds { double E[2][36], D[2][36], G[2][6], C[36], L[36], pad[4]; };      // 232 doubles
+// the sixteen lanes of a group sit in one wavefront, whose LDS operations execute in program order: waiting for the LDS queue
+// (not for the global stores in flight -- a fence would) and keeping the compiler from moving memory operations across is enough
+#define PG_COMPILER_FENCE() asm volatile("" ::: "memory")
+#define PG_GROUP_SYNC() do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_wave_barrier(); } while (0)
+__global__ __launch_bounds__(256, 2) void pg_segment_kernel(int nseg, const int* __restrict__ sep_pose, const double* __restrict__ D,
                                                         const double* __restrict__ C, const double* __restrict__ g,
                                                         double* __restrict__ E, double* __restrict__ Dl, double* __restrict__ gi,
                                                         double* __restrict__ segDL, double* __restrict__ segDR, double* __restrict__ segGL,
@@ -235,59 +238,119 @@ __global__ __launch_bounds__(256) void pg_segment_kernel(int nseg, const int* __
         if (c < 6) { segGL[(size_t)s * 6 + c] = 0; segGR[(size_t)s * 6 + c] = 0; }
         return;
     }
-    for (int a = c; a < 36; a += PG_SEG_LANES) { sh.E[a] = C[(size_t)L * 36 + a]; sh.D[a] = D[(size_t)(L + 1) * 36 + a]; }
-    if (c < 6) sh.G[c] = g[(size_t)(L + 1) * 6 + c];
-    double accL[6] = { 0, 0, 0, 0, 0, 0 };                      // lane b < 6: column b of DL; lane 12: GL
+    for (int a = c; a < 36; a += PG_SEG_LANES) { sh.E[0][a] = C[(size_t)L * 36 + a]; sh.D[0][a] = D[(size_t)(L + 1) * 36 + a]; }
+    if (c < 6) sh.G[0][c] = g[(size_t)(L + 1) * 6 + c];
+    // Global memory is touched at ONE point of a step, its top: the blocks of the next step are requested there (nC = this lane's
+    // share of C_(i+1); column c - 6 of D_(i+1) on lanes 6..11, g_(i+1) on lane 13) and consumed at the top of the next
+    // step, and the records of the back-substitution (E_i, g_i, and the factor of the PREVIOUS step, parked in LDS) are stored
+    // there, so the one wait on the memory counter per step finds everything a whole step old.  (Dependent loads inside the
+    // step cost 8 000 of its 12 500 cycles.)  E, D, G are double-buffered in LDS: the next step's blocks are written as soon
+    // as they are computed, which keeps the live registers under 168 (three wavefronts per SIMD) and saves a group sync.
+    // pers[]: lanes 0..5 and 12 accumulate column c of DL / GL in it; lanes 6..11 and 13 keep their prefetched column in it.
+    double nC[3], pers[6] = { 0, 0, 0, 0, 0, 0 };
+    const bool is_acc = c < 6 || c == 12, is_nd = (c >= 6 && c < 12) || c == 13;
+    const int nd_stride = c == 13 ? 1 : 6;
+    const double* nd_src = c == 13 ? g : D + (c - 6);
+    const int nd_lds = c == 13 ? (int)(&sh.G[0][0] - &sh.E[0][0]) : (int)(&sh.D[0][0] - &sh.E[0][0]) + (c - 6);     // offsets from sh.E[0] in doubles
+    const int nd_flip = c == 13 ? 6 : 36;
+    int cb = 0;
+#pragma unroll
+    for (int u = 0; u < 3; ++u) { const int a = c + PG_SEG_LANES * u; nC[u] = a < 36 ? C[(size_t)(L + 1) * 36 + a] : 0.0; }
     for (int i = L + 1; i < R; ++i) {
         const bool last = (i + 1 == R);
-        for (int a = c; a < 36; a += PG_SEG_LANES) sh.C[a] = C[(size_t)i * 36 + a];
-        PG_GROUP_SYNC();
-        // per-step records for the back-substitution
-        for (int a = c; a < 36; a += PG_SEG_LANES) E[(size_t)i * 36 + a] = sh.E[a];
-        if (c < 6) gi[(size_t)i * 6 + c] = sh.G[c];
-        double Li[36], ri[6], y[6];
+        double* __restrict__ Ec = sh.E[cb]; double* __restrict__ Dc = sh.D[cb]; double* __restrict__ Gc = sh.G[cb];
+        double* __restrict__ En = sh.E[cb ^ 1]; double* __restrict__ Dn = sh.D[cb ^ 1]; double* __restrict__ Gn = sh.G[cb ^ 1];
 #pragma unroll
-        for (int a = 0; a < 36; ++a) Li[a] = sh.D[a];
-        if (chol6_fast(Li, ri)) { *fail = 1; return; }          // every lane of the group sees the same pivot: they leave together
+        for (int u = 0; u < 3; ++u) { const int a = c + PG_SEG_LANES * u; if (a < 36) sh.C[a] = nC[u]; }
+        if (is_nd) {                                             // completes the entries the last step left in D and G
+            double* dst = &sh.E[0][0] + nd_lds + cb * nd_flip;
+#pragma unroll
+            for (int a = 0; a < 6; ++a) dst[a * nd_stride] += pers[a];
+        }
+        if (!last) {
+#pragma unroll
+            for (int u = 0; u < 3; ++u) { const int a = c + PG_SEG_LANES * u; if (a < 36) nC[u] = C[(size_t)(i + 1) * 36 + a]; }
+            if (is_nd) {                                         // ONE load sequence for both kinds of lane: two divergent ones that
+                const double* src = nd_src + (size_t)(i + 1) * (c == 13 ? 6 : 36);       // write the same registers are serialised by a full wait
+#pragma unroll
+                for (int a = 0; a < 6; ++a) pers[a] = src[a * nd_stride];
+            }
+        }
+        if (i > L + 1) for (int a = c; a < 36; a += PG_SEG_LANES) Dl[(size_t)(i - 1) * 36 + a] = sh.L[a];
+        PG_GROUP_SYNC();
+        for (int a = c; a < 36; a += PG_SEG_LANES) E[(size_t)i * 36 + a] = Ec[a];
+        if (c < 6) gi[(size_t)i * 6 + c] = Gc[c];
+        // (the compiler-only barriers keep the LDS reads of the later phases from being hoisted to the top of the step)
+        double Li[36], ri[6], y[6];
 #pragma unroll
         for (int a = 0; a < 6; ++a)
 #pragma unroll
-            for (int b2 = 0; b2 < 6; ++b2) if (b2 > a) Li[a * 6 + b2] = 0.0;
+            for (int b2 = 0; b2 < 6; ++b2) Li[a * 6 + b2] = b2 <= a ? Dc[a * 6 + b2] : 0.0;
+        if (chol6_fast(Li, ri)) { *fail = 1; return; }          // every lane of the group sees the same pivot: they leave together
+        if (c == 0) {                                            // the factor, for the record (stored at the top of the next step)
+#pragma unroll
+            for (int a = 0; a < 36; ++a) sh.L[a] = Li[a];
+        }
+        PG_COMPILER_FENCE();
         // right-hand side of this lane: c < 6 row c of E (column of E^T), 6 <= c < 12 column c - 6 of C, c == 12 the gradient
-        if (c < 6) { for (int q = 0; q < 6; ++q) y[q] = sh.E[c * 6 + q]; }
-        else if (c < 12) { for (int q = 0; q < 6; ++q) y[q] = sh.C[q * 6 + (c - 6)]; }
-        else { for (int q = 0; q < 6; ++q) y[q] = sh.G[q]; }
+        {
+            const double* ysrc = c < 6 ? Ec + c * 6 : c < 12 ? sh.C + (c - 6) : Gc;
+            const int ystr = (c >= 6 && c < 12) ? 6 : 1;
+#pragma unroll
+            for (int q = 0; q < 6; ++q) y[q] = ysrc[q * ystr];
+        }
 #pragma unroll
         for (int a = 0; a < 6; ++a) { double t = y[a]; for (int k = 0; k < a; ++k) t -= Li[a * 6 + k] * y[k]; y[a] = t * ri[a]; }
 #pragma unroll
         for (int a = 5; a >= 0; --a) { double t = y[a]; for (int k = a + 1; k < 6; ++k) t -= Li[k * 6 + a] * y[k]; y[a] = t * ri[a]; }
-        double eo[6], co[6];                                     // E y and C^T y
+        PG_COMPILER_FENCE();
+        {   // E y: column c - 6 of E_next = -E X_C on lanes 6..11; accumulated into DL / GL on lanes 0..5 and 12
+            double eo[6];
 #pragma unroll
-        for (int a = 0; a < 6; ++a) {
-            double t = 0, u = 0;
-#pragma unroll
-            for (int q = 0; q < 6; ++q) { t += sh.E[a * 6 + q] * y[q]; u += sh.C[q * 6 + a] * y[q]; }
-            eo[a] = t; co[a] = u;
-        }
-        if (c < 6 || c == 12) for (int a = 0; a < 6; ++a) accL[a] -= eo[a];
-        PG_GROUP_SYNC();                                         // everybody is done reading E, D, G of this step
-        if (c == 0) for (int a = 0; a < 36; ++a) sh.D[a] = Li[a];                // the factor, for the record below
-        PG_GROUP_SYNC();
-        for (int a = c; a < 36; a += PG_SEG_LANES) Dl[(size_t)i * 36 + a] = sh.D[a];
-        PG_GROUP_SYNC();
-        if (c >= 6 && c < 12) {
-            const int b2 = c - 6;
             for (int a = 0; a < 6; ++a) {
-                sh.E[a * 6 + b2] = -eo[a];                                         // E_next = -E X_C
-                sh.D[a * 6 + b2] = (last ? 0.0 : D[(size_t)(i + 1) * 36 + a * 6 + b2]) - co[a];      // next pivot (the right separator's share when i + 1 == R)
+                double t = 0;
+#pragma unroll
+                for (int q = 0; q < 6; ++q) t += Ec[a * 6 + q] * y[q];
+                eo[a] = t;
             }
-        } else if (c == 12) for (int a = 0; a < 6; ++a) sh.G[a] = (last ? 0.0 : g[(size_t)(i + 1) * 6 + a]) - co[a];
+            if (is_acc) {
+#pragma unroll
+                for (int a = 0; a < 6; ++a) pers[a] -= eo[a];
+            } else if (c < 12) {
+#pragma unroll
+                for (int a = 0; a < 6; ++a) En[a * 6 + (c - 6)] = -eo[a];
+            }
+        }
+        PG_COMPILER_FENCE();
+        {   // C^T y: the next pivot less D_(i+1) (added at the top of the next step; the right separator's share when i + 1 == R)
+            double co[6];
+#pragma unroll
+            for (int a = 0; a < 6; ++a) {
+                double u = 0;
+#pragma unroll
+                for (int q = 0; q < 6; ++q) u += sh.C[q * 6 + a] * y[q];
+                co[a] = u;
+            }
+            if (c >= 6 && c < 12) {
+#pragma unroll
+                for (int a = 0; a < 6; ++a) Dn[a * 6 + (c - 6)] = -co[a];
+            } else if (c == 12) {
+#pragma unroll
+                for (int a = 0; a < 6; ++a) Gn[a] = -co[a];
+            }
+        }
+        if (last && is_nd) {
+#pragma unroll
+            for (int a = 0; a < 6; ++a) pers[a] = 0.0;
+        }
+        cb ^= 1;
         PG_GROUP_SYNC();
     }
-    if (c < 6) for (int a = 0; a < 6; ++a) segDL[(size_t)s * 36 + a * 6 + c] = accL[a];
-    if (c == 12) for (int a = 0; a < 6; ++a) segGL[(size_t)s * 6 + a] = accL[a];
-    for (int a = c; a < 36; a += PG_SEG_LANES) { segDR[(size_t)s * 36 + a] = sh.D[a]; segS[(size_t)s * 36 + a] = sh.E[a]; }
-    if (c < 6) segGR[(size_t)s * 6 + c] = sh.G[c];
+    for (int a = c; a < 36; a += PG_SEG_LANES) Dl[(size_t)(R - 1) * 36 + a] = sh.L[a];
+    if (c < 6) for (int a = 0; a < 6; ++a) segDL[(size_t)s * 36 + a * 6 + c] = pers[a];
+    if (c == 12) for (int a = 0; a < 6; ++a) segGL[(size_t)s * 6 + a] = pers[a];
+    for (int a = c; a < 36; a += PG_SEG_LANES) { segDR[(size_t)s * 36 + a] = sh.D[cb][a]; segS[(size_t)s * 36 + a] = sh.E[cb][a]; }
+    if (c < 6) segGR[(size_t)s * 6 + c] = sh.G[cb][c];
 }
 
 // the level-1 chain after pass 1: diagonal block, coupling to the next entry and gradient of every chunk end / true separator

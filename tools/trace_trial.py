@@ -9,7 +9,7 @@ with open(sys.argv[1]) as f:
     for x in csv.DictReader(f):
         rows.append((int(x["Start_Timestamp"]), int(x["End_Timestamp"]), x["Kernel_Name"].split("(")[0], int(x["Grid_Size_X"]), int(x["Workgroup_Size_X"]), int(x["Grid_Size_Y"]), int(x["Grid_Size_Z"])))
 rows.sort()
-idx = [i for i, x in enumerate(rows) if x[2] == "pg_segment_kernel"]
+idx = [i for i, x in enumerate(rows) if x[2] == "pg_assemble_kernel"]
 a, b = idx[-3], idx[-2]
 t0 = rows[a][0]
 print("one trial span %.3f ms" % ((rows[b][0] - t0) / 1e6))
