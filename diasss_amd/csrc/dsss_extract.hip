@@ -192,8 +192,6 @@ __global__ __launch_bounds__(256) void resize_kernel(const ex_frame* __restrict_
 // ------------------------------------------------------------------ K3: cv::FAST 9/16 per 30-px cell
 struct level_tab { const uint8_t* img[DSSS_MAX_LEVELS]; int cols[DSSS_MAX_LEVELS]; };
 
-__constant__ int c_ring_dx[16] = { 0, 1, 2, 3, 3, 3, 2, 1, 0, -1, -2, -3, -3, -3, -2, -1 };
-__constant__ int c_ring_dy[16] = { 3, 3, 2, 1, 0, -1, -2, -3, -3, -3, -2, -1, 0, 1, 2, 3 };
 
 // arc value A = max over the 16 arcs of 9 contiguous ring pixels of max(min(v - ring), min(ring - v));
 // corner at threshold t iff A > t, cornerScore = A - 1.  Values <= tmin are reported as 0 (never a corner, and never
@@ -204,14 +202,19 @@ __constant__ int c_ring_dy[16] = { 3, 3, 2, 1, 0, -1, -2, -3, -3, -3, -2, -1, 0,
 // opposite-pair early exit at minThFAST, so there is none.)
 typedef short fast_v2 __attribute__((ext_vector_type(2)));
 __device__ inline fast_v2 fast_swap(fast_v2 a) { return __builtin_shufflevector(a, a, 1, 0); }
-__device__ inline int fast_arc(const uint8_t* w, int stride, int x, int y, int tmin)
+template <int stride>
+__device__ inline int fast_arc(const uint8_t* w, int x, int y, int tmin)
 {
-    const short v = (short)w[y * stride + x];
+    // ring offsets from the top-left corner of the 7 x 7 patch: all positive, so they fit the immediate field of the LDS loads
+    constexpr int rdx[16] = { 0, 1, 2, 3, 3, 3, 2, 1, 0, -1, -2, -3, -3, -3, -2, -1 };
+    constexpr int rdy[16] = { 3, 3, 2, 1, 0, -1, -2, -3, -3, -3, -2, -1, 0, 1, 2, 3 };
+    const uint8_t* __restrict__ p = w + (y - 3) * stride + (x - 3);
+    const short v = (short)p[3 * stride + 3];
     const fast_v2 vv = { v, v };
     fast_v2 P[16];                                   // P[j] = (d[j], d[j + 8]), j < 8; P[j + 8] = (d[j + 8], d[j])
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-        const fast_v2 r = { (short)w[(y + c_ring_dy[j]) * stride + (x + c_ring_dx[j])], (short)w[(y + c_ring_dy[j + 8]) * stride + (x + c_ring_dx[j + 8])] };
+        const fast_v2 r = { (short)p[(rdy[j] + 3) * stride + rdx[j] + 3], (short)p[(rdy[j + 8] + 3) * stride + rdx[j + 8] + 3] };
         P[j] = vv - r;
     }
 #pragma unroll
@@ -258,72 +261,84 @@ __device__ inline int block_scan_excl256(int v, int* total, int* s_w)
     return base + inc - v;
 }
 
-// one block per cell window (ORBextractor.cpp:789-816): FAST at iniThFAST, retried at minThFAST if the cell is
-// empty, non-max suppression inside the window only, keypoints emitted row-major.
-__global__ __launch_bounds__(256) void fast_cells_kernel(const ex_frame* __restrict__ frs, int ini_th, int min_th)
+// ONE WAVEFRONT per cell window (ORBextractor.cpp:789-816), four cells per workgroup: FAST at iniThFAST, retried at
+// minThFAST if the cell is empty, non-max suppression inside the window only, keypoints emitted row-major.  The wavefront
+// owns a slice of LDS (window + arc values) and nothing of it is shared, so there is no workgroup barrier and no block scan:
+// lanes talk through the LDS in program order and the compaction is a ballot + popcount.  (With one workgroup per cell the
+// kernel was bound by the per-cell latency chain -- byte loads, three barriers, four block scans -- at 8 ms per 200 frames.)
+#define FAST_WAVE_SYNC() do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_wave_barrier(); } while (0)
+template <int stride>      // LDS row stride of the window: a compile-time constant, so that the ring offsets are immediates of the LDS loads
+__global__ __launch_bounds__(256) void fast_cells_kernel(const ex_frame* __restrict__ frs, int ini_th, int min_th, int wave_bytes)
 {
-    __shared__ uint8_t win[CELL_MAX * CELL_STRIDE];
-    __shared__ uint8_t A[CELL_MAX * CELL_STRIDE];
-    __shared__ int s_w[4];
-    __shared__ int s_n12;
+    extern __shared__ __attribute__((aligned(16))) uint8_t fast_lds[];
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const ex_frame& f = frs[blockIdx.y];
-    if ((int)blockIdx.x >= f.ncells) return;
-    uint32_t* __restrict__ cand = f.cand; int* __restrict__ counts = f.counts; const int cell_cap = f.cell_cap;
-    const fast_cell c = f.cells[blockIdx.x];
-    const uint8_t* img = f.lvl[c.level];
+    const int cell = blockIdx.x * 4 + wv;
+    if (cell >= f.ncells) return;
+    uint8_t* __restrict__ win = fast_lds + (size_t)wv * wave_bytes;
+    uint8_t* __restrict__ A = win + wave_bytes / 2;
+    uint32_t* __restrict__ cand = f.cand; const int cell_cap = f.cell_cap;
+    const fast_cell c = f.cells[cell];
+    const uint8_t* __restrict__ img = f.lvl[c.level];
     const int cols = f.cols[c.level];
-    // t / d for t < 66 * 66 by multiplication: (t * ceil(2^20 / d)) >> 20 is exact while t * d < 2^20
+    // the window, eight byte loads in flight per lane; t / d for t < 66 * 66 by multiplication: (t * ceil(2^20 / d)) >> 20 is exact while t * d < 2^20
     const unsigned mg_w = ((1u << 20) + (unsigned)c.w - 1u) / (unsigned)c.w;
-    for (int t = threadIdx.x; t < c.w * c.h; t += 256) {
-        const int y = (int)(((unsigned)t * mg_w) >> 20), x = t - y * c.w;
-        win[y * CELL_STRIDE + x] = img[(size_t)(c.y0 + y) * cols + (c.x0 + x)];
-        A[y * CELL_STRIDE + x] = 0;
+    const int nwin = c.w * c.h;
+    for (int t0 = 0; t0 < nwin; t0 += 512) {
+        uint8_t v[8]; int o[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int t = t0 + 64 * u + lane;
+            const int y = (int)(((unsigned)t * mg_w) >> 20), x = t - y * c.w;
+            o[u] = t < nwin ? y * stride + x : -1;
+            v[u] = t < nwin ? img[(size_t)(c.y0 + y) * cols + (c.x0 + x)] : (uint8_t)0;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) if (o[u] >= 0) { win[o[u]] = v[u]; A[o[u]] = 0; }
     }
-    if (threadIdx.x == 0) s_n12 = 0;
-    __syncthreads();
+    FAST_WAVE_SYNC();
     const int ew = c.w - 6, eh = c.h - 6;
     const int ne = (ew > 0 && eh > 0) ? ew * eh : 0;
     const int tmin = ini_th < min_th ? ini_th : min_th;
     const unsigned mg_e = ((1u << 20) + (unsigned)(ew > 0 ? ew : 1) - 1u) / (unsigned)(ew > 0 ? ew : 1);
-    for (int t = threadIdx.x; t < ne; t += 256) {
+    for (int t = lane; t < ne; t += 64) {
         const int q = (int)(((unsigned)t * mg_e) >> 20);
         const int y = 3 + q, x = 3 + t - q * ew;
-        A[y * CELL_STRIDE + x] = (uint8_t)fast_arc(win, CELL_STRIDE, x, y, tmin);
+        A[y * stride + x] = (uint8_t)fast_arc<stride>(win, x, y, tmin);
     }
-    __syncthreads();
-    // strict 3x3 maxima; neighbours outside the evaluated range hold 0
-    int mine[15]; int nm = 0, n12 = 0;
-    for (int t = threadIdx.x; t < ne; t += 256, ++nm) {
+    FAST_WAVE_SYNC();
+    // strict 3x3 maxima (neighbours outside the evaluated range hold 0); the survivors' values replace the window, which is not needed any more
+    int n12 = 0;
+    for (int t = lane; t < ne; t += 64) {
         const int q = (int)(((unsigned)t * mg_e) >> 20);
         const int y = 3 + q, x = 3 + t - q * ew;
-        const int a = A[y * CELL_STRIDE + x];
+        const int a = A[y * stride + x];
         bool mx = a > 0;
         if (mx) {
-            mx = a > A[(y - 1) * CELL_STRIDE + x - 1] && a > A[(y - 1) * CELL_STRIDE + x] && a > A[(y - 1) * CELL_STRIDE + x + 1] &&
-                 a > A[y * CELL_STRIDE + x - 1] && a > A[y * CELL_STRIDE + x + 1] &&
-                 a > A[(y + 1) * CELL_STRIDE + x - 1] && a > A[(y + 1) * CELL_STRIDE + x] && a > A[(y + 1) * CELL_STRIDE + x + 1];
+            mx = a > A[(y - 1) * stride + x - 1] && a > A[(y - 1) * stride + x] && a > A[(y - 1) * stride + x + 1] &&
+                 a > A[y * stride + x - 1] && a > A[y * stride + x + 1] &&
+                 a > A[(y + 1) * stride + x - 1] && a > A[(y + 1) * stride + x] && a > A[(y + 1) * stride + x + 1];
         }
-        mine[nm] = mx ? a : 0;
-        n12 += mx && a > ini_th;
+        win[y * stride + x] = (uint8_t)(mx ? a : 0);
+        n12 |= (int)(mx && a > ini_th);
     }
-    if (n12) atomicAdd(&s_n12, n12);
-    __syncthreads();
-    const int thr = s_n12 > 0 ? ini_th : min_th;
-    int base = 0, k = 0;
-    for (int c0 = 0; c0 < ne; c0 += 256, ++k) {
-        const int t = c0 + threadIdx.x;
-        const int a = (t < ne) ? mine[k] : 0;
+    FAST_WAVE_SYNC();
+    const int thr = __builtin_amdgcn_ballot_w64(n12 != 0) != 0 ? ini_th : min_th;
+    int base = 0;
+    for (int t0 = 0; t0 < ne; t0 += 64) {
+        const int t = t0 + lane;
+        const int q = (int)(((unsigned)t * mg_e) >> 20);
+        const int y = 3 + q, x = 3 + t - q * ew;
+        const int a = t < ne ? win[y * stride + x] : 0;
         const bool keep = a > thr;
-        int tot;
-        const int pos = block_scan_excl256(keep, &tot, s_w);
+        const unsigned long long m = __builtin_amdgcn_ballot_w64(keep);
         if (keep) {
-            const int q = (int)(((unsigned)t * mg_e) >> 20);
-            const int y = 3 + q, x = 3 + t - q * ew;
-            if (base + pos < cell_cap) cand[(size_t)blockIdx.x * cell_cap + base + pos] = (uint32_t)x | ((uint32_t)y << 8) | ((uint32_t)(a - 1) << 16);
+            const int pos = base + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0));
+            if (pos < cell_cap) cand[(size_t)cell * cell_cap + pos] = (uint32_t)x | ((uint32_t)y << 8) | ((uint32_t)(a - 1) << 16);
         }
-        base += tot;
+        base += __builtin_popcountll(m);
     }
-    if (threadIdx.x == 0) counts[blockIdx.x] = base < cell_cap ? base : cell_cap;
+    if (lane == 0) f.counts[cell] = base < cell_cap ? base : cell_cap;
 }
 
 __global__ __launch_bounds__(256) void scan_counts_kernel(const ex_frame* __restrict__ frs)
@@ -532,6 +547,7 @@ struct level_geom {
     std::vector<fast_cell> cells;
     int cell_begin[DSSS_MAX_LEVELS + 1];
     int cell_cap = 0;                     // strict local maxima possible in the largest cell
+    int cell_wmax = 0, cell_hmax = 0;     // largest FAST window
     long long cand_bound = 0;             // sum over the cells of the strict local maxima each can hold: the frame can never exceed it
     fast_cell* d_cells = nullptr;         // device copy (per geometry, cached in the context)
     int* d_lrows = nullptr; float* d_lscale = nullptr;
@@ -558,7 +574,7 @@ void build_geom(const dsss_orb_params& op, int rows, int cols, level_geom& g)
     for (int l = 0; l < op.nlevels - 1; ++l) { g.quota[l] = (int)lrintf(nDesired); sum += g.quota[l]; nDesired *= factor; }
     g.quota[op.nlevels - 1] = std::max(op.nfeatures - sum, 0);
     // cell windows of ComputeKeyPointsOctTree (ORBextractor.cpp:769-806)
-    g.cells.clear(); g.cand_bound = 0;
+    g.cells.clear(); g.cand_bound = 0; g.cell_wmax = 0; g.cell_hmax = 0;
     int cap = 1;
     for (int l = 0; l < op.nlevels; ++l) {
         g.cell_begin[l] = (int)g.cells.size();
@@ -586,6 +602,7 @@ void build_geom(const dsss_orb_params& op, int rows, int cols, level_geom& g)
                 const int ew = std::max(c.w - 6, 0), eh = std::max(c.h - 6, 0);
                 cap = std::max(cap, ((ew + 1) / 2) * ((eh + 1) / 2));
                 g.cand_bound += std::min(((ew + 1) / 2) * ((eh + 1) / 2), CELL_CAP);   // no two 8-neighbours are both strict maxima
+                g.cell_wmax = std::max(g.cell_wmax, c.w); g.cell_hmax = std::max(g.cell_hmax, c.h);
                 g.cells.push_back(c);
             }
         }
@@ -781,7 +798,7 @@ static int extract_frames(dsss_ctx* c, const int* ids, int n, bool keep_taps)
             if (b0 + B < n) HIPCHK(c, upload_batch(b0 + B, up_ev[(bk + 1) & 1]));      // next batch's images start moving now
             HIPCHK(c, hipStreamWaitEvent(st, up_ev[bk & 1], 0));                       // this batch's images are in HBM before its kernels read them
         }
-        int ninst = 0, maxN = 0, maxNM4 = 0, max_cells = 0, max_levels = 0;
+        int ninst = 0, maxN = 0, maxNM4 = 0, max_cells = 0, max_levels = 0, max_cw = 8, max_ch = 8;
         size_t max_tot = 0;
         int max_rows[DSSS_MAX_LEVELS] = { 0 }, max_cols[DSSS_MAX_LEVELS] = { 0 };
         double w_tot = 0;
@@ -805,6 +822,7 @@ static int extract_frames(dsss_ctx* c, const int* ids, int n, bool keep_taps)
             e.pose6 = f.pose6; e.gr = f.gr;
             e.err = d_errs + s; e.kout = c->kps + (size_t)id * c->kcap; e.dout = c->desc + (size_t)id * c->kcap * 32; e.geo = c->geo + (size_t)id * c->kcap * 2; e.count = c->nkp_dev + id;
             maxN = std::max(maxN, f.N); max_tot = std::max(max_tot, (size_t)f.N * f.M); max_cells = std::max(max_cells, e.ncells); max_levels = std::max(max_levels, g.nlevels);
+            max_cw = std::max(max_cw, g.cell_wmax); max_ch = std::max(max_ch, g.cell_hmax);
             for (int l = 0; l < g.nlevels; ++l) { max_rows[l] = std::max(max_rows[l], g.rows[l]); max_cols[l] = std::max(max_cols[l], g.cols[l]); }
             w_tot += (double)f.N * f.M;
             // quadtree descriptors
@@ -838,7 +856,9 @@ static int extract_frames(dsss_ctx* c, const int* ids, int n, bool keep_taps)
           for (int l = 1; l < max_levels; ++l)
               hipLaunchKernelGGL(resize_kernel, dim3((unsigned)(((size_t)max_cols[l] * max_rows[l] / 4 + 256) / 256), nb), dim3(256), 0, st, d_exf, l); }
         { dsss_scope sc(c, DSSS_K_FAST, 2.906 * w_tot);
-          hipLaunchKernelGGL(fast_cells_kernel, dim3(max_cells, nb), dim3(256), 0, st, d_exf, c->op.ini_th, c->op.min_th); }
+          const int fstride = max_cw <= 40 ? 40 : CELL_STRIDE, fwave = (2 * max_ch * fstride + 15) & ~15;      // window + arc values of one wavefront
+          if (fstride == 40) hipLaunchKernelGGL(fast_cells_kernel<40>, dim3((max_cells + 3) / 4, nb), dim3(256), 4 * fwave, st, d_exf, c->op.ini_th, c->op.min_th, fwave);
+          else hipLaunchKernelGGL(fast_cells_kernel<CELL_STRIDE>, dim3((max_cells + 3) / 4, nb), dim3(256), 4 * fwave, st, d_exf, c->op.ini_th, c->op.min_th, fwave); }
         { dsss_scope sc(c, DSSS_K_FAST_COMPACT, 0, 2);
           hipLaunchKernelGGL(scan_counts_kernel, dim3(nb), dim3(256), 0, st, d_exf);
           hipLaunchKernelGGL(gather_cand_kernel, dim3(max_cells, nb), dim3(64), 0, st, d_exf); }
