@@ -313,12 +313,12 @@ __global__ __launch_bounds__(256) void fast_cells_kernel(const ex_frame* __restr
         const int q = (int)(((unsigned)t * mg_e) >> 20);
         const int y = 3 + q, x = 3 + t - q * ew;
         const int a = A[y * stride + x];
-        bool mx = a > 0;
-        if (mx) {
-            mx = a > A[(y - 1) * stride + x - 1] && a > A[(y - 1) * stride + x] && a > A[(y - 1) * stride + x + 1] &&
-                 a > A[y * stride + x - 1] && a > A[y * stride + x + 1] &&
-                 a > A[(y + 1) * stride + x - 1] && a > A[(y + 1) * stride + x] && a > A[(y + 1) * stride + x + 1];
-        }
+        // branch-free: eight loads with immediate offsets from the corner of the 3 x 3 patch, a max tree, one compare
+        const uint8_t* __restrict__ pa = A + (y - 1) * stride + (x - 1);
+        const int m0 = max(max((int)pa[0], (int)pa[1]), (int)pa[2]);
+        const int m1 = max((int)pa[stride], (int)pa[stride + 2]);
+        const int m2 = max(max((int)pa[2 * stride], (int)pa[2 * stride + 1]), (int)pa[2 * stride + 2]);
+        const bool mx = a > max(max(m0, m1), m2);            // a == 0 never passes
         win[y * stride + x] = (uint8_t)(mx ? a : 0);
         n12 |= (int)(mx && a > ini_th);
     }
