@@ -1378,6 +1378,7 @@ __global__ __launch_bounds__(256) void pg_front_trsm2_kernel(const int* __restri
 // ten row slots accumulate the 96 column sums (folded in slot order), L11 goes global -> registers -> LDS behind them, and
 // wavefront 0 runs the block back-substitution: x_blk = Linv^T z_blk, z[earlier columns] -= L11[blk rows][columns]^T x_blk.
 #define PG_BWD2_LD 97
+#define PG_BWD2_SX 8192                         // rows of x2 staged in LDS at a time
 __global__ __launch_bounds__(1024) void pg_front_bwd2_kernel(const int* __restrict__ it_front, const int* __restrict__ it_step, const pg_front* __restrict__ FD,
                                                              const int* __restrict__ f_rows, const double* __restrict__ F, const double* __restrict__ R,
                                                              double* __restrict__ x, const double* __restrict__ Tinv)
@@ -1394,33 +1395,35 @@ __global__ __launch_bounds__(1024) void pg_front_bwd2_kernel(const int* __restri
     { const double* __restrict__ L11 = F + fd.off + (size_t)col0 * ld + col0;
 #pragma unroll
       for (int e = 0; e < 9; ++e) { const int id = e * 1024 + threadIdx.x, r = id / 96, cc = id - 96 * r; lreg[e] = (r < n && cc <= r) ? L11[(size_t)r * ld + cc] : 0.0; } }
-    for (int i = threadIdx.x; i < nrows; i += 1024) { const int g = row0 + i; sx[i] = x[(size_t)f_rows[fd.rowptr + g / 6] * 6 + g % 6]; }
-    __syncthreads();
     {
         const int slot = threadIdx.x / 96, cc = threadIdx.x - slot * 96;
-        if (slot < 10) {
-            double acc0 = 0, acc1 = 0;
-            if (cc < n) {
-                const double* __restrict__ Ab = F + fd.off + (size_t)row0 * ld + col0 + cc;
+        double acc0 = 0, acc1 = 0;
+        for (int base = 0; base < nrows; base += PG_BWD2_SX) {      // x2 goes through LDS in pieces of PG_BWD2_SX rows (one piece for all but the largest interface fronts)
+            const int cn = min(PG_BWD2_SX, nrows - base);
+            if (base > 0) __syncthreads();
+            for (int i = threadIdx.x; i < cn; i += 1024) { const int g = row0 + base + i; sx[i] = x[(size_t)f_rows[fd.rowptr + g / 6] * 6 + g % 6]; }
+            __syncthreads();
+            if (slot < 10 && cc < n) {
+                const double* __restrict__ Ab = F + fd.off + (size_t)(row0 + base) * ld + col0 + cc;
                 int i = slot;
-                for (; i + 150 < nrows; i += 160) {                // sixteen loads in flight
+                for (; i + 150 < cn; i += 160) {                   // sixteen loads in flight
                     double a16[16];
 #pragma unroll
                     for (int u = 0; u < 16; ++u) a16[u] = Ab[(size_t)(i + 10 * u) * ld];
 #pragma unroll
                     for (int u = 0; u < 16; ++u) { if (u & 1) acc1 += a16[u] * sx[i + 10 * u]; else acc0 += a16[u] * sx[i + 10 * u]; }
                 }
-                for (; i + 30 < nrows; i += 40) {
+                for (; i + 30 < cn; i += 40) {
                     double a4[4];
 #pragma unroll
                     for (int u = 0; u < 4; ++u) a4[u] = Ab[(size_t)(i + 10 * u) * ld];
 #pragma unroll
                     for (int u = 0; u < 4; ++u) { if (u & 1) acc1 += a4[u] * sx[i + 10 * u]; else acc0 += a4[u] * sx[i + 10 * u]; }
                 }
-                for (; i < nrows; i += 10) acc0 += Ab[(size_t)i * ld] * sx[i];
+                for (; i < cn; i += 10) acc0 += Ab[(size_t)i * ld] * sx[i];
             }
-            s_acc[slot * (PG_PW * 6) + cc] = acc0 + acc1;
         }
+        if (slot < 10) s_acc[slot * (PG_PW * 6) + cc] = acc0 + acc1;
     }
 #pragma unroll
     for (int e = 0; e < 9; ++e) { const int id = e * 1024 + threadIdx.x, r = id / 96, cc = id - 96 * r; sL[r * PG_BWD2_LD + cc] = lreg[e]; }
@@ -2044,7 +2047,7 @@ static int pg_solve_impl(dsss_ctx* c, const double* dr6, int total, const dsss_l
     unsigned long long* d_stamps = nullptr; if (getenv("DSSS_PG_STAMPS")) TRY(dv.alloc(c, &d_stamps, 16));
     static const bool one_wave = getenv("DSSS_PG_PANEL") && !strcmp(getenv("DSSS_PG_PANEL"), "onewave");
     double* d_Tinv; TRY(dv.alloc(c, &d_Tinv, (size_t)std::max(npan, 1) * PG_NB4 * 16));
-    const int bwd_lds = old_panel ? PG_BWD_LDS(max_n6) : (int)(((PG_PW * 6) * PG_BWD2_LD + 10 * (PG_PW * 6) + max_n6 + 16) * sizeof(double));
+    const int bwd_lds = old_panel ? PG_BWD_LDS(max_n6) : (int)(((PG_PW * 6) * PG_BWD2_LD + 10 * (PG_PW * 6) + std::min(max_n6, PG_BWD2_SX) + 16) * sizeof(double));
     if (bwd_lds > 160 * 1024) { dv.release(); DSSS_FAIL(c, DSSS_E_CAPACITY, "front of %d scalar rows: back-substitution needs %d B of LDS", max_n6, bwd_lds); }
     {   // pg_front_diag_kernel keeps the panel and its inverse (2 x 75 KB) in dynamic LDS, pg_front_bwd_kernel W and x2
         hipFuncSetAttribute((const void*)pg_front_diag_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, PG_DIAG_LDS);
