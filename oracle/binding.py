@@ -294,3 +294,14 @@ def pg_solve(dr, edges, params=None):
     edges = np.ascontiguousarray(edges)
     lib().orc_pg_solve(dp(dr), len(dr), edges.ctypes.data_as(C.POINTER(LCEdge)), len(edges), C.byref(p), dp(out), dp(stats))
     return out, stats
+
+
+def pg_error_at(dr, edges, poses12):
+    """0.5 sum |r|^2 of the pose graph (dr, edges) at the poses `poses12` (total x 12)"""
+    dr = np.ascontiguousarray(dr, np.float64).reshape(-1, 6)
+    x = np.ascontiguousarray(poses12, np.float64).reshape(-1, 12)
+    assert len(x) == len(dr)
+    edges = np.ascontiguousarray(edges)
+    f = lib().orc_pg_error_at
+    f.restype = C.c_double
+    return float(f(dp(dr), len(dr), edges.ctypes.data_as(C.POINTER(LCEdge)), len(edges), dp(x)))

@@ -196,6 +196,8 @@ int orc_pg_select_lc(int F, const int* frame_rows, int npairs, const int* pair_s
 /* batch LM over all pings; dr = total x 6 (roll,pitch,yaw,x,y,z); out poses total x 12 (R row-major, t) */
 int orc_pg_solve(const double* dr, int total, const orc_lc_edge* edges, int ne, const orc_pg_params* p,
                  double* out12, double* stats /* [iters, err0, err1, lambda] */);
+/* the same graph's LM objective evaluated at given poses (total x 12), for full-size checks of a solver's answer */
+double orc_pg_error_at(const double* dr, int total, const orc_lc_edge* edges, int ne, const double* x12);
 
 #ifdef __cplusplus
 }

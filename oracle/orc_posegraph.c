@@ -398,3 +398,41 @@ int orc_pg_solve(const double* dr, int total, const orc_lc_edge* edges, int ne, 
     free(delta); free(g.f); free(g.r); free(g.Ji); free(g.Jj); free(DR); free(X); free(Xn);
     return iters;
 }
+
+/* The LM objective 0.5 sum |r|^2 of the graph orc_pg_solve builds from (dr, edges), evaluated at the poses `x12` (total x 12,
+ * R row-major then t) instead of being minimised: the full-size check of a solver's answer where running the LM here would
+ * take hours (the error function is the one above: optimizer.cpp:134-199 factors, GTSAM Pose3 local coordinates). */
+double orc_pg_error_at(const double* dr, int total, const orc_lc_edge* edges, int ne, const double* x12)
+{
+    const double PI = ORC_PI_REF;
+    const double wgt1 = 0.001, wgt2 = 10;
+    const double sig_odo[6] = { wgt1 * PI / 180, wgt1 * PI / 180, 0.1 * wgt1 * wgt2 * PI / 180, wgt1 * wgt2, wgt1 * wgt2, wgt1 };
+    int n = total;
+    pg_t g;
+    g.n = n; g.nf = n + ne; g.r = NULL; g.Ji = NULL; g.Jj = NULL;
+    g.f = (pg_factor*)malloc(sizeof(pg_factor) * g.nf);
+    orc_pose* DR = (orc_pose*)malloc(sizeof(orc_pose) * n);
+    orc_pose* X = (orc_pose*)malloc(sizeof(orc_pose) * n);
+    for (int i = 0; i < n; ++i) {
+        orc_pose_from_rodrigues(dr + (size_t)i * 6, &DR[i]);
+        memcpy(X[i].R, x12 + (size_t)i * 12, sizeof(double) * 9);
+        memcpy(X[i].t, x12 + (size_t)i * 12 + 9, sizeof(double) * 3);
+    }
+    g.f[0].i = -1; g.f[0].j = 0; g.f[0].meas = DR[0];
+    for (int k = 0; k < 6; ++k) g.f[0].w[k] = 1.0 / 0.000001;
+    for (int i = 1; i < n; ++i) {
+        g.f[i].i = i - 1; g.f[i].j = i;
+        orc_pose_between(&DR[i - 1], &DR[i], &g.f[i].meas);
+        for (int k = 0; k < 6; ++k) g.f[i].w[k] = 1.0 / sig_odo[k];
+    }
+    for (int e = 0; e < ne; ++e) {
+        pg_factor* f = &g.f[n + e];
+        f->i = edges[e].a; f->j = edges[e].b;
+        memcpy(f->meas.R, edges[e].rel, sizeof(double) * 9);
+        memcpy(f->meas.t, edges[e].rel + 9, sizeof(double) * 3);
+        for (int k = 0; k < 6; ++k) f->w[k] = 1.0 / sqrt(edges[e].var[k]);
+    }
+    double err = pg_error(&g, X);
+    free(g.f); free(DR); free(X);
+    return err;
+}

@@ -291,3 +291,39 @@ def test_config_C5_scale_pose_graph():
     p8, s8 = c.posegraph_solve_edges(dr, edges)
     assert s8[0] == s1[0] and np.abs(p8 - p1).max() < 1e-5      # another elimination order: rounding only (the track spans 4 km; 6e-7 measured)
     c.close()
+
+
+def test_config_C3_scale_pose_graph_against_oracle_objective(orc):
+    """C3's graph size (400 k poses, 12 k loop closures).  The oracle's envelope Cholesky needs hours at this size (its LM is
+    compared with the device at C2 scale and below), but its OBJECTIVE is cheap: the LM error the device reports for its
+    initial estimate and for its answer must be the oracle's error function at those poses, the answer must be a local
+    minimum of that function (random retractions of the right size only raise it), and one more LM run started from the
+    answer must not move it."""
+    from diasss_amd import capi
+    dr, gt, edges = _lawnmower_graph(10, 40000, 12000, seed=7)
+    oe = np.zeros(len(edges), orc.LCEDGE_DTYPE)
+    for k in ("a", "b", "rel", "var"): oe[k] = edges[k]
+    c = capi.Context(max_frames=2)
+    mp, op, mt, pg = c.default_params()
+    pg.max_iters = 0
+    c.set_params(pg=pg)
+    x0, s0 = c.posegraph_solve_edges(dr, edges)                      # initial estimate DR o noise (optimizer.cpp:150-160)
+    pg.max_iters = 100
+    c.set_params(pg=pg)
+    x1, s1 = c.posegraph_solve_edges(dr, edges)
+    c.close()
+    e0 = orc.pg_error_at(dr, oe, x0); e1 = orc.pg_error_at(dr, oe, x1)
+    print("C3-scale graph: oracle objective %.6e -> %.9e; device reports %.6e -> %.9e in %d iterations" % (e0, e1, s1[1], s1[2], s1[0]))
+    assert abs(e0 - s1[1]) <= 1e-12 * e0
+    assert abs(e1 - s1[2]) <= 1e-9 * e1
+    assert e1 < 1e-6 * e0
+    # local minimum: 20 random perturbations (translations of 1 mm, rotations of 1e-5 rad on 1 % of the poses) never lower it
+    rng = np.random.default_rng(0)
+    from scipy.spatial.transform import Rotation as Rot
+    for trial in range(20):
+        xp = x1.copy()
+        sel = rng.choice(len(dr), len(dr) // 100, replace=False)
+        xp[sel, 9:] += rng.normal(0, 1e-3, (len(sel), 3))
+        Rp = Rot.from_rotvec(rng.normal(0, 1e-5, (len(sel), 3))).as_matrix()
+        xp[sel, :9] = np.einsum("nij,njk->nik", xp[sel, :9].reshape(-1, 3, 3), Rp).reshape(-1, 9)
+        assert orc.pg_error_at(dr, oe, xp) > e1
