@@ -237,6 +237,10 @@ F64_PEAK_TFLOPS = 78.6   # MI355X FP64 vector/matrix peak (AMD spec sheet; MI355
 # matcher ceiling: one gate + Hamming evaluation is about 30 VALU operations (5 f64 + 8 xor + 8 popcount + compares); the chip
 # issues 256 CUs x 4 SIMDs x 32 lanes per cycle at 2.4 GHz
 MATCH_PEAK_GEVALS = 256 * 4 * 32 * 2.4 / 30.0
+# FAST ceiling: the arc value of 64 pixels costs about 127 wave instructions (78 packed min/max + 8 sub + 8 perm + 17 LDS byte
+# loads + index arithmetic: the ISA of fast_cells_kernel's arc loop); a SIMD issues one wave instruction per
+# 4 cycles, 1024 SIMDs at 2.4 GHz.  Non-max suppression, threshold fallback and compaction come on top and are not priced.
+FAST_PEAK_GPX = 256 * 4 * 2.4 / 4.0 * 64 / 127.0
 
 # what bounds each timed kernel.  The streaming kernels are priced in algorithmic HBM bytes, the
 # pose-graph factorisation kernels in f64 flops against the f64 matrix peak they should eventually run at.
@@ -247,9 +251,10 @@ MFMA_SLOTS = {"pg_acc", "pg_diag", "pg_trsm"}             # kernels whose flops 
 # profile slot -> kernel name in the rocprofv3 tables under profiles/
 SLOT_KERNEL = {"row_reduce": "row_reduce_kernel", "normalize": "normalize_kernel", "pyramid": "resize_kernel", "fast": "fast_cells_kernel",
                "desc": "orient_desc_kernel", "quadtree": "quadtree_kernel", "lc": "lc_kernel", "match": "match_nn_kernel<false>",
-               "pg_acc": "pg_front_syrk_kernel", "pg_diag": "pg_front_diag2_kernel", "pg_trsm": "pg_front_trsm2_kernel", "pg_bwd": "pg_front_bwd2_kernel"}
+               "pg_acc": "pg_front_syrk_kernel", "pg_diag": "pg_front_diag3_kernel", "pg_trsm": "pg_front_trsm2_kernel", "pg_bwd": "pg_front_bwd2_kernel"}
 NOTES = {"pg_acc": "trailing update of the multifrontal fronts, 64 x 64 tiles on v_mfma_f64_16x16x4_f64 (K = one 96-column panel): the bulk of the factorisation flops; launches are short, so the matrix cores idle between levels",
-         "pg_diag": "96-column panel Cholesky in the registers of one wavefront: 24 dependent 4 x 4 pivot blocks, every rank-4 update one v_mfma_f64_16x16x4_f64 per tile; latency-bound",
+         "pg_diag": "96-column panel Cholesky in the registers of four wavefronts: 24 dependent 4 x 4 pivot blocks (about 1950 cycles each: readlane, 4 x rsq + Newton, LDS, MFMA, LDS, MFMA), every rank-4 update one v_mfma_f64_16x16x4_f64 per tile; latency-bound",
+         "fast": "VALU-bound: packed 16-bit sliding min/max over the 16-pixel ring; work = pixels of all pyramid levels",
          "pg_trsm": "row solve below the panel by the same 4-column MFMA steps", "pg_bwd": "latency-bound matvec + block back-substitution per panel",
          "match": "VALU-bound by design: (Na + Nb) x 48 B per directed pair against Na x Nb gate + popcount evaluations",
          "lc": "f64 VALU, 16 lanes per 15-DoF problem; flops = 3e4 per LM iteration (DESIGN.md section 4) x iterations summed over the problems"}
@@ -278,6 +283,11 @@ def one_roofline(slot, ms, n, work, traffic):
     elif slot == "match":
         ach = work / n / per_launch_s / 1e9
         r = {"kernel": slot, "bound": "valu_int", "achieved": ach, "peak": MATCH_PEAK_GEVALS, "unit": "G gate+Hamming evaluations/s", "frac": ach / MATCH_PEAK_GEVALS}
+        if tr:
+            r["hbm_GBs"] = tr[0] / per_launch_s / 1e9
+    elif slot == "fast":                                    # the work figure of the slot is the bytes of all levels = one per pixel
+        ach = work / n / per_launch_s / 1e9
+        r = {"kernel": slot, "bound": "valu_int", "achieved": ach, "peak": FAST_PEAK_GPX, "unit": "G pixels/s", "frac": ach / FAST_PEAK_GPX}
         if tr:
             r["hbm_GBs"] = tr[0] / per_launch_s / 1e9
     else:

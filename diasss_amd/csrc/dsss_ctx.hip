@@ -8,6 +8,18 @@
 #include <atomic>
 #include <cstdlib>
 
+void dsss_prof_flush(dsss_ctx* c)
+{
+    if (!c || c->prof.pending.empty()) return;
+    hipStreamSynchronize(c->stream);
+    for (const dsss_prof::rec& r : c->prof.pending) {
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, r.e0, r.e1) == hipSuccess) { c->prof.ms[r.k] += ms; c->prof.launches[r.k] += r.nl; }
+        c->prof.pool.push_back(r.e0); c->prof.pool.push_back(r.e1);
+    }
+    c->prof.pending.clear();
+}
+
 extern "C" {
 
 void dsss_mask_params_default(dsss_mask_params* p) { p->factor = 2.5; p->width = 10; p->r = 6; p->side = 150; }
@@ -108,6 +120,9 @@ void dsss_destroy(dsss_ctx* c)
     if (c->bbox_pinned) hipHostFree(c->bbox_pinned);
     dsss_pg_free(c); dsss_comm_free(c);
     hipEventDestroy(c->prof.e0); hipEventDestroy(c->prof.e1);
+    dsss_prof_flush(c);
+    for (hipEvent_t e : c->prof.pool) hipEventDestroy(e);
+    c->prof.pool.clear();
     for (int i = 0; i < 4; ++i) { if (c->xs[i]) hipStreamDestroy(c->xs[i]); if (c->xev[i]) hipEventDestroy(c->xev[i]); }
     if (c->xev_main) hipEventDestroy(c->xev_main);
     hipStreamDestroy(c->stream);
@@ -567,10 +582,11 @@ int dsss_features_allgather(dsss_ctx* c, int nframes)
     return rc;
 }
 
-int dsss_profile_enable(dsss_ctx* c, int on) { if (!c) return DSSS_E_ARG; c->prof.on = on != 0; return DSSS_OK; }
+int dsss_profile_enable(dsss_ctx* c, int on) { if (!c) return DSSS_E_ARG; if (!on) dsss_prof_flush(c); c->prof.on = on != 0; return DSSS_OK; }
 int dsss_profile_reset(dsss_ctx* c)
 {
     if (!c) return DSSS_E_ARG;
+    dsss_prof_flush(c);
     for (int i = 0; i < DSSS_K_COUNT; ++i) { c->prof.ms[i] = 0; c->prof.launches[i] = 0; c->prof.work[i] = 0; }
     return DSSS_OK;
 }
@@ -583,6 +599,7 @@ int dsss_profile_get_work(dsss_ctx* c, double* work)
 int dsss_profile_get(dsss_ctx* c, double* ms, int64_t* launches)
 {
     if (!c) return DSSS_E_ARG;
+    dsss_prof_flush(c);
     for (int i = 0; i < DSSS_K_COUNT; ++i) { if (ms) ms[i] = c->prof.ms[i]; if (launches) launches[i] = c->prof.launches[i]; }
     return DSSS_OK;
 }

@@ -50,7 +50,14 @@ struct dsss_prof {
     int64_t launches[DSSS_K_COUNT] = {0};
     double work[DSSS_K_COUNT] = {0};      // algorithmic bytes / flops (include/dsss.h)
     hipEvent_t e0 = nullptr, e1 = nullptr;
+    // event pairs of the scopes that have been recorded but not read yet: reading them without a host synchronisation per
+    // scope keeps the kernels back to back on the stream, so a short launch is timed as it runs in production (a synchronised
+    // scope adds the idle-queue dispatch latency, 5-10 us, to every launch)
+    struct rec { int k, nl; hipEvent_t e0, e1; };
+    std::vector<rec> pending;
+    std::vector<hipEvent_t> pool;
 };
+void dsss_prof_flush(dsss_ctx* c);       // synchronises the stream and folds the pending event pairs into ms[] / launches[]
 
 struct dsss_ctx {
     int device = 0;
@@ -115,16 +122,19 @@ struct dsss_ctx {
 // kernel-family timing with HIP events on the context stream (dsss_profile_*)
 struct dsss_scope {
     dsss_ctx* c; int k; int nl; hipEvent_t e0 = nullptr, e1 = nullptr;     // own event pair: scopes may nest (pose-graph solve)
+    static hipEvent_t take(dsss_ctx* c) {
+        hipEvent_t e = nullptr;
+        if (!c->prof.pool.empty()) { e = c->prof.pool.back(); c->prof.pool.pop_back(); } else hipEventCreate(&e);
+        return e;
+    }
     dsss_scope(dsss_ctx* c_, int k_, double work = 0, int launches = 1) : c(c_), k(k_), nl(launches) {
-        if (c->prof.on) { c->prof.work[k] += work; hipEventCreate(&e0); hipEventCreate(&e1); hipEventRecord(e0, c->stream); }
+        if (c->prof.on) { c->prof.work[k] += work; e0 = take(c); e1 = take(c); hipEventRecord(e0, c->stream); }
     }
     ~dsss_scope() {
         if (e0) {
             hipEventRecord(e1, c->stream);
-            hipEventSynchronize(e1);
-            float ms = 0; hipEventElapsedTime(&ms, e0, e1);
-            c->prof.ms[k] += ms; c->prof.launches[k] += nl;
-            hipEventDestroy(e0); hipEventDestroy(e1);
+            c->prof.pending.push_back({ k, nl, e0, e1 });
+            if (c->prof.pending.size() >= 16384) dsss_prof_flush(c);
         }
     }
 };

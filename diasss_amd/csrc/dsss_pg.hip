@@ -155,57 +155,78 @@ __global__ __launch_bounds__(256) void pg_final_sum_kernel(const double* __restr
 }
 
 // per-pose Hessian blocks: D (diagonal), C = H(i, i+1), g = J^T r.  LC contributions are summed over the
-// pose's incidence list in a fixed order (no atomics).
-__global__ __launch_bounds__(256) void pg_assemble_kernel(int n, pg_weights W, const double* __restrict__ r, const double* __restrict__ Ji,
+// pose's incidence list in a fixed order (no atomics).  SIX LANES PER POSE: lane a builds row a of D and C and g[a] (one
+// thread per pose held 2 x 36 accumulators + a Jacobian: 280 registers, one wavefront per SIMD); the six lanes read the same
+// Jacobian, which the memory pipeline broadcasts.  Every entry is summed in the order of the one-thread form.
+#define PG_ASM_POSES 32                              // poses per workgroup of 192 threads
+__global__ __launch_bounds__(6 * PG_ASM_POSES) void pg_assemble_kernel(int n, pg_weights W, const double* __restrict__ r, const double* __restrict__ Ji,
                                                           const int* __restrict__ adj_ptr, const int* __restrict__ adj_edge,
                                                           const double* __restrict__ ew, const double* __restrict__ lambda_ptr,
                                                           double* __restrict__ D, double* __restrict__ C, double* __restrict__ g,
                                                           const int* __restrict__ eb, int mp0, int mp1)
 {
-    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int i = blockIdx.x * PG_ASM_POSES + threadIdx.x / 6, a = threadIdx.x % 6;
     if (i >= n) return;
-    double Dd[36], Cc[36], gg[6];
-    for (int a = 0; a < 36; ++a) { Dd[a] = 0; Cc[a] = 0; }
-    for (int a = 0; a < 6; ++a) gg[a] = 0;
+    double Dd[6] = { 0, 0, 0, 0, 0, 0 }, Cc[6] = { 0, 0, 0, 0, 0, 0 }, gg = 0;
     const bool own_i = i >= mp0 && i < mp1, own_next = i + 1 >= mp0 && i + 1 < mp1;
     // factor i with this pose as the second variable (Jacobian W)
     const double* w2 = i == 0 ? W.prior : W.odo;
-    if (own_i) for (int a = 0; a < 6; ++a) { Dd[a * 6 + a] += w2[a] * w2[a]; gg[a] += w2[a] * r[(size_t)i * 6 + a]; }
+    if (own_i) {
+        const double wa = w2[a];
+#pragma unroll
+        for (int b = 0; b < 6; ++b) if (b == a) Dd[b] += wa * wa;
+        gg += wa * r[(size_t)i * 6 + a];
+    }
     if (i + 1 < n && own_next) {   // factor i+1 with this pose as the first variable
         const double* J = Ji + (size_t)(i + 1) * 36; const double* rr = r + (size_t)(i + 1) * 6;
-        for (int a = 0; a < 6; ++a) {
-            for (int b = 0; b < 6; ++b) {
-                double s = 0;
-                for (int q = 0; q < 6; ++q) s += J[q * 6 + a] * J[q * 6 + b];
-                Dd[a * 6 + b] += s;
-                Cc[a * 6 + b] = J[b * 6 + a] * W.odo[b];            // Ji^T W
-            }
-            double s = 0;
-            for (int q = 0; q < 6; ++q) s += J[q * 6 + a] * rr[q];
-            gg[a] += s;
-        }
+        double ja[6], sb[6] = { 0, 0, 0, 0, 0, 0 };            // column a of J; row a of J^T J
+#pragma unroll
+        for (int q = 0; q < 6; ++q) ja[q] = J[q * 6 + a];
+#pragma unroll
+        for (int q = 0; q < 6; ++q)
+#pragma unroll
+            for (int b = 0; b < 6; ++b) sb[b] += ja[q] * J[q * 6 + b];
+#pragma unroll
+        for (int b = 0; b < 6; ++b) { Dd[b] += sb[b]; Cc[b] = ja[b] * W.odo[b]; }       // C = Ji^T W
+        double s = 0;
+#pragma unroll
+        for (int q = 0; q < 6; ++q) s += ja[q] * rr[q];
+        gg += s;
     }
     for (int p = adj_ptr[i]; p < adj_ptr[i + 1]; ++p) {
         const int code = adj_edge[p], e = code >> 1, second = code & 1;
         if (eb[e] < mp0 || eb[e] >= mp1) continue;             // the edge belongs to another rank
         const double* rr = r + (size_t)(n + e) * 6;
         if (second) {
-            const double* w = ew + (size_t)e * 6;
-            for (int a = 0; a < 6; ++a) { Dd[a * 6 + a] += w[a] * w[a]; gg[a] += w[a] * rr[a]; }
+            const double wa = ew[(size_t)e * 6 + a];
+#pragma unroll
+            for (int b = 0; b < 6; ++b) if (b == a) Dd[b] += wa * wa;
+            gg += wa * rr[a];
         } else {
             const double* J = Ji + (size_t)(n + e) * 36;
-            for (int a = 0; a < 6; ++a) {
-                for (int b = 0; b < 6; ++b) { double s = 0; for (int q = 0; q < 6; ++q) s += J[q * 6 + a] * J[q * 6 + b]; Dd[a * 6 + b] += s; }
-                double s = 0;
-                for (int q = 0; q < 6; ++q) s += J[q * 6 + a] * rr[q];
-                gg[a] += s;
-            }
+            double ja[6], sb[6] = { 0, 0, 0, 0, 0, 0 };
+#pragma unroll
+            for (int q = 0; q < 6; ++q) ja[q] = J[q * 6 + a];
+#pragma unroll
+            for (int q = 0; q < 6; ++q)
+#pragma unroll
+                for (int b = 0; b < 6; ++b) sb[b] += ja[q] * J[q * 6 + b];
+#pragma unroll
+            for (int b = 0; b < 6; ++b) Dd[b] += sb[b];
+            double s = 0;
+#pragma unroll
+            for (int q = 0; q < 6; ++q) s += ja[q] * rr[q];
+            gg += s;
         }
     }
     const double lambda = *lambda_ptr;
-    if (own_i) for (int a = 0; a < 6; ++a) Dd[a * 6 + a] += lambda;        // the damping of a pose is added once, by its owner
-    for (int a = 0; a < 36; ++a) { D[(size_t)i * 36 + a] = Dd[a]; C[(size_t)i * 36 + a] = Cc[a]; }
-    for (int a = 0; a < 6; ++a) g[(size_t)i * 6 + a] = gg[a];
+    if (own_i) {                                               // the damping of a pose is added once, by its owner
+#pragma unroll
+        for (int b = 0; b < 6; ++b) if (b == a) Dd[b] += lambda;
+    }
+#pragma unroll
+    for (int b = 0; b < 6; ++b) { D[(size_t)i * 36 + a * 6 + b] = Dd[b]; C[(size_t)i * 36 + a * 6 + b] = Cc[b]; }
+    g[(size_t)i * 6 + a] = gg;
 }
 
 // Schur complement of the interior of segment s (poses L+1 .. R-1) onto its end points L, R (block Thomas recursion).
@@ -1378,7 +1399,7 @@ __global__ __launch_bounds__(256) void pg_front_trsm2_kernel(const int* __restri
 // ten row slots accumulate the 96 column sums (folded in slot order), L11 goes global -> registers -> LDS behind them, and
 // wavefront 0 runs the block back-substitution: x_blk = Linv^T z_blk, z[earlier columns] -= L11[blk rows][columns]^T x_blk.
 #define PG_BWD2_LD 97
-#define PG_BWD2_SX 8192                         // rows of x2 staged in LDS at a time
+#define PG_BWD2_SX 8192                         // rows of x2 the LDS stages; taller fronts read x2 through the row map
 __global__ __launch_bounds__(1024) void pg_front_bwd2_kernel(const int* __restrict__ it_front, const int* __restrict__ it_step, const pg_front* __restrict__ FD,
                                                              const int* __restrict__ f_rows, const double* __restrict__ F, const double* __restrict__ R,
                                                              double* __restrict__ x, const double* __restrict__ Tinv)
@@ -1395,35 +1416,37 @@ __global__ __launch_bounds__(1024) void pg_front_bwd2_kernel(const int* __restri
     { const double* __restrict__ L11 = F + fd.off + (size_t)col0 * ld + col0;
 #pragma unroll
       for (int e = 0; e < 9; ++e) { const int id = e * 1024 + threadIdx.x, r = id / 96, cc = id - 96 * r; lreg[e] = (r < n && cc <= r) ? L11[(size_t)r * ld + cc] : 0.0; } }
+    const bool big = nrows > PG_BWD2_SX;           // only the largest interface fronts: x2 does not fit the LDS, read it through the row map
+    if (!big) for (int i = threadIdx.x; i < nrows; i += 1024) { const int g = row0 + i; sx[i] = x[(size_t)f_rows[fd.rowptr + g / 6] * 6 + g % 6]; }
+    __syncthreads();
     {
         const int slot = threadIdx.x / 96, cc = threadIdx.x - slot * 96;
-        double acc0 = 0, acc1 = 0;
-        for (int base = 0; base < nrows; base += PG_BWD2_SX) {      // x2 goes through LDS in pieces of PG_BWD2_SX rows (one piece for all but the largest interface fronts)
-            const int cn = min(PG_BWD2_SX, nrows - base);
-            if (base > 0) __syncthreads();
-            for (int i = threadIdx.x; i < cn; i += 1024) { const int g = row0 + base + i; sx[i] = x[(size_t)f_rows[fd.rowptr + g / 6] * 6 + g % 6]; }
-            __syncthreads();
-            if (slot < 10 && cc < n) {
-                const double* __restrict__ Ab = F + fd.off + (size_t)(row0 + base) * ld + col0 + cc;
+        if (slot < 10) {
+            double acc0 = 0, acc1 = 0;
+            if (cc < n && !big) {
+                const double* __restrict__ Ab = F + fd.off + (size_t)row0 * ld + col0 + cc;
                 int i = slot;
-                for (; i + 150 < cn; i += 160) {                   // sixteen loads in flight
+                for (; i + 150 < nrows; i += 160) {                // sixteen loads in flight
                     double a16[16];
 #pragma unroll
                     for (int u = 0; u < 16; ++u) a16[u] = Ab[(size_t)(i + 10 * u) * ld];
 #pragma unroll
                     for (int u = 0; u < 16; ++u) { if (u & 1) acc1 += a16[u] * sx[i + 10 * u]; else acc0 += a16[u] * sx[i + 10 * u]; }
                 }
-                for (; i + 30 < cn; i += 40) {
+                for (; i + 30 < nrows; i += 40) {
                     double a4[4];
 #pragma unroll
                     for (int u = 0; u < 4; ++u) a4[u] = Ab[(size_t)(i + 10 * u) * ld];
 #pragma unroll
                     for (int u = 0; u < 4; ++u) { if (u & 1) acc1 += a4[u] * sx[i + 10 * u]; else acc0 += a4[u] * sx[i + 10 * u]; }
                 }
-                for (; i < cn; i += 10) acc0 += Ab[(size_t)i * ld] * sx[i];
+                for (; i < nrows; i += 10) acc0 += Ab[(size_t)i * ld] * sx[i];
+            } else if (cc < n) {
+                const double* __restrict__ Ab = F + fd.off + (size_t)row0 * ld + col0 + cc;
+                for (int i = slot; i < nrows; i += 10) { const int g = row0 + i; acc0 += Ab[(size_t)i * ld] * x[(size_t)f_rows[fd.rowptr + g / 6] * 6 + g % 6]; }
             }
+            s_acc[slot * (PG_PW * 6) + cc] = acc0 + acc1;
         }
-        if (slot < 10) s_acc[slot * (PG_PW * 6) + cc] = acc0 + acc1;
     }
 #pragma unroll
     for (int e = 0; e < 9; ++e) { const int id = e * 1024 + threadIdx.x, r = id / 96, cc = id - 96 * r; sL[r * PG_BWD2_LD + cc] = lreg[e]; }
@@ -2129,7 +2152,7 @@ static int pg_solve_impl(dsss_ctx* c, const double* dr6, int total, const dsss_l
                 hipMemsetAsync(d_fail, 0, sizeof(int), st);
                 hipMemsetAsync(d_L, 0, nnzL * 36 * sizeof(double), st);
                 if (nparts > 1) hipMemsetAsync(d_comm, 0, comm_total * sizeof(double), st);
-                hipLaunchKernelGGL(pg_assemble_kernel, dim3((n + 255) / 256), dim3(256), 0, st, n, W, d_r, d_Ji, d_adj_ptr, d_adj_edge, d_ew, d_scal + 3, d_D, d_C, d_g, d_eb, mp0, mp1);
+                hipLaunchKernelGGL(pg_assemble_kernel, dim3((n + PG_ASM_POSES - 1) / PG_ASM_POSES), dim3(6 * PG_ASM_POSES), 0, st, n, W, d_r, d_Ji, d_adj_ptr, d_adj_edge, d_ew, d_scal + 3, d_D, d_C, d_g, d_eb, mp0, mp1);
                 // pass 1: chunks of poses onto their ends; the level-1 chain; pass 2: runs of chunk ends onto the true separators
                 hipLaunchKernelGGL(pg_segment_kernel, dim3((nseg1 + 15) / 16), dim3(256), 0, st, nseg1, d_sep1, d_D, d_C, d_g, d_E, d_Dl, d_gi, d_sDL, d_sDR, d_sGL, d_sGR, d_sS, d_fail, mp0, mp1);
                 hipLaunchKernelGGL(pg_chain1_kernel, dim3((ns1 + 255) / 256), dim3(256), 0, st, ns1, d_sep1, d_D, d_g, d_sDL, d_sDR, d_sGL, d_sGR, d_sS, d_D1, d_C1, d_g1, mp0, mp1);
