@@ -1404,9 +1404,10 @@ __global__ __launch_bounds__(1024) void pg_front_bwd2_kernel(const int* __restri
                                                              const int* __restrict__ f_rows, const double* __restrict__ F, const double* __restrict__ R,
                                                              double* __restrict__ x, const double* __restrict__ Tinv)
 {
-    extern __shared__ double s_bw[];               // L11 [96 x 97] | slot sums [10][96] | x2 [nrows]
+    extern __shared__ double s_bw[];               // L11 [96 x 97] | Tinv [24][16] | slot sums [10][96] | x2 [nrows]
     double* sL = s_bw;
-    double* s_acc = s_bw + (PG_PW * 6) * PG_BWD2_LD;
+    double* sT = s_bw + (PG_PW * 6) * PG_BWD2_LD;  // the panel's 4 x 4 inverse blocks: a global load per block would sit on the serial chain of wave 0
+    double* s_acc = sT + PG_NB4 * 16;
     double* sx = s_acc + 10 * (PG_PW * 6);
     const pg_front fd = FD[it_front[blockIdx.x]];
     const int step = it_step[blockIdx.x], col0 = 96 * step;
@@ -1416,6 +1417,7 @@ __global__ __launch_bounds__(1024) void pg_front_bwd2_kernel(const int* __restri
     { const double* __restrict__ L11 = F + fd.off + (size_t)col0 * ld + col0;
 #pragma unroll
       for (int e = 0; e < 9; ++e) { const int id = e * 1024 + threadIdx.x, r = id / 96, cc = id - 96 * r; lreg[e] = (r < n && cc <= r) ? L11[(size_t)r * ld + cc] : 0.0; } }
+    if (threadIdx.x < PG_NB4 * 16) sT[threadIdx.x] = Tinv[(size_t)p * PG_NB4 * 16 + threadIdx.x];
     const bool big = nrows > PG_BWD2_SX;           // only the largest interface fronts: x2 does not fit the LDS, read it through the row map
     if (!big) for (int i = threadIdx.x; i < nrows; i += 1024) { const int g = row0 + i; sx[i] = x[(size_t)f_rows[fd.rowptr + g / 6] * 6 + g % 6]; }
     __syncthreads();
@@ -1464,7 +1466,7 @@ __global__ __launch_bounds__(1024) void pg_front_bwd2_kernel(const int* __restri
         if (c1 < n) for (int g = 0; g < 10; ++g) w -= s_acc[g * (PG_PW * 6) + c1];
         z1 = w;
     }
-    const double* __restrict__ tin = Tinv + (size_t)p * PG_NB4 * 16;
+    const double* __restrict__ tin = sT;
 #pragma unroll
     for (int blk = PG_NB4 - 1; blk >= 0; --blk) {
         if (4 * blk >= n) continue;                 // uniform (identity padding)
@@ -2070,7 +2072,7 @@ static int pg_solve_impl(dsss_ctx* c, const double* dr6, int total, const dsss_l
     unsigned long long* d_stamps = nullptr; if (getenv("DSSS_PG_STAMPS")) TRY(dv.alloc(c, &d_stamps, 16));
     static const bool one_wave = getenv("DSSS_PG_PANEL") && !strcmp(getenv("DSSS_PG_PANEL"), "onewave");
     double* d_Tinv; TRY(dv.alloc(c, &d_Tinv, (size_t)std::max(npan, 1) * PG_NB4 * 16));
-    const int bwd_lds = old_panel ? PG_BWD_LDS(max_n6) : (int)(((PG_PW * 6) * PG_BWD2_LD + 10 * (PG_PW * 6) + std::min(max_n6, PG_BWD2_SX) + 16) * sizeof(double));
+    const int bwd_lds = old_panel ? PG_BWD_LDS(max_n6) : (int)(((PG_PW * 6) * PG_BWD2_LD + PG_NB4 * 16 + 10 * (PG_PW * 6) + std::min(max_n6, PG_BWD2_SX) + 16) * sizeof(double));
     if (bwd_lds > 160 * 1024) { dv.release(); DSSS_FAIL(c, DSSS_E_CAPACITY, "front of %d scalar rows: back-substitution needs %d B of LDS", max_n6, bwd_lds); }
     {   // pg_front_diag_kernel keeps the panel and its inverse (2 x 75 KB) in dynamic LDS, pg_front_bwd_kernel W and x2
         hipFuncSetAttribute((const void*)pg_front_diag_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, PG_DIAG_LDS);

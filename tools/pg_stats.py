@@ -17,13 +17,20 @@ a, b, N, F = d["a"], d["b"], int(d["N"]), int(d["F"])
 n = N * F
 sv = Survey(F, N, 1024 if N == 2000 else 512, seed=20240601 + (1 if N == 2000 else 0))
 dr = np.concatenate([sv.inputs(f)[0] for f in range(F)])
+# the TRUE separators of the two-level chain elimination (dsss_pg.hip, pg_solve_impl): LC-touched poses, both ends, partition
+# ends, and one pose every 16 chunks inside gaps of 16 chunks or more
 is_sep = np.zeros(n, bool); is_sep[0] = is_sep[-1] = True; is_sep[a] = True; is_sep[b] = True
-if chunk > 0:
-    is_sep[::chunk] = True
 fpr = (F + nparts - 1) // nparts
 if nparts > 1:
     for r in range(1, nparts):
         is_sep[r * fpr * N - 1] = True
+if chunk > 0:
+    last = 0
+    for i in range(n):
+        if is_sep[i]:
+            last = i
+        elif i - last >= 16 * chunk and i % chunk == 0:
+            is_sep[i] = True; last = i
 sep = np.nonzero(is_sep)[0]
 sidx = -np.ones(n, np.int64); sidx[sep] = np.arange(len(sep))
 ns = len(sep)

@@ -1,20 +1,28 @@
-"""Wall-clock time of each stage of the hot path (frames, extract, match+LC, pose graph) with a device sync between
-stages; for use through gpurun:  python tools/stage_times.py C3"""
-import sys, time, os
+#!/usr/bin/env python3
+"""Wall time of the four pipeline stages of one C3 step, a device synchronisation after each (the bench itself does not
+synchronise between stages): where the host-side time of a step sits.  python tools/stage_times.py [steps]"""
+import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import numpy as np, torch
-from diasss_amd.pipeline import Pipeline
+import numpy as np
+import torch
 from diasss_amd.synth import Survey
-wl = sys.argv[1] if len(sys.argv) > 1 else "C2"
-F, N, M = {"C2": (50, 1000, 512), "C3": (200, 2000, 1024), "C3s": (40, 2000, 1024)}[wl]
-sv = Survey(F, N, M, seed=20240601, device="cuda:0")
+from diasss_amd.pipeline import Pipeline
+
+F, N, M = 200, 2000, 1024
+sv = Survey(F, N, M, seed=20240601 + 1, device="cuda:0")
 raws = [sv.frame(f) for f in range(F)]
-poses = [sv.inputs(f)[0] for f in range(F)]; alts = [sv.inputs(f)[1] for f in range(F)]; grs = [sv.inputs(f)[2] for f in range(F)]
+ins = [sv.inputs(f) for f in range(F)]
+poses = [i[0] for i in ins]; alts = [i[1] for i in ins]; grs = [i[2] for i in ins]
 pipe = Pipeline(F)
-for it in range(int(sys.argv[2]) if len(sys.argv) > 2 else 3):
-    torch.cuda.synchronize(); t0 = time.perf_counter()
-    pipe.set_frames(raws, poses, alts, grs); pipe.ctx.sync(); t1 = time.perf_counter()
-    pipe.extract(); pipe.ctx.sync(); t2 = time.perf_counter()
-    pipe.match(); pipe.ctx.sync(); t3 = time.perf_counter()
-    out, stats = pipe.optimize(); t4 = time.perf_counter()
-    print("frames %.1f ms  extract %.1f ms  match+lc %.1f ms  pg %.1f ms  total %.1f ms" % ((t1-t0)*1e3, (t2-t1)*1e3, (t3-t2)*1e3, (t4-t3)*1e3, (t4-t0)*1e3), "rows", pipe.ctx.match_total(), stats)
+steps = int(sys.argv[1]) if len(sys.argv) > 1 else 4
+acc = np.zeros(5)
+for s in range(steps + 1):
+    t = [time.perf_counter()]
+    pipe.set_frames(raws, poses, alts, grs); torch.cuda.synchronize(); t.append(time.perf_counter())
+    pipe.extract(); torch.cuda.synchronize(); t.append(time.perf_counter())
+    src_tgt = pipe.match(); torch.cuda.synchronize(); t.append(time.perf_counter())
+    pipe.optimize(); torch.cuda.synchronize(); t.append(time.perf_counter())
+    if s > 0:
+        acc[:4] += np.diff(t); acc[4] += t[-1] - t[0]
+print("ms per step: set_frames %.2f  extract %.2f  match+lc %.2f  posegraph %.2f  total %.2f" % tuple(1e3 * acc / steps))
+pipe.close()
