@@ -1341,6 +1341,15 @@ __global__ __launch_bounds__(256) void pg_front_trsm2_kernel(const int* __restri
     const int n = min(96, fd.s6 - col0), p = fd.pan0 + step, ld = fd.ld;
     const int row0 = col0 + n, nrows = fd.n6 - row0;
     if ((int)blockIdx.y * 64 >= nrows) return;     // workgroup-uniform
+    const int l = threadIdx.x & 63, c = l & 15, q = l >> 4;
+    const int rowbase = ((int)blockIdx.y * 4 + (int)(threadIdx.x >> 6)) * 16;
+    const bool rok = rowbase + c < nrows;
+    double* __restrict__ Arow = F + fd.off + (size_t)(row0 + min(max(rowbase + c, 0), nrows - 1)) * ld + col0;
+    pg_d4 S[6];                                    // the slab's own rows are requested first: their latency hides behind the staging of L11
+#pragma unroll
+    for (int T = 0; T < 6; ++T)
+#pragma unroll
+        for (int v = 0; v < 4; ++v) { const int col = 16 * T + q + 4 * v; S[T][v] = (rok && col < n) ? Arow[col] : 0.0; }
     {
         const double* __restrict__ L11 = F + fd.off + (size_t)col0 * ld + col0;
         double v[36];
@@ -1352,16 +1361,7 @@ __global__ __launch_bounds__(256) void pg_front_trsm2_kernel(const int* __restri
         if (threadIdx.x < 96) sY[threadIdx.x] = (int)threadIdx.x < n ? R[fd.roff + col0 + threadIdx.x] : 0.0;
     }
     __syncthreads();
-    const int l = threadIdx.x & 63, c = l & 15, q = l >> 4;
-    const int rowbase = ((int)blockIdx.y * 4 + (int)(threadIdx.x >> 6)) * 16;
     if (rowbase >= nrows) return;                  // wavefront-uniform
-    const bool rok = rowbase + c < nrows;
-    double* __restrict__ Arow = F + fd.off + (size_t)(row0 + min(rowbase + c, nrows - 1)) * ld + col0;
-    pg_d4 S[6];
-#pragma unroll
-    for (int T = 0; T < 6; ++T)
-#pragma unroll
-        for (int v = 0; v < 4; ++v) { const int col = 16 * T + q + 4 * v; S[T][v] = (rok && col < n) ? Arow[col] : 0.0; }
 #pragma unroll
     for (int t = 0; t < 6; ++t) {
         if (16 * t >= n) break;                     // uniform: nothing beyond the panel's columns
