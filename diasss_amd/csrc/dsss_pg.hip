@@ -308,9 +308,9 @@ __global__ __launch_bounds__(256, 2) void pg_segment_kernel(int nseg, const int*
 #pragma unroll
             for (int b2 = 0; b2 < 6; ++b2) Li[a * 6 + b2] = b2 <= a ? Dc[a * 6 + b2] : 0.0;
         if (chol6_fast(Li, ri)) { *fail = 1; return; }          // every lane of the group sees the same pivot: they leave together
-        if (c == 0) {                                            // the factor, for the record (stored at the top of the next step)
+        if (c == 0) {                                            // the factor, for the record (stored at the top of the next step);
 #pragma unroll
-            for (int a = 0; a < 36; ++a) sh.L[a] = Li[a];
+            for (int a = 0; a < 36; ++a) sh.L[a] = (a % 7 == 0) ? ri[a / 7] : Li[a];     // its diagonal as 1 / L_jj: the back-substitution multiplies
         }
         PG_COMPILER_FENCE();
         // right-hand side of this lane: c < 6 row c of E (column of E^T), 6 <= c < 12 column c - 6 of C, c == 12 the gradient
@@ -381,22 +381,24 @@ __global__ __launch_bounds__(256) void pg_chain1_kernel(int ns1, const int* __re
                                                         const double* __restrict__ segGL, const double* __restrict__ segGR, const double* __restrict__ segS,
                                                         double* __restrict__ D1, double* __restrict__ C1, double* __restrict__ g1, int mp0, int mp1)
 {
-    const int k = blockIdx.x * 256 + threadIdx.x;
+    // one thread per element (36 of D1 / C1 + 6 of g1 per node): a thread per node read its eight 288-byte rows alone (114 us)
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    const int k = (int)(t / 42), a = (int)(t - 42LL * k);
     if (k >= ns1) return;
     const int p = sep1[k];
     const bool segl = k > 0 && sep1[k - 1] + 1 >= mp0 && sep1[k - 1] + 1 < mp1, segr = k + 1 < ns1 && p + 1 >= mp0 && p + 1 < mp1;
-    for (int a = 0; a < 36; ++a) {
+    if (a < 36) {
         double v = D[(size_t)p * 36 + a];
         if (segl) v += segDR[(size_t)(k - 1) * 36 + a];
         if (segr) v += segDL[(size_t)k * 36 + a];
         D1[(size_t)k * 36 + a] = v;
         C1[(size_t)k * 36 + a] = segr ? segS[(size_t)k * 36 + a] : 0.0;
-    }
-    for (int a = 0; a < 6; ++a) {
-        double v = g[(size_t)p * 6 + a];
-        if (segl) v += segGR[(size_t)(k - 1) * 6 + a];
-        if (segr) v += segGL[(size_t)k * 6 + a];
-        g1[(size_t)k * 6 + a] = v;
+    } else {
+        const int b = a - 36;
+        double v = g[(size_t)p * 6 + b];
+        if (segl) v += segGR[(size_t)(k - 1) * 6 + b];
+        if (segr) v += segGL[(size_t)k * 6 + b];
+        g1[(size_t)k * 6 + b] = v;
     }
 }
 
@@ -412,40 +414,38 @@ __global__ __launch_bounds__(256) void pg_scatter_base_kernel(int ns, const int*
                                                               double* __restrict__ Lvals, double* __restrict__ aval, double* __restrict__ rhs,
                                                               const int* __restrict__ if_slot, double* __restrict__ aval_if, double* __restrict__ x_if, int mp0, int mp1)
 {
-    const int k = blockIdx.x * 256 + threadIdx.x;
+    // one thread per element: 36 of the diagonal block, 6 of the right-hand side, 36 of the coupling S(k, k+1)
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    const int k = (int)(t / 78), el = (int)(t - 78LL * k);
     if (k >= ns) return;
     const int p = sep_pose[k];
     // segment k-1 ends in this separator, segment k starts in it; each belongs to the owner of its first interior pose
     const bool segl = k > 0 && sep_pose[k - 1] + 1 >= mp0 && sep_pose[k - 1] + 1 < mp1, segr = k + 1 < ns && p + 1 >= mp0 && p + 1 < mp1;
     const int code = dest[k];
     const bool iface = code <= -2, own = p >= mp0 && p < mp1;
-    if (iface || own) {
+    if (el < 42) {
+        if (!(iface || own)) return;
         // an interface separator takes a partial sum from every rank (summed by the all-reduce), an interior one is complete
-        double* dst = code >= 0 ? Lvals + (size_t)(code >> 1) * 36 : (iface ? aval_if + (size_t)(-2 - code) * 36 : aval + (size_t)k * 36);
-        for (int a = 0; a < 36; ++a) {
-            double v = D[(size_t)p * 36 + a];
-            if (segl) v += segDR[(size_t)(k - 1) * 36 + a];
-            if (segr) v += segDL[(size_t)k * 36 + a];
-            dst[a] = v;
-        }
-        double* rr = iface ? x_if + (size_t)if_slot[k] * 6 : rhs + (size_t)perm[k] * 6;
-        for (int a = 0; a < 6; ++a) {
+        if (el < 36) {
+            double* dst = code >= 0 ? Lvals + (size_t)(code >> 1) * 36 : (iface ? aval_if + (size_t)(-2 - code) * 36 : aval + (size_t)k * 36);
+            double v = D[(size_t)p * 36 + el];
+            if (segl) v += segDR[(size_t)(k - 1) * 36 + el];
+            if (segr) v += segDL[(size_t)k * 36 + el];
+            dst[el] = v;
+        } else {
+            const int a = el - 36;
+            double* rr = iface ? x_if + (size_t)if_slot[k] * 6 : rhs + (size_t)perm[k] * 6;
             double v = g[(size_t)p * 6 + a];
             if (segl) v += segGR[(size_t)(k - 1) * 6 + a];
             if (segr) v += segGL[(size_t)k * 6 + a];
             rr[a] = -v;
         }
-    }
-    if (segr) {            // S(k, k+1), written by the owner of segment k: the factor holds the (larger index, smaller index) block
+    } else if (segr) {     // S(k, k+1), written by the owner of segment k: the factor holds the (larger index, smaller index) block
+        const int e = el - 42, a = e / 6, b = e - 6 * a;
         const int cc = dest[ns + k];
         const double* S = segS + (size_t)k * 36;
-        if (cc >= 0) {
-            double* c = Lvals + (size_t)(cc >> 1) * 36; const int tr = cc & 1;
-            for (int a = 0; a < 6; ++a) for (int b = 0; b < 6; ++b) c[a * 6 + b] = tr ? S[b * 6 + a] : S[a * 6 + b];
-        } else {
-            double* c = cc <= -2 ? aval_if + (size_t)(-2 - cc) * 36 : aval + (size_t)(ns + k) * 36;
-            for (int a = 0; a < 36; ++a) c[a] = S[a];
-        }
+        if (cc >= 0) Lvals[(size_t)(cc >> 1) * 36 + e] = (cc & 1) ? S[b * 6 + a] : S[e];
+        else (cc <= -2 ? aval_if + (size_t)(-2 - cc) * 36 : aval + (size_t)(ns + k) * 36)[e] = S[e];
     }
 }
 // LC off-diagonal blocks H(a, b) = Ji^T W (added after the chain couplings; (a,b) is unique per edge)
@@ -453,21 +453,14 @@ __global__ __launch_bounds__(256) void pg_scatter_lc_kernel(int n, int ne, int n
                                                             const int* __restrict__ dest, double* __restrict__ Lvals, double* __restrict__ aval,
                                                             double* __restrict__ aval_if, const int* __restrict__ eb, int mp0, int mp1)
 {
-    const int e = blockIdx.x * 256 + threadIdx.x;
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;          // one thread per element of the 6 x 6 block
+    const int e = (int)(t / 36), el = (int)(t - 36LL * e), a = el / 6, b = el - 6 * a;
     if (e >= ne) return;
     if (eb[e] < mp0 || eb[e] >= mp1) return;
     const int code = dest[2 * ns - 1 + e];
-    const double* J = Ji + (size_t)(n + e) * 36; const double* w = ew + (size_t)e * 6;
-    if (code >= 0) {
-        double* c = Lvals + (size_t)(code >> 1) * 36; const int tr = code & 1;
-        for (int a = 0; a < 6; ++a) for (int b = 0; b < 6; ++b) {
-            const double h_ab = J[b * 6 + a] * w[b];               // (Ji^T W)(a, b)
-            if (tr) c[b * 6 + a] += h_ab; else c[a * 6 + b] += h_ab;
-        }
-    } else {
-        double* c = code <= -2 ? aval_if + (size_t)(-2 - code) * 36 : aval + (size_t)(2 * ns - 1 + e) * 36;
-        for (int a = 0; a < 6; ++a) for (int b = 0; b < 6; ++b) c[a * 6 + b] = J[b * 6 + a] * w[b];
-    }
+    const double h_ab = Ji[(size_t)(n + e) * 36 + b * 6 + a] * ew[(size_t)e * 6 + b];               // (Ji^T W)(a, b)
+    if (code >= 0) Lvals[(size_t)(code >> 1) * 36 + ((code & 1) ? b * 6 + a : el)] += h_ab;
+    else (code <= -2 ? aval_if + (size_t)(-2 - code) * 36 : aval + (size_t)(2 * ns - 1 + e) * 36)[el] = h_ab;
 }
 
 // update matrices that cross from this rank's interior into the interface, packed (6b x 6b lower block triangle, then 6b of
@@ -1644,28 +1637,55 @@ __global__ __launch_bounds__(256) void pg_sep_delta_kernel(int ns, const int* __
     for (int a = 0; a < 6; ++a) delta[(size_t)sep_pose[k] * 6 + a] = x[(size_t)src * 6 + a];
 }
 
-// interiors, right to left: delta_i = D_i^-1 (-g_i - E_i^T delta_L - C_i delta_{i+1})
-__global__ __launch_bounds__(64) void pg_backsub_kernel(int nseg, const int* __restrict__ sep_pose, const double* __restrict__ C,
-                                                        const double* __restrict__ E, const double* __restrict__ Dl, const double* __restrict__ gi,
-                                                        double* __restrict__ delta, int mp0, int mp1)
+// interiors, right to left: delta_i = D_i^-1 (-g_i - E_i^T delta_L - C_i delta_{i+1}).  EIGHT LANES PER SEGMENT: lane a < 6 forms
+// component a of the right-hand side (column a of E_i, row a of C_i: the group reads the 288-byte blocks together; one thread
+// per segment read them alone, 8.7 us per pose), the six components are exchanged, and every lane solves the 6 x 6 system itself,
+// which leaves delta_i in all of them for the next step.  The blocks of pose i - 1 are requested before pose i is computed.
+#define PG_BS_LANES 8
+struct pg_bs_blk { double Ec[6], Cr[6], gv, Lm[21]; };
+__device__ __forceinline__ void pg_bs_load(pg_bs_blk& B, int i, int aa, const double* __restrict__ C, const double* __restrict__ E,
+                                           const double* __restrict__ Dl, const double* __restrict__ gi)
 {
-    const int s = blockIdx.x * 64 + threadIdx.x;
-    if (s >= nseg) return;
+#pragma unroll
+    for (int q = 0; q < 6; ++q) { B.Ec[q] = E[(size_t)i * 36 + q * 6 + aa]; B.Cr[q] = C[(size_t)i * 36 + aa * 6 + q]; }
+    B.gv = gi[(size_t)i * 6 + aa];
+#pragma unroll
+    for (int r = 0; r < 6; ++r)
+#pragma unroll
+        for (int k = 0; k <= r; ++k) B.Lm[r * (r + 1) / 2 + k] = Dl[(size_t)i * 36 + r * 6 + k];
+}
+__global__ __launch_bounds__(256) void pg_backsub_kernel(int nseg, const int* __restrict__ sep_pose, const double* __restrict__ C,
+                                                         const double* __restrict__ E, const double* __restrict__ Dl, const double* __restrict__ gi,
+                                                         double* __restrict__ delta, int mp0, int mp1)
+{
+    const int s = blockIdx.x * (256 / PG_BS_LANES) + threadIdx.x / PG_BS_LANES, a = threadIdx.x % PG_BS_LANES;
+    if (s >= nseg) return;                                      // whole groups leave together
     const int L = sep_pose[s], R = sep_pose[s + 1];
-    if (L + 1 < mp0 || L + 1 >= mp1) return;
+    if (L + 1 < mp0 || L + 1 >= mp1 || R == L + 1) return;
+    const int aa = a < 6 ? a : 5;                               // lanes 6 and 7 shadow lane 5 and store nothing
     double dL[6], dn[6];
-    for (int a = 0; a < 6; ++a) { dL[a] = delta[(size_t)L * 6 + a]; dn[a] = delta[(size_t)R * 6 + a]; }
+#pragma unroll
+    for (int q = 0; q < 6; ++q) { dL[q] = delta[(size_t)L * 6 + q]; dn[q] = delta[(size_t)R * 6 + q]; }
+    pg_bs_blk cur, nxt;
+    pg_bs_load(cur, R - 1, aa, C, E, Dl, gi);
     for (int i = R - 1; i > L; --i) {
+        if (i - 1 > L) pg_bs_load(nxt, i - 1, aa, C, E, Dl, gi);
+        double t = -cur.gv;
+#pragma unroll
+        for (int q = 0; q < 6; ++q) { t -= cur.Ec[q] * dL[q]; t -= cur.Cr[q] * dn[q]; }
         double b[6];
-        for (int a = 0; a < 6; ++a) {
-            double t = -gi[(size_t)i * 6 + a];
-            for (int q = 0; q < 6; ++q) { t -= E[(size_t)i * 36 + q * 6 + a] * dL[q]; t -= C[(size_t)i * 36 + a * 6 + q] * dn[q]; }
-            b[a] = t;
-        }
-        double Li[36];
-        for (int a = 0; a < 36; ++a) Li[a] = Dl[(size_t)i * 36 + a];
-        chol6_solve(Li, b, 1);
-        for (int a = 0; a < 6; ++a) { delta[(size_t)i * 6 + a] = b[a]; dn[a] = b[a]; }
+#pragma unroll
+        for (int q = 0; q < 6; ++q) b[q] = __shfl(t, q, PG_BS_LANES);
+        // (L L^T) x = b; the record holds 1 / L_jj on the diagonal (pg_segment_kernel)
+#pragma unroll
+        for (int r = 0; r < 6; ++r) { double v = b[r]; for (int k = 0; k < r; ++k) v -= cur.Lm[r * (r + 1) / 2 + k] * b[k]; b[r] = v * cur.Lm[r * (r + 1) / 2 + r]; }
+#pragma unroll
+        for (int r = 5; r >= 0; --r) { double v = b[r]; for (int k = r + 1; k < 6; ++k) v -= cur.Lm[k * (k + 1) / 2 + r] * b[k]; b[r] = v * cur.Lm[r * (r + 1) / 2 + r]; }
+        const double mine = a == 0 ? b[0] : a == 1 ? b[1] : a == 2 ? b[2] : a == 3 ? b[3] : a == 4 ? b[4] : b[5];
+        if (a < 6) delta[(size_t)i * 6 + a] = mine;
+#pragma unroll
+        for (int q = 0; q < 6; ++q) dn[q] = b[q];
+        cur = nxt;
     }
 }
 
@@ -1675,15 +1695,18 @@ __global__ __launch_bounds__(256) void pg_linerr_kernel(int n, int ne, pg_weight
                                                         const double* __restrict__ delta, double* __restrict__ partial, int mp0, int mp1)
 {
     __shared__ double s_w[4];
-    const int k = blockIdx.x * 256 + threadIdx.x;
+    // a block covers 256 factors; a thread takes residual component (factor, a) six times over, so that consecutive threads read
+    // consecutive rows of the Jacobians (a thread per factor read its 288-byte block alone)
     double e2 = 0;
-    if (k < n + ne && pg_owned_factor(k, n, eb, mp0, mp1)) {
-        int i = -1, j; const double* w;
-        if (k == 0) { j = 0; w = W.prior; }
-        else if (k < n) { i = k - 1; j = k; w = W.odo; }
-        else { i = ea[k - n]; j = eb[k - n]; w = ew + (size_t)(k - n) * 6; }
-        for (int a = 0; a < 6; ++a) {
-            double s = r[(size_t)k * 6 + a] + w[a] * delta[(size_t)j * 6 + a];
+#pragma unroll
+    for (int it = 0; it < 6; ++it) {
+        const int el = it * 256 + threadIdx.x, k = blockIdx.x * 256 + el / 6, a = el % 6;
+        if (k < n + ne && pg_owned_factor(k, n, eb, mp0, mp1)) {
+            int i = -1, j; double wa;
+            if (k == 0) { j = 0; wa = W.prior[a]; }
+            else if (k < n) { i = k - 1; j = k; wa = W.odo[a]; }
+            else { i = ea[k - n]; j = eb[k - n]; wa = ew[(size_t)(k - n) * 6 + a]; }
+            double s = r[(size_t)k * 6 + a] + wa * delta[(size_t)j * 6 + a];
             if (i >= 0) for (int q = 0; q < 6; ++q) s += Ji[(size_t)k * 36 + a * 6 + q] * delta[(size_t)i * 6 + q];
             e2 += s * s;
         }
@@ -2157,11 +2180,11 @@ static int pg_solve_impl(dsss_ctx* c, const double* dr6, int total, const dsss_l
                 hipLaunchKernelGGL(pg_assemble_kernel, dim3((n + PG_ASM_POSES - 1) / PG_ASM_POSES), dim3(6 * PG_ASM_POSES), 0, st, n, W, d_r, d_Ji, d_adj_ptr, d_adj_edge, d_ew, d_scal + 3, d_D, d_C, d_g, d_eb, mp0, mp1);
                 // pass 1: chunks of poses onto their ends; the level-1 chain; pass 2: runs of chunk ends onto the true separators
                 hipLaunchKernelGGL(pg_segment_kernel, dim3((nseg1 + 15) / 16), dim3(256), 0, st, nseg1, d_sep1, d_D, d_C, d_g, d_E, d_Dl, d_gi, d_sDL, d_sDR, d_sGL, d_sGR, d_sS, d_fail, mp0, mp1);
-                hipLaunchKernelGGL(pg_chain1_kernel, dim3((ns1 + 255) / 256), dim3(256), 0, st, ns1, d_sep1, d_D, d_g, d_sDL, d_sDR, d_sGL, d_sGR, d_sS, d_D1, d_C1, d_g1, mp0, mp1);
+                hipLaunchKernelGGL(pg_chain1_kernel, dim3((unsigned)(((long long)ns1 * 42 + 255) / 256)), dim3(256), 0, st, ns1, d_sep1, d_D, d_g, d_sDL, d_sDR, d_sGL, d_sGR, d_sS, d_D1, d_C1, d_g1, mp0, mp1);
                 if (nseg > 0) hipLaunchKernelGGL(pg_segment_kernel, dim3((nseg + 15) / 16), dim3(256), 0, st, nseg, d_t2, d_D1, d_C1, d_g1, d_E1, d_Dl1, d_gi1, d_s2DL, d_s2DR, d_s2GL, d_s2GR, d_s2S, d_fail, kp0, kp1);
-                hipLaunchKernelGGL(pg_scatter_base_kernel, dim3((ns + 255) / 256), dim3(256), 0, st, ns, d_t2, d_perm, d_D1, d_g1, d_s2DL, d_s2DR, d_s2GL, d_s2GR, d_s2S, d_dest, d_L, d_aval, d_x,
+                hipLaunchKernelGGL(pg_scatter_base_kernel, dim3((unsigned)(((long long)ns * 78 + 255) / 256)), dim3(256), 0, st, ns, d_t2, d_perm, d_D1, d_g1, d_s2DL, d_s2DR, d_s2GL, d_s2GR, d_s2S, d_dest, d_L, d_aval, d_x,
                                    d_ifslot, d_avalif, d_xif, kp0, kp1);
-                if (ne > 0) hipLaunchKernelGGL(pg_scatter_lc_kernel, dim3((ne + 255) / 256), dim3(256), 0, st, n, ne, ns, d_Ji, d_ew, d_dest, d_L, d_aval, d_avalif, d_eb, mp0, mp1);
+                if (ne > 0) hipLaunchKernelGGL(pg_scatter_lc_kernel, dim3((unsigned)(((long long)ne * 36 + 255) / 256)), dim3(256), 0, st, n, ne, ns, d_Ji, d_ew, d_dest, d_L, d_aval, d_avalif, d_eb, mp0, mp1);
                 if (nbins > 0) { dsss_scope s1(c, DSSS_K_PG_SUBTREE);
                                  hipLaunchKernelGGL(pg_factor_subtree_kernel, dim3(nbins), dim3(256), 0, st, d_binptr + bin_lo, d_bincols, d_colptr, d_rlptr, d_rlcol, d_rlpos, d_mapptr, d_map, d_L, d_x, d_fail,
                                                     d_binroot_ptr + bin_lo, d_binroot_idx, d_broot_b, d_broot_uoff, d_broot_of_col, d_anc_first, d_anc_rel, d_ubin); }
@@ -2215,9 +2238,9 @@ static int pg_solve_impl(dsss_ctx* c, const double* dr6, int total, const dsss_l
                 if (nbins > 0) { dsss_scope s7(c, DSSS_K_PG_SUBTREE);
                     hipLaunchKernelGGL(pg_bwd_subtree_kernel, dim3(nbins), dim3(64), 0, st, d_binptr + bin_lo, d_bincols, d_colptr, d_rowidx, d_L, d_x); }
                 hipLaunchKernelGGL(pg_sep_delta_kernel, dim3((ns + 255) / 256), dim3(256), 0, st, ns, d_t2, d_perm, d_x, d_delta1);
-                if (nseg > 0) hipLaunchKernelGGL(pg_backsub_kernel, dim3((nseg + 63) / 64), dim3(64), 0, st, nseg, d_t2, d_C1, d_E1, d_Dl1, d_gi1, d_delta1, kp0, kp1);
+                if (nseg > 0) hipLaunchKernelGGL(pg_backsub_kernel, dim3((nseg + 31) / 32), dim3(256), 0, st, nseg, d_t2, d_C1, d_E1, d_Dl1, d_gi1, d_delta1, kp0, kp1);
                 hipLaunchKernelGGL(pg_sep_delta_kernel, dim3((ns1 + 255) / 256), dim3(256), 0, st, ns1, d_sep1, (const int*)nullptr, d_delta1, d_delta);
-                hipLaunchKernelGGL(pg_backsub_kernel, dim3((nseg1 + 63) / 64), dim3(64), 0, st, nseg1, d_sep1, d_C, d_E, d_Dl, d_gi, d_delta, mp0, mp1);
+                hipLaunchKernelGGL(pg_backsub_kernel, dim3((nseg1 + 31) / 32), dim3(256), 0, st, nseg1, d_sep1, d_C, d_E, d_Dl, d_gi, d_delta, mp0, mp1);
                 hipLaunchKernelGGL(pg_linerr_kernel, dim3(nblk), dim3(256), 0, st, n, ne, W, d_ea, d_eb, d_ew, d_r, d_Ji, d_delta, d_part, mp0, mp1);
                 hipLaunchKernelGGL(pg_final_sum_kernel, dim3(1), dim3(256), 0, st, d_part, nblk, 0.5, d_scal + 1);
             }
