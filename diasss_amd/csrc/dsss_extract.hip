@@ -436,9 +436,17 @@ __global__ __launch_bounds__(256) void orient_desc_kernel(const ex_frame* __rest
     const int cx = __float2int_rn(in.x), cy = __float2int_rn(in.y);
     uint8_t* P = sP[wv]; uint16_t* H = sH[wv]; uint8_t* B = sB[wv];
     if (act)
-        for (int t = lane; t < PW * PW; t += 64) {
-            const int py = t / PW, px = t - py * PW;
-            P[py * PS + px] = img[(size_t)reflect101_dev(cy + py - PR, rows) * cols + reflect101_dev(cx + px - PR, cols)];
+        for (int t0 = 0; t0 < PW * PW; t0 += 64 * 13) {             // thirteen byte loads in flight per lane: three round trips for the
+            uint8_t v[13]; int o[13];                                // 49 x 49 patch (one load per iteration made it 38)
+#pragma unroll
+            for (int u = 0; u < 13; ++u) {
+                const int t = t0 + 64 * u + lane;
+                const int py = t / PW, px = t - py * PW;
+                o[u] = t < PW * PW ? py * PS + px : -1;
+                v[u] = t < PW * PW ? img[(size_t)reflect101_dev(cy + py - PR, rows) * cols + reflect101_dev(cx + px - PR, cols)] : (uint8_t)0;
+            }
+#pragma unroll
+            for (int u = 0; u < 13; ++u) if (o[u] >= 0) P[o[u]] = v[u];
         }
     __syncthreads();
     // IC_Angle (ORBextractor.cpp:77-104): integer moments over the radius-15 disc

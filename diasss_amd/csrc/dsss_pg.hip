@@ -1983,7 +1983,7 @@ static int pg_solve_impl(dsss_ctx* c, const double* dr6, int total, const dsss_l
     const auto T1 = std::chrono::steady_clock::now();
     pg_sym S;
     { pg_sym_opts opt; opt.threads = sym_threads();
-      static const double bin_cost = getenv("DSSS_PG_BIN_COST") ? atof(getenv("DSSS_PG_BIN_COST")) : 1000;   // ~ update-list iterations + 20 per column; measured optimum at C3 (800-1500)
+      static const double bin_cost = getenv("DSSS_PG_BIN_COST") ? atof(getenv("DSSS_PG_BIN_COST")) : 600;   // ~ update-list iterations + 20 per column; measured optimum at C3 (800-1500)
       opt.bin_cost = bin_cost; pg_sym_opts_env(opt);
       std::vector<int> part(ns);
       for (int k = 0; k < ns; ++k) part[k] = (int)(std::upper_bound(pbound.begin(), pbound.end(), sep_pose[k]) - pbound.begin()) - 1;
