@@ -312,7 +312,12 @@ void pg_symbolic(int ns, const std::vector<std::pair<int, int>>& edges, int ncha
                     const double zeros = (double)(g.n - bc) * sc;                     // explicit zero blocks the merge puts into L
                     const double f_sep = flops_of(sc, nc) + flops_of(g.s, g.n), f_mrg = flops_of(sc + g.s, sc + g.n);
                     const bool one_panel = sc + g.s <= PG_PW;
-                    if (zeros <= opt.relax_zero_blocks || f_mrg <= f_sep * (one_panel ? opt.relax_flops_small : opt.relax_flops)) {
+                    // a merge that removes a panel step (the two column counts round up to fewer panels together) is worth a bounded
+                    // amount of extra arithmetic whatever the ratio: a level costs about 100 us of dependent launches, i.e. more than
+                    // a GFLOP of trailing update
+                    const bool saves_step = (sc + g.s + PG_PW - 1) / PG_PW < (sc + PG_PW - 1) / PG_PW + (g.s + PG_PW - 1) / PG_PW;
+                    if (zeros <= opt.relax_zero_blocks || f_mrg <= f_sep * (one_panel ? opt.relax_flops_small : opt.relax_flops) ||
+                        (saves_step && f_mrg - f_sep <= opt.relax_abs_flops)) {
                         // rows of the merged front: the child's own columns, then the parent's rows (a superset of the child's boundary)
                         std::vector<int> rows(cr, cr + sc);
                         rows.insert(rows.end(), S.rowidx.begin() + S.colptr[g.c0], S.rowidx.begin() + S.colptr[g.c0] + g.n);
@@ -546,6 +551,7 @@ void pg_sym_opts_env(pg_sym_opts& opt)
     if (getenv("DSSS_PG_RELAX_ZERO")) opt.relax_zero_blocks = atof(getenv("DSSS_PG_RELAX_ZERO"));
     if (getenv("DSSS_PG_RELAX_FLOPS")) opt.relax_flops = atof(getenv("DSSS_PG_RELAX_FLOPS"));
     if (getenv("DSSS_PG_RELAX_SMALL")) opt.relax_flops_small = atof(getenv("DSSS_PG_RELAX_SMALL"));
+    if (getenv("DSSS_PG_RELAX_ABS")) opt.relax_abs_flops = atof(getenv("DSSS_PG_RELAX_ABS"));
 }
 
 // ------------------------------------------------------------------ host twin of the numeric phase (CPU tests only)

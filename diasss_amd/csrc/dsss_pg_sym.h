@@ -102,9 +102,10 @@ struct pg_sym_opts {
     // zero blocks, or when the merged front costs at most relax_flops x the two separate ones (relax_flops_small while the
     // merged front still fits one 96-column panel: such a merge removes a whole level for very little arithmetic)
     double relax_zero_blocks = 8, relax_flops = 1.05, relax_flops_small = 1.6;
+    double relax_abs_flops = 0;         // extra flops a merge may cost when it removes a panel step
 };
 
-void pg_sym_opts_env(pg_sym_opts& opt);    // DSSS_PG_RELAX_ZERO / _FLOPS / _SMALL overrides (experiments)
+void pg_sym_opts_env(pg_sym_opts& opt);    // DSSS_PG_RELAX_ZERO / _FLOPS / _SMALL / _ABS overrides (experiments)
 
 // edges: pairs of chain-order separator indices, the ns-1 chain couplings (k, k+1) first, then the LC edges.
 // part[k] (may be null): rank that owns separator k, non-decreasing in k.  cx, cy: DR positions of the separators.
