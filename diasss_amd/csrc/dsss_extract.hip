@@ -160,6 +160,7 @@ __device__ inline int cvfloorf_dev(float v) { const int i = (int)v; return i - (
 // output column / row (tables built once per geometry by resize_tables(), the same float arithmetic OpenCV uses), horizontal pass
 // in int, vertical pass with the two 16-bit shifts.  A thread produces FOUR consecutive bytes of the level (flat index, so the
 // 4-byte store is always aligned, a group may wrap into the next row) -- the one-byte-per-thread form stored at 7 % of HBM speed.
+typedef uint16_t u16_unaligned __attribute__((aligned(1)));
 __global__ __launch_bounds__(256) void resize_kernel(const ex_frame* __restrict__ frs, int level)
 {
     const ex_frame& f = frs[blockIdx.y];
@@ -172,6 +173,29 @@ __global__ __launch_bounds__(256) void resize_kernel(const ex_frame* __restrict_
     if (g0 >= total) return;
     int dy = (int)(g0 / dw), dx = (int)(g0 - (long long)dy * dw);
     uint32_t out = 0;
+    // The kernel is bound by the NUMBER of global load instructions, so the two horizontal neighbours come in as one unaligned
+    // 16-bit load (sx + 1 is always addressable: the next row, or the 64 bytes of slack behind the image) and, when the four
+    // pixels share a row, their x entries as 8-byte loads and the y entry once: 13 loads instead of 24.
+    if (dx + 3 < dw) {
+        const resize_ytab Y = yt[dy];
+        uint32_t xs[4], xw[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { const uint2 xe = *reinterpret_cast<const uint2*>(xt + dx + u); xs[u] = xe.x; xw[u] = xe.y; }
+        const uint8_t* S0 = src + (size_t)Y.ya * sw; const uint8_t* S1 = src + (size_t)Y.yb * sw;
+        uint32_t p0[4], p1[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            p0[u] = *reinterpret_cast<const u16_unaligned*>(S0 + xs[u]);
+            p1[u] = *reinterpret_cast<const u16_unaligned*>(S1 + xs[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int a0 = (short)(xw[u] & 0xffffu), a1 = (short)(xw[u] >> 16);
+            const int r0 = (int)(p0[u] & 255u) * a0 + (int)(p0[u] >> 8) * a1, r1 = (int)(p1[u] & 255u) * a0 + (int)(p1[u] >> 8) * a1;
+            const uint32_t v = (uint32_t)((((Y.b0 * (r0 >> 4)) >> 16) + ((Y.b1 * (r1 >> 4)) >> 16) + 2) >> 2) & 255u;
+            out |= v << (8 * u);
+        }
+    } else
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
         if (g0 + u < total) {
