@@ -875,6 +875,12 @@ static int extract_frames(dsss_ctx* c, const int* ids, int n, bool keep_taps)
             qf.kin = (kp_in*)(S + L.kin); qf.nk = (int*)(S + L.nk); qf.err = d_errs + s;
         }
         (void)maxNM4;
+        {   // the workgroups of the large levels first: an instance is one workgroup whose time grows with its level's candidates, and
+            // two of them fit a CU, so the launch ends sooner when the small levels fill the gaps at the end
+            std::vector<qt_inst> tmp(h_inst, h_inst + ninst);
+            std::stable_sort(tmp.begin(), tmp.end(), [](const qt_inst& a, const qt_inst& b) { return (long long)a.W * a.H > (long long)b.W * b.H; });
+            std::copy(tmp.begin(), tmp.end(), h_inst);
+        }
         HIPCHK(c, hipMemcpyAsync(T0, P0, tab_bytes - err_bytes, hipMemcpyHostToDevice, st));
         HIPCHK(c, hipMemsetAsync(d_errs, 0, sizeof(int) * nb, st));
         { dsss_scope sc(c, DSSS_K_ROW_REDUCE, 8.0 * w_tot);

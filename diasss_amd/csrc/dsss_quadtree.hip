@@ -17,6 +17,12 @@
 
 struct qnode { int x0, y0, x1, y1; int kbeg, kcnt; int buf; int leaf; };   // 32 B
 
+// The workgroup of one (frame, level) instance: sixteen wavefronts.  The passes stream the level's whole key segment several times
+// and the first passes have a handful of nodes, so the time of the kernel is the time of ONE workgroup on the largest level: four
+// wavefronts took 3 ms per launch.
+#define QT_THREADS 1024
+#define QT_WAVES (QT_THREADS / 64)
+#define QT_RANK_CAP 4096                           // expandable nodes whose (size, id) pairs fit the LDS staging of the rank pass
 __device__ inline int qt_block_scan(int v, int* total, int* s_w)
 {
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -28,15 +34,15 @@ __device__ inline int qt_block_scan(int v, int* total, int* s_w)
     __syncthreads();
     int base = 0, tot = 0;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) { const int t = s_w[k]; if (k < w) base += t; tot += t; }
+    for (int k = 0; k < QT_WAVES; ++k) { const int t = s_w[k]; if (k < w) base += t; tot += t; }
     *total = tot;
     return base + inc - v;
 }
 
 // ExtractorNode::DivideNode (:481-537): stable 4-way partition of a node's key segment from its buffer into the other
 // one; cnt[0..3] = keys of n1..n4 (top-left, top-right, bottom-left, bottom-right).  The key -> coordinate loads are
-// dependent global loads, so a wave classifies four chunks of 64 keys per trip to keep several of them in flight.
-#define QT_ILP 4
+// streamed with QT_ILP chunks of 64 keys in flight per wave: a pass over the level costs (keys / (1024 x QT_ILP)) round trips.
+#define QT_ILP 8
 // A key carries the candidate's coordinates (integers: FAST cell offset + position in the cell) next to its index, so
 // DivideNode streams the key segment and never gathers xs / ys:  key = y << 48 | x << 32 | index.
 typedef unsigned long long qkey;
@@ -102,7 +108,7 @@ __device__ inline void qt_divide_wave(const qnode& P, qkey* __restrict__ keys0, 
     qt_scatter_range(P, src, dst, 0, P.kcnt, mx, my, off);
 }
 // one node, the whole workgroup (the first passes have fewer nodes than waves, and those nodes hold most of the keys):
-// every wave takes a contiguous quarter of the segment; s_cnt[wave][class] carries the counts between the two passes
+// every wave takes a contiguous share of the segment; s_cnt[wave][class] carries the counts between the two passes
 __device__ inline void qt_divide_block(const qnode& P, qkey* __restrict__ keys0, qkey* __restrict__ keys1, int* cnt, int (*s_cnt)[4])
 {
     const qkey* src = P.buf ? keys1 : keys0;
@@ -110,7 +116,7 @@ __device__ inline void qt_divide_block(const qnode& P, qkey* __restrict__ keys0,
     const float mx = (float)(P.x0 + (int)ceilf((float)(P.x1 - P.x0) / 2));
     const float my = (float)(P.y0 + (int)ceilf((float)(P.y1 - P.y0) / 2));
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int q = ((P.kcnt + 3) / 4 + 63) & ~63;
+    const int q = ((P.kcnt + QT_WAVES - 1) / QT_WAVES + 63) & ~63;
     const int lo = min(wv * q, P.kcnt), hi = min(lo + q, P.kcnt);
     int mine[4];
     qt_count_range(P, src, lo, hi, mx, my, mine);
@@ -121,7 +127,7 @@ __device__ inline void qt_divide_block(const qnode& P, qkey* __restrict__ keys0,
     for (int c = 0; c < 4; ++c) {
         int before = 0, tot = 0;
 #pragma unroll
-        for (int w = 0; w < 4; ++w) { const int t = s_cnt[w][c]; if (w < wv) before += t; tot += t; }
+        for (int w = 0; w < QT_WAVES; ++w) { const int t = s_cnt[w][c]; if (w < wv) before += t; tot += t; }
         off[c] = run + before; cnt[c] = tot; run += tot;
     }
     qt_scatter_range(P, src, dst, lo, hi, mx, my, off);
@@ -141,11 +147,12 @@ __device__ inline qnode qt_child(const qnode& P, int c, const int* cnt)
 }
 
 // work layout per instance (ints): pool (qnode x pool_cap) | listA listB parents exp order flags (cap each) | pcnt[4*cap]
-__global__ __launch_bounds__(256) void quadtree_kernel(const qt_inst* __restrict__ tab)
+__global__ __launch_bounds__(QT_THREADS) void quadtree_kernel(const qt_inst* __restrict__ tab)
 {
-    __shared__ int s_w[4];
+    __shared__ int s_w[QT_WAVES];
     __shared__ int s_S, s_pool, s_nexp, s_done, s_phase2, s_t;
-    __shared__ int s_cnt[4][4];
+    __shared__ int s_cnt[QT_WAVES][4];
+    __shared__ int2 s_rank[QT_RANK_CAP];
     const qt_inst I = tab[blockIdx.x];
     const int base = I.offs[I.cell_begin];
     const int n = min(I.offs[I.cell_end], I.cand_cap) - base;         // never index past the candidate arrays (the overflow itself is flagged by scan_counts_kernel)
@@ -164,7 +171,15 @@ __global__ __launch_bounds__(256) void quadtree_kernel(const qt_inst* __restrict
     if (nIni < 1) nIni = 1;
     if (nIni > 32) nIni = 32;
     const float hX = (float)I.W / nIni;
-    if (nIni == 1) { for (int i = threadIdx.x; i < n; i += 256) keys0[i] = qt_make_key(i, xs[i], ys[i]); }
+    if (nIni == 1) {
+        for (int i0 = threadIdx.x; i0 < n; i0 += 8 * QT_THREADS) {      // eight coordinate pairs in flight per thread
+            float x8[8], y8[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { const int i = i0 + u * QT_THREADS; x8[u] = i < n ? xs[i] : 0.f; y8[u] = i < n ? ys[i] : 0.f; }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { const int i = i0 + u * QT_THREADS; if (i < n) keys0[i] = qt_make_key(i, x8[u], y8[u]); }
+        }
+    }
     else if (wv == 0) {                              // stable partition of 0..n-1 by root index, one wave
         int off = 0;
         for (int r = 0; r < nIni; ++r) {
@@ -202,7 +217,7 @@ __global__ __launch_bounds__(256) void quadtree_kernel(const qt_inst* __restrict
         const int S = s_S;
         // non-leaf nodes in list order -> parents[], leaves keep their relative order
         int np = 0, nl = 0;
-        for (int b = 0; b < S; b += 256) {
+        for (int b = 0; b < S; b += QT_THREADS) {
             const int i = b + threadIdx.x;
             const int id = i < S ? L[i] : -1;
             const int isp = (id >= 0 && !pool[id].leaf) ? 1 : 0, isl = (id >= 0 && pool[id].leaf) ? 1 : 0;
@@ -215,14 +230,14 @@ __global__ __launch_bounds__(256) void quadtree_kernel(const qt_inst* __restrict
         __syncthreads();
         if (np == 0) break;                          // every node holds one point: size == prevSize
         if (s_pool + 4 * np > pool_cap) { if (threadIdx.x == 0) *I.err = 1; break; }
-        if (np < 4) {
+        if (np < QT_WAVES) {
             for (int r = 0; r < np; ++r) {
                 int cnt[4];
                 qt_divide_block(pool[parents[r]], keys0, keys1, cnt, s_cnt);
                 if (threadIdx.x == 0) { pcnt[4 * r] = cnt[0]; pcnt[4 * r + 1] = cnt[1]; pcnt[4 * r + 2] = cnt[2]; pcnt[4 * r + 3] = cnt[3]; }
             }
         } else
-            for (int r = wv; r < np; r += 4) {
+            for (int r = wv; r < np; r += QT_WAVES) {
                 int cnt[4];
                 qt_divide_wave(pool[parents[r]], keys0, keys1, cnt);
                 if (lane == 0) { pcnt[4 * r] = cnt[0]; pcnt[4 * r + 1] = cnt[1]; pcnt[4 * r + 2] = cnt[2]; pcnt[4 * r + 3] = cnt[3]; }
@@ -231,7 +246,7 @@ __global__ __launch_bounds__(256) void quadtree_kernel(const qt_inst* __restrict
         // children in creation order: parents in list order, n1..n4, empty ones skipped
         int Cn = 0, nexp = 0;
         const int pool0 = s_pool;
-        for (int b = 0; b < np; b += 256) {
+        for (int b = 0; b < np; b += QT_THREADS) {
             const int r = b + threadIdx.x;
             int ne = 0, nx = 0, cnt[4] = { 0, 0, 0, 0 };
             if (r < np) for (int c = 0; c < 4; ++c) { cnt[c] = pcnt[4 * r + c]; ne += cnt[c] > 0; nx += cnt[c] > 1; }
@@ -251,8 +266,8 @@ __global__ __launch_bounds__(256) void quadtree_kernel(const qt_inst* __restrict
         __syncthreads();
         const int Snew = Cn + nl;
         if (Snew > cap) { if (threadIdx.x == 0) *I.err = 2; break; }
-        for (int i = threadIdx.x; i < Cn; i += 256) Ln[Cn - 1 - i] = pool0 + i;      // push_front order
-        for (int i = threadIdx.x; i < nl; i += 256) Ln[Cn + i] = flags[i];
+        for (int i = threadIdx.x; i < Cn; i += QT_THREADS) Ln[Cn - 1 - i] = pool0 + i;      // push_front order
+        for (int i = threadIdx.x; i < nl; i += QT_THREADS) Ln[Cn + i] = flags[i];
         __syncthreads();
         if (threadIdx.x == 0) {
             s_pool = pool0 + Cn; s_nexp = nexp;
@@ -270,15 +285,26 @@ __global__ __launch_bounds__(256) void quadtree_kernel(const qt_inst* __restrict
         const int S = s_S, m = s_nexp, pool0 = s_pool;
         if (m == 0) break;
         if (pool0 + 4 * m > pool_cap) { if (threadIdx.x == 0) *I.err = 1; break; }
-        // processing order: descending (size, creation order)
-        for (int e = threadIdx.x; e < m; e += 256) {
-            const int id = expv[e], sz = pool[id].kcnt;
-            int rank = 0;
-            for (int f = 0; f < m; ++f) { const int id2 = expv[f], s2 = pool[id2].kcnt; rank += (s2 > sz) || (s2 == sz && id2 > id); }
-            order[rank] = id;
-        }
+        // processing order: descending (size, creation order).  The m x m comparison runs on (size, id) pairs staged in LDS: straight
+        // from the node pool every comparison was two dependent global loads (0.6 ms per round at m = 600)
+        if (m <= QT_RANK_CAP) {
+            for (int e = threadIdx.x; e < m; e += QT_THREADS) { const int id = expv[e]; s_rank[e] = make_int2(pool[id].kcnt, id); }
+            __syncthreads();
+            for (int e = threadIdx.x; e < m; e += QT_THREADS) {
+                const int2 me = s_rank[e];
+                int rank = 0;
+                for (int f = 0; f < m; ++f) { const int2 o = s_rank[f]; rank += (o.x > me.x) || (o.x == me.x && o.y > me.y); }
+                order[rank] = me.y;
+            }
+        } else
+            for (int e = threadIdx.x; e < m; e += QT_THREADS) {
+                const int id = expv[e], sz = pool[id].kcnt;
+                int rank = 0;
+                for (int f = 0; f < m; ++f) { const int id2 = expv[f], s2 = pool[id2].kcnt; rank += (s2 > sz) || (s2 == sz && id2 > id); }
+                order[rank] = id;
+            }
         __syncthreads();
-        for (int r = wv; r < m; r += 4) {            // divide all of them; only the first t+1 take effect
+        for (int r = wv; r < m; r += QT_WAVES) {     // divide all of them; only the first t+1 take effect
             int cnt[4];
             qt_divide_wave(pool[order[r]], keys0, keys1, cnt);
             if (lane == 0) { pcnt[4 * r] = cnt[0]; pcnt[4 * r + 1] = cnt[1]; pcnt[4 * r + 2] = cnt[2]; pcnt[4 * r + 3] = cnt[3]; }
@@ -287,7 +313,7 @@ __global__ __launch_bounds__(256) void quadtree_kernel(const qt_inst* __restrict
         __syncthreads();
         // running node count; the reference breaks once it reaches the quota (:730-731)
         int run = S;
-        for (int b = 0; b < m; b += 256) {
+        for (int b = 0; b < m; b += QT_THREADS) {
             const int r = b + threadIdx.x;
             int d = 0;
             if (r < m) { for (int c = 0; c < 4; ++c) d += pcnt[4 * r + c] > 0; d -= 1; }
@@ -300,7 +326,7 @@ __global__ __launch_bounds__(256) void quadtree_kernel(const qt_inst* __restrict
         __syncthreads();
         const int t = s_t;                           // parents order[0..t] are divided
         int Cn = 0, nexp = 0;
-        for (int b = 0; b <= t; b += 256) {
+        for (int b = 0; b <= t; b += QT_THREADS) {
             const int r = b + threadIdx.x;
             int ne = 0, nx = 0, cnt[4] = { 0, 0, 0, 0 };
             if (r <= t) for (int c = 0; c < 4; ++c) { cnt[c] = pcnt[4 * r + c]; ne += cnt[c] > 0; nx += cnt[c] > 1; }
@@ -321,7 +347,7 @@ __global__ __launch_bounds__(256) void quadtree_kernel(const qt_inst* __restrict
         __syncthreads();
         // new list = reverse(children) ++ old list without the divided parents
         int kept = 0;
-        for (int b = 0; b < S; b += 256) {
+        for (int b = 0; b < S; b += QT_THREADS) {
             const int i = b + threadIdx.x;
             const int id = i < S ? L[i] : -1;
             const int keep = (id >= 0 && pool[id].kcnt >= 0) ? 1 : 0;
@@ -332,9 +358,9 @@ __global__ __launch_bounds__(256) void quadtree_kernel(const qt_inst* __restrict
         }
         const int Snew = Cn + kept;
         if (Snew > cap) { if (threadIdx.x == 0) *I.err = 2; break; }
-        for (int i = threadIdx.x; i < Cn; i += 256) Ln[Cn - 1 - i] = pool0 + i;
+        for (int i = threadIdx.x; i < Cn; i += QT_THREADS) Ln[Cn - 1 - i] = pool0 + i;
         __syncthreads();
-        for (int i = threadIdx.x; i < nexp; i += 256) expv[i] = parents[i];
+        for (int i = threadIdx.x; i < nexp; i += QT_THREADS) expv[i] = parents[i];
         if (threadIdx.x == 0) {
             s_pool = pool0 + Cn; s_nexp = nexp; s_S = Snew;
             if (Snew >= N || Snew == S) s_done = 1;
@@ -346,12 +372,17 @@ __global__ __launch_bounds__(256) void quadtree_kernel(const qt_inst* __restrict
 
     // ---- retain the best point of each node, list order (:741-760): first maximum response in key order
     const int S = s_S;
-    for (int i = threadIdx.x; i < S; i += 256) {
+    for (int i = wv; i < S; i += QT_WAVES) {           // one wavefront per node: keys read together, first maximum by (response, position)
         const qnode q = pool[L[i]];
         const qkey* kk = (q.buf ? keys1 : keys0) + q.kbeg;
-        int best = qt_key_idx(kk[0]); float r = rs[best];
-        for (int k = 1; k < q.kcnt; ++k) { const int c = qt_key_idx(kk[k]); const float v = rs[c]; if (v > r) { best = c; r = v; } }
-        if (i < I.out_cap) out[i] = base + best;
+        float r = -1.0f; int pos = 0x7fffffff, best = 0;
+        for (int k = lane; k < q.kcnt; k += 64) { const int c = qt_key_idx(kk[k]); const float v = rs[c]; if (v > r) { r = v; pos = k; best = c; } }
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) {
+            const float r2 = __shfl_xor(r, o, 64); const int p2 = __shfl_xor(pos, o, 64), b2 = __shfl_xor(best, o, 64);
+            if (r2 > r || (r2 == r && p2 < pos)) { r = r2; pos = p2; best = b2; }
+        }
+        if (lane == 0 && i < I.out_cap) out[i] = base + best;
     }
     if (threadIdx.x == 0) { *out_n = S < I.out_cap ? S : I.out_cap; if (S > I.out_cap) *I.err = 3; }
 }
@@ -378,6 +409,6 @@ __global__ __launch_bounds__(256) void quadtree_collect_kernel(const qt_frame* _
 
 void dsss_launch_quadtree(hipStream_t st, const qt_inst* d_inst, int ninst, const qt_frame* d_frames, int nframes)
 {
-    if (ninst > 0) hipLaunchKernelGGL(quadtree_kernel, dim3(ninst), dim3(256), 0, st, d_inst);
+    if (ninst > 0) hipLaunchKernelGGL(quadtree_kernel, dim3(ninst), dim3(QT_THREADS), 0, st, d_inst);
     if (nframes > 0) hipLaunchKernelGGL(quadtree_collect_kernel, dim3(nframes), dim3(256), 0, st, d_frames);
 }
