@@ -383,20 +383,25 @@ __global__ __launch_bounds__(256) void scan_counts_kernel(const ex_frame* __rest
 }
 
 // candidates in reference order with the cell offset applied (ORBextractor.cpp:820-825)
-__global__ __launch_bounds__(64) void gather_cand_kernel(const ex_frame* __restrict__ frs)
+#define GC_CELLS 32                                 // cells per workgroup (four wavefronts, eight cells each): one tiny workgroup per cell was launch-rate bound
+__global__ __launch_bounds__(256) void gather_cand_kernel(const ex_frame* __restrict__ frs)
 {
     const ex_frame& f = frs[blockIdx.y];
-    if ((int)blockIdx.x >= f.ncells) return;
     const uint32_t* __restrict__ cand = f.cand; const int* __restrict__ counts = f.counts; const int* __restrict__ offs = f.offs;
     float* __restrict__ xs = f.xs; float* __restrict__ ys = f.ys; float* __restrict__ rs = f.rs; const int cap = f.cand_cap, cell_cap = f.cell_cap;
-    const fast_cell c = f.cells[blockIdx.x];
-    const int n = counts[blockIdx.x], o = offs[blockIdx.x];
-    for (int q = threadIdx.x; q < n; q += 64) {
-        if (o + q >= cap) return;
-        const uint32_t v = cand[(size_t)blockIdx.x * cell_cap + q];
-        xs[o + q] = (float)(v & 255u) + (float)c.offx;
-        ys[o + q] = (float)((v >> 8) & 255u) + (float)c.offy;
-        rs[o + q] = (float)(v >> 16);
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    for (int k = 0; k < GC_CELLS / 4; ++k) {
+        const int cell = blockIdx.x * GC_CELLS + k * 4 + wv;
+        if (cell >= f.ncells) return;
+        const fast_cell c = f.cells[cell];
+        const int n = counts[cell], o = offs[cell];
+        for (int q = lane; q < n; q += 64) {
+            if (o + q >= cap) break;
+            const uint32_t v = cand[(size_t)cell * cell_cap + q];
+            xs[o + q] = (float)(v & 255u) + (float)c.offx;
+            ys[o + q] = (float)((v >> 8) & 255u) + (float)c.offy;
+            rs[o + q] = (float)(v >> 16);
+        }
     }
 }
 
@@ -899,7 +904,7 @@ static int extract_frames(dsss_ctx* c, const int* ids, int n, bool keep_taps)
           else hipLaunchKernelGGL(fast_cells_kernel<CELL_STRIDE>, dim3((max_cells + 3) / 4, nb), dim3(256), 4 * fwave, st, d_exf, c->op.ini_th, c->op.min_th, fwave); }
         { dsss_scope sc(c, DSSS_K_FAST_COMPACT, 0, 2);
           hipLaunchKernelGGL(scan_counts_kernel, dim3(nb), dim3(256), 0, st, d_exf);
-          hipLaunchKernelGGL(gather_cand_kernel, dim3(max_cells, nb), dim3(64), 0, st, d_exf); }
+          hipLaunchKernelGGL(gather_cand_kernel, dim3((max_cells + GC_CELLS - 1) / GC_CELLS, nb), dim3(256), 0, st, d_exf); }
         { dsss_scope sc(c, DSSS_K_QUADTREE);
           dsss_launch_quadtree(st, d_inst, ninst, d_fr, nb); }
         { dsss_scope sc(c, DSSS_K_DESC, (double)nb * c->op.nfeatures * (49.0 * 49.0 + 56.0));
