@@ -1355,24 +1355,36 @@ __global__ __launch_bounds__(256) void pg_front_trsm2_kernel(const int* __restri
     }
     __syncthreads();
     if (rowbase >= nrows) return;                  // wavefront-uniform
+    // The operands of a 4-column step do not depend on the step before: they are read from LDS one step ahead, so that the matrix
+    // core never waits for an LDS round trip between two dependent products (it did, 130 cycles per product).
+    double lop_n, a_n[6];
+    auto fetch = [&](int t, int b) {
+        lop_n = c < 4 ? sT[(4 * t + b) * 16 + c * 4 + q] : 0.0;     // A operand of LP = Linv x P^T: lane (i, m) = Linv[i][m], i < 4
+#pragma unroll
+        for (int T2 = 0; T2 < 6; ++T2) {
+            // A operand of the updates: -L11[16 T2 + i][16 t + 4 b + k] on lane (i = c, k = q), rows beyond the pivot block only
+            const int ri = 16 * T2 + c, ck = 16 * t + 4 * b + q;
+            a_n[T2] = (T2 > t || (T2 == t && c > 4 * b + 3)) ? -sL[ri * PG_T2_LD + ck] : 0.0;
+        }
+    };
+    fetch(0, 0);
 #pragma unroll
     for (int t = 0; t < 6; ++t) {
         if (16 * t >= n) break;                     // uniform: nothing beyond the panel's columns
 #pragma unroll
         for (int b = 0; b < 4; ++b) {
-            // LP = P Linv^T through the matrix core (see pg_front_diag2_kernel): A operand lane (i, m) = Linv[i][m], i < 4
-            const double lop = c < 4 ? sT[(4 * t + b) * 16 + c * 4 + q] : 0.0;
+            const double lop = lop_n;
+            double a[6];
+#pragma unroll
+            for (int T2 = 0; T2 < 6; ++T2) a[T2] = a_n[T2];
+            if (b < 3) fetch(t, b + 1); else if (t < 5) fetch(t + 1, 0);
+            // LP = P Linv^T through the matrix core (see pg_front_diag2_kernel)
             const pg_d4 zero4 = { 0.0, 0.0, 0.0, 0.0 };
             const pg_d4 r4 = __builtin_amdgcn_mfma_f64_16x16x4f64(lop, S[t][b], zero4, 0, 0, 0);
             const double LP = r4[0];
             S[t][b] = LP;
 #pragma unroll
-            for (int T2 = t; T2 < 6; ++T2) {
-                // A operand: L11[16 T2 + i][16 t + 4 b + k] on lane (i = c, k = q), rows beyond the pivot block only (zero above the diagonal in sL)
-                const int ri = 16 * T2 + c, ck = 16 * t + 4 * b + q;
-                const double a = (T2 > t || c > 4 * b + 3) ? -sL[ri * PG_T2_LD + ck] : 0.0;
-                S[T2] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, LP, S[T2], 0, 0, 0);
-            }
+            for (int T2 = t; T2 < 6; ++T2) S[T2] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[T2], LP, S[T2], 0, 0, 0);
         }
     }
     double dot = 0;
