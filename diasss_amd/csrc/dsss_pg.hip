@@ -15,6 +15,7 @@
 //      extend-add of the children's update matrices, panel Cholesky / row solve / trailing update on the f64 matrix cores;
 //   4. back-substitution through the segments.
 #include "dsss_internal.h"
+#include <utility>
 #include "dsss_pose.h"
 #include "dsss_pg_sym.h"
 #include <algorithm>
@@ -1295,6 +1296,282 @@ __device__ __forceinline__ void pg_diag3_body(pg_d3_lds& sh, double* __restrict_
             }
     }
 }
+// workgroup barrier that orders LDS traffic only (__syncthreads() also waits for the global stores in flight)
+#define PG_LDS_BARRIER() do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); } while (0)
+// ---- The panel factorisation once more, as a PIPELINE (default).  In pg_diag3_body every 4-column block costs two workgroup barriers
+// and two LDS round trips on the one chain that matters: pivot block -> Cholesky + inverse -> LP of the pivot tile -> update of the
+// pivot tile -> next pivot block (1 950 cycles per block, 870 of them the Cholesky).  Here the owner of the pivot tile runs that
+// chain through its own registers (the tile register that comes out of the matrix core IS both operands of the pivot tile's update)
+// and the other work trails behind it, one barrier per block:
+//     region r (between barriers r - 1 and r)
+//         every wavefront   U(r - 2): updates of block r - 2 on its tiles, operands from the LDS ring (3 buffers)
+//                           L(r - 1): LP of block r - 1 for its tile columns, Linv(r - 1) from LDS (2 buffers) -> ring
+//         pivot wavefront   C(r): Linv(r), LP of the pivot tile, update of the pivot tile -- registers only; Linv and LP -> LDS
+// When the pivot tile changes, its new owner catches up on the one update it trails by (again from its own registers).
+// U and L of a region do not feed C, so the compiler is free to fill the Cholesky's dependency bubbles with their matrix-core
+// work.  The tile count NT = ceil(n / 16) is a template parameter: straight-line code, no runtime guards inside the pipeline.
+// Every tile receives the same updates in the same order as in pg_diag3_body: the result is bit-identical.
+struct pg_d4_lds { double lp[3][7][64]; double li[2][16]; int bad; };
+// The trailing work of region R on wavefront W, as a compile-time list of matrix-core operations: kind 1 = update U(R - 2) of tile
+// (T2, I), kind 2 = LP of block R - 1 for tile column I (with the catch-up update when I becomes the pivot tile), 0 = end of list.
+struct pg_lag_desc { int kind, I, T2; };
+constexpr pg_lag_desc pg_lag_get(int W, int NT, int R, int want)
+{
+    const int I0 = W, I1 = W + 4, K = 4 * NT;
+    const bool act0 = I0 < NT, act1 = I1 < 7 && (I1 < NT || I1 == 6);
+    int idx = 0;
+    if (R >= 2) {
+        const int k = R - 2, t = k / 4, b = k % 4;
+        const bool piv = (t & 3) == W;                                  // this wavefront ran the critical part of block k
+        for (int c = 0; c < 2; ++c) {
+            const int I = c ? I1 : I0;
+            if (!(c ? act1 : act0) || I < t) continue;
+            for (int T2 = t; T2 < 6; ++T2) {
+                if (T2 > I || T2 >= NT) continue;
+                if (piv && T2 == t && I == t) continue;                 // done in C(k)
+                if (b == 3 && T2 == t + 1 && I == t + 1) continue;      // done in the catch-up of region k + 1
+                if (idx == want) return { 1, I, T2 };
+                ++idx;
+            }
+        }
+    }
+    if (R >= 1 && R <= K) {
+        const int k = R - 1, t = k / 4;
+        const bool piv = (t & 3) == W;
+        for (int c = 0; c < 2; ++c) {
+            const int I = c ? I1 : I0;
+            if (!(c ? act1 : act0) || I < t || (piv && I == t)) continue;
+            if (idx == want) return { 2, I, 0 };
+            ++idx;
+        }
+    }
+    return { 0, 0, 0 };
+}
+template <int W, int NT, int R, int IDX, typename TS0, typename TS1>
+__device__ __forceinline__ void pg_d4_lag_one(pg_d4_lds& sh, TS0& S0, TS1& S1, const double* aop, double B0, double B1, double lopL, int l)
+{
+    constexpr pg_lag_desc d = pg_lag_get(W, NT, R, IDX);
+    constexpr int I0 = W;
+    if constexpr (d.kind == 1) {
+        if constexpr (d.I == I0) S0[d.T2] = __builtin_amdgcn_mfma_f64_16x16x4f64(aop[d.T2], B0, S0[d.T2], 0, 0, 0);
+        else S1[d.T2] = __builtin_amdgcn_mfma_f64_16x16x4f64(aop[d.T2], B1, S1[d.T2], 0, 0, 0);
+    } else if constexpr (d.kind == 2) {
+        constexpr int k = R - 1, t = k / 4, b = k % 4, rb = k % 3;
+        const pg_d4 zero4 = { 0.0, 0.0, 0.0, 0.0 };
+        if constexpr (d.I == I0) {
+            const pg_d4 r4 = __builtin_amdgcn_mfma_f64_16x16x4f64(lopL, S0[t][b], zero4, 0, 0, 0);
+            const double v = r4[0];
+            S0[t][b] = v;
+            sh.lp[rb][d.I][l] = v;
+            if constexpr (b == 3 && d.I == t + 1 && d.I < NT) S0[d.I] = __builtin_amdgcn_mfma_f64_16x16x4f64(-v, v, S0[d.I], 0, 0, 0);      // next pivot tile: its update of block k now
+        } else {
+            const pg_d4 r4 = __builtin_amdgcn_mfma_f64_16x16x4f64(lopL, S1[t][b], zero4, 0, 0, 0);
+            const double v = r4[0];
+            S1[t][b] = v;
+            sh.lp[rb][d.I][l] = v;
+            if constexpr (b == 3 && d.I == t + 1 && d.I < NT) S1[d.I] = __builtin_amdgcn_mfma_f64_16x16x4f64(-v, v, S1[d.I], 0, 0, 0);
+        }
+    }
+}
+template <int W, int NT, int R, int LO, int HI, typename TS0, typename TS1>
+__device__ __forceinline__ void pg_d4_lag(pg_d4_lds& sh, TS0& S0, TS1& S1, const double* aop, double B0, double B1, double lopL, int l)
+{
+    if constexpr (LO < HI) {
+        if constexpr (pg_lag_get(W, NT, R, LO).kind != 0) {
+            pg_d4_lag_one<W, NT, R, LO>(sh, S0, S1, aop, B0, B1, lopL, l);
+            pg_d4_lag<W, NT, R, LO + 1, HI>(sh, S0, S1, aop, B0, B1, lopL, l);
+        }
+    }
+}
+// one region (see above); `bad` accumulates the pivot failures
+template <int W, int NT, int R, typename TS0, typename TS1>
+__device__ __forceinline__ void pg_d4_region(pg_d4_lds& sh, TS0& S0, TS1& S1, double* __restrict__ tout, int l, int& bad)
+{
+    constexpr int I0 = W, I1 = W + 4, K = 4 * NT;
+    constexpr bool act0 = I0 < NT, act1 = I1 < 7 && (I1 < NT || I1 == 6);
+    const int j = l & 15, q = l >> 4;
+    // operands of the trailing work, read from LDS at the top of the region
+    double aop[6] = { 0, 0, 0, 0, 0, 0 }, lopL = 0.0, B0 = 0.0, B1 = 0.0;
+    if constexpr (R >= 2) {
+        constexpr int k = R - 2, t = k / 4, b = k % 4, rb = k % 3;
+#pragma unroll
+        for (int T2 = 0; T2 < 6; ++T2) aop[T2] = (T2 >= t && T2 < NT) ? -sh.lp[rb][T2][l] : 0.0;
+        if (j < 4 * b + 4) aop[t] = 0.0;                                // pivot tile row: only the rows below the pivot block are updated
+        if constexpr (act0 && I0 >= t) B0 = sh.lp[rb][I0][l];
+        if constexpr (act1 && I1 >= t) B1 = sh.lp[rb][I1][l];
+    }
+    if constexpr (R >= 1 && R <= K) lopL = j < 4 ? sh.li[(R - 1) & 1][j * 4 + q] : 0.0;      // A operand of Linv x P^T: lane (i, m) = Linv[i][m]
+    constexpr bool piv_now = R < K && ((R / 4) & 3) == W;
+    constexpr bool steady = piv_now && (R % 4) != 0;                    // same pivot tile as in the region before: C(R) does not wait for the trailing work
+    if constexpr (!steady) pg_d4_lag<W, NT, R, 0, 64>(sh, S0, S1, aop, B0, B1, lopL, l);
+    // ---- C(R): the pivot chain, registers only.  In a steady region the trailing products sit BETWEEN its dependent vector
+    // instructions (a wavefront issues in order: a product placed there costs an issue slot, its 64 cycles run beside the chain)
+    if constexpr (piv_now) {
+        constexpr int t = R / 4, b = R % 4, rb = R % 3;
+        double m[10], li[10];
+        double dv;
+        if constexpr (t < 4) dv = S0[t][b]; else dv = S1[t][b];
+        {
+            int e = 0;
+#pragma unroll
+            for (int rr2 = 0; rr2 < 4; ++rr2)
+#pragma unroll
+                for (int c2 = 0; c2 <= rr2; ++c2) m[e++] = pg_readlane(dv, (4 * b + rr2) + 16 * c2);
+        }
+// slot i: the i-th trailing product, tied to the chain value `cv` just computed by an empty asm (the operands "pass through" it), so
+// that neither the optimiser nor the scheduler can lift the product above this point of the chain
+#define PG_SLOT(i, cv) do { if constexpr (steady) { asm volatile("" : "+v"(B0), "+v"(B1), "+v"(lopL) : "v"(cv)); pg_d4_lag<W, NT, R, (i), (i) + 1>(sh, S0, S1, aop, B0, B1, lopL, l); } } while (0)
+#define PG_RSQ(x, rv, s0) do { rv = __builtin_amdgcn_rsq(x); PG_SLOT(s0, rv); rv = rv * (1.5 - 0.5 * x * rv * rv); PG_SLOT((s0) + 1, rv); rv = rv * (1.5 - 0.5 * x * rv * rv); } while (0)
+        {   // pg_chol4_inv with the slots
+            double d0 = m[0]; if (!(d0 > 0) || !isfinite(d0)) { bad = 1; d0 = 1.0; }
+            double r0, r1, r2, r3;
+            PG_RSQ(d0, r0, 0);
+            const double l10 = m[1] * r0, l20 = m[3] * r0, l30 = m[6] * r0;
+            PG_SLOT(2, l30);
+            double d1 = m[2] - l10 * l10; if (!(d1 > 0) || !isfinite(d1)) { bad = 1; d1 = 1.0; }
+            PG_RSQ(d1, r1, 3);
+            const double l21 = (m[4] - l20 * l10) * r1, l31 = (m[7] - l30 * l10) * r1;
+            PG_SLOT(5, l31);
+            double d2 = m[5] - l20 * l20 - l21 * l21; if (!(d2 > 0) || !isfinite(d2)) { bad = 1; d2 = 1.0; }
+            PG_RSQ(d2, r2, 6);
+            const double l32 = (m[8] - l30 * l20 - l31 * l21) * r2;
+            PG_SLOT(8, l32);
+            double d3 = m[9] - l30 * l30 - l31 * l31 - l32 * l32; if (!(d3 > 0) || !isfinite(d3)) { bad = 1; d3 = 1.0; }
+            PG_RSQ(d3, r3, 9);
+            li[0] = r0; li[2] = r1; li[5] = r2; li[9] = r3;
+            li[1] = -(l10 * r0) * r1;
+            PG_SLOT(11, li[1]);
+            li[3] = -(l20 * r0 + l21 * li[1]) * r2; li[4] = -(l21 * r1) * r2;
+            li[6] = -(l30 * r0 + l31 * li[1] + l32 * li[3]) * r3; li[7] = -(l31 * r1 + l32 * li[4]) * r3; li[8] = -(l32 * r2) * r3;
+        }
+        if constexpr (steady) pg_d4_lag<W, NT, R, 12, 64>(sh, S0, S1, aop, B0, B1, lopL, l);
+#undef PG_RSQ
+#undef PG_SLOT
+        if (l == 0) {                        // Linv row-major 4 x 4 into LDS (the zeros above its diagonal are there): the other wavefronts
+            int e = 0;                       // read it in the next region, this one reads its own operand back right away
+#pragma unroll
+            for (int rr2 = 0; rr2 < 4; ++rr2)
+#pragma unroll
+                for (int c2 = 0; c2 <= rr2; ++c2) sh.li[R & 1][rr2 * 4 + c2] = li[e++];
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");              // same wavefront: LDS operations complete in order
+        const double lop = j < 4 ? sh.li[R & 1][j * 4 + q] : 0.0;      // A operand of Linv x P^T: lane (i, m) = Linv[i][m]
+        const int rj = j - 4 * b;
+        const pg_d4 zero4 = { 0.0, 0.0, 0.0, 0.0 };
+        if constexpr (t < 4) {
+            const pg_d4 r4 = __builtin_amdgcn_mfma_f64_16x16x4f64(lop, S0[t][b], zero4, 0, 0, 0);
+            double v = r4[0];
+            if (rj < 0 || (rj < 4 && q > rj)) v = 0.0;               // rows above the block; zeros of L44
+            S0[t][b] = v;
+            sh.lp[rb][t][l] = v;
+            const double a = j < 4 * b + 4 ? 0.0 : -v;               // only the rows below the pivot block are updated
+            S0[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, v, S0[t], 0, 0, 0);
+        } else {
+            const pg_d4 r4 = __builtin_amdgcn_mfma_f64_16x16x4f64(lop, S1[t][b], zero4, 0, 0, 0);
+            double v = r4[0];
+            if (rj < 0 || (rj < 4 && q > rj)) v = 0.0;
+            S1[t][b] = v;
+            sh.lp[rb][t][l] = v;
+            const double a = j < 4 * b + 4 ? 0.0 : -v;
+            S1[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, v, S1[t], 0, 0, 0);
+        }
+    }
+    if constexpr (piv_now) {                 // Linv for the kernels below the panel, off the chain
+        if (l < 16) tout[(4 * (R / 4) + (R % 4)) * 16 + l] = sh.li[R & 1][l];
+    }
+    if constexpr (R < K + 1) PG_LDS_BARRIER();
+}
+template <int W, int NT, typename TS0, typename TS1, int... Rs>
+__device__ __forceinline__ void pg_d4_regions(pg_d4_lds& sh, TS0& S0, TS1& S1, double* __restrict__ tout, int l, int& bad, std::integer_sequence<int, Rs...>)
+{
+    (pg_d4_region<W, NT, Rs>(sh, S0, S1, tout, l, bad), ...);
+}
+template <int W, int NT>
+__device__ __forceinline__ void pg_diag4_body(pg_d4_lds& sh, double* __restrict__ A, double* __restrict__ rr, double* __restrict__ tout, int n, int ld, int l)
+{
+    constexpr int I0 = W, I1 = W + 4;
+    constexpr bool has1 = I1 < 7;
+    constexpr int K = 4 * NT;
+    const int j = l & 15, q = l >> 4;
+    pg_d4 S0[I0 + 1], S1[6];                       // tiles (T, I0), T <= I0 and (T, I1), T <= min(I1, 5)
+#pragma unroll
+    for (int T = 0; T <= I0; ++T)
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            const int row = 16 * I0 + j, col = 16 * T + q + 4 * v;
+            double val;
+            if (row < n && col < n) val = col <= row ? A[(size_t)row * ld + col] : A[(size_t)col * ld + row];
+            else val = row == col ? 1.0 : 0.0;
+            S0[T][v] = val;
+        }
+    if (has1) {
+#pragma unroll
+        for (int T = 0; T <= (I1 < 6 ? I1 : 5); ++T)
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                const int row = 16 * I1 + j, col = 16 * T + q + 4 * v;
+                double val;
+                if (I1 == 6) val = (j == 0 && col < n) ? rr[col] : 0.0;
+                else if (row < n && col < n) val = col <= row ? A[(size_t)row * ld + col] : A[(size_t)col * ld + row];
+                else val = row == col ? 1.0 : 0.0;
+                S1[T][v] = val;
+            }
+    }
+    int bad = 0;
+    pg_d4_regions<W, NT>(sh, S0, S1, tout, l, bad, std::make_integer_sequence<int, K + 2>{});
+    if (bad) sh.bad = 1;
+#pragma unroll
+    for (int T = 0; T <= I0; ++T)
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            const int row = 16 * I0 + j, col = 16 * T + q + 4 * v;
+            if (row < n && col <= row) A[(size_t)row * ld + col] = S0[T][v];
+        }
+    if (has1) {
+#pragma unroll
+        for (int T = 0; T <= (I1 < 6 ? I1 : 5); ++T)
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                const int row = 16 * I1 + j, col = 16 * T + q + 4 * v;
+                if (I1 == 6) { if (j == 0 && col < n) rr[col] = S1[T][v]; }
+                else if (row < n && col <= row) A[(size_t)row * ld + col] = S1[T][v];
+            }
+    }
+}
+template <int NT>
+__device__ __forceinline__ void pg_diag4_waves(pg_d4_lds& sh, double* __restrict__ A, double* __restrict__ rr, double* __restrict__ tout, int n, int ld, int w, int l)
+{
+    if (w == 0) pg_diag4_body<0, NT>(sh, A, rr, tout, n, ld, l);
+    else if (w == 1) pg_diag4_body<1, NT>(sh, A, rr, tout, n, ld, l);
+    else if (w == 2) pg_diag4_body<2, NT>(sh, A, rr, tout, n, ld, l);
+    else pg_diag4_body<3, NT>(sh, A, rr, tout, n, ld, l);
+}
+__global__ __launch_bounds__(256) void pg_front_diag4_kernel(const int* __restrict__ it_front, const int* __restrict__ it_step, const pg_front* __restrict__ FD,
+                                                             double* __restrict__ F, double* __restrict__ R, int* __restrict__ fail, double* __restrict__ Tinv)
+{
+    __shared__ pg_d4_lds sh;
+    const pg_front fd = FD[it_front[blockIdx.x]];
+    const int step = it_step[blockIdx.x], col0 = 96 * step;
+    const int n = min(96, fd.s6 - col0), p = fd.pan0 + step, ld = fd.ld;
+    double* __restrict__ A = F + fd.off + (size_t)col0 * ld + col0;
+    double* __restrict__ rr = R + fd.roff + col0;
+    double* __restrict__ tout = Tinv + (size_t)p * PG_NB4 * 16;
+    const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+    if (threadIdx.x == 0) sh.bad = 0;
+    if (threadIdx.x < 32) sh.li[threadIdx.x >> 4][threadIdx.x & 15] = 0.0;     // the zeros above the diagonal of Linv stay
+    __syncthreads();
+    switch ((n + 15) / 16) {                       // uniform over the workgroup
+    case 1: pg_diag4_waves<1>(sh, A, rr, tout, n, ld, w, l); break;
+    case 2: pg_diag4_waves<2>(sh, A, rr, tout, n, ld, w, l); break;
+    case 3: pg_diag4_waves<3>(sh, A, rr, tout, n, ld, w, l); break;
+    case 4: pg_diag4_waves<4>(sh, A, rr, tout, n, ld, w, l); break;
+    case 5: pg_diag4_waves<5>(sh, A, rr, tout, n, ld, w, l); break;
+    default: pg_diag4_waves<6>(sh, A, rr, tout, n, ld, w, l); break;
+    }
+    __syncthreads();
+    if (sh.bad && threadIdx.x == 0) *fail = 1;
+}
+
 __global__ __launch_bounds__(256) void pg_front_diag3_kernel(const int* __restrict__ it_front, const int* __restrict__ it_step, const pg_front* __restrict__ FD,
                                                              double* __restrict__ F, double* __restrict__ R, int* __restrict__ fail, double* __restrict__ Tinv,
                                                              unsigned long long* __restrict__ stamps)
@@ -2106,6 +2383,7 @@ static int pg_solve_impl(dsss_ctx* c, const double* dr6, int total, const dsss_l
     static const bool old_panel = getenv("DSSS_PG_PANEL") && !strcmp(getenv("DSSS_PG_PANEL"), "inverse");      // A/B: the explicit-inverse panel kernels
     unsigned long long* d_stamps = nullptr; if (getenv("DSSS_PG_STAMPS")) TRY(dv.alloc(c, &d_stamps, 16));
     static const bool one_wave = getenv("DSSS_PG_PANEL") && !strcmp(getenv("DSSS_PG_PANEL"), "onewave");
+    static const bool diag3_panel = getenv("DSSS_PG_PANEL") && !strcmp(getenv("DSSS_PG_PANEL"), "diag3");          // A/B: two barriers per block
     double* d_Tinv; TRY(dv.alloc(c, &d_Tinv, (size_t)std::max(npan, 1) * PG_NB4 * 16));
     const int bwd_lds = old_panel ? PG_BWD_LDS(max_n6) : (int)(((PG_PW * 6) * PG_BWD2_LD + PG_NB4 * 16 + 10 * (PG_PW * 6) + std::min(max_n6, PG_BWD2_SX) + 16) * sizeof(double));
     if (bwd_lds > 160 * 1024) { dv.release(); DSSS_FAIL(c, DSSS_E_CAPACITY, "front of %d scalar rows: back-substitution needs %d B of LDS", max_n6, bwd_lds); }
@@ -2212,6 +2490,7 @@ static int pg_solve_impl(dsss_ctx* c, const double* dr6, int total, const dsss_l
                         { dsss_scope s3(c, DSSS_K_PG_DIAG, H.fl_diag[l]);
                           if (old_panel) hipLaunchKernelGGL(pg_front_diag_kernel, dim3(nit), dim3(256), PG_DIAG_LDS, st, itf, its, d_FD, d_F, d_R, d_fail, d_Wsw, d_Wrow, d_Uvec);
                           else if (one_wave) hipLaunchKernelGGL(pg_front_diag2_kernel, dim3(nit), dim3(64), 0, st, itf, its, d_FD, d_F, d_R, d_fail, d_Tinv);
+                          else if (!diag3_panel) hipLaunchKernelGGL(pg_front_diag4_kernel, dim3(nit), dim3(256), 0, st, itf, its, d_FD, d_F, d_R, d_fail, d_Tinv);
                           else {
                               hipLaunchKernelGGL(pg_front_diag3_kernel, dim3(nit), dim3(256), 0, st, itf, its, d_FD, d_F, d_R, d_fail, d_Tinv, d_stamps);
                               if (d_stamps && l == H.nlev - 1) { unsigned long long hs[16]; hipMemcpyAsync(hs, d_stamps, sizeof hs, hipMemcpyDeviceToHost, st); hipStreamSynchronize(st);
