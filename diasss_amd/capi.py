@@ -215,14 +215,23 @@ class Context:
         device tensors)"""
         n = len(ids)
         self._keep = getattr(self, "_keep", {})
+        cache = self.__dict__.setdefault("_addr_cache", {})    # id(array) -> (array, address) of the host geometry arrays: a survey re-submits the
+                                                                # same ones every step, and 600 dtype / contiguity checks + look-ups cost a millisecond
 
         def addr(a):
             if a is None:
                 return 0
-            if isinstance(a, np.ndarray):
-                assert a.dtype == np.float64 and a.flags.c_contiguous
-                return a.__array_interface__["data"][0]
-            return _ptr(a).value or 0
+            if not isinstance(a, np.ndarray):
+                return _ptr(a).value or 0                      # device tensors: data_ptr() is cheap, and they are not kept alive here
+            hit = cache.get(id(a))
+            if hit is not None and hit[0] is a:
+                return hit[1]
+            assert a.dtype == np.float64 and a.flags.c_contiguous
+            v = a.__array_interface__["data"][0]
+            if len(cache) > 4096:
+                cache.clear()
+            cache[id(a)] = (a, v)                              # the entry keeps the (small) geometry array alive, so its id cannot be reused while cached
+            return v
 
         def ptrs(seq):                                        # uintp array == array of void*
             return np.fromiter((addr(a) for a in seq), np.uintp, n)
