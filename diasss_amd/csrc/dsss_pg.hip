@@ -2270,38 +2270,37 @@ static int pg_solve_impl(dsss_ctx* c, const double* dr6, int total, const dsss_l
     }
     const double t_prep = ms_since(T0);
     const auto T1 = std::chrono::steady_clock::now();
+    // The analysis of the reduced system runs on a host thread of its own while this thread sets up everything that does not depend
+    // on it -- device arrays of the pose chain, initial values, the first linearisation and the chain part of the first LM trial
+    // (assembly, both segment passes): the device works through those while the host orders and analyses.
     pg_sym S;
-    { pg_sym_opts opt; opt.threads = sym_threads();
-      static const double bin_cost = getenv("DSSS_PG_BIN_COST") ? atof(getenv("DSSS_PG_BIN_COST")) : 600;   // ~ update-list iterations + 20 per column; measured optimum at C3 (800-1500)
-      opt.bin_cost = bin_cost; pg_sym_opts_env(opt);
-      std::vector<int> part(ns);
-      for (int k = 0; k < ns; ++k) part[k] = (int)(std::upper_bound(pbound.begin(), pbound.end(), sep_pose[k]) - pbound.begin()) - 1;
-      pg_symbolic(ns, redges, nseg, cx.data(), cy.data(), nparts > 1 ? part.data() : nullptr, nparts, opt, S); }
-    // launch lists: this rank's interior fronts, then (after the all-reduce) the replicated interface fronts
     pg_sched SO, SI;
-    pg_build_schedule(S, part_lo, part_hi, SO);
-    if (nparts > 1) pg_build_schedule(S, -1, 0, SI);
-    const double t_sym = ms_since(T1);
-    const auto T2 = std::chrono::steady_clock::now();
-    const int nfr = (int)S.f_c0.size(), npan = S.npanels;
-    const size_t nnzL = S.rowidx.size();
-    const int nval = (int)S.dest_bin.size();
+    std::vector<int> sym_part(ns);
+    for (int k = 0; k < ns; ++k) sym_part[k] = (int)(std::upper_bound(pbound.begin(), pbound.end(), sep_pose[k]) - pbound.begin()) - 1;
+    std::thread sym_thread([&] {
+        pg_sym_opts opt; opt.threads = sym_threads();
+        static const double bin_cost = getenv("DSSS_PG_BIN_COST") ? atof(getenv("DSSS_PG_BIN_COST")) : 600;   // ~ update-list iterations + 20 per column; measured optimum at C3 (500-700)
+        opt.bin_cost = bin_cost; pg_sym_opts_env(opt);
+        pg_symbolic(ns, redges, nseg, cx.data(), cy.data(), nparts > 1 ? sym_part.data() : nullptr, nparts, opt, S);
+        // launch lists: this rank's interior fronts, then (after the all-reduce) the replicated interface fronts
+        pg_build_schedule(S, part_lo, part_hi, SO);
+        if (nparts > 1) pg_build_schedule(S, -1, 0, SI);
+    });
+    struct pg_joiner { std::thread& t; ~pg_joiner() { if (t.joinable()) t.join(); } } sym_join{ sym_thread };      // every return path waits for the thread before its data goes away
     const bool verbose = getenv("DSSS_PG_VERBOSE") != nullptr;
-    if (verbose)
-        fprintf(stderr, "[dsss pg] rank %d/%d parts %d (own %d..%d, poses %d..%d)  poses %d  LC edges %d  separators %d (interface %zu)  nnz(L) blocks %zu  bins %d (%d cols)  fronts %d (largest %d block rows, arena %.0f MB)  panels %d in %d levels  all-reduce %.1f MB\n",
-                rank, world, nparts, part_lo, part_hi, mp0, mp1, n, ne, ns, S.iface_seps.size(), nnzL, (int)S.binptr.size() - 1, (int)S.bincols.size(), nfr, S.max_front_n, S.front_doubles * 8e-6, npan, S.nlev,
-                (S.comm_doubles + 36.0 * S.comm_vals.size() + 6.0 * S.iface_seps.size()) * 8e-6);
 
+    // ---- early device set-up (nothing here reads S)
     pose_t *d_X, *d_Xn, *d_meas, *d_emeas; int *d_ea, *d_eb, *d_adj_ptr, *d_adj_edge, *d_perm;
     double *d_ew, *d_r, *d_Ji, *d_D, *d_C, *d_g, *d_delta, *d_E, *d_Dl, *d_gi, *d_sDL, *d_sDR, *d_sGL, *d_sGR, *d_sS, *d_L, *d_x, *d_part, *d_scal;
     double *d_F, *d_R, *d_ubin, *d_aval, *d_Wsw, *d_Wrow, *d_Uvec;
     int *d_colptr, *d_rowidx, *d_rlptr, *d_rlcol, *d_rlpos, *d_rlrow, *d_binptr, *d_bincols, *d_dest, *d_fail, *d_map; long long* d_mapptr;
     int *d_binroot_ptr, *d_binroot_idx, *d_broot_b, *d_broot_of_col, *d_anc_first, *d_anc_rel, *d_rel, *d_fa_src, *d_fa_col, *d_fa_tr, *d_frows, *d_xr_ptr, *d_xr_child, *d_xr_row, *d_fa_rowptr;
     long long* d_broot_uoff; pg_front* d_FD; pg_child* d_CH;
+    double* d_red;
     const int nf = n + ne, nblk = (nf + 255) / 256;
     TRY(dv.alloc(c, &d_X, n)); TRY(dv.alloc(c, &d_Xn, n)); TRY(dv.alloc(c, &d_meas, n)); TRY(dv.upload(c, &d_emeas, emeas));
     TRY(dv.upload(c, &d_ea, ea)); TRY(dv.upload(c, &d_eb, eb)); TRY(dv.upload(c, &d_ew, ew));
-    TRY(dv.upload(c, &d_adj_ptr, adj_ptr)); TRY(dv.upload(c, &d_adj_edge, adj_edge)); TRY(dv.upload(c, &d_perm, S.perm));
+    TRY(dv.upload(c, &d_adj_ptr, adj_ptr)); TRY(dv.upload(c, &d_adj_edge, adj_edge));
     TRY(dv.alloc(c, &d_r, (size_t)nf * 6)); TRY(dv.alloc(c, &d_Ji, (size_t)nf * 36));
     TRY(dv.alloc(c, &d_D, (size_t)n * 36)); TRY(dv.alloc(c, &d_C, (size_t)n * 36)); TRY(dv.alloc(c, &d_g, (size_t)n * 6)); TRY(dv.alloc(c, &d_delta, (size_t)n * 6));
     TRY(dv.alloc(c, &d_E, (size_t)n * 36)); TRY(dv.alloc(c, &d_Dl, (size_t)n * 36)); TRY(dv.alloc(c, &d_gi, (size_t)n * 6));
@@ -2313,7 +2312,94 @@ static int pg_solve_impl(dsss_ctx* c, const double* dr6, int total, const dsss_l
     TRY(dv.alloc(c, &d_E1, (size_t)ns1 * 36)); TRY(dv.alloc(c, &d_Dl1, (size_t)ns1 * 36)); TRY(dv.alloc(c, &d_gi1, (size_t)ns1 * 6));
     TRY(dv.alloc(c, &d_s2DL, (size_t)std::max(nseg, 1) * 36)); TRY(dv.alloc(c, &d_s2DR, (size_t)std::max(nseg, 1) * 36)); TRY(dv.alloc(c, &d_s2GL, (size_t)std::max(nseg, 1) * 6));
     TRY(dv.alloc(c, &d_s2GR, (size_t)std::max(nseg, 1) * 6)); TRY(dv.alloc(c, &d_s2S, (size_t)std::max(nseg, 1) * 36));
-    TRY(dv.alloc(c, &d_L, nnzL * 36)); TRY(dv.alloc(c, &d_x, (size_t)ns * 6)); TRY(dv.alloc(c, &d_part, (size_t)nblk)); TRY(dv.alloc(c, &d_scal, 8)); TRY(dv.alloc(c, &d_fail, 1));
+    TRY(dv.alloc(c, &d_x, (size_t)ns * 6)); TRY(dv.alloc(c, &d_part, (size_t)nblk)); TRY(dv.alloc(c, &d_scal, 8)); TRY(dv.alloc(c, &d_fail, 1)); TRY(dv.alloc(c, &d_red, 8));
+    hipStream_t st = c->stream;
+#define HCK(x) do { hipError_t _e = (x); if (_e != hipSuccess) { c->err = std::string(#x) + ": " + hipGetErrorString(_e); dv.release(); return DSSS_E_HIP; } } while (0)
+    // sums over the factors are partial on every rank: one small all-reduce makes them global (and identical everywhere)
+    auto reduce_scalars = [&](double* host3, int* failed) -> int {
+        if (world > 1) {
+            hipLaunchKernelGGL(pg_comm_scal_kernel, dim3(1), dim3(64), 0, st, d_scal, d_fail, d_red);
+            int rc2 = dsss_comm_allreduce(c, d_red, 4, st); if (rc2) { dv.release(); return rc2; }
+            double h4[4];
+            HCK(hipMemcpyAsync(h4, d_red, 4 * sizeof(double), hipMemcpyDeviceToHost, st));
+            HCK(hipStreamSynchronize(st));
+            host3[0] = h4[0]; host3[1] = h4[1]; host3[2] = h4[2]; *failed = h4[3] != 0.0;
+        } else {
+            HCK(hipMemcpyAsync(host3, d_scal, 3 * sizeof(double), hipMemcpyDeviceToHost, st));
+            HCK(hipMemcpyAsync(failed, d_fail, sizeof(int), hipMemcpyDeviceToHost, st));
+            HCK(hipStreamSynchronize(st));
+        }
+        return DSSS_OK;
+    };
+    auto error_of = [&](const pose_t* Xd, double* out) -> int {
+        hipLaunchKernelGGL(pg_linearize_kernel, dim3(nblk), dim3(256), 0, st, n, ne, Xd, d_meas, W, d_ea, d_eb, d_emeas, d_ew, (double*)nullptr, (double*)nullptr, d_part, mp0, mp1);
+        hipLaunchKernelGGL(pg_final_sum_kernel, dim3(1), dim3(256), 0, st, d_part, nblk, 0.5, d_scal);
+        double h3[3]; int f0 = 0;
+        HCK(hipMemsetAsync(d_fail, 0, sizeof(int), st));
+        int rc2 = reduce_scalars(h3, &f0); if (rc2) return rc2;
+        *out = h3[0];
+        return DSSS_OK;
+    };
+    {   // initial values
+        double* d_norm = nullptr;
+        if (c->pg.add_noise) {
+            const long long need_pairs = 3LL * n;
+            long long natt = (long long)(need_pairs * 1.32) + 4096;          // acceptance rate pi/4
+            for (int attempt = 0;; ++attempt) {
+                double* d_pairs; int* d_flags; int* d_bsum; int* d_total;
+                const int nb = (int)((natt + 4095) / 4096);
+                TRY(dv.alloc(c, &d_pairs, (size_t)natt * 2)); TRY(dv.alloc(c, &d_flags, (size_t)natt)); TRY(dv.alloc(c, &d_bsum, (size_t)nb)); TRY(dv.alloc(c, &d_total, 1));
+                if (!d_norm) TRY(dv.alloc(c, &d_norm, (size_t)need_pairs * 2));
+                const long long nthr = (natt + RNG_PER_THREAD - 1) / RNG_PER_THREAD;
+                hipLaunchKernelGGL(pg_rng_attempts_kernel, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, st, natt, d_pairs, d_flags);
+                hipLaunchKernelGGL(pg_flag_blocksum_kernel, dim3(nb), dim3(256), 0, st, d_flags, natt, d_bsum);
+                hipLaunchKernelGGL(pg_flag_scan_kernel, dim3(1), dim3(256), 0, st, d_bsum, nb, d_total);
+                hipLaunchKernelGGL(pg_flag_compact_kernel, dim3(nb), dim3(256), 0, st, d_flags, d_pairs, natt, d_bsum, need_pairs, d_norm);
+                int total_ok = 0;
+                HCK(hipMemcpyAsync(&total_ok, d_total, sizeof(int), hipMemcpyDeviceToHost, st));
+                HCK(hipStreamSynchronize(st));
+                if (total_ok >= need_pairs) break;
+                if (attempt > 3) { dv.release(); DSSS_FAIL(c, DSSS_E_NUMERIC, "normal generator: not enough accepted attempts"); }
+                natt *= 2;
+            }
+        }
+        hipLaunchKernelGGL(pg_init_kernel, dim3((n + 255) / 256), dim3(256), 0, st, n, d_dr6, d_norm, c->pg.add_noise, d_X, d_meas);
+    }
+    double lambda = c->pg.lambda0, err = 0, err0 = 0, cur = 0;
+    int iters = 0, nfact = 0;
+    TRY(error_of(d_X, &err));
+    err0 = err;
+    // the chain part of a trial: per-pose blocks, pass 1 (chunks of poses onto their ends), the level-1 chain, pass 2 (runs of
+    // chunk ends onto the true separators)
+    auto chain_part = [&]() {
+        hipMemsetAsync(d_fail, 0, sizeof(int), st);
+        hipLaunchKernelGGL(pg_assemble_kernel, dim3((n + PG_ASM_POSES - 1) / PG_ASM_POSES), dim3(6 * PG_ASM_POSES), 0, st, n, W, d_r, d_Ji, d_adj_ptr, d_adj_edge, d_ew, d_scal + 3, d_D, d_C, d_g, d_eb, mp0, mp1);
+        hipLaunchKernelGGL(pg_segment_kernel, dim3((nseg1 + 15) / 16), dim3(256), 0, st, nseg1, d_sep1, d_D, d_C, d_g, d_E, d_Dl, d_gi, d_sDL, d_sDR, d_sGL, d_sGR, d_sS, d_fail, mp0, mp1);
+        hipLaunchKernelGGL(pg_chain1_kernel, dim3((unsigned)(((long long)ns1 * 42 + 255) / 256)), dim3(256), 0, st, ns1, d_sep1, d_D, d_g, d_sDL, d_sDR, d_sGL, d_sGR, d_sS, d_D1, d_C1, d_g1, mp0, mp1);
+        if (nseg > 0) hipLaunchKernelGGL(pg_segment_kernel, dim3((nseg + 15) / 16), dim3(256), 0, st, nseg, d_t2, d_D1, d_C1, d_g1, d_E1, d_Dl1, d_gi1, d_s2DL, d_s2DR, d_s2GL, d_s2GR, d_s2S, d_fail, kp0, kp1);
+    };
+    const bool will_iterate = err > 0 && c->pg.max_iters > 0;
+    bool pre_lin = false, pre_chain = false;
+    if (will_iterate) {                              // first linearisation and the chain part of the first trial, before the analysis is in
+        hipLaunchKernelGGL(pg_linearize_kernel, dim3(nblk), dim3(256), 0, st, n, ne, d_X, d_meas, W, d_ea, d_eb, d_emeas, d_ew, d_r, d_Ji, d_part, mp0, mp1);
+        hipLaunchKernelGGL(pg_final_sum_kernel, dim3(1), dim3(256), 0, st, d_part, nblk, 0.5, d_scal);
+        HCK(hipMemcpyAsync(d_scal + 3, &lambda, sizeof(double), hipMemcpyHostToDevice, st));
+        chain_part();
+        pre_lin = pre_chain = true;
+    }
+    sym_thread.join();
+    const double t_sym = ms_since(T1);
+    const auto T2 = std::chrono::steady_clock::now();
+    const int nfr = (int)S.f_c0.size(), npan = S.npanels;
+    const size_t nnzL = S.rowidx.size();
+    const int nval = (int)S.dest_bin.size();
+    if (verbose)
+        fprintf(stderr, "[dsss pg] rank %d/%d parts %d (own %d..%d, poses %d..%d)  poses %d  LC edges %d  separators %d (interface %zu)  nnz(L) blocks %zu  bins %d (%d cols)  fronts %d (largest %d block rows, arena %.0f MB)  panels %d in %d levels  all-reduce %.1f MB\n",
+                rank, world, nparts, part_lo, part_hi, mp0, mp1, n, ne, ns, S.iface_seps.size(), nnzL, (int)S.binptr.size() - 1, (int)S.bincols.size(), nfr, S.max_front_n, S.front_doubles * 8e-6, npan, S.nlev,
+                (S.comm_doubles + 36.0 * S.comm_vals.size() + 6.0 * S.iface_seps.size()) * 8e-6);
+
+    TRY(dv.upload(c, &d_perm, S.perm));
+    TRY(dv.alloc(c, &d_L, nnzL * 36));
     TRY(dv.alloc(c, &d_F, (size_t)S.front_doubles)); TRY(dv.alloc(c, &d_R, (size_t)S.frhs_doubles)); TRY(dv.alloc(c, &d_ubin, (size_t)S.ubin_doubles));
     // value array of the fronts; its tail IS the buffer the all-reduce sums: [interface values | interface right-hand sides |
     // update matrices that cross into the interface | 8 scalars]
@@ -2321,9 +2407,9 @@ static int pg_solve_impl(dsss_ctx* c, const double* dr6, int total, const dsss_l
     const size_t comm_total = ncv * 36 + nif * 6 + (size_t)S.comm_doubles + 8;
     TRY(dv.alloc(c, &d_aval, (size_t)nval * 36 + comm_total));
     double* d_comm = d_aval + (size_t)nval * 36; double* d_avalif = d_comm; double* d_xif = d_comm + ncv * 36; double* d_commU = d_xif + nif * 6;
-    int *d_ifslot, *d_ifsep, *d_pk_child, *d_pk_row; pg_pack* d_PK; double* d_red;
+    int *d_ifslot, *d_ifsep, *d_pk_child, *d_pk_row; pg_pack* d_PK;
     { std::vector<int> ifslot(ns, -1); for (size_t q = 0; q < nif; ++q) ifslot[S.iface_seps[q]] = (int)q;
-      TRY(dv.upload(c, &d_ifslot, ifslot)); TRY(dv.upload(c, &d_ifsep, S.iface_seps)); TRY(dv.alloc(c, &d_red, 8)); }
+      TRY(dv.upload(c, &d_ifslot, ifslot)); TRY(dv.upload(c, &d_ifsep, S.iface_seps)); }
     TRY(dv.upload(c, &d_colptr, S.colptr)); TRY(dv.upload(c, &d_rowidx, S.rowidx)); TRY(dv.upload(c, &d_rlptr, S.rlptr)); TRY(dv.upload(c, &d_rlcol, S.rlcol));
     TRY(dv.upload(c, &d_rlpos, S.rlpos)); TRY(dv.upload(c, &d_rlrow, S.rlrow)); TRY(dv.upload(c, &d_mapptr, S.mapptr)); TRY(dv.upload(c, &d_binptr, S.binptr)); TRY(dv.upload(c, &d_bincols, S.bincols));
     TRY(dv.upload(c, &d_dest, S.dest_bin));
@@ -2393,85 +2479,28 @@ static int pg_solve_impl(dsss_ctx* c, const double* dr6, int total, const dsss_l
         hipFuncSetAttribute((const void*)pg_front_bwd2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipGetLastError();
     }
-    hipStream_t st = c->stream;
-#define HCK(x) do { hipError_t _e = (x); if (_e != hipSuccess) { c->err = std::string(#x) + ": " + hipGetErrorString(_e); dv.release(); return DSSS_E_HIP; } } while (0)
-    // sums over the factors are partial on every rank: one small all-reduce makes them global (and identical everywhere)
-    auto reduce_scalars = [&](double* host3, int* failed) -> int {
-        if (world > 1) {
-            hipLaunchKernelGGL(pg_comm_scal_kernel, dim3(1), dim3(64), 0, st, d_scal, d_fail, d_red);
-            int rc2 = dsss_comm_allreduce(c, d_red, 4, st); if (rc2) { dv.release(); return rc2; }
-            double h4[4];
-            HCK(hipMemcpyAsync(h4, d_red, 4 * sizeof(double), hipMemcpyDeviceToHost, st));
-            HCK(hipStreamSynchronize(st));
-            host3[0] = h4[0]; host3[1] = h4[1]; host3[2] = h4[2]; *failed = h4[3] != 0.0;
-        } else {
-            HCK(hipMemcpyAsync(host3, d_scal, 3 * sizeof(double), hipMemcpyDeviceToHost, st));
-            HCK(hipMemcpyAsync(failed, d_fail, sizeof(int), hipMemcpyDeviceToHost, st));
-            HCK(hipStreamSynchronize(st));
-        }
-        return DSSS_OK;
-    };
-    auto error_of = [&](const pose_t* Xd, double* out) -> int {
-        hipLaunchKernelGGL(pg_linearize_kernel, dim3(nblk), dim3(256), 0, st, n, ne, Xd, d_meas, W, d_ea, d_eb, d_emeas, d_ew, (double*)nullptr, (double*)nullptr, d_part, mp0, mp1);
-        hipLaunchKernelGGL(pg_final_sum_kernel, dim3(1), dim3(256), 0, st, d_part, nblk, 0.5, d_scal);
-        double h3[3]; int f0 = 0;
-        HCK(hipMemsetAsync(d_fail, 0, sizeof(int), st));
-        int rc2 = reduce_scalars(h3, &f0); if (rc2) return rc2;
-        *out = h3[0];
-        return DSSS_OK;
-    };
-    {   // initial values
-        double* d_norm = nullptr;
-        if (c->pg.add_noise) {
-            const long long need_pairs = 3LL * n;
-            long long natt = (long long)(need_pairs * 1.32) + 4096;          // acceptance rate pi/4
-            for (int attempt = 0;; ++attempt) {
-                double* d_pairs; int* d_flags; int* d_bsum; int* d_total;
-                const int nb = (int)((natt + 4095) / 4096);
-                TRY(dv.alloc(c, &d_pairs, (size_t)natt * 2)); TRY(dv.alloc(c, &d_flags, (size_t)natt)); TRY(dv.alloc(c, &d_bsum, (size_t)nb)); TRY(dv.alloc(c, &d_total, 1));
-                if (!d_norm) TRY(dv.alloc(c, &d_norm, (size_t)need_pairs * 2));
-                const long long nthr = (natt + RNG_PER_THREAD - 1) / RNG_PER_THREAD;
-                hipLaunchKernelGGL(pg_rng_attempts_kernel, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, st, natt, d_pairs, d_flags);
-                hipLaunchKernelGGL(pg_flag_blocksum_kernel, dim3(nb), dim3(256), 0, st, d_flags, natt, d_bsum);
-                hipLaunchKernelGGL(pg_flag_scan_kernel, dim3(1), dim3(256), 0, st, d_bsum, nb, d_total);
-                hipLaunchKernelGGL(pg_flag_compact_kernel, dim3(nb), dim3(256), 0, st, d_flags, d_pairs, natt, d_bsum, need_pairs, d_norm);
-                int total_ok = 0;
-                HCK(hipMemcpyAsync(&total_ok, d_total, sizeof(int), hipMemcpyDeviceToHost, st));
-                HCK(hipStreamSynchronize(st));
-                if (total_ok >= need_pairs) break;
-                if (attempt > 3) { dv.release(); DSSS_FAIL(c, DSSS_E_NUMERIC, "normal generator: not enough accepted attempts"); }
-                natt *= 2;
-            }
-        }
-        hipLaunchKernelGGL(pg_init_kernel, dim3((n + 255) / 256), dim3(256), 0, st, n, d_dr6, d_norm, c->pg.add_noise, d_X, d_meas);
-    }
     HCK(hipMemsetAsync(d_map, 0xff, (size_t)std::max<long long>(mapsz, 1) * sizeof(int), st));
     { const int nupd = (int)S.rlcol.size();
       if (nupd > 0) hipLaunchKernelGGL(pg_build_map_kernel, dim3((nupd + 255) / 256), dim3(256), 0, st, nupd, d_rlrow, d_rlptr, d_rlcol, d_rlpos, d_colptr, d_rowidx, d_mapptr, d_map); }
     const double t_up = ms_since(T2);
     const auto T3 = std::chrono::steady_clock::now();
     dsss_scope sc(c, DSSS_K_PG);
-    double lambda = c->pg.lambda0, err = 0, err0 = 0, cur = 0;
-    int iters = 0, nfact = 0;
-    TRY(error_of(d_X, &err));
-    err0 = err;
-    if (err > 0 && c->pg.max_iters > 0) do {     // NonlinearOptimizer::defaultOptimize returns before iterating when maxIterations is reached
+    if (will_iterate) do {                        // NonlinearOptimizer::defaultOptimize returns before iterating when maxIterations is reached
         cur = err;
         double oldLin = err;                                                   // linear error at delta = 0 == the error at X (same sum, already global)
-        hipLaunchKernelGGL(pg_linearize_kernel, dim3(nblk), dim3(256), 0, st, n, ne, d_X, d_meas, W, d_ea, d_eb, d_emeas, d_ew, d_r, d_Ji, d_part, mp0, mp1);
-        hipLaunchKernelGGL(pg_final_sum_kernel, dim3(1), dim3(256), 0, st, d_part, nblk, 0.5, d_scal);
+        if (!pre_lin) {
+            hipLaunchKernelGGL(pg_linearize_kernel, dim3(nblk), dim3(256), 0, st, n, ne, d_X, d_meas, W, d_ea, d_eb, d_emeas, d_ew, d_r, d_Ji, d_part, mp0, mp1);
+            hipLaunchKernelGGL(pg_final_sum_kernel, dim3(1), dim3(256), 0, st, d_part, nblk, 0.5, d_scal);
+        }
+        pre_lin = false;
         for (;;) {
             // ---- solve (H + lambda I) delta = -g ; lambda lives in device memory
-            HCK(hipMemcpyAsync(d_scal + 3, &lambda, sizeof(double), hipMemcpyHostToDevice, st));
+            if (!pre_chain) HCK(hipMemcpyAsync(d_scal + 3, &lambda, sizeof(double), hipMemcpyHostToDevice, st));
             {
-                hipMemsetAsync(d_fail, 0, sizeof(int), st);
                 hipMemsetAsync(d_L, 0, nnzL * 36 * sizeof(double), st);
                 if (nparts > 1) hipMemsetAsync(d_comm, 0, comm_total * sizeof(double), st);
-                hipLaunchKernelGGL(pg_assemble_kernel, dim3((n + PG_ASM_POSES - 1) / PG_ASM_POSES), dim3(6 * PG_ASM_POSES), 0, st, n, W, d_r, d_Ji, d_adj_ptr, d_adj_edge, d_ew, d_scal + 3, d_D, d_C, d_g, d_eb, mp0, mp1);
-                // pass 1: chunks of poses onto their ends; the level-1 chain; pass 2: runs of chunk ends onto the true separators
-                hipLaunchKernelGGL(pg_segment_kernel, dim3((nseg1 + 15) / 16), dim3(256), 0, st, nseg1, d_sep1, d_D, d_C, d_g, d_E, d_Dl, d_gi, d_sDL, d_sDR, d_sGL, d_sGR, d_sS, d_fail, mp0, mp1);
-                hipLaunchKernelGGL(pg_chain1_kernel, dim3((unsigned)(((long long)ns1 * 42 + 255) / 256)), dim3(256), 0, st, ns1, d_sep1, d_D, d_g, d_sDL, d_sDR, d_sGL, d_sGR, d_sS, d_D1, d_C1, d_g1, mp0, mp1);
-                if (nseg > 0) hipLaunchKernelGGL(pg_segment_kernel, dim3((nseg + 15) / 16), dim3(256), 0, st, nseg, d_t2, d_D1, d_C1, d_g1, d_E1, d_Dl1, d_gi1, d_s2DL, d_s2DR, d_s2GL, d_s2GR, d_s2S, d_fail, kp0, kp1);
+                if (!pre_chain) chain_part();
+                pre_chain = false;
                 hipLaunchKernelGGL(pg_scatter_base_kernel, dim3((unsigned)(((long long)ns * 78 + 255) / 256)), dim3(256), 0, st, ns, d_t2, d_perm, d_D1, d_g1, d_s2DL, d_s2DR, d_s2GL, d_s2GR, d_s2S, d_dest, d_L, d_aval, d_x,
                                    d_ifslot, d_avalif, d_xif, kp0, kp1);
                 if (ne > 0) hipLaunchKernelGGL(pg_scatter_lc_kernel, dim3((unsigned)(((long long)ne * 36 + 255) / 256)), dim3(256), 0, st, n, ne, ns, d_Ji, d_ew, d_dest, d_L, d_aval, d_avalif, d_eb, mp0, mp1);
