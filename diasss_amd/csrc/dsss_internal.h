@@ -111,6 +111,7 @@ struct dsss_ctx {
     dsss_comm* comm = nullptr;          // ranks of one job (dsss_comm_init): null = single process
     int pg_parts = 0;                   // pose-graph partitions (0: one per rank); > ranks only to exercise the interface logic on few GPUs
     int* tmp_dev = nullptr;             // 64 ints of device scratch for one-value results (dsss_descriptor_distance)
+    void* pg_edges_host = nullptr; size_t pg_edges_cap = 0;     // page-locked staging of the selected LC edges (dsss_posegraph_solve)
     dsss_prof prof;
 };
 

@@ -2760,11 +2760,21 @@ int dsss_posegraph_solve(dsss_ctx* c, int nframes, double* poses12, double* rpy6
         if (!c->frames[f].has_geom) DSSS_FAIL(c, DSSS_E_STATE, "frame %d has no geometry", f);
         total += (size_t)c->frames[f].N;
     }
-    std::vector<dsss_lc_edge> edges((size_t)std::max(c->total_kp7, 1));
+    // the selected edges come back into a page-locked buffer the context keeps (a fresh 7 MB vector per solve cost a millisecond of
+    // page faults, and a pageable destination halves the copy rate)
+    const size_t ecap = (size_t)std::max(c->total_kp7, 1);
+    if (c->pg_edges_cap < ecap) {
+        if (c->pg_edges_host) hipHostFree(c->pg_edges_host);
+        c->pg_edges_host = nullptr; c->pg_edges_cap = 0;
+        HIPCHK(c, hipHostMalloc(&c->pg_edges_host, ecap * sizeof(dsss_lc_edge), hipHostMallocDefault));
+        c->pg_edges_cap = ecap;
+    }
+    dsss_lc_edge* edges_p = static_cast<dsss_lc_edge*>(c->pg_edges_host);
+    std::vector<dsss_lc_edge> edges;              // only used when the edges of several ranks are merged
     int ne = 0;
     const double t_dr = ms(t0);
     const auto t1 = std::chrono::steady_clock::now();
-    int rc = dsss_posegraph_select(c, nframes, edges.data(), (int)edges.size(), &ne);
+    int rc = dsss_posegraph_select(c, nframes, edges_p, (int)ecap, &ne);
     if (rc) return rc;
     const int world = dsss_comm_world(c), rank = dsss_comm_rank(c);
     if (world > 1) {
@@ -2785,9 +2795,9 @@ int dsss_posegraph_solve(dsss_ctx* c, int nframes, double* poses12, double* rpy6
         std::vector<double> rec(std::max<size_t>(tot, 1) * 20, 0.0);
         for (int i = 0; i < ne; ++i) {
             double* q = rec.data() + (off + i) * 20;
-            q[0] = edges[i].a; q[1] = edges[i].b;
-            for (int k = 0; k < 12; ++k) q[2 + k] = edges[i].rel[k];
-            for (int k = 0; k < 6; ++k) q[14 + k] = edges[i].var[k];
+            q[0] = edges_p[i].a; q[1] = edges_p[i].b;
+            for (int k = 0; k < 12; ++k) q[2 + k] = edges_p[i].rel[k];
+            for (int k = 0; k < 6; ++k) q[14 + k] = edges_p[i].var[k];
         }
         if (tot > 0) {
             HIPCHK(c, hipMalloc(&d_tmp, rec.size() * sizeof(double)));
@@ -2806,10 +2816,11 @@ int dsss_posegraph_solve(dsss_ctx* c, int nframes, double* poses12, double* rpy6
             for (int k = 0; k < 6; ++k) edges[i].var[k] = q[14 + k];
         }
         std::stable_sort(edges.begin(), edges.begin() + ne, [](const dsss_lc_edge& x, const dsss_lc_edge& y) { return x.b < y.b; });
+        edges_p = edges.data();
     }
     const double t_sel = ms(t1);
     const auto t2 = std::chrono::steady_clock::now();
-    rc = pg_solve_impl(c, nullptr, (int)total, edges.data(), ne, poses12, stats4, rpy6, nframes);
+    rc = pg_solve_impl(c, nullptr, (int)total, edges_p, ne, poses12, stats4, rpy6, nframes);
     if (rc) return rc;
     if (getenv("DSSS_PG_VERBOSE")) fprintf(stderr, "[dsss pg] DR rows %.1f ms, LC selection %.1f ms, solve + download %.1f ms\n", t_dr, t_sel, ms(t2));
     return DSSS_OK;
