@@ -566,10 +566,10 @@ __device__ inline void pg_acc_rows(const int* __restrict__ mp, int m, int tn, co
 //          [ F11            ]   s6 own scalar columns          assembled from the original entries + the update matrices of its
 //          [ F21   F22      ]   n6 - s6 boundary rows          children (extend-add), factorised in 96-column panel steps:
 //     pg_front_asm_kernel      zero + original entries + children, parent rows owned by workgroups, children in fixed order
-//     pg_front_diag_kernel     L11 = chol(A11), W = L11^-1, y = L11^-1 b, u = W^T y       one workgroup per panel, dense in LDS
-//     pg_front_trsm_kernel     L21 = A21 W^T, b2 -= A21 u                                  one wavefront per 16 rows
+//     pg_front_diag4_kernel    L11 = chol(A11) in 4-column pivot blocks, their inverses Linv, y = L11^-1 b      one workgroup per panel
+//     pg_front_trsm2_kernel    L21 = A21 L11^-T, b2 -= L21 y                              one wavefront per 16 rows
 //     pg_front_syrk_kernel     A22 -= L21 L21^T                                           64 x 64 tiles of the trailing part
-//     pg_front_bwd_kernel      x1 = W^T (y1 - L21^T x2)
+//     pg_front_bwd2_kernel     x1 = L11^-T (y1 - L21^T x2)
 // all dense products on v_mfma_f64_16x16x4_f64.  What is left in F22 after the last panel is the front's update matrix.
 struct pg_front {
     long long off, roff;            // front / right-hand-side arena offsets (doubles)
@@ -629,298 +629,11 @@ __global__ __launch_bounds__(256) void pg_front_asm_kernel(const int* __restrict
     }
 }
 
-#define PG_BWD_LDS(maxn6) ((((PG_PW * 6) * (PG_PW * 6) + 10 * (PG_PW * 6) + (PG_PW * 6) + (maxn6)) + 16) * (int)sizeof(double))
-#define PG_LD 98                                   // LDS row stride of the 96 x 96 images (doubles)
-#define PG_DIAG_LDS (2 * (PG_PW * 6) * PG_LD * (int)sizeof(double))
 typedef double pg_d4 __attribute__((ext_vector_type(4)));
 __device__ inline double pg_readlane(double v, int lane)
 {
     const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane), hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
     return __hiloint2double(hi, lo);
-}
-// MFMA operand images of a 16 x 16 tile at (R0, C0) of a row-major LDS matrix.  "a": lane l holds [l & 15][4 ks + (l >> 4)],
-// i.e. the tile as the A operand, or its transpose as the B operand; "b": lane l holds [4 ks + (l >> 4)][l & 15].
-__device__ inline void pg_ld_a(const double* s, int R0, int C0, int l, double sign, double* f)
-{
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) f[ks] = sign * s[(R0 + (l & 15)) * PG_LD + C0 + 4 * ks + (l >> 4)];
-}
-__device__ inline void pg_ld_b(const double* s, int R0, int C0, int l, double* f)
-{
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) f[ks] = s[(R0 + 4 * ks + (l >> 4)) * PG_LD + C0 + (l & 15)];
-}
-__device__ inline pg_d4 pg_ld_c(const double* s, int R0, int C0, int l)
-{
-    pg_d4 c;
-#pragma unroll
-    for (int v = 0; v < 4; ++v) c[v] = s[(R0 + (l >> 4) + 4 * v) * PG_LD + C0 + (l & 15)];
-    return c;
-}
-__device__ inline void pg_st_c(double* s, int R0, int C0, int l, pg_d4 c)
-{
-#pragma unroll
-    for (int v = 0; v < 4; ++v) s[(R0 + (l >> 4) + 4 * v) * PG_LD + C0 + (l & 15)] = c[v];
-}
-__device__ inline pg_d4 pg_mma4(const double* a, const double* b, pg_d4 c)
-{
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) c = __builtin_amdgcn_mfma_f64_16x16x4f64(a[ks], b[ks], c, 0, 0, 0);
-    return c;
-}
-// Cholesky of the 16 x 16 diagonal tile t and its inverse V_t, executed by lanes 0..15 of one wavefront: lane i owns row i
-// of A_tt, then column i of V_t
-__device__ inline int pg_tile_factor(double* sA, double* sW, int t, int lane)
-{
-    double d[16], v[16];
-    double* row = sA + (16 * t + lane) * PG_LD + 16 * t;
-#pragma unroll
-    for (int j = 0; j < 16; ++j) d[j] = row[j];
-    int bad = 0;
-#pragma unroll
-    for (int j = 0; j < 16; ++j) {
-        double pj = pg_readlane(d[j], j);
-        if (!(pj > 0) || !isfinite(pj)) { bad = 1; pj = 1.0; }
-        double r = __builtin_amdgcn_rsq(pj);                 // v_rsq_f64 seed, two Newton steps
-        r = r * (1.5 - 0.5 * pj * r * r);
-        r = r * (1.5 - 0.5 * pj * r * r);
-        d[j] = (lane == j ? pj : d[j]) * r;
-#pragma unroll
-        for (int k = 0; k < 16; ++k) if (k > j) d[k] -= d[j] * pg_readlane(d[j], k);      // A_ik -= L_ij L_kj (used for i >= k)
-        // row j of V = L^-1 is complete data-wise now (it needs rows <= j of L): lane c holds V[j][c], zero above the
-        // diagonal; two interleaved partial sums, and the work overlaps with the next pivot's reciprocal square root
-        {
-            double s0 = 0, s1 = 0;
-#pragma unroll
-            for (int k = 0; k < 16; ++k) if (k < j) { const double pr = pg_readlane(d[k], j) * v[k]; if (k & 1) s1 += pr; else s0 += pr; }
-            v[j] = lane == j ? r : (lane < j ? -(s0 + s1) * r : 0.0);
-        }
-    }
-#pragma unroll
-    for (int j = 0; j < 16; ++j) row[j] = j <= lane ? d[j] : 0.0;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) sW[(16 * t + i) * PG_LD + 16 * t + lane] = v[i];
-    return bad;
-}
-
-// panel step `step` of a front: n = min(96, s6 - 96 step) columns starting at scalar column 96 step.
-//   per tile step t:  A  (16 lanes) L_tt = chol(A_tt) and V_t = L_tt^-1
-//                     B  L_it = A_it V_t^T for the tiles below            (v_mfma_f64_16x16x4_f64, 4 per tile)
-//                     C  A_ij -= L_it L_jt^T for the trailing tiles       (same); wavefront 0 takes tile (t+1, t+1) first
-//                        and goes straight on to step A of t+1 while wavefronts 1-3 finish the rest (look-ahead)
-//   then W = L11^-1 by recursive doubling over tiles, [A 0; B C]^-1 = [A^-1 0; -C^-1 B A^-1  C^-1], again on the matrix
-//   cores, so that the row solve below the panel and the back-substitution are plain products with W.
-// The right-hand side rides along: y_t = V_t b_t, b_i -= L_it y_t; u = W^T y goes out for the row kernel.
-__global__ __launch_bounds__(256) void pg_front_diag_kernel(const int* __restrict__ it_front, const int* __restrict__ it_step, const pg_front* __restrict__ FD,
-                                                            double* __restrict__ F, double* __restrict__ R, int* __restrict__ fail,
-                                                            double* __restrict__ Wsw, double* __restrict__ Wrow, double* __restrict__ Uvec)
-{
-    extern __shared__ double s_dyn[];
-    __shared__ double sy[PG_PW * 6];
-    __shared__ int s_bad;
-    double* sA = s_dyn;
-    double* sW = s_dyn + (PG_PW * 6) * PG_LD;
-    const pg_front fd = FD[it_front[blockIdx.x]];
-    const int step = it_step[blockIdx.x], col0 = 96 * step;
-    const int n = min(96, fd.s6 - col0), w = n / 6, p = fd.pan0 + step, ld = fd.ld;
-    double* __restrict__ A = F + fd.off + (size_t)col0 * ld + col0;
-    double* __restrict__ rr = R + fd.roff + col0;
-    const int nt = (n + 15) >> 4, np = 16 * nt;
-    const int bi = threadIdx.x >> 4, bj = threadIdx.x & 15;
-    const bool act = bi < w && bj <= bi;
-    const int wave = threadIdx.x >> 6, l = threadIdx.x & 63;
-    if (threadIdx.x == 0) s_bad = 0;
-    for (int i = wave; i < n; i += 4) for (int j = l; j < n; j += 64) sA[i * PG_LD + j] = A[(size_t)i * ld + j];
-    for (int e = threadIdx.x; e < (np - n) * np; e += 256) {        // identity padding up to the tile boundary
-        const int i = n + e / np, c2 = e % np;
-        sA[i * PG_LD + c2] = i == c2 ? 1.0 : 0.0;
-    }
-    if ((int)threadIdx.x < np) sy[threadIdx.x] = (int)threadIdx.x < n ? rr[threadIdx.x] : 0.0;
-    __syncthreads();
-    if (threadIdx.x < 16) { if (pg_tile_factor(sA, sW, 0, threadIdx.x)) s_bad = 1; }
-    __syncthreads();
-    for (int t = 0; t < nt; ++t) {
-        // ---- B: tiles below the diagonal tile, one per wavefront in turn; lanes 0..15 of wavefront 0 also finish y_t
-        for (int i = t + 1 + wave; i < nt; i += 4) {
-            double fa[4], fb[4];
-            pg_ld_a(sA, 16 * i, 16 * t, l, 1.0, fa);
-            pg_ld_a(sW, 16 * t, 16 * t, l, 1.0, fb);          // B[k][c] = V_t[c][k]
-            pg_d4 acc = { 0.0, 0.0, 0.0, 0.0 };
-            acc = pg_mma4(fa, fb, acc);
-            pg_st_c(sA, 16 * i, 16 * t, l, acc);
-        }
-        if (threadIdx.x < 16) {
-            double bb[16];
-#pragma unroll
-            for (int k = 0; k < 16; ++k) bb[k] = sy[16 * t + k];
-            double yv = 0;
-#pragma unroll
-            for (int k = 0; k < 16; ++k) yv += sW[(16 * t + threadIdx.x) * PG_LD + 16 * t + k] * bb[k];
-            sy[16 * t + threadIdx.x] = yv;
-        }
-        __syncthreads();
-        // ---- C: trailing update
-        if (t + 1 < nt) {
-            if (wave == 0) {
-                double fa[4], fb[4];
-                pg_ld_a(sA, 16 * (t + 1), 16 * t, l, -1.0, fa);
-                pg_ld_a(sA, 16 * (t + 1), 16 * t, l, 1.0, fb);
-                pg_d4 acc = pg_ld_c(sA, 16 * (t + 1), 16 * (t + 1), l);
-                acc = pg_mma4(fa, fb, acc);
-                pg_st_c(sA, 16 * (t + 1), 16 * (t + 1), l, acc);
-                if (l < 16) { if (pg_tile_factor(sA, sW, t + 1, l)) s_bad = 1; }
-            } else {
-                int cnt = 0;
-                for (int i = t + 1; i < nt; ++i)
-                    for (int j = t + 1; j <= i; ++j) {
-                        if (i == t + 1 && j == t + 1) continue;
-                        if (cnt++ % 3 != wave - 1) continue;
-                        double fa[4], fb[4];
-                        pg_ld_a(sA, 16 * i, 16 * t, l, -1.0, fa);
-                        pg_ld_a(sA, 16 * j, 16 * t, l, 1.0, fb);
-                        pg_d4 acc = pg_ld_c(sA, 16 * i, 16 * j, l);
-                        acc = pg_mma4(fa, fb, acc);
-                        pg_st_c(sA, 16 * i, 16 * j, l, acc);
-                    }
-                const int i = 16 * (t + 1) + (int)threadIdx.x - 64;      // b_i -= L_it y_t
-                if (i < np) {
-                    double v = sy[i];
-#pragma unroll
-                    for (int k = 0; k < 16; ++k) v -= sA[i * PG_LD + 16 * t + k] * sy[16 * t + k];
-                    sy[i] = v;
-                }
-            }
-        }
-        __syncthreads();
-    }
-    if (s_bad && threadIdx.x == 0) *fail = 1;
-    for (int i = wave; i < n; i += 4) for (int j = l; j <= i; j += 64) A[(size_t)i * ld + j] = sA[i * PG_LD + j];       // L11, lower triangle
-    if ((int)threadIdx.x < n) rr[threadIdx.x] = sy[threadIdx.x];
-    // ---- W = L11^-1: off-diagonal tiles by recursive doubling (the diagonal tiles V_t are in place)
-    for (int h = 1; h < nt; h <<= 1) {
-        {   int cnt = 0;                                        // T = B A^-1 into the target tiles
-            for (int g = 0; (2 * g + 1) * h < nt; ++g) {
-                const int gmid = (2 * g + 1) * h, iend = min(gmid + h, nt);
-                for (int i = gmid; i < iend; ++i)
-                    for (int j = 2 * g * h; j < gmid; ++j) {
-                        if ((cnt++ & 3) != wave) continue;
-                        pg_d4 acc = { 0.0, 0.0, 0.0, 0.0 };
-                        for (int k = j; k < gmid; ++k) {
-                            double fa[4], fb[4];
-                            pg_ld_a(sA, 16 * i, 16 * k, l, 1.0, fa);
-                            pg_ld_b(sW, 16 * k, 16 * j, l, fb);
-                            acc = pg_mma4(fa, fb, acc);
-                        }
-                        pg_st_c(sW, 16 * i, 16 * j, l, acc);
-                    }
-            }
-        }
-        __syncthreads();
-        pg_d4 r0 = { 0.0, 0.0, 0.0, 0.0 }, r1 = { 0.0, 0.0, 0.0, 0.0 };
-        int ti0 = -1, tj0 = 0, ti1 = -1, tj1 = 0;
-        {   int cnt = 0;                                        // W_B = -C^-1 T, kept in registers until every T is consumed
-            for (int g = 0; (2 * g + 1) * h < nt; ++g) {
-                const int gmid = (2 * g + 1) * h, iend = min(gmid + h, nt);
-                for (int i = gmid; i < iend; ++i)
-                    for (int j = 2 * g * h; j < gmid; ++j) {
-                        if ((cnt++ & 3) != wave) continue;
-                        pg_d4 acc = { 0.0, 0.0, 0.0, 0.0 };
-                        for (int k = gmid; k <= i; ++k) {
-                            double fa[4], fb[4];
-                            pg_ld_a(sW, 16 * i, 16 * k, l, -1.0, fa);
-                            pg_ld_b(sW, 16 * k, 16 * j, l, fb);
-                            acc = pg_mma4(fa, fb, acc);
-                        }
-                        if (ti0 < 0) { r0 = acc; ti0 = i; tj0 = j; } else { r1 = acc; ti1 = i; tj1 = j; }
-                    }
-            }
-        }
-        __syncthreads();
-        if (ti0 >= 0) pg_st_c(sW, 16 * ti0, 16 * tj0, l, r0);
-        if (ti1 >= 0) pg_st_c(sW, 16 * ti1, 16 * tj1, l, r1);
-        __syncthreads();
-    }
-    // u = W^T y for the row kernel (b2 -= A21 u): u[i] = sum_{k >= i} W[k][i] y[k]
-    if ((int)threadIdx.x < PG_PW * 6) {
-        const int i = threadIdx.x;
-        double v0 = 0, v1 = 0;
-        if (i < n) {
-            int k = i;
-            for (; k + 1 < n; k += 2) { v0 += sW[k * PG_LD + i] * sy[k]; v1 += sW[(k + 1) * PG_LD + i] * sy[k + 1]; }
-            if (k < n) v0 += sW[k * PG_LD + i] * sy[k];
-        }
-        Uvec[(size_t)p * (PG_PW * 6) + i] = v0 + v1;
-    }
-    // W out: row-major for the back-substitution, and in MFMA B-operand order for the row solve (tile nt = 16 output
-    // columns, k-step ks = 4 k's: lane l holds W[16 nt + (l & 15)][4 ks + (l >> 4)]).  Thread (bi, bj) writes its block;
-    // everything outside the lower block triangle of the first w block rows was zeroed once by the host and stays zero.
-    if (act) {
-        double* wr = Wrow + (size_t)p * (PG_PW * 6) * (PG_PW * 6);
-        double* ws = Wsw + (size_t)p * (PG_PW * 6) * (PG_PW * 6);
-        int offc[6];
-#pragma unroll
-        for (int c2 = 0; c2 < 6; ++c2) { const int kc = 6 * bj + c2; offc[c2] = (kc >> 2) * 64 + (kc & 3) * 16; }
-#pragma unroll
-        for (int r = 0; r < 6; ++r) {
-            const int jr = 6 * bi + r;
-            const int offr = (jr >> 4) * (24 * 64) + (jr & 15);
-#pragma unroll
-            for (int c2 = 0; c2 < 6; ++c2) {
-                const double v = (bi == bj && c2 > r) ? 0.0 : sW[jr * PG_LD + 6 * bj + c2];
-                wr[(size_t)jr * (PG_PW * 6) + 6 * bj + c2] = v;
-                ws[offr + offc[c2]] = v;
-            }
-        }
-    }
-}
-
-// L21 = A21 W^T with W = L11^-1 from pg_front_diag_kernel: a plain f64 GEMM on the matrix cores.  One wavefront per
-// 16 scalar rows: the 16 x 96 slab of A21 sits in 24 A-operand registers per lane (lane l: row l & 15, k = 4 ks + (l >> 4)),
-// W^T streams in as pre-swizzled B operands (one coalesced 512-byte load per v_mfma_f64_16x16x4_f64), and output tile nt
-// only runs the k-steps its triangular W reaches (4 nt + 4 of 24).  Forward substitution rides along: b2 -= A21 u.
-__global__ __launch_bounds__(256) void pg_front_trsm_kernel(const int* __restrict__ it_front, const int* __restrict__ it_step, const pg_front* __restrict__ FD,
-                                                            double* __restrict__ F, double* __restrict__ R, const double* __restrict__ Wsw, const double* __restrict__ Uvec)
-{
-    const pg_front fd = FD[it_front[blockIdx.x]];
-    const int step = it_step[blockIdx.x], col0 = 96 * step;
-    const int n = min(96, fd.s6 - col0), p = fd.pan0 + step, ld = fd.ld;
-    const int row0 = col0 + n, nrows = fd.n6 - row0;
-    const int l = threadIdx.x & 63;
-    const int rowbase = ((int)blockIdx.y * 4 + (int)(threadIdx.x >> 6)) * 16;
-    if (rowbase >= nrows) return;                  // wavefront-uniform
-    const double* Wp = Wsw + (size_t)p * (PG_PW * 6) * (PG_PW * 6);
-    const double* up = Uvec + (size_t)p * (PG_PW * 6);
-    const int arow = rowbase + (l & 15);
-    const bool rok = arow < nrows;
-    double* __restrict__ Arow = F + fd.off + (size_t)(row0 + arow) * ld + col0;
-    double a[24];
-    double dot = 0;
-#pragma unroll
-    for (int ks = 0; ks < 24; ++ks) {
-        const int k = 4 * ks + (l >> 4);
-        a[ks] = (rok && k < n) ? Arow[k] : 0.0;
-        dot += a[ks] * up[k];
-    }
-    dot += __shfl_xor(dot, 16, 64);
-    dot += __shfl_xor(dot, 32, 64);
-    if (l < 16 && rok) R[fd.roff + row0 + arow] -= dot;
-#pragma unroll
-    for (int nt = 0; nt < 6; ++nt) {
-        if (16 * nt < n) {                         // uniform
-            pg_d4 acc = { 0.0, 0.0, 0.0, 0.0 };
-#pragma unroll
-            for (int ks = 0; ks < 4 * nt + 4; ++ks)
-                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[ks], Wp[(nt * 24 + ks) * 64 + l], acc, 0, 0, 0);
-            const int col = 16 * nt + (l & 15);
-            if (col < n) {
-#pragma unroll
-                for (int v = 0; v < 4; ++v) {
-                    const int row = rowbase + (l >> 4) + 4 * v;
-                    if (row < nrows) F[fd.off + (size_t)(row0 + row) * ld + col0 + col] = acc[v];
-                }
-            }
-        }
-    }
 }
 
 // A22 -= L21 L21^T on the trailing part of the front (rows and columns beyond the panel): one workgroup per 64 x 64 tile of
@@ -989,72 +702,16 @@ __global__ __launch_bounds__(256) void pg_front_syrk_kernel(const int* __restric
     }
 }
 
-// x1 = W^T (y1 - L21^T x2) for one panel: one workgroup of 1024 threads.  x2 (the rows below the panel, inside the front
-// and in its boundary) is gathered into LDS once; ten row slots accumulate the 96 column sums, folded in slot order.
-__global__ __launch_bounds__(1024) void pg_front_bwd_kernel(const int* __restrict__ it_front, const int* __restrict__ it_step, const pg_front* __restrict__ FD,
-                                                            const int* __restrict__ f_rows, const double* __restrict__ F, const double* __restrict__ R,
-                                                            double* __restrict__ x, const double* __restrict__ Wrow)
-{
-    extern __shared__ double s_bw[];               // W [96 x 96] | slot sums [10][96] | z [96] | x2 [nrows]
-    double* sW = s_bw;
-    double* s_acc = s_bw + (PG_PW * 6) * (PG_PW * 6);
-    double* sz = s_acc + 10 * (PG_PW * 6);
-    double* sx = sz + (PG_PW * 6);
-    const pg_front fd = FD[it_front[blockIdx.x]];
-    const int step = it_step[blockIdx.x], col0 = 96 * step;
-    const int n = min(96, fd.s6 - col0), p = fd.pan0 + step, ld = fd.ld;
-    const int row0 = col0 + n, nrows = fd.n6 - row0;
-    double wreg[9];
-    { const double* wr = Wrow + (size_t)p * (PG_PW * 6) * (PG_PW * 6);
-#pragma unroll
-      for (int e = 0; e < 9; ++e) wreg[e] = wr[e * 1024 + threadIdx.x]; }
-    for (int i = threadIdx.x; i < nrows; i += 1024) { const int g = row0 + i; sx[i] = x[(size_t)f_rows[fd.rowptr + g / 6] * 6 + g % 6]; }
-    __syncthreads();
-    {
-        const int slot = threadIdx.x / 96, cc = threadIdx.x - slot * 96;
-        if (slot < 10) {
-            double acc0 = 0, acc1 = 0;
-            if (cc < n) {
-                const double* __restrict__ Ab = F + fd.off + (size_t)row0 * ld + col0 + cc;
-                int i = slot;
-                for (; i + 10 < nrows; i += 20) { acc0 += Ab[(size_t)i * ld] * sx[i]; acc1 += Ab[(size_t)(i + 10) * ld] * sx[i + 10]; }
-                if (i < nrows) acc0 += Ab[(size_t)i * ld] * sx[i];
-            }
-            s_acc[slot * (PG_PW * 6) + cc] = acc0 + acc1;
-        }
-    }
-#pragma unroll
-    for (int e = 0; e < 9; ++e) sW[e * 1024 + threadIdx.x] = wreg[e];
-    __syncthreads();
-    if ((int)threadIdx.x < n) {
-        const int gj = threadIdx.x;
-        double v = R[fd.roff + col0 + gj];
-        for (int g = 0; g < 10; ++g) v -= s_acc[g * (PG_PW * 6) + gj];
-        sz[gj] = v;
-    }
-    __syncthreads();
-    // x[i] = sum_{k >= i} W[k][i] z[k], ascending k, two interleaved partial sums
-    if ((int)threadIdx.x < n) {
-        const int i = threadIdx.x;
-        double v0 = 0, v1 = 0;
-        int k = i;
-        for (; k + 1 < n; k += 2) { v0 += sW[k * (PG_PW * 6) + i] * sz[k]; v1 += sW[(k + 1) * (PG_PW * 6) + i] * sz[k + 1]; }
-        if (k < n) v0 += sW[k * (PG_PW * 6) + i] * sz[k];
-        x[(size_t)fd.c0 * 6 + col0 + i] = v0 + v1;
-    }
-}
-
-
-// ---- panel kernels without an explicit inverse: the whole 96 x 96 panel lives in the registers of ONE wavefront as 16 x 16
+// ---- panel kernels without an explicit inverse: the 96 x 96 panel lives in registers as 16 x 16
 // MFMA accumulator tiles and is factorised RIGHT-LOOKING IN BLOCKS OF FOUR COLUMNS, every rank-4 update being one
 // v_mfma_f64_16x16x4_f64 per tile (K = 4 is exactly one instruction).  Tile (T, I), T <= I, holds the symmetric matrix
 // TRANSPOSED: D[i][j] = M[16 I + j][16 T + i], i.e. lane (j = l & 15, q = l >> 4), register v holds M[16 I + j][16 T + q + 4 v].
 // In that layout the four pivot columns p_k = 16 t + 4 b + k of tile row I are register b of lanes (j, k): exactly the MFMA
 // operand layout (A: [i][k] on lane (i, k); B: [k][j] on lane (j, k)), so no data moves between the pivot solve and the update:
 //     M44 (4 x 4 pivot block)  -> 10 v_readlane pairs -> Cholesky + inverse Linv, the same scalars on every lane
-//     LP_I(j, k) = sum_{m <= k} P_I(j, m) Linv[k][m]     three lane shuffles per tile row (P = register b of tile (t, I))
+//     LP_I = Linv x P_I^T                                 one MFMA per tile (P = register b of tile (t, I)), result in operand layout
 //     tile (T', I') -= LP_T' LP_I'^T                      one MFMA per tile, A = -LP_T', B = LP_I'
-// No LDS, no barriers, no explicit L11^-1: the kernels below the panel (row solve, back-substitution) repeat the same 4-column
+// No explicit L11^-1: the kernels below the panel (row solve, back-substitution) repeat the same 4-column
 // steps with the stored Linv blocks.  The right-hand side rides along as row 96 of the matrix (tile row 6): the Cholesky factor
 // of the augmented matrix carries y = L11^-1 b in that row.
 #define PG_NB4 24                                   // 4-column blocks per panel
@@ -1087,98 +744,7 @@ __device__ inline int pg_chol4_inv(const double* m, double* li)
     li[6] = -(l30 * r0 + l31 * li[1] + l32 * li[3]) * r3; li[7] = -(l31 * r1 + l32 * li[4]) * r3; li[8] = -(l32 * r2) * r3;
     return bad;
 }
-__device__ inline double pg_shfl(double v, int src) { return __shfl(v, src, 64); }
-
-__global__ __launch_bounds__(64) void pg_front_diag2_kernel(const int* __restrict__ it_front, const int* __restrict__ it_step, const pg_front* __restrict__ FD,
-                                                            double* __restrict__ F, double* __restrict__ R, int* __restrict__ fail, double* __restrict__ Tinv)
-{
-    const pg_front fd = FD[it_front[blockIdx.x]];
-    const int step = it_step[blockIdx.x], col0 = 96 * step;
-    const int n = min(96, fd.s6 - col0), p = fd.pan0 + step, ld = fd.ld;
-    double* __restrict__ A = F + fd.off + (size_t)col0 * ld + col0;
-    double* __restrict__ rr = R + fd.roff + col0;
-    const int l = threadIdx.x, j = l & 15, q = l >> 4;
-    pg_d4 S[6][7];                                  // S[T][I], T <= I; I = 6 is the right-hand-side row
-#pragma unroll
-    for (int T = 0; T < 6; ++T)
-#pragma unroll
-        for (int I = T; I < 7; ++I)
-#pragma unroll
-            for (int v = 0; v < 4; ++v) {
-                const int row = 16 * I + j, col = 16 * T + q + 4 * v;
-                double val;
-                if (I == 6) val = (j == 0 && col < n) ? rr[col] : 0.0;
-                else if (row < n && col < n) val = col <= row ? A[(size_t)row * ld + col] : A[(size_t)col * ld + row];
-                else val = row == col ? 1.0 : 0.0;               // identity padding up to 96
-                S[T][I][v] = val;
-            }
-    int bad = 0;
-    double* __restrict__ tout = Tinv + (size_t)p * PG_NB4 * 16;
-#pragma unroll
-    for (int t = 0; t < 6; ++t) {
-        if (16 * t >= n) break;                     // uniform: the rest is identity padding
-#pragma unroll
-        for (int b = 0; b < 4; ++b) {
-            // pivot block -> every lane
-            double m[10], li[10];
-            {
-                const double dv = S[t][t][b];
-                int e = 0;
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-#pragma unroll
-                    for (int c = 0; c <= r; ++c) m[e++] = pg_readlane(dv, (4 * b + r) + 16 * c);
-            }
-            bad |= pg_chol4_inv(m, li);
-            if (l < 16) {                                        // Linv (row-major 4 x 4, zeros above the diagonal) for the row solve and the back-substitution
-                const int r = l >> 2, c = l & 3;
-                double v = 0.0;
-                if (c <= r) { const int e = r * (r + 1) / 2 + c;
-                    v = e == 0 ? li[0] : e == 1 ? li[1] : e == 2 ? li[2] : e == 3 ? li[3] : e == 4 ? li[4] : e == 5 ? li[5] : e == 6 ? li[6] : e == 7 ? li[7] : e == 8 ? li[8] : li[9]; }
-                tout[(4 * t + b) * 16 + l] = v;
-            }
-            // LP_I = P_I Linv^T without moving data between lanes: as the product Linv (4 x 4, padded to 16 x 4) x P_I^T the
-            // matrix core returns LP_I(j, k) in register 0 of lane (j, k) -- the operand layout the updates below need.
-            // A operand: lane (i, m) holds Linv[i][m] for i < 4, zero otherwise; B operand: P_I as it stands.
-            double lop;
-            {
-                const int e = j * (j + 1) / 2 + q;
-                lop = (j < 4 && q <= j) ? (e == 0 ? li[0] : e == 1 ? li[1] : e == 2 ? li[2] : e == 3 ? li[3] : e == 4 ? li[4] : e == 5 ? li[5] : e == 6 ? li[6] : e == 7 ? li[7] : e == 8 ? li[8] : li[9]) : 0.0;
-            }
-            double LP[7];
-#pragma unroll
-            for (int I = 0; I < 7; ++I) {
-                if (I < t) { LP[I] = 0.0; continue; }
-                const pg_d4 zero4 = { 0.0, 0.0, 0.0, 0.0 };
-                const pg_d4 r4 = __builtin_amdgcn_mfma_f64_16x16x4f64(lop, S[t][I][b], zero4, 0, 0, 0);
-                double v = r4[0];
-                if (I == t) { const int rj = j - 4 * b; if (rj < 0 || (rj < 4 && q > rj)) v = 0.0; }     // rows above the block; zeros of L44
-                LP[I] = v;
-                S[t][I][b] = v;                                  // the finished four columns of L (rows of tile row I)
-            }
-#pragma unroll
-            for (int T2 = t; T2 < 6; ++T2) {
-                double a = -LP[T2];
-                if (T2 == t && j < 4 * b + 4) a = 0.0;           // only the rows below the pivot block are updated
-#pragma unroll
-                for (int I2 = T2; I2 < 7; ++I2) S[T2][I2] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, LP[I2], S[T2][I2], 0, 0, 0);
-            }
-        }
-    }
-    if (bad && l == 0) *fail = 1;
-#pragma unroll
-    for (int T = 0; T < 6; ++T)
-#pragma unroll
-        for (int I = T; I < 7; ++I)
-#pragma unroll
-            for (int v = 0; v < 4; ++v) {
-                const int row = 16 * I + j, col = 16 * T + q + 4 * v;
-                if (I == 6) { if (j == 0 && col < n) rr[col] = S[T][I][v]; }
-                else if (row < n && col <= row) A[(size_t)row * ld + col] = S[T][I][v];
-            }
-}
-
-// The same panel factorisation on FOUR wavefronts: tile column I (= tile row I of the matrix) belongs to wavefront I mod 4, so a
+// The panel factorisation on FOUR wavefronts: tile column I (= tile row I of the matrix) belongs to wavefront I mod 4, so a
 // wavefront holds at most nine tiles and a quarter of the updates.  Per 4-column block:
 //     pivot wavefront (owner of tile (t, t)):  M44 -> Cholesky + inverse -> Linv into LDS                     barrier
 //     every wavefront:  LP_I = Linv x P_I^T (one MFMA) for its tile columns I >= t, LP_I into LDS              barrier
@@ -2292,7 +1858,7 @@ static int pg_solve_impl(dsss_ctx* c, const double* dr6, int total, const dsss_l
     // ---- early device set-up (nothing here reads S)
     pose_t *d_X, *d_Xn, *d_meas, *d_emeas; int *d_ea, *d_eb, *d_adj_ptr, *d_adj_edge, *d_perm;
     double *d_ew, *d_r, *d_Ji, *d_D, *d_C, *d_g, *d_delta, *d_E, *d_Dl, *d_gi, *d_sDL, *d_sDR, *d_sGL, *d_sGR, *d_sS, *d_L, *d_x, *d_part, *d_scal;
-    double *d_F, *d_R, *d_ubin, *d_aval, *d_Wsw, *d_Wrow, *d_Uvec;
+    double *d_F, *d_R, *d_ubin, *d_aval;
     int *d_colptr, *d_rowidx, *d_rlptr, *d_rlcol, *d_rlpos, *d_rlrow, *d_binptr, *d_bincols, *d_dest, *d_fail, *d_map; long long* d_mapptr;
     int *d_binroot_ptr, *d_binroot_idx, *d_broot_b, *d_broot_of_col, *d_anc_first, *d_anc_rel, *d_rel, *d_fa_src, *d_fa_col, *d_fa_tr, *d_frows, *d_xr_ptr, *d_xr_child, *d_xr_row, *d_fa_rowptr;
     long long* d_broot_uoff; pg_front* d_FD; pg_child* d_CH;
@@ -2463,19 +2029,12 @@ static int pg_solve_impl(dsss_ctx* c, const double* dr6, int total, const dsss_l
     const long long mapsz = S.mapptr[ns];
     if (mapsz > (1LL << 31)) { dv.release(); DSSS_FAIL(c, DSSS_E_CAPACITY, "update map of %lld entries", mapsz); }
     TRY(dv.alloc(c, &d_map, (size_t)mapsz));
-    // per panel: W = L11^-1 (96 x 96, zero padded) in MFMA operand order and row-major, u = W^T y
-    { const size_t wn = (size_t)std::max(npan, 1) * (PG_PW * 6) * (PG_PW * 6); TRY(dv.alloc(c, &d_Wsw, wn)); TRY(dv.alloc(c, &d_Wrow, wn)); TRY(dv.alloc(c, &d_Uvec, (size_t)std::max(npan, 1) * (PG_PW * 6)));
-      HIPCHK(c, hipMemsetAsync(d_Wsw, 0, wn * sizeof(double), c->stream)); HIPCHK(c, hipMemsetAsync(d_Wrow, 0, wn * sizeof(double), c->stream)); }
-    static const bool old_panel = getenv("DSSS_PG_PANEL") && !strcmp(getenv("DSSS_PG_PANEL"), "inverse");      // A/B: the explicit-inverse panel kernels
     unsigned long long* d_stamps = nullptr; if (getenv("DSSS_PG_STAMPS")) TRY(dv.alloc(c, &d_stamps, 16));
-    static const bool one_wave = getenv("DSSS_PG_PANEL") && !strcmp(getenv("DSSS_PG_PANEL"), "onewave");
     static const bool diag3_panel = getenv("DSSS_PG_PANEL") && !strcmp(getenv("DSSS_PG_PANEL"), "diag3");          // A/B: two barriers per block
     double* d_Tinv; TRY(dv.alloc(c, &d_Tinv, (size_t)std::max(npan, 1) * PG_NB4 * 16));
-    const int bwd_lds = old_panel ? PG_BWD_LDS(max_n6) : (int)(((PG_PW * 6) * PG_BWD2_LD + PG_NB4 * 16 + 10 * (PG_PW * 6) + std::min(max_n6, PG_BWD2_SX) + 16) * sizeof(double));
+    const int bwd_lds = (int)(((PG_PW * 6) * PG_BWD2_LD + PG_NB4 * 16 + 10 * (PG_PW * 6) + std::min(max_n6, PG_BWD2_SX) + 16) * sizeof(double));
     if (bwd_lds > 160 * 1024) { dv.release(); DSSS_FAIL(c, DSSS_E_CAPACITY, "front of %d scalar rows: back-substitution needs %d B of LDS", max_n6, bwd_lds); }
-    {   // pg_front_diag_kernel keeps the panel and its inverse (2 x 75 KB) in dynamic LDS, pg_front_bwd_kernel W and x2
-        hipFuncSetAttribute((const void*)pg_front_diag_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, PG_DIAG_LDS);
-        hipFuncSetAttribute((const void*)pg_front_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    {   // the back-substitution keeps L11, the slot sums and x2 in dynamic LDS
         hipFuncSetAttribute((const void*)pg_front_bwd2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipGetLastError();
     }
@@ -2517,9 +2076,7 @@ static int pg_solve_impl(dsss_ctx* c, const double* dr6, int total, const dsss_l
                                                d_fa_rowptr, d_fa_src, d_fa_col, d_fa_tr, d_aval, d_x, d_F, d_R); }
                         if (nit == 0) continue;
                         { dsss_scope s3(c, DSSS_K_PG_DIAG, H.fl_diag[l]);
-                          if (old_panel) hipLaunchKernelGGL(pg_front_diag_kernel, dim3(nit), dim3(256), PG_DIAG_LDS, st, itf, its, d_FD, d_F, d_R, d_fail, d_Wsw, d_Wrow, d_Uvec);
-                          else if (one_wave) hipLaunchKernelGGL(pg_front_diag2_kernel, dim3(nit), dim3(64), 0, st, itf, its, d_FD, d_F, d_R, d_fail, d_Tinv);
-                          else if (!diag3_panel) hipLaunchKernelGGL(pg_front_diag4_kernel, dim3(nit), dim3(256), 0, st, itf, its, d_FD, d_F, d_R, d_fail, d_Tinv);
+                          if (!diag3_panel) hipLaunchKernelGGL(pg_front_diag4_kernel, dim3(nit), dim3(256), 0, st, itf, its, d_FD, d_F, d_R, d_fail, d_Tinv);
                           else {
                               hipLaunchKernelGGL(pg_front_diag3_kernel, dim3(nit), dim3(256), 0, st, itf, its, d_FD, d_F, d_R, d_fail, d_Tinv, d_stamps);
                               if (d_stamps && l == H.nlev - 1) { unsigned long long hs[16]; hipMemcpyAsync(hs, d_stamps, sizeof hs, hipMemcpyDeviceToHost, st); hipStreamSynchronize(st);
@@ -2527,8 +2084,7 @@ static int pg_solve_impl(dsss_ctx* c, const double* dr6, int total, const dsss_l
                           } }
                         if (H.trsm_chunks[l] > 0) {
                             { dsss_scope s4(c, DSSS_K_PG_TRSM, H.fl_trsm[l]);
-                              if (old_panel) hipLaunchKernelGGL(pg_front_trsm_kernel, dim3(nit, H.trsm_chunks[l]), dim3(256), 0, st, itf, its, d_FD, d_F, d_R, d_Wsw, d_Uvec);
-                              else hipLaunchKernelGGL(pg_front_trsm2_kernel, dim3(nit, H.trsm_chunks[l]), dim3(256), 0, st, itf, its, d_FD, d_F, d_R, d_Tinv); }
+                              hipLaunchKernelGGL(pg_front_trsm2_kernel, dim3(nit, H.trsm_chunks[l]), dim3(256), 0, st, itf, its, d_FD, d_F, d_R, d_Tinv); }
                             { dsss_scope s5(c, DSSS_K_PG_ACC, H.fl_syrk[l]);
                               if (ntl > 0) hipLaunchKernelGGL(pg_front_syrk_kernel, dim3(ntl), dim3(256), 0, st, itf, its, d_FD, Dv.tile_item + H.tile_ptr[l], Dv.tile_ij + H.tile_ptr[l], d_F); }
                         }
@@ -2539,8 +2095,7 @@ static int pg_solve_impl(dsss_ctx* c, const double* dr6, int total, const dsss_l
                         const int nit = H.lv_ptr[l + 1] - H.lv_ptr[l];
                         if (nit == 0) continue;
                         dsss_scope s6(c, DSSS_K_PG_BWD, H.fl_bwd[l]);
-                        if (old_panel) hipLaunchKernelGGL(pg_front_bwd_kernel, dim3(nit), dim3(1024), bwd_lds, st, Dv.lv_front + H.lv_ptr[l], Dv.lv_step + H.lv_ptr[l], d_FD, d_frows, d_F, d_R, d_x, d_Wrow);
-                        else hipLaunchKernelGGL(pg_front_bwd2_kernel, dim3(nit), dim3(1024), bwd_lds, st, Dv.lv_front + H.lv_ptr[l], Dv.lv_step + H.lv_ptr[l], d_FD, d_frows, d_F, d_R, d_x, d_Tinv);
+                        hipLaunchKernelGGL(pg_front_bwd2_kernel, dim3(nit), dim3(1024), bwd_lds, st, Dv.lv_front + H.lv_ptr[l], Dv.lv_step + H.lv_ptr[l], d_FD, d_frows, d_F, d_R, d_x, d_Tinv);
                     }
                 };
                 run_levels(SO, DO);
