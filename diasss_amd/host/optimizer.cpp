@@ -16,6 +16,8 @@ namespace Diasss
 
 bool Optimizer::USE_ANNO = 0;
 bool Optimizer::ADD_LC = 1;
+bool Optimizer::EVAL_1 = 0;
+bool Optimizer::EVAL_2 = 0;
 
 std::vector<Vector7> Optimizer::GetKpsPairs(const bool &use_anno, const cv::Mat &kps, const int &id_s, const int &id_t,
                                             const std::vector<double> &alts_s, const std::vector<double> &gras_s,
@@ -135,6 +137,143 @@ void Optimizer::TrajOptimizationAll(std::vector<Frame> &AllFrames)
     std::vector<cv::Mat> dr_poses_all;
     for (size_t i = 0; i < F; i++) dr_poses_all.push_back(AllFrames[i].dr_poses);
     SaveTrajactoryAll(poses12, unique_id, dr_poses_all);
+    // --- evaluation with the annotated keypoints (optimizer.cpp:288-312)
+    if (EVAL_1 || EVAL_2) {
+        std::vector<std::vector<Vector7>> anno_pairs;
+        std::vector<std::pair<int,int>> ids;
+        for (size_t i = 0; i < F; i++)
+            for (size_t j = i + 1; j < F; j++) {
+                anno_pairs.push_back(GetKpsPairs(true, AllFrames[i].anno_kps, AllFrames[i].img_id, AllFrames[j].img_id, AllFrames[i].altitudes,
+                                                 AllFrames[i].ground_ranges, AllFrames[j].altitudes, AllFrames[j].ground_ranges));
+                ids.push_back(std::make_pair((int)i, (int)j));
+            }
+        EvaluateByAnnosAll(poses12, unique_id, AllFrames, anno_pairs, ids);
+    }
+}
+
+// Frame::GetGeoImg for one bin (frame.cpp:126-165, tf = 0): starboard = columns >= M/2 at yaw + PI/2, port = columns < M/2 at yaw - PI/2
+static void geo_of(const cv::Mat &dr, const std::vector<double> &gr, int M, int row, int col, double &x, double &y)
+{
+    const double PI = 3.14159265358979323846;
+    const double* P = dr.ptr<double>(row);
+    const int half = M / 2;
+    int idx; double ang;
+    if (col >= half) { idx = col - half; ang = P[2] + PI / 2; }
+    else { idx = half - col; if (idx > half - 1) idx = half - 1; ang = P[2] - PI / 2; }
+    x = P[3] + gr[idx] * std::cos(ang); y = P[4] + gr[idx] * std::sin(ang);
+}
+static void rodrigues(const double* w, double* R);
+static void rpy_of(const double* R, double* rpy);
+
+std::vector<Optimizer::AnnoStats> Optimizer::EvaluateByAnnosAll(const std::vector<double> &poses12, const std::vector<std::vector<int>> &unique_id,
+                                                                const std::vector<Frame> &AllFrames,
+                                                                const std::vector<std::vector<Vector7>> &kps_pairs_all,
+                                                                const std::vector<std::pair<int,int>> &img_pairs_ids)
+{
+    const double PI = 3.14159265358979323846;
+    const bool save_result = true, show_stats = true;                       // optimizer.cpp:1578
+    const char* dir = std::getenv("DSSS_OUT_DIR");
+    const std::string base = dir ? std::string(dir) + "/" : std::string("../");
+    auto open_out = [&](std::ofstream &f, const std::string &rel) { if (save_result) f.open((base + rel).c_str(), std::ios::trunc); };
+    std::vector<AnnoStats> out(kps_pairs_all.size());
+    for (size_t i = 0; i < kps_pairs_all.size(); i++) { out[i].img_s = img_pairs_ids[i].first; out[i].img_t = img_pairs_ids[i].second; out[i].n = (int)kps_pairs_all[i].size(); }
+    if (EVAL_2) {
+        // every landmark is triangulated twice (dead-reckoning poses, estimated poses): two batched device calls for all pairs
+        std::vector<double> kp7, in_dr, in_est;
+        for (size_t i = 0; i < kps_pairs_all.size(); i++) {
+            const Frame &S = AllFrames[img_pairs_ids[i].first], &T = AllFrames[img_pairs_ids[i].second];
+            for (const Vector7 &v : kps_pairs_all[i]) {
+                const int id_s = (int)v[0], id_ss = (int)v[1], id_t = (int)v[3], id_tt = (int)v[4];
+                double xs, ys, xt, yt;
+                geo_of(S.dr_poses, S.ground_ranges, S.raw_img.cols, id_s, id_ss, xs, ys);
+                geo_of(T.dr_poses, T.ground_ranges, T.raw_img.cols, id_t, id_tt, xt, yt);
+                const double ini[3] = { (xs + xt) / 2, (ys + yt) / 2,
+                                        ((S.dr_poses.at<double>(id_s, 5) - S.altitudes[id_s]) + (T.dr_poses.at<double>(id_t, 5) - T.altitudes[id_t])) / 2 };
+                kp7.insert(kp7.end(), v.begin(), v.end());
+                double r27[27];
+                rodrigues(S.dr_poses.ptr<double>(id_s), r27); rodrigues(T.dr_poses.ptr<double>(id_t), r27 + 12);
+                for (int k = 0; k < 3; ++k) { r27[9 + k] = S.dr_poses.at<double>(id_s, 3 + k); r27[21 + k] = T.dr_poses.at<double>(id_t, 3 + k); r27[24 + k] = ini[k]; }
+                in_dr.insert(in_dr.end(), r27, r27 + 27);
+                const double* Es = poses12.data() + (size_t)unique_id[img_pairs_ids[i].first][id_s] * 12;
+                const double* Et = poses12.data() + (size_t)unique_id[img_pairs_ids[i].second][id_t] * 12;
+                std::copy(Es, Es + 12, r27); std::copy(Et, Et + 12, r27 + 12);
+                in_est.insert(in_est.end(), r27, r27 + 27);
+            }
+        }
+        const int n = (int)(kp7.size() / 7);
+        std::vector<double> o_dr((size_t)std::max(n, 1) * 7), o_est((size_t)std::max(n, 1) * 7);
+        if (n > 0) {
+            Device::check(dsss_triangulate_poses(Device::ctx(), kp7.data(), in_dr.data(), n, o_dr.data()), "dsss_triangulate_poses");
+            Device::check(dsss_triangulate_poses(Device::ctx(), kp7.data(), in_est.data(), n, o_est.data()), "dsss_triangulate_poses");
+        }
+        // out7 = landmark (3) and the four consistency figures of the call: |range_s|, |plane_s|, |range_t|, |plane_t| (dsss.h)
+        std::ofstream a1, a2, a3, a4;
+        open_out(a1, "result/pr_errors/dr_range_e_avg.txt"); open_out(a2, "result/pr_errors/dr_plane_e_avg.txt");
+        open_out(a3, "result/pr_errors/est_range_e_avg.txt"); open_out(a4, "result/pr_errors/est_plane_e_avg.txt");
+        size_t q = 0;
+        for (size_t i = 0; i < kps_pairs_all.size(); i++) {
+            AnnoStats &st = out[i];
+            std::ofstream f1, f2, f3, f4;
+            open_out(f1, "result/pr_errors/dr_range_e_" + std::to_string(i) + ".txt"); open_out(f2, "result/pr_errors/dr_plane_e_" + std::to_string(i) + ".txt");
+            open_out(f3, "result/pr_errors/est_range_e_" + std::to_string(i) + ".txt"); open_out(f4, "result/pr_errors/est_plane_e_" + std::to_string(i) + ".txt");
+            int g1 = 0, g2 = 0;
+            for (size_t j = 0; j < kps_pairs_all[i].size(); j++, q++) {
+                const double* d = o_dr.data() + q * 7; const double* e = o_est.data() + q * 7;
+                const double range_dr = (d[3] + d[5]) / 2, plane_dr = (d[4] + d[6]) / 2, range_est = (e[3] + e[5]) / 2, plane_est = (e[6] + e[4]) / 2;
+                if (f1.is_open()) { f1 << range_dr << std::endl; f2 << plane_dr << std::endl; f3 << range_est << std::endl; f4 << plane_est << std::endl; }
+                g1 += range_dr > range_est; g2 += plane_dr > plane_est;
+                st.range_dr += range_dr; st.plane_dr += plane_dr; st.range_est += range_est; st.plane_est += plane_est;
+            }
+            const double m = (double)kps_pairs_all[i].size();
+            st.good_range = g1 / m * 100; st.good_plane = g2 / m * 100;
+            st.range_dr /= m; st.plane_dr /= m; st.range_est /= m; st.plane_est /= m;
+            if (a1.is_open()) { a1 << st.range_dr << std::endl; a2 << st.plane_dr << std::endl; a3 << st.range_est << std::endl; a4 << st.plane_est << std::endl; }
+            if (show_stats) {
+                std::cout << "Metric Statics: " << st.good_range << " " << st.good_plane << " " << kps_pairs_all[i].size() << " " << st.img_s << " " << st.img_t << std::endl;
+                std::cout << "Avg R and P (DR/EST): " << st.range_dr << "/" << st.range_est << " " << st.plane_dr << "/" << st.plane_est << std::endl << std::endl;
+            }
+        }
+    }
+    if (EVAL_1) {
+        for (size_t i = 0; i < kps_pairs_all.size(); i++) {
+            AnnoStats &st = out[i];
+            const Frame &S = AllFrames[img_pairs_ids[i].first], &T = AllFrames[img_pairs_ids[i].second];
+            std::ofstream f1, f2, f3;
+            open_out(f1, "result/anno_errors/dr_lm_dist_" + std::to_string(i) + ".txt"); open_out(f2, "result/anno_errors/est_lm_dist_" + std::to_string(i) + ".txt");
+            open_out(f3, "result/anno_errors/lm_dist_compare_" + std::to_string(i) + ".txt");
+            int good = 0;
+            for (const Vector7 &v : kps_pairs_all[i]) {
+                const int id_s = (int)v[0], id_ss = (int)v[1], id_t = (int)v[3], id_tt = (int)v[4];
+                double xs, ys, xt, yt;
+                geo_of(S.dr_poses, S.ground_ranges, S.raw_img.cols, id_s, id_ss, xs, ys);
+                geo_of(T.dr_poses, T.ground_ranges, T.raw_img.cols, id_t, id_tt, xt, yt);
+                const double ix = xs - xt, iy = ys - yt, ini = std::sqrt(ix * ix + iy * iy);
+                auto est_geo = [&](const Frame &Fm, int uid, int bin, double &gx, double &gy) {          // optimizer.cpp:1806-1832
+                    const double* E = poses12.data() + (size_t)uid * 12;
+                    double rpy[3]; rpy_of(E, rpy);
+                    const int half = Fm.raw_img.cols / 2;
+                    if (bin < half) { const int g = half - bin; gx = E[9] + Fm.ground_ranges[g] * std::cos(rpy[2] + PI / 2 - PI); gy = E[10] + Fm.ground_ranges[g] * std::sin(rpy[2] + PI / 2 - PI); }
+                    else { const int g = bin - half; gx = E[9] + Fm.ground_ranges[g] * std::cos(rpy[2] - PI / 2 - PI); gy = E[10] + Fm.ground_ranges[g] * std::sin(rpy[2] - PI / 2 - PI); }
+                };
+                double sx, sy, tx, ty;
+                est_geo(S, unique_id[img_pairs_ids[i].first][id_s], id_ss, sx, sy);
+                est_geo(T, unique_id[img_pairs_ids[i].second][id_t], id_tt, tx, ty);
+                const double fx = sx - tx, fy = sy - ty, fin = std::sqrt(fx * fx + fy * fy);
+                st.x_dr += std::fabs(ix); st.y_dr += std::fabs(iy); st.all_dr += std::fabs(ini);
+                st.x_est += std::fabs(fx); st.y_est += std::fabs(fy); st.all_est += std::fabs(fin);
+                good += ini > fin;
+                if (f1.is_open()) { f1 << ini << std::endl; f2 << fin << std::endl; f3 << ini - fin << std::endl; }
+            }
+            const double m = (double)kps_pairs_all[i].size();
+            st.good_dist = good / m * 100;
+            st.x_dr /= m; st.y_dr /= m; st.all_dr /= m; st.x_est /= m; st.y_est /= m; st.all_est /= m;
+            if (show_stats) {
+                std::cout << "LM Metric Statics: " << st.good_dist << " " << kps_pairs_all[i].size() << " " << st.img_s << " " << st.img_t << std::endl;
+                std::cout << "Avg X,Y,NORM (DR/EST): " << st.x_dr << "/" << st.x_est << " " << st.y_dr << "/" << st.y_est << " " << st.all_dr << "/" << st.all_est << std::endl << std::endl;
+            }
+        }
+    }
+    return out;
 }
 
 static void rpy_of(const double* R, double* rpy)

@@ -25,6 +25,9 @@ namespace Diasss
         // the synthetic configs need the matcher's output, so the default here is 0
         static bool USE_ANNO;
         static bool ADD_LC;
+        // the two annotation evaluators of EvaluateByAnnosAll; the reference hard-codes both to 0 (optimizer.cpp:1579)
+        static bool EVAL_1;
+        static bool EVAL_2;
 
         void static TrajOptimizationAll(std::vector<Frame> &AllFrames);                                   // optimizer.h:43
 
@@ -44,6 +47,21 @@ namespace Diasss
         typedef std::array<double, 3> Point3;
         Point3 static TriangulateOneLandmark(const Vector7 &kps_pair, const Pose3 &Ts_s, const Pose3 &Ts_t,
                                              const Pose3 &Tp_s, const Pose3 &Tp_t, const Point3 &lm_ini);
+
+        // optimizer.h:84-91 / optimizer.cpp:1568-1886: consistency of the annotated keypoint pairs under the dead-reckoning and the
+        // estimated poses.  eval_2 (:1581-1762): landmark triangulated from both pings (TriangulateOneLandmark), slant-range and
+        // plane error per pair; eval_1 (:1764-1883): distance of the two geo-referenced observations of the landmark.  One entry per
+        // frame pair; the reference prints these figures ("Metric Statics", "Avg R and P", "LM Metric Statics", "Avg X,Y,NORM") and
+        // writes the per-match values under ../result/{pr_errors,anno_errors}/ -- here under $DSSS_OUT_DIR or ../ when the folder exists.
+        struct AnnoStats {
+            int img_s = 0, img_t = 0, n = 0;
+            double good_range = 0, good_plane = 0, range_dr = 0, range_est = 0, plane_dr = 0, plane_est = 0;          // eval_2 (percent, averages)
+            double good_dist = 0, x_dr = 0, x_est = 0, y_dr = 0, y_est = 0, all_dr = 0, all_est = 0;                   // eval_1
+        };
+        std::vector<AnnoStats> static EvaluateByAnnosAll(const std::vector<double> &poses12, const std::vector<std::vector<int>> &unique_id,
+                                                         const std::vector<Frame> &AllFrames,
+                                                         const std::vector<std::vector<Vector7>> &kps_pairs_all,
+                                                         const std::vector<std::pair<int,int>> &img_pairs_ids);
 
         // optimizer.h:73-74; poses12 = total x 12 (R row-major, t) instead of gtsam::Values
         void static SaveTrajactoryAll(const std::vector<double> &poses12, const std::vector<std::vector<int>> &unique_id,

@@ -1,6 +1,6 @@
 // diasss_amd/host/test_demo.cpp -- the driver loop of /root/reference/src/diasss2.cpp:83-101 against the drop-in
 // classes.  Two input forms:
-//   test_demo --image DIR --pose DIR --altitude DIR --groundrange DIR [--annotation DIR] [--min-overlap X] [--use-anno 0|1] [--add-lc 0|1]
+//   test_demo --image DIR --pose DIR --altitude DIR --groundrange DIR [--annotation DIR] [--min-overlap X] [--use-anno 0|1] [--add-lc 0|1] [--eval 0..3]
 //       the reference's own layout (diasss2.cpp:33-66) through Util::LoadInputData: OpenCV FileStorage XML / YAML + txt
 //   test_demo <dir with frame_%03d.bin> [min_overlap]
 //       flat binary dumps written by tools/export_survey.py:
@@ -29,6 +29,7 @@ int main(int argc, char** argv)
             else if (k == "--groundrange") dG = v; else if (k == "--annotation") dN = v; else if (k == "--min-overlap") MIN_OVERLAP = (float)atof(v.c_str());
             else if (k == "--use-anno") Optimizer::USE_ANNO = atoi(v.c_str()) != 0;      // optimizer.cpp:26 hard-codes 1 (hand annotations); default here 0
             else if (k == "--add-lc") Optimizer::ADD_LC = atoi(v.c_str()) != 0;
+            else if (k == "--eval") { Optimizer::EVAL_1 = (atoi(v.c_str()) & 1) != 0; Optimizer::EVAL_2 = (atoi(v.c_str()) & 2) != 0; }      // optimizer.cpp:1579 hard-codes both off
         }
         if (dI.empty() || dP.empty() || dA.empty() || dG.empty()) { std::cout << "Please provide the image, pose, altitude and groundrange folders..." << std::endl; return 0; }
         std::vector<cv::Mat> vmImgs, vmPoses, vmAnnos; std::vector<std::vector<double>> vvAltts, vvGranges;

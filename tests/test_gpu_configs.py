@@ -123,11 +123,76 @@ def test_config_C1_substitute_through_test_demo(orc, tmp_path):
     assert est0.shape == (F * N, 6) and len(e0) > 20
     _cmp_traj(est0, o0)
     # USE_ANNO = 1: annotations -> constraints (the shipped default of the reference)
-    est1, log = _run_demo(tmp_path, d, ["--annotation", d["annotation"], "--use-anno", "1"], "a")
+    est1, log = _run_demo(tmp_path, d, ["--annotation", d["annotation"], "--use-anno", "1", "--eval", "3"], "a")
     e1, o1, s1, _, _ = _oracle_backend(orc, fr, F, N, M, lambda i, j: annos[i].astype(np.float64)[:, :6])
     assert 0 < len(e1) < len(e0) and ("%d loop closures" % len(e1)) in log
     _cmp_traj(est1, o1)
     assert np.abs(est1 - est0).max() > 1e-6                                   # the two branches really are different solves
+    _check_anno_evaluators(orc, log, fr, annos, o1, F, N, M)
+
+
+def _check_anno_evaluators(orc, log, fr, annos, est12, F, N, M):
+    """EvaluateByAnnosAll (optimizer.cpp:1568-1886; both evaluators are switched off in the shipped reference): the figures
+    test_demo --eval 3 prints against the same figures from the oracle's primitives (orc_triangulate_one, orc_geo_at, Pose3)."""
+    import ctypes as C
+    import re
+    def pose12(p6):
+        T = orc.Pose(); orc.lib().orc_pose_from_rodrigues(orc.dp(np.ascontiguousarray(p6, np.float64)), C.byref(T))
+        return np.concatenate([np.array(T.R), np.array(T.t)])
+    def geo(f, row, col):
+        x = C.c_double(); y = C.c_double()
+        orc.lib().orc_geo_at(orc.dp(np.ascontiguousarray(fr[f]["pose"])), orc.dp(np.ascontiguousarray(fr[f]["gr"])), N, M, int(row), int(col), C.byref(x), C.byref(y))
+        return x.value, y.value
+    def sensor(T12, lm):
+        R = T12[:9].reshape(3, 3); return R.T @ (lm - T12[9:])
+    exp2, exp1 = [], []
+    for i in range(F):
+        for j in range(i + 1, F):
+            a, b = fr[i], fr[j]
+            kp7 = orc.get_kps_pairs(annos[i].astype(np.float64)[:, :6], j, a["alt"], a["gr"], b["alt"], b["gr"])
+            acc2 = np.zeros(4); g = np.zeros(3); acc1 = np.zeros(6)
+            for k in kp7:
+                ids, iss, idt, itt = int(k[0]), int(k[1]), int(k[3]), int(k[4])
+                xs, ys = geo(i, ids, iss); xt, yt = geo(j, idt, itt)
+                ini = np.array([(xs + xt) / 2, (ys + yt) / 2, ((a["pose"][ids, 5] - a["alt"][ids]) + (b["pose"][idt, 5] - b["alt"][idt])) / 2])
+                vals = []
+                for Ts, Tt in ((pose12(a["pose"][ids]), pose12(b["pose"][idt])), (est12[i * N + ids], est12[j * N + idt])):
+                    lm, _ = orc.triangulate_one(k, Ts, Tt, ini)
+                    ls, lt = sensor(Ts, lm), sensor(Tt, lm)
+                    vals.append(((abs(np.linalg.norm(ls) - k[2]) + abs(np.linalg.norm(lt) - k[5])) / 2, (abs(ls[0]) + abs(lt[0])) / 2))
+                (r_dr, p_dr), (r_est, p_est) = vals
+                acc2 += [r_dr, r_est, p_dr, p_est]; g[0] += r_dr > r_est; g[1] += p_dr > p_est
+                # eval_1: the two geo-referenced observations under DR and under the estimate (yaw of the estimated pose)
+                ix, iy = xs - xt, ys - yt
+                def est_geo(f, T12, col):
+                    yaw = np.arctan2(T12[3], T12[0]); half = M // 2
+                    if col < half: gi, ang = half - col, yaw + np.pi / 2 - np.pi
+                    else: gi, ang = col - half, yaw - np.pi / 2 - np.pi
+                    return T12[9] + fr[f]["gr"][gi] * np.cos(ang), T12[10] + fr[f]["gr"][gi] * np.sin(ang)
+                sx, sy = est_geo(i, est12[i * N + ids], iss); tx, ty = est_geo(j, est12[j * N + idt], itt)
+                fx, fy = sx - tx, sy - ty
+                acc1 += [abs(ix), abs(fx), abs(iy), abs(fy), np.hypot(ix, iy), np.hypot(fx, fy)]; g[2] += np.hypot(ix, iy) > np.hypot(fx, fy)
+            m = max(len(kp7), 1)
+            exp2.append((g[0] / m * 100, g[1] / m * 100, len(kp7), i, j) + tuple(acc2 / m))
+            exp1.append((g[2] / m * 100, len(kp7), i, j) + tuple(acc1 / m))
+    num = r"([-+0-9.eE]+|nan|-nan)"
+    got2 = re.findall(r"Metric Statics: %s %s (\d+) (\d+) (\d+)\nAvg R and P \(DR/EST\): %s/%s %s/%s" % ((num,) * 6), log)
+    got2 = [g for g in got2]
+    got1 = re.findall(r"LM Metric Statics: %s (\d+) (\d+) (\d+)\nAvg X,Y,NORM \(DR/EST\): %s/%s %s/%s %s/%s" % ((num,) * 7), log)
+    assert len(got2) == len(exp2) == F * (F - 1) // 2 and len(got1) == len(exp1)
+    checked = 0
+    for g, e in zip(got2, exp2):
+        assert (int(g[2]), int(g[3]), int(g[4])) == (e[2], e[3], e[4])
+        if e[2] == 0: continue
+        assert abs(float(g[0]) - e[0]) < 1e-3 and abs(float(g[1]) - e[1]) < 1e-3
+        for a_, b_ in zip((g[5], g[6], g[7], g[8]), e[5:]): assert abs(float(a_) - b_) <= 2e-5 * max(abs(b_), 1e-3) + 1e-7
+        checked += 1
+    for g, e in zip(got1, exp1):
+        assert (int(g[1]), int(g[2]), int(g[3])) == (e[1], e[2], e[3])
+        if e[1] == 0: continue
+        assert abs(float(g[0]) - e[0]) < 1e-3
+        for a_, b_ in zip(g[4:], e[4:]): assert abs(float(a_) - b_) <= 2e-5 * max(abs(b_), 1e-3) + 1e-7
+    assert checked >= 3
 
 
 def test_speckle_frame_candidate_capacity(orc):
