@@ -65,6 +65,28 @@ __device__ inline int chol6_fast(double* A, double* ri)
     }
     return bad;
 }
+// the same with 1 / L[j][j] left ON the diagonal (what the solves multiply by): no separate reciprocal array, twelve registers less
+__device__ inline int chol6_rdiag(double* A)
+{
+    int bad = 0;
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+        double d = A[j * 6 + j];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) if (k < j) d -= A[j * 6 + k] * A[j * 6 + k];
+        if (!(d > 0) || !isfinite(d)) { bad = 1; d = 1.0; }
+        const double r = rsqrt(d);
+        A[j * 6 + j] = r;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) if (i > j) {
+            double s = A[i * 6 + j];
+#pragma unroll
+            for (int k = 0; k < 6; ++k) if (k < j) s -= A[i * 6 + k] * A[j * 6 + k];
+            A[i * 6 + j] = s * r;
+        }
+    }
+    return bad;
+}
 // b (6 x nrhs, row-major) <- (L L^T)^-1 b
 __device__ inline void chol6_solve(const double* L, double* b, int nrhs)
 {
@@ -303,15 +325,15 @@ __global__ __launch_bounds__(256, 2) void pg_segment_kernel(int nseg, const int*
         for (int a = c; a < 36; a += PG_SEG_LANES) E[(size_t)i * 36 + a] = Ec[a];
         if (c < 6) gi[(size_t)i * 6 + c] = Gc[c];
         // (the compiler-only barriers keep the LDS reads of the later phases from being hoisted to the top of the step)
-        double Li[36], ri[6], y[6];
+        double Li[36], y[6];                                     // the factor with 1 / L_jj on its diagonal
 #pragma unroll
         for (int a = 0; a < 6; ++a)
 #pragma unroll
             for (int b2 = 0; b2 < 6; ++b2) Li[a * 6 + b2] = b2 <= a ? Dc[a * 6 + b2] : 0.0;
-        if (chol6_fast(Li, ri)) { *fail = 1; return; }          // every lane of the group sees the same pivot: they leave together
-        if (c == 0) {                                            // the factor, for the record (stored at the top of the next step);
+        if (chol6_rdiag(Li)) { *fail = 1; return; }              // every lane of the group sees the same pivot: they leave together
+        if (c == 0) {                                            // the factor, for the record (stored at the top of the next step): the
 #pragma unroll
-            for (int a = 0; a < 36; ++a) sh.L[a] = (a % 7 == 0) ? ri[a / 7] : Li[a];     // its diagonal as 1 / L_jj: the back-substitution multiplies
+            for (int a = 0; a < 36; ++a) sh.L[a] = Li[a];        // back-substitution multiplies by its diagonal too
         }
         PG_COMPILER_FENCE();
         // right-hand side of this lane: c < 6 row c of E (column of E^T), 6 <= c < 12 column c - 6 of C, c == 12 the gradient
@@ -322,9 +344,9 @@ __global__ __launch_bounds__(256, 2) void pg_segment_kernel(int nseg, const int*
             for (int q = 0; q < 6; ++q) y[q] = ysrc[q * ystr];
         }
 #pragma unroll
-        for (int a = 0; a < 6; ++a) { double t = y[a]; for (int k = 0; k < a; ++k) t -= Li[a * 6 + k] * y[k]; y[a] = t * ri[a]; }
+        for (int a = 0; a < 6; ++a) { double t = y[a]; for (int k = 0; k < a; ++k) t -= Li[a * 6 + k] * y[k]; y[a] = t * Li[a * 7]; }
 #pragma unroll
-        for (int a = 5; a >= 0; --a) { double t = y[a]; for (int k = a + 1; k < 6; ++k) t -= Li[k * 6 + a] * y[k]; y[a] = t * ri[a]; }
+        for (int a = 5; a >= 0; --a) { double t = y[a]; for (int k = a + 1; k < 6; ++k) t -= Li[k * 6 + a] * y[k]; y[a] = t * Li[a * 7]; }
         PG_COMPILER_FENCE();
         {   // E y: column c - 6 of E_next = -E X_C on lanes 6..11; accumulated into DL / GL on lanes 0..5 and 12
             double eo[6];
