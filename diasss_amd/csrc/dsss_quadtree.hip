@@ -134,7 +134,9 @@ __device__ inline void qt_divide_block(const qnode& P, qkey* __restrict__ keys0,
     __syncthreads();
 }
 
-__device__ inline qnode qt_child(const qnode& P, int c, const int* cnt)
+// qnode::leaf: bit 0 = the node holds one key; for the nodes of a PRE-SORTED level (see quadtree_kernel) bits 4..6 = depth and
+// bits 8.. = the path code (two bits per level), which is also where the node's keys start in the sorted array
+__device__ inline qnode qt_child(const qnode& P, int c, const int* cnt, bool presorted = false)
 {
     const int mx = P.x0 + (int)ceilf((float)(P.x1 - P.x0) / 2), my = P.y0 + (int)ceilf((float)(P.y1 - P.y0) / 2);
     qnode q;
@@ -142,8 +144,22 @@ __device__ inline qnode qt_child(const qnode& P, int c, const int* cnt)
     q.y0 = (c & 2) ? my : P.y0; q.y1 = (c & 2) ? P.y1 : my;
     int off = 0;
     for (int k = 0; k < c; ++k) off += cnt[k];
-    q.kbeg = P.kbeg + off; q.kcnt = cnt[c]; q.buf = P.buf ^ 1; q.leaf = cnt[c] == 1;
+    q.kbeg = P.kbeg + off; q.kcnt = cnt[c]; q.buf = presorted ? 1 : P.buf ^ 1; q.leaf = cnt[c] == 1;
+    if (presorted) q.leaf |= ((((P.leaf >> 4) & 7) + 1) << 4) | ((((P.leaf >> 8) << 2) | c) << 8);
     return q;
+}
+// path code of a point after D levels of DivideNode starting from the root box (0, 0, W, H): two bits per level, n1..n4 = 0..3
+__device__ inline int qt_code(float x, float y, int W, int H, int D)
+{
+    int x0 = 0, y0 = 0, x1 = W, y1 = H, code = 0;
+    for (int l = 0; l < D; ++l) {
+        const int mx = x0 + (int)ceilf((float)(x1 - x0) / 2), my = y0 + (int)ceilf((float)(y1 - y0) / 2);
+        const bool left = x < (float)mx, top = y < (float)my;
+        code = (code << 2) | (left ? (top ? 0 : 2) : (top ? 1 : 3));
+        if (left) x1 = mx; else x0 = mx;
+        if (top) y1 = my; else y0 = my;
+    }
+    return code;
 }
 
 // work layout per instance (ints): pool (qnode x pool_cap) | listA listB parents exp order flags (cap each) | pcnt[4*cap]
@@ -152,7 +168,9 @@ __global__ __launch_bounds__(QT_THREADS) void quadtree_kernel(const qt_inst* __r
     __shared__ int s_w[QT_WAVES];
     __shared__ int s_S, s_pool, s_nexp, s_done, s_phase2, s_t;
     __shared__ int s_cnt[QT_WAVES][4];
-    __shared__ int2 s_rank[QT_RANK_CAP];
+    __shared__ __attribute__((aligned(16))) int s_big[2 * QT_RANK_CAP + 16];      // phase 2: (size, id) pairs; before it: bucket offsets + cursors of the pre-sort
+    int2* s_rank = reinterpret_cast<int2*>(s_big);
+    int* s_off = s_big; int* s_cur = s_big + QT_RANK_CAP + 8;
     const qt_inst I = tab[blockIdx.x];
     const int base = I.offs[I.cell_begin];
     const int n = min(I.offs[I.cell_end], I.cand_cap) - base;         // never index past the candidate arrays (the overflow itself is flagged by scan_counts_kernel)
@@ -172,6 +190,7 @@ __global__ __launch_bounds__(QT_THREADS) void quadtree_kernel(const qt_inst* __r
     if (nIni > 32) nIni = 32;
     const float hX = (float)I.W / nIni;
     if (nIni == 1) {
+        if (N <= 1)                                  // (with a quota above one the pre-sort below writes the keys)
         for (int i0 = threadIdx.x; i0 < n; i0 += 8 * QT_THREADS) {      // eight coordinate pairs in flight per thread
             float x8[8], y8[8];
 #pragma unroll
@@ -212,6 +231,56 @@ __global__ __launch_bounds__(QT_THREADS) void quadtree_kernel(const qt_inst* __r
     __syncthreads();
     int* L = listA; int* Ln = listB;
 
+    // ---- PRE-SORT.  The whole-list passes below divide every node of the list, so after p of them the keys are bucket-sorted by
+    // their p-level path code.  With one root the code of a key follows from its coordinates alone (the boxes of DivideNode are a
+    // function of the path), so ONE counting sort by the D-level code replaces the first D passes, each of which streamed the
+    // level's keys twice and wrote them once through the single compute unit this workgroup runs on (the kernel's bound).  The
+    // passes keep their node bookkeeping and read the children's sizes from the bucket offsets.  Sorting deeper than the passes
+    // go is harmless: a node's keys are a contiguous range whatever their order inside it, and the point kept per node is picked
+    // by (response, candidate index), not by position.
+    int D = 0;
+    if (nIni == 1) { int cells = 1; while (cells < N && D < 6) { cells *= 4; ++D; } }
+    const bool presorted = D > 0;
+    if (presorted) {
+        const int nb = 1 << (2 * D);
+        for (int i = threadIdx.x; i <= nb; i += QT_THREADS) s_off[i] = 0;
+        __syncthreads();
+        for (int i0 = threadIdx.x; i0 < n; i0 += 8 * QT_THREADS) {
+            float x8[8], y8[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { const int i = i0 + u * QT_THREADS; x8[u] = i < n ? xs[i] : 0.f; y8[u] = i < n ? ys[i] : 0.f; }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { const int i = i0 + u * QT_THREADS; if (i < n) atomicAdd(&s_off[qt_code((float)(int)x8[u], (float)(int)y8[u], I.W, I.H, D)], 1); }
+        }
+        __syncthreads();
+        {   // exclusive scan of the nb bucket sizes, four consecutive buckets per thread
+            const int b0 = 4 * threadIdx.x;
+            int v[4], sum = 0;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { v[u] = b0 + u < nb ? s_off[b0 + u] : 0; sum += v[u]; }
+            int tot;
+            int run = qt_block_scan(sum, &tot, s_w);
+            __syncthreads();
+#pragma unroll
+            for (int u = 0; u < 4; ++u) if (b0 + u < nb) { s_off[b0 + u] = run; s_cur[b0 + u] = run; run += v[u]; }
+            if (threadIdx.x == 0) s_off[nb] = n;
+        }
+        __syncthreads();
+        for (int i0 = threadIdx.x; i0 < n; i0 += 8 * QT_THREADS) {
+            float x8[8], y8[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { const int i = i0 + u * QT_THREADS; x8[u] = i < n ? xs[i] : 0.f; y8[u] = i < n ? ys[i] : 0.f; }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int i = i0 + u * QT_THREADS;
+                if (i < n) keys1[atomicAdd(&s_cur[qt_code((float)(int)x8[u], (float)(int)y8[u], I.W, I.H, D)], 1)] = qt_make_key(i, x8[u], y8[u]);
+            }
+        }
+        if (threadIdx.x == 0) pool[0].buf = 1;        // the root's keys are the sorted array
+        __syncthreads();
+    }
+    int pass = 0;
+
     // ---- whole-list passes (:594-672)
     while (true) {
         const int S = s_S;
@@ -220,7 +289,7 @@ __global__ __launch_bounds__(QT_THREADS) void quadtree_kernel(const qt_inst* __r
         for (int b = 0; b < S; b += QT_THREADS) {
             const int i = b + threadIdx.x;
             const int id = i < S ? L[i] : -1;
-            const int isp = (id >= 0 && !pool[id].leaf) ? 1 : 0, isl = (id >= 0 && pool[id].leaf) ? 1 : 0;
+            const int isp = (id >= 0 && !(pool[id].leaf & 1)) ? 1 : 0, isl = (id >= 0 && (pool[id].leaf & 1)) ? 1 : 0;
             int tp, tl;
             const int rp = qt_block_scan(isp, &tp, s_w), rl = qt_block_scan(isl, &tl, s_w);
             if (isp) parents[np + rp] = id;
@@ -230,7 +299,15 @@ __global__ __launch_bounds__(QT_THREADS) void quadtree_kernel(const qt_inst* __r
         __syncthreads();
         if (np == 0) break;                          // every node holds one point: size == prevSize
         if (s_pool + 4 * np > pool_cap) { if (threadIdx.x == 0) *I.err = 1; break; }
-        if (np < QT_WAVES) {
+        const bool from_buckets = presorted && pass < D;       // the parents of this pass sit at depth `pass`: their children are bucket ranges
+        if (from_buckets) {
+            const int sh = 2 * (D - pass - 1);
+            for (int r = threadIdx.x; r < np; r += QT_THREADS) {
+                const int pf = pool[parents[r]].leaf >> 8;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) { const int cp = (pf << 2) | c; pcnt[4 * r + c] = s_off[(cp + 1) << sh] - s_off[cp << sh]; }
+            }
+        } else if (np < QT_WAVES) {
             for (int r = 0; r < np; ++r) {
                 int cnt[4];
                 qt_divide_block(pool[parents[r]], keys0, keys1, cnt, s_cnt);
@@ -256,13 +333,14 @@ __global__ __launch_bounds__(QT_THREADS) void quadtree_kernel(const qt_inst* __r
                 const qnode P = pool[parents[r]];
                 int q = Cn + qe, x = nexp + qx;
                 for (int c = 0; c < 4; ++c) if (cnt[c] > 0) {
-                    pool[pool0 + q] = qt_child(P, c, cnt);
+                    pool[pool0 + q] = qt_child(P, c, cnt, from_buckets);
                     if (cnt[c] > 1) expv[x++] = pool0 + q;
                     ++q;
                 }
             }
             Cn += te; nexp += tx;
         }
+        ++pass;
         __syncthreads();
         const int Snew = Cn + nl;
         if (Snew > cap) { if (threadIdx.x == 0) *I.err = 2; break; }
@@ -372,15 +450,15 @@ __global__ __launch_bounds__(QT_THREADS) void quadtree_kernel(const qt_inst* __r
 
     // ---- retain the best point of each node, list order (:741-760): first maximum response in key order
     const int S = s_S;
-    for (int i = wv; i < S; i += QT_WAVES) {           // one wavefront per node: keys read together, first maximum by (response, position)
+    for (int i = wv; i < S; i += QT_WAVES) {           // one wavefront per node: keys read together, first maximum by (response, candidate index)
         const qnode q = pool[L[i]];
         const qkey* kk = (q.buf ? keys1 : keys0) + q.kbeg;
-        float r = -1.0f; int pos = 0x7fffffff, best = 0;
-        for (int k = lane; k < q.kcnt; k += 64) { const int c = qt_key_idx(kk[k]); const float v = rs[c]; if (v > r) { r = v; pos = k; best = c; } }
+        float r = -1.0f; int best = 0x7fffffff;                // keys of a node are in candidate order in the reference (stable partitions):
+        for (int k = lane; k < q.kcnt; k += 64) { const int c = qt_key_idx(kk[k]); const float v = rs[c]; if (v > r || (v == r && c < best)) { r = v; best = c; } }      // "first maximum" = smallest candidate index among the maxima
 #pragma unroll
         for (int o = 32; o >= 1; o >>= 1) {
-            const float r2 = __shfl_xor(r, o, 64); const int p2 = __shfl_xor(pos, o, 64), b2 = __shfl_xor(best, o, 64);
-            if (r2 > r || (r2 == r && p2 < pos)) { r = r2; pos = p2; best = b2; }
+            const float r2 = __shfl_xor(r, o, 64); const int b2 = __shfl_xor(best, o, 64);
+            if (r2 > r || (r2 == r && b2 < best)) { r = r2; best = b2; }
         }
         if (lane == 0 && i < I.out_cap) out[i] = base + best;
     }
