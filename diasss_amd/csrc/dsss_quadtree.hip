@@ -44,11 +44,14 @@ __device__ inline int qt_block_scan(int v, int* total, int* s_w)
 // streamed with QT_ILP chunks of 64 keys in flight per wave: a pass over the level costs (keys / (1024 x QT_ILP)) round trips.
 #define QT_ILP 8
 // A key carries the candidate's coordinates (integers: FAST cell offset + position in the cell) next to its index, so
-// DivideNode streams the key segment and never gathers xs / ys:  key = y << 48 | x << 32 | index.
+// DivideNode streams the key segment and never gathers xs / ys.
 typedef unsigned long long qkey;
 #define QT_NOKEY (~0ull)
-__device__ inline qkey qt_make_key(int idx, float x, float y) { return ((qkey)(unsigned)(int)y << 48) | ((qkey)((unsigned)(int)x & 0xffffu) << 32) | (qkey)(unsigned)idx; }
-__device__ inline int qt_key_idx(qkey k) { return (int)(unsigned)(k & 0xffffffffull); }
+// The response rides along (FAST scores are integers below 256, the index keeps 24 bits): the point kept per node is then found
+// from the keys alone.   key = y << 48 | x << 32 | response << 24 | index
+__device__ inline qkey qt_make_key(int idx, float x, float y, float resp) { return ((qkey)(unsigned)(int)y << 48) | ((qkey)((unsigned)(int)x & 0xffffu) << 32) | ((qkey)((unsigned)(int)resp & 0xffu) << 24) | (qkey)((unsigned)idx & 0xffffffu); }
+__device__ inline int qt_key_idx(qkey k) { return (int)(unsigned)(k & 0xffffffull); }
+__device__ inline unsigned qt_key_rank(qkey k) { return ((unsigned)(k >> 24) & 0xffu) << 24 | (0xffffffu - (unsigned)(k & 0xffffffull)); }      // larger = higher response, then smaller index
 __device__ inline void qt_classify4(const qkey* __restrict__ src, int beg, int end, int b, int lane, float mx, float my, int* c, qkey* k)
 {
 #pragma unroll
@@ -177,6 +180,7 @@ __global__ __launch_bounds__(QT_THREADS) void quadtree_kernel(const qt_inst* __r
     const float* xs = I.xs + base; const float* ys = I.ys + base; const float* rs = I.rs + base;
     int* out = I.out_idx; int* out_n = I.out_n;
     if (n <= 0) { if (threadIdx.x == 0) *out_n = 0; return; }
+    if (n >= (1 << 24)) { if (threadIdx.x == 0) { *out_n = 0; *I.err = 5; } return; }      // the key keeps 24 bits of the candidate index
     const int cap = I.list_cap, pool_cap = I.pool_cap, N = I.quota;
     qkey* keys0 = I.keys0 + base; qkey* keys1 = I.keys1 + base;      // frame-wide key arrays, this level's segment
     qnode* pool = reinterpret_cast<qnode*>(I.work);
@@ -196,7 +200,7 @@ __global__ __launch_bounds__(QT_THREADS) void quadtree_kernel(const qt_inst* __r
 #pragma unroll
             for (int u = 0; u < 8; ++u) { const int i = i0 + u * QT_THREADS; x8[u] = i < n ? xs[i] : 0.f; y8[u] = i < n ? ys[i] : 0.f; }
 #pragma unroll
-            for (int u = 0; u < 8; ++u) { const int i = i0 + u * QT_THREADS; if (i < n) keys0[i] = qt_make_key(i, x8[u], y8[u]); }
+            for (int u = 0; u < 8; ++u) { const int i = i0 + u * QT_THREADS; if (i < n) keys0[i] = qt_make_key(i, x8[u], y8[u], rs[i]); }
         }
     }
     else if (wv == 0) {                              // stable partition of 0..n-1 by root index, one wave
@@ -208,7 +212,7 @@ __global__ __launch_bounds__(QT_THREADS) void quadtree_kernel(const qt_inst* __r
                 bool in = false;
                 if (i < n) { int w = (int)(xs[i] / hX); if (w >= nIni) w = nIni - 1; in = (w == r); }
                 const unsigned long long m = __ballot(in);
-                if (in) keys0[off + run + __popcll(m & ((1ull << lane) - 1ull))] = qt_make_key(i, xs[i], ys[i]);
+                if (in) keys0[off + run + __popcll(m & ((1ull << lane) - 1ull))] = qt_make_key(i, xs[i], ys[i], rs[i]);
                 run += __popcll(m);
             }
             if (lane == 0) pcnt[r] = run;
@@ -267,13 +271,13 @@ __global__ __launch_bounds__(QT_THREADS) void quadtree_kernel(const qt_inst* __r
         }
         __syncthreads();
         for (int i0 = threadIdx.x; i0 < n; i0 += 8 * QT_THREADS) {
-            float x8[8], y8[8];
+            float x8[8], y8[8], r8[8];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) { const int i = i0 + u * QT_THREADS; x8[u] = i < n ? xs[i] : 0.f; y8[u] = i < n ? ys[i] : 0.f; }
+            for (int u = 0; u < 8; ++u) { const int i = i0 + u * QT_THREADS; x8[u] = i < n ? xs[i] : 0.f; y8[u] = i < n ? ys[i] : 0.f; r8[u] = i < n ? rs[i] : 0.f; }
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
                 const int i = i0 + u * QT_THREADS;
-                if (i < n) keys1[atomicAdd(&s_cur[qt_code((float)(int)x8[u], (float)(int)y8[u], I.W, I.H, D)], 1)] = qt_make_key(i, x8[u], y8[u]);
+                if (i < n) keys1[atomicAdd(&s_cur[qt_code((float)(int)x8[u], (float)(int)y8[u], I.W, I.H, D)], 1)] = qt_make_key(i, x8[u], y8[u], r8[u]);
             }
         }
         if (threadIdx.x == 0) pool[0].buf = 1;        // the root's keys are the sorted array
@@ -453,13 +457,11 @@ __global__ __launch_bounds__(QT_THREADS) void quadtree_kernel(const qt_inst* __r
     for (int i = wv; i < S; i += QT_WAVES) {           // one wavefront per node: keys read together, first maximum by (response, candidate index)
         const qnode q = pool[L[i]];
         const qkey* kk = (q.buf ? keys1 : keys0) + q.kbeg;
-        float r = -1.0f; int best = 0x7fffffff;                // keys of a node are in candidate order in the reference (stable partitions):
-        for (int k = lane; k < q.kcnt; k += 64) { const int c = qt_key_idx(kk[k]); const float v = rs[c]; if (v > r || (v == r && c < best)) { r = v; best = c; } }      // "first maximum" = smallest candidate index among the maxima
+        unsigned best = 0;                                       // keys of a node are in candidate order in the reference (stable partitions): its
+        for (int k = lane; k < q.kcnt; k += 64) best = max(best, qt_key_rank(kk[k]));      // "first maximum" = the smallest candidate index among the maxima
 #pragma unroll
-        for (int o = 32; o >= 1; o >>= 1) {
-            const float r2 = __shfl_xor(r, o, 64); const int b2 = __shfl_xor(best, o, 64);
-            if (r2 > r || (r2 == r && b2 < best)) { r = r2; best = b2; }
-        }
+        for (int o = 32; o >= 1; o >>= 1) best = max(best, (unsigned)__shfl_xor((int)best, o, 64));
+        best = 0xffffffu - (best & 0xffffffu);
         if (lane == 0 && i < I.out_cap) out[i] = base + best;
     }
     if (threadIdx.x == 0) { *out_n = S < I.out_cap ? S : I.out_cap; if (S > I.out_cap) *I.err = 3; }
