@@ -442,13 +442,15 @@ __device__ inline int reflect101_dev(int p, int len)
 #define BR 18
 #define BW 37
 #define BS 40
+#define HS 50                  // row stride (in 16-bit elements) of the transposed horizontal pass: PW rounded up to even
+typedef unsigned short u16x2_t __attribute__((ext_vector_type(2)));
 
 // one wave per keypoint, four keypoints per block.  The Gaussian blur of the level clone (ORBextractor.cpp:1091-1092)
 // is evaluated only on the 37 x 37 patch the rotated pattern can reach, from a 49 x 49 LDS tile of the level image.
 __global__ __launch_bounds__(256) void orient_desc_kernel(const ex_frame* __restrict__ frs)
 {
-    __shared__ uint8_t sP[4][PW * PS];
-    __shared__ uint16_t sH[4][PW * BW];
+    __shared__ __attribute__((aligned(16))) uint8_t sP[4][PW * PS];
+    __shared__ __attribute__((aligned(16))) uint16_t sH[4][BW * HS];      // horizontal pass, TRANSPOSED: H[bx][py], so that the vertical taps are contiguous
     __shared__ uint8_t sB[4][BW * BS];
     const ex_frame& f = frs[blockIdx.y];
     const kp_in* __restrict__ kin = f.kin; const float* __restrict__ lscale = f.lscale;
@@ -492,22 +494,37 @@ __global__ __launch_bounds__(256) void orient_desc_kernel(const ex_frame* __rest
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) { m10 += __shfl_xor(m10, o, 64); m01 += __shfl_xor(m01, o, 64); }
     const float angle = fast_atan2_dev((float)m01, (float)m10);
-    // separable 13-tap blur, 8.8 fixed point (own taps, see oracle/orc.h)
+    // separable 13-tap blur, 8.8 fixed point (own taps, see oracle/orc.h).  The taps go through the packed dot products: a lane
+    // reads the 13 bytes of its window as four aligned dwords, shifts them into place (v_alignbyte) and folds them with three
+    // v_dot4_u32_u8 + one multiply-add (13 byte loads + 13 multiply-adds before); the vertical pass does the same on 16-bit sums
+    // with v_dot2_u32_u16, which is why the horizontal pass stores its result transposed.  Integer arithmetic: same sums.
+    const unsigned G0 = 1u | 2u << 8 | 7u << 16 | 17u << 24, G1 = 31u | 45u << 8 | 50u << 16 | 45u << 24, G2 = 31u | 17u << 8 | 7u << 16 | 2u << 24;
     if (act)
         for (int t = lane; t < PW * BW; t += 64) {
-            const int py = t / BW, bx = t - py * BW;                 // H(py, bx): column bx of the 37-wide band
-            int acc = 0;
-#pragma unroll
-            for (int q = 0; q < 13; ++q) acc += c_gauss13[q] * P[py * PS + (bx + q)];      // bx + (PR-BR) + q - 6 = bx + q
-            H[py * BW + bx] = (uint16_t)acc;
+            const int py = t / BW, bx = t - py * BW;                 // H(py, bx): column bx of the 37-wide band, taps on P[py][bx .. bx + 12]
+            const uint32_t* w = reinterpret_cast<const uint32_t*>(P + py * PS + (bx & ~3));      // PS and the slice offsets are multiples of 4
+            const unsigned sft = bx & 3;
+            const uint32_t w0 = w[0], w1 = w[1], w2 = w[2], w3 = w[3];
+            unsigned acc = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(w1, w0, sft), G0, 0u, false);
+            acc = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(w2, w1, sft), G1, acc, false);
+            acc = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(w3, w2, sft), G2, acc, false);
+            acc += (w3 >> (8 * sft)) & 255u;                          // tap 12 has weight 1
+            H[bx * HS + py] = (uint16_t)acc;
         }
     __syncthreads();
     if (act)
         for (int t = lane; t < BW * BW; t += 64) {
-            const int by = t / BW, bx = t - by * BW;
-            unsigned acc = 0;
+            const int by = t / BW, bx = t - by * BW;                 // taps on H[bx][by .. by + 12]
+            const uint32_t* w = reinterpret_cast<const uint32_t*>(H + bx * HS + (by & ~1));      // HS is even
+            const unsigned sft = 2 * (by & 1);
+            uint32_t v[7];
 #pragma unroll
-            for (int q = 0; q < 13; ++q) acc += (unsigned)c_gauss13[q] * H[(by + q) * BW + bx];
+            for (int k = 0; k < 7; ++k) v[k] = w[k];
+            unsigned acc = 0;
+            const unsigned T[6] = { 1u | 2u << 16, 7u | 17u << 16, 31u | 45u << 16, 50u | 45u << 16, 31u | 17u << 16, 7u | 2u << 16 };
+#pragma unroll
+            for (int k = 0; k < 6; ++k) acc = __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2_t, __builtin_amdgcn_alignbyte(v[k + 1], v[k], sft)), __builtin_bit_cast(u16x2_t, T[k]), acc, false);
+            acc += (v[6] >> (8 * sft)) & 65535u;                      // tap 12 has weight 1
             B[by * BS + bx] = (uint8_t)((acc + 32768u) >> 16);
         }
     __syncthreads();
