@@ -305,20 +305,33 @@ __global__ __launch_bounds__(256) void fast_cells_kernel(const ex_frame* __restr
     const fast_cell c = f.cells[cell];
     const uint8_t* __restrict__ img = f.lvl[c.level];
     const int cols = f.cols[c.level];
-    // the window, eight byte loads in flight per lane; t / d for t < 66 * 66 by multiplication: (t * ceil(2^20 / d)) >> 20 is exact while t * d < 2^20
-    const unsigned mg_w = ((1u << 20) + (unsigned)c.w - 1u) / (unsigned)c.w;
-    const int nwin = c.w * c.h;
-    for (int t0 = 0; t0 < nwin; t0 += 512) {
-        uint8_t v[8]; int o[8];
+    // The window comes in as aligned dwords (a row of the window is c.w <= 66 bytes at any alignment: at most 18 dwords) and is
+    // written to LDS byte by byte; items = (row, dword of the row), six in flight per lane.  One byte per load cost 840
+    // instructions per cell, a quarter of the kernel.
+    {
+        for (int t = lane; t < wave_bytes / 8; t += 64) reinterpret_cast<uint32_t*>(A)[t] = 0u;       // the arc values start at zero (borders stay zero)
+        const int dpr = (c.w + 6) >> 2;                              // dwords that can touch a row of c.w bytes at any alignment
+        const unsigned mg = (65536u + (unsigned)dpr - 1u) / (unsigned)dpr;      // t / dpr = (t * mg) >> 16, exact for t * dpr < 65536
+        const int items = c.h * dpr;
+        for (int t0 = 0; t0 < items; t0 += 64 * 6) {
+            uint32_t v[6]; int rr[6], x0[6];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const int t = t0 + 64 * u + lane;
-            const int y = (int)(((unsigned)t * mg_w) >> 20), x = t - y * c.w;
-            o[u] = t < nwin ? y * stride + x : -1;
-            v[u] = t < nwin ? img[(size_t)(c.y0 + y) * cols + (c.x0 + x)] : (uint8_t)0;
+            for (int u = 0; u < 6; ++u) {
+                const int t = t0 + 64 * u + lane;
+                const int r = (int)(((unsigned)t * mg) >> 16), j = t - dpr * r;
+                const uint8_t* row = img + (size_t)(c.y0 + min(r, c.h - 1)) * cols + c.x0;
+                const int mis = (int)((size_t)row & 3);
+                rr[u] = r; x0[u] = 4 * j - mis;                       // window column of the dword's first byte
+                const bool ok = t < items && x0[u] < c.w;
+                v[u] = ok ? *reinterpret_cast<const uint32_t*>(row + x0[u]) : 0u;
+                if (!ok) rr[u] = -1;
+            }
+#pragma unroll
+            for (int u = 0; u < 6; ++u) if (rr[u] >= 0) {
+#pragma unroll
+                for (int b = 0; b < 4; ++b) { const int x = x0[u] + b; if (x >= 0 && x < c.w) win[rr[u] * stride + x] = (uint8_t)(v[u] >> (8 * b)); }
+            }
         }
-#pragma unroll
-        for (int u = 0; u < 8; ++u) if (o[u] >= 0) { win[o[u]] = v[u]; A[o[u]] = 0; }
     }
     FAST_WAVE_SYNC();
     const int ew = c.w - 6, eh = c.h - 6;
