@@ -344,9 +344,13 @@ __global__ __launch_bounds__(256) void fast_cells_kernel(const ex_frame* __restr
         A[y * stride + x] = (uint8_t)fast_arc<stride>(win, x, y, tmin);
     }
     FAST_WAVE_SYNC();
-    // strict 3x3 maxima (neighbours outside the evaluated range hold 0); the survivors' values replace the window, which is not needed any more
-    int n12 = 0;
-    for (int t = lane; t < ne; t += 64) {
+    // strict 3x3 maxima (neighbours outside the evaluated range hold 0); the survivors' values replace the window, which is not needed
+    // any more.  The survivors above iniThFAST are emitted in this same pass: if there is one the cell keeps exactly those, and if
+    // there is none nothing was emitted -- only then does a second pass emit the survivors above minThFAST (ORBextractor.cpp:796-810).
+    int base = 0;
+    for (int t0 = 0; t0 < ne; t0 += 64) {
+        const int t = min(t0 + lane, ne - 1);
+        const bool valid = t0 + lane < ne;
         const int q = (int)(((unsigned)t * mg_e) >> 20);
         const int y = 3 + q, x = 3 + t - q * ew;
         const int a = A[y * stride + x];
@@ -355,25 +359,31 @@ __global__ __launch_bounds__(256) void fast_cells_kernel(const ex_frame* __restr
         const int m0 = max(max((int)pa[0], (int)pa[1]), (int)pa[2]);
         const int m1 = max((int)pa[stride], (int)pa[stride + 2]);
         const int m2 = max(max((int)pa[2 * stride], (int)pa[2 * stride + 1]), (int)pa[2 * stride + 2]);
-        const bool mx = a > max(max(m0, m1), m2);            // a == 0 never passes
-        win[y * stride + x] = (uint8_t)(mx ? a : 0);
-        n12 |= (int)(mx && a > ini_th);
-    }
-    FAST_WAVE_SYNC();
-    const int thr = __builtin_amdgcn_ballot_w64(n12 != 0) != 0 ? ini_th : min_th;
-    int base = 0;
-    for (int t0 = 0; t0 < ne; t0 += 64) {
-        const int t = t0 + lane;
-        const int q = (int)(((unsigned)t * mg_e) >> 20);
-        const int y = 3 + q, x = 3 + t - q * ew;
-        const int a = t < ne ? win[y * stride + x] : 0;
-        const bool keep = a > thr;
+        const int sv = (valid && a > max(max(m0, m1), m2)) ? a : 0;      // a == 0 never passes
+        if (valid) win[y * stride + x] = (uint8_t)sv;
+        const bool keep = sv > ini_th;
         const unsigned long long m = __builtin_amdgcn_ballot_w64(keep);
         if (keep) {
             const int pos = base + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0));
-            if (pos < cell_cap) cand[(size_t)cell * cell_cap + pos] = (uint32_t)x | ((uint32_t)y << 8) | ((uint32_t)(a - 1) << 16);
+            if (pos < cell_cap) cand[(size_t)cell * cell_cap + pos] = (uint32_t)x | ((uint32_t)y << 8) | ((uint32_t)(sv - 1) << 16);
         }
         base += __builtin_popcountll(m);
+    }
+    if (base == 0 && min_th < ini_th) {              // (with minThFAST >= iniThFAST the second pass could not add anything)
+        FAST_WAVE_SYNC();
+        for (int t0 = 0; t0 < ne; t0 += 64) {
+            const int t = t0 + lane;
+            const int q = (int)(((unsigned)t * mg_e) >> 20);
+            const int y = 3 + q, x = 3 + t - q * ew;
+            const int a = t < ne ? win[y * stride + x] : 0;
+            const bool keep = a > min_th;
+            const unsigned long long m = __builtin_amdgcn_ballot_w64(keep);
+            if (keep) {
+                const int pos = base + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0));
+                if (pos < cell_cap) cand[(size_t)cell * cell_cap + pos] = (uint32_t)x | ((uint32_t)y << 8) | ((uint32_t)(a - 1) << 16);
+            }
+            base += __builtin_popcountll(m);
+        }
     }
     if (lane == 0) f.counts[cell] = base < cell_cap ? base : cell_cap;
 }
