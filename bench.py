@@ -251,7 +251,7 @@ MFMA_SLOTS = {"pg_acc", "pg_diag", "pg_trsm"}             # kernels whose flops 
 # profile slot -> kernel name in the rocprofv3 tables under profiles/
 SLOT_KERNEL = {"row_reduce": "row_reduce_kernel", "normalize": "normalize_kernel", "pyramid": "resize_kernel", "fast": "fast_cells_kernel",
                "desc": "orient_desc_kernel", "quadtree": "quadtree_kernel", "lc": "lc_kernel", "match": "match_nn_kernel<false>",
-               "pg_acc": "pg_front_syrk_kernel", "pg_diag": "pg_front_diag3_kernel", "pg_trsm": "pg_front_trsm2_kernel", "pg_bwd": "pg_front_bwd2_kernel"}
+               "pg_acc": "pg_front_syrk_kernel", "pg_diag": "pg_front_diag4_kernel", "pg_trsm": "pg_front_trsm2_kernel", "pg_bwd": "pg_front_bwd2_kernel"}
 NOTES = {"pg_acc": "trailing update of the multifrontal fronts, 64 x 64 tiles on v_mfma_f64_16x16x4_f64 (K = one 96-column panel): the bulk of the factorisation flops; launches are short, so the matrix cores idle between levels",
          "pg_diag": "96-column panel Cholesky in the registers of four wavefronts: 24 dependent 4 x 4 pivot blocks (about 1950 cycles each: readlane, 4 x rsq + Newton, LDS, MFMA, LDS, MFMA), every rank-4 update one v_mfma_f64_16x16x4_f64 per tile; latency-bound",
          "fast": "VALU-bound: packed 16-bit sliding min/max over the 16-pixel ring; work = pixels of all pyramid levels",
