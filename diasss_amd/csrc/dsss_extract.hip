@@ -161,56 +161,91 @@ __device__ inline int cvfloorf_dev(float v) { const int i = (int)v; return i - (
 // in int, vertical pass with the two 16-bit shifts.  A thread produces FOUR consecutive bytes of the level (flat index, so the
 // 4-byte store is always aligned, a group may wrap into the next row) -- the one-byte-per-thread form stored at 7 % of HBM speed.
 typedef uint16_t u16_unaligned __attribute__((aligned(1)));
+// RS_K groups of four pixels per thread, 1024 pixels apart, written as four straight-line phases (indices, tables, pixels,
+// arithmetic): with one group per thread the kernel waited three dependent memory latencies (frame record, tables, pixels)
+// for 256 pixels per wavefront and ran at a ninth of the memory rate; the groups of a thread now wait together.  A group that
+// runs over the end of a row takes its last pixels from the next one by selects, not by a branch.
+#define RS_K 4
+#if defined(__HIP_DEVICE_COMPILE__)
+#define DSSS_GLOBAL __attribute__((address_space(1)))     // device pass: global_load with a scalar base instead of flat_load
+#else
+#define DSSS_GLOBAL                                       // host pass of the same source: the qualifier means nothing there
+#endif
+typedef unsigned short rs_u16x2 __attribute__((ext_vector_type(2)));
 __global__ __launch_bounds__(256) void resize_kernel(const ex_frame* __restrict__ frs, int level)
 {
     const ex_frame& f = frs[blockIdx.y];
     if (level >= f.nlevels) return;
-    const uint8_t* __restrict__ src = f.lvl[level - 1]; uint8_t* __restrict__ dst = f.lvl[level];
+    // pointers read from the frame record are generic to the compiler (flat loads, 64-bit address arithmetic per access): say
+    // they are global, and index them with 32-bit offsets from the wave-uniform base
+    const DSSS_GLOBAL uint8_t* __restrict__ src = (const DSSS_GLOBAL uint8_t*)f.lvl[level - 1]; DSSS_GLOBAL uint8_t* __restrict__ dst = (DSSS_GLOBAL uint8_t*)f.lvl[level];
     const int sw = f.cols[level - 1], dh = f.rows[level], dw = f.cols[level];
-    const resize_xtab* __restrict__ xt = f.xt[level]; const resize_ytab* __restrict__ yt = f.yt[level];
-    const long long total = (long long)dw * dh;
-    const long long g0 = 4 * ((long long)blockIdx.x * 256 + threadIdx.x);
-    if (g0 >= total) return;
-    int dy = (int)(g0 / dw), dx = (int)(g0 - (long long)dy * dw);
-    uint32_t out = 0;
-    // The kernel is bound by the NUMBER of global load instructions, so the two horizontal neighbours come in as one unaligned
-    // 16-bit load (sx + 1 is always addressable: the next row, or the 64 bytes of slack behind the image) and, when the four
-    // pixels share a row, their x entries as 8-byte loads and the y entry once: 13 loads instead of 24.
-    if (dx + 3 < dw) {
-        const resize_ytab Y = yt[dy];
-        uint32_t xs[4], xw[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) { const uint2 xe = *reinterpret_cast<const uint2*>(xt + dx + u); xs[u] = xe.x; xw[u] = xe.y; }
-        const uint8_t* S0 = src + (size_t)Y.ya * sw; const uint8_t* S1 = src + (size_t)Y.yb * sw;
-        uint32_t p0[4], p1[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            p0[u] = *reinterpret_cast<const u16_unaligned*>(S0 + xs[u]);
-            p1[u] = *reinterpret_cast<const u16_unaligned*>(S1 + xs[u]);
-        }
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int a0 = (short)(xw[u] & 0xffffu), a1 = (short)(xw[u] >> 16);
-            const int r0 = (int)(p0[u] & 255u) * a0 + (int)(p0[u] >> 8) * a1, r1 = (int)(p1[u] & 255u) * a0 + (int)(p1[u] >> 8) * a1;
-            const uint32_t v = (uint32_t)((((Y.b0 * (r0 >> 4)) >> 16) + ((Y.b1 * (r1 >> 4)) >> 16) + 2) >> 2) & 255u;
-            out |= v << (8 * u);
-        }
-    } else
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-        if (g0 + u < total) {
-            const resize_xtab X = xt[dx]; const resize_ytab Y = yt[dy];
-            const uint8_t* S0 = src + (size_t)Y.ya * sw; const uint8_t* S1 = src + (size_t)Y.yb * sw;
-            int r0, r1;
-            if (X.a1) { r0 = S0[X.sx] * X.a0 + S0[X.sx + 1] * X.a1; r1 = S1[X.sx] * X.a0 + S1[X.sx + 1] * X.a1; }
-            else { r0 = S0[X.sx] * X.a0; r1 = S1[X.sx] * X.a0; }
-            const uint32_t v = (uint32_t)((((Y.b0 * (r0 >> 4)) >> 16) + ((Y.b1 * (r1 >> 4)) >> 16) + 2) >> 2) & 255u;
-            out |= v << (8 * u);
-        }
-        if (++dx == dw) { dx = 0; ++dy; }
+    const DSSS_GLOBAL resize_xtab* __restrict__ xt = (const DSSS_GLOBAL resize_xtab*)f.xt[level]; const DSSS_GLOBAL resize_ytab* __restrict__ yt = (const DSSS_GLOBAL resize_ytab*)f.yt[level];
+    const uint32_t total = (uint32_t)dw * (uint32_t)dh;                   // < 2^31: the host refuses larger frames
+    const uint32_t gb = 4u * (blockIdx.x * (256u * RS_K) + threadIdx.x);
+    if (gb >= total) return;
+    if (dw < 8) {                                                         // degenerate levels: one pixel at a time
+        for (int k = 0; k < RS_K; ++k)
+            for (uint32_t g = gb + 1024u * k; g < gb + 1024u * k + 4 && g < total; ++g) {
+                const int dy = (int)(g / (uint32_t)dw), dx = (int)(g - (uint32_t)dy * dw);
+                const resize_xtab X = xt[dx]; const resize_ytab Y = yt[dy];
+                const DSSS_GLOBAL uint8_t* S0 = src + (size_t)Y.ya * sw; const DSSS_GLOBAL uint8_t* S1 = src + (size_t)Y.yb * sw;
+                int r0, r1;
+                if (X.a1) { r0 = S0[X.sx] * X.a0 + S0[X.sx + 1] * X.a1; r1 = S1[X.sx] * X.a0 + S1[X.sx + 1] * X.a1; }
+                else { r0 = S0[X.sx] * X.a0; r1 = S1[X.sx] * X.a0; }
+                dst[g] = (uint8_t)((((Y.b0 * (r0 >> 4)) >> 16) + ((Y.b1 * (r1 >> 4)) >> 16) + 2) >> 2);
+            }
+        return;
     }
-    if (g0 + 3 < total) *reinterpret_cast<uint32_t*>(dst + g0) = out;
-    else for (int u = 0; g0 + u < total; ++u) dst[g0 + u] = (uint8_t)(out >> (8 * u));
+    const double inv = 1.0 / (double)dw;                                  // quotient by reciprocal (exact to one unit below 2^31), one correction
+    uint32_t g0[RS_K]; uint32_t xi[RS_K][4]; bool wr[RS_K][4]; uint32_t q0[RS_K], q1[RS_K];
+#pragma unroll
+    for (int k = 0; k < RS_K; ++k) {
+        const uint32_t g = gb + 1024u * k;
+        g0[k] = g;
+        const uint32_t gv = g < total ? g : gb;                           // a group past the end recomputes group 0 and stores nothing
+        int q = (int)((double)gv * inv), r = (int)gv - q * dw;
+        const int adj = r < 0 ? -1 : (r >= dw ? 1 : 0);
+        q += adj; r -= adj * dw;
+        q0[k] = (uint32_t)q; q1[k] = (uint32_t)(q + 1 < dh ? q + 1 : dh - 1);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { const int x = r + u; wr[k][u] = x >= dw; xi[k][u] = (uint32_t)(wr[k][u] ? x - dw : x); }
+    }
+    resize_ytab Y0[RS_K], Y1[RS_K]; uint32_t xs[RS_K][4], xw[RS_K][4];
+#pragma unroll
+    for (int k = 0; k < RS_K; ++k) {
+        Y0[k] = *reinterpret_cast<const DSSS_GLOBAL resize_ytab*>(reinterpret_cast<const DSSS_GLOBAL char*>(yt) + q0[k] * (uint32_t)sizeof(resize_ytab));
+        Y1[k] = *reinterpret_cast<const DSSS_GLOBAL resize_ytab*>(reinterpret_cast<const DSSS_GLOBAL char*>(yt) + q1[k] * (uint32_t)sizeof(resize_ytab));
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { const uint2 xe = *reinterpret_cast<const DSSS_GLOBAL uint2*>(reinterpret_cast<const DSSS_GLOBAL char*>(xt) + xi[k][u] * 8u); xs[k][u] = xe.x; xw[k][u] = xe.y; }
+    }
+    uint32_t p0[RS_K][4], p1[RS_K][4];                                    // 32-bit offsets from the uniform level base: one add per load
+#pragma unroll
+    for (int k = 0; k < RS_K; ++k) {
+        const uint32_t A0 = __umul24((uint32_t)Y0[k].ya, (uint32_t)sw), A1 = __umul24((uint32_t)Y0[k].yb, (uint32_t)sw);      // rows, columns < 65536
+        const uint32_t B0 = __umul24((uint32_t)Y1[k].ya, (uint32_t)sw), B1 = __umul24((uint32_t)Y1[k].yb, (uint32_t)sw);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            p0[k][u] = *reinterpret_cast<const DSSS_GLOBAL u16_unaligned*>(src + ((wr[k][u] ? B0 : A0) + xs[k][u]));
+            p1[k][u] = *reinterpret_cast<const DSSS_GLOBAL u16_unaligned*>(src + ((wr[k][u] ? B1 : A1) + xs[k][u]));
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < RS_K; ++k) {
+        uint32_t out = 0;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const uint32_t b0 = (uint32_t)(wr[k][u] ? Y1[k].b0 : Y0[k].b0), b1 = (uint32_t)(wr[k][u] ? Y1[k].b1 : Y0[k].b1);
+            // the two pixels of a row spread to 16-bit halves, then one dot product with the (a0, a1) pair: all operands are >= 0
+            const rs_u16x2 w = __builtin_bit_cast(rs_u16x2, xw[k][u]);
+            const uint32_t r0 = __builtin_amdgcn_udot2(__builtin_bit_cast(rs_u16x2, __builtin_amdgcn_perm(0u, p0[k][u], 0x0c010c00u)), w, 0u, false);
+            const uint32_t r1 = __builtin_amdgcn_udot2(__builtin_bit_cast(rs_u16x2, __builtin_amdgcn_perm(0u, p1[k][u], 0x0c010c00u)), w, 0u, false);
+            const uint32_t v = ((((b0 * (r0 >> 4)) >> 16) + ((b1 * (r1 >> 4)) >> 16) + 2u) >> 2) & 255u;
+            out |= v << (8 * u);
+        }
+        if (g0[k] + 3 < total) *reinterpret_cast<DSSS_GLOBAL uint32_t*>(dst + g0[k]) = out;
+        else for (int u = 0; u < 4; ++u) if (g0[k] + u < total) dst[g0[k] + u] = (uint8_t)(out >> (8 * u));
+    }
 }
 
 // ------------------------------------------------------------------ K3: cv::FAST 9/16 per 30-px cell
@@ -731,6 +766,7 @@ static int get_geom(dsss_ctx* c, int N, int M, level_geom** out)
     if (it == geoms.end()) {
         std::unique_ptr<level_geom> g(new level_geom());
         if (N >= 65536 || M >= 65536) DSSS_FAIL(c, DSSS_E_ARG, "frames of 65536 or more pings / bins are not supported (quadtree keys pack 16-bit coordinates)");
+        if ((size_t)N * (size_t)M >= ((size_t)1 << 31)) DSSS_FAIL(c, DSSS_E_ARG, "frames of 2^31 or more samples are not supported (32-bit pixel indices in the pyramid kernel)");
         build_geom(c->op, N, M, *g);
         for (int l = 0; l < g->nlevels; ++l)
             if (g->rows[l] < 2 * EDGE_T + 31 || g->cols[l] < 2 * EDGE_T + 31)
@@ -937,7 +973,7 @@ static int extract_frames(dsss_ctx* c, const int* ids, int n, bool keep_taps)
           hipLaunchKernelGGL(normalize_kernel, dim3((unsigned)((max_tot / 4 + 256) / 256), nb), dim3(256), 0, st, d_exf, c->mp.r); }
         { dsss_scope sc(c, DSSS_K_PYRAMID, (1.906 + 2.74) * w_tot, std::max(max_levels - 1, 1));
           for (int l = 1; l < max_levels; ++l)
-              hipLaunchKernelGGL(resize_kernel, dim3((unsigned)(((size_t)max_cols[l] * max_rows[l] / 4 + 256) / 256), nb), dim3(256), 0, st, d_exf, l); }
+              hipLaunchKernelGGL(resize_kernel, dim3((unsigned)(((size_t)max_cols[l] * max_rows[l] / 4 + 256 * RS_K) / (256 * RS_K)), nb), dim3(256), 0, st, d_exf, l); }
         { dsss_scope sc(c, DSSS_K_FAST, 2.906 * w_tot);
           const int fstride = max_cw <= 40 ? 40 : CELL_STRIDE, fwave = (2 * max_ch * fstride + 15) & ~15;      // window + arc values of one wavefront
           if (fstride == 40) hipLaunchKernelGGL(fast_cells_kernel<40>, dim3((max_cells + 3) / 4, nb), dim3(256), 4 * fwave, st, d_exf, c->op.ini_th, c->op.min_th, fwave);
