@@ -172,6 +172,7 @@ typedef uint16_t u16_unaligned __attribute__((aligned(1)));
 #define DSSS_GLOBAL                                       // host pass of the same source: the qualifier means nothing there
 #endif
 typedef unsigned short rs_u16x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t rs_u32x3 __attribute__((ext_vector_type(3)));
 __global__ __launch_bounds__(256) void resize_kernel(const ex_frame* __restrict__ frs, int level)
 {
     const ex_frame& f = frs[blockIdx.y];
@@ -198,7 +199,7 @@ __global__ __launch_bounds__(256) void resize_kernel(const ex_frame* __restrict_
         return;
     }
     const double inv = 1.0 / (double)dw;                                  // quotient by reciprocal (exact to one unit below 2^31), one correction
-    uint32_t g0[RS_K]; uint32_t xi[RS_K][4]; bool wr[RS_K][4]; uint32_t q0[RS_K], q1[RS_K];
+    uint32_t g0[RS_K], rr[RS_K]; uint32_t q0[RS_K], q1[RS_K];
 #pragma unroll
     for (int k = 0; k < RS_K; ++k) {
         const uint32_t g = gb + 1024u * k;
@@ -207,44 +208,78 @@ __global__ __launch_bounds__(256) void resize_kernel(const ex_frame* __restrict_
         int q = (int)((double)gv * inv), r = (int)gv - q * dw;
         const int adj = r < 0 ? -1 : (r >= dw ? 1 : 0);
         q += adj; r -= adj * dw;
-        q0[k] = (uint32_t)q; q1[k] = (uint32_t)(q + 1 < dh ? q + 1 : dh - 1);
-#pragma unroll
-        for (int u = 0; u < 4; ++u) { const int x = r + u; wr[k][u] = x >= dw; xi[k][u] = (uint32_t)(wr[k][u] ? x - dw : x); }
+        rr[k] = (uint32_t)r; q0[k] = (uint32_t)q; q1[k] = (uint32_t)(q + 1 < dh ? q + 1 : dh - 1);
     }
-    resize_ytab Y0[RS_K], Y1[RS_K]; uint32_t xs[RS_K][4], xw[RS_K][4];
+    // tables: xt[r .. r + 3] in two 16-byte loads (the table carries its first entries again behind the last column)
+    resize_ytab Y0[RS_K]; uint32_t xs[RS_K][4], xw[RS_K][4];
 #pragma unroll
     for (int k = 0; k < RS_K; ++k) {
         Y0[k] = *reinterpret_cast<const DSSS_GLOBAL resize_ytab*>(reinterpret_cast<const DSSS_GLOBAL char*>(yt) + q0[k] * (uint32_t)sizeof(resize_ytab));
-        Y1[k] = *reinterpret_cast<const DSSS_GLOBAL resize_ytab*>(reinterpret_cast<const DSSS_GLOBAL char*>(yt) + q1[k] * (uint32_t)sizeof(resize_ytab));
-#pragma unroll
-        for (int u = 0; u < 4; ++u) { const uint2 xe = *reinterpret_cast<const DSSS_GLOBAL uint2*>(reinterpret_cast<const DSSS_GLOBAL char*>(xt) + xi[k][u] * 8u); xs[k][u] = xe.x; xw[k][u] = xe.y; }
+        const uint4 xa = *reinterpret_cast<const DSSS_GLOBAL uint4*>(reinterpret_cast<const DSSS_GLOBAL char*>(xt) + rr[k] * 8u);
+        const uint4 xb = *reinterpret_cast<const DSSS_GLOBAL uint4*>(reinterpret_cast<const DSSS_GLOBAL char*>(xt) + rr[k] * 8u + 16u);
+        xs[k][0] = xa.x; xw[k][0] = xa.y; xs[k][1] = xa.z; xw[k][1] = xa.w; xs[k][2] = xb.x; xw[k][2] = xb.y; xs[k][3] = xb.z; xw[k][3] = xb.w;
     }
-    uint32_t p0[RS_K][4], p1[RS_K][4];                                    // 32-bit offsets from the uniform level base: one add per load
+    const bool windowed = xt[dw + 4].sx != 0;
+    uint32_t outv[RS_K];
+    if (windowed) {
+        // The 14 loads per group of the first form (8 unaligned 16-bit pixel pairs) made the kernel wait for the texture
+        // addresser (one wave-load per ~20 cycles).  The source bytes of the four pixels of a group lie within six consecutive
+        // bytes of each of the two source rows: ONE aligned 12-byte load per row, the pairs come out of it by v_perm.
+        uint32_t W0[RS_K][3], W1[RS_K][3], m0[RS_K], m1[RS_K];
+#pragma unroll
+        for (int k = 0; k < RS_K; ++k) {
+            const uint32_t b0 = __umul24((uint32_t)Y0[k].ya, (uint32_t)sw) + xs[k][0], b1 = __umul24((uint32_t)Y0[k].yb, (uint32_t)sw) + xs[k][0];
+            m0[k] = b0 & 3u; m1[k] = b1 & 3u;                            // the level base is 256-byte aligned
+            const rs_u32x3 w0 = *reinterpret_cast<const DSSS_GLOBAL rs_u32x3*>(src + (b0 & ~3u));
+            const rs_u32x3 w1 = *reinterpret_cast<const DSSS_GLOBAL rs_u32x3*>(src + (b1 & ~3u));
+            W0[k][0] = w0.x; W0[k][1] = w0.y; W0[k][2] = w0.z; W1[k][0] = w1.x; W1[k][1] = w1.y; W1[k][2] = w1.z;
+        }
+#pragma unroll
+        for (int k = 0; k < RS_K; ++k) {
+            uint32_t out = 0;
+            const uint32_t b0 = (uint32_t)Y0[k].b0, b1 = (uint32_t)Y0[k].b1;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const uint32_t d = xs[k][u] - xs[k][0];                   // 0 .. 4
+                const uint32_t o0 = m0[k] + d, o1 = m1[k] + d;            // byte index of the left pixel in the 12-byte window: 0 .. 7
+                const uint32_t lo0 = o0 & 4u ? W0[k][1] : W0[k][0], hi0 = o0 & 4u ? W0[k][2] : W0[k][1];
+                const uint32_t lo1 = o1 & 4u ? W1[k][1] : W1[k][0], hi1 = o1 & 4u ? W1[k][2] : W1[k][1];
+                const rs_u16x2 w = __builtin_bit_cast(rs_u16x2, xw[k][u]);
+                const uint32_t r0 = __builtin_amdgcn_udot2(__builtin_bit_cast(rs_u16x2, __builtin_amdgcn_perm(hi0, lo0, 0x0c010c00u + (o0 & 3u) * 0x00010001u)), w, 0u, false);
+                const uint32_t r1 = __builtin_amdgcn_udot2(__builtin_bit_cast(rs_u16x2, __builtin_amdgcn_perm(hi1, lo1, 0x0c010c00u + (o1 & 3u) * 0x00010001u)), w, 0u, false);
+                const uint32_t v = ((((b0 * (r0 >> 4)) >> 16) + ((b1 * (r1 >> 4)) >> 16) + 2u) >> 2) & 255u;
+                out |= v << (8 * u);
+            }
+            outv[k] = out;
+        }
+    }
+    // groups that run over the end of a row (one in a row), and every group of a geometry the windows do not fit: pixel by pixel
 #pragma unroll
     for (int k = 0; k < RS_K; ++k) {
-        const uint32_t A0 = __umul24((uint32_t)Y0[k].ya, (uint32_t)sw), A1 = __umul24((uint32_t)Y0[k].yb, (uint32_t)sw);      // rows, columns < 65536
-        const uint32_t B0 = __umul24((uint32_t)Y1[k].ya, (uint32_t)sw), B1 = __umul24((uint32_t)Y1[k].yb, (uint32_t)sw);
+        if (!windowed || rr[k] + 3u >= (uint32_t)dw) {
+            const resize_ytab Y1k = *reinterpret_cast<const DSSS_GLOBAL resize_ytab*>(reinterpret_cast<const DSSS_GLOBAL char*>(yt) + q1[k] * (uint32_t)sizeof(resize_ytab));
+            const uint32_t A0 = __umul24((uint32_t)Y0[k].ya, (uint32_t)sw), A1 = __umul24((uint32_t)Y0[k].yb, (uint32_t)sw);      // rows, columns < 65536
+            const uint32_t B0 = __umul24((uint32_t)Y1k.ya, (uint32_t)sw), B1 = __umul24((uint32_t)Y1k.yb, (uint32_t)sw);
+            uint32_t out = 0;
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            p0[k][u] = *reinterpret_cast<const DSSS_GLOBAL u16_unaligned*>(src + ((wr[k][u] ? B0 : A0) + xs[k][u]));
-            p1[k][u] = *reinterpret_cast<const DSSS_GLOBAL u16_unaligned*>(src + ((wr[k][u] ? B1 : A1) + xs[k][u]));
+            for (int u = 0; u < 4; ++u) {
+                const bool wr = rr[k] + (uint32_t)u >= (uint32_t)dw;
+                const uint32_t p0 = *reinterpret_cast<const DSSS_GLOBAL u16_unaligned*>(src + ((wr ? B0 : A0) + xs[k][u]));
+                const uint32_t p1 = *reinterpret_cast<const DSSS_GLOBAL u16_unaligned*>(src + ((wr ? B1 : A1) + xs[k][u]));
+                const uint32_t b0 = (uint32_t)(wr ? Y1k.b0 : Y0[k].b0), b1 = (uint32_t)(wr ? Y1k.b1 : Y0[k].b1);
+                const rs_u16x2 w = __builtin_bit_cast(rs_u16x2, xw[k][u]);
+                const uint32_t r0 = __builtin_amdgcn_udot2(__builtin_bit_cast(rs_u16x2, __builtin_amdgcn_perm(0u, p0, 0x0c010c00u)), w, 0u, false);
+                const uint32_t r1 = __builtin_amdgcn_udot2(__builtin_bit_cast(rs_u16x2, __builtin_amdgcn_perm(0u, p1, 0x0c010c00u)), w, 0u, false);
+                const uint32_t v = ((((b0 * (r0 >> 4)) >> 16) + ((b1 * (r1 >> 4)) >> 16) + 2u) >> 2) & 255u;
+                out |= v << (8 * u);
+            }
+            outv[k] = out;
         }
     }
 #pragma unroll
     for (int k = 0; k < RS_K; ++k) {
-        uint32_t out = 0;
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const uint32_t b0 = (uint32_t)(wr[k][u] ? Y1[k].b0 : Y0[k].b0), b1 = (uint32_t)(wr[k][u] ? Y1[k].b1 : Y0[k].b1);
-            // the two pixels of a row spread to 16-bit halves, then one dot product with the (a0, a1) pair: all operands are >= 0
-            const rs_u16x2 w = __builtin_bit_cast(rs_u16x2, xw[k][u]);
-            const uint32_t r0 = __builtin_amdgcn_udot2(__builtin_bit_cast(rs_u16x2, __builtin_amdgcn_perm(0u, p0[k][u], 0x0c010c00u)), w, 0u, false);
-            const uint32_t r1 = __builtin_amdgcn_udot2(__builtin_bit_cast(rs_u16x2, __builtin_amdgcn_perm(0u, p1[k][u], 0x0c010c00u)), w, 0u, false);
-            const uint32_t v = ((((b0 * (r0 >> 4)) >> 16) + ((b1 * (r1 >> 4)) >> 16) + 2u) >> 2) & 255u;
-            out |= v << (8 * u);
-        }
-        if (g0[k] + 3 < total) *reinterpret_cast<DSSS_GLOBAL uint32_t*>(dst + g0[k]) = out;
-        else for (int u = 0; u < 4; ++u) if (g0[k] + u < total) dst[g0[k] + u] = (uint8_t)(out >> (8 * u));
+        if (g0[k] + 3 < total) *reinterpret_cast<DSSS_GLOBAL uint32_t*>(dst + g0[k]) = outv[k];
+        else for (int u = 0; u < 4; ++u) if (g0[k] + u < total) dst[g0[k] + u] = (uint8_t)(outv[k] >> (8 * u));
     }
 }
 
@@ -740,6 +775,13 @@ void resize_tables(int sh, int sw, int dh, int dw, std::vector<resize_xtab>& xt,
         if (sx >= sw - 1) { fx = 0; sx = sw - 1; }              // dx >= xmax in OpenCV's HResize: the last source column alone
         xt[dx].sx = sx; xt[dx].a0 = (short)lrintf((1.f - fx) * 2048.f); xt[dx].a1 = (short)lrintf(fx * 2048.f);
     }
+    // four more entries = the first four again (a group of four pixels that runs over the end of a row reads xt[dx .. dx + 3]
+    // as one piece), then one entry whose sx says whether the windowed loads of resize_kernel are valid for this geometry: the
+    // source bytes of four consecutive output pixels span at most six
+    int span = 0;
+    for (int dx = 0; dx + 3 < dw; ++dx) span = std::max(span, xt[dx + 3].sx + 1 - xt[dx].sx);
+    for (int u = 0; u < 4; ++u) { const resize_xtab e = xt[u % dw]; xt.push_back(e); }
+    resize_xtab flag; flag.sx = (span <= 5 && dw >= 8) ? 1 : 0; flag.a0 = flag.a1 = 0; xt.push_back(flag);
     for (int dy = 0; dy < dh; ++dy) {
         float fy = (float)((dy + 0.5) * scale_y - 0.5);
         const int sy = cvfloorf_host(fy);
