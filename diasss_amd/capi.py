@@ -403,6 +403,20 @@ class Context:
         self._chk(self.L.dsss_posegraph_solve(self.h, nframes, _ptr(poses), _ptr(rpy) if want_rpy else None, _ptr(stats)), "dsss_posegraph_solve")
         return poses, rpy, stats
 
+    def posegraph_update(self, nframes, total, want_rpy=False):
+        """online use (dsss_posegraph_update): frames 0..nframes-1, started from the previous update's estimate, on the accumulated
+        loop closures; consumes the LC result set the context holds.  Returns poses (total x 12), rpy or None, stats."""
+        poses = np.empty((total, 12), np.float64); stats = np.zeros(4, np.float64)
+        rpy = np.empty((total, 6), np.float64) if want_rpy else None
+        self._chk(self.L.dsss_posegraph_update(self.h, nframes, _ptr(poses), _ptr(rpy) if want_rpy else None, _ptr(stats)), "dsss_posegraph_update")
+        return poses, rpy, stats
+
+    def posegraph_reset(self):
+        self._chk(self.L.dsss_posegraph_reset(self.h), "dsss_posegraph_reset")
+
+    def posegraph_online_edges(self):
+        return int(self.L.dsss_posegraph_online_edges(self.h))
+
     def posegraph_solve_edges(self, dr6, edges):
         dr6 = np.ascontiguousarray(dr6, np.float64).reshape(-1, 6)
         edges = np.ascontiguousarray(edges, LCEDGE_DTYPE)

@@ -112,6 +112,10 @@ struct dsss_ctx {
     int pg_parts = 0;                   // pose-graph partitions (0: one per rank); > ranks only to exercise the interface logic on few GPUs
     int* tmp_dev = nullptr;             // 64 ints of device scratch for one-value results (dsss_descriptor_distance)
     void* pg_edges_host = nullptr; size_t pg_edges_cap = 0;     // page-locked staging of the selected LC edges (dsss_posegraph_solve)
+    // online use (dsss_posegraph_update): the estimate of the previous update stays on the device, the LC edges accumulate
+    void* pg_warm = nullptr; size_t pg_warm_cap = 0; int pg_warm_n = 0;   // pose_t[pg_warm_n]
+    bool pg_online = false;             // set by dsss_posegraph_update: pg_solve_impl starts from pg_warm and leaves its result there
+    std::vector<dsss_lc_edge> pg_inc_edges; unsigned long long lc_gen = 0, pg_inc_gen = 0;    // lc_gen counts LC result sets; the last one consumed
     dsss_prof prof;
 };
 

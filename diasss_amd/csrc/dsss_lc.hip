@@ -454,7 +454,7 @@ int dsss_lc_solve_all(dsss_ctx* c)
     if (!c) return DSSS_E_ARG;
     HIPCHK(c, hipSetDevice(c->device));
     const int n = c->total_kp7;
-    c->has_lc = true;
+    c->has_lc = true; ++c->lc_gen;
     if (n == 0) return DSSS_OK;
     if ((size_t)n > c->lcs_cap) {
         HIPCHK(c, hipStreamSynchronize(c->stream)); hipFree(c->lcs); c->lcs = nullptr;
@@ -510,7 +510,7 @@ int dsss_lc_solve_pairs(dsss_ctx* c, const int* src_ids, const int* tgt_ids, int
     c->h_kp7_off.assign(pair_off, pair_off + npairs + 1);
     c->h_row_off.assign(npairs + 1, 0);
     c->total_rows = 0; c->total_kp7 = n;
-    if (npairs == 0 || n == 0) { c->has_lc = true; return DSSS_OK; }
+    if (npairs == 0 || n == 0) { c->has_lc = true; ++c->lc_gen; return DSSS_OK; }
     std::vector<double> h((size_t)n * 7);
     HIPCHK(c, hipMemcpy(h.data(), kp7, h.size() * sizeof(double), hipMemcpyDefault));
     std::vector<int> h_pair(n); std::vector<uint8_t> h_flip(n);

@@ -1952,6 +1952,10 @@ static int pg_solve_impl(dsss_ctx* c, const double* dr6, int total, const dsss_l
             }
         }
         hipLaunchKernelGGL(pg_init_kernel, dim3((n + 255) / 256), dim3(256), 0, st, n, d_dr6, d_norm, c->pg.add_noise, d_X, d_meas);
+        // online use (dsss_posegraph_update): the pings the previous update covered start from its estimate, the new ones where
+        // the reference puts them (dead reckoning o noise, optimizer.cpp:150-160)
+        if (c->pg_online && c->pg_warm_n > 0)
+            HCK(hipMemcpyAsync(d_X, c->pg_warm, (size_t)std::min(n, c->pg_warm_n) * sizeof(pose_t), hipMemcpyDeviceToDevice, st));
     }
     double lambda = c->pg.lambda0, err = 0, err0 = 0, cur = 0;
     int iters = 0, nfact = 0;
@@ -2182,6 +2186,18 @@ static int pg_solve_impl(dsss_ctx* c, const double* dr6, int total, const dsss_l
         hipLaunchKernelGGL(pg_rpy_kernel, dim3((n + 255) / 256), dim3(256), 0, st, n, d_X, d_rpy);
         HCK(hipMemcpyAsync(rpy6, d_rpy, (size_t)n * 6 * sizeof(double), hipMemcpyDeviceToHost, st));
     }
+    if (c->pg_online) {
+        if (c->pg_warm_cap < (size_t)n) {
+            HCK(hipStreamSynchronize(st));
+            if (c->pg_warm) hipFree(c->pg_warm);
+            c->pg_warm = nullptr; c->pg_warm_cap = 0; c->pg_warm_n = 0;
+            const size_t cap = (size_t)n + (size_t)n / 2 + 1024;            // the graph grows by a frame per update
+            HCK(hipMalloc(&c->pg_warm, cap * sizeof(pose_t)));
+            c->pg_warm_cap = cap;
+        }
+        HCK(hipMemcpyAsync(c->pg_warm, d_X, (size_t)n * sizeof(pose_t), hipMemcpyDeviceToDevice, st));
+        c->pg_warm_n = n;
+    }
     HCK(hipStreamSynchronize(st));
     if (stats4) { stats4[0] = iters; stats4[1] = err0; stats4[2] = err; stats4[3] = lambda; }
     dv.release();
@@ -2401,6 +2417,54 @@ int dsss_posegraph_solve(dsss_ctx* c, int nframes, double* poses12, double* rpy6
     if (rc) return rc;
     if (getenv("DSSS_PG_VERBOSE")) fprintf(stderr, "[dsss pg] DR rows %.1f ms, LC selection %.1f ms, solve + download %.1f ms\n", t_dr, t_sel, ms(t2));
     return DSSS_OK;
+}
+
+/* N3, the online use of the solver (optimizer.cpp:134-139 ISAM2, :262-266 isam.update per ping + calculateEstimate): the
+ * graph grows frame by frame.  Each call consumes the LC result set the context holds (if it has not been consumed yet) into
+ * the accumulated edge list, and solves frames 0..nframes-1 by the batch LM STARTED FROM THE PREVIOUS ESTIMATE -- no factor is
+ * carried over, the analysis and the factorisation are redone (they take milliseconds), but a converged prefix needs one
+ * or two trials instead of the cold start's five.                                                                     */
+int dsss_posegraph_reset(dsss_ctx* c)
+{
+    if (!c) return DSSS_E_ARG;
+    c->pg_inc_edges.clear(); c->pg_inc_gen = c->lc_gen; c->pg_warm_n = 0;
+    return DSSS_OK;
+}
+
+int dsss_posegraph_online_edges(dsss_ctx* c) { return c ? (int)c->pg_inc_edges.size() : DSSS_E_ARG; }
+
+int dsss_posegraph_update(dsss_ctx* c, int nframes, double* poses12, double* rpy6, double* stats4)
+{
+    if (!c || nframes <= 0 || nframes > c->max_frames) return DSSS_E_ARG;
+    if (dsss_comm_world(c) > 1) DSSS_FAIL(c, DSSS_E_STATE, "dsss_posegraph_update is a single-rank call (the online use is one vehicle, one GPU)");
+    size_t total = 0;
+    for (int f = 0; f < nframes; ++f) {
+        if (!c->frames[f].has_geom) DSSS_FAIL(c, DSSS_E_STATE, "frame %d has no geometry", f);
+        total += (size_t)c->frames[f].N;
+    }
+    if (c->has_lc && c->pg_inc_gen != c->lc_gen && c->total_kp7 > 0) {
+        std::vector<dsss_lc_edge> fresh((size_t)c->total_kp7);
+        int ne = 0;
+        const int rc = dsss_posegraph_select(c, nframes, fresh.data(), (int)fresh.size(), &ne);
+        if (rc) return rc;
+        // a target ping keeps ONE loop closure, the latest (optimizer.cpp:203-258 within a call; across calls the later set wins)
+        if (ne > 0 && !c->pg_inc_edges.empty()) {
+            std::vector<char> hit(total, 0);
+            for (int e = 0; e < ne; ++e) hit[fresh[e].b] = 1;
+            size_t w = 0;
+            for (size_t e = 0; e < c->pg_inc_edges.size(); ++e) if (!hit[c->pg_inc_edges[e].b]) c->pg_inc_edges[w++] = c->pg_inc_edges[e];
+            c->pg_inc_edges.resize(w);
+        }
+        c->pg_inc_edges.insert(c->pg_inc_edges.end(), fresh.begin(), fresh.begin() + ne);
+        std::stable_sort(c->pg_inc_edges.begin(), c->pg_inc_edges.end(), [](const dsss_lc_edge& x, const dsss_lc_edge& y) { return x.b < y.b; });
+    }
+    c->pg_inc_gen = c->lc_gen;
+    for (const dsss_lc_edge& e : c->pg_inc_edges)
+        if (e.a >= (int)total || e.b >= (int)total) DSSS_FAIL(c, DSSS_E_ARG, "an accumulated LC edge references ping %d of %zu: nframes went down; dsss_posegraph_reset first", std::max(e.a, e.b), total);
+    c->pg_online = true;
+    const int rc = pg_solve_impl(c, nullptr, (int)total, c->pg_inc_edges.data(), (int)c->pg_inc_edges.size(), poses12, stats4, rpy6, nframes);
+    c->pg_online = false;
+    return rc;
 }
 
 } // extern "C"

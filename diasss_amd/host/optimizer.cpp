@@ -16,6 +16,7 @@ namespace Diasss
 
 bool Optimizer::USE_ANNO = 0;
 bool Optimizer::ADD_LC = 1;
+bool Optimizer::ONLINE = 0;
 bool Optimizer::EVAL_1 = 0;
 bool Optimizer::EVAL_2 = 0;
 
@@ -103,7 +104,8 @@ void Optimizer::TrajOptimizationAll(std::vector<Frame> &AllFrames)
     // the device works on frame ids 0..F-1 in AllFrames order (diasss2.cpp:84 numbers them that way)
     for (size_t i = 0; i < F; i++)
         if (AllFrames[i].img_id != (int)i) throw std::runtime_error("TrajOptimizationAll: AllFrames[i].img_id must equal i (diasss2.cpp:84)");
-    Device::check(dsss_lc_solve_pairs(c, ps.data(), pt.data(), (int)ps.size(), kp7.data(), pair_off.data()), "dsss_lc_solve_pairs");
+    if (!(ADD_LC && ONLINE))
+        Device::check(dsss_lc_solve_pairs(c, ps.data(), pt.data(), (int)ps.size(), kp7.data(), pair_off.data()), "dsss_lc_solve_pairs");
     // --- unique pose ids (optimizer.cpp:101-114)
     int id_sum = 0;
     std::vector<std::vector<int>> unique_id;
@@ -117,7 +119,30 @@ void Optimizer::TrajOptimizationAll(std::vector<Frame> &AllFrames)
     std::vector<double> poses12((size_t)id_sum * 12);
     double stats[4] = { 0, 0, 0, 0 };
     int n_edges = 0;
-    if (ADD_LC) {
+    if (ADD_LC && ONLINE) {
+        // the reference's own order of events (optimizer.cpp:145-272): frame by frame, the loop closures that END in the new
+        // frame join the graph together with its pings, and the estimate is brought up to date before the next frame
+        Device::check(dsss_posegraph_reset(c), "dsss_posegraph_reset");
+        int updates = 0, trials = 0;
+        for (size_t j = 0; j < F; j++) {
+            std::vector<int> s_j, t_j, off_j(1, 0);
+            std::vector<double> k_j;
+            for (size_t p = 0; p < ps.size(); p++)
+                if (pt[p] == (int)j && pair_off[p + 1] > pair_off[p]) {
+                    s_j.push_back(ps[p]); t_j.push_back(pt[p]);
+                    k_j.insert(k_j.end(), kp7.begin() + (size_t)7 * pair_off[p], kp7.begin() + (size_t)7 * pair_off[p + 1]);
+                    off_j.push_back((int)(k_j.size() / 7));
+                }
+            if (!s_j.empty()) Device::check(dsss_lc_solve_pairs(c, s_j.data(), t_j.data(), (int)s_j.size(), k_j.data(), off_j.data()), "dsss_lc_solve_pairs");
+            double st_j[4] = { 0, 0, 0, 0 };
+            Device::check(dsss_posegraph_update(c, (int)j + 1, j + 1 == F ? poses12.data() : nullptr, nullptr, st_j), "dsss_posegraph_update");
+            ++updates; trials += (int)st_j[0];
+            if (j == 0) stats[1] = st_j[1];
+            stats[0] = st_j[0]; stats[2] = st_j[2]; stats[3] = st_j[3];
+        }
+        n_edges = dsss_posegraph_online_edges(c);
+        std::cout << "online: " << updates << " updates, " << trials << " accepted LM steps in all" << std::endl;
+    } else if (ADD_LC) {
         Device::check(dsss_posegraph_solve(c, (int)F, poses12.data(), nullptr, stats), "dsss_posegraph_solve");
         std::vector<dsss_lc_edge> tmp((size_t)std::max<size_t>(kp7.size() / 7, 1));
         Device::check(dsss_posegraph_select(c, (int)F, tmp.data(), (int)tmp.size(), &n_edges), "dsss_posegraph_select");

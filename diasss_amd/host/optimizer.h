@@ -25,6 +25,7 @@ namespace Diasss
         // the synthetic configs need the matcher's output, so the default here is 0
         static bool USE_ANNO;
         static bool ADD_LC;
+        static bool ONLINE;      // frame-by-frame updates (the reference's iSAM2 loop, optimizer.cpp:134-272) instead of one batch solve
         // the two annotation evaluators of EvaluateByAnnosAll; the reference hard-codes both to 0 (optimizer.cpp:1579)
         static bool EVAL_1;
         static bool EVAL_2;

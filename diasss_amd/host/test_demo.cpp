@@ -29,6 +29,7 @@ int main(int argc, char** argv)
             else if (k == "--groundrange") dG = v; else if (k == "--annotation") dN = v; else if (k == "--min-overlap") MIN_OVERLAP = (float)atof(v.c_str());
             else if (k == "--use-anno") Optimizer::USE_ANNO = atoi(v.c_str()) != 0;      // optimizer.cpp:26 hard-codes 1 (hand annotations); default here 0
             else if (k == "--add-lc") Optimizer::ADD_LC = atoi(v.c_str()) != 0;
+            else if (k == "--online") Optimizer::ONLINE = atoi(v.c_str()) != 0;      // frame-by-frame updates as the reference's iSAM2 loop does (default: one batch solve)
             else if (k == "--eval") { Optimizer::EVAL_1 = (atoi(v.c_str()) & 1) != 0; Optimizer::EVAL_2 = (atoi(v.c_str()) & 2) != 0; }      // optimizer.cpp:1579 hard-codes both off
         }
         if (dI.empty() || dP.empty() || dA.empty() || dG.empty()) { std::cout << "Please provide the image, pose, altitude and groundrange folders..." << std::endl; return 0; }

@@ -173,6 +173,14 @@ int dsss_triangulate_poses(dsss_ctx*, const double* kp7, const double* in27, int
  * Page-locked output buffers make the download run at PCIe speed.                                             */
 int dsss_posegraph_select(dsss_ctx*, int nframes, dsss_lc_edge* edges_host, int cap, int* n_edges);
 int dsss_posegraph_solve(dsss_ctx*, int nframes, double* poses12_host, double* rpy6_host, double* stats4_host);
+/* N3, the online use (optimizer.cpp:134-139, 262-272: one ISAM2 object, isam.update as pings arrive, calculateEstimate):
+ * dsss_posegraph_update solves frames 0..nframes-1 like dsss_posegraph_solve, but (a) starts from the estimate the previous
+ * update of this context left for the pings it covered (new pings start at DR o noise as in the reference), and (b) works on
+ * the ACCUMULATED loop closures: every LC result set (dsss_lc_solve_all / dsss_lc_solve_pairs) is consumed once, by the next
+ * update; its pairs must lie within the nframes frames.  dsss_posegraph_reset forgets estimate and edges.  Single rank.     */
+int dsss_posegraph_update(dsss_ctx*, int nframes, double* poses12_host, double* rpy6_host, double* stats4_host);
+int dsss_posegraph_reset(dsss_ctx*);
+int dsss_posegraph_online_edges(dsss_ctx*);      /* loop closures accumulated so far (>= 0) */
 /* stand-alone form: explicit DR chain + edges                                                               */
 int dsss_posegraph_solve_edges(dsss_ctx*, const double* dr6, int total, const dsss_lc_edge* edges, int ne,
                                double* poses12_host, double* stats4_host);

@@ -129,6 +129,23 @@ def test_config_C1_substitute_through_test_demo(orc, tmp_path):
     _cmp_traj(est1, o1)
     assert np.abs(est1 - est0).max() > 1e-6                                   # the two branches really are different solves
     _check_anno_evaluators(orc, log, fr, annos, o1, F, N, M)
+    # N3, the online use: frame-by-frame updates as the reference's iSAM2 loop makes them (optimizer.cpp:134-272) end at the
+    # optimum of the same graph -- same loop closures, and the oracle's objective at the online result is the batch one to the LM
+    # stopping tolerance (1e-5 relative per step; 1e-3 here), positions within millimetres
+    est2, log2 = _run_demo(tmp_path, d, ["--annotation", d["annotation"], "--use-anno", "0", "--online", "1"], "o")
+    assert ("%d loop closures" % len(e0)) in log2 and ("online: %d updates" % F) in log2
+    dr = np.concatenate([f["pose"] for f in fr])
+    def as12(est):                                                            # trajectory rows "r p y x y z" -> R (row-major), t
+        out = np.zeros((len(est), 12))
+        cr, sr, cp, sp, cy, sy = np.cos(est[:, 0]), np.sin(est[:, 0]), np.cos(est[:, 1]), np.sin(est[:, 1]), np.cos(est[:, 2]), np.sin(est[:, 2])
+        out[:, 0] = cy * cp; out[:, 1] = cy * sp * sr - sy * cr; out[:, 2] = cy * sp * cr + sy * sr
+        out[:, 3] = sy * cp; out[:, 4] = sy * sp * sr + cy * cr; out[:, 5] = sy * sp * cr - cy * sr
+        out[:, 6] = -sp; out[:, 7] = cp * sr; out[:, 8] = cp * cr
+        out[:, 9:] = est[:, 3:]
+        return out
+    eb, eo = orc.pg_error_at(dr, e0, as12(est0)), orc.pg_error_at(dr, e0, as12(est2))
+    assert eo <= eb * (1 + 1e-3) + 1e-6, (eo, eb)
+    assert np.abs(est2[:, 3:] - est0[:, 3:]).max() < 5e-3
 
 
 def _check_anno_evaluators(orc, log, fr, annos, est12, F, N, M):

@@ -85,6 +85,28 @@ def test_extract_small_orb_config_and_reuse(ctx, orc):
     ctx.set_params(orb=dp)
 
 
+@pytest.mark.parametrize("scale,N,M", [(2.0, 1000, 802), (1.5, 801, 598), (1.1, 501, 334)])
+def test_extract_other_scale_factors(ctx, orc, scale, N, M):
+    """pyramid scale factors other than 1.2 and odd sizes: at 2.0 the source bytes of four output pixels do not fit the
+    12-byte windows of resize_kernel and the pixel-by-pixel form runs; every level must match the oracle's byte for byte"""
+    raw, pose, alt, gr = _frame(N, M, 11, hot=False)
+    mp, op, mt, pg = ctx.default_params()
+    op.nfeatures = 600; op.nlevels = 4; op.scale = scale
+    ctx.set_params(orb=op)
+    try:
+        ctx.frame_set(2, raw, N, M, pose, alt, gr)
+        n = ctx.extract(2)
+        po = orc.orb_params(); po.nfeatures = 600; po.nlevels = 4; po.scale = scale
+        kps, desc, _, _ = orc.detect_feature(raw, None, po)
+        g_kps, g_desc, _ = ctx.features_get(2)
+        assert n == len(kps) and n > 50
+        for fld in ("x", "y", "octave", "angle", "response"):
+            assert (g_kps[fld] == kps[fld]).all(), fld
+        assert (g_desc == desc).all()
+    finally:
+        ctx.set_params(orb=ctx.default_params()[1])
+
+
 def test_extract_device_resident_input(ctx, orc):
     """raw image handed over as a device pointer (torch tensor in HBM): same result, no host copy"""
     import torch

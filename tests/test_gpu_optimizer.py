@@ -135,3 +135,39 @@ def test_initial_values_follow_libstdcxx_normal_stream(ctx, orc):
     z = np.zeros(6 * n); orc.lib().orc_normal_fill(orc.dp(z), 6 * n)
     assert np.abs(o_out[:, 9:] - dr[:, 3:]).max() > 0.5            # noise really applied (sigma 0.5 m)
     assert np.abs(g_out - o_out).max() < 1e-12
+
+
+def test_online_updates_reach_the_batch_optimum(ctx, orc, survey):
+    """N3 (optimizer.cpp:134-272, the iSAM2 loop): frame-by-frame dsss_posegraph_update -- each update consumes the loop
+    closures that END in the new frame and starts from the previous estimate -- against ONE batch solve of the same graph.
+    Both are LM iterates stopped by the same relative tolerance (1e-5 on the objective) near the same minimum, so the
+    comparison is on the objective (oracle-evaluated at both results), not bit for bit on the poses."""
+    F, N = survey["F"], survey["N"]
+    src, tgt = survey["src"], survey["tgt"]
+    b_edges = ctx.posegraph_select(F)
+    b_out, _, b_stats = ctx.posegraph_solve(F, F * N, want_rpy=False)
+    kp7 = [ctx.match_kp7(p) for p in range(len(src))]
+    try:
+        ctx.posegraph_reset()                      # marks the LC set of the fixture as consumed: the graph starts empty
+        steps = []
+        for j in range(F):
+            pj = [p for p in range(len(src)) if tgt[p] == j and len(kp7[p])]
+            if pj:
+                ctx.lc_solve_pairs([src[p] for p in pj], [tgt[p] for p in pj], [kp7[p] for p in pj])
+            o_out, _, o_stats = ctx.posegraph_update(j + 1, (j + 1) * N)
+            steps.append(int(o_stats[0]))
+        assert ctx.posegraph_online_edges() == len(b_edges)
+        dr = np.concatenate([f["pose"] for f in survey["fr"]])
+        e_batch = orc.pg_error_at(dr, b_edges, b_out); e_online = orc.pg_error_at(dr, b_edges, o_out)
+        assert np.isclose(e_batch, b_stats[2], rtol=1e-6) and np.isclose(e_online, o_stats[2], rtol=1e-6)
+        assert e_online <= e_batch * (1 + 1e-3), (e_online, e_batch)
+        assert np.abs(o_out[:, 9:] - b_out[:, 9:]).max() < 5e-3                  # metres: same minimum to the LM stopping tolerance
+        # an update that adds nothing converges at once: one more call, no new LC set, at most one accepted step
+        again, _, st = ctx.posegraph_update(F, F * N)
+        assert st[0] <= 1 and np.abs(again - o_out).max() < 1e-3
+        # shrinking the graph under accumulated edges is refused, not silently wrong
+        with pytest.raises(Exception):
+            ctx.posegraph_update(1, N)
+    finally:
+        ctx.posegraph_reset()
+        ctx.match_pairs(src, tgt); ctx.lc_solve_all()
