@@ -2,7 +2,11 @@
 // system (see dsss_pg_sym.h), plus a host twin of the numeric phase for the CPU test-suite.  Plain C++, no HIP.
 #include "dsss_pg_sym.h"
 #include <algorithm>
+#include <atomic>
 #include <chrono>
+#include <condition_variable>
+#include <deque>
+#include <functional>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -12,13 +16,82 @@
 
 namespace {
 
+// A small pool of worker threads that lives as long as the process: the analysis is ~7 ms of host work per solve made of a
+// dozen short parallel phases, and a fresh std::thread per phase (50-100 us each to create, plus scheduling jitter) cost as
+// much as it saved.  Workers spin for a short while after a task before they go to sleep on the condition variable, so the
+// phases of one analysis find them awake.  fork() runs a task on a worker (or inline, if no worker took it by the time the
+// caller waits: the waiter steals it back), so recursion can fork at every level without ever blocking on a busy pool.
+class pg_pool {
+public:
+    struct task { std::function<void()> fn; std::atomic<int> st{ 0 }; };      // 0 queued, 1 running, 2 done
+    static pg_pool& get() { static pg_pool P; return P; }
+    void fork(task* t)
+    {
+        if (workers.empty()) { t->st.store(1); t->fn(); t->st.store(2, std::memory_order_release); return; }
+        { std::lock_guard<std::mutex> lk(mu); q.push_back(t); npending.fetch_add(1, std::memory_order_release); }
+        if (nsleep.load(std::memory_order_acquire) > 0) cv.notify_one();
+    }
+    void join(task* t)
+    {
+        if (t->st.load(std::memory_order_acquire) == 0) {        // not started yet: take it out of the queue and run it here
+            bool mine = false;
+            { std::lock_guard<std::mutex> lk(mu);
+              auto it = std::find(q.begin(), q.end(), t);
+              if (it != q.end()) { q.erase(it); npending.fetch_sub(1, std::memory_order_release); mine = true; } }
+            if (mine) { t->st.store(1); t->fn(); t->st.store(2, std::memory_order_release); return; }
+        }
+        for (int spins = 0; t->st.load(std::memory_order_acquire) != 2; ++spins) { if (spins > 2000) std::this_thread::yield(); }
+    }
+    ~pg_pool()
+    {
+        { std::lock_guard<std::mutex> lk(mu); stop.store(true); }
+        cv.notify_all();
+        for (auto& w : workers) w.join();
+    }
+private:
+    pg_pool()
+    {
+        const unsigned hc = std::thread::hardware_concurrency();
+        int n = hc > 1 ? (int)std::min(7u, hc - 1) : 0;
+        if (const char* e = getenv("DSSS_SYM_POOL")) n = std::max(0, std::min(63, atoi(e)));
+        for (int i = 0; i < n; ++i) workers.emplace_back([this] { run(); });
+    }
+    void run()
+    {
+        for (;;) {
+            task* t = nullptr;
+            const auto t0 = std::chrono::steady_clock::now();
+            for (int spins = 0; !t; ++spins) {
+                if (stop.load(std::memory_order_acquire)) return;
+                if (npending.load(std::memory_order_acquire) > 0) {
+                    std::lock_guard<std::mutex> lk(mu);
+                    if (!q.empty()) { t = q.front(); q.pop_front(); npending.fetch_sub(1, std::memory_order_release); t->st.store(1, std::memory_order_release); }
+                } else if ((spins & 255) == 255 && std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(300)) {
+                    std::unique_lock<std::mutex> lk(mu);
+                    nsleep.fetch_add(1, std::memory_order_release);
+                    cv.wait(lk, [&] { return stop.load() || !q.empty(); });
+                    nsleep.fetch_sub(1, std::memory_order_release);
+                    if (stop.load()) return;
+                    t = q.front(); q.pop_front(); npending.fetch_sub(1, std::memory_order_release); t->st.store(1, std::memory_order_release);
+                }
+            }
+            t->fn();
+            t->st.store(2, std::memory_order_release);
+        }
+    }
+    std::mutex mu; std::condition_variable cv; std::deque<task*> q;
+    std::atomic<int> npending{ 0 }, nsleep{ 0 }; std::atomic<bool> stop{ false };
+    std::vector<std::thread> workers;
+};
+
 template <class F> void par_ranges(int n, int T, F fn)          // fn(t, lo, hi) over T contiguous ranges of [0, n)
 {
     T = std::max(1, std::min(T, std::max(n, 1)));
-    std::vector<std::thread> th;
-    for (int t = 1; t < T; ++t) th.emplace_back([&, t] { fn(t, (int)((long long)n * t / T), (int)((long long)n * (t + 1) / T)); });
+    pg_pool& P = pg_pool::get();
+    std::vector<pg_pool::task> tk(T > 1 ? T - 1 : 0);
+    for (int t = 1; t < T; ++t) { tk[t - 1].fn = [&fn, n, T, t] { fn(t, (int)((long long)n * t / T), (int)((long long)n * (t + 1) / T)); }; P.fork(&tk[t - 1]); }
     fn(0, 0, (int)((long long)n / T));
-    for (auto& x : th) x.join();
+    for (auto& x : tk) P.join(&x);
 }
 
 // nested dissection with vertex separators taken from the lower half.  The order of a subtree is [A][B][separator]; A and B
@@ -74,10 +147,11 @@ int nd_order(std::vector<int>& nodes, const nd_ctx& C, std::vector<int>& order, 
     const int alo = plo, ahi = by_part ? pmid : phi, blo = by_part ? pmid : plo, bhi = phi;
     if (depth < PG_ND_PAR && (total > 2048 || by_part)) {
         std::vector<int> oa;
-        std::thread th([&] { na = nd_order(A, C, oa, depth + 1, alo, ahi); });
+        pg_pool::task tk; tk.fn = [&] { na = nd_order(A, C, oa, depth + 1, alo, ahi); };
+        pg_pool::get().fork(&tk);
         std::vector<int> ob;
         nb = nd_order(B, C, ob, depth + 1, blo, bhi);
-        th.join();
+        pg_pool::get().join(&tk);
         order.insert(order.end(), oa.begin(), oa.end());
         order.insert(order.end(), ob.begin(), ob.end());
     } else {
@@ -106,9 +180,10 @@ void col_structs(const cs_ctx& C, int t, int lo, int size, std::vector<std::pair
     if (t >= 0 && nd.a >= 0 && nd.b >= 0) {
         const int sa = (*C.pool)[nd.a].size, sb = (*C.pool)[nd.b].size;
         std::vector<std::pair<int, int>> ua, ub;
-        std::thread th([&] { col_structs(C, nd.a, lo, sa, ua, depth + 1); });
+        pg_pool::task tk; tk.fn = [&] { col_structs(C, nd.a, lo, sa, ua, depth + 1); };
+        pg_pool::get().fork(&tk);
         col_structs(C, nd.b, lo + sa, sb, ub, depth + 1);
-        th.join();
+        pg_pool::get().join(&tk);
         for (auto* u : { &ua, &ub })
             for (auto& e : *u) { if (e.first < hi) add_kid(e.first, e.second); else up.push_back(e); }
         seq_lo = lo + sa + sb;
@@ -197,12 +272,21 @@ void pg_symbolic(int ns, const std::vector<std::pair<int, int>>& edges, int ncha
     par_ranges(ns, T, [&](int, int lo, int hi) {
         for (int k = lo; k < hi; ++k) { const int* d = pools[cols[k].pool].data() + cols[k].off; std::copy(d, d + cols[k].n, S.rowidx.begin() + S.colptr[k]); }
     });
+    const auto f0 = tnow();
     const std::vector<int>& parent = S.parent;
     // ---- bottom subtrees -> bins (one workgroup each); only interior columns of one rank, at most 42 blocks per column
     std::vector<double> sub_cost(ns, 0);
     std::vector<char> sub_ok(ns, 0);
     std::vector<int> nsrc(ns, 0);                          // number of source columns of every column = its count of off-diagonal blocks in row j
-    for (int k = 0; k < ns; ++k) for (int q = S.colptr[k] + 1; q < S.colptr[k + 1]; ++q) nsrc[S.rowidx[q]]++;
+    {   // a histogram per range of source columns, then summed (788 k scattered increments at C3: a third of this phase when serial)
+        std::vector<std::vector<int>> part_h(T > 1 ? T - 1 : 0);
+        par_ranges(ns, T, [&](int t, int lo, int hi) {
+            int* h = nsrc.data();
+            if (t > 0) { part_h[t - 1].assign(ns, 0); h = part_h[t - 1].data(); }
+            for (int k = lo; k < hi; ++k) for (int q = S.colptr[k] + 1; q < S.colptr[k + 1]; ++q) h[S.rowidx[q]]++;
+        });
+        par_ranges(ns, T, [&](int, int lo, int hi) { for (auto& h : part_h) if (!h.empty()) for (int j = lo; j < hi; ++j) nsrc[j] += h[j]; });
+    }
     for (int j = 0; j < ns; ++j) {
         const int mj = csz(j);
         double cst = nsrc[j] + 20.0; bool ok = mj <= 42 && S.col_part[j] >= 0;
@@ -245,6 +329,7 @@ void pg_symbolic(int ns, const std::vector<std::pair<int, int>>& edges, int ncha
         for (size_t i = 0; i < S.broot.size(); ++i) { S.broot_uoff[i] = o; const long long n6 = 6LL * S.broot_b[i]; o += n6 * n6 + n6; o = (o + 31) & ~31LL; }
         S.ubin_doubles = o;
     }
+    const auto f1 = tnow();
     // rows of a binned column beyond its subtree root, as indices into the root's boundary list
     S.anc_first.assign(ns, 0);
     S.anc_rel.assign(S.nnzL, -1);
@@ -260,6 +345,7 @@ void pg_symbolic(int ns, const std::vector<std::pair<int, int>>& edges, int ncha
             for (; q < m; ++q) { const int row = S.rowidx[c0 + q]; while (w < nb && rb[w] < row) ++w; S.anc_rel[c0 + q] = (w < nb && rb[w] == row) ? w : -1; }
         }
     });
+    const auto f2 = tnow();
     // update lists of the binned columns (sources are binned columns of the same subtree), ascending source
     {
         std::vector<std::vector<int>> hist(T, std::vector<int>(ns, 0));
@@ -286,6 +372,7 @@ void pg_symbolic(int ns, const std::vector<std::pair<int, int>>& edges, int ncha
         for (int j = 0; j < ns; ++j) S.mapptr[j + 1] = S.mapptr[j] + (long long)(S.rlptr[j + 1] - S.rlptr[j]) * (long long)csz(j);
     }
     const auto q3 = tnow();
+    if (tv) fprintf(stderr, "[dsss pg symbolic] bins+lists: rowidx copy %.2f, bins %.2f, anc_rel %.2f, update lists %.2f ms\n", tms(q2, f0), tms(f0, f1), tms(f1, f2), tms(f2, q3));
     // ---- top: supernodes of the remaining columns become fronts.  Fundamental supernodes (consecutive columns with nested
     // structure) first; then RELAXED amalgamation along the column order: a front whose columns end where its parent's begin is
     // merged into the parent when that adds few explicit zero blocks -- every merge removes a level of the schedule, and the
