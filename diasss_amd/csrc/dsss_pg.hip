@@ -1682,6 +1682,15 @@ __global__ __launch_bounds__(256) void pg_flag_compact_kernel(const int* __restr
         __syncthreads();
     }
 }
+// DR rows of the frames (device copies kept by dsss_frame_set) into one array, frame after frame
+__global__ __launch_bounds__(256) void pg_gather_dr_kernel(const unsigned long long* __restrict__ fptr, const int* __restrict__ foff, double* __restrict__ out)
+{
+    const int f = blockIdx.y;
+    const double* __restrict__ src = reinterpret_cast<const double*>(fptr[f]);
+    const size_t n6 = (size_t)(foff[f + 1] - foff[f]) * 6;
+    double* __restrict__ dst = out + (size_t)foff[f] * 6;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n6; i += (size_t)gridDim.x * 256) dst[i] = src[i];
+}
 // x, y of the separator poses (the coordinates the nested dissection bisects)
 __global__ __launch_bounds__(256) void pg_sep_xy_kernel(int ns, const int* __restrict__ sep_pose, const double* __restrict__ dr6, double* __restrict__ xy)
 {
@@ -1802,12 +1811,6 @@ static int pg_solve_impl(dsss_ctx* c, const double* dr6, int total, const dsss_l
         }
         for (int k = 0; k < 12; ++k) if (!std::isfinite(edges[e].rel[k])) DSSS_FAIL(c, DSSS_E_NUMERIC, "LC edge %d: relative pose is not finite", e);
     }
-    // incidence lists (edge order), separators, segments
-    std::vector<int> adj_ptr(n + 1, 0), adj_edge(2 * (size_t)ne);
-    for (int e = 0; e < ne; ++e) { adj_ptr[ea[e] + 1]++; adj_ptr[eb[e] + 1]++; }
-    for (int i = 0; i < n; ++i) adj_ptr[i + 1] += adj_ptr[i];
-    { std::vector<int> fill(adj_ptr.begin(), adj_ptr.end() - 1);
-      for (int e = 0; e < ne; ++e) { adj_edge[fill[ea[e]]++] = e << 1; adj_edge[fill[eb[e]]++] = (e << 1) | 1; } }
     // Two levels of chain elimination.  TRUE separators (the unknowns of the sparse factorisation): LC-touched poses, the first and
     // the last pose, the last pose of every partition.  CHUNK ends: every PG_CHUNK-th pose as well, which bounds the sequential
     // depth of the per-segment block-Thomas recursion (one thread per segment).  Pass 1 condenses every chunk onto its two ends
@@ -1848,8 +1851,15 @@ static int pg_solve_impl(dsss_ctx* c, const double* dr6, int total, const dsss_l
     {
         hipError_t e = hipSuccess;
         if (dr6) e = hipMemcpyAsync(d_dr6, dr6, (size_t)n * 6 * sizeof(double), hipMemcpyHostToDevice, c->stream);
-        else for (int f = 0; f < nframes && e == hipSuccess; ++f)
-            e = hipMemcpyAsync(d_dr6 + (size_t)foff[f] * 6, c->frames[f].pose6, (size_t)c->frames[f].N * 6 * sizeof(double), hipMemcpyDeviceToDevice, c->stream);
+        else {      // one gather launch over the frames' device copies (a device-to-device copy per frame cost 0.5 ms of launches at 200 frames)
+            std::vector<unsigned long long> fp(nframes);
+            for (int f = 0; f < nframes; ++f) fp[f] = (unsigned long long)(uintptr_t)c->frames[f].pose6;
+            unsigned long long* d_fp = nullptr; int* d_foff = nullptr;
+            int r2 = dv.upload(c, &d_fp, fp); if (!r2) r2 = dv.upload(c, &d_foff, foff);
+            if (r2) { dv.release(); return r2; }
+            hipLaunchKernelGGL(pg_gather_dr_kernel, dim3(8, nframes), dim3(256), 0, c->stream, d_fp, d_foff, d_dr6);
+            e = hipGetLastError();
+        }
         if (e == hipSuccess) { hipLaunchKernelGGL(pg_sep_xy_kernel, dim3((ns + 255) / 256), dim3(256), 0, c->stream, ns, d_sep, d_dr6, d_sxy); e = hipGetLastError(); }
         if (e == hipSuccess) e = hipMemcpyAsync(sxy.data(), d_sxy, sxy.size() * sizeof(double), hipMemcpyDeviceToHost, c->stream);
         if (e == hipSuccess) e = hipStreamSynchronize(c->stream);      // the library's stream does not synchronise with the null stream
@@ -1877,6 +1887,12 @@ static int pg_solve_impl(dsss_ctx* c, const double* dr6, int total, const dsss_l
     struct pg_joiner { std::thread& t; ~pg_joiner() { if (t.joinable()) t.join(); } } sym_join{ sym_thread };      // every return path waits for the thread before its data goes away
     const bool verbose = getenv("DSSS_PG_VERBOSE") != nullptr;
 
+    // incidence lists of the poses (edge order): only the device kernels read them, so they are built while the analysis runs
+    std::vector<int> adj_ptr(n + 1, 0), adj_edge(2 * (size_t)ne);
+    for (int e = 0; e < ne; ++e) { adj_ptr[ea[e] + 1]++; adj_ptr[eb[e] + 1]++; }
+    for (int i = 0; i < n; ++i) adj_ptr[i + 1] += adj_ptr[i];
+    { std::vector<int> fill(adj_ptr.begin(), adj_ptr.end() - 1);
+      for (int e = 0; e < ne; ++e) { adj_edge[fill[ea[e]]++] = e << 1; adj_edge[fill[eb[e]]++] = (e << 1) | 1; } }
     // ---- early device set-up (nothing here reads S)
     pose_t *d_X, *d_Xn, *d_meas, *d_emeas; int *d_ea, *d_eb, *d_adj_ptr, *d_adj_edge, *d_perm;
     double *d_ew, *d_r, *d_Ji, *d_D, *d_C, *d_g, *d_delta, *d_E, *d_Dl, *d_gi, *d_sDL, *d_sDR, *d_sGL, *d_sGR, *d_sS, *d_L, *d_x, *d_part, *d_scal;
