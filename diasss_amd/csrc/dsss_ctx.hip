@@ -2,6 +2,7 @@
 // Mirrors the data side of Diasss::Frame (/root/reference/src/core/frame.h:19-46, frame.cpp:18-55,126-165)
 // and Util::ComputeIntersection (/root/reference/src/util/util.cpp:13-43).
 #include "dsss_internal.h"
+#include "dsss_pg_sym.h"
 #include <algorithm>
 #include <chrono>
 #include <thread>
@@ -409,10 +410,10 @@ int dsss_frames_set(dsss_ctx* c, int n, const int* ids, const double* const* raw
     dsss_geo_batch& G = c->gbatches[b];
     HIPCHK(c, hipEventSynchronize(G.ev));                   // the staging area may still feed its previous upload
     static const int T_env = getenv("DSSS_FS_THREADS") ? atoi(getenv("DSSS_FS_THREADS")) : 0;
-    const int T = T_env > 0 ? T_env : (n >= 16 ? 4 : 1);
+    const int T = T_env > 0 ? T_env : (n >= 16 ? 8 : 1);
     std::vector<hipError_t> errs(T, hipSuccess);
     auto work = [&](int t) { for (int i = t; i < n; i += T) { const hipError_t e = frame_fill(c, ids[i], G.h + off[i], pose6[i], alt[i], grange[i]); if (e != hipSuccess) errs[t] = e; } };
-    { std::vector<std::thread> th; for (int t = 1; t < T; ++t) th.emplace_back(work, t); work(0); for (auto& x : th) x.join(); }
+    dsss_pool_run(T, work);
     for (int t = 0; t < T; ++t) HIPCHK(c, errs[t]);
     HIPCHK(c, hipMemcpyAsync(G.d, G.h, total * sizeof(double), hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipEventRecord(G.ev, c->stream));

@@ -94,6 +94,20 @@ template <class F> void par_ranges(int n, int T, F fn)          // fn(t, lo, hi)
     for (auto& x : tk) P.join(&x);
 }
 
+} // namespace
+
+void dsss_pool_run(int T, const std::function<void(int)>& fn)
+{
+    T = std::max(1, T);
+    pg_pool& P = pg_pool::get();
+    std::vector<pg_pool::task> tk(T - 1);
+    for (int t = 1; t < T; ++t) { tk[t - 1].fn = [&fn, t] { fn(t); }; P.fork(&tk[t - 1]); }
+    fn(0);
+    for (auto& x : tk) P.join(&x);
+}
+
+namespace {
+
 // nested dissection with vertex separators taken from the lower half.  The order of a subtree is [A][B][separator]; A and B
 // never touch, so the first PG_ND_PAR levels run their two halves on two host threads and the same tree of ranges later
 // drives the parallel column-structure pass.  While a node set spans several ranks the cut is the rank boundary (lower

@@ -18,7 +18,12 @@
 // Replaces GTSAM's ordering + symbolic factorisation inside ISAM2 / LevenbergMarquardtOptimizer
 // (/root/reference/src/core/optimizer.cpp:134-139, 265-279).
 #pragma once
+#include <functional>
 #include <vector>
+
+// fn(t) for t in [0, T) on the process-wide worker pool of the analysis (threads that outlive the call: no thread is created per
+// use); returns when every t is done.  The caller runs t = 0 itself.
+void dsss_pool_run(int T, const std::function<void(int)>& fn);
 
 #define PG_PW 16                        // panel width in block columns (96 scalar columns)
 
