@@ -168,6 +168,16 @@ def test_online_updates_reach_the_batch_optimum(ctx, orc, survey):
         # shrinking the graph under accumulated edges is refused, not silently wrong
         with pytest.raises(Exception):
             ctx.posegraph_update(1, N)
+        # the same through the matcher itself, frame by frame (the call sequence of INTEGRATION.md): frame j is matched against
+        # the earlier frames, its loop closures are solved, the graph is updated
+        ctx.posegraph_reset()
+        for j in range(F):
+            pj = [p for p in range(len(src)) if tgt[p] == j]
+            if pj:
+                ctx.match_pairs([src[p] for p in pj], [tgt[p] for p in pj]); ctx.lc_solve_all()
+            m_out, _, m_stats = ctx.posegraph_update(j + 1, (j + 1) * N)
+        assert ctx.posegraph_online_edges() == len(b_edges)
+        assert np.abs(m_out - o_out).max() < 1e-9 and m_stats[0] == o_stats[0]      # same edges, same warm starts: the same run
     finally:
         ctx.posegraph_reset()
         ctx.match_pairs(src, tgt); ctx.lc_solve_all()
