@@ -3,8 +3,11 @@ update matrices, multifrontal fronts, extend-add maps, schedule -- diasss_amd/cs
 twin: the multifrontal solve of a random SPD block system must equal numpy's dense solve, for one rank and for a rank
 partition (where the interface columns are ordered last), for chain-only graphs, dense-ish graphs and lawn-mower-like ones."""
 import ctypes as C
+import os
 import numpy as np
 import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _system(ns, chords, seed):
@@ -105,3 +108,16 @@ def test_host_multifrontal_solve_with_rank_partition(nparts, monkeypatch):
     assert st[5] > 0                                             # update matrices cross from interiors into the interface
     x1, st1 = _solve(ea, eb, aval, rhs, cx, cy)
     assert np.abs(x - x1).max() < 1e-9
+
+
+def test_host_solver_under_thread_sanitizer():
+    """the analysis runs its parallel phases on a process-wide worker pool (spin-then-sleep workers, stolen-back tasks):
+    three threads solve different graphs at once under -fsanitize=thread (tools/sanitize/run.sh; ASan/UBSan: `run.sh asan`)"""
+    import shutil, subprocess
+    if shutil.which("g++") is None:
+        pytest.skip("no g++")
+    probe = subprocess.run("echo 'int main(){}' | g++ -x c++ -fsanitize=thread - -o /dev/null", shell=True, capture_output=True)
+    if probe.returncode != 0:
+        pytest.skip("g++ without libtsan")
+    out = subprocess.run(["bash", os.path.join(ROOT, "tools", "sanitize", "run.sh"), "tsan"], capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0 and "sanitizers: clean" in out.stdout, out.stdout[-2000:] + out.stderr[-3000:]

@@ -1,0 +1,46 @@
+// Sanitizer harness of the host side of the pose-graph solver (ordering, symbolic analysis, worker pool, host twin of the numeric
+// phase): three threads call dsss_host_pg_solve concurrently on lawn-mower-like graphs.  Built and run by tools/sanitize/run.sh with
+// -fsanitize=thread and with -fsanitize=address,undefined (CPU only: the GPU box has no sanitizer support).
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cmath>
+#include <thread>
+#include <vector>
+extern "C" int dsss_host_pg_solve(int ns, const int32_t* edge_a, const int32_t* edge_b, int nedges, const double* cx, const double* cy,
+                                  const int32_t* part, int nparts, const double* aval36, const double* rhs6, double* x6_host, int64_t* stats8);
+static void run(unsigned seed, int ns, int nlc, int reps)
+{
+    unsigned long long lcg = seed * 2654435761ull + 1; auto rnd = [&]() { lcg = lcg * 6364136223846793005ull + 1442695040888963407ull; return (int)((lcg >> 33) & 0x7fffffff); };
+    std::vector<int32_t> ea, eb; std::vector<double> cx(ns), cy(ns);
+    for (int k = 0; k + 1 < ns; ++k) { ea.push_back(k); eb.push_back(k + 1); }
+    const int leg = 200;
+    for (int k = 0; k < ns; ++k) { const int l = k / leg, p = k % leg; cx[k] = (l & 1) ? leg - p : p; cy[k] = 3.0 * l; }
+    for (int e = 0; e < nlc; ++e) {
+        int a = rnd() % ns, l = a / leg, p = a % leg;
+        int b = (l + 1) * leg + (leg - 1 - p) + (rnd() % 5 - 2);
+        if (b <= a || b >= ns) { --e; if (l + 1 >= ns / leg) { ++e; } continue; }
+        bool dup = false; for (size_t q = ns - 1; q < ea.size(); ++q) if (ea[q] == a && eb[q] == b) dup = true;
+        if (dup || b == a + 1) continue;
+        ea.push_back(a); eb.push_back(b);
+    }
+    const int ne = (int)ea.size();
+    std::vector<double> aval((size_t)(ns + ne) * 36, 0.0), rhs((size_t)ns * 6), x((size_t)ns * 6);
+    std::vector<double> diag(ns, 1.0);
+    for (int e = 0; e < ne; ++e) { for (int i = 0; i < 6; ++i) aval[(size_t)(ns + e) * 36 + i * 6 + i] = -0.3; diag[ea[e]] += 0.5; diag[eb[e]] += 0.5; }
+    for (int k = 0; k < ns; ++k) for (int i = 0; i < 6; ++i) aval[(size_t)k * 36 + i * 6 + i] = diag[k] + 0.1 * i;
+    for (size_t i = 0; i < rhs.size(); ++i) rhs[i] = sin(0.1 * i);
+    for (int r = 0; r < reps; ++r) {
+        int64_t st[8];
+        const int rc = dsss_host_pg_solve(ns, ea.data(), eb.data(), ne, cx.data(), cy.data(), nullptr, 1, aval.data(), rhs.data(), x.data(), st);
+        if (rc) { printf("rc %d\n", rc); exit(1); }
+    }
+    printf("seed %u ok: x[0] %.6f\n", seed, x[0]);
+}
+int main()
+{
+    std::thread a(run, 1u, 3000, 400, 3), b(run, 2u, 2400, 300, 3);
+    run(3u, 1800, 250, 3);
+    a.join(); b.join();
+    return 0;
+}
