@@ -115,7 +115,7 @@ namespace {
 struct nd_tree { int a = -1, b = -1, size = 0; };          // children (indices into the node pool) or -1,-1 for a leaf
 #define PG_ND_PAR 4
 struct nd_ctx {
-    const int* adj_ptr; const int* adj_idx; const double* cx; const double* cy; char* side; int leaf;
+    const int* adj_ptr; const int* adj_idx; const double* cx; const double* cy; char* side; int leaf; int both_axes;
     const int* part; char* iface;                          // rank of every node (or null); iface[v] = 1 for rank-level separator nodes
     std::vector<nd_tree>* pool; std::mutex* mu;
 };
@@ -127,27 +127,44 @@ int nd_order(std::vector<int>& nodes, const nd_ctx& C, std::vector<int>& order, 
     if (!by_part && total <= C.leaf) { std::sort(nodes.begin(), nodes.end()); for (int v : nodes) order.push_back(v); return depth <= PG_ND_PAR ? new_node(-1, -1, total) : -1; }
     size_t half;
     const int pmid = (plo + phi) / 2;
+    std::vector<int> A, B, S;
+    // lower-half nodes with a neighbour in the upper half = the separator of a split (sides are marked in C.side)
+    auto boundary = [&](const std::vector<int>& nd, size_t h, std::vector<int>* a, std::vector<int>* s) {
+        for (size_t i = 0; i < nd.size(); ++i) C.side[nd[i]] = i < h ? 1 : 2;
+        size_t cnt = 0;
+        for (size_t i = 0; i < h; ++i) {
+            const int v = nd[i];
+            bool cut = false;
+            for (int q = C.adj_ptr[v]; q < C.adj_ptr[v + 1]; ++q) if (C.side[C.adj_idx[q]] == 2) { cut = true; break; }
+            if (cut) { ++cnt; if (s) s->push_back(v); } else if (a) a->push_back(v);
+        }
+        return cnt;
+    };
     if (by_part) {
         half = std::stable_partition(nodes.begin(), nodes.end(), [&](int v) { return C.part[v] < pmid; }) - nodes.begin();
     } else {
         double x0 = 1e300, x1 = -1e300, y0 = 1e300, y1 = -1e300;
         for (int v : nodes) { x0 = std::min(x0, C.cx[v]); x1 = std::max(x1, C.cx[v]); y0 = std::min(y0, C.cy[v]); y1 = std::max(y1, C.cy[v]); }
-        const bool byx = (x1 - x0) >= (y1 - y0);
+        bool byx = (x1 - x0) >= (y1 - y0);
         half = nodes.size() / 2;
         // split at the median of the (coordinate, index) total order; only the two halves matter, not their inner order
-        const double* key = byx ? C.cx : C.cy;
-        std::nth_element(nodes.begin(), nodes.begin() + half, nodes.end(), [&](int a, int b) {
-            const double ka = key[a], kb = key[b];
-            return ka != kb ? ka < kb : a < b; });
+        auto split = [&](std::vector<int>& nd, bool bx) {
+            const double* key = bx ? C.cx : C.cy;
+            std::nth_element(nd.begin(), nd.begin() + half, nd.end(), [&](int a, int b) {
+                const double ka = key[a], kb = key[b];
+                return ka != kb ? ka < kb : a < b; });
+        };
+        if (total >= C.both_axes) {
+            // a survey is a long strip of parallel legs: the cut across the longer extent is not the cheaper one once a piece
+            // holds few legs (a cut between legs costs the loop closures of two legs, a cut across them one pose per leg).
+            // Both medians are tried and the smaller separator wins (ties: the longer extent).
+            std::vector<int> alt(nodes);
+            split(nodes, byx); split(alt, !byx);
+            const size_t c0 = boundary(nodes, half, nullptr, nullptr), c1 = boundary(alt, half, nullptr, nullptr);
+            if (c1 < c0) nodes.swap(alt);
+        } else split(nodes, byx);
     }
-    for (size_t i = 0; i < nodes.size(); ++i) C.side[nodes[i]] = i < half ? 1 : 2;
-    std::vector<int> A, B, S;
-    for (size_t i = 0; i < half; ++i) {
-        const int v = nodes[i];
-        bool cut = false;
-        for (int q = C.adj_ptr[v]; q < C.adj_ptr[v + 1]; ++q) if (C.side[C.adj_idx[q]] == 2) { cut = true; break; }
-        (cut ? S : A).push_back(v);
-    }
+    boundary(nodes, half, &A, &S);
     B.assign(nodes.begin() + half, nodes.end());
     for (int v : nodes) C.side[v] = 0;
     std::sort(S.begin(), S.end());
@@ -260,7 +277,7 @@ void pg_symbolic(int ns, const std::vector<std::pair<int, int>>& edges, int ncha
         std::vector<int> nodes(ns); std::iota(nodes.begin(), nodes.end(), 0);
         std::vector<char> side(ns, 0);
         S.order.reserve(ns);
-        nd_ctx C{ adj_ptr.data(), adj_idx.data(), cx, cy, side.data(), opt.leaf, S.nparts > 1 ? part : nullptr, iface.data(), &pool, &mu };
+        nd_ctx C{ adj_ptr.data(), adj_idx.data(), cx, cy, side.data(), opt.leaf, opt.nd_both_axes, S.nparts > 1 ? part : nullptr, iface.data(), &pool, &mu };
         root = nd_order(nodes, C, S.order, 0, 0, S.nparts);
     }
     const auto q1 = tnow();
@@ -792,6 +809,7 @@ extern "C" int dsss_host_pg_solve(int ns, const int32_t* edge_a, const int32_t* 
     pg_sym S; pg_sym_opts opt;
     if (getenv("DSSS_PG_BIN_COST")) opt.bin_cost = atof(getenv("DSSS_PG_BIN_COST"));
     if (getenv("DSSS_PG_LEAF")) opt.leaf = atoi(getenv("DSSS_PG_LEAF"));
+    if (getenv("DSSS_PG_ND_BOTH")) opt.nd_both_axes = atoi(getenv("DSSS_PG_ND_BOTH"));
     pg_sym_opts_env(opt);
     pg_symbolic(ns, edges, ns - 1, cx, cy, part, nparts, opt, S);
     const int rc = x ? pg_host_solve(S, nedges - (ns - 1), edges, aval, rhs, x) : 0;
