@@ -94,6 +94,26 @@ def test_host_multifrontal_solve_equals_dense(case):
         assert st[1] > 3 and st[6] > 0 and st[3] >= 2            # fronts, binned columns and several levels all occur
 
 
+def test_nested_dissection_picks_the_cheaper_axis_on_a_strip(monkeypatch):
+    """A survey is a long strip of legs: cutting across the longer extent (between legs) costs the loop closures of two legs
+    at every level, cutting across the legs one node per leg.  With both median cuts tried (pg_sym_opts::nd_both_axes) the
+    factor of a 40-leg strip must be markedly sparser than with the longer-extent rule alone, and the solve stays exact."""
+    legs, per_leg = 40, 30
+    ns, chords, cx, cy = _lawnmower(legs, per_leg, 21, density=0.9)
+    cy = cy * 4.0                                                # legs 12 apart, 30 long: the strip is 16 x longer than wide
+    ea, eb, aval, rhs, A = _system(ns, chords, 23)
+    ref = np.linalg.solve(A, rhs.ravel()).reshape(ns, 6)
+    monkeypatch.setenv("DSSS_PG_ND_BOTH", "1000000")
+    x0, st0 = _solve(ea, eb, aval, rhs, cx, cy)
+    monkeypatch.delenv("DSSS_PG_ND_BOTH")
+    x1, st1 = _solve(ea, eb, aval, rhs, cx, cy)
+    for x in (x0, x1):
+        assert np.abs(x - ref).max() < 1e-10 * max(1.0, np.abs(ref).max())
+    assert st1[0] < 0.8 * st0[0], (st0.tolist(), st1.tolist())   # factor blocks
+    x2, st2 = _solve(ea, eb, aval, rhs, cx, cy)
+    assert np.array_equal(x1, x2) and np.array_equal(st1, st2)   # deterministic
+
+
 @pytest.mark.parametrize("nparts", [2, 3, 4, 8])
 def test_host_multifrontal_solve_with_rank_partition(nparts, monkeypatch):
     """contiguous leg blocks per rank: interface columns last, comm children exist, same solution"""
