@@ -5,9 +5,9 @@
 # Output under gpurun_out/<tag>_*; tools/pmc_summary.py and tools/pmc_mfma_summary.py turn them into the tables under profiles/.
 TAG=${1:-r02}
 cd /tmp && export TMPDIR=/tmp; cd "$GRAFT_REPO_ROOT"
-B="python3 bench.py --steps 3 --warmup 1 --cpu-frames 0 --pcie-steps 0"
+B="python3 bench.py --steps 3 --warmup 1 --cpu-frames 0 --pcie-steps 0 --jobs-in-flight 1"
 rocprofv3 --kernel-trace --stats -d gpurun_out/${TAG}_stats -o ${TAG} --output-format csv -- $B > gpurun_out/${TAG}_bench_under_rocprof.log 2>&1
-P="python3 bench.py --steps 1 --warmup 0 --cpu-frames 0 --no-roofline --pcie-steps 0"
+P="python3 bench.py --steps 1 --warmup 0 --cpu-frames 0 --no-roofline --pcie-steps 0 --jobs-in-flight 1"
 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d gpurun_out/${TAG}_pmc_fetch -o f --output-format csv -- $P > gpurun_out/${TAG}_pmc_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d gpurun_out/${TAG}_pmc_write -o w --output-format csv -- $P > gpurun_out/${TAG}_pmc_write.log 2>&1
 rocprofv3 --pmc SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace -d gpurun_out/${TAG}_pmc_mfma -o m --output-format csv -- $P > gpurun_out/${TAG}_pmc_mfma.log 2>&1
