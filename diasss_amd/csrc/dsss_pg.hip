@@ -264,7 +264,7 @@ struct pg_seg_lds { double E[2][36], D[2][36], G[2][6], C[36], L[36], pad[4]; };
 // (not for the global stores in flight -- a fence would) and keeping the compiler from moving memory operations across is enough
 #define PG_COMPILER_FENCE() asm volatile("" ::: "memory")
 #define PG_GROUP_SYNC() do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_wave_barrier(); } while (0)
-__global__ __launch_bounds__(256, 2) void pg_segment_kernel(int nseg, const int* __restrict__ sep_pose, const double* __restrict__ D,
+__global__ __launch_bounds__(256, 2) void pg_segment_kernel(int nseg, const int* __restrict__ seg_order, const int* __restrict__ sep_pose, const double* __restrict__ D,
                                                         const double* __restrict__ C, const double* __restrict__ g,
                                                         double* __restrict__ E, double* __restrict__ Dl, double* __restrict__ gi,
                                                         double* __restrict__ segDL, double* __restrict__ segDR, double* __restrict__ segGL,
@@ -272,8 +272,12 @@ __global__ __launch_bounds__(256, 2) void pg_segment_kernel(int nseg, const int*
 {
     __shared__ pg_seg_lds sh_all[256 / PG_SEG_LANES];
     const int grp = threadIdx.x / PG_SEG_LANES, c = threadIdx.x % PG_SEG_LANES;
-    const int s = blockIdx.x * (256 / PG_SEG_LANES) + grp;
-    if (s >= nseg) return;                                      // whole groups leave together
+    const int slot = blockIdx.x * (256 / PG_SEG_LANES) + grp;
+    if (slot >= nseg) return;                                   // whole groups leave together
+    // segments are taken in descending order of length (host counting sort): the four segments of a wavefront run the same number
+    // of dependent steps (lengths are spread evenly over 1..15, a wavefront of unsorted ones idles a third of its lanes) and the
+    // longest start first
+    const int s = seg_order[slot];
     pg_seg_lds& sh = sh_all[grp];
     const int L = sep_pose[s], R = sep_pose[s + 1];
     if (L + 1 < mp0 || L + 1 >= mp1) return;                    // a segment belongs to the owner of its poses (partitions end on a separator)
@@ -1531,12 +1535,13 @@ __device__ __forceinline__ void pg_bs_load(pg_bs_blk& B, int i, int aa, const do
 #pragma unroll
         for (int k = 0; k <= r; ++k) B.Lm[r * (r + 1) / 2 + k] = Dl[(size_t)i * 36 + r * 6 + k];
 }
-__global__ __launch_bounds__(256) void pg_backsub_kernel(int nseg, const int* __restrict__ sep_pose, const double* __restrict__ C,
+__global__ __launch_bounds__(256) void pg_backsub_kernel(int nseg, const int* __restrict__ seg_order, const int* __restrict__ sep_pose, const double* __restrict__ C,
                                                          const double* __restrict__ E, const double* __restrict__ Dl, const double* __restrict__ gi,
                                                          double* __restrict__ delta, int mp0, int mp1)
 {
-    const int s = blockIdx.x * (256 / PG_BS_LANES) + threadIdx.x / PG_BS_LANES, a = threadIdx.x % PG_BS_LANES;
-    if (s >= nseg) return;                                      // whole groups leave together
+    const int slot = blockIdx.x * (256 / PG_BS_LANES) + threadIdx.x / PG_BS_LANES, a = threadIdx.x % PG_BS_LANES;
+    if (slot >= nseg) return;                                   // whole groups leave together
+    const int s = seg_order[slot];                              // descending length, as in pg_segment_kernel
     const int L = sep_pose[s], R = sep_pose[s + 1];
     if (L + 1 < mp0 || L + 1 >= mp1 || R == L + 1) return;
     const int aa = a < 6 ? a : 5;                               // lanes 6 and 7 shadow lane 5 and store nothing
@@ -1845,8 +1850,23 @@ static int pg_solve_impl(dsss_ctx* c, const double* dr6, int total, const dsss_l
 #define TRY(x) do { rc = (x); if (rc) { dv.release(); return rc; } } while (0)
     // DR rows on the device first: the separator coordinates for the ordering come back from there (host reads of the
     // frames' pinned copies are slow), and the copies overlap with the rest of the host preparation
-    double* d_dr6; double* d_sxy; int* d_sep; int* d_sep1; int* d_t2;
+    double* d_dr6; double* d_sxy; int* d_sep; int* d_sep1; int* d_t2; int* d_ord1; int* d_ord2;
     TRY(dv.alloc(c, &d_dr6, (size_t)n * 6)); TRY(dv.alloc(c, &d_sxy, (size_t)ns * 2)); TRY(dv.upload(c, &d_sep, sep_pose)); TRY(dv.upload(c, &d_sep1, sep1)); TRY(dv.upload(c, &d_t2, t2));
+    {   // segments of both passes in descending order of length (stable counting sort: ties stay in chain order)
+        auto by_length = [](const std::vector<int>& ends, std::vector<int>& ord) {
+            const int m = (int)ends.size() - 1;
+            ord.resize(std::max(m, 1));
+            int maxlen = 0;
+            for (int k = 0; k < m; ++k) maxlen = std::max(maxlen, ends[k + 1] - ends[k]);
+            std::vector<int> cnt(maxlen + 2, 0);
+            for (int k = 0; k < m; ++k) cnt[maxlen - (ends[k + 1] - ends[k]) + 1]++;
+            for (int l = 0; l <= maxlen; ++l) cnt[l + 1] += cnt[l];
+            for (int k = 0; k < m; ++k) ord[cnt[maxlen - (ends[k + 1] - ends[k])]++] = k;
+        };
+        std::vector<int> ord1, ord2;
+        by_length(sep1, ord1); by_length(t2, ord2);
+        TRY(dv.upload(c, &d_ord1, ord1)); TRY(dv.upload(c, &d_ord2, ord2));
+    }
     std::vector<double> sxy((size_t)ns * 2), cx(ns), cy(ns);
     {
         hipError_t e = hipSuccess;
@@ -1982,9 +2002,9 @@ static int pg_solve_impl(dsss_ctx* c, const double* dr6, int total, const dsss_l
     auto chain_part = [&]() {
         hipMemsetAsync(d_fail, 0, sizeof(int), st);
         hipLaunchKernelGGL(pg_assemble_kernel, dim3((n + PG_ASM_POSES - 1) / PG_ASM_POSES), dim3(6 * PG_ASM_POSES), 0, st, n, W, d_r, d_Ji, d_adj_ptr, d_adj_edge, d_ew, d_scal + 3, d_D, d_C, d_g, d_eb, mp0, mp1);
-        hipLaunchKernelGGL(pg_segment_kernel, dim3((nseg1 + 15) / 16), dim3(256), 0, st, nseg1, d_sep1, d_D, d_C, d_g, d_E, d_Dl, d_gi, d_sDL, d_sDR, d_sGL, d_sGR, d_sS, d_fail, mp0, mp1);
+        hipLaunchKernelGGL(pg_segment_kernel, dim3((nseg1 + 15) / 16), dim3(256), 0, st, nseg1, d_ord1, d_sep1, d_D, d_C, d_g, d_E, d_Dl, d_gi, d_sDL, d_sDR, d_sGL, d_sGR, d_sS, d_fail, mp0, mp1);
         hipLaunchKernelGGL(pg_chain1_kernel, dim3((unsigned)(((long long)ns1 * 42 + 255) / 256)), dim3(256), 0, st, ns1, d_sep1, d_D, d_g, d_sDL, d_sDR, d_sGL, d_sGR, d_sS, d_D1, d_C1, d_g1, mp0, mp1);
-        if (nseg > 0) hipLaunchKernelGGL(pg_segment_kernel, dim3((nseg + 15) / 16), dim3(256), 0, st, nseg, d_t2, d_D1, d_C1, d_g1, d_E1, d_Dl1, d_gi1, d_s2DL, d_s2DR, d_s2GL, d_s2GR, d_s2S, d_fail, kp0, kp1);
+        if (nseg > 0) hipLaunchKernelGGL(pg_segment_kernel, dim3((nseg + 15) / 16), dim3(256), 0, st, nseg, d_ord2, d_t2, d_D1, d_C1, d_g1, d_E1, d_Dl1, d_gi1, d_s2DL, d_s2DR, d_s2GL, d_s2GR, d_s2S, d_fail, kp0, kp1);
     };
     const bool will_iterate = err > 0 && c->pg.max_iters > 0;
     bool pre_lin = false, pre_chain = false;
@@ -2155,9 +2175,9 @@ static int pg_solve_impl(dsss_ctx* c, const double* dr6, int total, const dsss_l
                 if (nbins > 0) { dsss_scope s7(c, DSSS_K_PG_SUBTREE);
                     hipLaunchKernelGGL(pg_bwd_subtree_kernel, dim3(nbins), dim3(64), 0, st, d_binptr + bin_lo, d_bincols, d_colptr, d_rowidx, d_L, d_x); }
                 hipLaunchKernelGGL(pg_sep_delta_kernel, dim3((ns + 255) / 256), dim3(256), 0, st, ns, d_t2, d_perm, d_x, d_delta1);
-                if (nseg > 0) hipLaunchKernelGGL(pg_backsub_kernel, dim3((nseg + 31) / 32), dim3(256), 0, st, nseg, d_t2, d_C1, d_E1, d_Dl1, d_gi1, d_delta1, kp0, kp1);
+                if (nseg > 0) hipLaunchKernelGGL(pg_backsub_kernel, dim3((nseg + 31) / 32), dim3(256), 0, st, nseg, d_ord2, d_t2, d_C1, d_E1, d_Dl1, d_gi1, d_delta1, kp0, kp1);
                 hipLaunchKernelGGL(pg_sep_delta_kernel, dim3((ns1 + 255) / 256), dim3(256), 0, st, ns1, d_sep1, (const int*)nullptr, d_delta1, d_delta);
-                hipLaunchKernelGGL(pg_backsub_kernel, dim3((nseg1 + 31) / 32), dim3(256), 0, st, nseg1, d_sep1, d_C, d_E, d_Dl, d_gi, d_delta, mp0, mp1);
+                hipLaunchKernelGGL(pg_backsub_kernel, dim3((nseg1 + 31) / 32), dim3(256), 0, st, nseg1, d_ord1, d_sep1, d_C, d_E, d_Dl, d_gi, d_delta, mp0, mp1);
                 hipLaunchKernelGGL(pg_linerr_kernel, dim3(nblk), dim3(256), 0, st, n, ne, W, d_ea, d_eb, d_ew, d_r, d_Ji, d_delta, d_part, mp0, mp1);
                 hipLaunchKernelGGL(pg_final_sum_kernel, dim3(1), dim3(256), 0, st, d_part, nblk, 0.5, d_scal + 1);
             }
