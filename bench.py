@@ -215,10 +215,10 @@ def main():
             p.run(raws, poses, alts, grs)
         barrier()
 
-        def work(p):
+        def run_job(p):
             for _ in range(args.steps):
                 p.run(raws, poses, alts, grs)
-        th = [threading.Thread(target=work, args=(p,)) for p in pipes]
+        th = [threading.Thread(target=run_job, args=(p,)) for p in pipes]
         t2 = time.perf_counter()
         for t in th:
             t.start()
