@@ -215,10 +215,13 @@ def main():
             p.run(raws, poses, alts, grs)
         barrier()
 
-        def run_job(p):
+        stagger = dt / args.steps / len(pipes)           # surveys arrive evenly spaced (inside the timed region): solve of one under the extraction of the next
+
+        def run_job(p, k):
+            time.sleep(k * stagger)
             for _ in range(args.steps):
                 p.run(raws, poses, alts, grs)
-        th = [threading.Thread(target=run_job, args=(p,)) for p in pipes]
+        th = [threading.Thread(target=run_job, args=(p, k)) for k, p in enumerate(pipes)]
         t2 = time.perf_counter()
         for t in th:
             t.start()
