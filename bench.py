@@ -301,7 +301,7 @@ SLOT_KERNEL = {"row_reduce": "row_reduce_kernel", "normalize": "normalize_kernel
                "pg_acc": "pg_front_syrk_kernel", "pg_diag": "pg_front_diag4_kernel", "pg_trsm": "pg_front_trsm2_kernel", "pg_bwd": "pg_front_bwd2_kernel"}
 NOTES = {"pg_acc": "trailing update of the multifrontal fronts, 64 x 64 tiles on v_mfma_f64_16x16x4_f64 (K = one 96-column panel): the bulk of the factorisation flops; launches are short, so the matrix cores idle between levels",
          "pg_diag": "96-column panel Cholesky in the registers of four wavefronts: 24 dependent 4 x 4 pivot blocks (about 1950 cycles each: readlane, 4 x rsq + Newton, LDS, MFMA, LDS, MFMA), every rank-4 update one v_mfma_f64_16x16x4_f64 per tile; latency-bound",
-         "fast": "VALU-bound: packed 16-bit sliding min/max over the 16-pixel ring; work = pixels of all pyramid levels",
+         "fast": "VALU-bound: packed 16-bit sliding min/max over the 16-pixel ring; work = pixels of all pyramid levels; frac prices the arc loop alone (127 instructions per 64 pixels), valu_issue_util is the share of the chip's vector issue slots the whole kernel fills (PMC instruction count over the live duration)",
          "pg_trsm": "row solve below the panel by the same 4-column MFMA steps", "pg_bwd": "latency-bound matvec + block back-substitution per panel",
          "match": "VALU-bound by design: (Na + Nb) x 48 B per directed pair against Na x Nb gate + popcount evaluations",
          "lc": "f64 VALU, 16 lanes per 15-DoF problem; flops = 3e4 per LM iteration (DESIGN.md section 4) x iterations summed over the problems"}
@@ -321,7 +321,25 @@ def pmc_traffic(workload):
     return out
 
 
-def one_roofline(slot, ms, n, work, traffic):
+def pmc_valu(workload):
+    """vector instructions per launch from the committed counter pass (profiles/r02_pmc_issue_<workload>.csv, tools/pmc_issue_summary.py)"""
+    path = os.path.join(ROOT, "profiles", "r02_pmc_issue_%s.csv" % workload)
+    out = {}
+    if os.path.exists(path):
+        import csv
+        with open(path) as fh:
+            for r in csv.DictReader(fh):
+                k = r["kernel"][5:] if r["kernel"].startswith("void ") else r["kernel"]
+                out[k] = float(r["SQ_INSTS_VALU_per_launch"])
+                if k.split("<")[0]:
+                    out.setdefault(k.split("<")[0], out[k])
+    return out
+
+
+VALU_ISSUE_PER_S = 1024 * 2.4e9 / 4.0    # vector instructions the chip can issue per second: one per SIMD per 4 cycles
+
+
+def one_roofline(slot, ms, n, work, traffic, valu=None):
     per_launch_s = ms * 1e-3 / n
     tr = traffic.get(SLOT_KERNEL.get(slot, ""))
     if slot in FLOP_SLOTS:
@@ -337,9 +355,16 @@ def one_roofline(slot, ms, n, work, traffic):
         r = {"kernel": slot, "bound": "valu_int", "achieved": ach, "peak": FAST_PEAK_GPX, "unit": "G pixels/s", "frac": ach / FAST_PEAK_GPX}
         if tr:
             r["hbm_GBs"] = tr[0] / per_launch_s / 1e9
+    elif slot == "desc" and valu and valu.get(SLOT_KERNEL[slot]):
+        # no byte or flop roof fits: one wavefront per keypoint works out of a 49 x 49 LDS tile.  Priced by what it is bound by, the
+        # vector issue slots: instructions per launch (PMC) x live launches per second against one instruction per SIMD per 4 cycles
+        ach = valu[SLOT_KERNEL[slot]] / per_launch_s / 1e9
+        r = {"kernel": slot, "bound": "valu_issue", "achieved": ach, "peak": VALU_ISSUE_PER_S / 1e9, "unit": "G vector instructions/s", "frac": ach / (VALU_ISSUE_PER_S / 1e9)}
     else:
         ach = work / n / per_launch_s / 1e9
         r = {"kernel": slot, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS}
+    if valu and slot in SLOT_KERNEL and valu.get(SLOT_KERNEL[slot]):
+        r["valu_issue_util"] = valu[SLOT_KERNEL[slot]] / per_launch_s / VALU_ISSUE_PER_S      # measured instruction count (PMC) over the live duration
     r.update({"traffic": tr[0] if tr else None, "traffic_calibrated": tr[1] if tr else None, "launches": n, "avg_launch_us": per_launch_s * 1e6})
     if slot in NOTES:
         r["note"] = NOTES[slot]
@@ -353,9 +378,10 @@ def roofline(prof, workload):
     if not cand:
         return None, None
     traffic = pmc_traffic(workload)
+    valu = pmc_valu(workload)
     best = max(cand, key=lambda k: cand[k][0])
-    allr = {k: one_roofline(k, *cand[k], traffic) for k in cand}
-    return allr[best], {k: {kk: (round(vv, 4) if isinstance(vv, float) else vv) for kk, vv in v.items() if kk in ("bound", "achieved", "unit", "frac", "avg_launch_us", "traffic", "traffic_calibrated", "hbm_GBs", "launches")}
+    allr = {k: one_roofline(k, *cand[k], traffic, valu) for k in cand}
+    return allr[best], {k: {kk: (round(vv, 4) if isinstance(vv, float) else vv) for kk, vv in v.items() if kk in ("bound", "achieved", "unit", "frac", "avg_launch_us", "traffic", "traffic_calibrated", "hbm_GBs", "launches", "valu_issue_util")}
                         for k, v in allr.items()}
 
 

@@ -11,6 +11,8 @@ P="python3 bench.py --steps 1 --warmup 0 --cpu-frames 0 --no-roofline --pcie-ste
 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d gpurun_out/${TAG}_pmc_fetch -o f --output-format csv -- $P > gpurun_out/${TAG}_pmc_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d gpurun_out/${TAG}_pmc_write -o w --output-format csv -- $P > gpurun_out/${TAG}_pmc_write.log 2>&1
 rocprofv3 --pmc SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace -d gpurun_out/${TAG}_pmc_mfma -o m --output-format csv -- $P > gpurun_out/${TAG}_pmc_mfma.log 2>&1
+rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES --kernel-trace -d gpurun_out/${TAG}_pmc_issue -o i --output-format csv -- $P > gpurun_out/${TAG}_pmc_issue.log 2>&1
+python3 tools/pmc_issue_summary.py gpurun_out/${TAG}_pmc_issue/i_counter_collection.csv gpurun_out/${TAG}_pmc_issue/i_kernel_trace.csv gpurun_out/${TAG}_pmc_issue_C3.csv > gpurun_out/${TAG}_pmc_issue.txt 2>&1
 python3 tools/pmc_summary.py gpurun_out/${TAG}_pmc_fetch/f_counter_collection.csv gpurun_out/${TAG}_pmc_write/w_counter_collection.csv gpurun_out/${TAG}_pmc_hbm_traffic_C3.csv > gpurun_out/${TAG}_pmc_hbm.txt 2>&1
 python3 tools/pmc_mfma_summary.py gpurun_out/${TAG}_pmc_mfma/m_counter_collection.csv gpurun_out/${TAG}_pmc_mfma_C3.csv > gpurun_out/${TAG}_pmc_mfma.txt 2>&1
 # keep what travels back small: the traces stay on the box except the stats tables
