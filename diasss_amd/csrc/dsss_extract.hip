@@ -375,32 +375,34 @@ __global__ __launch_bounds__(256) void fast_cells_kernel(const ex_frame* __restr
     const fast_cell c = f.cells[cell];
     const uint8_t* __restrict__ img = f.lvl[c.level];
     const int cols = f.cols[c.level];
-    // The window comes in as aligned dwords (a row of the window is c.w <= 66 bytes at any alignment: at most 18 dwords) and is
-    // written to LDS byte by byte; items = (row, dword of the row), six in flight per lane.  One byte per load cost 840
-    // instructions per cell, a quarter of the kernel.
+    // The window comes in as UNALIGNED dwords, one per (row, four window columns), written to LDS as dwords (the LDS stride is a
+    // multiple of four and the slice is 16-byte aligned), six in flight per lane.  The bytes a dword carries beyond c.w land in
+    // columns no evaluated pixel reads; only a dword that would run over the end of the level image is assembled from bytes.
+    // (Aligned dwords scattered byte by byte cost 320 vector instructions per cell, an eighth of the kernel; one byte per load 840.)
+    typedef uint32_t u32_unaligned __attribute__((aligned(1)));
     {
         for (int t = lane; t < wave_bytes / 8; t += 64) reinterpret_cast<uint32_t*>(A)[t] = 0u;       // the arc values start at zero (borders stay zero)
-        const int dpr = (c.w + 6) >> 2;                              // dwords that can touch a row of c.w bytes at any alignment
+        const int dpr = (c.w + 3) >> 2;                              // dwords per window row
         const unsigned mg = (65536u + (unsigned)dpr - 1u) / (unsigned)dpr;      // t / dpr = (t * mg) >> 16, exact for t * dpr < 65536
         const int items = c.h * dpr;
+        const uint8_t* __restrict__ corner = img + (size_t)c.y0 * cols + c.x0;
+        const uint8_t* __restrict__ img_end = img + (size_t)f.rows[c.level] * cols;
         for (int t0 = 0; t0 < items; t0 += 64 * 6) {
-            uint32_t v[6]; int rr[6], x0[6];
+            uint32_t v[6]; int off[6];
 #pragma unroll
             for (int u = 0; u < 6; ++u) {
                 const int t = t0 + 64 * u + lane;
                 const int r = (int)(((unsigned)t * mg) >> 16), j = t - dpr * r;
-                const uint8_t* row = img + (size_t)(c.y0 + min(r, c.h - 1)) * cols + c.x0;
-                const int mis = (int)((size_t)row & 3);
-                rr[u] = r; x0[u] = 4 * j - mis;                       // window column of the dword's first byte
-                const bool ok = t < items && x0[u] < c.w;
-                v[u] = ok ? *reinterpret_cast<const uint32_t*>(row + x0[u]) : 0u;
-                if (!ok) rr[u] = -1;
+                const uint8_t* src = corner + (size_t)r * cols + 4 * j;
+                off[u] = t < items ? r * stride + 4 * j : -1;
+                v[u] = 0u;
+                if (t < items) {
+                    if (src + 4 <= img_end) v[u] = *reinterpret_cast<const u32_unaligned*>(src);
+                    else for (int b = 0; b < 4; ++b) if (src + b < img_end) v[u] |= (uint32_t)src[b] << (8 * b);
+                }
             }
 #pragma unroll
-            for (int u = 0; u < 6; ++u) if (rr[u] >= 0) {
-#pragma unroll
-                for (int b = 0; b < 4; ++b) { const int x = x0[u] + b; if (x >= 0 && x < c.w) win[rr[u] * stride + x] = (uint8_t)(v[u] >> (8 * b)); }
-            }
+            for (int u = 0; u < 6; ++u) if (off[u] >= 0) *reinterpret_cast<uint32_t*>(win + off[u]) = v[u];
         }
     }
     FAST_WAVE_SYNC();
@@ -414,45 +416,78 @@ __global__ __launch_bounds__(256) void fast_cells_kernel(const ex_frame* __restr
         A[y * stride + x] = (uint8_t)fast_arc<stride>(win, x, y, tmin);
     }
     FAST_WAVE_SYNC();
-    // strict 3x3 maxima (neighbours outside the evaluated range hold 0); the survivors' values replace the window, which is not needed
-    // any more.  The survivors above iniThFAST are emitted in this same pass: if there is one the cell keeps exactly those, and if
-    // there is none nothing was emitted -- only then does a second pass emit the survivors above minThFAST (ORBextractor.cpp:796-810).
+    // strict 3x3 maxima (neighbours outside the evaluated range hold 0), FOUR PIXELS OF A ROW PER LANE: the 3 x 6 patch of arc values
+    // they need comes in as six aligned dwords (the kernel is bound by its vector issue slots; a pixel per lane spent 50 instructions
+    // on index arithmetic, nine byte loads and the emission, four per lane 24).  The survivors' values replace the window, which is not
+    // needed any more, four to a dword at column x - 3.  The survivors above iniThFAST are emitted in this same pass: if there is one
+    // the cell keeps exactly those, and if there is none nothing was emitted -- only then does a second pass emit the survivors above
+    // minThFAST (ORBextractor.cpp:796-810).  Emission order = row-major = (group, pixel of the group): four ballots, one running
+    // count of the survivors in lower lanes, plus the lane's own earlier survivors.
     int base = 0;
-    for (int t0 = 0; t0 < ne; t0 += 64) {
-        const int t = min(t0 + lane, ne - 1);
-        const bool valid = t0 + lane < ne;
-        const int q = (int)(((unsigned)t * mg_e) >> 20);
-        const int y = 3 + q, x = 3 + t - q * ew;
-        const int a = A[y * stride + x];
-        // branch-free: eight loads with immediate offsets from the corner of the 3 x 3 patch, a max tree, one compare
-        const uint8_t* __restrict__ pa = A + (y - 1) * stride + (x - 1);
-        const int m0 = max(max((int)pa[0], (int)pa[1]), (int)pa[2]);
-        const int m1 = max((int)pa[stride], (int)pa[stride + 2]);
-        const int m2 = max(max((int)pa[2 * stride], (int)pa[2 * stride + 1]), (int)pa[2 * stride + 2]);
-        const int sv = (valid && a > max(max(m0, m1), m2)) ? a : 0;      // a == 0 never passes
-        if (valid) win[y * stride + x] = (uint8_t)sv;
-        const bool keep = sv > ini_th;
-        const unsigned long long m = __builtin_amdgcn_ballot_w64(keep);
-        if (keep) {
-            const int pos = base + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0));
-            if (pos < cell_cap) cand[(size_t)cell * cell_cap + pos] = (uint32_t)x | ((uint32_t)y << 8) | ((uint32_t)(sv - 1) << 16);
+    const int G = (ew + 3) >> 2, ngroups = ne > 0 ? eh * G : 0;
+    const unsigned mg_g = ((1u << 20) + (unsigned)(G > 0 ? G : 1) - 1u) / (unsigned)(G > 0 ? G : 1);
+    DSSS_GLOBAL uint32_t* __restrict__ cell_out = (DSSS_GLOBAL uint32_t*)(cand + (size_t)cell * cell_cap);      // global, not flat, stores
+    for (int g0 = 0; g0 < ngroups; g0 += 64) {
+        const int g = min(g0 + lane, ngroups - 1);
+        const bool gvalid = g0 + lane < ngroups;
+        const int gy = (int)(((unsigned)g * mg_g) >> 20), xg = 4 * (g - gy * G);
+        const int y = 3 + gy;
+        const uint8_t* __restrict__ pr = A + (y - 1) * stride + xg;              // dword-aligned: stride and xg are multiples of four
+        // bytes 2..7 of (lo, hi) of a row = columns x0 - 1 .. x0 + 4, x0 = 3 + xg
+        const uint32_t t_lo = *reinterpret_cast<const uint32_t*>(pr), t_hi = *reinterpret_cast<const uint32_t*>(pr + 4);
+        const uint32_t m_lo = *reinterpret_cast<const uint32_t*>(pr + stride), m_hi = *reinterpret_cast<const uint32_t*>(pr + stride + 4);
+        const uint32_t b_lo = *reinterpret_cast<const uint32_t*>(pr + 2 * stride), b_hi = *reinterpret_cast<const uint32_t*>(pr + 2 * stride + 4);
+        auto by = [](uint32_t lo, uint32_t hi, int k) -> int { return k < 2 ? (int)((lo >> (16 + 8 * k)) & 255u) : (int)((hi >> (8 * (k - 2))) & 255u); };
+        int tv[6], mv[6], bv[6];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) { tv[k] = by(t_lo, t_hi, k); mv[k] = by(m_lo, m_hi, k); bv[k] = by(b_lo, b_hi, k); }
+        int sv[4]; uint32_t packed = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int nb = max(max(max(max(tv[k], tv[k + 1]), tv[k + 2]), max(max(bv[k], bv[k + 1]), bv[k + 2])), max(mv[k], mv[k + 2]));
+            const int a = mv[k + 1];
+            sv[k] = (gvalid && xg + k < ew && a > nb) ? a : 0;                   // a == 0 never passes
+            packed |= (uint32_t)sv[k] << (8 * k);
         }
-        base += __builtin_popcountll(m);
+        if (gvalid) *reinterpret_cast<uint32_t*>(win + y * stride + xg) = packed;
+        unsigned long long mk[4]; int below = 0, total = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            mk[k] = __builtin_amdgcn_ballot_w64(sv[k] > ini_th);
+            below = __builtin_amdgcn_mbcnt_hi((unsigned)(mk[k] >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mk[k], below));
+            total += __builtin_popcountll(mk[k]);
+        }
+        int pos = base + below;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) if (sv[k] > ini_th) {
+            if (pos < cell_cap) cell_out[pos] = (uint32_t)(3 + xg + k) | ((uint32_t)y << 8) | ((uint32_t)(sv[k] - 1) << 16);
+            ++pos;
+        }
+        base += total;
     }
     if (base == 0 && min_th < ini_th) {              // (with minThFAST >= iniThFAST the second pass could not add anything)
         FAST_WAVE_SYNC();
-        for (int t0 = 0; t0 < ne; t0 += 64) {
-            const int t = t0 + lane;
-            const int q = (int)(((unsigned)t * mg_e) >> 20);
-            const int y = 3 + q, x = 3 + t - q * ew;
-            const int a = t < ne ? win[y * stride + x] : 0;
-            const bool keep = a > min_th;
-            const unsigned long long m = __builtin_amdgcn_ballot_w64(keep);
-            if (keep) {
-                const int pos = base + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0));
-                if (pos < cell_cap) cand[(size_t)cell * cell_cap + pos] = (uint32_t)x | ((uint32_t)y << 8) | ((uint32_t)(a - 1) << 16);
+        for (int g0 = 0; g0 < ngroups; g0 += 64) {
+            const int g = min(g0 + lane, ngroups - 1);
+            const bool gvalid = g0 + lane < ngroups;
+            const int gy = (int)(((unsigned)g * mg_g) >> 20), xg = 4 * (g - gy * G);
+            const int y = 3 + gy;
+            const uint32_t packed = gvalid ? *reinterpret_cast<const uint32_t*>(win + y * stride + xg) : 0u;
+            int a4[4]; unsigned long long mk[4]; int below = 0, total = 0;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                a4[k] = (int)((packed >> (8 * k)) & 255u);
+                mk[k] = __builtin_amdgcn_ballot_w64(a4[k] > min_th);
+                below = __builtin_amdgcn_mbcnt_hi((unsigned)(mk[k] >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mk[k], below));
+                total += __builtin_popcountll(mk[k]);
             }
-            base += __builtin_popcountll(m);
+            int pos = base + below;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) if (a4[k] > min_th) {
+                if (pos < cell_cap) cell_out[pos] = (uint32_t)(3 + xg + k) | ((uint32_t)y << 8) | ((uint32_t)(a4[k] - 1) << 16);
+                ++pos;
+            }
+            base += total;
         }
     }
     if (lane == 0) f.counts[cell] = base < cell_cap ? base : cell_cap;
