@@ -541,6 +541,27 @@ __constant__ signed char c_pattern[1024] = {
 };
 __constant__ int c_umax[16] = { 15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 8, 6, 3 };   // ORBextractor.cpp:454-469
 __constant__ int c_gauss13[13] = { 1, 2, 7, 17, 31, 45, 50, 45, 31, 17, 7, 2, 1 };               // 8.8 taps, sum 256
+// IC_Angle over the radius-15 disc as packed dot products: row v of the 31 x 31 patch is eight aligned dwords of the LDS tile
+// (columns 8 .. 39 = u -16 .. 15); wu holds u + 15 inside the disc and 0 outside, w1 holds 1 / 0, so that
+// m10 = sum (u + 15) I - 15 sum I and m01 = sum v (row sum) come out of two v_dot4_u32_u8 per dword (the same integers in another order)
+struct ic_tab { uint32_t wu[31 * 8], w1[31 * 8]; };
+constexpr ic_tab make_ic_tab()
+{
+    ic_tab t{};
+    constexpr int um[16] = { 15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 8, 6, 3 };
+    for (int ri = 0; ri < 31; ++ri)
+        for (int j = 0; j < 8; ++j) {
+            uint32_t a = 0, o = 0;
+            for (int k = 0; k < 4; ++k) {
+                const int u = 4 * j + k - 16, v = ri - 15;
+                const int au = u < 0 ? -u : u, av = v < 0 ? -v : v;
+                if (au <= um[av]) { a |= (uint32_t)(u + 15) << (8 * k); o |= 1u << (8 * k); }
+            }
+            t.wu[ri * 8 + j] = a; t.w1[ri * 8 + j] = o;
+        }
+    return t;
+}
+__constant__ ic_tab c_ic = make_ic_tab();
 
 __device__ inline float fast_atan2_dev(float y, float x)        // cv::fastAtan2 (ORBextractor.cpp:103)
 {
@@ -594,7 +615,26 @@ __global__ __launch_bounds__(256) void orient_desc_kernel(const ex_frame* __rest
     const int cols = f.cols[L], rows = f.lrows[L];
     const int cx = __float2int_rn(in.x), cy = __float2int_rn(in.y);
     uint8_t* P = sP[wv]; uint16_t* H = sH[wv]; uint8_t* B = sB[wv];
-    if (act)
+    // A patch that lies inside the level image (every keypoint more than PR + 3 pixels from the border: all but a thin frame) comes
+    // in as 13 unaligned dwords per row and goes to LDS as dwords (PS = 52 = 13 dwords; the three bytes beyond column 48 are never
+    // read).  The byte-wise path with its reflect-101 index arithmetic cost 950 of the kernel's 2 800 vector instructions per keypoint.
+    typedef uint32_t u32_unaligned __attribute__((aligned(1)));
+    const bool inside = cx - PR >= 0 && cx + PR + 3 < cols && cy - PR >= 0 && cy + PR < rows;      // uniform over the wavefront
+    if (act && inside) {
+        const uint8_t* __restrict__ corner = img + (size_t)(cy - PR) * cols + (cx - PR);
+        for (int t0 = 0; t0 < PW * 13; t0 += 64 * 10) {
+            uint32_t v[10]; int o[10];
+#pragma unroll
+            for (int u = 0; u < 10; ++u) {
+                const int t = t0 + 64 * u + lane;
+                const int py = (int)(((unsigned)t * 5042u) >> 16), j = t - 13 * py;      // t / 13, exact for t < 49 * 13
+                o[u] = t < PW * 13 ? py * PS + 4 * j : -1;
+                v[u] = t < PW * 13 ? *reinterpret_cast<const u32_unaligned*>(corner + (size_t)py * cols + 4 * j) : 0u;
+            }
+#pragma unroll
+            for (int u = 0; u < 10; ++u) if (o[u] >= 0) *reinterpret_cast<uint32_t*>(P + o[u]) = v[u];
+        }
+    } else if (act)
         for (int t0 = 0; t0 < PW * PW; t0 += 64 * 13) {             // thirteen byte loads in flight per lane: three round trips for the
             uint8_t v[13]; int o[13];                                // 49 x 49 patch (one load per iteration made it 38)
 #pragma unroll
@@ -609,18 +649,18 @@ __global__ __launch_bounds__(256) void orient_desc_kernel(const ex_frame* __rest
         }
     __syncthreads();
     // IC_Angle (ORBextractor.cpp:77-104): integer moments over the radius-15 disc
-    int m10 = 0, m01 = 0;
+    int m10 = 0, m01 = 0, msum = 0;
     if (act)
-        for (int t = lane; t < 31 * 31; t += 64) {
-            const int v = t / 31 - HALF_PATCH, u = t % 31 - HALF_PATCH;
-            const int av = v < 0 ? -v : v;
-            if ((u < 0 ? -u : u) <= c_umax[av]) {
-                const int I = P[(v + PR) * PS + (u + PR)];
-                m10 += u * I; m01 += v * I;
-            }
+        for (int t = lane; t < 31 * 8; t += 64) {                    // (row, dword of the row): see c_ic
+            const int ri = t >> 3, j = t & 7;
+            const uint32_t pix = *reinterpret_cast<const uint32_t*>(P + (ri + PR - HALF_PATCH) * PS + 8 + 4 * j);
+            const unsigned rs = __builtin_amdgcn_udot4(pix, c_ic.w1[t], 0u, false);
+            m10 = (int)__builtin_amdgcn_udot4(pix, c_ic.wu[t], (unsigned)m10, false);
+            msum += (int)rs; m01 += (ri - HALF_PATCH) * (int)rs;
         }
 #pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) { m10 += __shfl_xor(m10, o, 64); m01 += __shfl_xor(m01, o, 64); }
+    for (int o = 32; o >= 1; o >>= 1) { m10 += __shfl_xor(m10, o, 64); m01 += __shfl_xor(m01, o, 64); msum += __shfl_xor(msum, o, 64); }
+    m10 -= HALF_PATCH * msum;
     const float angle = fast_atan2_dev((float)m01, (float)m10);
     // separable 13-tap blur, 8.8 fixed point (own taps, see oracle/orc.h).  The taps go through the packed dot products: a lane
     // reads the 13 bytes of its window as four aligned dwords, shifts them into place (v_alignbyte) and folds them with three
@@ -628,32 +668,40 @@ __global__ __launch_bounds__(256) void orient_desc_kernel(const ex_frame* __rest
     // with v_dot2_u32_u16, which is why the horizontal pass stores its result transposed.  Integer arithmetic: same sums.
     const unsigned G0 = 1u | 2u << 8 | 7u << 16 | 17u << 24, G1 = 31u | 45u << 8 | 50u << 16 | 45u << 24, G2 = 31u | 17u << 8 | 7u << 16 | 2u << 24;
     if (act)
-        for (int t = lane; t < PW * BW; t += 64) {
-            const int py = t / BW, bx = t - py * BW;                 // H(py, bx): column bx of the 37-wide band, taps on P[py][bx .. bx + 12]
-            const uint32_t* w = reinterpret_cast<const uint32_t*>(P + py * PS + (bx & ~3));      // PS and the slice offsets are multiples of 4
-            const unsigned sft = bx & 3;
+        for (int t = lane; t < PW * 10; t += 64) {                   // (row py, four columns bx0 .. bx0 + 3 of the 37-wide band): their windows
+            const int py = (int)(((unsigned)t * 6554u) >> 16), g = t - 10 * py;      // share the sixteen bytes P[py][bx0 .. bx0 + 15]; t / 10 exact for t < 554
+            const uint32_t* w = reinterpret_cast<const uint32_t*>(P + py * PS + 4 * g);          // PS and the slice offsets are multiples of 4
             const uint32_t w0 = w[0], w1 = w[1], w2 = w[2], w3 = w[3];
-            unsigned acc = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(w1, w0, sft), G0, 0u, false);
-            acc = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(w2, w1, sft), G1, acc, false);
-            acc = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(w3, w2, sft), G2, acc, false);
-            acc += (w3 >> (8 * sft)) & 255u;                          // tap 12 has weight 1
-            H[bx * HS + py] = (uint16_t)acc;
+#pragma unroll
+            for (int o = 0; o < 4; ++o) {
+                if (4 * g + o >= BW) break;                           // the tenth group holds one column
+                const uint32_t a0 = o ? __builtin_amdgcn_alignbyte(w1, w0, o) : w0, a1 = o ? __builtin_amdgcn_alignbyte(w2, w1, o) : w1,
+                               a2 = o ? __builtin_amdgcn_alignbyte(w3, w2, o) : w2;
+                unsigned acc = __builtin_amdgcn_udot4(a0, G0, 0u, false);
+                acc = __builtin_amdgcn_udot4(a1, G1, acc, false);
+                acc = __builtin_amdgcn_udot4(a2, G2, acc, false);
+                acc += (w3 >> (8 * o)) & 255u;                        // tap 12 has weight 1
+                H[(4 * g + o) * HS + py] = (uint16_t)acc;
+            }
         }
     __syncthreads();
     if (act)
-        for (int t = lane; t < BW * BW; t += 64) {
-            const int by = t / BW, bx = t - by * BW;                 // taps on H[bx][by .. by + 12]
-            const uint32_t* w = reinterpret_cast<const uint32_t*>(H + bx * HS + (by & ~1));      // HS is even
-            const unsigned sft = 2 * (by & 1);
+        for (int t = lane; t < BW * 19; t += 64) {                   // (column bx, rows by0 and by0 + 1): taps on H[bx][by0 .. by0 + 13], seven aligned dwords
+            const int bx = (int)(((unsigned)t * 3450u) >> 16), by0 = 2 * (t - 19 * bx);          // t / 19 exact for t < 767
+            const uint32_t* w = reinterpret_cast<const uint32_t*>(H + bx * HS + by0);            // HS and by0 are even
             uint32_t v[7];
 #pragma unroll
             for (int k = 0; k < 7; ++k) v[k] = w[k];
-            unsigned acc = 0;
             const unsigned T[6] = { 1u | 2u << 16, 7u | 17u << 16, 31u | 45u << 16, 50u | 45u << 16, 31u | 17u << 16, 7u | 2u << 16 };
+            unsigned acc0 = 0, acc1 = 0;
 #pragma unroll
-            for (int k = 0; k < 6; ++k) acc = __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2_t, __builtin_amdgcn_alignbyte(v[k + 1], v[k], sft)), __builtin_bit_cast(u16x2_t, T[k]), acc, false);
-            acc += (v[6] >> (8 * sft)) & 65535u;                      // tap 12 has weight 1
-            B[by * BS + bx] = (uint8_t)((acc + 32768u) >> 16);
+            for (int k = 0; k < 6; ++k) {
+                acc0 = __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2_t, v[k]), __builtin_bit_cast(u16x2_t, T[k]), acc0, false);
+                acc1 = __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2_t, __builtin_amdgcn_alignbyte(v[k + 1], v[k], 2)), __builtin_bit_cast(u16x2_t, T[k]), acc1, false);
+            }
+            acc0 += v[6] & 65535u; acc1 += v[6] >> 16;                // tap 12 has weight 1
+            B[by0 * BS + bx] = (uint8_t)((acc0 + 32768u) >> 16);
+            if (by0 + 1 < BW) B[(by0 + 1) * BS + bx] = (uint8_t)((acc1 + 32768u) >> 16);
         }
     __syncthreads();
     // computeOrbDescriptor (ORBextractor.cpp:108-147): 4 tests per lane
