@@ -540,7 +540,7 @@ __constant__ signed char c_pattern[1024] = {
 #include "orb_pattern_31.inc"
 };
 __constant__ int c_umax[16] = { 15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 8, 6, 3 };   // ORBextractor.cpp:454-469
-__constant__ int c_gauss13[13] = { 1, 2, 7, 17, 31, 45, 50, 45, 31, 17, 7, 2, 1 };               // 8.8 taps, sum 256
+__constant__ int c_gauss13[13] = { 1, 2, 7, 16, 31, 45, 52, 45, 31, 16, 7, 2, 1 };               // 8.8 taps, sum 256 (oracle/orc_orb.c:orc_gauss13_taps)
 // IC_Angle over the radius-15 disc as packed dot products: row v of the 31 x 31 patch is eight aligned dwords of the LDS tile
 // (columns 8 .. 39 = u -16 .. 15); wu holds u + 15 inside the disc and 0 outside, w1 holds 1 / 0, so that
 // m10 = sum (u + 15) I - 15 sum I and m01 = sum v (row sum) come out of two v_dot4_u32_u8 per dword (the same integers in another order)
@@ -662,11 +662,11 @@ __global__ __launch_bounds__(256) void orient_desc_kernel(const ex_frame* __rest
     for (int o = 32; o >= 1; o >>= 1) { m10 += __shfl_xor(m10, o, 64); m01 += __shfl_xor(m01, o, 64); msum += __shfl_xor(msum, o, 64); }
     m10 -= HALF_PATCH * msum;
     const float angle = fast_atan2_dev((float)m01, (float)m10);
-    // separable 13-tap blur, 8.8 fixed point (own taps, see oracle/orc.h).  The taps go through the packed dot products: a lane
+    // separable 13-tap blur, 8.8 fixed point (taps: oracle/orc_orb.c:orc_gauss13_taps).  The taps go through the packed dot products: a lane
     // reads the 13 bytes of its window as four aligned dwords, shifts them into place (v_alignbyte) and folds them with three
     // v_dot4_u32_u8 + one multiply-add (13 byte loads + 13 multiply-adds before); the vertical pass does the same on 16-bit sums
     // with v_dot2_u32_u16, which is why the horizontal pass stores its result transposed.  Integer arithmetic: same sums.
-    const unsigned G0 = 1u | 2u << 8 | 7u << 16 | 17u << 24, G1 = 31u | 45u << 8 | 50u << 16 | 45u << 24, G2 = 31u | 17u << 8 | 7u << 16 | 2u << 24;
+    const unsigned G0 = 1u | 2u << 8 | 7u << 16 | 16u << 24, G1 = 31u | 45u << 8 | 52u << 16 | 45u << 24, G2 = 31u | 16u << 8 | 7u << 16 | 2u << 24;
     if (act)
         for (int t = lane; t < PW * 10; t += 64) {                   // (row py, four columns bx0 .. bx0 + 3 of the 37-wide band): their windows
             const int py = (int)(((unsigned)t * 6554u) >> 16), g = t - 10 * py;      // share the sixteen bytes P[py][bx0 .. bx0 + 15]; t / 10 exact for t < 554
@@ -692,7 +692,7 @@ __global__ __launch_bounds__(256) void orient_desc_kernel(const ex_frame* __rest
             uint32_t v[7];
 #pragma unroll
             for (int k = 0; k < 7; ++k) v[k] = w[k];
-            const unsigned T[6] = { 1u | 2u << 16, 7u | 17u << 16, 31u | 45u << 16, 50u | 45u << 16, 31u | 17u << 16, 7u | 2u << 16 };
+            const unsigned T[6] = { 1u | 2u << 16, 7u | 16u << 16, 31u | 45u << 16, 52u | 45u << 16, 31u | 16u << 16, 7u | 2u << 16 };
             unsigned acc0 = 0, acc1 = 0;
 #pragma unroll
             for (int k = 0; k < 6; ++k) {

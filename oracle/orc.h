@@ -31,8 +31,9 @@
  *   - cos/sin use a deterministic fdlibm-style polynomial (no FMA) so that the
  *     oracle and the HIP kernels agree bit for bit; mean uses a fixed
  *     summation order (OpenCV leaves it unspecified);
- *   - GaussianBlur 13x13 sigma 2: own 8.8 fixed-point taps (OpenCV's exact
- *     fixed-point table is not recoverable here).
+ *   - GaussianBlur 13x13 sigma 2: 8.8 fixed-point taps by OpenCV's error-diffusion
+ *     rule (getGaussianKernelFixedPoint_ED, restated; not checkable against an
+ *     OpenCV build here).
  */
 #ifndef ORC_H
 #define ORC_H

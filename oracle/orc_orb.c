@@ -438,15 +438,24 @@ float orc_ic_angle(const uint8_t* img, int stride, int x, int y)
     return orc_fast_atan2((float)m_01, (float)m_10);
 }
 
-/* 13-tap sigma-2 Gaussian in 8.8 fixed point: round(256*g[i]/sum g), rounding residue folded into the
- * centre tap so the taps sum to 256 (own definition, see orc.h) */
+/* 13-tap sigma-2 Gaussian in 8.8 fixed point, by the rule OpenCV >= 4.5.2 uses for its bit-exact 8-bit GaussianBlur
+ * (imgproc smooth.dispatch.cpp, getGaussianKernelFixedPoint_ED, restated from its published source: OpenCV is not in this
+ * image): the normalised taps times 256 are rounded from the edge inwards, every rounding error carried into the next tap,
+ * and the centre tap takes what is left of 256.  -> 1 2 7 16 31 45 52 45 31 16 7 2 1.  (Rounds 1 and 2 of this project
+ * rounded every tap on its own and folded the residue into the centre: 17 and 50 where this has 16 and 52.) */
 void orc_gauss13_taps(int taps[13])
 {
     double g[13], s = 0;
     for (int i = 0; i < 13; ++i) { double d = i - 6; g[i] = exp(-(d * d) / 8.0); s += g[i]; }
+    double err = 0;
     int tot = 0;
-    for (int i = 0; i < 13; ++i) { taps[i] = (int)floor(g[i] / s * 256.0 + 0.5); tot += taps[i]; }
-    taps[6] += 256 - tot;
+    for (int i = 0; i < 6; ++i) {
+        const double adj = g[i] / s * 256.0 + err;
+        const int v0 = (int)lrint(adj);                    /* cvRound */
+        err = adj - v0;
+        taps[i] = taps[12 - i] = v0; tot += v0;
+    }
+    taps[6] = 256 - 2 * tot;
 }
 
 static int reflect101(int p, int len)
