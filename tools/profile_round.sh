@@ -15,6 +15,6 @@ rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES --kernel-trace
 python3 tools/pmc_issue_summary.py gpurun_out/${TAG}_pmc_issue/i_counter_collection.csv gpurun_out/${TAG}_pmc_issue/i_kernel_trace.csv gpurun_out/${TAG}_pmc_issue_C3.csv > gpurun_out/${TAG}_pmc_issue.txt 2>&1
 python3 tools/pmc_summary.py gpurun_out/${TAG}_pmc_fetch/f_counter_collection.csv gpurun_out/${TAG}_pmc_write/w_counter_collection.csv gpurun_out/${TAG}_pmc_hbm_traffic_C3.csv > gpurun_out/${TAG}_pmc_hbm.txt 2>&1
 python3 tools/pmc_mfma_summary.py gpurun_out/${TAG}_pmc_mfma/m_counter_collection.csv gpurun_out/${TAG}_pmc_mfma_C3.csv > gpurun_out/${TAG}_pmc_mfma.txt 2>&1
-# keep what travels back small: the traces stay on the box except the stats tables
-rm -f gpurun_out/${TAG}_pmc_*/?_kernel_trace.csv gpurun_out/${TAG}_stats/${TAG}_kernel_trace.csv
+# keep what travels back small (gpurun merges at most 64 MiB): traces and raw counter dumps stay on the box, the reduced tables travel
+rm -f gpurun_out/${TAG}_pmc_*/?_kernel_trace.csv gpurun_out/${TAG}_pmc_*/?_counter_collection.csv gpurun_out/${TAG}_stats/${TAG}_kernel_trace.csv
 ls -la gpurun_out/${TAG}_* | head -40
