@@ -23,7 +23,9 @@ struct mini_val { double L[3]; pose_t X1, X2; };
 // bit for bit while the serial chains shrink from O(15^3) to O(15^2) and nothing spills to scratch.
 #define LG 16                  // lanes per problem
 #define LS 16                  // LDS row stride (doubles)
-struct lc_lds { double J[MR * LS]; double H[MD * LS]; double L[MD * LS]; };
+// The problem's constants and its current / trial values live in LDS too: every lane of the group holds the same 100 doubles,
+// and kept in registers (200 VGPRs of the 512) they were what held the kernel at one wavefront per SIMD with 110 spills.
+struct lc_lds { double J[MR * LS]; double H[MD * LS]; double L[MD * LS]; mini_prob m; mini_val v, nv; };
 
 // whitened residual r (registers, every lane) and Jacobian J (LDS; lane `lane` clears row `lane`, lane 0 writes the entries)
 __device__ static void mini_lin(const mini_prob& m, const mini_val& v, double* r, double* J, int lane)
@@ -190,7 +192,7 @@ __global__ __launch_bounds__(64) void lc_kernel(const double* __restrict__ kp7, 
     if (flip & 1) so3_exp(flipv, cps_s.R);
     if (flip & 2) so3_exp(flipv, cps_t.R);
     const double sigma_r = 0.1, alpha_bw = 0.1 * PI / 180;     // :685
-    mini_prob m;
+    mini_prob m;                                            // built in registers, parked in LDS below (S.m)
     m.slant_s = kp[2]; m.slant_t = kp[5];
     m.sig_s[0] = sigma_r; m.sig_s[1] = kp[2] * alpha_bw;
     m.sig_t[0] = sigma_r; m.sig_t[1] = kp[5] * alpha_bw;
@@ -214,18 +216,21 @@ __global__ __launch_bounds__(64) void lc_kernel(const double* __restrict__ kp7, 
     v.L[0] = (gsx + gtx) / 2; v.L[1] = (gsy + gty) / 2;                                                    // :792-795
     v.L[2] = ((pose_s[(size_t)id_s * 6 + 5] - alt_ptr[fs][id_s]) + (pose_t_[(size_t)id_t * 6 + 5] - alt_ptr[ft][id_t])) / 2;
     v.X1 = Tp_s; v.X2 = Tp_t;
+    if (lane == 0) { S.m = m; S.v = v; }
+    __builtin_amdgcn_wave_barrier();                        // the group's lanes sit in one wavefront: its LDS operations execute in program order
+    const mini_prob& M_ = S.m; const mini_val& V_ = S.v;
     // ---- LevenbergMarquardtOptimizer::optimize, default params
     const double relTol = 1e-5, absTol = 1e-5, lamMax = 1e5, minFid = 1e-3;
     double lambda = 1e-5;
     int iters = 0;
-    double err = mini_err(m, v);
+    double err = mini_err(M_, V_);
     const double err0 = err;
     double r[MR], d[MD];
     if (err > 0) {
         double cur;
         do {
             cur = err;
-            mini_lin(m, v, r, S.J, lane);
+            mini_lin(M_, V_, r, S.J, lane);
             const double g_mine = normal_eq(S.J, r, S.H, lane);
             double oldLin = 0;
 #pragma unroll
@@ -234,7 +239,7 @@ __global__ __launch_bounds__(64) void lc_kernel(const double* __restrict__ kp7, 
             for (;;) {
                 const bool ok = chol15(S.H, lambda, S.L, lane) == 0;
                 bool success = false, stop = false;
-                double newErr = 0; mini_val nv;
+                double newErr = 0;
                 if (ok) {
 #pragma unroll
                     for (int a = 0; a < MD; ++a) d[a] = -__shfl(g_mine, a, LG);
@@ -250,16 +255,30 @@ __global__ __launch_bounds__(64) void lc_kernel(const double* __restrict__ kp7, 
                     newLin *= 0.5;
                     const double linChange = oldLin - newLin;
                     if (linChange >= 0) {
-                        for (int a = 0; a < 3; ++a) nv.L[a] = v.L[a] + d[a];
-                        pose_retract(&v.X1, d + 3, &nv.X1);
-                        pose_retract(&v.X2, d + 9, &nv.X2);
-                        newErr = mini_err(m, nv);
+                        {   // the trial values go to LDS (S.nv); the registers that held them are free again afterwards
+                            mini_val nv;
+                            for (int a = 0; a < 3; ++a) nv.L[a] = V_.L[a] + d[a];
+                            pose_retract(&V_.X1, d + 3, &nv.X1);
+                            pose_retract(&V_.X2, d + 9, &nv.X2);
+                            if (lane == 0) S.nv = nv;
+                            __builtin_amdgcn_wave_barrier();
+                        }
+                        newErr = mini_err(M_, S.nv);
                         const double costChange = err - newErr;
                         if (linChange > 2.220446049250313e-16 * oldLin) success = (costChange / linChange) > minFid;
                         if (fabs(costChange) < relTol * err) stop = true;
                     }
                 }
-                if (success) { v = nv; err = newErr; lambda /= 10; ++iters; break; }
+                if (success) {
+                    {   // v = nv, element-wise by the lanes of the group (27 doubles)
+                        const double* src = reinterpret_cast<const double*>(&S.nv); double* dst = reinterpret_cast<double*>(&S.v);
+                        const double e0 = src[lane], e1 = lane + LG < (int)(sizeof(mini_val) / sizeof(double)) ? src[lane + LG] : 0.0;
+                        __builtin_amdgcn_wave_barrier();
+                        dst[lane] = e0; if (lane + LG < (int)(sizeof(mini_val) / sizeof(double))) dst[lane + LG] = e1;
+                        __builtin_amdgcn_wave_barrier();
+                    }
+                    err = newErr; lambda /= 10; ++iters; break;
+                }
                 else if (!stop) { lambda *= 10; if (lambda >= lamMax) break; }
                 else break;
             }
@@ -269,8 +288,12 @@ __global__ __launch_bounds__(64) void lc_kernel(const double* __restrict__ kp7, 
     o.iters = iters; o.pad_ = 0; o.err0 = err0; o.err1 = err;
     // eval_1 (:853-896)
     pose_t cti, new_pose;
-    pose_inverse(&cps_t, &cti);
-    pose_compose(&v.X2, &cti, &new_pose);
+    {   // the yaw compensations are rebuilt from the flags here rather than kept in registers across the LM loop
+        pose_t cq; pose_identity(&cq);
+        if (flip & 2) so3_exp(flipv, cq.R);
+        pose_inverse(&cq, &cti);
+    }
+    pose_compose(&V_.X2, &cti, &new_pose);
     const double x_o = gsx - gtx, y_o = gsy - gty;
     const double ini = sqrt(x_o * x_o + y_o * y_o);
     double rpy[3];
@@ -290,7 +313,7 @@ __global__ __launch_bounds__(64) void lc_kernel(const double* __restrict__ kp7, 
     const double fin = sqrt(x_n * x_n + y_n * y_n);
     o.score = ini / fin - 2;
     // Marginals(graph, result).marginalCovariance(X2).diagonal() (:956-959): lane c < 6 solves for unit vector 9 + c
-    mini_lin(m, v, r, S.J, lane);
+    mini_lin(M_, V_, r, S.J, lane);
     (void)normal_eq(S.J, r, S.H, lane);
     double var_mine = NAN;
     if (chol15(S.H, 0.0, S.L, lane) == 0) {
@@ -304,8 +327,12 @@ __global__ __launch_bounds__(64) void lc_kernel(const double* __restrict__ kp7, 
 #pragma unroll
     for (int c2 = 0; c2 < 6; ++c2) o.var[c2] = __shfl(var_mine, c2, LG);
     pose_t csi, src, rel;
-    pose_inverse(&cps_s, &csi);
-    pose_compose(&Tp_s, &csi, &src);
+    {
+        pose_t cq; pose_identity(&cq);
+        if (flip & 1) so3_exp(flipv, cq.R);
+        pose_inverse(&cq, &csi);
+    }
+    pose_compose(&M_.prior, &csi, &src);                         // m.prior = Tp_s
     pose_between(&src, &new_pose, &rel);                         // :958
     for (int a = 0; a < 9; ++a) o.rel[a] = rel.R[a];
     for (int a = 0; a < 3; ++a) o.rel[9 + a] = rel.t[a];
