@@ -85,11 +85,14 @@ class Pipeline:
     # ---- stage 1: frames
     def set_frames(self, raws, poses, alts, grs):
         """raws[f] may be None for frames this rank does not extract"""
-        self.N = [p.shape[0] for p in poses]
-        self.M = [2 * len(g) for g in grs]
+        if getattr(self, "_dims_of", None) is None or self._dims_of[0] is not poses or self._dims_of[1] is not grs:
+            self.N = [p.shape[0] for p in poses]
+            self.M = [2 * len(g) for g in grs]
+            self._dims_of = (poses, grs)
+            self._ids = list(range(self.F))
         self.poses = poses
         if hasattr(self.ctx, "frames_set"):
-            self.ctx.frames_set(list(range(self.F)), raws, self.N, self.M, poses, alts, grs)
+            self.ctx.frames_set(self._ids, raws, self.N, self.M, poses, alts, grs)
         else:
             for f in range(self.F):
                 self.ctx.frame_set(f, raws[f], self.N[f], self.M[f], poses[f], alts[f], grs[f])
@@ -101,11 +104,13 @@ class Pipeline:
 
     # ---- stage 2: matching + loop-closure measurements
     def match(self):
-        src, tgt = all_pairs(self.F)
-        if self.min_overlap is not None:
-            keep = np.array([self.ctx.overlap(int(i), int(j)) > self.min_overlap for i, j in zip(src, tgt)], bool)
-            src, tgt = src[keep], tgt[keep]
-        self.src, self.tgt = shard_pairs(src, tgt, self.rank, self.world, self.F)
+        if self.min_overlap is not None or getattr(self, "_pairs", None) is None:
+            src, tgt = all_pairs(self.F)
+            if self.min_overlap is not None:
+                keep = np.array([self.ctx.overlap(int(i), int(j)) > self.min_overlap for i, j in zip(src, tgt)], bool)
+                src, tgt = src[keep], tgt[keep]
+            self._pairs = shard_pairs(src, tgt, self.rank, self.world, self.F)     # dense all-pairs: the list depends on F and the rank only
+        self.src, self.tgt = self._pairs
         self.ctx.match_pairs(self.src, self.tgt)
         self.ctx.lc_solve_all()
 
