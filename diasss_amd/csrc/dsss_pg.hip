@@ -1766,9 +1766,38 @@ struct pg_dev {
         }
     }
     template <typename T> int upload(dsss_ctx* c, T** p, const std::vector<T>& v) { int rc = alloc(c, p, v.size()); if (rc) return rc; if (!v.empty()) HIPCHK(c, hipMemcpy(*p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice)); return DSSS_OK; }
+    // The tables of the analysis (some forty arrays, a few MB) go up as ONE copy: `later` books a slice of a block, `flush` copies
+    // the arrays into the context's page-locked staging area on the worker pool, issues one asynchronous upload on `st` and sets the
+    // device pointers.  (Forty synchronous copies from pageable memory cost 0.7 ms per solve.)  The vectors must live until flush.
+    struct pend { void** p; const void* src; size_t bytes, off; };
+    std::vector<pend> pending; size_t pend_total = 0;
+    template <typename T> void later(T** p, const std::vector<T>& v) {
+        *p = nullptr;
+        pending.push_back({ (void**)p, v.data(), v.size() * sizeof(T), pend_total });
+        pend_total += (std::max<size_t>(v.size(), 1) * sizeof(T) + 255) & ~(size_t)255;
+    }
+    int flush(dsss_ctx* c, hipStream_t st) {
+        if (pending.empty()) return DSSS_OK;
+        char* dev = nullptr;
+        int rc = alloc(c, &dev, pend_total); if (rc) return rc;
+        if (c->pg_stage_cap < pend_total) {
+            if (c->pg_stage) hipHostFree(c->pg_stage);
+            c->pg_stage = nullptr; c->pg_stage_cap = 0;
+            const size_t cap = pend_total + pend_total / 4;
+            HIPCHK(c, hipHostMalloc(&c->pg_stage, cap, hipHostMallocDefault));
+            c->pg_stage_cap = cap;
+        }
+        char* stage = static_cast<char*>(c->pg_stage);
+        const int T = pend_total > ((size_t)1 << 20) ? 4 : 1;
+        dsss_pool_run(T, [&](int t) { for (size_t k = t; k < pending.size(); k += T) if (pending[k].bytes) memcpy(stage + pending[k].off, pending[k].src, pending[k].bytes); });
+        HIPCHK(c, hipMemcpyAsync(dev, stage, pend_total, hipMemcpyHostToDevice, st));
+        for (const pend& q : pending) *q.p = dev + q.off;
+        pending.clear(); pend_total = 0;
+        return DSSS_OK;
+    }
     std::vector<hipEvent_t> events;
     hipEvent_t event() { hipEvent_t e = nullptr; hipEventCreateWithFlags(&e, hipEventDisableTiming); events.push_back(e); return e; }
-    void release() { if (ctx) { hipStreamSynchronize(ctx->stream); ctx->pg_chunk_cur = 0; ctx->pg_chunk_off = 0; } for (hipEvent_t e : events) if (e) hipEventDestroy(e); events.clear(); }
+    void release() { if (ctx) { hipStreamSynchronize(ctx->stream); ctx->pg_chunk_cur = 0; ctx->pg_chunk_off = 0; } for (hipEvent_t e : events) if (e) hipEventDestroy(e); events.clear(); pending.clear(); pend_total = 0; }
 };
 
 } // namespace
@@ -1851,7 +1880,10 @@ static int pg_solve_impl(dsss_ctx* c, const double* dr6, int total, const dsss_l
     // DR rows on the device first: the separator coordinates for the ordering come back from there (host reads of the
     // frames' pinned copies are slow), and the copies overlap with the rest of the host preparation
     double* d_dr6; double* d_sxy; int* d_sep; int* d_sep1; int* d_t2; int* d_ord1; int* d_ord2;
-    TRY(dv.alloc(c, &d_dr6, (size_t)n * 6)); TRY(dv.alloc(c, &d_sxy, (size_t)ns * 2)); TRY(dv.upload(c, &d_sep, sep_pose)); TRY(dv.upload(c, &d_sep1, sep1)); TRY(dv.upload(c, &d_t2, t2));
+    TRY(dv.alloc(c, &d_dr6, (size_t)n * 6)); TRY(dv.alloc(c, &d_sxy, (size_t)ns * 2)); dv.later(&d_sep, sep_pose); dv.later(&d_sep1, sep1); dv.later(&d_t2, t2);
+    std::vector<int> ord1, ord2;                            // (alive until the flush below)
+    std::vector<unsigned long long> fp;
+    unsigned long long* d_fp = nullptr; int* d_foff = nullptr;
     {   // segments of both passes in descending order of length (stable counting sort: ties stay in chain order)
         auto by_length = [](const std::vector<int>& ends, std::vector<int>& ord) {
             const int m = (int)ends.size() - 1;
@@ -1863,20 +1895,20 @@ static int pg_solve_impl(dsss_ctx* c, const double* dr6, int total, const dsss_l
             for (int l = 0; l <= maxlen; ++l) cnt[l + 1] += cnt[l];
             for (int k = 0; k < m; ++k) ord[cnt[maxlen - (ends[k + 1] - ends[k])]++] = k;
         };
-        std::vector<int> ord1, ord2;
         by_length(sep1, ord1); by_length(t2, ord2);
-        TRY(dv.upload(c, &d_ord1, ord1)); TRY(dv.upload(c, &d_ord2, ord2));
+        dv.later(&d_ord1, ord1); dv.later(&d_ord2, ord2);
     }
     std::vector<double> sxy((size_t)ns * 2), cx(ns), cy(ns);
     {
+        if (!dr6) {
+            fp.resize(nframes);
+            for (int f = 0; f < nframes; ++f) fp[f] = (unsigned long long)(uintptr_t)c->frames[f].pose6;
+            dv.later(&d_fp, fp); dv.later(&d_foff, foff);
+        }
+        TRY(dv.flush(c, c->stream));                          // separator lists, segment orders, frame pointers: one upload
         hipError_t e = hipSuccess;
         if (dr6) e = hipMemcpyAsync(d_dr6, dr6, (size_t)n * 6 * sizeof(double), hipMemcpyHostToDevice, c->stream);
         else {      // one gather launch over the frames' device copies (a device-to-device copy per frame cost 0.5 ms of launches at 200 frames)
-            std::vector<unsigned long long> fp(nframes);
-            for (int f = 0; f < nframes; ++f) fp[f] = (unsigned long long)(uintptr_t)c->frames[f].pose6;
-            unsigned long long* d_fp = nullptr; int* d_foff = nullptr;
-            int r2 = dv.upload(c, &d_fp, fp); if (!r2) r2 = dv.upload(c, &d_foff, foff);
-            if (r2) { dv.release(); return r2; }
             hipLaunchKernelGGL(pg_gather_dr_kernel, dim3(8, nframes), dim3(256), 0, c->stream, d_fp, d_foff, d_dr6);
             e = hipGetLastError();
         }
@@ -2026,7 +2058,7 @@ static int pg_solve_impl(dsss_ctx* c, const double* dr6, int total, const dsss_l
                 rank, world, nparts, part_lo, part_hi, mp0, mp1, n, ne, ns, S.iface_seps.size(), nnzL, (int)S.binptr.size() - 1, (int)S.bincols.size(), nfr, S.max_front_n, S.front_doubles * 8e-6, npan, S.nlev,
                 (S.comm_doubles + 36.0 * S.comm_vals.size() + 6.0 * S.iface_seps.size()) * 8e-6);
 
-    TRY(dv.upload(c, &d_perm, S.perm));
+    dv.later(&d_perm, S.perm);
     TRY(dv.alloc(c, &d_L, nnzL * 36));
     TRY(dv.alloc(c, &d_F, (size_t)S.front_doubles)); TRY(dv.alloc(c, &d_R, (size_t)S.frhs_doubles)); TRY(dv.alloc(c, &d_ubin, (size_t)S.ubin_doubles));
     // value array of the fronts; its tail IS the buffer the all-reduce sums: [interface values | interface right-hand sides |
@@ -2036,21 +2068,21 @@ static int pg_solve_impl(dsss_ctx* c, const double* dr6, int total, const dsss_l
     TRY(dv.alloc(c, &d_aval, (size_t)nval * 36 + comm_total));
     double* d_comm = d_aval + (size_t)nval * 36; double* d_avalif = d_comm; double* d_xif = d_comm + ncv * 36; double* d_commU = d_xif + nif * 6;
     int *d_ifslot, *d_ifsep, *d_pk_child, *d_pk_row; pg_pack* d_PK;
-    { std::vector<int> ifslot(ns, -1); for (size_t q = 0; q < nif; ++q) ifslot[S.iface_seps[q]] = (int)q;
-      TRY(dv.upload(c, &d_ifslot, ifslot)); TRY(dv.upload(c, &d_ifsep, S.iface_seps)); }
-    TRY(dv.upload(c, &d_colptr, S.colptr)); TRY(dv.upload(c, &d_rowidx, S.rowidx)); TRY(dv.upload(c, &d_rlptr, S.rlptr)); TRY(dv.upload(c, &d_rlcol, S.rlcol));
-    TRY(dv.upload(c, &d_rlpos, S.rlpos)); TRY(dv.upload(c, &d_rlrow, S.rlrow)); TRY(dv.upload(c, &d_mapptr, S.mapptr)); TRY(dv.upload(c, &d_binptr, S.binptr)); TRY(dv.upload(c, &d_bincols, S.bincols));
-    TRY(dv.upload(c, &d_dest, S.dest_bin));
-    TRY(dv.upload(c, &d_binroot_ptr, S.binroot_ptr)); TRY(dv.upload(c, &d_binroot_idx, S.binroot_idx)); TRY(dv.upload(c, &d_broot_b, S.broot_b)); TRY(dv.upload(c, &d_broot_uoff, S.broot_uoff));
-    TRY(dv.upload(c, &d_broot_of_col, S.broot_of_col)); TRY(dv.upload(c, &d_anc_first, S.anc_first)); TRY(dv.upload(c, &d_anc_rel, S.anc_rel));
-    TRY(dv.upload(c, &d_rel, S.rel)); TRY(dv.upload(c, &d_fa_src, S.fa_src)); TRY(dv.upload(c, &d_fa_col, S.fa_col)); TRY(dv.upload(c, &d_fa_tr, S.fa_tr));
-    TRY(dv.upload(c, &d_frows, S.f_rows)); TRY(dv.upload(c, &d_xr_ptr, S.xr_ptr)); TRY(dv.upload(c, &d_xr_child, S.xr_child));
-    TRY(dv.upload(c, &d_xr_row, S.xr_row)); TRY(dv.upload(c, &d_fa_rowptr, S.fa_rowptr));
+    std::vector<int> ifslot(ns, -1); for (size_t q = 0; q < nif; ++q) ifslot[S.iface_seps[q]] = (int)q;
+    dv.later(&d_ifslot, ifslot); dv.later(&d_ifsep, S.iface_seps);
+    dv.later(&d_colptr, S.colptr); dv.later(&d_rowidx, S.rowidx); dv.later(&d_rlptr, S.rlptr); dv.later(&d_rlcol, S.rlcol);
+    dv.later(&d_rlpos, S.rlpos); dv.later(&d_rlrow, S.rlrow); dv.later(&d_mapptr, S.mapptr); dv.later(&d_binptr, S.binptr); dv.later(&d_bincols, S.bincols);
+    dv.later(&d_dest, S.dest_bin);
+    dv.later(&d_binroot_ptr, S.binroot_ptr); dv.later(&d_binroot_idx, S.binroot_idx); dv.later(&d_broot_b, S.broot_b); dv.later(&d_broot_uoff, S.broot_uoff);
+    dv.later(&d_broot_of_col, S.broot_of_col); dv.later(&d_anc_first, S.anc_first); dv.later(&d_anc_rel, S.anc_rel);
+    dv.later(&d_rel, S.rel); dv.later(&d_fa_src, S.fa_src); dv.later(&d_fa_col, S.fa_col); dv.later(&d_fa_tr, S.fa_tr);
+    dv.later(&d_frows, S.f_rows); dv.later(&d_xr_ptr, S.xr_ptr); dv.later(&d_xr_child, S.xr_child);
+    dv.later(&d_xr_row, S.xr_row); dv.later(&d_fa_rowptr, S.fa_rowptr);
     struct dsched { int *lv_front, *lv_step, *asm_front, *asm_row, *tile_item, *tile_ij; } DO = {}, DI = {};
     for (int w2 = 0; w2 < 2; ++w2) {
         const pg_sched& H = w2 ? SI : SO; dsched& Dv = w2 ? DI : DO;
-        TRY(dv.upload(c, &Dv.lv_front, H.lv_front)); TRY(dv.upload(c, &Dv.lv_step, H.lv_step)); TRY(dv.upload(c, &Dv.asm_front, H.asmrow_front)); TRY(dv.upload(c, &Dv.asm_row, H.asmrow_row));
-        TRY(dv.upload(c, &Dv.tile_item, H.tile_item)); TRY(dv.upload(c, &Dv.tile_ij, H.tile_ij));
+        dv.later(&Dv.lv_front, H.lv_front); dv.later(&Dv.lv_step, H.lv_step); dv.later(&Dv.asm_front, H.asmrow_front); dv.later(&Dv.asm_row, H.asmrow_row);
+        dv.later(&Dv.tile_item, H.tile_item); dv.later(&Dv.tile_ij, H.tile_ij);
     }
     // this rank's bins are one contiguous range (bins never straddle partitions, partitions are ascending in the order)
     int bin_lo = 0, bin_hi = 0;
@@ -2084,7 +2116,8 @@ static int pg_solve_impl(dsss_ctx* c, const double* dr6, int total, const dsss_l
                 if (S.comm_part[cq] >= part_lo && S.comm_part[cq] < part_hi) for (int r2 = 0; r2 < d.cb; ++r2) { pk_child.push_back(cq); pk_row.push_back(r2); }
             }
         }
-        TRY(dv.upload(c, &d_FD, FD)); TRY(dv.upload(c, &d_CH, CH)); TRY(dv.upload(c, &d_PK, PK)); TRY(dv.upload(c, &d_pk_child, pk_child)); TRY(dv.upload(c, &d_pk_row, pk_row));
+        dv.later(&d_FD, FD); dv.later(&d_CH, CH); dv.later(&d_PK, PK); dv.later(&d_pk_child, pk_child); dv.later(&d_pk_row, pk_row);
+        TRY(dv.flush(c, st));                                   // FD, CH, PK and the lists above are still alive here
         n_pack = (int)pk_child.size();
     }
     const int max_n6 = std::max(SO.max_n6, SI.max_n6);
