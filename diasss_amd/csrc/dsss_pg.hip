@@ -1850,29 +1850,57 @@ static int pg_solve_impl(dsss_ctx* c, const double* dr6, int total, const dsss_l
     // depth of the per-segment block-Thomas recursion (one thread per segment).  Pass 1 condenses every chunk onto its two ends
     // (poses -> "level-1" chain of true separators + chunk ends); pass 2 condenses the runs of chunk ends between two true
     // separators the same way (same kernel, on the level-1 chain).  Exact: only the elimination order changes.
-    std::vector<char> is_true(n, 0), is_sep(n, 0);
-    is_true[0] = 1; is_true[n - 1] = 1;
-    for (int e = 0; e < ne; ++e) { is_true[ea[e]] = 1; is_true[eb[e]] = 1; }
-    for (int p = 1; p < nparts; ++p) is_true[pbound[p] - 1] = 1;         // a partition ends on a separator: segments never straddle ranks
-    { const char* ev = getenv("DSSS_PG_CHUNK"); const int chunk = ev ? std::max(2, atoi(ev)) : 16;
-      for (int i = 0; i < n; i += chunk) is_sep[i] = 1;
-      // pass 2 is sequential over the chunk ends between two true separators: a gap of more than 16 chunks (frame boundaries
-      // without keypoints reach 900 poses) gets true separators of its own every 16 chunks
-      const int run = 16 * chunk;
-      for (int i = 0, last = 0; i < n; ++i) { if (is_true[i]) last = i; else if (i - last >= run && i % chunk == 0) { is_true[i] = 1; last = i; } } }
-    std::vector<int> sep1, sep_pose, t2, sidx(n, -1);                    // level-1 chain (poses); true separators (poses; positions in sep1)
-    for (int i = 0; i < n; ++i) {
-        if (!is_true[i] && !is_sep[i]) continue;
-        if (is_true[i]) { sidx[i] = (int)sep_pose.size(); sep_pose.push_back(i); t2.push_back((int)sep1.size()); }
-        sep1.push_back(i);
+    // (All of this in time proportional to the separators, not to the poses: three passes over 400 k poses cost a millisecond of the
+    // solve's serial host preparation.)  True separators are marked in a bit set and read back in order.
+    const double t_p1 = ms_since(T0);
+    std::vector<unsigned long long> tbits(((size_t)n + 63) / 64, 0ull);
+    auto mark = [&](int i) { tbits[(size_t)i >> 6] |= 1ull << (i & 63); };
+    mark(0); mark(n - 1);
+    for (int e = 0; e < ne; ++e) { mark(ea[e]); mark(eb[e]); }
+    for (int p = 1; p < nparts; ++p) mark(pbound[p] - 1);                // a partition ends on a separator: segments never straddle ranks
+    const char* chunk_env = getenv("DSSS_PG_CHUNK"); const int chunk = chunk_env ? std::max(2, atoi(chunk_env)) : 16;
+    // pass 2 is sequential over the chunk ends between two true separators: a gap of more than 16 chunks (frame boundaries
+    // without keypoints reach 900 poses) gets true separators of its own, the first chunk end at least 16 chunks after the last one
+    const int run = 16 * chunk;
+    std::vector<int> sep1, sep_pose, t2;                                 // level-1 chain (poses); true separators (poses; positions in sep1)
+    sep_pose.reserve((size_t)2 * ne + nparts + n / run + 8);
+    {
+        int last = 0;
+        for (size_t w = 0; w < tbits.size(); ++w)
+            for (unsigned long long bits = tbits[w]; bits; bits &= bits - 1) {
+                const int b = (int)(w * 64) + __builtin_ctzll(bits);
+                for (;;) {                                               // fill the gap (last, b)
+                    const long long nx = ((long long)last + run + chunk - 1) / chunk * chunk;
+                    if (nx >= b) break;
+                    sep_pose.push_back((int)nx); last = (int)nx;
+                }
+                sep_pose.push_back(b); last = b;
+            }
     }
+    const double t_q1 = ms_since(T0);
+    sep1.reserve(sep_pose.size() + n / chunk + 2); t2.reserve(sep_pose.size());
+    for (size_t it = 0, m = 0; it < sep_pose.size() || m < (size_t)n;) {   // level-1 chain = true separators merged with the chunk ends 0, chunk, 2 chunk ...
+        const long long a = it < sep_pose.size() ? sep_pose[it] : (1LL << 40), bm = m < (size_t)n ? (long long)m : (1LL << 40);
+        if (a <= bm) { t2.push_back((int)sep1.size()); sep1.push_back((int)a); ++it; if (a == bm) m += chunk; }
+        else { sep1.push_back((int)bm); m += chunk; }
+    }
+    const double t_q2 = ms_since(T0);
+    // index of a true separator among the true separators = number of marked poses below it: word prefix + popcount (a binary search
+    // per loop-closure end point cost 0.6 ms)
+    for (int v : sep_pose) mark(v);                                      // the gap fillers too
+    std::vector<int> tpre(tbits.size() + 1, 0);
+    for (size_t w = 0; w < tbits.size(); ++w) tpre[w + 1] = tpre[w] + __builtin_popcountll(tbits[w]);
+    auto sidx = [&](int pose) { return tpre[(size_t)pose >> 6] + __builtin_popcountll(tbits[(size_t)pose >> 6] & ((1ull << (pose & 63)) - 1ull)); };
     const int ns1 = (int)sep1.size(), nseg1 = ns1 - 1;
     const int ns = (int)sep_pose.size(), nseg = ns - 1;
     // this rank's range of the level-1 chain (its poses are [mp0, mp1))
     const int kp0 = (int)(std::lower_bound(sep1.begin(), sep1.end(), mp0) - sep1.begin()), kp1 = (int)(std::lower_bound(sep1.begin(), sep1.end(), mp1) - sep1.begin());
     std::vector<std::pair<int, int>> redges;
+    redges.reserve((size_t)ns + ne);
+    const double t_q3 = ms_since(T0);
     for (int k = 0; k + 1 < ns; ++k) redges.push_back({ k, k + 1 });
-    for (int e = 0; e < ne; ++e) redges.push_back({ sidx[ea[e]], sidx[eb[e]] });
+    for (int e = 0; e < ne; ++e) redges.push_back({ sidx(ea[e]), sidx(eb[e]) });
+    const double t_p2 = ms_since(T0);
     // device state
     pg_dev dv;
     int rc = DSSS_OK;
@@ -1919,6 +1947,7 @@ static int pg_solve_impl(dsss_ctx* c, const double* dr6, int total, const dsss_l
         for (int k = 0; k < ns; ++k) { cx[k] = sxy[2 * (size_t)k]; cy[k] = sxy[2 * (size_t)k + 1]; }
     }
     const double t_prep = ms_since(T0);
+    if (getenv("DSSS_PG_VERBOSE")) fprintf(stderr, "[dsss pg prep] edges %.2f ms, separators %.2f ms (bits %.2f merge %.2f mid %.2f redges %.2f), uploads + round trip %.2f ms\n", t_p1, t_p2 - t_p1, t_q1 - t_p1, t_q2 - t_q1, t_q3 - t_q2, t_p2 - t_q3, t_prep - t_p2);
     const auto T1 = std::chrono::steady_clock::now();
     // The analysis of the reduced system runs on a host thread of its own while this thread sets up everything that does not depend
     // on it -- device arrays of the pose chain, initial values, the first linearisation and the chain part of the first LM trial
