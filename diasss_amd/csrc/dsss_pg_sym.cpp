@@ -255,21 +255,30 @@ void pg_symbolic(int ns, const std::vector<std::pair<int, int>>& edges, int ncha
     const int T = std::max(1, opt.threads);
     // adjacency in CSR form, rows sorted and deduplicated
     std::vector<int> adj_ptr(ns + 1, 0), adj_idx;
-    {
+    {   // rows are tiny (two chain neighbours + the loop closures of the pose): insertion sort and duplicate removal in place, rows
+        // compacted behind each other (std::sort + std::unique + a vector insert per row cost a millisecond at 23 k rows)
         for (auto& e : edges) if (e.first != e.second) { adj_ptr[e.first + 1]++; adj_ptr[e.second + 1]++; }
         for (int i = 0; i < ns; ++i) adj_ptr[i + 1] += adj_ptr[i];
-        std::vector<int> raw(adj_ptr[ns]), fill(adj_ptr.begin(), adj_ptr.end() - 1);
-        for (auto& e : edges) if (e.first != e.second) { raw[fill[e.first]++] = e.second; raw[fill[e.second]++] = e.first; }
-        adj_idx.reserve(raw.size());
-        std::vector<int> nptr(ns + 1, 0);
+        adj_idx.resize(adj_ptr[ns]);
+        std::vector<int> fill(adj_ptr.begin(), adj_ptr.end() - 1);
+        for (auto& e : edges) if (e.first != e.second) { adj_idx[fill[e.first]++] = e.second; adj_idx[fill[e.second]++] = e.first; }
+        int w = 0;
         for (int i = 0; i < ns; ++i) {
-            int* b0 = raw.data() + adj_ptr[i]; int* e0 = raw.data() + adj_ptr[i + 1];
-            std::sort(b0, e0); e0 = std::unique(b0, e0);
-            adj_idx.insert(adj_idx.end(), b0, e0);
-            nptr[i + 1] = (int)adj_idx.size();
+            const int b0 = adj_ptr[i], e0 = adj_ptr[i + 1];
+            adj_ptr[i] = w;
+            for (int q = b0; q < e0; ++q) {                          // insert adj_idx[q] into the sorted, duplicate-free run [adj_ptr[i], w)
+                const int v = adj_idx[q];
+                int pos = w;
+                while (pos > adj_ptr[i] && adj_idx[pos - 1] > v) --pos;
+                if (pos > adj_ptr[i] && adj_idx[pos - 1] == v) continue;
+                for (int k = w; k > pos; --k) adj_idx[k] = adj_idx[k - 1];
+                adj_idx[pos] = v; ++w;
+            }
         }
-        adj_ptr.swap(nptr);
+        adj_ptr[ns] = w;
+        adj_idx.resize(w);
     }
+    const auto q0a = tnow();
     std::vector<nd_tree> pool; std::mutex mu;
     std::vector<char> iface(ns, 0);
     int root = -1;
@@ -631,8 +640,8 @@ void pg_symbolic(int ns, const std::vector<std::pair<int, int>>& edges, int ncha
         long long zeros = 0;
         int big = 0;
         for (int f = 0; f < nf; ++f) { if (S.f_n[f] > 100) ++big; zeros += 0; }
-        fprintf(stderr, "[dsss pg symbolic] adjacency+ND %.1f ms, column structures %.1f ms, bins+lists %.1f ms, fronts+schedule %.1f ms | ns %d nnzL %lld bins %d (%zu cols, %zu roots, U %.1f MB) fronts %d (>100 rows: %d, max %d) panels %d levels %d front arena %.1f MB comm %.1f MB front GFLOP %.1f (column count %.1f)\n",
-                tms(q0, q1), tms(q1, q2), tms(q2, q3), tms(q3, tnow()), ns, S.nnzL, (int)S.binptr.size() - 1, S.bincols.size(), S.broot.size(), S.ubin_doubles * 8e-6,
+        fprintf(stderr, "[dsss pg symbolic] adjacency %.2f + ND %.2f ms, column structures %.1f ms, bins+lists %.1f ms, fronts+schedule %.1f ms | ns %d nnzL %lld bins %d (%zu cols, %zu roots, U %.1f MB) fronts %d (>100 rows: %d, max %d) panels %d levels %d front arena %.1f MB comm %.1f MB front GFLOP %.1f (column count %.1f)\n",
+                tms(q0, q0a), tms(q0a, q1), tms(q1, q2), tms(q2, q3), tms(q3, tnow()), ns, S.nnzL, (int)S.binptr.size() - 1, S.bincols.size(), S.broot.size(), S.ubin_doubles * 8e-6,
                 nf, big, S.max_front_n, S.npanels, S.nlev, S.front_doubles * 8e-6, S.comm_doubles * 8e-6, S.flops_fronts * 1e-9, S.flops_factor * 1e-9);
     }
 }
@@ -670,6 +679,8 @@ void pg_sym_opts_env(pg_sym_opts& opt)
     if (getenv("DSSS_PG_RELAX_FLOPS")) opt.relax_flops = atof(getenv("DSSS_PG_RELAX_FLOPS"));
     if (getenv("DSSS_PG_RELAX_SMALL")) opt.relax_flops_small = atof(getenv("DSSS_PG_RELAX_SMALL"));
     if (getenv("DSSS_PG_RELAX_ABS")) opt.relax_abs_flops = atof(getenv("DSSS_PG_RELAX_ABS"));
+    if (getenv("DSSS_PG_ND_BOTH")) opt.nd_both_axes = atoi(getenv("DSSS_PG_ND_BOTH"));
+    if (getenv("DSSS_PG_LEAF")) opt.leaf = atoi(getenv("DSSS_PG_LEAF"));
 }
 
 // ------------------------------------------------------------------ host twin of the numeric phase (CPU tests only)
