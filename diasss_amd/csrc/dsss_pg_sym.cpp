@@ -478,6 +478,7 @@ void pg_symbolic(int ns, const std::vector<std::pair<int, int>>& edges, int ncha
         }
         S.front_doubles = o; S.frhs_doubles = ro;
     }
+    const auto fA = tnow();
     // children (bin roots first, then fronts, both ascending) and their boundary -> parent row maps
     {
         std::vector<int> cnt(nf + 1, 0);
@@ -508,6 +509,7 @@ void pg_symbolic(int ns, const std::vector<std::pair<int, int>>& edges, int ncha
             }
         });
     }
+    const auto fB = tnow();
     // ---- where the assembled blocks go
     const int ne = (int)edges.size() - nchain, nval = ns + nchain + ne;
     S.dest_bin.assign(nval, -1);
@@ -554,6 +556,7 @@ void pg_symbolic(int ns, const std::vector<std::pair<int, int>>& edges, int ncha
             }
         });
     }
+    const auto fC = tnow();
     // ---- schedule: a front starts one level after its last child front has finished; panel steps are consecutive levels
     S.f_level0.assign(nf, 0); S.f_npan.resize(nf); S.f_pan0.resize(nf);
     int maxl = -1, np = 0;
@@ -585,6 +588,7 @@ void pg_symbolic(int ns, const std::vector<std::pair<int, int>>& edges, int ncha
             f = nxt;
         }
     }
+    const auto fD = tnow();
     // ---- per-row views for the assembly, work items of the assembly and of the trailing update
     {
         const int nrows_all = S.f_rowptr[nf];
@@ -604,6 +608,7 @@ void pg_symbolic(int ns, const std::vector<std::pair<int, int>>& edges, int ncha
                 for (long long q = r0; q < r1; ++q) { const int at = fp[S.f_rowptr[f] + S.rel[q]]++; S.xr_child[at] = c; S.xr_row[at] = (int)(q - r0); }
             }
     }
+    const auto fE = tnow();
     // ---- children that cross from a rank's interior into the interface
     {
         long long o = 0;
@@ -636,6 +641,7 @@ void pg_symbolic(int ns, const std::vector<std::pair<int, int>>& edges, int ncha
     }
     // statistics
     for (int j = 0; j < ns; ++j) { const double m = csz(j) - 1; S.flops_factor += 36.0 * 6.0 * (m * m + 3 * m) + 72.0; }
+    if (tv) fprintf(stderr, "[dsss pg symbolic] fronts+schedule: supernodes %.2f, children+rel %.2f, destinations+entries %.2f, schedule %.2f, row views %.2f, rest %.2f ms\n", tms(q3, fA), tms(fA, fB), tms(fB, fC), tms(fC, fD), tms(fD, fE), tms(fE, tnow()));
     if (tv) {
         long long zeros = 0;
         int big = 0;
