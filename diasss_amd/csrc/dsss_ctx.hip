@@ -122,6 +122,7 @@ void dsss_destroy(dsss_ctx* c)
     if (c->geoms && c->geoms_free) c->geoms_free(c->geoms);
     if (c->ex_pinned) hipHostFree(c->ex_pinned);
     if (c->bbox_pinned) hipHostFree(c->bbox_pinned);
+    hipFree(c->bbox_jobs_dev);
     dsss_pg_free(c); dsss_comm_free(c);
     hipEventDestroy(c->prof.e0); hipEventDestroy(c->prof.e1);
     dsss_prof_flush(c);
@@ -245,13 +246,12 @@ int dsss_sync_bboxes(dsss_ctx* c)
     for (int f = 0; f < c->max_frames; ++f)
         if (c->frames[f].bbox_async) { const dsss_frame& fr = c->frames[f]; jobs.push_back(bbox_job{ fr.pose6, fr.gr, fr.N, fr.M, f, 0 }); }
     if (!jobs.empty()) {
-        bbox_job* d_jobs = nullptr;
-        HIPCHK(c, hipMalloc(&d_jobs, jobs.size() * sizeof(bbox_job)));
+        if (!c->bbox_jobs_dev) HIPCHK(c, hipMalloc(&c->bbox_jobs_dev, (size_t)c->max_frames * sizeof(bbox_job)));
+        bbox_job* d_jobs = static_cast<bbox_job*>(c->bbox_jobs_dev);
         hipError_t e = hipMemcpyAsync(d_jobs, jobs.data(), jobs.size() * sizeof(bbox_job), hipMemcpyHostToDevice, c->stream);
         if (e == hipSuccess) { hipLaunchKernelGGL(geo_bbox_kernel, dim3((unsigned)jobs.size()), dim3(256), 0, c->stream, d_jobs, c->bbox_dev, c->rows_dev, c->cols_dev); e = hipGetLastError(); }
         if (e == hipSuccess) e = hipMemcpyAsync(c->bbox_pinned, c->bbox_dev, (size_t)c->max_frames * 4 * sizeof(double), hipMemcpyDeviceToHost, c->stream);
         if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-        hipFree(d_jobs);
         HIPCHK(c, e);
         for (const bbox_job& j : jobs) { memcpy(c->frames[j.id].bbox, c->bbox_pinned + (size_t)j.id * 4, 4 * sizeof(double)); c->frames[j.id].bbox_async = false; }
     }
@@ -411,7 +411,7 @@ int dsss_frames_set(dsss_ctx* c, int n, const int* ids, const double* const* raw
     dsss_geo_batch& G = c->gbatches[b];
     HIPCHK(c, hipEventSynchronize(G.ev));                   // the staging area may still feed its previous upload
     static const int T_env = getenv("DSSS_FS_THREADS") ? atoi(getenv("DSSS_FS_THREADS")) : 0;
-    const int T = T_env > 0 ? T_env : (n >= 16 ? 8 : 1);
+    const int T = T_env > 0 ? T_env : (n >= 16 ? 4 : 1);       // (eight threads were slower than four: the pointer-attribute queries of frame_fill serialise)
     std::vector<hipError_t> errs(T, hipSuccess);
     auto work = [&](int t) { for (int i = t; i < n; i += T) { const hipError_t e = frame_fill(c, ids[i], G.h + off[i], pose6[i], alt[i], grange[i]); if (e != hipSuccess) errs[t] = e; } };
     dsss_pool_run(T, work);

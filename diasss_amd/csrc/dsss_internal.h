@@ -82,6 +82,7 @@ struct dsss_ctx {
     double* bbox_dev = nullptr;         // [F][4]
     double* bbox_pinned = nullptr;      // [F][4] pinned host mirror, filled asynchronously
     bool bbox_pending = false;          // boxes launched but not yet copied into dsss_frame::bbox
+    void* bbox_jobs_dev = nullptr;      // [max_frames] job records of dsss_sync_bboxes (a hipMalloc / hipFree pair per call cost 0.15 ms)
     // extraction scratch (grown on demand)
     void* ex_scratch = nullptr; size_t ex_scratch_bytes = 0;
     void* ex_pinned = nullptr; size_t ex_pinned_bytes = 0;
