@@ -539,8 +539,8 @@ typedef qt_kp_in kp_in;
 __constant__ signed char c_pattern[1024] = {
 #include "orb_pattern_31.inc"
 };
-__constant__ int c_umax[16] = { 15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 8, 6, 3 };   // ORBextractor.cpp:454-469
-__constant__ int c_gauss13[13] = { 1, 2, 7, 16, 31, 45, 52, 45, 31, 16, 7, 2, 1 };               // 8.8 taps, sum 256 (oracle/orc_orb.c:orc_gauss13_taps)
+// (umax of the patch disc, ORBextractor.cpp:454-469: { 15 15 15 15 14 14 14 13 13 12 11 10 9 8 6 3 }, folded into c_ic below; the 13 blur taps
+// 1 2 7 16 31 45 52 45 31 16 7 2 1, oracle/orc_orb.c:orc_gauss13_taps, are the packed constants G0..G2 / T[] of orient_desc_kernel)
 // IC_Angle over the radius-15 disc as packed dot products: row v of the 31 x 31 patch is eight aligned dwords of the LDS tile
 // (columns 8 .. 39 = u -16 .. 15); wu holds u + 15 inside the disc and 0 outside, w1 holds 1 / 0, so that
 // m10 = sum (u + 15) I - 15 sum I and m01 = sum v (row sum) come out of two v_dot4_u32_u8 per dword (the same integers in another order)
