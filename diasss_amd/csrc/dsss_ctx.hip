@@ -118,6 +118,7 @@ void dsss_destroy(dsss_ctx* c)
     hipFree(c->lcs); hipFree(c->ex_scratch); hipFree(c->mt_aux); hipFree(c->tmp_dev);
     if (c->pg_edges_host) hipHostFree(c->pg_edges_host);
     if (c->pg_stage) hipHostFree(c->pg_stage);
+    if (c->pg_scal_host) hipHostFree(c->pg_scal_host);
     if (c->pg_warm) hipFree(c->pg_warm);
     if (c->geoms && c->geoms_free) c->geoms_free(c->geoms);
     if (c->ex_pinned) hipHostFree(c->ex_pinned);

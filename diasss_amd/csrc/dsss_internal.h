@@ -113,6 +113,7 @@ struct dsss_ctx {
     int pg_parts = 0;                   // pose-graph partitions (0: one per rank); > ranks only to exercise the interface logic on few GPUs
     int* tmp_dev = nullptr;             // 64 ints of device scratch for one-value results (dsss_descriptor_distance)
     void* pg_edges_host = nullptr; size_t pg_edges_cap = 0;     // page-locked staging of the selected LC edges (dsss_posegraph_solve)
+    double* pg_scal_host = nullptr;                             // page-locked landing place of the LM trial's scalars (8 doubles)
     void* pg_stage = nullptr; size_t pg_stage_cap = 0;          // page-locked staging of the analysis tables: one upload per solve (pg_dev::flush)
     // online use (dsss_posegraph_update): the estimate of the previous update stays on the device, the LC edges accumulate
     void* pg_warm = nullptr; size_t pg_warm_cap = 0; int pg_warm_n = 0;   // pose_t[pg_warm_n]

@@ -2010,9 +2010,13 @@ static int pg_solve_impl(dsss_ctx* c, const double* dr6, int total, const dsss_l
             HCK(hipStreamSynchronize(st));
             host3[0] = h4[0]; host3[1] = h4[1]; host3[2] = h4[2]; *failed = h4[3] != 0.0;
         } else {
-            HCK(hipMemcpyAsync(host3, d_scal, 3 * sizeof(double), hipMemcpyDeviceToHost, st));
-            HCK(hipMemcpyAsync(failed, d_fail, sizeof(int), hipMemcpyDeviceToHost, st));
+            // into page-locked memory: a copy to the caller's stack is staged by the runtime and waits for it twice per trial
+            if (!c->pg_scal_host) HCK(hipHostMalloc((void**)&c->pg_scal_host, 8 * sizeof(double), hipHostMallocDefault));
+            HCK(hipMemcpyAsync(c->pg_scal_host, d_scal, 3 * sizeof(double), hipMemcpyDeviceToHost, st));
+            HCK(hipMemcpyAsync(c->pg_scal_host + 4, d_fail, sizeof(int), hipMemcpyDeviceToHost, st));
             HCK(hipStreamSynchronize(st));
+            host3[0] = c->pg_scal_host[0]; host3[1] = c->pg_scal_host[1]; host3[2] = c->pg_scal_host[2];
+            *failed = *reinterpret_cast<const int*>(c->pg_scal_host + 4);
         }
         return DSSS_OK;
     };
