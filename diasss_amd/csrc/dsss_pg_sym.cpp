@@ -115,18 +115,20 @@ namespace {
 struct nd_tree { int a = -1, b = -1, size = 0; };          // children (indices into the node pool) or -1,-1 for a leaf
 #define PG_ND_PAR 4
 struct nd_ctx {
-    const int* adj_ptr; const int* adj_idx; const double* cx; const double* cy; char* side; int leaf; int both_axes;
+    const int* adj_ptr; const int* adj_idx; const double* cx; const double* cy; char* side; int leaf; int both_axes; bool geo_first;
     const int* part; char* iface;                          // rank of every node (or null); iface[v] = 1 for rank-level separator nodes
     std::vector<nd_tree>* pool; std::mutex* mu;
 };
-int nd_order(std::vector<int>& nodes, const nd_ctx& C, std::vector<int>& order, int depth, int plo, int phi)
+int nd_order(std::vector<int>& nodes, const nd_ctx& C, std::vector<int>& order, int depth)
 {
     auto new_node = [&](int a, int b, int size) { std::lock_guard<std::mutex> g(*C.mu); C.pool->push_back({ a, b, size }); return (int)C.pool->size() - 1; };
     const int total = (int)nodes.size();
-    const bool by_part = C.part && phi - plo > 1;
-    if (!by_part && total <= C.leaf) { std::sort(nodes.begin(), nodes.end()); for (int v : nodes) order.push_back(v); return depth <= PG_ND_PAR ? new_node(-1, -1, total) : -1; }
-    size_t half;
-    const int pmid = (plo + phi) / 2;
+    // ranks the node set spans: while it spans several, every separator cut out of it is INTERFACE (replicated on all ranks), and the
+    // recursion must go on until the pieces belong to one rank each
+    int pmin = 0, pmax = 0;
+    if (C.part) { pmin = 1 << 30; pmax = -1; for (int v : nodes) { pmin = std::min(pmin, C.part[v]); pmax = std::max(pmax, C.part[v]); } }
+    const bool multi = pmax > pmin;
+    if (!multi && total <= C.leaf) { std::sort(nodes.begin(), nodes.end()); for (int v : nodes) order.push_back(v); return depth <= PG_ND_PAR ? new_node(-1, -1, total) : -1; }
     std::vector<int> A, B, S;
     // lower-half nodes with a neighbour in the upper half = the separator of a split (sides are marked in C.side)
     auto boundary = [&](const std::vector<int>& nd, size_t h, std::vector<int>* a, std::vector<int>* s) {
@@ -140,54 +142,63 @@ int nd_order(std::vector<int>& nodes, const nd_ctx& C, std::vector<int>& order, 
         }
         return cnt;
     };
-    if (by_part) {
+    // candidates: the rank cut (lower ranks first) while the set spans several ranks; the median cut along the longer extent, and --
+    // for sets of at least both_axes nodes -- along the other axis too.  A survey is a long strip of parallel legs: the cut across the
+    // longer extent is not the cheaper one once a piece holds few legs (a cut between legs costs the loop closures of two legs, a cut
+    // across them one pose per leg), and rank cuts are cuts between legs.  The smallest separator wins; ties go to the rank cut, then
+    // to the longer extent.  (With geo_first off a multi-rank set always takes its rank cut: every rank's interior is then ONE range
+    // of the order, the layout of rounds 1-2.)
+    size_t half = 0, best = (size_t)-1;
+    std::vector<int> cand;
+    if (multi) {
+        const int pmid = (pmin + pmax + 1) / 2;
         half = std::stable_partition(nodes.begin(), nodes.end(), [&](int v) { return C.part[v] < pmid; }) - nodes.begin();
-    } else {
+        best = boundary(nodes, half, nullptr, nullptr);
+    }
+    const bool geo = !multi || (C.geo_first && total > C.leaf);
+    if (geo) {
         double x0 = 1e300, x1 = -1e300, y0 = 1e300, y1 = -1e300;
         for (int v : nodes) { x0 = std::min(x0, C.cx[v]); x1 = std::max(x1, C.cx[v]); y0 = std::min(y0, C.cy[v]); y1 = std::max(y1, C.cy[v]); }
-        bool byx = (x1 - x0) >= (y1 - y0);
-        half = nodes.size() / 2;
+        const bool byx = (x1 - x0) >= (y1 - y0);
+        const size_t h2 = nodes.size() / 2;
         // split at the median of the (coordinate, index) total order; only the two halves matter, not their inner order
         auto split = [&](std::vector<int>& nd, bool bx) {
             const double* key = bx ? C.cx : C.cy;
-            std::nth_element(nd.begin(), nd.begin() + half, nd.end(), [&](int a, int b) {
+            std::nth_element(nd.begin(), nd.begin() + h2, nd.end(), [&](int a, int b) {
                 const double ka = key[a], kb = key[b];
                 return ka != kb ? ka < kb : a < b; });
         };
-        if (total >= C.both_axes) {
-            // a survey is a long strip of parallel legs: the cut across the longer extent is not the cheaper one once a piece
-            // holds few legs (a cut between legs costs the loop closures of two legs, a cut across them one pose per leg).
-            // Both medians are tried and the smaller separator wins (ties: the longer extent).
-            std::vector<int> alt(nodes);
-            split(nodes, byx); split(alt, !byx);
-            const size_t c0 = boundary(nodes, half, nullptr, nullptr), c1 = boundary(alt, half, nullptr, nullptr);
-            if (c1 < c0) nodes.swap(alt);
-        } else split(nodes, byx);
+        if (!multi && total < C.both_axes) { split(nodes, byx); half = h2; }       // the only candidate: nothing to compare
+        else for (int pass = 0; pass < (total >= C.both_axes ? 2 : 1); ++pass) {
+            cand = nodes;
+            split(cand, pass == 0 ? byx : !byx);
+            const size_t c = boundary(cand, h2, nullptr, nullptr);
+            if (c < best) { best = c; nodes.swap(cand); half = h2; }
+        }
     }
     boundary(nodes, half, &A, &S);
     B.assign(nodes.begin() + half, nodes.end());
     for (int v : nodes) C.side[v] = 0;
     std::sort(S.begin(), S.end());
-    if (by_part) for (int v : S) C.iface[v] = 1;
-    if (!by_part && (A.empty() || B.empty())) {          // degenerate cut: fall back to index order
+    if (multi) for (int v : S) C.iface[v] = 1;
+    if (!multi && (A.empty() || B.empty())) {            // degenerate cut: fall back to index order
         std::sort(nodes.begin(), nodes.end());
         for (int v : nodes) order.push_back(v);
         return depth <= PG_ND_PAR ? new_node(-1, -1, total) : -1;
     }
     int na = -1, nb = -1;
-    const int alo = plo, ahi = by_part ? pmid : phi, blo = by_part ? pmid : plo, bhi = phi;
-    if (depth < PG_ND_PAR && (total > 2048 || by_part)) {
+    if (depth < PG_ND_PAR && (total > 2048 || multi)) {
         std::vector<int> oa;
-        pg_pool::task tk; tk.fn = [&] { na = nd_order(A, C, oa, depth + 1, alo, ahi); };
+        pg_pool::task tk; tk.fn = [&] { na = nd_order(A, C, oa, depth + 1); };
         pg_pool::get().fork(&tk);
         std::vector<int> ob;
-        nb = nd_order(B, C, ob, depth + 1, blo, bhi);
+        nb = nd_order(B, C, ob, depth + 1);
         pg_pool::get().join(&tk);
         order.insert(order.end(), oa.begin(), oa.end());
         order.insert(order.end(), ob.begin(), ob.end());
     } else {
-        nd_order(A, C, order, PG_ND_PAR + 1, alo, ahi);
-        nd_order(B, C, order, PG_ND_PAR + 1, blo, bhi);
+        nd_order(A, C, order, PG_ND_PAR + 1);
+        nd_order(B, C, order, PG_ND_PAR + 1);
     }
     for (int v : S) order.push_back(v);
     return depth <= PG_ND_PAR ? new_node(na, nb, total) : -1;
@@ -286,8 +297,8 @@ void pg_symbolic(int ns, const std::vector<std::pair<int, int>>& edges, int ncha
         std::vector<int> nodes(ns); std::iota(nodes.begin(), nodes.end(), 0);
         std::vector<char> side(ns, 0);
         S.order.reserve(ns);
-        nd_ctx C{ adj_ptr.data(), adj_idx.data(), cx, cy, side.data(), opt.leaf, opt.nd_both_axes, S.nparts > 1 ? part : nullptr, iface.data(), &pool, &mu };
-        root = nd_order(nodes, C, S.order, 0, 0, S.nparts);
+        nd_ctx C{ adj_ptr.data(), adj_idx.data(), cx, cy, side.data(), opt.leaf, opt.nd_both_axes, opt.nd_geo_first, S.nparts > 1 ? part : nullptr, iface.data(), &pool, &mu };
+        root = nd_order(nodes, C, S.order, 0);
     }
     const auto q1 = tnow();
     S.perm.assign(ns, 0);
@@ -344,6 +355,8 @@ void pg_symbolic(int ns, const std::vector<std::pair<int, int>>& edges, int ncha
     {   // greedy packing of whole subtrees into bins, subtrees taken in ascending root order, never across ranks
         std::vector<int> roots;
         for (int j = 0; j < ns; ++j) if (sub_ok[j] && root_of[j] == j) roots.push_back(j);
+        // (a rank's interior may be several ranges of the order when geometric cuts come before rank cuts: its bins stay one range)
+        std::stable_sort(roots.begin(), roots.end(), [&](int a, int b) { return S.col_part[a] < S.col_part[b]; });
         int nbins = 0; double fill = opt.bin_cost + 1; int cur_part = -2;
         for (int r : roots) {
             if (fill + sub_cost[r] > opt.bin_cost || S.col_part[r] != cur_part) { ++nbins; fill = 0; cur_part = S.col_part[r]; S.bin_part.push_back(cur_part); }
@@ -687,6 +700,7 @@ void pg_sym_opts_env(pg_sym_opts& opt)
     if (getenv("DSSS_PG_RELAX_ABS")) opt.relax_abs_flops = atof(getenv("DSSS_PG_RELAX_ABS"));
     if (getenv("DSSS_PG_ND_BOTH")) opt.nd_both_axes = atoi(getenv("DSSS_PG_ND_BOTH"));
     if (getenv("DSSS_PG_LEAF")) opt.leaf = atoi(getenv("DSSS_PG_LEAF"));
+    if (getenv("DSSS_PG_GEO_FIRST")) opt.nd_geo_first = atoi(getenv("DSSS_PG_GEO_FIRST")) != 0;
 }
 
 // ------------------------------------------------------------------ host twin of the numeric phase (CPU tests only)
