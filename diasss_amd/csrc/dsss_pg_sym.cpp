@@ -130,16 +130,26 @@ int nd_order(std::vector<int>& nodes, const nd_ctx& C, std::vector<int>& order, 
     const bool multi = pmax > pmin;
     if (!multi && total <= C.leaf) { std::sort(nodes.begin(), nodes.end()); for (int v : nodes) order.push_back(v); return depth <= PG_ND_PAR ? new_node(-1, -1, total) : -1; }
     std::vector<int> A, B, S;
-    // lower-half nodes with a neighbour in the upper half = the separator of a split (sides are marked in C.side)
-    auto boundary = [&](const std::vector<int>& nd, size_t h, std::vector<int>* a, std::vector<int>* s) {
+    // The separator of a split (sides are marked in C.side): a lower-half node with a neighbour in the upper half -- except that of a
+    // cut edge between nodes of DIFFERENT ranks it is always the lower-rank end that goes into the separator.  The numeric phase relies
+    // on that: a factor belongs to the rank of its higher pose and adds to the diagonal block of the lower one, which therefore has to
+    // be an interface separator (summed over the ranks).  Rank cuts satisfy it by themselves (lower ranks are the lower half).
+    // b: when given, receives the upper half without its separator nodes.
+    auto boundary = [&](const std::vector<int>& nd, size_t h, std::vector<int>* a, std::vector<int>* s, std::vector<int>* b = nullptr) {
         for (size_t i = 0; i < nd.size(); ++i) C.side[nd[i]] = i < h ? 1 : 2;
         size_t cnt = 0;
         for (size_t i = 0; i < h; ++i) {
             const int v = nd[i];
             bool cut = false;
-            for (int q = C.adj_ptr[v]; q < C.adj_ptr[v + 1]; ++q) if (C.side[C.adj_idx[q]] == 2) { cut = true; break; }
+            for (int q = C.adj_ptr[v]; q < C.adj_ptr[v + 1]; ++q) {
+                const int u = C.adj_idx[q];
+                if (C.side[u] != 2 && C.side[u] != 4) continue;
+                if (multi && C.part[u] < C.part[v]) { if (C.side[u] == 2) { C.side[u] = 4; ++cnt; } }      // the upper-half end has the lower rank
+                else cut = true;
+            }
             if (cut) { ++cnt; if (s) s->push_back(v); } else if (a) a->push_back(v);
         }
+        if (s || b) for (size_t i = h; i < nd.size(); ++i) { const int u = nd[i]; if (C.side[u] == 4) { if (s) s->push_back(u); } else if (b) b->push_back(u); }
         return cnt;
     };
     // candidates: the rank cut (lower ranks first) while the set spans several ranks; the median cut along the longer extent, and --
@@ -176,8 +186,7 @@ int nd_order(std::vector<int>& nodes, const nd_ctx& C, std::vector<int>& order, 
             if (c < best) { best = c; nodes.swap(cand); half = h2; }
         }
     }
-    boundary(nodes, half, &A, &S);
-    B.assign(nodes.begin() + half, nodes.end());
+    boundary(nodes, half, &A, &S, &B);
     for (int v : nodes) C.side[v] = 0;
     std::sort(S.begin(), S.end());
     if (multi) for (int v : S) C.iface[v] = 1;
