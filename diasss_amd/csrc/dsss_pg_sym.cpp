@@ -117,6 +117,7 @@ struct nd_tree { int a = -1, b = -1, size = 0; };          // children (indices 
 struct nd_ctx {
     const int* adj_ptr; const int* adj_idx; const double* cx; const double* cy; char* side; int leaf; int both_axes; bool geo_first;
     const int* part; char* iface;                          // rank of every node (or null); iface[v] = 1 for rank-level separator nodes
+    const char* forced;                                    // nodes with a neighbour of a HIGHER rank: they must end up in the interface (see nd_order)
     std::vector<nd_tree>* pool; std::mutex* mu;
 };
 int nd_order(std::vector<int>& nodes, const nd_ctx& C, std::vector<int>& order, int depth)
@@ -188,6 +189,20 @@ int nd_order(std::vector<int>& nodes, const nd_ctx& C, std::vector<int>& order, 
     }
     boundary(nodes, half, &A, &S, &B);
     for (int v : nodes) C.side[v] = 0;
+    if (multi) {
+        // A factor belongs to the rank of its higher pose and adds to the diagonal block of the lower one too, so a node with a
+        // neighbour of a higher rank has to be INTERFACE (its entries are summed over the ranks) whether or not a cut ever runs between
+        // the two -- the neighbour may have left into a separator higher up.  Such nodes are pulled into this separator when the half
+        // they sit in has become one rank's (a half that still spans ranks passes them on): the lowest interface level there is.
+        for (std::vector<int>* X : { &A, &B }) {
+            int lo = 1 << 30, hi = -1;
+            for (int v : *X) { lo = std::min(lo, C.part[v]); hi = std::max(hi, C.part[v]); }
+            if (hi > lo) continue;
+            size_t w = 0;
+            for (size_t i = 0; i < X->size(); ++i) { const int v = (*X)[i]; if (C.forced[v]) S.push_back(v); else (*X)[w++] = v; }
+            X->resize(w);
+        }
+    }
     std::sort(S.begin(), S.end());
     if (multi) for (int v : S) C.iface[v] = 1;
     if (!multi && (A.empty() || B.empty())) {            // degenerate cut: fall back to index order
@@ -306,7 +321,9 @@ void pg_symbolic(int ns, const std::vector<std::pair<int, int>>& edges, int ncha
         std::vector<int> nodes(ns); std::iota(nodes.begin(), nodes.end(), 0);
         std::vector<char> side(ns, 0);
         S.order.reserve(ns);
-        nd_ctx C{ adj_ptr.data(), adj_idx.data(), cx, cy, side.data(), opt.leaf, opt.nd_both_axes, opt.nd_geo_first, S.nparts > 1 ? part : nullptr, iface.data(), &pool, &mu };
+        std::vector<char> forced(ns, 0);
+        if (S.nparts > 1 && part) for (int v = 0; v < ns; ++v) for (int q = adj_ptr[v]; q < adj_ptr[v + 1]; ++q) if (part[adj_idx[q]] > part[v]) { forced[v] = 1; break; }
+        nd_ctx C{ adj_ptr.data(), adj_idx.data(), cx, cy, side.data(), opt.leaf, opt.nd_both_axes, opt.nd_geo_first, S.nparts > 1 ? part : nullptr, iface.data(), forced.data(), &pool, &mu };
         root = nd_order(nodes, C, S.order, 0);
     }
     const auto q1 = tnow();

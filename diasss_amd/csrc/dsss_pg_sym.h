@@ -102,7 +102,7 @@ void pg_build_schedule(const pg_sym& S, int part_lo, int part_hi, pg_sched& out)
 struct pg_sym_opts {
     int leaf = 24;                      // nested-dissection leaf size
     int nd_both_axes = 64;              // node sets of at least this size try the median cut along both axes and keep the smaller separator
-    bool nd_geo_first = false;          // a node set that spans several ranks may take a geometric cut when its separator is smaller than the rank cut's (its separator is interface then)
+    bool nd_geo_first = true;           // a node set that spans several ranks may take a geometric cut when its separator is smaller than the rank cut's (its separator is interface then)
     double bin_cost = 1000;             // work bound of a binned subtree
     int threads = 4;
     // relaxed amalgamation of a front into its parent (columns adjacent): accepted when it adds at most relax_zero_blocks
