@@ -2081,6 +2081,7 @@ static int pg_solve_impl(dsss_ctx* c, const double* dr6, int total, const dsss_l
         pre_lin = pre_chain = true;
     }
     sym_thread.join();
+    if (S.ownership_violations) { dv.release(); DSSS_FAIL(c, DSSS_E_STATE, "pose-graph analysis: %d separators with a higher-rank neighbour are not interface", S.ownership_violations); }
     const double t_sym = ms_since(T1);
     const auto T2 = std::chrono::steady_clock::now();
     const int nfr = (int)S.f_c0.size(), npan = S.npanels;

@@ -331,6 +331,8 @@ void pg_symbolic(int ns, const std::vector<std::pair<int, int>>& edges, int ncha
     for (int i = 0; i < ns; ++i) S.perm[S.order[i]] = i;
     S.col_part.assign(ns, 0);
     for (int j = 0; j < ns; ++j) { const int v = S.order[j]; S.col_part[j] = iface[v] ? -1 : (part && S.nparts > 1 ? part[v] : 0); }
+    if (part && S.nparts > 1)
+        for (int v = 0; v < ns; ++v) if (!iface[v]) for (int q = adj_ptr[v]; q < adj_ptr[v + 1]; ++q) if (part[adj_idx[q]] > part[v]) { S.ownership_violations++; break; }
     std::vector<cref> cols(ns);
     S.parent.assign(ns, -1);
     std::vector<int> kid_head(ns, -1), kid_next(ns, -1);
@@ -869,6 +871,7 @@ extern "C" int dsss_host_pg_solve(int ns, const int32_t* edge_a, const int32_t* 
     if (getenv("DSSS_PG_ND_BOTH")) opt.nd_both_axes = atoi(getenv("DSSS_PG_ND_BOTH"));
     pg_sym_opts_env(opt);
     pg_symbolic(ns, edges, ns - 1, cx, cy, part, nparts, opt, S);
+    if (S.ownership_violations) return DSSS_E_STATE;        // a lower-rank end of a cross-rank factor outside the interface
     const int rc = x ? pg_host_solve(S, nedges - (ns - 1), edges, aval, rhs, x) : 0;
     if (stats8) {
         stats8[0] = S.nnzL; stats8[1] = (int64_t)S.f_c0.size(); stats8[2] = S.npanels; stats8[3] = S.nlev;

@@ -84,6 +84,9 @@ struct pg_sym {
     int nval = 0;
     // statistics
     double flops_factor = 0, flops_fronts = 0; long long nnzL = 0; int max_front_n = 0;
+    // ownership invariant of the partitioned numeric phase: a separator with a neighbour of a higher rank must be interface (its
+    // diagonal block is summed over the ranks).  Counted by pg_symbolic, must be 0.
+    int ownership_violations = 0;
 };
 
 // launch lists of a subset of the fronts (all of them, one rank's interior, or the interface), level by level
