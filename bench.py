@@ -100,6 +100,69 @@ def sample_parity(sv, n_frames, o_poses, o_edges, device):
             "max_abs_pose_entry": float(np.abs(poses - o_poses).max())}
 
 
+def launch_ranks(n, argv):
+    """one child process per GPU, as `python -m torch.distributed.run --nnodes=1 --nproc-per-node n` would start them; this
+    process never initialises the GPU.  A child that fails takes the others down (they would wait in a collective for ever)."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")        # dmabuf IPC: RCCL between processes needs it on this driver
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env))
+    rc = 0
+    live = list(procs)
+    while live:
+        for p in list(live):
+            try:
+                p.wait(timeout=0.2)
+            except subprocess.TimeoutExpired:
+                continue
+            live.remove(p)
+            if p.returncode != 0 and rc == 0:
+                rc = p.returncode
+                for q in live:
+                    q.terminate()                               # exactly the children started above
+    return rc
+
+
+def dry_run(args, rank, world):
+    """the multi-rank plumbing of this file without a device: rendezvous over gloo, the sharded Pipeline on a context stub, the
+    barrier + max-over-ranks reduction of the step time, ONE line from rank 0.  No frames, no kernels: value is null."""
+    import importlib
+    import torch
+    import torch.distributed as dist
+    from diasss_amd.pipeline import Pipeline, make_comm
+    mod, cls = os.environ["DSSS_BENCH_CTX"].split(":")
+    wl = WORKLOADS[args.workload]
+    F = wl["F"]
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    stub = getattr(importlib.import_module(mod), cls)(F)
+    if world > 1:
+        make_comm(stub, dist, rank, world)
+    pipe = Pipeline(F, rank=rank, world=world, dist=dist if world > 1 else None, ctx=stub)
+    pipe.N = [wl["N"]] * F; pipe.poses = [None] * F
+    t0 = time.perf_counter()
+    for _ in range(args.warmup + args.steps):
+        pipe.extract(); pipe.match(); pipe.optimize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64); dist.all_reduce(t, op=dist.ReduceOp.MAX); dt = float(t.item())
+    if rank == 0:
+        print(json.dumps({"metric": "sonar frames/sec end-to-end (extract+match+LM solve)", "value": None, "unit": "frames/s", "n_gpus": world, "steps": args.steps,
+                          "warmup": args.warmup, "ms_per_step": None, "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dry_run": True,
+                          "config": {"workload": wl["name"], "frames": F}}))
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -110,20 +173,29 @@ def main():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--pcie-steps", type=int, default=2, help="steps of the PCIe-inclusive leg (raw frames in page-locked host memory); 0 = skip")
     ap.add_argument("--jobs-in-flight", type=int, default=2, help="surveys overlapped in the extra throughput leg (1 = skip)")
+    ap.add_argument("--dry-run", action="store_true", help="plumbing check without a GPU (CPU test-suite): gloo ranks, the context class named by DSSS_BENCH_CTX "
+                                                           "(module:Class, a recording stub), no frames, no timing claim -- the line carries value null and dry_run true")
     args = ap.parse_args()
+
+    # `python bench.py --gpus N` started plainly (no torch.distributed.run): this process becomes the launcher.  It starts one
+    # child per GPU BEFORE anything here has touched the GPU (nothing is imported that could), hands them the rendezvous through
+    # the environment torch.distributed.run would have set, and exits with their status; rank 0 prints the JSON line.
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(launch_ranks(args.gpus, sys.argv[1:]))
 
     import torch
     import torch.distributed as dist
-    from diasss_amd import capi
-    from diasss_amd.pipeline import Pipeline, shard_frames
-    from diasss_amd.synth import Survey
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus %d needs torch.distributed.run with --nproc-per-node %d" % (args.gpus, args.gpus))
+        raise SystemExit("--gpus %d but WORLD_SIZE is %d" % (args.gpus, world))
+    if args.dry_run:
+        return dry_run(args, rank, world)
+    from diasss_amd import capi
+    from diasss_amd.pipeline import Pipeline, shard_frames
+    from diasss_amd.synth import Survey
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
     torch.cuda.set_device(local_rank)

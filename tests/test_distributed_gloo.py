@@ -30,9 +30,9 @@ class StubCtx:
     def features_allgather(self, F):                       # what dsss_features_allgather does: padded slices, own slice in place
         per = max(F * (r + 1) // self.world - F * r // self.world for r in range(self.world))
         buf = np.zeros((self.world, per * self.NB), np.uint8)
-        f0 = F * self.rank // self.world
-        for f, rec in self.have.items():
-            buf[self.rank, (f - f0) * self.NB:(f - f0 + 1) * self.NB] = rec
+        f0, f1 = F * self.rank // self.world, F * (self.rank + 1) // self.world
+        for f in range(f0, f1):                            # own frames only (a second step finds the others' records still there)
+            buf[self.rank, (f - f0) * self.NB:(f - f0 + 1) * self.NB] = self.have[f]
         self.fn(1, buf)
         for r in range(self.world):
             g0, g1 = F * r // self.world, F * (r + 1) // self.world
@@ -109,3 +109,24 @@ def test_frame_owner_matches_library():
         if world == 1:
             assert [L.dsss_comm_frame_owner(None, F, f) for f in range(F)] == own.tolist()
         assert (np.diff(own) >= 0).all() and own[0] == 0 and own[-1] == world - 1
+
+
+def test_bench_launches_its_own_ranks():
+    """`python bench.py --gpus 2` started plainly (no torch.distributed.run, WORLD_SIZE unset) starts one child per rank before
+    anything touches a GPU, and rank 0 prints ONE JSON line with n_gpus 2.  --dry-run: gloo ranks on the recording stub above
+    (this container has no GPU); the line says so and carries no value."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env["DSSS_BENCH_CTX"] = "tests.test_distributed_gloo:StubCtx"
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--workload", "smoke", "--dry-run"],
+                         env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["steps"] == 2 and rec["warmup"] == 1 and rec["dry_run"] is True and rec["value"] is None
+    # a rank that fails takes the launcher down with a non-zero status instead of leaving the others in a collective
+    env["DSSS_BENCH_CTX"] = "tests.test_distributed_gloo:NoSuchStub"
+    bad = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--workload", "smoke", "--dry-run"], env=env, capture_output=True, text=True, timeout=300)
+    assert bad.returncode != 0
