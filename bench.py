@@ -28,6 +28,8 @@ WORKLOADS = {
     # BASELINE.json configs[1..2]; "smoke" is for quick checks only
     "C2": dict(F=50, N=1000, M=512, name="50 synthetic 1000x512 frames, dense all-pairs"),
     "C3": dict(F=200, N=2000, M=1024, name="200 synthetic 2000x1024 frames, dense all-pairs"),
+    # BASELINE.json configs[4] on ONE GPU (the config names 8; the whole survey fits one 288 GB device): --workload C5
+    "C5": dict(F=1000, N=4000, M=2048, nfeatures=8000, name="1000 synthetic 4000x2048 frames, 8k kp/frame, dense all-pairs, long-trajectory pose graph"),
     "smoke": dict(F=6, N=700, M=480, name="6 synthetic 700x480 frames (not a BASELINE config)"),
 }
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy ceiling)
@@ -44,8 +46,12 @@ def cpu_baseline(sv, wl, n_frames, threads=1):
     ins = [sv.inputs(f) for f in range(n_frames)]
     O.lib()
 
+    po = None
+    if wl.get("nfeatures"):
+        po = O.orb_params(); po.nfeatures = wl["nfeatures"]
+
     def extract(f):
-        kps, desc, _, _ = O.detect_feature(raws[f])
+        kps, desc, _, _ = O.detect_feature(raws[f], None, po) if po is not None else O.detect_feature(raws[f])
         return kps, desc
     pool = ThreadPoolExecutor(max_workers=threads) if threads > 1 else None
     mp = (lambda fn, it: list(pool.map(fn, it))) if pool else (lambda fn, it: [fn(v) for v in it])
@@ -83,10 +89,10 @@ def cpu_baseline(sv, wl, n_frames, threads=1):
                        "all %d pairs + LC + pose graph %.1fs" % (threads, "" if threads == 1 else "s", n_frames, wl["F"], N, M, t_extract, len(pairs), t_rest)), o_poses, len(edges)
 
 
-def sample_parity(sv, n_frames, o_poses, o_edges, device):
+def sample_parity(sv, n_frames, o_poses, o_edges, device, nfeatures=None):
     """the HIP path on the CPU sample's frames against the oracle's trajectory (pose RMSE vs the oracle's batch LM)"""
     from diasss_amd.pipeline import Pipeline
-    pipe = Pipeline(n_frames, device=device)
+    pipe = Pipeline(n_frames, device=device, nfeatures=nfeatures)
     raws = [sv.frame(f) for f in range(n_frames)]
     ins = [sv.inputs(f) for f in range(n_frames)]
     poses, stats = pipe.run(raws, [i[0] for i in ins], [i[1] for i in ins], [i[2] for i in ins])
@@ -205,7 +211,12 @@ def main():
 
     wl = WORKLOADS[args.workload]
     F, N, M = wl["F"], wl["N"], wl["M"]
-    sv = Survey(F, N, M, seed=20240601 + sorted(WORKLOADS).index(args.workload), device="cuda:%d" % local_rank)
+    big = F * N * M > (1 << 32)                        # C5: 65 GB of frames -- device-side noise, no host-resident or second-context legs by default
+    if big:
+        args.pcie_steps = 0 if args.pcie_steps == 2 else args.pcie_steps
+        args.jobs_in_flight = 1 if args.jobs_in_flight == 2 else args.jobs_in_flight
+        args.cpu_frames = min(args.cpu_frames, 6)
+    sv = Survey(F, N, M, seed=20240601 + ["C2", "C3", "smoke", "C5"].index(args.workload), device="cuda:%d" % local_rank, noise_on_device=big)
     mine = shard_frames(F, rank, world)
     raws = [None] * F
     for f in mine:
@@ -213,7 +224,7 @@ def main():
     poses = [sv.inputs(f)[0] for f in range(F)]; alts = [sv.inputs(f)[1] for f in range(F)]; grs = [sv.inputs(f)[2] for f in range(F)]
     torch.cuda.synchronize()
 
-    pipe = Pipeline(F, device=local_rank, rank=rank, world=world, dist=dist if world > 1 else None)
+    pipe = Pipeline(F, device=local_rank, rank=rank, world=world, dist=dist if world > 1 else None, nfeatures=wl.get("nfeatures"))
 
     def barrier():
         if world > 1:
@@ -244,7 +255,11 @@ def main():
         prof = pipe.ctx.profile_get()
         pipe.ctx.profile(False)
         # mini-LM work: 3e4 flops per LM iteration and problem (+ one linearisation for the marginal covariance)
-        lc_iters = sum(int(pipe.ctx.lc_get(p)["iters"].sum()) + len(pipe.ctx.lc_get(p)) for p in range(len(pipe.src)))
+        act = [p for p in range(len(pipe.src)) if pipe.ctx.pair_is_active(p)]
+        lc_iters = 0
+        for p in act:
+            g = pipe.ctx.lc_get(p)
+            lc_iters += int(g["iters"].sum()) + len(g)
         if "lc" in prof and prof["lc"][1] > 0:
             prof["lc"] = (prof["lc"][0], prof["lc"][1], 3e4 * lc_iters)
         breakdown = {k: round(v[0], 3) for k, v in prof.items() if v[1] > 0}
@@ -253,8 +268,10 @@ def main():
     nkp = [pipe.ctx.features_get(f)[0].shape[0] for f in mine[:8]]
     tot_rows, tot_kp7 = pipe.ctx.match_total()
     active_pairs = sum(1 for p in range(len(pipe.src)) if pipe.ctx.pair_is_active(p))
-    if world > 1:
-        t = torch.tensor([active_pairs], dtype=torch.int64, device="cuda"); dist.all_reduce(t); active_pairs = int(t.item())
+    pairs_per_rank, active_per_rank = [len(pipe.src)], [active_pairs]
+    if world > 1:       # pairs go to the owner of their TARGET frame (contiguous blocks): rank r holds ~(2r+1)/world^2 of the dense pair list, but the
+        t = torch.zeros((2, world), dtype=torch.int64, device="cuda"); t[0, rank] = len(pipe.src); t[1, rank] = active_pairs   # ACTIVE pairs (the only ones that cost anything) follow the survey's geometry
+        dist.all_reduce(t); pairs_per_rank, active_per_rank = t[0].tolist(), t[1].tolist(); active_pairs = int(sum(active_per_rank))
 
     # ---- the same steps with the raw frames in page-locked HOST memory: the library streams them in under the extraction kernels
     # (SURVEY.md 8d lists the upload inside the metric; `value` stays the HBM-resident figure, this is the PCIe-inclusive one)
@@ -282,7 +299,7 @@ def main():
     inflight = None
     if args.jobs_in_flight > 1 and world == 1:
         import threading
-        pipes = [pipe] + [Pipeline(F, device=local_rank) for _ in range(args.jobs_in_flight - 1)]
+        pipes = [pipe] + [Pipeline(F, device=local_rank, nfeatures=wl.get("nfeatures")) for _ in range(args.jobs_in_flight - 1)]
         for p in pipes[1:]:
             p.run(raws, poses, alts, grs)
         barrier()
@@ -331,7 +348,7 @@ def main():
             "config": {"workload": wl["name"], "frames": F, "pings": N, "bins": M, "pairs": F * (F - 1) // 2, "active_pairs": active_pairs,
                        "active_pairs_note": "pairs whose geo bounding boxes intersect; the others are provably empty (FEAmatcher.cpp:84) and skipped",
                        "input": "raw float64 frames resident in HBM before the timed region (PCIe-inclusive figure: pcie_inclusive)",
-                       "kp_per_frame": int(np.mean(nkp)) if nkp else 0, "matches_rank0": tot_rows, "lc_problems_rank0": tot_kp7,
+                       "pairs_per_rank": pairs_per_rank, "active_pairs_per_rank": active_per_rank, "kp_per_frame": int(np.mean(nkp)) if nkp else 0, "matches_rank0": tot_rows, "lc_problems_rank0": tot_kp7,
                        "pg_stats": [float(s) for s in stats] if stats is not None else None,
                        "parallelism": "contiguous frame blocks over %d rank(s): RCCL all-gather of features, pairs to the owner of the target frame, pose graph sharded with one RCCL all-reduce of the reduced Hessian per LM trial" % world},
             "roofline": roof, "roofline_all_kernels": roof_all, "breakdown_ms": breakdown, "work_per_step": work, "pcie_inclusive": pcie, "throughput_surveys_in_flight": inflight,
@@ -342,7 +359,7 @@ def main():
         if args.cpu_frames > 0 and world == 1:
             nf = min(args.cpu_frames, F)
             out["cpu_baseline"], o_poses, o_edges = cpu_baseline(sv, wl, nf)
-            out["parity_vs_oracle_on_cpu_sample"] = sample_parity(sv, nf, o_poses, o_edges, local_rank)
+            out["parity_vs_oracle_on_cpu_sample"] = sample_parity(sv, nf, o_poses, o_edges, local_rank, wl.get("nfeatures"))
             nthr = min(os.cpu_count() or 1, 32)
             if nthr > 1:                                        # the same sample on the host's cores (a reported extra, not the baseline)
                 out["cpu_baseline_allcores"] = cpu_baseline(sv, wl, nf, threads=nthr)[0]

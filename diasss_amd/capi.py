@@ -129,6 +129,8 @@ class Context:
         if getattr(self, "h", None):
             self.L.dsss_destroy(self.h)
             self.h = None
+        for k in ("_keep", "_addr_cache", "_pinned"):      # nothing of the caller's stays referenced by a closed context
+            self.__dict__.pop(k, None)
 
     def __del__(self):
         try:
@@ -215,16 +217,6 @@ class Context:
         device tensors)"""
         n = len(ids)
         self._keep = getattr(self, "_keep", {})
-        # A survey that is submitted again as the SAME Python objects (same lists holding the same arrays / tensors, as a
-        # benchmark loop does) reuses the marshalled pointer tables: building them costs 0.7 ms of Python per 200 frames.
-        # (Identity of every element is checked; a tensor whose storage is replaced in place must come as a new object.)
-        fs = self.__dict__.get("_fs_cache")
-        if fs is not None and fs[0] is raws and fs[1] is poses and fs[2] is alts and fs[3] is grs and fs[4] == (n, tuple(ids), tuple(Ns), tuple(Ms)) \
-                and all(x is y for x, y in zip(raws, fs[5])) and all(x is y for x, y in zip(poses, fs[6])) \
-                and all(x is y for x, y in zip(alts, fs[7])) and all(x is y for x, y in zip(grs, fs[8])):
-            a_ids, a_N, a_M, p_raw, p_pose, p_alt, p_gr = fs[9]
-            self._chk(self.L.dsss_frames_set(self.h, n, _ptr(a_ids), _ptr(p_raw), _ptr(a_N), _ptr(a_M), _ptr(p_pose), _ptr(p_alt), _ptr(p_gr)), "dsss_frames_set")
-            return
         cache = self.__dict__.setdefault("_addr_cache", {})    # id(array) -> (array, address) of the host geometry arrays: a survey re-submits the
                                                                 # same ones every step, and 600 dtype / contiguity checks + look-ups cost a millisecond
 
@@ -250,9 +242,6 @@ class Context:
         a_ids = np.ascontiguousarray(ids, np.int32); a_N = np.ascontiguousarray(Ns, np.int32); a_M = np.ascontiguousarray(Ms, np.int32)
         p_raw, p_pose, p_alt, p_gr = ptrs(raws), ptrs(poses), ptrs(alts), ptrs(grs)       # locals keep the arrays alive over the call
         self._chk(self.L.dsss_frames_set(self.h, n, _ptr(a_ids), _ptr(p_raw), _ptr(a_N), _ptr(a_M), _ptr(p_pose), _ptr(p_alt), _ptr(p_gr)), "dsss_frames_set")
-        if isinstance(raws, list) and isinstance(poses, list) and isinstance(alts, list) and isinstance(grs, list):
-            self._fs_cache = (raws, poses, alts, grs, (n, tuple(ids), tuple(Ns), tuple(Ms)), list(raws), list(poses), list(alts), list(grs),
-                              (a_ids, a_N, a_M, p_raw, p_pose, p_alt, p_gr))
 
     def extract(self, fid):
         n = C.c_int(0)

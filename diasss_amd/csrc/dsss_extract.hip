@@ -968,7 +968,7 @@ static ex_layout make_layout(int N, const level_geom& g, int kcap)
 
 // extraction of a list of frames, batched: every stage is one launch for the whole batch (the pyramid: one per level),
 // about twenty launches and one host synchronisation per batch of up to EX_BATCH frames.
-static int extract_frames(dsss_ctx* c, const int* ids, int n, bool keep_taps)
+static int extract_frames_impl(dsss_ctx* c, const int* ids, int n, bool keep_taps)
 {
     if (n <= 0) return DSSS_OK;
     int rc = dsss_ensure_store(c); if (rc) return rc;
@@ -1145,6 +1145,16 @@ static int extract_frames(dsss_ctx* c, const int* ids, int n, bool keep_taps)
         }
     }
     return DSSS_OK;
+}
+
+// Error exits of the batch loop can leave asynchronous uploads FROM CALLER MEMORY queued on the copy stream (the upload of batch
+// k + 1 is issued before the kernels of batch k have run): no error is returned before those copies have finished, so the caller's
+// page-locked images are free again whenever dsss_extract* returns, with or without an error (include/dsss.h, dsss_frame_set).
+static int extract_frames(dsss_ctx* c, const int* ids, int n, bool keep_taps)
+{
+    const int rc = extract_frames_impl(c, ids, n, keep_taps);
+    if (rc != DSSS_OK) { (void)hipStreamSynchronize(c->xs[1]); (void)hipStreamSynchronize(c->stream); (void)hipGetLastError(); }
+    return rc;
 }
 
 extern "C" {

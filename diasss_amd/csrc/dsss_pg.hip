@@ -143,22 +143,24 @@ __device__ inline double block_sum256(double v, double* s_w)
 }
 
 // Ownership with several ranks (dsss_comm.hip): a rank owns the poses [mp0, mp1); chain factor k belongs to the owner of pose k,
-// LC edge (a, b) to the owner of its target pose b.  Every kernel below skips what the rank does not own; with one rank
-// [mp0, mp1) is everything.
-__device__ inline bool pg_owned_factor(int k, int n, const int* __restrict__ eb, int mp0, int mp1)
+// LC edge (a, b) to the owner of its HIGHER pose eo = max(a, b) -- the rule the analysis builds the interface on (dsss_pg_sym.cpp:
+// "a factor belongs to the rank of its higher pose and adds to the diagonal block of the lower one").  The pipeline's own edges
+// have a < b, so eo = b there; dsss_posegraph_solve_edges also takes a > b.  Every kernel below skips what the rank does not
+// own; with one rank [mp0, mp1) is everything.
+__device__ inline bool pg_owned_factor(int k, int n, const int* __restrict__ eo, int mp0, int mp1)
 {
-    const int p = k < n ? k : eb[k - n];
+    const int p = k < n ? k : eo[k - n];
     return p >= mp0 && p < mp1;
 }
 __global__ __launch_bounds__(256) void pg_linearize_kernel(int n, int ne, const pose_t* __restrict__ X, const pose_t* __restrict__ meas,
-                                                           pg_weights W, const int* __restrict__ ea, const int* __restrict__ eb,
+                                                           pg_weights W, const int* __restrict__ ea, const int* __restrict__ eb, const int* __restrict__ eo,
                                                            const pose_t* __restrict__ emeas, const double* __restrict__ ew,
                                                            double* __restrict__ r, double* __restrict__ Ji, double* __restrict__ partial, int mp0, int mp1)
 {
     __shared__ double s_w[4];
     const int k = blockIdx.x * 256 + threadIdx.x;
     double e2 = 0;
-    if (k < n + ne && pg_owned_factor(k, n, eb, mp0, mp1)) {
+    if (k < n + ne && pg_owned_factor(k, n, eo, mp0, mp1)) {
         double rr[6], J[36];
         factor_eval(k, n, X, meas, W, ea, eb, emeas, ew, rr, Ji ? J : nullptr);
         for (int a = 0; a < 6; ++a) { e2 += rr[a] * rr[a]; if (r) r[(size_t)k * 6 + a] = rr[a]; }
@@ -186,7 +188,7 @@ __global__ __launch_bounds__(6 * PG_ASM_POSES) void pg_assemble_kernel(int n, pg
                                                           const int* __restrict__ adj_ptr, const int* __restrict__ adj_edge,
                                                           const double* __restrict__ ew, const double* __restrict__ lambda_ptr,
                                                           double* __restrict__ D, double* __restrict__ C, double* __restrict__ g,
-                                                          const int* __restrict__ eb, int mp0, int mp1)
+                                                          const int* __restrict__ eo, int mp0, int mp1)
 {
     const int i = blockIdx.x * PG_ASM_POSES + threadIdx.x / 6, a = threadIdx.x % 6;
     if (i >= n) return;
@@ -218,7 +220,7 @@ __global__ __launch_bounds__(6 * PG_ASM_POSES) void pg_assemble_kernel(int n, pg
     }
     for (int p = adj_ptr[i]; p < adj_ptr[i + 1]; ++p) {
         const int code = adj_edge[p], e = code >> 1, second = code & 1;
-        if (eb[e] < mp0 || eb[e] >= mp1) continue;             // the edge belongs to another rank
+        if (eo[e] < mp0 || eo[e] >= mp1) continue;             // the edge belongs to another rank
         const double* rr = r + (size_t)(n + e) * 6;
         if (second) {
             const double wa = ew[(size_t)e * 6 + a];
@@ -478,12 +480,12 @@ __global__ __launch_bounds__(256) void pg_scatter_base_kernel(int ns, const int*
 // LC off-diagonal blocks H(a, b) = Ji^T W (added after the chain couplings; (a,b) is unique per edge)
 __global__ __launch_bounds__(256) void pg_scatter_lc_kernel(int n, int ne, int ns, const double* __restrict__ Ji, const double* __restrict__ ew,
                                                             const int* __restrict__ dest, double* __restrict__ Lvals, double* __restrict__ aval,
-                                                            double* __restrict__ aval_if, const int* __restrict__ eb, int mp0, int mp1)
+                                                            double* __restrict__ aval_if, const int* __restrict__ eo, int mp0, int mp1)
 {
     const long long t = (long long)blockIdx.x * 256 + threadIdx.x;          // one thread per element of the 6 x 6 block
     const int e = (int)(t / 36), el = (int)(t - 36LL * e), a = el / 6, b = el - 6 * a;
     if (e >= ne) return;
-    if (eb[e] < mp0 || eb[e] >= mp1) return;
+    if (eo[e] < mp0 || eo[e] >= mp1) return;
     const int code = dest[2 * ns - 1 + e];
     const double h_ab = Ji[(size_t)(n + e) * 36 + b * 6 + a] * ew[(size_t)e * 6 + b];               // (Ji^T W)(a, b)
     if (code >= 0) Lvals[(size_t)(code >> 1) * 36 + ((code & 1) ? b * 6 + a : el)] += h_ab;
@@ -1572,7 +1574,7 @@ __global__ __launch_bounds__(256) void pg_backsub_kernel(int nseg, const int* __
 }
 
 // 0.5 * || J delta + r ||^2 over all factors (linear.error(delta))
-__global__ __launch_bounds__(256) void pg_linerr_kernel(int n, int ne, pg_weights W, const int* __restrict__ ea, const int* __restrict__ eb,
+__global__ __launch_bounds__(256) void pg_linerr_kernel(int n, int ne, pg_weights W, const int* __restrict__ ea, const int* __restrict__ eb, const int* __restrict__ eo,
                                                         const double* __restrict__ ew, const double* __restrict__ r, const double* __restrict__ Ji,
                                                         const double* __restrict__ delta, double* __restrict__ partial, int mp0, int mp1)
 {
@@ -1583,7 +1585,7 @@ __global__ __launch_bounds__(256) void pg_linerr_kernel(int n, int ne, pg_weight
 #pragma unroll
     for (int it = 0; it < 6; ++it) {
         const int el = it * 256 + threadIdx.x, k = blockIdx.x * 256 + el / 6, a = el % 6;
-        if (k < n + ne && pg_owned_factor(k, n, eb, mp0, mp1)) {
+        if (k < n + ne && pg_owned_factor(k, n, eo, mp0, mp1)) {
             int i = -1, j; double wa;
             if (k == 0) { j = 0; wa = W.prior[a]; }
             else if (k < n) { i = k - 1; j = k; wa = W.odo[a]; }
@@ -1833,9 +1835,9 @@ static int pg_solve_impl(dsss_ctx* c, const double* dr6, int total, const dsss_l
       const double so[6] = { wgt1 * PI / 180, wgt1 * PI / 180, 0.1 * wgt1 * wgt2 * PI / 180, wgt1 * wgt2, wgt1 * wgt2, wgt1 };
       for (int k = 0; k < 6; ++k) { W.prior[k] = 1.0 / 0.000001; W.odo[k] = 1.0 / so[k]; } }
     // DR poses, measurements and initial values are produced on the device (pg_init_kernel) further down
-    std::vector<int> ea(ne), eb(ne); std::vector<pose_t> emeas(ne); std::vector<double> ew((size_t)ne * 6);
+    std::vector<int> ea(ne), eb(ne), eo(ne); std::vector<pose_t> emeas(ne); std::vector<double> ew((size_t)ne * 6);
     for (int e = 0; e < ne; ++e) {
-        ea[e] = edges[e].a; eb[e] = edges[e].b;
+        ea[e] = edges[e].a; eb[e] = edges[e].b; eo[e] = std::max(edges[e].a, edges[e].b);
         if (ea[e] < 0 || ea[e] >= n || eb[e] < 0 || eb[e] >= n || ea[e] == eb[e]) DSSS_FAIL(c, DSSS_E_ARG, "LC edge %d out of range", e);
         for (int k = 0; k < 9; ++k) emeas[e].R[k] = edges[e].rel[k];
         for (int k = 0; k < 3; ++k) emeas[e].t[k] = edges[e].rel[9 + k];
@@ -1975,7 +1977,7 @@ static int pg_solve_impl(dsss_ctx* c, const double* dr6, int total, const dsss_l
     { std::vector<int> fill(adj_ptr.begin(), adj_ptr.end() - 1);
       for (int e = 0; e < ne; ++e) { adj_edge[fill[ea[e]]++] = e << 1; adj_edge[fill[eb[e]]++] = (e << 1) | 1; } }
     // ---- early device set-up (nothing here reads S)
-    pose_t *d_X, *d_Xn, *d_meas, *d_emeas; int *d_ea, *d_eb, *d_adj_ptr, *d_adj_edge, *d_perm;
+    pose_t *d_X, *d_Xn, *d_meas, *d_emeas; int *d_ea, *d_eb, *d_eo, *d_adj_ptr, *d_adj_edge, *d_perm;
     double *d_ew, *d_r, *d_Ji, *d_D, *d_C, *d_g, *d_delta, *d_E, *d_Dl, *d_gi, *d_sDL, *d_sDR, *d_sGL, *d_sGR, *d_sS, *d_L, *d_x, *d_part, *d_scal;
     double *d_F, *d_R, *d_ubin, *d_aval;
     int *d_colptr, *d_rowidx, *d_rlptr, *d_rlcol, *d_rlpos, *d_rlrow, *d_binptr, *d_bincols, *d_dest, *d_fail, *d_map; long long* d_mapptr;
@@ -1984,7 +1986,7 @@ static int pg_solve_impl(dsss_ctx* c, const double* dr6, int total, const dsss_l
     double* d_red;
     const int nf = n + ne, nblk = (nf + 255) / 256;
     TRY(dv.alloc(c, &d_X, n)); TRY(dv.alloc(c, &d_Xn, n)); TRY(dv.alloc(c, &d_meas, n)); TRY(dv.upload(c, &d_emeas, emeas));
-    TRY(dv.upload(c, &d_ea, ea)); TRY(dv.upload(c, &d_eb, eb)); TRY(dv.upload(c, &d_ew, ew));
+    TRY(dv.upload(c, &d_ea, ea)); TRY(dv.upload(c, &d_eb, eb)); TRY(dv.upload(c, &d_eo, eo)); TRY(dv.upload(c, &d_ew, ew));
     TRY(dv.upload(c, &d_adj_ptr, adj_ptr)); TRY(dv.upload(c, &d_adj_edge, adj_edge));
     TRY(dv.alloc(c, &d_r, (size_t)nf * 6)); TRY(dv.alloc(c, &d_Ji, (size_t)nf * 36));
     TRY(dv.alloc(c, &d_D, (size_t)n * 36)); TRY(dv.alloc(c, &d_C, (size_t)n * 36)); TRY(dv.alloc(c, &d_g, (size_t)n * 6)); TRY(dv.alloc(c, &d_delta, (size_t)n * 6));
@@ -2021,7 +2023,7 @@ static int pg_solve_impl(dsss_ctx* c, const double* dr6, int total, const dsss_l
         return DSSS_OK;
     };
     auto error_of = [&](const pose_t* Xd, double* out) -> int {
-        hipLaunchKernelGGL(pg_linearize_kernel, dim3(nblk), dim3(256), 0, st, n, ne, Xd, d_meas, W, d_ea, d_eb, d_emeas, d_ew, (double*)nullptr, (double*)nullptr, d_part, mp0, mp1);
+        hipLaunchKernelGGL(pg_linearize_kernel, dim3(nblk), dim3(256), 0, st, n, ne, Xd, d_meas, W, d_ea, d_eb, d_eo, d_emeas, d_ew, (double*)nullptr, (double*)nullptr, d_part, mp0, mp1);
         hipLaunchKernelGGL(pg_final_sum_kernel, dim3(1), dim3(256), 0, st, d_part, nblk, 0.5, d_scal);
         double h3[3]; int f0 = 0;
         HCK(hipMemsetAsync(d_fail, 0, sizeof(int), st));
@@ -2066,7 +2068,7 @@ static int pg_solve_impl(dsss_ctx* c, const double* dr6, int total, const dsss_l
     // chunk ends onto the true separators)
     auto chain_part = [&]() {
         hipMemsetAsync(d_fail, 0, sizeof(int), st);
-        hipLaunchKernelGGL(pg_assemble_kernel, dim3((n + PG_ASM_POSES - 1) / PG_ASM_POSES), dim3(6 * PG_ASM_POSES), 0, st, n, W, d_r, d_Ji, d_adj_ptr, d_adj_edge, d_ew, d_scal + 3, d_D, d_C, d_g, d_eb, mp0, mp1);
+        hipLaunchKernelGGL(pg_assemble_kernel, dim3((n + PG_ASM_POSES - 1) / PG_ASM_POSES), dim3(6 * PG_ASM_POSES), 0, st, n, W, d_r, d_Ji, d_adj_ptr, d_adj_edge, d_ew, d_scal + 3, d_D, d_C, d_g, d_eo, mp0, mp1);
         hipLaunchKernelGGL(pg_segment_kernel, dim3((nseg1 + 15) / 16), dim3(256), 0, st, nseg1, d_ord1, d_sep1, d_D, d_C, d_g, d_E, d_Dl, d_gi, d_sDL, d_sDR, d_sGL, d_sGR, d_sS, d_fail, mp0, mp1);
         hipLaunchKernelGGL(pg_chain1_kernel, dim3((unsigned)(((long long)ns1 * 42 + 255) / 256)), dim3(256), 0, st, ns1, d_sep1, d_D, d_g, d_sDL, d_sDR, d_sGL, d_sGR, d_sS, d_D1, d_C1, d_g1, mp0, mp1);
         if (nseg > 0) hipLaunchKernelGGL(pg_segment_kernel, dim3((nseg + 15) / 16), dim3(256), 0, st, nseg, d_ord2, d_t2, d_D1, d_C1, d_g1, d_E1, d_Dl1, d_gi1, d_s2DL, d_s2DR, d_s2GL, d_s2GR, d_s2S, d_fail, kp0, kp1);
@@ -2074,7 +2076,7 @@ static int pg_solve_impl(dsss_ctx* c, const double* dr6, int total, const dsss_l
     const bool will_iterate = err > 0 && c->pg.max_iters > 0;
     bool pre_lin = false, pre_chain = false;
     if (will_iterate) {                              // first linearisation and the chain part of the first trial, before the analysis is in
-        hipLaunchKernelGGL(pg_linearize_kernel, dim3(nblk), dim3(256), 0, st, n, ne, d_X, d_meas, W, d_ea, d_eb, d_emeas, d_ew, d_r, d_Ji, d_part, mp0, mp1);
+        hipLaunchKernelGGL(pg_linearize_kernel, dim3(nblk), dim3(256), 0, st, n, ne, d_X, d_meas, W, d_ea, d_eb, d_eo, d_emeas, d_ew, d_r, d_Ji, d_part, mp0, mp1);
         hipLaunchKernelGGL(pg_final_sum_kernel, dim3(1), dim3(256), 0, st, d_part, nblk, 0.5, d_scal);
         HCK(hipMemcpyAsync(d_scal + 3, &lambda, sizeof(double), hipMemcpyHostToDevice, st));
         chain_part();
@@ -2177,7 +2179,7 @@ static int pg_solve_impl(dsss_ctx* c, const double* dr6, int total, const dsss_l
         cur = err;
         double oldLin = err;                                                   // linear error at delta = 0 == the error at X (same sum, already global)
         if (!pre_lin) {
-            hipLaunchKernelGGL(pg_linearize_kernel, dim3(nblk), dim3(256), 0, st, n, ne, d_X, d_meas, W, d_ea, d_eb, d_emeas, d_ew, d_r, d_Ji, d_part, mp0, mp1);
+            hipLaunchKernelGGL(pg_linearize_kernel, dim3(nblk), dim3(256), 0, st, n, ne, d_X, d_meas, W, d_ea, d_eb, d_eo, d_emeas, d_ew, d_r, d_Ji, d_part, mp0, mp1);
             hipLaunchKernelGGL(pg_final_sum_kernel, dim3(1), dim3(256), 0, st, d_part, nblk, 0.5, d_scal);
         }
         pre_lin = false;
@@ -2191,7 +2193,7 @@ static int pg_solve_impl(dsss_ctx* c, const double* dr6, int total, const dsss_l
                 pre_chain = false;
                 hipLaunchKernelGGL(pg_scatter_base_kernel, dim3((unsigned)(((long long)ns * 78 + 255) / 256)), dim3(256), 0, st, ns, d_t2, d_perm, d_D1, d_g1, d_s2DL, d_s2DR, d_s2GL, d_s2GR, d_s2S, d_dest, d_L, d_aval, d_x,
                                    d_ifslot, d_avalif, d_xif, kp0, kp1);
-                if (ne > 0) hipLaunchKernelGGL(pg_scatter_lc_kernel, dim3((unsigned)(((long long)ne * 36 + 255) / 256)), dim3(256), 0, st, n, ne, ns, d_Ji, d_ew, d_dest, d_L, d_aval, d_avalif, d_eb, mp0, mp1);
+                if (ne > 0) hipLaunchKernelGGL(pg_scatter_lc_kernel, dim3((unsigned)(((long long)ne * 36 + 255) / 256)), dim3(256), 0, st, n, ne, ns, d_Ji, d_ew, d_dest, d_L, d_aval, d_avalif, d_eo, mp0, mp1);
                 if (nbins > 0) { dsss_scope s1(c, DSSS_K_PG_SUBTREE);
                                  hipLaunchKernelGGL(pg_factor_subtree_kernel, dim3(nbins), dim3(256), 0, st, d_binptr + bin_lo, d_bincols, d_colptr, d_rlptr, d_rlcol, d_rlpos, d_mapptr, d_map, d_L, d_x, d_fail,
                                                     d_binroot_ptr + bin_lo, d_binroot_idx, d_broot_b, d_broot_uoff, d_broot_of_col, d_anc_first, d_anc_rel, d_ubin); }
@@ -2245,13 +2247,13 @@ static int pg_solve_impl(dsss_ctx* c, const double* dr6, int total, const dsss_l
                 if (nseg > 0) hipLaunchKernelGGL(pg_backsub_kernel, dim3((nseg + 31) / 32), dim3(256), 0, st, nseg, d_ord2, d_t2, d_C1, d_E1, d_Dl1, d_gi1, d_delta1, kp0, kp1);
                 hipLaunchKernelGGL(pg_sep_delta_kernel, dim3((ns1 + 255) / 256), dim3(256), 0, st, ns1, d_sep1, (const int*)nullptr, d_delta1, d_delta);
                 hipLaunchKernelGGL(pg_backsub_kernel, dim3((nseg1 + 31) / 32), dim3(256), 0, st, nseg1, d_ord1, d_sep1, d_C, d_E, d_Dl, d_gi, d_delta, mp0, mp1);
-                hipLaunchKernelGGL(pg_linerr_kernel, dim3(nblk), dim3(256), 0, st, n, ne, W, d_ea, d_eb, d_ew, d_r, d_Ji, d_delta, d_part, mp0, mp1);
+                hipLaunchKernelGGL(pg_linerr_kernel, dim3(nblk), dim3(256), 0, st, n, ne, W, d_ea, d_eb, d_eo, d_ew, d_r, d_Ji, d_delta, d_part, mp0, mp1);
                 hipLaunchKernelGGL(pg_final_sum_kernel, dim3(1), dim3(256), 0, st, d_part, nblk, 0.5, d_scal + 1);
             }
             ++nfact;
             // X and Xn swap between trials, so these two stay outside the captured graph
             hipLaunchKernelGGL(pg_retract_kernel, dim3((n + 255) / 256), dim3(256), 0, st, n, d_X, d_delta, d_Xn);
-            hipLaunchKernelGGL(pg_linearize_kernel, dim3(nblk), dim3(256), 0, st, n, ne, d_Xn, d_meas, W, d_ea, d_eb, d_emeas, d_ew, (double*)nullptr, (double*)nullptr, d_part, mp0, mp1);
+            hipLaunchKernelGGL(pg_linearize_kernel, dim3(nblk), dim3(256), 0, st, n, ne, d_Xn, d_meas, W, d_ea, d_eb, d_eo, d_emeas, d_ew, (double*)nullptr, (double*)nullptr, d_part, mp0, mp1);
             hipLaunchKernelGGL(pg_final_sum_kernel, dim3(1), dim3(256), 0, st, d_part, nblk, 0.5, d_scal + 2);
             HCK(hipGetLastError());
             double h[3]; int failed = 0;
@@ -2551,6 +2553,9 @@ int dsss_posegraph_update(dsss_ctx* c, int nframes, double* poses12, double* rpy
         const int rc = dsss_posegraph_select(c, nframes, fresh.data(), (int)fresh.size(), &ne);
         if (rc) return rc;
         // a target ping keeps ONE loop closure, the latest (optimizer.cpp:203-258 within a call; across calls the later set wins)
+        // (the accumulated edges are range-checked BEFORE they index anything: nframes may have gone down since the last update)
+        for (const dsss_lc_edge& e : c->pg_inc_edges)
+            if (e.a >= (int)total || e.b >= (int)total) DSSS_FAIL(c, DSSS_E_ARG, "an accumulated LC edge references ping %d of %zu: nframes went down; dsss_posegraph_reset first", std::max(e.a, e.b), total);
         if (ne > 0 && !c->pg_inc_edges.empty()) {
             std::vector<char> hit(total, 0);
             for (int e = 0; e < ne; ++e) hit[fresh[e].b] = 1;

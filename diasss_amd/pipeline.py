@@ -72,9 +72,13 @@ def make_comm(ctx, dist, rank, world):
 
 
 class Pipeline:
-    def __init__(self, F, device=0, rank=0, world=1, dist=None, min_overlap=None, ctx=None, force_collectives=False):
+    def __init__(self, F, device=0, rank=0, world=1, dist=None, min_overlap=None, ctx=None, force_collectives=False, nfeatures=None):
         self.F, self.rank, self.world, self.dist = F, rank, world, dist
         self.ctx = ctx if ctx is not None else capi.Context(max_frames=F, device=device)   # ctx injection: sharding tests
+        if nfeatures is not None:            # frame.cpp:180 hard-codes ORBextractor(2000, ...); BASELINE config 5 asks for 8000
+            _, op, _, _ = self.ctx.default_params()
+            op.nfeatures = int(nfeatures)
+            self.ctx.set_params(orb=op)
         self.min_overlap = min_overlap      # None: dense all-pairs (BASELINE configs); 0.4 reproduces diasss2.cpp:28,93
         if (world > 1 or force_collectives) and dist is not None and ctx is None:
             make_comm(self.ctx, dist, rank, world)       # a 1-rank RCCL communicator drives the same code path

@@ -45,8 +45,12 @@ class Survey:
     """F legs of N pings x M bins."""
 
     def __init__(self, F, N, M, seed=20240601, res=0.05, spacing_frac=0.39, drift_xy=0.002, yaw_bias_deg=0.03,
-                 noise=0.02, device="cpu", tile=2048):
+                 noise=0.02, device="cpu", tile=2048, noise_on_device=False):
         self.F, self.N, self.M, self.res, self.seed = F, N, M, res, seed
+        # sensor noise from the device's own generator (seeded per frame): the 1000 frames of BASELINE config 5 are 8 M pixels
+        # each, and the host generator below would spend a minute on them.  Another noise field than the host one, so a survey
+        # made with this switch is a different (equally seeded, equally reproducible) survey.
+        self.noise_on_device = noise_on_device
         self.device = torch.device(device)
         rng = np.random.default_rng(seed + 1)
         half = M // 2
@@ -114,8 +118,12 @@ class Survey:
         y = pose[:, 4:5] + g * torch.sin(ang)
         img = self._sample(x, y).to(torch.float64)
         # range-dependent gain ripple + additive sensor noise (seeded per frame)
-        gen = torch.Generator(device="cpu"); gen.manual_seed(self.seed * 1000 + f)
-        nz = torch.randn((N, M), generator=gen, dtype=torch.float32).to(dev).to(torch.float64)
+        if self.noise_on_device and dev.type != "cpu":
+            gen = torch.Generator(device=dev); gen.manual_seed(self.seed * 1000 + f)
+            nz = torch.randn((N, M), generator=gen, dtype=torch.float32, device=dev).to(torch.float64)
+        else:
+            gen = torch.Generator(device="cpu"); gen.manual_seed(self.seed * 1000 + f)
+            nz = torch.randn((N, M), generator=gen, dtype=torch.float32).to(dev).to(torch.float64)
         gain = 1.0 + 0.05 * torch.cos(g / 7.0)
         img = torch.clamp(img * gain + self.noise * nz, min=0.02) * 1000.0
         return img

@@ -97,7 +97,16 @@ int dsss_set_pg_partitions(dsss_ctx*, int nparts);
 
 /* ------------------------------------------------------------------ Frame (frame.h:19-20, frame.cpp:18-55)
  * Frame::Frame(id, img CV_64F NxM, pose CV_64F Nx6 [roll pitch yaw x y z], altitudes[N], ground_ranges[M/2], anno)
- * raw may stay resident in HBM (device pointer): nothing is copied back to the host.                     */
+ * raw may stay resident in HBM (device pointer): nothing is copied back to the host.
+ * LIFETIME OF raw (the reference's Frame keeps a ref-counted cv::Mat, frame.cpp:23-28; a C pointer has no such thing):
+ *   - device pointer: borrowed, must stay valid and unchanged until the frame is set again or the context is destroyed;
+ *   - pageable host pointer: copied before the call returns, free to reuse afterwards;
+ *   - PAGE-LOCKED host pointer (hipHostMalloc / hipHostRegister / torch pin_memory): NOT copied by this call -- the upload is
+ *     deferred to dsss_extract / dsss_extract_many, which stream the images in on a copy stream under the kernels of the
+ *     frames before them.  The buffer must stay valid and unchanged until the dsss_extract* call that covers this frame has
+ *     RETURNED (with or without an error: error exits drain the copy stream first).  Setting the frame again, or
+ *     destroying the context, before extracting it drops the pending upload without reading the buffer.
+ * pose6 / alt / grange are copied before the call returns.                                                 */
 int dsss_frame_set(dsss_ctx*, int id, const double* raw, int N, int M,
                    const double* pose6, const double* alt, const double* grange);
 /* the same for n frames in one call (arrays of per-frame arguments; raw[i] may be NULL; ids distinct).  The

@@ -409,3 +409,48 @@ def test_config_C3_scale_pose_graph_against_oracle_objective(orc):
         Rp = Rot.from_rotvec(rng.normal(0, 1e-5, (len(sel), 3))).as_matrix()
         xp[sel, :9] = np.einsum("nij,njk->nik", xp[sel, :9].reshape(-1, 3, 3), Rp).reshape(-1, 9)
         assert orc.pg_error_at(dr, oe, xp) > e1
+
+
+def test_config_C5_whole_pipeline_on_one_gpu():
+    """BASELINE config 5 end to end on ONE MI355X: 1000 frames of 4000 x 2048 (65.5 GB of float64 waterfall, generated on the
+    device), nfeatures 8000, dense all-pairs (499 500 pairs), reprojection, every mini-LM and the 4 M-pose graph.  No oracle can
+    run this size; the run is held to the size-independent properties of test_full_size_C3_properties and must be bit-reproducible."""
+    import time
+    import torch
+    from diasss_amd.pipeline import Pipeline
+    from diasss_amd.synth import Survey
+    F, N, M = 1000, 4000, 2048
+    free0 = torch.cuda.mem_get_info()[0]
+    sv = Survey(F, N, M, seed=20240601 + 4, device="cuda:0", noise_on_device=True)
+    t0 = time.time()
+    raws = [sv.frame(f) for f in range(F)]
+    torch.cuda.synchronize()
+    t_gen = time.time() - t0
+    ins = [sv.inputs(f) for f in range(F)]
+    poses, alts, grs = [i[0] for i in ins], [i[1] for i in ins], [i[2] for i in ins]
+    pipe = Pipeline(F, nfeatures=8000)
+    t0 = time.time(); out1, st1 = pipe.run(raws, poses, alts, grs); t1 = time.time() - t0
+    out1 = out1.copy(); st1 = np.array(st1)
+    edges = pipe.ctx.posegraph_select(F, cap=1 << 22)
+    rows, kp7 = pipe.ctx.match_total()
+    active = sum(1 for p in range(0, len(pipe.src)) if pipe.ctx.pair_is_active(p))
+    for f in (0, 1, 499, 999):
+        kps, desc, geo = pipe.ctx.features_get(f, cap=9000)
+        assert 4000 < len(kps) <= 8018                                       # nfeatures + 3 per level is the upper bound after the mask filter
+        assert (kps["x"] >= 0).all() and (kps["x"] < M).all() and (kps["y"] >= 0).all() and (kps["y"] < N).all()
+        assert (kps["octave"] >= 0).all() and (kps["octave"] < 6).all() and (kps["angle"] >= 0).all() and (kps["angle"] < 360.0001).all()
+        assert desc.any(axis=1).all() and np.isfinite(geo).all()
+    t0 = time.time(); out2, st2 = pipe.run(raws, poses, alts, grs); t2 = time.time() - t0
+    high_gb = (free0 - torch.cuda.mem_get_info()[0]) / 2**30
+    print("C5 whole pipeline: frames generated in %.1f s; first run %.2f s, second run %.3f s = %.0f frames/s; %d of %d pairs active, %d rows, %d LC problems, %d edges, "
+          "%d LM iterations, error %.4g -> %.4g; device memory in use %.0f GB" % (t_gen, t1, t2, F / t2, active, len(pipe.src), rows, kp7, len(edges), st1[0], st1[1], st1[2], high_gb))
+    assert len(pipe.src) == F * (F - 1) // 2 and active >= F - 1             # every pair of neighbouring legs overlaps
+    assert rows > 50000 and 0 < kp7 <= rows
+    assert len(edges) > 20000 and (np.diff(edges["b"]) > 0).all()             # one edge per target ping, ascending: the reference's loop order
+    assert (edges["a"] != edges["b"]).all() and (edges["var"] > 0).all()
+    assert len(out1) == F * N and st1[0] >= 3 and st1[2] < 1e-6 * st1[1]      # 4 M poses; LM error before -> after
+    R = out1[:, :9].reshape(-1, 3, 3)
+    assert np.isfinite(out1).all() and np.abs(np.einsum("nij,nkj->nik", R, R) - np.eye(3)).max() < 1e-9
+    assert (out2 == out1).all() and (np.array(st2) == st1).all()              # the whole path again: identical to the last bit
+    assert high_gb < 250.0
+    pipe.close()

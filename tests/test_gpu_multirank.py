@@ -129,3 +129,136 @@ def test_rccl_one_rank_communicator():
     (rank, out, stats, repro, cs), = _run(1, "nccl", 29700 + os.getpid() % 1000)
     assert stats[0] == ref_stats[0] and np.abs(out - ref).max() < 1e-9 and repro
     assert cs[1] == 1 and cs[3] > 0
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# BASELINE config 4 ("200 frames sharded 8 ways") as far as ONE GPU can take it: the full C3 survey (200 x 2000 x 1024, dense
+# all-pairs) with the pose graph cut into the 8 partitions of the 8-GPU layout on one rank, and with 2 ranks (gloo: RCCL
+# refuses two ranks on one device) that share the GPU -- feature all-gather, pairs to the owner of the target frame, edge
+# exchange, partitioned solve with ONE interface all-reduce per LM trial -- against the single-rank trajectory.
+C3 = dict(F=200, N=2000, M=1024, seed=20240601 + 1)
+
+
+def _c3_inputs(mine):
+    from diasss_amd.synth import Survey
+    sv = Survey(C3["F"], C3["N"], C3["M"], seed=C3["seed"], device="cuda:0")
+    raws = [sv.frame(f) if f in mine else None for f in range(C3["F"])]
+    ins = [sv.inputs(f) for f in range(C3["F"])]
+    return raws, [i[0] for i in ins], [i[1] for i in ins], [i[2] for i in ins]
+
+
+def _c3_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+    from diasss_amd.pipeline import Pipeline, shard_frames
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    F = C3["F"]
+    raws, poses, alts, grs = _c3_inputs(set(shard_frames(F, rank, world)))
+    pipe = Pipeline(F, device=0, rank=rank, world=world, dist=dist)
+    out, stats = pipe.run(raws, poses, alts, grs)
+    torch.cuda.synchronize()
+    q.put((rank, out.copy(), np.array(stats), pipe.ctx.comm_stats()))
+    pipe.close()
+    dist.destroy_process_group()
+
+
+def test_config_C4_full_size_8_partitions_and_2_ranks():
+    from diasss_amd.pipeline import Pipeline
+    F = C3["F"]
+    raws, poses, alts, grs = _c3_inputs(set(range(F)))
+    pipe = Pipeline(F, device=0)
+    ref, ref_stats = pipe.run(raws, poses, alts, grs)
+    ref = ref.copy(); ref_stats = np.array(ref_stats)
+    n_edges = len(pipe.ctx.posegraph_select(F))
+    assert n_edges > 5000 and ref_stats[0] >= 3
+    span = np.abs(ref[:, 9:]).max()                                # the track spans hundreds of metres
+    pipe.ctx.set_pg_partitions(8)                                  # the 8-GPU layout of the solve, every partition on this rank
+    p8, s8 = pipe.run(raws, poses, alts, grs)
+    p8 = p8.copy()
+    d8 = np.abs(p8 - ref).max()
+    p8b, _ = pipe.run(raws, poses, alts, grs)
+    assert (p8b == p8).all()                                       # bit-reproducible
+    pipe.close()
+    del raws
+    import torch; torch.cuda.empty_cache()
+    res = _run_fn(_c3_worker, 2, 29900 + os.getpid() % 1000)
+    d2 = max(np.abs(out - ref).max() for _, out, _, _ in res)
+    print("C4 on one GPU: %d LC edges, %d LM iterations, track extent %.0f m; max |pose - single rank|: 8 partitions %.3g, 2 gloo ranks %.3g; "
+          "all-reduce bytes per rank %.1f MB in %d calls" % (n_edges, ref_stats[0], span, d8, d2, res[0][3][2] / 1e6, res[0][3][3]))
+    assert s8[0] == ref_stats[0] and abs(s8[2] - ref_stats[2]) <= 1e-6 * ref_stats[2]
+    assert d8 < 1e-6 * max(1.0, span / 100.0)                      # another elimination order: rounding only (1e-6 per 100 m of track)
+    for rank, out, stats, cs in res:
+        assert stats[0] == ref_stats[0] and abs(stats[2] - ref_stats[2]) <= 1e-6 * ref_stats[2]
+        assert np.abs(out - ref).max() < 1e-6 * max(1.0, span / 100.0)
+        assert cs[1] == 2 and cs[3] > 0 and cs[2] > 0
+    assert (res[0][1] == res[1][1]).all()                          # identical bits on both ranks
+
+
+def _run_fn(fn, world, port, timeout=900):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=fn, args=(r, world, port, q)) for r in range(world)]
+    for p in procs: p.start()
+    res = sorted([q.get(timeout=timeout) for _ in range(world)], key=lambda t: t[0])
+    for p in procs: p.join(timeout=120)
+    return res
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# dsss_posegraph_solve_edges takes loop closures in either direction (a > b as well as a < b).  A factor belongs to the rank of
+# its HIGHER pose (the rule the analysis builds the interface on); an edge that crosses ranks with a > b used to be evaluated by
+# the owner of b, against a pose it never updates.
+def _reversed_edge_graph():
+    from oracle import binding as orc
+    import ctypes as C
+    n = 24000
+    rng = np.random.default_rng(11)
+    dr = np.zeros((n, 6)); dr[:, 3] = 0.05 * np.arange(n); dr[:, 4] = 2.0 * np.sin(np.arange(n) / 500.0); dr[:, 2] = 0.05 * np.cos(np.arange(n) / 700.0)
+    ne = 300
+    hi = np.sort(rng.choice(np.arange(3000, n), ne, replace=False)); lo = (hi - rng.integers(500, 2900, ne)).astype(np.int64)
+    flip = rng.random(ne) < 0.5                                   # half of the edges are given as (higher, lower)
+    a = np.where(flip, hi, lo).astype(np.int32); b = np.where(flip, lo, hi).astype(np.int32)
+    edges = np.zeros(ne, orc.LCEDGE_DTYPE)
+    for e in range(ne):
+        Ta = orc.Pose(); Tb = orc.Pose(); Tr = orc.Pose()
+        orc.lib().orc_pose_from_rodrigues(orc.dp(np.ascontiguousarray(dr[a[e]])), C.byref(Ta))
+        orc.lib().orc_pose_from_rodrigues(orc.dp(np.ascontiguousarray(dr[b[e]])), C.byref(Tb))
+        orc.lib().orc_pose_between(C.byref(Ta), C.byref(Tb), C.byref(Tr))
+        rel = np.concatenate([np.array(Tr.R), np.array(Tr.t)]); rel[9:] += rng.normal(0, 0.05, 3)
+        edges["a"][e] = a[e]; edges["b"][e] = b[e]; edges["rel"][e] = rel; edges["var"][e] = [1e-5, 1e-5, 1e-4, 1e-2, 1e-2, 1e-2]
+    assert ((a > b) & ((a >= n // 2) != (b >= n // 2))).sum() > 5   # reversed edges that cross the 2-rank cut exist
+    return dr, edges
+
+
+def _rev_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    from diasss_amd import capi
+    from diasss_amd.pipeline import make_comm
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dr, edges = _reversed_edge_graph()
+    c = capi.Context(max_frames=2)
+    make_comm(c, dist, rank, world)
+    p, s = c.posegraph_solve_edges(dr, edges)
+    q.put((rank, p.copy(), np.array(s)))
+    c.close()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_reversed_edges_across_ranks(orc, world):
+    from diasss_amd import capi
+    dr, edges = _reversed_edge_graph()
+    c = capi.Context(max_frames=2)
+    ref, sref = c.posegraph_solve_edges(dr, edges)
+    c.close()
+    o_poses, o_stats = orc.pg_solve(dr, edges)                     # the oracle takes either direction as well
+    assert sref[0] == o_stats[0] and np.abs(ref - o_poses).max() < 1e-6
+    res = _run_fn(_rev_worker, world, 29300 + os.getpid() % 500 + world)
+    for rank, p, s in res:
+        assert s[0] == sref[0] and np.abs(p - ref).max() < 1e-8, (rank, np.abs(p - ref).max())
+    for r in range(1, world):
+        assert (res[0][1] == res[r][1]).all()
