@@ -247,7 +247,7 @@ def main():
         dt = float(t.item())
 
     # ---- per-kernel timing pass (HIP events on the library's stream), outside the timed region
-    breakdown, roof, roof_all, work = None, None, None, None
+    breakdown, roof, roof_groups, roof_all, work = None, None, None, None, None
     if not args.no_roofline:
         pipe.ctx.profile(True); pipe.ctx.profile_reset()
         pipe.run(raws, poses, alts, grs)
@@ -263,7 +263,8 @@ def main():
         if "lc" in prof and prof["lc"][1] > 0:
             prof["lc"] = (prof["lc"][0], prof["lc"][1], 3e4 * lc_iters)
         breakdown = {k: round(v[0], 3) for k, v in prof.items() if v[1] > 0}
-        roof, roof_all = roofline(prof, args.workload)
+        trials = prof["pg_subtree"][1] // 2 if "pg_subtree" in prof and prof["pg_subtree"][1] > 0 else 1     # bins forward + backward once per LM trial
+        roof, roof_groups, roof_all = roofline(prof, args.workload, wl, trials)
         work = {k: ("%.3g flop" if k in FLOP_SLOTS else "%.3g B") % v[2] for k, v in prof.items() if v[1] > 0 and v[2] > 0}
     nkp = [pipe.ctx.features_get(f)[0].shape[0] for f in mine[:8]]
     tot_rows, tot_kp7 = pipe.ctx.match_total()
@@ -351,7 +352,7 @@ def main():
                        "pairs_per_rank": pairs_per_rank, "active_pairs_per_rank": active_per_rank, "kp_per_frame": int(np.mean(nkp)) if nkp else 0, "matches_rank0": tot_rows, "lc_problems_rank0": tot_kp7,
                        "pg_stats": [float(s) for s in stats] if stats is not None else None,
                        "parallelism": "contiguous frame blocks over %d rank(s): RCCL all-gather of features, pairs to the owner of the target frame, pose graph sharded with one RCCL all-reduce of the reduced Hessian per LM trial" % world},
-            "roofline": roof, "roofline_all_kernels": roof_all, "breakdown_ms": breakdown, "work_per_step": work, "pcie_inclusive": pcie, "throughput_surveys_in_flight": inflight,
+            "roofline": roof, "roofline_stages": roof_groups, "roofline_all_kernels": roof_all, "breakdown_ms": breakdown, "work_per_step": work, "pcie_inclusive": pcie, "throughput_surveys_in_flight": inflight,
         }
         if world > 1:
             cs = pipe.ctx.comm_stats()
@@ -369,52 +370,67 @@ def main():
         dist.destroy_process_group()
 
 
-F64_PEAK_TFLOPS = 78.6   # MI355X FP64 vector/matrix peak (AMD spec sheet; MI355X_MICROARCH.md lists no f64 MFMA row)
-# matcher ceiling: one gate + Hamming evaluation is about 30 VALU operations (5 f64 + 8 xor + 8 popcount + compares); the chip
-# issues 256 CUs x 4 SIMDs x 32 lanes per cycle at 2.4 GHz
-MATCH_PEAK_GEVALS = 256 * 4 * 32 * 2.4 / 30.0
-# FAST ceiling: the arc value of 64 pixels costs about 127 wave instructions (78 packed min/max + 8 sub + 8 perm + 17 LDS byte
-# loads + index arithmetic: the ISA of fast_cells_kernel's arc loop); a SIMD issues one wave instruction per
-# 4 cycles, 1024 SIMDs at 2.4 GHz.  Non-max suppression, threshold fallback and compaction come on top and are not priced.
-FAST_PEAK_GPX = 256 * 4 * 2.4 / 4.0 * 64 / 127.0
+F64_PEAK_TFLOPS = 78.6   # MI355X FP64 vector/matrix peak (AMD spec sheet; v_mfma_f64_16x16x4_f64 measured at 64 cycles: the two peaks coincide)
+# ONE measured constant for everything that is priced in vector instructions: the chip-wide wave-instruction issue rate of the
+# full-rate class at 8 wavefronts per SIMD, tools/ubench/valu_issue.hip on MI355X (profiles/r03_ubench_valu_issue.txt: v_fma_f32
+# 1015 G/s = one per 2.4 nominal cycles per SIMD; v_add_u32 / v_xor_b32 786-844).  The half-rate classes (packed 16-bit min/max,
+# v_bcnt, v_dot4, v_perm, three-operand integer ops, every f64 op) issue at 490-570 G/s: a kernel made of them fills at most ~0.5.
+VALU_ISSUE_PER_S = 1015e9
+# comparisons/s against `lanes x clock / ~30 operations per comparison` -- with the measured issue rate for
+# lanes x clock.  (The kernel itself spends 13.4 lane-instructions per gate + Hamming evaluation, PMC; it is NOT priced against that.)
+MATCH_PEAK_GEVALS = VALU_ISSUE_PER_S * 64 / 30.0 / 1e9
 
-# what bounds each timed kernel.  The streaming kernels are priced in algorithmic HBM bytes, the
-# pose-graph factorisation kernels in f64 flops against the f64 matrix peak they should eventually run at.
-FLOP_SLOTS = {"pg_acc", "pg_diag", "pg_trsm", "pg_bwd", "lc"}
+FLOP_SLOTS = {"pg_acc", "pg_diag", "pg_trsm", "pg_bwd", "pg_subtree", "lc"}
 MFMA_SLOTS = {"pg_acc", "pg_diag", "pg_trsm"}             # kernels whose flops run on v_mfma_f64_16x16x4_f64
-
+# stages = kernel groups of SURVEY.md 8(d); the headline `roofline` is the group with the most GPU time
+GROUPS = {
+    "extract": ("hbm", ["row_reduce", "pre_misc", "normalize", "pyramid", "fast", "fast_compact", "quadtree", "desc", "filter"]),
+    "match": ("valu_int", ["match", "scc", "rows"]),
+    "lc": ("valu_f64", ["lc"]),
+    "pg_factor": ("mfma", ["pg_subtree", "pg_asm", "pg_diag", "pg_trsm", "pg_acc", "pg_bwd"]),
+}
+GROUP_NOTE = {
+    "extract": "SURVEY 8(d): 29.4 N M algorithmic bytes per frame (raw f64 twice, L0, pyramid r/w, FAST reads, blur r/w) over the summed time of the extraction kernels, against HBM",
+    "pg_factor": "multifrontal factorisation + solves of the reduced pose-graph system, all kernels of one LM trial (bins, extend-add, panel Cholesky, row solve, trailing update, "
+                 "back-substitution): algorithmic f64 flops of one factorisation over their summed time, against the f64 matrix peak.  Latency-bound: ~100 dependent short launches per trial",
+    "match": "SURVEY 8(d) K9: Na x Nb gate + Hamming evaluations of the active pairs against lanes x clock / 30 operations, lanes x clock = the measured issue rate",
+    "lc": "f64 VALU, 3e4 flop per LM iteration and match (SURVEY 8(d) K11)",
+}
 
 # profile slot -> kernel name in the rocprofv3 tables under profiles/
 SLOT_KERNEL = {"row_reduce": "row_reduce_kernel", "normalize": "normalize_kernel", "pyramid": "resize_kernel", "fast": "fast_cells_kernel",
                "desc": "orient_desc_kernel", "quadtree": "quadtree_kernel", "lc": "lc_kernel", "match": "match_nn_kernel<false>",
-               "pg_acc": "pg_front_syrk_kernel", "pg_diag": "pg_front_diag4_kernel", "pg_trsm": "pg_front_trsm2_kernel", "pg_bwd": "pg_front_bwd2_kernel"}
-NOTES = {"pg_acc": "trailing update of the multifrontal fronts, 64 x 64 tiles on v_mfma_f64_16x16x4_f64 (K = one 96-column panel): the bulk of the factorisation flops; launches are short, so the matrix cores idle between levels",
-         "pg_diag": "96-column panel Cholesky in the registers of four wavefronts: 24 dependent 4 x 4 pivot blocks (about 1950 cycles each: readlane, 4 x rsq + Newton, LDS, MFMA, LDS, MFMA), every rank-4 update one v_mfma_f64_16x16x4_f64 per tile; latency-bound",
-         "fast": "VALU-bound: packed 16-bit sliding min/max over the 16-pixel ring; work = pixels of all pyramid levels; frac prices the arc loop alone (127 instructions per 64 pixels), valu_issue_util is the share of the chip's vector issue slots the whole kernel fills (PMC instruction count over the live duration)",
-         "pg_trsm": "row solve below the panel by the same 4-column MFMA steps", "pg_bwd": "latency-bound matvec + block back-substitution per panel",
-         "match": "VALU-bound by design: (Na + Nb) x 48 B per directed pair against Na x Nb gate + popcount evaluations",
-         "lc": "f64 VALU, 16 lanes per 15-DoF problem; flops = 3e4 per LM iteration (DESIGN.md section 4) x iterations summed over the problems"}
+               "pg_acc": "pg_front_syrk_kernel", "pg_diag": "pg_front_diag4_kernel", "pg_trsm": "pg_front_trsm2_kernel", "pg_bwd": "pg_front_bwd2_kernel",
+               "pg_subtree": "pg_factor_subtree_kernel", "pg_asm": "pg_front_asm_kernel"}
+
+
+def _latest(pattern):
+    import glob
+    hits = sorted(glob.glob(os.path.join(ROOT, "profiles", pattern)))
+    return hits[-1] if hits else None
 
 
 def pmc_traffic(workload):
-    """HBM bytes per launch from the committed rocprofv3 PMC passes: profiles/r02_pmc_hbm_traffic_<workload>.csv, written by
-    tools/pmc_summary.py (FETCH_SIZE x2 only for the kernels whose reads are 16-byte-per-lane streams, + WRITE_SIZE).
-    Returns kernel -> (bytes, calibrated)"""
-    path = os.path.join(ROOT, "profiles", "r02_pmc_hbm_traffic_%s.csv" % workload)
+    """HBM bytes per launch from the committed rocprofv3 PMC passes of the latest round: profiles/rNN_pmc_hbm_traffic_<workload>.csv,
+    written by tools/pmc_summary.py (separate FETCH_SIZE and WRITE_SIZE passes; FETCH_SIZE x2 only for the kernels whose reads are
+    16-byte-per-lane streams, as MI355X_MICROARCH.md prescribes).  Returns kernel -> (bytes, calibrated)"""
+    path = _latest("r*_pmc_hbm_traffic_%s.csv" % workload)
     out = {}
-    if os.path.exists(path):
+    if path:
         import csv
         with open(path) as fh:
             for r in csv.DictReader(fh):
-                out[r["kernel"]] = (float(r["fetch_bytes_per_launch_used"]) + float(r["write_bytes_per_launch"]), bool(int(r["fetch_calibrated_x2"])))
+                k = r["kernel"][5:] if r["kernel"].startswith("void ") else r["kernel"]
+                out[k] = (float(r["fetch_bytes_per_launch_used"]) + float(r["write_bytes_per_launch"]), bool(int(r["fetch_calibrated_x2"])))
+                out.setdefault(k.split("<")[0], out[k])
     return out
 
 
 def pmc_valu(workload):
-    """vector instructions per launch from the committed counter pass (profiles/r02_pmc_issue_<workload>.csv, tools/pmc_issue_summary.py)"""
-    path = os.path.join(ROOT, "profiles", "r02_pmc_issue_%s.csv" % workload)
+    """vector instructions per launch from the committed counter pass (profiles/rNN_pmc_issue_<workload>.csv, tools/pmc_issue_summary.py)"""
+    path = _latest("r*_pmc_issue_%s.csv" % workload)
     out = {}
-    if os.path.exists(path):
+    if path:
         import csv
         with open(path) as fh:
             for r in csv.DictReader(fh):
@@ -425,53 +441,81 @@ def pmc_valu(workload):
     return out
 
 
-VALU_ISSUE_PER_S = 1024 * 2.4e9 / 4.0    # vector instructions the chip can issue per second: one per SIMD per 4 cycles
-
-
 def one_roofline(slot, ms, n, work, traffic, valu=None):
+    """one kernel: `frac` = algorithmic bytes (or flops, or SURVEY 8(d)'s comparisons) per launch over the live average launch duration,
+    against the hardware peak -- never against the kernel's own instruction count; `valu_issue_util` is reported beside it"""
     per_launch_s = ms * 1e-3 / n
-    tr = traffic.get(SLOT_KERNEL.get(slot, ""))
+    kern = SLOT_KERNEL.get(slot, "")
+    tr = traffic.get(kern) or traffic.get(kern.split("<")[0])
     if slot in FLOP_SLOTS:
         ach = work / n / per_launch_s / 1e12
         r = {"kernel": slot, "bound": "mfma" if slot in MFMA_SLOTS else "valu_f64", "achieved": ach, "peak": F64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / F64_PEAK_TFLOPS}
     elif slot == "match":
         ach = work / n / per_launch_s / 1e9
         r = {"kernel": slot, "bound": "valu_int", "achieved": ach, "peak": MATCH_PEAK_GEVALS, "unit": "G gate+Hamming evaluations/s", "frac": ach / MATCH_PEAK_GEVALS}
-        if tr:
-            r["hbm_GBs"] = tr[0] / per_launch_s / 1e9
-    elif slot == "fast":                                    # the work figure of the slot is the bytes of all levels = one per pixel
-        ach = work / n / per_launch_s / 1e9
-        r = {"kernel": slot, "bound": "valu_int", "achieved": ach, "peak": FAST_PEAK_GPX, "unit": "G pixels/s", "frac": ach / FAST_PEAK_GPX}
-        if tr:
-            r["hbm_GBs"] = tr[0] / per_launch_s / 1e9
-    elif slot == "desc" and valu and valu.get(SLOT_KERNEL[slot]):
-        # no byte or flop roof fits: one wavefront per keypoint works out of a 49 x 49 LDS tile.  Priced by what it is bound by, the
-        # vector issue slots: instructions per launch (PMC) x live launches per second against one instruction per SIMD per 4 cycles
-        ach = valu[SLOT_KERNEL[slot]] / per_launch_s / 1e9
-        r = {"kernel": slot, "bound": "valu_issue", "achieved": ach, "peak": VALU_ISSUE_PER_S / 1e9, "unit": "G vector instructions/s", "frac": ach / (VALU_ISSUE_PER_S / 1e9)}
     else:
         ach = work / n / per_launch_s / 1e9
         r = {"kernel": slot, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS}
-    if valu and slot in SLOT_KERNEL and valu.get(SLOT_KERNEL[slot]):
-        r["valu_issue_util"] = valu[SLOT_KERNEL[slot]] / per_launch_s / VALU_ISSUE_PER_S      # measured instruction count (PMC) over the live duration
+    if tr:
+        r["hbm_GBs"] = tr[0] / per_launch_s / 1e9
+    v = valu.get(kern) or valu.get(kern.split("<")[0]) if valu else None
+    if v:
+        r["valu_issue_util"] = v / per_launch_s / VALU_ISSUE_PER_S      # measured instruction count (PMC) over the live duration
     r.update({"traffic": tr[0] if tr else None, "traffic_calibrated": tr[1] if tr else None, "launches": n, "avg_launch_us": per_launch_s * 1e6})
-    if slot in NOTES:
-        r["note"] = NOTES[slot]
     return r
 
 
-def roofline(prof, workload):
-    """roofline of the single kernel with the largest accumulated GPU time (umbrella slots excluded), and of every other
-    kernel that has an algorithmic work figure"""
-    cand = {k: v for k, v in prof.items() if k not in ("pg", "pg_subtree", "pg_asm", "pg_comm") and v[1] > 0 and v[2] > 0}
-    if not cand:
-        return None, None
+def group_roofline(name, prof, traffic, units, unit_work):
+    """a stage of SURVEY.md 8(d) = a group of kernels.  One "launch" of the group = one pass over its unit (`units` per profiled step:
+    1 for the per-survey stages, the number of LM trials for the factorisation); duration = the summed event time of its kernels."""
+    bound, slots = GROUPS[name]
+    live = [k for k in slots if k in prof and prof[k][1] > 0]
+    if not live:
+        return None
+    ms = sum(prof[k][0] for k in live)
+    per_unit_s = ms * 1e-3 / units
+    work = unit_work if unit_work is not None else sum(prof[k][2] for k in live) / units
+    tr, cal = 0.0, True
+    for k in live:
+        kern = SLOT_KERNEL.get(k, "")
+        t = traffic.get(kern) or traffic.get(kern.split("<")[0])
+        if t is None:
+            cal = False
+            continue
+        tr += t[0] * prof[k][1] / units
+        cal = cal and t[1]
+    if bound == "hbm":
+        ach, peak, unit = work / per_unit_s / 1e9, HBM_PEAK_GBS, "GB/s"
+    elif bound == "valu_int":
+        ach, peak, unit = work / per_unit_s / 1e9, MATCH_PEAK_GEVALS, "G gate+Hamming evaluations/s"
+    else:
+        ach, peak, unit = work / per_unit_s / 1e12, F64_PEAK_TFLOPS, "TFLOP/s"
+    return {"kernel": name + " (" + " + ".join(SLOT_KERNEL.get(k, k) for k in live) + ")", "bound": "hbm" if bound == "hbm" else ("mfma" if bound == "mfma" else bound),
+            "achieved": ach, "peak": peak, "unit": unit, "frac": ach / peak, "traffic": tr if tr > 0 else None, "traffic_calibrated": cal if tr > 0 else None,
+            "launches": units, "avg_launch_us": per_unit_s * 1e6, "ms_per_step": ms, "note": GROUP_NOTE.get(name)}
+
+
+def roofline(prof, workload, wl=None, trials=1):
+    """headline = the kernel GROUP with the largest accumulated GPU time (SURVEY 8(d) stages); plus every group and every kernel
+    that has an algorithmic work figure, each against the hardware peak of what bounds it"""
     traffic = pmc_traffic(workload)
     valu = pmc_valu(workload)
-    best = max(cand, key=lambda k: cand[k][0])
+    F, N, M = (wl["F"], wl["N"], wl["M"]) if wl else (0, 0, 0)
+    groups = {}
+    for g in GROUPS:
+        units = max(trials, 1) if g == "pg_factor" else 1
+        unit_work = 29.4 * N * M * F if g == "extract" else (prof["match"][2] if g == "match" and "match" in prof else None)
+        r = group_roofline(g, prof, traffic, units, unit_work)
+        if r:
+            groups[g] = r
+    if not groups:
+        return None, None, None
+    best = max(groups, key=lambda g: groups[g]["ms_per_step"])
+    cand = {k: v for k, v in prof.items() if k not in ("pg", "pg_comm") and v[1] > 0 and v[2] > 0}
     allr = {k: one_roofline(k, *cand[k], traffic, valu) for k in cand}
-    return allr[best], {k: {kk: (round(vv, 4) if isinstance(vv, float) else vv) for kk, vv in v.items() if kk in ("bound", "achieved", "unit", "frac", "avg_launch_us", "traffic", "traffic_calibrated", "hbm_GBs", "launches", "valu_issue_util")}
-                        for k, v in allr.items()}
+    keep = ("bound", "achieved", "peak", "unit", "frac", "avg_launch_us", "traffic", "traffic_calibrated", "hbm_GBs", "launches", "valu_issue_util", "ms_per_step")
+    rnd = lambda d: {kk: (round(vv, 5) if isinstance(vv, float) else vv) for kk, vv in d.items() if kk in keep}
+    return groups[best], {g: rnd(v) for g, v in groups.items()}, {k: rnd(v) for k, v in allr.items()}
 
 
 if __name__ == "__main__":

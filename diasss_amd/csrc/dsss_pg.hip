@@ -2194,7 +2194,7 @@ static int pg_solve_impl(dsss_ctx* c, const double* dr6, int total, const dsss_l
                 hipLaunchKernelGGL(pg_scatter_base_kernel, dim3((unsigned)(((long long)ns * 78 + 255) / 256)), dim3(256), 0, st, ns, d_t2, d_perm, d_D1, d_g1, d_s2DL, d_s2DR, d_s2GL, d_s2GR, d_s2S, d_dest, d_L, d_aval, d_x,
                                    d_ifslot, d_avalif, d_xif, kp0, kp1);
                 if (ne > 0) hipLaunchKernelGGL(pg_scatter_lc_kernel, dim3((unsigned)(((long long)ne * 36 + 255) / 256)), dim3(256), 0, st, n, ne, ns, d_Ji, d_ew, d_dest, d_L, d_aval, d_avalif, d_eo, mp0, mp1);
-                if (nbins > 0) { dsss_scope s1(c, DSSS_K_PG_SUBTREE);
+                if (nbins > 0) { dsss_scope s1(c, DSSS_K_PG_SUBTREE, std::max(0.0, S.flops_factor - S.flops_fronts));      // flops of the binned columns
                                  hipLaunchKernelGGL(pg_factor_subtree_kernel, dim3(nbins), dim3(256), 0, st, d_binptr + bin_lo, d_bincols, d_colptr, d_rlptr, d_rlcol, d_rlpos, d_mapptr, d_map, d_L, d_x, d_fail,
                                                     d_binroot_ptr + bin_lo, d_binroot_idx, d_broot_b, d_broot_uoff, d_broot_of_col, d_anc_first, d_anc_rel, d_ubin); }
                 // fronts, level by level: assemble the fronts that start here, then one panel step of every active front

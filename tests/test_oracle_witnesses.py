@@ -5,6 +5,7 @@ numpy FAST-9/16 written from the published definition, and a dense numpy Gauss-N
 real libraries stays "unpinned"; these shrink the room for a wrong restatement."""
 import ctypes as C
 import numpy as np
+import pytest
 import scipy.linalg as sla
 from scipy.optimize import least_squares
 from scipy.spatial.transform import Rotation
@@ -179,3 +180,118 @@ def test_posegraph_vs_dense_numpy_gauss_newton(orc):
     assert 0.5 * (resid(np.zeros(6 * n)) ** 2).sum() > 1.5 * sol.cost          # the loop closures really move the optimum off DR
     assert np.abs(out - ref).max() < 2e-5, np.abs(out - ref).max()          # the oracle stops at GTSAM's relative tolerance 1e-5
     assert abs(stats[2] - sol.cost) <= 1e-3 * max(sol.cost, 1e-12) + 1e-9
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Round 3: three more witnesses for the OpenCV primitives the oracle restates (none of them is OpenCV: parity stays unpinned,
+# but each is an INDEPENDENT derivation -- another language, another structure, or the continuous definition with an error bound).
+def _np_resize_linear_u8(src, dh, dw):
+    """cv::resize(INTER_LINEAR) for CV_8UC1 written from the published algorithm (SURVEY.md A.1), vectorised: float32 source
+    coordinates at half-pixel centres, 11-bit coefficients rounded half to even, integer horizontal pass, the >>4 / >>16 / +2 >>2
+    vertical pass."""
+    sh, sw = src.shape
+    def table(d, s, clamp):
+        scale = 1.0 / (np.float64(d) / np.float64(s))
+        f = ((np.arange(d, dtype=np.float64) + 0.5) * scale - 0.5).astype(np.float32)
+        i = np.floor(f).astype(np.int64)
+        f = (f - i.astype(np.float32)).astype(np.float32)
+        if clamp:
+            lo = i < 0; f[lo] = 0; i[lo] = 0
+            hi = i >= s - 1; f[hi] = 0; i[hi] = s - 1
+        c1 = np.rint(f * np.float32(2048)).astype(np.int64); c0 = np.rint((np.float32(1) - f) * np.float32(2048)).astype(np.int64)
+        return i, c0, c1
+    sx, a0, a1 = table(dw, sw, True)
+    sy, b0, b1 = table(dh, sh, False)
+    S = src.astype(np.int64)
+    H = S[:, sx] * a0[None, :] + S[:, np.minimum(sx + 1, sw - 1)] * a1[None, :]           # sh x dw, scaled by 2^11
+    ya = np.clip(sy, 0, sh - 1); yb = np.clip(sy + 1, 0, sh - 1)
+    out = (((b0[:, None] * (H[ya] >> 4)) >> 16) + ((b1[:, None] * (H[yb] >> 4)) >> 16) + 2) >> 2
+    return out.astype(np.uint8)
+
+
+def _exact_bilinear(src, dh, dw):
+    sh, sw = src.shape
+    fy = np.clip((np.arange(dh) + 0.5) * sh / dh - 0.5, 0, sh - 1); fx = np.clip((np.arange(dw) + 0.5) * sw / dw - 0.5, 0, sw - 1)
+    y0 = np.floor(fy).astype(int); x0 = np.floor(fx).astype(int); y1 = np.minimum(y0 + 1, sh - 1); x1 = np.minimum(x0 + 1, sw - 1)
+    wy = (fy - y0)[:, None]; wx = (fx - x0)[None, :]
+    S = src.astype(np.float64)
+    return (S[y0][:, x0] * (1 - wx) + S[y0][:, x1] * wx) * (1 - wy) + (S[y1][:, x0] * (1 - wx) + S[y1][:, x1] * wx) * wy
+
+
+@pytest.mark.parametrize("shape", [(700, 480), (583, 400), (97, 131), (2000, 1024)])
+def test_resize_vs_independent_numpy_and_exact_bilinear(orc, shape):
+    import ctypes as C
+    rng = np.random.default_rng(shape[0])
+    src = rng.integers(0, 256, shape, dtype=np.uint8)
+    inv = np.float32(1.0) / np.float32(1.2)                                    # mvInvScaleFactor[1] (ORBextractor.cpp:417-424)
+    dh, dw = int(np.rint(np.float32(shape[0]) * inv)), int(np.rint(np.float32(shape[1]) * inv))
+    dst = np.zeros((dh, dw), np.uint8)
+    orc.lib().orc_resize_linear_u8(orc.u8(src), shape[0], shape[1], orc.u8(dst), dh, dw)
+    assert (dst == _np_resize_linear_u8(src, dh, dw)).all()                    # bit for bit
+    # and the fixed-point result is the continuous bilinear interpolant to within one grey level (11-bit weights, two roundings)
+    assert np.abs(dst.astype(np.float64) - _exact_bilinear(src, dh, dw)).max() <= 1.0
+    # smooth input: the same bound, and the down-scaled image keeps the mean
+    yy, xx = np.mgrid[0:shape[0], 0:shape[1]]
+    smooth = (127 + 100 * np.sin(yy / 23.0) * np.cos(xx / 31.0)).astype(np.uint8)
+    orc.lib().orc_resize_linear_u8(orc.u8(smooth), shape[0], shape[1], orc.u8(dst), dh, dw)
+    assert np.abs(dst.astype(np.float64) - _exact_bilinear(smooth, dh, dw)).max() <= 1.0
+    assert abs(dst.mean() - smooth.mean()) < 0.6
+
+
+def test_fast_atan2_vs_numpy_arctan2(orc):
+    """cv::fastAtan2's documented accuracy is 0.3 degrees; the restated polynomial must stay inside it against np.arctan2 on a
+    dense set of directions and magnitudes, hit the axes exactly and keep its range [0, 360)"""
+    import ctypes as C
+    L = orc.lib()
+    L.orc_fast_atan2.argtypes = [C.c_float, C.c_float]
+    rng = np.random.default_rng(4)
+    worst = 0.0
+    for k in range(20000):
+        ang = rng.uniform(0, 2 * np.pi); r = 10 ** rng.uniform(-3, 6)
+        y, x = np.float32(r * np.sin(ang)), np.float32(r * np.cos(ang))
+        got = L.orc_fast_atan2(float(y), float(x))
+        ref = np.degrees(np.arctan2(float(y), float(x))) % 360.0
+        d = abs(got - ref); d = min(d, 360.0 - d)
+        worst = max(worst, d)
+        assert 0.0 <= got <= 360.0
+    assert worst < 0.3, worst
+    assert worst > 1e-4                                                       # it IS the polynomial, not libm
+    for y, x, ref in ((0, 1, 0.0), (1, 0, 90.0), (0, -1, 180.0), (-1, 0, 270.0), (0, 0, 0.0)):
+        assert abs(L.orc_fast_atan2(float(y), float(x)) - ref) < 1e-4
+    for y, x in ((1, 1), (1, -1), (-1, -1), (-1, 1)):                         # diagonals: within the polynomial's error of 45 + 90 k
+        assert abs(L.orc_fast_atan2(float(y), float(x)) - (np.degrees(np.arctan2(y, x)) % 360)) < 0.3
+
+
+def test_gaussian_taps_derived_in_the_test(orc):
+    """The 8.8 taps of the 13 x 13, sigma 2 blur, derived here and not copied: error diffusion from the edge inwards means the running
+    sum of the integer taps is the ROUNDED running sum of the real ones (256 g_i / sum g), so tap_i = rint(C_i) - rint(C_(i-1));
+    the centre takes what is left of 256.  Also: symmetric, every tap within one of its own rounding, and the blur it defines is the
+    real Gaussian filter to within one grey level."""
+    import ctypes as C
+    taps = (C.c_int * 13)()
+    orc.lib().orc_gauss13_taps(taps)
+    taps = np.array(list(taps))
+    d = np.arange(13) - 6.0
+    g = np.exp(-d * d / (2 * 2.0 ** 2)); g = 256.0 * g / g.sum()
+    Cs = np.concatenate([[0.0], np.cumsum(g[:6])])
+    assert np.abs(np.abs(Cs[1:] - np.floor(Cs[1:])) - 0.5).min() > 1e-6       # no running sum sits on a rounding tie
+    derived = np.diff(np.rint(Cs)).astype(int)
+    expect = np.concatenate([derived, [256 - 2 * derived.sum()], derived[::-1]])
+    assert (taps == expect).all(), (taps, expect)
+    assert taps.sum() == 256 and (taps == taps[::-1]).all() and (np.diff(taps[:7]) > 0).all()
+    assert np.abs(taps - g).max() < 1.0                                       # each tap within one unit of the real 8.8 value
+    # the filter it defines vs the real-valued separable Gaussian with the same reflect-101 border
+    rng = np.random.default_rng(2)
+    img = rng.integers(0, 256, (90, 120), dtype=np.uint8)
+    out = np.zeros_like(img)
+    orc.lib().orc_blur13(orc.u8(img), 90, 120, orc.u8(out))
+    gn = g / 256.0
+    pad = np.pad(img.astype(np.float64), 6, mode="reflect")
+    h = sum(gn[k] * pad[:, k:k + 120] for k in range(13))
+    v = sum(gn[k] * h[k:k + 90, :] for k in range(13))
+    # error bound from the taps themselves: each pass is off by at most 255 * sum |t_k / 256 - g_k|, plus the final rounding
+    eps = np.abs(taps / 256.0 - gn).sum()
+    bound = 255.0 * (2 * eps + eps * eps) + 0.5
+    err = np.abs(out.astype(np.float64) - v).max()
+    assert err <= bound and err <= 3.0, (err, bound)                         # worst case from the taps; white noise stays well inside it
+    assert abs(out.mean() - v.mean()) < 0.1                                   # the taps sum to exactly 256: no brightness drift

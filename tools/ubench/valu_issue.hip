@@ -6,10 +6,11 @@
 //
 // Every kernel runs ITERS x 16 INDEPENDENT instructions of one opcode (sixteen destination registers, inline asm so the
 // compiler can neither fuse nor drop them).  Reported per (opcode, waves per SIMD):
-//     cyc/inst/SIMD   shader cycles between two issues of that opcode on one SIMD (s_memtime ticks of a wavefront, divided by its
-//                     instruction count and multiplied by the wavefronts per SIMD that ran beside it)
-//     G inst/s chip   wave-instructions per second over all 1024 SIMDs, from the host-timed launch
-//     clock           effective shader clock = s_memtime ticks / s_memrealtime ticks x 100 MHz
+//     G inst/s chip   wave-instructions per second over all 1024 SIMDs, from the host-timed launch (HIP events): THE figure of record
+//     cyc@2.4/SIMD    the same as nominal 2.4 GHz cycles between two issues on one SIMD = SIMDs x 2.4e9 / (inst/s)
+//     ticks/inst/SIMD s_memtime ticks of a wavefront / its instructions / wavefronts per SIMD (in-kernel view; the tick is not the
+//                     shader cycle on every launch here -- it disagrees with the host clock by 1.0-2.0x -- so it is not used)
+//     tick ratio      s_memtime ticks / s_memrealtime ticks x 100 MHz
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
@@ -98,7 +99,7 @@ int main(int argc, char** argv)
     const int ncu = pr.multiProcessorCount, nsimd = 4 * ncu;
     const int iters = argc > 1 ? atoi(argv[1]) : 4096;
     printf("# %s, %d CUs, %d SIMDs; %d x 16 independent instructions per wavefront\n", pr.gcnArchName, ncu, nsimd, iters);
-    printf("# %-16s %6s %14s %16s %10s %12s\n", "opcode", "waves", "cyc/inst/SIMD", "G inst/s chip", "clock GHz", "launch us");
+    printf("# %-16s %6s %14s %13s %16s %11s %10s\n", "opcode", "waves", "G inst/s chip", "cyc@2.4/SIMD", "ticks/inst/SIMD", "tick ratio", "launch us");
     const int maxwaves = nsimd * 8;
     unsigned* d_out; unsigned long long* d_ticks;
     CK(hipMalloc(&d_out, sizeof(unsigned) * 64 * maxwaves)); CK(hipMalloc(&d_ticks, sizeof(unsigned long long) * 2 * maxwaves));
@@ -121,9 +122,11 @@ int main(int argc, char** argv)
             std::nth_element(cyc.begin(), cyc.begin() + nwaves / 2, cyc.end());
             std::nth_element(clk.begin(), clk.begin() + nwaves / 2, clk.end());
             const double inst = (double)iters * 16.0;
-            printf("  %-16s %6d %14.3f %16.1f %10.3f %12.1f\n", OP_NAME[op], w, cyc[nwaves / 2] / inst / w, inst * nwaves / (ms * 1e-3) / 1e9, clk[nwaves / 2], ms * 1e3);
+            const double ips = inst * nwaves / (ms * 1e-3);
+            printf("  %-16s %6d %14.1f %13.2f %16.3f %11.3f %10.1f\n", OP_NAME[op], w, ips / 1e9, nsimd * 2.4e9 / ips, cyc[nwaves / 2] / inst / w, clk[nwaves / 2], ms * 1e3);
         }
-    printf("# cyc/inst/SIMD: the guide's figure is 2 (a wave64 instruction occupies a SIMD-32 for two cycles) once >= 2 wavefronts share the SIMD, 4 for one wavefront alone;\n"
-           "# f64 and dot4 / transcendental classes differ -- read them here.  bench.py takes VALU_ISSUE_CYCLES from the 8-wave rows of the opcode mix of each kernel.\n");
+    printf("# The guide's figure is 2 cycles per wave64 instruction per SIMD-32 once >= 2 wavefronts share the SIMD.  Read the 8-wave rows: the full-rate class\n"
+           "# (v_fma_f32, v_add_u32, v_xor_b32) gets there; packed 16-bit min/max, v_bcnt, v_dot4, v_perm, three-operand integer ops and all f64 ops are half rate.\n"
+           "# bench.py: VALU_ISSUE_PER_S = the v_fma_f32 8-wave row.\n");
     return 0;
 }
