@@ -169,6 +169,21 @@ def dry_run(args, rank, world):
         dist.destroy_process_group()
 
 
+def emulate_rank(args):
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import emulate_ranks as E
+    which, world = args.emulate_rank.split("/")
+    world = int(world)
+    wl = WORKLOADS[args.workload]
+    ranks = None if which == "all" else [int(which)]
+    rows, stats = E.emulate(wl, 20240601 + ["C2", "C3", "smoke", "C5"].index(args.workload), world, ranks, steps=args.steps, warmup=args.warmup, profile=True)
+    worst = max(r["ms_per_step"] + r["wire_ms_model"] for r in rows)
+    print(json.dumps({"metric": "per-rank step time of a %d-rank job, emulated on one GPU by replaying recorded collectives" % world, "unit": "ms", "world": world,
+                      "workload": wl["name"], "ranks": rows, "lm_iterations": int(stats[0]),
+                      "implied_step_ms": worst if ranks is None else None, "implied_frames_per_s": wl["F"] / worst * 1e3 if ranks is None else None,
+                      "wire_model": "ring collectives bound by one xGMI link at %.0f GB/s: all-reduce 2 (W-1)/W x bytes, all-gather (W-1)/W x bytes" % E.XGMI_LINK_GBS}))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -181,7 +196,12 @@ def main():
     ap.add_argument("--jobs-in-flight", type=int, default=2, help="surveys overlapped in the extra throughput leg (1 = skip)")
     ap.add_argument("--dry-run", action="store_true", help="plumbing check without a GPU (CPU test-suite): gloo ranks, the context class named by DSSS_BENCH_CTX "
                                                            "(module:Class, a recording stub), no frames, no timing claim -- the line carries value null and dry_run true")
+    ap.add_argument("--emulate-rank", default=None, metavar="r/W", help="time rank r (or `all`) of a W-rank job on ONE GPU: all W ranks run once in lock step inside "
+                                                                       "this process and record the results of their collectives, then rank r runs alone and replays them "
+                                                                       "(tools/emulate_ranks.py).  Prints its own JSON line, not the bench contract's")
     args = ap.parse_args()
+    if args.emulate_rank:
+        return emulate_rank(args)
 
     # `python bench.py --gpus N` started plainly (no torch.distributed.run): this process becomes the launcher.  It starts one
     # child per GPU BEFORE anything here has touched the GPU (nothing is imported that could), hands them the rendezvous through

@@ -92,12 +92,14 @@ def lib():
         L.dsss_features_pack_bytes.restype = C.c_size_t
         L.dsss_features_pack_bytes.argtypes = [C.c_void_p]
         L.dsss_comm_init_callback.argtypes = [C.c_void_p, C.c_int, C.c_int, COMM_FN, C.c_void_p]
+        L.dsss_comm_init_device_callback.argtypes = [C.c_void_p, C.c_int, C.c_int, COMM_DEV_FN, C.c_void_p]
         L.dsss_comm_frame_owner.argtypes = [C.c_void_p, C.c_int, C.c_int]
         _LIB = L
     return _LIB
 
 
 COMM_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_size_t)
+COMM_DEV_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p)
 
 
 def _ptr(a):
@@ -184,6 +186,19 @@ class Context:
                 return 1
         self._cb_keep = COMM_FN(_cb)
         self._chk(self.L.dsss_comm_init_callback(self.h, int(rank), int(world), self._cb_keep, None), "dsss_comm_init_callback")
+
+    def comm_init_device_callback(self, rank, world, fn):
+        """fn(op, dev_ptr, n, stream): the library's collectives handed over as DEVICE buffers (dsss_comm_init_device_callback); op 0:
+        n doubles to be summed in place, op 1: world x n bytes with this rank's slice in place; work must be ordered on `stream`"""
+        def _cb(user, op, buf, n, stream):
+            try:
+                fn(int(op), int(buf or 0), int(n), int(stream or 0))
+                return 0
+            except Exception:
+                import traceback; traceback.print_exc()
+                return 1
+        self._dcb_keep = COMM_DEV_FN(_cb)
+        self._chk(self.L.dsss_comm_init_device_callback(self.h, int(rank), int(world), self._dcb_keep, None), "dsss_comm_init_device_callback")
 
     def comm_destroy(self):
         self._chk(self.L.dsss_comm_destroy(self.h), "dsss_comm_destroy")

@@ -47,6 +47,7 @@ struct dsss_comm {
     int rank = 0, world = 1;
     void* nccl = nullptr;                                              // ncclComm_t
     dsss_comm_fn cb = nullptr; void* cb_user = nullptr;
+    dsss_comm_dev_fn dcb = nullptr;                                    // transport that works on the DEVICE buffer, ordered on the stream
     double* h_stage = nullptr; size_t h_cap = 0;                       // pinned staging of the callback transport
     double bytes = 0; long long calls = 0;
 };
@@ -73,6 +74,10 @@ int dsss_comm_allreduce(dsss_ctx* c, double* dev, size_t n, hipStream_t st)
         if (rc != 0) DSSS_FAIL(c, DSSS_E_COMM, "ncclAllReduce: %s", g_rccl.errstr ? g_rccl.errstr(rc) : "error");
         return DSSS_OK;
     }
+    if (m->dcb) {
+        if (m->dcb(m->cb_user, 0, dev, n, (void*)st) != 0) DSSS_FAIL(c, DSSS_E_COMM, "all-reduce device callback failed");
+        return DSSS_OK;
+    }
     if (m->cb) {
         if (m->h_cap < n) { if (m->h_stage) hipHostFree(m->h_stage); m->h_stage = nullptr; m->h_cap = 0;
                             HIPCHK(c, hipHostMalloc(&m->h_stage, n * sizeof(double), hipHostMallocDefault)); m->h_cap = n; }
@@ -95,6 +100,10 @@ int dsss_comm_allgather(dsss_ctx* c, void* recv_dev, size_t bytes, hipStream_t s
         if (!g_rccl.allgather) DSSS_FAIL(c, DSSS_E_COMM, "librccl lacks ncclAllGather");
         const int rc = g_rccl.allgather((const char*)recv_dev + (size_t)m->rank * bytes, recv_dev, bytes, RCCL_UINT8, m->nccl, st);
         if (rc != 0) DSSS_FAIL(c, DSSS_E_COMM, "ncclAllGather: %s", g_rccl.errstr ? g_rccl.errstr(rc) : "error");
+        return DSSS_OK;
+    }
+    if (m->dcb) {
+        if (m->dcb(m->cb_user, 1, recv_dev, bytes, (void*)st) != 0) DSSS_FAIL(c, DSSS_E_COMM, "all-gather device callback failed");
         return DSSS_OK;
     }
     if (m->cb) {
@@ -142,6 +151,15 @@ int dsss_comm_init_callback(dsss_ctx* c, int rank, int world, dsss_comm_fn fn, v
     if (!c || world < 1 || rank < 0 || rank >= world || (world > 1 && !fn)) return DSSS_E_ARG;
     dsss_comm_free(c);
     dsss_comm* m = new dsss_comm(); m->rank = rank; m->world = world; m->cb = fn; m->cb_user = user;
+    c->comm = m;
+    return DSSS_OK;
+}
+
+int dsss_comm_init_device_callback(dsss_ctx* c, int rank, int world, dsss_comm_dev_fn fn, void* user)
+{
+    if (!c || world < 1 || rank < 0 || rank >= world || (world > 1 && !fn)) return DSSS_E_ARG;
+    dsss_comm_free(c);
+    dsss_comm* m = new dsss_comm(); m->rank = rank; m->world = world; m->dcb = fn; m->cb_user = user;
     c->comm = m;
     return DSSS_OK;
 }

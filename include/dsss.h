@@ -85,6 +85,12 @@ typedef int (*dsss_comm_fn)(void* user, int op, void* host_buf, size_t n);
 int dsss_comm_unique_id(void* id128_out);
 int dsss_comm_init(dsss_ctx*, const void* id128, int rank, int world);
 int dsss_comm_init_callback(dsss_ctx*, int rank, int world, dsss_comm_fn fn, void* user);
+/* The same two operations on the DEVICE buffer itself, to be ordered on `stream` (a hipStream_t): for callers whose transport moves
+ * device memory (another collective library), and for timing ONE rank of an N-rank job on a single GPU by replaying the sums a
+ * lock-step run of all ranks recorded (tools/emulate_ranks.py, bench.py --emulate-rank).  op 0: n doubles at dev_buf, summed in
+ * place; op 1: world x n bytes at dev_buf, own slice in place.                                                              */
+typedef int (*dsss_comm_dev_fn)(void* user, int op, void* dev_buf, size_t n, void* stream);
+int dsss_comm_init_device_callback(dsss_ctx*, int rank, int world, dsss_comm_dev_fn fn, void* user);
 int dsss_comm_destroy(dsss_ctx*);
 int dsss_comm_stats(dsss_ctx*, int* rank, int* world, double* allreduce_bytes, int64_t* allreduce_calls);
 /* frames are owned in contiguous blocks: rank r owns frames [nframes r / world, nframes (r+1) / world)                     */

@@ -262,3 +262,20 @@ def test_reversed_edges_across_ranks(orc, world):
         assert s[0] == sref[0] and np.abs(p - ref).max() < 1e-8, (rank, np.abs(p - ref).max())
     for r in range(1, world):
         assert (res[0][1] == res[r][1]).all()
+
+
+def test_emulated_ranks_replay_reproduces_lockstep():
+    """tools/emulate_ranks.py (bench.py --emulate-rank): three ranks in lock step inside one process over the host-callback
+    transport, then every rank ALONE through the device-callback transport replaying the recorded collectives: same trajectory to
+    the bit, and the single-rank answer to rounding."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import emulate_ranks as E
+    wl = dict(F=6, N=700, M=480)
+    F, raws, poses, alts, grs = _survey()
+    ref, ref_stats, _ = _reference(F, raws, poses, alts, grs)
+    log, traj, stats, data = E.record(wl, 91, 3)                    # seed 91 = _survey()'s survey
+    assert stats[0] == ref_stats[0] and np.abs(traj - ref).max() < 1e-9
+    for r in range(3):
+        ms, comm, brk, out = E.replay_rank(wl, 3, r, log[r], data, steps=1, warmup=1, profile=True)
+        assert (out == traj).all()
+        assert comm["allreduce_bytes"] > 0 and comm["allgather_bytes"] > 0 and brk["pg"] > 0
