@@ -116,6 +116,7 @@ void dsss_destroy(dsss_ctx* c)
     c->gbatches.clear();
     free_match(c); free_store(c);
     hipFree(c->lcs); hipFree(c->ex_scratch); hipFree(c->mt_aux); hipFree(c->tmp_dev);
+    hipFree(c->ag_buf); if (c->ag_host) hipHostFree(c->ag_host); hipFree(c->xch_dev);
     if (c->pg_edges_host) hipHostFree(c->pg_edges_host);
     if (c->pg_stage) hipHostFree(c->pg_stage);
     if (c->pg_scal_host) hipHostFree(c->pg_scal_host);
@@ -560,31 +561,93 @@ int dsss_comm_frame_owner(const dsss_ctx* c, int nframes, int frame)
     while (r > 0 && (long long)nframes * r / world > frame) --r;
     return r;
 }
+// All frames of a rank in ONE launch each way (the per-frame dsss_features_pack / _unpack -- five copies and a synchronisation
+// per frame -- cost 9 ms per step at 200 frames and 8 ranks, more than the all-gather moves in 0.2 ms).  Record layout as in
+// dsss_features_pack.  frame -> owner by the block rule of dsss_comm_frame_owner.
+__device__ inline int ag_owner(int nframes, int world, int f)
+{
+    int r = (int)(((long long)f * world) / nframes);
+    while (r + 1 < world && (long long)nframes * (r + 1) / world <= f) ++r;
+    while (r > 0 && (long long)nframes * r / world > f) --r;
+    return r;
+}
+__global__ __launch_bounds__(256) void ag_copy_kernel(int nframes, int world, int rank, int unpack, char* __restrict__ buf, size_t slice, size_t nb, int K,
+                                                      dsss_kp* __restrict__ kps, uint8_t* __restrict__ desc, double* __restrict__ geo, int* __restrict__ nkp,
+                                                      int* __restrict__ rows, int* __restrict__ cols, double* __restrict__ bbox)
+{
+    const int f = blockIdx.y;
+    const int r = ag_owner(nframes, world, f);
+    if (unpack ? r == rank : r != rank) return;           // pack: own frames into the own slice; unpack: everybody else's out of theirs
+    const int g0 = (int)((long long)nframes * r / world);
+    char* rec = buf + (size_t)r * slice + (size_t)(f - g0) * nb;
+    const size_t kb = (size_t)K * sizeof(dsss_kp), db = (size_t)K * 32, gb = (size_t)K * 16;     // multiples of 16 (K is a multiple of 64)
+    uint4* r4 = reinterpret_cast<uint4*>(rec + 48);
+    uint4* k4 = reinterpret_cast<uint4*>(reinterpret_cast<char*>(kps) + (size_t)f * kb);
+    uint4* d4 = reinterpret_cast<uint4*>(desc + (size_t)f * db);
+    uint4* g4 = reinterpret_cast<uint4*>(reinterpret_cast<char*>(geo) + (size_t)f * gb);
+    const size_t nk = kb / 16, nd = db / 16, ng = gb / 16, tot = nk + nd + ng;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < tot; i += (size_t)gridDim.x * 256) {
+        uint4* own = i < nk ? k4 + i : (i < nk + nd ? d4 + (i - nk) : g4 + (i - nk - nd));
+        if (unpack) *own = r4[i]; else r4[i] = *own;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        int* h = reinterpret_cast<int*>(rec); double* bb = reinterpret_cast<double*>(rec + 16);
+        if (unpack) { nkp[f] = h[0]; rows[f] = h[1]; cols[f] = h[2]; for (int q = 0; q < 4; ++q) bbox[(size_t)f * 4 + q] = bb[q]; }
+        else { h[0] = nkp[f]; h[1] = rows[f]; h[2] = cols[f]; h[3] = 0; for (int q = 0; q < 4; ++q) bb[q] = bbox[(size_t)f * 4 + q]; }
+    }
+}
+
 int dsss_features_allgather(dsss_ctx* c, int nframes)
 {
     if (!c || nframes <= 0 || nframes > c->max_frames) return DSSS_E_ARG;
     const int world = dsss_comm_world(c), rank = dsss_comm_rank(c);
     if (world == 1) return DSSS_OK;
     HIPCHK(c, hipSetDevice(c->device));
+    const int f0 = (int)((long long)nframes * rank / world), f1 = (int)((long long)nframes * (rank + 1) / world);
+    for (int f = f0; f < f1; ++f) if (!c->frames[f].has_feat) DSSS_FAIL(c, DSSS_E_STATE, "frame %d (owned by this rank) has no features", f);
+    { int rc = dsss_sync_bboxes(c); if (rc) return rc; }     // the boxes of the own frames are on the device
     const size_t nb = dsss_features_pack_bytes(c);
     int per = 0;
     for (int r = 0; r < world; ++r) per = std::max(per, (int)((long long)nframes * (r + 1) / world - (long long)nframes * r / world));
     const size_t slice = (size_t)per * nb;
-    char* d_buf = nullptr;
-    HIPCHK(c, hipMalloc(&d_buf, slice * world));
-    int rc = DSSS_OK;
-    const int f0 = (int)((long long)nframes * rank / world), f1 = (int)((long long)nframes * (rank + 1) / world);
-    for (int f = f0; f < f1 && rc == DSSS_OK; ++f) rc = dsss_features_pack(c, f, d_buf + (size_t)rank * slice + (size_t)(f - f0) * nb);
-    if (rc == DSSS_OK) rc = dsss_comm_allgather(c, d_buf, slice, c->stream);
-    if (rc == DSSS_OK && hipStreamSynchronize(c->stream) != hipSuccess) rc = DSSS_E_HIP;
-    for (int r = 0; r < world && rc == DSSS_OK; ++r) {
-        if (r == rank) continue;
-        const int g0 = (int)((long long)nframes * r / world), g1 = (int)((long long)nframes * (r + 1) / world);
-        for (int f = g0; f < g1 && rc == DSSS_OK; ++f) rc = dsss_features_unpack(c, f, d_buf + (size_t)r * slice + (size_t)(f - g0) * nb);
+    if (c->ag_cap < slice * world) {
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        hipFree(c->ag_buf); c->ag_buf = nullptr; c->ag_cap = 0;
+        HIPCHK(c, hipMalloc(&c->ag_buf, slice * world)); c->ag_cap = slice * world;
     }
-    hipStreamSynchronize(c->stream);
-    hipFree(d_buf);
-    return rc;
+    const size_t hbytes = (size_t)c->max_frames * (3 * sizeof(int) + 4 * sizeof(double)) + 16;
+    if (c->ag_host_cap < hbytes) {
+        if (c->ag_host) hipHostFree(c->ag_host);
+        c->ag_host = nullptr; c->ag_host_cap = 0;
+        HIPCHK(c, hipHostMalloc(&c->ag_host, hbytes, hipHostMallocDefault)); c->ag_host_cap = hbytes;
+    }
+    char* d_buf = static_cast<char*>(c->ag_buf);
+    const hipStream_t st = c->stream;
+    const dim3 grid(8, nframes);
+    hipLaunchKernelGGL(ag_copy_kernel, grid, dim3(256), 0, st, nframes, world, rank, 0, d_buf, slice, nb, c->kcap, c->kps, c->desc, c->geo, c->nkp_dev, c->rows_dev, c->cols_dev, c->bbox_dev);
+    HIPCHK(c, hipGetLastError());
+    int rc = dsss_comm_allgather(c, d_buf, slice, st);
+    if (rc) return rc;
+    hipLaunchKernelGGL(ag_copy_kernel, grid, dim3(256), 0, st, nframes, world, rank, 1, d_buf, slice, nb, c->kcap, c->kps, c->desc, c->geo, c->nkp_dev, c->rows_dev, c->cols_dev, c->bbox_dev);
+    HIPCHK(c, hipGetLastError());
+    // the host's view of the gathered frames: counts, sizes and boxes in one download
+    int* h_n = static_cast<int*>(c->ag_host); int* h_r = h_n + c->max_frames; int* h_c = h_r + c->max_frames;
+    double* h_bb = reinterpret_cast<double*>(h_c + c->max_frames + (c->max_frames & 1));
+    HIPCHK(c, hipMemcpyAsync(h_n, c->nkp_dev, sizeof(int) * nframes, hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipMemcpyAsync(h_r, c->rows_dev, sizeof(int) * nframes, hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipMemcpyAsync(h_c, c->cols_dev, sizeof(int) * nframes, hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipMemcpyAsync(h_bb, c->bbox_dev, sizeof(double) * 4 * nframes, hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipStreamSynchronize(st));
+    for (int f = 0; f < nframes; ++f) {
+        if (f >= f0 && f < f1) continue;
+        dsss_frame& fr = c->frames[f];
+        if (h_n[f] < 0 || h_n[f] > c->kcap) DSSS_FAIL(c, DSSS_E_CAPACITY, "gathered frame %d: %d features exceed the per-frame capacity %d", f, h_n[f], c->kcap);
+        if (!fr.has_geom) { fr.N = h_r[f]; fr.M = h_c[f]; }
+        else if (fr.N != h_r[f] || fr.M != h_c[f]) DSSS_FAIL(c, DSSS_E_ARG, "gathered frame %d: geometry mismatch (%d x %d here, %d x %d at its owner)", f, fr.N, fr.M, h_r[f], h_c[f]);
+        fr.nkp = h_n[f]; fr.has_feat = true;
+        memcpy(fr.bbox, h_bb + (size_t)f * 4, 4 * sizeof(double)); fr.has_bbox = true; fr.bbox_async = false;
+    }
+    return DSSS_OK;
 }
 
 int dsss_profile_enable(dsss_ctx* c, int on) { if (!c) return DSSS_E_ARG; if (!on) dsss_prof_flush(c); c->prof.on = on != 0; return DSSS_OK; }

@@ -112,6 +112,9 @@ struct dsss_ctx {
     dsss_comm* comm = nullptr;          // ranks of one job (dsss_comm_init): null = single process
     int pg_parts = 0;                   // pose-graph partitions (0: one per rank); > ranks only to exercise the interface logic on few GPUs
     int* tmp_dev = nullptr;             // 64 ints of device scratch for one-value results (dsss_descriptor_distance)
+    void* ag_buf = nullptr; size_t ag_cap = 0;                  // staging of dsss_features_allgather: world x (frames per rank) packed records, kept between calls
+    void* ag_host = nullptr; size_t ag_host_cap = 0;            // page-locked landing place of the gathered headers (keypoint counts, boxes, sizes)
+    double* xch_dev = nullptr; size_t xch_cap = 0;              // device scratch of the loop-closure exchange between ranks (dsss_posegraph_solve)
     void* pg_edges_host = nullptr; size_t pg_edges_cap = 0;     // page-locked staging of the selected LC edges (dsss_posegraph_solve)
     double* pg_scal_host = nullptr;                             // page-locked landing place of the LM trial's scalars (8 doubles)
     void* pg_stage = nullptr; size_t pg_stage_cap = 0;          // page-locked staging of the analysis tables: one upload per solve (pg_dev::flush)

@@ -1390,6 +1390,12 @@ __global__ __launch_bounds__(256) void pg_factor_subtree_kernel(const int* __res
                                                                 const int* __restrict__ broot_of_col, const int* __restrict__ anc_first,
                                                                 const int* __restrict__ anc_rel, double* __restrict__ ubin)
 {
+    // A column costs a handful of DEPENDENT round trips, and they are what its time is made of (round 2: ~15 us per column).  So:
+    // the thread that owns row (q, r) of the column requests its old values BEFORE the updates are gathered and keeps the row in
+    // registers from the update to the row solve (it used to be stored and read back twice); the pivot block and the right-hand
+    // side travel through LDS, not memory; the pivot is factorised with reciprocal square roots (1 / L_jj stays on the diagonal, the
+    // solves multiply); and the outer product into the update matrix of the subtree root is ONE flat pass over its block pairs
+    // with four read-modify-writes in flight per thread (it was a loop over block rows, one round trip each).
     __shared__ double s_Ljk[PG_TCH * 36];          // update staging; reused for the column's ancestor blocks (42 x 36)
     __shared__ double s_yk[PG_TCH * 6];
     __shared__ double s_diag[36];
@@ -1410,6 +1416,13 @@ __global__ __launch_bounds__(256) void pg_factor_subtree_kernel(const int* __res
         const bool rhs = threadIdx.x >= 250;
         const int rs_ = threadIdx.x - 250;
         double acc[6] = { 0, 0, 0, 0, 0, 0 }, accy = 0;
+        double mine[6] = { 0, 0, 0, 0, 0, 0 }, xold = 0;     // this thread's row of the column / component of the right-hand side: in flight under the gather
+        if (act) {
+            const double* row = Lvals + (size_t)(c0 + q) * 36 + r * 6;
+#pragma unroll
+            for (int s2 = 0; s2 < 6; ++s2) mine[s2] = row[s2];
+        }
+        if (rhs) xold = x[(size_t)j * 6 + rs_];
         for (int tc = 0; tc < T; tc += PG_TCH) {
             const int tn = min(PG_TCH, T - tc);
             __syncthreads();
@@ -1432,31 +1445,53 @@ __global__ __launch_bounds__(256) void pg_factor_subtree_kernel(const int* __res
             if (act)
                 pg_acc_rows(mp + (size_t)tc * m + q, m, tn, Lvals, r, s_Ljk, acc);
         }
-        if (rhs && T > 0) x[(size_t)j * 6 + rs_] -= accy;
-        if (act && T > 0) for (int s = 0; s < 6; ++s) Lvals[(size_t)(c0 + q) * 36 + r * 6 + s] -= acc[s];
+        if (T > 0) {
+#pragma unroll
+            for (int s2 = 0; s2 < 6; ++s2) mine[s2] -= acc[s2];
+            xold -= accy;
+        }
+        __syncthreads();                                   // (the staging area is free again)
+        if (act && q == 0) {
+#pragma unroll
+            for (int s2 = 0; s2 < 6; ++s2) s_diag[r * 6 + s2] = mine[s2];
+        }
+        if (rhs) s_y[rs_] = xold;
         __syncthreads();
         if (threadIdx.x == 0) {
             double A[36];
-            for (int a = 0; a < 36; ++a) A[a] = Lvals[(size_t)c0 * 36 + a];
-            const int bad = chol6(A);
+#pragma unroll
+            for (int a = 0; a < 36; ++a) A[a] = s_diag[a];
+            const int bad = chol6_rdiag(A);                // lower triangle = L, diagonal = 1 / L_jj
             if (bad) *fail = 1;
             s_ok = !bad;
-            for (int a = 0; a < 6; ++a) for (int b = 0; b < 6; ++b) { const double v = b <= a ? A[a * 6 + b] : 0.0; s_diag[a * 6 + b] = v; Lvals[(size_t)c0 * 36 + a * 6 + b] = v; }
-            if (!bad) {
-                double v[6];
-                for (int a = 0; a < 6; ++a) { double t = x[(size_t)j * 6 + a]; for (int b = 0; b < a; ++b) t -= A[a * 6 + b] * v[b]; v[a] = t / A[a * 6 + a]; }
-                for (int a = 0; a < 6; ++a) { x[(size_t)j * 6 + a] = v[a]; s_y[a] = v[a]; }
-            }
+            double v[6];
+#pragma unroll
+            for (int a = 0; a < 6; ++a) { double t = s_y[a]; for (int b = 0; b < a; ++b) t -= A[a * 6 + b] * v[b]; v[a] = t * A[a * 7]; }
+#pragma unroll
+            for (int a = 0; a < 6; ++a)
+#pragma unroll
+                for (int b = 0; b < 6; ++b) {
+                    const double lv = b < a ? A[a * 6 + b] : (b == a ? 1.0 / A[a * 7] : 0.0);     // the factor as every reader expects it: L_jj on the diagonal
+                    s_diag[a * 6 + b] = b <= a ? A[a * 6 + b] : 0.0;                              // for the row solves below: 1 / L_jj on the diagonal
+                    Lvals[(size_t)c0 * 36 + a * 6 + b] = lv;
+                }
+#pragma unroll
+            for (int a = 0; a < 6; ++a) { s_y[a] = v[a]; if (!bad) x[(size_t)j * 6 + a] = v[a]; }
         }
         __syncthreads();
         if (!s_ok) return;
         const int af = anc_first[j], ta = m - af;                       // block rows beyond the subtree root (a suffix of the column)
         if (act && idx >= 6) {
-            double* row = Lvals + (size_t)(c0 + q) * 36 + r * 6;
             double xr[6];
-            for (int s = 0; s < 6; ++s) { double v = row[s]; for (int c = 0; c < s; ++c) v -= xr[c] * s_diag[s * 6 + c]; xr[s] = v / s_diag[s * 6 + s]; }
-            for (int s = 0; s < 6; ++s) row[s] = xr[s];
-            if (q >= af) for (int s = 0; s < 6; ++s) s_Ljk[(q - af) * 36 + r * 6 + s] = xr[s];       // keep the ancestor rows for the update matrix
+#pragma unroll
+            for (int s2 = 0; s2 < 6; ++s2) { double v = mine[s2]; for (int c = 0; c < s2; ++c) v -= xr[c] * s_diag[s2 * 6 + c]; xr[s2] = v * s_diag[s2 * 7]; }
+            double* row = Lvals + (size_t)(c0 + q) * 36 + r * 6;
+#pragma unroll
+            for (int s2 = 0; s2 < 6; ++s2) row[s2] = xr[s2];
+            if (q >= af) {
+#pragma unroll
+                for (int s2 = 0; s2 < 6; ++s2) s_Ljk[(q - af) * 36 + r * 6 + s2] = xr[s2];       // keep the ancestor rows for the update matrix
+            }
         }
         __syncthreads();
         const int ri = broot_of_col[j];
@@ -1470,13 +1505,33 @@ __global__ __launch_bounds__(256) void pg_factor_subtree_kernel(const int* __res
                 const double* La = s_Ljk + pa * 36 + a * 6;
                 g[arel[pa] * 6 + a] -= La[0] * s_y[0] + La[1] * s_y[1] + La[2] * s_y[2] + La[3] * s_y[3] + La[4] * s_y[4] + La[5] * s_y[5];
             }
-            for (int pa = 0; pa < ta; ++pa) {                           // U[ia][ib] -= L_a L_b^T for the block pairs ib <= ia
-                const int ia = arel[pa];
-                for (int e = threadIdx.x; e < 36 * (pa + 1); e += 256) {
-                    const int pb = e / 36, ab = e - 36 * pb, a = ab / 6, b = ab - 6 * a;
-                    const double* La = s_Ljk + pa * 36 + a * 6; const double* Lb = s_Ljk + pb * 36 + b * 6;
-                    U[(size_t)(ia * 6 + a) * b6 + arel[pb] * 6 + b] -= La[0] * Lb[0] + La[1] * Lb[1] + La[2] * Lb[2] + La[3] * Lb[3] + La[4] * Lb[4] + La[5] * Lb[5];
+            // U[ia][ib] -= L_a L_b^T for the block pairs pb <= pa: one flat pass over the ta x ta pairs (the upper ones are skipped),
+            // every element touched by exactly one thread, four read-modify-writes in flight
+            const int ne = 36 * ta * ta;
+            for (int e0 = threadIdx.x; e0 < ne; e0 += 4 * 256) {
+                double* dst[4]; double old[4], sub[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int e = e0 + u * 256;
+                    dst[u] = nullptr; old[u] = 0; sub[u] = 0;
+                    if (e < ne) {
+                        const int blk = e / 36, ab = e - 36 * blk, pa = blk / ta, pb = blk - pa * ta, a = ab / 6, b = ab - 6 * a;
+                        if (pb <= pa) dst[u] = U + (size_t)(arel[pa] * 6 + a) * b6 + arel[pb] * 6 + b;
+                    }
                 }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) if (dst[u]) old[u] = *dst[u];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int e = e0 + u * 256;
+                    if (dst[u]) {
+                        const int blk = e / 36, ab = e - 36 * blk, pa = blk / ta, pb = blk - pa * ta, a = ab / 6, b = ab - 6 * a;
+                        const double* La = s_Ljk + pa * 36 + a * 6; const double* Lb = s_Ljk + pb * 36 + b * 6;
+                        sub[u] = La[0] * Lb[0] + La[1] * Lb[1] + La[2] * Lb[2] + La[3] * Lb[3] + La[4] * Lb[4] + La[5] * Lb[5];
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) if (dst[u]) *dst[u] = old[u] - sub[u];
             }
         }
         __syncthreads();
@@ -2480,13 +2535,20 @@ int dsss_posegraph_solve(dsss_ctx* c, int nframes, double* poses12, double* rpy6
         // ping's "last pair wins" choice is rank-local): exchange them with two small all-reduces (counts, then the records in
         // rank order = ascending target pose, the reference's loop order)
         std::vector<double> cnt(world, 0.0); cnt[rank] = ne;
-        double* d_tmp = nullptr;
-        HIPCHK(c, hipMalloc(&d_tmp, world * sizeof(double)));
+        auto xch = [&](size_t n) -> int {                    // device scratch of the exchange, kept by the context (a hipMalloc / hipFree pair per call cost 0.3 ms)
+            if (c->xch_cap >= n) return DSSS_OK;
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+            hipFree(c->xch_dev); c->xch_dev = nullptr; c->xch_cap = 0;
+            const size_t cap = n + n / 2 + 1024;
+            HIPCHK(c, hipMalloc(&c->xch_dev, cap * sizeof(double))); c->xch_cap = cap;
+            return DSSS_OK;
+        };
+        rc = xch(world); if (rc) return rc;
+        double* d_tmp = c->xch_dev;
         hipError_t e = hipMemcpyAsync(d_tmp, cnt.data(), world * sizeof(double), hipMemcpyHostToDevice, c->stream);
-        if (e == hipSuccess) { rc = dsss_comm_allreduce(c, d_tmp, world, c->stream); if (rc) { hipFree(d_tmp); return rc; } }
+        if (e == hipSuccess) { rc = dsss_comm_allreduce(c, d_tmp, world, c->stream); if (rc) return rc; }
         if (e == hipSuccess) e = hipMemcpyAsync(cnt.data(), d_tmp, world * sizeof(double), hipMemcpyDeviceToHost, c->stream);
         if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-        hipFree(d_tmp);
         HIPCHK(c, e);
         size_t off = 0, tot = 0;
         for (int r = 0; r < world; ++r) { if (r < rank) off += (size_t)cnt[r]; tot += (size_t)cnt[r]; }
@@ -2498,12 +2560,12 @@ int dsss_posegraph_solve(dsss_ctx* c, int nframes, double* poses12, double* rpy6
             for (int k = 0; k < 6; ++k) q[14 + k] = edges_p[i].var[k];
         }
         if (tot > 0) {
-            HIPCHK(c, hipMalloc(&d_tmp, rec.size() * sizeof(double)));
+            rc = xch(rec.size()); if (rc) return rc;
+            d_tmp = c->xch_dev;
             e = hipMemcpyAsync(d_tmp, rec.data(), rec.size() * sizeof(double), hipMemcpyHostToDevice, c->stream);
-            if (e == hipSuccess) { rc = dsss_comm_allreduce(c, d_tmp, tot * 20, c->stream); if (rc) { hipFree(d_tmp); return rc; } }
+            if (e == hipSuccess) { rc = dsss_comm_allreduce(c, d_tmp, tot * 20, c->stream); if (rc) return rc; }
             if (e == hipSuccess) e = hipMemcpyAsync(rec.data(), d_tmp, rec.size() * sizeof(double), hipMemcpyDeviceToHost, c->stream);
             if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-            hipFree(d_tmp);
             HIPCHK(c, e);
         }
         edges.resize(std::max<size_t>(tot, 1)); ne = (int)tot;

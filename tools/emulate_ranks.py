@@ -155,6 +155,13 @@ def replay_rank(wl, world, r, log, data, steps=5, warmup=2, device=0, profile=Fa
         pipe.ctx.sync()
         brk = {k: round(v[0], 3) for k, v in pipe.ctx.profile_get().items() if v[1] > 0}
         pipe.ctx.profile(False)
+        # wall time of the four host-visible stages (each closed by a stream synchronisation): frames, extraction + feature
+        # all-gather, matching + mini-LMs, pose graph (selection, edge exchange, solve, trajectory all-reduce)
+        rp.begin_step()
+        st = {}
+        for name, fn in (("frames", lambda: pipe.set_frames(my_raws, poses, alts, grs)), ("extract+allgather", pipe.extract), ("match+lc", pipe.match), ("posegraph", pipe.optimize)):
+            t1 = time.perf_counter(); fn(); pipe.ctx.sync(); st[name] = round(1e3 * (time.perf_counter() - t1), 3)
+        brk["stage_wall_ms"] = st
     out = res[0].copy()
     pipe.close()
     # wire model: ring all-reduce moves 2 (W-1)/W of the buffer over every link, all-gather (W-1)/W of the total
