@@ -553,43 +553,6 @@ __global__ __launch_bounds__(256) void pg_build_map_kernel(int nupd, const int* 
 }
 
 #define PG_TCH 128
-// acc[s] += sum_t L(i,k_t)[r][:] . L(j,k_t)[s][:] for the tn updates staged in LDS.  Updates that do not touch this
-// row (map entry -1) are masked instead of skipped, and four updates are in flight at once, so the index load and the
-// six operand loads of different updates overlap instead of forming one dependent chain per update.
-__device__ inline void pg_acc_rows(const int* __restrict__ mp, int m, int tn, const double* __restrict__ Lvals, int r,
-                                   const double* __restrict__ s_Ljk, double* acc)
-{
-    int t = 0;
-    for (; t + 4 <= tn; t += 4) {
-        int pos[4]; double a[4][6];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) pos[u] = mp[(size_t)(t + u) * m];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const double* Lik = Lvals + (size_t)(pos[u] < 0 ? 0 : pos[u]) * 36 + r * 6;
-#pragma unroll
-            for (int c = 0; c < 6; ++c) a[u][c] = Lik[c];
-        }
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            if (pos[u] < 0) continue;
-            const double* B = s_Ljk + (t + u) * 36;
-#pragma unroll
-            for (int s = 0; s < 6; ++s)
-                acc[s] += a[u][0] * B[s * 6] + a[u][1] * B[s * 6 + 1] + a[u][2] * B[s * 6 + 2] + a[u][3] * B[s * 6 + 3] + a[u][4] * B[s * 6 + 4] + a[u][5] * B[s * 6 + 5];
-        }
-    }
-    for (; t < tn; ++t) {
-        const int pos = mp[(size_t)t * m];
-        if (pos < 0) continue;
-        const double* Lik = Lvals + (size_t)pos * 36 + r * 6;
-        const double* B = s_Ljk + t * 36;
-        const double a0 = Lik[0], a1 = Lik[1], a2 = Lik[2], a3 = Lik[3], a4 = Lik[4], a5 = Lik[5];
-#pragma unroll
-        for (int s = 0; s < 6; ++s)
-            acc[s] += a0 * B[s * 6] + a1 * B[s * 6 + 1] + a2 * B[s * 6 + 2] + a3 * B[s * 6 + 3] + a4 * B[s * 6 + 4] + a5 * B[s * 6 + 5];
-    }
-}
 // ---- multifrontal top of the tree (dsss_pg_sym.h).  A front is a dense ld x ld lower-triangular image
 //          [ F11            ]   s6 own scalar columns          assembled from the original entries + the update matrices of its
 //          [ F21   F22      ]   n6 - s6 boundary rows          children (extend-add), factorised in 96-column panel steps:
@@ -1380,6 +1343,41 @@ __global__ __launch_bounds__(1024) void pg_front_bwd2_kernel(const int* __restri
 // (6m <= 256 rows: one pass) are binned.  Every finished column also adds its outer product over the rows BEYOND its subtree
 // root to the root's update matrix U_root (and L y to its right-hand side part): what the first front above the bin
 // extend-adds, exactly like the F22 of a child front.  One workgroup owns a bin, columns in fixed order: deterministic.
+// acc[s] += sum over the updates t = t0, t0 + tstep, ... < tn of A_t[0..5] . L(j,k_t)[s][:], where A_t is row r of L(i_q, k_t) (looked up
+// through the update map, skipped when the block does not exist) or, for the right-hand-side pseudo-row, y_(k_t).  Six updates in
+// flight: the index load and the operand loads of different updates overlap.
+__device__ inline void pg_acc_group(const int* __restrict__ mp, int m, int tn, int t0, int tstep, const double* __restrict__ Lvals, int r, bool is_rhs,
+                                    const double* __restrict__ s_Ljk, const double* __restrict__ s_yk, double* acc)
+{
+    constexpr int U = 6;
+    for (int tb = t0; tb < tn; tb += U * tstep) {
+        int pos[U]; double a[U][6];
+#pragma unroll
+        for (int u = 0; u < U; ++u) { const int t = tb + u * tstep; pos[u] = (t < tn && !is_rhs) ? mp[(size_t)t * m] : -1; }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int t = tb + u * tstep;
+            if (is_rhs) {
+#pragma unroll
+                for (int c = 0; c < 6; ++c) a[u][c] = t < tn ? s_yk[t * 6 + c] : 0.0;
+            } else {
+                const double* Lik = Lvals + (size_t)(pos[u] < 0 ? 0 : pos[u]) * 36 + r * 6;
+#pragma unroll
+                for (int c = 0; c < 6; ++c) a[u][c] = Lik[c];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int t = tb + u * tstep;
+            if (t >= tn || (!is_rhs && pos[u] < 0)) continue;
+            const double* B = s_Ljk + t * 36;
+#pragma unroll
+            for (int s2 = 0; s2 < 6; ++s2)
+                acc[s2] += a[u][0] * B[s2 * 6] + a[u][1] * B[s2 * 6 + 1] + a[u][2] * B[s2 * 6 + 2] + a[u][3] * B[s2 * 6 + 3] + a[u][4] * B[s2 * 6 + 4] + a[u][5] * B[s2 * 6 + 5];
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void pg_factor_subtree_kernel(const int* __restrict__ binptr, const int* __restrict__ bincols,
                                                                 const int* __restrict__ colptr, const int* __restrict__ rlptr,
                                                                 const int* __restrict__ rlcol, const int* __restrict__ rlpos,
@@ -1390,13 +1388,15 @@ __global__ __launch_bounds__(256) void pg_factor_subtree_kernel(const int* __res
                                                                 const int* __restrict__ broot_of_col, const int* __restrict__ anc_first,
                                                                 const int* __restrict__ anc_rel, double* __restrict__ ubin)
 {
-    // A column costs a handful of DEPENDENT round trips, and they are what its time is made of (round 2: ~15 us per column).  So:
-    // the thread that owns row (q, r) of the column requests its old values BEFORE the updates are gathered and keeps the row in
-    // registers from the update to the row solve (it used to be stored and read back twice); the pivot block and the right-hand
-    // side travel through LDS, not memory; the pivot is factorised with reciprocal square roots (1 / L_jj stays on the diagonal, the
-    // solves multiply); and the outer product into the update matrix of the subtree root is ONE flat pass over its block pairs
-    // with four read-modify-writes in flight per thread (it was a loop over block rows, one round trip each).
-    __shared__ double s_Ljk[PG_TCH * 36];          // update staging; reused for the column's ancestor blocks (42 x 36)
+    // A column's time is its chain of DEPENDENT round trips (round 2: ~15 us per column), most of it the update gather: every
+    // row (q, r) of the column walked ALL its T source columns, one dependent (map entry -> block) pair after the other, and a
+    // column of m blocks kept only 6 m of the 256 threads busy.  Now the workgroup is cut into 256 / (6 m + 1) thread groups that take
+    // every ngrp-th update each (six in flight per thread) and the partial sums are folded through LDS in group order (fixed:
+    // deterministic); the right-hand side is one more row of the same product.  Besides: the owner of a row requests its old values
+    // BEFORE the gather and keeps the row in registers up to the row solve; the pivot block and the right-hand side travel through
+    // LDS, not memory; the pivot is factorised with reciprocal square roots; and the outer product into the update matrix of the
+    // subtree root is ONE flat pass over its block pairs with four read-modify-writes in flight per thread.
+    __shared__ double s_Ljk[PG_TCH * 36];          // update staging; reused for the partial sums and for the column's ancestor blocks (42 x 36)
     __shared__ double s_yk[PG_TCH * 6];
     __shared__ double s_diag[36];
     __shared__ double s_y[6];
@@ -1410,19 +1410,24 @@ __global__ __launch_bounds__(256) void pg_factor_subtree_kernel(const int* __res
         const int c0 = colptr[j], m = colptr[j + 1] - c0;
         const int t0 = rlptr[j], T = rlptr[j + 1] - t0;
         const int* mp = upd_map + mapptr[j];
-        const int idx = threadIdx.x;
-        const bool act = idx < 6 * m;
-        const int q = act ? idx / 6 : 0, r = idx - q * 6;
-        const bool rhs = threadIdx.x >= 250;
-        const int rs_ = threadIdx.x - 250;
-        double acc[6] = { 0, 0, 0, 0, 0, 0 }, accy = 0;
-        double mine[6] = { 0, 0, 0, 0, 0, 0 }, xold = 0;     // this thread's row of the column / component of the right-hand side: in flight under the gather
+        const int gs = 6 * m + 1, ngrp = 256 / gs;                      // m <= 42: at least one group
+        const int grp = (int)threadIdx.x / gs, li = (int)threadIdx.x - grp * gs;
+        const bool ingrp = grp < ngrp;
+        const bool is_rhs = li == 6 * m;
+        const int q = is_rhs ? 0 : li / 6, r = is_rhs ? 0 : li - q * 6;
+        const bool act = ingrp && grp == 0 && !is_rhs;                   // owner of row (q, r) of the column
+        const bool rhs = ingrp && grp == 0 && is_rhs;                    // owner of the right-hand side
+        double acc[6] = { 0, 0, 0, 0, 0, 0 };
+        double mine[6] = { 0, 0, 0, 0, 0, 0 };                           // the owner's row of the column / the right-hand side: in flight under the gather
         if (act) {
             const double* row = Lvals + (size_t)(c0 + q) * 36 + r * 6;
 #pragma unroll
             for (int s2 = 0; s2 < 6; ++s2) mine[s2] = row[s2];
         }
-        if (rhs) xold = x[(size_t)j * 6 + rs_];
+        if (rhs) {
+#pragma unroll
+            for (int s2 = 0; s2 < 6; ++s2) mine[s2] = x[(size_t)j * 6 + s2];
+        }
         for (int tc = 0; tc < T; tc += PG_TCH) {
             const int tn = min(PG_TCH, T - tc);
             __syncthreads();
@@ -1437,25 +1442,34 @@ __global__ __launch_bounds__(256) void pg_factor_subtree_kernel(const int* __res
             }
             for (int xx = threadIdx.x; xx < tn * 6; xx += 256) s_yk[xx] = x[(size_t)rlcol[t0 + tc + xx / 6] * 6 + (xx % 6)];
             __syncthreads();
-            if (rhs)
-                for (int t = 0; t < tn; ++t) {
-                    const double* yk = s_yk + t * 6; const double* B = s_Ljk + t * 36 + rs_ * 6;
-                    accy += B[0] * yk[0] + B[1] * yk[1] + B[2] * yk[2] + B[3] * yk[3] + B[4] * yk[4] + B[5] * yk[5];
+            if (ingrp) pg_acc_group(mp + (size_t)tc * m + q, m, tn, grp, ngrp, Lvals, r, is_rhs, s_Ljk, s_yk, acc);
+        }
+        __syncthreads();                                   // (the staging area is free again)
+        if (T > 0 && ngrp > 1) {                           // fold the groups' partial sums, in group order
+            if (ingrp && grp > 0) {
+#pragma unroll
+                for (int s2 = 0; s2 < 6; ++s2) s_Ljk[((grp - 1) * gs + li) * 6 + s2] = acc[s2];
+            }
+            __syncthreads();
+            if (ingrp && grp == 0)
+                for (int g2 = 1; g2 < ngrp; ++g2) {
+#pragma unroll
+                    for (int s2 = 0; s2 < 6; ++s2) acc[s2] += s_Ljk[((g2 - 1) * gs + li) * 6 + s2];
                 }
-            if (act)
-                pg_acc_rows(mp + (size_t)tc * m + q, m, tn, Lvals, r, s_Ljk, acc);
+            __syncthreads();
         }
         if (T > 0) {
 #pragma unroll
             for (int s2 = 0; s2 < 6; ++s2) mine[s2] -= acc[s2];
-            xold -= accy;
         }
-        __syncthreads();                                   // (the staging area is free again)
         if (act && q == 0) {
 #pragma unroll
             for (int s2 = 0; s2 < 6; ++s2) s_diag[r * 6 + s2] = mine[s2];
         }
-        if (rhs) s_y[rs_] = xold;
+        if (rhs) {
+#pragma unroll
+            for (int s2 = 0; s2 < 6; ++s2) s_y[s2] = mine[s2];
+        }
         __syncthreads();
         if (threadIdx.x == 0) {
             double A[36];
@@ -1481,7 +1495,7 @@ __global__ __launch_bounds__(256) void pg_factor_subtree_kernel(const int* __res
         __syncthreads();
         if (!s_ok) return;
         const int af = anc_first[j], ta = m - af;                       // block rows beyond the subtree root (a suffix of the column)
-        if (act && idx >= 6) {
+        if (act && q >= 1) {
             double xr[6];
 #pragma unroll
             for (int s2 = 0; s2 < 6; ++s2) { double v = mine[s2]; for (int c = 0; c < s2; ++c) v -= xr[c] * s_diag[s2 * 6 + c]; xr[s2] = v * s_diag[s2 * 7]; }
