@@ -1343,41 +1343,43 @@ __global__ __launch_bounds__(1024) void pg_front_bwd2_kernel(const int* __restri
 // (6m <= 256 rows: one pass) are binned.  Every finished column also adds its outer product over the rows BEYOND its subtree
 // root to the root's update matrix U_root (and L y to its right-hand side part): what the first front above the bin
 // extend-adds, exactly like the F22 of a child front.  One workgroup owns a bin, columns in fixed order: deterministic.
-// acc[s] += sum over the updates t = t0, t0 + tstep, ... < tn of A_t[0..5] . L(j,k_t)[s][:], where A_t is row r of L(i_q, k_t) (looked up
-// through the update map, skipped when the block does not exist) or, for the right-hand-side pseudo-row, y_(k_t).  Six updates in
-// flight: the index load and the operand loads of different updates overlap.
-__device__ inline void pg_acc_group(const int* __restrict__ mp, int m, int tn, int t0, int tstep, const double* __restrict__ Lvals, int r, bool is_rhs,
-                                    const double* __restrict__ s_Ljk, const double* __restrict__ s_yk, double* acc)
+// acc[s] += sum_t L(i,k_t)[r][:] . L(j,k_t)[s][:] for the tn updates staged in LDS.  Updates that do not touch this
+// row (map entry -1) are masked instead of skipped, and four updates are in flight at once, so the index load and the
+// six operand loads of different updates overlap instead of forming one dependent chain per update.
+__device__ inline void pg_acc_rows(const int* __restrict__ mp, int m, int tn, const double* __restrict__ Lvals, int r,
+                                   const double* __restrict__ s_Ljk, double* acc)
 {
-    constexpr int U = 6;
-    for (int tb = t0; tb < tn; tb += U * tstep) {
-        int pos[U]; double a[U][6];
+    int t = 0;
+    for (; t + 4 <= tn; t += 4) {
+        int pos[4]; double a[4][6];
 #pragma unroll
-        for (int u = 0; u < U; ++u) { const int t = tb + u * tstep; pos[u] = (t < tn && !is_rhs) ? mp[(size_t)t * m] : -1; }
+        for (int u = 0; u < 4; ++u) pos[u] = mp[(size_t)(t + u) * m];
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int t = tb + u * tstep;
-            if (is_rhs) {
+        for (int u = 0; u < 4; ++u) {
+            const double* Lik = Lvals + (size_t)(pos[u] < 0 ? 0 : pos[u]) * 36 + r * 6;
 #pragma unroll
-                for (int c = 0; c < 6; ++c) a[u][c] = t < tn ? s_yk[t * 6 + c] : 0.0;
-            } else {
-                const double* Lik = Lvals + (size_t)(pos[u] < 0 ? 0 : pos[u]) * 36 + r * 6;
-#pragma unroll
-                for (int c = 0; c < 6; ++c) a[u][c] = Lik[c];
-            }
+            for (int c = 0; c < 6; ++c) a[u][c] = Lik[c];
         }
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int t = tb + u * tstep;
-            if (t >= tn || (!is_rhs && pos[u] < 0)) continue;
-            const double* B = s_Ljk + t * 36;
+        for (int u = 0; u < 4; ++u) {
+            if (pos[u] < 0) continue;
+            const double* B = s_Ljk + (t + u) * 36;
 #pragma unroll
-            for (int s2 = 0; s2 < 6; ++s2)
-                acc[s2] += a[u][0] * B[s2 * 6] + a[u][1] * B[s2 * 6 + 1] + a[u][2] * B[s2 * 6 + 2] + a[u][3] * B[s2 * 6 + 3] + a[u][4] * B[s2 * 6 + 4] + a[u][5] * B[s2 * 6 + 5];
+            for (int s = 0; s < 6; ++s)
+                acc[s] += a[u][0] * B[s * 6] + a[u][1] * B[s * 6 + 1] + a[u][2] * B[s * 6 + 2] + a[u][3] * B[s * 6 + 3] + a[u][4] * B[s * 6 + 4] + a[u][5] * B[s * 6 + 5];
         }
     }
+    for (; t < tn; ++t) {
+        const int pos = mp[(size_t)t * m];
+        if (pos < 0) continue;
+        const double* Lik = Lvals + (size_t)pos * 36 + r * 6;
+        const double* B = s_Ljk + t * 36;
+        const double a0 = Lik[0], a1 = Lik[1], a2 = Lik[2], a3 = Lik[3], a4 = Lik[4], a5 = Lik[5];
+#pragma unroll
+        for (int s = 0; s < 6; ++s)
+            acc[s] += a0 * B[s * 6] + a1 * B[s * 6 + 1] + a2 * B[s * 6 + 2] + a3 * B[s * 6 + 3] + a4 * B[s * 6 + 4] + a5 * B[s * 6 + 5];
+    }
 }
-
 __global__ __launch_bounds__(256) void pg_factor_subtree_kernel(const int* __restrict__ binptr, const int* __restrict__ bincols,
                                                                 const int* __restrict__ colptr, const int* __restrict__ rlptr,
                                                                 const int* __restrict__ rlcol, const int* __restrict__ rlpos,
@@ -1388,15 +1390,7 @@ __global__ __launch_bounds__(256) void pg_factor_subtree_kernel(const int* __res
                                                                 const int* __restrict__ broot_of_col, const int* __restrict__ anc_first,
                                                                 const int* __restrict__ anc_rel, double* __restrict__ ubin)
 {
-    // A column's time is its chain of DEPENDENT round trips (round 2: ~15 us per column), most of it the update gather: every
-    // row (q, r) of the column walked ALL its T source columns, one dependent (map entry -> block) pair after the other, and a
-    // column of m blocks kept only 6 m of the 256 threads busy.  Now the workgroup is cut into 256 / (6 m + 1) thread groups that take
-    // every ngrp-th update each (six in flight per thread) and the partial sums are folded through LDS in group order (fixed:
-    // deterministic); the right-hand side is one more row of the same product.  Besides: the owner of a row requests its old values
-    // BEFORE the gather and keeps the row in registers up to the row solve; the pivot block and the right-hand side travel through
-    // LDS, not memory; the pivot is factorised with reciprocal square roots; and the outer product into the update matrix of the
-    // subtree root is ONE flat pass over its block pairs with four read-modify-writes in flight per thread.
-    __shared__ double s_Ljk[PG_TCH * 36];          // update staging; reused for the partial sums and for the column's ancestor blocks (42 x 36)
+    __shared__ double s_Ljk[PG_TCH * 36];          // update staging; reused for the column's ancestor blocks (42 x 36)
     __shared__ double s_yk[PG_TCH * 6];
     __shared__ double s_diag[36];
     __shared__ double s_y[6];
@@ -1410,24 +1404,12 @@ __global__ __launch_bounds__(256) void pg_factor_subtree_kernel(const int* __res
         const int c0 = colptr[j], m = colptr[j + 1] - c0;
         const int t0 = rlptr[j], T = rlptr[j + 1] - t0;
         const int* mp = upd_map + mapptr[j];
-        const int gs = 6 * m + 1, ngrp = 256 / gs;                      // m <= 42: at least one group
-        const int grp = (int)threadIdx.x / gs, li = (int)threadIdx.x - grp * gs;
-        const bool ingrp = grp < ngrp;
-        const bool is_rhs = li == 6 * m;
-        const int q = is_rhs ? 0 : li / 6, r = is_rhs ? 0 : li - q * 6;
-        const bool act = ingrp && grp == 0 && !is_rhs;                   // owner of row (q, r) of the column
-        const bool rhs = ingrp && grp == 0 && is_rhs;                    // owner of the right-hand side
-        double acc[6] = { 0, 0, 0, 0, 0, 0 };
-        double mine[6] = { 0, 0, 0, 0, 0, 0 };                           // the owner's row of the column / the right-hand side: in flight under the gather
-        if (act) {
-            const double* row = Lvals + (size_t)(c0 + q) * 36 + r * 6;
-#pragma unroll
-            for (int s2 = 0; s2 < 6; ++s2) mine[s2] = row[s2];
-        }
-        if (rhs) {
-#pragma unroll
-            for (int s2 = 0; s2 < 6; ++s2) mine[s2] = x[(size_t)j * 6 + s2];
-        }
+        const int idx = threadIdx.x;
+        const bool act = idx < 6 * m;
+        const int q = act ? idx / 6 : 0, r = idx - q * 6;
+        const bool rhs = threadIdx.x >= 250;
+        const int rs_ = threadIdx.x - 250;
+        double acc[6] = { 0, 0, 0, 0, 0, 0 }, accy = 0;
         for (int tc = 0; tc < T; tc += PG_TCH) {
             const int tn = min(PG_TCH, T - tc);
             __syncthreads();
@@ -1442,70 +1424,39 @@ __global__ __launch_bounds__(256) void pg_factor_subtree_kernel(const int* __res
             }
             for (int xx = threadIdx.x; xx < tn * 6; xx += 256) s_yk[xx] = x[(size_t)rlcol[t0 + tc + xx / 6] * 6 + (xx % 6)];
             __syncthreads();
-            if (ingrp) pg_acc_group(mp + (size_t)tc * m + q, m, tn, grp, ngrp, Lvals, r, is_rhs, s_Ljk, s_yk, acc);
-        }
-        __syncthreads();                                   // (the staging area is free again)
-        if (T > 0 && ngrp > 1) {                           // fold the groups' partial sums, in group order
-            if (ingrp && grp > 0) {
-#pragma unroll
-                for (int s2 = 0; s2 < 6; ++s2) s_Ljk[((grp - 1) * gs + li) * 6 + s2] = acc[s2];
-            }
-            __syncthreads();
-            if (ingrp && grp == 0)
-                for (int g2 = 1; g2 < ngrp; ++g2) {
-#pragma unroll
-                    for (int s2 = 0; s2 < 6; ++s2) acc[s2] += s_Ljk[((g2 - 1) * gs + li) * 6 + s2];
+            if (rhs)
+                for (int t = 0; t < tn; ++t) {
+                    const double* yk = s_yk + t * 6; const double* B = s_Ljk + t * 36 + rs_ * 6;
+                    accy += B[0] * yk[0] + B[1] * yk[1] + B[2] * yk[2] + B[3] * yk[3] + B[4] * yk[4] + B[5] * yk[5];
                 }
-            __syncthreads();
+            if (act)
+                pg_acc_rows(mp + (size_t)tc * m + q, m, tn, Lvals, r, s_Ljk, acc);
         }
-        if (T > 0) {
-#pragma unroll
-            for (int s2 = 0; s2 < 6; ++s2) mine[s2] -= acc[s2];
-        }
-        if (act && q == 0) {
-#pragma unroll
-            for (int s2 = 0; s2 < 6; ++s2) s_diag[r * 6 + s2] = mine[s2];
-        }
-        if (rhs) {
-#pragma unroll
-            for (int s2 = 0; s2 < 6; ++s2) s_y[s2] = mine[s2];
-        }
+        if (rhs && T > 0) x[(size_t)j * 6 + rs_] -= accy;
+        if (act && T > 0) for (int s = 0; s < 6; ++s) Lvals[(size_t)(c0 + q) * 36 + r * 6 + s] -= acc[s];
         __syncthreads();
         if (threadIdx.x == 0) {
             double A[36];
-#pragma unroll
-            for (int a = 0; a < 36; ++a) A[a] = s_diag[a];
-            const int bad = chol6_rdiag(A);                // lower triangle = L, diagonal = 1 / L_jj
+            for (int a = 0; a < 36; ++a) A[a] = Lvals[(size_t)c0 * 36 + a];
+            const int bad = chol6(A);
             if (bad) *fail = 1;
             s_ok = !bad;
-            double v[6];
-#pragma unroll
-            for (int a = 0; a < 6; ++a) { double t = s_y[a]; for (int b = 0; b < a; ++b) t -= A[a * 6 + b] * v[b]; v[a] = t * A[a * 7]; }
-#pragma unroll
-            for (int a = 0; a < 6; ++a)
-#pragma unroll
-                for (int b = 0; b < 6; ++b) {
-                    const double lv = b < a ? A[a * 6 + b] : (b == a ? 1.0 / A[a * 7] : 0.0);     // the factor as every reader expects it: L_jj on the diagonal
-                    s_diag[a * 6 + b] = b <= a ? A[a * 6 + b] : 0.0;                              // for the row solves below: 1 / L_jj on the diagonal
-                    Lvals[(size_t)c0 * 36 + a * 6 + b] = lv;
-                }
-#pragma unroll
-            for (int a = 0; a < 6; ++a) { s_y[a] = v[a]; if (!bad) x[(size_t)j * 6 + a] = v[a]; }
+            for (int a = 0; a < 6; ++a) for (int b = 0; b < 6; ++b) { const double v = b <= a ? A[a * 6 + b] : 0.0; s_diag[a * 6 + b] = v; Lvals[(size_t)c0 * 36 + a * 6 + b] = v; }
+            if (!bad) {
+                double v[6];
+                for (int a = 0; a < 6; ++a) { double t = x[(size_t)j * 6 + a]; for (int b = 0; b < a; ++b) t -= A[a * 6 + b] * v[b]; v[a] = t / A[a * 6 + a]; }
+                for (int a = 0; a < 6; ++a) { x[(size_t)j * 6 + a] = v[a]; s_y[a] = v[a]; }
+            }
         }
         __syncthreads();
         if (!s_ok) return;
         const int af = anc_first[j], ta = m - af;                       // block rows beyond the subtree root (a suffix of the column)
-        if (act && q >= 1) {
-            double xr[6];
-#pragma unroll
-            for (int s2 = 0; s2 < 6; ++s2) { double v = mine[s2]; for (int c = 0; c < s2; ++c) v -= xr[c] * s_diag[s2 * 6 + c]; xr[s2] = v * s_diag[s2 * 7]; }
+        if (act && idx >= 6) {
             double* row = Lvals + (size_t)(c0 + q) * 36 + r * 6;
-#pragma unroll
-            for (int s2 = 0; s2 < 6; ++s2) row[s2] = xr[s2];
-            if (q >= af) {
-#pragma unroll
-                for (int s2 = 0; s2 < 6; ++s2) s_Ljk[(q - af) * 36 + r * 6 + s2] = xr[s2];       // keep the ancestor rows for the update matrix
-            }
+            double xr[6];
+            for (int s = 0; s < 6; ++s) { double v = row[s]; for (int c = 0; c < s; ++c) v -= xr[c] * s_diag[s * 6 + c]; xr[s] = v / s_diag[s * 6 + s]; }
+            for (int s = 0; s < 6; ++s) row[s] = xr[s];
+            if (q >= af) for (int s = 0; s < 6; ++s) s_Ljk[(q - af) * 36 + r * 6 + s] = xr[s];       // keep the ancestor rows for the update matrix
         }
         __syncthreads();
         const int ri = broot_of_col[j];
@@ -1519,33 +1470,13 @@ __global__ __launch_bounds__(256) void pg_factor_subtree_kernel(const int* __res
                 const double* La = s_Ljk + pa * 36 + a * 6;
                 g[arel[pa] * 6 + a] -= La[0] * s_y[0] + La[1] * s_y[1] + La[2] * s_y[2] + La[3] * s_y[3] + La[4] * s_y[4] + La[5] * s_y[5];
             }
-            // U[ia][ib] -= L_a L_b^T for the block pairs pb <= pa: one flat pass over the ta x ta pairs (the upper ones are skipped),
-            // every element touched by exactly one thread, four read-modify-writes in flight
-            const int ne = 36 * ta * ta;
-            for (int e0 = threadIdx.x; e0 < ne; e0 += 4 * 256) {
-                double* dst[4]; double old[4], sub[4];
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const int e = e0 + u * 256;
-                    dst[u] = nullptr; old[u] = 0; sub[u] = 0;
-                    if (e < ne) {
-                        const int blk = e / 36, ab = e - 36 * blk, pa = blk / ta, pb = blk - pa * ta, a = ab / 6, b = ab - 6 * a;
-                        if (pb <= pa) dst[u] = U + (size_t)(arel[pa] * 6 + a) * b6 + arel[pb] * 6 + b;
-                    }
+            for (int pa = 0; pa < ta; ++pa) {                           // U[ia][ib] -= L_a L_b^T for the block pairs ib <= ia
+                const int ia = arel[pa];
+                for (int e = threadIdx.x; e < 36 * (pa + 1); e += 256) {
+                    const int pb = e / 36, ab = e - 36 * pb, a = ab / 6, b = ab - 6 * a;
+                    const double* La = s_Ljk + pa * 36 + a * 6; const double* Lb = s_Ljk + pb * 36 + b * 6;
+                    U[(size_t)(ia * 6 + a) * b6 + arel[pb] * 6 + b] -= La[0] * Lb[0] + La[1] * Lb[1] + La[2] * Lb[2] + La[3] * Lb[3] + La[4] * Lb[4] + La[5] * Lb[5];
                 }
-#pragma unroll
-                for (int u = 0; u < 4; ++u) if (dst[u]) old[u] = *dst[u];
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const int e = e0 + u * 256;
-                    if (dst[u]) {
-                        const int blk = e / 36, ab = e - 36 * blk, pa = blk / ta, pb = blk - pa * ta, a = ab / 6, b = ab - 6 * a;
-                        const double* La = s_Ljk + pa * 36 + a * 6; const double* Lb = s_Ljk + pb * 36 + b * 6;
-                        sub[u] = La[0] * Lb[0] + La[1] * Lb[1] + La[2] * Lb[2] + La[3] * Lb[3] + La[4] * Lb[4] + La[5] * Lb[5];
-                    }
-                }
-#pragma unroll
-                for (int u = 0; u < 4; ++u) if (dst[u]) *dst[u] = old[u] - sub[u];
             }
         }
         __syncthreads();

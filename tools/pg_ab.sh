@@ -1,4 +1,5 @@
 #!/bin/bash
 # quick A/B of the pose-graph solve on the dumped C3 graph (tools/dump_graph.py): wall time of dsss_posegraph_solve_edges per setting
 G=${1:-tools/_data/C3_edges.npz}
-for v in "X=1" "DSSS_PG_BIN_COST=300" "DSSS_PG_BIN_COST=450" "DSSS_PG_BIN_COST=800" "DSSS_PG_BIN_COST=1100"; do env $v python tools/pg_sweep.py $G 9 2>/dev/null | tail -1; done
+shift
+for v in "X=1" "$@"; do env $v python tools/pg_sweep.py $G 9 2>/dev/null | tail -2; done
