@@ -225,8 +225,11 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
     torch.cuda.set_device(local_rank)
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    # DSSS_BENCH_FORCE_COMM=1: drive the multi-rank code path (RCCL communicator inside the library, feature all-gather, edge exchange,
+    # interface all-reduce) with ONE rank -- a rehearsal of the N > 1 launch on a one-GPU box; the pose graph is cut into 8 partitions
+    force_comm = world == 1 and os.environ.get("DSSS_BENCH_FORCE_COMM") == "1"
+    if world > 1 or force_comm:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     wl = WORKLOADS[args.workload]
@@ -244,7 +247,9 @@ def main():
     poses = [sv.inputs(f)[0] for f in range(F)]; alts = [sv.inputs(f)[1] for f in range(F)]; grs = [sv.inputs(f)[2] for f in range(F)]
     torch.cuda.synchronize()
 
-    pipe = Pipeline(F, device=local_rank, rank=rank, world=world, dist=dist if world > 1 else None, nfeatures=wl.get("nfeatures"))
+    pipe = Pipeline(F, device=local_rank, rank=rank, world=world, dist=dist if (world > 1 or force_comm) else None, nfeatures=wl.get("nfeatures"), force_collectives=force_comm)
+    if force_comm:
+        pipe.ctx.set_pg_partitions(8)
 
     def barrier():
         if world > 1:
@@ -374,7 +379,7 @@ def main():
                        "parallelism": "contiguous frame blocks over %d rank(s): RCCL all-gather of features, pairs to the owner of the target frame, pose graph sharded with one RCCL all-reduce of the reduced Hessian per LM trial" % world},
             "roofline": roof, "roofline_stages": roof_groups, "roofline_all_kernels": roof_all, "breakdown_ms": breakdown, "work_per_step": work, "pcie_inclusive": pcie, "throughput_surveys_in_flight": inflight,
         }
-        if world > 1:
+        if world > 1 or force_comm:
             cs = pipe.ctx.comm_stats()
             out["comm"] = {"allreduce_bytes_total": cs[2], "calls": cs[3]}
         if args.cpu_frames > 0 and world == 1:
@@ -386,7 +391,7 @@ def main():
                 out["cpu_baseline_allcores"] = cpu_baseline(sv, wl, nf, threads=nthr)[0]
         print(json.dumps(out))
     pipe.close()
-    if world > 1:
+    if world > 1 or force_comm:
         dist.destroy_process_group()
 
 

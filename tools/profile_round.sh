@@ -3,7 +3,7 @@
 #   kernel trace + stats of the default bench command, then three SEPARATE counter passes (MI355X_MICROARCH.md "HBM" / "PMC slots":
 #   FETCH_SIZE and WRITE_SIZE do not fit one pass; counters never together with --sys-trace)
 # Output under gpurun_out/<tag>_*; tools/pmc_summary.py and tools/pmc_mfma_summary.py turn them into the tables under profiles/.
-TAG=${1:-r02}
+TAG=${1:-r03}
 cd /tmp && export TMPDIR=/tmp; cd "$GRAFT_REPO_ROOT"
 B="python3 bench.py --steps 3 --warmup 1 --cpu-frames 0 --pcie-steps 0 --jobs-in-flight 1"
 rocprofv3 --kernel-trace --stats -d gpurun_out/${TAG}_stats -o ${TAG} --output-format csv -- $B > gpurun_out/${TAG}_bench_under_rocprof.log 2>&1
