@@ -1234,13 +1234,141 @@ __global__ __launch_bounds__(256) void pg_front_trsm2_kernel(const int* __restri
     if (l < 16 && rok) R[fd.roff + row0 + rowbase + c] -= dot;
 }
 
+// ---- Row solve and trailing update FUSED per 64 x 64 tile (levels with at most PG_RSU_MAX_TILES tiles: every level but the few at the
+// bottom of the front tree).  pg_front_trsm2_kernel followed by pg_front_syrk_kernel costs two dependent launches per level, each with
+// its ~10 us floor (arrival of the data the previous kernel wrote, prologue, strided stores), for a few microseconds of products.
+// Here the workgroup of tile (ti, tj) solves BOTH row chunks it needs itself -- wavefronts 0..3 chunk ti (kept in registers: the tile
+// registers ARE the A operands of the update), wavefronts 4..7 chunk tj (into LDS, the B operands) -- by the very steps of
+// pg_front_trsm2_kernel, then updates the tile by the steps of pg_front_syrk_kernel: the same products in the same order, bit for bit.
+// A chunk is solved once per tile that needs it (redundant flops on idle matrix cores); the diagonal tile (ti, ti) of a chunk stores
+// its L21 rows and folds them into the right-hand side.  L21 goes to a SECOND front arena (FL): the tiles of a level run concurrently
+// and read A21 in place, which an in-place store would pull from under them (the race that stopped round 2's version of this).
+#define PG_RSU_MAX_TILES 320
+__global__ __launch_bounds__(512) void pg_front_rsu_kernel(const int* __restrict__ it_front, const int* __restrict__ it_step, const pg_front* __restrict__ FD,
+                                                           const int* __restrict__ tile_item, const int* __restrict__ tile_ij,
+                                                           double* __restrict__ F, double* __restrict__ FL, double* __restrict__ R, const double* __restrict__ Tinv)
+{
+    __shared__ double sL[(PG_PW * 6) * PG_T2_LD];      // L11 of the panel (lower triangle), the A operands of every solve step
+    __shared__ double sT[PG_NB4 * 16];                 // the 4 x 4 inverse blocks
+    __shared__ double sY[PG_PW * 6];
+    __shared__ double sB[64 * PG_SYRK_LD];             // solved chunk tj: the B operands of the update
+    const int item = tile_item[blockIdx.x], ij = tile_ij[blockIdx.x], ti = ij >> 16, tj = ij & 0xffff;
+    const pg_front fd = FD[it_front[item]];
+    const int step = it_step[item], col0 = 96 * step;
+    const int n = min(96, fd.s6 - col0), p = fd.pan0 + step, ld = fd.ld;
+    const int row0 = col0 + n, nrows = fd.n6 - row0;
+    const int wave = threadIdx.x >> 6, l = threadIdx.x & 63, c = l & 15, q = l >> 4;
+    const bool grp_i = wave < 4;                       // wavefronts 0..3: chunk ti; 4..7: chunk tj
+    const bool diag = ti == tj;
+    const int w4 = wave & 3;
+    const int rowbase = ((grp_i ? ti : tj) * 4 + w4) * 16;
+    const bool rok = rowbase + c < nrows;
+    const bool solve = grp_i || !diag;                 // on a diagonal tile the second group has nothing to solve
+    double* __restrict__ A = F + fd.off;
+    const double* __restrict__ Arow = A + (size_t)(row0 + min(max(rowbase + c, 0), nrows - 1)) * ld + col0;
+    pg_d4 S[6];                                        // the slab's own rows are requested first: their latency hides behind the staging of L11
+#pragma unroll
+    for (int T = 0; T < 6; ++T)
+#pragma unroll
+        for (int v = 0; v < 4; ++v) { const int col = 16 * T + q + 4 * v; S[T][v] = (solve && rok && col < n) ? Arow[col] : 0.0; }
+    // the tile of C this wavefront updates comes in with the operands too (first group only)
+    const int i0 = 64 * ti + 16 * w4;
+    pg_d4 acc[4];
+#pragma unroll
+    for (int cb = 0; cb < 4; ++cb) {
+        const int j0 = 64 * tj + 16 * cb, jr = j0 + (l & 15);
+        const double* __restrict__ Cp = A + (size_t)(row0 + i0 + (l >> 4)) * ld + row0 + j0 + (l & 15);
+#pragma unroll
+        for (int v = 0; v < 4; ++v) acc[cb][v] = (grp_i && i0 < nrows && j0 <= i0 + 15 && i0 + (l >> 4) + 4 * v < nrows && jr < nrows) ? Cp[(size_t)(4 * v) * ld] : 0.0;
+    }
+    {
+        const double* __restrict__ L11 = A + (size_t)col0 * ld + col0;
+        double v[18];
+#pragma unroll
+        for (int e = 0; e < 18; ++e) { const int id = e * 512 + threadIdx.x, r = id / 96, cc = id - 96 * r; v[e] = (r < n && cc <= r) ? L11[(size_t)r * ld + cc] : 0.0; }
+#pragma unroll
+        for (int e = 0; e < 18; ++e) { const int id = e * 512 + threadIdx.x, r = id / 96, cc = id - 96 * r; sL[r * PG_T2_LD + cc] = v[e]; }
+        for (int e = threadIdx.x; e < PG_NB4 * 16; e += 512) sT[e] = Tinv[(size_t)p * PG_NB4 * 16 + e];
+        if (threadIdx.x < 96) sY[threadIdx.x] = (int)threadIdx.x < n ? R[fd.roff + col0 + threadIdx.x] : 0.0;
+    }
+    __syncthreads();
+    if (solve && rowbase < nrows) {                    // wavefront-uniform: the 4-column steps of pg_front_trsm2_kernel
+        double lop_n, a_n[6];
+        auto fetch = [&](int t, int b) {
+            lop_n = c < 4 ? sT[(4 * t + b) * 16 + c * 4 + q] : 0.0;
+#pragma unroll
+            for (int T2 = 0; T2 < 6; ++T2) {
+                const int ri = 16 * T2 + c, ck = 16 * t + 4 * b + q;
+                a_n[T2] = (T2 > t || (T2 == t && c > 4 * b + 3)) ? -sL[ri * PG_T2_LD + ck] : 0.0;
+            }
+        };
+        fetch(0, 0);
+#pragma unroll
+        for (int t = 0; t < 6; ++t) {
+            if (16 * t >= n) break;
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                const double lop = lop_n;
+                double a[6];
+#pragma unroll
+                for (int T2 = 0; T2 < 6; ++T2) a[T2] = a_n[T2];
+                if (b < 3) fetch(t, b + 1); else if (t < 5) fetch(t + 1, 0);
+                const pg_d4 zero4 = { 0.0, 0.0, 0.0, 0.0 };
+                const pg_d4 r4 = __builtin_amdgcn_mfma_f64_16x16x4f64(lop, S[t][b], zero4, 0, 0, 0);
+                const double LP = r4[0];
+                S[t][b] = LP;
+#pragma unroll
+                for (int T2 = t; T2 < 6; ++T2) S[T2] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[T2], LP, S[T2], 0, 0, 0);
+            }
+        }
+    }
+    // chunk tj -> LDS in row-major order (the B operands); on a diagonal tile the first group's rows are that chunk
+    if (diag ? grp_i : !grp_i) {
+#pragma unroll
+        for (int T = 0; T < 6; ++T)
+#pragma unroll
+            for (int v = 0; v < 4; ++v) sB[(16 * w4 + c) * PG_SYRK_LD + 16 * T + q + 4 * v] = S[T][v];
+    }
+    if (diag && grp_i && rowbase < nrows) {            // the chunk's L21 rows for the back-substitution, and their share of the forward solve
+        double* __restrict__ Lrow = FL + fd.off + (size_t)(row0 + min(rowbase + c, nrows - 1)) * ld + col0;
+        double dot = 0;
+#pragma unroll
+        for (int T = 0; T < 6; ++T)
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                const int col = 16 * T + q + 4 * v;
+                if (col < n) { if (rok) Lrow[col] = S[T][v]; dot += S[T][v] * sY[col]; }
+            }
+        dot += __shfl_xor(dot, 16, 64);
+        dot += __shfl_xor(dot, 32, 64);
+        if (l < 16 && rok) R[fd.roff + row0 + rowbase + c] -= dot;
+    }
+    __syncthreads();
+    if (!grp_i || i0 >= nrows) return;
+    // A22 -= L21 L21^T on the tile: the steps of pg_front_syrk_kernel; A operand k = 4 ks + (l >> 4) of row (l & 15) is register (ks & 3) of
+    // tile register ks >> 2 of this very lane
+#pragma unroll
+    for (int cb = 0; cb < 4; ++cb) {
+        const int j0 = 64 * tj + 16 * cb;
+        if (j0 >= nrows || j0 > i0 + 15) break;
+        const int jr = j0 + (l & 15);
+        const double* __restrict__ sb = sB + (16 * cb + (l & 15)) * PG_SYRK_LD + (l >> 4);
+        double* __restrict__ Cp = A + (size_t)(row0 + i0 + (l >> 4)) * ld + row0 + j0 + (l & 15);
+        pg_d4 r = acc[cb];
+#pragma unroll
+        for (int ks = 0; ks < 24; ++ks) r = __builtin_amdgcn_mfma_f64_16x16x4f64(-S[ks >> 2][ks & 3], sb[4 * ks], r, 0, 0, 0);
+#pragma unroll
+        for (int v = 0; v < 4; ++v) if (i0 + (l >> 4) + 4 * v < nrows && jr < nrows) Cp[(size_t)(4 * v) * ld] = r[v];
+    }
+}
+
 // x1 = L11^-T (y1 - L21^T x2) for one panel: one workgroup of 1024 threads.  x2 (the rows below the panel) is gathered into LDS,
 // ten row slots accumulate the 96 column sums (folded in slot order), L11 goes global -> registers -> LDS behind them, and
 // wavefront 0 runs the block back-substitution: x_blk = Linv^T z_blk, z[earlier columns] -= L11[blk rows][columns]^T x_blk.
 #define PG_BWD2_LD 97
 #define PG_BWD2_SX 8192                         // rows of x2 the LDS stages; taller fronts read x2 through the row map
 __global__ __launch_bounds__(1024) void pg_front_bwd2_kernel(const int* __restrict__ it_front, const int* __restrict__ it_step, const pg_front* __restrict__ FD,
-                                                             const int* __restrict__ f_rows, const double* __restrict__ F, const double* __restrict__ R,
+                                                             const int* __restrict__ f_rows, const double* __restrict__ F, const double* __restrict__ FL, const double* __restrict__ R,
                                                              double* __restrict__ x, const double* __restrict__ Tinv)
 {
     extern __shared__ double s_bw[];               // L11 [96 x 97] | Tinv [24][16] | slot sums [10][96] | x2 [nrows]
@@ -1265,7 +1393,7 @@ __global__ __launch_bounds__(1024) void pg_front_bwd2_kernel(const int* __restri
         if (slot < 10) {
             double acc0 = 0, acc1 = 0;
             if (cc < n && !big) {
-                const double* __restrict__ Ab = F + fd.off + (size_t)row0 * ld + col0 + cc;
+                const double* __restrict__ Ab = FL + fd.off + (size_t)row0 * ld + col0 + cc;      // L21: in place, or in the second arena where the level ran the fused row solve + update
                 int i = slot;
                 for (; i + 150 < nrows; i += 160) {                // sixteen loads in flight
                     double a16[16];
@@ -1283,7 +1411,7 @@ __global__ __launch_bounds__(1024) void pg_front_bwd2_kernel(const int* __restri
                 }
                 for (; i < nrows; i += 10) acc0 += Ab[(size_t)i * ld] * sx[i];
             } else if (cc < n) {
-                const double* __restrict__ Ab = F + fd.off + (size_t)row0 * ld + col0 + cc;
+                const double* __restrict__ Ab = FL + fd.off + (size_t)row0 * ld + col0 + cc;      // L21: in place, or in the second arena where the level ran the fused row solve + update
                 for (int i = slot; i < nrows; i += 10) { const int g = row0 + i; acc0 += Ab[(size_t)i * ld] * x[(size_t)f_rows[fd.rowptr + g / 6] * 6 + g % 6]; }
             }
             s_acc[slot * (PG_PW * 6) + cc] = acc0 + acc1;
@@ -2097,6 +2225,9 @@ static int pg_solve_impl(dsss_ctx* c, const double* dr6, int total, const dsss_l
     dv.later(&d_perm, S.perm);
     TRY(dv.alloc(c, &d_L, nnzL * 36));
     TRY(dv.alloc(c, &d_F, (size_t)S.front_doubles)); TRY(dv.alloc(c, &d_R, (size_t)S.frhs_doubles)); TRY(dv.alloc(c, &d_ubin, (size_t)S.ubin_doubles));
+    static const bool use_rsu = !(getenv("DSSS_PG_RSU") && atoi(getenv("DSSS_PG_RSU")) == 0);      // A/B: 0 = separate row solve and update launches on every level
+    double* d_FL = nullptr;                              // second front arena: L21 of the levels that run the fused kernel
+    if (use_rsu) TRY(dv.alloc(c, &d_FL, (size_t)S.front_doubles));
     // value array of the fronts; its tail IS the buffer the all-reduce sums: [interface values | interface right-hand sides |
     // update matrices that cross into the interface | 8 scalars]
     const size_t ncv = S.comm_vals.size(), nif = S.iface_seps.size();
@@ -2213,7 +2344,10 @@ static int pg_solve_impl(dsss_ctx* c, const double* dr6, int total, const dsss_l
                               if (d_stamps && l == H.nlev - 1) { unsigned long long hs[16]; hipMemcpyAsync(hs, d_stamps, sizeof hs, hipMemcpyDeviceToHost, st); hipStreamSynchronize(st);
                                   fprintf(stderr, "[dsss pg stamps] diag3 last level: %llu cycles\n", hs[2] - hs[0]); }
                           } }
-                        if (H.trsm_chunks[l] > 0) {
+                        if (use_rsu && ntl > 0 && ntl <= PG_RSU_MAX_TILES) {
+                            dsss_scope s45(c, DSSS_K_PG_ACC, H.fl_trsm[l] + H.fl_syrk[l]);
+                            hipLaunchKernelGGL(pg_front_rsu_kernel, dim3(ntl), dim3(512), 0, st, itf, its, d_FD, Dv.tile_item + H.tile_ptr[l], Dv.tile_ij + H.tile_ptr[l], d_F, d_FL, d_R, d_Tinv);
+                        } else if (H.trsm_chunks[l] > 0) {
                             { dsss_scope s4(c, DSSS_K_PG_TRSM, H.fl_trsm[l]);
                               hipLaunchKernelGGL(pg_front_trsm2_kernel, dim3(nit, H.trsm_chunks[l]), dim3(256), 0, st, itf, its, d_FD, d_F, d_R, d_Tinv); }
                             { dsss_scope s5(c, DSSS_K_PG_ACC, H.fl_syrk[l]);
@@ -2226,7 +2360,9 @@ static int pg_solve_impl(dsss_ctx* c, const double* dr6, int total, const dsss_l
                         const int nit = H.lv_ptr[l + 1] - H.lv_ptr[l];
                         if (nit == 0) continue;
                         dsss_scope s6(c, DSSS_K_PG_BWD, H.fl_bwd[l]);
-                        hipLaunchKernelGGL(pg_front_bwd2_kernel, dim3(nit), dim3(1024), bwd_lds, st, Dv.lv_front + H.lv_ptr[l], Dv.lv_step + H.lv_ptr[l], d_FD, d_frows, d_F, d_R, d_x, d_Tinv);
+                        const int ntl = H.tile_ptr[l + 1] - H.tile_ptr[l];
+                        const double* Fl = (use_rsu && ntl > 0 && ntl <= PG_RSU_MAX_TILES) ? d_FL : d_F;
+                        hipLaunchKernelGGL(pg_front_bwd2_kernel, dim3(nit), dim3(1024), bwd_lds, st, Dv.lv_front + H.lv_ptr[l], Dv.lv_step + H.lv_ptr[l], d_FD, d_frows, d_F, Fl, d_R, d_x, d_Tinv);
                     }
                 };
                 run_levels(SO, DO);

@@ -31,6 +31,7 @@ c.posegraph_solve_edges(dr, edges)
 prof = {k: (round(v[0], 3), v[1]) for k, v in c.profile_get().items() if v[1] > 0}
 c.profile(False)
 print("  kernel families of one solve (ms, launches):", prof)
-print("solve ms median %.2f min %.2f | iterations %d error %.6f | %s" % (ts[len(ts) // 2], ts[0], s[0], s[2],
+import hashlib
+print("solve ms median %.2f min %.2f | iterations %d error %.6f | poses sha %s | %s" % (ts[len(ts) // 2], ts[0], s[0], s[2], hashlib.sha1(p.tobytes()).hexdigest()[:12],
       " ".join("%s=%s" % (k, v) for k, v in sorted(os.environ.items()) if k.startswith("DSSS_PG_") and k != "DSSS_PG_VERBOSE")))
 c.close()
