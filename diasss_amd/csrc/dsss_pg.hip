@@ -2225,7 +2225,8 @@ static int pg_solve_impl(dsss_ctx* c, const double* dr6, int total, const dsss_l
     dv.later(&d_perm, S.perm);
     TRY(dv.alloc(c, &d_L, nnzL * 36));
     TRY(dv.alloc(c, &d_F, (size_t)S.front_doubles)); TRY(dv.alloc(c, &d_R, (size_t)S.frhs_doubles)); TRY(dv.alloc(c, &d_ubin, (size_t)S.ubin_doubles));
-    static const bool use_rsu = !(getenv("DSSS_PG_RSU") && atoi(getenv("DSSS_PG_RSU")) == 0);      // A/B: 0 = separate row solve and update launches on every level
+    static const int rsu_max = getenv("DSSS_PG_RSU") ? atoi(getenv("DSSS_PG_RSU")) : PG_RSU_MAX_TILES;      // A/B: 0 = separate row solve and update launches on every level; n = tile limit
+    const bool use_rsu = rsu_max > 0;
     double* d_FL = nullptr;                              // second front arena: L21 of the levels that run the fused kernel
     if (use_rsu) TRY(dv.alloc(c, &d_FL, (size_t)S.front_doubles));
     // value array of the fronts; its tail IS the buffer the all-reduce sums: [interface values | interface right-hand sides |
@@ -2344,7 +2345,7 @@ static int pg_solve_impl(dsss_ctx* c, const double* dr6, int total, const dsss_l
                               if (d_stamps && l == H.nlev - 1) { unsigned long long hs[16]; hipMemcpyAsync(hs, d_stamps, sizeof hs, hipMemcpyDeviceToHost, st); hipStreamSynchronize(st);
                                   fprintf(stderr, "[dsss pg stamps] diag3 last level: %llu cycles\n", hs[2] - hs[0]); }
                           } }
-                        if (use_rsu && ntl > 0 && ntl <= PG_RSU_MAX_TILES) {
+                        if (use_rsu && ntl > 0 && ntl <= rsu_max) {
                             dsss_scope s45(c, DSSS_K_PG_ACC, H.fl_trsm[l] + H.fl_syrk[l]);
                             hipLaunchKernelGGL(pg_front_rsu_kernel, dim3(ntl), dim3(512), 0, st, itf, its, d_FD, Dv.tile_item + H.tile_ptr[l], Dv.tile_ij + H.tile_ptr[l], d_F, d_FL, d_R, d_Tinv);
                         } else if (H.trsm_chunks[l] > 0) {
@@ -2361,7 +2362,7 @@ static int pg_solve_impl(dsss_ctx* c, const double* dr6, int total, const dsss_l
                         if (nit == 0) continue;
                         dsss_scope s6(c, DSSS_K_PG_BWD, H.fl_bwd[l]);
                         const int ntl = H.tile_ptr[l + 1] - H.tile_ptr[l];
-                        const double* Fl = (use_rsu && ntl > 0 && ntl <= PG_RSU_MAX_TILES) ? d_FL : d_F;
+                        const double* Fl = (use_rsu && ntl > 0 && ntl <= rsu_max) ? d_FL : d_F;
                         hipLaunchKernelGGL(pg_front_bwd2_kernel, dim3(nit), dim3(1024), bwd_lds, st, Dv.lv_front + H.lv_ptr[l], Dv.lv_step + H.lv_ptr[l], d_FD, d_frows, d_F, Fl, d_R, d_x, d_Tinv);
                     }
                 };

@@ -165,6 +165,21 @@ def test_online_updates_reach_the_batch_optimum(ctx, orc, survey):
         # an update that adds nothing converges at once: one more call, no new LC set, at most one accepted step
         again, _, st = ctx.posegraph_update(F, F * N)
         assert st[0] <= 1 and np.abs(again - o_out).max() < 1e-3
+        # ... and the online run ENDS AT THE BATCH OPTIMUM, not merely near it: with the stopping tolerances tightened for both
+        # (the LM then runs until the objective stops changing in the 12th digit) the last update and a batch solve of the same
+        # graph agree to a tenth of a micrometre and to 1e-9 on the objective
+        mp_, op_, mt_, pg_ = ctx.default_params()
+        pg_.rel_tol = 1e-13; pg_.abs_tol = 1e-13; pg_.max_iters = 100
+        ctx.set_params(pg=pg_)
+        try:
+            tight_o, _, st_o = ctx.posegraph_update(F, F * N)
+            tight_b, st_b = ctx.posegraph_solve_edges(dr, b_edges)           # the batch solve of the accumulated graph (explicit edges: the context holds only the last LC set)
+        finally:
+            mp_, op_, mt_, pg_ = ctx.default_params()
+            ctx.set_params(pg=pg_)
+        e_b = orc.pg_error_at(dr, b_edges, tight_b); e_o = orc.pg_error_at(dr, b_edges, tight_o)
+        assert abs(e_o - e_b) <= 1e-9 * e_b, (e_o, e_b)
+        assert np.abs(tight_o[:, 9:] - tight_b[:, 9:]).max() < 1e-7 and np.abs(tight_o[:, :9] - tight_b[:, :9]).max() < 1e-9
         # shrinking the graph under accumulated edges is refused, not silently wrong
         with pytest.raises(Exception):
             ctx.posegraph_update(1, N)
