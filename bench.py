@@ -405,18 +405,18 @@ VALU_ISSUE_PER_S = 1015e9
 # lanes x clock.  (The kernel itself spends 13.4 lane-instructions per gate + Hamming evaluation, PMC; it is NOT priced against that.)
 MATCH_PEAK_GEVALS = VALU_ISSUE_PER_S * 64 / 30.0 / 1e9
 
-FLOP_SLOTS = {"pg_acc", "pg_diag", "pg_trsm", "pg_bwd", "pg_subtree", "lc"}
-MFMA_SLOTS = {"pg_acc", "pg_diag", "pg_trsm"}             # kernels whose flops run on v_mfma_f64_16x16x4_f64
+FLOP_SLOTS = {"pg_acc", "pg_rsu", "pg_diag", "pg_trsm", "pg_bwd", "pg_subtree", "lc"}
+MFMA_SLOTS = {"pg_acc", "pg_rsu", "pg_diag", "pg_trsm"}             # kernels whose flops run on v_mfma_f64_16x16x4_f64
 # stages = kernel groups of SURVEY.md 8(d); the headline `roofline` is the group with the most GPU time
 GROUPS = {
     "extract": ("hbm", ["row_reduce", "pre_misc", "normalize", "pyramid", "fast", "fast_compact", "quadtree", "desc", "filter"]),
     "match": ("valu_int", ["match", "scc", "rows"]),
     "lc": ("valu_f64", ["lc"]),
-    "pg_factor": ("mfma", ["pg_subtree", "pg_asm", "pg_diag", "pg_trsm", "pg_acc", "pg_bwd"]),
+    "pg_factor": ("mfma", ["pg_subtree", "pg_asm", "pg_diag", "pg_trsm", "pg_acc", "pg_rsu", "pg_bwd"]),
 }
 GROUP_NOTE = {
     "extract": "SURVEY 8(d): 29.4 N M algorithmic bytes per frame (raw f64 twice, L0, pyramid r/w, FAST reads, blur r/w) over the summed time of the extraction kernels, against HBM",
-    "pg_factor": "multifrontal factorisation + solves of the reduced pose-graph system, all kernels of one LM trial (bins, extend-add, panel Cholesky, row solve, trailing update, "
+    "pg_factor": "multifrontal factorisation + solves of the reduced pose-graph system, all kernels of one LM trial (bins, extend-add, panel Cholesky, row solve + trailing update -- fused per tile on most levels --, "
                  "back-substitution): algorithmic f64 flops of one factorisation over their summed time, against the f64 matrix peak.  Latency-bound: ~100 dependent short launches per trial",
     "match": "SURVEY 8(d) K9: Na x Nb gate + Hamming evaluations of the active pairs against lanes x clock / 30 operations, lanes x clock = the measured issue rate",
     "lc": "f64 VALU, 3e4 flop per LM iteration and match (SURVEY 8(d) K11)",
@@ -426,7 +426,7 @@ GROUP_NOTE = {
 SLOT_KERNEL = {"row_reduce": "row_reduce_kernel", "normalize": "normalize_kernel", "pyramid": "resize_kernel", "fast": "fast_cells_kernel",
                "desc": "orient_desc_kernel", "quadtree": "quadtree_kernel", "lc": "lc_kernel", "match": "match_nn_kernel<false>",
                "pg_acc": "pg_front_syrk_kernel", "pg_diag": "pg_front_diag4_kernel", "pg_trsm": "pg_front_trsm2_kernel", "pg_bwd": "pg_front_bwd2_kernel",
-               "pg_subtree": "pg_factor_subtree_kernel", "pg_asm": "pg_front_asm_kernel"}
+               "pg_subtree": "pg_factor_subtree_kernel", "pg_asm": "pg_front_asm_kernel", "pg_rsu": "pg_front_rsu_kernel"}
 
 
 def _latest(pattern):

@@ -2346,7 +2346,7 @@ static int pg_solve_impl(dsss_ctx* c, const double* dr6, int total, const dsss_l
                                   fprintf(stderr, "[dsss pg stamps] diag3 last level: %llu cycles\n", hs[2] - hs[0]); }
                           } }
                         if (use_rsu && ntl > 0 && ntl <= rsu_max) {
-                            dsss_scope s45(c, DSSS_K_PG_ACC, H.fl_trsm[l] + H.fl_syrk[l]);
+                            dsss_scope s45(c, DSSS_K_PG_RSU, H.fl_trsm[l] + H.fl_syrk[l]);
                             hipLaunchKernelGGL(pg_front_rsu_kernel, dim3(ntl), dim3(512), 0, st, itf, its, d_FD, Dv.tile_item + H.tile_ptr[l], Dv.tile_ij + H.tile_ptr[l], d_F, d_FL, d_R, d_Tinv);
                         } else if (H.trsm_chunks[l] > 0) {
                             { dsss_scope s4(c, DSSS_K_PG_TRSM, H.fl_trsm[l]);

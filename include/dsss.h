@@ -232,6 +232,7 @@ int dsss_host_pg_solve(int ns, const int32_t* edge_a, const int32_t* edge_b, int
 #define DSSS_K_PG_SUBTREE  18   /* pg_factor_subtree_kernel + pg_bwd_subtree_kernel */
 #define DSSS_K_PG_ASM      19   /* pg_front_asm_kernel (extend-add) */
 #define DSSS_K_PG_COMM     20   /* the reduced-Hessian all-reduce of a trial (work = bytes) */
+#define DSSS_K_PG_RSU      21   /* pg_front_rsu_kernel: row solve + trailing update fused per tile (the levels with few tiles) */
 #define DSSS_K_COUNT       22
 int dsss_profile_enable(dsss_ctx*, int on);
 int dsss_profile_get(dsss_ctx*, double* ms_host /*DSSS_K_COUNT*/, int64_t* launches_host /*DSSS_K_COUNT*/);
