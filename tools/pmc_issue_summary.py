@@ -2,15 +2,16 @@
 """Instruction-issue counters of one rocprofv3 --pmc pass (SQ_INSTS_VALU, SQ_INSTS_SALU, SQ_INSTS_LDS, SQ_WAVES) per kernel,
 joined with the kernel durations of the same run's kernel trace:
     python tools/pmc_issue_summary.py <counter_collection.csv> <kernel_trace.csv> <out.csv>
-VALU issue utilisation = SQ_INSTS_VALU x 4 cycles / (duration x clock x 1024 SIMDs): a SIMD issues one 64-lane vector
-instruction in 4 cycles (16 lanes per cycle), so this is the fraction of the chip's vector issue slots the kernel used.  It is the
-roof of the integer / f64 vector kernels (FAST, descriptors, matcher, mini-LM); packed and dot instructions count once."""
+VALU issue utilisation = SQ_INSTS_VALU / duration against the MEASURED issue rate of the full-rate instruction class at 8
+wavefronts per SIMD, chip-wide (tools/ubench/valu_issue.hip, profiles/r03_ubench_valu_issue.txt: v_fma_f32 1015 G wave-instructions/s;
+the same constant bench.py uses).  The half-rate classes -- packed 16-bit min / max, v_bcnt, v_dot4, v_perm, three-operand integer
+operations, every f64 operation -- issue at 490-570 G/s, so a kernel made of them (FAST, descriptors, matcher, mini-LM) saturates at
+about 0.5 on this scale; round 2 priced everything at one instruction per 4 cycles (614 G/s), i.e. 1.65 x these figures."""
 import csv
 import sys
 from collections import defaultdict
 
-CLK = 2.4e9
-SIMDS = 1024
+VALU_ISSUE_PER_S = 1015e9
 acc = defaultdict(lambda: defaultdict(float)); cnt = defaultdict(int)
 with open(sys.argv[1]) as fh:
     for r in csv.DictReader(fh):
@@ -30,7 +31,7 @@ for k, v in acc.items():
     n = max(cnt[k], 1)
     t = dur[k] / max(nd[k], 1)
     valu = v.get("SQ_INSTS_VALU", 0.0) / n; salu = v.get("SQ_INSTS_SALU", 0.0) / n; lds = v.get("SQ_INSTS_LDS", 0.0) / n; waves = v.get("SQ_WAVES", 0.0) / n
-    util = valu * 4.0 / (t * CLK * SIMDS) if t > 0 else 0.0
+    util = valu / t / VALU_ISSUE_PER_S if t > 0 else 0.0
     rows.append((k, n, t * 1e6, waves, valu, salu, lds, util))
 rows.sort(key=lambda r: -r[2] * r[1])
 with open(sys.argv[3], "w", newline="") as fh:
