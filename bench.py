@@ -417,7 +417,7 @@ GROUPS = {
 GROUP_NOTE = {
     "extract": "SURVEY 8(d): 29.4 N M algorithmic bytes per frame (raw f64 twice, L0, pyramid r/w, FAST reads, blur r/w) over the summed time of the extraction kernels, against HBM",
     "pg_factor": "multifrontal factorisation + solves of the reduced pose-graph system, all kernels of one LM trial (bins, extend-add, panel Cholesky, row solve + trailing update -- fused per tile on most levels --, "
-                 "back-substitution): algorithmic f64 flops of one factorisation over their summed time, against the f64 matrix peak.  Latency-bound: ~100 dependent short launches per trial",
+                 "back-substitution): algorithmic f64 flops of one factorisation over their summed time, against the f64 matrix peak.  Latency-bound: ~133 dependent short launches per trial",
     "match": "SURVEY 8(d) K9: Na x Nb gate + Hamming evaluations of the active pairs against lanes x clock / 30 operations, lanes x clock = the measured issue rate",
     "lc": "f64 VALU, 3e4 flop per LM iteration and match (SURVEY 8(d) K11)",
 }
