@@ -228,7 +228,11 @@ def main():
     # DSSS_BENCH_FORCE_COMM=1: drive the multi-rank code path (RCCL communicator inside the library, feature all-gather, edge exchange,
     # interface all-reduce) with ONE rank -- a rehearsal of the N > 1 launch on a one-GPU box; the pose graph is cut into 8 partitions
     force_comm = world == 1 and os.environ.get("DSSS_BENCH_FORCE_COMM") == "1"
+    saved_stdout = None
     if world > 1 or force_comm:
+        # RCCL prints a version banner on STDOUT when its first communicator comes up; stdout carries the one JSON line and nothing else,
+        # so file descriptor 1 points at stderr until both communicators (torch's and the library's) exist
+        sys.stdout.flush(); saved_stdout = os.dup(1); os.dup2(2, 1)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
@@ -250,6 +254,9 @@ def main():
     pipe = Pipeline(F, device=local_rank, rank=rank, world=world, dist=dist if (world > 1 or force_comm) else None, nfeatures=wl.get("nfeatures"), force_collectives=force_comm)
     if force_comm:
         pipe.ctx.set_pg_partitions(8)
+    if saved_stdout is not None:
+        dist.barrier(); torch.cuda.synchronize()
+        sys.stdout.flush(); os.dup2(saved_stdout, 1); os.close(saved_stdout)
 
     def barrier():
         if world > 1:
