@@ -25,6 +25,7 @@
 #include <chrono>
 #include <thread>
 #include <mutex>
+#include <future>
 
 // ------------------------------------------------------------------ small dense helpers (6x6 row-major)
 __device__ inline int chol6(double* A)
@@ -1906,8 +1907,10 @@ struct pg_dev {
         pending.push_back({ (void**)p, v.data(), v.size() * sizeof(T), pend_total });
         pend_total += (std::max<size_t>(v.size(), 1) * sizeof(T) + 255) & ~(size_t)255;
     }
+    hipEvent_t stage_ev = nullptr; bool stage_ev_live = false;      // recorded behind the upload of a flush: the staging area is busy until it fires
     int flush(dsss_ctx* c, hipStream_t st) {
         if (pending.empty()) return DSSS_OK;
+        if (stage_ev_live) { hipEventSynchronize(stage_ev); stage_ev_live = false; }
         char* dev = nullptr;
         int rc = alloc(c, &dev, pend_total); if (rc) return rc;
         if (c->pg_stage_cap < pend_total) {
@@ -1917,17 +1920,20 @@ struct pg_dev {
             HIPCHK(c, hipHostMalloc(&c->pg_stage, cap, hipHostMallocDefault));
             c->pg_stage_cap = cap;
         }
+        if (stage_ev_live) { hipEventSynchronize(stage_ev); stage_ev_live = false; }      // the previous upload out of the staging area has left it
         char* stage = static_cast<char*>(c->pg_stage);
         const int T = pend_total > ((size_t)1 << 20) ? 4 : 1;
         dsss_pool_run(T, [&](int t) { for (size_t k = t; k < pending.size(); k += T) if (pending[k].bytes) memcpy(stage + pending[k].off, pending[k].src, pending[k].bytes); });
         HIPCHK(c, hipMemcpyAsync(dev, stage, pend_total, hipMemcpyHostToDevice, st));
+        if (!stage_ev) stage_ev = event();
+        if (stage_ev) { hipEventRecord(stage_ev, st); stage_ev_live = true; }
         for (const pend& q : pending) *q.p = dev + q.off;
         pending.clear(); pend_total = 0;
         return DSSS_OK;
     }
     std::vector<hipEvent_t> events;
     hipEvent_t event() { hipEvent_t e = nullptr; hipEventCreateWithFlags(&e, hipEventDisableTiming); events.push_back(e); return e; }
-    void release() { if (ctx) { hipStreamSynchronize(ctx->stream); ctx->pg_chunk_cur = 0; ctx->pg_chunk_off = 0; } for (hipEvent_t e : events) if (e) hipEventDestroy(e); events.clear(); pending.clear(); pend_total = 0; }
+    void release() { stage_ev_live = false; stage_ev = nullptr; if (ctx) { hipStreamSynchronize(ctx->stream); ctx->pg_chunk_cur = 0; ctx->pg_chunk_off = 0; } for (hipEvent_t e : events) if (e) hipEventDestroy(e); events.clear(); pending.clear(); pend_total = 0; }
 };
 
 } // namespace
@@ -2086,14 +2092,18 @@ static int pg_solve_impl(dsss_ctx* c, const double* dr6, int total, const dsss_l
     pg_sched SO, SI;
     std::vector<int> sym_part(ns);
     for (int k = 0; k < ns; ++k) sym_part[k] = (int)(std::upper_bound(pbound.begin(), pbound.end(), sep_pose[k]) - pbound.begin()) - 1;
+    std::promise<void> bottom_prom; std::future<void> bottom_fut = bottom_prom.get_future();
+    bool bottom_signalled = false;
     std::thread sym_thread([&] {
         pg_sym_opts opt; opt.threads = sym_threads();
+        opt.on_bottom_ready = [&] { bottom_signalled = true; bottom_prom.set_value(); };
         static const double bin_cost = getenv("DSSS_PG_BIN_COST") ? atof(getenv("DSSS_PG_BIN_COST")) : 600;   // ~ update-list iterations + 20 per column; measured optimum at C3 (500-700)
         opt.bin_cost = bin_cost; pg_sym_opts_env(opt);
         pg_symbolic(ns, redges, nseg, cx.data(), cy.data(), nparts > 1 ? sym_part.data() : nullptr, nparts, opt, S);
         // launch lists: this rank's interior fronts, then (after the all-reduce) the replicated interface fronts
         pg_build_schedule(S, part_lo, part_hi, SO);
         if (nparts > 1) pg_build_schedule(S, -1, 0, SI);
+        if (!bottom_signalled) bottom_prom.set_value();      // (several partitions: nothing is ready early)
     });
     struct pg_joiner { std::thread& t; ~pg_joiner() { if (t.joinable()) t.join(); } } sym_join{ sym_thread };      // every return path waits for the thread before its data goes away
     const bool verbose = getenv("DSSS_PG_VERBOSE") != nullptr;
@@ -2210,39 +2220,84 @@ static int pg_solve_impl(dsss_ctx* c, const double* dr6, int total, const dsss_l
         chain_part();
         pre_lin = pre_chain = true;
     }
+    // ---- The bottom of the tree (ordering, column structures, bins, update lists, destinations) is final about a millisecond before the
+    // fronts and the schedule are: with one partition its tables go up as soon as the analysing thread says so, and the scatter and
+    // the bins of the FIRST trial run while the host finishes the analysis.
+    size_t nnzL = 0; int nval = 0;
+    size_t ncv = 0, nif = 0, comm_total = 8;
+    double *d_comm = nullptr, *d_avalif = nullptr, *d_xif = nullptr, *d_commU = nullptr;
+    int *d_ifslot = nullptr, *d_ifsep = nullptr;
+    std::vector<int> ifslot;
+    int bin_lo = 0, bin_hi = 0, nbins = 0;
+    bool pre_bins = false;
+    auto upload_bottom = [&]() -> int {
+        nnzL = S.rowidx.size(); nval = (int)S.dest_bin.size();
+        ncv = S.comm_vals.size(); nif = S.iface_seps.size();
+        comm_total = ncv * 36 + nif * 6 + (size_t)S.comm_doubles + 8;
+        int rc2 = DSSS_OK;
+        dv.later(&d_perm, S.perm);
+        if ((rc2 = dv.alloc(c, &d_L, nnzL * 36))) return rc2;
+        if ((rc2 = dv.alloc(c, &d_ubin, (size_t)S.ubin_doubles))) return rc2;
+        // value array of the fronts; its tail IS the buffer the all-reduce sums: [interface values | interface right-hand sides |
+        // update matrices that cross into the interface | 8 scalars]
+        if ((rc2 = dv.alloc(c, &d_aval, (size_t)nval * 36 + comm_total))) return rc2;
+        d_comm = d_aval + (size_t)nval * 36; d_avalif = d_comm; d_xif = d_comm + ncv * 36; d_commU = d_xif + nif * 6;
+        ifslot.assign(ns, -1); for (size_t q = 0; q < nif; ++q) ifslot[S.iface_seps[q]] = (int)q;
+        dv.later(&d_ifslot, ifslot); dv.later(&d_ifsep, S.iface_seps);
+        dv.later(&d_colptr, S.colptr); dv.later(&d_rowidx, S.rowidx); dv.later(&d_rlptr, S.rlptr); dv.later(&d_rlcol, S.rlcol);
+        dv.later(&d_rlpos, S.rlpos); dv.later(&d_rlrow, S.rlrow); dv.later(&d_mapptr, S.mapptr); dv.later(&d_binptr, S.binptr); dv.later(&d_bincols, S.bincols);
+        dv.later(&d_dest, S.dest_bin);
+        dv.later(&d_binroot_ptr, S.binroot_ptr); dv.later(&d_binroot_idx, S.binroot_idx); dv.later(&d_broot_b, S.broot_b); dv.later(&d_broot_uoff, S.broot_uoff);
+        dv.later(&d_broot_of_col, S.broot_of_col); dv.later(&d_anc_first, S.anc_first); dv.later(&d_anc_rel, S.anc_rel);
+        if ((rc2 = dv.flush(c, st))) return rc2;
+        // this rank's bins are one contiguous range (bins never straddle partitions, partitions are ascending in the order)
+        { const int nb_all = (int)S.binptr.size() - 1; bin_lo = 0; while (bin_lo < nb_all && S.bin_part[bin_lo] < part_lo) ++bin_lo; bin_hi = bin_lo; while (bin_hi < nb_all && S.bin_part[bin_hi] < part_hi) ++bin_hi; }
+        nbins = bin_hi - bin_lo;
+        const long long mapsz = S.mapptr[ns];
+        if (mapsz > (1LL << 31)) DSSS_FAIL(c, DSSS_E_CAPACITY, "update map of %lld entries", mapsz);
+        if ((rc2 = dv.alloc(c, &d_map, (size_t)mapsz))) return rc2;
+        if (hipMemsetAsync(d_map, 0xff, (size_t)std::max<long long>(mapsz, 1) * sizeof(int), st) != hipSuccess) DSSS_FAIL(c, DSSS_E_HIP, "hipMemsetAsync(update map)");
+        const int nupd = (int)S.rlcol.size();
+        if (nupd > 0) hipLaunchKernelGGL(pg_build_map_kernel, dim3((nupd + 255) / 256), dim3(256), 0, st, nupd, d_rlrow, d_rlptr, d_rlcol, d_rlpos, d_colptr, d_rowidx, d_mapptr, d_map);
+        return DSSS_OK;
+    };
+    // the bottom part of a trial: reduced system into the factor / the value array, then the bins
+    auto bottom_trial = [&](double bins_flops) {
+        hipMemsetAsync(d_L, 0, nnzL * 36 * sizeof(double), st);
+        if (nparts > 1) hipMemsetAsync(d_comm, 0, comm_total * sizeof(double), st);
+        hipLaunchKernelGGL(pg_scatter_base_kernel, dim3((unsigned)(((long long)ns * 78 + 255) / 256)), dim3(256), 0, st, ns, d_t2, d_perm, d_D1, d_g1, d_s2DL, d_s2DR, d_s2GL, d_s2GR, d_s2S, d_dest, d_L, d_aval, d_x,
+                           d_ifslot, d_avalif, d_xif, kp0, kp1);
+        if (ne > 0) hipLaunchKernelGGL(pg_scatter_lc_kernel, dim3((unsigned)(((long long)ne * 36 + 255) / 256)), dim3(256), 0, st, n, ne, ns, d_Ji, d_ew, d_dest, d_L, d_aval, d_avalif, d_eo, mp0, mp1);
+        if (nbins > 0) { dsss_scope s1(c, DSSS_K_PG_SUBTREE, bins_flops);      // flops of the binned columns
+                         hipLaunchKernelGGL(pg_factor_subtree_kernel, dim3(nbins), dim3(256), 0, st, d_binptr + bin_lo, d_bincols, d_colptr, d_rlptr, d_rlcol, d_rlpos, d_mapptr, d_map, d_L, d_x, d_fail,
+                                            d_binroot_ptr + bin_lo, d_binroot_idx, d_broot_b, d_broot_uoff, d_broot_of_col, d_anc_first, d_anc_rel, d_ubin); }
+    };
+    static const bool early_ok = !(getenv("DSSS_PG_EARLY") && atoi(getenv("DSSS_PG_EARLY")) == 0);      // A/B switch
+    const bool early_bottom = early_ok && nparts == 1 && will_iterate && pre_chain;
+    if (early_bottom) {
+        bottom_fut.wait();
+        TRY(upload_bottom());
+        bottom_trial(0.0);                                   // (its flop count is known when the analysis has finished: added below)
+        pre_bins = true;
+    }
     sym_thread.join();
     if (S.ownership_violations) { dv.release(); DSSS_FAIL(c, DSSS_E_STATE, "pose-graph analysis: %d separators with a higher-rank neighbour are not interface", S.ownership_violations); }
     const double t_sym = ms_since(T1);
     const auto T2 = std::chrono::steady_clock::now();
     const int nfr = (int)S.f_c0.size(), npan = S.npanels;
-    const size_t nnzL = S.rowidx.size();
-    const int nval = (int)S.dest_bin.size();
+    if (!early_bottom) TRY(upload_bottom());
+    else if (c->prof.on) c->prof.work[DSSS_K_PG_SUBTREE] += std::max(0.0, S.flops_factor - S.flops_fronts);
     if (verbose)
         fprintf(stderr, "[dsss pg] rank %d/%d parts %d (own %d..%d, poses %d..%d)  poses %d  LC edges %d  separators %d (interface %zu)  nnz(L) blocks %zu  bins %d (%d cols)  fronts %d (largest %d block rows, arena %.0f MB)  panels %d in %d levels  all-reduce %.1f MB\n",
                 rank, world, nparts, part_lo, part_hi, mp0, mp1, n, ne, ns, S.iface_seps.size(), nnzL, (int)S.binptr.size() - 1, (int)S.bincols.size(), nfr, S.max_front_n, S.front_doubles * 8e-6, npan, S.nlev,
                 (S.comm_doubles + 36.0 * S.comm_vals.size() + 6.0 * S.iface_seps.size()) * 8e-6);
 
-    dv.later(&d_perm, S.perm);
-    TRY(dv.alloc(c, &d_L, nnzL * 36));
-    TRY(dv.alloc(c, &d_F, (size_t)S.front_doubles)); TRY(dv.alloc(c, &d_R, (size_t)S.frhs_doubles)); TRY(dv.alloc(c, &d_ubin, (size_t)S.ubin_doubles));
+    TRY(dv.alloc(c, &d_F, (size_t)S.front_doubles)); TRY(dv.alloc(c, &d_R, (size_t)S.frhs_doubles));
     static const int rsu_max = getenv("DSSS_PG_RSU") ? atoi(getenv("DSSS_PG_RSU")) : PG_RSU_MAX_TILES;      // A/B: 0 = separate row solve and update launches on every level; n = tile limit
     const bool use_rsu = rsu_max > 0;
     double* d_FL = nullptr;                              // second front arena: L21 of the levels that run the fused kernel
     if (use_rsu) TRY(dv.alloc(c, &d_FL, (size_t)S.front_doubles));
-    // value array of the fronts; its tail IS the buffer the all-reduce sums: [interface values | interface right-hand sides |
-    // update matrices that cross into the interface | 8 scalars]
-    const size_t ncv = S.comm_vals.size(), nif = S.iface_seps.size();
-    const size_t comm_total = ncv * 36 + nif * 6 + (size_t)S.comm_doubles + 8;
-    TRY(dv.alloc(c, &d_aval, (size_t)nval * 36 + comm_total));
-    double* d_comm = d_aval + (size_t)nval * 36; double* d_avalif = d_comm; double* d_xif = d_comm + ncv * 36; double* d_commU = d_xif + nif * 6;
-    int *d_ifslot, *d_ifsep, *d_pk_child, *d_pk_row; pg_pack* d_PK;
-    std::vector<int> ifslot(ns, -1); for (size_t q = 0; q < nif; ++q) ifslot[S.iface_seps[q]] = (int)q;
-    dv.later(&d_ifslot, ifslot); dv.later(&d_ifsep, S.iface_seps);
-    dv.later(&d_colptr, S.colptr); dv.later(&d_rowidx, S.rowidx); dv.later(&d_rlptr, S.rlptr); dv.later(&d_rlcol, S.rlcol);
-    dv.later(&d_rlpos, S.rlpos); dv.later(&d_rlrow, S.rlrow); dv.later(&d_mapptr, S.mapptr); dv.later(&d_binptr, S.binptr); dv.later(&d_bincols, S.bincols);
-    dv.later(&d_dest, S.dest_bin);
-    dv.later(&d_binroot_ptr, S.binroot_ptr); dv.later(&d_binroot_idx, S.binroot_idx); dv.later(&d_broot_b, S.broot_b); dv.later(&d_broot_uoff, S.broot_uoff);
-    dv.later(&d_broot_of_col, S.broot_of_col); dv.later(&d_anc_first, S.anc_first); dv.later(&d_anc_rel, S.anc_rel);
+    int *d_pk_child, *d_pk_row; pg_pack* d_PK;
     dv.later(&d_rel, S.rel); dv.later(&d_fa_src, S.fa_src); dv.later(&d_fa_col, S.fa_col); dv.later(&d_fa_tr, S.fa_tr);
     dv.later(&d_frows, S.f_rows); dv.later(&d_xr_ptr, S.xr_ptr); dv.later(&d_xr_child, S.xr_child);
     dv.later(&d_xr_row, S.xr_row); dv.later(&d_fa_rowptr, S.fa_rowptr);
@@ -2252,10 +2307,6 @@ static int pg_solve_impl(dsss_ctx* c, const double* dr6, int total, const dsss_l
         dv.later(&Dv.lv_front, H.lv_front); dv.later(&Dv.lv_step, H.lv_step); dv.later(&Dv.asm_front, H.asmrow_front); dv.later(&Dv.asm_row, H.asmrow_row);
         dv.later(&Dv.tile_item, H.tile_item); dv.later(&Dv.tile_ij, H.tile_ij);
     }
-    // this rank's bins are one contiguous range (bins never straddle partitions, partitions are ascending in the order)
-    int bin_lo = 0, bin_hi = 0;
-    { const int nb_all = (int)S.binptr.size() - 1; while (bin_lo < nb_all && S.bin_part[bin_lo] < part_lo) ++bin_lo; bin_hi = bin_lo; while (bin_hi < nb_all && S.bin_part[bin_hi] < part_hi) ++bin_hi; }
-    const int nbins = bin_hi - bin_lo;
     int n_pack = 0;
     {   // front and child descriptors (the children point straight at the update matrices: F22 of a front, U of a bin root)
         std::vector<pg_front> FD(nfr); std::vector<pg_child> CH(S.ch_kind.size());
@@ -2289,9 +2340,6 @@ static int pg_solve_impl(dsss_ctx* c, const double* dr6, int total, const dsss_l
         n_pack = (int)pk_child.size();
     }
     const int max_n6 = std::max(SO.max_n6, SI.max_n6);
-    const long long mapsz = S.mapptr[ns];
-    if (mapsz > (1LL << 31)) { dv.release(); DSSS_FAIL(c, DSSS_E_CAPACITY, "update map of %lld entries", mapsz); }
-    TRY(dv.alloc(c, &d_map, (size_t)mapsz));
     unsigned long long* d_stamps = nullptr; if (getenv("DSSS_PG_STAMPS")) TRY(dv.alloc(c, &d_stamps, 16));
     static const bool diag3_panel = getenv("DSSS_PG_PANEL") && !strcmp(getenv("DSSS_PG_PANEL"), "diag3");          // A/B: two barriers per block
     double* d_Tinv; TRY(dv.alloc(c, &d_Tinv, (size_t)std::max(npan, 1) * PG_NB4 * 16));
@@ -2301,9 +2349,6 @@ static int pg_solve_impl(dsss_ctx* c, const double* dr6, int total, const dsss_l
         hipFuncSetAttribute((const void*)pg_front_bwd2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipGetLastError();
     }
-    HCK(hipMemsetAsync(d_map, 0xff, (size_t)std::max<long long>(mapsz, 1) * sizeof(int), st));
-    { const int nupd = (int)S.rlcol.size();
-      if (nupd > 0) hipLaunchKernelGGL(pg_build_map_kernel, dim3((nupd + 255) / 256), dim3(256), 0, st, nupd, d_rlrow, d_rlptr, d_rlcol, d_rlpos, d_colptr, d_rowidx, d_mapptr, d_map); }
     const double t_up = ms_since(T2);
     const auto T3 = std::chrono::steady_clock::now();
     dsss_scope sc(c, DSSS_K_PG);
@@ -2319,16 +2364,10 @@ static int pg_solve_impl(dsss_ctx* c, const double* dr6, int total, const dsss_l
             // ---- solve (H + lambda I) delta = -g ; lambda lives in device memory
             if (!pre_chain) HCK(hipMemcpyAsync(d_scal + 3, &lambda, sizeof(double), hipMemcpyHostToDevice, st));
             {
-                hipMemsetAsync(d_L, 0, nnzL * 36 * sizeof(double), st);
-                if (nparts > 1) hipMemsetAsync(d_comm, 0, comm_total * sizeof(double), st);
                 if (!pre_chain) chain_part();
                 pre_chain = false;
-                hipLaunchKernelGGL(pg_scatter_base_kernel, dim3((unsigned)(((long long)ns * 78 + 255) / 256)), dim3(256), 0, st, ns, d_t2, d_perm, d_D1, d_g1, d_s2DL, d_s2DR, d_s2GL, d_s2GR, d_s2S, d_dest, d_L, d_aval, d_x,
-                                   d_ifslot, d_avalif, d_xif, kp0, kp1);
-                if (ne > 0) hipLaunchKernelGGL(pg_scatter_lc_kernel, dim3((unsigned)(((long long)ne * 36 + 255) / 256)), dim3(256), 0, st, n, ne, ns, d_Ji, d_ew, d_dest, d_L, d_aval, d_avalif, d_eo, mp0, mp1);
-                if (nbins > 0) { dsss_scope s1(c, DSSS_K_PG_SUBTREE, std::max(0.0, S.flops_factor - S.flops_fronts));      // flops of the binned columns
-                                 hipLaunchKernelGGL(pg_factor_subtree_kernel, dim3(nbins), dim3(256), 0, st, d_binptr + bin_lo, d_bincols, d_colptr, d_rlptr, d_rlcol, d_rlpos, d_mapptr, d_map, d_L, d_x, d_fail,
-                                                    d_binroot_ptr + bin_lo, d_binroot_idx, d_broot_b, d_broot_uoff, d_broot_of_col, d_anc_first, d_anc_rel, d_ubin); }
+                if (!pre_bins) bottom_trial(std::max(0.0, S.flops_factor - S.flops_fronts));
+                pre_bins = false;
                 // fronts, level by level: assemble the fronts that start here, then one panel step of every active front
                 auto run_levels = [&](const pg_sched& H, const dsched& Dv) {
                     for (int l = 0; l < H.nlev; ++l) {

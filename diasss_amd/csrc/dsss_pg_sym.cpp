@@ -452,6 +452,28 @@ void pg_symbolic(int ns, const std::vector<std::pair<int, int>>& edges, int ncha
         S.mapptr.assign(ns + 1, 0);
         for (int j = 0; j < ns; ++j) S.mapptr[j + 1] = S.mapptr[j] + (long long)(S.rlptr[j + 1] - S.rlptr[j]) * (long long)csz(j);
     }
+    // ---- where the assembled blocks go, first half: value index k < ns diagonal of separator k, then the chain couplings, then the
+    // LC edges; a value whose destination column is binned gets its position in the block-sparse factor (the rest -- fronts,
+    // interface -- is settled after the fronts exist)
+    const int ne = (int)edges.size() - nchain, nval = ns + nchain + ne;
+    S.dest_bin.assign(nval, -1);
+    std::vector<int> v_row(nval), v_col(nval), v_tr(nval);
+    {
+        auto find = [&](int row, int col) { const auto b = S.rowidx.begin() + S.colptr[col], e = S.rowidx.begin() + S.colptr[col + 1];
+                                            return (int)(std::lower_bound(b, e, row) - S.rowidx.begin()); };
+        par_ranges(nval, T, [&](int, int lo, int hi) {
+            for (int v = lo; v < hi; ++v) {
+                int pa, pb;                                   // block H(a, b): rows of a, columns of b
+                if (v < ns) { pa = pb = S.perm[v]; }
+                else { const auto& e = edges[v - ns]; pa = S.perm[e.first]; pb = S.perm[e.second]; }
+                const int row = std::max(pa, pb), col = std::min(pa, pb), tr = (pa >= pb) ? 0 : 1;
+                v_row[v] = row; v_col[v] = col; v_tr[v] = tr;
+                if (sub_ok[col]) S.dest_bin[v] = (find(row, col) << 1) | tr;
+            }
+        });
+    }
+    S.nval = nval;
+    if (opt.on_bottom_ready && nparts <= 1) opt.on_bottom_ready();
     const auto q3 = tnow();
     if (tv) fprintf(stderr, "[dsss pg symbolic] bins+lists: rowidx copy %.2f, bins %.2f, anc_rel %.2f, update lists %.2f ms\n", tms(q2, f0), tms(f0, f1), tms(f1, f2), tms(f2, q3));
     // ---- top: supernodes of the remaining columns become fronts.  Fundamental supernodes (consecutive columns with nested
@@ -551,23 +573,8 @@ void pg_symbolic(int ns, const std::vector<std::pair<int, int>>& edges, int ncha
         });
     }
     const auto fB = tnow();
-    // ---- where the assembled blocks go
-    const int ne = (int)edges.size() - nchain, nval = ns + nchain + ne;
-    S.dest_bin.assign(nval, -1);
+    // ---- where the assembled blocks go, second half: the original entries of every front
     {
-        std::vector<int> v_row(nval), v_col(nval), v_tr(nval);
-        auto find = [&](int row, int col) { const auto b = S.rowidx.begin() + S.colptr[col], e = S.rowidx.begin() + S.colptr[col + 1];
-                                            return (int)(std::lower_bound(b, e, row) - S.rowidx.begin()); };
-        par_ranges(nval, T, [&](int, int lo, int hi) {
-            for (int v = lo; v < hi; ++v) {
-                int pa, pb;                                   // block H(a, b): rows of a, columns of b
-                if (v < ns) { pa = pb = S.perm[v]; }
-                else { const auto& e = edges[v - ns]; pa = S.perm[e.first]; pb = S.perm[e.second]; }
-                const int row = std::max(pa, pb), col = std::min(pa, pb), tr = (pa >= pb) ? 0 : 1;
-                v_row[v] = row; v_col[v] = col; v_tr[v] = tr;
-                if (sub_ok[col]) S.dest_bin[v] = (find(row, col) << 1) | tr;
-            }
-        });
         std::vector<int> cnt(nf + 1, 0);
         for (int v = 0; v < nval; ++v) if (!sub_ok[v_col[v]]) cnt[S.front_of_col[v_col[v]] + 1]++;
         S.fa_ptr.assign(nf + 1, 0);

@@ -113,6 +113,11 @@ struct pg_sym_opts {
     // merged front still fits one 96-column panel: such a merge removes a whole level for very little arithmetic)
     double relax_zero_blocks = 8, relax_flops = 1.05, relax_flops_small = 1.6;
     double relax_abs_flops = 0;         // extra flops a merge may cost when it removes a panel step
+    // called (on the analysing thread) as soon as everything the BOTTOM of the tree needs is final -- ordering, column structures, bins,
+    // update lists, dest_bin -- while the fronts and the schedule are still to come: the caller can upload those tables and run the
+    // scatter and the bins of the first trial under the rest of the analysis.  Only with one partition (interface values get their
+    // dest_bin codes at the very end).  None of the vectors it may read is touched afterwards.
+    std::function<void()> on_bottom_ready;
 };
 
 void pg_sym_opts_env(pg_sym_opts& opt);    // DSSS_PG_RELAX_ZERO / _FLOPS / _SMALL / _ABS overrides (experiments)
