@@ -289,54 +289,65 @@ struct level_tab { const uint8_t* img[DSSS_MAX_LEVELS]; int cols[DSSS_MAX_LEVELS
 
 // arc value A = max over the 16 arcs of 9 contiguous ring pixels of max(min(v - ring), min(ring - v));
 // corner at threshold t iff A > t, cornerScore = A - 1.  Values <= tmin are reported as 0 (never a corner, and never
-// able to suppress one).  The differences are 9-bit, so two ring positions (k, k + 8) share one register and the
-// sliding min / max over 9 contiguous positions runs on packed 16-bit lanes (v_pk_min_i16 / v_pk_max_i16): windows of
-// 2, 4, 8 by doubling, then one more pixel.  Position k + 8 of a pair register is the other half of register k, so a
-// window that wraps past 15 is a half-swap.  (On speckled sonar imagery four pixels in five fail the usual
-// opposite-pair early exit at minThFAST, so there is none.)
+// able to suppress one).  (On speckled sonar imagery four pixels in five fail the usual opposite-pair early exit at
+// minThFAST, so there is none.)
+// FOUR PIXELS OF A ROW PER LANE (round 3; one pixel per lane with ring positions k and k + 8 sharing a register cost 139 vector
+// instructions per pixel, and the kernel sits at the issue ceiling of its half-rate packed-16 instruction mix):
+//   * the 7 x 10 patch of the four pixels comes out of LDS as 7 x 3 ALIGNED dwords (the group starts at a window column that is a
+//     multiple of four) instead of 4 x 17 byte loads;
+//   * two horizontally adjacent pixels share a register (16-bit halves): ring position j of the pair is two ADJACENT bytes of one
+//     patch row, spread into the halves by ONE v_perm_b32 with a compile-time selector; all sixteen positions stay separate
+//     registers, so an arc that wraps past position 15 is index arithmetic, not a half swap;
+//   * the arcs that start at k and k + 1 (k even) share the window [k + 1, k + 8]: eight windows of 8 by doubling over the ODD
+//     positions (2 x 24 packed min / max), and  max(min(W, d[k]), min(W, d[k + 9])) = min(W, max(d[k], d[k + 9]))  closes both
+//     arcs with three instructions per polarity.
+// 72 vector instructions per pixel; min and max are exact, so the value is the same whatever the order: bit-identical output.
 typedef short fast_v2 __attribute__((ext_vector_type(2)));
-__device__ inline fast_v2 fast_swap(fast_v2 a) { return __builtin_shufflevector(a, a, 1, 0); }
 template <int stride>
-__device__ inline int fast_arc(const uint8_t* w, int x, int y, int tmin)
+__device__ inline uint32_t fast_arc4(const uint8_t* __restrict__ w, int xg, int y, int tmin)      // pixels (3 + xg + k, y), k = 0..3; xg a multiple of 4
 {
-    // ring offsets from the top-left corner of the 7 x 7 patch: all positive, so they fit the immediate field of the LDS loads
     constexpr int rdx[16] = { 0, 1, 2, 3, 3, 3, 2, 1, 0, -1, -2, -3, -3, -3, -2, -1 };
     constexpr int rdy[16] = { 3, 3, 2, 1, 0, -1, -2, -3, -3, -3, -2, -1, 0, 1, 2, 3 };
-    const uint8_t* __restrict__ p = w + (y - 3) * stride + (x - 3);
-    const short v = (short)p[3 * stride + 3];
-    const fast_v2 vv = { v, v };
-    fast_v2 P[16];                                   // P[j] = (d[j], d[j + 8]), j < 8; P[j + 8] = (d[j + 8], d[j])
+    const uint32_t* __restrict__ base = reinterpret_cast<const uint32_t*>(w + (y - 3) * stride + xg);      // stride is a multiple of 4, the slice 16-byte aligned
+    uint32_t R[7][3];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        const fast_v2 r = { (short)p[(rdy[j] + 3) * stride + rdx[j] + 3], (short)p[(rdy[j + 8] + 3) * stride + rdx[j + 8] + 3] };
-        P[j] = vv - r;
+    for (int r = 0; r < 7; ++r)
+#pragma unroll
+        for (int q = 0; q < 3; ++q) R[r][q] = base[r * (stride / 4) + q];
+    uint32_t out = 0;
+#pragma unroll
+    for (int pr = 0; pr < 2; ++pr) {                 // pixel pair (2 pr, 2 pr + 1)
+        // bytes c0 and c0 + 1 of patch row r, zero-extended into the two halves
+        auto pair_at = [&](int r, int c0) -> fast_v2 {
+            const bool lowq = c0 + 1 <= 7;
+            const uint32_t lo = lowq ? R[r][0] : R[r][1], hi = lowq ? R[r][1] : R[r][2];
+            const uint32_t idx = (uint32_t)(lowq ? c0 : c0 - 4);
+            return __builtin_bit_cast(fast_v2, __builtin_amdgcn_perm(hi, lo, 0x0c000c00u | idx | ((idx + 1u) << 16)));
+        };
+        const fast_v2 vv = pair_at(3, 2 * pr + 3);
+        fast_v2 d[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) d[j] = vv - pair_at(rdy[j] + 3, 2 * pr + rdx[j] + 3);
+        fast_v2 lo2[8], hi2[8], lo4[8], hi4[8];      // windows starting at the odd positions 2 i + 1
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { lo2[i] = __builtin_elementwise_min(d[2 * i + 1], d[(2 * i + 2) & 15]); hi2[i] = __builtin_elementwise_max(d[2 * i + 1], d[(2 * i + 2) & 15]); }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { lo4[i] = __builtin_elementwise_min(lo2[i], lo2[(i + 1) & 7]); hi4[i] = __builtin_elementwise_max(hi2[i], hi2[(i + 1) & 7]); }
+        fast_v2 bmin = { -32768, -32768 }, bmax = { 32767, 32767 };
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {                // k = 2 i: window [k + 1, k + 8], closed by d[k] and by d[k + 9]
+            const fast_v2 w8lo = __builtin_elementwise_min(lo4[i], lo4[(i + 2) & 7]), w8hi = __builtin_elementwise_max(hi4[i], hi4[(i + 2) & 7]);
+            const fast_v2 e0 = d[2 * i], e1 = d[(2 * i + 9) & 15];
+            bmin = __builtin_elementwise_max(bmin, __builtin_elementwise_min(w8lo, __builtin_elementwise_max(e0, e1)));
+            bmax = __builtin_elementwise_min(bmax, __builtin_elementwise_max(w8hi, __builtin_elementwise_min(e0, e1)));
+        }
+        const fast_v2 zero = { 0, 0 };
+        const fast_v2 best = __builtin_elementwise_max(bmin, zero - bmax);
+        const int b0 = best.x, b1 = best.y;
+        out |= (uint32_t)(b0 > tmin ? b0 : 0) << (16 * pr);
+        out |= (uint32_t)(b1 > tmin ? b1 : 0) << (16 * pr + 8);
     }
-#pragma unroll
-    for (int j = 0; j < 8; ++j) P[j + 8] = fast_swap(P[j]);
-    fast_v2 lo[12], hi[12];                          // windows of 2 starting at j (and j + 8)
-#pragma unroll
-    for (int j = 0; j < 8; ++j) { lo[j] = __builtin_elementwise_min(P[j], P[j + 1]); hi[j] = __builtin_elementwise_max(P[j], P[j + 1]); }
-#pragma unroll
-    for (int j = 8; j < 10; ++j) { lo[j] = fast_swap(lo[j - 8]); hi[j] = fast_swap(hi[j - 8]); }
-    fast_v2 lo4[12], hi4[12];                        // windows of 4
-#pragma unroll
-    for (int j = 0; j < 8; ++j) { lo4[j] = __builtin_elementwise_min(lo[j], lo[j + 2]); hi4[j] = __builtin_elementwise_max(hi[j], hi[j + 2]); }
-#pragma unroll
-    for (int j = 8; j < 12; ++j) { lo4[j] = fast_swap(lo4[j - 8]); hi4[j] = fast_swap(hi4[j - 8]); }
-    fast_v2 bmin = { -32768, -32768 }, bmax = { 32767, 32767 };
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {                    // windows of 8, plus position j + 8 (= the other half of P[j])
-        fast_v2 mn = __builtin_elementwise_min(lo4[j], lo4[j + 4]);
-        fast_v2 mx = __builtin_elementwise_max(hi4[j], hi4[j + 4]);
-        mn = __builtin_elementwise_min(mn, P[j + 8]);
-        mx = __builtin_elementwise_max(mx, P[j + 8]);
-        bmin = __builtin_elementwise_max(bmin, mn);
-        bmax = __builtin_elementwise_min(bmax, mx);
-    }
-    int best = bmin.x > bmin.y ? bmin.x : bmin.y;
-    const int nb = bmax.x < bmax.y ? bmax.x : bmax.y;
-    best = -nb > best ? -nb : best;
-    return best > tmin ? best : 0;
+    return out;
 }
 
 __device__ inline int block_scan_excl256(int v, int* total, int* s_w)
@@ -409,11 +420,17 @@ __global__ __launch_bounds__(256) void fast_cells_kernel(const ex_frame* __restr
     const int ew = c.w - 6, eh = c.h - 6;
     const int ne = (ew > 0 && eh > 0) ? ew * eh : 0;
     const int tmin = ini_th < min_th ? ini_th : min_th;
-    const unsigned mg_e = ((1u << 20) + (unsigned)(ew > 0 ? ew : 1) - 1u) / (unsigned)(ew > 0 ? ew : 1);
-    for (int t = lane; t < ne; t += 64) {
-        const int q = (int)(((unsigned)t * mg_e) >> 20);
-        const int y = 3 + q, x = 3 + t - q * ew;
-        A[y * stride + x] = (uint8_t)fast_arc<stride>(win, x, y, tmin);
+    const int G = (ew + 3) >> 2, ngroups = ne > 0 ? eh * G : 0;      // groups of four pixels of a row, the unit of both passes below
+    const unsigned mg_g = ((1u << 20) + (unsigned)(G > 0 ? G : 1) - 1u) / (unsigned)(G > 0 ? G : 1);
+    for (int g = lane; g < ngroups; g += 64) {
+        const int gy = (int)(((unsigned)g * mg_g) >> 20), xg = 4 * (g - gy * G);
+        const int y = 3 + gy;
+        // (a group that runs over the evaluated range reads window bytes nobody wrote -- inside this wavefront's slice -- for pixels whose
+        // values are dropped here: the border of A stays zero)
+        const uint32_t a4 = fast_arc4<stride>(win, xg, y, tmin);
+        uint8_t* __restrict__ ap = A + y * stride + 3 + xg;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) if (xg + k < ew) ap[k] = (uint8_t)(a4 >> (8 * k));
     }
     FAST_WAVE_SYNC();
     // strict 3x3 maxima (neighbours outside the evaluated range hold 0), FOUR PIXELS OF A ROW PER LANE: the 3 x 6 patch of arc values
@@ -424,8 +441,6 @@ __global__ __launch_bounds__(256) void fast_cells_kernel(const ex_frame* __restr
     // minThFAST (ORBextractor.cpp:796-810).  Emission order = row-major = (group, pixel of the group): four ballots, one running
     // count of the survivors in lower lanes, plus the lane's own earlier survivors.
     int base = 0;
-    const int G = (ew + 3) >> 2, ngroups = ne > 0 ? eh * G : 0;
-    const unsigned mg_g = ((1u << 20) + (unsigned)(G > 0 ? G : 1) - 1u) / (unsigned)(G > 0 ? G : 1);
     DSSS_GLOBAL uint32_t* __restrict__ cell_out = (DSSS_GLOBAL uint32_t*)(cand + (size_t)cell * cell_cap);      // global, not flat, stores
     for (int g0 = 0; g0 < ngroups; g0 += 64) {
         const int g = min(g0 + lane, ngroups - 1);

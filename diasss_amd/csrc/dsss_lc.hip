@@ -27,31 +27,59 @@ struct mini_val { double L[3]; pose_t X1, X2; };
 // and kept in registers (200 VGPRs of the 512) they were what held the kernel at one wavefront per SIMD with 110 spills.
 struct lc_lds { double J[MR * LS]; double H[MD * LS]; double L[MD * LS]; mini_prob m; mini_val v, nv; };
 
-// whitened residual r (registers, every lane) and Jacobian J (LDS; lane `lane` clears row `lane`, lane 0 writes the entries)
+// The pose algebra of a problem is a chain of a few hundred dependent f64 operations (two Logmaps with acos / sin / tan, two sss
+// factors with a square root and divisions) that every lane of the group used to run in full: 75 % of the kernel's cycles (in-kernel
+// stamps, round 3).  The factors come in PAIRS of the same code on different data -- prior / between (Logmap of a relative pose),
+// source / target sss factor, retraction of X1 / X2, the two DR poses of the set-up -- so lanes 0..7 of the group run the first of
+// a pair and lanes 8..15 the second, at the same time, and the results cross by one shuffle each.  Every value is produced by the
+// same operations in the same order as before: the output is bit-identical.
+__device__ inline void lc_bcast_pose(const pose_t& mine, int src, pose_t* out)
+{
+#pragma unroll
+    for (int k = 0; k < 9; ++k) out->R[k] = __shfl(mine.R[k], src, LG);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) out->t[k] = __shfl(mine.t[k], src, LG);
+}
+__device__ inline void lc_select_pose(bool second, const pose_t& a, const pose_t& b, pose_t* out)
+{
+#pragma unroll
+    for (int k = 0; k < 9; ++k) out->R[k] = second ? b.R[k] : a.R[k];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) out->t[k] = second ? b.t[k] : a.t[k];
+}
+// whitened residual r (registers, every lane) and Jacobian J (LDS; lane `lane` clears row `lane`, lanes 0 and 8 write the entries of
+// their halves)
 __device__ static void mini_lin(const mini_prob& m, const mini_val& v, double* r, double* J, int lane)
 {
-    const bool wr = J && lane == 0;
+    const bool hb = (lane & 8) != 0;                       // second half of the group: between factor, target's sss factor
+    const bool wr = J && (lane & 7) == 0;
     if (J) {
 #pragma unroll
         for (int c2 = 0; c2 < LS; ++c2) J[lane * LS + c2] = 0.0;
         __builtin_amdgcn_wave_barrier();
     }
-    pose_t d; double xi[6];
-    pose_between(&m.prior, &v.X1, &d);                     // PriorFactor: e = Logmap(prior^-1 x), H = I
-    pose_log(&d, xi);
+    // first half:  PriorFactor   e = Logmap(prior^-1 X1), H = I
+    // second half: BetweenFactor e = Logmap(meas^-1 h), h = X1^-1 X2, H1 = -Ad(h^-1), H2 = I
+    pose_t t1, t2, E; double xi[6], rr[6];
+    const pose_t* P = hb ? &v.X1 : &m.prior;               // (lane-dependent LDS addresses: one load per element)
+    const pose_t* Q = hb ? &v.X2 : &v.X1;
+    pose_between(P, Q, &t1);
+    pose_between(&m.odo, &t1, &t2);                        // (unused by the first half)
+    lc_select_pose(hb, t1, t2, &E);
+    pose_log(&E, xi);
 #pragma unroll
-    for (int i = 0; i < 6; ++i) { r[i] = xi[i] / m.sig_prior[i]; if (wr) J[i * LS + 3 + i] = 1.0 / m.sig_prior[i]; }
-    pose_t h, e;
-    pose_between(&v.X1, &v.X2, &h);                        // BetweenFactor: e = Logmap(meas^-1 h), H1 = -Ad(h^-1), H2 = I
-    pose_between(&m.odo, &h, &e);
-    pose_log(&e, xi);
+    for (int i = 0; i < 6; ++i) { const double sg = hb ? m.sig_odo[i] : m.sig_prior[i]; rr[i] = xi[i] / sg; }
 #pragma unroll
-    for (int i = 0; i < 6; ++i) r[6 + i] = xi[i] / m.sig_odo[i];
+    for (int i = 0; i < 6; ++i) { r[i] = __shfl(rr[i], 0, LG); r[6 + i] = __shfl(rr[i], 8, LG); }
     if (J) {
         pose_t hi; double Ad[36];
-        pose_inverse(&h, &hi);
+        pose_inverse(&t1, &hi);                            // t1 = h on the second half
         pose_adjoint(&hi, Ad);
-        if (wr) {
+        if (wr && !hb) {
+#pragma unroll
+            for (int i = 0; i < 6; ++i) J[i * LS + 3 + i] = 1.0 / m.sig_prior[i];
+        }
+        if (wr && hb) {
 #pragma unroll
             for (int i = 0; i < 6; ++i) {
 #pragma unroll
@@ -60,35 +88,32 @@ __device__ static void mini_lin(const mini_prob& m, const mini_val& v, double* r
             }
         }
     }
-    double ee[2], H1[6], H2[12];
-    sss_factor(v.L, &v.X1, m.slant_s, 0.0, ee, J ? H1 : nullptr, H2);
+    // first half: SssPoint(L1, X1), second half: SssPoint(L1, X2)
+    double ee[2], H1[6], H2[12], r2[2];
+    const pose_t* X = hb ? &v.X2 : &v.X1;
+    const double slant = hb ? m.slant_t : m.slant_s;
+    const double sg0 = hb ? m.sig_t[0] : m.sig_s[0], sg1 = hb ? m.sig_t[1] : m.sig_s[1];
+    sss_factor(v.L, X, slant, 0.0, ee, J ? H1 : nullptr, H2);
+    r2[0] = ee[0] / sg0; r2[1] = ee[1] / sg1;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        r[12 + i] = ee[i] / m.sig_s[i];
-        if (wr) {
+    for (int i = 0; i < 2; ++i) { r[12 + i] = __shfl(r2[i], 0, LG); r[14 + i] = __shfl(r2[i], 8, LG); }
+    if (wr) {
+        const int row0 = hb ? 14 : 12, col0 = hb ? 9 : 3;
 #pragma unroll
-            for (int j = 0; j < 3; ++j) J[(12 + i) * LS + j] = H1[3 * i + j] / m.sig_s[i];
+        for (int i = 0; i < 2; ++i) {
+            const double sg = i ? sg1 : sg0;
 #pragma unroll
-            for (int j = 0; j < 6; ++j) J[(12 + i) * LS + 3 + j] = H2[6 * i + j] / m.sig_s[i];
-        }
-    }
-    sss_factor(v.L, &v.X2, m.slant_t, 0.0, ee, J ? H1 : nullptr, H2);
+            for (int j = 0; j < 3; ++j) J[(row0 + i) * LS + j] = H1[3 * i + j] / sg;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        r[14 + i] = ee[i] / m.sig_t[i];
-        if (wr) {
-#pragma unroll
-            for (int j = 0; j < 3; ++j) J[(14 + i) * LS + j] = H1[3 * i + j] / m.sig_t[i];
-#pragma unroll
-            for (int j = 0; j < 6; ++j) J[(14 + i) * LS + 9 + j] = H2[6 * i + j] / m.sig_t[i];
+            for (int j = 0; j < 6; ++j) J[(row0 + i) * LS + col0 + j] = H2[6 * i + j] / sg;
         }
     }
     if (J) __builtin_amdgcn_wave_barrier();
 }
-__device__ static double mini_err(const mini_prob& m, const mini_val& v)
+__device__ static double mini_err(const mini_prob& m, const mini_val& v, int lane)
 {
     double r[MR];
-    mini_lin(m, v, r, nullptr, 0);
+    mini_lin(m, v, r, nullptr, lane);
     double s = 0;
 #pragma unroll
     for (int i = 0; i < MR; ++i) s += r[i] * r[i];
@@ -196,11 +221,15 @@ __global__ __launch_bounds__(64) void lc_kernel(const double* __restrict__ kp7, 
     m.slant_s = kp[2]; m.slant_t = kp[5];
     m.sig_s[0] = sigma_r; m.sig_s[1] = kp[2] * alpha_bw;
     m.sig_t[0] = sigma_r; m.sig_t[1] = kp[5] * alpha_bw;
-    pose_t Ps, Pt, Tp_s, Tp_t, Tp_st;
-    pose_from_rodrigues(pose_s + (size_t)id_s * 6, &Ps);
-    pose_from_rodrigues(pose_t_ + (size_t)id_t * 6, &Pt);
-    pose_compose(&Ps, &cps_s, &Tp_s);
-    pose_compose(&Pt, &cps_t, &Tp_t);
+    pose_t Tp_s, Tp_t, Tp_st;
+    const bool hb0 = (lane & 8) != 0;                       // lanes 0..7: the source ping's pose and geo sample, lanes 8..15: the target's
+    {
+        pose_t Pm, Cm, Tm;
+        pose_from_rodrigues(hb0 ? pose_t_ + (size_t)id_t * 6 : pose_s + (size_t)id_s * 6, &Pm);
+        lc_select_pose(hb0, cps_s, cps_t, &Cm);
+        pose_compose(&Pm, &Cm, &Tm);
+        lc_bcast_pose(Tm, 0, &Tp_s); lc_bcast_pose(Tm, 8, &Tp_t);
+    }
     pose_between(&Tp_s, &Tp_t, &Tp_st);
     for (int k = 0; k < 6; ++k) m.sig_prior[k] = 0.000001;
     m.sig_odo[0] = 0.1 * PI / 180; m.sig_odo[1] = 0.1 * PI / 180; m.sig_odo[2] = 0.5 * PI / 180;          // :778
@@ -210,8 +239,11 @@ __global__ __launch_bounds__(64) void lc_kernel(const double* __restrict__ kp7, 
     const int Ms = fcols[fs], Mt = fcols[ft];
     const int id_ss = (int)kp[1], id_tt = (int)kp[4];
     double gsx, gsy, gtx, gty;
-    dsss_geo_at(pose_s, gr_ptr[fs], Ms, id_s, id_ss, &gsx, &gsy);
-    dsss_geo_at(pose_t_, gr_ptr[ft], Mt, id_t, id_tt, &gtx, &gty);
+    {
+        double gx, gy;
+        dsss_geo_at(hb0 ? pose_t_ : pose_s, hb0 ? gr_ptr[ft] : gr_ptr[fs], hb0 ? Mt : Ms, hb0 ? id_t : id_s, hb0 ? id_tt : id_ss, &gx, &gy);
+        gsx = __shfl(gx, 0, LG); gsy = __shfl(gy, 0, LG); gtx = __shfl(gx, 8, LG); gty = __shfl(gy, 8, LG);
+    }
     mini_val v;
     v.L[0] = (gsx + gtx) / 2; v.L[1] = (gsy + gty) / 2;                                                    // :792-795
     v.L[2] = ((pose_s[(size_t)id_s * 6 + 5] - alt_ptr[fs][id_s]) + (pose_t_[(size_t)id_t * 6 + 5] - alt_ptr[ft][id_t])) / 2;
@@ -223,7 +255,7 @@ __global__ __launch_bounds__(64) void lc_kernel(const double* __restrict__ kp7, 
     const double relTol = 1e-5, absTol = 1e-5, lamMax = 1e5, minFid = 1e-3;
     double lambda = 1e-5;
     int iters = 0;
-    double err = mini_err(M_, V_);
+    double err = mini_err(M_, V_, lane);
     const double err0 = err;
     double r[MR], d[MD];
     if (err > 0) {
@@ -256,14 +288,17 @@ __global__ __launch_bounds__(64) void lc_kernel(const double* __restrict__ kp7, 
                     const double linChange = oldLin - newLin;
                     if (linChange >= 0) {
                         {   // the trial values go to LDS (S.nv); the registers that held them are free again afterwards
-                            mini_val nv;
-                            for (int a = 0; a < 3; ++a) nv.L[a] = V_.L[a] + d[a];
-                            pose_retract(&V_.X1, d + 3, &nv.X1);
-                            pose_retract(&V_.X2, d + 9, &nv.X2);
-                            if (lane == 0) S.nv = nv;
+                            const bool hb = (lane & 8) != 0;                  // lanes 0..7 retract X1, lanes 8..15 X2
+                            pose_t Xn; double dx[6];
+                            const pose_t* X = hb ? &V_.X2 : &V_.X1;
+#pragma unroll
+                            for (int a = 0; a < 6; ++a) dx[a] = hb ? d[9 + a] : d[3 + a];
+                            pose_retract(X, dx, &Xn);
+                            if (lane == 0) { for (int a = 0; a < 3; ++a) S.nv.L[a] = V_.L[a] + d[a]; S.nv.X1 = Xn; }
+                            if (lane == 8) S.nv.X2 = Xn;
                             __builtin_amdgcn_wave_barrier();
                         }
-                        newErr = mini_err(M_, S.nv);
+                        newErr = mini_err(M_, S.nv, lane);
                         const double costChange = err - newErr;
                         if (linChange > 2.220446049250313e-16 * oldLin) success = (costChange / linChange) > minFid;
                         if (fabs(costChange) < relTol * err) stop = true;
