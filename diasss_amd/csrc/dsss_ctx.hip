@@ -71,6 +71,8 @@ int dsss_create(int device, int max_frames, dsss_ctx** out)
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return DSSS_E_HIP; }
     hipEventCreate(&c->prof.e0); hipEventCreate(&c->prof.e1);
     for (int i = 0; i < 4; ++i) { hipStreamCreateWithFlags(&c->xs[i], hipStreamNonBlocking); hipEventCreateWithFlags(&c->xev[i], hipEventDisableTiming); }
+    for (int i = 0; i < DSSS_MAX_LEVELS; ++i) { hipEventCreateWithFlags(&c->ex_lev_ev[i], hipEventDisableTiming); hipEventCreateWithFlags(&c->ex_cmp_ev[i], hipEventDisableTiming); }
+    for (int i = 0; i < 3; ++i) hipEventCreateWithFlags(&c->ex_side_ev[i], hipEventDisableTiming);
     hipEventCreateWithFlags(&c->xev_main, hipEventDisableTiming);
     *out = c;
     return DSSS_OK;
@@ -131,6 +133,8 @@ void dsss_destroy(dsss_ctx* c)
     for (hipEvent_t e : c->prof.pool) hipEventDestroy(e);
     c->prof.pool.clear();
     for (int i = 0; i < 4; ++i) { if (c->xs[i]) hipStreamDestroy(c->xs[i]); if (c->xev[i]) hipEventDestroy(c->xev[i]); }
+    for (int i = 0; i < DSSS_MAX_LEVELS; ++i) { if (c->ex_lev_ev[i]) hipEventDestroy(c->ex_lev_ev[i]); if (c->ex_cmp_ev[i]) hipEventDestroy(c->ex_cmp_ev[i]); }
+    for (int i = 0; i < 3; ++i) if (c->ex_side_ev[i]) hipEventDestroy(c->ex_side_ev[i]);
     if (c->xev_main) hipEventDestroy(c->xev_main);
     hipStreamDestroy(c->stream);
     delete c;

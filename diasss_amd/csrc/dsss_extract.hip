@@ -33,6 +33,7 @@ struct ex_frame {
     double* rowsum; double* rowmin; double* stats;
     uint8_t* mask; uint8_t* lvl[DSSS_MAX_LEVELS]; int rows[DSSS_MAX_LEVELS], cols[DSSS_MAX_LEVELS]; int nlevels;
     const fast_cell* cells; int ncells, cell_cap;
+    int cell_begin[DSSS_MAX_LEVELS + 1];      // cells of level l: [cell_begin[l], cell_begin[l + 1])
     uint32_t* cand; int* counts; int* offs; float* xs; float* ys; float* rs; int cand_cap;
     const qt_kp_in* kin; const int* nk; const int* lrows; const float* lscale; dsss_kp* kptmp; uint8_t* dtmp;
     const double* pose6; const double* gr;
@@ -373,13 +374,13 @@ __device__ inline int block_scan_excl256(int v, int* total, int* s_w)
 // kernel was bound by the per-cell latency chain -- byte loads, three barriers, four block scans -- at 8 ms per 200 frames.)
 #define FAST_WAVE_SYNC() do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_wave_barrier(); } while (0)
 template <int stride>      // LDS row stride of the window: a compile-time constant, so that the ring offsets are immediates of the LDS loads
-__global__ __launch_bounds__(256) void fast_cells_kernel(const ex_frame* __restrict__ frs, int ini_th, int min_th, int wave_bytes)
+__global__ __launch_bounds__(256) void fast_cells_kernel(const ex_frame* __restrict__ frs, int lev_lo, int lev_hi, int ini_th, int min_th, int wave_bytes)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t fast_lds[];
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const ex_frame& f = frs[blockIdx.y];
-    const int cell = blockIdx.x * 4 + wv;
-    if (cell >= f.ncells) return;
+    const int cell = f.cell_begin[lev_lo] + blockIdx.x * 4 + wv;     // one launch per group of pyramid levels [lev_lo, lev_hi): a level's quadtree starts while the FAST of the levels above runs
+    if (cell >= f.cell_begin[lev_hi]) return;                        // (cell_begin[l] = ncells for l past the frame's levels)
     uint8_t* __restrict__ win = fast_lds + (size_t)wv * wave_bytes;
     uint8_t* __restrict__ A = win + wave_bytes / 2;
     uint32_t* __restrict__ cand = f.cand; const int cell_cap = f.cell_cap;
@@ -508,13 +509,18 @@ __global__ __launch_bounds__(256) void fast_cells_kernel(const ex_frame* __restr
     if (lane == 0) f.counts[cell] = base < cell_cap ? base : cell_cap;
 }
 
-__global__ __launch_bounds__(256) void scan_counts_kernel(const ex_frame* __restrict__ frs)
+// candidate offsets of the cells of the levels [lev_lo, lev_hi); the first offset is where the scan of the levels below ended
+// (offs[cell_begin[lev_lo]], written by that launch: the scans of a frame follow each other on one stream)
+__global__ __launch_bounds__(256) void scan_counts_kernel(const ex_frame* __restrict__ frs, int lev_lo, int lev_hi)
 {
     const ex_frame& f = frs[blockIdx.x];
-    const int* __restrict__ counts = f.counts; int* __restrict__ offs = f.offs; const int n = f.ncells;
+    if (lev_lo >= f.nlevels) return;
+    const int* __restrict__ counts = f.counts; int* __restrict__ offs = f.offs;
+    const int lo = f.cell_begin[lev_lo], n = f.cell_begin[lev_hi];
     __shared__ int s_w[4];
-    int base = 0;
-    for (int c0 = 0; c0 < n; c0 += 256) {
+    int base = lo == 0 ? 0 : offs[lo];
+    __syncthreads();                                 // (offs[lo] is rewritten below)
+    for (int c0 = lo; c0 < n; c0 += 256) {
         const int i = c0 + threadIdx.x;
         const int v = i < n ? counts[i] : 0;
         int tot;
@@ -527,15 +533,16 @@ __global__ __launch_bounds__(256) void scan_counts_kernel(const ex_frame* __rest
 
 // candidates in reference order with the cell offset applied (ORBextractor.cpp:820-825)
 #define GC_CELLS 32                                 // cells per workgroup (four wavefronts, eight cells each): one tiny workgroup per cell was launch-rate bound
-__global__ __launch_bounds__(256) void gather_cand_kernel(const ex_frame* __restrict__ frs)
+__global__ __launch_bounds__(256) void gather_cand_kernel(const ex_frame* __restrict__ frs, int lev_lo, int lev_hi)
 {
     const ex_frame& f = frs[blockIdx.y];
+    const int cell_lo = f.cell_begin[lev_lo], cell_hi = f.cell_begin[lev_hi];
     const uint32_t* __restrict__ cand = f.cand; const int* __restrict__ counts = f.counts; const int* __restrict__ offs = f.offs;
     float* __restrict__ xs = f.xs; float* __restrict__ ys = f.ys; float* __restrict__ rs = f.rs; const int cap = f.cand_cap, cell_cap = f.cell_cap;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     for (int k = 0; k < GC_CELLS / 4; ++k) {
-        const int cell = blockIdx.x * GC_CELLS + k * 4 + wv;
-        if (cell >= f.ncells) return;
+        const int cell = cell_lo + blockIdx.x * GC_CELLS + k * 4 + wv;
+        if (cell >= cell_hi) return;
         const fast_cell c = f.cells[cell];
         const int n = counts[cell], o = offs[cell];
         for (int q = lane; q < n; q += 64) {
@@ -1051,7 +1058,8 @@ static int extract_frames_impl(dsss_ctx* c, const int* ids, int n, bool keep_tap
             if (b0 + B < n) HIPCHK(c, upload_batch(b0 + B, up_ev[(bk + 1) & 1]));      // next batch's images start moving now
             HIPCHK(c, hipStreamWaitEvent(st, up_ev[bk & 1], 0));                       // this batch's images are in HBM before its kernels read them
         }
-        int ninst = 0, maxN = 0, maxNM4 = 0, max_cells = 0, max_levels = 0, max_cw = 8, max_ch = 8;
+        int maxN = 0, maxNM4 = 0, max_cells = 0, max_levels = 0, max_cw = 8, max_ch = 8;
+        int lev_cnt[DSSS_MAX_LEVELS] = { 0 };           // frames that have level l
         size_t max_tot = 0;
         int max_rows[DSSS_MAX_LEVELS] = { 0 }, max_cols[DSSS_MAX_LEVELS] = { 0 };
         double w_tot = 0;
@@ -1067,6 +1075,7 @@ static int extract_frames_impl(dsss_ctx* c, const int* ids, int n, bool keep_tap
             e.mask = f.mask; e.nlevels = g.nlevels;
             for (int l = 0; l < DSSS_MAX_LEVELS; ++l) { e.lvl[l] = l < g.nlevels ? f.lvl[l] : nullptr; e.rows[l] = l < g.nlevels ? g.rows[l] : 0; e.cols[l] = l < g.nlevels ? g.cols[l] : 0; }
             e.cells = g.d_cells; e.ncells = (int)g.cells.size(); e.cell_cap = g.cell_cap;
+            for (int l = 0; l <= DSSS_MAX_LEVELS; ++l) e.cell_begin[l] = g.cell_begin[std::min(l, g.nlevels)];
             e.cand = (uint32_t*)(S + L.cand); e.counts = (int*)(S + L.counts); e.offs = (int*)(S + L.offs);
             e.xs = (float*)(S + L.xs); e.ys = (float*)(S + L.ys); e.rs = (float*)(S + L.rs); e.cand_cap = L.cand_cap;
             e.kin = (kp_in*)(S + L.kin); e.nk = (int*)(S + L.nk); e.lrows = g.d_lrows; e.lscale = g.d_lscale;
@@ -1078,9 +1087,9 @@ static int extract_frames_impl(dsss_ctx* c, const int* ids, int n, bool keep_tap
             max_cw = std::max(max_cw, g.cell_wmax); max_ch = std::max(max_ch, g.cell_hmax);
             for (int l = 0; l < g.nlevels; ++l) { max_rows[l] = std::max(max_rows[l], g.rows[l]); max_cols[l] = std::max(max_cols[l], g.cols[l]); }
             w_tot += (double)f.N * f.M;
-            // quadtree descriptors
+            // quadtree descriptors, level-major: the instances of level l are one launch
             for (int l = 0; l < g.nlevels; ++l) {
-                qt_inst& q = h_inst[ninst++];
+                qt_inst& q = h_inst[(size_t)l * B + lev_cnt[l]++];
                 q.offs = e.offs; q.cell_begin = g.cell_begin[l]; q.cell_end = g.cell_begin[l + 1];
                 q.xs = e.xs; q.ys = e.ys; q.rs = e.rs;
                 q.W = (g.cols[l] - EDGE_T + 3) - (EDGE_T - 3); q.H = (g.rows[l] - EDGE_T + 3) - (EDGE_T - 3); q.quota = g.quota[l];
@@ -1096,12 +1105,6 @@ static int extract_frames_impl(dsss_ctx* c, const int* ids, int n, bool keep_tap
             qf.kin = (kp_in*)(S + L.kin); qf.nk = (int*)(S + L.nk); qf.err = d_errs + s;
         }
         (void)maxNM4;
-        {   // the workgroups of the large levels first: an instance is one workgroup whose time grows with its level's candidates, and
-            // two of them fit a CU, so the launch ends sooner when the small levels fill the gaps at the end
-            std::vector<qt_inst> tmp(h_inst, h_inst + ninst);
-            std::stable_sort(tmp.begin(), tmp.end(), [](const qt_inst& a, const qt_inst& b) { return (long long)a.W * a.H > (long long)b.W * b.H; });
-            std::copy(tmp.begin(), tmp.end(), h_inst);
-        }
         HIPCHK(c, hipMemcpyAsync(T0, P0, tab_bytes - err_bytes, hipMemcpyHostToDevice, st));
         HIPCHK(c, hipMemsetAsync(d_errs, 0, sizeof(int) * nb, st));
         { dsss_scope sc(c, DSSS_K_ROW_REDUCE, 8.0 * w_tot);
@@ -1114,15 +1117,48 @@ static int extract_frames_impl(dsss_ctx* c, const int* ids, int n, bool keep_tap
         { dsss_scope sc(c, DSSS_K_PYRAMID, (1.906 + 2.74) * w_tot, std::max(max_levels - 1, 1));
           for (int l = 1; l < max_levels; ++l)
               hipLaunchKernelGGL(resize_kernel, dim3((unsigned)(((size_t)max_cols[l] * max_rows[l] / 4 + 256 * RS_K) / (256 * RS_K)), nb), dim3(256), 0, st, d_exf, l); }
-        { dsss_scope sc(c, DSSS_K_FAST, 2.906 * w_tot);
-          const int fstride = max_cw <= 40 ? 40 : CELL_STRIDE, fwave = (2 * max_ch * fstride + 15) & ~15;      // window + arc values of one wavefront
-          if (fstride == 40) hipLaunchKernelGGL(fast_cells_kernel<40>, dim3((max_cells + 3) / 4, nb), dim3(256), 4 * fwave, st, d_exf, c->op.ini_th, c->op.min_th, fwave);
-          else hipLaunchKernelGGL(fast_cells_kernel<CELL_STRIDE>, dim3((max_cells + 3) / 4, nb), dim3(256), 4 * fwave, st, d_exf, c->op.ini_th, c->op.min_th, fwave); }
-        { dsss_scope sc(c, DSSS_K_FAST_COMPACT, 0, 2);
-          hipLaunchKernelGGL(scan_counts_kernel, dim3(nb), dim3(256), 0, st, d_exf);
-          hipLaunchKernelGGL(gather_cand_kernel, dim3((max_cells + GC_CELLS - 1) / GC_CELLS, nb), dim3(256), 0, st, d_exf); }
-        { dsss_scope sc(c, DSSS_K_QUADTREE);
-          dsss_launch_quadtree(st, d_inst, ninst, d_fr, nb); }
+        // FAST, candidate compaction and the quadtree run BY GROUPS OF LEVELS.  A quadtree instance is one workgroup whose time is the latency
+        // of its own level's candidates (1.4 ms on level 0 of a 2000 x 1024 frame, whatever the number of frames) during which most of the
+        // chip idles, so the levels are pipelined over four streams:
+        //     main            FAST of group 0, 1, ... back to back (the groups are independent of each other)
+        //     xs[2], xs[3]    per group, once its FAST is done: offsets (a chain over the groups: one more event) + candidate gather + the
+        //                     quadtrees of its levels; the groups alternate between the two streams
+        // and the main stream picks the results up after the last group.  Groups: levels 0 .. 4 alone, the small top levels together
+        // (every launch ends with a partly empty chip).  Two side streams, not more: the runtime folds streams onto four hardware queues,
+        // and a quadtree that shares its queue with the next group's gather holds it up.  DSSS_EX_PIPE=0: all on the main stream.
+        static const bool pipe_levels = !(getenv("DSSS_EX_PIPE") && atoi(getenv("DSSS_EX_PIPE")) == 0);
+        static const int solo_levels = getenv("DSSS_EX_SOLO") ? std::max(0, atoi(getenv("DSSS_EX_SOLO"))) : 5;
+        const int fstride = max_cw <= 40 ? 40 : CELL_STRIDE, fwave = (2 * max_ch * fstride + 15) & ~15;      // window + arc values of one wavefront
+        const hipStream_t s_qt[2] = { pipe_levels ? c->xs[2] : st, pipe_levels ? c->xs[3] : st };
+        bool qt_used[2] = { false, false };
+        int prev_group = -1;
+        int ngroups = 0;
+        for (int lo = 0; lo < max_levels; ++ngroups) {
+            const int hi = lo < solo_levels ? lo + 1 : max_levels;
+            int cells = 0;                               // the most cells a frame has in the group
+            for (int s2 = 0; s2 < nb; ++s2) { const level_geom& g = *G[b0 + s2]; cells = std::max(cells, g.cell_begin[std::min(hi, g.nlevels)] - g.cell_begin[std::min(lo, g.nlevels)]); }
+            if (cells > 0) {
+                { dsss_scope sc(c, DSSS_K_FAST, lo == 0 ? 2.906 * w_tot : 0.0);
+                  if (fstride == 40) hipLaunchKernelGGL(fast_cells_kernel<40>, dim3((cells + 3) / 4, nb), dim3(256), 4 * fwave, st, d_exf, lo, hi, c->op.ini_th, c->op.min_th, fwave);
+                  else hipLaunchKernelGGL(fast_cells_kernel<CELL_STRIDE>, dim3((cells + 3) / 4, nb), dim3(256), 4 * fwave, st, d_exf, lo, hi, c->op.ini_th, c->op.min_th, fwave); }
+                const int k = ngroups & 1;
+                const hipStream_t ss = s_qt[k];
+                if (pipe_levels) {
+                    HIPCHK(c, hipEventRecord(c->ex_lev_ev[ngroups], st)); HIPCHK(c, hipStreamWaitEvent(ss, c->ex_lev_ev[ngroups], 0));
+                    if (prev_group >= 0) HIPCHK(c, hipStreamWaitEvent(ss, c->ex_cmp_ev[prev_group], 0));      // this group's offsets start where the previous group's end
+                }
+                hipLaunchKernelGGL(scan_counts_kernel, dim3(nb), dim3(256), 0, ss, d_exf, lo, hi);
+                if (pipe_levels) HIPCHK(c, hipEventRecord(c->ex_cmp_ev[ngroups], ss));
+                prev_group = ngroups;
+                hipLaunchKernelGGL(gather_cand_kernel, dim3((cells + GC_CELLS - 1) / GC_CELLS, nb), dim3(256), 0, ss, d_exf, lo, hi);
+                for (int l = lo; l < hi; ++l) if (lev_cnt[l] > 0) dsss_launch_quadtree(ss, d_inst + (size_t)l * B, lev_cnt[l]);
+                qt_used[k] = true;
+            }
+            lo = hi;
+        }
+        { dsss_scope sc(c, DSSS_K_QUADTREE, 0, max_levels);        // (with the level pipeline: what compaction and quadtrees leave exposed after the last FAST launch)
+          if (pipe_levels) for (int k = 0; k < 2; ++k) if (qt_used[k]) { HIPCHK(c, hipEventRecord(c->ex_side_ev[k], s_qt[k])); HIPCHK(c, hipStreamWaitEvent(st, c->ex_side_ev[k], 0)); }
+          dsss_launch_quadtree_collect(st, d_fr, nb); }
         { dsss_scope sc(c, DSSS_K_DESC, (double)nb * c->op.nfeatures * (49.0 * 49.0 + 56.0));
           hipLaunchKernelGGL(orient_desc_kernel, dim3((c->kcap + 3) / 4, nb), dim3(256), 0, st, d_exf); }
         { dsss_scope sc(c, DSSS_K_FILTER);
@@ -1168,7 +1204,7 @@ static int extract_frames_impl(dsss_ctx* c, const int* ids, int n, bool keep_tap
 static int extract_frames(dsss_ctx* c, const int* ids, int n, bool keep_taps)
 {
     const int rc = extract_frames_impl(c, ids, n, keep_taps);
-    if (rc != DSSS_OK) { (void)hipStreamSynchronize(c->xs[1]); (void)hipStreamSynchronize(c->stream); (void)hipGetLastError(); }
+    if (rc != DSSS_OK) { for (int k = 0; k < 4; ++k) (void)hipStreamSynchronize(c->xs[k]); (void)hipStreamSynchronize(c->stream); (void)hipGetLastError(); }
     return rc;
 }
 

@@ -64,6 +64,7 @@ struct dsss_ctx {
     hipStream_t stream = nullptr;
     hipStream_t xs[4] = {nullptr, nullptr, nullptr, nullptr};   // extra streams: frames of one extraction batch overlap on them
     hipEvent_t xev[4] = {nullptr, nullptr, nullptr, nullptr}; hipEvent_t xev_main = nullptr;
+    hipEvent_t ex_lev_ev[DSSS_MAX_LEVELS] = {}, ex_cmp_ev[DSSS_MAX_LEVELS] = {}; hipEvent_t ex_side_ev[3] = {};    // extraction: FAST of level group g done (main stream), its candidate offsets known (side stream); quadtrees of a side stream done
     std::string err;
     dsss_mask_params mp;
     dsss_orb_params op;

@@ -24,4 +24,5 @@ struct qt_frame {                // one frame: gathers its levels into kp_in rec
     qt_kp_in* kin; int* nk; int* err;
 };
 
-void dsss_launch_quadtree(hipStream_t st, const qt_inst* d_inst, int ninst, const qt_frame* d_frames, int nframes);
+void dsss_launch_quadtree(hipStream_t st, const qt_inst* d_inst, int ninst);                      // one workgroup per instance
+void dsss_launch_quadtree_collect(hipStream_t st, const qt_frame* d_frames, int nframes);         // after every level of the frames has run

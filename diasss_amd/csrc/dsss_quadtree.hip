@@ -487,8 +487,11 @@ __global__ __launch_bounds__(256) void quadtree_collect_kernel(const qt_frame* _
     if (threadIdx.x == 0) { if (off > Fm.kcap) { *Fm.err = 4; off = Fm.kcap; } *Fm.nk = off; }
 }
 
-void dsss_launch_quadtree(hipStream_t st, const qt_inst* d_inst, int ninst, const qt_frame* d_frames, int nframes)
+void dsss_launch_quadtree(hipStream_t st, const qt_inst* d_inst, int ninst)
 {
     if (ninst > 0) hipLaunchKernelGGL(quadtree_kernel, dim3(ninst), dim3(QT_THREADS), 0, st, d_inst);
+}
+void dsss_launch_quadtree_collect(hipStream_t st, const qt_frame* d_frames, int nframes)
+{
     if (nframes > 0) hipLaunchKernelGGL(quadtree_collect_kernel, dim3(nframes), dim3(256), 0, st, d_frames);
 }
