@@ -295,3 +295,55 @@ def test_gaussian_taps_derived_in_the_test(orc):
     err = np.abs(out.astype(np.float64) - v).max()
     assert err <= bound and err <= 3.0, (err, bound)                         # worst case from the taps; white noise stays well inside it
     assert abs(out.mean() - v.mean()) < 0.1                                   # the taps sum to exactly 256: no brightness drift
+
+
+def test_sincos_polynomial_vs_numpy(orc):
+    """The deterministic sin / cos that stands in for libm (frame.cpp:141-149 geo image, ORBextractor.cpp:113 through a float cast):
+    Cody-Waite reduction + the fdlibm kernels without FMA.  Against numpy's libm on a dense set of angles -- headings, headings +- pi / 2,
+    descriptor angles in radians -- it must stay within an ulp or two of the correctly rounded value, and be exact at 0."""
+    L = orc.lib()
+    rng = np.random.default_rng(6)
+    xs = np.concatenate([rng.uniform(-4 * np.pi, 4 * np.pi, 120000), np.linspace(-np.pi, np.pi, 20001),
+                         np.deg2rad(np.arange(0, 360, 0.01)), rng.uniform(-1e-3, 1e-3, 5000)])
+    s = C.c_double(0); c = C.c_double(0)
+    worst = 0.0
+    for x in xs:
+        L.orc_sincos(float(x), C.byref(s), C.byref(c))
+        worst = max(worst, abs(s.value - np.sin(x)), abs(c.value - np.cos(x)))
+    assert worst < 4.5e-16, worst                                             # |sin|, |cos| <= 1: 2 ulp of 1.0
+    L.orc_sincos(0.0, C.byref(s), C.byref(c))
+    assert s.value == 0.0 and c.value == 1.0
+
+
+def test_brief_rotation_rounding_vs_float32_libm():
+    """computeOrbDescriptor rotates the 512 pattern points by (cosf, sinf) of the keypoint angle and rounds (ORBextractor.cpp:108-126);
+    the oracle and the kernels take (float) of the deterministic double sin / cos instead.  How often can that change a descriptor?
+    For every angle fastAtan2 can return to 0.01 degree and every pattern point: the rounded coordinates from the two kinds of sin / cos.
+    They differ only where a float sin / cos differs in its last bit AND the rotated coordinate sits on a rounding boundary."""
+    import os
+    pat = np.array([int(t) for t in open(os.path.join(os.path.dirname(__file__), "..", "oracle", "orb_pattern_31.inc")).read().replace("\n", "").split(",") if t.strip()],
+                   np.float32).reshape(-1, 2)
+    assert pat.shape == (512, 2)
+    import ctypes as C2
+    from oracle import binding as orc
+    L = orc.lib()
+    factor = np.float32(np.float32(3.1415926535897932384626433832795) / np.float32(180.0))
+    ang = (np.arange(0, 36000, dtype=np.float32) * np.float32(0.01)) * factor          # float angle in radians, as the reference forms it
+    s = C2.c_double(0); c = C2.c_double(0)
+    a_poly = np.empty(len(ang), np.float32); b_poly = np.empty(len(ang), np.float32)
+    for i, x in enumerate(ang):
+        L.orc_sincos(float(x), C2.byref(s), C2.byref(c))
+        a_poly[i] = np.float32(c.value); b_poly[i] = np.float32(s.value)
+    a_libm = np.cos(ang); b_libm = np.sin(ang)                                          # float32 in, float32 out: the float routines
+    assert a_libm.dtype == np.float32
+    last_bit = np.mean((a_poly != a_libm) | (b_poly != b_libm))
+    x0 = pat[:, 0][None, :]; y0 = pat[:, 1][None, :]
+    def coords(a, b):
+        a = a[:, None]; b = b[:, None]
+        return np.rint(x0 * b + y0 * a).astype(np.int32), np.rint(x0 * a - y0 * b).astype(np.int32)     # float32 products and sums, round half to even
+    r1, c1 = coords(a_poly, b_poly); r2, c2 = coords(a_libm, b_libm)
+    differ = (r1 != r2) | (c1 != c2)
+    frac = differ.mean()
+    assert last_bit < 0.5                                                     # the float of the double result is the correctly rounded one almost always
+    assert frac < 2e-5, (frac, last_bit)                                      # < 0.01 pattern points of a descriptor on average: at most a stray bit
+    assert np.abs(r1 - r2).max() <= 1 and np.abs(c1 - c2).max() <= 1
