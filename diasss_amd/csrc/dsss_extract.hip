@@ -302,7 +302,7 @@ struct level_tab { const uint8_t* img[DSSS_MAX_LEVELS]; int cols[DSSS_MAX_LEVELS
 //   * the arcs that start at k and k + 1 (k even) share the window [k + 1, k + 8]: eight windows of 8 by doubling over the ODD
 //     positions (2 x 24 packed min / max), and  max(min(W, d[k]), min(W, d[k + 9])) = min(W, max(d[k], d[k + 9]))  closes both
 //     arcs with three instructions per polarity.
-// 72 vector instructions per pixel; min and max are exact, so the value is the same whatever the order: bit-identical output.
+// 65 vector instructions per pixel; min and max are exact, so the value is the same whatever the order: bit-identical output.
 typedef short fast_v2 __attribute__((ext_vector_type(2)));
 template <int stride>
 __device__ inline uint32_t fast_arc4(const uint8_t* __restrict__ w, int xg, int y, int tmin)      // pixels (3 + xg + k, y), k = 0..3; xg a multiple of 4
@@ -325,16 +325,18 @@ __device__ inline uint32_t fast_arc4(const uint8_t* __restrict__ w, int xg, int 
             const uint32_t idx = (uint32_t)(lowq ? c0 : c0 - 4);
             return __builtin_bit_cast(fast_v2, __builtin_amdgcn_perm(hi, lo, 0x0c000c00u | idx | ((idx + 1u) << 16)));
         };
+        // (the arcs are taken over the ring VALUES: max over arcs of min (v - ring) = v - min over arcs of max ring, and the dark side
+        // likewise -- two subtractions per pair instead of sixteen)
         const fast_v2 vv = pair_at(3, 2 * pr + 3);
         fast_v2 d[16];
 #pragma unroll
-        for (int j = 0; j < 16; ++j) d[j] = vv - pair_at(rdy[j] + 3, 2 * pr + rdx[j] + 3);
+        for (int j = 0; j < 16; ++j) d[j] = pair_at(rdy[j] + 3, 2 * pr + rdx[j] + 3);
         fast_v2 lo2[8], hi2[8], lo4[8], hi4[8];      // windows starting at the odd positions 2 i + 1
 #pragma unroll
         for (int i = 0; i < 8; ++i) { lo2[i] = __builtin_elementwise_min(d[2 * i + 1], d[(2 * i + 2) & 15]); hi2[i] = __builtin_elementwise_max(d[2 * i + 1], d[(2 * i + 2) & 15]); }
 #pragma unroll
         for (int i = 0; i < 8; ++i) { lo4[i] = __builtin_elementwise_min(lo2[i], lo2[(i + 1) & 7]); hi4[i] = __builtin_elementwise_max(hi2[i], hi2[(i + 1) & 7]); }
-        fast_v2 bmin = { -32768, -32768 }, bmax = { 32767, 32767 };
+        fast_v2 bmin = { -32768, -32768 }, bmax = { 32767, 32767 };      // largest arc minimum (dark side), smallest arc maximum (bright side) of the ring
 #pragma unroll
         for (int i = 0; i < 8; ++i) {                // k = 2 i: window [k + 1, k + 8], closed by d[k] and by d[k + 9]
             const fast_v2 w8lo = __builtin_elementwise_min(lo4[i], lo4[(i + 2) & 7]), w8hi = __builtin_elementwise_max(hi4[i], hi4[(i + 2) & 7]);
@@ -342,8 +344,7 @@ __device__ inline uint32_t fast_arc4(const uint8_t* __restrict__ w, int xg, int 
             bmin = __builtin_elementwise_max(bmin, __builtin_elementwise_min(w8lo, __builtin_elementwise_max(e0, e1)));
             bmax = __builtin_elementwise_min(bmax, __builtin_elementwise_max(w8hi, __builtin_elementwise_min(e0, e1)));
         }
-        const fast_v2 zero = { 0, 0 };
-        const fast_v2 best = __builtin_elementwise_max(bmin, zero - bmax);
+        const fast_v2 best = __builtin_elementwise_max(vv - bmax, bmin - vv);
         const int b0 = best.x, b1 = best.y;
         out |= (uint32_t)(b0 > tmin ? b0 : 0) << (16 * pr);
         out |= (uint32_t)(b1 > tmin ? b1 : 0) << (16 * pr + 8);
