@@ -25,7 +25,11 @@ struct mini_val { double L[3]; pose_t X1, X2; };
 #define LS 16                  // LDS row stride (doubles)
 // The problem's constants and its current / trial values live in LDS too: every lane of the group holds the same 100 doubles,
 // and kept in registers (200 VGPRs of the 512) they were what held the kernel at one wavefront per SIMD with 110 spills.
-struct lc_lds { double J[MR * LS]; double H[MD * LS]; double L[MD * LS]; mini_prob m; mini_val v, nv; };
+// H and its Cholesky factor share one 15 x 16 array: H keeps its lower triangle ([i][j], j <= i), the factor goes into the other half
+// transposed and shifted by a column (L(i, k), k <= i, at [k][i + 1]) -- H survives the retries of a trial with a larger lambda, and
+// 4.9 KB per problem instead of 6.8 let eight workgroups share a compute unit's LDS (two wavefronts per SIMD).
+#define LIDX(i, k) ((k) * LS + (i) + 1)
+struct lc_lds { double J[MR * LS]; double H[MD * LS]; double r[MR]; mini_prob m; mini_val v, nv; };
 
 // The pose algebra of a problem is a chain of a few hundred dependent f64 operations (two Logmaps with acos / sin / tan, two sss
 // factors with a square root and divisions) that every lane of the group used to run in full: 75 % of the kernel's cycles (in-kernel
@@ -47,8 +51,8 @@ __device__ inline void lc_select_pose(bool second, const pose_t& a, const pose_t
 #pragma unroll
     for (int k = 0; k < 3; ++k) out->t[k] = second ? b.t[k] : a.t[k];
 }
-// whitened residual r (registers, every lane) and Jacobian J (LDS; lane `lane` clears row `lane`, lanes 0 and 8 write the entries of
-// their halves)
+// whitened residual r and Jacobian J.  With J: both go to LDS (lane `lane` clears row `lane` of J, lanes 0 and 8 write the entries of their
+// halves and their halves of r).  Without J (error evaluation): r in registers on every lane.
 __device__ static void mini_lin(const mini_prob& m, const mini_val& v, double* r, double* J, int lane)
 {
     const bool hb = (lane & 8) != 0;                       // second half of the group: between factor, target's sss factor
@@ -69,8 +73,13 @@ __device__ static void mini_lin(const mini_prob& m, const mini_val& v, double* r
     pose_log(&E, xi);
 #pragma unroll
     for (int i = 0; i < 6; ++i) { const double sg = hb ? m.sig_odo[i] : m.sig_prior[i]; rr[i] = xi[i] / sg; }
+    if (!J) {
 #pragma unroll
-    for (int i = 0; i < 6; ++i) { r[i] = __shfl(rr[i], 0, LG); r[6 + i] = __shfl(rr[i], 8, LG); }
+        for (int i = 0; i < 6; ++i) { r[i] = __shfl(rr[i], 0, LG); r[6 + i] = __shfl(rr[i], 8, LG); }
+    } else if (wr) {                                       // the linearisation keeps its residual in LDS (r = the group's S.r): sixteen registers less across the solve
+#pragma unroll
+        for (int i = 0; i < 6; ++i) r[(hb ? 6 : 0) + i] = rr[i];
+    }
     if (J) {
         pose_t hi; double Ad[36];
         pose_inverse(&t1, &hi);                            // t1 = h on the second half
@@ -95,10 +104,13 @@ __device__ static void mini_lin(const mini_prob& m, const mini_val& v, double* r
     const double sg0 = hb ? m.sig_t[0] : m.sig_s[0], sg1 = hb ? m.sig_t[1] : m.sig_s[1];
     sss_factor(v.L, X, slant, 0.0, ee, J ? H1 : nullptr, H2);
     r2[0] = ee[0] / sg0; r2[1] = ee[1] / sg1;
+    if (!J) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i) { r[12 + i] = __shfl(r2[i], 0, LG); r[14 + i] = __shfl(r2[i], 8, LG); }
+        for (int i = 0; i < 2; ++i) { r[12 + i] = __shfl(r2[i], 0, LG); r[14 + i] = __shfl(r2[i], 8, LG); }
+    }
     if (wr) {
         const int row0 = hb ? 14 : 12, col0 = hb ? 9 : 3;
+        r[row0] = r2[0]; r[row0 + 1] = r2[1];
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const double sg = i ? sg1 : sg0;
@@ -119,7 +131,7 @@ __device__ static double mini_err(const mini_prob& m, const mini_val& v, int lan
     for (int i = 0; i < MR; ++i) s += r[i] * r[i];
     return 0.5 * s;
 }
-// lane a < 15: row a of H = J^T J (the whole row: both triangles hold bitwise equal sums), and g[a] = (J^T r)[a]
+// lane a < 15: row a of H = J^T J up to the diagonal, and g[a] = (J^T r)[a]
 __device__ static double normal_eq(const double* J, const double* r, double* H, int lane)
 {
     double g = 0;
@@ -133,32 +145,34 @@ __device__ static double normal_eq(const double* J, const double* r, double* H, 
             double t = 0;
 #pragma unroll
             for (int k = 0; k < MR; ++k) t += ca[k] * J[k * LS + b2];
-            H[lane * LS + b2] = t;
+            if (b2 <= lane) H[lane * LS + b2] = t;
+            __builtin_amdgcn_sched_barrier(0);
         }
     }
     __builtin_amdgcn_wave_barrier();
     return g;
 }
-// in-place lower Cholesky of A = H + lambda I into L (LDS): lane i owns row i in registers; returns 0 on success (uniform
+// lower Cholesky of A = H + lambda I into L (LDS, the LIDX half of the array H lives in): lane i owns row i in registers; returns 0 on success (uniform
 // over the group).  Column j: lanes i >= j subtract sum_k L(i,k) L(j,k), k ascending, exactly as the sequential form.
 __device__ static int chol15(const double* H, double lambda, double* L, int lane)
 {
     double row[MD];
     const int li = lane < MD ? lane : MD - 1;               // lane 15 shadows row 14 and never writes
 #pragma unroll
-    for (int j = 0; j < MD; ++j) row[j] = H[li * LS + j] + (j == li ? lambda : 0.0);
+    for (int j = 0; j < MD; ++j) row[j] = j <= li ? H[li * LS + j] + (j == li ? lambda : 0.0) : 0.0;      // (the entries right of the diagonal are never used)
     int bad = 0;
 #pragma unroll
     for (int j = 0; j < MD; ++j) {
         double sacc = row[j];
 #pragma unroll
-        for (int k = 0; k < MD; ++k) if (k < j) sacc -= row[k] * L[j * LS + k];
+        for (int k = 0; k < MD; ++k) if (k < j) sacc -= row[k] * L[LIDX(j, k)];
         const double dj = __shfl(sacc, j, LG);              // pivot before the square root, from the diagonal lane
         if (!(dj > 0) || !isfinite(dj)) { bad = 1; break; }
         const double dq = sqrt(dj);
         row[j] = li == j ? dq : sacc / dq;
-        if (lane < MD && li >= j) L[li * LS + j] = row[j];
+        if (lane < MD && li >= j) L[LIDX(li, j)] = row[j];
         __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_sched_barrier(0);
     }
     return bad;
 }
@@ -169,20 +183,22 @@ __device__ static void chol15_solve(const double* L, double* b)
     for (int i = 0; i < MD; ++i) {
         double sacc = b[i];
 #pragma unroll
-        for (int k = 0; k < MD; ++k) if (k < i) sacc -= L[i * LS + k] * b[k];
-        b[i] = sacc / L[i * LS + i];
+        for (int k = 0; k < MD; ++k) if (k < i) sacc -= L[LIDX(i, k)] * b[k];
+        b[i] = sacc / L[LIDX(i, i)];
+        __builtin_amdgcn_sched_barrier(0);
     }
 #pragma unroll
     for (int i = MD - 1; i >= 0; --i) {
         double sacc = b[i];
 #pragma unroll
-        for (int k = 0; k < MD; ++k) if (k > i) sacc -= L[k * LS + i] * b[k];
-        b[i] = sacc / L[i * LS + i];
+        for (int k = 0; k < MD; ++k) if (k > i) sacc -= L[LIDX(k, i)] * b[k];
+        b[i] = sacc / L[LIDX(i, i)];
+        __builtin_amdgcn_sched_barrier(0);
     }
 }
 
 // kp7: n x 7; per problem: frame pointers (pose6 / alt / gr of source and target), M of both, flip flags
-__global__ __launch_bounds__(64) void lc_kernel(const double* __restrict__ kp7, int n,
+__global__ __launch_bounds__(64, 2) void lc_kernel(const double* __restrict__ kp7, int n,
                                                 const int* __restrict__ kp7_pair, const uint8_t* __restrict__ kp7_flip,
                                                 const int* __restrict__ act_s, const int* __restrict__ act_t,
                                                 int single_s, int single_t, int single_flip,
@@ -257,28 +273,27 @@ __global__ __launch_bounds__(64) void lc_kernel(const double* __restrict__ kp7, 
     int iters = 0;
     double err = mini_err(M_, V_, lane);
     const double err0 = err;
-    double r[MR], d[MD];
+    double d[MD];
+    const double* r = S.r;                                  // (LDS; written by mini_lin)
     if (err > 0) {
         double cur;
         do {
             cur = err;
-            mini_lin(M_, V_, r, S.J, lane);
+            mini_lin(M_, V_, S.r, S.J, lane);
             const double g_mine = normal_eq(S.J, r, S.H, lane);
             double oldLin = 0;
 #pragma unroll
             for (int k = 0; k < MR; ++k) oldLin += r[k] * r[k];
             oldLin *= 0.5;
             for (;;) {
-                const bool ok = chol15(S.H, lambda, S.L, lane) == 0;
+                const bool ok = chol15(S.H, lambda, S.H, lane) == 0;
                 bool success = false, stop = false;
                 double newErr = 0;
                 if (ok) {
 #pragma unroll
                     for (int a = 0; a < MD; ++a) d[a] = -__shfl(g_mine, a, LG);
-                    chol15_solve(S.L, d);
-                    double sk = r[0];                                   // lane k: row k of J d + r
-#pragma unroll
-                    for (int k = 0; k < MR; ++k) if (k == lane) sk = r[k];
+                    chol15_solve(S.H, d);
+                    double sk = r[lane];                                // lane k: row k of J d + r
 #pragma unroll
                     for (int a = 0; a < MD; ++a) sk += S.J[lane * LS + a] * d[a];
                     double newLin = 0;
@@ -348,13 +363,13 @@ __global__ __launch_bounds__(64) void lc_kernel(const double* __restrict__ kp7, 
     const double fin = sqrt(x_n * x_n + y_n * y_n);
     o.score = ini / fin - 2;
     // Marginals(graph, result).marginalCovariance(X2).diagonal() (:956-959): lane c < 6 solves for unit vector 9 + c
-    mini_lin(M_, V_, r, S.J, lane);
+    mini_lin(M_, V_, S.r, S.J, lane);
     (void)normal_eq(S.J, r, S.H, lane);
     double var_mine = NAN;
-    if (chol15(S.H, 0.0, S.L, lane) == 0) {
+    if (chol15(S.H, 0.0, S.H, lane) == 0) {
 #pragma unroll
         for (int a = 0; a < MD; ++a) d[a] = (a == 9 + lane) ? 1.0 : 0.0;
-        chol15_solve(S.L, d);
+        chol15_solve(S.H, d);
         var_mine = 0;
 #pragma unroll
         for (int a = 9; a < MD; ++a) if (a == 9 + lane) var_mine = d[a];
