@@ -416,20 +416,29 @@ int dsss_frames_set(dsss_ctx* c, int n, const int* ids, const double* const* raw
     }
     dsss_geo_batch& G = c->gbatches[b];
     HIPCHK(c, hipEventSynchronize(G.ev));                   // the staging area may still feed its previous upload
-    static const int T_env = getenv("DSSS_FS_THREADS") ? atoi(getenv("DSSS_FS_THREADS")) : 0;
-    const int T = T_env > 0 ? T_env : (n >= 16 ? 4 : 1);       // (eight threads were slower than four: the pointer-attribute queries of frame_fill serialise)
-    std::vector<hipError_t> errs(T, hipSuccess);
-    auto work = [&](int t) { for (int i = t; i < n; i += T) { const hipError_t e = frame_fill(c, ids[i], G.h + off[i], pose6[i], alt[i], grange[i]); if (e != hipSuccess) errs[t] = e; } };
-    dsss_pool_run(T, work);
-    for (int t = 0; t < T; ++t) HIPCHK(c, errs[t]);
-    HIPCHK(c, hipMemcpyAsync(G.d, G.h, total * sizeof(double), hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipEventRecord(G.ev, c->stream));
+    // The frames point into the batch's device buffer first; then the extraction of the frames whose images are already in HBM is
+    // STARTED (everything but the last kernel, which samples the geometry) and runs while this thread packs the geometry into the
+    // staging area; the upload follows on the copy stream and the context's stream waits for it behind those kernels.  The
+    // reference's Frame constructor normalises, masks and runs DetectFeature itself (frame.cpp:45-52); dsss_extract_many then
+    // only finishes.  (The 1.3 ms of host work of a 200-frame call were idle time of the GPU.)
     for (int i = 0; i < n; ++i) {
         dsss_frame& f = c->frames[ids[i]];
         f.gbatch = b; G.refs++;
         f.pose6 = G.d + off[i]; f.alt = f.pose6 + (size_t)f.N * 6; f.gr = f.alt + f.N; f.h_geo = G.h + off[i];
         rc = frame_submit(c, ids[i], raw ? raw[i] : nullptr, false); if (rc) return rc;
     }
+    HIPCHK(c, hipEventRecord(c->xev[0], c->stream));        // whatever is queued so far may still read the buffer's previous contents
+    if (raw) dsss_extract_eager(c, ids, n);
+    static const int T_env = getenv("DSSS_FS_THREADS") ? atoi(getenv("DSSS_FS_THREADS")) : 0;
+    const int T = T_env > 0 ? T_env : (n >= 16 ? 4 : 1);       // (eight threads were slower than four: the pointer-attribute queries of frame_fill serialise)
+    std::vector<hipError_t> errs(T, hipSuccess);
+    auto work = [&](int t) { for (int i = t; i < n; i += T) { const hipError_t e = frame_fill(c, ids[i], G.h + off[i], pose6[i], alt[i], grange[i]); if (e != hipSuccess) errs[t] = e; } };
+    dsss_pool_run(T, work);
+    for (int t = 0; t < T; ++t) if (errs[t] != hipSuccess) { c->ex_eager_valid = false; HIPCHK(c, errs[t]); }
+    HIPCHK(c, hipStreamWaitEvent(c->xs[1], c->xev[0], 0));
+    HIPCHK(c, hipMemcpyAsync(G.d, G.h, total * sizeof(double), hipMemcpyHostToDevice, c->xs[1]));
+    HIPCHK(c, hipEventRecord(G.ev, c->xs[1]));
+    HIPCHK(c, hipStreamWaitEvent(c->stream, G.ev, 0));      // every later consumer of the geometry is ordered behind the upload
     if (getenv("DSSS_EX_VERBOSE")) fprintf(stderr, "[dsss frames_set] %d frames in %.1f us\n", n, std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count());
     return DSSS_OK;
 }

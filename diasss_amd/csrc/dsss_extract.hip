@@ -991,9 +991,14 @@ static ex_layout make_layout(int N, const level_geom& g, int kcap)
 
 // extraction of a list of frames, batched: every stage is one launch for the whole batch (the pyramid: one per level),
 // about twenty launches and one host synchronisation per batch of up to EX_BATCH frames.
-static int extract_frames_impl(dsss_ctx* c, const int* ids, int n, bool keep_taps)
+// phase 0: the whole extraction.  Phases 1 and 2 split it at the one kernel that needs the frame GEOMETRY (mask_filter_kernel: the geo
+// sample of the surviving keypoints): phase 1 enqueues everything before it and returns without waiting, phase 2 enqueues the rest and
+// finishes -- dsss_frames_set starts phase 1 while it still packs and uploads the geometry (dsss_extract_eager below), as the
+// reference's Frame constructor runs DetectFeature itself (frame.cpp:45-52).  Both need the frames to fit one batch, images in HBM.
+static int extract_frames_impl(dsss_ctx* c, const int* ids, int n, bool keep_taps, int phase = 0)
 {
     if (n <= 0) return DSSS_OK;
+    const bool doA = phase != 2, doB = phase != 1;
     int rc = dsss_ensure_store(c); if (rc) return rc;
     std::vector<level_geom*> G(n);
     size_t slot_bytes = 0;
@@ -1013,6 +1018,7 @@ static int extract_frames_impl(dsss_ctx* c, const int* ids, int n, bool keep_tap
     bool any_pending = false;
     for (int i = 0; i < n; ++i) any_pending = any_pending || c->frames[ids[i]].raw_pending;
     if (any_pending) { static const int sb = getenv("DSSS_EX_UPLOAD_BATCH") ? std::max(1, atoi(getenv("DSSS_EX_UPLOAD_BATCH"))) : 8; B = std::min(B, sb); }
+    if (phase != 0 && (any_pending || B < n)) DSSS_FAIL(c, DSSS_E_STATE, "two-phase extraction needs one batch of device-resident images");
     hipEvent_t up_ev[2] = { c->xev[1], c->xev[2] };
     auto upload_batch = [&](int b0, hipEvent_t ev) -> hipError_t {
         hipError_t e = hipSuccess;
@@ -1106,6 +1112,7 @@ static int extract_frames_impl(dsss_ctx* c, const int* ids, int n, bool keep_tap
             qf.kin = (kp_in*)(S + L.kin); qf.nk = (int*)(S + L.nk); qf.err = d_errs + s;
         }
         (void)maxNM4;
+        if (doA) {
         HIPCHK(c, hipMemcpyAsync(T0, P0, tab_bytes - err_bytes, hipMemcpyHostToDevice, st));
         HIPCHK(c, hipMemsetAsync(d_errs, 0, sizeof(int) * nb, st));
         { dsss_scope sc(c, DSSS_K_ROW_REDUCE, 8.0 * w_tot);
@@ -1162,6 +1169,9 @@ static int extract_frames_impl(dsss_ctx* c, const int* ids, int n, bool keep_tap
           dsss_launch_quadtree_collect(st, d_fr, nb); }
         { dsss_scope sc(c, DSSS_K_DESC, (double)nb * c->op.nfeatures * (49.0 * 49.0 + 56.0));
           hipLaunchKernelGGL(orient_desc_kernel, dim3((c->kcap + 3) / 4, nb), dim3(256), 0, st, d_exf); }
+        HIPCHK(c, hipGetLastError());
+        }       // doA
+        if (!doB) return DSSS_OK;                    // (phase 1: one batch)
         { dsss_scope sc(c, DSSS_K_FILTER);
           hipLaunchKernelGGL(mask_filter_kernel, dim3(nb), dim3(256), 0, st, d_exf); }
         HIPCHK(c, hipGetLastError());
@@ -1204,9 +1214,36 @@ static int extract_frames_impl(dsss_ctx* c, const int* ids, int n, bool keep_tap
 // page-locked images are free again whenever dsss_extract* returns, with or without an error (include/dsss.h, dsss_frame_set).
 static int extract_frames(dsss_ctx* c, const int* ids, int n, bool keep_taps)
 {
-    const int rc = extract_frames_impl(c, ids, n, keep_taps);
+    // the frames dsss_frames_set already started on (phase 1): only the tail is left.  Anything else drops that start (its kernels
+    // are queued on the context's stream ahead of whatever follows; their results are simply overwritten)
+    int phase = 0;
+    if (c->ex_eager_valid) {
+        const bool same = !keep_taps && (int)c->ex_eager_ids.size() == n && std::equal(ids, ids + n, c->ex_eager_ids.begin())
+                          && memcmp(&c->ex_eager_op, &c->op, sizeof c->op) == 0 && memcmp(&c->ex_eager_mp, &c->mp, sizeof c->mp) == 0;
+        c->ex_eager_valid = false;
+        if (same) phase = 2;
+    }
+    const int rc = extract_frames_impl(c, ids, n, keep_taps, phase);
     if (rc != DSSS_OK) { for (int k = 0; k < 4; ++k) (void)hipStreamSynchronize(c->xs[k]); (void)hipStreamSynchronize(c->stream); (void)hipGetLastError(); }
     return rc;
+}
+
+// dsss_frames_set: start the extraction of the frames whose images are in HBM (see extract_frames_impl).  Not an error if it cannot.
+void dsss_extract_eager(dsss_ctx* c, const int* ids, int n)
+{
+    static const bool on = !(getenv("DSSS_EX_EAGER") && atoi(getenv("DSSS_EX_EAGER")) == 0);
+    c->ex_eager_valid = false;
+    if (!on || n <= 0 || n > EX_BATCH) return;
+    std::vector<int> mine;
+    for (int i = 0; i < n; ++i) {
+        const dsss_frame& f = c->frames[ids[i]];
+        if (!f.has_raw) continue;                    // (a rank sets every frame's geometry and the images of its own)
+        if (f.raw_pending) return;                   // host-resident images are streamed in by the batch loop of the full path
+        mine.push_back(ids[i]);
+    }
+    if (mine.empty()) return;
+    if (extract_frames_impl(c, mine.data(), (int)mine.size(), false, 1) != DSSS_OK) { (void)hipGetLastError(); return; }      // (the full path will report what is wrong)
+    c->ex_eager_ids.swap(mine); c->ex_eager_op = c->op; c->ex_eager_mp = c->mp; c->ex_eager_valid = true;
 }
 
 extern "C" {

@@ -87,6 +87,8 @@ struct dsss_ctx {
     // extraction scratch (grown on demand)
     void* ex_scratch = nullptr; size_t ex_scratch_bytes = 0;
     void* ex_pinned = nullptr; size_t ex_pinned_bytes = 0;
+    // extraction started by dsss_frames_set (everything but the kernel that needs the geometry): for which frames, under which parameters
+    bool ex_eager_valid = false; std::vector<int> ex_eager_ids; dsss_orb_params ex_eager_op; dsss_mask_params ex_eager_mp;
     std::vector<dsss_geo_batch> gbatches;
     // pose-graph solver arena: device chunks kept between solves (dsss_pg.hip), bump-allocated, reset per solve
     std::vector<std::pair<void*, size_t>> pg_chunks; size_t pg_chunk_cur = 0, pg_chunk_off = 0;
@@ -151,6 +153,7 @@ struct dsss_scope {
     }
 };
 
+void dsss_extract_eager(dsss_ctx* c, const int* ids, int n);      // dsss_frames_set: start extracting the frames whose images are in HBM
 int dsss_ensure_store(dsss_ctx* c);                 // allocate the feature store for the current kcap
 int dsss_frame_geo_bbox(dsss_ctx* c, int id);       // device computation of the geo bounding box (asynchronous)
 int dsss_sync_bboxes(dsss_ctx* c);                  // make dsss_frame::bbox valid on the host
