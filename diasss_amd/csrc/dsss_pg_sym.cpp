@@ -115,7 +115,7 @@ namespace {
 struct nd_tree { int a = -1, b = -1, size = 0; };          // children (indices into the node pool) or -1,-1 for a leaf
 #define PG_ND_PAR 4
 struct nd_ctx {
-    const int* adj_ptr; const int* adj_idx; const double* cx; const double* cy; char* side; int leaf; int both_axes; bool geo_first;
+    const int* adj_ptr; const int* adj_idx; const double* cx; const double* cy; char* side; char* side2; int leaf; int both_axes; bool geo_first;
     const int* part; char* iface;                          // rank of every node (or null); iface[v] = 1 for rank-level separator nodes
     const char* forced;                                    // nodes with a neighbour of a HIGHER rank: they must end up in the interface (see nd_order)
     std::vector<nd_tree>* pool; std::mutex* mu;
@@ -136,21 +136,23 @@ int nd_order(std::vector<int>& nodes, const nd_ctx& C, std::vector<int>& order, 
     // on that: a factor belongs to the rank of its higher pose and adds to the diagonal block of the lower one, which therefore has to
     // be an interface separator (summed over the ranks).  Rank cuts satisfy it by themselves (lower ranks are the lower half).
     // b: when given, receives the upper half without its separator nodes.
-    auto boundary = [&](const std::vector<int>& nd, size_t h, std::vector<int>* a, std::vector<int>* s, std::vector<int>* b = nullptr) {
-        for (size_t i = 0; i < nd.size(); ++i) C.side[nd[i]] = i < h ? 1 : 2;
+    // (sd: the scratch marks of the split -- C.side, or C.side2 for the second candidate, which is evaluated on another thread)
+    auto boundary = [&](const std::vector<int>& nd, size_t h, std::vector<int>* a, std::vector<int>* s, std::vector<int>* b = nullptr, char* sd = nullptr) {
+        if (!sd) sd = C.side;
+        for (size_t i = 0; i < nd.size(); ++i) sd[nd[i]] = i < h ? 1 : 2;
         size_t cnt = 0;
         for (size_t i = 0; i < h; ++i) {
             const int v = nd[i];
             bool cut = false;
             for (int q = C.adj_ptr[v]; q < C.adj_ptr[v + 1]; ++q) {
                 const int u = C.adj_idx[q];
-                if (C.side[u] != 2 && C.side[u] != 4) continue;
-                if (multi && C.part[u] < C.part[v]) { if (C.side[u] == 2) { C.side[u] = 4; ++cnt; } }      // the upper-half end has the lower rank
+                if (sd[u] != 2 && sd[u] != 4) continue;
+                if (multi && C.part[u] < C.part[v]) { if (sd[u] == 2) { sd[u] = 4; ++cnt; } }      // the upper-half end has the lower rank
                 else cut = true;
             }
             if (cut) { ++cnt; if (s) s->push_back(v); } else if (a) a->push_back(v);
         }
-        if (s || b) for (size_t i = h; i < nd.size(); ++i) { const int u = nd[i]; if (C.side[u] == 4) { if (s) s->push_back(u); } else if (b) b->push_back(u); }
+        if (s || b) for (size_t i = h; i < nd.size(); ++i) { const int u = nd[i]; if (sd[u] == 4) { if (s) s->push_back(u); } else if (b) b->push_back(u); }
         return cnt;
     };
     // candidates: the rank cut (lower ranks first) while the set spans several ranks; the median cut along the longer extent, and --
@@ -180,6 +182,20 @@ int nd_order(std::vector<int>& nodes, const nd_ctx& C, std::vector<int>& order, 
                 return ka != kb ? ka < kb : a < b; });
         };
         if (!multi && total < C.both_axes) { split(nodes, byx); half = h2; }       // the only candidate: nothing to compare
+        else if (total >= C.both_axes && total >= 4096 && depth <= PG_ND_PAR) {
+            // both axes, large set: the two candidates are counted at the same time (the top of the recursion is the serial part of the
+            // ordering); the marks of a node set are private to the call that holds it, the second candidate marks in side2
+            std::vector<int> cand2 = nodes;
+            size_t c2 = 0;
+            pg_pool::task tk; tk.fn = [&] { split(cand2, !byx); c2 = boundary(cand2, h2, nullptr, nullptr, nullptr, C.side2); for (int v : cand2) C.side2[v] = 0; };
+            pg_pool::get().fork(&tk);
+            cand = nodes;
+            split(cand, byx);
+            const size_t c1 = boundary(cand, h2, nullptr, nullptr);
+            pg_pool::get().join(&tk);
+            if (c1 < best) { best = c1; nodes.swap(cand); half = h2; }
+            if (c2 < best) { best = c2; nodes.swap(cand2); half = h2; }
+        }
         else for (int pass = 0; pass < (total >= C.both_axes ? 2 : 1); ++pass) {
             cand = nodes;
             split(cand, pass == 0 ? byx : !byx);
@@ -319,11 +335,11 @@ void pg_symbolic(int ns, const std::vector<std::pair<int, int>>& edges, int ncha
     int root = -1;
     {
         std::vector<int> nodes(ns); std::iota(nodes.begin(), nodes.end(), 0);
-        std::vector<char> side(ns, 0);
+        std::vector<char> side(ns, 0), side2(ns, 0);
         S.order.reserve(ns);
         std::vector<char> forced(ns, 0);
         if (S.nparts > 1 && part) for (int v = 0; v < ns; ++v) for (int q = adj_ptr[v]; q < adj_ptr[v + 1]; ++q) if (part[adj_idx[q]] > part[v]) { forced[v] = 1; break; }
-        nd_ctx C{ adj_ptr.data(), adj_idx.data(), cx, cy, side.data(), opt.leaf, opt.nd_both_axes, opt.nd_geo_first, S.nparts > 1 ? part : nullptr, iface.data(), forced.data(), &pool, &mu };
+        nd_ctx C{ adj_ptr.data(), adj_idx.data(), cx, cy, side.data(), side2.data(), opt.leaf, opt.nd_both_axes, opt.nd_geo_first, S.nparts > 1 ? part : nullptr, iface.data(), forced.data(), &pool, &mu };
         root = nd_order(nodes, C, S.order, 0);
     }
     const auto q1 = tnow();
