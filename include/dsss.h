@@ -116,7 +116,11 @@ int dsss_set_pg_partitions(dsss_ctx*, int nparts);
 int dsss_frame_set(dsss_ctx*, int id, const double* raw, int N, int M,
                    const double* pose6, const double* alt, const double* grange);
 /* the same for n frames in one call (arrays of per-frame arguments; raw[i] may be NULL; ids distinct).  The
- * geometry of the whole call is staged once and uploaded with ONE copy; N and M must be below 65536.          */
+ * geometry of the whole call is staged once and uploaded with ONE copy; N and M must be below 65536.
+ * As the reference's constructor normalises, masks and runs DetectFeature itself (frame.cpp:45-52), this call STARTS the extraction
+ * of the frames whose raw image is a device pointer (asynchronously, with the parameters set at that moment) while it packs the
+ * geometry; dsss_extract_many over the same frames then only finishes it.  Nothing observable changes: parameters set in between, another
+ * list of frames or dsss_extract make the extraction run again from the start (DSSS_EX_EAGER=0 in the environment: never start early). */
 int dsss_frames_set(dsss_ctx*, int n, const int* ids, const double* const* raw, const int* N, const int* M,
                     const double* const* pose6, const double* const* alt, const double* const* grange);
 /* GetNormalizeSSS + GetFilteredMask + DetectFeature (frame.cpp:57-124,167-203) with the ORB descriptor
