@@ -2014,23 +2014,13 @@ static int pg_solve_impl(dsss_ctx* c, const double* dr6, int total, const dsss_l
             }
     }
     const double t_q1 = ms_since(T0);
-    sep1.reserve(sep_pose.size() + n / chunk + 2); t2.reserve(sep_pose.size());
-    for (size_t it = 0, m = 0; it < sep_pose.size() || m < (size_t)n;) {   // level-1 chain = true separators merged with the chunk ends 0, chunk, 2 chunk ...
-        const long long a = it < sep_pose.size() ? sep_pose[it] : (1LL << 40), bm = m < (size_t)n ? (long long)m : (1LL << 40);
-        if (a <= bm) { t2.push_back((int)sep1.size()); sep1.push_back((int)a); ++it; if (a == bm) m += chunk; }
-        else { sep1.push_back((int)bm); m += chunk; }
-    }
-    const double t_q2 = ms_since(T0);
     // index of a true separator among the true separators = number of marked poses below it: word prefix + popcount (a binary search
     // per loop-closure end point cost 0.6 ms)
     for (int v : sep_pose) mark(v);                                      // the gap fillers too
     std::vector<int> tpre(tbits.size() + 1, 0);
     for (size_t w = 0; w < tbits.size(); ++w) tpre[w + 1] = tpre[w] + __builtin_popcountll(tbits[w]);
     auto sidx = [&](int pose) { return tpre[(size_t)pose >> 6] + __builtin_popcountll(tbits[(size_t)pose >> 6] & ((1ull << (pose & 63)) - 1ull)); };
-    const int ns1 = (int)sep1.size(), nseg1 = ns1 - 1;
     const int ns = (int)sep_pose.size(), nseg = ns - 1;
-    // this rank's range of the level-1 chain (its poses are [mp0, mp1))
-    const int kp0 = (int)(std::lower_bound(sep1.begin(), sep1.end(), mp0) - sep1.begin()), kp1 = (int)(std::lower_bound(sep1.begin(), sep1.end(), mp1) - sep1.begin());
     std::vector<std::pair<int, int>> redges;
     redges.reserve((size_t)ns + ne);
     const double t_q3 = ms_since(T0);
@@ -2042,12 +2032,77 @@ static int pg_solve_impl(dsss_ctx* c, const double* dr6, int total, const dsss_l
     int rc = DSSS_OK;
 #define TRY(x) do { rc = (x); if (rc) { dv.release(); return rc; } } while (0)
     // DR rows on the device first: the separator coordinates for the ordering come back from there (host reads of the
-    // frames' pinned copies are slow), and the copies overlap with the rest of the host preparation
+    // frames' pinned copies are slow).  The analysis thread is started BEFORE they are back and before the rest of this thread's
+    // preparation (the level-1 chain of the device's chain condensation, the segment orders): it builds its adjacency first and waits for
+    // the coordinates where it first needs them (pg_sym_opts::before_order).
     double* d_dr6; double* d_sxy; int* d_sep; int* d_sep1; int* d_t2; int* d_ord1; int* d_ord2;
-    TRY(dv.alloc(c, &d_dr6, (size_t)n * 6)); TRY(dv.alloc(c, &d_sxy, (size_t)ns * 2)); dv.later(&d_sep, sep_pose); dv.later(&d_sep1, sep1); dv.later(&d_t2, t2);
-    std::vector<int> ord1, ord2;                            // (alive until the flush below)
+    TRY(dv.alloc(c, &d_dr6, (size_t)n * 6)); TRY(dv.alloc(c, &d_sxy, (size_t)ns * 2)); dv.later(&d_sep, sep_pose);
+    std::vector<int> ord1, ord2;                            // (alive until the second flush below)
     std::vector<unsigned long long> fp;
     unsigned long long* d_fp = nullptr; int* d_foff = nullptr;
+    std::vector<double> sxy((size_t)ns * 2), cx(ns), cy(ns);
+    {
+        if (!dr6) {
+            fp.resize(nframes);
+            for (int f = 0; f < nframes; ++f) fp[f] = (unsigned long long)(uintptr_t)c->frames[f].pose6;
+            dv.later(&d_fp, fp); dv.later(&d_foff, foff);
+        }
+        TRY(dv.flush(c, c->stream));                          // true separators, frame pointers: one upload
+        hipError_t e = hipSuccess;
+        if (dr6) e = hipMemcpyAsync(d_dr6, dr6, (size_t)n * 6 * sizeof(double), hipMemcpyHostToDevice, c->stream);
+        else {      // one gather launch over the frames' device copies (a device-to-device copy per frame cost 0.5 ms of launches at 200 frames)
+            hipLaunchKernelGGL(pg_gather_dr_kernel, dim3(8, nframes), dim3(256), 0, c->stream, d_fp, d_foff, d_dr6);
+            e = hipGetLastError();
+        }
+        if (e == hipSuccess) { hipLaunchKernelGGL(pg_sep_xy_kernel, dim3((ns + 255) / 256), dim3(256), 0, c->stream, ns, d_sep, d_dr6, d_sxy); e = hipGetLastError(); }
+        if (e != hipSuccess) { dv.release(); HIPCHK(c, e); }
+    }
+    const double t_prep0 = ms_since(T0);
+    const auto T1 = std::chrono::steady_clock::now();
+    // The analysis of the reduced system runs on a host thread of its own while this thread sets up everything that does not depend
+    // on it -- device arrays of the pose chain, initial values, the first linearisation and the chain part of the first LM trial
+    // (assembly, both segment passes): the device works through those while the host orders and analyses.
+    pg_sym S;
+    pg_sched SO, SI;
+    std::vector<int> sym_part(ns);
+    for (int k = 0; k < ns; ++k) sym_part[k] = (int)(std::upper_bound(pbound.begin(), pbound.end(), sep_pose[k]) - pbound.begin()) - 1;
+    std::promise<void> bottom_prom; std::future<void> bottom_fut = bottom_prom.get_future();
+    std::promise<void> coords_prom; std::future<void> coords_fut = coords_prom.get_future();
+    bool bottom_signalled = false;
+    std::thread sym_thread([&] {
+        pg_sym_opts opt; opt.threads = sym_threads();
+        opt.on_bottom_ready = [&] { bottom_signalled = true; bottom_prom.set_value(); };
+        opt.before_order = [&] { coords_fut.wait(); };
+        static const double bin_cost = getenv("DSSS_PG_BIN_COST") ? atof(getenv("DSSS_PG_BIN_COST")) : 600;   // ~ update-list iterations + 20 per column; measured optimum at C3 (500-700)
+        opt.bin_cost = bin_cost; pg_sym_opts_env(opt);
+        pg_symbolic(ns, redges, nseg, cx.data(), cy.data(), nparts > 1 ? sym_part.data() : nullptr, nparts, opt, S);
+        // launch lists: this rank's interior fronts, then (after the all-reduce) the replicated interface fronts
+        pg_build_schedule(S, part_lo, part_hi, SO);
+        if (nparts > 1) pg_build_schedule(S, -1, 0, SI);
+        if (!bottom_signalled) bottom_prom.set_value();      // (several partitions: nothing is ready early)
+    });
+    struct pg_joiner { std::thread& t; ~pg_joiner() { if (t.joinable()) t.join(); } } sym_join{ sym_thread };      // every return path waits for the thread before its data goes away
+    struct pg_coords_guard { std::promise<void>& p; bool done = false; void set() { if (!done) { done = true; p.set_value(); } } ~pg_coords_guard() { set(); } } coords_guard{ coords_prom };      // (an error exit must not leave the thread waiting)
+    {   // the coordinates come back while the analysis builds its adjacency: hand them over
+        hipError_t e = hipMemcpyAsync(sxy.data(), d_sxy, sxy.size() * sizeof(double), hipMemcpyDeviceToHost, c->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);      // the library's stream does not synchronise with the null stream
+        if (e != hipSuccess) { dv.release(); HIPCHK(c, e); }
+        for (int k = 0; k < ns; ++k) { cx[k] = sxy[2 * (size_t)k]; cy[k] = sxy[2 * (size_t)k + 1]; }
+        coords_guard.set();
+    }
+    // level-1 chain = true separators merged with the chunk ends 0, chunk, 2 chunk ...; segment orders: only the device reads them
+    const double t_m0 = ms_since(T0);
+    sep1.reserve(sep_pose.size() + n / chunk + 2); t2.reserve(sep_pose.size());
+    for (size_t it = 0, m = 0; it < sep_pose.size() || m < (size_t)n;) {
+        const long long a = it < sep_pose.size() ? sep_pose[it] : (1LL << 40), bm = m < (size_t)n ? (long long)m : (1LL << 40);
+        if (a <= bm) { t2.push_back((int)sep1.size()); sep1.push_back((int)a); ++it; if (a == bm) m += chunk; }
+        else { sep1.push_back((int)bm); m += chunk; }
+    }
+    const double t_q2 = ms_since(T0) - t_m0;
+    const int ns1 = (int)sep1.size(), nseg1 = ns1 - 1;
+    // this rank's range of the level-1 chain (its poses are [mp0, mp1))
+    const int kp0 = (int)(std::lower_bound(sep1.begin(), sep1.end(), mp0) - sep1.begin()), kp1 = (int)(std::lower_bound(sep1.begin(), sep1.end(), mp1) - sep1.begin());
+    dv.later(&d_sep1, sep1); dv.later(&d_t2, t2);
     {   // segments of both passes in descending order of length (stable counting sort: ties stay in chain order)
         auto by_length = [](const std::vector<int>& ends, std::vector<int>& ord) {
             const int m = (int)ends.size() - 1;
@@ -2062,50 +2117,9 @@ static int pg_solve_impl(dsss_ctx* c, const double* dr6, int total, const dsss_l
         by_length(sep1, ord1); by_length(t2, ord2);
         dv.later(&d_ord1, ord1); dv.later(&d_ord2, ord2);
     }
-    std::vector<double> sxy((size_t)ns * 2), cx(ns), cy(ns);
-    {
-        if (!dr6) {
-            fp.resize(nframes);
-            for (int f = 0; f < nframes; ++f) fp[f] = (unsigned long long)(uintptr_t)c->frames[f].pose6;
-            dv.later(&d_fp, fp); dv.later(&d_foff, foff);
-        }
-        TRY(dv.flush(c, c->stream));                          // separator lists, segment orders, frame pointers: one upload
-        hipError_t e = hipSuccess;
-        if (dr6) e = hipMemcpyAsync(d_dr6, dr6, (size_t)n * 6 * sizeof(double), hipMemcpyHostToDevice, c->stream);
-        else {      // one gather launch over the frames' device copies (a device-to-device copy per frame cost 0.5 ms of launches at 200 frames)
-            hipLaunchKernelGGL(pg_gather_dr_kernel, dim3(8, nframes), dim3(256), 0, c->stream, d_fp, d_foff, d_dr6);
-            e = hipGetLastError();
-        }
-        if (e == hipSuccess) { hipLaunchKernelGGL(pg_sep_xy_kernel, dim3((ns + 255) / 256), dim3(256), 0, c->stream, ns, d_sep, d_dr6, d_sxy); e = hipGetLastError(); }
-        if (e == hipSuccess) e = hipMemcpyAsync(sxy.data(), d_sxy, sxy.size() * sizeof(double), hipMemcpyDeviceToHost, c->stream);
-        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);      // the library's stream does not synchronise with the null stream
-        if (e != hipSuccess) { dv.release(); HIPCHK(c, e); }
-        for (int k = 0; k < ns; ++k) { cx[k] = sxy[2 * (size_t)k]; cy[k] = sxy[2 * (size_t)k + 1]; }
-    }
+    TRY(dv.flush(c, c->stream));                              // level-1 chain and segment orders: one upload
     const double t_prep = ms_since(T0);
-    if (getenv("DSSS_PG_VERBOSE")) fprintf(stderr, "[dsss pg prep] edges %.2f ms, separators %.2f ms (bits %.2f merge %.2f mid %.2f redges %.2f), uploads + round trip %.2f ms\n", t_p1, t_p2 - t_p1, t_q1 - t_p1, t_q2 - t_q1, t_q3 - t_q2, t_p2 - t_q3, t_prep - t_p2);
-    const auto T1 = std::chrono::steady_clock::now();
-    // The analysis of the reduced system runs on a host thread of its own while this thread sets up everything that does not depend
-    // on it -- device arrays of the pose chain, initial values, the first linearisation and the chain part of the first LM trial
-    // (assembly, both segment passes): the device works through those while the host orders and analyses.
-    pg_sym S;
-    pg_sched SO, SI;
-    std::vector<int> sym_part(ns);
-    for (int k = 0; k < ns; ++k) sym_part[k] = (int)(std::upper_bound(pbound.begin(), pbound.end(), sep_pose[k]) - pbound.begin()) - 1;
-    std::promise<void> bottom_prom; std::future<void> bottom_fut = bottom_prom.get_future();
-    bool bottom_signalled = false;
-    std::thread sym_thread([&] {
-        pg_sym_opts opt; opt.threads = sym_threads();
-        opt.on_bottom_ready = [&] { bottom_signalled = true; bottom_prom.set_value(); };
-        static const double bin_cost = getenv("DSSS_PG_BIN_COST") ? atof(getenv("DSSS_PG_BIN_COST")) : 600;   // ~ update-list iterations + 20 per column; measured optimum at C3 (500-700)
-        opt.bin_cost = bin_cost; pg_sym_opts_env(opt);
-        pg_symbolic(ns, redges, nseg, cx.data(), cy.data(), nparts > 1 ? sym_part.data() : nullptr, nparts, opt, S);
-        // launch lists: this rank's interior fronts, then (after the all-reduce) the replicated interface fronts
-        pg_build_schedule(S, part_lo, part_hi, SO);
-        if (nparts > 1) pg_build_schedule(S, -1, 0, SI);
-        if (!bottom_signalled) bottom_prom.set_value();      // (several partitions: nothing is ready early)
-    });
-    struct pg_joiner { std::thread& t; ~pg_joiner() { if (t.joinable()) t.join(); } } sym_join{ sym_thread };      // every return path waits for the thread before its data goes away
+    if (getenv("DSSS_PG_VERBOSE")) fprintf(stderr, "[dsss pg prep] edges %.2f ms, separators %.2f ms (bits %.2f mid %.2f redges %.2f), coordinates launched at %.2f ms; beside the analysis: level-1 chain %.2f ms, rest %.2f ms\n", t_p1, t_p2 - t_p1, t_q1 - t_p1, t_q3 - t_q1, t_p2 - t_q3, t_prep0, t_q2, t_prep - t_prep0 - t_q2);
     const bool verbose = getenv("DSSS_PG_VERBOSE") != nullptr;
 
     // incidence lists of the poses (edge order): only the device kernels read them, so they are built while the analysis runs

@@ -329,6 +329,7 @@ void pg_symbolic(int ns, const std::vector<std::pair<int, int>>& edges, int ncha
         adj_ptr[ns] = w;
         adj_idx.resize(w);
     }
+    if (opt.before_order) opt.before_order();
     const auto q0a = tnow();
     std::vector<nd_tree> pool; std::mutex mu;
     std::vector<char> iface(ns, 0);

@@ -118,6 +118,7 @@ struct pg_sym_opts {
     // scatter and the bins of the first trial under the rest of the analysis.  Only with one partition (interface values get their
     // dest_bin codes at the very end).  None of the vectors it may read is touched afterwards.
     std::function<void()> on_bottom_ready;
+    std::function<void()> before_order;          // called once the adjacency is built, before the first use of the coordinates (which may still be on their way)
 };
 
 void pg_sym_opts_env(pg_sym_opts& opt);    // DSSS_PG_RELAX_ZERO / _FLOPS / _SMALL / _ABS overrides (experiments)
