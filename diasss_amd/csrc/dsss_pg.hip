@@ -2027,41 +2027,11 @@ static int pg_solve_impl(dsss_ctx* c, const double* dr6, int total, const dsss_l
     for (int k = 0; k + 1 < ns; ++k) redges.push_back({ k, k + 1 });
     for (int e = 0; e < ne; ++e) redges.push_back({ sidx(ea[e]), sidx(eb[e]) });
     const double t_p2 = ms_since(T0);
-    // device state
-    pg_dev dv;
-    int rc = DSSS_OK;
-#define TRY(x) do { rc = (x); if (rc) { dv.release(); return rc; } } while (0)
-    // DR rows on the device first: the separator coordinates for the ordering come back from there (host reads of the
-    // frames' pinned copies are slow).  The analysis thread is started BEFORE they are back and before the rest of this thread's
-    // preparation (the level-1 chain of the device's chain condensation, the segment orders): it builds its adjacency first and waits for
-    // the coordinates where it first needs them (pg_sym_opts::before_order).
-    double* d_dr6; double* d_sxy; int* d_sep; int* d_sep1; int* d_t2; int* d_ord1; int* d_ord2;
-    TRY(dv.alloc(c, &d_dr6, (size_t)n * 6)); TRY(dv.alloc(c, &d_sxy, (size_t)ns * 2)); dv.later(&d_sep, sep_pose);
-    std::vector<int> ord1, ord2;                            // (alive until the second flush below)
-    std::vector<unsigned long long> fp;
-    unsigned long long* d_fp = nullptr; int* d_foff = nullptr;
-    std::vector<double> sxy((size_t)ns * 2), cx(ns), cy(ns);
-    {
-        if (!dr6) {
-            fp.resize(nframes);
-            for (int f = 0; f < nframes; ++f) fp[f] = (unsigned long long)(uintptr_t)c->frames[f].pose6;
-            dv.later(&d_fp, fp); dv.later(&d_foff, foff);
-        }
-        TRY(dv.flush(c, c->stream));                          // true separators, frame pointers: one upload
-        hipError_t e = hipSuccess;
-        if (dr6) e = hipMemcpyAsync(d_dr6, dr6, (size_t)n * 6 * sizeof(double), hipMemcpyHostToDevice, c->stream);
-        else {      // one gather launch over the frames' device copies (a device-to-device copy per frame cost 0.5 ms of launches at 200 frames)
-            hipLaunchKernelGGL(pg_gather_dr_kernel, dim3(8, nframes), dim3(256), 0, c->stream, d_fp, d_foff, d_dr6);
-            e = hipGetLastError();
-        }
-        if (e == hipSuccess) { hipLaunchKernelGGL(pg_sep_xy_kernel, dim3((ns + 255) / 256), dim3(256), 0, c->stream, ns, d_sep, d_dr6, d_sxy); e = hipGetLastError(); }
-        if (e != hipSuccess) { dv.release(); HIPCHK(c, e); }
-    }
-    const double t_prep0 = ms_since(T0);
     const auto T1 = std::chrono::steady_clock::now();
     // The analysis of the reduced system runs on a host thread of its own while this thread sets up everything that does not depend
     // on it -- device arrays of the pose chain, initial values, the first linearisation and the chain part of the first LM trial
     // (assembly, both segment passes): the device works through those while the host orders and analyses.
+    std::vector<double> cx(ns), cy(ns);                       // separator coordinates: filled below, read by the analysis after its adjacency pass
     pg_sym S;
     pg_sched SO, SI;
     std::vector<int> sym_part(ns);
@@ -2083,6 +2053,37 @@ static int pg_solve_impl(dsss_ctx* c, const double* dr6, int total, const dsss_l
     });
     struct pg_joiner { std::thread& t; ~pg_joiner() { if (t.joinable()) t.join(); } } sym_join{ sym_thread };      // every return path waits for the thread before its data goes away
     struct pg_coords_guard { std::promise<void>& p; bool done = false; void set() { if (!done) { done = true; p.set_value(); } } ~pg_coords_guard() { set(); } } coords_guard{ coords_prom };      // (an error exit must not leave the thread waiting)
+    // device state
+    pg_dev dv;
+    int rc = DSSS_OK;
+#define TRY(x) do { rc = (x); if (rc) { dv.release(); return rc; } } while (0)
+    // DR rows on the device first: the separator coordinates for the ordering come back from there (host reads of the
+    // frames' pinned copies are slow).  The analysis thread is started BEFORE they are back and before the rest of this thread's
+    // preparation (the level-1 chain of the device's chain condensation, the segment orders): it builds its adjacency first and waits for
+    // the coordinates where it first needs them (pg_sym_opts::before_order).
+    double* d_dr6; double* d_sxy; int* d_sep; int* d_sep1; int* d_t2; int* d_ord1; int* d_ord2;
+    TRY(dv.alloc(c, &d_dr6, (size_t)n * 6)); TRY(dv.alloc(c, &d_sxy, (size_t)ns * 2)); dv.later(&d_sep, sep_pose);
+    std::vector<int> ord1, ord2;                            // (alive until the second flush below)
+    std::vector<unsigned long long> fp;
+    unsigned long long* d_fp = nullptr; int* d_foff = nullptr;
+    std::vector<double> sxy((size_t)ns * 2);
+    {
+        if (!dr6) {
+            fp.resize(nframes);
+            for (int f = 0; f < nframes; ++f) fp[f] = (unsigned long long)(uintptr_t)c->frames[f].pose6;
+            dv.later(&d_fp, fp); dv.later(&d_foff, foff);
+        }
+        TRY(dv.flush(c, c->stream));                          // true separators, frame pointers: one upload
+        hipError_t e = hipSuccess;
+        if (dr6) e = hipMemcpyAsync(d_dr6, dr6, (size_t)n * 6 * sizeof(double), hipMemcpyHostToDevice, c->stream);
+        else {      // one gather launch over the frames' device copies (a device-to-device copy per frame cost 0.5 ms of launches at 200 frames)
+            hipLaunchKernelGGL(pg_gather_dr_kernel, dim3(8, nframes), dim3(256), 0, c->stream, d_fp, d_foff, d_dr6);
+            e = hipGetLastError();
+        }
+        if (e == hipSuccess) { hipLaunchKernelGGL(pg_sep_xy_kernel, dim3((ns + 255) / 256), dim3(256), 0, c->stream, ns, d_sep, d_dr6, d_sxy); e = hipGetLastError(); }
+        if (e != hipSuccess) { dv.release(); HIPCHK(c, e); }
+    }
+    const double t_prep0 = ms_since(T0);
     {   // the coordinates come back while the analysis builds its adjacency: hand them over
         hipError_t e = hipMemcpyAsync(sxy.data(), d_sxy, sxy.size() * sizeof(double), hipMemcpyDeviceToHost, c->stream);
         if (e == hipSuccess) e = hipStreamSynchronize(c->stream);      // the library's stream does not synchronise with the null stream
