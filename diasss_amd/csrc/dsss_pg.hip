@@ -1970,16 +1970,9 @@ static int pg_solve_impl(dsss_ctx* c, const double* dr6, int total, const dsss_l
       for (int k = 0; k < 6; ++k) { W.prior[k] = 1.0 / 0.000001; W.odo[k] = 1.0 / so[k]; } }
     // DR poses, measurements and initial values are produced on the device (pg_init_kernel) further down
     std::vector<int> ea(ne), eb(ne), eo(ne); std::vector<pose_t> emeas(ne); std::vector<double> ew((size_t)ne * 6);
-    for (int e = 0; e < ne; ++e) {
+    for (int e = 0; e < ne; ++e) {                  // the end points first: they are all the analysis needs (the measurements are unpacked beside it, below)
         ea[e] = edges[e].a; eb[e] = edges[e].b; eo[e] = std::max(edges[e].a, edges[e].b);
         if (ea[e] < 0 || ea[e] >= n || eb[e] < 0 || eb[e] >= n || ea[e] == eb[e]) DSSS_FAIL(c, DSSS_E_ARG, "LC edge %d out of range", e);
-        for (int k = 0; k < 9; ++k) emeas[e].R[k] = edges[e].rel[k];
-        for (int k = 0; k < 3; ++k) emeas[e].t[k] = edges[e].rel[9 + k];
-        for (int k = 0; k < 6; ++k) {
-            if (!(edges[e].var[k] > 0) || !std::isfinite(edges[e].var[k])) DSSS_FAIL(c, DSSS_E_NUMERIC, "LC edge %d: variance %d is not finite and positive", e, k);
-            ew[(size_t)e * 6 + k] = 1.0 / std::sqrt(edges[e].var[k]);
-        }
-        for (int k = 0; k < 12; ++k) if (!std::isfinite(edges[e].rel[k])) DSSS_FAIL(c, DSSS_E_NUMERIC, "LC edge %d: relative pose is not finite", e);
     }
     // Two levels of chain elimination.  TRUE separators (the unknowns of the sparse factorisation): LC-touched poses, the first and
     // the last pose, the last pose of every partition.  CHUNK ends: every PG_CHUNK-th pose as well, which bounds the sequential
@@ -2053,6 +2046,15 @@ static int pg_solve_impl(dsss_ctx* c, const double* dr6, int total, const dsss_l
     });
     struct pg_joiner { std::thread& t; ~pg_joiner() { if (t.joinable()) t.join(); } } sym_join{ sym_thread };      // every return path waits for the thread before its data goes away
     struct pg_coords_guard { std::promise<void>& p; bool done = false; void set() { if (!done) { done = true; p.set_value(); } } ~pg_coords_guard() { set(); } } coords_guard{ coords_prom };      // (an error exit must not leave the thread waiting)
+    for (int e = 0; e < ne; ++e) {                  // measurements and weights of the loop closures (the analysis is running)
+        for (int k = 0; k < 9; ++k) emeas[e].R[k] = edges[e].rel[k];
+        for (int k = 0; k < 3; ++k) emeas[e].t[k] = edges[e].rel[9 + k];
+        for (int k = 0; k < 6; ++k) {
+            if (!(edges[e].var[k] > 0) || !std::isfinite(edges[e].var[k])) DSSS_FAIL(c, DSSS_E_NUMERIC, "LC edge %d: variance %d is not finite and positive", e, k);
+            ew[(size_t)e * 6 + k] = 1.0 / std::sqrt(edges[e].var[k]);
+        }
+        for (int k = 0; k < 12; ++k) if (!std::isfinite(edges[e].rel[k])) DSSS_FAIL(c, DSSS_E_NUMERIC, "LC edge %d: relative pose is not finite", e);
+    }
     // device state
     pg_dev dv;
     int rc = DSSS_OK;
