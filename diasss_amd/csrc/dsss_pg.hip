@@ -1368,9 +1368,55 @@ __global__ __launch_bounds__(512) void pg_front_rsu_kernel(const int* __restrict
 // wavefront 0 runs the block back-substitution: x_blk = Linv^T z_blk, z[earlier columns] -= L11[blk rows][columns]^T x_blk.
 #define PG_BWD2_LD 97
 #define PG_BWD2_SX 8192                         // rows of x2 the LDS stages; taller fronts read x2 through the row map
+// Tall fronts (the 4 M-pose graph of BASELINE config 5 has fronts of 7 000 rows): L21^T x2 of a panel is a 5 MB stream, and one
+// workgroup pulls it through one compute unit at 30 - 50 GB/s -- 100 us and more per panel on the levels where the root front is alone.
+// For panels with more than PG_BWD_SPLIT rows below them the product is split over workgroups of PG_BWD_RC rows each (this kernel:
+// partial column sums, folded in slot order), and pg_front_bwd2_kernel adds the partial sums in chunk order instead of streaming L21.
+#define PG_BWD_SPLIT 2048
+#define PG_BWD_RC 512
+__global__ __launch_bounds__(1024) void pg_front_bwd_part_kernel(const int* __restrict__ it_front, const int* __restrict__ it_step, const pg_front* __restrict__ FD,
+                                                                 const int* __restrict__ f_rows, const double* __restrict__ FL, const double* __restrict__ x,
+                                                                 double* __restrict__ part, int maxchunks)
+{
+    __shared__ double sx[PG_BWD_RC];
+    __shared__ double s_acc[10 * (PG_PW * 6)];
+    const pg_front fd = FD[it_front[blockIdx.y]];
+    const int step = it_step[blockIdx.y], col0 = 96 * step;
+    const int n = min(96, fd.s6 - col0), ld = fd.ld;
+    const int row0 = col0 + n, nrows = fd.n6 - row0;
+    if (nrows <= PG_BWD_SPLIT) return;
+    const int r0 = blockIdx.x * PG_BWD_RC;
+    if (r0 >= nrows) return;
+    const int nr = min(PG_BWD_RC, nrows - r0);
+    for (int i = threadIdx.x; i < nr; i += 1024) { const int g = row0 + r0 + i; sx[i] = x[(size_t)f_rows[fd.rowptr + g / 6] * 6 + g % 6]; }
+    __syncthreads();
+    const int slot = threadIdx.x / 96, cc = threadIdx.x - slot * 96;
+    if (slot < 10) {
+        double acc0 = 0, acc1 = 0;
+        if (cc < n) {
+            const double* __restrict__ Ab = FL + fd.off + (size_t)(row0 + r0) * ld + col0 + cc;
+            int i = slot;
+            for (; i + 150 < nr; i += 160) {                   // sixteen loads in flight
+                double a16[16];
+#pragma unroll
+                for (int u = 0; u < 16; ++u) a16[u] = Ab[(size_t)(i + 10 * u) * ld];
+#pragma unroll
+                for (int u = 0; u < 16; ++u) { if (u & 1) acc1 += a16[u] * sx[i + 10 * u]; else acc0 += a16[u] * sx[i + 10 * u]; }
+            }
+            for (; i < nr; i += 10) acc0 += Ab[(size_t)i * ld] * sx[i];
+        }
+        s_acc[slot * (PG_PW * 6) + cc] = acc0 + acc1;
+    }
+    __syncthreads();
+    if (threadIdx.x < 96) {
+        double v = 0;
+        for (int g = 0; g < 10; ++g) v += s_acc[g * (PG_PW * 6) + threadIdx.x];
+        part[((size_t)blockIdx.y * maxchunks + blockIdx.x) * 96 + threadIdx.x] = v;
+    }
+}
 __global__ __launch_bounds__(1024) void pg_front_bwd2_kernel(const int* __restrict__ it_front, const int* __restrict__ it_step, const pg_front* __restrict__ FD,
                                                              const int* __restrict__ f_rows, const double* __restrict__ F, const double* __restrict__ FL, const double* __restrict__ R,
-                                                             double* __restrict__ x, const double* __restrict__ Tinv)
+                                                             double* __restrict__ x, const double* __restrict__ Tinv, const double* __restrict__ part, int maxchunks)
 {
     extern __shared__ double s_bw[];               // L11 [96 x 97] | Tinv [24][16] | slot sums [10][96] | x2 [nrows]
     double* sL = s_bw;
@@ -1386,14 +1432,21 @@ __global__ __launch_bounds__(1024) void pg_front_bwd2_kernel(const int* __restri
 #pragma unroll
       for (int e = 0; e < 9; ++e) { const int id = e * 1024 + threadIdx.x, r = id / 96, cc = id - 96 * r; lreg[e] = (r < n && cc <= r) ? L11[(size_t)r * ld + cc] : 0.0; } }
     if (threadIdx.x < PG_NB4 * 16) sT[threadIdx.x] = Tinv[(size_t)p * PG_NB4 * 16 + threadIdx.x];
+    const bool split = part != nullptr && nrows > PG_BWD_SPLIT;      // the product came in as partial sums (pg_front_bwd_part_kernel)
     const bool big = nrows > PG_BWD2_SX;           // only the largest interface fronts: x2 does not fit the LDS, read it through the row map
-    if (!big) for (int i = threadIdx.x; i < nrows; i += 1024) { const int g = row0 + i; sx[i] = x[(size_t)f_rows[fd.rowptr + g / 6] * 6 + g % 6]; }
+    if (!big && !split) for (int i = threadIdx.x; i < nrows; i += 1024) { const int g = row0 + i; sx[i] = x[(size_t)f_rows[fd.rowptr + g / 6] * 6 + g % 6]; }
     __syncthreads();
     {
         const int slot = threadIdx.x / 96, cc = threadIdx.x - slot * 96;
         if (slot < 10) {
             double acc0 = 0, acc1 = 0;
-            if (cc < n && !big) {
+            if (split) {
+                if (slot == 0 && cc < n) {
+                    const int nch = (nrows + PG_BWD_RC - 1) / PG_BWD_RC;
+                    const double* __restrict__ pp = part + (size_t)blockIdx.x * maxchunks * 96 + cc;
+                    for (int ch = 0; ch < nch; ++ch) acc0 += pp[(size_t)ch * 96];
+                }
+            } else if (cc < n && !big) {
                 const double* __restrict__ Ab = FL + fd.off + (size_t)row0 * ld + col0 + cc;      // L21: in place, or in the second arena where the level ran the fused row solve + update
                 int i = slot;
                 for (; i + 150 < nrows; i += 160) {                // sixteen loads in flight
@@ -2360,6 +2413,14 @@ static int pg_solve_impl(dsss_ctx* c, const double* dr6, int total, const dsss_l
     unsigned long long* d_stamps = nullptr; if (getenv("DSSS_PG_STAMPS")) TRY(dv.alloc(c, &d_stamps, 16));
     static const bool diag3_panel = getenv("DSSS_PG_PANEL") && !strcmp(getenv("DSSS_PG_PANEL"), "diag3");          // A/B: two barriers per block
     double* d_Tinv; TRY(dv.alloc(c, &d_Tinv, (size_t)std::max(npan, 1) * PG_NB4 * 16));
+    double* d_bwp = nullptr;                                // partial sums of the split back-substitution products (tall fronts only)
+    {
+        size_t need = 0;
+        for (const pg_sched* H : { &SO, &SI })
+            for (int l = 0; l < H->nlev; ++l)
+                if (64 * H->trsm_chunks[l] > PG_BWD_SPLIT) need = std::max(need, (size_t)(H->lv_ptr[l + 1] - H->lv_ptr[l]) * ((64 * H->trsm_chunks[l] + PG_BWD_RC - 1) / PG_BWD_RC) * 96);
+        if (need > 0) TRY(dv.alloc(c, &d_bwp, need));
+    }
     const int bwd_lds = (int)(((PG_PW * 6) * PG_BWD2_LD + PG_NB4 * 16 + 10 * (PG_PW * 6) + std::min(max_n6, PG_BWD2_SX) + 16) * sizeof(double));
     if (bwd_lds > 160 * 1024) { dv.release(); DSSS_FAIL(c, DSSS_E_CAPACITY, "front of %d scalar rows: back-substitution needs %d B of LDS", max_n6, bwd_lds); }
     {   // the back-substitution keeps L11, the slot sums and x2 in dynamic LDS
@@ -2416,10 +2477,13 @@ static int pg_solve_impl(dsss_ctx* c, const double* dr6, int total, const dsss_l
                     for (int l = H.nlev - 1; l >= 0; --l) {
                         const int nit = H.lv_ptr[l + 1] - H.lv_ptr[l];
                         if (nit == 0) continue;
-                        dsss_scope s6(c, DSSS_K_PG_BWD, H.fl_bwd[l]);
+                        dsss_scope s6(c, DSSS_K_PG_BWD, H.fl_bwd[l], 2);
                         const int ntl = H.tile_ptr[l + 1] - H.tile_ptr[l];
                         const double* Fl = (use_rsu && ntl > 0 && ntl <= rsu_max) ? d_FL : d_F;
-                        hipLaunchKernelGGL(pg_front_bwd2_kernel, dim3(nit), dim3(1024), bwd_lds, st, Dv.lv_front + H.lv_ptr[l], Dv.lv_step + H.lv_ptr[l], d_FD, d_frows, d_F, Fl, d_R, d_x, d_Tinv);
+                        const int nch = 64 * H.trsm_chunks[l] > PG_BWD_SPLIT ? (64 * H.trsm_chunks[l] + PG_BWD_RC - 1) / PG_BWD_RC : 0;      // tall fronts on this level: their L21^T x2 by many workgroups
+                        if (nch > 0) hipLaunchKernelGGL(pg_front_bwd_part_kernel, dim3(nch, nit), dim3(1024), 0, st, Dv.lv_front + H.lv_ptr[l], Dv.lv_step + H.lv_ptr[l], d_FD, d_frows, Fl, d_x, d_bwp, nch);
+                        hipLaunchKernelGGL(pg_front_bwd2_kernel, dim3(nit), dim3(1024), bwd_lds, st, Dv.lv_front + H.lv_ptr[l], Dv.lv_step + H.lv_ptr[l], d_FD, d_frows, d_F, Fl, d_R, d_x, d_Tinv,
+                                           nch > 0 ? (const double*)d_bwp : (const double*)nullptr, nch);
                     }
                 };
                 run_levels(SO, DO);
