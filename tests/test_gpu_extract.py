@@ -118,3 +118,38 @@ def test_extract_device_resident_input(ctx, orc):
     kps, desc, _, _ = orc.detect_feature(raw)
     g_kps, g_desc, _ = ctx.features_get(2)
     assert n == len(kps) and (g_desc == desc).all()
+
+
+def test_eager_extraction_started_by_frames_set_and_its_fallbacks(ctx, orc):
+    """dsss_frames_set starts the extraction of device-resident frames (as the reference's Frame constructor runs DetectFeature);
+    dsss_extract_many over the same list only finishes it.  Whatever happens in between -- another list of frames, parameters changed,
+    frames set again -- the features must be those of the oracle for the parameters in force at the extraction."""
+    import torch
+    N, M = 640, 400
+    frames = [_frame(N, M, 20 + k, hot=(k == 0)) for k in range(3)]
+    dev = [torch.from_numpy(f[0]).cuda() for f in frames]
+    ids = [0, 1, 2]
+
+    def set_all():
+        ctx.frames_set(ids, dev, [N] * 3, [M] * 3, [f[1] for f in frames], [f[2] for f in frames], [f[3] for f in frames])
+
+    def check(po=None):
+        for k in ids:
+            kps, desc, _, _ = orc.detect_feature(frames[k][0], None, po) if po is not None else orc.detect_feature(frames[k][0])
+            g_kps, g_desc, g_geo = ctx.features_get(k)
+            assert len(g_kps) == len(kps) and (g_desc == desc).all() and (g_kps["x"] == kps["x"]).all() and (g_kps["angle"] == kps["angle"]).all()
+            ref_geo = orc.geo_at_kps(frames[k][1], frames[k][3], M, kps)
+            assert (np.asarray(g_geo).reshape(-1, 2) == np.asarray(ref_geo).reshape(-1, 2)).all()       # the one kernel that waits for the geometry upload
+
+    set_all(); ctx.extract_many(ids); check()                                   # the plain pair: only the tail runs in extract_many
+    set_all(); ctx.extract_many([2, 0, 1]); check()                             # another order: the started extraction is dropped, all of it runs again
+    set_all(); set_all(); ctx.extract_many(ids); check()                        # set twice: the second start is the one that counts
+    mp, op, mt, pg = ctx.default_params()
+    op.nfeatures = 500; op.nlevels = 4
+    try:
+        set_all(); ctx.set_params(orb=op); ctx.extract_many(ids)                # parameters changed after the start: extracted with the NEW ones
+        po = orc.orb_params(); po.nfeatures = 500; po.nlevels = 4
+        check(po)
+    finally:
+        ctx.set_params(orb=ctx.default_params()[1])
+    set_all(); assert ctx.extract(1) > 0; ctx.extract_many(ids); check()        # a single-frame extraction in between
