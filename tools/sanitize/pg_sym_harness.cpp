@@ -39,7 +39,7 @@ static void run(unsigned seed, int ns, int nlc, int reps)
 }
 int main()
 {
-    std::thread a(run, 1u, 3000, 400, 3), b(run, 2u, 2400, 300, 3);
+    std::thread a(run, 1u, 9000, 1200, 2), b(run, 2u, 2400, 300, 3);     // (9000 separators: large enough for the concurrently counted cut candidates of the ordering)
     run(3u, 1800, 250, 3);
     a.join(); b.join();
     return 0;
