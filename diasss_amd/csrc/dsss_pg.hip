@@ -538,10 +538,10 @@ __global__ __launch_bounds__(256) void pg_mask_own_kernel(int n, pose_t* __restr
 __global__ __launch_bounds__(256) void pg_build_map_kernel(int nupd, const int* __restrict__ rlrow, const int* __restrict__ rlptr,
                                                            const int* __restrict__ rlcol, const int* __restrict__ rlpos,
                                                            const int* __restrict__ colptr, const int* __restrict__ rowidx,
-                                                           const long long* __restrict__ mapptr, int* __restrict__ upd_map)
+                                                           const long long* __restrict__ mapptr, int* __restrict__ upd_map, const int* __restrict__ nupd_dev)
 {
     const int e = blockIdx.x * 256 + threadIdx.x;
-    if (e >= nupd) return;
+    if (e >= (nupd_dev ? *nupd_dev : nupd)) return;             // (lists built on the device: their total stays there, the grid covers the bound)
     const int j = rlrow[e], k = rlcol[e];
     const int c0 = colptr[j], m = colptr[j + 1] - c0;
     int* mp = upd_map + mapptr[j] + (long long)(e - rlptr[j]) * m;
@@ -551,6 +551,121 @@ __global__ __launch_bounds__(256) void pg_build_map_kernel(int nupd, const int* 
         while (q < m && rowidx[c0 + q] < i) ++q;
         if (q < m && rowidx[c0 + q] == i) mp[q] = p;
     }
+}
+
+// ---- The bins' index tables built ON THE DEVICE (round 3): the update lists (per target column j the binned source columns k < j
+// with L(j, k) != 0, ascending, and the position of that block), the offsets of the update map, and for the rows of a binned column
+// beyond its subtree root their index in the root's boundary list.  On the host they were the last 0.9 ms of the analysis before the
+// first trial could touch the bins (35 ms at the 4 M-pose graph of config 5); they are independent of everything the analysis does
+// afterwards.  Same content, same order (a list is sorted by source column), so the factor is bit-identical to the host-built one
+// (DSSS_PG_LISTS=host keeps the host path; the host twin of the CPU tests always uses it).
+__global__ __launch_bounds__(256) void pg_rl_count_kernel(int ns, const int* __restrict__ colptr, const int* __restrict__ rowidx, const char* __restrict__ binned,
+                                                          int* __restrict__ cnt)
+{
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    if (k >= ns || !binned[k]) return;
+    for (int q = colptr[k] + 1; q < colptr[k + 1]; ++q) { const int j = rowidx[q]; if (binned[j]) atomicAdd(&cnt[j], 1); }
+}
+// exclusive scan in three launches (1024 values per workgroup, up to 1024 x 1024 values): VAL 0 = the counts themselves (int),
+// VAL 1 = count x blocks of the column (long long: the update map holds one entry per (update, target block))
+template <typename T, int VAL>
+__global__ __launch_bounds__(1024) void pg_scan_block_kernel(int n, const int* __restrict__ cnt, const int* __restrict__ colptr, T* __restrict__ out, T* __restrict__ block_sum)
+{
+    __shared__ T s_w[16];
+    const int i = blockIdx.x * 1024 + threadIdx.x, lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    T v = 0;
+    if (i < n) v = VAL == 0 ? (T)cnt[i] : (T)cnt[i] * (T)(colptr[i + 1] - colptr[i]);
+    T inc = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const T t = __shfl_up(inc, o, 64); if (lane >= o) inc += t; }
+    if (lane == 63) s_w[w] = inc;
+    __syncthreads();
+    T base = 0, tot = 0;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) { const T t = s_w[k]; if (k < w) base += t; tot += t; }
+    if (i < n) out[i] = base + inc - v;
+    if (threadIdx.x == 0) block_sum[blockIdx.x] = tot;
+}
+template <typename T>
+__global__ __launch_bounds__(1024) void pg_scan_tops_kernel(int nblocks, T* __restrict__ block_sum, T* __restrict__ total)
+{
+    __shared__ T s_w[16];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    T carry = 0;
+    for (int b0 = 0; b0 < nblocks; b0 += 1024) {
+        const int i = b0 + threadIdx.x;
+        const T v = i < nblocks ? block_sum[i] : (T)0;
+        T inc = v;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const T t = __shfl_up(inc, o, 64); if (lane >= o) inc += t; }
+        __syncthreads();
+        if (lane == 63) s_w[w] = inc;
+        __syncthreads();
+        T base = 0, tot = 0;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) { const T t = s_w[k]; if (k < w) base += t; tot += t; }
+        if (i < nblocks) block_sum[i] = carry + base + inc - v;
+        carry += tot;
+    }
+    if (threadIdx.x == 0) *total = carry;
+}
+template <typename T>
+__global__ __launch_bounds__(1024) void pg_scan_add_kernel(int n, T* __restrict__ out, const T* __restrict__ block_sum, const T* __restrict__ total)
+{
+    const int i = blockIdx.x * 1024 + threadIdx.x;
+    if (i < n) out[i] += block_sum[blockIdx.x];
+    if (i == 0) out[n] = *total;
+}
+__global__ __launch_bounds__(256) void pg_rl_fill_kernel(int ns, const int* __restrict__ colptr, const int* __restrict__ rowidx, const char* __restrict__ binned,
+                                                         const int* __restrict__ rlptr, int* __restrict__ cur, int* __restrict__ rlcol, int* __restrict__ rlpos)
+{
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    if (k >= ns || !binned[k]) return;
+    for (int q = colptr[k] + 1; q < colptr[k + 1]; ++q) {
+        const int j = rowidx[q];
+        if (!binned[j]) continue;
+        const int at = rlptr[j] + atomicAdd(&cur[j], 1);          // any order: pg_rl_sort_kernel sorts the list by source column
+        rlcol[at] = k; rlpos[at] = q;
+    }
+}
+// one wavefront per target column: its list sorted by source column (the keys are distinct: rank = number of smaller keys)
+#define PG_RL_SORT_CAP 1024
+__global__ __launch_bounds__(256) void pg_rl_sort_kernel(int ns, const int* __restrict__ rlptr, int* __restrict__ rlcol, int* __restrict__ rlpos, int* __restrict__ rlrow,
+                                                         int* __restrict__ fail)
+{
+    __shared__ int s_k[4][PG_RL_SORT_CAP], s_q[4][PG_RL_SORT_CAP];
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int j = blockIdx.x * 4 + wv;
+    if (j >= ns) return;
+    const int b = rlptr[j], len = rlptr[j + 1] - b;
+    if (len <= 0) return;
+    if (len > PG_RL_SORT_CAP) { if (lane == 0) *fail = 2; return; }      // (a bin's lists sum to a few hundred entries: cannot happen; never silent)
+    for (int e = lane; e < len; e += 64) { s_k[wv][e] = rlcol[b + e]; s_q[wv][e] = rlpos[b + e]; }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_wave_barrier();
+    for (int e = lane; e < len; e += 64) {
+        const int key = s_k[wv][e];
+        int rank = 0;
+        for (int f = 0; f < len; ++f) rank += s_k[wv][f] < key;
+        rlcol[b + rank] = key; rlpos[b + rank] = s_q[wv][e]; rlrow[b + rank] = j;
+    }
+}
+__global__ __launch_bounds__(256) void pg_fill_map_kernel(int* __restrict__ upd_map, const long long* __restrict__ total)
+{
+    const long long n = *total;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) upd_map[i] = -1;
+}
+__global__ __launch_bounds__(256) void pg_anc_rel_kernel(int ns, const int* __restrict__ colptr, const int* __restrict__ rowidx, const char* __restrict__ binned,
+                                                         const int* __restrict__ root_of, int* __restrict__ anc_first, int* __restrict__ anc_rel)
+{
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    if (k >= ns || !binned[k]) return;
+    const int r = root_of[k], c0 = colptr[k], m = colptr[k + 1] - c0;
+    int q = 0;
+    while (q < m && rowidx[c0 + q] <= r) ++q;
+    anc_first[k] = q;
+    const int* __restrict__ rb = rowidx + colptr[r] + 1; const int nb = colptr[r + 1] - colptr[r] - 1;
+    int w = 0;
+    for (; q < m; ++q) { const int row = rowidx[c0 + q]; while (w < nb && rb[w] < row) ++w; anc_rel[c0 + q] = (w < nb && rb[w] == row) ? w : -1; }
 }
 
 #define PG_TCH 128
@@ -2077,6 +2192,7 @@ static int pg_solve_impl(dsss_ctx* c, const double* dr6, int total, const dsss_l
     // The analysis of the reduced system runs on a host thread of its own while this thread sets up everything that does not depend
     // on it -- device arrays of the pose chain, initial values, the first linearisation and the chain part of the first LM trial
     // (assembly, both segment passes): the device works through those while the host orders and analyses.
+    static const bool lists_on_device = !(getenv("DSSS_PG_LISTS") && !strcmp(getenv("DSSS_PG_LISTS"), "host"));      // A/B: the bins' update lists built by the analysis (host) instead of on the device
     std::vector<double> cx(ns), cy(ns);                       // separator coordinates: filled below, read by the analysis after its adjacency pass
     pg_sym S;
     pg_sched SO, SI;
@@ -2089,6 +2205,7 @@ static int pg_solve_impl(dsss_ctx* c, const double* dr6, int total, const dsss_l
         pg_sym_opts opt; opt.threads = sym_threads();
         opt.on_bottom_ready = [&] { bottom_signalled = true; bottom_prom.set_value(); };
         opt.before_order = [&] { coords_fut.wait(); };
+        opt.lists_on_device = lists_on_device;
         static const double bin_cost = getenv("DSSS_PG_BIN_COST") ? atof(getenv("DSSS_PG_BIN_COST")) : 600;   // ~ update-list iterations + 20 per column; measured optimum at C3 (500-700)
         opt.bin_cost = bin_cost; pg_sym_opts_env(opt);
         pg_symbolic(ns, redges, nseg, cx.data(), cy.data(), nparts > 1 ? sym_part.data() : nullptr, nparts, opt, S);
@@ -2314,21 +2431,56 @@ static int pg_solve_impl(dsss_ctx* c, const double* dr6, int total, const dsss_l
         d_comm = d_aval + (size_t)nval * 36; d_avalif = d_comm; d_xif = d_comm + ncv * 36; d_commU = d_xif + nif * 6;
         ifslot.assign(ns, -1); for (size_t q = 0; q < nif; ++q) ifslot[S.iface_seps[q]] = (int)q;
         dv.later(&d_ifslot, ifslot); dv.later(&d_ifsep, S.iface_seps);
-        dv.later(&d_colptr, S.colptr); dv.later(&d_rowidx, S.rowidx); dv.later(&d_rlptr, S.rlptr); dv.later(&d_rlcol, S.rlcol);
-        dv.later(&d_rlpos, S.rlpos); dv.later(&d_rlrow, S.rlrow); dv.later(&d_mapptr, S.mapptr); dv.later(&d_binptr, S.binptr); dv.later(&d_bincols, S.bincols);
+        dv.later(&d_colptr, S.colptr); dv.later(&d_rowidx, S.rowidx); dv.later(&d_binptr, S.binptr); dv.later(&d_bincols, S.bincols);
         dv.later(&d_dest, S.dest_bin);
         dv.later(&d_binroot_ptr, S.binroot_ptr); dv.later(&d_binroot_idx, S.binroot_idx); dv.later(&d_broot_b, S.broot_b); dv.later(&d_broot_uoff, S.broot_uoff);
-        dv.later(&d_broot_of_col, S.broot_of_col); dv.later(&d_anc_first, S.anc_first); dv.later(&d_anc_rel, S.anc_rel);
+        dv.later(&d_broot_of_col, S.broot_of_col);
+        char* d_binned = nullptr; int* d_rootof = nullptr;
+        if (lists_on_device) { dv.later(&d_binned, S.binned); dv.later(&d_rootof, S.root_of); }
+        else { dv.later(&d_rlptr, S.rlptr); dv.later(&d_rlcol, S.rlcol); dv.later(&d_rlpos, S.rlpos); dv.later(&d_rlrow, S.rlrow); dv.later(&d_mapptr, S.mapptr);
+               dv.later(&d_anc_first, S.anc_first); dv.later(&d_anc_rel, S.anc_rel); }
         if ((rc2 = dv.flush(c, st))) return rc2;
         // this rank's bins are one contiguous range (bins never straddle partitions, partitions are ascending in the order)
         { const int nb_all = (int)S.binptr.size() - 1; bin_lo = 0; while (bin_lo < nb_all && S.bin_part[bin_lo] < part_lo) ++bin_lo; bin_hi = bin_lo; while (bin_hi < nb_all && S.bin_part[bin_hi] < part_hi) ++bin_hi; }
         nbins = bin_hi - bin_lo;
-        const long long mapsz = S.mapptr[ns];
+        long long mapsz = 0; int nupd = 0;
+        if (lists_on_device) {
+            // update lists, update-map offsets and root-boundary indices of the bins: built here, from the column structures
+            // (pg_rl_count_kernel ... pg_anc_rel_kernel); two totals come back for the allocation of the map
+            int *d_cnt, *d_cur, *d_bs32, *d_tot32; long long *d_bs64, *d_tot64;
+            const int nsb = (ns + 1023) / 1024;
+            if ((rc2 = dv.alloc(c, &d_cnt, (size_t)ns)) || (rc2 = dv.alloc(c, &d_cur, (size_t)ns)) || (rc2 = dv.alloc(c, &d_bs32, (size_t)nsb)) || (rc2 = dv.alloc(c, &d_tot32, 1)) ||
+                (rc2 = dv.alloc(c, &d_bs64, (size_t)nsb)) || (rc2 = dv.alloc(c, &d_tot64, 1)) || (rc2 = dv.alloc(c, &d_rlptr, (size_t)ns + 1)) || (rc2 = dv.alloc(c, &d_mapptr, (size_t)ns + 1)) ||
+                (rc2 = dv.alloc(c, &d_rlcol, nnzL)) || (rc2 = dv.alloc(c, &d_rlpos, nnzL)) || (rc2 = dv.alloc(c, &d_rlrow, nnzL)) ||      // (an entry of L is on at most one list)
+                (rc2 = dv.alloc(c, &d_anc_first, (size_t)ns)) || (rc2 = dv.alloc(c, &d_anc_rel, nnzL))) return rc2;
+            if (nsb > 1024 * 1024) DSSS_FAIL(c, DSSS_E_CAPACITY, "%d separators", ns);
+            hipMemsetAsync(d_cnt, 0, sizeof(int) * (size_t)ns, st); hipMemsetAsync(d_cur, 0, sizeof(int) * (size_t)ns, st);
+            hipMemsetAsync(d_anc_first, 0, sizeof(int) * (size_t)ns, st); hipMemsetAsync(d_anc_rel, 0xff, sizeof(int) * nnzL, st);
+            const dim3 gcol((ns + 255) / 256);
+            hipLaunchKernelGGL(pg_rl_count_kernel, gcol, dim3(256), 0, st, ns, d_colptr, d_rowidx, d_binned, d_cnt);
+            hipLaunchKernelGGL((pg_scan_block_kernel<int, 0>), dim3(nsb), dim3(1024), 0, st, ns, d_cnt, d_colptr, d_rlptr, d_bs32);
+            hipLaunchKernelGGL((pg_scan_tops_kernel<int>), dim3(1), dim3(1024), 0, st, nsb, d_bs32, d_tot32);
+            hipLaunchKernelGGL((pg_scan_add_kernel<int>), dim3(nsb), dim3(1024), 0, st, ns, d_rlptr, d_bs32, d_tot32);
+            hipLaunchKernelGGL((pg_scan_block_kernel<long long, 1>), dim3(nsb), dim3(1024), 0, st, ns, d_cnt, d_colptr, d_mapptr, d_bs64);
+            hipLaunchKernelGGL((pg_scan_tops_kernel<long long>), dim3(1), dim3(1024), 0, st, nsb, d_bs64, d_tot64);
+            hipLaunchKernelGGL((pg_scan_add_kernel<long long>), dim3(nsb), dim3(1024), 0, st, ns, d_mapptr, d_bs64, d_tot64);
+            hipLaunchKernelGGL(pg_rl_fill_kernel, gcol, dim3(256), 0, st, ns, d_colptr, d_rowidx, d_binned, d_rlptr, d_cur, d_rlcol, d_rlpos);
+            hipLaunchKernelGGL(pg_rl_sort_kernel, dim3((ns + 3) / 4), dim3(256), 0, st, ns, d_rlptr, d_rlcol, d_rlpos, d_rlrow, d_fail);
+            hipLaunchKernelGGL(pg_anc_rel_kernel, gcol, dim3(256), 0, st, ns, d_colptr, d_rowidx, d_binned, d_rootof, d_anc_first, d_anc_rel);
+            // the totals stay on the device: a binned column has at most 42 blocks and an entry of L is on at most one list, so the map
+            // has at most 42 nnz(L) entries -- allocated to that bound (54 MB at C3), filled and built up to the device-side totals
+            mapsz = 42LL * (long long)nnzL; nupd = (int)nnzL;
+            if (mapsz > (1LL << 31)) DSSS_FAIL(c, DSSS_E_CAPACITY, "update map bound of %lld entries", mapsz);
+            if ((rc2 = dv.alloc(c, &d_map, (size_t)mapsz))) return rc2;
+            hipLaunchKernelGGL(pg_fill_map_kernel, dim3(2048), dim3(256), 0, st, d_map, d_tot64);
+            if (nupd > 0) hipLaunchKernelGGL(pg_build_map_kernel, dim3((nupd + 255) / 256), dim3(256), 0, st, nupd, d_rlrow, d_rlptr, d_rlcol, d_rlpos, d_colptr, d_rowidx, d_mapptr, d_map, d_tot32);
+            return DSSS_OK;
+        }
+        mapsz = S.mapptr[ns]; nupd = (int)S.rlcol.size();
         if (mapsz > (1LL << 31)) DSSS_FAIL(c, DSSS_E_CAPACITY, "update map of %lld entries", mapsz);
         if ((rc2 = dv.alloc(c, &d_map, (size_t)mapsz))) return rc2;
         if (hipMemsetAsync(d_map, 0xff, (size_t)std::max<long long>(mapsz, 1) * sizeof(int), st) != hipSuccess) DSSS_FAIL(c, DSSS_E_HIP, "hipMemsetAsync(update map)");
-        const int nupd = (int)S.rlcol.size();
-        if (nupd > 0) hipLaunchKernelGGL(pg_build_map_kernel, dim3((nupd + 255) / 256), dim3(256), 0, st, nupd, d_rlrow, d_rlptr, d_rlcol, d_rlpos, d_colptr, d_rowidx, d_mapptr, d_map);
+        if (nupd > 0) hipLaunchKernelGGL(pg_build_map_kernel, dim3((nupd + 255) / 256), dim3(256), 0, st, nupd, d_rlrow, d_rlptr, d_rlcol, d_rlpos, d_colptr, d_rowidx, d_mapptr, d_map, (const int*)nullptr);
         return DSSS_OK;
     };
     // the bottom part of a trial: reduced system into the factor / the value array, then the bins

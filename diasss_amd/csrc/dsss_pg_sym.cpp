@@ -396,6 +396,7 @@ void pg_symbolic(int ns, const std::vector<std::pair<int, int>>& edges, int ncha
         const int par = parent[j];
         root_of[j] = (par >= 0 && sub_ok[par]) ? root_of[par] : j;
     }
+    S.root_of = root_of;
     std::vector<int> bin_of_root(ns, -1);
     {   // greedy packing of whole subtrees into bins, subtrees taken in ascending root order, never across ranks
         std::vector<int> roots;
@@ -429,6 +430,7 @@ void pg_symbolic(int ns, const std::vector<std::pair<int, int>>& edges, int ncha
     }
     const auto f1 = tnow();
     // rows of a binned column beyond its subtree root, as indices into the root's boundary list
+    if (!opt.lists_on_device) {
     S.anc_first.assign(ns, 0);
     S.anc_rel.assign(S.nnzL, -1);
     par_ranges(ns, T, [&](int, int lo, int hi) {
@@ -443,9 +445,10 @@ void pg_symbolic(int ns, const std::vector<std::pair<int, int>>& edges, int ncha
             for (; q < m; ++q) { const int row = S.rowidx[c0 + q]; while (w < nb && rb[w] < row) ++w; S.anc_rel[c0 + q] = (w < nb && rb[w] == row) ? w : -1; }
         }
     });
+    }
     const auto f2 = tnow();
     // update lists of the binned columns (sources are binned columns of the same subtree), ascending source
-    {
+    if (!opt.lists_on_device) {
         std::vector<std::vector<int>> hist(T, std::vector<int>(ns, 0));
         par_ranges(ns, T, [&](int t, int lo, int hi) {
             std::vector<int>& h = hist[t];
@@ -469,6 +472,7 @@ void pg_symbolic(int ns, const std::vector<std::pair<int, int>>& edges, int ncha
         S.mapptr.assign(ns + 1, 0);
         for (int j = 0; j < ns; ++j) S.mapptr[j + 1] = S.mapptr[j] + (long long)(S.rlptr[j + 1] - S.rlptr[j]) * (long long)csz(j);
     }
+    const auto f3 = tnow();
     // ---- where the assembled blocks go, first half: value index k < ns diagonal of separator k, then the chain couplings, then the
     // LC edges; a value whose destination column is binned gets its position in the block-sparse factor (the rest -- fronts,
     // interface -- is settled after the fronts exist)
@@ -492,7 +496,8 @@ void pg_symbolic(int ns, const std::vector<std::pair<int, int>>& edges, int ncha
     S.nval = nval;
     if (opt.on_bottom_ready && nparts <= 1) opt.on_bottom_ready();
     const auto q3 = tnow();
-    if (tv) fprintf(stderr, "[dsss pg symbolic] bins+lists: rowidx copy %.2f, bins %.2f, anc_rel %.2f, update lists %.2f ms\n", tms(q2, f0), tms(f0, f1), tms(f1, f2), tms(f2, q3));
+    if (tv) fprintf(stderr, "[dsss pg symbolic] bins+lists: rowidx copy %.2f, bins %.2f, anc_rel %.2f, update lists %.2f, destinations %.2f ms%s\n", tms(q2, f0), tms(f0, f1), tms(f1, f2), tms(f2, f3), tms(f3, q3),
+                    opt.lists_on_device ? " (lists and root indices: on the device)" : "");
     // ---- top: supernodes of the remaining columns become fronts.  Fundamental supernodes (consecutive columns with nested
     // structure) first; then RELAXED amalgamation along the column order: a front whose columns end where its parent's begin is
     // merged into the parent when that adds few explicit zero blocks -- every merge removes a level of the schedule, and the

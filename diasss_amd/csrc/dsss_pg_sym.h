@@ -42,6 +42,7 @@ struct pg_sym {
     std::vector<long long> mapptr;      // update map offsets (binned targets only; see pg_build_map_kernel)
     std::vector<int> broot;             // subtree roots inside bins that have ancestors outside (they hand an update matrix up)
     std::vector<int> broot_of_col;      // per column: index into broot of its subtree root, or -1
+    std::vector<int> root_of;           // per binned column: its subtree root (column), -1 for the others
     std::vector<int> broot_b;           // boundary size in blocks = |struct(root)| - 1
     std::vector<long long> broot_uoff;  // offset (doubles) of U_root in the bin-update arena: (6b)^2 row-major, then 6b of right-hand side
     std::vector<int> binroot_ptr, binroot_idx;     // roots per bin (CSR into broot)
@@ -118,6 +119,7 @@ struct pg_sym_opts {
     // scatter and the bins of the first trial under the rest of the analysis.  Only with one partition (interface values get their
     // dest_bin codes at the very end).  None of the vectors it may read is touched afterwards.
     std::function<void()> on_bottom_ready;
+    bool lists_on_device = false;                // the caller builds the update lists, the update-map offsets and the root-boundary indices of the bins itself (dsss_pg.hip: on the device); rlptr .. anc_rel stay empty
     std::function<void()> before_order;          // called once the adjacency is built, before the first use of the coordinates (which may still be on their way)
 };
 
