@@ -397,106 +397,110 @@ void pg_symbolic(int ns, const std::vector<std::pair<int, int>>& edges, int ncha
         root_of[j] = (par >= 0 && sub_ok[par]) ? root_of[par] : j;
     }
     S.root_of = root_of;
-    std::vector<int> bin_of_root(ns, -1);
-    {   // greedy packing of whole subtrees into bins, subtrees taken in ascending root order, never across ranks
-        std::vector<int> roots;
-        for (int j = 0; j < ns; ++j) if (sub_ok[j] && root_of[j] == j) roots.push_back(j);
-        // (a rank's interior may be several ranges of the order when geometric cuts come before rank cuts: its bins stay one range)
-        std::stable_sort(roots.begin(), roots.end(), [&](int a, int b) { return S.col_part[a] < S.col_part[b]; });
-        int nbins = 0; double fill = opt.bin_cost + 1; int cur_part = -2;
-        for (int r : roots) {
-            if (fill + sub_cost[r] > opt.bin_cost || S.col_part[r] != cur_part) { ++nbins; fill = 0; cur_part = S.col_part[r]; S.bin_part.push_back(cur_part); }
-            fill += sub_cost[r]; bin_of_root[r] = nbins - 1;
-        }
-        S.binptr.assign(nbins + 1, 0);
-        for (int j = 0; j < ns; ++j) if (sub_ok[j]) S.binptr[bin_of_root[root_of[j]] + 1]++;
-        for (int b = 0; b < nbins; ++b) S.binptr[b + 1] += S.binptr[b];
-        S.bincols.resize(S.binptr[nbins]);
-        std::vector<int> fillp(S.binptr.begin(), S.binptr.end() - 1);
-        for (int j = 0; j < ns; ++j) if (sub_ok[j]) S.bincols[fillp[bin_of_root[root_of[j]]]++] = j;     // ascending within a bin
-        // roots that hand an update matrix up
-        S.broot_of_col.assign(ns, -1);
-        S.binroot_ptr.assign(nbins + 1, 0);
-        std::vector<int> idx_of_root(ns, -1);
-        for (int r : roots) if (csz(r) > 1) { idx_of_root[r] = (int)S.broot.size(); S.broot.push_back(r); S.broot_b.push_back(csz(r) - 1); S.binroot_ptr[bin_of_root[r] + 1]++; }
-        for (int b = 0; b < nbins; ++b) S.binroot_ptr[b + 1] += S.binroot_ptr[b];
-        S.binroot_idx.resize(S.broot.size());
-        { std::vector<int> fp(S.binroot_ptr.begin(), S.binroot_ptr.end() - 1); for (size_t i = 0; i < S.broot.size(); ++i) S.binroot_idx[fp[bin_of_root[S.broot[i]]]++] = (int)i; }
-        for (int j = 0; j < ns; ++j) if (sub_ok[j]) S.broot_of_col[j] = idx_of_root[root_of[j]];
-        S.broot_uoff.resize(S.broot.size());
-        long long o = 0;
-        for (size_t i = 0; i < S.broot.size(); ++i) { S.broot_uoff[i] = o; const long long n6 = 6LL * S.broot_b[i]; o += n6 * n6 + n6; o = (o + 31) & ~31LL; }
-        S.ubin_doubles = o;
-    }
-    const auto f1 = tnow();
-    // rows of a binned column beyond its subtree root, as indices into the root's boundary list
-    if (!opt.lists_on_device) {
-    S.anc_first.assign(ns, 0);
-    S.anc_rel.assign(S.nnzL, -1);
-    par_ranges(ns, T, [&](int, int lo, int hi) {
-        for (int k = lo; k < hi; ++k) {
-            if (!sub_ok[k]) continue;
-            const int r = root_of[k], c0 = S.colptr[k], m = csz(k);
-            int q = 0;
-            while (q < m && S.rowidx[c0 + q] <= r) ++q;
-            S.anc_first[k] = q;
-            const int* rb = S.rowidx.data() + S.colptr[r] + 1; const int nb = csz(r) - 1;
-            int w = 0;
-            for (; q < m; ++q) { const int row = S.rowidx[c0 + q]; while (w < nb && rb[w] < row) ++w; S.anc_rel[c0 + q] = (w < nb && rb[w] == row) ? w : -1; }
-        }
-    });
-    }
-    const auto f2 = tnow();
-    // update lists of the binned columns (sources are binned columns of the same subtree), ascending source
-    if (!opt.lists_on_device) {
-        std::vector<std::vector<int>> hist(T, std::vector<int>(ns, 0));
-        par_ranges(ns, T, [&](int t, int lo, int hi) {
-            std::vector<int>& h = hist[t];
-            for (int k = lo; k < hi; ++k) { if (!sub_ok[k]) continue; for (int q = S.colptr[k] + 1; q < S.colptr[k + 1]; ++q) { const int j = S.rowidx[q]; if (sub_ok[j]) h[j]++; } }
-        });
-        S.rlptr.assign(ns + 1, 0);
-        for (int j = 0; j < ns; ++j) { int tot = 0; for (int t = 0; t < T; ++t) { const int c = hist[t][j]; hist[t][j] = tot; tot += c; } S.rlptr[j + 1] = S.rlptr[j] + tot; }
-        S.rlcol.resize(S.rlptr[ns]); S.rlpos.resize(S.rlptr[ns]); S.rlrow.resize(S.rlptr[ns]);
-        par_ranges(ns, T, [&](int t, int lo, int hi) {
-            std::vector<int>& fill = hist[t];
-            for (int k = lo; k < hi; ++k) {
-                if (!sub_ok[k]) continue;
-                for (int q = S.colptr[k] + 1; q < S.colptr[k + 1]; ++q) {
-                    const int j = S.rowidx[q];
-                    if (!sub_ok[j]) continue;
-                    const int at = S.rlptr[j] + fill[j]++;
-                    S.rlcol[at] = k; S.rlpos[at] = q; S.rlrow[at] = j;
-                }
-            }
-        });
-        S.mapptr.assign(ns + 1, 0);
-        for (int j = 0; j < ns; ++j) S.mapptr[j + 1] = S.mapptr[j] + (long long)(S.rlptr[j + 1] - S.rlptr[j]) * (long long)csz(j);
-    }
-    const auto f3 = tnow();
-    // ---- where the assembled blocks go, first half: value index k < ns diagonal of separator k, then the chain couplings, then the
-    // LC edges; a value whose destination column is binned gets its position in the block-sparse factor (the rest -- fronts,
-    // interface -- is settled after the fronts exist)
+    // subtree roots in bin order, and the roots that hand an update matrix up (the fronts of the top need these; the packing itself not)
+    std::vector<int> roots;
+    for (int j = 0; j < ns; ++j) if (sub_ok[j] && root_of[j] == j) roots.push_back(j);
+    // (a rank's interior may be several ranges of the order when geometric cuts come before rank cuts: its bins stay one range)
+    std::stable_sort(roots.begin(), roots.end(), [&](int a, int b) { return S.col_part[a] < S.col_part[b]; });
+    std::vector<int> idx_of_root(ns, -1);
+    for (int r : roots) if (csz(r) > 1) { idx_of_root[r] = (int)S.broot.size(); S.broot.push_back(r); S.broot_b.push_back(csz(r) - 1); }
+    // where the assembled blocks go: value index k < ns diagonal of separator k, then the chain couplings, then the LC edges
     const int ne = (int)edges.size() - nchain, nval = ns + nchain + ne;
     S.dest_bin.assign(nval, -1);
     std::vector<int> v_row(nval), v_col(nval), v_tr(nval);
-    {
-        auto find = [&](int row, int col) { const auto b = S.rowidx.begin() + S.colptr[col], e = S.rowidx.begin() + S.colptr[col + 1];
-                                            return (int)(std::lower_bound(b, e, row) - S.rowidx.begin()); };
-        par_ranges(nval, T, [&](int, int lo, int hi) {
-            for (int v = lo; v < hi; ++v) {
-                int pa, pb;                                   // block H(a, b): rows of a, columns of b
-                if (v < ns) { pa = pb = S.perm[v]; }
-                else { const auto& e = edges[v - ns]; pa = S.perm[e.first]; pb = S.perm[e.second]; }
-                const int row = std::max(pa, pb), col = std::min(pa, pb), tr = (pa >= pb) ? 0 : 1;
-                v_row[v] = row; v_col[v] = col; v_tr[v] = tr;
-                if (sub_ok[col]) S.dest_bin[v] = (find(row, col) << 1) | tr;
-            }
-        });
-    }
+    par_ranges(nval, T, [&](int, int lo, int hi) {
+        for (int v = lo; v < hi; ++v) {
+            int pa, pb;                                   // block H(a, b): rows of a, columns of b
+            if (v < ns) { pa = pb = S.perm[v]; }
+            else { const auto& e = edges[v - ns]; pa = S.perm[e.first]; pb = S.perm[e.second]; }
+            v_row[v] = std::max(pa, pb); v_col[v] = std::min(pa, pb); v_tr[v] = (pa >= pb) ? 0 : 1;
+        }
+    });
     S.nval = nval;
-    if (opt.on_bottom_ready && nparts <= 1) opt.on_bottom_ready();
+    const auto f1 = tnow();
+    // ---- THE BOTTOM TABLES (bin packing, the bins' index lists unless the caller builds them, the destinations of the values that go
+    // into binned columns) and THE TOP (fronts and schedule, below) do not depend on each other: with one partition the bottom runs as a
+    // task of the pool beside the top, and hands itself over (on_bottom_ready) as soon as it is complete
+    std::vector<int> bin_of_root(ns, -1);
+    auto bottom_tables = [&] {
+        {   // greedy packing of whole subtrees into bins, subtrees taken in ascending root order, never across ranks
+            int nbins = 0; double fill = opt.bin_cost + 1; int cur_part = -2;
+            for (int r : roots) {
+                if (fill + sub_cost[r] > opt.bin_cost || S.col_part[r] != cur_part) { ++nbins; fill = 0; cur_part = S.col_part[r]; S.bin_part.push_back(cur_part); }
+                fill += sub_cost[r]; bin_of_root[r] = nbins - 1;
+            }
+            S.binptr.assign(nbins + 1, 0);
+            for (int j = 0; j < ns; ++j) if (sub_ok[j]) S.binptr[bin_of_root[root_of[j]] + 1]++;
+            for (int b = 0; b < nbins; ++b) S.binptr[b + 1] += S.binptr[b];
+            S.bincols.resize(S.binptr[nbins]);
+            std::vector<int> fillp(S.binptr.begin(), S.binptr.end() - 1);
+            for (int j = 0; j < ns; ++j) if (sub_ok[j]) S.bincols[fillp[bin_of_root[root_of[j]]]++] = j;     // ascending within a bin
+            S.broot_of_col.assign(ns, -1);
+            S.binroot_ptr.assign(nbins + 1, 0);
+            for (size_t i = 0; i < S.broot.size(); ++i) S.binroot_ptr[bin_of_root[S.broot[i]] + 1]++;
+            for (int b = 0; b < nbins; ++b) S.binroot_ptr[b + 1] += S.binroot_ptr[b];
+            S.binroot_idx.resize(S.broot.size());
+            { std::vector<int> fp(S.binroot_ptr.begin(), S.binroot_ptr.end() - 1); for (size_t i = 0; i < S.broot.size(); ++i) S.binroot_idx[fp[bin_of_root[S.broot[i]]]++] = (int)i; }
+            for (int j = 0; j < ns; ++j) if (sub_ok[j]) S.broot_of_col[j] = idx_of_root[root_of[j]];
+            S.broot_uoff.resize(S.broot.size());
+            long long o = 0;
+            for (size_t i = 0; i < S.broot.size(); ++i) { S.broot_uoff[i] = o; const long long n6 = 6LL * S.broot_b[i]; o += n6 * n6 + n6; o = (o + 31) & ~31LL; }
+            S.ubin_doubles = o;
+        }
+        if (!opt.lists_on_device) {
+            // rows of a binned column beyond its subtree root, as indices into the root's boundary list
+            S.anc_first.assign(ns, 0);
+            S.anc_rel.assign(S.nnzL, -1);
+            par_ranges(ns, T, [&](int, int lo, int hi) {
+                for (int k = lo; k < hi; ++k) {
+                    if (!sub_ok[k]) continue;
+                    const int r = root_of[k], c0 = S.colptr[k], m = csz(k);
+                    int q = 0;
+                    while (q < m && S.rowidx[c0 + q] <= r) ++q;
+                    S.anc_first[k] = q;
+                    const int* rb = S.rowidx.data() + S.colptr[r] + 1; const int nb = csz(r) - 1;
+                    int w = 0;
+                    for (; q < m; ++q) { const int row = S.rowidx[c0 + q]; while (w < nb && rb[w] < row) ++w; S.anc_rel[c0 + q] = (w < nb && rb[w] == row) ? w : -1; }
+                }
+            });
+            // update lists of the binned columns (sources are binned columns of the same subtree), ascending source
+            std::vector<std::vector<int>> hist(T, std::vector<int>(ns, 0));
+            par_ranges(ns, T, [&](int t, int lo, int hi) {
+                std::vector<int>& h = hist[t];
+                for (int k = lo; k < hi; ++k) { if (!sub_ok[k]) continue; for (int q = S.colptr[k] + 1; q < S.colptr[k + 1]; ++q) { const int j = S.rowidx[q]; if (sub_ok[j]) h[j]++; } }
+            });
+            S.rlptr.assign(ns + 1, 0);
+            for (int j = 0; j < ns; ++j) { int tot = 0; for (int t = 0; t < T; ++t) { const int c = hist[t][j]; hist[t][j] = tot; tot += c; } S.rlptr[j + 1] = S.rlptr[j] + tot; }
+            S.rlcol.resize(S.rlptr[ns]); S.rlpos.resize(S.rlptr[ns]); S.rlrow.resize(S.rlptr[ns]);
+            par_ranges(ns, T, [&](int t, int lo, int hi) {
+                std::vector<int>& fill = hist[t];
+                for (int k = lo; k < hi; ++k) {
+                    if (!sub_ok[k]) continue;
+                    for (int q = S.colptr[k] + 1; q < S.colptr[k + 1]; ++q) {
+                        const int j = S.rowidx[q];
+                        if (!sub_ok[j]) continue;
+                        const int at = S.rlptr[j] + fill[j]++;
+                        S.rlcol[at] = k; S.rlpos[at] = q; S.rlrow[at] = j;
+                    }
+                }
+            });
+            S.mapptr.assign(ns + 1, 0);
+            for (int j = 0; j < ns; ++j) S.mapptr[j + 1] = S.mapptr[j] + (long long)(S.rlptr[j + 1] - S.rlptr[j]) * (long long)csz(j);
+        }
+        {   // a value whose destination column is binned gets its position in the block-sparse factor (the rest -- fronts, interface --
+            // is settled with the fronts)
+            auto find = [&](int row, int col) { const auto b = S.rowidx.begin() + S.colptr[col], e = S.rowidx.begin() + S.colptr[col + 1];
+                                                return (int)(std::lower_bound(b, e, row) - S.rowidx.begin()); };
+            par_ranges(nval, T, [&](int, int lo, int hi) { for (int v = lo; v < hi; ++v) if (sub_ok[v_col[v]]) S.dest_bin[v] = (find(v_row[v], v_col[v]) << 1) | v_tr[v]; });
+        }
+        if (opt.on_bottom_ready && nparts <= 1) opt.on_bottom_ready();
+    };
+    pg_pool::task bottom_task; bool bottom_forked = false;
+    if (nparts <= 1 && T > 1) { bottom_task.fn = bottom_tables; pg_pool::get().fork(&bottom_task); bottom_forked = true; }
+    else bottom_tables();
+    struct bottom_joiner { pg_pool::task* t; bool on; ~bottom_joiner() { if (on) pg_pool::get().join(t); } } bottom_join{ &bottom_task, bottom_forked };      // (before anything of this function goes away)
     const auto q3 = tnow();
-    if (tv) fprintf(stderr, "[dsss pg symbolic] bins+lists: rowidx copy %.2f, bins %.2f, anc_rel %.2f, update lists %.2f, destinations %.2f ms%s\n", tms(q2, f0), tms(f0, f1), tms(f1, f2), tms(f2, f3), tms(f3, q3),
+    if (tv) fprintf(stderr, "[dsss pg symbolic] bins: flags + roots + value coordinates %.2f ms; bottom tables %s%s\n", tms(f0, f1), bottom_forked ? "as a task beside the fronts" : "in line",
                     opt.lists_on_device ? " (lists and root indices: on the device)" : "");
     // ---- top: supernodes of the remaining columns become fronts.  Fundamental supernodes (consecutive columns with nested
     // structure) first; then RELAXED amalgamation along the column order: a front whose columns end where its parent's begin is
@@ -709,6 +713,7 @@ void pg_symbolic(int ns, const std::vector<std::pair<int, int>>& edges, int ncha
             for (int k = 0; k < ns; ++k) if (S.col_part[S.perm[k]] < 0) S.iface_seps.push_back(k);
         }
     }
+    if (bottom_join.on) { pg_pool::get().join(&bottom_task); bottom_join.on = false; }      // the bottom tables are complete from here on
     // statistics
     for (int j = 0; j < ns; ++j) { const double m = csz(j) - 1; S.flops_factor += 36.0 * 6.0 * (m * m + 3 * m) + 72.0; }
     if (tv) fprintf(stderr, "[dsss pg symbolic] fronts+schedule: supernodes %.2f, children+rel %.2f, destinations+entries %.2f, schedule %.2f, row views %.2f, rest %.2f ms\n", tms(q3, fA), tms(fA, fB), tms(fB, fC), tms(fC, fD), tms(fD, fE), tms(fE, tnow()));
