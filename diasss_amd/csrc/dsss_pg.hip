@@ -2216,15 +2216,6 @@ static int pg_solve_impl(dsss_ctx* c, const double* dr6, int total, const dsss_l
     });
     struct pg_joiner { std::thread& t; ~pg_joiner() { if (t.joinable()) t.join(); } } sym_join{ sym_thread };      // every return path waits for the thread before its data goes away
     struct pg_coords_guard { std::promise<void>& p; bool done = false; void set() { if (!done) { done = true; p.set_value(); } } ~pg_coords_guard() { set(); } } coords_guard{ coords_prom };      // (an error exit must not leave the thread waiting)
-    for (int e = 0; e < ne; ++e) {                  // measurements and weights of the loop closures (the analysis is running)
-        for (int k = 0; k < 9; ++k) emeas[e].R[k] = edges[e].rel[k];
-        for (int k = 0; k < 3; ++k) emeas[e].t[k] = edges[e].rel[9 + k];
-        for (int k = 0; k < 6; ++k) {
-            if (!(edges[e].var[k] > 0) || !std::isfinite(edges[e].var[k])) DSSS_FAIL(c, DSSS_E_NUMERIC, "LC edge %d: variance %d is not finite and positive", e, k);
-            ew[(size_t)e * 6 + k] = 1.0 / std::sqrt(edges[e].var[k]);
-        }
-        for (int k = 0; k < 12; ++k) if (!std::isfinite(edges[e].rel[k])) DSSS_FAIL(c, DSSS_E_NUMERIC, "LC edge %d: relative pose is not finite", e);
-    }
     // device state
     pg_dev dv;
     int rc = DSSS_OK;
@@ -2262,6 +2253,15 @@ static int pg_solve_impl(dsss_ctx* c, const double* dr6, int total, const dsss_l
         if (e != hipSuccess) { dv.release(); HIPCHK(c, e); }
         for (int k = 0; k < ns; ++k) { cx[k] = sxy[2 * (size_t)k]; cy[k] = sxy[2 * (size_t)k + 1]; }
         coords_guard.set();
+    }
+    for (int e = 0; e < ne; ++e) {                  // measurements and weights of the loop closures (the analysis is running and has its coordinates)
+        for (int k = 0; k < 9; ++k) emeas[e].R[k] = edges[e].rel[k];
+        for (int k = 0; k < 3; ++k) emeas[e].t[k] = edges[e].rel[9 + k];
+        for (int k = 0; k < 6; ++k) {
+            if (!(edges[e].var[k] > 0) || !std::isfinite(edges[e].var[k])) { dv.release(); DSSS_FAIL(c, DSSS_E_NUMERIC, "LC edge %d: variance %d is not finite and positive", e, k); }
+            ew[(size_t)e * 6 + k] = 1.0 / std::sqrt(edges[e].var[k]);
+        }
+        for (int k = 0; k < 12; ++k) if (!std::isfinite(edges[e].rel[k])) { dv.release(); DSSS_FAIL(c, DSSS_E_NUMERIC, "LC edge %d: relative pose is not finite", e); }
     }
     // level-1 chain = true separators merged with the chunk ends 0, chunk, 2 chunk ...; segment orders: only the device reads them
     const double t_m0 = ms_since(T0);
