@@ -2185,9 +2185,7 @@ static int pg_solve_impl(dsss_ctx* c, const double* dr6, int total, const dsss_l
     std::vector<std::pair<int, int>> redges;
     redges.reserve((size_t)ns + ne);
     const double t_q3 = ms_since(T0);
-    for (int k = 0; k + 1 < ns; ++k) redges.push_back({ k, k + 1 });
-    for (int e = 0; e < ne; ++e) redges.push_back({ sidx(ea[e]), sidx(eb[e]) });
-    const double t_p2 = ms_since(T0);
+    const double t_p2 = ms_since(T0);                   // (the reduced edges themselves are written by the analysis thread, first thing)
     const auto T1 = std::chrono::steady_clock::now();
     // The analysis of the reduced system runs on a host thread of its own while this thread sets up everything that does not depend
     // on it -- device arrays of the pose chain, initial values, the first linearisation and the chain part of the first LM trial
@@ -2206,6 +2204,8 @@ static int pg_solve_impl(dsss_ctx* c, const double* dr6, int total, const dsss_l
         opt.on_bottom_ready = [&] { bottom_signalled = true; bottom_prom.set_value(); };
         opt.before_order = [&] { coords_fut.wait(); };
         opt.lists_on_device = lists_on_device;
+        for (int k = 0; k + 1 < ns; ++k) redges.push_back({ k, k + 1 });      // the reduced graph: the chain of the separators, then the loop closures
+        for (int e = 0; e < ne; ++e) redges.push_back({ sidx(ea[e]), sidx(eb[e]) });
         static const double bin_cost = getenv("DSSS_PG_BIN_COST") ? atof(getenv("DSSS_PG_BIN_COST")) : 600;   // ~ update-list iterations + 20 per column; measured optimum at C3 (500-700)
         opt.bin_cost = bin_cost; pg_sym_opts_env(opt);
         pg_symbolic(ns, redges, nseg, cx.data(), cy.data(), nparts > 1 ? sym_part.data() : nullptr, nparts, opt, S);
