@@ -405,8 +405,8 @@ __global__ __launch_bounds__(256) void fast_cells_kernel(const ex_frame* __restr
 #pragma unroll
             for (int u = 0; u < 6; ++u) {
                 const int t = t0 + 64 * u + lane;
-                const int r = (int)(((unsigned)t * mg) >> 16), j = t - dpr * r;
-                const uint8_t* src = corner + (size_t)r * cols + 4 * j;
+                const int r = (int)(__umul24((unsigned)t, mg) >> 16), j = t - (int)__umul24((unsigned)dpr, (unsigned)r);      // (24-bit multiplies are full rate, 32-bit ones a quarter: every operand here is below 2^21)
+                const uint8_t* src = corner + (size_t)__umul24((unsigned)r, (unsigned)cols) + 4 * j;
                 off[u] = t < items ? r * stride + 4 * j : -1;
                 v[u] = 0u;
                 if (t < items) {
@@ -425,7 +425,7 @@ __global__ __launch_bounds__(256) void fast_cells_kernel(const ex_frame* __restr
     const int G = (ew + 3) >> 2, ngroups = ne > 0 ? eh * G : 0;      // groups of four pixels of a row, the unit of both passes below
     const unsigned mg_g = ((1u << 20) + (unsigned)(G > 0 ? G : 1) - 1u) / (unsigned)(G > 0 ? G : 1);
     for (int g = lane; g < ngroups; g += 64) {
-        const int gy = (int)(((unsigned)g * mg_g) >> 20), xg = 4 * (g - gy * G);
+        const int gy = (int)(__umul24((unsigned)g, mg_g) >> 20), xg = 4 * (g - (int)__umul24((unsigned)gy, (unsigned)G));
         const int y = 3 + gy;
         // (a group that runs over the evaluated range reads window bytes nobody wrote -- inside this wavefront's slice -- for pixels whose
         // values are dropped here: the border of A stays zero)
@@ -447,7 +447,7 @@ __global__ __launch_bounds__(256) void fast_cells_kernel(const ex_frame* __restr
     for (int g0 = 0; g0 < ngroups; g0 += 64) {
         const int g = min(g0 + lane, ngroups - 1);
         const bool gvalid = g0 + lane < ngroups;
-        const int gy = (int)(((unsigned)g * mg_g) >> 20), xg = 4 * (g - gy * G);
+        const int gy = (int)(__umul24((unsigned)g, mg_g) >> 20), xg = 4 * (g - (int)__umul24((unsigned)gy, (unsigned)G));
         const int y = 3 + gy;
         const uint8_t* __restrict__ pr = A + (y - 1) * stride + xg;              // dword-aligned: stride and xg are multiples of four
         // bytes 2..7 of (lo, hi) of a row = columns x0 - 1 .. x0 + 4, x0 = 3 + xg
@@ -487,7 +487,7 @@ __global__ __launch_bounds__(256) void fast_cells_kernel(const ex_frame* __restr
         for (int g0 = 0; g0 < ngroups; g0 += 64) {
             const int g = min(g0 + lane, ngroups - 1);
             const bool gvalid = g0 + lane < ngroups;
-            const int gy = (int)(((unsigned)g * mg_g) >> 20), xg = 4 * (g - gy * G);
+            const int gy = (int)(__umul24((unsigned)g, mg_g) >> 20), xg = 4 * (g - (int)__umul24((unsigned)gy, (unsigned)G));
             const int y = 3 + gy;
             const uint32_t packed = gvalid ? *reinterpret_cast<const uint32_t*>(win + y * stride + xg) : 0u;
             int a4[4]; unsigned long long mk[4]; int below = 0, total = 0;

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Wall time of the extraction stage alone (set_frames + extract, device-resident frames), for A/B runs of its switches
+"""Wall time of frame set-up + extraction (set_frames starts the extraction, extract finishes it; device-resident frames), for A/B runs of its switches
 (DSSS_EX_PIPE, DSSS_LIB): python tools/extract_only.py [frames=200] [repeats=10]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -16,11 +16,12 @@ poses = [i[0] for i in ins]; alts = [i[1] for i in ins]; grs = [i[2] for i in in
 pipe = Pipeline(F)
 ts = []
 for s in range(reps + 2):
-    pipe.set_frames(raws, poses, alts, grs); torch.cuda.synchronize(); pipe.ctx.sync()
+    torch.cuda.synchronize(); pipe.ctx.sync()
     t0 = time.perf_counter()
+    pipe.set_frames(raws, poses, alts, grs)                 # (starts the extraction of device-resident frames itself)
     pipe.extract(); pipe.ctx.sync()
     ts.append(1e3 * (time.perf_counter() - t0))
 ts = sorted(ts[2:])
-print("extract %d frames: median %.3f ms, min %.3f | %s %s" % (F, ts[len(ts) // 2], ts[0], os.environ.get("DSSS_LIB", "<tree>")[-18:],
+print("set_frames + extract, %d frames: median %.3f ms, min %.3f | %s %s" % (F, ts[len(ts) // 2], ts[0], os.environ.get("DSSS_LIB", "<tree>")[-18:],
       " ".join("%s=%s" % (k, v) for k, v in sorted(os.environ.items()) if k.startswith("DSSS_EX_"))))
 pipe.close()
