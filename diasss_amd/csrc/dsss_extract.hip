@@ -206,9 +206,9 @@ __global__ __launch_bounds__(256) void resize_kernel(const ex_frame* __restrict_
         const uint32_t g = gb + 1024u * k;
         g0[k] = g;
         const uint32_t gv = g < total ? g : gb;                           // a group past the end recomputes group 0 and stores nothing
-        int q = (int)((double)gv * inv), r = (int)gv - q * dw;
+        int q = (int)((double)gv * inv), r = (int)gv - (int)__umul24((uint32_t)q, (uint32_t)dw);      // (rows and columns < 65536)
         const int adj = r < 0 ? -1 : (r >= dw ? 1 : 0);
-        q += adj; r -= adj * dw;
+        q += adj; r -= adj < 0 ? -dw : (adj > 0 ? dw : 0);
         rr[k] = (uint32_t)r; q0[k] = (uint32_t)q; q1[k] = (uint32_t)(q + 1 < dh ? q + 1 : dh - 1);
     }
     // tables: xt[r .. r + 3] in two 16-byte loads (the table carries its first entries again behind the last column)
@@ -248,7 +248,7 @@ __global__ __launch_bounds__(256) void resize_kernel(const ex_frame* __restrict_
                 const rs_u16x2 w = __builtin_bit_cast(rs_u16x2, xw[k][u]);
                 const uint32_t r0 = __builtin_amdgcn_udot2(__builtin_bit_cast(rs_u16x2, __builtin_amdgcn_perm(hi0, lo0, 0x0c010c00u + (o0 & 3u) * 0x00010001u)), w, 0u, false);
                 const uint32_t r1 = __builtin_amdgcn_udot2(__builtin_bit_cast(rs_u16x2, __builtin_amdgcn_perm(hi1, lo1, 0x0c010c00u + (o1 & 3u) * 0x00010001u)), w, 0u, false);
-                const uint32_t v = ((((b0 * (r0 >> 4)) >> 16) + ((b1 * (r1 >> 4)) >> 16) + 2u) >> 2) & 255u;
+                const uint32_t v = (((__umul24(b0, r0 >> 4) >> 16) + (__umul24(b1, r1 >> 4) >> 16) + 2u) >> 2) & 255u;        // (weights <= 2048, row sums >> 4 < 2^16: 24-bit multiplies, full rate)
                 out |= v << (8 * u);
             }
             outv[k] = out;
@@ -271,7 +271,7 @@ __global__ __launch_bounds__(256) void resize_kernel(const ex_frame* __restrict_
                 const rs_u16x2 w = __builtin_bit_cast(rs_u16x2, xw[k][u]);
                 const uint32_t r0 = __builtin_amdgcn_udot2(__builtin_bit_cast(rs_u16x2, __builtin_amdgcn_perm(0u, p0, 0x0c010c00u)), w, 0u, false);
                 const uint32_t r1 = __builtin_amdgcn_udot2(__builtin_bit_cast(rs_u16x2, __builtin_amdgcn_perm(0u, p1, 0x0c010c00u)), w, 0u, false);
-                const uint32_t v = ((((b0 * (r0 >> 4)) >> 16) + ((b1 * (r1 >> 4)) >> 16) + 2u) >> 2) & 255u;
+                const uint32_t v = (((__umul24(b0, r0 >> 4) >> 16) + (__umul24(b1, r1 >> 4) >> 16) + 2u) >> 2) & 255u;        // (weights <= 2048, row sums >> 4 < 2^16: 24-bit multiplies, full rate)
                 out |= v << (8 * u);
             }
             outv[k] = out;
