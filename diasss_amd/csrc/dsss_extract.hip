@@ -650,9 +650,9 @@ __global__ __launch_bounds__(256) void orient_desc_kernel(const ex_frame* __rest
 #pragma unroll
             for (int u = 0; u < 10; ++u) {
                 const int t = t0 + 64 * u + lane;
-                const int py = (int)(((unsigned)t * 5042u) >> 16), j = t - 13 * py;      // t / 13, exact for t < 49 * 13
+                const int py = (int)(__umul24((unsigned)t, 5042u) >> 16), j = t - 13 * py;      // t / 13, exact for t < 49 * 13
                 o[u] = t < PW * 13 ? py * PS + 4 * j : -1;
-                v[u] = t < PW * 13 ? *reinterpret_cast<const u32_unaligned*>(corner + (size_t)py * cols + 4 * j) : 0u;
+                v[u] = t < PW * 13 ? *reinterpret_cast<const u32_unaligned*>(corner + (size_t)__umul24((unsigned)py, (unsigned)cols) + 4 * j) : 0u;      // (py < 49, cols < 65536: a full-rate multiply)
             }
 #pragma unroll
             for (int u = 0; u < 10; ++u) if (o[u] >= 0) *reinterpret_cast<uint32_t*>(P + o[u]) = v[u];
@@ -692,7 +692,7 @@ __global__ __launch_bounds__(256) void orient_desc_kernel(const ex_frame* __rest
     const unsigned G0 = 1u | 2u << 8 | 7u << 16 | 16u << 24, G1 = 31u | 45u << 8 | 52u << 16 | 45u << 24, G2 = 31u | 16u << 8 | 7u << 16 | 2u << 24;
     if (act)
         for (int t = lane; t < PW * 10; t += 64) {                   // (row py, four columns bx0 .. bx0 + 3 of the 37-wide band): their windows
-            const int py = (int)(((unsigned)t * 6554u) >> 16), g = t - 10 * py;      // share the sixteen bytes P[py][bx0 .. bx0 + 15]; t / 10 exact for t < 554
+            const int py = (int)(__umul24((unsigned)t, 6554u) >> 16), g = t - 10 * py;      // share the sixteen bytes P[py][bx0 .. bx0 + 15]; t / 10 exact for t < 554
             const uint32_t* w = reinterpret_cast<const uint32_t*>(P + py * PS + 4 * g);          // PS and the slice offsets are multiples of 4
             const uint32_t w0 = w[0], w1 = w[1], w2 = w[2], w3 = w[3];
 #pragma unroll
@@ -710,7 +710,7 @@ __global__ __launch_bounds__(256) void orient_desc_kernel(const ex_frame* __rest
     __syncthreads();
     if (act)
         for (int t = lane; t < BW * 19; t += 64) {                   // (column bx, rows by0 and by0 + 1): taps on H[bx][by0 .. by0 + 13], seven aligned dwords
-            const int bx = (int)(((unsigned)t * 3450u) >> 16), by0 = 2 * (t - 19 * bx);          // t / 19 exact for t < 767
+            const int bx = (int)(__umul24((unsigned)t, 3450u) >> 16), by0 = 2 * (t - 19 * bx);          // t / 19 exact for t < 767
             const uint32_t* w = reinterpret_cast<const uint32_t*>(H + bx * HS + by0);            // HS and by0 are even
             uint32_t v[7];
 #pragma unroll
