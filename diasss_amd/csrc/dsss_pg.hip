@@ -191,9 +191,25 @@ __global__ __launch_bounds__(6 * PG_ASM_POSES) void pg_assemble_kernel(int n, pg
                                                           double* __restrict__ D, double* __restrict__ C, double* __restrict__ g,
                                                           const int* __restrict__ eo, int mp0, int mp1)
 {
+    // (a thread's six values of a block row are 48 contiguous bytes, the threads of a wavefront 48 bytes apart: stored directly, every
+    // store instruction touched 24 cache lines for a sixth each.  The rows go through LDS and leave as 16-byte stores of whole lines.)
+    __shared__ double s_dc[2][PG_ASM_POSES * 36];
+    __shared__ double s_j[PG_ASM_POSES * 36];            // Jacobians of the chain factors i + 1 of the workgroup's poses: one contiguous 9 KB read
     const int i = blockIdx.x * PG_ASM_POSES + threadIdx.x / 6, a = threadIdx.x % 6;
-    if (i >= n) return;
+    const bool live = i < n;
+    {
+        const size_t jb = ((size_t)blockIdx.x * PG_ASM_POSES + 1) * 36, lim = (size_t)n * 36;      // factor k lives at Ji + 36 k, k < n
+#pragma unroll
+        for (int u = 0; u < 3; ++u) {
+            const int e = 2 * (u * (6 * PG_ASM_POSES) + (int)threadIdx.x);
+            double2 v = make_double2(0.0, 0.0);
+            if (jb + e + 1 < lim) v = *reinterpret_cast<const double2*>(Ji + jb + e);
+            s_j[e] = v.x; s_j[e + 1] = v.y;
+        }
+    }
+    __syncthreads();
     double Dd[6] = { 0, 0, 0, 0, 0, 0 }, Cc[6] = { 0, 0, 0, 0, 0, 0 }, gg = 0;
+    if (live) {
     const bool own_i = i >= mp0 && i < mp1, own_next = i + 1 >= mp0 && i + 1 < mp1;
     // factor i with this pose as the second variable (Jacobian W)
     const double* w2 = i == 0 ? W.prior : W.odo;
@@ -204,7 +220,7 @@ __global__ __launch_bounds__(6 * PG_ASM_POSES) void pg_assemble_kernel(int n, pg
         gg += wa * r[(size_t)i * 6 + a];
     }
     if (i + 1 < n && own_next) {   // factor i+1 with this pose as the first variable
-        const double* J = Ji + (size_t)(i + 1) * 36; const double* rr = r + (size_t)(i + 1) * 6;
+        const double* J = s_j + (threadIdx.x / 6) * 36; const double* rr = r + (size_t)(i + 1) * 6;
         double ja[6], sb[6] = { 0, 0, 0, 0, 0, 0 };            // column a of J; row a of J^T J
 #pragma unroll
         for (int q = 0; q < 6; ++q) ja[q] = J[q * 6 + a];
@@ -250,9 +266,23 @@ __global__ __launch_bounds__(6 * PG_ASM_POSES) void pg_assemble_kernel(int n, pg
 #pragma unroll
         for (int b = 0; b < 6; ++b) if (b == a) Dd[b] += lambda;
     }
-#pragma unroll
-    for (int b = 0; b < 6; ++b) { D[(size_t)i * 36 + a * 6 + b] = Dd[b]; C[(size_t)i * 36 + a * 6 + b] = Cc[b]; }
     g[(size_t)i * 6 + a] = gg;
+    }       // live
+#pragma unroll
+    for (int b = 0; b < 6; ++b) { s_dc[0][threadIdx.x * 6 + b] = Dd[b]; s_dc[1][threadIdx.x * 6 + b] = Cc[b]; }
+    __syncthreads();
+    {   // 32 poses x 36 doubles per array = 576 pairs of doubles: three 16-byte stores per thread and array, consecutive threads consecutive pairs
+        const size_t base = (size_t)blockIdx.x * PG_ASM_POSES * 36;
+        const size_t lim = (size_t)n * 36;
+#pragma unroll
+        for (int u = 0; u < 3; ++u) {
+            const int e = 2 * (u * (6 * PG_ASM_POSES) + (int)threadIdx.x);
+            if (base + e + 1 < lim) {                        // (n * 36 is even: a pair is either inside or outside)
+                *reinterpret_cast<double2*>(D + base + e) = make_double2(s_dc[0][e], s_dc[0][e + 1]);
+                *reinterpret_cast<double2*>(C + base + e) = make_double2(s_dc[1][e], s_dc[1][e + 1]);
+            }
+        }
+    }
 }
 
 // Schur complement of the interior of segment s (poses L+1 .. R-1) onto its end points L, R (block Thomas recursion).
