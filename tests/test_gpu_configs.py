@@ -77,6 +77,92 @@ def test_config_C2_full_pipeline_vs_oracle(orc):
     pipe.close()
 
 
+
+def test_config_C3_full_size_every_stage_vs_oracle(orc):
+    """BASELINE config 3 at FULL size, stage by stage against the oracle (the oracle's frames, pairs and mini-LMs run on a
+    thread pool: the C calls release the GIL): features of all 200 frames bit-exact (geo samples included), rows and kp7 of
+    every active pair bit-exact and every inactive pair empty in the oracle too, every mini-LM (same iteration count, relative
+    pose 1e-9), the selected loop-closure edges identical.  The oracle's own LM cannot finish 400 k poses (envelope Cholesky:
+    hours), so the last stage is held to the oracle's OBJECTIVE on the oracle's edges: the errors the device reports before and
+    after are orc_pg_error_at at the initial estimate and at its answer."""
+    import time
+    from concurrent.futures import ThreadPoolExecutor
+    from diasss_amd.pipeline import Pipeline, all_pairs
+    from diasss_amd.synth import Survey
+    F, N, M = 200, 2000, 1024
+    sv = Survey(F, N, M, seed=20240601 + 1, device="cuda:0")
+    raws = [sv.frame(f) for f in range(F)]
+    ins = [sv.inputs(f) for f in range(F)]
+    pipe = Pipeline(F)
+    g_poses, g_stats = pipe.run(raws, [i[0] for i in ins], [i[1] for i in ins], [i[2] for i in ins])
+    g_poses = g_poses.copy(); g_stats = np.array(g_stats)
+    pool = ThreadPoolExecutor(max_workers=min(os.cpu_count() or 1, 16))
+    t0 = time.time()
+
+    def o_frame(f):
+        pose, alt, gr = ins[f]
+        kps, desc, _, _ = orc.detect_feature(raws[f].cpu().numpy())
+        return dict(pose=pose, alt=alt, gr=gr, kps=kps, desc=desc, geo=orc.geo_at_kps(pose, gr, M, kps), bb=orc.geo_bbox(pose, gr, M))
+    fr = list(pool.map(o_frame, range(F)))
+    t_ex = time.time() - t0
+    nkp = 0
+    for f in range(F):                                                        # extraction: all 200 frames bit-exact
+        k, d, g = pipe.ctx.features_get(f)
+        o = fr[f]
+        assert len(k) == len(o["kps"]) and (d == o["desc"]).all(), "frame %d" % f
+        for fld in ("x", "y", "angle", "response", "octave"):
+            assert (k[fld] == o["kps"][fld]).all(), "frame %d %s" % (f, fld)
+        assert (g == o["geo"]).all(), "frame %d geo" % f
+        nkp += len(k)
+    src, tgt = all_pairs(F)
+    t0 = time.time()
+
+    def o_pair(p):
+        i, j = int(src[p]), int(tgt[p])
+        a, b = fr[i], fr[j]
+        rows = orc.robust_matching(i, j, N, N, a["kps"], a["desc"], a["geo"], a["bb"], b["kps"], b["desc"], b["geo"], b["bb"])
+        kp7 = orc.get_kps_pairs(rows, j, a["alt"], a["gr"], b["alt"], b["gr"])
+        return rows, kp7, orc.lc_solve(kp7, a["pose"], a["alt"], a["gr"], M, b["pose"], b["alt"], b["gr"], M)
+    res = list(pool.map(o_pair, range(len(src))))
+    t_pairs = time.time() - t0
+    pool.shutdown()
+    active = n_rows = n_lc = 0
+    off = [0]
+    for p in range(len(src)):                                                 # matching, reprojection, mini-LM: all 19 900 pairs
+        rows, kp7, lc = res[p]
+        off.append(off[-1] + len(kp7))
+        if not pipe.ctx.pair_is_active(p):
+            assert len(rows) == 0, "pair %d-%d was skipped (disjoint geo boxes) but the oracle matches it" % (src[p], tgt[p])
+            continue
+        active += 1
+        assert (pipe.ctx.match_rows(p) == rows).all(), "rows of pair %d-%d differ" % (src[p], tgt[p])
+        assert (pipe.ctx.match_kp7(p) == kp7).all(), "kp7 of pair %d-%d differ" % (src[p], tgt[p])
+        g = pipe.ctx.lc_get(p)
+        assert len(g) == len(lc)
+        n_rows += len(rows); n_lc += len(lc)
+        if len(g):
+            assert (g["iters"] == lc["iters"]).all(), "mini-LM iteration counts of pair %d-%d differ" % (src[p], tgt[p])
+            assert np.abs(g["rel"] - lc["rel"]).max() < 1e-9 and np.allclose(g["var"], lc["var"], rtol=1e-6, atol=0)
+    assert (n_rows, n_lc) == tuple(pipe.ctx.match_total())
+    edges = orc.pg_select_lc([N] * F, src, tgt, off, np.concatenate([r[1] for r in res]), np.concatenate([r[2] for r in res]))
+    g_edges = pipe.ctx.posegraph_select(F)
+    assert len(g_edges) == len(edges) > 5000
+    assert (g_edges["a"] == edges["a"]).all() and (g_edges["b"] == edges["b"]).all()
+    assert np.abs(g_edges["rel"] - edges["rel"]).max() < 1e-9 and np.allclose(g_edges["var"], edges["var"], rtol=1e-6, atol=0)
+    # pose graph: the oracle's objective on the ORACLE's edges at the device's initial estimate and at its answer
+    dr = np.concatenate([i[0] for i in ins])
+    mp_, op_, mt_, pg = pipe.ctx.default_params()
+    pg.max_iters = 0
+    pipe.ctx.set_params(pg=pg)
+    x0, _, _ = pipe.ctx.posegraph_solve(F, F * N)
+    e0 = orc.pg_error_at(dr, edges, x0); e1 = orc.pg_error_at(dr, edges, g_poses)
+    print("C3 full size vs the oracle: %d keypoints, %d active pairs of %d, %d rows, %d mini-LMs, %d edges; oracle objective %.6e -> %.9e, device reports "
+          "%.6e -> %.9e in %d iterations; oracle time: frames %.0f s, pairs %.0f s" % (nkp, active, len(src), n_rows, n_lc, len(edges), e0, e1, g_stats[1], g_stats[2], g_stats[0], t_ex, t_pairs))
+    assert active > 300 and n_lc > 30000
+    assert abs(e0 - g_stats[1]) <= 1e-9 * e0 and abs(e1 - g_stats[2]) <= 1e-7 * e1 and e1 < 1e-6 * e0
+    pipe.close()
+
+
 def _run_demo(tmp, d, extra, name):
     exe = os.path.join(ROOT, "diasss_amd", "host", "test_demo")
     od = tmp / name; od.mkdir()
@@ -371,7 +457,7 @@ def test_config_C5_scale_pose_graph():
     assert (p2 == p1).all() and (s2 == s1).all()                     # bit-reproducible
     c.set_pg_partitions(8)
     p8, s8 = c.posegraph_solve_edges(dr, edges)
-    assert s8[0] == s1[0] and np.abs(p8 - p1).max() < 1e-5      # another elimination order: rounding only (the track spans 4 km; 6e-7 measured)
+    assert s8[0] == s1[0] and np.abs(p8 - p1).max() < 1e-6      # another elimination order: rounding only (north_star's 1e-6, absolute; the track spans 4 km; 6e-7 measured)
     c.close()
 
 

@@ -92,3 +92,32 @@ def test_load_input_data_reference_layout(tmp_path):
                 assert first == a.reshape(-1)[0] and last == a.reshape(-1)[-1]          # exact round trip of the text form
                 assert abs(s_ - float(np.sum(a.astype(np.longdouble)))) <= 1e-9 * max(1.0, abs(s_))
             assert got[("anno", f)] == (anno.shape[0], anno.shape[1], int(anno.sum()), 4)   # CV_32S
+
+
+def test_reference_main_compiles_and_links_unchanged_against_the_drop_in(tmp_path):
+    """north_star: "Host code stays C++ with the existing Frame/constraint API surface so test_demo links unchanged".  The
+    reference's own driver, src/diasss2.cpp, is compiled UNCHANGED (read where it lies, never copied) against the host mirror in
+    diasss_amd/host/ and linked with the drop-in classes + libdsss.so; the resulting binary must start and print its usage.  The
+    third-party headers the driver names but does not use for anything the mirror does not provide (boost/filesystem, opencv2/*,
+    Eigen/Dense: none is in this image) are EMPTY files on the include path -- a type check of the API surface, not a build of the
+    reference (its own translation units under src/core are replaced, that is the point).  Skips where /root/reference is absent
+    (the GPU box)."""
+    import subprocess
+    ref = "/root/reference/src"
+    if not os.path.exists(os.path.join(ref, "diasss2.cpp")):
+        pytest.skip("/root/reference is not on this machine")
+    host = os.path.join(ROOT, "diasss_amd", "host")
+    inc = tmp_path / "standins"
+    for h in ("boost/filesystem.hpp", "opencv2/highgui/highgui.hpp", "opencv2/core/eigen.hpp", "opencv2/features2d.hpp", "opencv2/opencv.hpp", "Eigen/Dense"):
+        (inc / h).parent.mkdir(parents=True, exist_ok=True)
+        (inc / h).write_text("")
+    flags = ["-std=c++17", "-I" + host, "-I" + str(inc), "-I" + os.path.join(ref, "util")]       # util/ holds the vendored cxxopts.hpp; "util.h" resolves to the mirror first
+    subprocess.check_call(["g++", "-fsyntax-only", "-Wall"] + flags + [os.path.join(ref, "diasss2.cpp")])
+    obj = str(tmp_path / "diasss2.o"); exe = str(tmp_path / "diasss2_dropin")
+    subprocess.check_call(["g++", "-O1", "-c"] + flags + [os.path.join(ref, "diasss2.cpp"), "-o", obj])
+    rocm = os.environ.get("ROCM_PATH", "/opt/rocm")
+    subprocess.check_call(["g++", "-O1", "-std=c++17", "-o", exe, obj] + [os.path.join(host, s) for s in ("frame.cpp", "FEAmatcher.cpp", "optimizer.cpp", "util.cpp", "filestorage.cpp")]
+                          + ["-I" + host, "-L" + os.path.join(ROOT, "diasss_amd"), "-ldsss", "-L" + rocm + "/lib", "-lamdhip64",
+                             "-Wl,-rpath," + os.path.join(ROOT, "diasss_amd"), "-Wl,-rpath," + rocm + "/lib"])
+    out = subprocess.run([exe, "--help"], capture_output=True, text=True, timeout=60)
+    assert out.returncode == 0 and "--image" in out.stdout and "--groundrange" in out.stdout
