@@ -402,6 +402,7 @@ def main():
         dist.destroy_process_group()
 
 
+pmc_mfma_table = ({}, None)
 F64_PEAK_TFLOPS = 78.6   # MI355X FP64 vector/matrix peak (AMD spec sheet; v_mfma_f64_16x16x4_f64 measured at 64 cycles: the two peaks coincide)
 # ONE measured constant for everything that is priced in vector instructions: the chip-wide wave-instruction issue rate of the
 # full-rate class at 8 wavefronts per SIMD, tools/ubench/valu_issue.hip on MI355X (profiles/r03_ubench_valu_issue.txt: v_fma_f32
@@ -473,6 +474,20 @@ def pmc_valu(workload):
     return out
 
 
+def pmc_mfma(workload):
+    """MfmaUtil (SQ_VALU_MFMA_BUSY_CYCLES over GRBM_GUI_ACTIVE x all SIMDs, percent) per kernel from the committed counter pass of the latest
+    round: profiles/rNN_pmc_mfma_<workload>.csv (tools/pmc_mfma_summary.py) -- north_star asks for "MFMA utilisation on the solve" as evidence"""
+    path = _latest("r*_pmc_mfma_%s.csv" % workload)
+    out = {}
+    if path:
+        import csv
+        with open(path) as fh:
+            for r in csv.DictReader(fh):
+                k = r["kernel"][5:] if r["kernel"].startswith("void ") else r["kernel"]
+                out[k] = float(r["MfmaUtil_percent_of_all_1024_SIMDs"])
+    return out, (os.path.basename(path) if path else None)
+
+
 def one_roofline(slot, ms, n, work, traffic, valu=None):
     """one kernel: `frac` = algorithmic bytes (or flops, or SURVEY 8(d)'s comparisons) per launch over the live average launch duration,
     against the hardware peak -- never against the kernel's own instruction count; `valu_issue_util` is reported beside it"""
@@ -522,16 +537,29 @@ def group_roofline(name, prof, traffic, units, unit_work):
         ach, peak, unit = work / per_unit_s / 1e9, MATCH_PEAK_GEVALS, "G gate+Hamming evaluations/s"
     else:
         ach, peak, unit = work / per_unit_s / 1e12, F64_PEAK_TFLOPS, "TFLOP/s"
-    return {"kernel": name + " (" + " + ".join(SLOT_KERNEL.get(k, k) for k in live) + ")", "bound": "hbm" if bound == "hbm" else ("mfma" if bound == "mfma" else bound),
-            "achieved": ach, "peak": peak, "unit": unit, "frac": ach / peak, "traffic": tr if tr > 0 else None, "traffic_calibrated": cal if tr > 0 else None,
-            "launches": units, "avg_launch_us": per_unit_s * 1e6, "ms_per_step": ms, "note": GROUP_NOTE.get(name)}
+    out = {"kernel": name + " (" + " + ".join(SLOT_KERNEL.get(k, k) for k in live) + ")", "bound": "hbm" if bound == "hbm" else ("mfma" if bound == "mfma" else bound),
+           "achieved": ach, "peak": peak, "unit": unit, "frac": ach / peak, "traffic": tr if tr > 0 else None, "traffic_calibrated": cal if tr > 0 else None,
+           "launches": units, "avg_launch_us": per_unit_s * 1e6, "ms_per_step": ms, "note": GROUP_NOTE.get(name)}
+    if tr > 0:
+        out["hbm_GBs"] = tr / per_unit_s / 1e9       # counter traffic over the live duration: the "rocprof HBM GB/s" north_star asks for on the matcher
+    if bound == "mfma":                              # "MFMA utilisation on the solve": per kernel from the committed PMC pass, and their mean weighted by the live kernel times
+        mu, src = pmc_mfma_table
+        per = {SLOT_KERNEL[k]: mu[SLOT_KERNEL[k]] for k in live if SLOT_KERNEL.get(k) in mu}
+        if per:
+            tw = sum(prof[k][0] for k in live if SLOT_KERNEL.get(k) in mu)
+            out["mfma_util_pct_by_kernel"] = per
+            out["mfma_util_pct"] = sum(mu[SLOT_KERNEL[k]] * prof[k][0] for k in live if SLOT_KERNEL.get(k) in mu) / tw if tw > 0 else None
+            out["mfma_util_source"] = "profiles/" + src
+    return out
 
 
 def roofline(prof, workload, wl=None, trials=1):
     """headline = the kernel GROUP with the largest accumulated GPU time (SURVEY 8(d) stages); plus every group and every kernel
     that has an algorithmic work figure, each against the hardware peak of what bounds it"""
+    global pmc_mfma_table
     traffic = pmc_traffic(workload)
     valu = pmc_valu(workload)
+    pmc_mfma_table = pmc_mfma(workload)
     F, N, M = (wl["F"], wl["N"], wl["M"]) if wl else (0, 0, 0)
     groups = {}
     for g in GROUPS:
@@ -545,8 +573,13 @@ def roofline(prof, workload, wl=None, trials=1):
     best = max(groups, key=lambda g: groups[g]["ms_per_step"])
     cand = {k: v for k, v in prof.items() if k not in ("pg", "pg_comm") and v[1] > 0 and v[2] > 0}
     allr = {k: one_roofline(k, *cand[k], traffic, valu) for k in cand}
-    keep = ("bound", "achieved", "peak", "unit", "frac", "avg_launch_us", "traffic", "traffic_calibrated", "hbm_GBs", "launches", "valu_issue_util", "ms_per_step")
+    keep = ("bound", "achieved", "peak", "unit", "frac", "avg_launch_us", "traffic", "traffic_calibrated", "hbm_GBs", "launches", "valu_issue_util", "ms_per_step",
+            "mfma_util_pct", "mfma_util_pct_by_kernel", "mfma_util_source")
     rnd = lambda d: {kk: (round(vv, 5) if isinstance(vv, float) else vv) for kk, vv in d.items() if kk in keep}
+    mu = pmc_mfma_table[0]
+    for k, v in allr.items():
+        if SLOT_KERNEL.get(k) in mu:
+            v["mfma_util_pct"] = mu[SLOT_KERNEL[k]]
     return groups[best], {g: rnd(v) for g, v in groups.items()}, {k: rnd(v) for k, v in allr.items()}
 
 

@@ -429,7 +429,7 @@ int dsss_frames_set(dsss_ctx* c, int n, const int* ids, const double* const* raw
     }
     HIPCHK(c, hipEventRecord(c->xev[0], c->stream));        // whatever is queued so far may still read the buffer's previous contents
     if (raw) dsss_extract_eager(c, ids, n);
-    static const int T_env = getenv("DSSS_FS_THREADS") ? atoi(getenv("DSSS_FS_THREADS")) : 0;
+    const int T_env = getenv("DSSS_FS_THREADS") ? atoi(getenv("DSSS_FS_THREADS")) : 0;
     const int T = T_env > 0 ? T_env : (n >= 16 ? 4 : 1);       // (eight threads were slower than four: the pointer-attribute queries of frame_fill serialise)
     std::vector<hipError_t> errs(T, hipSuccess);
     auto work = [&](int t) { for (int i = t; i < n; i += T) { const hipError_t e = frame_fill(c, ids[i], G.h + off[i], pose6[i], alt[i], grange[i]); if (e != hipSuccess) errs[t] = e; } };

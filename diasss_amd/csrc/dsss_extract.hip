@@ -1017,7 +1017,7 @@ static int extract_frames_impl(dsss_ctx* c, const int* ids, int n, bool keep_tap
     // stream (xs[1]) under the kernels of batch k (PCIe: 16 B per pixel against ~6 ns of kernels per pixel, so the copies set the pace)
     bool any_pending = false;
     for (int i = 0; i < n; ++i) any_pending = any_pending || c->frames[ids[i]].raw_pending;
-    if (any_pending) { static const int sb = getenv("DSSS_EX_UPLOAD_BATCH") ? std::max(1, atoi(getenv("DSSS_EX_UPLOAD_BATCH"))) : 8; B = std::min(B, sb); }
+    if (any_pending) { const int sb = getenv("DSSS_EX_UPLOAD_BATCH") ? std::max(1, atoi(getenv("DSSS_EX_UPLOAD_BATCH"))) : 8; B = std::min(B, sb); }
     if (phase != 0 && (any_pending || B < n)) DSSS_FAIL(c, DSSS_E_STATE, "two-phase extraction needs one batch of device-resident images");
     hipEvent_t up_ev[2] = { c->xev[1], c->xev[2] };
     auto upload_batch = [&](int b0, hipEvent_t ev) -> hipError_t {
@@ -1134,8 +1134,8 @@ static int extract_frames_impl(dsss_ctx* c, const int* ids, int n, bool keep_tap
         // and the main stream picks the results up after the last group.  Groups: levels 0 .. 4 alone, the small top levels together
         // (every launch ends with a partly empty chip).  Two side streams, not more: the runtime folds streams onto four hardware queues,
         // and a quadtree that shares its queue with the next group's gather holds it up.  DSSS_EX_PIPE=0: all on the main stream.
-        static const bool pipe_levels = !(getenv("DSSS_EX_PIPE") && atoi(getenv("DSSS_EX_PIPE")) == 0);
-        static const int solo_levels = getenv("DSSS_EX_SOLO") ? std::max(0, atoi(getenv("DSSS_EX_SOLO"))) : 5;
+        const bool pipe_levels = !(getenv("DSSS_EX_PIPE") && atoi(getenv("DSSS_EX_PIPE")) == 0);
+        const int solo_levels = getenv("DSSS_EX_SOLO") ? std::max(0, atoi(getenv("DSSS_EX_SOLO"))) : 5;
         const int fstride = max_cw <= 40 ? 40 : CELL_STRIDE, fwave = (2 * max_ch * fstride + 15) & ~15;      // window + arc values of one wavefront
         const hipStream_t s_qt[2] = { pipe_levels ? c->xs[2] : st, pipe_levels ? c->xs[3] : st };
         bool qt_used[2] = { false, false };
@@ -1231,7 +1231,7 @@ static int extract_frames(dsss_ctx* c, const int* ids, int n, bool keep_taps)
 // dsss_frames_set: start the extraction of the frames whose images are in HBM (see extract_frames_impl).  Not an error if it cannot.
 void dsss_extract_eager(dsss_ctx* c, const int* ids, int n)
 {
-    static const bool on = !(getenv("DSSS_EX_EAGER") && atoi(getenv("DSSS_EX_EAGER")) == 0);
+    const bool on = !(getenv("DSSS_EX_EAGER") && atoi(getenv("DSSS_EX_EAGER")) == 0);
     c->ex_eager_valid = false;
     if (!on || n <= 0 || n > EX_BATCH) return;
     std::vector<int> mine;

@@ -2071,7 +2071,7 @@ __global__ __launch_bounds__(256) void pg_rpy_kernel(int n, const pose_t* __rest
 // ------------------------------------------------------------------ host: device memory of one solve
 namespace {
 
-inline int sym_threads() { static const int env = getenv("DSSS_SYM_THREADS") ? atoi(getenv("DSSS_SYM_THREADS")) : 0; if (env > 0) return env;
+inline int sym_threads() { const int env = getenv("DSSS_SYM_THREADS") ? atoi(getenv("DSSS_SYM_THREADS")) : 0; if (env > 0) return env;
                           const unsigned hc = std::thread::hardware_concurrency(); return (int)std::min(8u, std::max(1u, hc)); }      // ranges per parallel phase of the analysis (its worker pool has 7 threads); 16 gain another 10 % on an idle 128-core host
 
 struct pg_dev {
@@ -2220,7 +2220,7 @@ static int pg_solve_impl(dsss_ctx* c, const double* dr6, int total, const dsss_l
     // The analysis of the reduced system runs on a host thread of its own while this thread sets up everything that does not depend
     // on it -- device arrays of the pose chain, initial values, the first linearisation and the chain part of the first LM trial
     // (assembly, both segment passes): the device works through those while the host orders and analyses.
-    static const bool lists_on_device = !(getenv("DSSS_PG_LISTS") && !strcmp(getenv("DSSS_PG_LISTS"), "host"));      // A/B: the bins' update lists built by the analysis (host) instead of on the device
+    const bool lists_on_device = !(getenv("DSSS_PG_LISTS") && !strcmp(getenv("DSSS_PG_LISTS"), "host"));      // A/B: the bins' update lists built by the analysis (host) instead of on the device
     std::vector<double> cx(ns), cy(ns);                       // separator coordinates: filled below, read by the analysis after its adjacency pass
     pg_sym S;
     pg_sched SO, SI;
@@ -2236,7 +2236,7 @@ static int pg_solve_impl(dsss_ctx* c, const double* dr6, int total, const dsss_l
         opt.lists_on_device = lists_on_device;
         for (int k = 0; k + 1 < ns; ++k) redges.push_back({ k, k + 1 });      // the reduced graph: the chain of the separators, then the loop closures
         for (int e = 0; e < ne; ++e) redges.push_back({ sidx(ea[e]), sidx(eb[e]) });
-        static const double bin_cost = getenv("DSSS_PG_BIN_COST") ? atof(getenv("DSSS_PG_BIN_COST")) : 600;   // ~ update-list iterations + 20 per column; measured optimum at C3 (500-700)
+        const double bin_cost = getenv("DSSS_PG_BIN_COST") ? atof(getenv("DSSS_PG_BIN_COST")) : 600;   // ~ update-list iterations + 20 per column; measured optimum at C3 (500-700)
         opt.bin_cost = bin_cost; pg_sym_opts_env(opt);
         pg_symbolic(ns, redges, nseg, cx.data(), cy.data(), nparts > 1 ? sym_part.data() : nullptr, nparts, opt, S);
         // launch lists: this rank's interior fronts, then (after the all-reduce) the replicated interface fronts
@@ -2524,7 +2524,7 @@ static int pg_solve_impl(dsss_ctx* c, const double* dr6, int total, const dsss_l
                          hipLaunchKernelGGL(pg_factor_subtree_kernel, dim3(nbins), dim3(256), 0, st, d_binptr + bin_lo, d_bincols, d_colptr, d_rlptr, d_rlcol, d_rlpos, d_mapptr, d_map, d_L, d_x, d_fail,
                                             d_binroot_ptr + bin_lo, d_binroot_idx, d_broot_b, d_broot_uoff, d_broot_of_col, d_anc_first, d_anc_rel, d_ubin); }
     };
-    static const bool early_ok = !(getenv("DSSS_PG_EARLY") && atoi(getenv("DSSS_PG_EARLY")) == 0);      // A/B switch
+    const bool early_ok = !(getenv("DSSS_PG_EARLY") && atoi(getenv("DSSS_PG_EARLY")) == 0);      // A/B switch
     const bool early_bottom = early_ok && nparts == 1 && will_iterate && pre_chain;
     if (early_bottom) {
         bottom_fut.wait();
@@ -2545,7 +2545,7 @@ static int pg_solve_impl(dsss_ctx* c, const double* dr6, int total, const dsss_l
                 (S.comm_doubles + 36.0 * S.comm_vals.size() + 6.0 * S.iface_seps.size()) * 8e-6);
 
     TRY(dv.alloc(c, &d_F, (size_t)S.front_doubles)); TRY(dv.alloc(c, &d_R, (size_t)S.frhs_doubles));
-    static const int rsu_max = getenv("DSSS_PG_RSU") ? atoi(getenv("DSSS_PG_RSU")) : PG_RSU_MAX_TILES;      // A/B: 0 = separate row solve and update launches on every level; n = tile limit
+    const int rsu_max = getenv("DSSS_PG_RSU") ? atoi(getenv("DSSS_PG_RSU")) : PG_RSU_MAX_TILES;      // A/B: 0 = separate row solve and update launches on every level; n = tile limit
     const bool use_rsu = rsu_max > 0;
     double* d_FL = nullptr;                              // second front arena: L21 of the levels that run the fused kernel
     if (use_rsu) TRY(dv.alloc(c, &d_FL, (size_t)S.front_doubles));
@@ -2593,7 +2593,7 @@ static int pg_solve_impl(dsss_ctx* c, const double* dr6, int total, const dsss_l
     }
     const int max_n6 = std::max(SO.max_n6, SI.max_n6);
     unsigned long long* d_stamps = nullptr; if (getenv("DSSS_PG_STAMPS")) TRY(dv.alloc(c, &d_stamps, 16));
-    static const bool diag3_panel = getenv("DSSS_PG_PANEL") && !strcmp(getenv("DSSS_PG_PANEL"), "diag3");          // A/B: two barriers per block
+    const bool diag3_panel = getenv("DSSS_PG_PANEL") && !strcmp(getenv("DSSS_PG_PANEL"), "diag3");          // A/B: two barriers per block
     double* d_Tinv; TRY(dv.alloc(c, &d_Tinv, (size_t)std::max(npan, 1) * PG_NB4 * 16));
     double* d_bwp = nullptr;                                // partial sums of the split back-substitution products (tall fronts only)
     {

@@ -1,0 +1,81 @@
+"""GPU: every DSSS_* environment switch that selects another code path of the product is held to the default path's result.
+
+The switches exist for A/B measurements (DESIGN.md names each); an untested alternative path rots.  They are read per call, so one
+process can flip them.  Paths that run the SAME arithmetic in another arrangement (panel kernel with two barriers per block,
+separate row solve / trailing update launches, bin lists built on the host, no early start of the bins, extraction on one stream,
+no eager extraction, other upload batch) must reproduce the default's bits; knobs that change the ELIMINATION ORDER (chunk length of
+the chain condensation, bin size, dissection and amalgamation rules) must reproduce it to rounding, with the same LM path."""
+import hashlib
+import os
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+SAME_BITS_PG = [("DSSS_PG_PANEL", "diag3"), ("DSSS_PG_RSU", "0"), ("DSSS_PG_RSU", "64"), ("DSSS_PG_LISTS", "host"), ("DSSS_PG_EARLY", "0"),
+                ("DSSS_SYM_THREADS", "1"), ("DSSS_SYM_THREADS", "5")]
+SAME_OPTIMUM_PG = [("DSSS_PG_CHUNK", "8"), ("DSSS_PG_CHUNK", "24"), ("DSSS_PG_BIN_COST", "300"), ("DSSS_PG_BIN_COST", "1200"), ("DSSS_PG_ND_BOTH", "1000000"),
+                   ("DSSS_PG_LEAF", "12"), ("DSSS_PG_RELAX_ZERO", "0"), ("DSSS_PG_RELAX_FLOPS", "1.0"), ("DSSS_PG_RELAX_SMALL", "1.0"), ("DSSS_PG_RELAX_ABS", "1e6")]
+SAME_BITS_EX = [("DSSS_EX_PIPE", "0"), ("DSSS_EX_SOLO", "0"), ("DSSS_EX_SOLO", "3"), ("DSSS_EX_EAGER", "0"), ("DSSS_EX_UPLOAD_BATCH", "1"), ("DSSS_EX_UPLOAD_BATCH", "3"),
+                ("DSSS_FS_THREADS", "1")]
+
+
+class _env:
+    def __init__(self, k, v): self.k, self.v = k, v
+    def __enter__(self): self.old = os.environ.get(self.k); os.environ[self.k] = self.v
+    def __exit__(self, *a):
+        if self.old is None: os.environ.pop(self.k, None)
+        else: os.environ[self.k] = self.old
+
+
+def test_pose_graph_switches_reproduce_the_default():
+    from diasss_amd import capi
+    from tests.test_gpu_configs import _lawnmower_graph
+    dr, gt, edges = _lawnmower_graph(10, 12000, 4000, seed=11)           # 120 k poses, 4 k loop closures: bins, fronts of several panels, fused and unfused levels
+    c = capi.Context(max_frames=2)
+    ref, sref = c.posegraph_solve_edges(dr, edges)
+    href = hashlib.sha1(ref.tobytes()).hexdigest()
+    assert sref[0] >= 3 and sref[2] < 1e-6 * sref[1]
+    for k, v in SAME_BITS_PG:
+        with _env(k, v):
+            p, s = c.posegraph_solve_edges(dr, edges)
+        assert hashlib.sha1(p.tobytes()).hexdigest() == href and (s == sref).all(), "%s=%s changes the result" % (k, v)
+    for k, v in SAME_OPTIMUM_PG:
+        with _env(k, v):
+            p, s = c.posegraph_solve_edges(dr, edges)
+        assert s[0] == sref[0] and abs(s[2] - sref[2]) <= 1e-9 * sref[2] and np.abs(p - ref).max() < 1e-8, "%s=%s: %g" % (k, v, np.abs(p - ref).max())
+    for nparts, geo in ((4, "1"), (4, "0")):                             # the partitioned layout on one rank, interface dissected (default) or rank cuts first
+        c.set_pg_partitions(nparts)
+        with _env("DSSS_PG_GEO_FIRST", geo):
+            p, s = c.posegraph_solve_edges(dr, edges)
+        assert s[0] == sref[0] and np.abs(p - ref).max() < 1e-8
+    c.close()
+
+
+def test_extraction_switches_reproduce_the_default():
+    import torch
+    from diasss_amd import capi
+    from diasss_amd.synth import Survey
+    F, N, M = 5, 900, 512
+    sv = Survey(F, N, M, seed=123, device="cuda:0")
+    dev = [sv.frame(f) for f in range(F)]
+    host = [d.cpu().pin_memory() for d in dev]
+    ins = [sv.inputs(f) for f in range(F)]
+
+    def run(raws):
+        c = capi.Context(max_frames=F)
+        c.frames_set(list(range(F)), raws, [N] * F, [M] * F, [i[0] for i in ins], [i[1] for i in ins], [i[2] for i in ins])
+        c.extract_many(list(range(F)))
+        h = hashlib.sha1()
+        for f in range(F):
+            k, d, g = c.features_get(f)
+            h.update(k.tobytes()); h.update(d.tobytes()); h.update(g.tobytes())
+        c.close()
+        return h.hexdigest()
+    href = run(dev)
+    assert run(host) == href                                                 # page-locked host frames, uploaded under the kernels
+    for k, v in SAME_BITS_EX:
+        with _env(k, v):
+            assert run(dev) == href, "%s=%s changes the features (device-resident frames)" % (k, v)
+            assert run(host) == href, "%s=%s changes the features (host-resident frames)" % (k, v)
+    torch.cuda.synchronize()
