@@ -1390,24 +1390,41 @@ __global__ __launch_bounds__(256) void pg_front_trsm2_kernel(const int* __restri
 // its L21 rows and folds them into the right-hand side.  L21 goes to a SECOND front arena (FL): the tiles of a level run concurrently
 // and read A21 in place, which an in-place store would pull from under them (the race that stopped round 2's version of this).
 #define PG_RSU_MAX_TILES 320
-__global__ __launch_bounds__(512) void pg_front_rsu_kernel(const int* __restrict__ it_front, const int* __restrict__ it_step, const pg_front* __restrict__ FD,
-                                                           const int* __restrict__ tile_item, const int* __restrict__ tile_ij,
-                                                           double* __restrict__ F, double* __restrict__ FL, double* __restrict__ R, const double* __restrict__ Tinv)
+#define PG_RSU32_MAX_TILES 80
+// TS = 64: the tile list of the level as it is (512 threads).  TS = 32 (round 4): every 64 x 64 tile of the list is cut into its (up to) four
+// 32 x 32 quarters, one workgroup of 256 threads each (blockIdx & 3 = quarter; the quarters above the diagonal or beyond the front leave at
+// once).  On the levels near the root a launch holds a handful of tiles on a 256-CU chip, and what a workgroup costs there is what ONE
+// compute unit can pull and multiply: in-kernel variants with parts switched off put the fused kernel at 6.4 us (empty launch, with the
+// event scope) + 9.2 (operands: L11, Tinv, two 64-row chunks, the tile -- 170 KB through one CU) + 5.7 (the two solves, two wavefronts per
+// SIMD on the matrix core) + 3.6 (update).  A quarter moves 94 KB, solves two 32-row chunks on four SIMDs and updates a quarter of the
+// tile.  The 16-row slabs and the 16 x 16 blocks see the same products in the same order: bit-identical to the 64 x 64 form.
+template <int TS>
+__global__ __launch_bounds__(TS * 8) void pg_front_rsu_kernel(const int* __restrict__ it_front, const int* __restrict__ it_step, const pg_front* __restrict__ FD,
+                                                              const int* __restrict__ tile_item, const int* __restrict__ tile_ij,
+                                                              double* __restrict__ F, double* __restrict__ FL, double* __restrict__ R, const double* __restrict__ Tinv)
 {
+    constexpr int NW = TS / 16, NTH = TS * 8;          // wavefronts per chunk, threads
     __shared__ double sL[(PG_PW * 6) * PG_T2_LD];      // L11 of the panel (lower triangle), the A operands of every solve step
     __shared__ double sT[PG_NB4 * 16];                 // the 4 x 4 inverse blocks
     __shared__ double sY[PG_PW * 6];
-    __shared__ double sB[64 * PG_SYRK_LD];             // solved chunk tj: the B operands of the update
-    const int item = tile_item[blockIdx.x], ij = tile_ij[blockIdx.x], ti = ij >> 16, tj = ij & 0xffff;
+    __shared__ double sB[TS * PG_SYRK_LD];             // solved chunk tj: the B operands of the update
+    const int tix = TS == 64 ? (int)blockIdx.x : (int)(blockIdx.x >> 2);
+    const int item = tile_item[tix], ij = tile_ij[tix];
+    int ti = ij >> 16, tj = ij & 0xffff;
     const pg_front fd = FD[it_front[item]];
     const int step = it_step[item], col0 = 96 * step;
     const int n = min(96, fd.s6 - col0), p = fd.pan0 + step, ld = fd.ld;
     const int row0 = col0 + n, nrows = fd.n6 - row0;
+    if (TS == 32) {
+        const int sub = blockIdx.x & 3;
+        ti = 2 * ti + (sub >> 1); tj = 2 * tj + (sub & 1);
+        if (tj > ti || 32 * ti >= nrows) return;       // workgroup-uniform: a quarter above the diagonal, or one that lies beyond the front
+    }
     const int wave = threadIdx.x >> 6, l = threadIdx.x & 63, c = l & 15, q = l >> 4;
-    const bool grp_i = wave < 4;                       // wavefronts 0..3: chunk ti; 4..7: chunk tj
+    const bool grp_i = wave < NW;                      // first NW wavefronts: chunk ti; the others: chunk tj
     const bool diag = ti == tj;
-    const int w4 = wave & 3;
-    const int rowbase = ((grp_i ? ti : tj) * 4 + w4) * 16;
+    const int w4 = wave & (NW - 1);
+    const int rowbase = ((grp_i ? ti : tj) * NW + w4) * 16;
     const bool rok = rowbase + c < nrows;
     const bool solve = grp_i || !diag;                 // on a diagonal tile the second group has nothing to solve
     double* __restrict__ A = F + fd.off;
@@ -1418,23 +1435,24 @@ __global__ __launch_bounds__(512) void pg_front_rsu_kernel(const int* __restrict
 #pragma unroll
         for (int v = 0; v < 4; ++v) { const int col = 16 * T + q + 4 * v; S[T][v] = (solve && rok && col < n) ? Arow[col] : 0.0; }
     // the tile of C this wavefront updates comes in with the operands too (first group only)
-    const int i0 = 64 * ti + 16 * w4;
-    pg_d4 acc[4];
+    const int i0 = TS * ti + 16 * w4;
+    pg_d4 acc[NW];
 #pragma unroll
-    for (int cb = 0; cb < 4; ++cb) {
-        const int j0 = 64 * tj + 16 * cb, jr = j0 + (l & 15);
+    for (int cb = 0; cb < NW; ++cb) {
+        const int j0 = TS * tj + 16 * cb, jr = j0 + (l & 15);
         const double* __restrict__ Cp = A + (size_t)(row0 + i0 + (l >> 4)) * ld + row0 + j0 + (l & 15);
 #pragma unroll
         for (int v = 0; v < 4; ++v) acc[cb][v] = (grp_i && i0 < nrows && j0 <= i0 + 15 && i0 + (l >> 4) + 4 * v < nrows && jr < nrows) ? Cp[(size_t)(4 * v) * ld] : 0.0;
     }
     {
         const double* __restrict__ L11 = A + (size_t)col0 * ld + col0;
-        double v[18];
+        constexpr int NE = 96 * 96 / NTH;
+        double v[NE];
 #pragma unroll
-        for (int e = 0; e < 18; ++e) { const int id = e * 512 + threadIdx.x, r = id / 96, cc = id - 96 * r; v[e] = (r < n && cc <= r) ? L11[(size_t)r * ld + cc] : 0.0; }
+        for (int e = 0; e < NE; ++e) { const int id = e * NTH + threadIdx.x, r = id / 96, cc = id - 96 * r; v[e] = (r < n && cc <= r) ? L11[(size_t)r * ld + cc] : 0.0; }
 #pragma unroll
-        for (int e = 0; e < 18; ++e) { const int id = e * 512 + threadIdx.x, r = id / 96, cc = id - 96 * r; sL[r * PG_T2_LD + cc] = v[e]; }
-        for (int e = threadIdx.x; e < PG_NB4 * 16; e += 512) sT[e] = Tinv[(size_t)p * PG_NB4 * 16 + e];
+        for (int e = 0; e < NE; ++e) { const int id = e * NTH + threadIdx.x, r = id / 96, cc = id - 96 * r; sL[r * PG_T2_LD + cc] = v[e]; }
+        for (int e = threadIdx.x; e < PG_NB4 * 16; e += NTH) sT[e] = Tinv[(size_t)p * PG_NB4 * 16 + e];
         if (threadIdx.x < 96) sY[threadIdx.x] = (int)threadIdx.x < n ? R[fd.roff + col0 + threadIdx.x] : 0.0;
     }
     __syncthreads();
@@ -1494,8 +1512,8 @@ __global__ __launch_bounds__(512) void pg_front_rsu_kernel(const int* __restrict
     // A22 -= L21 L21^T on the tile: the steps of pg_front_syrk_kernel; A operand k = 4 ks + (l >> 4) of row (l & 15) is register (ks & 3) of
     // tile register ks >> 2 of this very lane
 #pragma unroll
-    for (int cb = 0; cb < 4; ++cb) {
-        const int j0 = 64 * tj + 16 * cb;
+    for (int cb = 0; cb < NW; ++cb) {
+        const int j0 = TS * tj + 16 * cb;
         if (j0 >= nrows || j0 > i0 + 15) break;
         const int jr = j0 + (l & 15);
         const double* __restrict__ sb = sB + (16 * cb + (l & 15)) * PG_SYRK_LD + (l >> 4);
@@ -2547,6 +2565,7 @@ static int pg_solve_impl(dsss_ctx* c, const double* dr6, int total, const dsss_l
     TRY(dv.alloc(c, &d_F, (size_t)S.front_doubles)); TRY(dv.alloc(c, &d_R, (size_t)S.frhs_doubles));
     const int rsu_max = getenv("DSSS_PG_RSU") ? atoi(getenv("DSSS_PG_RSU")) : PG_RSU_MAX_TILES;      // A/B: 0 = separate row solve and update launches on every level; n = tile limit
     const bool use_rsu = rsu_max > 0;
+    const int rsu32_max = getenv("DSSS_PG_RSU32") ? atoi(getenv("DSSS_PG_RSU32")) : PG_RSU32_MAX_TILES;      // levels with at most this many 64 x 64 tiles run them as 32 x 32 quarters (0 = never)
     double* d_FL = nullptr;                              // second front arena: L21 of the levels that run the fused kernel
     if (use_rsu) TRY(dv.alloc(c, &d_FL, (size_t)S.front_doubles));
     int *d_pk_child, *d_pk_row; pg_pack* d_PK;
@@ -2646,7 +2665,8 @@ static int pg_solve_impl(dsss_ctx* c, const double* dr6, int total, const dsss_l
                           } }
                         if (use_rsu && ntl > 0 && ntl <= rsu_max) {
                             dsss_scope s45(c, DSSS_K_PG_RSU, H.fl_trsm[l] + H.fl_syrk[l]);
-                            hipLaunchKernelGGL(pg_front_rsu_kernel, dim3(ntl), dim3(512), 0, st, itf, its, d_FD, Dv.tile_item + H.tile_ptr[l], Dv.tile_ij + H.tile_ptr[l], d_F, d_FL, d_R, d_Tinv);
+                            if (ntl <= rsu32_max) hipLaunchKernelGGL(pg_front_rsu_kernel<32>, dim3(4 * ntl), dim3(256), 0, st, itf, its, d_FD, Dv.tile_item + H.tile_ptr[l], Dv.tile_ij + H.tile_ptr[l], d_F, d_FL, d_R, d_Tinv);
+                            else hipLaunchKernelGGL(pg_front_rsu_kernel<64>, dim3(ntl), dim3(512), 0, st, itf, its, d_FD, Dv.tile_item + H.tile_ptr[l], Dv.tile_ij + H.tile_ptr[l], d_F, d_FL, d_R, d_Tinv);
                         } else if (H.trsm_chunks[l] > 0) {
                             { dsss_scope s4(c, DSSS_K_PG_TRSM, H.fl_trsm[l]);
                               hipLaunchKernelGGL(pg_front_trsm2_kernel, dim3(nit, H.trsm_chunks[l]), dim3(256), 0, st, itf, its, d_FD, d_F, d_R, d_Tinv); }
