@@ -171,9 +171,12 @@ __global__ __launch_bounds__(QT_THREADS) void quadtree_kernel(const qt_inst* __r
     __shared__ int s_w[QT_WAVES];
     __shared__ int s_S, s_pool, s_nexp, s_done, s_phase2, s_t;
     __shared__ int s_cnt[QT_WAVES][4];
-    __shared__ __attribute__((aligned(16))) int s_big[2 * QT_RANK_CAP + 16];      // phase 2: (size, id) pairs; before it: bucket offsets + cursors of the pre-sort
+    __shared__ __attribute__((aligned(16))) int s_big[2 * QT_RANK_CAP];           // phase 2: (size, id) pairs
+    __shared__ int s_off[QT_RANK_CAP + 8];             // bucket offsets of the D-level path codes (kept to the end: every division above depth D reads its children's sizes here)
+    __shared__ unsigned s_best[QT_RANK_CAP];           // per bucket: the best (response, smallest index) rank of its keys; the cursors of the key scatter once keys are needed
+    __shared__ int s_have_keys;
     int2* s_rank = reinterpret_cast<int2*>(s_big);
-    int* s_off = s_big; int* s_cur = s_big + QT_RANK_CAP + 8;
+    int* s_cur = reinterpret_cast<int*>(s_best);
     const qt_inst I = tab[blockIdx.x];
     const int base = I.offs[I.cell_begin];
     const int n = min(I.offs[I.cell_end], I.cand_cap) - base;         // never index past the candidate arrays (the overflow itself is flagged by scan_counts_kernel)
@@ -245,16 +248,30 @@ __global__ __launch_bounds__(QT_THREADS) void quadtree_kernel(const qt_inst* __r
     int D = 0;
     if (nIni == 1) { int cells = 1; while (cells < N && D < 6) { cells *= 4; ++D; } }
     const bool presorted = D > 0;
+    // Round 4: the keys themselves are NOT written any more unless a division below depth D turns up.  Everything the tree needs
+    // above depth D is the SIZE of a bucket range, and the point a node keeps is the maximum of (response, smallest index) over its
+    // buckets -- both come out of ONE pass over the candidates (LDS histogram + LDS atomicMax).  A level-0 instance of a 2000 x 1024
+    // frame (92 k candidates, quota 501: sorted to depth 5, divided to depth 5) read its candidates twice, wrote 8-byte keys, streamed
+    // them twice more and wrote them again in the size-ordered round, and read them once more for the kept points -- through the one
+    // compute unit it runs on; now it reads them once.  ensure_keys() below is the old second pass, run on demand.
+    if (threadIdx.x == 0) s_have_keys = presorted ? 0 : 1;
     if (presorted) {
         const int nb = 1 << (2 * D);
-        for (int i = threadIdx.x; i <= nb; i += QT_THREADS) s_off[i] = 0;
+        for (int i = threadIdx.x; i <= nb; i += QT_THREADS) { s_off[i] = 0; if (i < nb) s_best[i] = 0u; }
         __syncthreads();
         for (int i0 = threadIdx.x; i0 < n; i0 += 8 * QT_THREADS) {
-            float x8[8], y8[8];
+            float x8[8], y8[8], r8[8];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) { const int i = i0 + u * QT_THREADS; x8[u] = i < n ? xs[i] : 0.f; y8[u] = i < n ? ys[i] : 0.f; }
+            for (int u = 0; u < 8; ++u) { const int i = i0 + u * QT_THREADS; x8[u] = i < n ? xs[i] : 0.f; y8[u] = i < n ? ys[i] : 0.f; r8[u] = i < n ? rs[i] : 0.f; }
 #pragma unroll
-            for (int u = 0; u < 8; ++u) { const int i = i0 + u * QT_THREADS; if (i < n) atomicAdd(&s_off[qt_code((float)(int)x8[u], (float)(int)y8[u], I.W, I.H, D)], 1); }
+            for (int u = 0; u < 8; ++u) {
+                const int i = i0 + u * QT_THREADS;
+                if (i < n) {
+                    const int code = qt_code((float)(int)x8[u], (float)(int)y8[u], I.W, I.H, D);
+                    atomicAdd(&s_off[code], 1);
+                    atomicMax(&s_best[code], (((unsigned)(int)r8[u] & 0xffu) << 24) | (0xffffffu - (unsigned)i));      // = qt_key_rank of the key this candidate would get
+                }
+            }
         }
         __syncthreads();
         {   // exclusive scan of the nb bucket sizes, four consecutive buckets per thread
@@ -266,9 +283,18 @@ __global__ __launch_bounds__(QT_THREADS) void quadtree_kernel(const qt_inst* __r
             int run = qt_block_scan(sum, &tot, s_w);
             __syncthreads();
 #pragma unroll
-            for (int u = 0; u < 4; ++u) if (b0 + u < nb) { s_off[b0 + u] = run; s_cur[b0 + u] = run; run += v[u]; }
+            for (int u = 0; u < 4; ++u) if (b0 + u < nb) { s_off[b0 + u] = run; run += v[u]; }
             if (threadIdx.x == 0) s_off[nb] = n;
         }
+        if (threadIdx.x == 0) pool[0].buf = 1;        // the root's keys are the sorted array (once it exists)
+        __syncthreads();
+    }
+    // the sorted key array, on demand (workgroup-uniform calls only): counting-sort scatter by the D-level code into keys1
+    auto ensure_keys = [&]() {
+        if (s_have_keys) return;
+        const int nb = 1 << (2 * D);
+        __syncthreads();
+        for (int i = threadIdx.x; i < nb; i += QT_THREADS) s_cur[i] = s_off[i];      // (the bucket maxima are gone from here on: the kept points come from the keys)
         __syncthreads();
         for (int i0 = threadIdx.x; i0 < n; i0 += 8 * QT_THREADS) {
             float x8[8], y8[8], r8[8];
@@ -280,9 +306,10 @@ __global__ __launch_bounds__(QT_THREADS) void quadtree_kernel(const qt_inst* __r
                 if (i < n) keys1[atomicAdd(&s_cur[qt_code((float)(int)x8[u], (float)(int)y8[u], I.W, I.H, D)], 1)] = qt_make_key(i, x8[u], y8[u], r8[u]);
             }
         }
-        if (threadIdx.x == 0) pool[0].buf = 1;        // the root's keys are the sorted array
         __syncthreads();
-    }
+        if (threadIdx.x == 0) s_have_keys = 1;
+        __syncthreads();
+    };
     int pass = 0;
 
     // ---- whole-list passes (:594-672)
@@ -312,17 +339,20 @@ __global__ __launch_bounds__(QT_THREADS) void quadtree_kernel(const qt_inst* __r
                 for (int c = 0; c < 4; ++c) { const int cp = (pf << 2) | c; pcnt[4 * r + c] = s_off[(cp + 1) << sh] - s_off[cp << sh]; }
             }
         } else if (np < QT_WAVES) {
+            ensure_keys();
             for (int r = 0; r < np; ++r) {
                 int cnt[4];
                 qt_divide_block(pool[parents[r]], keys0, keys1, cnt, s_cnt);
                 if (threadIdx.x == 0) { pcnt[4 * r] = cnt[0]; pcnt[4 * r + 1] = cnt[1]; pcnt[4 * r + 2] = cnt[2]; pcnt[4 * r + 3] = cnt[3]; }
             }
-        } else
+        } else {
+            ensure_keys();
             for (int r = wv; r < np; r += QT_WAVES) {
                 int cnt[4];
                 qt_divide_wave(pool[parents[r]], keys0, keys1, cnt);
                 if (lane == 0) { pcnt[4 * r] = cnt[0]; pcnt[4 * r + 1] = cnt[1]; pcnt[4 * r + 2] = cnt[2]; pcnt[4 * r + 3] = cnt[3]; }
             }
+        }
         __syncthreads();
         // children in creation order: parents in list order, n1..n4, empty ones skipped
         int Cn = 0, nexp = 0;
@@ -386,10 +416,27 @@ __global__ __launch_bounds__(QT_THREADS) void quadtree_kernel(const qt_inst* __r
                 order[rank] = id;
             }
         __syncthreads();
-        for (int r = wv; r < m; r += QT_WAVES) {     // divide all of them; only the first t+1 take effect
-            int cnt[4];
-            qt_divide_wave(pool[order[r]], keys0, keys1, cnt);
-            if (lane == 0) { pcnt[4 * r] = cnt[0]; pcnt[4 * r + 1] = cnt[1]; pcnt[4 * r + 2] = cnt[2]; pcnt[4 * r + 3] = cnt[3]; }
+        // the nodes of a round were created together: when they sit above depth D (a pre-sorted level) their children are bucket ranges
+        // and nothing is streamed; otherwise every one of them is divided on the keys (only the first t + 1 take effect)
+        bool r2_buckets = false;
+        if (presorted && !s_have_keys) {
+            int deep = 0;
+            for (int e = threadIdx.x; e < m; e += QT_THREADS) { const int dp = (pool[order[e]].leaf >> 4) & 7; deep |= (dp == 0 || dp >= D); }
+            r2_buckets = __syncthreads_or(deep) == 0;
+        }
+        if (r2_buckets) {
+            for (int r = threadIdx.x; r < m; r += QT_THREADS) {
+                const int lf = pool[order[r]].leaf, pf = lf >> 8, sh = 2 * (D - ((lf >> 4) & 7) - 1);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) { const int cp = (pf << 2) | c; pcnt[4 * r + c] = s_off[(cp + 1) << sh] - s_off[cp << sh]; }
+            }
+        } else {
+            ensure_keys();
+            for (int r = wv; r < m; r += QT_WAVES) {
+                int cnt[4];
+                qt_divide_wave(pool[order[r]], keys0, keys1, cnt);
+                if (lane == 0) { pcnt[4 * r] = cnt[0]; pcnt[4 * r + 1] = cnt[1]; pcnt[4 * r + 2] = cnt[2]; pcnt[4 * r + 3] = cnt[3]; }
+            }
         }
         if (threadIdx.x == 0) s_t = m - 1;
         __syncthreads();
@@ -418,7 +465,7 @@ __global__ __launch_bounds__(QT_THREADS) void quadtree_kernel(const qt_inst* __r
                 const qnode P = pool[order[r]];
                 int q = Cn + qe, x = nexp + qx;
                 for (int c = 0; c < 4; ++c) if (cnt[c] > 0) {
-                    pool[pool0 + q] = qt_child(P, c, cnt);
+                    pool[pool0 + q] = qt_child(P, c, cnt, r2_buckets);
                     if (cnt[c] > 1) parents[x++] = pool0 + q;     // next round's expandables (parents[] is free here)
                     ++q;
                 }
@@ -454,6 +501,19 @@ __global__ __launch_bounds__(QT_THREADS) void quadtree_kernel(const qt_inst* __r
 
     // ---- retain the best point of each node, list order (:741-760): first maximum response in key order
     const int S = s_S;
+    if (!s_have_keys) {                                // no key was ever written: a node is a range of buckets, its point the best of their maxima
+        for (int i = wv; i < S; i += QT_WAVES) {
+            const int lf = pool[L[i]].leaf, sh = 2 * (D - ((lf >> 4) & 7)), b0 = (lf >> 8) << sh, b1 = ((lf >> 8) + 1) << sh;
+            unsigned best = 0;
+            for (int k = b0 + lane; k < b1; k += 64) best = max(best, s_best[k]);
+#pragma unroll
+            for (int o = 32; o >= 1; o >>= 1) best = max(best, (unsigned)__shfl_xor((int)best, o, 64));
+            best = 0xffffffu - (best & 0xffffffu);
+            if (lane == 0 && i < I.out_cap) out[i] = base + best;
+        }
+        if (threadIdx.x == 0) { *out_n = S < I.out_cap ? S : I.out_cap; if (S > I.out_cap) *I.err = 3; }
+        return;
+    }
     for (int i = wv; i < S; i += QT_WAVES) {           // one wavefront per node: keys read together, first maximum by (response, candidate index)
         const qnode q = pool[L[i]];
         const qkey* kk = (q.buf ? keys1 : keys0) + q.kbeg;
