@@ -452,10 +452,15 @@ def pmc_traffic(workload):
     if path:
         import csv
         with open(path) as fh:
+            agg = {}
             for r in csv.DictReader(fh):
                 k = r["kernel"][5:] if r["kernel"].startswith("void ") else r["kernel"]
                 out[k] = (float(r["fetch_bytes_per_launch_used"]) + float(r["write_bytes_per_launch"]), bool(int(r["fetch_calibrated_x2"])))
-                out.setdefault(k.split("<")[0], out[k])
+                a = agg.setdefault(k.split("<")[0], [0.0, 0.0, True])      # template instances of one kernel: bytes per launch averaged over all their launches
+                a[0] += out[k][0] * float(r["dispatches"]); a[1] += float(r["dispatches"]); a[2] = a[2] and out[k][1]
+            for k, (sb, n, cal) in agg.items():
+                if k not in out and n > 0:
+                    out[k] = (sb / n, cal)
     return out
 
 
@@ -466,11 +471,16 @@ def pmc_valu(workload):
     if path:
         import csv
         with open(path) as fh:
+            agg = {}
             for r in csv.DictReader(fh):
                 k = r["kernel"][5:] if r["kernel"].startswith("void ") else r["kernel"]
                 out[k] = float(r["SQ_INSTS_VALU_per_launch"])
-                if k.split("<")[0]:
-                    out.setdefault(k.split("<")[0], out[k])
+                a = agg.setdefault(k.split("<")[0], [0.0, 0.0])
+                n = float(r.get("dispatches", 1) or 1)
+                a[0] += out[k] * n; a[1] += n
+            for k, (sv, n) in agg.items():
+                if k and k not in out and n > 0:
+                    out[k] = sv / n
     return out
 
 
@@ -482,9 +492,16 @@ def pmc_mfma(workload):
     if path:
         import csv
         with open(path) as fh:
+            agg = {}
             for r in csv.DictReader(fh):
                 k = r["kernel"][5:] if r["kernel"].startswith("void ") else r["kernel"]
                 out[k] = float(r["MfmaUtil_percent_of_all_1024_SIMDs"])
+                a = agg.setdefault(k.split("<")[0], [0.0, 0.0])       # template instances of one kernel (tile sizes): mean weighted by GPU time (launches x active cycles)
+                w = float(r["dispatches"]) * float(r["GRBM_GUI_ACTIVE_per_launch"])
+                a[0] += out[k] * w; a[1] += w
+            for k, (sw, w) in agg.items():
+                if k not in out and w > 0:
+                    out[k] = sw / w
     return out, (os.path.basename(path) if path else None)
 
 

@@ -159,13 +159,39 @@ __global__ __launch_bounds__(256) void pg_linearize_kernel(int n, int ne, const 
                                                            double* __restrict__ r, double* __restrict__ Ji, double* __restrict__ partial, int mp0, int mp1)
 {
     __shared__ double s_w[4];
+    // (round 4) A thread's 36 Jacobian entries are 288 contiguous bytes and the threads of a wavefront lie 288 bytes apart: stored
+    // directly, every store instruction touched 64 cache lines for 8 bytes each.  The 64 Jacobians of a wavefront are ONE contiguous
+    // 18 KB range: they go through the wavefront's own slice of LDS (half a Jacobian at a time, rows padded to 19) and leave as whole lines.
+    __shared__ double s_j[4][64 * 19];
     const int k = blockIdx.x * 256 + threadIdx.x;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     double e2 = 0;
-    if (k < n + ne && pg_owned_factor(k, n, eo, mp0, mp1)) {
-        double rr[6], J[36];
+    const bool own = k < n + ne && pg_owned_factor(k, n, eo, mp0, mp1);
+    double rr[6], J[36];
+    if (own) {
         factor_eval(k, n, X, meas, W, ea, eb, emeas, ew, rr, Ji ? J : nullptr);
         for (int a = 0; a < 6; ++a) { e2 += rr[a] * rr[a]; if (r) r[(size_t)k * 6 + a] = rr[a]; }
-        if (Ji) for (int a = 0; a < 36; ++a) Ji[(size_t)k * 36 + a] = J[a];
+    }
+    if (Ji) {                                                   // (uniform over the grid)
+        const unsigned long long owned = __ballot(own);
+        const size_t k0 = (size_t)(blockIdx.x * 256 + wv * 64);   // first factor of this wavefront
+        double* __restrict__ sj = s_j[wv];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            if (own) {
+#pragma unroll
+                for (int a = 0; a < 18; ++a) sj[lane * 19 + a] = J[18 * h + a];
+            }
+            __builtin_amdgcn_wave_barrier();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int i = 0; i < 18; ++i) {
+                const int e = i * 64 + lane, f = e / 18, a = e - 18 * f;
+                if ((owned >> f) & 1ull) Ji[(k0 + f) * 36 + 18 * h + a] = sj[f * 19 + a];
+            }
+            __builtin_amdgcn_wave_barrier();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
     }
     const double s = block_sum256(e2, s_w);
     if (threadIdx.x == 0) partial[blockIdx.x] = s;
