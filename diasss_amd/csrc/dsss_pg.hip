@@ -1759,11 +1759,12 @@ __global__ __launch_bounds__(256) void pg_factor_subtree_kernel(const int* __res
                                                                 const int* __restrict__ binroot_ptr, const int* __restrict__ binroot_idx,
                                                                 const int* __restrict__ broot_b, const long long* __restrict__ broot_uoff,
                                                                 const int* __restrict__ broot_of_col, const int* __restrict__ anc_first,
-                                                                const int* __restrict__ anc_rel, double* __restrict__ ubin)
+                                                                const int* __restrict__ anc_rel, double* __restrict__ ubin, double* __restrict__ rdiag)
 {
     __shared__ double s_Ljk[PG_TCH * 36];          // update staging; reused for the column's ancestor blocks (42 x 36)
     __shared__ double s_yk[PG_TCH * 6];
     __shared__ double s_diag[36];
+    __shared__ double s_ri[6];                     // 1 / L(j, j)[a][a]: the solves below multiply (a dependent f64 division is ~15 instructions)
     __shared__ double s_y[6];
     __shared__ int s_ok;
     for (int q = binroot_ptr[blockIdx.x]; q < binroot_ptr[blockIdx.x + 1]; ++q) {        // zero the update matrices of this bin's roots
@@ -1807,15 +1808,32 @@ __global__ __launch_bounds__(256) void pg_factor_subtree_kernel(const int* __res
         if (act && T > 0) for (int s = 0; s < 6; ++s) Lvals[(size_t)(c0 + q) * 36 + r * 6 + s] -= acc[s];
         __syncthreads();
         if (threadIdx.x == 0) {
-            double A[36];
+            // (round 4: in-kernel stamps put this one-thread section at 4 200 cycles per column, 28 % of the kernel -- a square root and
+            // 21 dependent divisions; one reciprocal square root per pivot and multiplications by it from here on)
+            double A[36], xj[6], ri[6];
+#pragma unroll
             for (int a = 0; a < 36; ++a) A[a] = Lvals[(size_t)c0 * 36 + a];
-            const int bad = chol6(A);
+#pragma unroll
+            for (int a = 0; a < 6; ++a) xj[a] = x[(size_t)j * 6 + a];
+            const int bad = chol6_fast(A, ri);
             if (bad) *fail = 1;
             s_ok = !bad;
-            for (int a = 0; a < 6; ++a) for (int b = 0; b < 6; ++b) { const double v = b <= a ? A[a * 6 + b] : 0.0; s_diag[a * 6 + b] = v; Lvals[(size_t)c0 * 36 + a * 6 + b] = v; }
+#pragma unroll
+            for (int a = 0; a < 6; ++a)
+#pragma unroll
+                for (int b = 0; b < 6; ++b) { const double v = b <= a ? A[a * 6 + b] : 0.0; s_diag[a * 6 + b] = v; Lvals[(size_t)c0 * 36 + a * 6 + b] = v; }
+#pragma unroll
+            for (int a = 0; a < 6; ++a) { s_ri[a] = ri[a]; rdiag[(size_t)j * 6 + a] = ri[a]; }
             if (!bad) {
                 double v[6];
-                for (int a = 0; a < 6; ++a) { double t = x[(size_t)j * 6 + a]; for (int b = 0; b < a; ++b) t -= A[a * 6 + b] * v[b]; v[a] = t / A[a * 6 + a]; }
+#pragma unroll
+                for (int a = 0; a < 6; ++a) {
+                    double t = xj[a];
+#pragma unroll
+                    for (int b = 0; b < 6; ++b) if (b < a) t -= A[a * 6 + b] * v[b];
+                    v[a] = t * ri[a];
+                }
+#pragma unroll
                 for (int a = 0; a < 6; ++a) { x[(size_t)j * 6 + a] = v[a]; s_y[a] = v[a]; }
             }
         }
@@ -1825,7 +1843,11 @@ __global__ __launch_bounds__(256) void pg_factor_subtree_kernel(const int* __res
         if (act && idx >= 6) {
             double* row = Lvals + (size_t)(c0 + q) * 36 + r * 6;
             double xr[6];
-            for (int s = 0; s < 6; ++s) { double v = row[s]; for (int c = 0; c < s; ++c) v -= xr[c] * s_diag[s * 6 + c]; xr[s] = v / s_diag[s * 6 + s]; }
+#pragma unroll
+            for (int s = 0; s < 6; ++s) { double v = row[s];
+#pragma unroll
+                                          for (int c = 0; c < 6; ++c) if (c < s) v -= xr[c] * s_diag[s * 6 + c];
+                                          xr[s] = v * s_ri[s]; }
             for (int s = 0; s < 6; ++s) row[s] = xr[s];
             if (q >= af) for (int s = 0; s < 6; ++s) s_Ljk[(q - af) * 36 + r * 6 + s] = xr[s];       // keep the ancestor rows for the update matrix
         }
@@ -1857,7 +1879,7 @@ __global__ __launch_bounds__(256) void pg_factor_subtree_kernel(const int* __res
 // backward substitution through a bin, columns in descending order, one wave per bin
 __global__ __launch_bounds__(64) void pg_bwd_subtree_kernel(const int* __restrict__ binptr, const int* __restrict__ bincols,
                                                             const int* __restrict__ colptr, const int* __restrict__ rowidx,
-                                                            const double* __restrict__ Lvals, double* __restrict__ x)
+                                                            const double* __restrict__ Lvals, double* __restrict__ x, const double* __restrict__ rdiag)
 {
     const int lane = threadIdx.x;
     for (int ci = binptr[blockIdx.x + 1] - 1; ci >= binptr[blockIdx.x]; --ci) {
@@ -1872,8 +1894,17 @@ __global__ __launch_bounds__(64) void pg_bwd_subtree_kernel(const int* __restric
             for (int o = 32; o >= 1; o >>= 1) acc[a] += __shfl_xor(acc[a], o, 64);
         if (lane == 0) {
             const double* Ld = Lvals + (size_t)colptr[j] * 36;
-            double v[6];
-            for (int a = 5; a >= 0; --a) { double s = x[(size_t)j * 6 + a] - acc[a]; for (int b = a + 1; b < 6; ++b) s -= Ld[b * 6 + a] * v[b]; v[a] = s / Ld[a * 6 + a]; }
+            double v[6], ld[36], xj[6], ri[6];
+#pragma unroll
+            for (int a = 0; a < 36; ++a) ld[a] = Ld[a];
+#pragma unroll
+            for (int a = 0; a < 6; ++a) { xj[a] = x[(size_t)j * 6 + a]; ri[a] = rdiag[(size_t)j * 6 + a]; }
+#pragma unroll
+            for (int a = 5; a >= 0; --a) { double s = xj[a] - acc[a];
+#pragma unroll
+                                           for (int b = 0; b < 6; ++b) if (b > a) s -= ld[b * 6 + a] * v[b];
+                                           v[a] = s * ri[a]; }
+#pragma unroll
             for (int a = 0; a < 6; ++a) x[(size_t)j * 6 + a] = v[a];
         }
         __threadfence_block();
@@ -2398,6 +2429,7 @@ static int pg_solve_impl(dsss_ctx* c, const double* dr6, int total, const dsss_l
     TRY(dv.alloc(c, &d_E1, (size_t)ns1 * 36)); TRY(dv.alloc(c, &d_Dl1, (size_t)ns1 * 36)); TRY(dv.alloc(c, &d_gi1, (size_t)ns1 * 6));
     TRY(dv.alloc(c, &d_s2DL, (size_t)std::max(nseg, 1) * 36)); TRY(dv.alloc(c, &d_s2DR, (size_t)std::max(nseg, 1) * 36)); TRY(dv.alloc(c, &d_s2GL, (size_t)std::max(nseg, 1) * 6));
     TRY(dv.alloc(c, &d_s2GR, (size_t)std::max(nseg, 1) * 6)); TRY(dv.alloc(c, &d_s2S, (size_t)std::max(nseg, 1) * 36));
+    double* d_rdiag; TRY(dv.alloc(c, &d_rdiag, (size_t)ns * 6));      // reciprocal diagonals of the binned columns' pivots (forward -> backward substitution)
     TRY(dv.alloc(c, &d_x, (size_t)ns * 6)); TRY(dv.alloc(c, &d_part, (size_t)nblk)); TRY(dv.alloc(c, &d_scal, 8)); TRY(dv.alloc(c, &d_fail, 1)); TRY(dv.alloc(c, &d_red, 8));
     hipStream_t st = c->stream;
 #define HCK(x) do { hipError_t _e = (x); if (_e != hipSuccess) { c->err = std::string(#x) + ": " + hipGetErrorString(_e); dv.release(); return DSSS_E_HIP; } } while (0)
@@ -2566,7 +2598,7 @@ static int pg_solve_impl(dsss_ctx* c, const double* dr6, int total, const dsss_l
         if (ne > 0) hipLaunchKernelGGL(pg_scatter_lc_kernel, dim3((unsigned)(((long long)ne * 36 + 255) / 256)), dim3(256), 0, st, n, ne, ns, d_Ji, d_ew, d_dest, d_L, d_aval, d_avalif, d_eo, mp0, mp1);
         if (nbins > 0) { dsss_scope s1(c, DSSS_K_PG_SUBTREE, bins_flops);      // flops of the binned columns
                          hipLaunchKernelGGL(pg_factor_subtree_kernel, dim3(nbins), dim3(256), 0, st, d_binptr + bin_lo, d_bincols, d_colptr, d_rlptr, d_rlcol, d_rlpos, d_mapptr, d_map, d_L, d_x, d_fail,
-                                            d_binroot_ptr + bin_lo, d_binroot_idx, d_broot_b, d_broot_uoff, d_broot_of_col, d_anc_first, d_anc_rel, d_ubin); }
+                                            d_binroot_ptr + bin_lo, d_binroot_idx, d_broot_b, d_broot_uoff, d_broot_of_col, d_anc_first, d_anc_rel, d_ubin, d_rdiag); }
     };
     const bool early_ok = !(getenv("DSSS_PG_EARLY") && atoi(getenv("DSSS_PG_EARLY")) == 0);      // A/B switch
     const bool early_bottom = early_ok && nparts == 1 && will_iterate && pre_chain;
@@ -2727,7 +2759,7 @@ static int pg_solve_impl(dsss_ctx* c, const double* dr6, int total, const dsss_l
                 }
                 run_levels_bwd(SO, DO);
                 if (nbins > 0) { dsss_scope s7(c, DSSS_K_PG_SUBTREE);
-                    hipLaunchKernelGGL(pg_bwd_subtree_kernel, dim3(nbins), dim3(64), 0, st, d_binptr + bin_lo, d_bincols, d_colptr, d_rowidx, d_L, d_x); }
+                    hipLaunchKernelGGL(pg_bwd_subtree_kernel, dim3(nbins), dim3(64), 0, st, d_binptr + bin_lo, d_bincols, d_colptr, d_rowidx, d_L, d_x, d_rdiag); }
                 hipLaunchKernelGGL(pg_sep_delta_kernel, dim3((ns + 255) / 256), dim3(256), 0, st, ns, d_t2, d_perm, d_x, d_delta1);
                 if (nseg > 0) hipLaunchKernelGGL(pg_backsub_kernel, dim3((nseg + 31) / 32), dim3(256), 0, st, nseg, d_ord2, d_t2, d_C1, d_E1, d_Dl1, d_gi1, d_delta1, kp0, kp1);
                 hipLaunchKernelGGL(pg_sep_delta_kernel, dim3((ns1 + 255) / 256), dim3(256), 0, st, ns1, d_sep1, (const int*)nullptr, d_delta1, d_delta);
