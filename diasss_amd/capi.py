@@ -299,6 +299,12 @@ class Context:
         self._chk(self.L.dsss_frame_bbox(self.h, fid, _ptr(bb)), "dsss_frame_bbox")
         return bb
 
+    def frame_geo(self, fid, N, M):
+        """Frame::geo_img in full (dsss_frame_get_geo): two N x M float64 arrays (x, y)"""
+        gx = np.empty((N, M), np.float64); gy = np.empty((N, M), np.float64)
+        self._chk(self.L.dsss_frame_get_geo(self.h, fid, _ptr(gx), _ptr(gy)), "dsss_frame_get_geo")
+        return gx, gy
+
     def overlap(self, a, b):
         v = C.c_float(0)
         self._chk(self.L.dsss_overlap(self.h, a, b, C.byref(v)), "dsss_overlap")

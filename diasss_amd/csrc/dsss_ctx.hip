@@ -507,6 +507,40 @@ int dsss_frame_bbox(dsss_ctx* c, int id, double* bbox)
     return DSSS_OK;
 }
 
+// Frame::geo_img in full (frame.cpp:126-165): the product never materialises it -- every consumer on the hot path takes its extremes
+// (dsss_frame_bbox) or samples it at keypoints (dsss_features_get) -- but the reference's field is the N x M pair of matrices, and a caller
+// that wants exactly that gets it here: one kernel over the pixels (the arithmetic of dsss_geo_at, what geo_bbox_kernel and kp_geo_kernel
+// evaluate), two N x M f64 downloads.  Off the hot path (32 MB per frame at 2000 x 1024).
+__global__ __launch_bounds__(256) void geo_image_kernel(const double* __restrict__ pose6, const double* __restrict__ gr, int N, int M,
+                                                        double* __restrict__ gx, double* __restrict__ gy)
+{
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (size_t)N * M) return;
+    const int row = (int)(i / M), col = (int)(i - (size_t)row * M);
+    double x, y;
+    dsss_geo_at(pose6, gr, M, row, col, &x, &y);
+    gx[i] = x; gy[i] = y;
+}
+int dsss_frame_get_geo(dsss_ctx* c, int id, double* x_host, double* y_host)
+{
+    if (!c || !x_host || !y_host) return DSSS_E_ARG;
+    if (id < 0 || id >= c->max_frames) DSSS_FAIL(c, DSSS_E_ARG, "frame id %d out of range", id);
+    dsss_frame& f = c->frames[id];
+    if (!f.has_geom) DSSS_FAIL(c, DSSS_E_STATE, "frame %d has no geometry", id);
+    HIPCHK(c, hipSetDevice(c->device));
+    const size_t n = (size_t)f.N * f.M;
+    double* d = nullptr;
+    HIPCHK(c, hipMalloc(&d, 2 * n * sizeof(double)));
+    hipLaunchKernelGGL(geo_image_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, f.pose6, f.gr, f.N, f.M, d, d + n);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipMemcpyAsync(x_host, d, n * sizeof(double), hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(y_host, d + n, n * sizeof(double), hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    hipFree(d);
+    HIPCHK(c, e);
+    return DSSS_OK;
+}
+
 // Util::ComputeIntersection (util.cpp:13-43): float arithmetic on the double extrema; host code because it is
 // 20 flops on values that already live on the host (the expensive part, the 4 minMaxLoc scans, is the bbox kernel)
 int dsss_overlap(dsss_ctx* c, int id_s, int id_t, float* iou)

@@ -45,6 +45,13 @@ void Frame::FetchImages()
     Device::check(dsss_frame_get_norm(Device::ctx(), img_id, norm_img.data(), flt_mask.data()), "dsss_frame_get_norm");
 }
 
+void Frame::FetchGeoImg()
+{
+    cv::Mat gx(raw_img.rows, raw_img.cols, CV_64F), gy(raw_img.rows, raw_img.cols, CV_64F);
+    Device::check(dsss_frame_get_geo(Device::ctx(), img_id, gx.ptr<double>(), gy.ptr<double>()), "dsss_frame_get_geo");
+    geo_img = { gx, gy };
+}
+
 cv::Mat Frame::GetNormalizeSSS(const cv::Mat &) { if (norm_img.empty()) FetchImages(); return norm_img; }
 cv::Mat Frame::GetFilteredMask(const cv::Mat &) { if (flt_mask.empty()) FetchImages(); return flt_mask; }
 

@@ -46,6 +46,8 @@ namespace Diasss
         cv::Mat est_poses;
 
         void FetchImages();            // norm_img + flt_mask from the device (2 x N*M bytes over PCIe, off the hot path)
+        void FetchGeoImg();            // geo_img as the reference holds it: the full N x M pair (frame.cpp:126-165), 16 N M bytes over PCIe;
+                                       // Util::ComputeIntersection gives the same overlap on either form (it takes the extremes)
     };
 
 }

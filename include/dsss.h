@@ -145,6 +145,9 @@ int dsss_features_set(dsss_ctx*, int id, int N, int M, const dsss_kp* kps, const
                       const double* geo, const double* bbox, int n);
 /* geo bounding box = the minMaxLoc pairs of FEAmatcher.cpp:71-72 / util.cpp:21-26: xmin,xmax,ymin,ymax */
 int dsss_frame_bbox(dsss_ctx*, int id, double* bbox_host);
+/* Frame::geo_img in full -- frame.cpp:126-165 GetGeoImg, the two N x M CV_64F matrices (x, then y; row-major) of frame.h:40.  The hot
+ * path never builds them (it uses dsss_frame_bbox and the geo samples of dsss_features_get); this is for callers that read the field. */
+int dsss_frame_get_geo(dsss_ctx*, int id, double* x_host, double* y_host);
 /* Util::ComputeIntersection (util.h:25, util.cpp:13-43) */
 int dsss_overlap(dsss_ctx*, int id_s, int id_t, float* iou_host);
 /* packed per-frame feature record for collectives (all-gather over RCCL): size and (de)serialisation */

@@ -161,6 +161,15 @@ def geo_bbox(pose6, gr, M):
     return bb
 
 
+def geo_img(pose6, gr, M):
+    """Frame::GetGeoImg (frame.cpp:126-165): the full N x M pair (x, y)"""
+    pose6 = np.ascontiguousarray(pose6, np.float64); gr = np.ascontiguousarray(gr, np.float64)
+    N = pose6.shape[0]
+    gx = np.empty((N, M), np.float64); gy = np.empty((N, M), np.float64)
+    lib().orc_geo_img(dp(pose6), dp(gr), N, M, dp(gx), dp(gy))
+    return gx, gy
+
+
 def geo_at_kps(pose6, gr, M, kps):
     """geo lookup at int(pt.y), int(pt.x) (FEAmatcher.cpp:81-82) -> (n,2) f64"""
     pose6 = np.ascontiguousarray(pose6, np.float64); gr = np.ascontiguousarray(gr, np.float64)

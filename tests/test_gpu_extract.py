@@ -153,3 +153,19 @@ def test_eager_extraction_started_by_frames_set_and_its_fallbacks(ctx, orc):
     finally:
         ctx.set_params(orb=ctx.default_params()[1])
     set_all(); assert ctx.extract(1) > 0; ctx.extract_many(ids); check()        # a single-frame extraction in between
+
+
+def test_full_geo_image_on_request(ctx, orc):
+    """Frame::geo_img as the reference holds it (frame.cpp:126-165: the N x M pair) through dsss_frame_get_geo -- the hot path only
+    ever uses its extremes (dsss_frame_bbox) and its samples at the keypoints; a caller that reads the field gets the full image,
+    bit for bit the oracle's, and Util::ComputeIntersection sees the same extremes on either form"""
+    from tests import helpers as H
+    for leg, (N, M) in enumerate(((700, 480), (333, 130))):
+        pose, alt, gr = H.track(N, M, leg, seed=9)
+        raw = np.random.default_rng(leg).rayleigh(1.0, (N, M)) * 100.0
+        ctx.frame_set(leg, raw, N, M, pose, alt, gr)
+        gx, gy = ctx.frame_geo(leg, N, M)
+        ox, oy = orc.geo_img(pose, gr, M)
+        assert (gx == ox).all() and (gy == oy).all()
+        bb = ctx.frame_bbox(leg)
+        assert bb[0] == gx.min() and bb[1] == gx.max() and bb[2] == gy.min() and bb[3] == gy.max()
