@@ -1751,7 +1751,7 @@ __device__ inline void pg_acc_rows(const int* __restrict__ mp, int m, int tn, co
             acc[s] += a0 * B[s * 6] + a1 * B[s * 6 + 1] + a2 * B[s * 6 + 2] + a3 * B[s * 6 + 3] + a4 * B[s * 6 + 4] + a5 * B[s * 6 + 5];
     }
 }
-__global__ __launch_bounds__(256) void pg_factor_subtree_kernel(const int* __restrict__ binptr, const int* __restrict__ bincols,
+__global__ __launch_bounds__(256) void pg_factor_subtree_kernel(const int* __restrict__ bin_perm, const int* __restrict__ binptr, const int* __restrict__ bincols,
                                                                 const int* __restrict__ colptr, const int* __restrict__ rlptr,
                                                                 const int* __restrict__ rlcol, const int* __restrict__ rlpos,
                                                                 const long long* __restrict__ mapptr, const int* __restrict__ upd_map,
@@ -1767,11 +1767,12 @@ __global__ __launch_bounds__(256) void pg_factor_subtree_kernel(const int* __res
     __shared__ double s_ri[6];                     // 1 / L(j, j)[a][a]: the solves below multiply (a dependent f64 division is ~15 instructions)
     __shared__ double s_y[6];
     __shared__ int s_ok;
-    for (int q = binroot_ptr[blockIdx.x]; q < binroot_ptr[blockIdx.x + 1]; ++q) {        // zero the update matrices of this bin's roots
+    const int bin = bin_perm[blockIdx.x];          // bins in descending order of work
+    for (int q = binroot_ptr[bin]; q < binroot_ptr[bin + 1]; ++q) {        // zero the update matrices of this bin's roots
         const int ri = binroot_idx[q]; const long long b6 = 6LL * broot_b[ri]; double* U = ubin + broot_uoff[ri];
         for (long long e = threadIdx.x; e < b6 * b6 + b6; e += 256) U[e] = 0.0;
     }
-    for (int ci = binptr[blockIdx.x]; ci < binptr[blockIdx.x + 1]; ++ci) {
+    for (int ci = binptr[bin]; ci < binptr[bin + 1]; ++ci) {
         const int j = bincols[ci];
         const int c0 = colptr[j], m = colptr[j + 1] - c0;
         const int t0 = rlptr[j], T = rlptr[j + 1] - t0;
@@ -1877,12 +1878,13 @@ __global__ __launch_bounds__(256) void pg_factor_subtree_kernel(const int* __res
     }
 }
 // backward substitution through a bin, columns in descending order, one wave per bin
-__global__ __launch_bounds__(64) void pg_bwd_subtree_kernel(const int* __restrict__ binptr, const int* __restrict__ bincols,
+__global__ __launch_bounds__(64) void pg_bwd_subtree_kernel(const int* __restrict__ bin_perm, const int* __restrict__ binptr, const int* __restrict__ bincols,
                                                             const int* __restrict__ colptr, const int* __restrict__ rowidx,
                                                             const double* __restrict__ Lvals, double* __restrict__ x, const double* __restrict__ rdiag)
 {
     const int lane = threadIdx.x;
-    for (int ci = binptr[blockIdx.x + 1] - 1; ci >= binptr[blockIdx.x]; --ci) {
+    const int bin = bin_perm[blockIdx.x];
+    for (int ci = binptr[bin + 1] - 1; ci >= binptr[bin]; --ci) {
         const int j = bincols[ci];
         double acc[6] = { 0, 0, 0, 0, 0, 0 };
         for (int p = colptr[j] + 1 + lane; p < colptr[j + 1]; p += 64) {
@@ -2312,7 +2314,7 @@ static int pg_solve_impl(dsss_ctx* c, const double* dr6, int total, const dsss_l
         for (int k = 0; k + 1 < ns; ++k) redges.push_back({ k, k + 1 });      // the reduced graph: the chain of the separators, then the loop closures
         for (int e = 0; e < ne; ++e) redges.push_back({ sidx(ea[e]), sidx(eb[e]) });
         const double bin_cost = getenv("DSSS_PG_BIN_COST") ? atof(getenv("DSSS_PG_BIN_COST")) : 600;   // ~ update-list iterations + 20 per column; measured optimum at C3 (500-700)
-        opt.bin_cost = bin_cost; pg_sym_opts_env(opt);
+        opt.bin_cost = bin_cost; opt.pack_cost = getenv("DSSS_PG_PACK_COST") ? atof(getenv("DSSS_PG_PACK_COST")) : 0; pg_sym_opts_env(opt);
         pg_symbolic(ns, redges, nseg, cx.data(), cy.data(), nparts > 1 ? sym_part.data() : nullptr, nparts, opt, S);
         // launch lists: this rank's interior fronts, then (after the all-reduce) the replicated interface fronts
         pg_build_schedule(S, part_lo, part_hi, SO);
@@ -2410,6 +2412,7 @@ static int pg_solve_impl(dsss_ctx* c, const double* dr6, int total, const dsss_l
     pose_t *d_X, *d_Xn, *d_meas, *d_emeas; int *d_ea, *d_eb, *d_eo, *d_adj_ptr, *d_adj_edge, *d_perm;
     double *d_ew, *d_r, *d_Ji, *d_D, *d_C, *d_g, *d_delta, *d_E, *d_Dl, *d_gi, *d_sDL, *d_sDR, *d_sGL, *d_sGR, *d_sS, *d_L, *d_x, *d_part, *d_scal;
     double *d_F, *d_R, *d_ubin, *d_aval;
+    int* d_binperm = nullptr;
     int *d_colptr, *d_rowidx, *d_rlptr, *d_rlcol, *d_rlpos, *d_rlrow, *d_binptr, *d_bincols, *d_dest, *d_fail, *d_map; long long* d_mapptr;
     int *d_binroot_ptr, *d_binroot_idx, *d_broot_b, *d_broot_of_col, *d_anc_first, *d_anc_rel, *d_rel, *d_fa_src, *d_fa_col, *d_fa_tr, *d_frows, *d_xr_ptr, *d_xr_child, *d_xr_row, *d_fa_rowptr;
     long long* d_broot_uoff; pg_front* d_FD; pg_child* d_CH;
@@ -2537,7 +2540,7 @@ static int pg_solve_impl(dsss_ctx* c, const double* dr6, int total, const dsss_l
         d_comm = d_aval + (size_t)nval * 36; d_avalif = d_comm; d_xif = d_comm + ncv * 36; d_commU = d_xif + nif * 6;
         ifslot.assign(ns, -1); for (size_t q = 0; q < nif; ++q) ifslot[S.iface_seps[q]] = (int)q;
         dv.later(&d_ifslot, ifslot); dv.later(&d_ifsep, S.iface_seps);
-        dv.later(&d_colptr, S.colptr); dv.later(&d_rowidx, S.rowidx); dv.later(&d_binptr, S.binptr); dv.later(&d_bincols, S.bincols);
+        dv.later(&d_colptr, S.colptr); dv.later(&d_rowidx, S.rowidx); dv.later(&d_binptr, S.binptr); dv.later(&d_bincols, S.bincols); dv.later(&d_binperm, S.bin_perm);
         dv.later(&d_dest, S.dest_bin);
         dv.later(&d_binroot_ptr, S.binroot_ptr); dv.later(&d_binroot_idx, S.binroot_idx); dv.later(&d_broot_b, S.broot_b); dv.later(&d_broot_uoff, S.broot_uoff);
         dv.later(&d_broot_of_col, S.broot_of_col);
@@ -2597,8 +2600,8 @@ static int pg_solve_impl(dsss_ctx* c, const double* dr6, int total, const dsss_l
                            d_ifslot, d_avalif, d_xif, kp0, kp1);
         if (ne > 0) hipLaunchKernelGGL(pg_scatter_lc_kernel, dim3((unsigned)(((long long)ne * 36 + 255) / 256)), dim3(256), 0, st, n, ne, ns, d_Ji, d_ew, d_dest, d_L, d_aval, d_avalif, d_eo, mp0, mp1);
         if (nbins > 0) { dsss_scope s1(c, DSSS_K_PG_SUBTREE, bins_flops);      // flops of the binned columns
-                         hipLaunchKernelGGL(pg_factor_subtree_kernel, dim3(nbins), dim3(256), 0, st, d_binptr + bin_lo, d_bincols, d_colptr, d_rlptr, d_rlcol, d_rlpos, d_mapptr, d_map, d_L, d_x, d_fail,
-                                            d_binroot_ptr + bin_lo, d_binroot_idx, d_broot_b, d_broot_uoff, d_broot_of_col, d_anc_first, d_anc_rel, d_ubin, d_rdiag); }
+                         hipLaunchKernelGGL(pg_factor_subtree_kernel, dim3(nbins), dim3(256), 0, st, d_binperm + bin_lo, d_binptr, d_bincols, d_colptr, d_rlptr, d_rlcol, d_rlpos, d_mapptr, d_map, d_L, d_x, d_fail,
+                                            d_binroot_ptr, d_binroot_idx, d_broot_b, d_broot_uoff, d_broot_of_col, d_anc_first, d_anc_rel, d_ubin, d_rdiag); }
     };
     const bool early_ok = !(getenv("DSSS_PG_EARLY") && atoi(getenv("DSSS_PG_EARLY")) == 0);      // A/B switch
     const bool early_bottom = early_ok && nparts == 1 && will_iterate && pre_chain;
@@ -2759,7 +2762,7 @@ static int pg_solve_impl(dsss_ctx* c, const double* dr6, int total, const dsss_l
                 }
                 run_levels_bwd(SO, DO);
                 if (nbins > 0) { dsss_scope s7(c, DSSS_K_PG_SUBTREE);
-                    hipLaunchKernelGGL(pg_bwd_subtree_kernel, dim3(nbins), dim3(64), 0, st, d_binptr + bin_lo, d_bincols, d_colptr, d_rowidx, d_L, d_x, d_rdiag); }
+                    hipLaunchKernelGGL(pg_bwd_subtree_kernel, dim3(nbins), dim3(64), 0, st, d_binperm + bin_lo, d_binptr, d_bincols, d_colptr, d_rowidx, d_L, d_x, d_rdiag); }
                 hipLaunchKernelGGL(pg_sep_delta_kernel, dim3((ns + 255) / 256), dim3(256), 0, st, ns, d_t2, d_perm, d_x, d_delta1);
                 if (nseg > 0) hipLaunchKernelGGL(pg_backsub_kernel, dim3((nseg + 31) / 32), dim3(256), 0, st, nseg, d_ord2, d_t2, d_C1, d_E1, d_Dl1, d_gi1, d_delta1, kp0, kp1);
                 hipLaunchKernelGGL(pg_sep_delta_kernel, dim3((ns1 + 255) / 256), dim3(256), 0, st, ns1, d_sep1, (const int*)nullptr, d_delta1, d_delta);

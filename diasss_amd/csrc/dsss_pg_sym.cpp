@@ -424,10 +424,20 @@ void pg_symbolic(int ns, const std::vector<std::pair<int, int>>& edges, int ncha
     std::vector<int> bin_of_root(ns, -1);
     auto bottom_tables = [&] {
         {   // greedy packing of whole subtrees into bins, subtrees taken in ascending root order, never across ranks
-            int nbins = 0; double fill = opt.bin_cost + 1; int cur_part = -2;
+            const double pack = opt.pack_cost > 0 ? opt.pack_cost : opt.bin_cost;
+            int nbins = 0; double fill = pack + 1; int cur_part = -2;
+            std::vector<double> bin_fill;
             for (int r : roots) {
-                if (fill + sub_cost[r] > opt.bin_cost || S.col_part[r] != cur_part) { ++nbins; fill = 0; cur_part = S.col_part[r]; S.bin_part.push_back(cur_part); }
-                fill += sub_cost[r]; bin_of_root[r] = nbins - 1;
+                if (fill + sub_cost[r] > pack || S.col_part[r] != cur_part) { ++nbins; fill = 0; cur_part = S.col_part[r]; S.bin_part.push_back(cur_part); bin_fill.push_back(0.0); }
+                fill += sub_cost[r]; bin_of_root[r] = nbins - 1; bin_fill.back() = fill;
+            }
+            // launch order: descending work inside every rank's (contiguous) range of bins; ties keep the bin order
+            S.bin_perm.resize(nbins);
+            for (int b = 0; b < nbins; ++b) S.bin_perm[b] = b;
+            for (int b0 = 0; b0 < nbins;) {
+                int b1 = b0; while (b1 < nbins && S.bin_part[b1] == S.bin_part[b0]) ++b1;
+                std::stable_sort(S.bin_perm.begin() + b0, S.bin_perm.begin() + b1, [&](int x, int y) { return bin_fill[x] > bin_fill[y]; });
+                b0 = b1;
             }
             S.binptr.assign(nbins + 1, 0);
             for (int j = 0; j < ns; ++j) if (sub_ok[j]) S.binptr[bin_of_root[root_of[j]] + 1]++;
@@ -901,6 +911,7 @@ extern "C" int dsss_host_pg_solve(int ns, const int32_t* edge_a, const int32_t* 
     }
     pg_sym S; pg_sym_opts opt;
     if (getenv("DSSS_PG_BIN_COST")) opt.bin_cost = atof(getenv("DSSS_PG_BIN_COST"));
+    if (getenv("DSSS_PG_PACK_COST")) opt.pack_cost = atof(getenv("DSSS_PG_PACK_COST"));
     if (getenv("DSSS_PG_LEAF")) opt.leaf = atoi(getenv("DSSS_PG_LEAF"));
     if (getenv("DSSS_PG_ND_BOTH")) opt.nd_both_axes = atoi(getenv("DSSS_PG_ND_BOTH"));
     pg_sym_opts_env(opt);

@@ -38,6 +38,8 @@ struct pg_sym {
     std::vector<char> binned;
     std::vector<int> binptr, bincols;   // columns of every bin, ascending
     std::vector<int> bin_part;          // rank of every bin
+    std::vector<int> bin_perm;          // launch order of the bins: within every rank's range by descending work (the kernel's time is its longest
+                                        // bin plus whatever starts late: long bins first, the short ones fill in behind them)
     std::vector<int> rlptr, rlcol, rlpos, rlrow;   // per target column: source columns k < j with L(j,k) != 0 and the position of that block (binned targets only)
     std::vector<long long> mapptr;      // update map offsets (binned targets only; see pg_build_map_kernel)
     std::vector<int> broot;             // subtree roots inside bins that have ancestors outside (they hand an update matrix up)
@@ -108,6 +110,7 @@ struct pg_sym_opts {
     int nd_both_axes = 64;              // node sets of at least this size try the median cut along both axes and keep the smaller separator
     bool nd_geo_first = true;           // a node set that spans several ranks may take a geometric cut when its separator is smaller than the rank cut's (its separator is interface then)
     double bin_cost = 1000;             // work bound of a binned subtree
+    double pack_cost = 0;               // work bound of a BIN (several subtrees packed together); 0 = bin_cost
     int threads = 4;
     // relaxed amalgamation of a front into its parent (columns adjacent): accepted when it adds at most relax_zero_blocks
     // zero blocks, or when the merged front costs at most relax_flops x the two separate ones (relax_flops_small while the
