@@ -1764,6 +1764,7 @@ __global__ __launch_bounds__(256) void pg_factor_subtree_kernel(const int* __res
     __shared__ double s_Ljk[PG_TCH * 36];          // update staging; reused for the column's ancestor blocks (42 x 36)
     __shared__ double s_yk[PG_TCH * 6];
     __shared__ double s_diag[36];
+    __shared__ int s_arel[48];                     // boundary indices of the column's ancestor rows (at most 42)
     __shared__ double s_ri[6];                     // 1 / L(j, j)[a][a]: the solves below multiply (a dependent f64 division is ~15 instructions)
     __shared__ double s_y[6];
     __shared__ int s_ok;
@@ -1858,19 +1859,25 @@ __global__ __launch_bounds__(256) void pg_factor_subtree_kernel(const int* __res
             const int b6 = 6 * broot_b[ri];
             double* __restrict__ U = ubin + broot_uoff[ri];
             double* __restrict__ g = U + (size_t)b6 * b6;
-            const int* __restrict__ arel = anc_rel + c0 + af;
+            // (round 4) the boundary indices of the column's ancestor rows go to LDS once, and the block pairs ib <= ia are ONE flat loop:
+            // per ancestor row the pass was a dependent index load, a load and a store of U in global memory, and the rows followed each
+            // other (in-kernel stamps: 3 200 cycles per column, a quarter of the kernel).  Every entry of U still receives one term per column.
+            if ((int)threadIdx.x < ta) s_arel[threadIdx.x] = anc_rel[c0 + af + threadIdx.x];
+            __syncthreads();
             if ((int)threadIdx.x < 6 * ta) {                            // right-hand side: g[ia] -= L_a y_j
                 const int pa = threadIdx.x / 6, a = threadIdx.x - pa * 6;
                 const double* La = s_Ljk + pa * 36 + a * 6;
-                g[arel[pa] * 6 + a] -= La[0] * s_y[0] + La[1] * s_y[1] + La[2] * s_y[2] + La[3] * s_y[3] + La[4] * s_y[4] + La[5] * s_y[5];
+                g[s_arel[pa] * 6 + a] -= La[0] * s_y[0] + La[1] * s_y[1] + La[2] * s_y[2] + La[3] * s_y[3] + La[4] * s_y[4] + La[5] * s_y[5];
             }
-            for (int pa = 0; pa < ta; ++pa) {                           // U[ia][ib] -= L_a L_b^T for the block pairs ib <= ia
-                const int ia = arel[pa];
-                for (int e = threadIdx.x; e < 36 * (pa + 1); e += 256) {
-                    const int pb = e / 36, ab = e - 36 * pb, a = ab / 6, b = ab - 6 * a;
-                    const double* La = s_Ljk + pa * 36 + a * 6; const double* Lb = s_Ljk + pb * 36 + b * 6;
-                    U[(size_t)(ia * 6 + a) * b6 + arel[pb] * 6 + b] -= La[0] * Lb[0] + La[1] * Lb[1] + La[2] * Lb[2] + La[3] * Lb[3] + La[4] * Lb[4] + La[5] * Lb[5];
-                }
+            const int npair = ta * (ta + 1) / 2;                        // U[ia][ib] -= L_a L_b^T for the block pairs ib <= ia
+            for (int e = threadIdx.x; e < 36 * npair; e += 256) {
+                const int pr = e / 36, ab = e - 36 * pr;
+                int pa = (int)((sqrtf(8.0f * (float)pr + 1.0f) - 1.0f) * 0.5f);      // pr = pa (pa + 1) / 2 + pb, pb <= pa
+                while (pa * (pa + 1) / 2 > pr) --pa;
+                while ((pa + 1) * (pa + 2) / 2 <= pr) ++pa;
+                const int pb = pr - pa * (pa + 1) / 2, a = ab / 6, b = ab - 6 * a;
+                const double* La = s_Ljk + pa * 36 + a * 6; const double* Lb = s_Ljk + pb * 36 + b * 6;
+                U[(size_t)(s_arel[pa] * 6 + a) * b6 + s_arel[pb] * 6 + b] -= La[0] * Lb[0] + La[1] * Lb[1] + La[2] * Lb[2] + La[3] * Lb[3] + La[4] * Lb[4] + La[5] * Lb[5];
             }
         }
         __syncthreads();
