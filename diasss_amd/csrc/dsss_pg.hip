@@ -66,6 +66,30 @@ __device__ inline int chol6_fast(double* A, double* ri)
     }
     return bad;
 }
+// the same with the reciprocal of a correctly rounded square root (one sqrt and one division per pivot): for the bins, whose 17 k columns
+// carry the whole dynamic range of the chain condensation -- with rsqrt here two elimination orders of the C3 graph end 1.6e-6 apart, with
+// this 3e-7 (test_config_C4_full_size_8_partitions_and_2_ranks)
+__device__ inline int chol6_recip(double* A, double* ri)
+{
+    int bad = 0;
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+        double d = A[j * 6 + j];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) if (k < j) d -= A[j * 6 + k] * A[j * 6 + k];
+        if (!(d > 0) || !isfinite(d)) { bad = 1; d = 1.0; }
+        const double sq = sqrt(d), r = 1.0 / sq;
+        A[j * 6 + j] = sq; ri[j] = r;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) if (i > j) {
+            double s = A[i * 6 + j];
+#pragma unroll
+            for (int k = 0; k < 6; ++k) if (k < j) s -= A[i * 6 + k] * A[j * 6 + k];
+            A[i * 6 + j] = s * r;
+        }
+    }
+    return bad;
+}
 // the same with 1 / L[j][j] left ON the diagonal (what the solves multiply by): no separate reciprocal array, twelve registers less
 __device__ inline int chol6_rdiag(double* A)
 {
@@ -1817,7 +1841,7 @@ __global__ __launch_bounds__(256) void pg_factor_subtree_kernel(const int* __res
             for (int a = 0; a < 36; ++a) A[a] = Lvals[(size_t)c0 * 36 + a];
 #pragma unroll
             for (int a = 0; a < 6; ++a) xj[a] = x[(size_t)j * 6 + a];
-            const int bad = chol6_fast(A, ri);
+            const int bad = chol6_recip(A, ri);
             if (bad) *fail = 1;
             s_ok = !bad;
 #pragma unroll
