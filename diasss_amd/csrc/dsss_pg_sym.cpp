@@ -175,11 +175,21 @@ int nd_order(std::vector<int>& nodes, const nd_ctx& C, std::vector<int>& order, 
         const bool byx = (x1 - x0) >= (y1 - y0);
         const size_t h2 = nodes.size() / 2;
         // split at the median of the (coordinate, index) total order; only the two halves matter, not their inner order
+        // (round 4: the selection runs on a contiguous array of (coordinate, index) pairs -- through the index array every comparison was two
+        // dependent loads into the coordinate table, and the top of the recursion, where one or two threads hold most of the nodes, is the
+        // serial part of the ordering.  The two halves are determined by the total order alone: same sets, same elimination order.)
         auto split = [&](std::vector<int>& nd, bool bx) {
             const double* key = bx ? C.cx : C.cy;
-            std::nth_element(nd.begin(), nd.begin() + h2, nd.end(), [&](int a, int b) {
-                const double ka = key[a], kb = key[b];
-                return ka != kb ? ka < kb : a < b; });
+            if (nd.size() < 96) {
+                std::nth_element(nd.begin(), nd.begin() + h2, nd.end(), [&](int a, int b) {
+                    const double ka = key[a], kb = key[b];
+                    return ka != kb ? ka < kb : a < b; });
+                return;
+            }
+            std::vector<std::pair<double, int>> kv(nd.size());
+            for (size_t i = 0; i < nd.size(); ++i) kv[i] = { key[nd[i]], nd[i] };
+            std::nth_element(kv.begin(), kv.begin() + h2, kv.end());       // pair order = (coordinate, index): the comparator above
+            for (size_t i = 0; i < nd.size(); ++i) nd[i] = kv[i].second;
         };
         if (!multi && total < C.both_axes) { split(nodes, byx); half = h2; }       // the only candidate: nothing to compare
         else if (total >= C.both_axes && total >= 4096 && depth <= PG_ND_PAR) {
