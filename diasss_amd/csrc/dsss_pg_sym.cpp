@@ -119,11 +119,13 @@ struct nd_ctx {
     const int* part; char* iface;                          // rank of every node (or null); iface[v] = 1 for rank-level separator nodes
     const char* forced;                                    // nodes with a neighbour of a HIGHER rank: they must end up in the interface (see nd_order)
     std::vector<nd_tree>* pool; std::mutex* mu;
+    std::atomic<long long>* tns;                           // phase timers (nd_timer) or null
 };
-static std::atomic<long long> g_nd_ns[8];          // DSSS_PG_VERBOSE: time per phase of nd_order over all calls (0 scan, 1 candidates, 2 final boundary, 3 tail, 4 leaf)
-static bool g_nd_time = false;
-struct nd_timer { int k; std::chrono::steady_clock::time_point t0; nd_timer(int k_) : k(k_) { if (g_nd_time) t0 = std::chrono::steady_clock::now(); }
-                  ~nd_timer() { if (g_nd_time) g_nd_ns[k] += std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count(); } };
+// DSSS_PG_VERBOSE: thread-time per phase of nd_order over all calls of ONE analysis (1 candidates, 2 final boundary, 4 leaves); the counters
+// belong to the analysis that asked for them (several solves may run at once)
+struct nd_timer { std::atomic<long long>* a; std::chrono::steady_clock::time_point t0;
+                  nd_timer(std::atomic<long long>* tns, int k) : a(tns ? tns + k : nullptr) { if (a) t0 = std::chrono::steady_clock::now(); }
+                  ~nd_timer() { if (a) *a += std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count(); } };
 int nd_order(std::vector<int>& nodes, const nd_ctx& C, std::vector<int>& order, int depth)
 {
     auto new_node = [&](int a, int b, int size) { std::lock_guard<std::mutex> g(*C.mu); C.pool->push_back({ a, b, size }); return (int)C.pool->size() - 1; };
@@ -133,7 +135,7 @@ int nd_order(std::vector<int>& nodes, const nd_ctx& C, std::vector<int>& order, 
     int pmin = 0, pmax = 0;
     if (C.part) { pmin = 1 << 30; pmax = -1; for (int v : nodes) { pmin = std::min(pmin, C.part[v]); pmax = std::max(pmax, C.part[v]); } }
     const bool multi = pmax > pmin;
-    if (!multi && total <= C.leaf) { nd_timer tm(4); std::sort(nodes.begin(), nodes.end()); for (int v : nodes) order.push_back(v); return depth <= PG_ND_PAR ? new_node(-1, -1, total) : -1; }
+    if (!multi && total <= C.leaf) { nd_timer tm(C.tns, 4); std::sort(nodes.begin(), nodes.end()); for (int v : nodes) order.push_back(v); return depth <= PG_ND_PAR ? new_node(-1, -1, total) : -1; }
     std::vector<int> A, B, S;
     // The separator of a split (sides are marked in C.side): a lower-half node with a neighbour in the upper half -- except that of a
     // cut edge between nodes of DIFFERENT ranks it is always the lower-rank end that goes into the separator.  The numeric phase relies
@@ -174,7 +176,7 @@ int nd_order(std::vector<int>& nodes, const nd_ctx& C, std::vector<int>& order, 
     }
     const bool geo = !multi || (C.geo_first && total > C.leaf);
     if (geo) {
-        nd_timer tm(1);
+        nd_timer tm(C.tns, 1);
         double x0 = 1e300, x1 = -1e300, y0 = 1e300, y1 = -1e300;
         for (int v : nodes) { x0 = std::min(x0, C.cx[v]); x1 = std::max(x1, C.cx[v]); y0 = std::min(y0, C.cy[v]); y1 = std::max(y1, C.cy[v]); }
         const bool byx = (x1 - x0) >= (y1 - y0);
@@ -218,7 +220,7 @@ int nd_order(std::vector<int>& nodes, const nd_ctx& C, std::vector<int>& order, 
             if (c < best) { best = c; nodes.swap(cand); half = h2; }
         }
     }
-    { nd_timer tm(2);
+    { nd_timer tm(C.tns, 2);
     boundary(nodes, half, &A, &S, &B);
     for (int v : nodes) C.side[v] = 0; }
     if (multi) {
@@ -356,10 +358,11 @@ void pg_symbolic(int ns, const std::vector<std::pair<int, int>>& edges, int ncha
         S.order.reserve(ns);
         std::vector<char> forced(ns, 0);
         if (S.nparts > 1 && part) for (int v = 0; v < ns; ++v) for (int q = adj_ptr[v]; q < adj_ptr[v + 1]; ++q) if (part[adj_idx[q]] > part[v]) { forced[v] = 1; break; }
-        nd_ctx C{ adj_ptr.data(), adj_idx.data(), cx, cy, side.data(), side2.data(), opt.leaf, opt.nd_both_axes, opt.nd_geo_first, S.nparts > 1 ? part : nullptr, iface.data(), forced.data(), &pool, &mu };
-        g_nd_time = tv; for (auto& a : g_nd_ns) a = 0;
+        std::atomic<long long> nd_ns[8];
+        for (auto& a : nd_ns) a = 0;
+        nd_ctx C{ adj_ptr.data(), adj_idx.data(), cx, cy, side.data(), side2.data(), opt.leaf, opt.nd_both_axes, opt.nd_geo_first, S.nparts > 1 ? part : nullptr, iface.data(), forced.data(), &pool, &mu, tv ? nd_ns : nullptr };
         root = nd_order(nodes, C, S.order, 0);
-        if (tv) fprintf(stderr, "[dsss pg symbolic] nd_order thread-time: candidates %.2f ms, final boundary %.2f ms, leaves %.2f ms\n", g_nd_ns[1] / 1e6, g_nd_ns[2] / 1e6, g_nd_ns[4] / 1e6);
+        if (tv) fprintf(stderr, "[dsss pg symbolic] nd_order thread-time: candidates %.2f ms, final boundary %.2f ms, leaves %.2f ms\n", nd_ns[1] / 1e6, nd_ns[2] / 1e6, nd_ns[4] / 1e6);
     }
     const auto q1 = tnow();
     S.perm.assign(ns, 0);
