@@ -183,3 +183,34 @@ def test_full_size_C3_properties():
     out2, st2 = pipe.run(raws, poses, alts, grs)                              # the whole path again: identical to the last bit
     assert (out2 == out1).all() and (np.array(st2) == st1).all()
     pipe.close()
+
+
+@pytest.mark.parametrize("kind", ["one_patch", "two_patches", "stripe", "sparse_dots"])
+def test_clustered_candidates_divide_below_the_sort_depth(ctx, orc, kind):
+    """FAST candidates confined to a small part of the frame: DistributeOctTree must divide far below the depth the device's
+    one-pass bucket histogram covers (4^D >= quota), so the quadtree falls back to its key arrays (ensure_keys: counting-sort
+    scatter on demand, streamed divisions, key-based choice of the kept point).  Features bit-exact against the oracle."""
+    N, M = 900, 640
+    rng = np.random.default_rng(17)
+    raw = np.full((N, M), 100.0)                      # texture inside [20, 180): below the hot-pixel threshold 2.5 x mean, so nothing of it is masked
+    tex = lambda h, w: rng.uniform(20.0, 180.0, (h, w))
+    if kind == "one_patch":
+        raw[400:520, 250:370] = tex(120, 120)
+    elif kind == "two_patches":
+        raw[200:290, 110:200] = tex(90, 90); raw[600:700, 420:530] = tex(100, 110)
+    elif kind == "stripe":
+        raw[430:450, 100:540] = tex(20, 440)
+    else:
+        for _ in range(60):
+            r, c = int(rng.integers(170, N - 170)), int(rng.integers(100, M - 100))
+            if abs(c - M // 2) < 15: continue
+            raw[r - 2:r + 3, c - 2:c + 3] = rng.uniform(150, 220)
+    pose, alt, gr = _inputs(N, M)
+    ctx.frame_set(0, raw, N, M, pose, alt, gr)
+    n = ctx.extract(0)
+    k, d, g = ctx.features_get(0)
+    ok, od, _, _ = orc.detect_feature(raw)
+    assert n == len(ok) and n > 10, (kind, n, len(ok))
+    for fld in ("x", "y", "angle", "response", "octave"):
+        assert (k[fld] == ok[fld]).all(), (kind, fld)
+    assert (d == od).all()
