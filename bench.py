@@ -426,13 +426,15 @@ GROUP_NOTE = {
     "extract": "SURVEY 8(d): 29.4 N M algorithmic bytes per frame (raw f64 twice, L0, pyramid r/w, FAST reads, blur r/w) over the summed time of the extraction kernels, against HBM",
     "pg_factor": "multifrontal factorisation + solves of the reduced pose-graph system, all kernels of one LM trial (bins, extend-add, panel Cholesky, row solve + trailing update -- fused per tile on most levels --, "
                  "back-substitution): algorithmic f64 flops of one factorisation over their summed time, against the f64 matrix peak.  Latency-bound: ~133 dependent short launches per trial",
-    "match": "SURVEY 8(d) K9: Na x Nb gate + Hamming evaluations of the active pairs against lanes x clock / 30 operations, lanes x clock = the measured issue rate",
+    "match": "SURVEY 8(d) K9: gate + Hamming evaluations against lanes x clock / 30 operations (lanes x clock = the measured issue rate).  `achieved` counts the evaluations the kernel PERFORMS "
+             "(counted on the device in the profiled pass): a geo grid of radius / 2 cells hands a query only the keypoints of the 5 x 5 cells around it -- the same set passes the same f64 gate -- which is "
+             "`evaluations_performed_of_reference` of the reference's Na x Nb per directed pair; `reference_evaluations_per_s_G` prices the stage in the reference's own count",
     "lc": "f64 VALU, 3e4 flop per LM iteration and match (SURVEY 8(d) K11)",
 }
 
 # profile slot -> kernel name in the rocprofv3 tables under profiles/
 SLOT_KERNEL = {"row_reduce": "row_reduce_kernel", "normalize": "normalize_kernel", "pyramid": "resize_kernel", "fast": "fast_cells_kernel",
-               "desc": "orient_desc_kernel", "quadtree": "quadtree_kernel", "lc": "lc_kernel", "match": "match_nn_kernel<false>",
+               "desc": "orient_desc_kernel", "quadtree": "quadtree_kernel", "lc": "lc_kernel", "match": "match_grid_kernel<false>",
                "pg_acc": "pg_front_syrk_kernel", "pg_diag": "pg_front_diag4_kernel", "pg_trsm": "pg_front_trsm2_kernel", "pg_bwd": "pg_front_bwd2_kernel",
                "pg_subtree": "pg_factor_subtree_kernel", "pg_asm": "pg_front_asm_kernel", "pg_rsu": "pg_front_rsu_kernel"}
 
@@ -579,6 +581,10 @@ def roofline(prof, workload, wl=None, trials=1):
     pmc_mfma_table = pmc_mfma(workload)
     F, N, M = (wl["F"], wl["N"], wl["M"]) if wl else (0, 0, 0)
     groups = {}
+    match_alg = None
+    if "match" in prof and prof.get("match_done", (0, 0, 0))[2] > 0:      # the matcher is priced by the gate evaluations it PERFORMS (its geo grid skips the cells
+        match_alg = prof["match"][2]                                       # out of a query's reach); the reference's Na x Nb per pair is reported beside it
+        prof = dict(prof); prof["match"] = (prof["match"][0], prof["match"][1], prof["match_done"][2])
     for g in GROUPS:
         units = max(trials, 1) if g == "pg_factor" else 1
         unit_work = 29.4 * N * M * F if g == "extract" else (prof["match"][2] if g == "match" and "match" in prof else None)
@@ -591,8 +597,13 @@ def roofline(prof, workload, wl=None, trials=1):
     cand = {k: v for k, v in prof.items() if k not in ("pg", "pg_comm") and v[1] > 0 and v[2] > 0}
     allr = {k: one_roofline(k, *cand[k], traffic, valu) for k in cand}
     keep = ("bound", "achieved", "peak", "unit", "frac", "avg_launch_us", "traffic", "traffic_calibrated", "hbm_GBs", "launches", "valu_issue_util", "ms_per_step",
-            "mfma_util_pct", "mfma_util_pct_by_kernel", "mfma_util_source")
+            "mfma_util_pct", "mfma_util_pct_by_kernel", "mfma_util_source", "evaluations_performed_of_reference", "reference_evaluations_per_s_G", "note")
     rnd = lambda d: {kk: (round(vv, 5) if isinstance(vv, float) else vv) for kk, vv in d.items() if kk in keep}
+    if match_alg:
+        for r in (groups.get("match"), allr.get("match")):
+            if r:
+                r["evaluations_performed_of_reference"] = prof["match"][2] / match_alg
+                r["reference_evaluations_per_s_G"] = match_alg / (r["avg_launch_us"] * 1e-6 * r["launches"]) / 1e9 if "ms_per_step" not in r else match_alg / (r["ms_per_step"] * 1e-3) / 1e9
     mu = pmc_mfma_table[0]
     for k, v in allr.items():
         if SLOT_KERNEL.get(k) in mu:

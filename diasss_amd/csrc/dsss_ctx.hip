@@ -98,6 +98,8 @@ static void free_match(dsss_ctx* c)
     c->row_cnt = c->kp7_cnt = c->row_off = c->kp7_off = nullptr;
     c->rows6 = c->kp7 = nullptr; c->kp7_pair = nullptr; c->kp7_flip = nullptr;
     c->match_cap_pairs = 0; c->rows_cap = 0;
+    hipFree(c->mt_gs_geo); hipFree(c->mt_gs_desc); hipFree(c->mt_gs_idx); hipFree(c->mt_cells);
+    c->mt_gs_geo = nullptr; c->mt_gs_desc = nullptr; c->mt_gs_idx = nullptr; c->mt_cells = nullptr; c->mt_gs_cap = 0; c->mt_cells_bytes = 0;
 }
 
 static void free_store(dsss_ctx* c)

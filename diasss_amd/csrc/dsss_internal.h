@@ -106,6 +106,9 @@ struct dsss_ctx {
     double* rows6 = nullptr; double* kp7 = nullptr; int* kp7_pair = nullptr; uint8_t* kp7_flip = nullptr;
     int total_rows = 0, total_kp7 = 0;
     size_t match_cap_pairs = 0, rows_cap = 0;
+    // geo grid of the matcher: keypoints of the active pairs' frames sorted by cell (geo, descriptor, original index), cell offsets + tables
+    double* mt_gs_geo = nullptr; uint8_t* mt_gs_desc = nullptr; int* mt_gs_idx = nullptr; size_t mt_gs_cap = 0;
+    void* mt_cells = nullptr; size_t mt_cells_bytes = 0; unsigned long long mt_evals_host = 0;
     // LC results
     dsss_lc* lcs = nullptr; size_t lcs_cap = 0; bool has_lc = false;
     // pose-graph scratch

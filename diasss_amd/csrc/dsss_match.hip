@@ -4,6 +4,7 @@
 // ConsistentCheck (:323-405) + RobustMatching rows (:35-45) + Optimizer::GetKpsPairs (optimizer.cpp:575-639)
 // as ordered block compactions.  Integer results are bit-exact against oracle/orc_match.c.
 #include "dsss_internal.h"
+#include <functional>
 
 #define MT_TILE 256          // threads per block = keypoints of A per block = B entries per LDS tile
 
@@ -95,6 +96,210 @@ __global__ __launch_bounds__(MT_TILE) void match_nn_kernel(
         }
     }
     out[a] = res;
+}
+
+// ------------------------------------------------------------------ K9 on a geo grid
+// (best, second, lowest index at the minimum, number of candidates) of FEAmatcher.cpp:86-161 do not depend on the order in which the
+// candidates inside the search circle are met, so only the keypoints that CAN be inside it are looked at: every frame of an active pair
+// gets its keypoints counting-sorted by the cell of a grid over its geo box whose cells are a hair wider than the radius (so that two
+// points closer than the radius lie in the same or in adjacent cells whatever the rounding of the cell arithmetic), and a query walks the
+// three rows of three cells around its own cell -- three contiguous ranges of the sorted arrays.  The gate itself is the SAME double
+// comparison as in the all-pairs kernel, on the same coordinates: the set that passes it is the same set.  At C3 a query meets ~25
+// candidates instead of 2 000.
+struct mt_grid { int W, H, off, pad; };            // cells per row, rows, first entry of the frame's (W H + 1) cell offsets
+
+__device__ inline int mt_cell(double v, double o, double inv_cs, int n)
+{
+    const int c = (int)((v - o) * inv_cs);           // monotone in v (saturating conversion; NaN -> 0), and so is the clamp
+    return min(max(c, 0), n - 1);
+}
+
+// one workgroup per frame: count per cell (global atomics), exclusive scan over the cells, scatter.  The order inside a cell is
+// whatever the atomics give; nothing downstream depends on it.
+#define MTG_THREADS 1024
+__global__ __launch_bounds__(MTG_THREADS) void mt_grid_build_kernel(
+    const int* __restrict__ frames, const mt_grid* __restrict__ tab, const int* __restrict__ nkp,
+    const uint8_t* __restrict__ desc, const double* __restrict__ geo, const double* __restrict__ bbox, int kcap, double inv_cs,
+    int* __restrict__ start_all, int* __restrict__ cur_all, double2* __restrict__ s_geo, uint4* __restrict__ s_desc, int* __restrict__ s_idx)
+{
+    __shared__ int s_w[MTG_THREADS / 64];
+    __shared__ int s_base;
+    const int f = frames[blockIdx.x];
+    const mt_grid T = tab[f];
+    const int n = nkp[f], cells = T.W * T.H;
+    int* __restrict__ start = start_all + T.off; int* __restrict__ cur = cur_all + T.off;
+    const double ox = bbox[f * 4 + 0], oy = bbox[f * 4 + 2];
+    const double2* __restrict__ g = reinterpret_cast<const double2*>(geo) + (size_t)f * kcap;
+    for (int i = threadIdx.x; i <= cells; i += MTG_THREADS) cur[i] = 0;
+    if (threadIdx.x == 0) s_base = 0;
+    __syncthreads();
+    for (int i = threadIdx.x; i < n; i += MTG_THREADS) {
+        const double2 p = g[i];
+        atomicAdd(&cur[mt_cell(p.y, oy, inv_cs, T.H) * T.W + mt_cell(p.x, ox, inv_cs, T.W)], 1);
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    for (int c0 = 0; c0 < cells; c0 += MTG_THREADS) {
+        const int i = c0 + threadIdx.x;
+        const int v = i < cells ? __hip_atomic_load(&cur[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;      // (counted by atomics at L2: not through this CU's vector cache)
+        int inc = v;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(inc, o, 64); if (lane >= o) inc += t; }
+        if (lane == 63) s_w[wv] = inc;
+        __syncthreads();
+        int base = s_base;
+        for (int k = 0; k < wv; ++k) base += s_w[k];
+        if (i < cells) { start[i] = base + inc - v; cur[i] = base + inc - v; }
+        __syncthreads();
+        if (threadIdx.x == MTG_THREADS - 1) s_base = base + inc;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) start[cells] = n;
+    const uint4* __restrict__ d = reinterpret_cast<const uint4*>(desc + (size_t)f * kcap * 32);
+    const size_t ob = (size_t)f * kcap;
+    for (int i = threadIdx.x; i < n; i += MTG_THREADS) {
+        const double2 p = g[i];
+        const int pos = atomicAdd(&cur[mt_cell(p.y, oy, inv_cs, T.H) * T.W + mt_cell(p.x, ox, inv_cs, T.W)], 1);
+        s_geo[ob + pos] = p; s_desc[2 * (ob + pos)] = d[2 * i]; s_desc[2 * (ob + pos) + 1] = d[2 * i + 1]; s_idx[ob + pos] = i;
+    }
+}
+
+// grid: (tiles of MT_TILE / MT_LPQ queries, 2 * active pairs).  MT_LPQ = 8 ADJACENT LANES PER QUERY: lane s of the eight takes the
+// candidates s, s + 8, ... of each of the three row ranges (eight neighbouring geo points are one 128-byte read), and the eight partial
+// results are folded by three butterfly steps -- the fold of two (best, second, lowest index, count) is as order-free as the update.  The
+// kernel's time is its longest chain of dependent cache round trips: keypoints come in clumps (one landmark at several pyramid levels),
+// and with one lane per query a clump of 200 in a cell is 600 round trips for its lanes while the rest of the chip has long finished
+// (323 us at C3 against 926 us for the all-pairs kernel; with eight lanes per query and cells of half the radius 162 us + 27 us for the sort).  Queries in THEIR OWN sorted order:
+// neighbouring groups are neighbours on the sea floor and walk the same cells.  No LDS, no barrier.
+#ifndef MT_LPQ
+#define MT_LPQ 8
+#endif
+#ifndef MT_SUB
+#define MT_SUB 2                 // cells per radius: a query walks (2 MT_SUB + 1)^2 cells, 25 cells of 4 m = 400 m^2 against 9 of 8 m = 576 m^2 (the circle: 201 m^2)
+#endif
+template <bool L2>
+__global__ __launch_bounds__(MT_TILE) void match_grid_kernel(
+    const int* __restrict__ act_s, const int* __restrict__ act_t, const int* __restrict__ nkp, const double* __restrict__ bbox,
+    const mt_grid* __restrict__ tab, const int* __restrict__ start_all, const double2* __restrict__ s_geo, const uint4* __restrict__ s_desc,
+    const int* __restrict__ s_idx, int kcap, double inv_cs, double gate_T, int bound_same, int bound_diff, double l2_bound, double ratio_max,
+    int32_t* __restrict__ corres_nn)
+{
+    const int pd = blockIdx.y, p = pd >> 1, dir = pd & 1;
+    const int fa = dir ? act_t[p] : act_s[p];
+    const int fb = dir ? act_s[p] : act_t[p];
+    const int na = nkp[fa];
+    const int t = blockIdx.x * (MT_TILE / MT_LPQ) + (threadIdx.x / MT_LPQ), sub = threadIdx.x & (MT_LPQ - 1);
+    if (t >= na) return;                                         // (whole groups of eight lanes leave together: the shuffles below stay inside a group)
+    const size_t sa = (size_t)fa * kcap + t;
+    const double2 ga = s_geo[sa];
+    const int a = s_idx[sa];
+    int32_t* out = corres_nn + (size_t)pd * kcap;
+    const double bx0 = bbox[fb * 4 + 0], bx1 = bbox[fb * 4 + 1], by0 = bbox[fb * 4 + 2], by1 = bbox[fb * 4 + 3];
+    const double ax = ga.x, ay = ga.y;
+    if (ax < bx0 || ay < by0 || ax > bx1 || ay > by1) { if (sub == 0) out[a] = -1; return; }      // FEAmatcher.cpp:84
+    const uint4 alo = s_desc[2 * sa], ahi = s_desc[2 * sa + 1];
+    const mt_grid T = tab[fb];
+    const int* __restrict__ start = start_all + T.off;
+    const int cx = mt_cell(ax, bx0, inv_cs, T.W), cy = mt_cell(ay, by0, inv_cs, T.H);
+    const int c0 = max(cx - MT_SUB, 0), c1 = min(cx + MT_SUB, T.W - 1);
+    int jb[2 * MT_SUB + 1], je[2 * MT_SUB + 1];                  // the rows' ranges, fetched together
+#pragma unroll
+    for (int r = 0; r < 2 * MT_SUB + 1; ++r) {
+        const int row = cy - MT_SUB + r;
+        const bool ok = row >= 0 && row < T.H;
+        jb[r] = ok ? start[row * T.W + c0] : 0; je[r] = ok ? start[row * T.W + c1 + 1] : 0;
+    }
+    const size_t sb = (size_t)fb * kcap;
+    int best = L2 ? 1000000 : 1000, second = best, best_id = -1, nc = 0;
+#pragma unroll
+    for (int r = 0; r < 2 * MT_SUB + 1; ++r)
+        for (int j = jb[r] + sub; j < je[r]; j += MT_LPQ) {
+            const double2 g = s_geo[sb + j];
+            const double dx = ax - g.x, dy = ay - g.y;
+            const double d2 = dx * dx + dy * dy;
+            if (d2 < gate_T) {                                   // sqrt(d2) < radius, FEAmatcher.cpp:92-93
+                const uint4 lo = s_desc[2 * (sb + j)], hi = s_desc[2 * (sb + j) + 1];
+                const int id = s_idx[sb + j];
+                int d;
+                if (!L2) {
+                    d = __popc(alo.x ^ lo.x) + __popc(alo.y ^ lo.y) + __popc(alo.z ^ lo.z) + __popc(alo.w ^ lo.w)
+                      + __popc(ahi.x ^ hi.x) + __popc(ahi.y ^ hi.y) + __popc(ahi.z ^ hi.z) + __popc(ahi.w ^ hi.w);
+                } else {
+                    const unsigned wa[8] = { alo.x, alo.y, alo.z, alo.w, ahi.x, ahi.y, ahi.z, ahi.w };
+                    const unsigned wb[8] = { lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w };
+                    d = 0;
+#pragma unroll
+                    for (int w = 0; w < 8; ++w)
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            const int e = (int)((wa[w] >> (8 * k)) & 255u) - (int)((wb[w] >> (8 * k)) & 255u);
+                            d += e * e;
+                        }
+                }
+                ++nc;
+                // the scalar loop's "first index wins" (FEAmatcher.cpp:152-161) without its order: the two smallest distances of the
+                // candidates (a tie at the minimum makes the second equal to it) and the lowest index at the minimum
+                if (d < best) { second = best; best = d; best_id = id; }
+                else if (d == best) { second = d; if (id < best_id) best_id = id; }
+                else if (d < second) second = d;
+            }
+        }
+    // fold the eight lanes of the query: the two smallest of the union, the lowest index among the minima, the counts added
+#pragma unroll
+    for (int o = 1; o < MT_LPQ; o <<= 1) {
+        const int ob = __shfl_xor(best, o, 64), os = __shfl_xor(second, o, 64), oi = __shfl_xor(best_id, o, 64), on = __shfl_xor(nc, o, 64);
+        if (ob < best) { second = min(best, os); best = ob; best_id = oi; }
+        else if (ob == best) { second = best; best_id = min(best_id, oi); }      // (both -1 when nothing beat the initial value)
+        else second = min(second, ob);
+        nc += on;
+    }
+    if (sub != 0) return;
+    int res = -1;
+    if (nc > 0) {
+        if (!L2) {
+            const int bound = ((fa % 2) != (fb % 2)) ? bound_diff : bound_same;
+            const double r = (double)best / (double)second;
+            if (best_id != -1 && best <= bound && r <= ratio_max && second != 1000) res = best_id;
+            else if (nc == 1 && best <= bound) res = best_id;
+        } else {
+            const double bd = sqrt((double)best), sd = sqrt((double)second);   // cv::norm(NORM_L2), FEAmatcher.cpp:113
+            const double r = bd / sd;
+            if (best_id != -1 && bd < l2_bound && r <= ratio_max) res = best_id;
+            else if (nc == 1 && bd < l2_bound) res = best_id;
+        }
+    }
+    out[a] = res;
+}
+
+// per-kernel profile only (outside the matcher's timed scope): the gate evaluations match_grid_kernel performs = the sizes of the row
+// ranges its live queries walk; bench.py prices the kernel by them
+__global__ __launch_bounds__(MT_TILE) void mt_grid_count_kernel(
+    const int* __restrict__ act_s, const int* __restrict__ act_t, const int* __restrict__ nkp, const double* __restrict__ bbox,
+    const mt_grid* __restrict__ tab, const int* __restrict__ start_all, const double2* __restrict__ s_geo, int kcap, double inv_cs,
+    unsigned long long* __restrict__ n_evals)
+{
+    __shared__ unsigned long long s_tot;
+    if (threadIdx.x == 0) s_tot = 0;
+    __syncthreads();
+    const int pd = blockIdx.y, p = pd >> 1, dir = pd & 1;
+    const int fa = dir ? act_t[p] : act_s[p];
+    const int fb = dir ? act_s[p] : act_t[p];
+    const int t = blockIdx.x * MT_TILE + threadIdx.x;
+    if (t < nkp[fa]) {
+        const double2 ga = s_geo[(size_t)fa * kcap + t];
+        const double bx0 = bbox[fb * 4 + 0], bx1 = bbox[fb * 4 + 1], by0 = bbox[fb * 4 + 2], by1 = bbox[fb * 4 + 3];
+        if (!(ga.x < bx0 || ga.y < by0 || ga.x > bx1 || ga.y > by1)) {
+            const mt_grid T = tab[fb];
+            const int* __restrict__ start = start_all + T.off;
+            const int cx = mt_cell(ga.x, bx0, inv_cs, T.W), cy = mt_cell(ga.y, by0, inv_cs, T.H);
+            const int c0 = max(cx - MT_SUB, 0), c1 = min(cx + MT_SUB, T.W - 1);
+            int tot = 0;
+            for (int row = max(cy - MT_SUB, 0); row <= min(cy + MT_SUB, T.H - 1); ++row) tot += start[row * T.W + c1 + 1] - start[row * T.W + c0];
+            atomicAdd(&s_tot, (unsigned long long)tot);
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0 && s_tot) atomicAdd(n_evals, s_tot);
 }
 
 // ------------------------------------------------------------------ block scan helper (256 threads = 4 waves)
@@ -323,6 +528,8 @@ __global__ void hamming_one_kernel(const uint8_t* a, const uint8_t* b, int* out)
     *out = d;
 }
 
+#define DSSS_FREE0(p) do { hipFree(p); (p) = nullptr; } while (0)
+
 // threshold T with sqrt(d) < radius  <=>  d < T for correctly rounded sqrt
 static double gate_threshold(double radius)
 {
@@ -362,7 +569,6 @@ int dsss_match_pairs(dsss_ctx* c, const int* src_ids, const int* tgt_ids, int np
         // free + null first and publish the new capacity only after every allocation succeeded, so that a failed
         // hipMalloc leaves the context consistent (capacity 0, null pointers: the next call starts over, dsss_destroy is safe)
         c->match_cap_pairs = 0;
-#define DSSS_FREE0(p) do { hipFree(p); (p) = nullptr; } while (0)
         DSSS_FREE0(c->act_s); DSSS_FREE0(c->act_t); DSSS_FREE0(c->corres_nn); DSSS_FREE0(c->corres);
         DSSS_FREE0(c->scc_hist); DSSS_FREE0(c->scc_count); DSSS_FREE0(c->scc_model);
         DSSS_FREE0(c->row_cnt); DSSS_FREE0(c->kp7_cnt); DSSS_FREE0(c->row_off); DSSS_FREE0(c->kp7_off);
@@ -399,11 +605,81 @@ int dsss_match_pairs(dsss_ctx* c, const int* src_ids, const int* tgt_ids, int np
     for (int f = 0; f < F; ++f) if (c->frames[f].has_feat) max_nkp = std::max(max_nkp, c->frames[f].nkp);
     const dim3 grid((max_nkp + MT_TILE - 1) / MT_TILE, 2 * na);
     const double T = gate_threshold(c->mt.radius);
-    {
+    // geo grid over the frames of the active pairs (match_grid_kernel); the all-pairs kernel stays for a degenerate geometry (a
+    // non-finite box or radius, or a box of more than 2^22 cells) and as the A/B switch DSSS_MT_GRID=0
+    bool evals_pending = false;
+    std::function<hipError_t()> gcount;                // (profile on) counts the grid's evaluations, launched after the matcher's scope has closed
+    bool use_grid = !(getenv("DSSS_MT_GRID") && atoi(getenv("DSSS_MT_GRID")) == 0) && std::isfinite(c->mt.radius) && c->mt.radius > 0;
+    const double cs = c->mt.radius / MT_SUB * (1.0 + 1.0 / 1048576.0), inv_cs = 1.0 / cs;      // the hair: 1e-6 of a cell against 1e-13 of rounding
+    std::vector<mt_grid> gtab; std::vector<int> gframes; size_t gcells = 0;
+    if (use_grid) {
+        gtab.assign(F, mt_grid{ 0, 0, 0, 0 });
+        std::vector<char> seen(F, 0);
+        for (int a2 = 0; a2 < na && use_grid; ++a2)
+            for (int f : { as[a2], at[a2] }) {
+                if (seen[f]) continue;
+                seen[f] = 1;
+                const double* b = c->frames[f].bbox;
+                const double w = (b[1] - b[0]) * inv_cs, h = (b[3] - b[2]) * inv_cs;
+                if (!(std::isfinite(b[0]) && std::isfinite(b[2]) && w >= 0 && h >= 0 && (w + 1) * (h + 1) < 4194304.0)) { use_grid = false; break; }
+                mt_grid& g = gtab[f];
+                g.W = (int)w + 1; g.H = (int)h + 1; g.off = (int)gcells;
+                gcells += (size_t)g.W * g.H + 1;
+                gframes.push_back(f);
+            }
+        if (gcells >= (size_t)1 << 30) use_grid = false;
+    }
+    if (use_grid) {
+        if (c->mt_gs_cap != (size_t)F * K) {
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+            c->mt_gs_cap = 0;
+            DSSS_FREE0(c->mt_gs_geo); DSSS_FREE0(c->mt_gs_desc); DSSS_FREE0(c->mt_gs_idx);
+            HIPCHK(c, hipMalloc(&c->mt_gs_geo, (size_t)F * K * 2 * sizeof(double)));
+            HIPCHK(c, hipMalloc(&c->mt_gs_desc, (size_t)F * K * 32));
+            HIPCHK(c, hipMalloc(&c->mt_gs_idx, (size_t)F * K * sizeof(int)));
+            c->mt_gs_cap = (size_t)F * K;
+        }
+        const size_t need = 2 * gcells * sizeof(int) + (size_t)F * sizeof(mt_grid) + (size_t)F * sizeof(int) + 16;
+        if (c->mt_cells_bytes < need) {
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+            c->mt_cells_bytes = 0;
+            DSSS_FREE0(c->mt_cells);
+            HIPCHK(c, hipMalloc(&c->mt_cells, need + need / 4));
+            c->mt_cells_bytes = need + need / 4;
+        }
+        char* base = (char*)c->mt_cells;
+        mt_grid* d_tab = (mt_grid*)base;                                          // [F] (16-byte entries first: alignment)
+        int* d_frames = (int*)(base + (size_t)F * sizeof(mt_grid));               // [frames of the active pairs]
+        int* d_start = d_frames + F; int* d_cur = d_start + gcells;
+        unsigned long long* d_evals = c->prof.on ? (unsigned long long*)(((uintptr_t)(d_cur + gcells) + 7) & ~(uintptr_t)7) : nullptr;
+        if (d_evals) HIPCHK(c, hipMemsetAsync(d_evals, 0, sizeof(unsigned long long), c->stream));
+        HIPCHK(c, hipMemcpyAsync(d_tab, gtab.data(), (size_t)F * sizeof(mt_grid), hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipMemcpyAsync(d_frames, gframes.data(), gframes.size() * sizeof(int), hipMemcpyHostToDevice, c->stream));
+        double evals = 0;
+        for (int a2 = 0; a2 < na; ++a2) evals += 2.0 * c->frames[as[a2]].nkp * c->frames[at[a2]].nkp;
+        dsss_scope sc(c, DSSS_K_MATCH, evals, 2);
+        const dim3 ggrid((max_nkp + MT_TILE / MT_LPQ - 1) / (MT_TILE / MT_LPQ), 2 * na);
+        hipLaunchKernelGGL(mt_grid_build_kernel, dim3((unsigned)gframes.size()), dim3(MTG_THREADS), 0, c->stream, d_frames, d_tab, c->nkp_dev, c->desc, c->geo,
+                           c->bbox_dev, (int)K, inv_cs, d_start, d_cur, (double2*)c->mt_gs_geo, (uint4*)c->mt_gs_desc, c->mt_gs_idx);
+        if (c->mt.use_l2)
+            hipLaunchKernelGGL(match_grid_kernel<true>, ggrid, dim3(MT_TILE), 0, c->stream, c->act_s, c->act_t, c->nkp_dev, c->bbox_dev, d_tab, d_start,
+                               (const double2*)c->mt_gs_geo, (const uint4*)c->mt_gs_desc, c->mt_gs_idx, (int)K, inv_cs, T, c->mt.bound_same, c->mt.bound_diff,
+                               c->mt.l2_bound, c->mt.ratio, c->corres_nn);
+        else
+            hipLaunchKernelGGL(match_grid_kernel<false>, ggrid, dim3(MT_TILE), 0, c->stream, c->act_s, c->act_t, c->nkp_dev, c->bbox_dev, d_tab, d_start,
+                               (const double2*)c->mt_gs_geo, (const uint4*)c->mt_gs_desc, c->mt_gs_idx, (int)K, inv_cs, T, c->mt.bound_same, c->mt.bound_diff,
+                               c->mt.l2_bound, c->mt.ratio, c->corres_nn);
+        HIPCHK(c, hipGetLastError());
+        evals_pending = d_evals != nullptr;
+        if (d_evals) { gcount = [=]() {
+            hipLaunchKernelGGL(mt_grid_count_kernel, grid, dim3(MT_TILE), 0, c->stream, c->act_s, c->act_t, c->nkp_dev, c->bbox_dev, d_tab, d_start, (const double2*)c->mt_gs_geo, (int)K, inv_cs, d_evals);
+            return hipMemcpyAsync(&c->mt_evals_host, d_evals, sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream); }; }
+    } else {
         // algorithmic work of the matcher: gate + Hamming evaluations = sum over the directed active pairs of Na x Nb
         double evals = 0;
         for (int a2 = 0; a2 < na; ++a2) evals += 2.0 * c->frames[as[a2]].nkp * c->frames[at[a2]].nkp;
         dsss_scope sc(c, DSSS_K_MATCH, evals);
+        if (c->prof.on) c->prof.work[DSSS_K_MATCH_DONE] += evals;      // the all-pairs kernel performs every evaluation it is credited with
         if (c->mt.use_l2)
             hipLaunchKernelGGL(match_nn_kernel<true>, grid, dim3(MT_TILE), 0, c->stream, c->act_s, c->act_t, c->nkp_dev, c->desc, c->geo,
                                c->bbox_dev, (int)K, T, c->mt.bound_same, c->mt.bound_diff, c->mt.l2_bound, c->mt.ratio, c->corres_nn);
@@ -412,6 +688,7 @@ int dsss_match_pairs(dsss_ctx* c, const int* src_ids, const int* tgt_ids, int np
                                c->bbox_dev, (int)K, T, c->mt.bound_same, c->mt.bound_diff, c->mt.l2_bound, c->mt.ratio, c->corres_nn);
         HIPCHK(c, hipGetLastError());
     }
+    if (gcount) HIPCHK(c, gcount());
     {
         dsss_scope sc(c, DSSS_K_SCC);
         const size_t sh = K * 8 + (size_t)iters * 4;
@@ -432,6 +709,7 @@ int dsss_match_pairs(dsss_ctx* c, const int* src_ids, const int* tgt_ids, int np
     HIPCHK(c, hipMemcpyAsync(c->h_row_off.data(), c->row_off, (na + 1) * sizeof(int), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipMemcpyAsync(c->h_kp7_off.data(), c->kp7_off, (na + 1) * sizeof(int), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (evals_pending) c->prof.work[DSSS_K_MATCH_DONE] += (double)c->mt_evals_host;
     c->total_rows = c->h_row_off[na]; c->total_kp7 = c->h_kp7_off[na];
     if ((size_t)c->total_rows > c->rows_cap) {
         const size_t want = (size_t)c->total_rows + 1024;

@@ -226,7 +226,7 @@ int dsss_host_pg_solve(int ns, const int32_t* edge_a, const int32_t* edge_b, int
 #define DSSS_K_FAST_COMPACT 5   /* scan + gather of candidates */
 #define DSSS_K_DESC         6   /* orient_desc_kernel */
 #define DSSS_K_FILTER       7   /* mask_filter_kernel */
-#define DSSS_K_MATCH        8   /* match_nn_kernel */
+#define DSSS_K_MATCH        8   /* mt_grid_build_kernel + match_grid_kernel (or match_nn_kernel, all pairs) */
 #define DSSS_K_SCC          9   /* scc_kernel */
 #define DSSS_K_ROWS        10   /* pair_rows count/scan/write */
 #define DSSS_K_LC          11   /* lc_kernel */
@@ -240,7 +240,8 @@ int dsss_host_pg_solve(int ns, const int32_t* edge_a, const int32_t* edge_b, int
 #define DSSS_K_PG_ASM      19   /* pg_front_asm_kernel (extend-add) */
 #define DSSS_K_PG_COMM     20   /* the reduced-Hessian all-reduce of a trial (work = bytes) */
 #define DSSS_K_PG_RSU      21   /* pg_front_rsu_kernel: row solve + trailing update fused per tile (the levels with few tiles) */
-#define DSSS_K_COUNT       22
+#define DSSS_K_MATCH_DONE 22   /* no kernel of its own: work = the gate evaluations the matcher actually performed (its geo grid skips the cells out of reach; DSSS_K_MATCH's work is the reference's Na x Nb) */
+#define DSSS_K_COUNT       23
 int dsss_profile_enable(dsss_ctx*, int on);
 int dsss_profile_get(dsss_ctx*, double* ms_host /*DSSS_K_COUNT*/, int64_t* launches_host /*DSSS_K_COUNT*/);
 int dsss_profile_reset(dsss_ctx*);

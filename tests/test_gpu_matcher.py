@@ -167,3 +167,57 @@ def test_matcher_on_extracted_features(ctx, orc):
     ctx.match_pairs(src, tgt)
     n = [_check_pair(ctx, orc, p, i, j, fr) for p, (i, j) in enumerate(zip(src, tgt))]
     assert n[0] > 10 and n[2] > 10
+
+
+@pytest.mark.parametrize("kind", ["lattice", "cluster", "cell_edges"])
+@pytest.mark.parametrize("grid", ["1", "0"])
+def test_matcher_geo_grid_corner_cases(ctx, orc, kind, grid, monkeypatch):
+    """the geo grid of the matcher (and the all-pairs kernel, DSSS_MT_GRID=0) on geometry chosen against it: neighbours at exactly the
+    radius (excluded: strict <) and one ulp inside it, diagonal neighbours either side of it, every keypoint in ONE cell, points on the
+    cell borders and on the far edges of the box; few distinct descriptors, so that the minimum is tied all the time (lowest index wins,
+    second = best).  Explicit geo points and boxes through dsss_features_set."""
+    from tests import helpers as H
+    monkeypatch.setenv("DSSS_MT_GRID", grid)
+    N, M = 700, 480
+    rng = np.random.default_rng({"lattice": 1, "cluster": 2, "cell_edges": 3}[kind])
+    bb = np.array([-20.0, 100.0, 5.0, 65.0])                    # x0 x1 y0 y1
+    r = 8.0
+    if kind == "lattice":
+        gx, gy = np.meshgrid(bb[0] + 4 + r * np.arange(14), bb[2] + 4 + r * np.arange(7))
+        B = np.stack([gx.ravel(), gy.ravel()], 1)
+        d = 5.65685424949238                                     # 8 / sqrt 2: the diagonal neighbour lies at the radius to within rounding
+        offs = np.array([[0, 0], [r, 0], [np.nextafter(r, 0), 0], [0, -r], [0, np.nextafter(r, 0)], [d, d], [np.nextafter(d, 0), np.nextafter(d, 0)],
+                         [np.nextafter(d, 9), np.nextafter(d, 9)], [-d, d], [7.9, 1.2], [1.3, -7.95]])
+        A = (B[:, None, :] + offs[None, :, :]).reshape(-1, 2)
+    elif kind == "cluster":
+        B = np.array([30.0, 40.0]) + rng.uniform(-1e-3, 1e-3, (2000, 2))
+        A = np.concatenate([np.array([30.0, 40.0]) + rng.uniform(-1e-3, 1e-3, (200, 2)), np.array([30.0, 40.0]) + rng.uniform(-9, 9, (300, 2))])
+    else:
+        cs = r / 2 * (1.0 + 1.0 / 1048576.0)                     # the grid's cell (dsss_match.hip: MT_SUB = 2 cells per radius)
+        edges_x = bb[0] + cs * np.arange(1, 27); edges_y = bb[2] + cs * np.arange(1, 13)
+        bx = np.concatenate([edges_x, np.nextafter(edges_x, -1e9), [bb[0], bb[1], bb[1]]])
+        by = np.concatenate([edges_y, np.nextafter(edges_y, 1e9), [bb[2], bb[3]]])
+        gx, gy = np.meshgrid(bx, by)
+        B = np.stack([gx.ravel(), gy.ravel()], 1)
+        offs = np.array([[0, 0], [np.nextafter(r, 0), 0], [-np.nextafter(r, 0), 0], [0, np.nextafter(r, 0)], [0, -np.nextafter(r, 0)], [r, 0], [-r, 0], [3, 3]])
+        A = (B[::6, None, :] + offs[None, :, :]).reshape(-1, 2)
+    A = A[(A[:, 0] >= bb[0] - 3) & (A[:, 0] <= bb[1] + 3) & (A[:, 1] >= bb[2] - 3) & (A[:, 1] <= bb[3] + 3)]       # a few just outside the box: skipped (FEAmatcher.cpp:84)
+    assert len(A) <= 2000 and len(B) <= 2000
+    palette = rng.integers(0, 256, (4, 32), dtype=np.uint8)
+    fr = {}
+    for f, G in ((0, A), (2, B)):
+        n = len(G)
+        pose, alt, gr = H.track(N, M, 0, seed=3)
+        kps, _ = H.random_features(N, M, n, 7 + f)
+        desc = palette[rng.integers(0, 4, n)].copy()
+        flip = rng.integers(0, 3, n)                              # 0, 1 or 2 flipped bits: distances 0 .. 4 inside a palette entry
+        for i in range(n):
+            for b in rng.choice(256, flip[i], replace=False):
+                desc[i, b // 8] ^= np.uint8(1 << (b % 8))
+        ctx.frame_set(f, None, N, M, pose, alt, gr)
+        ctx.features_set(f, N, M, kps, desc, geo=G, bbox=bb)
+        fr[f] = dict(N=N, M=M, pose=pose, alt=alt, gr=gr, kps=kps, desc=desc, geo=np.ascontiguousarray(G), bb=bb)
+    ctx.match_pairs([0], [2])
+    _check_pair(ctx, orc, 0, 0, 2, fr)
+    nn = ctx.match_dir(0, 0)[0][:len(A)]
+    assert (nn >= 0).sum() > 10

@@ -79,3 +79,32 @@ def test_extraction_switches_reproduce_the_default():
             assert run(dev) == href, "%s=%s changes the features (device-resident frames)" % (k, v)
             assert run(host) == href, "%s=%s changes the features (host-resident frames)" % (k, v)
     torch.cuda.synchronize()
+
+
+def test_matcher_switch_reproduces_the_default():
+    """DSSS_MT_GRID=0 (the all-pairs gate + Hamming kernel) against the geo grid: first-stage and final CorresID, rows and kp7 of every
+    pair of a small survey, bit for bit"""
+    from diasss_amd import capi
+    from diasss_amd.synth import Survey
+    F, N, M = 6, 900, 512
+    sv = Survey(F, N, M, seed=77, device="cuda:0")
+    c = capi.Context(max_frames=F)
+    ins = [sv.inputs(f) for f in range(F)]
+    c.frames_set(list(range(F)), [sv.frame(f) for f in range(F)], [N] * F, [M] * F, [i[0] for i in ins], [i[1] for i in ins], [i[2] for i in ins])
+    c.extract_many(list(range(F)))
+    src = [i for i in range(F) for j in range(i + 1, F)]; tgt = [j for i in range(F) for j in range(i + 1, F)]
+
+    def run():
+        c.match_pairs(src, tgt)
+        h = hashlib.sha1(); rows = 0
+        for p in range(len(src)):
+            for d in (0, 1):
+                nn, co, hist, cnt, model = c.match_dir(p, d)
+                h.update(nn.tobytes()); h.update(co.tobytes()); h.update(np.array([hist, cnt], np.int64).tobytes()); h.update(np.float64(model).tobytes())
+            r = c.match_rows(p); h.update(r.tobytes()); h.update(c.match_kp7(p).tobytes()); rows += len(r)
+        return h.hexdigest(), rows
+    href, rows = run()
+    assert rows > 50
+    with _env("DSSS_MT_GRID", "0"):
+        assert run() == (href, rows)
+    c.close()
