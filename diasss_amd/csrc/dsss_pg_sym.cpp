@@ -198,26 +198,92 @@ int nd_order(std::vector<int>& nodes, const nd_ctx& C, std::vector<int>& order, 
             std::nth_element(kv.begin(), kv.begin() + h2, kv.end());       // pair order = (coordinate, index): the comparator above
             for (size_t i = 0; i < nd.size(); ++i) nd[i] = kv[i].second;
         };
+        // A CANDIDATE is only counted, not carried out: the element of rank h2 of the (coordinate, index) order is found through a
+        // histogram of the coordinates (one pass over a contiguous copy of the keys, then a selection inside ONE bucket), the halves are
+        // marked by comparing with it, and the separator is counted from the marks -- three light passes instead of a selection that moves
+        // 16-byte pairs about.  Only the winner is partitioned.  Same halves (they are determined by the total order), same counts.
+        struct cut_cand { bool bx; double pk; int pi; size_t cnt; };
+        std::vector<double> keys;                                          // (one candidate at a time per call; the second one of a large set brings its own)
+        auto less_than = [](double k, int v, double pk, int pi) { return k != pk ? k < pk : v < pi; };
+        auto count_cut = [&](const std::vector<int>& nd, bool bx, double lo, double hi, std::vector<double>& kx, char* sd) {
+            const double* key = bx ? C.cx : C.cy;
+            const size_t m = nd.size();
+            kx.resize(m);
+            for (size_t i = 0; i < m; ++i) kx[i] = key[nd[i]];
+            cut_cand cc{ bx, 0.0, 0, 0 };
+            constexpr int NB = 1024;
+            if (hi > lo && std::isfinite(hi - lo)) {
+                const double scale = NB / (hi - lo);
+                auto bucket = [&](double k) { const int b = (int)((k - lo) * scale); return b < 0 ? 0 : (b >= NB ? NB - 1 : b); };      // monotone in k
+                unsigned hist[NB] = { 0 };
+                for (size_t i = 0; i < m; ++i) hist[bucket(kx[i])]++;
+                size_t below = 0; int b = 0;
+                while (below + hist[b] <= h2) below += hist[b++];              // the bucket that holds rank h2 (h2 < m)
+                std::vector<std::pair<double, int>> in;
+                in.reserve(hist[b]);
+                for (size_t i = 0; i < m; ++i) if (bucket(kx[i]) == b) in.push_back({ kx[i], nd[i] });
+                std::nth_element(in.begin(), in.begin() + (h2 - below), in.end());
+                cc.pk = in[h2 - below].first; cc.pi = in[h2 - below].second;
+            } else {                                                          // all coordinates equal (or not finite): the order is the index order
+                std::vector<std::pair<double, int>> in(m);
+                for (size_t i = 0; i < m; ++i) in[i] = { kx[i], nd[i] };
+                std::nth_element(in.begin(), in.begin() + h2, in.end());
+                cc.pk = in[h2].first; cc.pi = in[h2].second;
+            }
+            for (size_t i = 0; i < m; ++i) sd[nd[i]] = less_than(kx[i], nd[i], cc.pk, cc.pi) ? 1 : 2;
+            size_t cnt = 0;
+            for (size_t i = 0; i < m; ++i) {
+                const int v = nd[i];
+                if (sd[v] != 1) continue;
+                bool cut = false;
+                for (int q = C.adj_ptr[v]; q < C.adj_ptr[v + 1]; ++q) {
+                    const int u = C.adj_idx[q];
+                    if (sd[u] != 2 && sd[u] != 4) continue;
+                    if (multi && C.part[u] < C.part[v]) { if (sd[u] == 2) { sd[u] = 4; ++cnt; } }
+                    else cut = true;
+                }
+                if (cut) ++cnt;
+            }
+            for (size_t i = 0; i < m; ++i) sd[nd[i]] = 0;
+            cc.cnt = cnt;
+            return cc;
+        };
+        auto carry_out = [&](std::vector<int>& nd, const cut_cand& cc) {      // lower half first (any inner order: only the halves matter)
+            const double* key = cc.bx ? C.cx : C.cy;
+            std::partition(nd.begin(), nd.end(), [&](int v) { return less_than(key[v], v, cc.pk, cc.pi); });
+        };
+        const double lo_of[2] = { y0, x0 }, hi_of[2] = { y1, x1 };           // [bx]
         if (!multi && total < C.both_axes) { split(nodes, byx); half = h2; }       // the only candidate: nothing to compare
+        else if (nodes.size() < 96) {
+            for (int pass = 0; pass < (total >= C.both_axes ? 2 : 1); ++pass) {
+                cand = nodes;
+                split(cand, pass == 0 ? byx : !byx);
+                const size_t c = boundary(cand, h2, nullptr, nullptr);
+                if (c < best) { best = c; nodes.swap(cand); half = h2; }
+            }
+        }
         else if (total >= C.both_axes && total >= 4096 && depth <= PG_ND_PAR) {
             // both axes, large set: the two candidates are counted at the same time (the top of the recursion is the serial part of the
             // ordering); the marks of a node set are private to the call that holds it, the second candidate marks in side2
-            std::vector<int> cand2 = nodes;
-            size_t c2 = 0;
-            pg_pool::task tk; tk.fn = [&] { split(cand2, !byx); c2 = boundary(cand2, h2, nullptr, nullptr, nullptr, C.side2); for (int v : cand2) C.side2[v] = 0; };
+            cut_cand c2{};
+            std::vector<double> keys2;
+            pg_pool::task tk; tk.fn = [&] { c2 = count_cut(nodes, !byx, lo_of[!byx], hi_of[!byx], keys2, C.side2); };
             pg_pool::get().fork(&tk);
-            cand = nodes;
-            split(cand, byx);
-            const size_t c1 = boundary(cand, h2, nullptr, nullptr);
+            const cut_cand c1 = count_cut(nodes, byx, lo_of[byx], hi_of[byx], keys, C.side);
             pg_pool::get().join(&tk);
-            if (c1 < best) { best = c1; nodes.swap(cand); half = h2; }
-            if (c2 < best) { best = c2; nodes.swap(cand2); half = h2; }
+            const cut_cand* win = nullptr;
+            if (c1.cnt < best) { best = c1.cnt; win = &c1; }
+            if (c2.cnt < best) { best = c2.cnt; win = &c2; }
+            if (win) { carry_out(nodes, *win); half = h2; }
         }
-        else for (int pass = 0; pass < (total >= C.both_axes ? 2 : 1); ++pass) {
-            cand = nodes;
-            split(cand, pass == 0 ? byx : !byx);
-            const size_t c = boundary(cand, h2, nullptr, nullptr);
-            if (c < best) { best = c; nodes.swap(cand); half = h2; }
+        else {
+            cut_cand wc{}; bool have = false;
+            for (int pass = 0; pass < (total >= C.both_axes ? 2 : 1); ++pass) {
+                const bool bx = pass == 0 ? byx : !byx;
+                const cut_cand c = count_cut(nodes, bx, lo_of[bx], hi_of[bx], keys, C.side);
+                if (c.cnt < best) { best = c.cnt; wc = c; have = true; }
+            }
+            if (have) { carry_out(nodes, wc); half = h2; }
         }
     }
     { nd_timer tm(C.tns, 2);
