@@ -128,7 +128,7 @@ void dsss_destroy(dsss_ctx* c)
     if (c->geoms && c->geoms_free) c->geoms_free(c->geoms);
     if (c->ex_pinned) hipHostFree(c->ex_pinned);
     if (c->bbox_pinned) hipHostFree(c->bbox_pinned);
-    hipFree(c->bbox_jobs_dev);
+    hipFree(c->bbox_jobs_dev); if (c->bbox_jobs_pinned) hipHostFree(c->bbox_jobs_pinned);
     dsss_pg_free(c); dsss_comm_free(c);
     hipEventDestroy(c->prof.e0); hipEventDestroy(c->prof.e1);
     dsss_prof_flush(c);
@@ -241,29 +241,48 @@ int dsss_frame_geo_bbox(dsss_ctx* c, int id)
     dsss_frame& f = c->frames[id];
     if (!f.has_geom) DSSS_FAIL(c, DSSS_E_STATE, "frame %d has no geometry", id);
     int rc = dsss_ensure_store(c); if (rc) return rc;
-    f.has_bbox = true; f.bbox_async = true; c->bbox_pending = true;     // computed for all pending frames at once in dsss_sync_bboxes
+    if (c->bbox_inflight) { rc = dsss_sync_bboxes(c); if (rc) return rc; }      // (a box on its way belongs to the geometry the frame had: take it in before the frame changes)
+    f.has_bbox = true; f.bbox_async = true; c->bbox_pending = true;     // computed for all pending frames at once (dsss_bboxes_enqueue)
     return DSSS_OK;
 }
 
-// one launch for every frame whose geo box is pending (one workgroup per frame), then one copy back
+// one launch for every frame whose geo box is pending (one workgroup per frame) and one copy back into the page-locked mirror, QUEUED on
+// the context's stream: the extraction queues it behind its own kernels, so that the synchronisation that ends the extraction brings the
+// boxes back as well (launched by the matcher, the boxes were a launch, a copy and a round trip of their own between the two stages)
+int dsss_bboxes_enqueue(dsss_ctx* c)
+{
+    if (!c->bbox_pending || c->bbox_inflight) return DSSS_OK;
+    if (!c->bbox_pinned) HIPCHK(c, hipHostMalloc((void**)&c->bbox_pinned, (size_t)c->max_frames * 4 * sizeof(double), hipHostMallocDefault));
+    if (!c->bbox_jobs_pinned) HIPCHK(c, hipHostMalloc((void**)&c->bbox_jobs_pinned, (size_t)c->max_frames * sizeof(bbox_job), hipHostMallocDefault));
+    bbox_job* jobs = static_cast<bbox_job*>(c->bbox_jobs_pinned);
+    c->bbox_inflight_ids.clear();
+    for (int f = 0; f < c->max_frames; ++f)
+        if (c->frames[f].bbox_async) { const dsss_frame& fr = c->frames[f]; jobs[c->bbox_inflight_ids.size()] = bbox_job{ fr.pose6, fr.gr, fr.N, fr.M, f, 0 }; c->bbox_inflight_ids.push_back(f); }
+    c->bbox_pending = false;
+    const size_t nj = c->bbox_inflight_ids.size();
+    if (nj == 0) return DSSS_OK;
+    if (!c->bbox_jobs_dev) HIPCHK(c, hipMalloc(&c->bbox_jobs_dev, (size_t)c->max_frames * sizeof(bbox_job)));
+    bbox_job* d_jobs = static_cast<bbox_job*>(c->bbox_jobs_dev);
+    hipError_t e = hipMemcpyAsync(d_jobs, jobs, nj * sizeof(bbox_job), hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) { hipLaunchKernelGGL(geo_bbox_kernel, dim3((unsigned)nj), dim3(256), 0, c->stream, d_jobs, c->bbox_dev, c->rows_dev, c->cols_dev); e = hipGetLastError(); }
+    if (e == hipSuccess) e = hipMemcpyAsync(c->bbox_pinned, c->bbox_dev, (size_t)c->max_frames * 4 * sizeof(double), hipMemcpyDeviceToHost, c->stream);
+    if (e != hipSuccess) { c->bbox_pending = true; HIPCHK(c, e); }
+    c->bbox_inflight = true;
+    return DSSS_OK;
+}
+
+// make dsss_frame::bbox valid on the host
 int dsss_sync_bboxes(dsss_ctx* c)
 {
-    if (!c->bbox_pending) return DSSS_OK;
-    if (!c->bbox_pinned) HIPCHK(c, hipHostMalloc((void**)&c->bbox_pinned, (size_t)c->max_frames * 4 * sizeof(double), hipHostMallocDefault));
-    std::vector<bbox_job> jobs;
-    for (int f = 0; f < c->max_frames; ++f)
-        if (c->frames[f].bbox_async) { const dsss_frame& fr = c->frames[f]; jobs.push_back(bbox_job{ fr.pose6, fr.gr, fr.N, fr.M, f, 0 }); }
-    if (!jobs.empty()) {
-        if (!c->bbox_jobs_dev) HIPCHK(c, hipMalloc(&c->bbox_jobs_dev, (size_t)c->max_frames * sizeof(bbox_job)));
-        bbox_job* d_jobs = static_cast<bbox_job*>(c->bbox_jobs_dev);
-        hipError_t e = hipMemcpyAsync(d_jobs, jobs.data(), jobs.size() * sizeof(bbox_job), hipMemcpyHostToDevice, c->stream);
-        if (e == hipSuccess) { hipLaunchKernelGGL(geo_bbox_kernel, dim3((unsigned)jobs.size()), dim3(256), 0, c->stream, d_jobs, c->bbox_dev, c->rows_dev, c->cols_dev); e = hipGetLastError(); }
-        if (e == hipSuccess) e = hipMemcpyAsync(c->bbox_pinned, c->bbox_dev, (size_t)c->max_frames * 4 * sizeof(double), hipMemcpyDeviceToHost, c->stream);
-        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-        HIPCHK(c, e);
-        for (const bbox_job& j : jobs) { memcpy(c->frames[j.id].bbox, c->bbox_pinned + (size_t)j.id * 4, 4 * sizeof(double)); c->frames[j.id].bbox_async = false; }
+    for (int round = 0; round < 2 && (c->bbox_pending || c->bbox_inflight); ++round) {      // (boxes on their way first, then whatever was set since)
+        int rc = dsss_bboxes_enqueue(c); if (rc) return rc;
+        if (c->bbox_inflight) {
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+            for (int id : c->bbox_inflight_ids)
+                if (c->frames[id].bbox_async) { memcpy(c->frames[id].bbox, c->bbox_pinned + (size_t)id * 4, 4 * sizeof(double)); c->frames[id].bbox_async = false; }      // (not a box the caller has set itself since: dsss_features_set)
+            c->bbox_inflight = false; c->bbox_inflight_ids.clear();
+        }
     }
-    c->bbox_pending = false;
     return DSSS_OK;
 }
 

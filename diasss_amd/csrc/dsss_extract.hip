@@ -1175,6 +1175,7 @@ static int extract_frames_impl(dsss_ctx* c, const int* ids, int n, bool keep_tap
         { dsss_scope sc(c, DSSS_K_FILTER);
           hipLaunchKernelGGL(mask_filter_kernel, dim3(nb), dim3(256), 0, st, d_exf); }
         HIPCHK(c, hipGetLastError());
+        if (b0 + B >= n) { const int rb = dsss_bboxes_enqueue(c); if (rb) return rb; }      // the geo boxes the matcher will ask for ride on this batch's synchronisation
         HIPCHK(c, hipMemcpyAsync(h_err, d_errs, sizeof(int) * nb, hipMemcpyDeviceToHost, st));
         HIPCHK(c, hipMemcpyAsync(h_nkp, c->nkp_dev, sizeof(int) * c->max_frames, hipMemcpyDeviceToHost, st));
         HIPCHK(c, hipStreamSynchronize(st));         // one synchronisation per batch of up to EX_BATCH frames

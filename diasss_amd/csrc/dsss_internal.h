@@ -82,7 +82,8 @@ struct dsss_ctx {
     int* cols_dev = nullptr;            // [F]
     double* bbox_dev = nullptr;         // [F][4]
     double* bbox_pinned = nullptr;      // [F][4] pinned host mirror, filled asynchronously
-    bool bbox_pending = false;          // boxes launched but not yet copied into dsss_frame::bbox
+    bool bbox_pending = false;          // frames whose box has not been launched yet
+    bool bbox_inflight = false; std::vector<int> bbox_inflight_ids; void* bbox_jobs_pinned = nullptr;      // boxes queued on the stream (dsss_bboxes_enqueue), not yet copied into dsss_frame::bbox
     void* bbox_jobs_dev = nullptr;      // [max_frames] job records of dsss_sync_bboxes (a hipMalloc / hipFree pair per call cost 0.15 ms)
     // extraction scratch (grown on demand)
     void* ex_scratch = nullptr; size_t ex_scratch_bytes = 0;
@@ -159,6 +160,7 @@ struct dsss_scope {
 void dsss_extract_eager(dsss_ctx* c, const int* ids, int n);      // dsss_frames_set: start extracting the frames whose images are in HBM
 int dsss_ensure_store(dsss_ctx* c);                 // allocate the feature store for the current kcap
 int dsss_frame_geo_bbox(dsss_ctx* c, int id);       // device computation of the geo bounding box (asynchronous)
+int dsss_bboxes_enqueue(dsss_ctx* c);               // queue the pending boxes on the context's stream (no synchronisation)
 int dsss_sync_bboxes(dsss_ctx* c);                  // make dsss_frame::bbox valid on the host
 int dsss_frame_kp_geo(dsss_ctx* c, int id, int n);  // geo lookup of the stored keypoints (frame.cpp:126-165)
 void dsss_pg_free(dsss_ctx* c);
