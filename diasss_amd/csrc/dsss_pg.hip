@@ -798,9 +798,15 @@ __global__ __launch_bounds__(256) void pg_front_asm_kernel(const int* __restrict
             }
     }
     __syncthreads();
-    for (int q = xr_ptr[fd.rowptr + Rb]; q < xr_ptr[fd.rowptr + Rb + 1]; ++q) {
-        const pg_child cd = CH[xr_child[q]];
-        const int i = xr_row[q], wcols = 6 * (i + 1);
+    // the record of the NEXT (child, row) pair is fetched while the current one is added: list entry -> child descriptor -> its row is a chain
+    // of dependent round trips (in-kernel stamps: 2.7 us per pair, four round trips), and the pairs of a parent row must stay in order
+    const int q_lo = xr_ptr[fd.rowptr + Rb], q_hi = xr_ptr[fd.rowptr + Rb + 1];
+    pg_child cd_n = {}; int i_n = 0;
+    if (q_lo < q_hi) { cd_n = CH[xr_child[q_lo]]; i_n = xr_row[q_lo]; }
+    for (int q = q_lo; q < q_hi; ++q) {
+        const pg_child cd = cd_n;
+        const int i = i_n, wcols = 6 * (i + 1);
+        if (q + 1 < q_hi) { cd_n = CH[xr_child[q + 1]]; i_n = xr_row[q + 1]; }
         const int* __restrict__ rl = rel + cd.relptr;
         const double* __restrict__ src = cd.U + (size_t)(6 * i) * cd.cld;
         for (int cc = threadIdx.x; cc < wcols; cc += 256) {
@@ -862,7 +868,7 @@ __global__ __launch_bounds__(256) void pg_front_syrk_kernel(const int* __restric
     {
         const double* __restrict__ Ai = A + (size_t)(row0 + min(ir, nrows - 1)) * ld + col0;
 #pragma unroll
-        for (int ks = 0; ks < 24; ++ks) { const int k = 4 * ks + (l >> 4); a[ks] = (ir < nrows && k < n) ? -Ai[k] : 0.0; }
+        for (int ks = 0; ks < 24; ++ks) { const int k = 4 * ks + (l >> 4); a[ks] = (ir < nrows && k < n) ? Ai[k] : 0.0; }      // (the sign further down: negated inside the conditional, every one of the 24 loads waited for its own round trip -- s_waitcnt vmcnt(0) after each)
         // the four 16 x 16 blocks of C this wavefront updates come in with the operands: one round trip to memory, not five
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
@@ -872,6 +878,8 @@ __global__ __launch_bounds__(256) void pg_front_syrk_kernel(const int* __restric
             for (int v = 0; v < 4; ++v) acc[c][v] = (i0 < nrows && j0 <= i0 + 15 && i0 + (l >> 4) + 4 * v < nrows && jr < nrows) ? Cp[(size_t)(4 * v) * ld] : 0.0;
         }
     }
+#pragma unroll
+    for (int ks = 0; ks < 24; ++ks) a[ks] = -a[ks];
     __syncthreads();
     if (i0 >= nrows) return;
 #pragma unroll
