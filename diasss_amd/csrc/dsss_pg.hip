@@ -2343,11 +2343,13 @@ static int pg_solve_impl(dsss_ctx* c, const double* dr6, int total, const dsss_l
     std::vector<int> sym_part(ns);
     for (int k = 0; k < ns; ++k) sym_part[k] = (int)(std::upper_bound(pbound.begin(), pbound.end(), sep_pose[k]) - pbound.begin()) - 1;
     std::promise<void> bottom_prom; std::future<void> bottom_fut = bottom_prom.get_future();
+    std::promise<void> lists_prom; std::future<void> lists_fut = lists_prom.get_future(); bool lists_signalled = false;
     std::promise<void> coords_prom; std::future<void> coords_fut = coords_prom.get_future();
     bool bottom_signalled = false;
     std::thread sym_thread([&] {
         pg_sym_opts opt; opt.threads = sym_threads();
         opt.on_bottom_ready = [&] { bottom_signalled = true; bottom_prom.set_value(); };
+        opt.on_lists_ready = [&] { lists_signalled = true; lists_prom.set_value(); };
         opt.before_order = [&] { coords_fut.wait(); };
         opt.lists_on_device = lists_on_device;
         for (int k = 0; k + 1 < ns; ++k) redges.push_back({ k, k + 1 });      // the reduced graph: the chain of the separators, then the loop closures
@@ -2358,6 +2360,7 @@ static int pg_solve_impl(dsss_ctx* c, const double* dr6, int total, const dsss_l
         // launch lists: this rank's interior fronts, then (after the all-reduce) the replicated interface fronts
         pg_build_schedule(S, part_lo, part_hi, SO);
         if (nparts > 1) pg_build_schedule(S, -1, 0, SI);
+        if (!lists_signalled) lists_prom.set_value();
         if (!bottom_signalled) bottom_prom.set_value();      // (several partitions: nothing is ready early)
     });
     struct pg_joiner { std::thread& t; ~pg_joiner() { if (t.joinable()) t.join(); } } sym_join{ sym_thread };      // every return path waits for the thread before its data goes away
@@ -2565,11 +2568,52 @@ static int pg_solve_impl(dsss_ctx* c, const double* dr6, int total, const dsss_l
     std::vector<int> ifslot;
     int bin_lo = 0, bin_hi = 0, nbins = 0;
     bool pre_bins = false;
+    // The bins' update lists, update-map offsets and root-boundary indices are built on the device from the column structures
+    // (pg_rl_count_kernel ... pg_build_map_kernel): everything they read -- colptr, rowidx, the binned flags, the subtree roots -- is final
+    // BEFORE the host packs the bins (pg_sym_opts::on_lists_ready), so they are uploaded and the ten kernels run while it does.
+    bool lists_done = false;
+    auto upload_lists = [&]() -> int {
+        nnzL = S.rowidx.size();
+        int rc2 = DSSS_OK;
+        char* d_binned = nullptr; int* d_rootof = nullptr;
+        dv.later(&d_colptr, S.colptr); dv.later(&d_rowidx, S.rowidx); dv.later(&d_binned, S.binned); dv.later(&d_rootof, S.root_of);
+        if ((rc2 = dv.flush(c, st))) return rc2;
+        int *d_cnt, *d_cur, *d_bs32, *d_tot32; long long *d_bs64, *d_tot64;
+        const int nsb = (ns + 1023) / 1024;
+        if ((rc2 = dv.alloc(c, &d_cnt, (size_t)ns)) || (rc2 = dv.alloc(c, &d_cur, (size_t)ns)) || (rc2 = dv.alloc(c, &d_bs32, (size_t)nsb)) || (rc2 = dv.alloc(c, &d_tot32, 1)) ||
+            (rc2 = dv.alloc(c, &d_bs64, (size_t)nsb)) || (rc2 = dv.alloc(c, &d_tot64, 1)) || (rc2 = dv.alloc(c, &d_rlptr, (size_t)ns + 1)) || (rc2 = dv.alloc(c, &d_mapptr, (size_t)ns + 1)) ||
+            (rc2 = dv.alloc(c, &d_rlcol, nnzL)) || (rc2 = dv.alloc(c, &d_rlpos, nnzL)) || (rc2 = dv.alloc(c, &d_rlrow, nnzL)) ||      // (an entry of L is on at most one list)
+            (rc2 = dv.alloc(c, &d_anc_first, (size_t)ns)) || (rc2 = dv.alloc(c, &d_anc_rel, nnzL))) return rc2;
+        if (nsb > 1024 * 1024) DSSS_FAIL(c, DSSS_E_CAPACITY, "%d separators", ns);
+        hipMemsetAsync(d_cnt, 0, sizeof(int) * (size_t)ns, st); hipMemsetAsync(d_cur, 0, sizeof(int) * (size_t)ns, st);
+        hipMemsetAsync(d_anc_first, 0, sizeof(int) * (size_t)ns, st); hipMemsetAsync(d_anc_rel, 0xff, sizeof(int) * nnzL, st);
+        const dim3 gcol((ns + 255) / 256);
+        hipLaunchKernelGGL(pg_rl_count_kernel, gcol, dim3(256), 0, st, ns, d_colptr, d_rowidx, d_binned, d_cnt);
+        hipLaunchKernelGGL((pg_scan_block_kernel<int, 0>), dim3(nsb), dim3(1024), 0, st, ns, d_cnt, d_colptr, d_rlptr, d_bs32);
+        hipLaunchKernelGGL((pg_scan_tops_kernel<int>), dim3(1), dim3(1024), 0, st, nsb, d_bs32, d_tot32);
+        hipLaunchKernelGGL((pg_scan_add_kernel<int>), dim3(nsb), dim3(1024), 0, st, ns, d_rlptr, d_bs32, d_tot32);
+        hipLaunchKernelGGL((pg_scan_block_kernel<long long, 1>), dim3(nsb), dim3(1024), 0, st, ns, d_cnt, d_colptr, d_mapptr, d_bs64);
+        hipLaunchKernelGGL((pg_scan_tops_kernel<long long>), dim3(1), dim3(1024), 0, st, nsb, d_bs64, d_tot64);
+        hipLaunchKernelGGL((pg_scan_add_kernel<long long>), dim3(nsb), dim3(1024), 0, st, ns, d_mapptr, d_bs64, d_tot64);
+        hipLaunchKernelGGL(pg_rl_fill_kernel, gcol, dim3(256), 0, st, ns, d_colptr, d_rowidx, d_binned, d_rlptr, d_cur, d_rlcol, d_rlpos);
+        hipLaunchKernelGGL(pg_rl_sort_kernel, dim3((ns + 3) / 4), dim3(256), 0, st, ns, d_rlptr, d_rlcol, d_rlpos, d_rlrow, d_fail);
+        hipLaunchKernelGGL(pg_anc_rel_kernel, gcol, dim3(256), 0, st, ns, d_colptr, d_rowidx, d_binned, d_rootof, d_anc_first, d_anc_rel);
+        // the totals stay on the device: a binned column has at most 42 blocks and an entry of L is on at most one list, so the map
+        // has at most 42 nnz(L) entries -- allocated to that bound (54 MB at C3), filled and built up to the device-side totals
+        const long long mapsz = 42LL * (long long)nnzL; const int nupd = (int)nnzL;
+        if (mapsz > (1LL << 31)) DSSS_FAIL(c, DSSS_E_CAPACITY, "update map bound of %lld entries", mapsz);
+        if ((rc2 = dv.alloc(c, &d_map, (size_t)mapsz))) return rc2;
+        hipLaunchKernelGGL(pg_fill_map_kernel, dim3(2048), dim3(256), 0, st, d_map, d_tot64);
+        if (nupd > 0) hipLaunchKernelGGL(pg_build_map_kernel, dim3((nupd + 255) / 256), dim3(256), 0, st, nupd, d_rlrow, d_rlptr, d_rlcol, d_rlpos, d_colptr, d_rowidx, d_mapptr, d_map, d_tot32);
+        lists_done = true;
+        return DSSS_OK;
+    };
     auto upload_bottom = [&]() -> int {
         nnzL = S.rowidx.size(); nval = (int)S.dest_bin.size();
         ncv = S.comm_vals.size(); nif = S.iface_seps.size();
         comm_total = ncv * 36 + nif * 6 + (size_t)S.comm_doubles + 8;
         int rc2 = DSSS_OK;
+        if (lists_on_device && !lists_done && (rc2 = upload_lists())) return rc2;
         dv.later(&d_perm, S.perm);
         if ((rc2 = dv.alloc(c, &d_L, nnzL * 36))) return rc2;
         if ((rc2 = dv.alloc(c, &d_ubin, (size_t)S.ubin_doubles))) return rc2;
@@ -2579,52 +2623,19 @@ static int pg_solve_impl(dsss_ctx* c, const double* dr6, int total, const dsss_l
         d_comm = d_aval + (size_t)nval * 36; d_avalif = d_comm; d_xif = d_comm + ncv * 36; d_commU = d_xif + nif * 6;
         ifslot.assign(ns, -1); for (size_t q = 0; q < nif; ++q) ifslot[S.iface_seps[q]] = (int)q;
         dv.later(&d_ifslot, ifslot); dv.later(&d_ifsep, S.iface_seps);
-        dv.later(&d_colptr, S.colptr); dv.later(&d_rowidx, S.rowidx); dv.later(&d_binptr, S.binptr); dv.later(&d_bincols, S.bincols); dv.later(&d_binperm, S.bin_perm);
+        if (!lists_on_device) { dv.later(&d_colptr, S.colptr); dv.later(&d_rowidx, S.rowidx); }
+        dv.later(&d_binptr, S.binptr); dv.later(&d_bincols, S.bincols); dv.later(&d_binperm, S.bin_perm);
         dv.later(&d_dest, S.dest_bin);
         dv.later(&d_binroot_ptr, S.binroot_ptr); dv.later(&d_binroot_idx, S.binroot_idx); dv.later(&d_broot_b, S.broot_b); dv.later(&d_broot_uoff, S.broot_uoff);
         dv.later(&d_broot_of_col, S.broot_of_col);
-        char* d_binned = nullptr; int* d_rootof = nullptr;
-        if (lists_on_device) { dv.later(&d_binned, S.binned); dv.later(&d_rootof, S.root_of); }
-        else { dv.later(&d_rlptr, S.rlptr); dv.later(&d_rlcol, S.rlcol); dv.later(&d_rlpos, S.rlpos); dv.later(&d_rlrow, S.rlrow); dv.later(&d_mapptr, S.mapptr);
-               dv.later(&d_anc_first, S.anc_first); dv.later(&d_anc_rel, S.anc_rel); }
+        if (!lists_on_device) { dv.later(&d_rlptr, S.rlptr); dv.later(&d_rlcol, S.rlcol); dv.later(&d_rlpos, S.rlpos); dv.later(&d_rlrow, S.rlrow); dv.later(&d_mapptr, S.mapptr);
+                                dv.later(&d_anc_first, S.anc_first); dv.later(&d_anc_rel, S.anc_rel); }
         if ((rc2 = dv.flush(c, st))) return rc2;
         // this rank's bins are one contiguous range (bins never straddle partitions, partitions are ascending in the order)
         { const int nb_all = (int)S.binptr.size() - 1; bin_lo = 0; while (bin_lo < nb_all && S.bin_part[bin_lo] < part_lo) ++bin_lo; bin_hi = bin_lo; while (bin_hi < nb_all && S.bin_part[bin_hi] < part_hi) ++bin_hi; }
         nbins = bin_hi - bin_lo;
-        long long mapsz = 0; int nupd = 0;
-        if (lists_on_device) {
-            // update lists, update-map offsets and root-boundary indices of the bins: built here, from the column structures
-            // (pg_rl_count_kernel ... pg_anc_rel_kernel); two totals come back for the allocation of the map
-            int *d_cnt, *d_cur, *d_bs32, *d_tot32; long long *d_bs64, *d_tot64;
-            const int nsb = (ns + 1023) / 1024;
-            if ((rc2 = dv.alloc(c, &d_cnt, (size_t)ns)) || (rc2 = dv.alloc(c, &d_cur, (size_t)ns)) || (rc2 = dv.alloc(c, &d_bs32, (size_t)nsb)) || (rc2 = dv.alloc(c, &d_tot32, 1)) ||
-                (rc2 = dv.alloc(c, &d_bs64, (size_t)nsb)) || (rc2 = dv.alloc(c, &d_tot64, 1)) || (rc2 = dv.alloc(c, &d_rlptr, (size_t)ns + 1)) || (rc2 = dv.alloc(c, &d_mapptr, (size_t)ns + 1)) ||
-                (rc2 = dv.alloc(c, &d_rlcol, nnzL)) || (rc2 = dv.alloc(c, &d_rlpos, nnzL)) || (rc2 = dv.alloc(c, &d_rlrow, nnzL)) ||      // (an entry of L is on at most one list)
-                (rc2 = dv.alloc(c, &d_anc_first, (size_t)ns)) || (rc2 = dv.alloc(c, &d_anc_rel, nnzL))) return rc2;
-            if (nsb > 1024 * 1024) DSSS_FAIL(c, DSSS_E_CAPACITY, "%d separators", ns);
-            hipMemsetAsync(d_cnt, 0, sizeof(int) * (size_t)ns, st); hipMemsetAsync(d_cur, 0, sizeof(int) * (size_t)ns, st);
-            hipMemsetAsync(d_anc_first, 0, sizeof(int) * (size_t)ns, st); hipMemsetAsync(d_anc_rel, 0xff, sizeof(int) * nnzL, st);
-            const dim3 gcol((ns + 255) / 256);
-            hipLaunchKernelGGL(pg_rl_count_kernel, gcol, dim3(256), 0, st, ns, d_colptr, d_rowidx, d_binned, d_cnt);
-            hipLaunchKernelGGL((pg_scan_block_kernel<int, 0>), dim3(nsb), dim3(1024), 0, st, ns, d_cnt, d_colptr, d_rlptr, d_bs32);
-            hipLaunchKernelGGL((pg_scan_tops_kernel<int>), dim3(1), dim3(1024), 0, st, nsb, d_bs32, d_tot32);
-            hipLaunchKernelGGL((pg_scan_add_kernel<int>), dim3(nsb), dim3(1024), 0, st, ns, d_rlptr, d_bs32, d_tot32);
-            hipLaunchKernelGGL((pg_scan_block_kernel<long long, 1>), dim3(nsb), dim3(1024), 0, st, ns, d_cnt, d_colptr, d_mapptr, d_bs64);
-            hipLaunchKernelGGL((pg_scan_tops_kernel<long long>), dim3(1), dim3(1024), 0, st, nsb, d_bs64, d_tot64);
-            hipLaunchKernelGGL((pg_scan_add_kernel<long long>), dim3(nsb), dim3(1024), 0, st, ns, d_mapptr, d_bs64, d_tot64);
-            hipLaunchKernelGGL(pg_rl_fill_kernel, gcol, dim3(256), 0, st, ns, d_colptr, d_rowidx, d_binned, d_rlptr, d_cur, d_rlcol, d_rlpos);
-            hipLaunchKernelGGL(pg_rl_sort_kernel, dim3((ns + 3) / 4), dim3(256), 0, st, ns, d_rlptr, d_rlcol, d_rlpos, d_rlrow, d_fail);
-            hipLaunchKernelGGL(pg_anc_rel_kernel, gcol, dim3(256), 0, st, ns, d_colptr, d_rowidx, d_binned, d_rootof, d_anc_first, d_anc_rel);
-            // the totals stay on the device: a binned column has at most 42 blocks and an entry of L is on at most one list, so the map
-            // has at most 42 nnz(L) entries -- allocated to that bound (54 MB at C3), filled and built up to the device-side totals
-            mapsz = 42LL * (long long)nnzL; nupd = (int)nnzL;
-            if (mapsz > (1LL << 31)) DSSS_FAIL(c, DSSS_E_CAPACITY, "update map bound of %lld entries", mapsz);
-            if ((rc2 = dv.alloc(c, &d_map, (size_t)mapsz))) return rc2;
-            hipLaunchKernelGGL(pg_fill_map_kernel, dim3(2048), dim3(256), 0, st, d_map, d_tot64);
-            if (nupd > 0) hipLaunchKernelGGL(pg_build_map_kernel, dim3((nupd + 255) / 256), dim3(256), 0, st, nupd, d_rlrow, d_rlptr, d_rlcol, d_rlpos, d_colptr, d_rowidx, d_mapptr, d_map, d_tot32);
-            return DSSS_OK;
-        }
-        mapsz = S.mapptr[ns]; nupd = (int)S.rlcol.size();
+        if (lists_on_device) return DSSS_OK;
+        const long long mapsz = S.mapptr[ns]; const int nupd = (int)S.rlcol.size();
         if (mapsz > (1LL << 31)) DSSS_FAIL(c, DSSS_E_CAPACITY, "update map of %lld entries", mapsz);
         if ((rc2 = dv.alloc(c, &d_map, (size_t)mapsz))) return rc2;
         if (hipMemsetAsync(d_map, 0xff, (size_t)std::max<long long>(mapsz, 1) * sizeof(int), st) != hipSuccess) DSSS_FAIL(c, DSSS_E_HIP, "hipMemsetAsync(update map)");
@@ -2645,6 +2656,7 @@ static int pg_solve_impl(dsss_ctx* c, const double* dr6, int total, const dsss_l
     const bool early_ok = !(getenv("DSSS_PG_EARLY") && atoi(getenv("DSSS_PG_EARLY")) == 0);      // A/B switch
     const bool early_bottom = early_ok && nparts == 1 && will_iterate && pre_chain;
     if (early_bottom) {
+        if (lists_on_device) { lists_fut.wait(); TRY(upload_lists()); }
         bottom_fut.wait();
         TRY(upload_bottom());
         bottom_trial(0.0);                                   // (its flop count is known when the analysis has finished: added below)

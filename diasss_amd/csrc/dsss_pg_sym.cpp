@@ -484,6 +484,7 @@ void pg_symbolic(int ns, const std::vector<std::pair<int, int>>& edges, int ncha
         root_of[j] = (par >= 0 && sub_ok[par]) ? root_of[par] : j;
     }
     S.root_of = root_of;
+    if (opt.on_lists_ready && nparts <= 1) opt.on_lists_ready();       // colptr, rowidx, binned, root_of: final
     // subtree roots in bin order, and the roots that hand an update matrix up (the fronts of the top need these; the packing itself not)
     std::vector<int> roots;
     for (int j = 0; j < ns; ++j) if (sub_ok[j] && root_of[j] == j) roots.push_back(j);

@@ -122,6 +122,9 @@ struct pg_sym_opts {
     // scatter and the bins of the first trial under the rest of the analysis.  Only with one partition (interface values get their
     // dest_bin codes at the very end).  None of the vectors it may read is touched afterwards.
     std::function<void()> on_bottom_ready;
+    // called earlier still (same conditions), as soon as the column structures, the binned flags and the subtree roots are final: all the
+    // device needs to build the bins' update lists, update map and root-boundary indices itself (lists_on_device) while the host packs the bins
+    std::function<void()> on_lists_ready;
     bool lists_on_device = false;                // the caller builds the update lists, the update-map offsets and the root-boundary indices of the bins itself (dsss_pg.hip: on the device); rlptr .. anc_rel stay empty
     std::function<void()> before_order;          // called once the adjacency is built, before the first use of the coordinates (which may still be on their way)
 };
