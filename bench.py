@@ -193,7 +193,7 @@ def main():
     ap.add_argument("--cpu-frames", type=int, default=24, help="frames in the CPU baseline sample (0 = skip); 24 frames of C3 are about 10 s of one core")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--pcie-steps", type=int, default=2, help="steps of the PCIe-inclusive leg (raw frames in page-locked host memory); 0 = skip")
-    ap.add_argument("--jobs-in-flight", type=int, default=2, help="surveys overlapped in the extra throughput leg (1 = skip)")
+    ap.add_argument("--jobs-in-flight", type=int, default=4, help="surveys overlapped in the extra throughput leg (1 = skip); the rate saturates at four on one MI355X")
     ap.add_argument("--dry-run", action="store_true", help="plumbing check without a GPU (CPU test-suite): gloo ranks, the context class named by DSSS_BENCH_CTX "
                                                            "(module:Class, a recording stub), no frames, no timing claim -- the line carries value null and dry_run true")
     ap.add_argument("--emulate-rank", default=None, metavar="r/W", help="time rank r (or `all`) of a W-rank job on ONE GPU: all W ranks run once in lock step inside "
@@ -241,7 +241,7 @@ def main():
     big = F * N * M > (1 << 32)                        # C5: 65 GB of frames -- device-side noise, no host-resident or second-context legs by default
     if big:
         args.pcie_steps = 0 if args.pcie_steps == 2 else args.pcie_steps
-        args.jobs_in_flight = 1 if args.jobs_in_flight == 2 else args.jobs_in_flight
+        args.jobs_in_flight = 1 if args.jobs_in_flight == 4 else args.jobs_in_flight
         args.cpu_frames = min(args.cpu_frames, 6)
     sv = Survey(F, N, M, seed=20240601 + ["C2", "C3", "smoke", "C5"].index(args.workload), device="cuda:%d" % local_rank, noise_on_device=big)
     mine = shard_frames(F, rank, world)
