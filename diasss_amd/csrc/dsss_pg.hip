@@ -2283,7 +2283,7 @@ static int pg_solve_impl(dsss_ctx* c, const double* dr6, int total, const dsss_l
       const double so[6] = { wgt1 * PI / 180, wgt1 * PI / 180, 0.1 * wgt1 * wgt2 * PI / 180, wgt1 * wgt2, wgt1 * wgt2, wgt1 };
       for (int k = 0; k < 6; ++k) { W.prior[k] = 1.0 / 0.000001; W.odo[k] = 1.0 / so[k]; } }
     // DR poses, measurements and initial values are produced on the device (pg_init_kernel) further down
-    std::vector<int> ea(ne), eb(ne), eo(ne); std::vector<pose_t> emeas(ne); std::vector<double> ew((size_t)ne * 6);
+    std::vector<int> ea(ne), eb(ne), eo(ne); std::vector<pose_t> emeas; std::vector<double> ew;      // (the measurements' 1.7 MB are allocated where they are filled, beside the analysis: touching fresh pages here is time the GPU waits for)
     for (int e = 0; e < ne; ++e) {                  // the end points first: they are all the analysis needs (the measurements are unpacked beside it, below)
         ea[e] = edges[e].a; eb[e] = edges[e].b; eo[e] = std::max(edges[e].a, edges[e].b);
         if (ea[e] < 0 || ea[e] >= n || eb[e] < 0 || eb[e] >= n || ea[e] == eb[e]) DSSS_FAIL(c, DSSS_E_ARG, "LC edge %d out of range", e);
@@ -2403,6 +2403,7 @@ static int pg_solve_impl(dsss_ctx* c, const double* dr6, int total, const dsss_l
         for (int k = 0; k < ns; ++k) { cx[k] = sxy[2 * (size_t)k]; cy[k] = sxy[2 * (size_t)k + 1]; }
         coords_guard.set();
     }
+    emeas.resize(ne); ew.resize((size_t)ne * 6);
     for (int e = 0; e < ne; ++e) {                  // measurements and weights of the loop closures (the analysis is running and has its coordinates)
         for (int k = 0; k < 9; ++k) emeas[e].R[k] = edges[e].rel[k];
         for (int k = 0; k < 3; ++k) emeas[e].t[k] = edges[e].rel[9 + k];
