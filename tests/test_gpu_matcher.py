@@ -221,3 +221,29 @@ def test_matcher_geo_grid_corner_cases(ctx, orc, kind, grid, monkeypatch):
     _check_pair(ctx, orc, 0, 0, 2, fr)
     nn = ctx.match_dir(0, 0)[0][:len(A)]
     assert (nn >= 0).sum() > 10
+
+
+@pytest.mark.parametrize("radius", [0.004, 0.5, 8.0, 50.0, 1000.0])
+def test_matcher_radius_sweep(ctx, orc, radius):
+    """the search radius from far below the keypoint spacing (the geo box would hold more than 2^22 cells: the call falls back to the
+    all-pairs kernel) to far above the box (one cell): geo grid against the oracle, and against DSSS_MT_GRID=0, on the features of a
+    synthetic pair"""
+    import os
+    fr = _mkframes(orc, ctx, (600, 600), seed=17)
+    frames = {0: fr[0], 1: fr[1]}
+    mp, op, mt, pg = ctx.default_params()
+    mt.radius = radius
+    ctx.set_params(match=mt)
+    op_ = orc.match_params(); op_.radius = radius
+    try:
+        ctx.match_pairs([0], [1])
+        _check_pair(ctx, orc, 0, 0, 1, frames, op_)
+        nn_grid = [ctx.match_dir(0, d)[0].copy() for d in (0, 1)]
+        os.environ["DSSS_MT_GRID"] = "0"
+        ctx.match_pairs([0], [1])
+        for d in (0, 1):
+            assert (ctx.match_dir(0, d)[0] == nn_grid[d]).all()
+    finally:
+        os.environ.pop("DSSS_MT_GRID", None)
+        mt.radius = 8.0
+        ctx.set_params(match=mt)
