@@ -388,6 +388,8 @@ void pg_symbolic(int ns, const std::vector<std::pair<int, int>>& edges, int ncha
     auto tms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
     const auto q0 = tnow();
     const int T = std::max(1, opt.threads);
+    const bool dev_nd = opt.device_order_start && opt.device_order_finish && S.nparts <= 1 && ns >= 2 && ns <= 65536;
+    if (dev_nd) opt.device_order_start(edges, opt.leaf, opt.nd_both_axes);
     // adjacency in CSR form, rows sorted and deduplicated
     std::vector<int> adj_ptr(ns + 1, 0), adj_idx;
     {   // rows are tiny (two chain neighbours + the loop closures of the pose): insertion sort and duplicate removal in place, rows
@@ -418,7 +420,27 @@ void pg_symbolic(int ns, const std::vector<std::pair<int, int>>& edges, int ncha
     std::vector<nd_tree> pool; std::mutex mu;
     std::vector<char> iface(ns, 0);
     int root = -1;
-    {
+    bool ordered = false;
+    if (dev_nd) {
+        std::vector<int> top;
+        if (opt.device_order_finish(S.order, top) && (int)S.order.size() == ns && top.size() >= 64 * 6) {
+            // the top of the recursion tree as nd_order would have left it: nodes down to depth PG_ND_PAR, children only below the sets the
+            // host would have forked at (depth < PG_ND_PAR and more than 2048 nodes)
+            std::function<int(int, int)> build = [&](int h, int depth) -> int {
+                if (depth > PG_ND_PAR || h >= 64) return -1;
+                const int* d = top.data() + 6 * (size_t)h;
+                const int size = d[1], kind = d[3];
+                int a = -1, b = -1;
+                if (kind == 2 && depth < PG_ND_PAR && size > 2048) { a = build(2 * h, depth + 1); b = build(2 * h + 1, depth + 1); }
+                pool.push_back({ a, b, size });
+                return (int)pool.size() - 1;
+            };
+            root = build(1, 0);
+            ordered = true;
+        } else S.order.clear();
+        if (tv) fprintf(stderr, "[dsss pg symbolic] ordering on the device: %s (waited %.2f ms for it after the adjacency)\n", ordered ? "used" : "NOT used, the host orders", tms(q0a, tnow()));
+    }
+    if (!ordered) {
         std::vector<int> nodes(ns); std::iota(nodes.begin(), nodes.end(), 0);
         std::vector<char> side(ns, 0), side2(ns, 0);
         S.order.reserve(ns);

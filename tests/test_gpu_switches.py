@@ -12,7 +12,7 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 
-SAME_BITS_PG = [("DSSS_PG_PANEL", "diag3"), ("DSSS_PG_PACK_COST", "300"), ("DSSS_PG_RSU32", "0"), ("DSSS_PG_RSU32", "1000"), ("DSSS_PG_RSU", "0"), ("DSSS_PG_RSU", "64"), ("DSSS_PG_LISTS", "host"), ("DSSS_PG_EARLY", "0"),
+SAME_BITS_PG = [("DSSS_PG_PANEL", "diag3"), ("DSSS_PG_PACK_COST", "300"), ("DSSS_PG_RSU32", "0"), ("DSSS_PG_RSU32", "1000"), ("DSSS_PG_RSU", "0"), ("DSSS_PG_RSU", "64"), ("DSSS_PG_LISTS", "host"), ("DSSS_PG_EARLY", "0"), ("DSSS_PG_ND", "host"),
                 ("DSSS_SYM_THREADS", "1"), ("DSSS_SYM_THREADS", "5")]
 SAME_OPTIMUM_PG = [("DSSS_PG_CHUNK", "8"), ("DSSS_PG_CHUNK", "24"), ("DSSS_PG_BIN_COST", "300"), ("DSSS_PG_BIN_COST", "1200"), ("DSSS_PG_ND_BOTH", "1000000"),
                    ("DSSS_PG_LEAF", "12"), ("DSSS_PG_RELAX_ZERO", "0"), ("DSSS_PG_RELAX_FLOPS", "1.0"), ("DSSS_PG_RELAX_SMALL", "1.0"), ("DSSS_PG_RELAX_ABS", "1e6")]
