@@ -124,6 +124,7 @@ void dsss_destroy(dsss_ctx* c)
     if (c->pg_edges_host) hipHostFree(c->pg_edges_host);
     if (c->pg_stage) hipHostFree(c->pg_stage);
     if (c->pg_scal_host) hipHostFree(c->pg_scal_host);
+    if (c->pg_nd_stream) hipStreamDestroy(c->pg_nd_stream);
     if (c->pg_nd_host) hipHostFree(c->pg_nd_host);
     if (c->pg_nd_dep) hipEventDestroy(c->pg_nd_dep);
     if (c->pg_nd_done) hipEventDestroy(c->pg_nd_done);

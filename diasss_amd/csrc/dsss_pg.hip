@@ -2362,10 +2362,10 @@ static int pg_solve_impl(dsss_ctx* c, const double* dr6, int total, const dsss_l
                 nd_ready_fut.wait();                             // the main thread has allocated the buffers and queued the coordinates
                 if (!nd_ok) return;
                 static_assert(sizeof(std::pair<int, int>) == 2 * sizeof(int), "reduced edges are pairs of ints");
-                if (hipSetDevice(c->device) != hipSuccess || hipStreamWaitEvent(c->xs[0], c->pg_nd_dep, 0) != hipSuccess) { (void)hipGetLastError(); return; }
+                if (hipSetDevice(c->device) != hipSuccess || hipStreamWaitEvent(c->pg_nd_stream, c->pg_nd_dep, 0) != hipSuccess) { (void)hipGetLastError(); return; }
                 ndB.nlev = pg_nd_levels(ns, leaf);
                 if (pg_nd_set_count(ndB.nlev) > nd_sets_cap || (int)ed.size() > nd_edges_cap) return;
-                nd_started = pg_nd_start(c, c->xs[0], ndB, reinterpret_cast<const int*>(ed.data()), (int)ed.size(), leaf, both_axes) == DSSS_OK;
+                nd_started = pg_nd_start(c, c->pg_nd_stream, ndB, reinterpret_cast<const int*>(ed.data()), (int)ed.size(), leaf, both_axes) == DSSS_OK;
             };
             opt.device_order_finish = [&](std::vector<int>& order, std::vector<int>& top6) -> bool {
                 if (!nd_started) return false;
@@ -2439,7 +2439,8 @@ static int pg_solve_impl(dsss_ctx* c, const double* dr6, int total, const dsss_l
         }
         ndB.h_sets = reinterpret_cast<pg_nd_set*>(c->pg_nd_host); ndB.h_order = c->pg_nd_host + 64 * 6 + 16;
         hipError_t e = hipSuccess;
-        if (!c->pg_nd_dep) e = hipEventCreateWithFlags(&c->pg_nd_dep, hipEventDisableTiming);
+        if (!c->pg_nd_stream) { int lo = 0, hi = 0; (void)hipDeviceGetStreamPriorityRange(&lo, &hi); e = hipStreamCreateWithPriority(&c->pg_nd_stream, hipStreamNonBlocking, hi); }
+        if (e == hipSuccess && !c->pg_nd_dep) e = hipEventCreateWithFlags(&c->pg_nd_dep, hipEventDisableTiming);
         if (e == hipSuccess && !c->pg_nd_done) e = hipEventCreateWithFlags(&c->pg_nd_done, hipEventDisableTiming);
         if (e == hipSuccess) e = hipEventRecord(c->pg_nd_dep, c->stream);        // behind pg_sep_xy_kernel
         if (e != hipSuccess) { dv.release(); HIPCHK(c, e); }
