@@ -2428,7 +2428,7 @@ static int pg_solve_impl(dsss_ctx* c, const double* dr6, int total, const dsss_l
         TRY(dv.alloc(c, &ndB.adj_idx, (size_t)2 * ne_red)); TRY(dv.alloc(c, &ndB.rank_x, (size_t)ns)); TRY(dv.alloc(c, &ndB.rank_y, (size_t)ns)); TRY(dv.alloc(c, &ndB.perm0, (size_t)ns));
         TRY(dv.alloc(c, &ndB.perm1, (size_t)ns)); TRY(dv.alloc(c, &ndB.setid, (size_t)ns)); TRY(dv.alloc(c, &ndB.order, (size_t)ns)); TRY(dv.alloc(c, &ndB.cut0, (size_t)ns)); TRY(dv.alloc(c, &ndB.cut1, (size_t)ns * 4));      // (cut1: the packed ranks, four bytes per node)
         nd_sets_cap = pg_nd_set_count(nlev_max); nd_edges_cap = ne_red;
-        TRY(dv.alloc(c, &ndB.sets, nd_sets_cap + 1024));      // (+ 24 KB behind the sets: the histograms of the rank kernels)
+        TRY(dv.alloc(c, &ndB.sets, nd_sets_cap + 4096));      // (+ 96 KB behind the sets: the histograms of the rank kernels, the per-set records of the big levels)
         const size_t host_ints = (size_t)ns + 64 * 6 + 16;
         if (c->pg_nd_host_cap < host_ints) {
             if (c->pg_nd_host) hipHostFree(c->pg_nd_host);

@@ -550,6 +550,247 @@ __global__ __launch_bounds__(G < 256 ? 256 : G) void nd_level_group_kernel(int L
     }
 }
 
+// ---- the levels whose sets do not fit one workgroup's registers (more than 4 096 nodes: the first three levels of C3).  One workgroup
+// walking such a set is bound by what ONE compute unit loads (0.8 MB a pass, six passes: 167 us for the 23 k nodes of level 0), so a set
+// is cut into slices of 4 096 nodes, a workgroup each, and the four steps that need the whole set's answer are four launches:
+//   A  box (atomic min / max on order-preserving keys), histograms of the high rank bytes      B  histograms of the low rank bytes
+//   C  medians, both cut candidates counted, a slice's class counts for either candidate       D  the choice, the stable partition
+#define ND_SL (1024 * ND_U)
+#define ND_WMAX 16                                   // slices per set: sets of up to 65 536 nodes
+struct nd_big { unsigned long long bb[4]; unsigned hist_hi[2][256], hist_lo[2][256]; int cnt[2]; int cls[ND_WMAX][2][3]; int pad[2]; };
+
+__device__ inline unsigned long long nd_key(double v) { const unsigned long long b = (unsigned long long)__double_as_longlong(v); return (b >> 63) ? ~b : (b | 0x8000000000000000ull); }
+__device__ inline double nd_unkey(unsigned long long k) { const unsigned long long b = (k >> 63) ? (k & 0x7fffffffffffffffull) : ~k; return __longlong_as_double((long long)b); }
+
+struct nd_slice { int h, m, lo, n; const int* P; };   // set, its size, the slice's first position and node count, the set's node list
+__device__ inline bool nd_get_slice(int L, int W, const nd_args& A, nd_slice* s, pg_nd_set* d)
+{
+    const int kset = blockIdx.x / W, j = blockIdx.x % W;
+    s->h = (1 << L) + kset;
+    *d = A.sets[s->h];
+    s->m = d->size;
+    s->lo = j * ND_SL;
+    s->n = min(ND_SL, s->m - s->lo);
+    s->P = ((L & 1) ? A.perm1 : A.perm0) + d->lo;
+    return s->m > A.leaf && s->n > 0;                 // (leaves of a big level -- a tiny DSSS_PG_LEAF aside there are none -- are handled by phase D's slice 0)
+}
+
+__global__ __launch_bounds__(1024) void nd_bigA_kernel(int L, int W, nd_args A, nd_big* __restrict__ G)
+{
+    __shared__ unsigned hist[512];
+    __shared__ double red[4][16];
+    nd_slice sl; pg_nd_set d;
+    if (!nd_get_slice(L, W, A, &sl, &d)) return;
+    nd_big& g = G[blockIdx.x / W];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    if (threadIdx.x < 512) hist[threadIdx.x] = 0u;
+    int v[ND_U]; unsigned r[ND_U]; double2 p[ND_U];
+#pragma unroll
+    for (int u = 0; u < ND_U; ++u) { const int i = 256 * wv + 64 * u + lane; v[u] = i < sl.n ? sl.P[sl.lo + i] : -1; }
+#pragma unroll
+    for (int u = 0; u < ND_U; ++u) { r[u] = v[u] >= 0 ? A.rank_xy[v[u]] : 0u; p[u] = v[u] >= 0 ? reinterpret_cast<const double2*>(A.sxy)[v[u]] : make_double2(0.0, 0.0); }
+    double x0 = 1e300, x1 = -1e300, y0 = 1e300, y1 = -1e300;
+#pragma unroll
+    for (int u = 0; u < ND_U; ++u) if (v[u] >= 0) { x0 = fmin(x0, p[u].x); x1 = fmax(x1, p[u].x); y0 = fmin(y0, p[u].y); y1 = fmax(y1, p[u].y); }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) { x0 = fmin(x0, nd_shfl_d(x0, o)); x1 = fmax(x1, nd_shfl_d(x1, o)); y0 = fmin(y0, nd_shfl_d(y0, o)); y1 = fmax(y1, nd_shfl_d(y1, o)); }
+    if (lane == 0) { red[0][wv] = x0; red[1][wv] = x1; red[2][wv] = y0; red[3][wv] = y1; }
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < ND_U; ++u) if (v[u] >= 0) { atomicAdd(&hist[(r[u] & 0xffffu) >> 8], 1u); atomicAdd(&hist[256 + (r[u] >> 24)], 1u); }
+    if (threadIdx.x == 0) {
+        for (int k = 0; k < 16; ++k) { x0 = fmin(x0, red[0][k]); x1 = fmax(x1, red[1][k]); y0 = fmin(y0, red[2][k]); y1 = fmax(y1, red[3][k]); }
+        atomicMin(&g.bb[0], nd_key(x0)); atomicMax(&g.bb[1], nd_key(x1)); atomicMin(&g.bb[2], nd_key(y0)); atomicMax(&g.bb[3], nd_key(y1));
+    }
+    __syncthreads();
+    if (threadIdx.x < 512 && hist[threadIdx.x]) atomicAdd(&g.hist_hi[threadIdx.x >> 8][threadIdx.x & 255], hist[threadIdx.x]);
+}
+
+// the set's two high bins (and what is left of h2 inside them) from its global histograms, by every workgroup for itself
+__device__ inline void nd_big_hi(const nd_big& g, nd_gl<16>& S, int h2, int* hx, int* kx, int* hy, int* ky)
+{
+    if (threadIdx.x < 512) S.hist2[threadIdx.x] = g.hist_hi[threadIdx.x >> 8][threadIdx.x & 255];
+    __syncthreads();
+    nd_find_bins_g<1024, 16>(S, threadIdx.x, h2, h2);
+    *hx = S.sel[0]; *kx = S.sel[1]; *hy = S.sel[2]; *ky = S.sel[3];
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(1024) void nd_bigB_kernel(int L, int W, nd_args A, nd_big* __restrict__ G)
+{
+    __shared__ nd_gl<16> S;
+    __shared__ unsigned hist[512];
+    nd_slice sl; pg_nd_set d;
+    if (!nd_get_slice(L, W, A, &sl, &d)) return;
+    nd_big& g = G[blockIdx.x / W];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    int v[ND_U]; unsigned r[ND_U];
+#pragma unroll
+    for (int u = 0; u < ND_U; ++u) { const int i = 256 * wv + 64 * u + lane; v[u] = i < sl.n ? sl.P[sl.lo + i] : -1; }
+#pragma unroll
+    for (int u = 0; u < ND_U; ++u) r[u] = v[u] >= 0 ? A.rank_xy[v[u]] : 0u;
+    if (threadIdx.x < 512) hist[threadIdx.x] = 0u;
+    int hx, kx, hy, ky;
+    nd_big_hi(g, S, sl.m / 2, &hx, &kx, &hy, &ky);
+#pragma unroll
+    for (int u = 0; u < ND_U; ++u) if (v[u] >= 0) {
+        const int rx = (int)(r[u] & 0xffffu), ry = (int)(r[u] >> 16);
+        if ((rx >> 8) == hx) atomicAdd(&hist[rx & 255], 1u);
+        if ((ry >> 8) == hy) atomicAdd(&hist[256 + (ry & 255)], 1u);
+    }
+    __syncthreads();
+    if (threadIdx.x < 512 && hist[threadIdx.x]) atomicAdd(&g.hist_lo[threadIdx.x >> 8][threadIdx.x & 255], hist[threadIdx.x]);
+}
+
+__device__ inline void nd_big_pivots(const nd_big& g, nd_gl<16>& S, int h2, int* pvx, int* pvy)
+{
+    int hx, kx, hy, ky;
+    nd_big_hi(g, S, h2, &hx, &kx, &hy, &ky);
+    if (threadIdx.x < 512) S.hist2[threadIdx.x] = g.hist_lo[threadIdx.x >> 8][threadIdx.x & 255];
+    __syncthreads();
+    nd_find_bins_g<1024, 16>(S, threadIdx.x, kx, ky);
+    *pvx = (hx << 8) | S.sel[0]; *pvy = (hy << 8) | S.sel[2];
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(1024) void nd_bigC_kernel(int L, int W, nd_args A, nd_big* __restrict__ G)
+{
+    __shared__ nd_gl<16> S;
+    nd_slice sl; pg_nd_set d;
+    if (!nd_get_slice(L, W, A, &sl, &d)) return;
+    nd_big& g = G[blockIdx.x / W];
+    const int h = sl.h, lane = threadIdx.x & 63, wv = threadIdx.x >> 6, j = blockIdx.x % W;
+    int v[ND_U], rx[ND_U], ry[ND_U], q0[ND_U], q1[ND_U];
+#pragma unroll
+    for (int u = 0; u < ND_U; ++u) { const int i = 256 * wv + 64 * u + lane; v[u] = i < sl.n ? sl.P[sl.lo + i] : -1; }
+#pragma unroll
+    for (int u = 0; u < ND_U; ++u) {
+        const bool ok = v[u] >= 0;
+        const unsigned r = ok ? A.rank_xy[v[u]] : 0u;
+        rx[u] = (int)(r & 0xffffu); ry[u] = (int)(r >> 16);
+        q0[u] = ok ? A.adj_ptr[v[u]] : 0; q1[u] = ok ? A.adj_ptr[v[u] + 1] : 0;
+    }
+    int pvx, pvy;
+    nd_big_pivots(g, S, sl.m / 2, &pvx, &pvy);
+    int c[2][3] = { { 0, 0, 0 }, { 0, 0, 0 } };      // [x-cut, y-cut][A, B, S]
+#pragma unroll
+    for (int u = 0; u < ND_U; ++u) {
+        if (v[u] < 0) continue;
+        const bool lx = rx[u] < pvx, ly = ry[u] < pvy;
+        unsigned fl = 0;
+        for (int q = q0[u]; q < q1[u]; q += ND_NBR) {
+            int w2[ND_NBR], s2[ND_NBR]; unsigned r2[ND_NBR];
+#pragma unroll
+            for (int t = 0; t < ND_NBR; ++t) w2[t] = q + t < q1[u] ? A.adj_idx[q + t] : -1;
+#pragma unroll
+            for (int t = 0; t < ND_NBR; ++t) { s2[t] = w2[t] >= 0 ? A.setid[w2[t]] : -1; r2[t] = w2[t] >= 0 ? A.rank_xy[w2[t]] : 0u; }
+#pragma unroll
+            for (int t = 0; t < ND_NBR; ++t) if (s2[t] == h) {
+                if (lx && (int)(r2[t] & 0xffffu) >= pvx) fl |= 1u;
+                if (ly && (int)(r2[t] >> 16) >= pvy) fl |= 2u;
+            }
+        }
+        A.cut0[v[u]] = (unsigned char)fl;
+        c[0][0] += lx && !(fl & 1u); c[0][1] += !lx; c[0][2] += lx && (fl & 1u);
+        c[1][0] += ly && !(fl & 2u); c[1][1] += !ly; c[1][2] += ly && (fl & 2u);
+    }
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            int t = c[a][k];
+#pragma unroll
+            for (int o = 32; o >= 1; o >>= 1) t += __shfl_xor(t, o, 64);
+            if (lane == 0 && t) atomicAdd(&g.cls[j][a][k], t);
+        }
+}
+
+__global__ __launch_bounds__(1024) void nd_bigD_kernel(int L, int W, nd_args A, nd_big* __restrict__ G)
+{
+    __shared__ nd_gl<16> S;
+    const int kset = blockIdx.x / W, j = blockIdx.x % W;
+    const int h = (1 << L) + kset;
+    pg_nd_set d = A.sets[h];
+    const int m = d.size;
+    if (m <= 0) return;
+    const int* __restrict__ P = ((L & 1) ? A.perm1 : A.perm0) + d.lo;
+    int* __restrict__ Pn = ((L & 1) ? A.perm0 : A.perm1) + d.lo;
+    const int lo = j * ND_SL, n = min(ND_SL, m - lo);
+    if (m <= A.leaf) {                                                      // (a leaf on a big level: slice 0 writes it)
+        if (j == 0) { for (int i = threadIdx.x; i < m; i += 1024) A.order[d.out + i] = P[i]; if (threadIdx.x == 0) { d.kind = 1; A.sets[h] = d; } }
+        return;
+    }
+    if (n <= 0) return;
+    const nd_big& g = G[kset];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    int v[ND_U]; unsigned r[ND_U]; unsigned char f[ND_U];
+#pragma unroll
+    for (int u = 0; u < ND_U; ++u) { const int i = 256 * wv + 64 * u + lane; v[u] = i < n ? P[lo + i] : -1; }
+#pragma unroll
+    for (int u = 0; u < ND_U; ++u) { r[u] = v[u] >= 0 ? A.rank_xy[v[u]] : 0u; f[u] = v[u] >= 0 ? A.cut0[v[u]] : 0; }
+    int pvx, pvy;
+    nd_big_pivots(g, S, m / 2, &pvx, &pvy);
+    const double x0 = nd_unkey(g.bb[0]), x1 = nd_unkey(g.bb[1]), y0 = nd_unkey(g.bb[2]), y1 = nd_unkey(g.bb[3]);
+    const bool byx = (x1 - x0) >= (y1 - y0);
+    const bool two = m >= A.both_axes;
+    int tot[2][3] = { { 0, 0, 0 }, { 0, 0, 0 } }, bef[2][3] = { { 0, 0, 0 }, { 0, 0, 0 } };
+    for (int jj = 0; jj < W; ++jj)
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int k = 0; k < 3; ++k) { const int t = g.cls[jj][a][k]; tot[a][k] += t; if (jj < j) bef[a][k] += t; }
+    const int cx_ = tot[0][2], cy_ = tot[1][2];
+    const int c0 = byx ? cx_ : cy_, c1 = byx ? cy_ : cx_;
+    const int win = (two && c1 < c0) ? 1 : 0;
+    const bool wbx = win == 0 ? byx : !byx;
+    const int wa = wbx ? 0 : 1;
+    const int pv = wbx ? pvx : pvy, h2 = m / 2, nS = tot[wa][2], nA = h2 - nS, nB = m - h2;
+    if (nA <= 0 || nB <= 0) {                                               // degenerate cut: index order (every slice its part)
+        for (int i = threadIdx.x; i < n; i += 1024) A.order[d.out + lo + i] = P[lo + i];
+        if (j == 0 && threadIdx.x == 0) { d.kind = 1; A.sets[h] = d; }
+        return;
+    }
+    bool isA[ND_U], isB[ND_U], isS[ND_U];
+    int cA = 0, cB = 0, cS = 0;
+#pragma unroll
+    for (int u = 0; u < ND_U; ++u) {
+        const bool ok = v[u] >= 0, lower = ok && (int)(wbx ? (r[u] & 0xffffu) : (r[u] >> 16)) < pv, cutf = (f[u] & (wbx ? 1u : 2u)) != 0;
+        isS[u] = lower && cutf; isA[u] = lower && !cutf; isB[u] = ok && !lower;
+        cA += isA[u]; cB += isB[u]; cS += isS[u];
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) { cA += __shfl_xor(cA, o, 64); cB += __shfl_xor(cB, o, 64); cS += __shfl_xor(cS, o, 64); }
+    if (lane == 0) { S.ired[0][wv] = cA; S.ired[1][wv] = cB; S.ired[2][wv] = cS; }
+    __syncthreads();
+    int bA = bef[wa][0], bB = bef[wa][1], bS = bef[wa][2];
+    for (int k = 0; k < wv; ++k) { bA += S.ired[0][k]; bB += S.ired[1][k]; bS += S.ired[2][k]; }
+#pragma unroll
+    for (int u = 0; u < ND_U; ++u) {
+        const unsigned long long mA = __ballot(isA[u]), mB = __ballot(isB[u]), mS = __ballot(isS[u]);
+        const unsigned long long below = (1ull << lane) - 1ull;
+        if (isA[u]) { Pn[bA + __popcll(mA & below)] = v[u]; A.setid[v[u]] = 2 * h; }
+        if (isB[u]) { Pn[nA + bB + __popcll(mB & below)] = v[u]; A.setid[v[u]] = 2 * h + 1; }
+        if (isS[u]) { A.order[d.out + nA + nB + bS + __popcll(mS & below)] = v[u]; A.setid[v[u]] = 0; }
+        bA += __popcll(mA); bB += __popcll(mB); bS += __popcll(mS);
+    }
+    if (j == 0 && threadIdx.x == 0) {
+        d.kind = 2; d.nA = nA; d.nB = nB; A.sets[h] = d;
+        pg_nd_set a; a.lo = d.lo; a.size = nA; a.out = d.out; a.kind = 0; a.nA = 0; a.nB = 0; A.sets[2 * h] = a;
+        pg_nd_set b; b.lo = d.lo + nA; b.size = nB; b.out = d.out + nA; b.kind = 0; b.nA = 0; b.nB = 0; A.sets[2 * h + 1] = b;
+    }
+}
+
+__global__ void nd_big_init_kernel(nd_big* __restrict__ G, int nsets)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int per = (int)(sizeof(nd_big) / sizeof(int));
+    if (i >= nsets * per) return;
+    int* w = reinterpret_cast<int*>(G) + i;
+    const int k = i % per;
+    // the box keys: minima start at the largest key, maxima at the smallest; everything else zero
+    if (k == 0 || k == 1 || k == 4 || k == 5) *w = (int)0xffffffff; else *w = 0;      // bb[0] (min x) and bb[2] (min y): all ones
+}
+
 } // namespace
 
 int pg_nd_levels(int n, int leaf)
@@ -588,10 +829,20 @@ int pg_nd_start(dsss_ctx* c, hipStream_t st, const pg_nd_buffers& B, const int* 
     A.perm0 = B.perm0; A.perm1 = B.perm1; A.setid = B.setid; A.cut0 = B.cut0; A.rank_xy = reinterpret_cast<const unsigned*>(B.cut1); A.order = B.order; A.sets = B.sets;
     A.fail = reinterpret_cast<int*>(B.sets);                          // (heap node 0 is nobody's: its first word is the failure flag, zeroed with the sets)
     {   // a set of level L holds at most ceil(n / 2^L) nodes (the larger child is the upper half)
+        nd_big* Gb = reinterpret_cast<nd_big*>(reinterpret_cast<char*>(B.sets + pg_nd_set_count(B.nlev)) + 4 * ND_NB * sizeof(int) + 64);      // behind the rank kernels' scratch: one record per big set (at most 16 sets of more than 4 096 nodes)
+        const bool big_ok = !(getenv("DSSS_PG_ND_BIG") && atoi(getenv("DSSS_PG_ND_BIG")) == 0) && n <= ND_SL * ND_WMAX;
         long long bound = n;
         for (int L = 0; L < B.nlev; ++L) {
             const unsigned nsets = 1u << L;
-            if (bound > 1024 * ND_U) hipLaunchKernelGGL(nd_level_kernel, dim3(nsets), dim3(ND_T), 0, st, L, A);
+            if (bound > 1024 * ND_U && big_ok) {
+                const int W = (int)((bound + ND_SL - 1) / ND_SL);
+                hipLaunchKernelGGL(nd_big_init_kernel, dim3((nsets * (unsigned)(sizeof(nd_big) / sizeof(int)) + 255) / 256), dim3(256), 0, st, Gb, (int)nsets);
+                hipLaunchKernelGGL(nd_bigA_kernel, dim3(nsets * W), dim3(1024), 0, st, L, W, A, Gb);
+                hipLaunchKernelGGL(nd_bigB_kernel, dim3(nsets * W), dim3(1024), 0, st, L, W, A, Gb);
+                hipLaunchKernelGGL(nd_bigC_kernel, dim3(nsets * W), dim3(1024), 0, st, L, W, A, Gb);
+                hipLaunchKernelGGL(nd_bigD_kernel, dim3(nsets * W), dim3(1024), 0, st, L, W, A, Gb);
+            }
+            else if (bound > 1024 * ND_U) hipLaunchKernelGGL(nd_level_kernel, dim3(nsets), dim3(ND_T), 0, st, L, A);
             else if (bound > 256 * ND_U) hipLaunchKernelGGL(nd_level_group_kernel<1024>, dim3(nsets), dim3(1024), 0, st, L, A);
             else if (bound > 64 * ND_U) hipLaunchKernelGGL(nd_level_group_kernel<256>, dim3(nsets), dim3(256), 0, st, L, A);
             else hipLaunchKernelGGL(nd_level_group_kernel<64>, dim3((nsets + 3) / 4), dim3(256), 0, st, L, A);
