@@ -570,7 +570,7 @@ __global__ __launch_bounds__(256) void pg_scatter_lc_kernel(int n, int ne, int n
     if (eo[e] < mp0 || eo[e] >= mp1) return;
     const int code = dest[2 * ns - 1 + e];
     const double h_ab = Ji[(size_t)(n + e) * 36 + b * 6 + a] * ew[(size_t)e * 6 + b];               // (Ji^T W)(a, b)
-    if (code >= 0) Lvals[(size_t)(code >> 1) * 36 + ((code & 1) ? b * 6 + a : el)] += h_ab;
+    if (code >= 0) atomicAdd(&Lvals[(size_t)(code >> 1) * 36 + ((code & 1) ? b * 6 + a : el)], h_ab);      // (atomic: two loop closures between the same two poses -- the pipeline's selection never produces them, a caller of dsss_posegraph_solve_edges may -- add to the same block; a plain += lost one of them now and then)
     else (code <= -2 ? aval_if + (size_t)(-2 - code) * 36 : aval + (size_t)(2 * ns - 1 + e) * 36)[el] = h_ab;
 }
 

@@ -10,6 +10,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <mutex>
 #include <numeric>
 #include <thread>
@@ -440,6 +441,9 @@ void pg_symbolic(int ns, const std::vector<std::pair<int, int>>& edges, int ncha
         } else S.order.clear();
         if (tv) fprintf(stderr, "[dsss pg symbolic] ordering on the device: %s (waited %.2f ms for it after the adjacency)\n", ordered ? "used" : "NOT used, the host orders", tms(q0a, tnow()));
     }
+    const bool nd_check = ordered && getenv("DSSS_PG_ND") && !strcmp(getenv("DSSS_PG_ND"), "check");      // diagnostic: order on the host as well and compare
+    std::vector<int> dev_order; std::vector<nd_tree> dev_pool; int dev_root = -1;
+    if (nd_check) { dev_order.swap(S.order); dev_pool.swap(pool); dev_root = root; root = -1; ordered = false; }
     if (!ordered) {
         std::vector<int> nodes(ns); std::iota(nodes.begin(), nodes.end(), 0);
         std::vector<char> side(ns, 0), side2(ns, 0);
@@ -451,6 +455,14 @@ void pg_symbolic(int ns, const std::vector<std::pair<int, int>>& edges, int ncha
         nd_ctx C{ adj_ptr.data(), adj_idx.data(), cx, cy, side.data(), side2.data(), opt.leaf, opt.nd_both_axes, opt.nd_geo_first, S.nparts > 1 ? part : nullptr, iface.data(), forced.data(), &pool, &mu, tv ? nd_ns : nullptr };
         root = nd_order(nodes, C, S.order, 0);
         if (tv) fprintf(stderr, "[dsss pg symbolic] nd_order thread-time: candidates %.2f ms, final boundary %.2f ms, leaves %.2f ms\n", nd_ns[1] / 1e6, nd_ns[2] / 1e6, nd_ns[4] / 1e6);
+    }
+    if (nd_check) {
+        int bad = -1;
+        for (int i = 0; i < ns; ++i) if (dev_order[i] != S.order[i]) { bad = i; break; }
+        if (bad >= 0) fprintf(stderr, "[dsss pg symbolic] DEVICE ORDER DIFFERS from the host's at position %d of %d: %d against %d (x %.17g y %.17g | x %.17g y %.17g)\n", bad, ns, dev_order[bad], S.order[bad],
+                              cx[dev_order[bad]], cy[dev_order[bad]], cx[S.order[bad]], cy[S.order[bad]]);
+        else fprintf(stderr, "[dsss pg symbolic] device order == host order (%d nodes)\n", ns);
+        (void)dev_root;
     }
     const auto q1 = tnow();
     S.perm.assign(ns, 0);

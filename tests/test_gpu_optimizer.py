@@ -94,7 +94,9 @@ def test_lc_selection_and_posegraph_parity(ctx, orc, survey):
 
 
 def test_posegraph_edges_api_small_cases(ctx, orc):
-    """explicit chains: no LC; one LC; LC between adjacent poses (coincides with a chain coupling); long interior segments"""
+    """explicit chains: no LC; one LC; LC between adjacent poses (coincides with a chain coupling); long interior segments; the SAME two
+    poses closed twice (two factors on one block: both count, as in the oracle's dense normal equations -- a plain += in the scatter lost one
+    of them now and then) and once more in the other direction"""
     n = 300
     rng = np.random.default_rng(3)
     dr = np.zeros((n, 6)); dr[:, 3] = 0.05 * np.arange(n); dr[:, 2] = 0.01 * np.sin(np.arange(n) / 30.0)
@@ -110,7 +112,8 @@ def test_posegraph_edges_api_small_cases(ctx, orc):
         rel = np.concatenate([np.array(Tr.R), np.array(Tr.t)]); rel[10] += dy
         e["rel"][0] = rel; e["var"][0] = [1e-6, 1e-6, 1e-5, 1e-3, 0.5, 1e-2]
         return e
-    cases = [np.zeros(0, orc.LCEDGE_DTYPE), edge(20, 280, 0.3), np.concatenate([edge(10, 290, 0.2), edge(60, 240, -0.1), edge(149, 150, 0.05), edge(100, 151, 0.1)])]
+    cases = [np.zeros(0, orc.LCEDGE_DTYPE), edge(20, 280, 0.3), np.concatenate([edge(10, 290, 0.2), edge(60, 240, -0.1), edge(149, 150, 0.05), edge(100, 151, 0.1)]),
+             np.concatenate([edge(10, 290, 0.2), edge(10, 290, 0.25), edge(60, 240, -0.1), edge(240, 60, 0.08)])]
     for edges in cases:
         o_out, o_stats = orc.pg_solve(dr, edges)
         g_out, g_stats = ctx.posegraph_solve_edges(dr, edges)

@@ -12,7 +12,7 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 
-SAME_BITS_PG = [("DSSS_PG_PANEL", "diag3"), ("DSSS_PG_PACK_COST", "300"), ("DSSS_PG_RSU32", "0"), ("DSSS_PG_RSU32", "1000"), ("DSSS_PG_RSU", "0"), ("DSSS_PG_RSU", "64"), ("DSSS_PG_LISTS", "host"), ("DSSS_PG_EARLY", "0"), ("DSSS_PG_ND", "host"),
+SAME_BITS_PG = [("DSSS_PG_PANEL", "diag3"), ("DSSS_PG_PACK_COST", "300"), ("DSSS_PG_RSU32", "0"), ("DSSS_PG_RSU32", "1000"), ("DSSS_PG_RSU", "0"), ("DSSS_PG_RSU", "64"), ("DSSS_PG_LISTS", "host"), ("DSSS_PG_EARLY", "0"), ("DSSS_PG_ND", "host"), ("DSSS_PG_ND_BIG", "0"),
                 ("DSSS_SYM_THREADS", "1"), ("DSSS_SYM_THREADS", "5")]
 SAME_OPTIMUM_PG = [("DSSS_PG_CHUNK", "8"), ("DSSS_PG_CHUNK", "24"), ("DSSS_PG_BIN_COST", "300"), ("DSSS_PG_BIN_COST", "1200"), ("DSSS_PG_ND_BOTH", "1000000"),
                    ("DSSS_PG_LEAF", "12"), ("DSSS_PG_RELAX_ZERO", "0"), ("DSSS_PG_RELAX_FLOPS", "1.0"), ("DSSS_PG_RELAX_SMALL", "1.0"), ("DSSS_PG_RELAX_ABS", "1e6")]
@@ -107,4 +107,22 @@ def test_matcher_switch_reproduces_the_default():
     assert rows > 50
     with _env("DSSS_MT_GRID", "0"):
         assert run() == (href, rows)
+    c.close()
+
+
+def test_device_ordering_on_degenerate_geometry():
+    """the nested dissection on the device against the host's on separator coordinates chosen against it: every y equal (one bucket, one
+    extent zero), duplicated loop closures, a graph below the both-axes threshold -- the same bits"""
+    from diasss_amd import capi
+    from tests.test_gpu_configs import _lawnmower_graph
+    c = capi.Context(max_frames=2)
+    for legs, per, nlc, flat in ((4, 3000, 900, True), (6, 2000, 1500, False), (2, 400, 12, True)):
+        dr, gt, edges = _lawnmower_graph(legs, per, nlc, seed=29)
+        if flat:
+            dr = dr.copy(); dr[:, 4] = 0.0                                 # all poses on one line: y extent exactly zero
+        edges = np.concatenate([edges, edges[: max(1, len(edges) // 7)]])   # duplicated loop closures
+        with _env("DSSS_PG_ND", "host"):
+            ph, sh = c.posegraph_solve_edges(dr, edges)
+        pd, sd = c.posegraph_solve_edges(dr, edges)
+        assert hashlib.sha1(pd.tobytes()).hexdigest() == hashlib.sha1(ph.tobytes()).hexdigest() and (sd == sh).all()
     c.close()
