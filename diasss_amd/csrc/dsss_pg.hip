@@ -559,19 +559,35 @@ __global__ __launch_bounds__(256) void pg_scatter_base_kernel(int ns, const int*
         else (cc <= -2 ? aval_if + (size_t)(-2 - cc) * 36 : aval + (size_t)(ns + k) * 36)[e] = S[e];
     }
 }
-// LC off-diagonal blocks H(a, b) = Ji^T W (added after the chain couplings; (a,b) is unique per edge)
+// LC off-diagonal blocks H(a, b) = Ji^T W, added after the chain couplings.  The pipeline's per-ping selection gives every unordered
+// pose pair at most one loop closure; a caller of dsss_posegraph_solve_edges may pass several (in either direction).  Those land on
+// ONE block of the factor: the host chains them in edge order (lc_link[2 e] = e is the first of its group, lc_link[2 e + 1] = the next
+// member or -1; NULL when no pair repeats) and the first member's threads add the whole group -- one writer per element, the sum in
+// edge order whatever the number of duplicates: same bits every run.  (Round 4 added them atomically, which is order-independent for
+// two addends on an empty block only.)
 __global__ __launch_bounds__(256) void pg_scatter_lc_kernel(int n, int ne, int ns, const double* __restrict__ Ji, const double* __restrict__ ew,
                                                             const int* __restrict__ dest, double* __restrict__ Lvals, double* __restrict__ aval,
-                                                            double* __restrict__ aval_if, const int* __restrict__ eo, int mp0, int mp1)
+                                                            double* __restrict__ aval_if, const int* __restrict__ eo, int mp0, int mp1, const int* __restrict__ lc_link)
 {
     const long long t = (long long)blockIdx.x * 256 + threadIdx.x;          // one thread per element of the 6 x 6 block
-    const int e = (int)(t / 36), el = (int)(t - 36LL * e), a = el / 6, b = el - 6 * a;
+    const int e = (int)(t / 36), el = (int)(t - 36LL * e);
     if (e >= ne) return;
     if (eo[e] < mp0 || eo[e] >= mp1) return;
     const int code = dest[2 * ns - 1 + e];
-    const double h_ab = Ji[(size_t)(n + e) * 36 + b * 6 + a] * ew[(size_t)e * 6 + b];               // (Ji^T W)(a, b)
-    if (code >= 0) atomicAdd(&Lvals[(size_t)(code >> 1) * 36 + ((code & 1) ? b * 6 + a : el)], h_ab);      // (atomic: two loop closures between the same two poses -- the pipeline's selection never produces them, a caller of dsss_posegraph_solve_edges may -- add to the same block; a plain += lost one of them now and then)
-    else (code <= -2 ? aval_if + (size_t)(-2 - code) * 36 : aval + (size_t)(2 * ns - 1 + e) * 36)[el] = h_ab;
+    if (code >= 0) {                                                        // element el of the factor's block (a group shares code >> 1)
+        if (lc_link && !lc_link[2 * e]) return;
+        double* dst = Lvals + (size_t)(code >> 1) * 36 + el;
+        double v = *dst;
+        for (int q = e; q >= 0; q = lc_link ? lc_link[2 * q + 1] : -1) {
+            const int tr = dest[2 * ns - 1 + q] & 1;                        // this member's block is stored transposed
+            const int a = tr ? el % 6 : el / 6, b = tr ? el / 6 : el % 6;
+            v += Ji[(size_t)(n + q) * 36 + b * 6 + a] * ew[(size_t)q * 6 + b];      // (Ji^T W)(a, b)
+        }
+        *dst = v;
+    } else {                                                                // the fronts' value array: a slot per edge, summed by the extend-add
+        const int a = el / 6, b = el - 6 * a;
+        (code <= -2 ? aval_if + (size_t)(-2 - code) * 36 : aval + (size_t)(2 * ns - 1 + e) * 36)[el] = Ji[(size_t)(n + e) * 36 + b * 6 + a] * ew[(size_t)e * 6 + b];
+    }
 }
 
 // update matrices that cross from this rank's interior into the interface, packed (6b x 6b lower block triangle, then 6b of
@@ -2371,7 +2387,17 @@ static int pg_solve_impl(dsss_ctx* c, const double* dr6, int total, const dsss_l
                 if (!nd_started) return false;
                 if (hipEventSynchronize(ndB.done) != hipSuccess) { (void)hipGetLastError(); return false; }
                 if (ndB.h_sets[0].lo != 0) return false;              // (the failure flag of the level kernels)
-                for (int i = 0; i < ns; ++i) if ((unsigned)ndB.h_order[i] >= (unsigned)ns) return false;      // a position nobody filled: the levels did not suffice
+                {   // the order must be a permutation of the separators before the symbolic phase may index with it: a position nobody
+                    // filled (the levels did not suffice) or a separator placed twice sends the solve to the host ordering
+                    std::vector<unsigned long long> seen(((size_t)ns + 63) / 64, 0ull);
+                    for (int i = 0; i < ns; ++i) {
+                        const unsigned v = (unsigned)ndB.h_order[i];
+                        if (v >= (unsigned)ns) return false;
+                        unsigned long long& w = seen[v >> 6]; const unsigned long long bit = 1ull << (v & 63);
+                        if (w & bit) return false;
+                        w |= bit;
+                    }
+                }
                 order.assign(ndB.h_order, ndB.h_order + ns);
                 top6.assign(reinterpret_cast<const int*>(ndB.h_sets), reinterpret_cast<const int*>(ndB.h_sets) + 64 * 6);
                 return true;
@@ -2394,7 +2420,15 @@ static int pg_solve_impl(dsss_ctx* c, const double* dr6, int total, const dsss_l
     // device state
     pg_dev dv;
     int rc = DSSS_OK;
-#define TRY(x) do { rc = (x); if (rc) { dv.release(); return rc; } } while (0)
+    // every error exit: let the analysis thread go, wait for it AND for what it queued on the ordering's stream, and only then hand the
+    // arena back (released first, the next solve could reuse memory the ordering's kernels of this one still write)
+    auto abandon = [&] {
+        coords_guard.set(); nd_guard.set();
+        if (sym_thread.joinable()) sym_thread.join();
+        if (c->pg_nd_stream && hipStreamSynchronize(c->pg_nd_stream) != hipSuccess) (void)hipGetLastError();
+        dv.release();
+    };
+#define TRY(x) do { rc = (x); if (rc) { abandon(); return rc; } } while (0)
     // DR rows on the device first: the separator coordinates for the ordering come back from there (host reads of the
     // frames' pinned copies are slow).  The analysis thread is started BEFORE they are back and before the rest of this thread's
     // preparation (the level-1 chain of the device's chain condensation, the segment orders): it builds its adjacency first and waits for
@@ -2419,7 +2453,7 @@ static int pg_solve_impl(dsss_ctx* c, const double* dr6, int total, const dsss_l
             e = hipGetLastError();
         }
         if (e == hipSuccess) { hipLaunchKernelGGL(pg_sep_xy_kernel, dim3((ns + 255) / 256), dim3(256), 0, c->stream, ns, d_sep, d_dr6, d_sxy); e = hipGetLastError(); }
-        if (e != hipSuccess) { dv.release(); HIPCHK(c, e); }
+        if (e != hipSuccess) { abandon(); HIPCHK(c, e); }
     }
     if (dev_nd) {   // buffers of the device ordering (this thread owns the arena), the event its stream waits for, then the analysis thread may queue it
         const int ne_red = (ns - 1) + ne, nlev_max = pg_nd_levels(ns, 4);       // (levels: sized for a leaf of 4, the smallest DSSS_PG_LEAF makes sense with)
@@ -2434,7 +2468,7 @@ static int pg_solve_impl(dsss_ctx* c, const double* dr6, int total, const dsss_l
             if (c->pg_nd_host) hipHostFree(c->pg_nd_host);
             c->pg_nd_host = nullptr; c->pg_nd_host_cap = 0;
             hipError_t e = hipHostMalloc((void**)&c->pg_nd_host, (host_ints + host_ints / 2) * sizeof(int), hipHostMallocDefault);
-            if (e != hipSuccess) { dv.release(); HIPCHK(c, e); }
+            if (e != hipSuccess) { abandon(); HIPCHK(c, e); }
             c->pg_nd_host_cap = host_ints + host_ints / 2;
         }
         ndB.h_sets = reinterpret_cast<pg_nd_set*>(c->pg_nd_host); ndB.h_order = c->pg_nd_host + 64 * 6 + 16;
@@ -2443,7 +2477,7 @@ static int pg_solve_impl(dsss_ctx* c, const double* dr6, int total, const dsss_l
         if (e == hipSuccess && !c->pg_nd_dep) e = hipEventCreateWithFlags(&c->pg_nd_dep, hipEventDisableTiming);
         if (e == hipSuccess && !c->pg_nd_done) e = hipEventCreateWithFlags(&c->pg_nd_done, hipEventDisableTiming);
         if (e == hipSuccess) e = hipEventRecord(c->pg_nd_dep, c->stream);        // behind pg_sep_xy_kernel
-        if (e != hipSuccess) { dv.release(); HIPCHK(c, e); }
+        if (e != hipSuccess) { abandon(); HIPCHK(c, e); }
         ndB.done = c->pg_nd_done;
         nd_ok = true;
     }
@@ -2452,7 +2486,7 @@ static int pg_solve_impl(dsss_ctx* c, const double* dr6, int total, const dsss_l
     {   // the coordinates come back while the analysis builds its adjacency: hand them over
         hipError_t e = hipMemcpyAsync(sxy.data(), d_sxy, sxy.size() * sizeof(double), hipMemcpyDeviceToHost, c->stream);
         if (e == hipSuccess) e = hipStreamSynchronize(c->stream);      // the library's stream does not synchronise with the null stream
-        if (e != hipSuccess) { dv.release(); HIPCHK(c, e); }
+        if (e != hipSuccess) { abandon(); HIPCHK(c, e); }
         for (int k = 0; k < ns; ++k) { cx[k] = sxy[2 * (size_t)k]; cy[k] = sxy[2 * (size_t)k + 1]; }
         coords_guard.set();
     }
@@ -2461,10 +2495,10 @@ static int pg_solve_impl(dsss_ctx* c, const double* dr6, int total, const dsss_l
         for (int k = 0; k < 9; ++k) emeas[e].R[k] = edges[e].rel[k];
         for (int k = 0; k < 3; ++k) emeas[e].t[k] = edges[e].rel[9 + k];
         for (int k = 0; k < 6; ++k) {
-            if (!(edges[e].var[k] > 0) || !std::isfinite(edges[e].var[k])) { dv.release(); DSSS_FAIL(c, DSSS_E_NUMERIC, "LC edge %d: variance %d is not finite and positive", e, k); }
+            if (!(edges[e].var[k] > 0) || !std::isfinite(edges[e].var[k])) { abandon(); DSSS_FAIL(c, DSSS_E_NUMERIC, "LC edge %d: variance %d is not finite and positive", e, k); }
             ew[(size_t)e * 6 + k] = 1.0 / std::sqrt(edges[e].var[k]);
         }
-        for (int k = 0; k < 12; ++k) if (!std::isfinite(edges[e].rel[k])) { dv.release(); DSSS_FAIL(c, DSSS_E_NUMERIC, "LC edge %d: relative pose is not finite", e); }
+        for (int k = 0; k < 12; ++k) if (!std::isfinite(edges[e].rel[k])) { abandon(); DSSS_FAIL(c, DSSS_E_NUMERIC, "LC edge %d: relative pose is not finite", e); }
     }
     // level-1 chain = true separators merged with the chunk ends 0, chunk, 2 chunk ...; segment orders: only the device reads them
     const double t_m0 = ms_since(T0);
@@ -2504,6 +2538,27 @@ static int pg_solve_impl(dsss_ctx* c, const double* dr6, int total, const dsss_l
     for (int i = 0; i < n; ++i) adj_ptr[i + 1] += adj_ptr[i];
     { std::vector<int> fill(adj_ptr.begin(), adj_ptr.end() - 1);
       for (int e = 0; e < ne; ++e) { adj_edge[fill[ea[e]]++] = e << 1; adj_edge[fill[eb[e]]++] = (e << 1) | 1; } }
+    // loop closures that repeat an unordered pose pair (see pg_scatter_lc_kernel).  The pipeline's edges -- a < b, b strictly
+    // ascending -- cannot: they skip the sort
+    std::vector<int> lc_link;
+    {
+        bool plain = true;
+        for (int e = 0; e < ne && plain; ++e) plain = ea[e] < eb[e] && (e == 0 || eb[e - 1] < eb[e]);
+        if (!plain) {
+            std::vector<std::pair<unsigned long long, int>> key(ne);
+            for (int e = 0; e < ne; ++e) key[e] = { ((unsigned long long)(unsigned)std::min(ea[e], eb[e]) << 32) | (unsigned)std::max(ea[e], eb[e]), e };
+            std::sort(key.begin(), key.end());                           // (pair, edge index): the members of a group in edge order
+            bool dups = false;
+            for (int k = 0; k + 1 < ne && !dups; ++k) dups = key[k].first == key[k + 1].first;
+            if (dups) {
+                lc_link.assign((size_t)2 * ne, -1);
+                for (int k = 0; k < ne; ++k) {
+                    lc_link[2 * (size_t)key[k].second] = (k == 0 || key[k - 1].first != key[k].first) ? 1 : 0;
+                    if (k + 1 < ne && key[k + 1].first == key[k].first) lc_link[2 * (size_t)key[k].second + 1] = key[k + 1].second;
+                }
+            }
+        }
+    }
     // ---- early device set-up (nothing here reads S)
     pose_t *d_X, *d_Xn, *d_meas, *d_emeas; int *d_ea, *d_eb, *d_eo, *d_adj_ptr, *d_adj_edge, *d_perm;
     double *d_ew, *d_r, *d_Ji, *d_D, *d_C, *d_g, *d_delta, *d_E, *d_Dl, *d_gi, *d_sDL, *d_sDR, *d_sGL, *d_sGR, *d_sS, *d_L, *d_x, *d_part, *d_scal;
@@ -2517,6 +2572,7 @@ static int pg_solve_impl(dsss_ctx* c, const double* dr6, int total, const dsss_l
     TRY(dv.alloc(c, &d_X, n)); TRY(dv.alloc(c, &d_Xn, n)); TRY(dv.alloc(c, &d_meas, n)); TRY(dv.upload(c, &d_emeas, emeas));
     TRY(dv.upload(c, &d_ea, ea)); TRY(dv.upload(c, &d_eb, eb)); TRY(dv.upload(c, &d_eo, eo)); TRY(dv.upload(c, &d_ew, ew));
     TRY(dv.upload(c, &d_adj_ptr, adj_ptr)); TRY(dv.upload(c, &d_adj_edge, adj_edge));
+    int* d_lc_link = nullptr; if (!lc_link.empty()) TRY(dv.upload(c, &d_lc_link, lc_link));
     TRY(dv.alloc(c, &d_r, (size_t)nf * 6)); TRY(dv.alloc(c, &d_Ji, (size_t)nf * 36));
     TRY(dv.alloc(c, &d_D, (size_t)n * 36)); TRY(dv.alloc(c, &d_C, (size_t)n * 36)); TRY(dv.alloc(c, &d_g, (size_t)n * 6)); TRY(dv.alloc(c, &d_delta, (size_t)n * 6));
     TRY(dv.alloc(c, &d_E, (size_t)n * 36)); TRY(dv.alloc(c, &d_Dl, (size_t)n * 36)); TRY(dv.alloc(c, &d_gi, (size_t)n * 6));
@@ -2531,12 +2587,12 @@ static int pg_solve_impl(dsss_ctx* c, const double* dr6, int total, const dsss_l
     double* d_rdiag; TRY(dv.alloc(c, &d_rdiag, (size_t)ns * 6));      // reciprocal diagonals of the binned columns' pivots (forward -> backward substitution)
     TRY(dv.alloc(c, &d_x, (size_t)ns * 6)); TRY(dv.alloc(c, &d_part, (size_t)nblk)); TRY(dv.alloc(c, &d_scal, 8)); TRY(dv.alloc(c, &d_fail, 1)); TRY(dv.alloc(c, &d_red, 8));
     hipStream_t st = c->stream;
-#define HCK(x) do { hipError_t _e = (x); if (_e != hipSuccess) { c->err = std::string(#x) + ": " + hipGetErrorString(_e); dv.release(); return DSSS_E_HIP; } } while (0)
+#define HCK(x) do { hipError_t _e = (x); if (_e != hipSuccess) { c->err = std::string(#x) + ": " + hipGetErrorString(_e); abandon(); return DSSS_E_HIP; } } while (0)
     // sums over the factors are partial on every rank: one small all-reduce makes them global (and identical everywhere)
     auto reduce_scalars = [&](double* host3, int* failed) -> int {
         if (world > 1) {
             hipLaunchKernelGGL(pg_comm_scal_kernel, dim3(1), dim3(64), 0, st, d_scal, d_fail, d_red);
-            int rc2 = dsss_comm_allreduce(c, d_red, 4, st); if (rc2) { dv.release(); return rc2; }
+            int rc2 = dsss_comm_allreduce(c, d_red, 4, st); if (rc2) { abandon(); return rc2; }
             double h4[4];
             HCK(hipMemcpyAsync(h4, d_red, 4 * sizeof(double), hipMemcpyDeviceToHost, st));
             HCK(hipStreamSynchronize(st));
@@ -2580,7 +2636,7 @@ static int pg_solve_impl(dsss_ctx* c, const double* dr6, int total, const dsss_l
                 HCK(hipMemcpyAsync(&total_ok, d_total, sizeof(int), hipMemcpyDeviceToHost, st));
                 HCK(hipStreamSynchronize(st));
                 if (total_ok >= need_pairs) break;
-                if (attempt > 3) { dv.release(); DSSS_FAIL(c, DSSS_E_NUMERIC, "normal generator: not enough accepted attempts"); }
+                if (attempt > 3) { abandon(); DSSS_FAIL(c, DSSS_E_NUMERIC, "normal generator: not enough accepted attempts"); }
                 natt *= 2;
             }
         }
@@ -2702,7 +2758,7 @@ static int pg_solve_impl(dsss_ctx* c, const double* dr6, int total, const dsss_l
         if (nparts > 1) hipMemsetAsync(d_comm, 0, comm_total * sizeof(double), st);
         hipLaunchKernelGGL(pg_scatter_base_kernel, dim3((unsigned)(((long long)ns * 78 + 255) / 256)), dim3(256), 0, st, ns, d_t2, d_perm, d_D1, d_g1, d_s2DL, d_s2DR, d_s2GL, d_s2GR, d_s2S, d_dest, d_L, d_aval, d_x,
                            d_ifslot, d_avalif, d_xif, kp0, kp1);
-        if (ne > 0) hipLaunchKernelGGL(pg_scatter_lc_kernel, dim3((unsigned)(((long long)ne * 36 + 255) / 256)), dim3(256), 0, st, n, ne, ns, d_Ji, d_ew, d_dest, d_L, d_aval, d_avalif, d_eo, mp0, mp1);
+        if (ne > 0) hipLaunchKernelGGL(pg_scatter_lc_kernel, dim3((unsigned)(((long long)ne * 36 + 255) / 256)), dim3(256), 0, st, n, ne, ns, d_Ji, d_ew, d_dest, d_L, d_aval, d_avalif, d_eo, mp0, mp1, d_lc_link);
         if (nbins > 0) { dsss_scope s1(c, DSSS_K_PG_SUBTREE, bins_flops);      // flops of the binned columns
                          hipLaunchKernelGGL(pg_factor_subtree_kernel, dim3(nbins), dim3(256), 0, st, d_binperm + bin_lo, d_binptr, d_bincols, d_colptr, d_rlptr, d_rlcol, d_rlpos, d_mapptr, d_map, d_L, d_x, d_fail,
                                             d_binroot_ptr, d_binroot_idx, d_broot_b, d_broot_uoff, d_broot_of_col, d_anc_first, d_anc_rel, d_ubin, d_rdiag); }
@@ -2717,7 +2773,7 @@ static int pg_solve_impl(dsss_ctx* c, const double* dr6, int total, const dsss_l
         pre_bins = true;
     }
     sym_thread.join();
-    if (S.ownership_violations) { dv.release(); DSSS_FAIL(c, DSSS_E_STATE, "pose-graph analysis: %d separators with a higher-rank neighbour are not interface", S.ownership_violations); }
+    if (S.ownership_violations) { abandon(); DSSS_FAIL(c, DSSS_E_STATE, "pose-graph analysis: %d separators with a higher-rank neighbour are not interface", S.ownership_violations); }
     const double t_sym = ms_since(T1);
     const auto T2 = std::chrono::steady_clock::now();
     const int nfr = (int)S.f_c0.size(), npan = S.npanels;
@@ -2789,7 +2845,7 @@ static int pg_solve_impl(dsss_ctx* c, const double* dr6, int total, const dsss_l
         if (need > 0) TRY(dv.alloc(c, &d_bwp, need));
     }
     const int bwd_lds = (int)(((PG_PW * 6) * PG_BWD2_LD + PG_NB4 * 16 + 10 * (PG_PW * 6) + std::min(max_n6, PG_BWD2_SX) + 16) * sizeof(double));
-    if (bwd_lds > 160 * 1024) { dv.release(); DSSS_FAIL(c, DSSS_E_CAPACITY, "front of %d scalar rows: back-substitution needs %d B of LDS", max_n6, bwd_lds); }
+    if (bwd_lds > 160 * 1024) { abandon(); DSSS_FAIL(c, DSSS_E_CAPACITY, "front of %d scalar rows: back-substitution needs %d B of LDS", max_n6, bwd_lds); }
     {   // the back-substitution keeps L11, the slot sums and x2 in dynamic LDS
         hipFuncSetAttribute((const void*)pg_front_bwd2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipGetLastError();
@@ -2860,7 +2916,7 @@ static int pg_solve_impl(dsss_ctx* c, const double* dr6, int total, const dsss_l
                     // right-hand sides, summed over the ranks by ONE all-reduce; then the small replicated interface factorisation
                     if (n_pack > 0) hipLaunchKernelGGL(pg_comm_pack_kernel, dim3(n_pack), dim3(256), 0, st, d_pk_child, d_pk_row, d_PK);
                     { dsss_scope s8(c, DSSS_K_PG_COMM, (double)comm_total * 8);
-                      int rc2 = dsss_comm_allreduce(c, d_comm, comm_total - 8, st); if (rc2) { dv.release(); return rc2; } }
+                      int rc2 = dsss_comm_allreduce(c, d_comm, comm_total - 8, st); if (rc2) { abandon(); return rc2; } }
                     if (nif > 0) hipLaunchKernelGGL(pg_comm_xif_kernel, dim3(((int)nif + 255) / 256), dim3(256), 0, st, (int)nif, d_ifsep, d_perm, d_xif, d_x);
                     run_levels(SI, DI);
                     run_levels_bwd(SI, DI);
@@ -2904,7 +2960,7 @@ static int pg_solve_impl(dsss_ctx* c, const double* dr6, int total, const dsss_l
     const double t_lm = ms_since(T3);
     if (world > 1) {    // every rank holds its own poses (and the interface): zero the rest, sum -> the whole trajectory everywhere
         hipLaunchKernelGGL(pg_mask_own_kernel, dim3((n + 255) / 256), dim3(256), 0, st, n, d_X, mp0, mp1);
-        int rc2 = dsss_comm_allreduce(c, (double*)d_X, (size_t)n * 12, st); if (rc2) { dv.release(); return rc2; }
+        int rc2 = dsss_comm_allreduce(c, (double*)d_X, (size_t)n * 12, st); if (rc2) { abandon(); return rc2; }
     }
     if (poses12) {      // pose_t is 12 contiguous doubles (R row-major, t): straight into the caller's buffer
         static_assert(sizeof(pose_t) == 12 * sizeof(double), "pose_t layout");

@@ -128,7 +128,16 @@ __global__ void nd_brank_kernel(int n, const double* __restrict__ sxy, const nd_
         const int s = hist[a * ND_NB + b], e = hist[(2 + a) * ND_NB + b];      // (the fill cursors ended at the bucket ends)
         const int* __restrict__ mem = a ? memy : memx;
         int before = 0;
-        for (int q = s; q < e; ++q) { const int u = mem[q]; const double ku = sxy[2 * (size_t)u + a]; before += (ku < key || (ku == key && u < v)) ? 1 : 0; }
+        // (coordinate, index) order, made TOTAL: a NaN coordinate sorts behind every number and ties with other NaNs by index, so the
+        // ranks are a permutation whatever the caller's dead-reckoning rows hold (with `ku < key || ku == key` alone both tests fail on
+        // a NaN, two nodes share a rank, and the level kernels' partitions leave their slices)
+        const bool nk = key != key;
+        for (int q = s; q < e; ++q) {
+            const int u = mem[q]; const double ku = sxy[2 * (size_t)u + a];
+            const bool nu = ku != ku;
+            const bool less = nu ? false : (nk ? true : ku < key), same = (nu && nk) || ku == key;
+            before += (less || (same && u < v)) ? 1 : 0;
+        }
         (a ? rank_y : rank_x)[v] = s + before;
     }
     rank_xy[v] = (unsigned)rank_x[v] | ((unsigned)rank_y[v] << 16);      // (n <= 65536)
@@ -803,13 +812,17 @@ int pg_nd_levels(int n, int leaf)
 size_t pg_nd_set_count(int nlev) { return (size_t)1 << (nlev + 1); }      // (the children the last level may still write)
 
 // queue the whole ordering on `st` (asynchronous); sxy must be complete on that stream before
+// (called from the ANALYSIS thread of a solve: it reports through its return value only -- the context's error string belongs to the
+// thread that called the library, which turns a failure here into "order on the host")
 int pg_nd_start(dsss_ctx* c, hipStream_t st, const pg_nd_buffers& B, const int* redges_host, int nedges, int leaf, int both_axes)
 {
+    (void)c;
+#define ND_HIP(call) do { if ((call) != hipSuccess) { (void)hipGetLastError(); return DSSS_E_HIP; } } while (0)
     const int n = B.n;
     if (n <= 0 || n > 65536 || nedges < 0) return DSSS_E_ARG;
-    HIPCHK(c, hipMemcpyAsync(B.edges, redges_host, (size_t)nedges * 2 * sizeof(int), hipMemcpyHostToDevice, st));
-    HIPCHK(c, hipMemsetAsync(B.deg, 0, (size_t)n * sizeof(int), st));
-    HIPCHK(c, hipMemsetAsync(B.sets, 0, pg_nd_set_count(B.nlev) * sizeof(pg_nd_set), st));
+    ND_HIP(hipMemcpyAsync(B.edges, redges_host, (size_t)nedges * 2 * sizeof(int), hipMemcpyHostToDevice, st));
+    ND_HIP(hipMemsetAsync(B.deg, 0, (size_t)n * sizeof(int), st));
+    ND_HIP(hipMemsetAsync(B.sets, 0, pg_nd_set_count(B.nlev) * sizeof(pg_nd_set), st));
     {   // ranks: scratch = [4 x 1024 ints: histograms and fill cursors | the parameters of the bucket map] in front of the sets, bucket member lists in perm1 / order
         int* hist = reinterpret_cast<int*>(B.sets + pg_nd_set_count(B.nlev)); nd_rk* rk = reinterpret_cast<nd_rk*>(hist + 4 * ND_NB);
         hipLaunchKernelGGL(nd_minmax_kernel, dim3(1), dim3(ND_T), 0, st, n, B.sxy, rk, hist);
@@ -822,8 +835,8 @@ int pg_nd_start(dsss_ctx* c, hipStream_t st, const pg_nd_buffers& B, const int* 
     hipLaunchKernelGGL(nd_scan_kernel, dim3(1), dim3(ND_T), 0, st, n, B.deg, B.adj_ptr, B.adj_cur, B.perm0, B.setid);
     if (nedges > 0) hipLaunchKernelGGL(nd_fill_kernel, dim3((nedges + 255) / 256), dim3(256), 0, st, nedges, (const int2*)B.edges, B.adj_cur, B.adj_idx);
     { pg_nd_set& root = B.h_sets[0]; root.lo = 0; root.size = n; root.out = 0; root.kind = 0; root.nA = 0; root.nB = 0; }      // (page-locked: read by the copy below, overwritten by the download at the end -- same stream)
-    HIPCHK(c, hipMemcpyAsync(B.sets + 1, B.h_sets, sizeof(pg_nd_set), hipMemcpyHostToDevice, st));
-    HIPCHK(c, hipMemsetAsync(B.order, 0xff, (size_t)n * sizeof(int), st));      // (a position nobody fills says the levels did not suffice)
+    ND_HIP(hipMemcpyAsync(B.sets + 1, B.h_sets, sizeof(pg_nd_set), hipMemcpyHostToDevice, st));
+    ND_HIP(hipMemsetAsync(B.order, 0xff, (size_t)n * sizeof(int), st));      // (a position nobody fills says the levels did not suffice)
     nd_args A;
     A.n = n; A.leaf = leaf; A.both_axes = both_axes; A.sxy = B.sxy; A.rank_x = B.rank_x; A.rank_y = B.rank_y; A.adj_ptr = B.adj_ptr; A.adj_idx = B.adj_idx;
     A.perm0 = B.perm0; A.perm1 = B.perm1; A.setid = B.setid; A.cut0 = B.cut0; A.rank_xy = reinterpret_cast<const unsigned*>(B.cut1); A.order = B.order; A.sets = B.sets;
@@ -849,9 +862,15 @@ int pg_nd_start(dsss_ctx* c, hipStream_t st, const pg_nd_buffers& B, const int* 
             bound = (bound + 1) / 2;
         }
     }
-    HIPCHK(c, hipGetLastError());
-    HIPCHK(c, hipMemcpyAsync(B.h_order, B.order, (size_t)n * sizeof(int), hipMemcpyDeviceToHost, st));
-    HIPCHK(c, hipMemcpyAsync(B.h_sets, B.sets, 64 * sizeof(pg_nd_set), hipMemcpyDeviceToHost, st));      // heap nodes 1 .. 63: the top of the tree (the host's parallel column-structure pass follows it)
-    HIPCHK(c, hipEventRecord(B.done, st));
+    ND_HIP(hipGetLastError());
+    ND_HIP(hipMemcpyAsync(B.h_order, B.order, (size_t)n * sizeof(int), hipMemcpyDeviceToHost, st));
+    {   // heap nodes 1 .. 63: the top of the tree (the host's parallel column-structure pass follows it).  A small graph has fewer than 64
+        // set records: only those that exist come back, the rest of the host copy reads "not reached" (behind them lies scratch)
+        const size_t have = std::min<size_t>(64, pg_nd_set_count(B.nlev));
+        for (size_t k = have; k < 64; ++k) { pg_nd_set& z = B.h_sets[k]; z.lo = 0; z.size = 0; z.out = 0; z.kind = 0; z.nA = 0; z.nB = 0; }
+        ND_HIP(hipMemcpyAsync(B.h_sets, B.sets, have * sizeof(pg_nd_set), hipMemcpyDeviceToHost, st));
+    }
+    ND_HIP(hipEventRecord(B.done, st));
+#undef ND_HIP
     return DSSS_OK;
 }

@@ -78,36 +78,38 @@ def test_config_C2_full_pipeline_vs_oracle(orc):
 
 
 
-def test_config_C3_full_size_every_stage_vs_oracle(orc):
-    """BASELINE config 3 at FULL size, stage by stage against the oracle (the oracle's frames, pairs and mini-LMs run on a
-    thread pool: the C calls release the GIL): features of all 200 frames bit-exact (geo samples included), rows and kp7 of
-    every active pair bit-exact and every inactive pair empty in the oracle too, every mini-LM (same iteration count, relative
-    pose 1e-9), the selected loop-closure edges identical.  The oracle's own LM cannot finish 400 k poses (envelope Cholesky:
-    hours), so the last stage is held to the oracle's OBJECTIVE on the oracle's edges: the errors the device reports before and
-    after are orc_pg_error_at at the initial estimate and at its answer."""
+def _every_stage_vs_oracle(orc, F, N, M, seed, nfeatures=None, oracle_lm=False, min_active=300, min_lc=30000, min_edges=5000):
+    """One survey through the whole pipeline and, stage by stage, through the oracle (its frames, pairs and mini-LMs on a thread pool:
+    the C calls release the GIL): features of every frame bit-exact (geo samples included), rows and kp7 of every active pair bit-exact
+    and every inactive pair empty in the oracle too, every mini-LM (same iteration count, relative pose 1e-9), the selected loop-closure
+    edges identical; the pose graph against the oracle's OBJECTIVE on the oracle's edges at the device's initial estimate and at its answer,
+    and (oracle_lm = n) against the oracle's own LM on every n-th edge (same iterations, poses 1e-6)."""
     import time
     from concurrent.futures import ThreadPoolExecutor
     from diasss_amd.pipeline import Pipeline, all_pairs
     from diasss_amd.synth import Survey
-    F, N, M = 200, 2000, 1024
-    sv = Survey(F, N, M, seed=20240601 + 1, device="cuda:0")
+    sv = Survey(F, N, M, seed=seed, device="cuda:0")
     raws = [sv.frame(f) for f in range(F)]
     ins = [sv.inputs(f) for f in range(F)]
-    pipe = Pipeline(F)
+    pipe = Pipeline(F, nfeatures=nfeatures)
     g_poses, g_stats = pipe.run(raws, [i[0] for i in ins], [i[1] for i in ins], [i[2] for i in ins])
     g_poses = g_poses.copy(); g_stats = np.array(g_stats)
+    po = None
+    if nfeatures is not None:
+        po = orc.orb_params(); po.nfeatures = int(nfeatures)
+    cap = 16384 if nfeatures is None else int(nfeatures) + 1024
     pool = ThreadPoolExecutor(max_workers=min(os.cpu_count() or 1, 16))
     t0 = time.time()
 
     def o_frame(f):
         pose, alt, gr = ins[f]
-        kps, desc, _, _ = orc.detect_feature(raws[f].cpu().numpy())
+        kps, desc, _, _ = orc.detect_feature(raws[f].cpu().numpy(), None, po)
         return dict(pose=pose, alt=alt, gr=gr, kps=kps, desc=desc, geo=orc.geo_at_kps(pose, gr, M, kps), bb=orc.geo_bbox(pose, gr, M))
     fr = list(pool.map(o_frame, range(F)))
     t_ex = time.time() - t0
     nkp = 0
-    for f in range(F):                                                        # extraction: all 200 frames bit-exact
-        k, d, g = pipe.ctx.features_get(f)
+    for f in range(F):                                                        # extraction: every frame bit-exact
+        k, d, g = pipe.ctx.features_get(f, cap=cap)
         o = fr[f]
         assert len(k) == len(o["kps"]) and (d == o["desc"]).all(), "frame %d" % f
         for fld in ("x", "y", "angle", "response", "octave"):
@@ -128,7 +130,7 @@ def test_config_C3_full_size_every_stage_vs_oracle(orc):
     pool.shutdown()
     active = n_rows = n_lc = 0
     off = [0]
-    for p in range(len(src)):                                                 # matching, reprojection, mini-LM: all 19 900 pairs
+    for p in range(len(src)):                                                 # matching, reprojection, mini-LM: every pair
         rows, kp7, lc = res[p]
         off.append(off[-1] + len(kp7))
         if not pipe.ctx.pair_is_active(p):
@@ -146,7 +148,7 @@ def test_config_C3_full_size_every_stage_vs_oracle(orc):
     assert (n_rows, n_lc) == tuple(pipe.ctx.match_total())
     edges = orc.pg_select_lc([N] * F, src, tgt, off, np.concatenate([r[1] for r in res]), np.concatenate([r[2] for r in res]))
     g_edges = pipe.ctx.posegraph_select(F)
-    assert len(g_edges) == len(edges) > 5000
+    assert len(g_edges) == len(edges) > min_edges
     assert (g_edges["a"] == edges["a"]).all() and (g_edges["b"] == edges["b"]).all()
     assert np.abs(g_edges["rel"] - edges["rel"]).max() < 1e-9 and np.allclose(g_edges["var"], edges["var"], rtol=1e-6, atol=0)
     # pose graph: the oracle's objective on the ORACLE's edges at the device's initial estimate and at its answer
@@ -156,11 +158,41 @@ def test_config_C3_full_size_every_stage_vs_oracle(orc):
     pipe.ctx.set_params(pg=pg)
     x0, _, _ = pipe.ctx.posegraph_solve(F, F * N)
     e0 = orc.pg_error_at(dr, edges, x0); e1 = orc.pg_error_at(dr, edges, g_poses)
-    print("C3 full size vs the oracle: %d keypoints, %d active pairs of %d, %d rows, %d mini-LMs, %d edges; oracle objective %.6e -> %.9e, device reports "
-          "%.6e -> %.9e in %d iterations; oracle time: frames %.0f s, pairs %.0f s" % (nkp, active, len(src), n_rows, n_lc, len(edges), e0, e1, g_stats[1], g_stats[2], g_stats[0], t_ex, t_pairs))
-    assert active > 300 and n_lc > 30000
+    t0 = time.time()
+    lm = ""
+    if oracle_lm:
+        # the oracle's own LM: its envelope Cholesky is as wide as the loop closures of a leg (thousands of scalar columns at 8000
+        # keypoints per frame: hours), so it solves the graph with every `oracle_lm`-th edge, and the device solves that same graph through
+        # dsss_posegraph_solve_edges -- same LM path, poses within 1e-6
+        pg.max_iters = 100
+        pipe.ctx.set_params(pg=pg)
+        thin = np.ascontiguousarray(edges[::int(oracle_lm)])
+        o_poses, o_stats = orc.pg_solve(dr, thin)
+        t_poses, t_stats = pipe.ctx.posegraph_solve_edges(dr, thin)
+        assert o_stats[0] == t_stats[0] >= 3, (o_stats, t_stats)
+        err = float(np.abs(t_poses - o_poses).max())
+        assert err < 1e-6, err
+        lm = "; oracle LM on %d of the edges: %d iterations, max |pose - oracle| %.3g (%.0f s)" % (len(thin), o_stats[0], err, time.time() - t0)
+    print("%d x %d x %d vs the oracle: %d keypoints, %d active pairs of %d, %d rows, %d mini-LMs, %d edges; oracle objective %.6e -> %.9e, device reports "
+          "%.6e -> %.9e in %d iterations; oracle time: frames %.0f s, pairs %.0f s%s" % (F, N, M, nkp, active, len(src), n_rows, n_lc, len(edges), e0, e1, g_stats[1], g_stats[2], g_stats[0], t_ex, t_pairs, lm))
+    assert active > min_active and n_lc > min_lc
     assert abs(e0 - g_stats[1]) <= 1e-9 * e0 and abs(e1 - g_stats[2]) <= 1e-7 * e1 and e1 < 1e-6 * e0
     pipe.close()
+
+
+def test_config_C3_full_size_every_stage_vs_oracle(orc):
+    """BASELINE config 3 at FULL size (200 x 2000 x 1024, dense all-pairs), stage by stage against the oracle.  The oracle's own LM
+    cannot finish 400 k poses (envelope Cholesky: hours), so the last stage is held to the oracle's OBJECTIVE on the oracle's edges:
+    the errors the device reports before and after are orc_pg_error_at at the initial estimate and at its answer."""
+    _every_stage_vs_oracle(orc, 200, 2000, 1024, 20240601 + 1)
+
+
+def test_config_C5_shaped_survey_every_stage_vs_oracle(orc):
+    """BASELINE config 5's PARAMETERS -- 4000 x 2048 frames, nfeatures 8000 (frame.cpp:180 hard-codes 2000), dense all-pairs -- on a
+    survey short enough for the oracle (10 legs, 40 000 poses): every stage as in the C3 test, and the oracle's own LM on a thinned edge
+    set of the same survey (same iterations, poses within 1e-6).  The 1000-frame run itself is sampled against the oracle inside
+    test_config_C5_whole_pipeline_on_one_gpu."""
+    _every_stage_vs_oracle(orc, 10, 4000, 2048, 20240601 + 4, nfeatures=8000, oracle_lm=16, min_active=12, min_lc=3000, min_edges=1000)
 
 
 def _run_demo(tmp, d, extra, name):
@@ -497,10 +529,12 @@ def test_config_C3_scale_pose_graph_against_oracle_objective(orc):
         assert orc.pg_error_at(dr, oe, xp) > e1
 
 
-def test_config_C5_whole_pipeline_on_one_gpu():
+def test_config_C5_whole_pipeline_on_one_gpu(orc):
     """BASELINE config 5 end to end on ONE MI355X: 1000 frames of 4000 x 2048 (65.5 GB of float64 waterfall, generated on the
     device), nfeatures 8000, dense all-pairs (499 500 pairs), reprojection, every mini-LM and the 4 M-pose graph.  No oracle can
-    run this size; the run is held to the size-independent properties of test_full_size_C3_properties and must be bit-reproducible."""
+    run this size; the run is held to the size-independent properties of test_full_size_C3_properties, must be bit-reproducible, and is
+    SAMPLED against the oracle: ten of its frames (both ends and the middle of the survey) bit-exact, and every active pair among them --
+    rows and kp7 bit-exact, the mini-LMs at 1e-9 with the same iteration counts."""
     import time
     import torch
     from diasss_amd.pipeline import Pipeline
@@ -539,4 +573,47 @@ def test_config_C5_whole_pipeline_on_one_gpu():
     assert np.isfinite(out1).all() and np.abs(np.einsum("nij,nkj->nik", R, R) - np.eye(3)).max() < 1e-9
     assert (out2 == out1).all() and (np.array(st2) == st1).all()              # the whole path again: identical to the last bit
     assert high_gb < 250.0
+    # ---- the run itself against the oracle, on a sample: frames at both ends and in the middle, and the active pairs among them
+    from concurrent.futures import ThreadPoolExecutor
+    S = [0, 1, 2, 498, 499, 500, 501, 997, 998, 999]
+    po = orc.orb_params(); po.nfeatures = 8000
+    t0 = time.time()
+
+    def o_frame(f):
+        kps, desc, _, _ = orc.detect_feature(raws[f].cpu().numpy(), None, po)
+        return dict(pose=poses[f], alt=alts[f], gr=grs[f], kps=kps, desc=desc, geo=orc.geo_at_kps(poses[f], grs[f], M, kps), bb=orc.geo_bbox(poses[f], grs[f], M))
+    with ThreadPoolExecutor(max_workers=min(os.cpu_count() or 1, 10)) as pool:
+        ofr = dict(zip(S, pool.map(o_frame, S)))
+        for f in S:
+            k, d, g = pipe.ctx.features_get(f, cap=9000)
+            o = ofr[f]
+            assert len(k) == len(o["kps"]) and (d == o["desc"]).all(), "frame %d" % f
+            for fld in ("x", "y", "angle", "response", "octave"):
+                assert (k[fld] == o["kps"][fld]).all(), "frame %d %s" % (f, fld)
+            assert (g == o["geo"]).all(), "frame %d geo" % f
+        pid = lambda i, j: i * F - i * (i + 1) // 2 + (j - i - 1)             # index of (i, j) in the (i < j) loop order of all_pairs
+        cand = [(i, j) for a, i in enumerate(S) for j in S[a + 1:]]
+        assert all(pipe.src[pid(i, j)] == i and pipe.tgt[pid(i, j)] == j for i, j in cand)
+        act = [(i, j) for i, j in cand if pipe.ctx.pair_is_active(pid(i, j))]
+
+        def o_pair(ij):
+            i, j = ij
+            a, b = ofr[i], ofr[j]
+            rows = orc.robust_matching(i, j, N, N, a["kps"], a["desc"], a["geo"], a["bb"], b["kps"], b["desc"], b["geo"], b["bb"])
+            kp7 = orc.get_kps_pairs(rows, j, a["alt"], a["gr"], b["alt"], b["gr"])
+            return rows, kp7, orc.lc_solve(kp7, a["pose"], a["alt"], a["gr"], M, b["pose"], b["alt"], b["gr"], M)
+        ores = list(pool.map(o_pair, act))
+    n_lc_s = 0
+    for (i, j), (o_rows, o_kp7, o_lc) in zip(act, ores):
+        p = pid(i, j)
+        assert (pipe.ctx.match_rows(p) == o_rows).all(), "rows of pair %d-%d differ" % (i, j)
+        assert (pipe.ctx.match_kp7(p) == o_kp7).all(), "kp7 of pair %d-%d differ" % (i, j)
+        g = pipe.ctx.lc_get(p)
+        assert len(g) == len(o_lc)
+        if len(g):
+            assert (g["iters"] == o_lc["iters"]).all(), "mini-LM iteration counts of pair %d-%d differ" % (i, j)
+            assert np.abs(g["rel"] - o_lc["rel"]).max() < 1e-9 and np.allclose(g["var"], o_lc["var"], rtol=1e-6, atol=0)
+        n_lc_s += len(g)
+    print("C5 run sampled against the oracle: %d frames bit-exact, %d active pairs among them (%d mini-LMs) in %.0f s" % (len(S), len(act), n_lc_s, time.time() - t0))
+    assert len(act) >= 8 and n_lc_s > 2000
     pipe.close()

@@ -113,12 +113,19 @@ def test_posegraph_edges_api_small_cases(ctx, orc):
         e["rel"][0] = rel; e["var"][0] = [1e-6, 1e-6, 1e-5, 1e-3, 0.5, 1e-2]
         return e
     cases = [np.zeros(0, orc.LCEDGE_DTYPE), edge(20, 280, 0.3), np.concatenate([edge(10, 290, 0.2), edge(60, 240, -0.1), edge(149, 150, 0.05), edge(100, 151, 0.1)]),
-             np.concatenate([edge(10, 290, 0.2), edge(10, 290, 0.25), edge(60, 240, -0.1), edge(240, 60, 0.08)])]
+             np.concatenate([edge(10, 290, 0.2), edge(10, 290, 0.25), edge(60, 240, -0.1), edge(240, 60, 0.08)]),
+             # three and four closures on ONE pair, in both directions and out of order, and two on a pair of NEIGHBOURING separators
+             # (their block already holds the chain coupling): the scatter sums a group in edge order with one writer per element
+             np.concatenate([edge(240, 60, 0.08), edge(10, 290, 0.2), edge(60, 240, -0.1), edge(290, 10, 0.22), edge(10, 290, 0.25),
+                             edge(60, 240, -0.05), edge(149, 150, 0.05), edge(150, 149, -0.02), edge(10, 290, 0.21)])]
     for edges in cases:
         o_out, o_stats = orc.pg_solve(dr, edges)
         g_out, g_stats = ctx.posegraph_solve_edges(dr, edges)
         assert g_stats[0] == o_stats[0]
         assert np.abs(g_out - o_out).max() < 1e-6
+        for _ in range(3):                                   # same bits every run (duplicates used to be added atomically)
+            g2, s2 = ctx.posegraph_solve_edges(dr, edges)
+            assert (g2 == g_out).all() and (np.asarray(s2) == np.asarray(g_stats)).all()
 
 
 def test_initial_values_follow_libstdcxx_normal_stream(ctx, orc):
