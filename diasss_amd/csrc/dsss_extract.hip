@@ -304,6 +304,18 @@ struct level_tab { const uint8_t* img[DSSS_MAX_LEVELS]; int cols[DSSS_MAX_LEVELS
 //     arcs with three instructions per polarity.
 // 65 vector instructions per pixel; min and max are exact, so the value is the same whatever the order: bit-identical output.
 typedef short fast_v2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ fast_v2 fast_min3(fast_v2 a, fast_v2 b, fast_v2 c)
+{
+    uint32_t r;
+    asm("v_pk_minimum3_f16 %0, %1, %2, %3" : "=v"(r) : "v"(__builtin_bit_cast(uint32_t, a)), "v"(__builtin_bit_cast(uint32_t, b)), "v"(__builtin_bit_cast(uint32_t, c)));
+    return __builtin_bit_cast(fast_v2, r);
+}
+__device__ __forceinline__ fast_v2 fast_max3(fast_v2 a, fast_v2 b, fast_v2 c)
+{
+    uint32_t r;
+    asm("v_pk_maximum3_f16 %0, %1, %2, %3" : "=v"(r) : "v"(__builtin_bit_cast(uint32_t, a)), "v"(__builtin_bit_cast(uint32_t, b)), "v"(__builtin_bit_cast(uint32_t, c)));
+    return __builtin_bit_cast(fast_v2, r);
+}
 template <int stride>
 __device__ inline uint32_t fast_arc4(const uint8_t* __restrict__ w, int xg, int y, int tmin)      // pixels (3 + xg + k, y), k = 0..3; xg a multiple of 4
 {
@@ -336,14 +348,21 @@ __device__ inline uint32_t fast_arc4(const uint8_t* __restrict__ w, int xg, int 
         for (int i = 0; i < 8; ++i) { lo2[i] = __builtin_elementwise_min(d[2 * i + 1], d[(2 * i + 2) & 15]); hi2[i] = __builtin_elementwise_max(d[2 * i + 1], d[(2 * i + 2) & 15]); }
 #pragma unroll
         for (int i = 0; i < 8; ++i) { lo4[i] = __builtin_elementwise_min(lo2[i], lo2[(i + 1) & 7]); hi4[i] = __builtin_elementwise_max(hi2[i], hi2[(i + 1) & 7]); }
-        fast_v2 bmin = { -32768, -32768 }, bmax = { 32767, 32767 };      // largest arc minimum (dark side), smallest arc maximum (bright side) of the ring
+        // (round 5) THREE-operand packed minima / maxima: gfx950 has v_pk_minimum3_f16 / v_pk_maximum3_f16, they issue at the rate of the
+        // two-operand packed forms (tools/ubench/pk_f16.hip: 508 - 517 against 489 - 515 G wave-instructions/s), and on halves that hold
+        // 0 .. 255 -- f16 denormals n x 2^-24, compared as the integers they are, returned unchanged -- they ARE the integer minimum and
+        // maximum (checked on all 2^24 byte triples in both halves).  The window of eight and its closing element fold into one
+        // instruction, the eight arc pairs reduce three at a time: 72 packed instructions per pixel pair where there were 96.
+        fast_v2 tlo[8], thi[8];
 #pragma unroll
         for (int i = 0; i < 8; ++i) {                // k = 2 i: window [k + 1, k + 8], closed by d[k] and by d[k + 9]
-            const fast_v2 w8lo = __builtin_elementwise_min(lo4[i], lo4[(i + 2) & 7]), w8hi = __builtin_elementwise_max(hi4[i], hi4[(i + 2) & 7]);
             const fast_v2 e0 = d[2 * i], e1 = d[(2 * i + 9) & 15];
-            bmin = __builtin_elementwise_max(bmin, __builtin_elementwise_min(w8lo, __builtin_elementwise_max(e0, e1)));
-            bmax = __builtin_elementwise_min(bmax, __builtin_elementwise_max(w8hi, __builtin_elementwise_min(e0, e1)));
+            tlo[i] = fast_min3(lo4[i], lo4[(i + 2) & 7], __builtin_elementwise_max(e0, e1));
+            thi[i] = fast_max3(hi4[i], hi4[(i + 2) & 7], __builtin_elementwise_min(e0, e1));
         }
+        // largest arc minimum (dark side), smallest arc maximum (bright side) of the ring
+        const fast_v2 bmin = __builtin_elementwise_max(fast_max3(fast_max3(tlo[0], tlo[1], tlo[2]), fast_max3(tlo[3], tlo[4], tlo[5]), tlo[6]), tlo[7]);
+        const fast_v2 bmax = __builtin_elementwise_min(fast_min3(fast_min3(thi[0], thi[1], thi[2]), fast_min3(thi[3], thi[4], thi[5]), thi[6]), thi[7]);
         const fast_v2 best = __builtin_elementwise_max(vv - bmax, bmin - vv);
         const int b0 = best.x, b1 = best.y;
         out |= (uint32_t)(b0 > tmin ? b0 : 0) << (16 * pr);

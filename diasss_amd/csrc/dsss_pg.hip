@@ -485,6 +485,142 @@ __global__ __launch_bounds__(256, 2) void pg_segment_kernel(int nseg, const int*
     if (c < 6) segGR[(size_t)s * 6 + c] = sh.G[cb][c];
 }
 
+// The same recursion on EIGHT lanes per segment (round 5; eight segments per wavefront).  With sixteen lanes a step cost the wavefront
+// ~540 vector instructions -- the 6 x 6 factor (150, the same on every lane), one pair of triangular solves (42) and two products (72) --
+// for FOUR segments, thirteen of sixteen lanes busy and half of the second product thrown away.  Here lane c < 6 carries TWO right-hand
+// sides -- row c of E_i (its E y accumulates column c of DL) and column c of C_i (its E y is column c of E_(i+1), its C^T y column c of the
+// next pivot) -- lane 6 the gradient, lane 7 only helps to move blocks: the factor is computed once per EIGHT segments, the two solves of a
+// lane are independent chains (the kernel is bound by dependent f64 latency at two wavefronts per SIMD), and a step is ~520 instructions
+// for eight segments.  Every right-hand side sees the arithmetic of pg_segment_kernel in the same order: the records are the same bits.
+#define PG_SEG8_LANES 8
+__global__ __launch_bounds__(256, 2) void pg_segment8_kernel(int nseg, const int* __restrict__ seg_order, const int* __restrict__ sep_pose, const double* __restrict__ D,
+                                                         const double* __restrict__ C, const double* __restrict__ g,
+                                                         double* __restrict__ E, double* __restrict__ Dl, double* __restrict__ gi,
+                                                         double* __restrict__ segDL, double* __restrict__ segDR, double* __restrict__ segGL,
+                                                         double* __restrict__ segGR, double* __restrict__ segS, int* __restrict__ fail, int mp0, int mp1)
+{
+    __shared__ pg_seg_lds sh_all[256 / PG_SEG8_LANES];
+    const int grp = threadIdx.x / PG_SEG8_LANES, c = threadIdx.x % PG_SEG8_LANES;
+    const int slot = blockIdx.x * (256 / PG_SEG8_LANES) + grp;
+    if (slot >= nseg) return;                                   // whole groups leave together
+    const int s = seg_order[slot];                              // descending length: the eight segments of a wavefront run the same number of steps
+    pg_seg_lds& sh = sh_all[grp];
+    const int L = sep_pose[s], R = sep_pose[s + 1];
+    if (L + 1 < mp0 || L + 1 >= mp1) return;
+    if (R == L + 1) {
+        for (int a = c; a < 36; a += PG_SEG8_LANES) { segDL[(size_t)s * 36 + a] = 0; segDR[(size_t)s * 36 + a] = 0; segS[(size_t)s * 36 + a] = C[(size_t)L * 36 + a]; }
+        if (c < 6) { segGL[(size_t)s * 6 + c] = 0; segGR[(size_t)s * 6 + c] = 0; }
+        return;
+    }
+    for (int a = c; a < 36; a += PG_SEG8_LANES) { sh.E[0][a] = C[(size_t)L * 36 + a]; sh.D[0][a] = D[(size_t)(L + 1) * 36 + a]; }
+    if (c < 6) sh.G[0][c] = g[(size_t)(L + 1) * 6 + c];
+    // acc[]: column c of DL on lanes 0..5, GL on lane 6.  pre[]: the prefetched column c of D_(i+1) on lanes 0..5, g_(i+1) on lane 6 -- added
+    // to the next step's pivot / gradient at its top (one load sequence for both kinds of lane, as in pg_segment_kernel).  nC: the lane's
+    // share of C_(i+1).
+    double nC[5], acc[6] = { 0, 0, 0, 0, 0, 0 }, pre[6] = { 0, 0, 0, 0, 0, 0 };
+    const bool has_role = c < 7, is_col = c < 6;
+    const int pre_stride = is_col ? 6 : 1;
+    const double* pre_src = is_col ? D + c : g;
+    const int pre_lds = is_col ? (int)(&sh.D[0][0] - &sh.E[0][0]) + c : (int)(&sh.G[0][0] - &sh.E[0][0]);     // offsets from sh.E[0] in doubles
+    const int pre_flip = is_col ? 36 : 6;
+    int cb = 0;
+#pragma unroll
+    for (int u = 0; u < 5; ++u) { const int a = c + PG_SEG8_LANES * u; nC[u] = a < 36 ? C[(size_t)(L + 1) * 36 + a] : 0.0; }
+    for (int i = L + 1; i < R; ++i) {
+        const bool last = (i + 1 == R);
+        double* __restrict__ Ec = sh.E[cb]; double* __restrict__ Dc = sh.D[cb]; double* __restrict__ Gc = sh.G[cb];
+        double* __restrict__ En = sh.E[cb ^ 1]; double* __restrict__ Dn = sh.D[cb ^ 1]; double* __restrict__ Gn = sh.G[cb ^ 1];
+#pragma unroll
+        for (int u = 0; u < 5; ++u) { const int a = c + PG_SEG8_LANES * u; if (a < 36) sh.C[a] = nC[u]; }
+        if (has_role) {                                          // completes the entries the last step left in D and G
+            double* dst = &sh.E[0][0] + pre_lds + cb * pre_flip;
+#pragma unroll
+            for (int a = 0; a < 6; ++a) dst[a * pre_stride] += pre[a];
+        }
+        if (!last) {
+#pragma unroll
+            for (int u = 0; u < 5; ++u) { const int a = c + PG_SEG8_LANES * u; if (a < 36) nC[u] = C[(size_t)(i + 1) * 36 + a]; }
+            if (has_role) {
+                const double* src = pre_src + (size_t)(i + 1) * (is_col ? 36 : 6);
+#pragma unroll
+                for (int a = 0; a < 6; ++a) pre[a] = src[a * pre_stride];
+            }
+        } else if (has_role) {
+#pragma unroll
+            for (int a = 0; a < 6; ++a) pre[a] = 0.0;
+        }
+        if (i > L + 1) for (int a = c; a < 36; a += PG_SEG8_LANES) Dl[(size_t)(i - 1) * 36 + a] = sh.L[a];
+        PG_GROUP_SYNC();
+        for (int a = c; a < 36; a += PG_SEG8_LANES) E[(size_t)i * 36 + a] = Ec[a];
+        if (c < 6) gi[(size_t)i * 6 + c] = Gc[c];
+        double Li[36];                                           // the factor with 1 / L_jj on its diagonal
+#pragma unroll
+        for (int a = 0; a < 6; ++a)
+#pragma unroll
+            for (int b2 = 0; b2 < 6; ++b2) Li[a * 6 + b2] = b2 <= a ? Dc[a * 6 + b2] : 0.0;
+        if (chol6_rdiag(Li)) { *fail = 1; return; }              // every lane of the group sees the same pivot: they leave together
+        if (c == 0) {
+#pragma unroll
+            for (int a = 0; a < 36; ++a) sh.L[a] = Li[a];
+        }
+        PG_COMPILER_FENCE();
+        // right-hand sides of this lane: yA = row c of E (lanes 0..5) or the gradient (lanes 6, 7); yB = column c of C (lanes 0..5; the
+        // gradient again on the others, unused)
+        double yA[6], yB[6];
+        {
+            const double* ya = is_col ? Ec + c * 6 : Gc;
+            const double* yb = is_col ? sh.C + c : Gc;
+            const int bstr = is_col ? 6 : 1;
+#pragma unroll
+            for (int q = 0; q < 6; ++q) { yA[q] = ya[q]; yB[q] = yb[q * bstr]; }
+        }
+#pragma unroll
+        for (int a = 0; a < 6; ++a) {
+            double t = yA[a], u = yB[a];
+            for (int k = 0; k < a; ++k) { t -= Li[a * 6 + k] * yA[k]; u -= Li[a * 6 + k] * yB[k]; }
+            yA[a] = t * Li[a * 7]; yB[a] = u * Li[a * 7];
+        }
+#pragma unroll
+        for (int a = 5; a >= 0; --a) {
+            double t = yA[a], u = yB[a];
+            for (int k = a + 1; k < 6; ++k) { t -= Li[k * 6 + a] * yA[k]; u -= Li[k * 6 + a] * yB[k]; }
+            yA[a] = t * Li[a * 7]; yB[a] = u * Li[a * 7];
+        }
+        PG_COMPILER_FENCE();
+        {   // E yA: accumulated into DL (lanes 0..5) / GL (lane 6).  E yB: column c of E_next = -E X_C
+#pragma unroll
+            for (int a = 0; a < 6; ++a) {
+                double t = 0, u = 0;
+#pragma unroll
+                for (int q = 0; q < 6; ++q) { t += Ec[a * 6 + q] * yA[q]; u += Ec[a * 6 + q] * yB[q]; }
+                acc[a] -= t;
+                if (is_col) En[a * 6 + c] = -u;
+            }
+        }
+        PG_COMPILER_FENCE();
+        {   // C^T y: the next pivot less D_(i+1) from yB (lanes 0..5), the next gradient less g_(i+1) from yA (lane 6)
+            double yc[6];
+#pragma unroll
+            for (int q = 0; q < 6; ++q) yc[q] = is_col ? yB[q] : yA[q];
+#pragma unroll
+            for (int a = 0; a < 6; ++a) {
+                double u = 0;
+#pragma unroll
+                for (int q = 0; q < 6; ++q) u += sh.C[q * 6 + a] * yc[q];
+                if (is_col) Dn[a * 6 + c] = -u;
+                else if (c == 6) Gn[a] = -u;
+            }
+        }
+        cb ^= 1;
+        PG_GROUP_SYNC();
+    }
+    for (int a = c; a < 36; a += PG_SEG8_LANES) Dl[(size_t)(R - 1) * 36 + a] = sh.L[a];
+    if (c < 6) for (int a = 0; a < 6; ++a) segDL[(size_t)s * 36 + a * 6 + c] = acc[a];
+    if (c == 6) for (int a = 0; a < 6; ++a) segGL[(size_t)s * 6 + a] = acc[a];
+    for (int a = c; a < 36; a += PG_SEG8_LANES) { segDR[(size_t)s * 36 + a] = sh.D[cb][a]; segS[(size_t)s * 36 + a] = sh.E[cb][a]; }
+    if (c < 6) segGR[(size_t)s * 6 + c] = sh.G[cb][c];
+}
+
 // the level-1 chain after pass 1: diagonal block, coupling to the next entry and gradient of every chunk end / true separator
 // (what pass 2 of pg_segment_kernel condenses; same meaning as D, C, g of the pose chain).  Partial sums on interface entries.
 __global__ __launch_bounds__(256) void pg_chain1_kernel(int ns1, const int* __restrict__ sep1, const double* __restrict__ D, const double* __restrict__ g,
@@ -1816,6 +1952,7 @@ __global__ __launch_bounds__(256) void pg_factor_subtree_kernel(const int* __res
     __shared__ int s_arel[48];                     // boundary indices of the column's ancestor rows (at most 42)
     __shared__ double s_ri[6];                     // 1 / L(j, j)[a][a]: the solves below multiply (a dependent f64 division is ~15 instructions)
     __shared__ double s_y[6];
+    __shared__ double s_xj[6];
     __shared__ int s_ok;
     const int bin = bin_perm[blockIdx.x];          // bins in descending order of work
     for (int q = binroot_ptr[bin]; q < binroot_ptr[bin + 1]; ++q) {        // zero the update matrices of this bin's roots
@@ -1855,17 +1992,21 @@ __global__ __launch_bounds__(256) void pg_factor_subtree_kernel(const int* __res
             if (act)
                 pg_acc_rows(mp + (size_t)tc * m + q, m, tn, Lvals, r, s_Ljk, acc);
         }
-        if (rhs && T > 0) x[(size_t)j * 6 + rs_] -= accy;
-        if (act && T > 0) for (int s = 0; s < 6; ++s) Lvals[(size_t)(c0 + q) * 36 + r * 6 + s] -= acc[s];
+        // (round 5) the updated pivot block and right-hand side reach the one-thread section below through LDS: stored to global memory
+        // and read back by another thread they were a round trip through the cache hierarchy on every column's chain.  The pivot thread
+        // writes both back (the factor and the solved right-hand side), as before.
+        if (rhs) s_xj[rs_] = x[(size_t)j * 6 + rs_] - accy;               // (accy = 0 without updates)
+        if (act && idx < 6) { for (int s = 0; s < 6; ++s) s_diag[r * 6 + s] = Lvals[(size_t)c0 * 36 + r * 6 + s] - acc[s]; }
+        else if (act && T > 0) for (int s = 0; s < 6; ++s) Lvals[(size_t)(c0 + q) * 36 + r * 6 + s] -= acc[s];
         __syncthreads();
         if (threadIdx.x == 0) {
             // (round 4: in-kernel stamps put this one-thread section at 4 200 cycles per column, 28 % of the kernel -- a square root and
             // 21 dependent divisions; one reciprocal square root per pivot and multiplications by it from here on)
             double A[36], xj[6], ri[6];
 #pragma unroll
-            for (int a = 0; a < 36; ++a) A[a] = Lvals[(size_t)c0 * 36 + a];
+            for (int a = 0; a < 36; ++a) A[a] = s_diag[a];
 #pragma unroll
-            for (int a = 0; a < 6; ++a) xj[a] = x[(size_t)j * 6 + a];
+            for (int a = 0; a < 6; ++a) xj[a] = s_xj[a];
             const int bad = chol6_recip(A, ri);
             if (bad) *fail = 1;
             s_ok = !bad;
@@ -2574,6 +2715,9 @@ static int pg_solve_impl(dsss_ctx* c, const double* dr6, int total, const dsss_l
     TRY(dv.upload(c, &d_adj_ptr, adj_ptr)); TRY(dv.upload(c, &d_adj_edge, adj_edge));
     int* d_lc_link = nullptr; if (!lc_link.empty()) TRY(dv.upload(c, &d_lc_link, lc_link));
     TRY(dv.alloc(c, &d_r, (size_t)nf * 6)); TRY(dv.alloc(c, &d_Ji, (size_t)nf * 36));
+    // a second set of residuals and Jacobians: the linearisation that measures a trial's error at X (+) delta IS the next iteration's
+    // linearisation when the trial is accepted (same kernel, same point, same bits) -- it writes them here and the sets swap
+    double *d_r2, *d_Ji2; TRY(dv.alloc(c, &d_r2, (size_t)nf * 6)); TRY(dv.alloc(c, &d_Ji2, (size_t)nf * 36));
     TRY(dv.alloc(c, &d_D, (size_t)n * 36)); TRY(dv.alloc(c, &d_C, (size_t)n * 36)); TRY(dv.alloc(c, &d_g, (size_t)n * 6)); TRY(dv.alloc(c, &d_delta, (size_t)n * 6));
     TRY(dv.alloc(c, &d_E, (size_t)n * 36)); TRY(dv.alloc(c, &d_Dl, (size_t)n * 36)); TRY(dv.alloc(c, &d_gi, (size_t)n * 6));
     TRY(dv.alloc(c, &d_sDL, (size_t)nseg1 * 36)); TRY(dv.alloc(c, &d_sDR, (size_t)nseg1 * 36)); TRY(dv.alloc(c, &d_sGL, (size_t)nseg1 * 6));
@@ -2652,12 +2796,15 @@ static int pg_solve_impl(dsss_ctx* c, const double* dr6, int total, const dsss_l
     err0 = err;
     // the chain part of a trial: per-pose blocks, pass 1 (chunks of poses onto their ends), the level-1 chain, pass 2 (runs of
     // chunk ends onto the true separators)
+    const bool seg8 = !(getenv("DSSS_PG_SEG") && atoi(getenv("DSSS_PG_SEG")) == 16);      // A/B: sixteen lanes per segment (rounds 2 - 4)
     auto chain_part = [&]() {
         hipMemsetAsync(d_fail, 0, sizeof(int), st);
         hipLaunchKernelGGL(pg_assemble_kernel, dim3((n + PG_ASM_POSES - 1) / PG_ASM_POSES), dim3(6 * PG_ASM_POSES), 0, st, n, W, d_r, d_Ji, d_adj_ptr, d_adj_edge, d_ew, d_scal + 3, d_D, d_C, d_g, d_eo, mp0, mp1);
-        hipLaunchKernelGGL(pg_segment_kernel, dim3((nseg1 + 15) / 16), dim3(256), 0, st, nseg1, d_ord1, d_sep1, d_D, d_C, d_g, d_E, d_Dl, d_gi, d_sDL, d_sDR, d_sGL, d_sGR, d_sS, d_fail, mp0, mp1);
+        if (seg8) hipLaunchKernelGGL(pg_segment8_kernel, dim3((nseg1 + 31) / 32), dim3(256), 0, st, nseg1, d_ord1, d_sep1, d_D, d_C, d_g, d_E, d_Dl, d_gi, d_sDL, d_sDR, d_sGL, d_sGR, d_sS, d_fail, mp0, mp1);
+        else hipLaunchKernelGGL(pg_segment_kernel, dim3((nseg1 + 15) / 16), dim3(256), 0, st, nseg1, d_ord1, d_sep1, d_D, d_C, d_g, d_E, d_Dl, d_gi, d_sDL, d_sDR, d_sGL, d_sGR, d_sS, d_fail, mp0, mp1);
         hipLaunchKernelGGL(pg_chain1_kernel, dim3((unsigned)(((long long)ns1 * 42 + 255) / 256)), dim3(256), 0, st, ns1, d_sep1, d_D, d_g, d_sDL, d_sDR, d_sGL, d_sGR, d_sS, d_D1, d_C1, d_g1, mp0, mp1);
-        if (nseg > 0) hipLaunchKernelGGL(pg_segment_kernel, dim3((nseg + 15) / 16), dim3(256), 0, st, nseg, d_ord2, d_t2, d_D1, d_C1, d_g1, d_E1, d_Dl1, d_gi1, d_s2DL, d_s2DR, d_s2GL, d_s2GR, d_s2S, d_fail, kp0, kp1);
+        if (nseg > 0 && seg8) hipLaunchKernelGGL(pg_segment8_kernel, dim3((nseg + 31) / 32), dim3(256), 0, st, nseg, d_ord2, d_t2, d_D1, d_C1, d_g1, d_E1, d_Dl1, d_gi1, d_s2DL, d_s2DR, d_s2GL, d_s2GR, d_s2S, d_fail, kp0, kp1);
+        else if (nseg > 0) hipLaunchKernelGGL(pg_segment_kernel, dim3((nseg + 15) / 16), dim3(256), 0, st, nseg, d_ord2, d_t2, d_D1, d_C1, d_g1, d_E1, d_Dl1, d_gi1, d_s2DL, d_s2DR, d_s2GL, d_s2GR, d_s2S, d_fail, kp0, kp1);
     };
     const bool will_iterate = err > 0 && c->pg.max_iters > 0;
     bool pre_lin = false, pre_chain = false;
@@ -2934,7 +3081,7 @@ static int pg_solve_impl(dsss_ctx* c, const double* dr6, int total, const dsss_l
             ++nfact;
             // X and Xn swap between trials, so these two stay outside the captured graph
             hipLaunchKernelGGL(pg_retract_kernel, dim3((n + 255) / 256), dim3(256), 0, st, n, d_X, d_delta, d_Xn);
-            hipLaunchKernelGGL(pg_linearize_kernel, dim3(nblk), dim3(256), 0, st, n, ne, d_Xn, d_meas, W, d_ea, d_eb, d_eo, d_emeas, d_ew, (double*)nullptr, (double*)nullptr, d_part, mp0, mp1);
+            hipLaunchKernelGGL(pg_linearize_kernel, dim3(nblk), dim3(256), 0, st, n, ne, d_Xn, d_meas, W, d_ea, d_eb, d_eo, d_emeas, d_ew, d_r2, d_Ji2, d_part, mp0, mp1);
             hipLaunchKernelGGL(pg_final_sum_kernel, dim3(1), dim3(256), 0, st, d_part, nblk, 0.5, d_scal + 2);
             HCK(hipGetLastError());
             double h[3]; int failed = 0;
@@ -2951,7 +3098,7 @@ static int pg_solve_impl(dsss_ctx* c, const double* dr6, int total, const dsss_l
                     if (std::fabs(costChange) < c->pg.rel_tol * err) stop = true;
                 }
             }
-            if (success) { std::swap(d_X, d_Xn); err = newErr; lambda /= c->pg.lambda_factor; ++iters; break; }
+            if (success) { std::swap(d_X, d_Xn); std::swap(d_r, d_r2); std::swap(d_Ji, d_Ji2); pre_lin = true; err = newErr; lambda /= c->pg.lambda_factor; ++iters; break; }
             else if (!stop) { lambda *= c->pg.lambda_factor; if (lambda >= c->pg.lambda_max) break; }
             else break;
         }

@@ -25,9 +25,11 @@ blocks, cur, order = collections.defaultdict(collections.Counter), "entry", ["en
 targets = collections.Counter()
 for l in text[start + 1:end + 1]:
     s = l.strip()
-    if not s or s.startswith((";", "//", ".")) and not s.endswith(":"): continue
-    if s.endswith(":"):
-        cur = s[:-1]; order.append(cur); continue
+    if not s or (s.startswith(("//", ".")) and not s.startswith(".LBB")): continue
+    m = re.match(r"^(\.LBB\d+_\d+|; %bb\.\d+):", s)
+    if m:
+        cur = m.group(1); order.append(cur); continue
+    if s.startswith(";"): continue
     op = s.split()[0]
     blocks[cur][cls(op)] += 1
     if op.startswith("s_cbranch") or op == "s_branch":
