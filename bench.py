@@ -298,6 +298,53 @@ def main():
         trials = prof["pg_subtree"][1] // 2 if "pg_subtree" in prof and prof["pg_subtree"][1] > 0 else 1     # bins forward + backward once per LM trial
         roof, roof_groups, roof_all = roofline(prof, args.workload, wl, trials)
         work = {k: ("%.3g flop" if k in FLOP_SLOTS else "%.3g B") % v[2] for k, v in prof.items() if v[1] > 0 and v[2] > 0}
+    # ---- side leg: the ALL-PAIRS matcher north_star describes (LDS-staged descriptor tiles, every keypoint of a against every keypoint of b).
+    # The step runs the geo-grid matcher (identical outputs from 3 % of the gate evaluations); DSSS_MT_GRID=0 selects the all-pairs kernel,
+    # which is timed here on the same features so that it keeps a measured number of its own.  Outside the timed region; the state of the
+    # context is put back by matching once more under the default.
+    match_allpairs = None
+    if not args.no_roofline and world == 1 and not big:
+        os.environ["DSSS_MT_GRID"] = "0"
+        try:
+            pipe.ctx.match_pairs(pipe.src, pipe.tgt); barrier()
+            pipe.ctx.profile(True); pipe.ctx.profile_reset()
+            pipe.ctx.match_pairs(pipe.src, pipe.tgt); barrier()
+            pm = pipe.ctx.profile_get(); pipe.ctx.profile(False)
+        finally:
+            del os.environ["DSSS_MT_GRID"]
+        pipe.ctx.match_pairs(pipe.src, pipe.tgt); pipe.ctx.lc_solve_all(); barrier()
+        if pm.get("match", (0, 0, 0))[1] > 0 and pm["match"][0] > 0:
+            nk = {f: pipe.ctx.features_get(f)[0].shape[0] for f in range(F)}
+            actp = [p for p in range(len(pipe.src)) if pipe.ctx.pair_is_active(p)]
+            evals = float(sum(2 * nk[int(pipe.src[p])] * nk[int(pipe.tgt[p])] for p in actp))          # both directions of every active pair
+            alg_bytes = float(sum(2 * (nk[int(pipe.src[p])] + nk[int(pipe.tgt[p])]) * 56 for p in actp))  # (Na + Nb) (32 + 16 + 8) per direction
+            sec = pm["match"][0] * 1e-3
+            tr = pmc_traffic(args.workload).get("match_nn_kernel<false>")
+            match_allpairs = {"kernel": "match_nn_kernel<false> (DSSS_MT_GRID=0)", "ms": pm["match"][0], "launches": pm["match"][1],
+                              "evaluations": evals, "evaluations_per_s_G": evals / sec / 1e9, "peak_G": MATCH_PEAK_GEVALS, "frac": evals / sec / 1e9 / MATCH_PEAK_GEVALS,
+                              "algorithmic_bytes": alg_bytes, "algorithmic_GBs": alg_bytes / sec / 1e9,
+                              "hbm_GBs": (tr[0] * pm["match"][1] / sec / 1e9) if tr else None,
+                              "note": "every keypoint of a against every keypoint of b over the active pairs (gate in f64, then the 256-bit Hamming distance), descriptor tiles staged in LDS; "
+                                      "bound by its integer issue slots, not by bytes: SURVEY 8(d) K9 prices it against lanes x clock / 30 operations"}
+    # ---- the dependent chains of the factorisation: what the LM trials would cost if every level took only its longest chain of dependent
+    # f64 operations (constants from the in-kernel stamps and tools/ubench/mfma_f64, see DESIGN.md "critical path")
+    crit = None
+    if not args.no_roofline:
+        lv, ntr = pipe.ctx.posegraph_schedule()
+        if len(lv):
+            CLK = 2.29e9                                     # s_memtime ticks per second in these kernels (profiles/r04_front_kernel_stamps.txt)
+            C_PIVOT, C_PROD, C_BWD = 570.0, 102.0, 312.0     # cycles: arithmetic of one 4-column pivot block; one dependent f64 matrix product (result -> operand); one block of the triangular back-substitution
+            cyc = 0.0
+            for items, w6, rows, _ in lv:
+                nb = (int(w6) + 3) // 4
+                cyc += nb * (C_PIVOT + 2 * C_PROD)           # panel Cholesky: pivot block -> two dependent products -> next pivot block
+                if rows > 0:
+                    cyc += nb * 2 * C_PROD                   # row solve: two dependent products per 4-column step
+                cyc += nb * C_BWD                            # back-substitution of the panel
+            crit = {"levels": int(len(lv)), "trials": int(ntr), "ms_per_trial": cyc / CLK * 1e3, "ms_per_step": cyc / CLK * 1e3 * ntr,
+                    "note": "sum over the panel levels of the schedule of the longest DEPENDENT f64 chain of each level (4-column pivot blocks: 570 cycles of pivot arithmetic + two matrix products at "
+                            "102 cycles result-to-operand; row solve 2 products per block; back-substitution 312 cycles per block), times the LM trials: the floor of the level-by-level factorisation "
+                            "on this chip whatever the launch structure -- the measured stage is `roofline.ms_per_step`"}
     nkp = [pipe.ctx.features_get(f)[0].shape[0] for f in mine[:8]]
     tot_rows, tot_kp7 = pipe.ctx.match_total()
     active_pairs = sum(1 for p in range(len(pipe.src)) if pipe.ctx.pair_is_active(p))
@@ -324,7 +371,8 @@ def main():
         if world > 1:
             t = torch.tensor([dt1], dtype=torch.float64, device="cuda"); dist.all_reduce(t, op=dist.ReduceOp.MAX); dt1 = float(t.item())
         pcie = {"value": F * args.pcie_steps / dt1, "unit": "frames/s", "ms_per_step": 1e3 * dt1 / args.pcie_steps, "steps": args.pcie_steps,
-                "bytes_per_step": float(sum(int(h_raws[f].numel()) * 8 for f in mine)), "input": "float64 frames in page-locked host memory, uploaded inside every step (double-buffered under the extraction kernels)"}
+                "bytes_per_step": float(sum(int(h_raws[f].numel()) * 8 for f in mine)), "input": "float64 frames in page-locked host memory, uploaded inside every step (double-buffered under the extraction kernels)",
+                "note": "the figure SURVEY.md 8(d) defines (upload inside the metric); floor = bytes_per_step / ~55 GB/s of a page-locked upload + the solve that cannot start before the last frame is in"}
 
     # ---- throughput with several surveys in flight (an extra, never `value`): the pose-graph solve of one survey is latency-bound
     # and leaves the chip idle, the extraction of the next survey fills it.  Two contexts (own streams), two host threads, whole
@@ -385,7 +433,12 @@ def main():
                        "pg_stats": [float(s) for s in stats] if stats is not None else None,
                        "parallelism": "contiguous frame blocks over %d rank(s): RCCL all-gather of features, pairs to the owner of the target frame, pose graph sharded with one RCCL all-reduce of the reduced Hessian per LM trial" % world},
             "roofline": roof, "roofline_stages": roof_groups, "roofline_all_kernels": roof_all, "breakdown_ms": breakdown, "work_per_step": work, "pcie_inclusive": pcie, "throughput_surveys_in_flight": inflight,
+            "match_allpairs": match_allpairs,
         }
+        if roof is not None and crit is not None:
+            out["roofline"] = dict(roof, critical_path_floor_ms=crit["ms_per_step"], critical_path=crit)
+        if pcie is not None:       # SURVEY.md 8(d) lists the upload INSIDE the metric: this is that figure; `value` is the HBM-resident one the bench contract asks for
+            out["survey_8d_figure"] = {"value": pcie["value"], "unit": "frames/s", "ms_per_step": pcie["ms_per_step"], "what": "upload of the raw frames inside every step (pcie_inclusive)"}
         if world > 1 or force_comm:
             cs = pipe.ctx.comm_stats()
             out["comm"] = {"allreduce_bytes_total": cs[2], "calls": cs[3]}

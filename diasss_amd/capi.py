@@ -448,6 +448,14 @@ class Context:
                   "dsss_posegraph_solve_edges")
         return poses, stats
 
+    def posegraph_schedule(self):
+        """panel levels of the last solve: (levels[n][4] = items, widest panel columns, tallest rows below, interface flag; trials)"""
+        n = C.c_int(0); t = C.c_int(0)
+        self._chk(self.L.dsss_posegraph_schedule_get(self.h, None, 0, C.byref(n), C.byref(t)), "dsss_posegraph_schedule_get")
+        lv = np.zeros((max(n.value, 1), 4), np.int32)
+        self._chk(self.L.dsss_posegraph_schedule_get(self.h, _ptr(lv), n.value, C.byref(n), C.byref(t)), "dsss_posegraph_schedule_get")
+        return lv[:n.value], t.value
+
     # ---- instrumentation
     def profile(self, on=True):
         self._chk(self.L.dsss_profile_enable(self.h, 1 if on else 0), "dsss_profile_enable")

@@ -65,7 +65,6 @@ int dsss_create(int device, int max_frames, dsss_ctx** out)
     dsss_mask_params_default(&c->mp); dsss_orb_params_default(&c->op);
     dsss_match_params_default(&c->mt); dsss_pg_params_default(&c->pg);
     c->max_frames = max_frames;
-    if (getenv("DSSS_PG_PARTS")) c->pg_parts = atoi(getenv("DSSS_PG_PARTS"));      // experiments: pose-graph partitions on one rank
     c->frames.resize(max_frames);
     c->kcap = kcap_for(c->op);
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return DSSS_E_HIP; }

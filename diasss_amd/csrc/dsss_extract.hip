@@ -1152,11 +1152,10 @@ static int extract_frames_impl(dsss_ctx* c, const int* ids, int n, bool keep_tap
         //                     quadtrees of its levels; the groups alternate between the two streams
         // and the main stream picks the results up after the last group.  Groups: levels 0 .. 4 alone, the small top levels together
         // (every launch ends with a partly empty chip).  Two side streams, not more: the runtime folds streams onto four hardware queues,
-        // and a quadtree that shares its queue with the next group's gather holds it up.  DSSS_EX_PIPE=0: all on the main stream.
-        const bool pipe_levels = !(getenv("DSSS_EX_PIPE") && atoi(getenv("DSSS_EX_PIPE")) == 0);
-        const int solo_levels = getenv("DSSS_EX_SOLO") ? std::max(0, atoi(getenv("DSSS_EX_SOLO"))) : 5;
+        // and a quadtree that shares its queue with the next group's gather holds it up.
+        const int solo_levels = 5;
         const int fstride = max_cw <= 40 ? 40 : CELL_STRIDE, fwave = (2 * max_ch * fstride + 15) & ~15;      // window + arc values of one wavefront
-        const hipStream_t s_qt[2] = { pipe_levels ? c->xs[2] : st, pipe_levels ? c->xs[3] : st };
+        const hipStream_t s_qt[2] = { c->xs[2], c->xs[3] };
         bool qt_used[2] = { false, false };
         int prev_group = -1;
         int ngroups = 0;
@@ -1170,12 +1169,12 @@ static int extract_frames_impl(dsss_ctx* c, const int* ids, int n, bool keep_tap
                   else hipLaunchKernelGGL(fast_cells_kernel<CELL_STRIDE>, dim3((cells + 3) / 4, nb), dim3(256), 4 * fwave, st, d_exf, lo, hi, c->op.ini_th, c->op.min_th, fwave); }
                 const int k = ngroups & 1;
                 const hipStream_t ss = s_qt[k];
-                if (pipe_levels) {
+                {
                     HIPCHK(c, hipEventRecord(c->ex_lev_ev[ngroups], st)); HIPCHK(c, hipStreamWaitEvent(ss, c->ex_lev_ev[ngroups], 0));
                     if (prev_group >= 0) HIPCHK(c, hipStreamWaitEvent(ss, c->ex_cmp_ev[prev_group], 0));      // this group's offsets start where the previous group's end
                 }
                 hipLaunchKernelGGL(scan_counts_kernel, dim3(nb), dim3(256), 0, ss, d_exf, lo, hi);
-                if (pipe_levels) HIPCHK(c, hipEventRecord(c->ex_cmp_ev[ngroups], ss));
+                HIPCHK(c, hipEventRecord(c->ex_cmp_ev[ngroups], ss));
                 prev_group = ngroups;
                 hipLaunchKernelGGL(gather_cand_kernel, dim3((cells + GC_CELLS - 1) / GC_CELLS, nb), dim3(256), 0, ss, d_exf, lo, hi);
                 for (int l = lo; l < hi; ++l) if (lev_cnt[l] > 0) dsss_launch_quadtree(ss, d_inst + (size_t)l * B, lev_cnt[l]);
@@ -1184,7 +1183,7 @@ static int extract_frames_impl(dsss_ctx* c, const int* ids, int n, bool keep_tap
             lo = hi;
         }
         { dsss_scope sc(c, DSSS_K_QUADTREE, 0, max_levels);        // (with the level pipeline: what compaction and quadtrees leave exposed after the last FAST launch)
-          if (pipe_levels) for (int k = 0; k < 2; ++k) if (qt_used[k]) { HIPCHK(c, hipEventRecord(c->ex_side_ev[k], s_qt[k])); HIPCHK(c, hipStreamWaitEvent(st, c->ex_side_ev[k], 0)); }
+          for (int k = 0; k < 2; ++k) if (qt_used[k]) { HIPCHK(c, hipEventRecord(c->ex_side_ev[k], s_qt[k])); HIPCHK(c, hipStreamWaitEvent(st, c->ex_side_ev[k], 0)); }
           dsss_launch_quadtree_collect(st, d_fr, nb); }
         { dsss_scope sc(c, DSSS_K_DESC, (double)nb * c->op.nfeatures * (49.0 * 49.0 + 56.0));
           hipLaunchKernelGGL(orient_desc_kernel, dim3((c->kcap + 3) / 4, nb), dim3(256), 0, st, d_exf); }
@@ -1251,9 +1250,8 @@ static int extract_frames(dsss_ctx* c, const int* ids, int n, bool keep_taps)
 // dsss_frames_set: start the extraction of the frames whose images are in HBM (see extract_frames_impl).  Not an error if it cannot.
 void dsss_extract_eager(dsss_ctx* c, const int* ids, int n)
 {
-    const bool on = !(getenv("DSSS_EX_EAGER") && atoi(getenv("DSSS_EX_EAGER")) == 0);
     c->ex_eager_valid = false;
-    if (!on || n <= 0 || n > EX_BATCH) return;
+    if (n <= 0 || n > EX_BATCH) return;
     std::vector<int> mine;
     for (int i = 0; i < n; ++i) {
         const dsss_frame& f = c->frames[ids[i]];

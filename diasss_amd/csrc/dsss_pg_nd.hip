@@ -843,7 +843,7 @@ int pg_nd_start(dsss_ctx* c, hipStream_t st, const pg_nd_buffers& B, const int* 
     A.fail = reinterpret_cast<int*>(B.sets);                          // (heap node 0 is nobody's: its first word is the failure flag, zeroed with the sets)
     {   // a set of level L holds at most ceil(n / 2^L) nodes (the larger child is the upper half)
         nd_big* Gb = reinterpret_cast<nd_big*>(reinterpret_cast<char*>(B.sets + pg_nd_set_count(B.nlev)) + 4 * ND_NB * sizeof(int) + 64);      // behind the rank kernels' scratch: one record per big set (at most 16 sets of more than 4 096 nodes)
-        const bool big_ok = !(getenv("DSSS_PG_ND_BIG") && atoi(getenv("DSSS_PG_ND_BIG")) == 0) && n <= ND_SL * ND_WMAX;
+        const bool big_ok = n <= ND_SL * ND_WMAX;
         long long bound = n;
         for (int L = 0; L < B.nlev; ++L) {
             const unsigned nsets = 1u << L;

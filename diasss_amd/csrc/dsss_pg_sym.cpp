@@ -54,7 +54,6 @@ private:
     {
         const unsigned hc = std::thread::hardware_concurrency();
         int n = hc > 1 ? (int)std::min(7u, hc - 1) : 0;
-        if (const char* e = getenv("DSSS_SYM_POOL")) n = std::max(0, std::min(63, atoi(e)));
         for (int i = 0; i < n; ++i) workers.emplace_back([this] { run(); });
     }
     void run()
@@ -874,7 +873,17 @@ void pg_build_schedule(const pg_sym& S, int part_lo, int part_hi, pg_sched& out)
     const int nl = S.nlev;
     out.lv_ptr.assign(nl + 1, 0); out.asmrow_ptr.assign(nl + 1, 0); out.tile_ptr.assign(nl + 1, 0);
     out.trsm_chunks.assign(nl, 0); out.fl_diag.assign(nl, 0); out.fl_trsm.assign(nl, 0); out.fl_syrk.assign(nl, 0); out.fl_bwd.assign(nl, 0);
+    out.max_w6.assign(nl, 0); out.max_rows.assign(nl, 0);
     auto sel = [&](int f) { return S.f_part[f] >= part_lo && S.f_part[f] < part_hi; };
+    {   // (sizes first: the lists are filled on the analysing thread, which the GPU waits for -- no reallocation on the way)
+        size_t nrow = 0, nitem = 0, ntile = 0;
+        for (size_t f = 0; f < S.f_c0.size(); ++f) {
+            if (!sel((int)f)) continue;
+            nrow += (size_t)S.f_n[f]; nitem += (size_t)S.f_npan[f];
+            for (int k = 0; k < S.f_npan[f]; ++k) { const int n6 = 6 * S.f_n[f], w6 = std::min(96, 6 * S.f_s[f] - 96 * k), nt = (n6 - 96 * k - w6 + 63) / 64; ntile += (size_t)nt * (nt + 1) / 2; }
+        }
+        out.asmrow_front.reserve(nrow); out.asmrow_row.reserve(nrow); out.lv_front.reserve(nitem); out.lv_step.reserve(nitem); out.tile_item.reserve(ntile); out.tile_ij.reserve(ntile);
+    }
     for (int l = 0; l < nl; ++l) {
         for (int q = S.asm_ptr[l]; q < S.asm_ptr[l + 1]; ++q) { const int f = S.asm_front[q]; if (!sel(f)) continue; for (int r = 0; r < S.f_n[f]; ++r) { out.asmrow_front.push_back(f); out.asmrow_row.push_back(r); } }
         out.asmrow_ptr[l + 1] = (int)out.asmrow_front.size();
@@ -886,6 +895,7 @@ void pg_build_schedule(const pg_sym& S, int part_lo, int part_hi, pg_sched& out)
             const int n6 = 6 * S.f_n[f], w6 = std::min(96, 6 * S.f_s[f] - 96 * k), nrows = n6 - 96 * k - w6, nt = (nrows + 63) / 64;
             for (int ti = 0; ti < nt; ++ti) for (int tj = 0; tj <= ti; ++tj) { out.tile_item.push_back(item); out.tile_ij.push_back((ti << 16) | tj); }
             out.max_n6 = std::max(out.max_n6, n6);
+            out.max_w6[l] = std::max(out.max_w6[l], w6); out.max_rows[l] = std::max(out.max_rows[l], nrows);
             out.trsm_chunks[l] = std::max(out.trsm_chunks[l], (nrows + 63) / 64);
             const double nn = w6, rows = nrows;
             out.fl_diag[l] += nn * nn * nn / 3.0 + nn * nn; out.fl_trsm[l] += rows * nn * nn; out.fl_bwd[l] += 2.0 * rows * nn + nn * nn; out.fl_syrk[l] += rows * (rows + 1) * nn;
@@ -896,13 +906,8 @@ void pg_build_schedule(const pg_sym& S, int part_lo, int part_hi, pg_sched& out)
 
 void pg_sym_opts_env(pg_sym_opts& opt)
 {
-    if (getenv("DSSS_PG_RELAX_ZERO")) opt.relax_zero_blocks = atof(getenv("DSSS_PG_RELAX_ZERO"));
-    if (getenv("DSSS_PG_RELAX_FLOPS")) opt.relax_flops = atof(getenv("DSSS_PG_RELAX_FLOPS"));
-    if (getenv("DSSS_PG_RELAX_SMALL")) opt.relax_flops_small = atof(getenv("DSSS_PG_RELAX_SMALL"));
-    if (getenv("DSSS_PG_RELAX_ABS")) opt.relax_abs_flops = atof(getenv("DSSS_PG_RELAX_ABS"));
     if (getenv("DSSS_PG_ND_BOTH")) opt.nd_both_axes = atoi(getenv("DSSS_PG_ND_BOTH"));
     if (getenv("DSSS_PG_LEAF")) opt.leaf = atoi(getenv("DSSS_PG_LEAF"));
-    if (getenv("DSSS_PG_GEO_FIRST")) opt.nd_geo_first = atoi(getenv("DSSS_PG_GEO_FIRST")) != 0;
 }
 
 // ------------------------------------------------------------------ host twin of the numeric phase (CPU tests only)
@@ -1041,7 +1046,6 @@ extern "C" int dsss_host_pg_solve(int ns, const int32_t* edge_a, const int32_t* 
     }
     pg_sym S; pg_sym_opts opt;
     if (getenv("DSSS_PG_BIN_COST")) opt.bin_cost = atof(getenv("DSSS_PG_BIN_COST"));
-    if (getenv("DSSS_PG_PACK_COST")) opt.pack_cost = atof(getenv("DSSS_PG_PACK_COST"));
     if (getenv("DSSS_PG_LEAF")) opt.leaf = atoi(getenv("DSSS_PG_LEAF"));
     if (getenv("DSSS_PG_ND_BOTH")) opt.nd_both_axes = atoi(getenv("DSSS_PG_ND_BOTH"));
     pg_sym_opts_env(opt);

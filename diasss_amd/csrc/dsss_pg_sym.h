@@ -100,6 +100,7 @@ struct pg_sched {
     std::vector<int> tile_ptr, tile_item, tile_ij;             // (panel item within its level, ti << 16 | tj) 64 x 64 trailing-update tiles per level
     std::vector<int> trsm_chunks;                              // 64-row chunks below the panel, maximum over the level's items
     std::vector<double> fl_diag, fl_trsm, fl_syrk, fl_bwd;     // algorithmic flops per level
+    std::vector<int> max_w6, max_rows;                         // per level: scalar columns of its widest panel step, scalar rows below its tallest one (the dependent chains of the level)
     int max_n6 = 6;
 };
 // part_lo <= front part < part_hi selects fronts; (-1, 0) selects the interface fronts
@@ -135,7 +136,7 @@ struct pg_sym_opts {
     std::function<void()> before_order;          // called once the adjacency is built, before the first use of the coordinates (which may still be on their way)
 };
 
-void pg_sym_opts_env(pg_sym_opts& opt);    // DSSS_PG_RELAX_ZERO / _FLOPS / _SMALL / _ABS overrides (experiments)
+void pg_sym_opts_env(pg_sym_opts& opt);    // DSSS_PG_ND_BOTH / DSSS_PG_LEAF overrides (analysis knobs kept for tools/pg_sweep.sh)
 
 // edges: pairs of chain-order separator indices, the ns-1 chain couplings (k, k+1) first, then the LC edges.
 // part[k] (may be null): rank that owns separator k, non-decreasing in k.  cx, cy: DR positions of the separators.

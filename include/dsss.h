@@ -120,7 +120,7 @@ int dsss_frame_set(dsss_ctx*, int id, const double* raw, int N, int M,
  * As the reference's constructor normalises, masks and runs DetectFeature itself (frame.cpp:45-52), this call STARTS the extraction
  * of the frames whose raw image is a device pointer (asynchronously, with the parameters set at that moment) while it packs the
  * geometry; dsss_extract_many over the same frames then only finishes it.  Nothing observable changes: parameters set in between, another
- * list of frames or dsss_extract make the extraction run again from the start (DSSS_EX_EAGER=0 in the environment: never start early). */
+ * list of frames or dsss_extract make the extraction run again from the start.                                                          */
 int dsss_frames_set(dsss_ctx*, int n, const int* ids, const double* const* raw, const int* N, const int* M,
                     const double* const* pose6, const double* const* alt, const double* const* grange);
 /* GetNormalizeSSS + GetFilteredMask + DetectFeature (frame.cpp:57-124,167-203) with the ORB descriptor
@@ -203,6 +203,10 @@ int dsss_posegraph_solve(dsss_ctx*, int nframes, double* poses12_host, double* r
 int dsss_posegraph_update(dsss_ctx*, int nframes, double* poses12_host, double* rpy6_host, double* stats4_host);
 int dsss_posegraph_reset(dsss_ctx*);
 int dsss_posegraph_online_edges(dsss_ctx*);      /* loop closures accumulated so far (>= 0) */
+/* Instrumentation (no reference counterpart: GTSAM keeps its elimination tree to itself): the panel levels of the last solve of this
+ * context, four ints per level in launch order -- panel steps on the level, scalar columns of its widest panel, scalar rows below its
+ * tallest one, 1 for a level of the replicated interface tree -- and the number of factorisations (LM trials) that solve ran.        */
+int dsss_posegraph_schedule_get(dsss_ctx*, int* levels4_host, int cap_levels, int* n_levels, int* n_trials);
 /* stand-alone form: explicit DR chain + edges                                                               */
 int dsss_posegraph_solve_edges(dsss_ctx*, const double* dr6, int total, const dsss_lc_edge* edges, int ne,
                                double* poses12_host, double* stats4_host);

@@ -1,10 +1,9 @@
 """GPU: every DSSS_* environment switch that selects another code path of the product is held to the default path's result.
 
-The switches exist for A/B measurements (DESIGN.md names each); an untested alternative path rots.  They are read per call, so one
-process can flip them.  Paths that run the SAME arithmetic in another arrangement (panel kernel with two barriers per block,
-separate row solve / trailing update launches, bin lists built on the host, no early start of the bins, extraction on one stream,
-no eager extraction, other upload batch) must reproduce the default's bits; knobs that change the ELIMINATION ORDER (chunk length of
-the chain condensation, bin size, dissection and amalgamation rules) must reproduce it to rounding, with the same LM path."""
+Round 5 pruned the experiment surface to ten switches (DESIGN.md names each): two print diagnostics (DSSS_PG_VERBOSE, DSSS_EX_VERBOSE), the
+others are read per call, so one process can flip them.  Paths that run the SAME arithmetic in another arrangement (ordering on the host,
+other thread counts, other upload batch, the all-pairs matcher) must reproduce the default's bits; knobs that change the ELIMINATION ORDER
+(bin size, dissection leaf and both-axes threshold) must reproduce it to rounding, with the same LM path."""
 import hashlib
 import os
 import numpy as np
@@ -12,12 +11,9 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 
-SAME_BITS_PG = [("DSSS_PG_PANEL", "diag3"), ("DSSS_PG_PACK_COST", "300"), ("DSSS_PG_RSU32", "0"), ("DSSS_PG_RSU32", "1000"), ("DSSS_PG_RSU", "0"), ("DSSS_PG_RSU", "64"), ("DSSS_PG_LISTS", "host"), ("DSSS_PG_EARLY", "0"), ("DSSS_PG_ND", "host"), ("DSSS_PG_ND_BIG", "0"),
-                ("DSSS_SYM_THREADS", "1"), ("DSSS_SYM_THREADS", "5")]
-SAME_OPTIMUM_PG = [("DSSS_PG_CHUNK", "8"), ("DSSS_PG_CHUNK", "24"), ("DSSS_PG_BIN_COST", "300"), ("DSSS_PG_BIN_COST", "1200"), ("DSSS_PG_ND_BOTH", "1000000"),
-                   ("DSSS_PG_LEAF", "12"), ("DSSS_PG_RELAX_ZERO", "0"), ("DSSS_PG_RELAX_FLOPS", "1.0"), ("DSSS_PG_RELAX_SMALL", "1.0"), ("DSSS_PG_RELAX_ABS", "1e6")]
-SAME_BITS_EX = [("DSSS_EX_PIPE", "0"), ("DSSS_EX_SOLO", "0"), ("DSSS_EX_SOLO", "3"), ("DSSS_EX_EAGER", "0"), ("DSSS_EX_UPLOAD_BATCH", "1"), ("DSSS_EX_UPLOAD_BATCH", "3"),
-                ("DSSS_FS_THREADS", "1")]
+SAME_BITS_PG = [("DSSS_PG_ND", "host"), ("DSSS_PG_ND", "check"), ("DSSS_SYM_THREADS", "1"), ("DSSS_SYM_THREADS", "5")]
+SAME_OPTIMUM_PG = [("DSSS_PG_BIN_COST", "300"), ("DSSS_PG_BIN_COST", "1200"), ("DSSS_PG_ND_BOTH", "1000000"), ("DSSS_PG_LEAF", "12")]
+SAME_BITS_EX = [("DSSS_EX_UPLOAD_BATCH", "1"), ("DSSS_EX_UPLOAD_BATCH", "3"), ("DSSS_FS_THREADS", "1")]
 
 
 class _env:
@@ -44,10 +40,9 @@ def test_pose_graph_switches_reproduce_the_default():
         with _env(k, v):
             p, s = c.posegraph_solve_edges(dr, edges)
         assert s[0] == sref[0] and abs(s[2] - sref[2]) <= 1e-9 * sref[2] and np.abs(p - ref).max() < 1e-8, "%s=%s: %g" % (k, v, np.abs(p - ref).max())
-    for nparts, geo in ((4, "1"), (4, "0")):                             # the partitioned layout on one rank, interface dissected (default) or rank cuts first
+    for nparts in (4, 8):                                                # the partitioned layout on one rank (the interface is dissected too)
         c.set_pg_partitions(nparts)
-        with _env("DSSS_PG_GEO_FIRST", geo):
-            p, s = c.posegraph_solve_edges(dr, edges)
+        p, s = c.posegraph_solve_edges(dr, edges)
         assert s[0] == sref[0] and np.abs(p - ref).max() < 1e-8
     c.close()
 

@@ -130,14 +130,11 @@ def test_host_multifrontal_solve_with_rank_partition(nparts, monkeypatch):
     assert np.abs(x - x1).max() < 1e-9
 
 
-@pytest.mark.parametrize("geo_first", ["0", "1"])
-def test_partitioned_analysis_keeps_the_ownership_invariant(geo_first, monkeypatch):
+def test_partitioned_analysis_keeps_the_ownership_invariant(monkeypatch):
     """One leg per rank and chords over one and two legs: a pose is the target of a loop closure from a lower rank AND the source
     of one into a higher rank, so its lower-rank partner can lose sight of it (it leaves into a separator higher up) before a
     cut runs between the two.  A factor belongs to the rank of its higher pose and adds to the diagonal block of the lower one:
-    that lower node must be interface whatever the cuts were (dsss_host_pg_solve fails with DSSS_E_STATE otherwise), with rank
-    cuts first and with the dissected interface; the solve stays exact."""
-    monkeypatch.setenv("DSSS_PG_GEO_FIRST", geo_first)
+    that lower node must be interface whatever the cuts were (dsss_host_pg_solve fails with DSSS_E_STATE otherwise); the solve stays exact."""
     monkeypatch.setenv("DSSS_PG_BIN_COST", "200")
     legs, per_leg = 6, 60
     ns, chords, cx, cy = _lawnmower(legs, per_leg, 31, density=0.8)

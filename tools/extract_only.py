@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Wall time of frame set-up + extraction (set_frames starts the extraction, extract finishes it; device-resident frames), for A/B runs of its switches
-(DSSS_EX_PIPE, DSSS_LIB): python tools/extract_only.py [frames=200] [repeats=10]"""
+(DSSS_LIB = another build of the library): python tools/extract_only.py [frames=200] [repeats=10]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch

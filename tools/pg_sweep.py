@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Time the pose-graph solve alone on a dumped loop-closure edge set (tools/dump_graph.py), for A/B runs of the
-analysis knobs (DSSS_PG_BIN_COST, DSSS_PG_ND_BOTH, DSSS_PG_RELAX_*, DSSS_PG_LEAF ...: they are read once per process, so
+analysis knobs (DSSS_PG_BIN_COST, DSSS_PG_ND_BOTH, DSSS_PG_LEAF: they are read per solve, but the worker pool is per process, so
 one process per setting).
     python tools/pg_sweep.py gpurun_out/C3_edges.npz [repeats]
 Prints: median / minimum wall time of dsss_posegraph_solve_edges, LM iterations and final error."""

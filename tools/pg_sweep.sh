@@ -5,9 +5,6 @@ out=gpurun_out/pg_sweep.log; : > $out
 run() { env "$@" python tools/pg_sweep.py $G 7 2>/dev/null | tail -1 >> $out; }
 run X=1
 for v in 300 1000 1500 2500; do run DSSS_PG_BIN_COST=$v; done
-run DSSS_PG_ND_BOTH=25
-run DSSS_PG_RELAX_SMALL=3
-for v in 3e5 1e6 3e6; do run DSSS_PG_RELAX_ABS=$v; done
+for v in 25 256; do run DSSS_PG_ND_BOTH=$v; done
 for v in 16 32; do run DSSS_PG_LEAF=$v; done
-for v in 8 32; do run DSSS_PG_CHUNK=$v; done
 cat $out
