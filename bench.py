@@ -194,6 +194,8 @@ def main():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--pcie-steps", type=int, default=2, help="steps of the PCIe-inclusive leg (raw frames in page-locked host memory); 0 = skip")
     ap.add_argument("--jobs-in-flight", type=int, default=4, help="surveys overlapped in the extra throughput leg (1 = skip); the rate saturates at four on one MI355X")
+    ap.add_argument("--pg-partitions", type=int, default=0, help="cut the pose graph into this many contiguous blocks of frames on the rank(s) present (dsss_set_pg_partitions): the layout of a "
+                                                                 "P-rank job on fewer ranks, and on one GPU a nested dissection whose first levels run between frame blocks (0 = the library's default)")
     ap.add_argument("--dry-run", action="store_true", help="plumbing check without a GPU (CPU test-suite): gloo ranks, the context class named by DSSS_BENCH_CTX "
                                                            "(module:Class, a recording stub), no frames, no timing claim -- the line carries value null and dry_run true")
     ap.add_argument("--emulate-rank", default=None, metavar="r/W", help="time rank r (or `all`) of a W-rank job on ONE GPU: all W ranks run once in lock step inside "
@@ -254,6 +256,8 @@ def main():
     pipe = Pipeline(F, device=local_rank, rank=rank, world=world, dist=dist if (world > 1 or force_comm) else None, nfeatures=wl.get("nfeatures"), force_collectives=force_comm)
     if force_comm:
         pipe.ctx.set_pg_partitions(8)
+    if args.pg_partitions > 0:
+        pipe.ctx.set_pg_partitions(args.pg_partitions)
     if saved_stdout is not None:
         dist.barrier(); torch.cuda.synchronize()
         sys.stdout.flush(); os.dup2(saved_stdout, 1); os.close(saved_stdout)

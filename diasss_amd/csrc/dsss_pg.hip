@@ -30,8 +30,11 @@
 // ------------------------------------------------------------------ host: device memory of one solve
 namespace {
 
-inline int sym_threads() { const int env = getenv("DSSS_SYM_THREADS") ? atoi(getenv("DSSS_SYM_THREADS")) : 0; if (env > 0) return env;
-                          const unsigned hc = std::thread::hardware_concurrency(); return (int)std::min(8u, std::max(1u, hc)); }      // ranges per parallel phase of the analysis (its worker pool has 7 threads); 16 gain another 10 % on an idle 128-core host
+// ranges per parallel phase of the analysis: eight for a graph of C3's size (more forks cost what they gain at 23 k separators; 16 gain
+// another 10 % on an idle 128-core host), up to twenty-four from a few hundred thousand separators on (C5: 635 k), where a phase is
+// milliseconds of work.  The worker pool (dsss_pg_sym.cpp) holds up to 23 threads.
+inline int sym_threads(int ns) { const int env = getenv("DSSS_SYM_THREADS") ? atoi(getenv("DSSS_SYM_THREADS")) : 0; if (env > 0) return env;
+                                const unsigned hc = std::thread::hardware_concurrency(); return (int)std::min(ns >= 131072 ? 24u : 8u, std::max(1u, hc)); }
 
 struct pg_dev {
     // device memory of one solve comes from the context's arena: a few large chunks that stay allocated between solves,
@@ -189,11 +192,15 @@ static int pg_solve_impl(dsss_ctx* c, const double* dr6, int total, const dsss_l
     std::promise<void> coords_prom; std::future<void> coords_fut = coords_prom.get_future();
     bool bottom_signalled = false;
     // the ordering on the device (dsss_pg_nd.hip): one partition, at most 65 536 separators; DSSS_PG_ND=host keeps it on the host
-    const bool dev_nd = nparts == 1 && ns >= 2 && ns <= 65536 && !(getenv("DSSS_PG_ND") && !strcmp(getenv("DSSS_PG_ND"), "host"));
+    // (round 5: the host ordering has a cut candidate the device kernels do not have yet -- the cheapest cut of the chain order, which
+    // takes C3 from 29 panel levels to 12 -- and is the default; DSSS_PG_ND_INDEX=0 switches that candidate off and, with it, the device
+    // ordering back on)
+    const bool chain_cuts = !(getenv("DSSS_PG_ND_INDEX") && atoi(getenv("DSSS_PG_ND_INDEX")) == 0);
+    const bool dev_nd = !chain_cuts && nparts == 1 && ns >= 2 && ns <= 65536 && !(getenv("DSSS_PG_ND") && !strcmp(getenv("DSSS_PG_ND"), "host"));
     pg_nd_buffers ndB; bool nd_ok = false, nd_started = false; size_t nd_sets_cap = 0; int nd_edges_cap = 0;
     std::promise<void> nd_ready_prom; std::future<void> nd_ready_fut = nd_ready_prom.get_future();
     std::thread sym_thread([&] {
-        pg_sym_opts opt; opt.threads = sym_threads();
+        pg_sym_opts opt; opt.threads = sym_threads(ns);
         opt.on_bottom_ready = [&] { bottom_signalled = true; bottom_prom.set_value(); };
         opt.on_lists_ready = [&] { lists_signalled = true; lists_prom.set_value(); };
         opt.before_order = [&] { coords_fut.wait(); };

@@ -53,7 +53,7 @@ private:
     pg_pool()
     {
         const unsigned hc = std::thread::hardware_concurrency();
-        int n = hc > 1 ? (int)std::min(7u, hc - 1) : 0;
+        int n = hc > 1 ? (int)std::min(23u, hc - 1) : 0;      // (the analysis of a C3-size graph forks eight ways; graphs of several hundred thousand separators use them all: dsss_pg.hip, sym_threads)
         for (int i = 0; i < n; ++i) workers.emplace_back([this] { run(); });
     }
     void run()
@@ -120,6 +120,8 @@ struct nd_ctx {
     const char* forced;                                    // nodes with a neighbour of a HIGHER rank: they must end up in the interface (see nd_order)
     std::vector<nd_tree>* pool; std::mutex* mu;
     std::atomic<long long>* tns;                           // phase timers (nd_timer) or null
+    bool index_cuts;                                       // a third candidate per set: the cheapest cut of the CHAIN ORDER near the median (see nd_order)
+    int* pos;                                              // scratch of that candidate: rank of a node inside the set that holds it (-1: in a separator already)
 };
 // DSSS_PG_VERBOSE: thread-time per phase of nd_order over all calls of ONE analysis (1 candidates, 2 final boundary, 4 leaves); the counters
 // belong to the analysis that asked for them (several solves may run at once)
@@ -177,8 +179,8 @@ int nd_order(std::vector<int>& nodes, const nd_ctx& C, std::vector<int>& order, 
     const bool geo = !multi || (C.geo_first && total > C.leaf);
     if (geo) {
         nd_timer tm(C.tns, 1);
-        double x0 = 1e300, x1 = -1e300, y0 = 1e300, y1 = -1e300;
-        for (int v : nodes) { x0 = std::min(x0, C.cx[v]); x1 = std::max(x1, C.cx[v]); y0 = std::min(y0, C.cy[v]); y1 = std::max(y1, C.cy[v]); }
+        double x0 = 1e300, x1 = -1e300, y0 = 1e300, y1 = -1e300; int i0 = 1 << 30, i1 = -1;
+        for (int v : nodes) { x0 = std::min(x0, C.cx[v]); x1 = std::max(x1, C.cx[v]); y0 = std::min(y0, C.cy[v]); y1 = std::max(y1, C.cy[v]); i0 = std::min(i0, v); i1 = std::max(i1, v); }
         const bool byx = (x1 - x0) >= (y1 - y0);
         const size_t h2 = nodes.size() / 2;
         // split at the median of the (coordinate, index) total order; only the two halves matter, not their inner order
@@ -202,15 +204,20 @@ int nd_order(std::vector<int>& nodes, const nd_ctx& C, std::vector<int>& order, 
         // histogram of the coordinates (one pass over a contiguous copy of the keys, then a selection inside ONE bucket), the halves are
         // marked by comparing with it, and the separator is counted from the marks -- three light passes instead of a selection that moves
         // 16-byte pairs about.  Only the winner is partitioned.  Same halves (they are determined by the total order), same counts.
-        struct cut_cand { bool bx; double pk; int pi; size_t cnt; };
+        // axis 0 = y, 1 = x: median cuts of the dead-reckoned coordinates.  2 = a cut of the CHAIN ORDER (round 5, chain_cut below): a
+        // survey is a lawn-mower chain, consecutive separators lie on one leg, so a cut of the chain order runs BETWEEN two legs (or through
+        // one leg at ONE chain edge) and costs the loop closures that cross it.  The median of y does the same only on paper -- the median
+        // node sits in the middle of some leg whose dead-reckoned y wanders by centimetres, and the cut zig-zags through that leg's chain
+        // edges -- and, worse, it is taken wherever the median happens to fall.
+        struct cut_cand { int bx; double pk; int pi; size_t cnt; size_t half; };
         std::vector<double> keys;                                          // (one candidate at a time per call; the second one of a large set brings its own)
         auto less_than = [](double k, int v, double pk, int pi) { return k != pk ? k < pk : v < pi; };
-        auto count_cut = [&](const std::vector<int>& nd, bool bx, double lo, double hi, std::vector<double>& kx, char* sd) {
-            const double* key = bx ? C.cx : C.cy;
+        auto count_cut = [&](const std::vector<int>& nd, int bx, double lo, double hi, std::vector<double>& kx, char* sd) {
+            const double* key = bx == 1 ? C.cx : C.cy;
             const size_t m = nd.size();
             kx.resize(m);
             for (size_t i = 0; i < m; ++i) kx[i] = key[nd[i]];
-            cut_cand cc{ bx, 0.0, 0, 0 };
+            cut_cand cc{ bx, 0.0, 0, 0, h2 };
             constexpr int NB = 1024;
             if (hi > lo && std::isfinite(hi - lo)) {
                 const double scale = NB / (hi - lo);
@@ -248,11 +255,43 @@ int nd_order(std::vector<int>& nodes, const nd_ctx& C, std::vector<int>& order, 
             cc.cnt = cnt;
             return cc;
         };
-        auto carry_out = [&](std::vector<int>& nd, const cut_cand& cc) {      // lower half first (any inner order: only the halves matter)
-            const double* key = cc.bx ? C.cx : C.cy;
-            std::partition(nd.begin(), nd.end(), [&](int v) { return less_than(key[v], v, cc.pk, cc.pi); });
+        // The chain-order candidate.  Node sets are kept in ascending index order (every split is a stable partition), so a cut of the
+        // chain order is a position p of the list: nodes [0, p) below, [p, m) above.  A node of rank r whose highest neighbour inside the
+        // set has rank R > r is a separator node of every cut r < p <= R: one difference array prices ALL positions in one pass over the
+        // edges, and the cheapest position of the balance window [m / 3, 2 m / 3] is the candidate (the one nearest the middle among equals).
+        // On the C5 graph the cost of a cut between two legs varies from 23 to 740 separator nodes with the pair of legs it runs between
+        // (few loop closures where two legs barely overlap); the median position is rarely a cheap one.  With this candidate the C3 graph
+        // factorises in 12 panel levels instead of 29 (0.6 instead of 2.1 GFLOP, largest front 49 instead of 140 block rows), the C5 graph
+        // in 37 instead of 169 (30 instead of 457 GFLOP, 172 instead of 1 184 block rows).
+        auto chain_cut = [&](const std::vector<int>& nd) {
+            const size_t m = nd.size();
+            cut_cand cc{ 2, 0.0, 0, (size_t)-1, h2 };
+            for (size_t r = 0; r < m; ++r) C.pos[nd[r]] = (int)r;
+            std::vector<int> diff(m + 2, 0);
+            for (size_t r = 0; r < m; ++r) {
+                const int v = nd[r];
+                int R = -1;
+                for (int q = C.adj_ptr[v]; q < C.adj_ptr[v + 1]; ++q) { const int pu = C.pos[C.adj_idx[q]]; if (pu > R) R = pu; }      // (neighbours outside the set sit in separators: -1)
+                if (R > (int)r) { diff[r + 1]++; diff[(size_t)R + 1]--; }
+            }
+            const size_t lo = std::max<size_t>(1, m / 3), hi = std::min(m - 1, m - m / 3);      // (windows of +-2 / 5 / 10 / 17 / 25 % of the set: C3 17 / 14 / 12 / 12 / 13 panel levels, C5 59 / 41 / 47 / 37 / 35)
+            long long run = 0;
+            for (size_t p2 = 1; p2 <= hi; ++p2) {
+                run += diff[p2];
+                if (p2 < lo) continue;
+                const size_t c = (size_t)run, dist = p2 > h2 ? p2 - h2 : h2 - p2, bdist = cc.half > h2 ? cc.half - h2 : h2 - cc.half;
+                if (c < cc.cnt || (c == cc.cnt && dist < bdist)) { cc.cnt = c; cc.half = p2; }
+            }
+            cc.pi = nd[cc.half];
+            return cc;
         };
-        const double lo_of[2] = { y0, x0 }, hi_of[2] = { y1, x1 };           // [bx]
+        auto carry_out = [&](std::vector<int>& nd, const cut_cand& cc) {      // lower half first, both halves in ascending index order
+            if (cc.bx == 2) return;                                           // (a position of the sorted list: nothing moves)
+            const double* key = cc.bx == 1 ? C.cx : C.cy;
+            std::stable_partition(nd.begin(), nd.end(), [&](int v) { return less_than(key[v], v, cc.pk, cc.pi); });
+        };
+        const double lo_of[3] = { y0, x0, (double)i0 }, hi_of[3] = { y1, x1, (double)i1 };           // [bx]
+        const bool idx_cand = C.index_cuts && total >= C.both_axes && total >= 96;
         if (!multi && total < C.both_axes) { split(nodes, byx); half = h2; }       // the only candidate: nothing to compare
         else if (nodes.size() < 96) {
             for (int pass = 0; pass < (total >= C.both_axes ? 2 : 1); ++pass) {
@@ -267,23 +306,25 @@ int nd_order(std::vector<int>& nodes, const nd_ctx& C, std::vector<int>& order, 
             // ordering); the marks of a node set are private to the call that holds it, the second candidate marks in side2
             cut_cand c2{};
             std::vector<double> keys2;
-            pg_pool::task tk; tk.fn = [&] { c2 = count_cut(nodes, !byx, lo_of[!byx], hi_of[!byx], keys2, C.side2); };
+            pg_pool::task tk; tk.fn = [&] { c2 = count_cut(nodes, (int)!byx, lo_of[!byx], hi_of[!byx], keys2, C.side2); };
             pg_pool::get().fork(&tk);
-            const cut_cand c1 = count_cut(nodes, byx, lo_of[byx], hi_of[byx], keys, C.side);
+            const cut_cand c1 = count_cut(nodes, (int)byx, lo_of[byx], hi_of[byx], keys, C.side);
             pg_pool::get().join(&tk);
             const cut_cand* win = nullptr;
             if (c1.cnt < best) { best = c1.cnt; win = &c1; }
             if (c2.cnt < best) { best = c2.cnt; win = &c2; }
-            if (win) { carry_out(nodes, *win); half = h2; }
+            cut_cand c3{};
+            if (idx_cand) { c3 = chain_cut(nodes); if (c3.cnt < best) { best = c3.cnt; win = &c3; } }
+            if (win) { carry_out(nodes, *win); half = win->half; }
         }
         else {
             cut_cand wc{}; bool have = false;
-            for (int pass = 0; pass < (total >= C.both_axes ? 2 : 1); ++pass) {
-                const bool bx = pass == 0 ? byx : !byx;
-                const cut_cand c = count_cut(nodes, bx, lo_of[bx], hi_of[bx], keys, C.side);
+            for (int pass = 0; pass < (total >= C.both_axes ? 2 : 1) + (idx_cand ? 1 : 0); ++pass) {
+                const int bx = pass == 0 ? (int)byx : (pass == 1 && total >= C.both_axes ? (int)!byx : 2);
+                const cut_cand c = bx == 2 ? chain_cut(nodes) : count_cut(nodes, bx, lo_of[bx], hi_of[bx], keys, C.side);
                 if (c.cnt < best) { best = c.cnt; wc = c; have = true; }
             }
-            if (have) { carry_out(nodes, wc); half = h2; }
+            if (have) { carry_out(nodes, wc); half = wc.half; }
         }
     }
     { nd_timer tm(C.tns, 2);
@@ -304,6 +345,7 @@ int nd_order(std::vector<int>& nodes, const nd_ctx& C, std::vector<int>& order, 
         }
     }
     std::sort(S.begin(), S.end());
+    if (C.index_cuts) for (int v : S) C.pos[v] = -1;
     if (multi) for (int v : S) C.iface[v] = 1;
     if (!multi && (A.empty() || B.empty())) {            // degenerate cut: fall back to index order
         std::sort(nodes.begin(), nodes.end());
@@ -448,10 +490,11 @@ void pg_symbolic(int ns, const std::vector<std::pair<int, int>>& edges, int ncha
         std::vector<char> side(ns, 0), side2(ns, 0);
         S.order.reserve(ns);
         std::vector<char> forced(ns, 0);
+        std::vector<int> pos_scratch(ns, -1);
         if (S.nparts > 1 && part) for (int v = 0; v < ns; ++v) for (int q = adj_ptr[v]; q < adj_ptr[v + 1]; ++q) if (part[adj_idx[q]] > part[v]) { forced[v] = 1; break; }
         std::atomic<long long> nd_ns[8];
         for (auto& a : nd_ns) a = 0;
-        nd_ctx C{ adj_ptr.data(), adj_idx.data(), cx, cy, side.data(), side2.data(), opt.leaf, opt.nd_both_axes, opt.nd_geo_first, S.nparts > 1 ? part : nullptr, iface.data(), forced.data(), &pool, &mu, tv ? nd_ns : nullptr };
+        nd_ctx C{ adj_ptr.data(), adj_idx.data(), cx, cy, side.data(), side2.data(), opt.leaf, opt.nd_both_axes, opt.nd_geo_first, S.nparts > 1 ? part : nullptr, iface.data(), forced.data(), &pool, &mu, tv ? nd_ns : nullptr, opt.nd_index_cuts != 0, pos_scratch.data() };
         root = nd_order(nodes, C, S.order, 0);
         if (tv) fprintf(stderr, "[dsss pg symbolic] nd_order thread-time: candidates %.2f ms, final boundary %.2f ms, leaves %.2f ms\n", nd_ns[1] / 1e6, nd_ns[2] / 1e6, nd_ns[4] / 1e6);
     }
@@ -647,7 +690,6 @@ void pg_symbolic(int ns, const std::vector<std::pair<int, int>>& edges, int ncha
             if (chain) fund.back().s++;
             else fund.push_back({ j, 1, csz(j) });
         }
-        S.f_rowptr.assign(1, 0);
         // sum over the s columns of a front of n block rows of 216 (m^2 + 3 m) + 72, m = n - 1 - j: in closed form and in integers (the
         // column-by-column sum is a sum of integers below 2^53, i.e. exact: the same double, so the same merge decisions; as a loop it made
         // every merge test of a growing front linear in its width -- 0.3 of the 0.5 ms of this phase, which the GPU waits for)
@@ -659,13 +701,19 @@ void pg_symbolic(int ns, const std::vector<std::pair<int, int>>& edges, int ncha
             const long long hi = n - 1, lo = n - s - 1;         // m runs over lo + 1 .. hi
             return (double)(216 * ((Q(hi) - Q(lo)) + 3 * (T1(hi) - T1(lo))) + 72 * s);
         };
+        // The merge decisions need sizes and ONE row of a front -- its first boundary row -- and the rows of a front are its own columns
+        // (consecutive) followed by the boundary of the LAST supernode merged into it: decided here in one cheap pass (f_last = that
+        // supernode's first column), the row lists are then written by all threads (at C5 they are 13 M entries: 8 ms when one thread
+        // copied them while it decided).
+        std::vector<int> f_last;
         for (const fnd& g : fund) {
             bool merged = false;
             if (!S.f_c0.empty()) {
                 const int c = (int)S.f_c0.size() - 1;
-                const int* cr = S.f_rows.data() + S.f_rowptr[c];
                 const int sc = S.f_s[c], nc = S.f_n[c], bc = nc - sc;
-                if (S.f_c0[c] + sc == g.c0 && bc > 0 && cr[sc] >= g.c0 && cr[sc] < g.c0 + g.s && S.f_part[c] == S.col_part[g.c0]) {
+                const int lastc = f_last[c];                                  // the boundary of front c is the tail of this column's structure
+                const int bfirst = bc > 0 ? S.rowidx[S.colptr[lastc] + (csz(lastc) - bc)] : -1;
+                if (S.f_c0[c] + sc == g.c0 && bc > 0 && bfirst >= g.c0 && bfirst < g.c0 + g.s && S.f_part[c] == S.col_part[g.c0]) {
                     const double zeros = (double)(g.n - bc) * sc;                     // explicit zero blocks the merge puts into L
                     const double f_sep = flops_of(sc, nc) + flops_of(g.s, g.n), f_mrg = flops_of(sc + g.s, sc + g.n);
                     const bool one_panel = sc + g.s <= PG_PW;
@@ -675,20 +723,26 @@ void pg_symbolic(int ns, const std::vector<std::pair<int, int>>& edges, int ncha
                     const bool saves_step = (sc + g.s + PG_PW - 1) / PG_PW < (sc + PG_PW - 1) / PG_PW + (g.s + PG_PW - 1) / PG_PW;
                     if (zeros <= opt.relax_zero_blocks || f_mrg <= f_sep * (one_panel ? opt.relax_flops_small : opt.relax_flops) ||
                         (saves_step && f_mrg - f_sep <= opt.relax_abs_flops)) {
-                        // rows of the merged front: the child's own columns, then the parent's rows (a superset of the child's boundary)
-                        S.f_rows.resize(S.f_rowptr[c] + sc);          // (the child's own columns stay where they are)
-                        S.f_rows.insert(S.f_rows.end(), S.rowidx.begin() + S.colptr[g.c0], S.rowidx.begin() + S.colptr[g.c0] + g.n);
-                        S.f_rowptr[c + 1] = (int)S.f_rows.size();
-                        S.f_s[c] = sc + g.s; S.f_n[c] = sc + g.n;
+                        S.f_s[c] = sc + g.s; S.f_n[c] = sc + g.n; f_last[c] = g.c0;
                         merged = true;
                     }
                 }
             }
-            if (!merged) {
-                S.f_c0.push_back(g.c0); S.f_s.push_back(g.s); S.f_n.push_back(g.n); S.f_part.push_back(S.col_part[g.c0]);
-                S.f_rows.insert(S.f_rows.end(), S.rowidx.begin() + S.colptr[g.c0], S.rowidx.begin() + S.colptr[g.c0] + g.n);
-                S.f_rowptr.push_back((int)S.f_rows.size());
-            }
+            if (!merged) { S.f_c0.push_back(g.c0); S.f_s.push_back(g.s); S.f_n.push_back(g.n); S.f_part.push_back(S.col_part[g.c0]); f_last.push_back(g.c0); }
+        }
+        {
+            const int nfr = (int)S.f_c0.size();
+            S.f_rowptr.assign(nfr + 1, 0);
+            for (int f = 0; f < nfr; ++f) S.f_rowptr[f + 1] = S.f_rowptr[f] + S.f_n[f];
+            S.f_rows.resize(S.f_rowptr[nfr]);
+            par_ranges(nfr, T, [&](int, int lo, int hi) {
+                for (int f = lo; f < hi; ++f) {
+                    int* out = S.f_rows.data() + S.f_rowptr[f];
+                    const int sc = S.f_s[f], bc = S.f_n[f] - sc, lastc = f_last[f];
+                    for (int q = 0; q < sc; ++q) out[q] = S.f_c0[f] + q;
+                    std::copy(S.rowidx.begin() + S.colptr[lastc] + (csz(lastc) - bc), S.rowidx.begin() + S.colptr[lastc + 1], out + sc);
+                }
+            });
         }
         for (size_t f = 0; f < S.f_c0.size(); ++f) for (int c = 0; c < S.f_s[f]; ++c) S.front_of_col[S.f_c0[f] + c] = (int)f;
     }
@@ -746,13 +800,18 @@ void pg_symbolic(int ns, const std::vector<std::pair<int, int>>& edges, int ncha
         for (int f = 0; f < nf; ++f) S.fa_ptr[f + 1] = S.fa_ptr[f] + cnt[f + 1];
         const int nfa = S.fa_ptr[nf];
         S.fa_src.resize(nfa); S.fa_row.resize(nfa); S.fa_col.resize(nfa); S.fa_tr.resize(nfa);
-        std::vector<int> fp(S.fa_ptr.begin(), S.fa_ptr.end() - 1);
-        for (int v = 0; v < nval; ++v) {
-            if (sub_ok[v_col[v]]) continue;
-            const int f = S.front_of_col[v_col[v]], at = fp[f]++;
-            const int* pr = S.f_rows.data() + S.f_rowptr[f];
-            S.fa_src[at] = v; S.fa_col[at] = v_col[v] - S.f_c0[f]; S.fa_tr[at] = v_tr[v];
-            S.fa_row[at] = (int)(std::lower_bound(pr, pr + S.f_n[f], v_row[v]) - pr);
+        {   // (any order inside a front: the sort below orders by (row, column, value index), and the value index is unique)
+            std::vector<std::atomic<int>> fp(nf);
+            for (int f = 0; f < nf; ++f) fp[f].store(S.fa_ptr[f], std::memory_order_relaxed);
+            par_ranges(nval, T, [&](int, int lo, int hi) {
+                for (int v = lo; v < hi; ++v) {
+                    if (sub_ok[v_col[v]]) continue;
+                    const int f = S.front_of_col[v_col[v]], at = fp[f].fetch_add(1, std::memory_order_relaxed);
+                    const int* pr = S.f_rows.data() + S.f_rowptr[f];
+                    S.fa_src[at] = v; S.fa_col[at] = v_col[v] - S.f_c0[f]; S.fa_tr[at] = v_tr[v];
+                    S.fa_row[at] = (int)(std::lower_bound(pr, pr + S.f_n[f], v_row[v]) - pr);
+                }
+            });
         }
         par_ranges(nf, T, [&](int, int lo, int hi) {
             std::vector<int> idx, a, b, c2, d;
@@ -806,20 +865,29 @@ void pg_symbolic(int ns, const std::vector<std::pair<int, int>>& edges, int ncha
     {
         const int nrows_all = S.f_rowptr[nf];
         S.fa_rowptr.assign(nrows_all + 1, 0);
-        for (int f = 0; f < nf; ++f) for (int e = S.fa_ptr[f]; e < S.fa_ptr[f + 1]; ++e) S.fa_rowptr[S.f_rowptr[f] + S.fa_row[e] + 1]++;
-        // entries are sorted by (front, row): the CSR offsets are global positions in fa_*
-        for (int i = 0; i < nrows_all; ++i) S.fa_rowptr[i + 1] += S.fa_rowptr[i];
         S.xr_ptr.assign(nrows_all + 1, 0);
-        for (int f = 0; f < nf; ++f)
-            for (int c = S.ch_ptr[f]; c < S.ch_ptr[f + 1]; ++c) { const long long r0 = S.ch_relptr[c], r1 = S.ch_relptr[c + 1]; for (long long q = r0; q < r1; ++q) S.xr_ptr[S.f_rowptr[f] + S.rel[q] + 1]++; }
-        for (int i = 0; i < nrows_all; ++i) S.xr_ptr[i + 1] += S.xr_ptr[i];
-        S.xr_child.resize(S.xr_ptr[nrows_all]); S.xr_row.resize(S.xr_ptr[nrows_all]);
-        std::vector<int> fp(S.xr_ptr.begin(), S.xr_ptr.end() - 1);
-        for (int f = 0; f < nf; ++f)
-            for (int c = S.ch_ptr[f]; c < S.ch_ptr[f + 1]; ++c) {                                   // children in their fixed order
-                const long long r0 = S.ch_relptr[c], r1 = S.ch_relptr[c + 1];
-                for (long long q = r0; q < r1; ++q) { const int at = fp[S.f_rowptr[f] + S.rel[q]]++; S.xr_child[at] = c; S.xr_row[at] = (int)(q - r0); }
+        // (a front's block rows are its own range of both views: counts and fills run by ranges of fronts, the two prefix sums between them
+        // are one pass each)
+        par_ranges(nf, T, [&](int, int lo, int hi) {
+            for (int f = lo; f < hi; ++f) {
+                for (int e = S.fa_ptr[f]; e < S.fa_ptr[f + 1]; ++e) S.fa_rowptr[S.f_rowptr[f] + S.fa_row[e] + 1]++;
+                for (int c = S.ch_ptr[f]; c < S.ch_ptr[f + 1]; ++c) { const long long r0 = S.ch_relptr[c], r1 = S.ch_relptr[c + 1]; for (long long q = r0; q < r1; ++q) S.xr_ptr[S.f_rowptr[f] + S.rel[q] + 1]++; }
             }
+        });
+        // entries are sorted by (front, row): the CSR offsets are global positions in fa_*
+        for (int i = 0; i < nrows_all; ++i) { S.fa_rowptr[i + 1] += S.fa_rowptr[i]; S.xr_ptr[i + 1] += S.xr_ptr[i]; }
+        S.xr_child.resize(S.xr_ptr[nrows_all]); S.xr_row.resize(S.xr_ptr[nrows_all]);
+        par_ranges(nf, T, [&](int, int lo, int hi) {
+            std::vector<int> fp;
+            for (int f = lo; f < hi; ++f) {
+                const int r0f = S.f_rowptr[f], nr = S.f_n[f];
+                fp.assign(S.xr_ptr.begin() + r0f, S.xr_ptr.begin() + r0f + nr);
+                for (int c = S.ch_ptr[f]; c < S.ch_ptr[f + 1]; ++c) {                                   // children in their fixed order
+                    const long long r0 = S.ch_relptr[c], r1 = S.ch_relptr[c + 1];
+                    for (long long q = r0; q < r1; ++q) { const int at = fp[S.rel[q]]++; S.xr_child[at] = c; S.xr_row[at] = (int)(q - r0); }
+                }
+            }
+        });
     }
     const auto fE = tnow();
     // ---- children that cross from a rank's interior into the interface
@@ -908,6 +976,7 @@ void pg_sym_opts_env(pg_sym_opts& opt)
 {
     if (getenv("DSSS_PG_ND_BOTH")) opt.nd_both_axes = atoi(getenv("DSSS_PG_ND_BOTH"));
     if (getenv("DSSS_PG_LEAF")) opt.leaf = atoi(getenv("DSSS_PG_LEAF"));
+    if (getenv("DSSS_PG_ND_INDEX")) opt.nd_index_cuts = atoi(getenv("DSSS_PG_ND_INDEX"));      // (tools/sym_time.py, tools/pg_sweep.sh: the chain-order cut candidate on / off)
 }
 
 // ------------------------------------------------------------------ host twin of the numeric phase (CPU tests only)
@@ -1049,8 +1118,16 @@ extern "C" int dsss_host_pg_solve(int ns, const int32_t* edge_a, const int32_t* 
     if (getenv("DSSS_PG_LEAF")) opt.leaf = atoi(getenv("DSSS_PG_LEAF"));
     if (getenv("DSSS_PG_ND_BOTH")) opt.nd_both_axes = atoi(getenv("DSSS_PG_ND_BOTH"));
     pg_sym_opts_env(opt);
+    if (getenv("DSSS_SYM_THREADS")) opt.threads = std::max(1, atoi(getenv("DSSS_SYM_THREADS")));
+    opt.lists_on_device = x == nullptr;                     // analysis only: as the product runs it (the bins' lists are built on the device there)
     pg_symbolic(ns, edges, ns - 1, cx, cy, part, nparts, opt, S);
     if (S.ownership_violations) return DSSS_E_STATE;        // a lower-rank end of a cross-rank factor outside the interface
+    if (!x) {      // (what the product builds next; timed with the analysis by tools/sym_time.py)
+        const auto t0 = std::chrono::steady_clock::now();
+        pg_sched so, si; pg_build_schedule(S, 0, std::max(1, nparts), so); if (nparts > 1) pg_build_schedule(S, -1, 0, si);
+        if (getenv("DSSS_PG_VERBOSE")) fprintf(stderr, "[dsss pg symbolic] launch lists %.2f ms (%zu assembly rows, %zu panel steps, %zu tiles)\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(),
+                                               so.asmrow_front.size() + si.asmrow_front.size(), so.lv_front.size() + si.lv_front.size(), so.tile_item.size() + si.tile_item.size());
+    }
     const int rc = x ? pg_host_solve(S, nedges - (ns - 1), edges, aval, rhs, x) : 0;
     if (stats8) {
         stats8[0] = S.nnzL; stats8[1] = (int64_t)S.f_c0.size(); stats8[2] = S.npanels; stats8[3] = S.nlev;

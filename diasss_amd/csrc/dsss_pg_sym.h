@@ -109,6 +109,7 @@ void pg_build_schedule(const pg_sym& S, int part_lo, int part_hi, pg_sched& out)
 struct pg_sym_opts {
     int leaf = 24;                      // nested-dissection leaf size
     int nd_both_axes = 64;              // node sets of at least this size try the median cut along both axes and keep the smaller separator
+    int nd_index_cuts = 1;              // a third cut candidate of every node set: the cheapest cut of the CHAIN ORDER with both sides between a third and two thirds of the set (dsss_pg_sym.cpp, nd_order).  0 = coordinate medians only: the ordering the device kernels of dsss_pg_nd.hip reproduce
     bool nd_geo_first = true;           // a node set that spans several ranks may take a geometric cut when its separator is smaller than the rank cut's (its separator is interface then)
     double bin_cost = 1000;             // work bound of a binned subtree
     double pack_cost = 0;               // work bound of a BIN (several subtrees packed together); 0 = bin_cost

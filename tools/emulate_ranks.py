@@ -50,11 +50,11 @@ class LockStep:
                 self.bar.wait()
                 arr[:] = self.tmp
             else:
-                rows = [self.slot[r][r].copy() for r in range(self.world)]
+                if rank == 0:
+                    self.tmp = np.stack([self.slot[r][r] for r in range(self.world)])
                 self.bar.wait()
-                for r in range(self.world):
-                    arr[r] = rows[r]
-            self.log[rank].append((op, arr.copy()))
+                arr[:] = self.tmp
+            self.log[rank].append((op, self.tmp))       # every rank receives the same result: ONE copy is kept (C5: 3 GB of collectives per step)
             self.bar.wait()
         return cb
 
@@ -84,20 +84,27 @@ class Replay:
         self.k += 1
 
 
+def is_big(wl):
+    return wl["F"] * wl["N"] * wl["M"] > (1 << 32)          # C5: 65 GB of raw frames (bench.py: device-side noise, frames of one rank at a time here)
+
+
 def inputs(wl, seed, device, frames):
     from diasss_amd.synth import Survey
     F, N, M = wl["F"], wl["N"], wl["M"]
-    sv = Survey(F, N, M, seed=seed, device=device)
+    sv = Survey(F, N, M, seed=seed, device=device, noise_on_device=is_big(wl))
     raws = [sv.frame(f) if f in frames else None for f in range(F)]
     ins = [sv.inputs(f) for f in range(F)]
     return raws, [i[0] for i in ins], [i[1] for i in ins], [i[2] for i in ins]
 
 
 def record(wl, seed, world, device=0):
-    """lock-step run of all ranks; returns (per-rank collective logs, the trajectory of rank 0, LM stats)"""
+    """lock-step run of all ranks; returns (per-rank collective logs, the trajectory of rank 0, LM stats, the inputs).  A big workload
+    (C5) runs stage by stage: the raw frames of all ranks are resident only until every rank has extracted (65 GB), the pose-graph
+    stage of the W contexts then has the device to itself; the replay regenerates one rank's frames at a time."""
     import torch
     from diasss_amd.pipeline import Pipeline
     F = wl["F"]
+    big = is_big(wl)
     raws, poses, alts, grs = inputs(wl, seed, "cuda:%d" % device, set(range(F)))
     ls = LockStep(world)
     pipes = []
@@ -107,14 +114,26 @@ def record(wl, seed, world, device=0):
         pipes.append(p)
     out = [None] * world
     err = []
+    stage_bar = threading.Barrier(world)
 
     def run(r):
         try:
             mine = set(range(F * r // world, F * (r + 1) // world))
-            out[r] = pipes[r].run([x if f in mine else None for f, x in enumerate(raws)], poses, alts, grs)
-            out[r] = (out[r][0].copy(), np.array(out[r][1]))
+            my = [x if f in mine else None for f, x in enumerate(raws)]
+            if not big:
+                res = pipes[r].run(my, poses, alts, grs)
+            else:
+                pipes[r].set_frames(my, poses, alts, grs); pipes[r].extract(); pipes[r].ctx.sync()
+                del my
+                if stage_bar.wait() == 0:                # one thread lets the raw frames go once every rank has extracted
+                    for f in range(F):
+                        raws[f] = None
+                    torch.cuda.empty_cache()
+                stage_bar.wait()
+                pipes[r].match(); res = pipes[r].optimize()
+            out[r] = (res[0].copy(), np.array(res[1]))
         except Exception as e:                      # a failed rank must not leave the others in the barrier
-            err.append(e); ls.bar.abort()
+            err.append(e); ls.bar.abort(); stage_bar.abort()
     th = [threading.Thread(target=run, args=(r,)) for r in range(world)]
     for t in th: t.start()
     for t in th: t.join()
@@ -123,9 +142,10 @@ def record(wl, seed, world, device=0):
     torch.cuda.synchronize()
     for p in pipes:
         p.close()
+    torch.cuda.empty_cache()
     for r in range(1, world):
         assert (out[r][0] == out[0][0]).all(), "ranks disagree"
-    return ls.log, out[0][0], out[0][1], (raws, poses, alts, grs)
+    return ls.log, out[0][0], out[0][1], (None if big else raws, poses, alts, grs)
 
 
 def replay_rank(wl, world, r, log, data, steps=5, warmup=2, device=0, profile=False):
@@ -135,7 +155,10 @@ def replay_rank(wl, world, r, log, data, steps=5, warmup=2, device=0, profile=Fa
     F = wl["F"]
     raws, poses, alts, grs = data
     mine = set(range(F * r // world, F * (r + 1) // world))
-    my_raws = [x if f in mine else None for f, x in enumerate(raws)]
+    if raws is None:                                    # big workload: this rank's frames only, made again (same seed, same generator: the same frames)
+        my_raws = inputs(wl, data_seed(wl), "cuda:%d" % device, mine)[0]
+    else:
+        my_raws = [x if f in mine else None for f, x in enumerate(raws)]
     rp = Replay(log, "cuda:%d" % device)
     pipe = Pipeline(F, device=device, rank=r, world=world, nfeatures=wl.get("nfeatures"))
     pipe.ctx.comm_init_device_callback(r, world, rp.fn)
@@ -176,7 +199,15 @@ def wire_ms(comm, world):
     return 1e3 * (2.0 * (world - 1) / world * comm["allreduce_bytes"] + (world - 1) / world * comm["allgather_bytes"]) / (XGMI_LINK_GBS * 1e9)
 
 
+_SEED = {}
+
+
+def data_seed(wl):
+    return _SEED[wl["name"]]
+
+
 def emulate(wl, seed, world, ranks=None, steps=5, warmup=2, device=0, profile=False):
+    _SEED[wl["name"]] = seed
     log, traj, stats, data = record(wl, seed, world, device)
     ranks = list(range(world)) if ranks is None else ranks
     rows = []
