@@ -122,6 +122,7 @@ struct nd_ctx {
     std::atomic<long long>* tns;                           // phase timers (nd_timer) or null
     bool index_cuts;                                       // a third candidate per set: the cheapest cut of the CHAIN ORDER near the median (see nd_order)
     int* pos;                                              // scratch of that candidate: rank of a node inside the set that holds it (-1: in a separator already)
+    int threads;                                           // ranges of the passes over a LARGE node set (the top of the recursion is the serial part of the ordering)
 };
 // DSSS_PG_VERBOSE: thread-time per phase of nd_order over all calls of ONE analysis (1 candidates, 2 final boundary, 4 leaves); the counters
 // belong to the analysis that asked for them (several solves may run at once)
@@ -216,14 +217,21 @@ int nd_order(std::vector<int>& nodes, const nd_ctx& C, std::vector<int>& order, 
             const double* key = bx == 1 ? C.cx : C.cy;
             const size_t m = nd.size();
             kx.resize(m);
-            for (size_t i = 0; i < m; ++i) kx[i] = key[nd[i]];
+            // (sets of 64 k nodes and more -- the top of the recursion at C5's 635 k separators, where one or two threads hold everything --
+            // run their passes over ranges of the set; same marks, same counts)
+            const int TP = (m >= 65536 && !multi) ? std::max(1, C.threads) : 1;
+            par_ranges((int)m, TP, [&](int, int a0, int a1) { for (int i = a0; i < a1; ++i) kx[i] = key[nd[i]]; });
             cut_cand cc{ bx, 0.0, 0, 0, h2 };
             constexpr int NB = 1024;
             if (hi > lo && std::isfinite(hi - lo)) {
                 const double scale = NB / (hi - lo);
                 auto bucket = [&](double k) { const int b = (int)((k - lo) * scale); return b < 0 ? 0 : (b >= NB ? NB - 1 : b); };      // monotone in k
                 unsigned hist[NB] = { 0 };
-                for (size_t i = 0; i < m; ++i) hist[bucket(kx[i])]++;
+                if (TP > 1) {
+                    std::vector<unsigned> ph((size_t)TP * NB, 0u);
+                    par_ranges((int)m, TP, [&](int t, int a0, int a1) { unsigned* h = ph.data() + (size_t)t * NB; for (int i = a0; i < a1; ++i) h[bucket(kx[i])]++; });
+                    for (int t = 0; t < TP; ++t) for (int q = 0; q < NB; ++q) hist[q] += ph[(size_t)t * NB + q];
+                } else for (size_t i = 0; i < m; ++i) hist[bucket(kx[i])]++;
                 size_t below = 0; int b = 0;
                 while (below + hist[b] <= h2) below += hist[b++];              // the bucket that holds rank h2 (h2 < m)
                 std::vector<std::pair<double, int>> in;
@@ -237,8 +245,21 @@ int nd_order(std::vector<int>& nodes, const nd_ctx& C, std::vector<int>& order, 
                 std::nth_element(in.begin(), in.begin() + h2, in.end());
                 cc.pk = in[h2].first; cc.pi = in[h2].second;
             }
-            for (size_t i = 0; i < m; ++i) sd[nd[i]] = less_than(kx[i], nd[i], cc.pk, cc.pi) ? 1 : 2;
+            par_ranges((int)m, TP, [&](int, int a0, int a1) { for (int i = a0; i < a1; ++i) sd[nd[i]] = less_than(kx[i], nd[i], cc.pk, cc.pi) ? 1 : 2; });
             size_t cnt = 0;
+            if (TP > 1) {                                                     // (one partition: the marks are only read here)
+                std::vector<size_t> pc(TP, 0);
+                par_ranges((int)m, TP, [&](int t, int a0, int a1) {
+                    size_t c2 = 0;
+                    for (int i = a0; i < a1; ++i) {
+                        const int v = nd[i];
+                        if (sd[v] != 1) continue;
+                        for (int q = C.adj_ptr[v]; q < C.adj_ptr[v + 1]; ++q) if (sd[C.adj_idx[q]] == 2) { ++c2; break; }
+                    }
+                    pc[t] = c2;
+                });
+                for (size_t c2 : pc) cnt += c2;
+            } else
             for (size_t i = 0; i < m; ++i) {
                 const int v = nd[i];
                 if (sd[v] != 1) continue;
@@ -251,7 +272,7 @@ int nd_order(std::vector<int>& nodes, const nd_ctx& C, std::vector<int>& order, 
                 }
                 if (cut) ++cnt;
             }
-            for (size_t i = 0; i < m; ++i) sd[nd[i]] = 0;
+            par_ranges((int)m, TP, [&](int, int a0, int a1) { for (int i = a0; i < a1; ++i) sd[nd[i]] = 0; });
             cc.cnt = cnt;
             return cc;
         };
@@ -266,14 +287,20 @@ int nd_order(std::vector<int>& nodes, const nd_ctx& C, std::vector<int>& order, 
         auto chain_cut = [&](const std::vector<int>& nd) {
             const size_t m = nd.size();
             cut_cand cc{ 2, 0.0, 0, (size_t)-1, h2 };
-            for (size_t r = 0; r < m; ++r) C.pos[nd[r]] = (int)r;
+            const int TP = m >= 65536 ? std::max(1, C.threads) : 1;
+            par_ranges((int)m, TP, [&](int, int a0, int a1) { for (int r = a0; r < a1; ++r) C.pos[nd[r]] = r; });
             std::vector<int> diff(m + 2, 0);
-            for (size_t r = 0; r < m; ++r) {
-                const int v = nd[r];
-                int R = -1;
-                for (int q = C.adj_ptr[v]; q < C.adj_ptr[v + 1]; ++q) { const int pu = C.pos[C.adj_idx[q]]; if (pu > R) R = pu; }      // (neighbours outside the set sit in separators: -1)
-                if (R > (int)r) { diff[r + 1]++; diff[(size_t)R + 1]--; }
-            }
+            par_ranges((int)m, TP, [&](int, int a0, int a1) {
+                for (int r = a0; r < a1; ++r) {
+                    const int v = nd[r];
+                    int R = -1;
+                    for (int q = C.adj_ptr[v]; q < C.adj_ptr[v + 1]; ++q) { const int pu = C.pos[C.adj_idx[q]]; if (pu > R) R = pu; }      // (neighbours outside the set sit in separators: -1)
+                    if (R > r) {
+                        if (TP > 1) { __atomic_fetch_add(&diff[(size_t)r + 1], 1, __ATOMIC_RELAXED); __atomic_fetch_sub(&diff[(size_t)R + 1], 1, __ATOMIC_RELAXED); }
+                        else { diff[(size_t)r + 1]++; diff[(size_t)R + 1]--; }
+                    }
+                }
+            });
             const size_t lo = std::max<size_t>(1, m / 3), hi = std::min(m - 1, m - m / 3);      // (windows of +-2 / 5 / 10 / 17 / 25 % of the set: C3 17 / 14 / 12 / 12 / 13 panel levels, C5 59 / 41 / 47 / 37 / 35)
             long long run = 0;
             for (size_t p2 = 1; p2 <= hi; ++p2) {
@@ -292,7 +319,16 @@ int nd_order(std::vector<int>& nodes, const nd_ctx& C, std::vector<int>& order, 
         };
         const double lo_of[3] = { y0, x0, (double)i0 }, hi_of[3] = { y1, x1, (double)i1 };           // [bx]
         const bool idx_cand = C.index_cuts && total >= C.both_axes && total >= 96;
-        if (!multi && total < C.both_axes) { split(nodes, byx); half = h2; }       // the only candidate: nothing to compare
+        // The chain-order candidate goes first, and a very cheap one (at most 1/1024 of the set) ends the search: at the top of the recursion --
+        // the serial part of the ordering -- it costs one pass over the set's edges and wins anyway (C3: 1 to 7 separator nodes where the
+        // coordinate medians cost 26 to 207), the coordinate candidates are a histogram selection and a counting pass each.
+        cut_cand c3{}; bool chain_done = false;
+        if (idx_cand) {
+            c3 = chain_cut(nodes);
+            if (c3.cnt < best && c3.cnt * 1024 <= (size_t)total) { best = c3.cnt; half = c3.half; chain_done = true; }      // (1/64 took cuts of 700 nodes where the cut across 79 k nodes of C5 costs 140: twice the flops)
+        }
+        if (chain_done) {}
+        else if (!multi && total < C.both_axes) { split(nodes, byx); half = h2; }       // the only candidate: nothing to compare
         else if (nodes.size() < 96) {
             for (int pass = 0; pass < (total >= C.both_axes ? 2 : 1); ++pass) {
                 cand = nodes;
@@ -313,17 +349,17 @@ int nd_order(std::vector<int>& nodes, const nd_ctx& C, std::vector<int>& order, 
             const cut_cand* win = nullptr;
             if (c1.cnt < best) { best = c1.cnt; win = &c1; }
             if (c2.cnt < best) { best = c2.cnt; win = &c2; }
-            cut_cand c3{};
-            if (idx_cand) { c3 = chain_cut(nodes); if (c3.cnt < best) { best = c3.cnt; win = &c3; } }
+            if (idx_cand && c3.cnt < best) { best = c3.cnt; win = &c3; }
             if (win) { carry_out(nodes, *win); half = win->half; }
         }
         else {
             cut_cand wc{}; bool have = false;
-            for (int pass = 0; pass < (total >= C.both_axes ? 2 : 1) + (idx_cand ? 1 : 0); ++pass) {
-                const int bx = pass == 0 ? (int)byx : (pass == 1 && total >= C.both_axes ? (int)!byx : 2);
-                const cut_cand c = bx == 2 ? chain_cut(nodes) : count_cut(nodes, bx, lo_of[bx], hi_of[bx], keys, C.side);
+            for (int pass = 0; pass < (total >= C.both_axes ? 2 : 1); ++pass) {
+                const int bx = pass == 0 ? (int)byx : (int)!byx;
+                const cut_cand c = count_cut(nodes, bx, lo_of[bx], hi_of[bx], keys, C.side);
                 if (c.cnt < best) { best = c.cnt; wc = c; have = true; }
             }
+            if (idx_cand && c3.cnt < best) { best = c3.cnt; wc = c3; have = true; }
             if (have) { carry_out(nodes, wc); half = wc.half; }
         }
     }
@@ -494,7 +530,7 @@ void pg_symbolic(int ns, const std::vector<std::pair<int, int>>& edges, int ncha
         if (S.nparts > 1 && part) for (int v = 0; v < ns; ++v) for (int q = adj_ptr[v]; q < adj_ptr[v + 1]; ++q) if (part[adj_idx[q]] > part[v]) { forced[v] = 1; break; }
         std::atomic<long long> nd_ns[8];
         for (auto& a : nd_ns) a = 0;
-        nd_ctx C{ adj_ptr.data(), adj_idx.data(), cx, cy, side.data(), side2.data(), opt.leaf, opt.nd_both_axes, opt.nd_geo_first, S.nparts > 1 ? part : nullptr, iface.data(), forced.data(), &pool, &mu, tv ? nd_ns : nullptr, opt.nd_index_cuts != 0, pos_scratch.data() };
+        nd_ctx C{ adj_ptr.data(), adj_idx.data(), cx, cy, side.data(), side2.data(), opt.leaf, opt.nd_both_axes, opt.nd_geo_first, S.nparts > 1 ? part : nullptr, iface.data(), forced.data(), &pool, &mu, tv ? nd_ns : nullptr, opt.nd_index_cuts != 0, pos_scratch.data(), T };
         root = nd_order(nodes, C, S.order, 0);
         if (tv) fprintf(stderr, "[dsss pg symbolic] nd_order thread-time: candidates %.2f ms, final boundary %.2f ms, leaves %.2f ms\n", nd_ns[1] / 1e6, nd_ns[2] / 1e6, nd_ns[4] / 1e6);
     }

@@ -125,6 +125,9 @@ def record(wl, seed, world, device=0):
             else:
                 pipes[r].set_frames(my, poses, alts, grs); pipes[r].extract(); pipes[r].ctx.sync()
                 del my
+                keep = getattr(pipes[r].ctx, "_keep", {})   # (the binding keeps the borrowed raw tensors alive; nothing reads them after the extraction)
+                for k in list(keep):
+                    keep[k] = (None,) + tuple(keep[k][1:])
                 if stage_bar.wait() == 0:                # one thread lets the raw frames go once every rank has extracted
                     for f in range(F):
                         raws[f] = None
@@ -140,6 +143,8 @@ def record(wl, seed, world, device=0):
     if err:
         raise err[0]
     torch.cuda.synchronize()
+    free_b, total_b = torch.cuda.mem_get_info()
+    print("[emulate] lock-step run of %d ranks done: %.0f of %.0f GB of device memory in use" % (world, (total_b - free_b) / 2**30, total_b / 2**30), file=sys.stderr, flush=True)
     for p in pipes:
         p.close()
     torch.cuda.empty_cache()

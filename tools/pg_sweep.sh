@@ -1,10 +1,11 @@
 #!/bin/bash
 # A/B sweep of the analysis knobs on a dumped edge set: one process per setting (tools/pg_sweep.py)
-G=${1:-gpurun_out/C3_edges.npz}
+G=${1:-tools/_data/C3_edges.npz}
 out=gpurun_out/pg_sweep.log; : > $out
-run() { env "$@" python tools/pg_sweep.py $G 7 2>/dev/null | tail -1 >> $out; }
+run() { env "$@" PG_SWEEP_NOPROF=1 python tools/pg_sweep.py $G 9 2>/dev/null | tail -1 >> $out; }
 run X=1
-for v in 300 1000 1500 2500; do run DSSS_PG_BIN_COST=$v; done
+for v in 150 250 400 900 1500; do run DSSS_PG_BIN_COST=$v; done
 for v in 25 256; do run DSSS_PG_ND_BOTH=$v; done
-for v in 16 32; do run DSSS_PG_LEAF=$v; done
+for v in 12 16 32 48; do run DSSS_PG_LEAF=$v; done
+run X=2
 cat $out
