@@ -120,7 +120,7 @@ static int pg_solve_impl(dsss_ctx* c, const double* dr6, int total, const dsss_l
     for (int p = 0; p < nparts; ++p) pbound[p] = dr6 ? (int)((long long)n * p / nparts) : foff[(int)((long long)nframes * p / nparts)];
     for (int p = 0; p < nparts; ++p) if (pbound[p + 1] <= pbound[p]) DSSS_FAIL(c, DSSS_E_ARG, "empty pose-graph partition %d", p);
     const int part_lo = (int)((long long)nparts * rank / world), part_hi = (int)((long long)nparts * (rank + 1) / world);
-    const int mp0 = pbound[part_lo], mp1 = pbound[part_hi];
+    int mp0 = pbound[part_lo], mp1 = pbound[part_hi];                     // (final once the partition boundaries have moved to their cheapest cuts, below)
     const auto T0 = std::chrono::steady_clock::now();
     auto ms_since = [&](std::chrono::steady_clock::time_point t) { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t).count(); };
     const double PI = DSSS_PI_REF;
@@ -146,6 +146,39 @@ static int pg_solve_impl(dsss_ctx* c, const double* dr6, int total, const dsss_l
     auto mark = [&](int i) { tbits[(size_t)i >> 6] |= 1ull << (i & 63); };
     mark(0); mark(n - 1);
     for (int e = 0; e < ne; ++e) { mark(ea[e]); mark(eb[e]); }
+    if (nparts > 1 && ne > 0) {
+        // Where the partitions end (round 5).  The boundaries used to be frame boundaries; the interface of the partitioned solve -- the
+        // separators every rank factorises again, summed by the all-reduce -- is the set of poses whose loop closures cross a boundary, and
+        // how many cross depends on WHERE the chain is cut (dsss_pg_sym.cpp, chain_cut: between 1 and 200 at C3).  Every boundary moves to
+        // the cheapest gap between two loop-closure poses within a third of a partition's length of its frame boundary: cost of a gap = loop
+        // closures that span it, all gaps priced by one difference array.  Every rank holds all edges (exchanged before the solve), so every
+        // rank moves the boundaries to the same places.  Frames, features and matches stay sharded by frame: only pose ownership moves.
+        std::vector<int> ends; ends.reserve((size_t)2 * ne + 2);
+        for (size_t w = 0; w < tbits.size(); ++w)
+            for (unsigned long long bits = tbits[w]; bits; bits &= bits - 1) ends.push_back((int)(w * 64) + __builtin_ctzll(bits));
+        std::vector<int> pre(tbits.size() + 1, 0);
+        for (size_t w = 0; w < tbits.size(); ++w) pre[w + 1] = pre[w] + __builtin_popcountll(tbits[w]);
+        auto eidx = [&](int pose) { return pre[(size_t)pose >> 6] + __builtin_popcountll(tbits[(size_t)pose >> 6] & ((1ull << (pose & 63)) - 1ull)); };
+        const int m = (int)ends.size();
+        std::vector<int> cross(m + 1, 0);                                  // cross[i]: loop closures that span the gap between ends[i - 1] and ends[i]
+        for (int e = 0; e < ne; ++e) { const int lo = eidx(std::min(ea[e], eb[e])), hi = eidx(std::max(ea[e], eb[e])); cross[lo + 1]++; cross[hi + 1]--; }
+        for (int i = 1; i <= m; ++i) cross[i] += cross[i - 1];
+        const int width = n / nparts / 3;
+        for (int p = 1; p < nparts; ++p) {
+            const int target = pbound[p];
+            int best = -1; long long bcost = 1LL << 60, bdist = 0;
+            const int i0 = (int)(std::lower_bound(ends.begin(), ends.end(), target - width) - ends.begin());
+            for (int i = std::max(i0, 1); i < m && ends[i - 1] + 1 <= target + width; ++i) {      // boundary between ends[i - 1] and ends[i]: partition p starts at ends[i - 1] + 1
+                const int start = ends[i - 1] + 1;
+                if (start <= pbound[p - 1] || start < target - width) continue;
+                const long long d = std::llabs((long long)start - target);
+                if (cross[i] < bcost || (cross[i] == bcost && d < bdist)) { bcost = cross[i]; bdist = d; best = start; }
+            }
+            if (best > pbound[p - 1] && best < n) pbound[p] = best;
+        }
+        for (int p = 0; p < nparts; ++p) if (pbound[p + 1] <= pbound[p]) DSSS_FAIL(c, DSSS_E_ARG, "empty pose-graph partition %d", p);
+        mp0 = pbound[part_lo]; mp1 = pbound[part_hi];
+    }
     for (int p = 1; p < nparts; ++p) mark(pbound[p] - 1);                // a partition ends on a separator: segments never straddle ranks
     const int chunk = 16;                                                // (8 and 24 reach the same optimum; measured flat in round 2)
     // pass 2 is sequential over the chunk ends between two true separators: a gap of more than 16 chunks (frame boundaries

@@ -26,8 +26,24 @@ if which in ("c3", "c5real"):
     sv = Survey(F, N, 1024 if which == "c3" else 2048, seed=20240601 + (1 if which == "c3" else 3))
     dr = np.concatenate([sv.inputs(f)[0] for f in range(F)])
     is_sep = np.zeros(n, bool); is_sep[0] = is_sep[-1] = True; is_sep[a] = True; is_sep[b] = True
+    pb = [(F * q // nparts) * N for q in range(nparts)] + [n]
+    if nparts > 1 and os.environ.get("SYM_MOVE", "1") != "0":          # the boundaries move to their cheapest cuts (pg_solve_impl)
+        ends = np.nonzero(is_sep)[0]
+        lo = np.searchsorted(ends, np.minimum(a, b)); hi = np.searchsorted(ends, np.maximum(a, b))
+        cross = np.zeros(len(ends) + 2, np.int64); np.add.at(cross, lo + 1, 1); np.add.at(cross, hi + 1, -1); cross = np.cumsum(cross)
+        width = n // nparts // 3
+        for q in range(1, nparts):
+            target = pb[q]; best = None
+            for i in range(max(1, np.searchsorted(ends, target - width)), len(ends)):
+                start = ends[i - 1] + 1
+                if start > target + width: break
+                if start <= pb[q - 1] or start < target - width: continue
+                key = (cross[i], abs(start - target))
+                if best is None or key < best[0]: best = (key, start)
+            if best is not None: pb[q] = int(best[1])
+        print("partition boundaries", pb[1:-1], "crossing loop closures", [int(cross[np.searchsorted(ends, x - 1) + 1]) for x in pb[1:-1]])
     for q in range(1, nparts):
-        is_sep[(F * q // nparts) * N - 1] = True
+        is_sep[pb[q] - 1] = True
     # gaps of 16 chunks or more get separators of their own (pg_solve_impl): the first chunk end at least 256 poses after the last one
     marked = np.nonzero(is_sep)[0]
     fill = []
@@ -40,9 +56,7 @@ if which in ("c3", "c5real"):
     is_sep[np.array(fill, np.int64)] = True
     sep = np.nonzero(is_sep)[0]
     if nparts > 1:
-        part = np.ascontiguousarray(((sep // N) * nparts // F).astype(np.int32))      # frame f belongs to partition p with F p / nparts <= f (pg_solve_impl's pbound)
-        bound = np.array([F * q // nparts for q in range(nparts + 1)])
-        part = np.ascontiguousarray((np.searchsorted(bound, sep // N, side="right") - 1).astype(np.int32))
+        part = np.ascontiguousarray((np.searchsorted(np.array(pb), sep, side="right") - 1).astype(np.int32))
     sidx = -np.ones(n, np.int64); sidx[sep] = np.arange(len(sep))
     ns = len(sep)
     ea = np.concatenate([np.arange(ns - 1), sidx[a]]).astype(np.int32)

@@ -10,7 +10,9 @@ with open(sys.argv[1]) as f:
         rows.append((int(x["Start_Timestamp"]), int(x["End_Timestamp"]), x["Kernel_Name"].split("(")[0], int(x["Grid_Size_X"]), int(x["Workgroup_Size_X"]), int(x["Grid_Size_Y"]), int(x["Grid_Size_Z"])))
 rows.sort()
 idx = [i for i, x in enumerate(rows) if x[2] == "pg_assemble_kernel"]
-a, b = idx[-3], idx[-2]
+import os
+back = int(os.environ.get("TRIAL_FROM_END", "3"))        # TRIAL_FROM_END=8: a trial of the last TIMED step of a default bench.py run (five trials per step; the last pass is the profiled one)
+a, b = idx[-back], idx[-back + 1]
 t0 = rows[a][0]
 print("one trial span %.3f ms" % ((rows[b][0] - t0) / 1e6))
 agg = defaultdict(lambda: [0, 0.0])
