@@ -318,7 +318,7 @@ int nd_order(std::vector<int>& nodes, const nd_ctx& C, std::vector<int>& order, 
             std::stable_partition(nd.begin(), nd.end(), [&](int v) { return less_than(key[v], v, cc.pk, cc.pi); });
         };
         const double lo_of[3] = { y0, x0, (double)i0 }, hi_of[3] = { y1, x1, (double)i1 };           // [bx]
-        const bool idx_cand = C.index_cuts && total >= C.both_axes && total >= 96;
+        const bool idx_cand = C.index_cuts && total >= C.both_axes && total >= 96;      // (only from 512 / 2 048 / 4 096 / 16 384 nodes on: C3 13 / 13 / 14 / 35 panel levels instead of 12, C5 35 / 36 / 37 / 44 instead of 35 -- the big sets matter most, the small ones still count)
         // The chain-order candidate goes first, and a very cheap one (at most 1/1024 of the set) ends the search: at the top of the recursion --
         // the serial part of the ordering -- it costs one pass over the set's edges and wins anyway (C3: 1 to 7 separator nodes where the
         // coordinate medians cost 26 to 207), the coordinate candidates are a histogram selection and a counting pass each.
