@@ -37,8 +37,26 @@ static void run(unsigned seed, int ns, int nlc, int reps)
     }
     printf("seed %u ok: x[0] %.6f\n", seed, x[0]);
 }
+// analysis only (x = NULL) of a graph beyond 65 536 separators: the passes of the ordering that run by ranges of a large node set (round 5:
+// key copies, histograms, marks, counts; the difference array of the chain-order cut with relaxed atomic adds)
+static void run_large(unsigned seed, int ns, int nlc)
+{
+    unsigned long long lcg = seed * 2654435761ull + 1; auto rnd = [&]() { lcg = lcg * 6364136223846793005ull + 1442695040888963407ull; return (int)((lcg >> 33) & 0x7fffffff); };
+    std::vector<int32_t> ea, eb; std::vector<double> cx(ns), cy(ns);
+    for (int k = 0; k + 1 < ns; ++k) { ea.push_back(k); eb.push_back(k + 1); }
+    const int leg = 400;
+    for (int k = 0; k < ns; ++k) { const int l = k / leg, p = k % leg; cx[k] = (l & 1) ? leg - p : p; cy[k] = 3.0 * l + 1e-3 * (rnd() % 100); }
+    for (int e = 0; e < nlc; ++e) { const int a = rnd() % (ns - 2 * leg), b = a + leg + (leg - 2 * (a % leg)) - 1 + (rnd() % 3); if (b > a && b < ns) { ea.push_back(a); eb.push_back(b); } }
+    int64_t st[8];
+    setenv("DSSS_SYM_THREADS", "4", 1);
+    const int rc = dsss_host_pg_solve(ns, ea.data(), eb.data(), (int)ea.size(), cx.data(), cy.data(), nullptr, 1, nullptr, nullptr, nullptr, st);
+    unsetenv("DSSS_SYM_THREADS");
+    if (rc) { printf("large analysis rc %d\n", rc); exit(1); }
+    printf("large analysis ok: %d separators, %lld blocks of L, %lld levels\n", ns, (long long)st[0], (long long)st[3]);
+}
 int main()
 {
+    run_large(7u, 90000, 40000);
     std::thread a(run, 1u, 9000, 1200, 2), b(run, 2u, 2400, 300, 3);     // (9000 separators: large enough for the concurrently counted cut candidates of the ordering)
     run(3u, 1800, 250, 3);
     a.join(); b.join();
