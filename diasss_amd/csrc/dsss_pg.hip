@@ -130,9 +130,18 @@ static int pg_solve_impl(dsss_ctx* c, const double* dr6, int total, const dsss_l
       for (int k = 0; k < 6; ++k) { W.prior[k] = 1.0 / 0.000001; W.odo[k] = 1.0 / so[k]; } }
     // DR poses, measurements and initial values are produced on the device (pg_init_kernel) further down
     std::vector<int> ea(ne), eb(ne), eo(ne); std::vector<pose_t> emeas; std::vector<double> ew;      // (the measurements' 1.7 MB are allocated where they are filled, beside the analysis: touching fresh pages here is time the GPU waits for)
-    for (int e = 0; e < ne; ++e) {                  // the end points first: they are all the analysis needs (the measurements are unpacked beside it, below)
-        ea[e] = edges[e].a; eb[e] = edges[e].b; eo[e] = std::max(edges[e].a, edges[e].b);
-        if (ea[e] < 0 || ea[e] >= n || eb[e] < 0 || eb[e] >= n || ea[e] == eb[e]) DSSS_FAIL(c, DSSS_E_ARG, "LC edge %d out of range", e);
+    {   // the end points first: they are all the analysis needs (the measurements are unpacked beside it, below).  The records are 152 bytes
+        // apart: at C5 (351 k edges, 53 MB) one thread spent 3.6 ms here before the analysis could start, so large edge sets go by ranges
+        const int TE = ne >= 65536 ? 8 : 1;
+        std::vector<int> bad(TE, -1);
+        dsss_pool_run(TE, [&](int t) {
+            const int e0 = (int)((long long)ne * t / TE), e1 = (int)((long long)ne * (t + 1) / TE);
+            for (int e = e0; e < e1; ++e) {
+                ea[e] = edges[e].a; eb[e] = edges[e].b; eo[e] = std::max(edges[e].a, edges[e].b);
+                if ((ea[e] < 0 || ea[e] >= n || eb[e] < 0 || eb[e] >= n || ea[e] == eb[e]) && bad[t] < 0) bad[t] = e;
+            }
+        });
+        for (int t = 0; t < TE; ++t) if (bad[t] >= 0) DSSS_FAIL(c, DSSS_E_ARG, "LC edge %d out of range", bad[t]);
     }
     // Two levels of chain elimination.  TRUE separators (the unknowns of the sparse factorisation): LC-touched poses, the first and
     // the last pose, the last pose of every partition.  CHUNK ends: every PG_CHUNK-th pose as well, which bounds the sequential
