@@ -1,5 +1,6 @@
 """GPU parity: batched mini-LM loop-closure solve, LC selection and the pose-graph LM against the CPU oracle.
 Floating point: tolerances are written next to each assertion (north_star: 1e-6 on optimised poses)."""
+import os
 import numpy as np
 import pytest
 
@@ -126,6 +127,40 @@ def test_posegraph_edges_api_small_cases(ctx, orc):
         for _ in range(3):                                   # same bits every run (duplicates used to be added atomically)
             g2, s2 = ctx.posegraph_solve_edges(dr, edges)
             assert (g2 == g_out).all() and (np.asarray(s2) == np.asarray(g_stats)).all()
+
+
+def test_posegraph_error_exits_leave_the_context_usable(orc):
+    """the error exits of the solve (an edge out of range before anything runs; a variance that is not positive or a relative pose that is not
+    finite AFTER the analysis thread has started and the device ordering / preparation is in flight) return an error, and the next solve on the
+    same context gives the bits of a fresh one: the exit joins the analysis thread and drains its stream before the arena goes back"""
+    from diasss_amd import capi
+    from tests.test_gpu_configs import _lawnmower_graph
+    dr, gt, edges = _lawnmower_graph(6, 3000, 800, seed=5)
+    c = capi.Context(max_frames=2)
+    ref, sref = c.posegraph_solve_edges(dr, edges)
+    for env in ({}, {"DSSS_PG_ND_INDEX": "0"}):                            # host ordering (default) and the device ordering
+        old = {k: os.environ.get(k) for k in env}
+        os.environ.update(env)
+        try:
+            for kind in ("range", "var0", "varnan", "relnan", "var0"):
+                bad = edges.copy()
+                k = len(bad) // 2
+                if kind == "range": bad["b"][k] = len(dr) + 5
+                elif kind == "var0": bad["var"][k, 3] = 0.0
+                elif kind == "varnan": bad["var"][k, 1] = np.nan
+                else: bad["rel"][k, 4] = np.inf
+                with pytest.raises(capi.DsssError):
+                    c.posegraph_solve_edges(dr, bad)
+                p, st = c.posegraph_solve_edges(dr, edges)
+                if not env:
+                    assert (p == ref).all() and (np.asarray(st) == np.asarray(sref)).all(), kind
+                else:
+                    assert st[0] == sref[0] and np.abs(p - ref).max() < 1e-8, kind
+        finally:
+            for k, v in old.items():
+                if v is None: os.environ.pop(k, None)
+                else: os.environ[k] = v
+    c.close()
 
 
 def test_initial_values_follow_libstdcxx_normal_stream(ctx, orc):
