@@ -174,10 +174,11 @@ typedef uint16_t u16_unaligned __attribute__((aligned(1)));
 #endif
 typedef unsigned short rs_u16x2 __attribute__((ext_vector_type(2)));
 typedef uint32_t rs_u32x3 __attribute__((ext_vector_type(3)));
-__global__ __launch_bounds__(256) void resize_kernel(const ex_frame* __restrict__ frs, int level)
+__global__ __launch_bounds__(256) void resize_kernel(const ex_frame* __restrict__ frs, int level, int rest_only)
 {
     const ex_frame& f = frs[blockIdx.y];
     if (level >= f.nlevels) return;
+    if (rest_only && f.xt[level][f.cols[level] + 4].sx != 0) return;      // resize_strip_kernel has done this frame
     // pointers read from the frame record are generic to the compiler (flat loads, 64-bit address arithmetic per access): say
     // they are global, and index them with 32-bit offsets from the wave-uniform base
     const DSSS_GLOBAL uint8_t* __restrict__ src = (const DSSS_GLOBAL uint8_t*)f.lvl[level - 1]; DSSS_GLOBAL uint8_t* __restrict__ dst = (DSSS_GLOBAL uint8_t*)f.lvl[level];
@@ -281,6 +282,85 @@ __global__ __launch_bounds__(256) void resize_kernel(const ex_frame* __restrict_
     for (int k = 0; k < RS_K; ++k) {
         if (g0[k] + 3 < total) *reinterpret_cast<DSSS_GLOBAL uint32_t*>(dst + g0[k]) = outv[k];
         else for (int u = 0; u < 4; ++u) if (g0[k] + u < total) dst[g0[k] + u] = (uint8_t)(outv[k] >> (8 * u));
+    }
+}
+
+// The same resize BY COLUMN STRIPS (round 5), for the geometries whose windows fit (every level of a pyramid with scale < 4/3): a
+// thread owns FOUR output columns and walks RS_R output rows.  What depends on the columns alone -- the four table entries, the
+// offsets d of the left source pixels from the first one -- is fetched and derived once per thread instead of once per group; per
+// row the 12-byte window of each of the two source rows is shifted to the first source pixel by v_alignbyte (the alignment of
+// ya * sw + sx is the row's), after which the pixel pairs come out by v_perm with selectors that are constants of the thread.
+// 65 vector instructions per four pixels where the flat form (division of the flat index, tables and selectors per group) took
+// 147; all loads of the RS_R rows are issued before the arithmetic.  Rows are sw bytes apart, not padded: the four output bytes
+// are one store at whatever alignment dy * dw + 4 g has.
+#define RS_R 8
+typedef uint32_t u32_unaligned __attribute__((aligned(1)));
+__global__ __launch_bounds__(256) void resize_strip_kernel(const ex_frame* __restrict__ frs, int level)
+{
+    const ex_frame& f = frs[blockIdx.y];
+    if (level >= f.nlevels) return;
+    const DSSS_GLOBAL uint8_t* __restrict__ src = (const DSSS_GLOBAL uint8_t*)f.lvl[level - 1]; DSSS_GLOBAL uint8_t* __restrict__ dst = (DSSS_GLOBAL uint8_t*)f.lvl[level];
+    const int sw = f.cols[level - 1], dh = f.rows[level], dw = f.cols[level];
+    const DSSS_GLOBAL resize_xtab* __restrict__ xt = (const DSSS_GLOBAL resize_xtab*)f.xt[level]; const DSSS_GLOBAL resize_ytab* __restrict__ yt = (const DSSS_GLOBAL resize_ytab*)f.yt[level];
+    if (xt[dw + 4].sx == 0) return;                                       // windows do not fit: resize_kernel(rest_only) does this frame
+    const uint32_t G = (uint32_t)(dw + 3) >> 2, nch = (uint32_t)(dh + RS_R - 1) / RS_R;
+    const uint32_t t = blockIdx.x * 256u + threadIdx.x;
+    if (t >= G * nch) return;
+    uint32_t ch = (uint32_t)((double)t * (1.0 / (double)G));              // quotient by reciprocal, one correction (t < 2^29)
+    int g = (int)t - (int)(ch * G);
+    if (g < 0) { --ch; g += (int)G; } else if (g >= (int)G) { ++ch; g -= (int)G; }
+    // columns: xt[4 g .. 4 g + 3] (the table carries four more entries behind the last column)
+    const uint4 xa = *reinterpret_cast<const DSSS_GLOBAL uint4*>(reinterpret_cast<const DSSS_GLOBAL char*>(xt) + (uint32_t)g * 32u);
+    const uint4 xb = *reinterpret_cast<const DSSS_GLOBAL uint4*>(reinterpret_cast<const DSSS_GLOBAL char*>(xt) + (uint32_t)g * 32u + 16u);
+    const uint32_t xs0 = xa.x;
+    const uint32_t xw[4] = { xa.y, xa.w, xb.y, xb.w };
+    uint32_t sel[4];
+    {
+        const uint32_t sx[4] = { xa.x, xa.z, xb.x, xb.z };
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            uint32_t d = sx[u] - xs0;                                     // 0 .. 4 (a column past the end of the row: anything, never stored)
+            d = d > 4u ? 0u : d;
+            sel[u] = 0x0c010c00u + d * 0x00010001u;                       // { 0, byte d + 1, 0, byte d } of the shifted window
+        }
+    }
+    const uint32_t dy0 = ch * RS_R;
+    resize_ytab Y[RS_R];
+#pragma unroll
+    for (int r = 0; r < RS_R; ++r) {
+        const uint32_t dy = dy0 + r < (uint32_t)dh ? dy0 + r : (uint32_t)dh - 1u;
+        Y[r] = *reinterpret_cast<const DSSS_GLOBAL resize_ytab*>(reinterpret_cast<const DSSS_GLOBAL char*>(yt) + dy * (uint32_t)sizeof(resize_ytab));
+    }
+    rs_u32x3 WA[RS_R], WB[RS_R]; uint32_t ma[RS_R], mb[RS_R];
+#pragma unroll
+    for (int r = 0; r < RS_R; ++r) {
+        const uint32_t ba = __umul24((uint32_t)Y[r].ya, (uint32_t)sw) + xs0, bb = __umul24((uint32_t)Y[r].yb, (uint32_t)sw) + xs0;
+        ma[r] = ba & 3u; mb[r] = bb & 3u;                                 // the level base is 256-byte aligned
+        WA[r] = *reinterpret_cast<const DSSS_GLOBAL rs_u32x3*>(src + (ba & ~3u));
+        WB[r] = *reinterpret_cast<const DSSS_GLOBAL rs_u32x3*>(src + (bb & ~3u));
+    }
+    const bool full = 4 * g + 3 < dw;
+#pragma unroll
+    for (int r = 0; r < RS_R; ++r) {
+        const uint32_t a0 = __builtin_amdgcn_alignbyte(WA[r].y, WA[r].x, ma[r]), a1 = __builtin_amdgcn_alignbyte(WA[r].z, WA[r].y, ma[r]);
+        const uint32_t c0 = __builtin_amdgcn_alignbyte(WB[r].y, WB[r].x, mb[r]), c1 = __builtin_amdgcn_alignbyte(WB[r].z, WB[r].y, mb[r]);
+        // (b (r >> 4)) >> 16 = the high word of the 24-bit product (b << 12) (r & ~15): weights <= 2^11, row sums < 2^19
+        const uint64_t b0 = (uint64_t)(((uint32_t)Y[r].b0 << 12) & 0xffffffu), b1 = (uint64_t)(((uint32_t)Y[r].b1 << 12) & 0xffffffu);
+        uint32_t out = 0;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const rs_u16x2 w = __builtin_bit_cast(rs_u16x2, xw[u]);
+            const uint32_t r0 = __builtin_amdgcn_udot2(__builtin_bit_cast(rs_u16x2, __builtin_amdgcn_perm(a1, a0, sel[u])), w, 0u, false);
+            const uint32_t r1 = __builtin_amdgcn_udot2(__builtin_bit_cast(rs_u16x2, __builtin_amdgcn_perm(c1, c0, sel[u])), w, 0u, false);
+            const uint32_t h0 = (uint32_t)((b0 * (uint64_t)(r0 & 0xfffff0u)) >> 32), h1 = (uint32_t)((b1 * (uint64_t)(r1 & 0xfffff0u)) >> 32);
+            const uint32_t v = ((h0 + h1 + 2u) >> 2) & 255u;
+            out |= v << (8 * u);
+        }
+        if (dy0 + r < (uint32_t)dh) {
+            DSSS_GLOBAL uint8_t* o = dst + ((dy0 + r) * (uint32_t)dw + 4u * (uint32_t)g);
+            if (full) *reinterpret_cast<DSSS_GLOBAL u32_unaligned*>(o) = out;
+            else for (int u = 0; u < 4; ++u) if (4 * g + u < dw) o[u] = (uint8_t)(out >> (8 * u));
+        }
     }
 }
 
@@ -824,6 +904,7 @@ struct level_geom {
     fast_cell* d_cells = nullptr;         // device copy (per geometry, cached in the context)
     int* d_lrows = nullptr; float* d_lscale = nullptr;
     resize_xtab* d_xt[DSSS_MAX_LEVELS] = { nullptr }; resize_ytab* d_yt[DSSS_MAX_LEVELS] = { nullptr };
+    bool strips[DSSS_MAX_LEVELS] = { false };                  // level l is resized by resize_strip_kernel (the windowed loads fit)
     ~level_geom() { hipFree(d_cells); hipFree(d_lrows); hipFree(d_lscale); for (int l = 0; l < DSSS_MAX_LEVELS; ++l) { hipFree(d_xt[l]); hipFree(d_yt[l]); } }
 };
 
@@ -947,6 +1028,7 @@ static int get_geom(dsss_ctx* c, int N, int M, level_geom** out)
         for (int l = 1; l < g->nlevels; ++l) {                  // cv::resize(INTER_LINEAR) tables of level l from level l - 1
             std::vector<resize_xtab> xt; std::vector<resize_ytab> yt;
             resize_tables(g->rows[l - 1], g->cols[l - 1], g->rows[l], g->cols[l], xt, yt);
+            g->strips[l] = xt[g->cols[l] + 4].sx != 0;
             HIPCHK(c, hipMalloc(&g->d_xt[l], xt.size() * sizeof(resize_xtab))); HIPCHK(c, hipMalloc(&g->d_yt[l], yt.size() * sizeof(resize_ytab)));
             HIPCHK(c, hipMemcpy(g->d_xt[l], xt.data(), xt.size() * sizeof(resize_xtab), hipMemcpyHostToDevice));
             HIPCHK(c, hipMemcpy(g->d_yt[l], yt.data(), yt.size() * sizeof(resize_ytab), hipMemcpyHostToDevice));
@@ -1142,8 +1224,12 @@ static int extract_frames_impl(dsss_ctx* c, const int* ids, int n, bool keep_tap
         { dsss_scope sc(c, DSSS_K_NORMALIZE, 9.0 * w_tot);
           hipLaunchKernelGGL(normalize_kernel, dim3((unsigned)((max_tot / 4 + 256) / 256), nb), dim3(256), 0, st, d_exf, c->mp.r); }
         { dsss_scope sc(c, DSSS_K_PYRAMID, (1.906 + 2.74) * w_tot, std::max(max_levels - 1, 1));
-          for (int l = 1; l < max_levels; ++l)
-              hipLaunchKernelGGL(resize_kernel, dim3((unsigned)(((size_t)max_cols[l] * max_rows[l] / 4 + 256 * RS_K) / (256 * RS_K)), nb), dim3(256), 0, st, d_exf, l); }
+          for (int l = 1; l < max_levels; ++l) {
+              bool strips = false, rest = false;
+              for (int s2 = 0; s2 < nb; ++s2) { const level_geom& g = *G[b0 + s2]; if (l < g.nlevels) (g.strips[l] ? strips : rest) = true; }
+              if (strips) hipLaunchKernelGGL(resize_strip_kernel, dim3((unsigned)(((size_t)((max_cols[l] + 3) / 4) * ((max_rows[l] + RS_R - 1) / RS_R) + 255) / 256), nb), dim3(256), 0, st, d_exf, l);
+              if (rest) hipLaunchKernelGGL(resize_kernel, dim3((unsigned)(((size_t)max_cols[l] * max_rows[l] / 4 + 256 * RS_K) / (256 * RS_K)), nb), dim3(256), 0, st, d_exf, l, strips ? 1 : 0);
+          } }
         // FAST, candidate compaction and the quadtree run BY GROUPS OF LEVELS.  A quadtree instance is one workgroup whose time is the latency
         // of its own level's candidates (1.4 ms on level 0 of a 2000 x 1024 frame, whatever the number of frames) during which most of the
         // chip idles, so the levels are pipelined over four streams:

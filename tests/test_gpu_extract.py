@@ -107,6 +107,29 @@ def test_extract_other_scale_factors(ctx, orc, scale, N, M):
         ctx.set_params(orb=ctx.default_params()[1])
 
 
+def test_resize_strips_and_flat_form_in_one_batch(ctx, orc):
+    """at a scale of 1.334 the 12-byte windows fit the 500 x 300 frame's first level (resize_strip_kernel) and do not fit the
+    500 x 302 frame's (resize_kernel, which then skips the frames the strips did): both in ONE extract_many, every keypoint and
+    descriptor as the oracle's"""
+    mp, op, mt, pg = ctx.default_params()
+    op.nfeatures = 500; op.nlevels = 4; op.scale = 1.334
+    ctx.set_params(orb=op)
+    try:
+        frames = [_frame(500, M, 21 + i, hot=False) for i, M in enumerate((300, 302))]
+        for i, (raw, pose, alt, gr) in enumerate(frames): ctx.frame_set(i, raw, 500, raw.shape[1], pose, alt, gr)
+        ctx.extract_many([0, 1])
+        po = orc.orb_params(); po.nfeatures = 500; po.nlevels = 4; po.scale = 1.334
+        for i, (raw, pose, alt, gr) in enumerate(frames):
+            kps, desc, _, _ = orc.detect_feature(raw, None, po)
+            g_kps, g_desc, _ = ctx.features_get(i)
+            assert len(g_kps) == len(kps) and len(kps) > 50
+            for fld in ("x", "y", "octave", "angle", "response"):
+                assert (g_kps[fld] == kps[fld]).all(), (i, fld)
+            assert (g_desc == desc).all()
+    finally:
+        ctx.set_params(orb=ctx.default_params()[1])
+
+
 def test_extract_device_resident_input(ctx, orc):
     """raw image handed over as a device pointer (torch tensor in HBM): same result, no host copy"""
     import torch
