@@ -103,8 +103,10 @@ void dsss_pg_free(dsss_ctx* c) { for (auto& ch : c->pg_chunks) hipFree(ch.first)
 // batch LM over `total` poses with `ne` LC edges (host).  The DR rows (total x 6) are either one host array (dr6) or,
 // with dr6 == NULL, the rows of frames 0 .. nframes-1 of the context: read on the host from the frames' pinned copies
 // (only the separator poses are looked at) and gathered on the device straight from the frames' device copies.
+// `ends` (optional): the (a, b) pairs of the edges, already on the host while the records themselves are still on their way
+// (pg_select_impl; c->pg_edges_ev says when they have arrived)
 static int pg_solve_impl(dsss_ctx* c, const double* dr6, int total, const dsss_lc_edge* edges, int ne, double* poses12, double* stats4, double* rpy6 = nullptr,
-                         int nframes = 0)
+                         int nframes = 0, const int* ends = nullptr)
 {
     std::vector<int> foff;
     if (!dr6) { foff.assign(nframes + 1, 0); for (int f = 0; f < nframes; ++f) foff[f + 1] = foff[f] + c->frames[f].N; }
@@ -137,7 +139,8 @@ static int pg_solve_impl(dsss_ctx* c, const double* dr6, int total, const dsss_l
         dsss_pool_run(TE, [&](int t) {
             const int e0 = (int)((long long)ne * t / TE), e1 = (int)((long long)ne * (t + 1) / TE);
             for (int e = e0; e < e1; ++e) {
-                ea[e] = edges[e].a; eb[e] = edges[e].b; eo[e] = std::max(edges[e].a, edges[e].b);
+                if (ends) { ea[e] = ends[2 * (size_t)e]; eb[e] = ends[2 * (size_t)e + 1]; } else { ea[e] = edges[e].a; eb[e] = edges[e].b; }
+                eo[e] = std::max(ea[e], eb[e]);
                 if ((ea[e] < 0 || ea[e] >= n || eb[e] < 0 || eb[e] >= n || ea[e] == eb[e]) && bad[t] < 0) bad[t] = e;
             }
         });
@@ -365,6 +368,7 @@ static int pg_solve_impl(dsss_ctx* c, const double* dr6, int total, const dsss_l
         coords_guard.set();
     }
     emeas.resize(ne); ew.resize((size_t)ne * 6);
+    if (ends && ne > 0) { const hipError_t e = hipEventSynchronize(c->pg_edges_ev); if (e != hipSuccess) { abandon(); HIPCHK(c, e); } }      // the records have arrived
     for (int e = 0; e < ne; ++e) {                  // measurements and weights of the loop closures (the analysis is running and has its coordinates)
         for (int k = 0; k < 9; ++k) emeas[e].R[k] = edges[e].rel[k];
         for (int k = 0; k < 3; ++k) emeas[e].t[k] = edges[e].rel[9 + k];
@@ -899,7 +903,7 @@ __global__ __launch_bounds__(256) void lc_edge_flag_kernel(const unsigned long l
 __global__ __launch_bounds__(256) void lc_edge_compact_kernel(const int* __restrict__ flags, const int* __restrict__ bsum, const unsigned long long* __restrict__ slot,
                                                               int total, const int* __restrict__ kp7_off, const double* __restrict__ kp7,
                                                               const dsss_lc* __restrict__ lcs, const int* __restrict__ act_s, const int* __restrict__ frame_off,
-                                                              int cap, dsss_lc_edge* __restrict__ edges)
+                                                              int cap, dsss_lc_edge* __restrict__ edges, int2* __restrict__ ab)
 {
     __shared__ int s_w[4];
     __shared__ int s_run;
@@ -929,6 +933,7 @@ __global__ __launch_bounds__(256) void lc_edge_compact_kernel(const int* __restr
             for (int q = 0; q < 12; ++q) ed.rel[q] = lcs[i].rel[q];
             for (int q = 0; q < 6; ++q) ed.var[q] = lcs[i].var[q];
             edges[pos] = ed;
+            if (ab) ab[pos] = make_int2(ed.a, ed.b);
         }
         __syncthreads();
         if (threadIdx.x == 0) s_run += s_w[0] + s_w[1] + s_w[2] + s_w[3];
@@ -936,9 +941,12 @@ __global__ __launch_bounds__(256) void lc_edge_compact_kernel(const int* __restr
     }
 }
 
-extern "C" {
-
-int dsss_posegraph_select(dsss_ctx* c, int nframes, dsss_lc_edge* edges, int cap, int* n_edges)
+// ends != NULL (dsss_posegraph_solve, one rank): the END POINTS of the edges come back first -- they are all the analysis of the solve
+// needs -- as (a, b) pairs in the context's page-locked buffer, *ends pointing at them; the 152-byte records follow asynchronously into
+// `edges` (page-locked as well) with c->pg_edges_ev recorded behind the copy: the solve waits for it where it unpacks the measurements,
+// beside the analysis.  (Records first cost 0.2 ms between the end of lc_kernel and the start of the analysis, with the GPU idle.)
+#define PG_AB_PREFIX 32768
+static int pg_select_impl(dsss_ctx* c, int nframes, dsss_lc_edge* edges, int cap, int* n_edges, const int** ends)
 {
     if (!c || nframes <= 0 || nframes > c->max_frames) return DSSS_E_ARG;
     if (!c->has_lc) DSSS_FAIL(c, DSSS_E_STATE, "dsss_lc_solve_all has not run");
@@ -958,7 +966,7 @@ int dsss_posegraph_select(dsss_ctx* c, int nframes, dsss_lc_edge* edges, int cap
         // everything on the device: winner per target pose (atomicMax), score filter, ordered compaction; only the
         // edge records come back.  Scratch comes from the solver arena (reset by the solve that follows).
         pg_dev dv;
-        unsigned long long* d_slot; int *d_off, *d_flags, *d_bsum, *d_total; dsss_lc_edge* d_edges;
+        unsigned long long* d_slot; int *d_off, *d_flags, *d_bsum, *d_total; dsss_lc_edge* d_edges; int2* d_ab = nullptr;
         const int nb = (total + 4095) / 4096;
         int rc = dv.alloc(c, &d_slot, (size_t)total); if (rc) return rc;
         rc = dv.alloc(c, &d_off, (size_t)nframes + 1); if (rc) return rc;
@@ -966,6 +974,16 @@ int dsss_posegraph_select(dsss_ctx* c, int nframes, dsss_lc_edge* edges, int cap
         rc = dv.alloc(c, &d_bsum, (size_t)nb); if (rc) return rc;
         rc = dv.alloc(c, &d_total, 1); if (rc) return rc;
         rc = dv.alloc(c, &d_edges, (size_t)cap); if (rc) return rc;
+        if (ends) {
+            rc = dv.alloc(c, &d_ab, (size_t)cap); if (rc) return rc;
+            if (c->pg_ab_cap < (size_t)cap) {
+                if (c->pg_ab_host) hipHostFree(c->pg_ab_host);
+                c->pg_ab_host = nullptr; c->pg_ab_cap = 0;
+                HIPCHK(c, hipHostMalloc((void**)&c->pg_ab_host, (size_t)cap * sizeof(int2), hipHostMallocDefault));
+                c->pg_ab_cap = (size_t)cap;
+            }
+            if (!c->pg_edges_ev) HIPCHK(c, hipEventCreateWithFlags(&c->pg_edges_ev, hipEventDisableTiming));
+        }
         hipStream_t st = c->stream;
         HIPCHK(c, hipMemsetAsync(d_slot, 0, (size_t)total * sizeof(unsigned long long), st));
         HIPCHK(c, hipMemcpyAsync(d_off, off.data(), (nframes + 1) * sizeof(int), hipMemcpyHostToDevice, st));
@@ -973,17 +991,30 @@ int dsss_posegraph_select(dsss_ctx* c, int nframes, dsss_lc_edge* edges, int cap
         hipLaunchKernelGGL(lc_edge_flag_kernel, dim3((total + 255) / 256), dim3(256), 0, st, d_slot, total, c->kp7_off, c->lcs, d_flags);
         hipLaunchKernelGGL(pg_flag_blocksum_kernel, dim3(nb), dim3(256), 0, st, d_flags, (long long)total, d_bsum);
         hipLaunchKernelGGL(pg_flag_scan_kernel, dim3(1), dim3(256), 0, st, d_bsum, nb, d_total);
-        hipLaunchKernelGGL(lc_edge_compact_kernel, dim3(nb), dim3(256), 0, st, d_flags, d_bsum, d_slot, total, c->kp7_off, c->kp7, c->lcs, c->act_s, d_off, cap, d_edges);
+        hipLaunchKernelGGL(lc_edge_compact_kernel, dim3(nb), dim3(256), 0, st, d_flags, d_bsum, d_slot, total, c->kp7_off, c->kp7, c->lcs, c->act_s, d_off, cap, d_edges, d_ab);
         HIPCHK(c, hipGetLastError());
         HIPCHK(c, hipMemcpyAsync(&ne, d_total, sizeof(int), hipMemcpyDeviceToHost, st));
+        const int pre = std::min(cap, PG_AB_PREFIX);               // the count is not known yet: the first pairs travel with it
+        if (ends) HIPCHK(c, hipMemcpyAsync(c->pg_ab_host, d_ab, (size_t)pre * sizeof(int2), hipMemcpyDeviceToHost, st));
         HIPCHK(c, hipStreamSynchronize(st));
         if (ne > cap) { dv.release(); DSSS_FAIL(c, DSSS_E_CAPACITY, "more than %d LC edges", cap); }
-        if (ne > 0) HIPCHK(c, hipMemcpy(edges, d_edges, (size_t)ne * sizeof(dsss_lc_edge), hipMemcpyDeviceToHost));
+        if (ends) {
+            if (ne > pre) { HIPCHK(c, hipMemcpyAsync(c->pg_ab_host + 2 * (size_t)pre, d_ab + pre, (size_t)(ne - pre) * sizeof(int2), hipMemcpyDeviceToHost, st)); HIPCHK(c, hipStreamSynchronize(st)); }
+            if (ne > 0) HIPCHK(c, hipMemcpyAsync(edges, d_edges, (size_t)ne * sizeof(dsss_lc_edge), hipMemcpyDeviceToHost, st));
+            HIPCHK(c, hipEventRecord(c->pg_edges_ev, st));         // (the arena the records sit in is reused by the solve: by work queued on this stream, behind the copy)
+            *ends = c->pg_ab_host;
+        }
+        else if (ne > 0) HIPCHK(c, hipMemcpy(edges, d_edges, (size_t)ne * sizeof(dsss_lc_edge), hipMemcpyDeviceToHost));
         dv.release();
     }
+    else if (ends) *ends = nullptr;
     if (n_edges) *n_edges = ne;
     return DSSS_OK;
 }
+
+extern "C" {
+
+int dsss_posegraph_select(dsss_ctx* c, int nframes, dsss_lc_edge* edges, int cap, int* n_edges) { return pg_select_impl(c, nframes, edges, cap, n_edges, nullptr); }
 
 int dsss_posegraph_solve_edges(dsss_ctx* c, const double* dr6, int total, const dsss_lc_edge* edges, int ne, double* poses12, double* stats4)
 {
@@ -1020,9 +1051,10 @@ int dsss_posegraph_solve(dsss_ctx* c, int nframes, double* poses12, double* rpy6
     int ne = 0;
     const double t_dr = ms(t0);
     const auto t1 = std::chrono::steady_clock::now();
-    int rc = dsss_posegraph_select(c, nframes, edges_p, (int)ecap, &ne);
-    if (rc) return rc;
     const int world = dsss_comm_world(c), rank = dsss_comm_rank(c);
+    const int* ends = nullptr;
+    int rc = pg_select_impl(c, nframes, edges_p, (int)ecap, &ne, world == 1 ? &ends : nullptr);
+    if (rc) return rc;
     if (world > 1) {
         // every rank selected the loop closures of the pairs it matched (pairs go to the owner of the TARGET frame, so a target
         // ping's "last pair wins" choice is rank-local): exchange them with two small all-reduces (counts, then the records in
@@ -1082,7 +1114,7 @@ int dsss_posegraph_solve(dsss_ctx* c, int nframes, double* poses12, double* rpy6
     }
     const double t_sel = ms(t1);
     const auto t2 = std::chrono::steady_clock::now();
-    rc = pg_solve_impl(c, nullptr, (int)total, edges_p, ne, poses12, stats4, rpy6, nframes);
+    rc = pg_solve_impl(c, nullptr, (int)total, edges_p, ne, poses12, stats4, rpy6, nframes, ends);
     if (rc) return rc;
     if (getenv("DSSS_PG_VERBOSE")) fprintf(stderr, "[dsss pg] DR rows %.1f ms, LC selection %.1f ms, solve + download %.1f ms\n", t_dr, t_sel, ms(t2));
     return DSSS_OK;

@@ -4,7 +4,8 @@ import csv, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 starts = [i for i, r in enumerate(rows) if r["Kernel_Name"].startswith("row_reduce_kernel")]
-i0 = starts[-int(__import__("os").environ.get("STEP_FROM_END", "1"))]          # STEP_FROM_END=2: the last TIMED step of a default bench.py run (the very last pass is the profiled one); t0 = int(rows[i0]["Start_Timestamp"])
+i0 = starts[-int(__import__("os").environ.get("STEP_FROM_END", "1"))]          # STEP_FROM_END=2: the last TIMED step of a default bench.py run (the very last pass is the profiled one)
+t0 = int(rows[i0]["Start_Timestamp"])
 on = False; prev_end = None
 _k = int(__import__("os").environ.get("STEP_FROM_END", "1"))
 _i1 = starts[-_k + 1] if _k > 1 else len(rows)
