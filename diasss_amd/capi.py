@@ -132,7 +132,7 @@ class Context:
         if getattr(self, "h", None):
             self.L.dsss_destroy(self.h)
             self.h = None
-        for k in ("_keep", "_addr_cache", "_pinned"):      # nothing of the caller's stays referenced by a closed context
+        for k in ("_keep", "_addr_cache", "_addr_alive", "_pinned"):      # nothing of the caller's stays referenced by a closed context
             self.__dict__.pop(k, None)
 
     def __del__(self):
