@@ -535,10 +535,11 @@ static int pg_solve_impl(dsss_ctx* c, const double* dr6, int total, const dsss_l
     // chunk ends onto the true separators)
     auto chain_part = [&]() {
         hipMemsetAsync(d_fail, 0, sizeof(int), st);
-        hipLaunchKernelGGL(pg_assemble_kernel, dim3((n + PG_ASM_POSES - 1) / PG_ASM_POSES), dim3(6 * PG_ASM_POSES), 0, st, n, W, d_r, d_Ji, d_adj_ptr, d_adj_edge, d_ew, d_scal + 3, d_D, d_C, d_g, d_eo, mp0, mp1);
-        hipLaunchKernelGGL(pg_segment_kernel, dim3((nseg1 + 31) / 32), dim3(256), 0, st, nseg1, d_ord1, d_sep1, d_D, d_C, d_g, d_E, d_Dl, d_gi, d_sDL, d_sDR, d_sGL, d_sGR, d_sS, d_fail, mp0, mp1);
+        // blocks of the ends of the level-1 chain only: pass 1 forms those of the interior poses from the Jacobians (pg_segment_kernel<true>)
+        hipLaunchKernelGGL(pg_assemble_kernel, dim3((ns1 + PG_ASM_POSES - 1) / PG_ASM_POSES), dim3(6 * PG_ASM_POSES), 0, st, n, W, d_r, d_Ji, d_adj_ptr, d_adj_edge, d_ew, d_scal + 3, d_D, d_C, d_g, d_eo, mp0, mp1, d_sep1, ns1);
+        hipLaunchKernelGGL(pg_segment_kernel<true>, dim3((nseg1 + 31) / 32), dim3(256), 0, st, nseg1, d_ord1, d_sep1, d_D, d_C, d_g, d_E, d_Dl, d_gi, d_sDL, d_sDR, d_sGL, d_sGR, d_sS, d_fail, mp0, mp1, d_r, d_Ji, W, d_scal + 3);
         hipLaunchKernelGGL(pg_chain1_kernel, dim3((unsigned)(((long long)ns1 * 42 + 255) / 256)), dim3(256), 0, st, ns1, d_sep1, d_D, d_g, d_sDL, d_sDR, d_sGL, d_sGR, d_sS, d_D1, d_C1, d_g1, mp0, mp1);
-        if (nseg > 0) hipLaunchKernelGGL(pg_segment_kernel, dim3((nseg + 31) / 32), dim3(256), 0, st, nseg, d_ord2, d_t2, d_D1, d_C1, d_g1, d_E1, d_Dl1, d_gi1, d_s2DL, d_s2DR, d_s2GL, d_s2GR, d_s2S, d_fail, kp0, kp1);
+        if (nseg > 0) hipLaunchKernelGGL(pg_segment_kernel<false>, dim3((nseg + 31) / 32), dim3(256), 0, st, nseg, d_ord2, d_t2, d_D1, d_C1, d_g1, d_E1, d_Dl1, d_gi1, d_s2DL, d_s2DR, d_s2GL, d_s2GR, d_s2S, d_fail, kp0, kp1, (const double*)nullptr, (const double*)nullptr, W, (const double*)nullptr);
     };
     const bool will_iterate = err > 0 && c->pg.max_iters > 0;
     bool pre_lin = false, pre_chain = false;
@@ -795,9 +796,9 @@ static int pg_solve_impl(dsss_ctx* c, const double* dr6, int total, const dsss_l
                 if (nbins > 0) { dsss_scope s7(c, DSSS_K_PG_SUBTREE);
                     hipLaunchKernelGGL(pg_bwd_subtree_kernel, dim3(nbins), dim3(64), 0, st, d_binperm + bin_lo, d_binptr, d_bincols, d_colptr, d_rowidx, d_L, d_x, d_rdiag); }
                 hipLaunchKernelGGL(pg_sep_delta_kernel, dim3((ns + 255) / 256), dim3(256), 0, st, ns, d_t2, d_perm, d_x, d_delta1);
-                if (nseg > 0) hipLaunchKernelGGL(pg_backsub_kernel, dim3((nseg + 31) / 32), dim3(256), 0, st, nseg, d_ord2, d_t2, d_C1, d_E1, d_Dl1, d_gi1, d_delta1, kp0, kp1);
+                if (nseg > 0) hipLaunchKernelGGL(pg_backsub_kernel<false>, dim3((nseg + 31) / 32), dim3(256), 0, st, nseg, d_ord2, d_t2, d_C1, d_E1, d_Dl1, d_gi1, d_delta1, kp0, kp1, (const double*)nullptr, W);
                 hipLaunchKernelGGL(pg_sep_delta_kernel, dim3((ns1 + 255) / 256), dim3(256), 0, st, ns1, d_sep1, (const int*)nullptr, d_delta1, d_delta);
-                hipLaunchKernelGGL(pg_backsub_kernel, dim3((nseg1 + 31) / 32), dim3(256), 0, st, nseg1, d_ord1, d_sep1, d_C, d_E, d_Dl, d_gi, d_delta, mp0, mp1);
+                hipLaunchKernelGGL(pg_backsub_kernel<true>, dim3((nseg1 + 31) / 32), dim3(256), 0, st, nseg1, d_ord1, d_sep1, d_C, d_E, d_Dl, d_gi, d_delta, mp0, mp1, d_Ji, W);
                 hipLaunchKernelGGL(pg_linerr_kernel, dim3(nblk), dim3(256), 0, st, n, ne, W, d_ea, d_eb, d_eo, d_ew, d_r, d_Ji, d_delta, d_part, mp0, mp1);
                 hipLaunchKernelGGL(pg_final_sum_kernel, dim3(1), dim3(256), 0, st, d_part, nblk, 0.5, d_scal + 1);
             }

@@ -115,19 +115,23 @@ __global__ __launch_bounds__(256) void pg_final_sum_kernel(const double* __restr
 // pose's incidence list in a fixed order (no atomics).  SIX LANES PER POSE: lane a builds row a of D and C and g[a] (one
 // thread per pose held 2 x 36 accumulators + a Jacobian: 280 registers, one wavefront per SIMD); the six lanes read the same
 // Jacobian, which the memory pipeline broadcasts.  Every entry is summed in the order of the one-thread form.
+// `plist` (round 5): the blocks of the np listed poses only -- the ends of the level-1 chain, whose D, C, g the chain kernels read; the
+// interior poses of the segments carry chain factors alone, and pg_segment_kernel<true> / pg_backsub_kernel<true> form their blocks
+// from the Jacobians themselves (the same sums in the same order).  NULL: every pose.
 __global__ __launch_bounds__(6 * PG_ASM_POSES) void pg_assemble_kernel(int n, pg_weights W, const double* __restrict__ r, const double* __restrict__ Ji,
                                                           const int* __restrict__ adj_ptr, const int* __restrict__ adj_edge,
                                                           const double* __restrict__ ew, const double* __restrict__ lambda_ptr,
                                                           double* __restrict__ D, double* __restrict__ C, double* __restrict__ g,
-                                                          const int* __restrict__ eo, int mp0, int mp1)
+                                                          const int* __restrict__ eo, int mp0, int mp1, const int* __restrict__ plist, int np)
 {
     // (a thread's six values of a block row are 48 contiguous bytes, the threads of a wavefront 48 bytes apart: stored directly, every
     // store instruction touched 24 cache lines for a sixth each.  The rows go through LDS and leave as 16-byte stores of whole lines.)
     __shared__ double s_dc[2][PG_ASM_POSES * 36];
     __shared__ double s_j[PG_ASM_POSES * 36];            // Jacobians of the chain factors i + 1 of the workgroup's poses: one contiguous 9 KB read
-    const int i = blockIdx.x * PG_ASM_POSES + threadIdx.x / 6, a = threadIdx.x % 6;
+    const int slot_ = blockIdx.x * PG_ASM_POSES + threadIdx.x / 6, a = threadIdx.x % 6;
+    const int i = plist ? (slot_ < np ? plist[slot_] : n) : slot_;
     const bool live = i < n;
-    {
+    if (!plist) {
         const size_t jb = ((size_t)blockIdx.x * PG_ASM_POSES + 1) * 36, lim = (size_t)n * 36;      // factor k lives at Ji + 36 k, k < n
 #pragma unroll
         for (int u = 0; u < 3; ++u) {
@@ -150,7 +154,7 @@ __global__ __launch_bounds__(6 * PG_ASM_POSES) void pg_assemble_kernel(int n, pg
         gg += wa * r[(size_t)i * 6 + a];
     }
     if (i + 1 < n && own_next) {   // factor i+1 with this pose as the first variable
-        const double* J = s_j + (threadIdx.x / 6) * 36; const double* rr = r + (size_t)(i + 1) * 6;
+        const double* J = plist ? Ji + (size_t)(i + 1) * 36 : s_j + (threadIdx.x / 6) * 36; const double* rr = r + (size_t)(i + 1) * 6;
         double ja[6], sb[6] = { 0, 0, 0, 0, 0, 0 };            // column a of J; row a of J^T J
 #pragma unroll
         for (int q = 0; q < 6; ++q) ja[q] = J[q * 6 + a];
@@ -197,7 +201,12 @@ __global__ __launch_bounds__(6 * PG_ASM_POSES) void pg_assemble_kernel(int n, pg
         for (int b = 0; b < 6; ++b) if (b == a) Dd[b] += lambda;
     }
     g[(size_t)i * 6 + a] = gg;
+    if (plist) {                                               // scattered poses: the row straight out
+#pragma unroll
+        for (int b = 0; b < 6; ++b) { D[(size_t)i * 36 + a * 6 + b] = Dd[b]; C[(size_t)i * 36 + a * 6 + b] = Cc[b]; }
+    }
     }       // live
+    if (plist) return;
 #pragma unroll
     for (int b = 0; b < 6; ++b) { s_dc[0][threadIdx.x * 6 + b] = Dd[b]; s_dc[1][threadIdx.x * 6 + b] = Cc[b]; }
     __syncthreads();
@@ -225,7 +234,7 @@ __global__ __launch_bounds__(6 * PG_ASM_POSES) void pg_assemble_kernel(int n, pg
 // in LDS) are stored there, so the one wait on the memory counter per step finds everything a whole step old (dependent loads inside
 // the step cost 8 000 of its 12 500 cycles).  E, D, G are double-buffered in LDS.  Rounds 2 - 4 ran SIXTEEN lanes per segment, one
 // right-hand side each: ~540 vector instructions per step
-struct pg_seg_lds { double E[2][36], D[2][36], G[2][6], C[36], L[36], pad[4]; };      // 232 doubles
+struct pg_seg_lds { double E[2][36], D[2][36], G[2][6], C[36], L[36], Rv[6], Wo[6]; };      // 240 doubles (x 32 groups = 61 440 B)
 // the lanes of a group sit in one wavefront, whose LDS operations execute in program order: waiting for the LDS queue
 // (not for the global stores in flight -- a fence would) and keeping the compiler from moving memory operations across is enough
 #define PG_COMPILER_FENCE() asm volatile("" ::: "memory")
@@ -239,11 +248,45 @@ struct pg_seg_lds { double E[2][36], D[2][36], G[2][6], C[36], L[36], pad[4]; };
 // for eight segments (124 -> 103 us per launch at C3).  Every right-hand side sees the arithmetic of the sixteen-lane kernel in the same
 // order: the records are the same bits.
 #define PG_SEG_LANES 8
+// FROMJ (round 5, pass 1 on the pose chain): the blocks of the INTERIOR poses are not read but formed here -- an interior pose p carries
+// the chain factors p and p + 1 and nothing else (every loop-closure pose is a separator), so with J = the Jacobian of factor p + 1
+//     D_p = diag(w^2) + J^T J + lambda I,   C_p = J^T diag(w),   g_p = w r_p + J^T r_(p+1)
+// in the order of operations of pg_assemble_kernel (which then runs on the 48 k ends of the level-1 chain instead of all 400 k poses: it
+// wrote 230 MB per trial that this kernel read back).  The Jacobian of the NEXT pose is requested at the top of a step, parked in LDS at
+// the step's end (in the slot of C_i, which is free by then) and turned into the lane's column of D, its entries of C and its component
+// of g there; D_p is symmetric bit for bit (the products commute, the sums run over the same index), so column c is row c.
+// D, C, g are read at the segment's LEFT END only (C_L couples it to the first interior pose).
+template <bool FROMJ>
+__device__ __forceinline__ void pg_seg_from_j(const double* __restrict__ Jl, const double* __restrict__ Rn, double rp, const double* __restrict__ Wl, double wa, double lambda,
+                                              int c, double* __restrict__ nC, double* __restrict__ pre, double& gpre)
+{
+    if constexpr (FROMJ) {
+#pragma unroll
+        for (int u = 0; u < 5; ++u) { const int a = c + PG_SEG_LANES * u; if (a < 36) { const int row = a / 6, col = a - 6 * row; nC[u] = Jl[col * 6 + row] * Wl[col]; } }
+        if (c < 6) {
+            double ja[6], sb[6] = { 0, 0, 0, 0, 0, 0 };
+#pragma unroll
+            for (int q = 0; q < 6; ++q) ja[q] = Jl[q * 6 + c];
+#pragma unroll
+            for (int q = 0; q < 6; ++q)
+#pragma unroll
+                for (int b = 0; b < 6; ++b) sb[b] += ja[q] * Jl[q * 6 + b];
+#pragma unroll
+            for (int b = 0; b < 6; ++b) { double d = b == c ? 0.0 + wa * wa : 0.0; d += sb[b]; if (b == c) d += lambda; pre[b] = d; }
+            double gg = 0.0 + wa * rp, s2 = 0;
+#pragma unroll
+            for (int q = 0; q < 6; ++q) s2 += ja[q] * Rn[q];
+            gpre = gg + s2;
+        }
+    }
+}
+template <bool FROMJ>
 __global__ __launch_bounds__(256, 2) void pg_segment_kernel(int nseg, const int* __restrict__ seg_order, const int* __restrict__ sep_pose, const double* __restrict__ D,
                                                          const double* __restrict__ C, const double* __restrict__ g,
                                                          double* __restrict__ E, double* __restrict__ Dl, double* __restrict__ gi,
                                                          double* __restrict__ segDL, double* __restrict__ segDR, double* __restrict__ segGL,
-                                                         double* __restrict__ segGR, double* __restrict__ segS, int* __restrict__ fail, int mp0, int mp1)
+                                                         double* __restrict__ segGR, double* __restrict__ segS, int* __restrict__ fail, int mp0, int mp1,
+                                                         const double* __restrict__ rf, const double* __restrict__ Jf, pg_weights W, const double* __restrict__ lambda_ptr)
 {
     __shared__ pg_seg_lds sh_all[256 / PG_SEG_LANES];
     const int grp = threadIdx.x / PG_SEG_LANES, c = threadIdx.x % PG_SEG_LANES;
@@ -258,8 +301,17 @@ __global__ __launch_bounds__(256, 2) void pg_segment_kernel(int nseg, const int*
         if (c < 6) { segGL[(size_t)s * 6 + c] = 0; segGR[(size_t)s * 6 + c] = 0; }
         return;
     }
-    for (int a = c; a < 36; a += PG_SEG_LANES) { sh.E[0][a] = C[(size_t)L * 36 + a]; sh.D[0][a] = D[(size_t)(L + 1) * 36 + a]; }
-    if (c < 6) sh.G[0][c] = g[(size_t)(L + 1) * 6 + c];
+    double lambda = 0.0, rp = 0.0, rn = 0.0, jn[5] = { 0, 0, 0, 0, 0 }, gpre = 0.0, wa = 0.0;      // FROMJ: r_p[c], r_(p+1)[c], the lane's share of the next Jacobian, its component of g, its weight
+    if constexpr (FROMJ) {
+        lambda = *lambda_ptr;
+        wa = c == 0 ? W.odo[0] : c == 1 ? W.odo[1] : c == 2 ? W.odo[2] : c == 3 ? W.odo[3] : c == 4 ? W.odo[4] : W.odo[5];      // (a lane-dependent index would put the argument into scratch)
+        if (c < 6) sh.Wo[c] = wa;
+        for (int a = c; a < 36; a += PG_SEG_LANES) { sh.E[0][a] = C[(size_t)L * 36 + a]; sh.C[a] = Jf[(size_t)(L + 2) * 36 + a]; }
+        if (c < 6) { rp = rf[(size_t)(L + 1) * 6 + c]; rn = rf[(size_t)(L + 2) * 6 + c]; sh.Rv[c] = rn; }
+    } else {
+        for (int a = c; a < 36; a += PG_SEG_LANES) { sh.E[0][a] = C[(size_t)L * 36 + a]; sh.D[0][a] = D[(size_t)(L + 1) * 36 + a]; }
+        if (c < 6) sh.G[0][c] = g[(size_t)(L + 1) * 6 + c];
+    }
     // acc[]: column c of DL on lanes 0..5, GL on lane 6.  pre[]: the prefetched column c of D_(i+1) on lanes 0..5, g_(i+1) on lane 6 -- added
     // to the next step's pivot / gradient at its top (one load sequence for both kinds of lane: two divergent ones that write the same registers are serialised by a full wait).  nC: the lane's
     // share of C_(i+1).
@@ -270,14 +322,42 @@ __global__ __launch_bounds__(256, 2) void pg_segment_kernel(int nseg, const int*
     const int pre_lds = is_col ? (int)(&sh.D[0][0] - &sh.E[0][0]) + c : (int)(&sh.G[0][0] - &sh.E[0][0]);     // offsets from sh.E[0] in doubles
     const int pre_flip = is_col ? 36 : 6;
     int cb = 0;
+    if constexpr (FROMJ) {                                      // the first interior pose: D, g into LDS, its C into nC
 #pragma unroll
-    for (int u = 0; u < 5; ++u) { const int a = c + PG_SEG_LANES * u; nC[u] = a < 36 ? C[(size_t)(L + 1) * 36 + a] : 0.0; }
+        for (int u = 0; u < 5; ++u) nC[u] = 0.0;
+        PG_GROUP_SYNC();
+        double d0[6] = { 0, 0, 0, 0, 0, 0 };
+        pg_seg_from_j<true>(sh.C, sh.Rv, rp, sh.Wo, wa, lambda, c, nC, d0, gpre);
+        if (c < 6) {
+#pragma unroll
+            for (int a = 0; a < 6; ++a) sh.D[0][a * 6 + c] = d0[a];
+            sh.G[0][c] = gpre;
+            rp = rn;
+        }
+        gpre = 0.0;
+        PG_GROUP_SYNC();
+    } else {
+#pragma unroll
+        for (int u = 0; u < 5; ++u) { const int a = c + PG_SEG_LANES * u; nC[u] = a < 36 ? C[(size_t)(L + 1) * 36 + a] : 0.0; }
+    }
     for (int i = L + 1; i < R; ++i) {
         const bool last = (i + 1 == R);
         double* __restrict__ Ec = sh.E[cb]; double* __restrict__ Dc = sh.D[cb]; double* __restrict__ Gc = sh.G[cb];
         double* __restrict__ En = sh.E[cb ^ 1]; double* __restrict__ Dn = sh.D[cb ^ 1]; double* __restrict__ Gn = sh.G[cb ^ 1];
 #pragma unroll
         for (int u = 0; u < 5; ++u) { const int a = c + PG_SEG_LANES * u; if (a < 36) sh.C[a] = nC[u]; }
+        if constexpr (FROMJ) {
+            if (is_col) {                                        // completes the entries the last step left in D and G: column c of D_i, component c of g_i
+#pragma unroll
+                for (int a = 0; a < 6; ++a) Dc[a * 6 + c] += pre[a];
+                Gc[c] += gpre;
+            }
+            if (!last) {                                         // the Jacobian of factor i + 2 and r_(i+2): pose i + 1's blocks, formed at the end of this step
+#pragma unroll
+                for (int u = 0; u < 5; ++u) { const int a = c + PG_SEG_LANES * u; if (a < 36) jn[u] = Jf[(size_t)(i + 2) * 36 + a]; }
+                if (is_col) rn = rf[(size_t)(i + 2) * 6 + c];
+            }
+        } else {
         if (has_role) {                                          // completes the entries the last step left in D and G
             double* dst = &sh.E[0][0] + pre_lds + cb * pre_flip;
 #pragma unroll
@@ -294,6 +374,7 @@ __global__ __launch_bounds__(256, 2) void pg_segment_kernel(int nseg, const int*
         } else if (has_role) {
 #pragma unroll
             for (int a = 0; a < 6; ++a) pre[a] = 0.0;
+        }
         }
         if (i > L + 1) for (int a = c; a < 36; a += PG_SEG_LANES) Dl[(size_t)(i - 1) * 36 + a] = sh.L[a];
         PG_GROUP_SYNC();
@@ -347,7 +428,11 @@ __global__ __launch_bounds__(256, 2) void pg_segment_kernel(int nseg, const int*
         {   // C^T y: the next pivot less D_(i+1) from yB (lanes 0..5), the next gradient less g_(i+1) from yA (lane 6)
             double yc[6];
 #pragma unroll
-            for (int q = 0; q < 6; ++q) yc[q] = is_col ? yB[q] : yA[q];
+            for (int q = 0; q < 6; ++q) {
+                double ya1 = yA[q], yb1 = yB[q];
+                if constexpr (FROMJ) asm volatile("" : "+v"(ya1), "+v"(yb1));      // (register values: the optimiser otherwise selects between the two ARRAYS through scratch memory)
+                yc[q] = is_col ? yb1 : ya1;
+            }
 #pragma unroll
             for (int a = 0; a < 6; ++a) {
                 double u = 0;
@@ -355,6 +440,21 @@ __global__ __launch_bounds__(256, 2) void pg_segment_kernel(int nseg, const int*
                 for (int q = 0; q < 6; ++q) u += sh.C[q * 6 + a] * yc[q];
                 if (is_col) Dn[a * 6 + c] = -u;
                 else if (c == 6) Gn[a] = -u;
+            }
+        }
+        if constexpr (FROMJ) {
+            if (!last) {                                         // C_i has been used for the last time: its slot takes the next Jacobian
+                PG_GROUP_SYNC();
+#pragma unroll
+                for (int u = 0; u < 5; ++u) { const int a = c + PG_SEG_LANES * u; if (a < 36) sh.C[a] = jn[u]; }
+                if (is_col) sh.Rv[c] = rn;
+                PG_GROUP_SYNC();
+                pg_seg_from_j<true>(sh.C, sh.Rv, rp, sh.Wo, wa, lambda, c, nC, pre, gpre);
+                rp = rn;
+            } else {
+#pragma unroll
+                for (int a = 0; a < 6; ++a) pre[a] = 0.0;
+                gpre = 0.0;
             }
         }
         cb ^= 1;
@@ -366,6 +466,8 @@ __global__ __launch_bounds__(256, 2) void pg_segment_kernel(int nseg, const int*
     for (int a = c; a < 36; a += PG_SEG_LANES) { segDR[(size_t)s * 36 + a] = sh.D[cb][a]; segS[(size_t)s * 36 + a] = sh.E[cb][a]; }
     if (c < 6) segGR[(size_t)s * 6 + c] = sh.G[cb][c];
 }
+template __global__ void pg_segment_kernel<false>(int, const int* __restrict__, const int* __restrict__, const double* __restrict__, const double* __restrict__, const double* __restrict__, double* __restrict__, double* __restrict__, double* __restrict__, double* __restrict__, double* __restrict__, double* __restrict__, double* __restrict__, double* __restrict__, int* __restrict__, int, int, const double* __restrict__, const double* __restrict__, pg_weights, const double* __restrict__);
+template __global__ void pg_segment_kernel<true>(int, const int* __restrict__, const int* __restrict__, const double* __restrict__, const double* __restrict__, const double* __restrict__, double* __restrict__, double* __restrict__, double* __restrict__, double* __restrict__, double* __restrict__, double* __restrict__, double* __restrict__, double* __restrict__, int* __restrict__, int, int, const double* __restrict__, const double* __restrict__, pg_weights, const double* __restrict__);
 
 // the level-1 chain after pass 1: diagonal block, coupling to the next entry and gradient of every chunk end / true separator
 // (what pass 2 of pg_segment_kernel condenses; same meaning as D, C, g of the pose chain).  Partial sums on interface entries.
@@ -520,20 +622,28 @@ __global__ __launch_bounds__(256) void pg_sep_delta_kernel(int ns, const int* __
 // which leaves delta_i in all of them for the next step.  The blocks of pose i - 1 are requested before pose i is computed.
 #define PG_BS_LANES 8
 struct pg_bs_blk { double Ec[6], Cr[6], gv, Lm[21]; };
+// FROMJ (pass 1 on the pose chain): row aa of C_i = column aa of the Jacobian of factor i + 1, times the weights -- the product
+// pg_assemble_kernel forms (it no longer writes the blocks of interior poses, see pg_segment_kernel<true>)
+template <bool FROMJ>
 __device__ __forceinline__ void pg_bs_load(pg_bs_blk& B, int i, int aa, const double* __restrict__ C, const double* __restrict__ E,
-                                           const double* __restrict__ Dl, const double* __restrict__ gi)
+                                           const double* __restrict__ Dl, const double* __restrict__ gi, const double* __restrict__ Jf, const pg_weights& W)
 {
 #pragma unroll
-    for (int q = 0; q < 6; ++q) { B.Ec[q] = E[(size_t)i * 36 + q * 6 + aa]; B.Cr[q] = C[(size_t)i * 36 + aa * 6 + q]; }
+    for (int q = 0; q < 6; ++q) {
+        B.Ec[q] = E[(size_t)i * 36 + q * 6 + aa];
+        if constexpr (FROMJ) B.Cr[q] = Jf[(size_t)(i + 1) * 36 + q * 6 + aa] * W.odo[q];
+        else B.Cr[q] = C[(size_t)i * 36 + aa * 6 + q];
+    }
     B.gv = gi[(size_t)i * 6 + aa];
 #pragma unroll
     for (int r = 0; r < 6; ++r)
 #pragma unroll
         for (int k = 0; k <= r; ++k) B.Lm[r * (r + 1) / 2 + k] = Dl[(size_t)i * 36 + r * 6 + k];
 }
+template <bool FROMJ>
 __global__ __launch_bounds__(256) void pg_backsub_kernel(int nseg, const int* __restrict__ seg_order, const int* __restrict__ sep_pose, const double* __restrict__ C,
                                                          const double* __restrict__ E, const double* __restrict__ Dl, const double* __restrict__ gi,
-                                                         double* __restrict__ delta, int mp0, int mp1)
+                                                         double* __restrict__ delta, int mp0, int mp1, const double* __restrict__ Jf, pg_weights W)
 {
     const int slot = blockIdx.x * (256 / PG_BS_LANES) + threadIdx.x / PG_BS_LANES, a = threadIdx.x % PG_BS_LANES;
     if (slot >= nseg) return;                                   // whole groups leave together
@@ -545,9 +655,9 @@ __global__ __launch_bounds__(256) void pg_backsub_kernel(int nseg, const int* __
 #pragma unroll
     for (int q = 0; q < 6; ++q) { dL[q] = delta[(size_t)L * 6 + q]; dn[q] = delta[(size_t)R * 6 + q]; }
     pg_bs_blk cur, nxt;
-    pg_bs_load(cur, R - 1, aa, C, E, Dl, gi);
+    pg_bs_load<FROMJ>(cur, R - 1, aa, C, E, Dl, gi, Jf, W);
     for (int i = R - 1; i > L; --i) {
-        if (i - 1 > L) pg_bs_load(nxt, i - 1, aa, C, E, Dl, gi);
+        if (i - 1 > L) pg_bs_load<FROMJ>(nxt, i - 1, aa, C, E, Dl, gi, Jf, W);
         double t = -cur.gv;
 #pragma unroll
         for (int q = 0; q < 6; ++q) { t -= cur.Ec[q] * dL[q]; t -= cur.Cr[q] * dn[q]; }
@@ -566,6 +676,8 @@ __global__ __launch_bounds__(256) void pg_backsub_kernel(int nseg, const int* __
         cur = nxt;
     }
 }
+template __global__ void pg_backsub_kernel<false>(int, const int* __restrict__, const int* __restrict__, const double* __restrict__, const double* __restrict__, const double* __restrict__, const double* __restrict__, double* __restrict__, int, int, const double* __restrict__, pg_weights);
+template __global__ void pg_backsub_kernel<true>(int, const int* __restrict__, const int* __restrict__, const double* __restrict__, const double* __restrict__, const double* __restrict__, const double* __restrict__, double* __restrict__, int, int, const double* __restrict__, pg_weights);
 
 // 0.5 * || J delta + r ||^2 over all factors (linear.error(delta))
 __global__ __launch_bounds__(256) void pg_linerr_kernel(int n, int ne, pg_weights W, const int* __restrict__ ea, const int* __restrict__ eb, const int* __restrict__ eo,

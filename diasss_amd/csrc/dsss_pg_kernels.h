@@ -37,8 +37,8 @@ struct pg_child { const double* U; const double* g; long long relptr; int cld, c
 // ---- dsss_pg_chain.hip
 __global__ void pg_linearize_kernel(int n, int ne, const pose_t* __restrict__ X, const pose_t* __restrict__ meas, pg_weights W, const int* __restrict__ ea, const int* __restrict__ eb, const int* __restrict__ eo, const pose_t* __restrict__ emeas, const double* __restrict__ ew, double* __restrict__ r, double* __restrict__ Ji, double* __restrict__ partial, int mp0, int mp1);
 __global__ void pg_final_sum_kernel(const double* __restrict__ partial, int n, double scale, double* __restrict__ out);
-__global__ void pg_assemble_kernel(int n, pg_weights W, const double* __restrict__ r, const double* __restrict__ Ji, const int* __restrict__ adj_ptr, const int* __restrict__ adj_edge, const double* __restrict__ ew, const double* __restrict__ lambda_ptr, double* __restrict__ D, double* __restrict__ C, double* __restrict__ g, const int* __restrict__ eo, int mp0, int mp1);
-__global__ void pg_segment_kernel(int nseg, const int* __restrict__ seg_order, const int* __restrict__ sep_pose, const double* __restrict__ D, const double* __restrict__ C, const double* __restrict__ g, double* __restrict__ E, double* __restrict__ Dl, double* __restrict__ gi, double* __restrict__ segDL, double* __restrict__ segDR, double* __restrict__ segGL, double* __restrict__ segGR, double* __restrict__ segS, int* __restrict__ fail, int mp0, int mp1);
+__global__ void pg_assemble_kernel(int n, pg_weights W, const double* __restrict__ r, const double* __restrict__ Ji, const int* __restrict__ adj_ptr, const int* __restrict__ adj_edge, const double* __restrict__ ew, const double* __restrict__ lambda_ptr, double* __restrict__ D, double* __restrict__ C, double* __restrict__ g, const int* __restrict__ eo, int mp0, int mp1, const int* __restrict__ plist, int np);
+template <bool FROMJ> __global__ void pg_segment_kernel(int nseg, const int* __restrict__ seg_order, const int* __restrict__ sep_pose, const double* __restrict__ D, const double* __restrict__ C, const double* __restrict__ g, double* __restrict__ E, double* __restrict__ Dl, double* __restrict__ gi, double* __restrict__ segDL, double* __restrict__ segDR, double* __restrict__ segGL, double* __restrict__ segGR, double* __restrict__ segS, int* __restrict__ fail, int mp0, int mp1, const double* __restrict__ rf, const double* __restrict__ Jf, pg_weights W, const double* __restrict__ lambda_ptr);
 __global__ void pg_chain1_kernel(int ns1, const int* __restrict__ sep1, const double* __restrict__ D, const double* __restrict__ g, const double* __restrict__ segDL, const double* __restrict__ segDR, const double* __restrict__ segGL, const double* __restrict__ segGR, const double* __restrict__ segS, double* __restrict__ D1, double* __restrict__ C1, double* __restrict__ g1, int mp0, int mp1);
 __global__ void pg_scatter_base_kernel(int ns, const int* __restrict__ sep_pose, const int* __restrict__ perm, const double* __restrict__ D, const double* __restrict__ g, const double* __restrict__ segDL, const double* __restrict__ segDR, const double* __restrict__ segGL, const double* __restrict__ segGR, const double* __restrict__ segS, const int* __restrict__ dest, double* __restrict__ Lvals, double* __restrict__ aval, double* __restrict__ rhs, const int* __restrict__ if_slot, double* __restrict__ aval_if, double* __restrict__ x_if, int mp0, int mp1);
 __global__ void pg_scatter_lc_kernel(int n, int ne, int ns, const double* __restrict__ Ji, const double* __restrict__ ew, const int* __restrict__ dest, double* __restrict__ Lvals, double* __restrict__ aval, double* __restrict__ aval_if, const int* __restrict__ eo, int mp0, int mp1, const int* __restrict__ lc_link);
@@ -47,7 +47,7 @@ __global__ void pg_comm_xif_kernel(int nif, const int* __restrict__ if_sep, cons
 __global__ void pg_comm_scal_kernel(const double* __restrict__ scal, const int* __restrict__ fail, double* __restrict__ red);
 __global__ void pg_mask_own_kernel(int n, pose_t* __restrict__ X, int mp0, int mp1);
 __global__ void pg_sep_delta_kernel(int ns, const int* __restrict__ sep_pose, const int* __restrict__ perm, const double* __restrict__ x, double* __restrict__ delta);
-__global__ void pg_backsub_kernel(int nseg, const int* __restrict__ seg_order, const int* __restrict__ sep_pose, const double* __restrict__ C, const double* __restrict__ E, const double* __restrict__ Dl, const double* __restrict__ gi, double* __restrict__ delta, int mp0, int mp1);
+template <bool FROMJ> __global__ void pg_backsub_kernel(int nseg, const int* __restrict__ seg_order, const int* __restrict__ sep_pose, const double* __restrict__ C, const double* __restrict__ E, const double* __restrict__ Dl, const double* __restrict__ gi, double* __restrict__ delta, int mp0, int mp1, const double* __restrict__ Jf, pg_weights W);
 __global__ void pg_linerr_kernel(int n, int ne, pg_weights W, const int* __restrict__ ea, const int* __restrict__ eb, const int* __restrict__ eo, const double* __restrict__ ew, const double* __restrict__ r, const double* __restrict__ Ji, const double* __restrict__ delta, double* __restrict__ partial, int mp0, int mp1);
 __global__ void pg_retract_kernel(int n, const pose_t* __restrict__ X, const double* __restrict__ delta, pose_t* __restrict__ Xn);
 __global__ void pg_rng_attempts_kernel(long long nattempts, double* __restrict__ pairs, int* __restrict__ flags);
