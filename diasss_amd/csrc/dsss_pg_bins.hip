@@ -211,17 +211,39 @@ __global__ __launch_bounds__(256) void pg_factor_subtree_kernel(const int* __res
         const int ri = binroot_idx[q]; const long long b6 = 6LL * broot_b[ri]; double* U = ubin + broot_uoff[ri];
         for (long long e = threadIdx.x; e < b6 * b6 + b6; e += 256) U[e] = 0.0;
     }
-    for (int ci = binptr[bin]; ci < binptr[bin + 1]; ++ci) {
-        const int j = bincols[ci];
-        const int c0 = colptr[j], m = colptr[j + 1] - c0;
-        const int t0 = rlptr[j], T = rlptr[j + 1] - t0;
-        const int* mp = upd_map + mapptr[j];
+    // (round 5) what a column needs to know about itself -- column -> pointers -> root descriptor, three dependent look-ups of a microsecond
+    // together -- is fetched one column AHEAD; and a thread keeps its row of the column in registers from the update to the triangular solve
+    // (it was stored after the update and read back after the pivot: a round trip through the caches on every column's chain)
+    struct colinfo { int j, c0, m, t0, T, af, ri, b6; long long mapoff, uoff; };
+    auto col_of = [&](int ci2) {
+        colinfo k;
+        k.j = bincols[ci2];
+        k.c0 = colptr[k.j]; k.m = colptr[k.j + 1] - k.c0;
+        k.t0 = rlptr[k.j]; k.T = rlptr[k.j + 1] - k.t0;
+        k.mapoff = mapptr[k.j]; k.af = anc_first[k.j]; k.ri = broot_of_col[k.j];
+        k.b6 = k.ri >= 0 ? 6 * broot_b[k.ri] : 0; k.uoff = k.ri >= 0 ? broot_uoff[k.ri] : 0;
+        return k;
+    };
+    const int ci_end = binptr[bin + 1];
+    colinfo cur = {}, nxt = {};
+    if (binptr[bin] < ci_end) cur = col_of(binptr[bin]);
+    for (int ci = binptr[bin]; ci < ci_end; ++ci, cur = nxt) {
+        if (ci + 1 < ci_end) nxt = col_of(ci + 1);
+        const int j = cur.j;
+        const int c0 = cur.c0, m = cur.m;
+        const int t0 = cur.t0, T = cur.T;
+        const int* mp = upd_map + cur.mapoff;
         const int idx = threadIdx.x;
         const bool act = idx < 6 * m;
         const int q = act ? idx / 6 : 0, r = idx - q * 6;
         const bool rhs = threadIdx.x >= 250;
         const int rs_ = threadIdx.x - 250;
         double acc[6] = { 0, 0, 0, 0, 0, 0 }, accy = 0;
+        double rowv[6] = { 0, 0, 0, 0, 0, 0 };                             // row r of block q of the column, as assembled: requested before the updates
+        if (act) {
+#pragma unroll
+            for (int s2 = 0; s2 < 6; ++s2) rowv[s2] = Lvals[(size_t)(c0 + q) * 36 + r * 6 + s2];
+        }
         for (int tc = 0; tc < T; tc += PG_TCH) {
             const int tn = min(PG_TCH, T - tc);
             __syncthreads();
@@ -248,8 +270,11 @@ __global__ __launch_bounds__(256) void pg_factor_subtree_kernel(const int* __res
         // and read back by another thread they were a round trip through the cache hierarchy on every column's chain.  The pivot thread
         // writes both back (the factor and the solved right-hand side), as before.
         if (rhs) s_xj[rs_] = x[(size_t)j * 6 + rs_] - accy;               // (accy = 0 without updates)
-        if (act && idx < 6) { for (int s = 0; s < 6; ++s) s_diag[r * 6 + s] = Lvals[(size_t)c0 * 36 + r * 6 + s] - acc[s]; }
-        else if (act && T > 0) for (int s = 0; s < 6; ++s) Lvals[(size_t)(c0 + q) * 36 + r * 6 + s] -= acc[s];
+        if (act) {
+#pragma unroll
+            for (int s = 0; s < 6; ++s) rowv[s] -= acc[s];                  // (no updates: acc = 0, x - 0 = x)
+            if (idx < 6) { for (int s = 0; s < 6; ++s) s_diag[r * 6 + s] = rowv[s]; }
+        }
         __syncthreads();
         if (threadIdx.x == 0) {
             // (round 4: in-kernel stamps put this one-thread section at 4 200 cycles per column, 28 % of the kernel -- a square root and
@@ -283,12 +308,12 @@ __global__ __launch_bounds__(256) void pg_factor_subtree_kernel(const int* __res
         }
         __syncthreads();
         if (!s_ok) return;
-        const int af = anc_first[j], ta = m - af;                       // block rows beyond the subtree root (a suffix of the column)
+        const int af = cur.af, ta = m - af;                             // block rows beyond the subtree root (a suffix of the column)
         if (act && idx >= 6) {
             double* row = Lvals + (size_t)(c0 + q) * 36 + r * 6;
             double xr[6];
 #pragma unroll
-            for (int s = 0; s < 6; ++s) { double v = row[s];
+            for (int s = 0; s < 6; ++s) { double v = rowv[s];
 #pragma unroll
                                           for (int c = 0; c < 6; ++c) if (c < s) v -= xr[c] * s_diag[s * 6 + c];
                                           xr[s] = v * s_ri[s]; }
@@ -296,10 +321,10 @@ __global__ __launch_bounds__(256) void pg_factor_subtree_kernel(const int* __res
             if (q >= af) for (int s = 0; s < 6; ++s) s_Ljk[(q - af) * 36 + r * 6 + s] = xr[s];       // keep the ancestor rows for the update matrix
         }
         __syncthreads();
-        const int ri = broot_of_col[j];
+        const int ri = cur.ri;
         if (ri >= 0 && ta > 0) {
-            const int b6 = 6 * broot_b[ri];
-            double* __restrict__ U = ubin + broot_uoff[ri];
+            const int b6 = cur.b6;
+            double* __restrict__ U = ubin + cur.uoff;
             double* __restrict__ g = U + (size_t)b6 * b6;
             // (round 4) the boundary indices of the column's ancestor rows go to LDS once, and the block pairs ib <= ia are ONE flat loop:
             // per ancestor row the pass was a dependent index load, a load and a store of U in global memory, and the rows followed each
