@@ -358,10 +358,32 @@ __global__ __launch_bounds__(64) void pg_bwd_subtree_kernel(const int* __restric
 {
     const int lane = threadIdx.x;
     const int bin = bin_perm[blockIdx.x];
-    for (int ci = binptr[bin + 1] - 1; ci >= binptr[bin]; --ci) {
-        const int j = bincols[ci];
+    // (round 5) column -> its pointers, and the pivot block with its reciprocals -- nothing of which depends on the solution so far -- are
+    // fetched one column ahead of the chain (x of the ancestors -> sums -> the 6 x 6 back-substitution -> x of the column)
+    const int ci_lo = binptr[bin];
+    int jn = 0, cn0 = 0, cn1 = 0;
+    double ldn[36], rin[6];
+    auto ahead = [&](int ci2) {
+        jn = bincols[ci2]; cn0 = colptr[jn]; cn1 = colptr[jn + 1];
+        if (lane == 0) {
+            const double* Ld = Lvals + (size_t)cn0 * 36;
+#pragma unroll
+            for (int a = 0; a < 36; ++a) ldn[a] = Ld[a];
+#pragma unroll
+            for (int a = 0; a < 6; ++a) rin[a] = rdiag[(size_t)jn * 6 + a];
+        }
+    };
+    if (binptr[bin + 1] - 1 >= ci_lo) ahead(binptr[bin + 1] - 1);
+    for (int ci = binptr[bin + 1] - 1; ci >= ci_lo; --ci) {
+        const int j = jn, c0 = cn0, c1 = cn1;
+        double ld[36], ri[6];
+#pragma unroll
+        for (int a = 0; a < 36; ++a) ld[a] = ldn[a];
+#pragma unroll
+        for (int a = 0; a < 6; ++a) ri[a] = rin[a];
+        if (ci - 1 >= ci_lo) ahead(ci - 1);
         double acc[6] = { 0, 0, 0, 0, 0, 0 };
-        for (int p = colptr[j] + 1 + lane; p < colptr[j + 1]; p += 64) {
+        for (int p = c0 + 1 + lane; p < c1; p += 64) {
             const double* B = Lvals + (size_t)p * 36; const double* xi = x + (size_t)rowidx[p] * 6;
             for (int a = 0; a < 6; ++a) { double s = 0; for (int b = 0; b < 6; ++b) s += B[b * 6 + a] * xi[b]; acc[a] += s; }
         }
@@ -369,12 +391,9 @@ __global__ __launch_bounds__(64) void pg_bwd_subtree_kernel(const int* __restric
 #pragma unroll
             for (int o = 32; o >= 1; o >>= 1) acc[a] += __shfl_xor(acc[a], o, 64);
         if (lane == 0) {
-            const double* Ld = Lvals + (size_t)colptr[j] * 36;
-            double v[6], ld[36], xj[6], ri[6];
+            double v[6], xj[6];
 #pragma unroll
-            for (int a = 0; a < 36; ++a) ld[a] = Ld[a];
-#pragma unroll
-            for (int a = 0; a < 6; ++a) { xj[a] = x[(size_t)j * 6 + a]; ri[a] = rdiag[(size_t)j * 6 + a]; }
+            for (int a = 0; a < 6; ++a) xj[a] = x[(size_t)j * 6 + a];
 #pragma unroll
             for (int a = 5; a >= 0; --a) { double s = xj[a] - acc[a];
 #pragma unroll
