@@ -191,9 +191,52 @@ def orb_extract(img, params=None, cap=None):
     return kps[:n].copy(), desc[:n].copy()
 
 
-def detect_feature(raw, mparams=None, oparams=None):
-    """Frame::DetectFeature on the normalised image + mask filter (frame.cpp:167-203)"""
+def orb_extract_sift(img, params=None, cap=None):
+    """the extractor with the descriptor of the SIFT call site next to the ORB one: (kps, desc n x 32, desc128 n x 128 u8)"""
+    img = np.ascontiguousarray(img, np.uint8)
+    p = params or orb_params()
+    cap = cap or (p.nfeatures + 64)
+    kps = np.zeros(cap, KP_DTYPE); desc = np.zeros((cap, 32), np.uint8); d128 = np.zeros((cap, 128), np.uint8)
+    n = lib().orc_orb_extract_sift(u8(img), img.shape[0], img.shape[1], C.byref(p), kp_ptr(kps), u8(desc), u8(d128), cap)
+    return kps[:n].copy(), desc[:n].copy(), d128[:n].copy()
+
+
+def blur13(img):
+    img = np.ascontiguousarray(img, np.uint8); out = np.empty_like(img)
+    lib().orc_blur13(u8(img), img.shape[0], img.shape[1], u8(out))
+    return out
+
+
+def sift_hist(blurred, x, y, angle_deg):
+    """the 4 x 4 x 8 histogram of oracle/orc_sift.c in 2^-12 fixed point (int32[128]) at integer level coordinates"""
+    b = np.ascontiguousarray(blurred, np.uint8); h = np.zeros(128, np.int32)
+    lib().orc_sift_hist(u8(b), b.shape[0], b.shape[1], int(x), int(y), C.c_float(angle_deg), ip(h))
+    return h
+
+
+def sift_finalize(h):
+    h = np.ascontiguousarray(h, np.int32); out = np.zeros(128, np.uint8)
+    lib().orc_sift_finalize(ip(h), u8(out))
+    return out
+
+
+def sift128(blurred, x, y, angle_deg):
+    return sift_finalize(sift_hist(blurred, x, y, angle_deg))
+
+
+def sift_weights(n):
+    w = np.zeros(n, np.float32)
+    lib().orc_sift_weights(fp(w), n)
+    return w
+
+
+def detect_feature(raw, mparams=None, oparams=None, sift=False):
+    """Frame::DetectFeature on the normalised image + mask filter (frame.cpp:167-203); sift=True also returns the n x 128 rows"""
     norm = normalize(raw); msk = mask(raw, mparams)
+    if sift:
+        kps, desc, d128 = orb_extract_sift(norm, oparams)
+        n = lib().orc_mask_filter2(kp_ptr(kps), u8(desc), u8(d128), len(kps), u8(msk), raw.shape[1]) if len(kps) else 0
+        return kps[:n].copy(), desc[:n].copy(), norm, msk, d128[:n].copy()
     kps, desc = orb_extract(norm, oparams)
     n = lib().orc_mask_filter(kp_ptr(kps), u8(desc), len(kps), u8(msk), raw.shape[1]) if len(kps) else 0
     return kps[:n].copy(), desc[:n].copy(), norm, msk
@@ -204,7 +247,9 @@ def robust_matching(id_s, id_t, rows_s, rows_t, kps_s, desc_s, geo_s, bbox_s, kp
     cap = len(kps_s) + len(kps_t) + 1
     rows = np.zeros((cap, 6), np.float64)
     kps_s = np.ascontiguousarray(kps_s); kps_t = np.ascontiguousarray(kps_t)
-    desc_s = np.ascontiguousarray(desc_s).reshape(-1, 32); desc_t = np.ascontiguousarray(desc_t).reshape(-1, 32)
+    dlen = 128 if p.use_l2 == 2 else 32            # use_l2 = 2: rows of the 128-element SIFT descriptor
+    desc_s = np.ascontiguousarray(desc_s, np.uint8).reshape(-1, dlen); desc_t = np.ascontiguousarray(desc_t, np.uint8).reshape(-1, dlen)
+    assert len(desc_s) == len(kps_s) and len(desc_t) == len(kps_t)
     geo_s = np.ascontiguousarray(geo_s, np.float64).reshape(-1, 2); geo_t = np.ascontiguousarray(geo_t, np.float64).reshape(-1, 2)
     n = lib().orc_robust_matching(id_s, id_t, rows_s, rows_t,
                                   kp_ptr(kps_s), u8(desc_s), dp(geo_s), len(kps_s), dp(np.ascontiguousarray(bbox_s, np.float64)),
@@ -219,7 +264,9 @@ def match_dir(id_a, id_b, rows_b, kps_a, desc_a, geo_a, kps_b, desc_b, geo_b, bb
     corres = np.full(max(na, 1), -1, np.int32)
     best = np.zeros(max(na, 1), np.int32); second = np.zeros(max(na, 1), np.int32); ncand = np.zeros(max(na, 1), np.int32)
     kps_a = np.ascontiguousarray(kps_a); kps_b = np.ascontiguousarray(kps_b)
-    desc_a = np.ascontiguousarray(desc_a).reshape(-1, 32); desc_b = np.ascontiguousarray(desc_b).reshape(-1, 32)
+    dlen = 128 if p.use_l2 == 2 else 32
+    desc_a = np.ascontiguousarray(desc_a, np.uint8).reshape(-1, dlen); desc_b = np.ascontiguousarray(desc_b, np.uint8).reshape(-1, dlen)
+    assert len(desc_a) == na and len(desc_b) == len(kps_b)
     geo_a = np.ascontiguousarray(geo_a, np.float64).reshape(-1, 2); geo_b = np.ascontiguousarray(geo_b, np.float64).reshape(-1, 2)
     bb = np.ascontiguousarray(bbox_b, np.float64)
     L = lib()
@@ -296,12 +343,71 @@ def pg_select_lc(frame_rows, pair_s, pair_t, pair_off, kp7, lcs):
     return edges[:n].copy()
 
 
-def pg_solve(dr, edges, params=None):
+_REDUCED_FN = C.CFUNCTYPE(C.c_int, C.c_int, C.c_int, c_ip, c_ip, c_dp, c_dp)
+
+
+def _make_reduced_solver(refine, log):
+    """The reduced (separator) system of orc_pg_solve through scipy's sparse LU (SuperLU, symmetric mode) instead of the
+    envelope Cholesky: what lets the oracle's own LM run at the size of BASELINE config 3 / 4 in a minute.  `refine`
+    steps of iterative refinement with the residual accumulated in long double."""
+    import scipy.sparse as sp
+    import scipy.sparse.linalg as spla
+
+    def solve(ns, nblk, bi, bj, blk, rhs):
+        try:
+            bi = np.ctypeslib.as_array(bi, (nblk,)).astype(np.int64)
+            bj = np.ctypeslib.as_array(bj, (nblk,)).astype(np.int64)
+            B = np.ctypeslib.as_array(blk, (nblk, 6, 6))
+            b = np.ctypeslib.as_array(rhs, (ns * 6,))
+            a6 = np.arange(6)
+            rows = (bi[:, None, None] * 6 + a6[None, :, None]) + np.zeros((1, 1, 6), np.int64)
+            cols = (bj[:, None, None] * 6 + a6[None, None, :]) + np.zeros((1, 6, 1), np.int64)
+            off = bi != bj
+            r = np.concatenate([rows.ravel(), cols[off].ravel()])
+            c = np.concatenate([cols.ravel(), rows[off].ravel()])
+            v = np.concatenate([B.ravel(), B[off].ravel()])
+            A = sp.coo_matrix((v, (r, c)), shape=(ns * 6, ns * 6)).tocsc()
+            lu = spla.splu(A, permc_spec="MMD_AT_PLUS_A", diag_pivot_thresh=0.0, options=dict(SymmetricMode=True))
+            b0 = b.copy()
+            x = lu.solve(b0)
+            for _ in range(refine):
+                Ac = A.tocoo()
+                res = b0.astype(np.longdouble)
+                np.subtract.at(res, Ac.row, Ac.data.astype(np.longdouble) * x[Ac.col].astype(np.longdouble))
+                x = x + lu.solve(res.astype(np.float64))
+            if not np.all(np.isfinite(x)):
+                return -1
+            b[:] = x
+            if log is not None:
+                log.append((ns, int(A.nnz), int(lu.L.nnz)))
+            return 0
+        except Exception as e:          # a Python exception must not unwind through the C frame
+            print("oracle reduced solver failed:", repr(e))
+            return -1
+    return _REDUCED_FN(solve)
+
+
+def pg_solve(dr, edges, params=None, solver="envelope", refine=0, log=None, full_refine=0):
+    """orc_pg_solve.  solver = "envelope" (the C file's own exact skyline Cholesky; small graphs) or "sparse" (the same LM loop,
+    chain condensation and back-substitution with the reduced system solved by scipy's sparse LU: full-size graphs)."""
     dr = np.ascontiguousarray(dr, np.float64).reshape(-1, 6)
     p = params or pg_params()
     out = np.zeros((len(dr), 12), np.float64); stats = np.zeros(4, np.float64)
     edges = np.ascontiguousarray(edges)
-    lib().orc_pg_solve(dp(dr), len(dr), edges.ctypes.data_as(C.POINTER(LCEdge)), len(edges), C.byref(p), dp(out), dp(stats))
+    L = lib()
+    L.orc_pg_set_reduced_solver.argtypes = [C.c_void_p]
+    cb = None
+    if solver == "sparse":
+        cb = _make_reduced_solver(refine, log)
+        L.orc_pg_set_reduced_solver(C.cast(cb, C.c_void_p))
+    else:
+        assert solver == "envelope"
+    L.orc_pg_set_full_refine(int(full_refine))
+    try:
+        L.orc_pg_solve(dp(dr), len(dr), edges.ctypes.data_as(C.POINTER(LCEdge)), len(edges), C.byref(p), dp(out), dp(stats))
+    finally:
+        L.orc_pg_set_reduced_solver(None)
+        L.orc_pg_set_full_refine(0)
     return out, stats
 
 

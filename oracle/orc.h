@@ -58,6 +58,7 @@ int      orc_cvrng_uniform(uint64_t* state, int a, int b);
 void     orc_normal_fill(double* out, int n);   /* default_random_engine + normal_distribution<double>(0,1) */
 int      orc_hamming256(const uint8_t* a, const uint8_t* b); /* FEAmatcher.cpp:442-458 (SWAR form) */
 int      orc_l2sq32(const uint8_t* a, const uint8_t* b);
+int      orc_l2sq(const uint8_t* a, const uint8_t* b, int n);
 
 /* ---------------------------------------------------------------- frame preprocessing (frame.cpp) */
 typedef struct {
@@ -113,10 +114,19 @@ int  orc_orb_extract(const uint8_t* img, int rows, int cols, const orc_orb_param
                      orc_kp* kps, uint8_t* desc, int cap);
 /* Frame::DetectFeature mask filter (frame.cpp:184-195) applied in place; returns new count */
 int  orc_mask_filter(orc_kp* kps, uint8_t* desc, int n, const uint8_t* mask, int cols);
+int  orc_mask_filter2(orc_kp* kps, uint8_t* desc, uint8_t* desc128 /* may be NULL */, int n, const uint8_t* mask, int cols);
+/* N4: the descriptor of the SIFT call site (ORBextractor.cpp:1043-1047,1098) as intended -- oracle/orc_sift.c */
+void orc_sift_weights(float* w, int n);                                /* exp(-k / 512), k < n */
+void orc_sift_hist(const uint8_t* blurred, int rows, int cols, int x, int y, float angle_deg, int32_t h[128]);  /* 2^-12 fixed point */
+void orc_sift_finalize(const int32_t h[128], uint8_t out[128]);        /* normalise, clip 0.2, renormalise, x 512, saturate */
+void orc_sift128(const uint8_t* blurred, int rows, int cols, int x, int y, float angle_deg, uint8_t out[128]);
+int  orc_orb_extract_sift(const uint8_t* img, int rows, int cols, const orc_orb_params* p,
+                          orc_kp* kps, uint8_t* desc, uint8_t* desc128, int cap);
 
 /* ---------------------------------------------------------------- matcher (FEAmatcher.cpp) */
 typedef struct {
-    int use_l2;        /* 0: Hamming branch (:141-176); 1: L2-on-bytes branch (:106-139, USE_SIFT) */
+    int use_l2;        /* 0: Hamming branch (:141-176); 1: L2 branch (:106-139, USE_SIFT) on the 32 ORB bytes the shipped
+                          reference feeds it; 2: the same branch on 128-element SIFT rows (desc = n x 128, oracle/orc_sift.c) */
     double radius;     /* 8  :66 */
     int bound_same;    /* 88 :143 */
     int bound_diff;    /* 80 :145 (frame-id parities differ) */
@@ -198,6 +208,10 @@ int orc_pg_select_lc(int F, const int* frame_rows, int npairs, const int* pair_s
 int orc_pg_solve(const double* dr, int total, const orc_lc_edge* edges, int ne, const orc_pg_params* p,
                  double* out12, double* stats /* [iters, err0, err1, lambda] */);
 /* the same graph's LM objective evaluated at given poses (total x 12), for full-size checks of a solver's answer */
+/* optional second linear solver of the reduced (separator) system of orc_pg_solve: see orc_posegraph.c */
+typedef int (*orc_pg_reduced_solver_fn)(int ns, int nblk, const int* bi, const int* bj, const double* blk36, double* rhs);
+void orc_pg_set_reduced_solver(orc_pg_reduced_solver_fn fn);
+void orc_pg_set_full_refine(int steps);   /* iterative refinement of every trial's solve against the full system (long double residual) */
 double orc_pg_error_at(const double* dr, int total, const orc_lc_edge* edges, int ne, const double* x12);
 
 #ifdef __cplusplus

@@ -49,7 +49,8 @@ int orc_match_nn(int id, int id_ref, const orc_kp* kps, const uint8_t* desc, con
             if (best_id != -1 && best <= bound && ratio <= p->ratio && second != 1000) { corres[i] = best_id; ++accepted; }
             else if (nc == 1 && best <= bound) { corres[i] = best_id; ++accepted; }
         } else {
-            /* L2-on-bytes branch (:106-139); distances are sqrt of integers */
+            /* L2 branch (:106-139); rows of integer-valued elements: distances are sqrt of integers */
+            const int dlen = p->use_l2 == 2 ? 128 : 32;
             double best = 1000, second = 1000;
             int bi = 1000000, si = 1000000;
             for (int j = 0; j < nb; ++j) {
@@ -57,7 +58,7 @@ int orc_match_nn(int id, int id_ref, const orc_kp* kps, const uint8_t* desc, con
                 double gd = sqrt((loc_x - rx) * (loc_x - rx) + (loc_y - ry) * (loc_y - ry));
                 if (!(gd < p->radius)) continue;
                 ++nc;
-                int sq = orc_l2sq32(desc + (size_t)i * 32, desc_ref + (size_t)j * 32);
+                int sq = orc_l2sq(desc + (size_t)i * dlen, desc_ref + (size_t)j * dlen, dlen);
                 double d = sqrt((double)sq);
                 if (d < best) { second = best; si = bi; best = d; bi = sq; best_id = j; }
                 else if (d < second) { second = d; si = sq; }

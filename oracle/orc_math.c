@@ -131,3 +131,9 @@ int orc_l2sq32(const uint8_t* a, const uint8_t* b)
     for (int i = 0; i < 32; ++i) { int d = (int)a[i] - (int)b[i]; s += d * d; }
     return s;
 }
+int orc_l2sq(const uint8_t* a, const uint8_t* b, int n)
+{
+    int s = 0;
+    for (int i = 0; i < n; ++i) { int d = (int)a[i] - (int)b[i]; s += d * d; }
+    return s;
+}

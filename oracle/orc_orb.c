@@ -510,8 +510,22 @@ void orc_brief(const uint8_t* img, int stride, int x, int y, float angle_deg, ui
 }
 
 /* ORBextractor::operator() with the ORB descriptor call (ORBextractor.cpp:1049-1113) */
+static int orb_extract_impl(const uint8_t* img, int rows, int cols, const orc_orb_params* p,
+                            orc_kp* kps, uint8_t* desc, uint8_t* desc128, int cap);
 int orc_orb_extract(const uint8_t* img, int rows, int cols, const orc_orb_params* p,
                     orc_kp* kps, uint8_t* desc, int cap)
+{
+    return orb_extract_impl(img, rows, cols, p, kps, desc, NULL, cap);
+}
+/* the same with the SIFT call site's descriptor next to the ORB one (ORBextractor.cpp:1098 as intended, oracle/orc_sift.c):
+ * desc128 = n x 128 integer-valued bytes (the 128 floats of a cv::SIFT row) */
+int orc_orb_extract_sift(const uint8_t* img, int rows, int cols, const orc_orb_params* p,
+                         orc_kp* kps, uint8_t* desc, uint8_t* desc128, int cap)
+{
+    return orb_extract_impl(img, rows, cols, p, kps, desc, desc128, cap);
+}
+static int orb_extract_impl(const uint8_t* img, int rows, int cols, const orc_orb_params* p,
+                            orc_kp* kps, uint8_t* desc, uint8_t* desc128, int cap)
 {
     int L = p->nlevels;
     int lrows[ORC_MAX_LEVELS], lcols[ORC_MAX_LEVELS], quota[ORC_MAX_LEVELS];
@@ -548,6 +562,7 @@ int orc_orb_extract(const uint8_t* img, int rows, int cols, const orc_orb_params
             int xi = orc_cvroundf(kp.x), yi = orc_cvroundf(kp.y);
             kp.angle = orc_ic_angle(pyr[l], c, xi, yi);
             orc_brief(blur, c, xi, yi, kp.angle, desc + (size_t)total * 32);
+            if (desc128) orc_sift128(blur, r, c, xi, yi, kp.angle, desc128 + (size_t)total * 128);
             if (l != 0) { kp.x *= sf[l]; kp.y *= sf[l]; }
             kps[total++] = kp;
         }
@@ -561,10 +576,15 @@ int orc_orb_extract(const uint8_t* img, int rows, int cols, const orc_orb_params
 /* Frame::DetectFeature tail (frame.cpp:184-195): keep kp iff mask(int(y), int(x)) != 0 */
 int orc_mask_filter(orc_kp* kps, uint8_t* desc, int n, const uint8_t* mask, int cols)
 {
+    return orc_mask_filter2(kps, desc, NULL, n, mask, cols);
+}
+int orc_mask_filter2(orc_kp* kps, uint8_t* desc, uint8_t* desc128, int n, const uint8_t* mask, int cols)
+{
     int m = 0;
     for (int i = 0; i < n; ++i) {
         int v = (int)kps[i].y, u = (int)kps[i].x;
         if (mask[(size_t)v * cols + u]) {
+            if (m != i && desc128) memmove(desc128 + (size_t)m * 128, desc128 + (size_t)i * 128, 128);
             if (m != i) { kps[m] = kps[i]; memmove(desc + (size_t)m * 32, desc + (size_t)i * 32, 32); }
             ++m;
         }

@@ -81,6 +81,20 @@ static void chol6_solve(const double* L, double* b, int nrhs) /* b is 6 x nrhs r
 
 typedef struct { int i, j; orc_pose meas; double w[6]; } pg_factor;  /* between(i,j); i<0: prior on j */
 
+/* Second linear solver for the reduced system (round 6).  The envelope Cholesky below is exact but as wide as a leg's
+ * loop closures: at the size of BASELINE config 3 (23 k separators) it needs hours.  When a callback is installed the
+ * reduced matrix leaves as lower-triangular 6 x 6 blocks (bi >= bj, row-major, duplicates are to be SUMMED) and the
+ * callback overwrites rhs with the solution (oracle/binding.py: scipy.sparse.linalg.splu) -- the LM loop, the chain
+ * condensation and the back-substitution stay the ones of this file.  Returns 0 on success. */
+static orc_pg_reduced_solver_fn g_reduced_solver = NULL;
+void orc_pg_set_reduced_solver(orc_pg_reduced_solver_fn fn) { g_reduced_solver = fn; }
+/* Steps of iterative refinement of every LM trial's linear solve against the FULL system (residual of the normal
+ * equations accumulated in long double from the factors' Jacobians, correction through the same condensation +
+ * reduced solve): with it the trial step is the exact solution of the damped normal equations to ~1e-19 relative --
+ * the yardstick for "how far does a solver's rounding move the LM iterate" (tests/test_gpu_configs.py). */
+static int g_full_refine = 0;
+void orc_pg_set_full_refine(int steps) { g_full_refine = steps; }
+
 typedef struct {
     int n, nf;
     pg_factor* f;
@@ -129,7 +143,7 @@ static double pg_error(const pg_t* g, const orc_pose* X)
 
 /* Solve (H + lambda I) delta = -g for H = sum J^T J.  Chain factors are f[0] (prior) and f[1..n-1]
  * (odometry i-1 -> i); LC factors follow.  Returns 0 on success. */
-static int pg_solve(const pg_t* g, double lambda, double* delta)
+static int pg_solve(const pg_t* g, double lambda, double* delta, const double* neg_rhs)
 {
     int n = g->n;
     double* D = (double*)calloc((size_t)n * 36, sizeof(double));      /* diagonal blocks */
@@ -163,6 +177,7 @@ static int pg_solve(const pg_t* g, double lambda, double* delta)
         if (k >= n) { sep[f->i] = 1; sep[f->j] = 1; }
     }
     for (int i = 0; i < n; ++i) for (int a = 0; a < 6; ++a) D[(size_t)i * 36 + a * 6 + a] += lambda;
+    if (neg_rhs) memcpy(gr, neg_rhs, (size_t)n * 6 * sizeof(double));   /* refinement: solve for another right-hand side */
     sep[0] = 1; sep[n - 1] = 1;
     int ns = 0;
     int* sidx = (int*)malloc(sizeof(int) * n);     /* pose -> separator index or -1 */
@@ -177,10 +192,11 @@ static int pg_solve(const pg_t* g, double lambda, double* delta)
         int lo = sa < sb ? sa : sb, hi = sa < sb ? sb : sa;
         for (int a = 0; a < 6; ++a) if (first[hi * 6 + a] > lo * 6) first[hi * 6 + a] = lo * 6;
     }
+    const int sparse = g_reduced_solver != NULL;
     size_t* rowp = (size_t*)malloc(sizeof(size_t) * (N + 1));
     rowp[0] = 0;
-    for (int i = 0; i < N; ++i) rowp[i + 1] = rowp[i] + (size_t)(i - first[i] + 1);
-    double* S = (double*)calloc(rowp[N], sizeof(double));
+    for (int i = 0; i < N; ++i) rowp[i + 1] = rowp[i] + (sparse ? 0 : (size_t)(i - first[i] + 1));
+    double* S = (double*)calloc(rowp[N] + 1, sizeof(double));
     double* rhs = (double*)calloc(N, sizeof(double));
 #define SREF(i, j) S[rowp[i] + (size_t)((j) - first[i])]
     /* eliminate interior chain nodes of every segment (left separator L, right separator R) */
@@ -232,7 +248,42 @@ static int pg_solve(const pg_t* g, double lambda, double* delta)
             }
         }
     }
-    if (!fail) {
+    if (!fail && sparse) {
+        /* block list: ns diagonal blocks, ns - 1 chain couplings, one block per loop closure */
+        int nblk = ns + (ns - 1) + (g->nf - n), q = 0;
+        int* bi = (int*)malloc(sizeof(int) * nblk);
+        int* bj = (int*)malloc(sizeof(int) * nblk);
+        double* blk = (double*)calloc((size_t)nblk * 36, sizeof(double));
+        for (int s = 0; s < ns; ++s) {
+            int p = spose[s];
+            bi[q] = s; bj[q] = s;
+            memcpy(blk + (size_t)q * 36, Dw + (size_t)p * 36, 36 * sizeof(double));
+            ++q;
+            for (int a = 0; a < 6; ++a) rhs[s * 6 + a] = -gi_[(size_t)p * 6 + a];
+        }
+        for (int s = 0; s + 1 < ns; ++s) {      /* S(s, s+1) = SLR[s]: lower block (s+1, s) is its transpose */
+            bi[q] = s + 1; bj[q] = s;
+            for (int a = 0; a < 6; ++a) for (int b = 0; b < 6; ++b) blk[(size_t)q * 36 + b * 6 + a] = SLR[(size_t)s * 36 + a * 6 + b];
+            ++q;
+        }
+        for (int k = n; k < g->nf; ++k) {
+            const pg_factor* f = &g->f[k];
+            const double* Ji = g->Ji + (size_t)k * 36;
+            const double* Jj = g->Jj + (size_t)k * 36;
+            int sa = sidx[f->i], sb = sidx[f->j];
+            if (sa == sb) continue;
+            bi[q] = sa > sb ? sa : sb; bj[q] = sa > sb ? sb : sa;
+            for (int a = 0; a < 6; ++a) for (int b = 0; b < 6; ++b) {
+                double sij = 0;
+                for (int t = 0; t < 6; ++t) sij += Ji[t * 6 + a] * Jj[t * 6 + b];
+                if (sa < sb) blk[(size_t)q * 36 + b * 6 + a] = sij; else blk[(size_t)q * 36 + a * 6 + b] = sij;
+            }
+            ++q;
+        }
+        if (g_reduced_solver(ns, q, bi, bj, blk, rhs) != 0) fail = 1;
+        free(bi); free(bj); free(blk);
+    }
+    if (!fail && !sparse) {
         for (int s = 0; s < ns; ++s) {
             int p = spose[s];
             for (int a = 0; a < 6; ++a) {
@@ -267,10 +318,12 @@ static int pg_solve(const pg_t* g, double lambda, double* delta)
         }
     }
     if (!fail) {
-        for (int i = 0; i < N; ++i) { double s = rhs[i]; for (int k = first[i]; k < i; ++k) s -= SREF(i, k) * rhs[k]; rhs[i] = s / SREF(i, i); }
-        for (int i = N - 1; i >= 0; --i) {
-            rhs[i] /= SREF(i, i);
-            for (int k = first[i]; k < i; ++k) rhs[k] -= SREF(i, k) * rhs[i];
+        if (!sparse) {
+            for (int i = 0; i < N; ++i) { double s = rhs[i]; for (int k = first[i]; k < i; ++k) s -= SREF(i, k) * rhs[k]; rhs[i] = s / SREF(i, i); }
+            for (int i = N - 1; i >= 0; --i) {
+                rhs[i] /= SREF(i, i);
+                for (int k = first[i]; k < i; ++k) rhs[k] -= SREF(i, k) * rhs[i];
+            }
         }
         for (int s = 0; s < ns; ++s) memcpy(delta + (size_t)spose[s] * 6, rhs + s * 6, 6 * sizeof(double));
         /* back-substitute the interiors, right to left */
@@ -359,7 +412,33 @@ int orc_pg_solve(const double* dr, int total, const orc_lc_edge* edges, int ne, 
         for (size_t k = 0; k < (size_t)g.nf * 6; ++k) oldLin += g.r[k] * g.r[k];
         oldLin *= 0.5;
         for (;;) {
-            int ok = pg_solve(&g, lambda, delta) == 0;
+            int ok = pg_solve(&g, lambda, delta, NULL) == 0;
+            for (int it = 0; ok && it < g_full_refine; ++it) {
+                /* rho = -J^T (r + J delta) - lambda delta, in long double; correction c: (H + lambda) c = rho */
+                long double* rho = (long double*)calloc((size_t)n * 6, sizeof(long double));
+                for (int k = 0; k < g.nf; ++k) {
+                    const pg_factor* f = &g.f[k];
+                    long double v[6];
+                    for (int a = 0; a < 6; ++a) {
+                        long double t = g.r[(size_t)k * 6 + a];
+                        for (int q = 0; q < 6; ++q) {
+                            t += (long double)g.Jj[(size_t)k * 36 + a * 6 + q] * delta[(size_t)f->j * 6 + q];
+                            if (f->i >= 0) t += (long double)g.Ji[(size_t)k * 36 + a * 6 + q] * delta[(size_t)f->i * 6 + q];
+                        }
+                        v[a] = t;
+                    }
+                    for (int q = 0; q < 6; ++q) for (int a = 0; a < 6; ++a) {
+                        rho[(size_t)f->j * 6 + q] -= (long double)g.Jj[(size_t)k * 36 + a * 6 + q] * v[a];
+                        if (f->i >= 0) rho[(size_t)f->i * 6 + q] -= (long double)g.Ji[(size_t)k * 36 + a * 6 + q] * v[a];
+                    }
+                }
+                double* nr = (double*)malloc(sizeof(double) * 6 * (size_t)n);
+                double* c = (double*)malloc(sizeof(double) * 6 * (size_t)n);
+                for (size_t q = 0; q < (size_t)n * 6; ++q) nr[q] = -(double)(rho[q] - (long double)lambda * delta[q]);
+                ok = pg_solve(&g, lambda, c, nr) == 0;
+                if (ok) for (size_t q = 0; q < (size_t)n * 6; ++q) delta[q] += c[q];
+                free(rho); free(nr); free(c);
+            }
             int success = 0, stop = 0;
             double newErr = 0;
             if (ok) {

@@ -164,14 +164,24 @@ def _c3_worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
-def test_config_C4_full_size_8_partitions_and_2_ranks():
+def test_config_C4_full_size_8_partitions_and_2_ranks(orc):
     from diasss_amd.pipeline import Pipeline
     F = C3["F"]
     raws, poses, alts, grs = _c3_inputs(set(range(F)))
     pipe = Pipeline(F, device=0)
     ref, ref_stats = pipe.run(raws, poses, alts, grs)
     ref = ref.copy(); ref_stats = np.array(ref_stats)
-    n_edges = len(pipe.ctx.posegraph_select(F))
+    g_edges = pipe.ctx.posegraph_select(F)
+    n_edges = len(g_edges)
+    # the ORACLE's LM on the same graph (its reduced system through a sparse LU, oracle/binding.py): every layout is held to IT (round 6),
+    # at the default stopping rule and converged.  The selected edges are the oracle's own to 1e-9 (test_config_C3_full_size_every_stage_vs_oracle).
+    o_edges = np.zeros(n_edges, orc.LCEDGE_DTYPE)
+    for k in ("a", "b", "rel", "var"):
+        o_edges[k] = g_edges[k]
+    dr = np.concatenate(poses)
+    o_def, o_def_stats = orc.pg_solve(dr, o_edges, solver="sparse")
+    po_ = orc.pg_params(); po_.rel_tol = 1e-13; po_.abs_tol = 1e-13
+    o_conv, o_conv_stats = orc.pg_solve(dr, o_edges, po_, solver="sparse")
     assert n_edges > 5000 and ref_stats[0] >= 3
     span = np.abs(ref[:, 9:]).max()                                # the track spans hundreds of metres
     pipe.ctx.set_pg_partitions(8)                                  # the 8-GPU layout of the solve, every partition on this rank
@@ -184,7 +194,7 @@ def test_config_C4_full_size_8_partitions_and_2_ranks():
     # of the optimum of a 4 km track, and the reduced system's conditioning -- prior sigma 1e-6 against loop-closure sigmas of decimetres --
     # lets two elimination orders stop that far apart): the optimum itself does not depend on the layout.
     mp_, op_, mt_, pg = pipe.ctx.default_params()
-    pg.rel_tol = 1e-13; pg.abs_tol = 1e-9
+    pg.rel_tol = 1e-13; pg.abs_tol = 1e-13
     pipe.ctx.set_params(pg=pg)
     c8, _, cs8 = pipe.ctx.posegraph_solve(F, len(ref), want_rpy=False); c8 = c8.copy(); cs8 = np.array(cs8)
     pipe.ctx.set_pg_partitions(1)
@@ -199,12 +209,24 @@ def test_config_C4_full_size_8_partitions_and_2_ranks():
           "all-reduce bytes per rank %.1f MB in %d calls" % (n_edges, ref_stats[0], span, d8, d2, res[0][3][2] / 1e6, res[0][3][3]))
     print("converged runs: %d / %d iterations, error %.9g / %.9g, max |8 partitions - 1| %.3g; default stopping rule: single rank to its converged run %.3g"
           % (cs8[0], cs1[0], cs8[2], cs1[2], dconv, np.abs(ref - c1).max()))
-    assert s8[0] == ref_stats[0] and abs(s8[2] - ref_stats[2]) <= 1e-6 * ref_stats[2]
-    assert dconv < 2e-7                                            # the optimum is the same: north_star's 1e-6 with margin, absolute, on a 4 km track
-    assert d8 < 3e-6                                               # GTSAM's default stopping rule: two LM iterates, each about a micrometre from that optimum (round 4's orderings: 2.6e-7; round 5's: 1.2e-6)
+    to_oracle = dict(single=np.abs(ref - o_def).max(), parts8=np.abs(p8 - o_def).max(), ranks2=max(np.abs(out - o_def).max() for _, out, _, _ in res))
+    conv_to_oracle = dict(single=np.abs(c1 - o_conv).max(), parts8=np.abs(c8 - o_conv).max())
+    print("against the ORACLE's LM (%d iterations, objective %.12e): default stopping rule %s; converged (%d iterations) %s"
+          % (o_def_stats[0], o_def_stats[2], {k: "%.3g" % v for k, v in to_oracle.items()}, o_conv_stats[0], {k: "%.3g" % v for k, v in conv_to_oracle.items()}))
+    assert s8[0] == ref_stats[0] == o_def_stats[0] and abs(s8[2] - ref_stats[2]) <= 1e-6 * ref_stats[2]
+    assert abs(ref_stats[2] - o_def_stats[2]) <= 1e-9 * o_def_stats[2]
+    # (a) the OPTIMUM does not depend on the layout and is the oracle's: north_star's 1e-6, absolute, on a 4 km track (measured 4e-8 between
+    #     layouts, 1.3e-7 .. 1.9e-7 to the oracle)
+    assert dconv < 2e-7
+    assert max(conv_to_oracle.values()) < 1e-6, conv_to_oracle
+    # (b) GTSAM's default stopping rule returns an iterate ~0.1 m short of that optimum, where the rounding of any f64 elimination moves it
+    #     by about a micrometre (the oracle against itself: 4e-7 .. 7e-7 between LU orderings / with iterative refinement, tools/pg_parity.py):
+    #     layouts 1e-6 apart, 2e-6 .. 4e-6 from the oracle.  Not north_star's 1e-6 -- stated in DESIGN.md section 0, not hidden in a tolerance.
+    assert d8 < 3e-6
+    assert max(to_oracle.values()) < 1e-5, to_oracle
     for rank, out, stats, cs in res:
         assert stats[0] == ref_stats[0] and abs(stats[2] - ref_stats[2]) <= 1e-6 * ref_stats[2]
-        assert np.abs(out - ref).max() < 3e-6                      # (as above: iterates of the default stopping rule; 1.5e-7 measured in round 4)
+        assert np.abs(out - ref).max() < 3e-6
         assert cs[1] == 2 and cs[3] > 0 and cs[2] > 0
     assert (res[0][1] == res[1][1]).all()                          # identical bits on both ranks
 
