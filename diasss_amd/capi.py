@@ -30,7 +30,10 @@ class MaskParams(C.Structure):
 
 class OrbParams(C.Structure):
     _fields_ = [("nfeatures", C.c_int32), ("scale", C.c_float), ("nlevels", C.c_int32),
-                ("ini_th", C.c_int32), ("min_th", C.c_int32)]
+                ("ini_th", C.c_int32), ("min_th", C.c_int32), ("descriptor", C.c_int32)]
+
+
+DESC_ORB, DESC_SIFT128 = 0, 1          # include/dsss.h DSSS_DESC_*
 
 
 class MatchParams(C.Structure):
@@ -304,6 +307,16 @@ class Context:
         n = C.c_int(0)
         self._chk(self.L.dsss_features_get(self.h, fid, _ptr(kps), _ptr(desc), _ptr(geo), cap, C.byref(n)), "dsss_features_get")
         return kps[:n.value].copy(), desc[:n.value].copy(), geo[:n.value].copy()
+
+    def features_get_sift(self, fid, cap=16384):
+        """Frame::dst of the SIFT call site: n x 128 float32 (integer-valued 0..255)"""
+        d = np.zeros((cap, 128), np.float32); n = C.c_int(0)
+        self._chk(self.L.dsss_features_get_sift(self.h, fid, _ptr(d), cap, C.byref(n)), "dsss_features_get_sift")
+        return d[:n.value].copy()
+
+    def features_set_sift(self, fid, d128):
+        d = np.ascontiguousarray(d128, np.float32).reshape(-1, 128)
+        self._chk(self.L.dsss_features_set_sift(self.h, fid, _ptr(d), len(d)), "dsss_features_set_sift")
 
     def features_set(self, fid, N, M, kps, desc, geo=None, bbox=None):
         kps = np.ascontiguousarray(kps, KP_DTYPE); desc = np.ascontiguousarray(desc, np.uint8).reshape(-1, 32)

@@ -24,7 +24,7 @@ void dsss_prof_flush(dsss_ctx* c)
 extern "C" {
 
 void dsss_mask_params_default(dsss_mask_params* p) { p->factor = 2.5; p->width = 10; p->r = 6; p->side = 150; }
-void dsss_orb_params_default(dsss_orb_params* p) { p->nfeatures = 2000; p->scale = 1.2f; p->nlevels = 6; p->ini_th = 12; p->min_th = 7; }
+void dsss_orb_params_default(dsss_orb_params* p) { p->nfeatures = 2000; p->scale = 1.2f; p->nlevels = 6; p->ini_th = 12; p->min_th = 7; p->descriptor = DSSS_DESC_ORB; }
 void dsss_match_params_default(dsss_match_params* p)
 {
     p->use_l2 = 0; p->radius = 8; p->bound_same = 88; p->bound_diff = 80; p->l2_bound = 350; p->ratio = 0.35;
@@ -103,6 +103,7 @@ static void free_match(dsss_ctx* c)
 
 static void free_store(dsss_ctx* c)
 {
+    hipFree(c->desc128); c->desc128 = nullptr;
     hipFree(c->kps); hipFree(c->desc); hipFree(c->geo); hipFree(c->nkp_dev); hipFree(c->rows_dev);
     hipFree(c->cols_dev); hipFree(c->bbox_dev);
     c->kps = nullptr; c->desc = nullptr; c->geo = nullptr; c->nkp_dev = nullptr; c->rows_dev = nullptr;
@@ -118,7 +119,7 @@ void dsss_destroy(dsss_ctx* c)
     for (auto& G : c->gbatches) { hipFree(G.d); if (G.h) hipHostFree(G.h); if (G.ev) hipEventDestroy(G.ev); }
     c->gbatches.clear();
     free_match(c); free_store(c);
-    hipFree(c->lcs); hipFree(c->ex_scratch); hipFree(c->mt_aux); hipFree(c->tmp_dev);
+    hipFree(c->lcs); hipFree(c->ex_scratch); hipFree(c->mt_aux); hipFree(c->tmp_dev); hipFree(c->sift_w);
     hipFree(c->ag_buf); if (c->ag_host) hipHostFree(c->ag_host); hipFree(c->xch_dev);
     if (c->pg_edges_host) hipHostFree(c->pg_edges_host);
     if (c->pg_ab_host) hipHostFree(c->pg_ab_host);
@@ -158,16 +159,20 @@ int dsss_set_params(dsss_ctx* c, const dsss_mask_params* mp, const dsss_orb_para
     if (!c) return DSSS_E_ARG;
     if (mp) c->mp = *mp;
     if (op) {
-        if (op->nlevels < 1 || op->nlevels > DSSS_MAX_LEVELS || op->nfeatures < 1 || !(op->scale > 1.0f))
+        if (op->nlevels < 1 || op->nlevels > DSSS_MAX_LEVELS || op->nfeatures < 1 || !(op->scale > 1.0f) ||
+            (op->descriptor != DSSS_DESC_ORB && op->descriptor != DSSS_DESC_SIFT128))
             DSSS_FAIL(c, DSSS_E_ARG, "orb params out of range");
         int k = kcap_for(*op);
         if (k != c->kcap) {
-            if (c->kps) { HIPCHK(c, hipStreamSynchronize(c->stream)); free_store(c); free_match(c); for (auto& f : c->frames) f.has_feat = false; }
+            if (c->kps) { HIPCHK(c, hipStreamSynchronize(c->stream)); free_store(c); free_match(c); for (auto& f : c->frames) { f.has_feat = false; f.has_sift = false; } }
             c->kcap = k;
         }
         c->op = *op;
     }
-    if (mt) c->mt = *mt;
+    if (mt) {
+        if (mt->use_l2 < 0 || mt->use_l2 > 2) DSSS_FAIL(c, DSSS_E_ARG, "match params: use_l2 must be 0, 1 or 2");
+        c->mt = *mt;
+    }
     if (pg) c->pg = *pg;
     return DSSS_OK;
 }
@@ -190,6 +195,27 @@ int dsss_ensure_store(dsss_ctx* c)
     HIPCHK(c, hipMemsetAsync(c->cols_dev, 0, F * sizeof(int), c->stream));
     HIPCHK(c, hipMemsetAsync(c->bbox_dev, 0, F * 4 * sizeof(double), c->stream));
     HIPCHK(c, hipMemsetAsync(c->desc, 0, F * K * 32, c->stream));
+    return DSSS_OK;
+}
+
+int dsss_ensure_sift_store(dsss_ctx* c)
+{
+    int rc = dsss_ensure_store(c); if (rc) return rc;
+    if (!c->desc128) {
+        const size_t bytes = (size_t)c->max_frames * c->kcap * 128;
+        HIPCHK(c, hipMalloc(&c->desc128, bytes));
+        HIPCHK(c, hipMemsetAsync(c->desc128, 0, bytes, c->stream));
+    }
+    if (!c->sift_w) {
+        // exp(-k / 512) by repeated multiplication in double: the loop of oracle/orc_sift.c:orc_sift_weights, same bits
+        const int n = 2 * 28 * 28 + 1;
+        std::vector<float> w(n);
+        const double q = 0.9980487811074755;
+        double v = 1.0;
+        for (int k = 0; k < n; ++k) { w[k] = (float)v; v = v * q; }
+        HIPCHK(c, hipMalloc(&c->sift_w, n * sizeof(float)));
+        HIPCHK(c, hipMemcpy(c->sift_w, w.data(), n * sizeof(float), hipMemcpyHostToDevice));
+    }
     return DSSS_OK;
 }
 
@@ -502,7 +528,41 @@ int dsss_features_set(dsss_ctx* c, int id, int N, int M, const dsss_kp* kps, con
     HIPCHK(c, hipMemcpyAsync(c->rows_dev + id, &f.N, sizeof(int), hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipMemcpyAsync(c->cols_dev + id, &f.M, sizeof(int), hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    f.nkp = n; f.has_feat = true;
+    f.nkp = n; f.has_feat = true; f.has_sift = false;
+    return DSSS_OK;
+}
+
+int dsss_features_set_sift(dsss_ctx* c, int id, const float* d128, int n)
+{
+    if (!c) return DSSS_E_ARG;
+    if (id < 0 || id >= c->max_frames) DSSS_FAIL(c, DSSS_E_ARG, "frame id %d out of range", id);
+    dsss_frame& f = c->frames[id];
+    if (!f.has_feat || n != f.nkp) DSSS_FAIL(c, DSSS_E_STATE, "frame %d: dsss_features_set with the same n first (have %d, got %d)", id, f.has_feat ? f.nkp : -1, n);
+    if (n > 0 && !d128) return DSSS_E_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    int rc = dsss_ensure_sift_store(c); if (rc) return rc;
+    std::vector<uint8_t> b((size_t)n * 128);
+    for (size_t i = 0; i < b.size(); ++i) { const float v = std::nearbyint(d128[i]); b[i] = (uint8_t)(v < 0 ? 0 : v > 255 ? 255 : v); }
+    if (n > 0) HIPCHK(c, hipMemcpy(c->desc128 + (size_t)id * c->kcap * 128, b.data(), b.size(), hipMemcpyHostToDevice));
+    f.has_sift = true;
+    return DSSS_OK;
+}
+
+int dsss_features_get_sift(dsss_ctx* c, int id, float* d128, int cap, int* n)
+{
+    if (!c) return DSSS_E_ARG;
+    if (id < 0 || id >= c->max_frames) DSSS_FAIL(c, DSSS_E_ARG, "frame id %d out of range", id);
+    dsss_frame& f = c->frames[id];
+    if (!f.has_feat || !f.has_sift) DSSS_FAIL(c, DSSS_E_STATE, "frame %d has no SIFT rows (extract with dsss_orb_params.descriptor = DSSS_DESC_SIFT128)", id);
+    if (n) *n = f.nkp;
+    if (cap < f.nkp) DSSS_FAIL(c, DSSS_E_CAPACITY, "caller capacity %d < %d features", cap, f.nkp);
+    if (f.nkp > 0) {
+        if (!d128) return DSSS_E_ARG;
+        std::vector<uint8_t> b((size_t)f.nkp * 128);
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        HIPCHK(c, hipMemcpy(b.data(), c->desc128 + (size_t)id * c->kcap * 128, b.size(), hipMemcpyDeviceToHost));
+        for (size_t i = 0; i < b.size(); ++i) d128[i] = (float)b[i];
+    }
     return DSSS_OK;
 }
 
@@ -592,11 +652,11 @@ int dsss_overlap(dsss_ctx* c, int id_s, int id_t, float* iou)
     return DSSS_OK;
 }
 
-// packed record for collectives: [int32 n, N, M, pad][bbox 4 f64][kps kcap][desc kcap*32][geo kcap*2]
+// packed record for collectives: [int32 n, N, M, pad][bbox 4 f64][kps kcap][desc kcap*32][geo kcap*2]( + [desc128 kcap*128] under DSSS_DESC_SIFT128)
 size_t dsss_features_pack_bytes(const dsss_ctx* c)
 {
     size_t K = c->kcap;
-    return 16 + 32 + K * sizeof(dsss_kp) + K * 32 + K * 16;
+    return 16 + 32 + K * sizeof(dsss_kp) + K * 32 + K * 16 + (c->op.descriptor == DSSS_DESC_SIFT128 ? K * 128 : 0);
 }
 int dsss_features_pack(dsss_ctx* c, int id, void* buf)
 {
@@ -612,6 +672,10 @@ int dsss_features_pack(dsss_ctx* c, int id, void* buf)
     HIPCHK(c, hipMemcpyAsync(p + 48, c->kps + id * K, K * sizeof(dsss_kp), hipMemcpyDefault, c->stream));
     HIPCHK(c, hipMemcpyAsync(p + 48 + K * sizeof(dsss_kp), c->desc + id * K * 32, K * 32, hipMemcpyDefault, c->stream));
     HIPCHK(c, hipMemcpyAsync(p + 48 + K * sizeof(dsss_kp) + K * 32, c->geo + id * K * 2, K * 16, hipMemcpyDefault, c->stream));
+    if (c->op.descriptor == DSSS_DESC_SIFT128) {
+        if (!f.has_sift) DSSS_FAIL(c, DSSS_E_STATE, "frame %d has no SIFT rows", id);
+        HIPCHK(c, hipMemcpyAsync(p + 48 + K * sizeof(dsss_kp) + K * 48, c->desc128 + (size_t)id * K * 128, K * 128, hipMemcpyDefault, c->stream));
+    }
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return DSSS_OK;
 }
@@ -622,8 +686,14 @@ int dsss_features_unpack(dsss_ctx* c, int id, const void* buf)
     int32_t hdr[4]; double bbox[4];
     HIPCHK(c, hipMemcpy(hdr, p, 16, hipMemcpyDefault));
     HIPCHK(c, hipMemcpy(bbox, p + 16, 32, hipMemcpyDefault));
-    return dsss_features_set(c, id, hdr[1], hdr[2], (const dsss_kp*)(p + 48), (const uint8_t*)(p + 48 + K * sizeof(dsss_kp)),
-                             (const double*)(p + 48 + K * sizeof(dsss_kp) + K * 32), bbox, hdr[0]);
+    int rc = dsss_features_set(c, id, hdr[1], hdr[2], (const dsss_kp*)(p + 48), (const uint8_t*)(p + 48 + K * sizeof(dsss_kp)),
+                               (const double*)(p + 48 + K * sizeof(dsss_kp) + K * 32), bbox, hdr[0]);
+    if (rc == DSSS_OK && c->op.descriptor == DSSS_DESC_SIFT128) {
+        rc = dsss_ensure_sift_store(c); if (rc) return rc;
+        HIPCHK(c, hipMemcpy(c->desc128 + (size_t)id * K * 128, p + 48 + K * sizeof(dsss_kp) + K * 48, K * 128, hipMemcpyDefault));
+        c->frames[id].has_sift = true;
+    }
+    return rc;
 }
 
 int dsss_comm_frame_owner(const dsss_ctx* c, int nframes, int frame)
@@ -647,7 +717,7 @@ __device__ inline int ag_owner(int nframes, int world, int f)
 }
 __global__ __launch_bounds__(256) void ag_copy_kernel(int nframes, int world, int rank, int unpack, char* __restrict__ buf, size_t slice, size_t nb, int K,
                                                       dsss_kp* __restrict__ kps, uint8_t* __restrict__ desc, double* __restrict__ geo, int* __restrict__ nkp,
-                                                      int* __restrict__ rows, int* __restrict__ cols, double* __restrict__ bbox)
+                                                      int* __restrict__ rows, int* __restrict__ cols, double* __restrict__ bbox, uint8_t* __restrict__ desc128)
 {
     const int f = blockIdx.y;
     const int r = ag_owner(nframes, world, f);
@@ -659,9 +729,10 @@ __global__ __launch_bounds__(256) void ag_copy_kernel(int nframes, int world, in
     uint4* k4 = reinterpret_cast<uint4*>(reinterpret_cast<char*>(kps) + (size_t)f * kb);
     uint4* d4 = reinterpret_cast<uint4*>(desc + (size_t)f * db);
     uint4* g4 = reinterpret_cast<uint4*>(reinterpret_cast<char*>(geo) + (size_t)f * gb);
-    const size_t nk = kb / 16, nd = db / 16, ng = gb / 16, tot = nk + nd + ng;
+    uint4* s4 = desc128 ? reinterpret_cast<uint4*>(desc128 + (size_t)f * K * 128) : nullptr;
+    const size_t nk = kb / 16, nd = db / 16, ng = gb / 16, ns = desc128 ? (size_t)K * 8 : 0, tot = nk + nd + ng + ns;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < tot; i += (size_t)gridDim.x * 256) {
-        uint4* own = i < nk ? k4 + i : (i < nk + nd ? d4 + (i - nk) : g4 + (i - nk - nd));
+        uint4* own = i < nk ? k4 + i : (i < nk + nd ? d4 + (i - nk) : (i < nk + nd + ng ? g4 + (i - nk - nd) : s4 + (i - nk - nd - ng)));
         if (unpack) *own = r4[i]; else r4[i] = *own;
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) {
@@ -698,11 +769,13 @@ int dsss_features_allgather(dsss_ctx* c, int nframes)
     char* d_buf = static_cast<char*>(c->ag_buf);
     const hipStream_t st = c->stream;
     const dim3 grid(8, nframes);
-    hipLaunchKernelGGL(ag_copy_kernel, grid, dim3(256), 0, st, nframes, world, rank, 0, d_buf, slice, nb, c->kcap, c->kps, c->desc, c->geo, c->nkp_dev, c->rows_dev, c->cols_dev, c->bbox_dev);
+    uint8_t* d128 = nullptr;
+    if (c->op.descriptor == DSSS_DESC_SIFT128) { int r2 = dsss_ensure_sift_store(c); if (r2) return r2; d128 = c->desc128; }
+    hipLaunchKernelGGL(ag_copy_kernel, grid, dim3(256), 0, st, nframes, world, rank, 0, d_buf, slice, nb, c->kcap, c->kps, c->desc, c->geo, c->nkp_dev, c->rows_dev, c->cols_dev, c->bbox_dev, d128);
     HIPCHK(c, hipGetLastError());
     int rc = dsss_comm_allgather(c, d_buf, slice, st);
     if (rc) return rc;
-    hipLaunchKernelGGL(ag_copy_kernel, grid, dim3(256), 0, st, nframes, world, rank, 1, d_buf, slice, nb, c->kcap, c->kps, c->desc, c->geo, c->nkp_dev, c->rows_dev, c->cols_dev, c->bbox_dev);
+    hipLaunchKernelGGL(ag_copy_kernel, grid, dim3(256), 0, st, nframes, world, rank, 1, d_buf, slice, nb, c->kcap, c->kps, c->desc, c->geo, c->nkp_dev, c->rows_dev, c->cols_dev, c->bbox_dev, d128);
     HIPCHK(c, hipGetLastError());
     // the host's view of the gathered frames: counts, sizes and boxes in one download
     int* h_n = static_cast<int*>(c->ag_host); int* h_r = h_n + c->max_frames; int* h_c = h_r + c->max_frames;
@@ -718,7 +791,7 @@ int dsss_features_allgather(dsss_ctx* c, int nframes)
         if (h_n[f] < 0 || h_n[f] > c->kcap) DSSS_FAIL(c, DSSS_E_CAPACITY, "gathered frame %d: %d features exceed the per-frame capacity %d", f, h_n[f], c->kcap);
         if (!fr.has_geom) { fr.N = h_r[f]; fr.M = h_c[f]; }
         else if (fr.N != h_r[f] || fr.M != h_c[f]) DSSS_FAIL(c, DSSS_E_ARG, "gathered frame %d: geometry mismatch (%d x %d here, %d x %d at its owner)", f, fr.N, fr.M, h_r[f], h_c[f]);
-        fr.nkp = h_n[f]; fr.has_feat = true;
+        fr.nkp = h_n[f]; fr.has_feat = true; fr.has_sift = d128 != nullptr;
         memcpy(fr.bbox, h_bb + (size_t)f * 4, 4 * sizeof(double)); fr.has_bbox = true; fr.bbox_async = false;
     }
     return DSSS_OK;

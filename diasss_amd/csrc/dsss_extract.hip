@@ -6,6 +6,7 @@
 // point / explicitly ordered floating point, so results are bit-exact against oracle/orc_frame.c + orc_orb.c.
 #include "dsss_internal.h"
 #include "dsss_quadtree.h"
+#include "dsss_extract.h"
 #include <algorithm>
 #include <map>
 #include <memory>
@@ -20,27 +21,6 @@ int dsss_quadtree_cull(const float* xs, const float* ys, const float* resp, int 
 #define CELL_MAX 66            // FAST window: cell (ceil(width/nCols) < 60) + 6; 37 once a level is >= 900 px wide
 #define CELL_STRIDE 68
 #define CELL_CAP 1024          // strict 8-neighbour local maxima in 60 x 60 <= 30 x 30
-
-// ------------------------------------------------------------------ batch table
-// Every stage is ONE launch for a whole batch of frames: blockIdx.y (or .z) is the slot, and this per-slot record
-// (uploaded once per batch) carries the frame's buffers and sizes.  Frames of different sizes share a launch; the
-// grid is sized for the largest and the rest exit early.
-struct fast_cell { int level, x0, y0, w, h, offx, offy, pad; };
-struct resize_xtab { int sx; short a0, a1; };     // cv::resize tables: source column (sx + 1 is read only when a1 != 0), 11-bit weights
-struct resize_ytab { int ya, yb; short b0, b1; };
-struct ex_frame {
-    const double* raw; int N, M;
-    double* rowsum; double* rowmin; double* stats;
-    uint8_t* mask; uint8_t* lvl[DSSS_MAX_LEVELS]; int rows[DSSS_MAX_LEVELS], cols[DSSS_MAX_LEVELS]; int nlevels;
-    const fast_cell* cells; int ncells, cell_cap;
-    int cell_begin[DSSS_MAX_LEVELS + 1];      // cells of level l: [cell_begin[l], cell_begin[l + 1])
-    uint32_t* cand; int* counts; int* offs; float* xs; float* ys; float* rs; int cand_cap;
-    const qt_kp_in* kin; const int* nk; const int* lrows; const float* lscale; dsss_kp* kptmp; uint8_t* dtmp;
-    const double* pose6; const double* gr;
-    dsss_kp* kout; uint8_t* dout; double* geo; int* count;
-    int* err;                      // per-slot error flag (shared with the quadtree descriptors)
-    const resize_xtab* xt[DSSS_MAX_LEVELS]; const resize_ytab* yt[DSSS_MAX_LEVELS];      // per level l >= 1: tables of the resize from l - 1
-};
 
 // ------------------------------------------------------------------ K1: mean / min, normalise, mask
 // Row sums in the fixed order of oracle/orc_frame.c:fixed_sum (128 strided partials -> lane pairs -> xor
@@ -685,28 +665,6 @@ constexpr ic_tab make_ic_tab()
 }
 __constant__ ic_tab c_ic = make_ic_tab();
 
-__device__ inline float fast_atan2_dev(float y, float x)        // cv::fastAtan2 (ORBextractor.cpp:103)
-{
-    const float scale = (float)(180.0 / 3.1415926535897932384626433832795);
-    const float p1 = 0.9997878412794807f * scale, p3 = -0.3258083974640975f * scale;
-    const float p5 = 0.1555786518463281f * scale, p7 = -0.04432655554792128f * scale;
-    const float eps = (float)2.2204460492503131e-16;
-    const float ax = fabsf(x), ay = fabsf(y);
-    float a, c, c2;
-    if (ax >= ay) { c = ay / (ax + eps); c2 = c * c; a = (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c; }
-    else { c = ax / (ay + eps); c2 = c * c; a = 90.f - (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c; }
-    if (x < 0) a = 180.f - a;
-    if (y < 0) a = 360.f - a;
-    return a;
-}
-
-__device__ inline int reflect101_dev(int p, int len)
-{
-    if (len == 1) return 0;
-    while (p < 0 || p >= len) { if (p < 0) p = -p; else p = 2 * len - 2 - p; }
-    return p;
-}
-
 #define PR 24                  // patch radius: 18 (rotated BRIEF reach) + 6 (blur)
 #define PW 49
 #define PS 52                  // LDS row stride of the raw patch
@@ -880,6 +838,12 @@ __global__ __launch_bounds__(256) void mask_filter_kernel(const ex_frame* __rest
             const uint4* s = reinterpret_cast<const uint4*>(din + (size_t)i * 32);
             uint4* d = reinterpret_cast<uint4*>(dout + (size_t)o * 32);
             d[0] = s[0]; d[1] = s[1];
+            if (f.d128out) {
+                const uint4* s8 = reinterpret_cast<const uint4*>(f.d128tmp + (size_t)i * 128);
+                uint4* d8 = reinterpret_cast<uint4*>(f.d128out + (size_t)o * 128);
+#pragma unroll
+                for (int q = 0; q < 8; ++q) d8[q] = s8[q];
+            }
             double x, y;
             dsss_geo_at(pose6, gr, M, (int)kp.y, (int)kp.x, &x, &y);
             geo[2 * o] = x; geo[2 * o + 1] = y;
@@ -1061,10 +1025,10 @@ static int ensure_frame_images(dsss_ctx* c, dsss_frame& f, const level_geom& g)
 
 // per-frame slot of the batch scratch (device)
 struct ex_layout {
-    size_t rowsum, rowmin, stats, counts, offs, cand, xs, ys, rs, keys0, keys1, work[DSSS_MAX_LEVELS], out_idx, out_n, kin, nk, err, kptmp, dtmp, total;
+    size_t rowsum, rowmin, stats, counts, offs, cand, xs, ys, rs, keys0, keys1, work[DSSS_MAX_LEVELS], out_idx, out_n, kin, nk, err, kptmp, dtmp, d128tmp, total;
     int cand_cap, list_cap[DSSS_MAX_LEVELS], pool_cap[DSSS_MAX_LEVELS], out_cap;
 };
-static ex_layout make_layout(int N, const level_geom& g, int kcap)
+static ex_layout make_layout(int N, const level_geom& g, int kcap, bool sift)
 {
     ex_layout L; size_t o = 0;
     const int ncells = (int)g.cells.size();
@@ -1084,6 +1048,7 @@ static ex_layout make_layout(int N, const level_geom& g, int kcap)
     L.out_idx = take(sizeof(int) * (size_t)DSSS_MAX_LEVELS * L.out_cap); L.out_n = take(sizeof(int) * DSSS_MAX_LEVELS);
     L.kin = take(sizeof(kp_in) * kcap); L.nk = take(sizeof(int)); L.err = take(sizeof(int));
     L.kptmp = take(sizeof(dsss_kp) * kcap); L.dtmp = take((size_t)32 * kcap);
+    L.d128tmp = sift ? take((size_t)128 * kcap) : 0;
     L.total = align_up(o, 4096);
     return L;
 }
@@ -1100,7 +1065,8 @@ static int extract_frames_impl(dsss_ctx* c, const int* ids, int n, bool keep_tap
 {
     if (n <= 0) return DSSS_OK;
     const bool doA = phase != 2, doB = phase != 1;
-    int rc = dsss_ensure_store(c); if (rc) return rc;
+    const bool sift = c->op.descriptor == DSSS_DESC_SIFT128;
+    int rc = sift ? dsss_ensure_sift_store(c) : dsss_ensure_store(c); if (rc) return rc;
     std::vector<level_geom*> G(n);
     size_t slot_bytes = 0;
     std::vector<ex_layout> Ls(n);
@@ -1109,7 +1075,7 @@ static int extract_frames_impl(dsss_ctx* c, const int* ids, int n, bool keep_tap
         if (!f.has_geom || !f.has_raw) DSSS_FAIL(c, DSSS_E_STATE, "frame %d has no raw image (dsss_frame_set with raw != NULL first)", ids[i]);
         rc = get_geom(c, f.N, f.M, &G[i]); if (rc) return rc;
         rc = ensure_frame_images(c, f, *G[i]); if (rc) return rc;
-        Ls[i] = make_layout(f.N, *G[i], c->kcap);
+        Ls[i] = make_layout(f.N, *G[i], c->kcap, sift);
         slot_bytes = std::max(slot_bytes, Ls[i].total);
     }
     // slots of one batch share one scratch allocation: bound it (24 GB) instead of the frame count alone
@@ -1189,6 +1155,7 @@ static int extract_frames_impl(dsss_ctx* c, const int* ids, int n, bool keep_tap
             e.kin = (kp_in*)(S + L.kin); e.nk = (int*)(S + L.nk); e.lrows = g.d_lrows; e.lscale = g.d_lscale;
             for (int l = 0; l < DSSS_MAX_LEVELS; ++l) { e.xt[l] = g.d_xt[l]; e.yt[l] = g.d_yt[l]; }
             e.kptmp = (dsss_kp*)(S + L.kptmp); e.dtmp = (uint8_t*)(S + L.dtmp);
+            e.d128tmp = sift ? (uint8_t*)(S + L.d128tmp) : nullptr; e.d128out = sift ? c->desc128 + (size_t)id * c->kcap * 128 : nullptr;
             e.pose6 = f.pose6; e.gr = f.gr;
             e.err = d_errs + s; e.kout = c->kps + (size_t)id * c->kcap; e.dout = c->desc + (size_t)id * c->kcap * 32; e.geo = c->geo + (size_t)id * c->kcap * 2; e.count = c->nkp_dev + id;
             maxN = std::max(maxN, f.N); max_tot = std::max(max_tot, (size_t)f.N * f.M); max_cells = std::max(max_cells, e.ncells); max_levels = std::max(max_levels, g.nlevels);
@@ -1272,7 +1239,8 @@ static int extract_frames_impl(dsss_ctx* c, const int* ids, int n, bool keep_tap
           for (int k = 0; k < 2; ++k) if (qt_used[k]) { HIPCHK(c, hipEventRecord(c->ex_side_ev[k], s_qt[k])); HIPCHK(c, hipStreamWaitEvent(st, c->ex_side_ev[k], 0)); }
           dsss_launch_quadtree_collect(st, d_fr, nb); }
         { dsss_scope sc(c, DSSS_K_DESC, (double)nb * c->op.nfeatures * (49.0 * 49.0 + 56.0));
-          hipLaunchKernelGGL(orient_desc_kernel, dim3((c->kcap + 3) / 4, nb), dim3(256), 0, st, d_exf); }
+          hipLaunchKernelGGL(orient_desc_kernel, dim3((c->kcap + 3) / 4, nb), dim3(256), 0, st, d_exf);
+          if (sift) dsss_launch_sift_desc(c, st, d_exf, c->kcap, nb); }      // N4: the 128-element rows at the same keypoints (dsss_sift.hip)
         HIPCHK(c, hipGetLastError());
         }       // doA
         if (!doB) return DSSS_OK;                    // (phase 1: one batch)
@@ -1286,7 +1254,7 @@ static int extract_frames_impl(dsss_ctx* c, const int* ids, int n, bool keep_tap
         for (int s = 0; s < nb; ++s) {
             dsss_frame& f = c->frames[ids[b0 + s]];
             if (h_err[s]) DSSS_FAIL(c, DSSS_E_CAPACITY, "frame %d: extraction capacity exceeded (code %d; 7 = FAST candidates, else quadtree lists)", ids[b0 + s], h_err[s]);
-            f.nkp = h_nkp[ids[b0 + s]]; f.has_feat = true; f.has_norm = true;
+            f.nkp = h_nkp[ids[b0 + s]]; f.has_feat = true; f.has_norm = true; f.has_sift = sift;
         }
         if (keep_taps) {                             // stage tap for the parity tests: FAST candidates per level
             for (int s = 0; s < nb; ++s) {

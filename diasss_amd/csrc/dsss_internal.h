@@ -15,6 +15,7 @@
 struct dsss_frame {
     int N = 0, M = 0;
     bool has_geom = false, has_raw = false, has_feat = false, has_norm = false;
+    bool has_sift = false;            // the frame's rows of desc128 are valid (extracted with DSSS_DESC_SIFT128 or imported)
     const double* raw = nullptr;      // device; borrowed when the caller passed a device pointer
     double* raw_owned = nullptr;      // device; owned copy of a host image
     const double* raw_host = nullptr; // page-locked host image whose upload is still pending (dsss_extract_many streams it in under the kernels)
@@ -76,6 +77,8 @@ struct dsss_ctx {
     // feature store, device, frame-major with stride kcap
     dsss_kp* kps = nullptr;             // [F][kcap]
     uint8_t* desc = nullptr;            // [F][kcap][32]
+    uint8_t* desc128 = nullptr;         // [F][kcap][128]: the integer-valued floats of DSSS_DESC_SIFT128 kept as bytes; allocated on first use
+    float* sift_w = nullptr;            // Gaussian window table of the SIFT descriptor, exp(-k / 512) (dsss_sift.hip)
     double* geo = nullptr;              // [F][kcap][2]
     int* nkp_dev = nullptr;             // [F]
     int* rows_dev = nullptr;            // [F] pings per frame
@@ -165,6 +168,9 @@ struct dsss_scope {
 
 void dsss_extract_eager(dsss_ctx* c, const int* ids, int n);      // dsss_frames_set: start extracting the frames whose images are in HBM
 int dsss_ensure_store(dsss_ctx* c);                 // allocate the feature store for the current kcap
+int dsss_ensure_sift_store(dsss_ctx* c);            // ... and the 128-byte rows + the window table (DSSS_DESC_SIFT128)
+struct ex_frame;
+void dsss_launch_sift_desc(dsss_ctx* c, hipStream_t st, const ex_frame* d_exf, int kcap, int nb);      // dsss_sift.hip
 int dsss_frame_geo_bbox(dsss_ctx* c, int id);       // device computation of the geo bounding box (asynchronous)
 int dsss_bboxes_enqueue(dsss_ctx* c);               // queue the pending boxes on the context's stream (no synchronisation)
 int dsss_sync_bboxes(dsss_ctx* c);                  // make dsss_frame::bbox valid on the host

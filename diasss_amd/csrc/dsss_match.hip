@@ -13,14 +13,31 @@
 // descriptors (32 B) and geo points (16 B) are staged through LDS in tiles of 256 and read as wave-wide
 // broadcasts (all lanes same address: conflict-free).  Order of b is index order, so "first index wins" ties
 // (FEAmatcher.cpp:152-161) come out exactly as in the scalar loop.
-template <bool L2>
+// MODE 0: Hamming on the 32 ORB bytes; 1: L2 on the same 32 bytes (what the shipped reference feeds its L2 branch); 2: L2 on the 128-element
+// rows of DSSS_DESC_SIFT128 (`desc` is then the 128-byte store).  The elements are integers 0..255, so the squared distance is an exact
+// integer: |a|^2 + |b|^2 - 2 a.b with the dot product on v_dot4_u32_u8 (32 of them per candidate).
+__device__ inline unsigned dot128(const uint4 (&q)[8], const uint4* __restrict__ b)
+{
+    unsigned acc = 0;
+#pragma unroll
+    for (int w = 0; w < 8; ++w) {
+        const uint4 v = b[w];
+        acc = __builtin_amdgcn_udot4(q[w].x, v.x, acc, false); acc = __builtin_amdgcn_udot4(q[w].y, v.y, acc, false);
+        acc = __builtin_amdgcn_udot4(q[w].z, v.z, acc, false); acc = __builtin_amdgcn_udot4(q[w].w, v.w, acc, false);
+    }
+    return acc;
+}
+template <int MODE>
 __global__ __launch_bounds__(MT_TILE) void match_nn_kernel(
     const int* __restrict__ act_s, const int* __restrict__ act_t, const int* __restrict__ nkp,
     const uint8_t* __restrict__ desc, const double* __restrict__ geo, const double* __restrict__ bbox,
     int kcap, double gate_T, int bound_same, int bound_diff, double l2_bound, double ratio_max,
     int32_t* __restrict__ corres_nn)
 {
-    __shared__ uint4 s_lo[MT_TILE], s_hi[MT_TILE];
+    constexpr bool L2 = MODE != 0;
+    constexpr int DW = MODE == 2 ? 8 : 1;          // uint4 per half-descriptor slot
+    __shared__ uint4 s_lo[MT_TILE * DW], s_hi[MODE == 2 ? 1 : MT_TILE];
+    __shared__ unsigned s_n2[MODE == 2 ? MT_TILE : 1];
     __shared__ double2 s_geo[MT_TILE];
     const int pd = blockIdx.y, p = pd >> 1, dir = pd & 1;
     const int fa = dir ? act_t[p] : act_s[p];
@@ -32,21 +49,39 @@ __global__ __launch_bounds__(MT_TILE) void match_nn_kernel(
     const double bx0 = bbox[fb * 4 + 0], bx1 = bbox[fb * 4 + 1], by0 = bbox[fb * 4 + 2], by1 = bbox[fb * 4 + 3];
     double ax = 0, ay = 0;
     uint4 alo = make_uint4(0, 0, 0, 0), ahi = alo;
+    uint4 q[8]; unsigned qn2 = 0;
+#pragma unroll
+    for (int w = 0; w < 8; ++w) q[w] = make_uint4(0, 0, 0, 0);
     bool live = a < na;
     if (live) {
         const double2 g = reinterpret_cast<const double2*>(geo)[(size_t)fa * kcap + a];
         ax = g.x; ay = g.y;
         live = !(ax < bx0 || ay < by0 || ax > bx1 || ay > by1);   // FEAmatcher.cpp:84
-        const uint4* d = reinterpret_cast<const uint4*>(desc + ((size_t)fa * kcap + a) * 32);
-        alo = d[0]; ahi = d[1];
+        if (MODE == 2) {
+            const uint4* d = reinterpret_cast<const uint4*>(desc + ((size_t)fa * kcap + a) * 128);
+#pragma unroll
+            for (int w = 0; w < 8; ++w) q[w] = d[w];
+            qn2 = dot128(q, d);
+        } else {
+            const uint4* d = reinterpret_cast<const uint4*>(desc + ((size_t)fa * kcap + a) * 32);
+            alo = d[0]; ahi = d[1];
+        }
     }
     if (!__syncthreads_or(live)) { if (a < na) out[a] = -1; return; }
     int best = L2 ? 1000000 : 1000, second = best, best_id = -1, nc = 0;
-    const uint4* bdesc = reinterpret_cast<const uint4*>(desc + (size_t)fb * kcap * 32);
+    const uint4* bdesc = reinterpret_cast<const uint4*>(desc + (size_t)fb * kcap * (MODE == 2 ? 128 : 32));
     const double2* bgeo = reinterpret_cast<const double2*>(geo) + (size_t)fb * kcap;
     for (int b0 = 0; b0 < nb; b0 += MT_TILE) {
         const int bj = b0 + threadIdx.x;
-        if (bj < nb) { s_lo[threadIdx.x] = bdesc[2 * bj]; s_hi[threadIdx.x] = bdesc[2 * bj + 1]; s_geo[threadIdx.x] = bgeo[bj]; }
+        if (bj < nb) {
+            if (MODE == 2) {
+                uint4 t[8];
+#pragma unroll
+                for (int w = 0; w < 8; ++w) { t[w] = bdesc[8 * bj + w]; s_lo[threadIdx.x * 8 + w] = t[w]; }
+                s_n2[threadIdx.x] = dot128(t, bdesc + 8 * bj);
+            } else { s_lo[threadIdx.x] = bdesc[2 * bj]; s_hi[threadIdx.x] = bdesc[2 * bj + 1]; }
+            s_geo[threadIdx.x] = bgeo[bj];
+        }
         __syncthreads();
         const int cnt = min(MT_TILE, nb - b0);
         if (live) {
@@ -55,8 +90,11 @@ __global__ __launch_bounds__(MT_TILE) void match_nn_kernel(
                 const double dx = ax - g.x, dy = ay - g.y;
                 const double d2 = dx * dx + dy * dy;
                 if (d2 < gate_T) {                               // sqrt(d2) < radius, FEAmatcher.cpp:92-93
-                    const uint4 lo = s_lo[j], hi = s_hi[j];
                     int d;
+                    if (MODE == 2) {
+                        d = (int)(qn2 + s_n2[j] - 2u * dot128(q, s_lo + 8 * j));
+                    } else {
+                    const uint4 lo = s_lo[j], hi = s_hi[j];
                     if (!L2) {
                         d = __popc(alo.x ^ lo.x) + __popc(alo.y ^ lo.y) + __popc(alo.z ^ lo.z) + __popc(alo.w ^ lo.w)
                           + __popc(ahi.x ^ hi.x) + __popc(ahi.y ^ hi.y) + __popc(ahi.z ^ hi.z) + __popc(ahi.w ^ hi.w);
@@ -71,6 +109,7 @@ __global__ __launch_bounds__(MT_TILE) void match_nn_kernel(
                                 const int e = (int)((wa[w] >> (8 * k)) & 255u) - (int)((wb[w] >> (8 * k)) & 255u);
                                 d += e * e;
                             }
+                    }
                     }
                     ++nc;
                     if (d < best) { second = best; best = d; best_id = b0 + j; }
@@ -177,13 +216,14 @@ __global__ __launch_bounds__(MTG_THREADS) void mt_grid_build_kernel(
 #ifndef MT_SUB
 #define MT_SUB 2                 // cells per radius: a query walks (2 MT_SUB + 1)^2 cells, 25 cells of 4 m = 400 m^2 against 9 of 8 m = 576 m^2 (the circle: 201 m^2)
 #endif
-template <bool L2>
+template <int MODE>          // as match_nn_kernel; MODE 2 reads the 128-byte rows of the feature store through the sorted index (s_desc = the store)
 __global__ __launch_bounds__(MT_TILE) void match_grid_kernel(
     const int* __restrict__ act_s, const int* __restrict__ act_t, const int* __restrict__ nkp, const double* __restrict__ bbox,
     const mt_grid* __restrict__ tab, const int* __restrict__ start_all, const double2* __restrict__ s_geo, const uint4* __restrict__ s_desc,
     const int* __restrict__ s_idx, int kcap, double inv_cs, double gate_T, int bound_same, int bound_diff, double l2_bound, double ratio_max,
     int32_t* __restrict__ corres_nn)
 {
+    constexpr bool L2 = MODE != 0;
     const int pd = blockIdx.y, p = pd >> 1, dir = pd & 1;
     const int fa = dir ? act_t[p] : act_s[p];
     const int fb = dir ? act_s[p] : act_t[p];
@@ -197,7 +237,14 @@ __global__ __launch_bounds__(MT_TILE) void match_grid_kernel(
     const double bx0 = bbox[fb * 4 + 0], bx1 = bbox[fb * 4 + 1], by0 = bbox[fb * 4 + 2], by1 = bbox[fb * 4 + 3];
     const double ax = ga.x, ay = ga.y;
     if (ax < bx0 || ay < by0 || ax > bx1 || ay > by1) { if (sub == 0) out[a] = -1; return; }      // FEAmatcher.cpp:84
-    const uint4 alo = s_desc[2 * sa], ahi = s_desc[2 * sa + 1];
+    uint4 alo = make_uint4(0, 0, 0, 0), ahi = alo;
+    uint4 q[8]; unsigned qn2 = 0;
+    if (MODE == 2) {
+        const uint4* d = s_desc + ((size_t)fa * kcap + a) * 8;
+#pragma unroll
+        for (int w = 0; w < 8; ++w) q[w] = d[w];
+        qn2 = dot128(q, d);
+    } else { alo = s_desc[2 * sa]; ahi = s_desc[2 * sa + 1]; }
     const mt_grid T = tab[fb];
     const int* __restrict__ start = start_all + T.off;
     const int cx = mt_cell(ax, bx0, inv_cs, T.W), cy = mt_cell(ay, by0, inv_cs, T.H);
@@ -218,9 +265,16 @@ __global__ __launch_bounds__(MT_TILE) void match_grid_kernel(
             const double dx = ax - g.x, dy = ay - g.y;
             const double d2 = dx * dx + dy * dy;
             if (d2 < gate_T) {                                   // sqrt(d2) < radius, FEAmatcher.cpp:92-93
-                const uint4 lo = s_desc[2 * (sb + j)], hi = s_desc[2 * (sb + j) + 1];
                 const int id = s_idx[sb + j];
                 int d;
+                if (MODE == 2) {
+                    const uint4* bd = s_desc + (sb + id) * 8;
+                    uint4 t[8];
+#pragma unroll
+                    for (int w = 0; w < 8; ++w) t[w] = bd[w];
+                    d = (int)(qn2 + dot128(t, bd) - 2u * dot128(q, bd));
+                } else {
+                const uint4 lo = s_desc[2 * (sb + j)], hi = s_desc[2 * (sb + j) + 1];
                 if (!L2) {
                     d = __popc(alo.x ^ lo.x) + __popc(alo.y ^ lo.y) + __popc(alo.z ^ lo.z) + __popc(alo.w ^ lo.w)
                       + __popc(ahi.x ^ hi.x) + __popc(ahi.y ^ hi.y) + __popc(ahi.z ^ hi.z) + __popc(ahi.w ^ hi.w);
@@ -235,6 +289,7 @@ __global__ __launch_bounds__(MT_TILE) void match_grid_kernel(
                             const int e = (int)((wa[w] >> (8 * k)) & 255u) - (int)((wb[w] >> (8 * k)) & 255u);
                             d += e * e;
                         }
+                }
                 }
                 ++nc;
                 // the scalar loop's "first index wins" (FEAmatcher.cpp:152-161) without its order: the two smallest distances of the
@@ -555,6 +610,7 @@ int dsss_match_pairs(dsss_ctx* c, const int* src_ids, const int* tgt_ids, int np
         if (s < 0 || s >= c->max_frames || t < 0 || t >= c->max_frames || s == t) DSSS_FAIL(c, DSSS_E_ARG, "pair %d: bad frame ids (%d,%d)", p, s, t);
         const dsss_frame &a = c->frames[s], &b = c->frames[t];
         if (!a.has_feat || !b.has_feat) DSSS_FAIL(c, DSSS_E_STATE, "pair %d: frames %d/%d have no features", p, s, t);
+        if (c->mt.use_l2 == 2 && (!a.has_sift || !b.has_sift)) DSSS_FAIL(c, DSSS_E_STATE, "pair %d: use_l2 = 2 needs the 128-element rows of frames %d/%d (dsss_orb_params.descriptor = DSSS_DESC_SIFT128)", p, s, t);
         // a keypoint outside the other frame's geo box is skipped (FEAmatcher.cpp:84), so disjoint boxes match nothing
         const bool disjoint = a.bbox[1] < b.bbox[0] || b.bbox[1] < a.bbox[0] || a.bbox[3] < b.bbox[2] || b.bbox[3] < a.bbox[2];
         if (!disjoint && a.nkp > 0 && b.nkp > 0) { c->pair_active[p] = (int)as.size(); as.push_back(s); at.push_back(t); }
@@ -661,12 +717,16 @@ int dsss_match_pairs(dsss_ctx* c, const int* src_ids, const int* tgt_ids, int np
         const dim3 ggrid((max_nkp + MT_TILE / MT_LPQ - 1) / (MT_TILE / MT_LPQ), 2 * na);
         hipLaunchKernelGGL(mt_grid_build_kernel, dim3((unsigned)gframes.size()), dim3(MTG_THREADS), 0, c->stream, d_frames, d_tab, c->nkp_dev, c->desc, c->geo,
                            c->bbox_dev, (int)K, inv_cs, d_start, d_cur, (double2*)c->mt_gs_geo, (uint4*)c->mt_gs_desc, c->mt_gs_idx);
-        if (c->mt.use_l2)
-            hipLaunchKernelGGL(match_grid_kernel<true>, ggrid, dim3(MT_TILE), 0, c->stream, c->act_s, c->act_t, c->nkp_dev, c->bbox_dev, d_tab, d_start,
+        if (c->mt.use_l2 == 2)
+            hipLaunchKernelGGL(match_grid_kernel<2>, ggrid, dim3(MT_TILE), 0, c->stream, c->act_s, c->act_t, c->nkp_dev, c->bbox_dev, d_tab, d_start,
+                               (const double2*)c->mt_gs_geo, (const uint4*)c->desc128, c->mt_gs_idx, (int)K, inv_cs, T, c->mt.bound_same, c->mt.bound_diff,
+                               c->mt.l2_bound, c->mt.ratio, c->corres_nn);
+        else if (c->mt.use_l2)
+            hipLaunchKernelGGL(match_grid_kernel<1>, ggrid, dim3(MT_TILE), 0, c->stream, c->act_s, c->act_t, c->nkp_dev, c->bbox_dev, d_tab, d_start,
                                (const double2*)c->mt_gs_geo, (const uint4*)c->mt_gs_desc, c->mt_gs_idx, (int)K, inv_cs, T, c->mt.bound_same, c->mt.bound_diff,
                                c->mt.l2_bound, c->mt.ratio, c->corres_nn);
         else
-            hipLaunchKernelGGL(match_grid_kernel<false>, ggrid, dim3(MT_TILE), 0, c->stream, c->act_s, c->act_t, c->nkp_dev, c->bbox_dev, d_tab, d_start,
+            hipLaunchKernelGGL(match_grid_kernel<0>, ggrid, dim3(MT_TILE), 0, c->stream, c->act_s, c->act_t, c->nkp_dev, c->bbox_dev, d_tab, d_start,
                                (const double2*)c->mt_gs_geo, (const uint4*)c->mt_gs_desc, c->mt_gs_idx, (int)K, inv_cs, T, c->mt.bound_same, c->mt.bound_diff,
                                c->mt.l2_bound, c->mt.ratio, c->corres_nn);
         HIPCHK(c, hipGetLastError());
@@ -680,11 +740,14 @@ int dsss_match_pairs(dsss_ctx* c, const int* src_ids, const int* tgt_ids, int np
         for (int a2 = 0; a2 < na; ++a2) evals += 2.0 * c->frames[as[a2]].nkp * c->frames[at[a2]].nkp;
         dsss_scope sc(c, DSSS_K_MATCH, evals);
         if (c->prof.on) c->prof.work[DSSS_K_MATCH_DONE] += evals;      // the all-pairs kernel performs every evaluation it is credited with
-        if (c->mt.use_l2)
-            hipLaunchKernelGGL(match_nn_kernel<true>, grid, dim3(MT_TILE), 0, c->stream, c->act_s, c->act_t, c->nkp_dev, c->desc, c->geo,
+        if (c->mt.use_l2 == 2)
+            hipLaunchKernelGGL(match_nn_kernel<2>, grid, dim3(MT_TILE), 0, c->stream, c->act_s, c->act_t, c->nkp_dev, c->desc128, c->geo,
+                               c->bbox_dev, (int)K, T, c->mt.bound_same, c->mt.bound_diff, c->mt.l2_bound, c->mt.ratio, c->corres_nn);
+        else if (c->mt.use_l2)
+            hipLaunchKernelGGL(match_nn_kernel<1>, grid, dim3(MT_TILE), 0, c->stream, c->act_s, c->act_t, c->nkp_dev, c->desc, c->geo,
                                c->bbox_dev, (int)K, T, c->mt.bound_same, c->mt.bound_diff, c->mt.l2_bound, c->mt.ratio, c->corres_nn);
         else
-            hipLaunchKernelGGL(match_nn_kernel<false>, grid, dim3(MT_TILE), 0, c->stream, c->act_s, c->act_t, c->nkp_dev, c->desc, c->geo,
+            hipLaunchKernelGGL(match_nn_kernel<0>, grid, dim3(MT_TILE), 0, c->stream, c->act_s, c->act_t, c->nkp_dev, c->desc, c->geo,
                                c->bbox_dev, (int)K, T, c->mt.bound_same, c->mt.bound_diff, c->mt.l2_bound, c->mt.ratio, c->corres_nn);
         HIPCHK(c, hipGetLastError());
     }

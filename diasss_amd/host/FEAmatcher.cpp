@@ -8,6 +8,15 @@
 namespace Diasss
 {
 
+int FEAmatcher::USE_SIFT = 0;
+
+static void apply_mode(dsss_ctx* c)
+{
+    dsss_match_params mt; dsss_match_params_default(&mt);
+    mt.use_l2 = FEAmatcher::USE_SIFT;
+    Device::check(dsss_set_params(c, nullptr, nullptr, &mt, nullptr), "dsss_set_params");
+}
+
 static void append_rows(Frame &S, Frame &T, const std::vector<double> &rows, int n)
 {
     for (int i = 0; i < n; ++i) {
@@ -26,6 +35,7 @@ void FEAmatcher::RobustMatchingAll(std::vector<Frame> &Frames, const std::vector
     dsss_ctx* c = Device::ctx();
     std::vector<int> s, t;
     for (auto &p : Pairs) { s.push_back(Frames[p.first].img_id); t.push_back(Frames[p.second].img_id); }
+    apply_mode(c);
     Device::check(dsss_match_pairs(c, s.data(), t.data(), (int)Pairs.size()), "dsss_match_pairs");
     for (size_t p = 0; p < Pairs.size(); ++p) {
         int n = 0;
@@ -41,6 +51,7 @@ void FEAmatcher::RobustMatching(Frame &SourceFrame, Frame &TargetFrame)
 {
     dsss_ctx* c = Device::ctx();
     const int s = SourceFrame.img_id, t = TargetFrame.img_id;
+    apply_mode(c);
     Device::check(dsss_match_pairs(c, &s, &t, 1), "dsss_match_pairs");
     int n = 0;
     Device::check(dsss_match_get_rows(c, 0, nullptr, 0, &n), "dsss_match_get_rows");
@@ -57,6 +68,7 @@ std::vector<int> FEAmatcher::GeoNearNeighSearch(const int &img_id, const int &im
 {
     dsss_ctx* c = Device::ctx();
     const int s = img_id, t = img_id_ref;
+    apply_mode(c);
     Device::check(dsss_match_pairs(c, &s, &t, 1), "dsss_match_pairs");
     std::vector<int> CorresID(kps.size(), -1);
     int hist = 0, count = 0; double model = 0;

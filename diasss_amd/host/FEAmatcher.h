@@ -35,6 +35,11 @@ namespace Diasss
                                     std::vector<std::pair<int,double>> &scc_1, std::vector<std::pair<int,double>> &scc_2,
                                     std::vector<cv::KeyPoint> &SourceKeys, std::vector<cv::KeyPoint> &TargetKeys);
 
+        // FEAmatcher.cpp:63 hard-codes USE_SIFT = 1 (the L2 branch :106-139 on whatever Frame::dst holds).  0 (default): the Hamming branch
+        // on the ORB rows; 1: the L2 branch on the 32 ORB bytes (the shipped behaviour, minus the uninitialised memory); 2: the L2 branch on
+        // the 128-float rows (needs Frame::USE_SIFT).  Applied to the device context by every matching call.
+        static int USE_SIFT;
+
         // FEAmatcher.h:33 on descriptor rows (host utility; the device matcher uses v_bcnt)
         static int DescriptorDistance(const cv::Mat &a, const cv::Mat &b);
     };

@@ -12,6 +12,7 @@
 
 #define CV_8U 0
 #define CV_32S 4
+#define CV_32F 5
 #define CV_64F 6
 
 namespace cv {
@@ -34,7 +35,7 @@ public:
     void create(int r, int c, int type) { rows = r; cols = c; type_ = type; buf_ = std::make_shared<std::vector<uint8_t>>((size_t)r * c * esz()); }
     int type() const { return type_; }
     bool empty() const { return rows == 0 || cols == 0; }
-    size_t esz() const { return type_ == CV_8U ? 1 : (type_ == CV_32S ? 4 : 8); }
+    size_t esz() const { return type_ == CV_8U ? 1 : ((type_ == CV_32S || type_ == CV_32F) ? 4 : 8); }
     size_t bytes() const { return (size_t)rows * cols * esz(); }
     uint8_t* data() { return buf_ ? buf_->data() : nullptr; }
     const uint8_t* data() const { return buf_ ? buf_->data() : nullptr; }

@@ -5,6 +5,8 @@
 namespace Diasss
 {
 
+bool Frame::USE_SIFT = false;
+
 Frame::Frame(const int &id, const cv::Mat &mImg, const cv::Mat &mPose, const std::vector<double> &vAltt,
              const std::vector<double> &vGrange, const cv::Mat &mAnno)
 {
@@ -21,10 +23,19 @@ void Frame::DetectFeature(const cv::Mat &, const cv::Mat &, std::vector<cv::KeyP
 {
     dsss_ctx* c = Device::ctx();
     int n = 0;
+    dsss_orb_params op; dsss_orb_params_default(&op);                            // frame.cpp:180: ORBextractor(2000, 1.2, 6, 12, 7)
+    op.descriptor = USE_SIFT ? DSSS_DESC_SIFT128 : DSSS_DESC_ORB;
+    Device::check(dsss_set_params(c, nullptr, &op, nullptr, nullptr), "dsss_set_params");
     Device::check(dsss_extract(c, img_id, &n), "dsss_extract");
     std::vector<dsss_kp> k(n > 0 ? n : 1);
-    out_dst = cv::Mat(n, 32, CV_8U);
-    Device::check(dsss_features_get(c, img_id, k.data(), n ? out_dst.data() : nullptr, nullptr, n, &n), "dsss_features_get");
+    if (USE_SIFT) {
+        out_dst = cv::Mat(n, 128, CV_32F);
+        Device::check(dsss_features_get(c, img_id, k.data(), nullptr, nullptr, n, &n), "dsss_features_get");
+        Device::check(dsss_features_get_sift(c, img_id, n ? out_dst.ptr<float>() : nullptr, n, &n), "dsss_features_get_sift");
+    } else {
+        out_dst = cv::Mat(n, 32, CV_8U);
+        Device::check(dsss_features_get(c, img_id, k.data(), n ? out_dst.data() : nullptr, nullptr, n, &n), "dsss_features_get");
+    }
     out_kps.clear();
     for (int i = 0; i < n; ++i) out_kps.push_back(cv::KeyPoint(k[i].x, k[i].y, k[i].size, k[i].angle, k[i].response, k[i].octave));
 }

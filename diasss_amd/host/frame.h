@@ -41,7 +41,12 @@ namespace Diasss
         std::vector<cv::Mat> geo_img;  // COMPACT: two 1x2 CV_64F mats [min,max] of x and y -- every consumer of the full
                                        // N x M geo image in the reference only takes its extremes or samples it at keypoints
         std::vector<cv::KeyPoint> kps;
-        cv::Mat dst;                   // K x 32 CV_8U
+        cv::Mat dst;                   // K x 32 CV_8U (ORB rows), or K x 128 CV_32F when Frame::USE_SIFT: what the SIFT call site of
+                                       // ORBextractor.cpp:1098 was meant to leave here
+
+        // The reference hard-codes its descriptor: the live call is the SIFT one (ORBextractor.cpp:1097-1098), whose output is lost.
+        // false (default): the ORB configuration; true: ORB keypoints + the 128-float rows (DSSS_DESC_SIFT128).  Set before constructing frames.
+        static bool USE_SIFT;
         cv::Mat corres_kps;            // rows: frame_id, ref_frame_id, kp_y, kp_x, kp_ref_y, kp_ref_x (CV_64F)
         cv::Mat est_poses;
 

@@ -1,6 +1,6 @@
 // diasss_amd/host/test_demo.cpp -- the driver loop of /root/reference/src/diasss2.cpp:83-101 against the drop-in
 // classes.  Two input forms:
-//   test_demo --image DIR --pose DIR --altitude DIR --groundrange DIR [--annotation DIR] [--min-overlap X] [--use-anno 0|1] [--add-lc 0|1] [--eval 0..3]
+//   test_demo --image DIR --pose DIR --altitude DIR --groundrange DIR [--annotation DIR] [--min-overlap X] [--descriptor orb|orb-l2|sift] [--use-anno 0|1] [--add-lc 0|1] [--eval 0..3]
 //       the reference's own layout (diasss2.cpp:33-66) through Util::LoadInputData: OpenCV FileStorage XML / YAML + txt
 //   test_demo <dir with frame_%03d.bin> [min_overlap]
 //       flat binary dumps written by tools/export_survey.py:
@@ -27,6 +27,7 @@ int main(int argc, char** argv)
             const std::string k = argv[a], v = argv[a + 1];
             if (k == "--image") dI = v; else if (k == "--pose") dP = v; else if (k == "--altitude") dA = v;
             else if (k == "--groundrange") dG = v; else if (k == "--annotation") dN = v; else if (k == "--min-overlap") MIN_OVERLAP = (float)atof(v.c_str());
+            else if (k == "--descriptor") { const bool sift = v == "sift"; Frame::USE_SIFT = sift; FEAmatcher::USE_SIFT = sift ? 2 : (v == "orb-l2" ? 1 : 0); }      // orb (default) | orb-l2 (the shipped matcher branch on the ORB bytes) | sift (N4: 128-float rows + L2)
             else if (k == "--use-anno") Optimizer::USE_ANNO = atoi(v.c_str()) != 0;      // optimizer.cpp:26 hard-codes 1 (hand annotations); default here 0
             else if (k == "--add-lc") Optimizer::ADD_LC = atoi(v.c_str()) != 0;
             else if (k == "--online") Optimizer::ONLINE = atoi(v.c_str()) != 0;      // frame-by-frame updates as the reference's iSAM2 loop does (default: one batch solve)

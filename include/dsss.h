@@ -43,10 +43,17 @@ typedef struct { float x, y, size, angle, response; int32_t octave; } dsss_kp;
 typedef struct {                 /* frame.cpp:59,85-86 */
     double factor;  int32_t width, r, side;
 } dsss_mask_params;
+#define DSSS_DESC_ORB      0      /* rotated BRIEF, 256 bits (ORBextractor.cpp:1034-1041,1097: the configuration north_star names) */
+#define DSSS_DESC_SIFT128  1      /* ... AND the 128-float descriptor of the live SIFT call site (ORBextractor.cpp:1043-1047,1098) as its
+                                     author evidently meant it: 4 x 4 x 8 gradient-orientation histogram on the blurred level image the
+                                     keypoint was found on, at its IC angle (definition: oracle/orc_sift.c)            */
 typedef struct {                 /* frame.cpp:180: ORBextractor(2000, 1.2, 6, 12, 7) */
     int32_t nfeatures; float scale; int32_t nlevels, ini_th, min_th;
+    int32_t descriptor;          /* DSSS_DESC_* (default DSSS_DESC_ORB) */
 } dsss_orb_params;
 typedef struct {                 /* FEAmatcher.cpp:63-66,108-110,143-147,189-190,329 */
+    /* use_l2: 0 = the Hamming branch (:141-176) on the ORB rows; 1 = the L2 branch (:106-139, USE_SIFT) on the 32 ORB bytes the shipped
+     * reference feeds it; 2 = the L2 branch on the 128-float rows of DSSS_DESC_SIFT128 (needs features extracted in that mode) */
     int32_t use_l2; double radius; int32_t bound_same, bound_diff; double l2_bound, ratio;
     int32_t scc_iters; double pix_err, merge_thr;
 } dsss_match_params;
@@ -139,6 +146,11 @@ int dsss_host_quadtree(const float* x_host, const float* y_host, const float* re
                        int minX, int maxX, int minY, int maxY, int quota, int32_t* keep_idx_host, int* n_keep);
 /* Frame::kps / Frame::dst (+ the geo_img samples FEAmatcher.cpp:81-82 reads) */
 int dsss_features_get(dsss_ctx*, int id, dsss_kp* kps_host, uint8_t* desc_host, double* geo_host, int cap, int* n);
+/* Frame::dst as the SIFT call site would fill it (N x 128 CV_32F, integer-valued 0..255): the rows of DSSS_DESC_SIFT128, in the order of
+ * dsss_features_get.  DSSS_E_STATE when the frame was extracted without them.  dsss_features_set_sift imports such rows for a frame whose
+ * other features were given with dsss_features_set (values are rounded and clamped to 0..255: the device keeps them as bytes).          */
+int dsss_features_get_sift(dsss_ctx*, int id, float* desc128_host, int cap, int* n);
+int dsss_features_set_sift(dsss_ctx*, int id, const float* desc128_host, int n);
 /* import features computed elsewhere (another rank's all-gather, or a test); geo/bbox may be NULL when the
  * frame geometry was given with dsss_frame_set (they are then recomputed on the device)                     */
 int dsss_features_set(dsss_ctx*, int id, int N, int M, const dsss_kp* kps, const uint8_t* desc,
