@@ -79,14 +79,17 @@ def cpu_baseline(sv, wl, n_frames, threads=1):
     lcs_all = np.concatenate([r[1] for r in res]) if res else np.zeros(0, O.LC_DTYPE)
     edges = O.pg_select_lc([N] * n_frames, [p[0] for p in pairs], [p[1] for p in pairs], pair_off, kp7_all, lcs_all)
     dr = np.concatenate([f["pose"] for f in fr])
-    o_poses, _ = O.pg_solve(dr, edges)
+    t3 = time.time()
+    o_poses, _ = O.pg_solve(dr, edges, solver="sparse")          # the oracle's LM with its reduced system through a sparse LU (round 6: the envelope Cholesky it
+    t_pg = time.time() - t3                                      # used before took 4.5 of this leg's 4.8 s -- GTSAM's sparse solvers would not)
     t_rest = time.time() - t2
     if pool:
         pool.shutdown()
     t_cpu = t_extract + t_rest
     return dict(value=n_frames / t_cpu, unit="frames/s", cores=threads, kind="port",
                 sample="oracle (C restatement of the reference, -O3, %d thread%s) on %d of %d frames of %dx%d: extraction %.1fs, "
-                       "all %d pairs + LC + pose graph %.1fs" % (threads, "" if threads == 1 else "s", n_frames, wl["F"], N, M, t_extract, len(pairs), t_rest)), o_poses, len(edges)
+                       "all %d pairs + LC + pose graph %.1fs (pose graph %.1fs%s)" % (threads, "" if threads == 1 else "s", n_frames, wl["F"], N, M, t_extract, len(pairs), t_rest, t_pg,
+                                                                                  ", on ONE core whatever the thread count: the threads speed up extraction and matching only" if threads > 1 else "")), o_poses, len(edges)
 
 
 def sample_parity(sv, n_frames, o_poses, o_edges, device, nfeatures=None):
@@ -268,13 +271,18 @@ def main():
         torch.cuda.synchronize()
         pipe.ctx.sync()
 
+    # the argument arrays of dsss_frames_set (ids, sizes, four arrays of per-frame pointers) are built ONCE, before the clock: a C++ caller of
+    # the C ABI holds them as plain arrays; building them from Python lists is the harness's cost, not the path's.  Every C-ABI call of a step
+    # (dsss_frames_set: geometry staging + upload + start of the extraction, dsss_extract_many, dsss_match_pairs, dsss_lc_solve_all,
+    # dsss_posegraph_solve) runs inside the timed region, on every step.
+    survey = pipe.prepare(raws, poses, alts, grs)
     stats = None
     for _ in range(args.warmup):
-        _, stats = pipe.run(raws, poses, alts, grs)
+        _, stats = pipe.run(survey)
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        _, stats = pipe.run(raws, poses, alts, grs)
+        _, stats = pipe.run(survey)
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
@@ -326,6 +334,10 @@ def main():
             tr = pmc_traffic(args.workload).get("match_nn_kernel<false>")
             match_allpairs = {"kernel": "match_nn_kernel<false> (DSSS_MT_GRID=0)", "ms": pm["match"][0], "launches": pm["match"][1],
                               "evaluations": evals, "evaluations_per_s_G": evals / sec / 1e9, "peak_G": MATCH_PEAK_GEVALS, "frac": evals / sec / 1e9 / MATCH_PEAK_GEVALS,
+                              # SURVEY K9's ceiling taken literally (256 CU x 64 lanes x 2.4 GHz / 30 operations): the kernel spends ~13.4 lane-instructions per
+                              # evaluation, not 30, so it reads above 1 -- "30 operations per comparison" is an estimate, not a hardware bound; the honest figure is the
+                              # issue utilisation of roofline_all_kernels (match_nn_kernel: ~0.6 of the measured full-rate issue slots)
+                              "peak_G_survey_literal": 256 * 64 * 2.4e9 / 30.0 / 1e9, "frac_survey_literal": evals / sec / 1e9 / (256 * 64 * 2.4e9 / 30.0 / 1e9),
                               "algorithmic_bytes": alg_bytes, "algorithmic_GBs": alg_bytes / sec / 1e9,
                               "hbm_GBs": (tr[0] * pm["match"][1] / sec / 1e9) if tr else None,
                               "note": "every keypoint of a against every keypoint of b over the active pairs (gate in f64, then the 256-bit Hamming distance), descriptor tiles staged in LDS; "
@@ -433,6 +445,7 @@ def main():
             "config": {"workload": wl["name"], "frames": F, "pings": N, "bins": M, "pairs": F * (F - 1) // 2, "active_pairs": active_pairs,
                        "active_pairs_note": "pairs whose geo bounding boxes intersect; the others are provably empty (FEAmatcher.cpp:84) and skipped",
                        "input": "raw float64 frames resident in HBM before the timed region (PCIe-inclusive figure: pcie_inclusive)",
+                       "harness": "the argument arrays of dsss_frames_set (ids, sizes, per-frame pointers) are built once before the clock, as a C++ caller holds them; every C-ABI call of a step is timed, on every step; no result or analysis is carried between steps",
                        "pairs_per_rank": pairs_per_rank, "active_pairs_per_rank": active_per_rank, "kp_per_frame": int(np.mean(nkp)) if nkp else 0, "matches_rank0": tot_rows, "lc_problems_rank0": tot_kp7,
                        "pg_stats": [float(s) for s in stats] if stats is not None else None,
                        "parallelism": "contiguous frame blocks over %d rank(s): RCCL all-gather of features, pairs to the owner of the target frame, pose graph sharded with one RCCL all-reduce of the reduced Hessian per LM trial" % world},

@@ -52,6 +52,41 @@ class DsssError(RuntimeError):
     pass
 
 
+class FramesArgs:
+    """argument arrays of dsss_frames_set (see Context.frames_args)"""
+
+    def __init__(self, ids, raws, Ns, Ms, poses, alts, grs):
+        n = self.n = len(ids)
+        if not (len(raws) == len(Ns) == len(Ms) == len(poses) == len(alts) == len(grs) == n):
+            raise ValueError("frames_set: the per-frame lists differ in length")
+        _torch = sys.modules.get("torch")                      # (only a caller that has torch can hand tensors over)
+
+        def addr(a, what, shape=None):
+            if a is None:
+                return 0
+            if isinstance(a, np.ndarray):
+                if a.dtype != np.float64 or not a.flags.c_contiguous:
+                    raise TypeError("frames_set: %s must be a C-contiguous float64 array" % what)
+                if shape is not None and a.shape != shape:
+                    raise ValueError("frames_set: %s has shape %s, expected %s" % (what, a.shape, shape))
+                return a.__array_interface__["data"][0]
+            if _torch is not None and isinstance(a, _torch.Tensor):
+                if a.dtype != _torch.float64 or not a.is_contiguous():
+                    raise TypeError("frames_set: %s must be a contiguous float64 tensor" % what)
+                if shape is not None and tuple(a.shape) != shape:
+                    raise ValueError("frames_set: %s has shape %s, expected %s" % (what, tuple(a.shape), shape))
+                return a.data_ptr()                            # host (pinned or pageable) or device: the library asks the runtime which
+            raise TypeError("frames_set: %s must be None, a numpy array or a torch tensor" % what)
+        self.ids = np.ascontiguousarray(ids, np.int32); self.N = np.ascontiguousarray(Ns, np.int32); self.M = np.ascontiguousarray(Ms, np.int32)
+        self.p_raw = np.fromiter((addr(a, "raw[%d]" % i, (int(self.N[i]), int(self.M[i]))) for i, a in enumerate(raws)), np.uintp, n)
+        self.p_pose = np.fromiter((addr(a, "pose[%d]" % i, (int(self.N[i]), 6)) for i, a in enumerate(poses)), np.uintp, n)
+        self.p_alt = np.fromiter((addr(a, "alt[%d]" % i, (int(self.N[i]),)) for i, a in enumerate(alts)), np.uintp, n)
+        self.p_gr = np.fromiter((addr(a, "grange[%d]" % i, (int(self.M[i]) // 2,)) for i, a in enumerate(grs)), np.uintp, n)
+        if (self.p_pose == 0).any() or (self.p_alt == 0).any() or (self.p_gr == 0).any():
+            raise ValueError("frames_set: pose, altitude and ground range are required for every frame")
+        self.keep = dict(zip(map(int, ids), zip(raws, poses, alts, grs)))      # the arrays stay alive as long as this object (or the Context) does
+
+
 def build(force=False):
     """compile libdsss.so for gfx950 with hipcc (cross-compiles without a GPU)"""
     src = os.path.join(_HERE, "csrc")
@@ -135,7 +170,7 @@ class Context:
         if getattr(self, "h", None):
             self.L.dsss_destroy(self.h)
             self.h = None
-        for k in ("_keep", "_addr_cache", "_addr_alive", "_pinned"):      # nothing of the caller's stays referenced by a closed context
+        for k in ("_keep", "_pinned"):      # nothing of the caller's stays referenced by a closed context
             self.__dict__.pop(k, None)
 
     def __del__(self):
@@ -231,52 +266,18 @@ class Context:
         self._keep = getattr(self, "_keep", {}); self._keep[fid] = raw      # keep device tensors alive
         self._chk(self.L.dsss_frame_set(self.h, fid, _ptr(raw), N, M, _ptr(pose6), _ptr(alt), _ptr(gr)), "dsss_frame_set")
 
-    def frames_set(self, ids, raws, Ns, Ms, poses, alts, grs):
-        """dsss_frames_set: one call for many frames (host arrays must be float64 C-contiguous; raws may hold None or
-        device tensors)"""
-        n = len(ids)
-        _torch = sys.modules.get("torch")                      # (only a caller that has torch can hand tensors over)
+    def frames_args(self, ids, raws, Ns, Ms, poses, alts, grs):
+        """The ARGUMENT ARRAYS of dsss_frames_set (ids, sizes, four arrays of per-frame pointers) built and validated once: what a C++
+        caller of the C ABI simply holds.  Host arrays must be float64 and C-contiguous, raws may hold None, host arrays or CUDA tensors
+        (float64, contiguous).  The object keeps every array alive; frames_set(args) is then the bare C call."""
+        return FramesArgs(ids, raws, Ns, Ms, poses, alts, grs)
+
+    def frames_set(self, ids, raws=None, Ns=None, Ms=None, poses=None, alts=None, grs=None):
+        """dsss_frames_set: one call for many frames.  Either the seven per-frame lists, or one FramesArgs built by frames_args()."""
+        a = ids if isinstance(ids, FramesArgs) else FramesArgs(ids, raws, Ns, Ms, poses, alts, grs)
         self._keep = getattr(self, "_keep", {})
-        cache = self.__dict__.setdefault("_addr_cache", {})    # id(array) -> address of the host geometry arrays; _addr_alive keeps every cached array alive, so
-        alive = self.__dict__.setdefault("_addr_alive", [])    # an id cannot be reused while its entry exists.  A survey re-submits the same arrays every step,
-                                                                # and 600 dtype / contiguity checks + look-ups per call cost a millisecond
-
-        def addr(a):
-            if a is None:
-                return 0
-            if not isinstance(a, np.ndarray):
-                if hasattr(a, "data_ptr"):                     # device tensors: nothing cached (a tensor's storage may be replaced behind the same object)
-                    assert a.is_contiguous()
-                    return a.data_ptr()
-                return int(a)
-            v = cache.get(id(a))
-            if v is None:
-                assert a.dtype == np.float64 and a.flags.c_contiguous
-                if len(cache) > 4096:
-                    cache.clear(); del alive[:]
-                v = cache[id(a)] = a.__array_interface__["data"][0]
-                alive.append(a)
-            return v
-
-        def ptrs(seq):                                        # uintp array == array of void*
-            if len(seq) == n and n > 0:
-                first = seq[0]
-                if isinstance(first, np.ndarray):              # host arrays seen before: two C-level passes
-                    vals = list(map(cache.get, map(id, seq)))
-                    if None not in vals:
-                        return np.array(vals, np.uintp)
-                elif _torch is not None and isinstance(first, _torch.Tensor):
-                    try:                                       # tensors only (a None or an array among them: the general path)
-                        out = np.fromiter(map(_torch.Tensor.data_ptr, seq), np.uintp, n)
-                        assert all(map(_torch.Tensor.is_contiguous, seq))
-                        return out
-                    except TypeError:
-                        pass
-            return np.fromiter((addr(a) for a in seq), np.uintp, n)
-        self._keep.update(zip(map(int, ids), zip(raws, poses, alts, grs)))      # (one pass in C: the Python loop was 70 us of a 200-frame call)
-        a_ids = np.ascontiguousarray(ids, np.int32); a_N = np.ascontiguousarray(Ns, np.int32); a_M = np.ascontiguousarray(Ms, np.int32)
-        p_raw, p_pose, p_alt, p_gr = ptrs(raws), ptrs(poses), ptrs(alts), ptrs(grs)       # locals keep the arrays alive over the call
-        self._chk(self.L.dsss_frames_set(self.h, n, _ptr(a_ids), _ptr(p_raw), _ptr(a_N), _ptr(a_M), _ptr(p_pose), _ptr(p_alt), _ptr(p_gr)), "dsss_frames_set")
+        self._keep.update(a.keep)                              # the library borrows device images until the frame is set again
+        self._chk(self.L.dsss_frames_set(self.h, a.n, _ptr(a.ids), _ptr(a.p_raw), _ptr(a.N), _ptr(a.M), _ptr(a.p_pose), _ptr(a.p_alt), _ptr(a.p_gr)), "dsss_frames_set")
 
     def extract(self, fid):
         n = C.c_int(0)

@@ -123,7 +123,6 @@ void dsss_destroy(dsss_ctx* c)
     hipFree(c->ag_buf); if (c->ag_host) hipHostFree(c->ag_host); hipFree(c->xch_dev);
     if (c->pg_edges_host) hipHostFree(c->pg_edges_host);
     if (c->pg_ab_host) hipHostFree(c->pg_ab_host);
-    if (c->pg_edges_ev) hipEventDestroy(c->pg_edges_ev);
     if (c->xch_host) hipHostFree(c->xch_host);
     if (c->pg_stage) hipHostFree(c->pg_stage);
     if (c->pg_scal_host) hipHostFree(c->pg_scal_host);

@@ -126,7 +126,7 @@ struct dsss_ctx {
     void* ag_host = nullptr; size_t ag_host_cap = 0;            // page-locked landing place of the gathered headers (keypoint counts, boxes, sizes)
     double* xch_dev = nullptr; size_t xch_cap = 0;              // device scratch of the loop-closure exchange between ranks (dsss_posegraph_solve)
     void* pg_edges_host = nullptr; size_t pg_edges_cap = 0;     // page-locked staging of the selected LC edges (dsss_posegraph_solve)
-    int* pg_ab_host = nullptr; size_t pg_ab_cap = 0; hipEvent_t pg_edges_ev = nullptr;      // their end points, which travel first (pairs); the records have arrived
+    int* pg_ab_host = nullptr; size_t pg_ab_cap = 0;      // their end points as packed (a, b) pairs
     void* xch_host = nullptr; size_t xch_host_cap = 0;          // page-locked landing place of the gathered edge records of all ranks (bytes)
     double* pg_scal_host = nullptr;                             // page-locked landing place of the LM trial's scalars (8 doubles)
     std::vector<int> pg_last_levels;                            // schedule of the last solve, four ints per panel level: items, widest panel (scalar columns), tallest rows below, this rank's or the interface's (dsss_posegraph_schedule_get)

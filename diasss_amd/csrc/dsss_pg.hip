@@ -103,8 +103,7 @@ void dsss_pg_free(dsss_ctx* c) { for (auto& ch : c->pg_chunks) hipFree(ch.first)
 // batch LM over `total` poses with `ne` LC edges (host).  The DR rows (total x 6) are either one host array (dr6) or,
 // with dr6 == NULL, the rows of frames 0 .. nframes-1 of the context: read on the host from the frames' pinned copies
 // (only the separator poses are looked at) and gathered on the device straight from the frames' device copies.
-// `ends` (optional): the (a, b) pairs of the edges, already on the host while the records themselves are still on their way
-// (pg_select_impl; c->pg_edges_ev says when they have arrived)
+// `ends` (optional): the (a, b) pairs of the edges packed 8 bytes apart (pg_select_impl)
 static int pg_solve_impl(dsss_ctx* c, const double* dr6, int total, const dsss_lc_edge* edges, int ne, double* poses12, double* stats4, double* rpy6 = nullptr,
                          int nframes = 0, const int* ends = nullptr)
 {
@@ -165,23 +164,23 @@ static int pg_solve_impl(dsss_ctx* c, const double* dr6, int total, const dsss_l
         // the cheapest gap between two loop-closure poses within a third of a partition's length of its frame boundary: cost of a gap = loop
         // closures that span it, all gaps priced by one difference array.  Every rank holds all edges (exchanged before the solve), so every
         // rank moves the boundaries to the same places.  Frames, features and matches stay sharded by frame: only pose ownership moves.
-        std::vector<int> ends; ends.reserve((size_t)2 * ne + 2);
+        std::vector<int> lc_ends; lc_ends.reserve((size_t)2 * ne + 2);
         for (size_t w = 0; w < tbits.size(); ++w)
-            for (unsigned long long bits = tbits[w]; bits; bits &= bits - 1) ends.push_back((int)(w * 64) + __builtin_ctzll(bits));
+            for (unsigned long long bits = tbits[w]; bits; bits &= bits - 1) lc_ends.push_back((int)(w * 64) + __builtin_ctzll(bits));
         std::vector<int> pre(tbits.size() + 1, 0);
         for (size_t w = 0; w < tbits.size(); ++w) pre[w + 1] = pre[w] + __builtin_popcountll(tbits[w]);
         auto eidx = [&](int pose) { return pre[(size_t)pose >> 6] + __builtin_popcountll(tbits[(size_t)pose >> 6] & ((1ull << (pose & 63)) - 1ull)); };
-        const int m = (int)ends.size();
-        std::vector<int> cross(m + 1, 0);                                  // cross[i]: loop closures that span the gap between ends[i - 1] and ends[i]
+        const int m = (int)lc_ends.size();
+        std::vector<int> cross(m + 1, 0);                                  // cross[i]: loop closures that span the gap between lc_ends[i - 1] and lc_ends[i]
         for (int e = 0; e < ne; ++e) { const int lo = eidx(std::min(ea[e], eb[e])), hi = eidx(std::max(ea[e], eb[e])); cross[lo + 1]++; cross[hi + 1]--; }
         for (int i = 1; i <= m; ++i) cross[i] += cross[i - 1];
         const int width = n / nparts / 3;
         for (int p = 1; p < nparts; ++p) {
             const int target = pbound[p];
             int best = -1; long long bcost = 1LL << 60, bdist = 0;
-            const int i0 = (int)(std::lower_bound(ends.begin(), ends.end(), target - width) - ends.begin());
-            for (int i = std::max(i0, 1); i < m && ends[i - 1] + 1 <= target + width; ++i) {      // boundary between ends[i - 1] and ends[i]: partition p starts at ends[i - 1] + 1
-                const int start = ends[i - 1] + 1;
+            const int i0 = (int)(std::lower_bound(lc_ends.begin(), lc_ends.end(), target - width) - lc_ends.begin());
+            for (int i = std::max(i0, 1); i < m && lc_ends[i - 1] + 1 <= target + width; ++i) {      // boundary between lc_ends[i - 1] and lc_ends[i]: partition p starts at lc_ends[i - 1] + 1
+                const int start = lc_ends[i - 1] + 1;
                 if (start <= pbound[p - 1] || start < target - width) continue;
                 const long long d = std::llabs((long long)start - target);
                 if (cross[i] < bcost || (cross[i] == bcost && d < bdist)) { bcost = cross[i]; bdist = d; best = start; }
@@ -368,7 +367,6 @@ static int pg_solve_impl(dsss_ctx* c, const double* dr6, int total, const dsss_l
         coords_guard.set();
     }
     emeas.resize(ne); ew.resize((size_t)ne * 6);
-    if (ends && ne > 0) { const hipError_t e = hipEventSynchronize(c->pg_edges_ev); if (e != hipSuccess) { abandon(); HIPCHK(c, e); } }      // the records have arrived
     for (int e = 0; e < ne; ++e) {                  // measurements and weights of the loop closures (the analysis is running and has its coordinates)
         for (int k = 0; k < 9; ++k) emeas[e].R[k] = edges[e].rel[k];
         for (int k = 0; k < 3; ++k) emeas[e].t[k] = edges[e].rel[9 + k];
@@ -942,10 +940,12 @@ __global__ __launch_bounds__(256) void lc_edge_compact_kernel(const int* __restr
     }
 }
 
-// ends != NULL (dsss_posegraph_solve, one rank): the END POINTS of the edges come back first -- they are all the analysis of the solve
-// needs -- as (a, b) pairs in the context's page-locked buffer, *ends pointing at them; the 152-byte records follow asynchronously into
-// `edges` (page-locked as well) with c->pg_edges_ev recorded behind the copy: the solve waits for it where it unpacks the measurements,
-// beside the analysis.  (Records first cost 0.2 ms between the end of lc_kernel and the start of the analysis, with the GPU idle.)
+// ends != NULL (dsss_posegraph_solve, one rank): the END POINTS of the edges also come back as packed (a, b) pairs in the context's
+// page-locked buffer (*ends): the first passes of the solve (separators, partition boundaries, reduced edges) walk 8 bytes per edge
+// instead of 152.  The records themselves are on the host as well when this returns: dv.release() synchronises the stream, and it has
+// to -- the arena the device copies sit in is handed back and the solve's uploads into it are blocking copies on the null stream,
+// which do not order against this non-blocking stream.  (Round 5 recorded an event behind the record copy and claimed an overlap
+// with the analysis; the release-time synchronisation made that event always already satisfied -- advisor, round 5 -- so it is gone.)
 #define PG_AB_PREFIX 32768
 static int pg_select_impl(dsss_ctx* c, int nframes, dsss_lc_edge* edges, int cap, int* n_edges, const int** ends)
 {
@@ -983,7 +983,6 @@ static int pg_select_impl(dsss_ctx* c, int nframes, dsss_lc_edge* edges, int cap
                 HIPCHK(c, hipHostMalloc((void**)&c->pg_ab_host, (size_t)cap * sizeof(int2), hipHostMallocDefault));
                 c->pg_ab_cap = (size_t)cap;
             }
-            if (!c->pg_edges_ev) HIPCHK(c, hipEventCreateWithFlags(&c->pg_edges_ev, hipEventDisableTiming));
         }
         hipStream_t st = c->stream;
         HIPCHK(c, hipMemsetAsync(d_slot, 0, (size_t)total * sizeof(unsigned long long), st));
@@ -1002,11 +1001,10 @@ static int pg_select_impl(dsss_ctx* c, int nframes, dsss_lc_edge* edges, int cap
         if (ends) {
             if (ne > pre) { HIPCHK(c, hipMemcpyAsync(c->pg_ab_host + 2 * (size_t)pre, d_ab + pre, (size_t)(ne - pre) * sizeof(int2), hipMemcpyDeviceToHost, st)); HIPCHK(c, hipStreamSynchronize(st)); }
             if (ne > 0) HIPCHK(c, hipMemcpyAsync(edges, d_edges, (size_t)ne * sizeof(dsss_lc_edge), hipMemcpyDeviceToHost, st));
-            HIPCHK(c, hipEventRecord(c->pg_edges_ev, st));         // (the arena the records sit in is reused by the solve: by work queued on this stream, behind the copy)
             *ends = c->pg_ab_host;
         }
         else if (ne > 0) HIPCHK(c, hipMemcpy(edges, d_edges, (size_t)ne * sizeof(dsss_lc_edge), hipMemcpyDeviceToHost));
-        dv.release();
+        dv.release();                                              // synchronises the stream: REQUIRED before the arena is reused (see above)
     }
     else if (ends) *ends = nullptr;
     if (n_edges) *n_edges = ne;

@@ -87,19 +87,22 @@ class Pipeline:
         self.ctx.close()
 
     # ---- stage 1: frames
-    def set_frames(self, raws, poses, alts, grs):
-        """raws[f] may be None for frames this rank does not extract"""
-        if getattr(self, "_dims_of", None) is None or self._dims_of[0] is not poses or self._dims_of[1] is not grs:
-            self.N = [p.shape[0] for p in poses]
-            self.M = [2 * len(g) for g in grs]
-            self._dims_of = (poses, grs)
-            self._ids = list(range(self.F))
-        self.poses = poses
-        if hasattr(self.ctx, "frames_set"):
-            self.ctx.frames_set(self._ids, raws, self.N, self.M, poses, alts, grs)
-        else:
+    def prepare(self, raws, poses, alts, grs):
+        """the argument arrays of dsss_frames_set for one survey, built and validated ONCE (capi.FramesArgs: what a C++ caller of the C ABI
+        holds anyway); run(prepared) / set_frames(prepared) then go straight to the C call.  raws[f] may be None for frames this rank
+        does not extract."""
+        N = [p.shape[0] for p in poses]; M = [2 * len(g) for g in grs]
+        args = self.ctx.frames_args(list(range(self.F)), raws, N, M, poses, alts, grs) if hasattr(self.ctx, "frames_args") else None
+        return dict(args=args, N=N, M=M, raws=raws, poses=poses, alts=alts, grs=grs)
+
+    def set_frames(self, raws, poses=None, alts=None, grs=None):
+        h = raws if isinstance(raws, dict) else self.prepare(raws, poses, alts, grs)
+        self.N, self.M, self.poses = h["N"], h["M"], h["poses"]
+        if h["args"] is not None:
+            self.ctx.frames_set(h["args"])
+        else:                                              # (a recording stub of the CPU tests)
             for f in range(self.F):
-                self.ctx.frame_set(f, raws[f], self.N[f], self.M[f], poses[f], alts[f], grs[f])
+                self.ctx.frame_set(f, h["raws"][f], self.N[f], self.M[f], h["poses"][f], h["alts"][f], h["grs"][f])
 
     def extract(self):
         self.ctx.extract_many(shard_frames(self.F, self.rank, self.world))
@@ -126,7 +129,8 @@ class Pipeline:
         self.n_edges = None
         return poses, stats
 
-    def run(self, raws, poses, alts, grs):
+    def run(self, raws, poses=None, alts=None, grs=None):
+        """one survey through the whole path; `raws` may be the handle of prepare()"""
         self.set_frames(raws, poses, alts, grs)
         self.extract()
         self.match()

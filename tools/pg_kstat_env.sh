@@ -1,13 +1,17 @@
 #!/bin/bash
 # per-kernel averages of solves of the dumped C3 graph under a kernel trace, one run per setting: tools/pg_kstat_env.sh <pattern> ["DSSS_X=v" ...]
-set -uo pipefail
+set -euo pipefail
 pat=${1:?usage: tools/pg_kstat_env.sh <pattern> [DSSS_NAME=value ...]}; shift
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
 export TMPDIR=/tmp
 cd "$ROOT"
 for v in "X=1" "$@"; do
+  name=${v%%=*}; val=${v#*=}
+  [[ "$v" == *=* && "$name" =~ ^(X|DSSS_[A-Z0-9_]+)$ ]] || { echo "pg_kstat_env.sh: '$v' is not DSSS_NAME=value" >&2; exit 2; }
   rm -rf gpurun_out/kst
-  env "$v" PG_SWEEP_NOPROF=1 rocprofv3 --kernel-trace --stats -d gpurun_out/kst -o k --output-format csv -- python3 tools/pg_sweep.py tools/_data/C3_edges.npz 5 > gpurun_out/kst.log 2>&1 || { echo "run failed under $v"; tail -5 gpurun_out/kst.log; continue; }
+  env "$name=$val" PG_SWEEP_NOPROF=1 rocprofv3 --kernel-trace --stats -d gpurun_out/kst -o k --output-format csv -- python3 tools/pg_sweep.py tools/_data/C3_edges.npz 5 > gpurun_out/kst.log 2>&1 \
+    || { echo "pg_kstat_env.sh: the profiled run failed under $v:" >&2; tail -20 gpurun_out/kst.log >&2; exit 1; }
+  [ -s gpurun_out/kst/k_kernel_stats.csv ] || { echo "pg_kstat_env.sh: no kernel stats under $v" >&2; exit 1; }
   echo "== $v   $(tail -1 gpurun_out/kst.log | cut -c1-120)"
   PAT="$pat" python3 - <<'PY'
 import csv, os, re
