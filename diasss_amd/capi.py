@@ -465,6 +465,14 @@ class Context:
         self._chk(self.L.dsss_posegraph_update(self.h, nframes, _ptr(poses), _ptr(rpy) if want_rpy else None, _ptr(stats)), "dsss_posegraph_update")
         return poses, rpy, stats
 
+    def posegraph_update_window(self, nframes, total, window, want_poses=True):
+        """the incremental form (dsss_posegraph_update_window): only the last `window` frames are solved, conditioned on the frozen estimate
+        of everything before them.  Returns (poses of ALL pings or None, stats of the window's LM)."""
+        poses = np.empty((total, 12), np.float64) if want_poses else None
+        stats = np.zeros(4, np.float64)
+        self._chk(self.L.dsss_posegraph_update_window(self.h, nframes, int(window), _ptr(poses) if want_poses else None, None, _ptr(stats)), "dsss_posegraph_update_window")
+        return poses, stats
+
     def posegraph_reset(self):
         self._chk(self.L.dsss_posegraph_reset(self.h), "dsss_posegraph_reset")
 

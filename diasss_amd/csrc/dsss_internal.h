@@ -137,6 +137,7 @@ struct dsss_ctx {
     // online use (dsss_posegraph_update): the estimate of the previous update stays on the device, the LC edges accumulate
     void* pg_warm = nullptr; size_t pg_warm_cap = 0; int pg_warm_n = 0;   // pose_t[pg_warm_n]
     bool pg_online = false;             // set by dsss_posegraph_update: pg_solve_impl starts from pg_warm and leaves its result there
+    int pg_win_f0 = 0, pg_win_p0 = 0;   // dsss_posegraph_update_window: first frame / first global pose of the window being solved (0: the whole graph)
     std::vector<dsss_lc_edge> pg_inc_edges; unsigned long long lc_gen = 0, pg_inc_gen = 0;    // lc_gen counts LC result sets; the last one consumed
     dsss_prof prof;
 };

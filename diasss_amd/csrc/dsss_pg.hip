@@ -104,11 +104,15 @@ void dsss_pg_free(dsss_ctx* c) { for (auto& ch : c->pg_chunks) hipFree(ch.first)
 // with dr6 == NULL, the rows of frames 0 .. nframes-1 of the context: read on the host from the frames' pinned copies
 // (only the separator poses are looked at) and gathered on the device straight from the frames' device copies.
 // `ends` (optional): the (a, b) pairs of the edges packed 8 bytes apart (pg_select_impl)
+// Window mode (dsss_posegraph_update_window; c->pg_win_f0 > 0): the chain is the poses of frames f0 .. f0 + nframes - 1 only, pose 0 of it is pinned
+// at its estimate of the previous update (the prior's measurement), everything else starts from that estimate where there is one, and the
+// result goes back into the context's warm buffer at the window's offset; poses12 / rpy6 then receive the WHOLE trajectory out of that buffer.
 static int pg_solve_impl(dsss_ctx* c, const double* dr6, int total, const dsss_lc_edge* edges, int ne, double* poses12, double* stats4, double* rpy6 = nullptr,
                          int nframes = 0, const int* ends = nullptr)
 {
     std::vector<int> foff;
-    if (!dr6) { foff.assign(nframes + 1, 0); for (int f = 0; f < nframes; ++f) foff[f + 1] = foff[f] + c->frames[f].N; }
+    const int f0 = (!dr6 && c->pg_online) ? c->pg_win_f0 : 0, win_p0 = f0 > 0 ? c->pg_win_p0 : 0;
+    if (!dr6) { foff.assign(nframes + 1, 0); for (int f = 0; f < nframes; ++f) foff[f + 1] = foff[f] + c->frames[f0 + f].N; }
     const int n = total;
     if (n < 2) DSSS_FAIL(c, DSSS_E_ARG, "pose graph needs at least 2 poses");
     // ranks: contiguous blocks of frames (of poses when the DR chain comes without frames) per partition, contiguous partitions
@@ -318,7 +322,7 @@ static int pg_solve_impl(dsss_ctx* c, const double* dr6, int total, const dsss_l
     {
         if (!dr6) {
             fp.resize(nframes);
-            for (int f = 0; f < nframes; ++f) fp[f] = (unsigned long long)(uintptr_t)c->frames[f].pose6;
+            for (int f = 0; f < nframes; ++f) fp[f] = (unsigned long long)(uintptr_t)c->frames[f0 + f].pose6;
             dv.later(&d_fp, fp); dv.later(&d_foff, foff);
         }
         TRY(dv.flush(c, c->stream));                          // true separators, frame pointers: one upload
@@ -522,8 +526,13 @@ static int pg_solve_impl(dsss_ctx* c, const double* dr6, int total, const dsss_l
         hipLaunchKernelGGL(pg_init_kernel, dim3((n + 255) / 256), dim3(256), 0, st, n, d_dr6, d_norm, c->pg.add_noise, d_X, d_meas);
         // online use (dsss_posegraph_update): the pings the previous update covered start from its estimate, the new ones where
         // the reference puts them (dead reckoning o noise, optimizer.cpp:150-160)
-        if (c->pg_online && c->pg_warm_n > 0)
-            HCK(hipMemcpyAsync(d_X, c->pg_warm, (size_t)std::min(n, c->pg_warm_n) * sizeof(pose_t), hipMemcpyDeviceToDevice, st));
+        if (c->pg_online && c->pg_warm_n > win_p0) {
+            const pose_t* warm = static_cast<const pose_t*>(c->pg_warm) + win_p0;
+            HCK(hipMemcpyAsync(d_X, warm, (size_t)std::min(n, c->pg_warm_n - win_p0) * sizeof(pose_t), hipMemcpyDeviceToDevice, st));
+            // a window is CONDITIONED on the frozen part of the trajectory through its first pose: the prior (sigma 1e-6) holds it where the
+            // previous update left it instead of at its dead-reckoned pose
+            if (win_p0 > 0) HCK(hipMemcpyAsync(d_meas, warm, sizeof(pose_t), hipMemcpyDeviceToDevice, st));
+        }
     }
     double lambda = c->pg.lambda0, err = 0, err0 = 0, cur = 0;
     int iters = 0, nfact = 0;
@@ -831,27 +840,33 @@ static int pg_solve_impl(dsss_ctx* c, const double* dr6, int total, const dsss_l
         hipLaunchKernelGGL(pg_mask_own_kernel, dim3((n + 255) / 256), dim3(256), 0, st, n, d_X, mp0, mp1);
         int rc2 = dsss_comm_allreduce(c, (double*)d_X, (size_t)n * 12, st); if (rc2) { abandon(); return rc2; }
     }
-    if (poses12) {      // pose_t is 12 contiguous doubles (R row-major, t): straight into the caller's buffer
-        static_assert(sizeof(pose_t) == 12 * sizeof(double), "pose_t layout");
-        HCK(hipMemcpyAsync(poses12, d_X, (size_t)n * sizeof(pose_t), hipMemcpyDeviceToHost, st));
+    static_assert(sizeof(pose_t) == 12 * sizeof(double), "pose_t layout");
+    if (c->pg_online) {
+        const size_t all = (size_t)win_p0 + (size_t)n;
+        if (c->pg_warm_cap < all) {
+            HCK(hipStreamSynchronize(st));
+            const size_t cap = all + all / 2 + 1024;                        // the graph grows by a frame per update
+            void* nw = nullptr;
+            HCK(hipMalloc(&nw, cap * sizeof(pose_t)));
+            if (win_p0 > 0 && c->pg_warm) {                                 // (a window keeps the frozen part in front of it)
+                const hipError_t e = hipMemcpy(nw, c->pg_warm, (size_t)win_p0 * sizeof(pose_t), hipMemcpyDeviceToDevice);
+                if (e != hipSuccess) { hipFree(nw); HCK(e); }
+            }
+            if (c->pg_warm) hipFree(c->pg_warm);
+            c->pg_warm = nw; c->pg_warm_cap = cap;
+        }
+        HCK(hipMemcpyAsync(static_cast<pose_t*>(c->pg_warm) + win_p0, d_X, (size_t)n * sizeof(pose_t), hipMemcpyDeviceToDevice, st));
+        c->pg_warm_n = (int)all;
     }
+    const pose_t* d_out = win_p0 > 0 ? static_cast<const pose_t*>(c->pg_warm) : d_X;      // a window reports the whole trajectory
+    const int n_out = win_p0 > 0 ? win_p0 + n : n;
+    if (poses12)        // pose_t is 12 contiguous doubles (R row-major, t): straight into the caller's buffer
+        HCK(hipMemcpyAsync(poses12, d_out, (size_t)n_out * sizeof(pose_t), hipMemcpyDeviceToHost, st));
     if (rpy6) {
         double* d_rpy;
-        TRY(dv.alloc(c, &d_rpy, (size_t)n * 6));
-        hipLaunchKernelGGL(pg_rpy_kernel, dim3((n + 255) / 256), dim3(256), 0, st, n, d_X, d_rpy);
-        HCK(hipMemcpyAsync(rpy6, d_rpy, (size_t)n * 6 * sizeof(double), hipMemcpyDeviceToHost, st));
-    }
-    if (c->pg_online) {
-        if (c->pg_warm_cap < (size_t)n) {
-            HCK(hipStreamSynchronize(st));
-            if (c->pg_warm) hipFree(c->pg_warm);
-            c->pg_warm = nullptr; c->pg_warm_cap = 0; c->pg_warm_n = 0;
-            const size_t cap = (size_t)n + (size_t)n / 2 + 1024;            // the graph grows by a frame per update
-            HCK(hipMalloc(&c->pg_warm, cap * sizeof(pose_t)));
-            c->pg_warm_cap = cap;
-        }
-        HCK(hipMemcpyAsync(c->pg_warm, d_X, (size_t)n * sizeof(pose_t), hipMemcpyDeviceToDevice, st));
-        c->pg_warm_n = n;
+        TRY(dv.alloc(c, &d_rpy, (size_t)n_out * 6));
+        hipLaunchKernelGGL(pg_rpy_kernel, dim3((n_out + 255) / 256), dim3(256), 0, st, n_out, d_out, d_rpy);
+        HCK(hipMemcpyAsync(rpy6, d_rpy, (size_t)n_out * 6 * sizeof(double), hipMemcpyDeviceToHost, st));
     }
     HCK(hipStreamSynchronize(st));
     if (stats4) { stats4[0] = iters; stats4[1] = err0; stats4[2] = err; stats4[3] = lambda; }
@@ -1144,7 +1159,7 @@ int dsss_posegraph_schedule_get(dsss_ctx* c, int* levels4, int cap_levels, int* 
     return DSSS_OK;
 }
 
-int dsss_posegraph_update(dsss_ctx* c, int nframes, double* poses12, double* rpy6, double* stats4)
+static int pg_update_impl(dsss_ctx* c, int nframes, int window_frames, double* poses12, double* rpy6, double* stats4)
 {
     if (!c || nframes <= 0 || nframes > c->max_frames) return DSSS_E_ARG;
     if (dsss_comm_world(c) > 1) DSSS_FAIL(c, DSSS_E_STATE, "dsss_posegraph_update is a single-rank call (the online use is one vehicle, one GPU)");
@@ -1169,16 +1184,74 @@ int dsss_posegraph_update(dsss_ctx* c, int nframes, double* poses12, double* rpy
             for (size_t e = 0; e < c->pg_inc_edges.size(); ++e) if (!hit[c->pg_inc_edges[e].b]) c->pg_inc_edges[w++] = c->pg_inc_edges[e];
             c->pg_inc_edges.resize(w);
         }
+        // the fresh set ascends in the target ping; when it starts behind everything accumulated (a new frame: the usual case) appending keeps the
+        // list sorted -- sorting 12 k records of 152 bytes on every update was the part of an update's cost that grew with the survey
+        const bool append_only = ne == 0 || c->pg_inc_edges.empty() || c->pg_inc_edges.back().b <= fresh[0].b;
         c->pg_inc_edges.insert(c->pg_inc_edges.end(), fresh.begin(), fresh.begin() + ne);
-        std::stable_sort(c->pg_inc_edges.begin(), c->pg_inc_edges.end(), [](const dsss_lc_edge& x, const dsss_lc_edge& y) { return x.b < y.b; });
+        if (!append_only) std::stable_sort(c->pg_inc_edges.begin(), c->pg_inc_edges.end(), [](const dsss_lc_edge& x, const dsss_lc_edge& y) { return x.b < y.b; });
     }
     c->pg_inc_gen = c->lc_gen;
     for (const dsss_lc_edge& e : c->pg_inc_edges)
         if (e.a >= (int)total || e.b >= (int)total) DSSS_FAIL(c, DSSS_E_ARG, "an accumulated LC edge references ping %d of %zu: nframes went down; dsss_posegraph_reset first", std::max(e.a, e.b), total);
-    c->pg_online = true;
-    const int rc = pg_solve_impl(c, nullptr, (int)total, c->pg_inc_edges.data(), (int)c->pg_inc_edges.size(), poses12, stats4, rpy6, nframes);
-    c->pg_online = false;
+    // ---- the window (dsss_posegraph_update_window): frames f0 .. nframes - 1 are solved, conditioned on the frozen estimate of everything before
+    // them.  Loop closures inside the window keep their form; one from a frozen pose a into the window becomes a BetweenFactor from the
+    // window's pinned first pose with the measurement X_0^-1 X_a rel -- exactly the same residual, since X_a = X_0 (X_0^-1 X_a) with both
+    // factors frozen (error = Log(rel^-1 X_a^-1 X_b) = Log((X_0^-1 X_a rel)^-1 X_0^-1 X_b)); closures between two frozen poses drop out.
+    const int f0 = window_frames > 0 ? std::max(0, nframes - window_frames) : 0;
+    int p0 = 0;
+    for (int f = 0; f < f0; ++f) p0 += c->frames[f].N;
+    if (f0 == 0 || c->pg_warm_n <= p0) {                // no frozen part yet (or nothing to condition on): the whole graph
+        c->pg_online = true; c->pg_win_f0 = 0; c->pg_win_p0 = 0;
+        const int rc = pg_solve_impl(c, nullptr, (int)total, c->pg_inc_edges.data(), (int)c->pg_inc_edges.size(), poses12, stats4, rpy6, nframes);
+        c->pg_online = false;
+        return rc;
+    }
+    std::vector<dsss_lc_edge> we; std::vector<int> frozen;       // window edges; global ids of the frozen end points (in edge order)
+    for (const dsss_lc_edge& e : c->pg_inc_edges) {
+        if (std::max(e.a, e.b) < p0) continue;
+        if (e.a >= p0 && e.b >= p0) { dsss_lc_edge w = e; w.a -= p0; w.b -= p0; we.push_back(w); continue; }
+        if (e.a > e.b) DSSS_FAIL(c, DSSS_E_ARG, "window update: loop closure %d -> %d runs from the window into the frozen part (the pipeline's closures end in the later frame)", e.a, e.b);
+        dsss_lc_edge w = e; w.b -= p0; w.a = -1 - (int)frozen.size(); frozen.push_back(e.a); we.push_back(w);
+    }
+    if (!frozen.empty()) {
+        HIPCHK(c, hipSetDevice(c->device));
+        // X_0 (the window's first pose) and the frozen end points: one gather out of the warm buffer
+        std::vector<int> idx(frozen); idx.push_back(p0);
+        int* d_idx = nullptr; pose_t* d_g = nullptr;
+        HIPCHK(c, hipMalloc(&d_idx, idx.size() * sizeof(int)));
+        hipError_t e = hipMalloc(&d_g, idx.size() * sizeof(pose_t));
+        std::vector<pose_t> g(idx.size());
+        if (e == hipSuccess) e = hipMemcpyAsync(d_idx, idx.data(), idx.size() * sizeof(int), hipMemcpyHostToDevice, c->stream);
+        if (e == hipSuccess) { hipLaunchKernelGGL(pg_gather_pose_kernel, dim3(((int)idx.size() + 255) / 256), dim3(256), 0, c->stream, (int)idx.size(), d_idx, static_cast<const pose_t*>(c->pg_warm), d_g); e = hipGetLastError(); }
+        if (e == hipSuccess) e = hipMemcpyAsync(g.data(), d_g, g.size() * sizeof(pose_t), hipMemcpyDeviceToHost, c->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        hipFree(d_idx); hipFree(d_g);
+        HIPCHK(c, e);
+        pose_t X0inv; pose_inverse(&g.back(), &X0inv);
+        for (dsss_lc_edge& w : we) {
+            if (w.a >= 0) continue;
+            const pose_t& Xa = g[(size_t)(-1 - w.a)];
+            pose_t rel, Y, M;
+            for (int k = 0; k < 9; ++k) rel.R[k] = w.rel[k];
+            for (int k = 0; k < 3; ++k) rel.t[k] = w.rel[9 + k];
+            pose_compose(&X0inv, &Xa, &Y); pose_compose(&Y, &rel, &M);
+            for (int k = 0; k < 9; ++k) w.rel[k] = M.R[k];
+            for (int k = 0; k < 3; ++k) w.rel[9 + k] = M.t[k];
+            w.a = 0;
+        }
+    }
+    // (several closures may now share the end point pair (0, b): the solver sums duplicates in edge order)
+    c->pg_online = true; c->pg_win_f0 = f0; c->pg_win_p0 = p0;
+    const int rc = pg_solve_impl(c, nullptr, (int)total - p0, we.data(), (int)we.size(), poses12, stats4, rpy6, nframes - f0);
+    c->pg_online = false; c->pg_win_f0 = 0; c->pg_win_p0 = 0;
     return rc;
+}
+
+int dsss_posegraph_update(dsss_ctx* c, int nframes, double* poses12, double* rpy6, double* stats4) { return pg_update_impl(c, nframes, 0, poses12, rpy6, stats4); }
+int dsss_posegraph_update_window(dsss_ctx* c, int nframes, int window_frames, double* poses12, double* rpy6, double* stats4)
+{
+    if (window_frames < 1) { if (c) c->err = "window_frames must be at least 1"; return DSSS_E_ARG; }
+    return pg_update_impl(c, nframes, window_frames, poses12, rpy6, stats4);
 }
 
 } // extern "C"

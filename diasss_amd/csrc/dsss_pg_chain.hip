@@ -803,6 +803,12 @@ __global__ __launch_bounds__(256) void pg_gather_dr_kernel(const unsigned long l
     double* __restrict__ dst = out + (size_t)foff[f] * 6;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n6; i += (size_t)gridDim.x * 256) dst[i] = src[i];
 }
+// poses picked out of a trajectory by index (the frozen end points of a window update)
+__global__ __launch_bounds__(256) void pg_gather_pose_kernel(int n, const int* __restrict__ idx, const pose_t* __restrict__ X, pose_t* __restrict__ out)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) out[i] = X[idx[i]];
+}
 // x, y of the separator poses (the coordinates the nested dissection bisects)
 __global__ __launch_bounds__(256) void pg_sep_xy_kernel(int ns, const int* __restrict__ sep_pose, const double* __restrict__ dr6, double* __restrict__ xy)
 {

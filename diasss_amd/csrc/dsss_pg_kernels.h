@@ -55,6 +55,7 @@ __global__ void pg_flag_blocksum_kernel(const int* __restrict__ flags, long long
 __global__ void pg_flag_scan_kernel(int* __restrict__ bsum, int nb, int* __restrict__ total);
 __global__ void pg_flag_compact_kernel(const int* __restrict__ flags, const double* __restrict__ pairs, long long n, const int* __restrict__ bsum, long long need_pairs, double* __restrict__ normals);
 __global__ void pg_gather_dr_kernel(const unsigned long long* __restrict__ fptr, const int* __restrict__ foff, double* __restrict__ out);
+__global__ void pg_gather_pose_kernel(int n, const int* __restrict__ idx, const pose_t* __restrict__ X, pose_t* __restrict__ out);
 __global__ void pg_sep_xy_kernel(int ns, const int* __restrict__ sep_pose, const double* __restrict__ dr6, double* __restrict__ xy);
 __global__ void pg_init_kernel(int n, const double* __restrict__ dr6, const double* __restrict__ normals, int add_noise, pose_t* __restrict__ X, pose_t* __restrict__ meas);
 __global__ void pg_rpy_kernel(int n, const pose_t* __restrict__ X, double* __restrict__ rpy6);

@@ -17,6 +17,7 @@ namespace Diasss
 bool Optimizer::USE_ANNO = 0;
 bool Optimizer::ADD_LC = 1;
 bool Optimizer::ONLINE = 0;
+int Optimizer::ONLINE_WINDOW = 0;
 bool Optimizer::EVAL_1 = 0;
 bool Optimizer::EVAL_2 = 0;
 
@@ -135,7 +136,11 @@ void Optimizer::TrajOptimizationAll(std::vector<Frame> &AllFrames)
                 }
             if (!s_j.empty()) Device::check(dsss_lc_solve_pairs(c, s_j.data(), t_j.data(), (int)s_j.size(), k_j.data(), off_j.data()), "dsss_lc_solve_pairs");
             double st_j[4] = { 0, 0, 0, 0 };
-            Device::check(dsss_posegraph_update(c, (int)j + 1, j + 1 == F ? poses12.data() : nullptr, nullptr, st_j), "dsss_posegraph_update");
+            // ONLINE_WINDOW > 0: the incremental form -- an update solves the last ONLINE_WINDOW frames conditioned on the frozen rest (cost per
+            // update independent of the survey's length); the LAST update is the global one, warm-started from the windowed estimates: the
+            // batch optimum is what the reference reads after its loop (calculateEstimate, optimizer.cpp:279)
+            if (ONLINE_WINDOW > 0 && j + 1 < F) Device::check(dsss_posegraph_update_window(c, (int)j + 1, ONLINE_WINDOW, nullptr, nullptr, st_j), "dsss_posegraph_update_window");
+            else Device::check(dsss_posegraph_update(c, (int)j + 1, j + 1 == F ? poses12.data() : nullptr, nullptr, st_j), "dsss_posegraph_update");
             ++updates; trials += (int)st_j[0];
             if (j == 0) stats[1] = st_j[1];
             stats[0] = st_j[0]; stats[2] = st_j[2]; stats[3] = st_j[3];

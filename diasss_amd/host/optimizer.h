@@ -26,6 +26,7 @@ namespace Diasss
         static bool USE_ANNO;
         static bool ADD_LC;
         static bool ONLINE;      // frame-by-frame updates (the reference's iSAM2 loop, optimizer.cpp:134-272) instead of one batch solve
+        static int ONLINE_WINDOW; // > 0 with ONLINE: an update solves only the last ONLINE_WINDOW frames, conditioned on the frozen rest (dsss_posegraph_update_window); the last update is global
         // the two annotation evaluators of EvaluateByAnnosAll; the reference hard-codes both to 0 (optimizer.cpp:1579)
         static bool EVAL_1;
         static bool EVAL_2;

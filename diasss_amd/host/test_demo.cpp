@@ -30,6 +30,7 @@ int main(int argc, char** argv)
             else if (k == "--descriptor") { const bool sift = v == "sift"; Frame::USE_SIFT = sift; FEAmatcher::USE_SIFT = sift ? 2 : (v == "orb-l2" ? 1 : 0); }      // orb (default) | orb-l2 (the shipped matcher branch on the ORB bytes) | sift (N4: 128-float rows + L2)
             else if (k == "--use-anno") Optimizer::USE_ANNO = atoi(v.c_str()) != 0;      // optimizer.cpp:26 hard-codes 1 (hand annotations); default here 0
             else if (k == "--add-lc") Optimizer::ADD_LC = atoi(v.c_str()) != 0;
+            else if (k == "--online-window") Optimizer::ONLINE_WINDOW = atoi(v.c_str());      // with --online 1: updates solve the last N frames only (incremental), the last one is global
             else if (k == "--online") Optimizer::ONLINE = atoi(v.c_str()) != 0;      // frame-by-frame updates as the reference's iSAM2 loop does (default: one batch solve)
             else if (k == "--eval") { Optimizer::EVAL_1 = (atoi(v.c_str()) & 1) != 0; Optimizer::EVAL_2 = (atoi(v.c_str()) & 2) != 0; }      // optimizer.cpp:1579 hard-codes both off
         }

@@ -213,6 +213,16 @@ int dsss_posegraph_solve(dsss_ctx*, int nframes, double* poses12_host, double* r
  * the ACCUMULATED loop closures: every LC result set (dsss_lc_solve_all / dsss_lc_solve_pairs) is consumed once, by the next
  * update; its pairs must lie within the nframes frames.  dsss_posegraph_reset forgets estimate and edges.  Single rank.     */
 int dsss_posegraph_update(dsss_ctx*, int nframes, double* poses12_host, double* rpy6_host, double* stats4_host);
+/* The INCREMENTAL form (round 6): the same bookkeeping, but only the last `window_frames` frames are solved -- their pings and the loop
+ * closures that end in them -- CONDITIONED on the estimate the earlier updates left for everything before: the window's first ping is pinned
+ * there, a loop closure from a frozen ping into the window keeps its exact residual with the frozen end folded into its measurement, closures
+ * between frozen pings drop out.  Cost of an update: the window, whatever the length of the survey (the global form re-analyses and
+ * re-factorises the whole graph, O(F) per update, O(F^2) over a survey).  The frozen part is NOT revisited: what iSAM2 does for variables
+ * below its relinearisation threshold (optimizer.cpp:134-137) done by age -- a later dsss_posegraph_update (global, warm-started from these
+ * estimates: one or two LM trials) gives the batch optimum, which is all the reference ever reads (calculateEstimate after the loop, :279).
+ * poses12_host / rpy6_host (either may be NULL: nothing is downloaded) receive ALL pings of frames 0 .. nframes-1.  Falls back to the global
+ * form while there is no frozen part (nframes <= window_frames).  Loop closures must end in the later ping (the pipeline's do).          */
+int dsss_posegraph_update_window(dsss_ctx*, int nframes, int window_frames, double* poses12_host, double* rpy6_host, double* stats4_host);
 int dsss_posegraph_reset(dsss_ctx*);
 int dsss_posegraph_online_edges(dsss_ctx*);      /* loop closures accumulated so far (>= 0) */
 /* Instrumentation (no reference counterpart: GTSAM keeps its elimination tree to itself): the panel levels of the last solve of this

@@ -241,3 +241,74 @@ def test_online_updates_reach_the_batch_optimum(ctx, orc, survey):
     finally:
         ctx.posegraph_reset()
         ctx.match_pairs(src, tgt); ctx.lc_solve_all()
+
+
+def test_incremental_window_updates(orc):
+    """N3, the incremental form (dsss_posegraph_update_window; optimizer.cpp:134-139,262-272 keeps ONE ISAM2 object across pings): a survey
+    fed frame by frame, every update solving only the last 3 frames conditioned on the frozen estimate of the rest.
+      - the cost of an update does not grow with the survey (the global update's does): timed and printed, asserted loosely;
+      - the windowed estimate is a good one on its own (objective within a few per cent of the batch optimum);
+      - ONE global update at the end, warm-started from it, lands on the batch optimum (objective 1e-9 relative, positions 1e-7 m with the
+        stopping tolerances tightened), in fewer LM iterations than a cold batch solve -- what the reference reads after its loop (:279);
+      - the whole online run costs less than three batch solves."""
+    import time
+    from diasss_amd import capi
+    from diasss_amd.pipeline import Pipeline, all_pairs
+    from diasss_amd.synth import Survey
+    F, N, M, W = 24, 700, 480, 3
+    sv = Survey(F, N, M, seed=77, device="cuda:0")
+    raws = [sv.frame(f) for f in range(F)]
+    ins = [sv.inputs(f) for f in range(F)]
+    pipe = Pipeline(F, device=0)
+    b_out, b_stats = pipe.run(raws, [i[0] for i in ins], [i[1] for i in ins], [i[2] for i in ins])      # the batch run: features, matches, mini-LMs, solve
+    b_out = b_out.copy(); b_stats = np.array(b_stats)
+    ctx = pipe.ctx
+    b_edges = ctx.posegraph_select(F)
+    assert len(b_edges) > 60
+    src, tgt = pipe.src, pipe.tgt
+    kp7 = [ctx.match_kp7(p) for p in range(len(src))]
+    dr = np.concatenate([i[0] for i in ins])
+    t0 = time.perf_counter(); ctx.posegraph_solve(F, F * N, want_rpy=False); t_batch = time.perf_counter() - t0
+
+    def online(window):
+        ctx.posegraph_reset()
+        ts, its = [], []
+        for j in range(F):
+            pj = [p for p in range(len(src)) if tgt[p] == j and len(kp7[p])]
+            if pj:
+                ctx.lc_solve_pairs([src[p] for p in pj], [tgt[p] for p in pj], [kp7[p] for p in pj])
+            ctx.sync(); t1 = time.perf_counter()
+            if window:
+                _, st = ctx.posegraph_update_window(j + 1, (j + 1) * N, window, want_poses=False)
+            else:
+                _, _, st = ctx.posegraph_update(j + 1, (j + 1) * N)
+            ts.append(time.perf_counter() - t1); its.append(int(st[0]))
+        return np.array(ts), its
+    online(W)                                                  # (first use: allocations)
+    tw, iw = online(W)
+    assert ctx.posegraph_online_edges() == len(b_edges)
+    w_out, _ = ctx.posegraph_update_window(F, F * N, W)        # nothing new: the window once more, and the whole trajectory comes back
+    e_b = orc.pg_error_at(dr, b_edges, b_out); e_w = orc.pg_error_at(dr, b_edges, w_out)
+    t1 = time.perf_counter(); p_out, _, p_stats = ctx.posegraph_update(F, F * N); t_polish = time.perf_counter() - t1
+    e_p = orc.pg_error_at(dr, b_edges, p_out)
+    tg, ig = online(0)
+    late_w, late_g = tw[F // 2:].mean(), tg[F // 2:].mean()
+    print("incremental updates, %d frames of %d pings, window %d: per update %.2f ms (first half %.2f, second half %.2f); global updates %.2f ms (%.2f -> %.2f); "
+          "one batch solve %.2f ms; online run %.1f ms windowed + %.2f ms final global update vs %.1f ms of global updates; objective batch %.6e, windowed %.6e, "
+          "after the final update %.6e (%d LM iterations; cold batch: %d)"
+          % (F, N, W, 1e3 * tw.mean(), 1e3 * tw[:F // 2].mean(), 1e3 * late_w, 1e3 * tg.mean(), 1e3 * tg[:F // 2].mean(), 1e3 * late_g, 1e3 * t_batch,
+             1e3 * tw.sum(), 1e3 * t_polish, 1e3 * tg.sum(), e_b, e_w, e_p, p_stats[0], b_stats[0]))
+    assert late_w < 0.8 * late_g                              # a window does not pay for the frames behind it
+    assert tw[F // 2:].mean() < 1.5 * tw[W + 1:F // 2].mean() # ... and does not grow with the survey
+    assert e_w < 1.10 * e_b and np.abs(w_out[:, 9:] - b_out[:, 9:]).max() < 0.5
+    assert e_p <= e_b * (1 + 1e-3) and p_stats[0] <= b_stats[0]
+    # tightened: the final global update ends AT the batch optimum
+    mp_, op_, mt_, pg_ = ctx.default_params()
+    pg_.rel_tol = 1e-13; pg_.abs_tol = 1e-13; pg_.max_iters = 100
+    ctx.set_params(pg=pg_)
+    tight_o, _, _ = ctx.posegraph_update(F, F * N)
+    tight_b, _ = ctx.posegraph_solve_edges(dr, b_edges)
+    e_o = orc.pg_error_at(dr, b_edges, tight_o); e_t = orc.pg_error_at(dr, b_edges, tight_b)
+    assert abs(e_o - e_t) <= 1e-9 * e_t and np.abs(tight_o[:, 9:] - tight_b[:, 9:]).max() < 1e-7
+    pipe.close()
+

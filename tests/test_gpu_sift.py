@@ -27,7 +27,7 @@ def _sift_mode(ctx, l2=True, **orb):
     return op, mt
 
 
-@pytest.mark.parametrize("shape,kw", [((700, 480), {}), ((333, 256), dict(nfeatures=500, nlevels=4)), ((1000, 512), dict(nfeatures=3000))])
+@pytest.mark.parametrize("shape,kw", [((700, 480), {}), ((640, 400), dict(nfeatures=500, nlevels=4)), ((1000, 512), dict(nfeatures=3000))])
 def test_sift_rows_bit_exact_vs_oracle(ctx, orc, shape, kw):
     """every keypoint of every pyramid level, border keypoints included (19 px from the edge: the window is clipped there)"""
     from diasss_amd.synth import Survey
