@@ -342,6 +342,41 @@ def main():
                               "hbm_GBs": (tr[0] * pm["match"][1] / sec / 1e9) if tr else None,
                               "note": "every keypoint of a against every keypoint of b over the active pairs (gate in f64, then the 256-bit Hamming distance), descriptor tiles staged in LDS; "
                                       "bound by its integer issue slots, not by bytes: SURVEY 8(d) K9 prices it against lanes x clock / 30 operations"}
+    # ---- side leg: N4 of SURVEY 8f -- the 128-float descriptor of the reference's SIFT call site and its L2 matcher (dsss_sift.hip, match_*<2>), on
+    # the same survey: extraction with DSSS_DESC_SIFT128, matching with use_l2 = 2.  Outside the timed region; the context goes back to the
+    # ORB / Hamming configuration (and to its features and matches) afterwards.
+    sift_leg = None
+    if not args.no_roofline and world == 1 and not big:
+        from diasss_amd import capi as _capi
+        mp_, op_, mt_, pg_ = pipe.ctx.default_params()
+        if wl.get("nfeatures"):
+            op_.nfeatures = wl["nfeatures"]
+        op_s = type(op_).from_buffer_copy(op_); mt_s = type(mt_).from_buffer_copy(mt_)
+        op_s.descriptor = _capi.DESC_SIFT128; mt_s.use_l2 = 2
+        try:
+            pipe.ctx.set_params(orb=op_s, match=mt_s)
+            pipe.set_frames(survey); pipe.extract(); pipe.match(); barrier()          # first use: the 128-byte store
+            pipe.ctx.profile(True); pipe.ctx.profile_reset()
+            t_s = time.perf_counter()
+            pipe.set_frames(survey); pipe.extract(); barrier()
+            t_e = time.perf_counter()
+            pipe.match(); barrier()
+            t_m = time.perf_counter()
+            ps = pipe.ctx.profile_get(); pipe.ctx.profile(False)
+            rows_s, kp7_s = pipe.ctx.match_total()
+            nkp_s = int(sum(pipe.ctx.features_get(f)[0].shape[0] for f in range(F)))
+            k_ms = ps["sift"][0]
+            sift_leg = {"kernel": "sift_desc_kernel", "ms": k_ms, "keypoints_pre_filter": int(F * op_s.nfeatures), "keypoints": nkp_s,
+                        "algorithmic_bytes": ps["sift"][2], "algorithmic_GBs": ps["sift"][2] / (k_ms * 1e-3) / 1e9 if k_ms > 0 else None,
+                        "us_per_keypoint": 1e3 * k_ms / max(1, F * op_s.nfeatures),
+                        "extract_wall_ms_with_sift": 1e3 * (t_e - t_s), "match_l2_128_ms": ps["match"][0], "match_lc_wall_ms": 1e3 * (t_m - t_e),
+                        "match_rows": int(rows_s), "lc_problems": int(kp7_s),
+                        "note": "one workgroup per keypoint: 71 x 71 window of the level image, 13-tap 8.8 blur, 57 x 57 samples (gradient, fastAtan2, sqrt, table weight, "
+                                "trilinear shares into a 2^-12 fixed-point histogram by LDS atomics), integer normalisation; rows bit-exact vs oracle/orc_sift.c "
+                                "(tests/test_gpu_sift.py).  An optional mode (dsss_orb_params.descriptor = DSSS_DESC_SIFT128), not part of `value`"}
+        finally:
+            pipe.ctx.set_params(orb=op_, match=mt_)
+            pipe.run(survey); barrier()
     # ---- the dependent chains of the factorisation: what the LM trials would cost if every level took only its longest chain of dependent
     # f64 operations (constants from the in-kernel stamps and tools/ubench/mfma_f64, see DESIGN.md "critical path")
     crit = None
@@ -450,7 +485,7 @@ def main():
                        "pg_stats": [float(s) for s in stats] if stats is not None else None,
                        "parallelism": "contiguous frame blocks over %d rank(s): RCCL all-gather of features, pairs to the owner of the target frame, pose graph sharded with one RCCL all-reduce of the reduced Hessian per LM trial" % world},
             "roofline": roof, "roofline_stages": roof_groups, "roofline_all_kernels": roof_all, "breakdown_ms": breakdown, "work_per_step": work, "pcie_inclusive": pcie, "throughput_surveys_in_flight": inflight,
-            "match_allpairs": match_allpairs,
+            "match_allpairs": match_allpairs, "sift128": sift_leg,
         }
         if crit is not None:      # the dependent-chain floor belongs to the factorisation stage; the headline carries it when that stage IS the headline
             if roof_groups and roof_groups.get("pg_factor"):

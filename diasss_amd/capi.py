@@ -21,7 +21,7 @@ LC_DTYPE = np.dtype([("rel", "<f8", (12,)), ("var", "<f8", (6,)), ("score", "<f8
 LCEDGE_DTYPE = np.dtype([("a", "<i4"), ("b", "<i4"), ("rel", "<f8", (12,)), ("var", "<f8", (6,))])
 
 K_NAMES = ["row_reduce", "pre_misc", "normalize", "pyramid", "fast", "fast_compact", "desc", "filter", "match", "scc", "rows", "lc", "pg",
-           "quadtree", "pg_acc", "pg_diag", "pg_trsm", "pg_bwd", "pg_subtree", "pg_asm", "pg_comm", "pg_rsu", "match_done"]
+           "quadtree", "pg_acc", "pg_diag", "pg_trsm", "pg_bwd", "pg_subtree", "pg_asm", "pg_comm", "pg_rsu", "match_done", "sift"]
 
 
 class MaskParams(C.Structure):

@@ -1239,8 +1239,9 @@ static int extract_frames_impl(dsss_ctx* c, const int* ids, int n, bool keep_tap
           for (int k = 0; k < 2; ++k) if (qt_used[k]) { HIPCHK(c, hipEventRecord(c->ex_side_ev[k], s_qt[k])); HIPCHK(c, hipStreamWaitEvent(st, c->ex_side_ev[k], 0)); }
           dsss_launch_quadtree_collect(st, d_fr, nb); }
         { dsss_scope sc(c, DSSS_K_DESC, (double)nb * c->op.nfeatures * (49.0 * 49.0 + 56.0));
-          hipLaunchKernelGGL(orient_desc_kernel, dim3((c->kcap + 3) / 4, nb), dim3(256), 0, st, d_exf);
-          if (sift) dsss_launch_sift_desc(c, st, d_exf, c->kcap, nb); }      // N4: the 128-element rows at the same keypoints (dsss_sift.hip)
+          hipLaunchKernelGGL(orient_desc_kernel, dim3((c->kcap + 3) / 4, nb), dim3(256), 0, st, d_exf); }
+        if (sift) { dsss_scope sc(c, DSSS_K_SIFT, (double)nb * c->op.nfeatures * (71.0 * 71.0 + 128.0));
+          dsss_launch_sift_desc(c, st, d_exf, c->kcap, nb); }               // N4: the 128-element rows at the same keypoints (dsss_sift.hip)
         HIPCHK(c, hipGetLastError());
         }       // doA
         if (!doB) return DSSS_OK;                    // (phase 1: one batch)

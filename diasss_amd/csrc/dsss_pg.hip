@@ -836,9 +836,22 @@ static int pg_solve_impl(dsss_ctx* c, const double* dr6, int total, const dsss_l
     } while (iters < c->pg.max_iters && !((err <= 0) || ((cur - err) / cur <= c->pg.rel_tol) || ((cur - err) <= c->pg.abs_tol)) && std::isfinite(cur));
     const auto T4 = std::chrono::steady_clock::now();
     const double t_lm = ms_since(T3);
-    if (world > 1) {    // every rank holds its own poses (and the interface): zero the rest, sum -> the whole trajectory everywhere
-        hipLaunchKernelGGL(pg_mask_own_kernel, dim3((n + 255) / 256), dim3(256), 0, st, n, d_X, mp0, mp1);
-        int rc2 = dsss_comm_allreduce(c, (double*)d_X, (size_t)n * 12, st); if (rc2) { abandon(); return rc2; }
+    if (world > 1) {
+        // every rank holds the final values of its own poses [mp0, mp1): ONE all-gather of equal slices (the longest rank's range; own slice in
+        // place) and a copy per rank put the whole trajectory everywhere.  (Rounds 2 - 5 zeroed the others' poses and all-reduced all n x 12
+        // doubles: a ring moves twice the bytes for a sum of zeros -- 38.4 MB per step at C3, the largest collective of a step by far.)
+        size_t maxlen = 0;
+        std::vector<int> r_lo(world), r_len(world);
+        for (int r = 0; r < world; ++r) {
+            r_lo[r] = pbound[(int)((long long)nparts * r / world)]; r_len[r] = pbound[(int)((long long)nparts * (r + 1) / world)] - r_lo[r];
+            maxlen = std::max(maxlen, (size_t)r_len[r]);
+        }
+        const size_t slice = maxlen * sizeof(pose_t);
+        char* d_gath; TRY(dv.alloc(c, &d_gath, slice * (size_t)world));
+        HCK(hipMemcpyAsync(d_gath + slice * (size_t)rank, d_X + mp0, (size_t)(mp1 - mp0) * sizeof(pose_t), hipMemcpyDeviceToDevice, st));
+        { int rc2 = dsss_comm_allgather(c, d_gath, slice, st); if (rc2) { abandon(); return rc2; } }
+        for (int r = 0; r < world; ++r)
+            if (r != rank && r_len[r] > 0) HCK(hipMemcpyAsync(d_X + r_lo[r], d_gath + slice * (size_t)r, (size_t)r_len[r] * sizeof(pose_t), hipMemcpyDeviceToDevice, st));
     }
     static_assert(sizeof(pose_t) == 12 * sizeof(double), "pose_t layout");
     if (c->pg_online) {

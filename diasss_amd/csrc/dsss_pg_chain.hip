@@ -599,13 +599,6 @@ __global__ void pg_comm_scal_kernel(const double* __restrict__ scal, const int* 
     if (threadIdx.x < 3) red[threadIdx.x] = scal[threadIdx.x];
     if (threadIdx.x == 3) red[3] = (double)*fail;
 }
-__global__ __launch_bounds__(256) void pg_mask_own_kernel(int n, pose_t* __restrict__ X, int mp0, int mp1)
-{
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= n || (i >= mp0 && i < mp1)) return;
-    for (int a = 0; a < 9; ++a) X[i].R[a] = 0.0;
-    for (int a = 0; a < 3; ++a) X[i].t[a] = 0.0;
-}
 
 __global__ __launch_bounds__(256) void pg_sep_delta_kernel(int ns, const int* __restrict__ sep_pose, const int* __restrict__ perm,
                                                            const double* __restrict__ x, double* __restrict__ delta)

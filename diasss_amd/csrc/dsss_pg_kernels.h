@@ -45,7 +45,6 @@ __global__ void pg_scatter_lc_kernel(int n, int ne, int ns, const double* __rest
 __global__ void pg_comm_pack_kernel(const int* __restrict__ it_child, const int* __restrict__ it_row, const pg_pack* __restrict__ PK);
 __global__ void pg_comm_xif_kernel(int nif, const int* __restrict__ if_sep, const int* __restrict__ perm, const double* __restrict__ x_if, double* __restrict__ x);
 __global__ void pg_comm_scal_kernel(const double* __restrict__ scal, const int* __restrict__ fail, double* __restrict__ red);
-__global__ void pg_mask_own_kernel(int n, pose_t* __restrict__ X, int mp0, int mp1);
 __global__ void pg_sep_delta_kernel(int ns, const int* __restrict__ sep_pose, const int* __restrict__ perm, const double* __restrict__ x, double* __restrict__ delta);
 template <bool FROMJ> __global__ void pg_backsub_kernel(int nseg, const int* __restrict__ seg_order, const int* __restrict__ sep_pose, const double* __restrict__ C, const double* __restrict__ E, const double* __restrict__ Dl, const double* __restrict__ gi, double* __restrict__ delta, int mp0, int mp1, const double* __restrict__ Jf, pg_weights W);
 __global__ void pg_linerr_kernel(int n, int ne, pg_weights W, const int* __restrict__ ea, const int* __restrict__ eb, const int* __restrict__ eo, const double* __restrict__ ew, const double* __restrict__ r, const double* __restrict__ Ji, const double* __restrict__ delta, double* __restrict__ partial, int mp0, int mp1);

@@ -267,7 +267,8 @@ int dsss_host_pg_solve(int ns, const int32_t* edge_a, const int32_t* edge_b, int
 #define DSSS_K_PG_COMM     20   /* the reduced-Hessian all-reduce of a trial (work = bytes) */
 #define DSSS_K_PG_RSU      21   /* pg_front_rsu_kernel: row solve + trailing update fused per tile (the levels with few tiles) */
 #define DSSS_K_MATCH_DONE 22   /* no kernel of its own: work = the gate evaluations the matcher actually performed (its geo grid skips the cells out of reach; DSSS_K_MATCH's work is the reference's Na x Nb) */
-#define DSSS_K_COUNT       23
+#define DSSS_K_SIFT       23   /* sift_desc_kernel (DSSS_DESC_SIFT128): work = bytes of the 71 x 71 raw windows read + the 128-byte rows written */
+#define DSSS_K_COUNT       24
 int dsss_profile_enable(dsss_ctx*, int on);
 int dsss_profile_get(dsss_ctx*, double* ms_host /*DSSS_K_COUNT*/, int64_t* launches_host /*DSSS_K_COUNT*/);
 int dsss_profile_reset(dsss_ctx*);
