@@ -195,6 +195,7 @@ def main():
     ap.add_argument("--workload", default=os.environ.get("DSSS_WORKLOAD", "C3"), choices=sorted(WORKLOADS))
     ap.add_argument("--cpu-frames", type=int, default=24, help="frames in the CPU baseline sample (0 = skip); 24 frames of C3 are about 10 s of one core")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-side-legs", action="store_true", help="skip the legs that run extra passes after the timed steps (all-pairs matcher, SIFT descriptor): a kernel trace of the command then ends with the timed steps and the profiled pass")
     ap.add_argument("--pcie-steps", type=int, default=2, help="steps of the PCIe-inclusive leg (raw frames in page-locked host memory); 0 = skip")
     ap.add_argument("--jobs-in-flight", type=int, default=4, help="surveys overlapped in the extra throughput leg (1 = skip); the rate saturates at four on one MI355X")
     ap.add_argument("--pg-partitions", type=int, default=0, help="cut the pose graph into this many contiguous blocks of frames on the rank(s) present (dsss_set_pg_partitions): the layout of a "
@@ -315,7 +316,7 @@ def main():
     # which is timed here on the same features so that it keeps a measured number of its own.  Outside the timed region; the state of the
     # context is put back by matching once more under the default.
     match_allpairs = None
-    if not args.no_roofline and world == 1 and not big:
+    if not args.no_roofline and not args.no_side_legs and world == 1 and not big:
         os.environ["DSSS_MT_GRID"] = "0"
         try:
             pipe.ctx.match_pairs(pipe.src, pipe.tgt); barrier()
@@ -346,7 +347,7 @@ def main():
     # the same survey: extraction with DSSS_DESC_SIFT128, matching with use_l2 = 2.  Outside the timed region; the context goes back to the
     # ORB / Hamming configuration (and to its features and matches) afterwards.
     sift_leg = None
-    if not args.no_roofline and world == 1 and not big:
+    if not args.no_roofline and not args.no_side_legs and world == 1 and not big:
         from diasss_amd import capi as _capi
         mp_, op_, mt_, pg_ = pipe.ctx.default_params()
         if wl.get("nfeatures"):
