@@ -126,10 +126,6 @@ void dsss_destroy(dsss_ctx* c)
     if (c->xch_host) hipHostFree(c->xch_host);
     if (c->pg_stage) hipHostFree(c->pg_stage);
     if (c->pg_scal_host) hipHostFree(c->pg_scal_host);
-    if (c->pg_nd_stream) hipStreamDestroy(c->pg_nd_stream);
-    if (c->pg_nd_host) hipHostFree(c->pg_nd_host);
-    if (c->pg_nd_dep) hipEventDestroy(c->pg_nd_dep);
-    if (c->pg_nd_done) hipEventDestroy(c->pg_nd_done);
     if (c->pg_warm) hipFree(c->pg_warm);
     if (c->geoms && c->geoms_free) c->geoms_free(c->geoms);
     if (c->ex_pinned) hipHostFree(c->ex_pinned);

@@ -131,8 +131,6 @@ struct dsss_ctx {
     double* pg_scal_host = nullptr;                             // page-locked landing place of the LM trial's scalars (8 doubles)
     std::vector<int> pg_last_levels;                            // schedule of the last solve, four ints per panel level: items, widest panel (scalar columns), tallest rows below, this rank's or the interface's (dsss_posegraph_schedule_get)
     int pg_last_trials = 0;                                     // factorisations of the last solve
-    hipStream_t pg_nd_stream = nullptr;                         // its own stream, highest priority: a chain of short launches beside the bandwidth kernels of the solve's first linearisation
-    int* pg_nd_host = nullptr; size_t pg_nd_host_cap = 0; hipEvent_t pg_nd_dep = nullptr, pg_nd_done = nullptr;      // device ordering (dsss_pg_nd.hip): page-locked landing place of the order and the top of its tree, its two events
     void* pg_stage = nullptr; size_t pg_stage_cap = 0;          // page-locked staging of the analysis tables: one upload per solve (pg_dev::flush)
     // online use (dsss_posegraph_update): the estimate of the previous update stays on the device, the LC edges accumulate
     void* pg_warm = nullptr; size_t pg_warm_cap = 0; int pg_warm_n = 0;   // pose_t[pg_warm_n]

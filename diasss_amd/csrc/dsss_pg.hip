@@ -17,7 +17,6 @@
 #include "dsss_internal.h"
 #include <utility>
 #include "dsss_pg_kernels.h"
-#include "dsss_pg_nd.h"
 #include <algorithm>
 #include <numeric>
 #include <random>
@@ -239,50 +238,14 @@ static int pg_solve_impl(dsss_ctx* c, const double* dr6, int total, const dsss_l
     std::promise<void> lists_prom; std::future<void> lists_fut = lists_prom.get_future(); bool lists_signalled = false;
     std::promise<void> coords_prom; std::future<void> coords_fut = coords_prom.get_future();
     bool bottom_signalled = false;
-    // the ordering on the device (dsss_pg_nd.hip): one partition, at most 65 536 separators; DSSS_PG_ND=host keeps it on the host
-    // (round 5: the host ordering has a cut candidate the device kernels do not have yet -- the cheapest cut of the chain order, which
-    // takes C3 from 29 panel levels to 12 -- and is the default; DSSS_PG_ND_INDEX=0 switches that candidate off and, with it, the device
-    // ordering back on)
-    const bool chain_cuts = !(getenv("DSSS_PG_ND_INDEX") && atoi(getenv("DSSS_PG_ND_INDEX")) == 0);
-    const bool dev_nd = !chain_cuts && nparts == 1 && ns >= 2 && ns <= 65536 && !(getenv("DSSS_PG_ND") && !strcmp(getenv("DSSS_PG_ND"), "host"));
-    pg_nd_buffers ndB; bool nd_ok = false, nd_started = false; size_t nd_sets_cap = 0; int nd_edges_cap = 0;
-    std::promise<void> nd_ready_prom; std::future<void> nd_ready_fut = nd_ready_prom.get_future();
+    // (Rounds 4 - 5 also had the ordering on the device, dsss_pg_nd.hip: coordinate medians only.  The chain-order cut of round 5 -- 12 panel
+    // levels instead of 29 at C3 -- exists on the host only, the device kernels were off by default from then on and were removed in round 6.)
     std::thread sym_thread([&] {
         pg_sym_opts opt; opt.threads = sym_threads(ns);
         opt.on_bottom_ready = [&] { bottom_signalled = true; bottom_prom.set_value(); };
         opt.on_lists_ready = [&] { lists_signalled = true; lists_prom.set_value(); };
         opt.before_order = [&] { coords_fut.wait(); };
         opt.lists_on_device = true;                          // (the bins' update lists, update map and root-boundary indices: built on the device, below)
-        if (dev_nd) {
-            opt.device_order_start = [&](const std::vector<std::pair<int, int>>& ed, int leaf, int both_axes) {
-                nd_ready_fut.wait();                             // the main thread has allocated the buffers and queued the coordinates
-                if (!nd_ok) return;
-                static_assert(sizeof(std::pair<int, int>) == 2 * sizeof(int), "reduced edges are pairs of ints");
-                if (hipSetDevice(c->device) != hipSuccess || hipStreamWaitEvent(c->pg_nd_stream, c->pg_nd_dep, 0) != hipSuccess) { (void)hipGetLastError(); return; }
-                ndB.nlev = pg_nd_levels(ns, leaf);
-                if (pg_nd_set_count(ndB.nlev) > nd_sets_cap || (int)ed.size() > nd_edges_cap) return;
-                nd_started = pg_nd_start(c, c->pg_nd_stream, ndB, reinterpret_cast<const int*>(ed.data()), (int)ed.size(), leaf, both_axes) == DSSS_OK;
-            };
-            opt.device_order_finish = [&](std::vector<int>& order, std::vector<int>& top6) -> bool {
-                if (!nd_started) return false;
-                if (hipEventSynchronize(ndB.done) != hipSuccess) { (void)hipGetLastError(); return false; }
-                if (ndB.h_sets[0].lo != 0) return false;              // (the failure flag of the level kernels)
-                {   // the order must be a permutation of the separators before the symbolic phase may index with it: a position nobody
-                    // filled (the levels did not suffice) or a separator placed twice sends the solve to the host ordering
-                    std::vector<unsigned long long> seen(((size_t)ns + 63) / 64, 0ull);
-                    for (int i = 0; i < ns; ++i) {
-                        const unsigned v = (unsigned)ndB.h_order[i];
-                        if (v >= (unsigned)ns) return false;
-                        unsigned long long& w = seen[v >> 6]; const unsigned long long bit = 1ull << (v & 63);
-                        if (w & bit) return false;
-                        w |= bit;
-                    }
-                }
-                order.assign(ndB.h_order, ndB.h_order + ns);
-                top6.assign(reinterpret_cast<const int*>(ndB.h_sets), reinterpret_cast<const int*>(ndB.h_sets) + 64 * 6);
-                return true;
-            };
-        }
         for (int k = 0; k + 1 < ns; ++k) redges.push_back({ k, k + 1 });      // the reduced graph: the chain of the separators, then the loop closures
         for (int e = 0; e < ne; ++e) redges.push_back({ sidx(ea[e]), sidx(eb[e]) });
         const double bin_cost = getenv("DSSS_PG_BIN_COST") ? atof(getenv("DSSS_PG_BIN_COST")) : 600;   // ~ update-list iterations + 20 per column; measured optimum at C3 (500-700)
@@ -296,16 +259,14 @@ static int pg_solve_impl(dsss_ctx* c, const double* dr6, int total, const dsss_l
     });
     struct pg_joiner { std::thread& t; ~pg_joiner() { if (t.joinable()) t.join(); } } sym_join{ sym_thread };      // every return path waits for the thread before its data goes away
     struct pg_coords_guard { std::promise<void>& p; bool done = false; void set() { if (!done) { done = true; p.set_value(); } } ~pg_coords_guard() { set(); } } coords_guard{ coords_prom };
-    pg_coords_guard nd_guard{ nd_ready_prom };                 // (an error exit before the buffers exist releases the analysis thread too: nd_ok stays false)      // (an error exit must not leave the thread waiting)
     // device state
     pg_dev dv;
     int rc = DSSS_OK;
     // every error exit: let the analysis thread go, wait for it AND for what it queued on the ordering's stream, and only then hand the
     // arena back (released first, the next solve could reuse memory the ordering's kernels of this one still write)
     auto abandon = [&] {
-        coords_guard.set(); nd_guard.set();
+        coords_guard.set();
         if (sym_thread.joinable()) sym_thread.join();
-        if (c->pg_nd_stream && hipStreamSynchronize(c->pg_nd_stream) != hipSuccess) (void)hipGetLastError();
         dv.release();
     };
 #define TRY(x) do { rc = (x); if (rc) { abandon(); return rc; } } while (0)
@@ -335,33 +296,6 @@ static int pg_solve_impl(dsss_ctx* c, const double* dr6, int total, const dsss_l
         if (e == hipSuccess) { hipLaunchKernelGGL(pg_sep_xy_kernel, dim3((ns + 255) / 256), dim3(256), 0, c->stream, ns, d_sep, d_dr6, d_sxy); e = hipGetLastError(); }
         if (e != hipSuccess) { abandon(); HIPCHK(c, e); }
     }
-    if (dev_nd) {   // buffers of the device ordering (this thread owns the arena), the event its stream waits for, then the analysis thread may queue it
-        const int ne_red = (ns - 1) + ne, nlev_max = pg_nd_levels(ns, 4);       // (levels: sized for a leaf of 4, the smallest DSSS_PG_LEAF makes sense with)
-        ndB.n = ns; ndB.sxy = d_sxy;
-        TRY(dv.alloc(c, &ndB.edges, (size_t)2 * ne_red)); TRY(dv.alloc(c, &ndB.deg, (size_t)ns)); TRY(dv.alloc(c, &ndB.adj_ptr, (size_t)ns + 1)); TRY(dv.alloc(c, &ndB.adj_cur, (size_t)ns));
-        TRY(dv.alloc(c, &ndB.adj_idx, (size_t)2 * ne_red)); TRY(dv.alloc(c, &ndB.rank_x, (size_t)ns)); TRY(dv.alloc(c, &ndB.rank_y, (size_t)ns)); TRY(dv.alloc(c, &ndB.perm0, (size_t)ns));
-        TRY(dv.alloc(c, &ndB.perm1, (size_t)ns)); TRY(dv.alloc(c, &ndB.setid, (size_t)ns)); TRY(dv.alloc(c, &ndB.order, (size_t)ns)); TRY(dv.alloc(c, &ndB.cut0, (size_t)ns)); TRY(dv.alloc(c, &ndB.cut1, (size_t)ns * 4));      // (cut1: the packed ranks, four bytes per node)
-        nd_sets_cap = pg_nd_set_count(nlev_max); nd_edges_cap = ne_red;
-        TRY(dv.alloc(c, &ndB.sets, nd_sets_cap + 4096));      // (+ 96 KB behind the sets: the histograms of the rank kernels, the per-set records of the big levels)
-        const size_t host_ints = (size_t)ns + 64 * 6 + 16;
-        if (c->pg_nd_host_cap < host_ints) {
-            if (c->pg_nd_host) hipHostFree(c->pg_nd_host);
-            c->pg_nd_host = nullptr; c->pg_nd_host_cap = 0;
-            hipError_t e = hipHostMalloc((void**)&c->pg_nd_host, (host_ints + host_ints / 2) * sizeof(int), hipHostMallocDefault);
-            if (e != hipSuccess) { abandon(); HIPCHK(c, e); }
-            c->pg_nd_host_cap = host_ints + host_ints / 2;
-        }
-        ndB.h_sets = reinterpret_cast<pg_nd_set*>(c->pg_nd_host); ndB.h_order = c->pg_nd_host + 64 * 6 + 16;
-        hipError_t e = hipSuccess;
-        if (!c->pg_nd_stream) { int lo = 0, hi = 0; (void)hipDeviceGetStreamPriorityRange(&lo, &hi); e = hipStreamCreateWithPriority(&c->pg_nd_stream, hipStreamNonBlocking, hi); }
-        if (e == hipSuccess && !c->pg_nd_dep) e = hipEventCreateWithFlags(&c->pg_nd_dep, hipEventDisableTiming);
-        if (e == hipSuccess && !c->pg_nd_done) e = hipEventCreateWithFlags(&c->pg_nd_done, hipEventDisableTiming);
-        if (e == hipSuccess) e = hipEventRecord(c->pg_nd_dep, c->stream);        // behind pg_sep_xy_kernel
-        if (e != hipSuccess) { abandon(); HIPCHK(c, e); }
-        ndB.done = c->pg_nd_done;
-        nd_ok = true;
-    }
-    nd_guard.set();
     const double t_prep0 = ms_since(T0);
     {   // the coordinates come back while the analysis builds its adjacency: hand them over
         hipError_t e = hipMemcpyAsync(sxy.data(), d_sxy, sxy.size() * sizeof(double), hipMemcpyDeviceToHost, c->stream);

@@ -466,8 +466,6 @@ void pg_symbolic(int ns, const std::vector<std::pair<int, int>>& edges, int ncha
     auto tms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
     const auto q0 = tnow();
     const int T = std::max(1, opt.threads);
-    const bool dev_nd = opt.device_order_start && opt.device_order_finish && S.nparts <= 1 && ns >= 2 && ns <= 65536;
-    if (dev_nd) opt.device_order_start(edges, opt.leaf, opt.nd_both_axes);
     // adjacency in CSR form, rows sorted and deduplicated
     std::vector<int> adj_ptr(ns + 1, 0), adj_idx;
     {   // rows are tiny (two chain neighbours + the loop closures of the pose): insertion sort and duplicate removal in place, rows
@@ -498,30 +496,7 @@ void pg_symbolic(int ns, const std::vector<std::pair<int, int>>& edges, int ncha
     std::vector<nd_tree> pool; std::mutex mu;
     std::vector<char> iface(ns, 0);
     int root = -1;
-    bool ordered = false;
-    if (dev_nd) {
-        std::vector<int> top;
-        if (opt.device_order_finish(S.order, top) && (int)S.order.size() == ns && top.size() >= 64 * 6) {
-            // the top of the recursion tree as nd_order would have left it: nodes down to depth PG_ND_PAR, children only below the sets the
-            // host would have forked at (depth < PG_ND_PAR and more than 2048 nodes)
-            std::function<int(int, int)> build = [&](int h, int depth) -> int {
-                if (depth > PG_ND_PAR || h >= 64) return -1;
-                const int* d = top.data() + 6 * (size_t)h;
-                const int size = d[1], kind = d[3];
-                int a = -1, b = -1;
-                if (kind == 2 && depth < PG_ND_PAR && size > 2048) { a = build(2 * h, depth + 1); b = build(2 * h + 1, depth + 1); }
-                pool.push_back({ a, b, size });
-                return (int)pool.size() - 1;
-            };
-            root = build(1, 0);
-            ordered = true;
-        } else S.order.clear();
-        if (tv) fprintf(stderr, "[dsss pg symbolic] ordering on the device: %s (waited %.2f ms for it after the adjacency)\n", ordered ? "used" : "NOT used, the host orders", tms(q0a, tnow()));
-    }
-    const bool nd_check = ordered && getenv("DSSS_PG_ND") && !strcmp(getenv("DSSS_PG_ND"), "check");      // diagnostic: order on the host as well and compare
-    std::vector<int> dev_order; std::vector<nd_tree> dev_pool; int dev_root = -1;
-    if (nd_check) { dev_order.swap(S.order); dev_pool.swap(pool); dev_root = root; root = -1; ordered = false; }
-    if (!ordered) {
+    {
         std::vector<int> nodes(ns); std::iota(nodes.begin(), nodes.end(), 0);
         std::vector<char> side(ns, 0), side2(ns, 0);
         S.order.reserve(ns);
@@ -533,14 +508,6 @@ void pg_symbolic(int ns, const std::vector<std::pair<int, int>>& edges, int ncha
         nd_ctx C{ adj_ptr.data(), adj_idx.data(), cx, cy, side.data(), side2.data(), opt.leaf, opt.nd_both_axes, opt.nd_geo_first, S.nparts > 1 ? part : nullptr, iface.data(), forced.data(), &pool, &mu, tv ? nd_ns : nullptr, opt.nd_index_cuts != 0, pos_scratch.data(), T };
         root = nd_order(nodes, C, S.order, 0);
         if (tv) fprintf(stderr, "[dsss pg symbolic] nd_order thread-time: candidates %.2f ms, final boundary %.2f ms, leaves %.2f ms\n", nd_ns[1] / 1e6, nd_ns[2] / 1e6, nd_ns[4] / 1e6);
-    }
-    if (nd_check) {
-        int bad = -1;
-        for (int i = 0; i < ns; ++i) if (dev_order[i] != S.order[i]) { bad = i; break; }
-        if (bad >= 0) fprintf(stderr, "[dsss pg symbolic] DEVICE ORDER DIFFERS from the host's at position %d of %d: %d against %d (x %.17g y %.17g | x %.17g y %.17g)\n", bad, ns, dev_order[bad], S.order[bad],
-                              cx[dev_order[bad]], cy[dev_order[bad]], cx[S.order[bad]], cy[S.order[bad]]);
-        else fprintf(stderr, "[dsss pg symbolic] device order == host order (%d nodes)\n", ns);
-        (void)dev_root;
     }
     const auto q1 = tnow();
     S.perm.assign(ns, 0);

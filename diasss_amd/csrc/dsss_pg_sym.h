@@ -109,7 +109,7 @@ void pg_build_schedule(const pg_sym& S, int part_lo, int part_hi, pg_sched& out)
 struct pg_sym_opts {
     int leaf = 24;                      // nested-dissection leaf size
     int nd_both_axes = 64;              // node sets of at least this size try the median cut along both axes and keep the smaller separator
-    int nd_index_cuts = 1;              // a third cut candidate of every node set: the cheapest cut of the CHAIN ORDER with both sides between a third and two thirds of the set (dsss_pg_sym.cpp, nd_order).  0 = coordinate medians only: the ordering the device kernels of dsss_pg_nd.hip reproduce
+    int nd_index_cuts = 1;              // a third cut candidate of every node set: the cheapest cut of the CHAIN ORDER with both sides between a third and two thirds of the set (dsss_pg_sym.cpp, nd_order).  0 = coordinate medians only: the ordering of rounds 2 - 4
     bool nd_geo_first = true;           // a node set that spans several ranks may take a geometric cut when its separator is smaller than the rank cut's (its separator is interface then)
     double bin_cost = 1000;             // work bound of a binned subtree
     double pack_cost = 0;               // work bound of a BIN (several subtrees packed together); 0 = bin_cost
@@ -127,12 +127,6 @@ struct pg_sym_opts {
     // called earlier still (same conditions), as soon as the column structures, the binned flags and the subtree roots are final: all the
     // device needs to build the bins' update lists, update map and root-boundary indices itself (lists_on_device) while the host packs the bins
     std::function<void()> on_lists_ready;
-    // the ordering on the device (dsss_pg_nd.hip; one partition, at most 65 536 separators): device_order_start is called first thing with the
-    // reduced edges and the leaf / both-axes parameters and queues the whole dissection; device_order_finish blocks until it is back, fills the
-    // elimination order and the top of the recursion tree (heap nodes 1 .. 63 as {lo, size, out, kind, nA, nB}) and returns false if the host
-    // has to order after all.  The adjacency the host needs anyway is built between the two.
-    std::function<void(const std::vector<std::pair<int, int>>& edges, int leaf, int both_axes)> device_order_start;
-    std::function<bool(std::vector<int>& order, std::vector<int>& top6)> device_order_finish;
     bool lists_on_device = false;                // the caller builds the update lists, the update-map offsets and the root-boundary indices of the bins itself (dsss_pg.hip: on the device); rlptr .. anc_rel stay empty
     std::function<void()> before_order;          // called once the adjacency is built, before the first use of the coordinates (which may still be on their way)
 };

@@ -131,14 +131,14 @@ def test_posegraph_edges_api_small_cases(ctx, orc):
 
 def test_posegraph_error_exits_leave_the_context_usable(orc):
     """the error exits of the solve (an edge out of range before anything runs; a variance that is not positive or a relative pose that is not
-    finite AFTER the analysis thread has started and the device ordering / preparation is in flight) return an error, and the next solve on the
+    finite AFTER the analysis thread has started and the preparation is in flight) return an error, and the next solve on the
     same context gives the bits of a fresh one: the exit joins the analysis thread and drains its stream before the arena goes back"""
     from diasss_amd import capi
     from tests.test_gpu_configs import _lawnmower_graph
     dr, gt, edges = _lawnmower_graph(6, 3000, 800, seed=5)
     c = capi.Context(max_frames=2)
     ref, sref = c.posegraph_solve_edges(dr, edges)
-    for env in ({}, {"DSSS_PG_ND_INDEX": "0"}):                            # host ordering (default) and the device ordering
+    for env in ({}, {"DSSS_PG_ND_INDEX": "0"}):                            # with and without the chain-order cut candidate
         old = {k: os.environ.get(k) for k in env}
         os.environ.update(env)
         try:

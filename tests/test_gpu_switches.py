@@ -13,7 +13,7 @@ pytestmark = pytest.mark.gpu
 
 SAME_BITS_PG = [("DSSS_SYM_THREADS", "1"), ("DSSS_SYM_THREADS", "5")]
 SAME_OPTIMUM_PG = [("DSSS_PG_BIN_COST", "300"), ("DSSS_PG_BIN_COST", "1200"), ("DSSS_PG_ND_BOTH", "1000000"), ("DSSS_PG_LEAF", "12"),
-                   ("DSSS_PG_ND_INDEX", "0")]       # coordinate medians only: the ordering of rounds 2 - 4, run by the device kernels of dsss_pg_nd.hip
+                   ("DSSS_PG_ND_INDEX", "0")]       # coordinate medians only: the ordering of rounds 2 - 4 (no chain-order cut candidate)
 SAME_BITS_EX = [("DSSS_EX_UPLOAD_BATCH", "1"), ("DSSS_EX_UPLOAD_BATCH", "3"), ("DSSS_FS_THREADS", "1")]
 
 
@@ -41,12 +41,6 @@ def test_pose_graph_switches_reproduce_the_default():
         with _env(k, v):
             p, s = c.posegraph_solve_edges(dr, edges)
         assert s[0] == sref[0] and abs(s[2] - sref[2]) <= 1e-9 * sref[2] and np.abs(p - ref).max() < 1e-8, "%s=%s: %g" % (k, v, np.abs(p - ref).max())
-    with _env("DSSS_PG_ND_INDEX", "0"):                                   # the device ordering (coordinate medians) against the same rule on the host: the same bits
-        pd, sd = c.posegraph_solve_edges(dr, edges)
-        for v in ("host", "check"):
-            with _env("DSSS_PG_ND", v):
-                ph, sh = c.posegraph_solve_edges(dr, edges)
-            assert hashlib.sha1(ph.tobytes()).hexdigest() == hashlib.sha1(pd.tobytes()).hexdigest() and (sh == sd).all(), "DSSS_PG_ND=%s differs from the device ordering" % v
     for nparts in (4, 8):                                                # the partitioned layout on one rank (the interface is dissected too)
         c.set_pg_partitions(nparts)
         p, s = c.posegraph_solve_edges(dr, edges)
@@ -112,9 +106,9 @@ def test_matcher_switch_reproduces_the_default():
     c.close()
 
 
-def test_device_ordering_on_degenerate_geometry():
-    """the nested dissection on the device against the host's on separator coordinates chosen against it: every y equal (one bucket, one
-    extent zero), duplicated loop closures, a graph below the both-axes threshold -- the same bits"""
+def test_ordering_on_degenerate_geometry():
+    """the nested dissection on separator coordinates chosen against it: every y equal (one bucket, one extent zero), duplicated loop closures,
+    a graph below the both-axes threshold -- with and without the chain-order cut candidate: another elimination order, the same optimum"""
     from diasss_amd import capi
     from tests.test_gpu_configs import _lawnmower_graph
     c = capi.Context(max_frames=2)
@@ -123,11 +117,10 @@ def test_device_ordering_on_degenerate_geometry():
         if flat:
             dr = dr.copy(); dr[:, 4] = 0.0                                 # all poses on one line: y extent exactly zero
         edges = np.concatenate([edges, edges[: max(1, len(edges) // 7)]])   # duplicated loop closures
-        with _env("DSSS_PG_ND_INDEX", "0"):                                # (the device ordering runs when the chain-order cut candidate is off)
-            with _env("DSSS_PG_ND", "host"):
-                ph, sh = c.posegraph_solve_edges(dr, edges)
+        with _env("DSSS_PG_ND_INDEX", "0"):
             pd, sd = c.posegraph_solve_edges(dr, edges)
-        assert hashlib.sha1(pd.tobytes()).hexdigest() == hashlib.sha1(ph.tobytes()).hexdigest() and (sd == sh).all()
-        pc, sc = c.posegraph_solve_edges(dr, edges)                         # the default (chain-order cuts): another elimination order, the same optimum
+            pd2, sd2 = c.posegraph_solve_edges(dr, edges)
+        assert hashlib.sha1(pd.tobytes()).hexdigest() == hashlib.sha1(pd2.tobytes()).hexdigest() and (sd == sd2).all()
+        pc, sc = c.posegraph_solve_edges(dr, edges)                         # the default (chain-order cuts)
         assert sc[0] == sd[0] and np.abs(pc - pd).max() < 1e-8
     c.close()
