@@ -69,7 +69,18 @@ int dsss_create(int device, int max_frames, dsss_ctx** out)
     c->kcap = kcap_for(c->op);
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return DSSS_E_HIP; }
     hipEventCreate(&c->prof.e0); hipEventCreate(&c->prof.e1);
-    for (int i = 0; i < 4; ++i) { hipStreamCreateWithFlags(&c->xs[i], hipStreamNonBlocking); hipEventCreateWithFlags(&c->xev[i], hipEventDisableTiming); }
+    // xs[1] carries the uploads (geometry, host-resident frames): nothing but copies.  It gets a priority of its own so that the runtime gives it a
+    // hardware queue of its own -- streams of one priority are folded onto four hardware queues in creation order, and when the copy stream lands
+    // on the queue of the compute stream (which it did or did not depending on how many streams the process had created before this context:
+    // bench.py yes, a script that made one torch stream first no) every batch's kernels queue behind the NEXT batch's 2.4 ms of copies: the
+    // PCIe-inclusive step 95 ms instead of 77 (round 6, found with a per-batch timer: kernels behind the upload 2.7 ms against 1.2)
+    int prio_lo = 0, prio_hi = 0;
+    (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
+    for (int i = 0; i < 4; ++i) {
+        if (i == 1 && prio_hi != prio_lo) { if (hipStreamCreateWithPriority(&c->xs[i], hipStreamNonBlocking, prio_hi) != hipSuccess) { (void)hipGetLastError(); c->xs[i] = nullptr; } }
+        if (!c->xs[i]) hipStreamCreateWithFlags(&c->xs[i], hipStreamNonBlocking);
+        hipEventCreateWithFlags(&c->xev[i], hipEventDisableTiming);
+    }
     for (int i = 0; i < DSSS_MAX_LEVELS; ++i) { hipEventCreateWithFlags(&c->ex_lev_ev[i], hipEventDisableTiming); hipEventCreateWithFlags(&c->ex_cmp_ev[i], hipEventDisableTiming); }
     for (int i = 0; i < 3; ++i) hipEventCreateWithFlags(&c->ex_side_ev[i], hipEventDisableTiming);
     hipEventCreateWithFlags(&c->xev_main, hipEventDisableTiming);

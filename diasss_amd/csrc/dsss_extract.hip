@@ -1126,8 +1126,12 @@ static int extract_frames_impl(dsss_ctx* c, const int* ids, int n, bool keep_tap
     int* h_nkp = h_err + B;
     const hipStream_t st = c->stream;
 
+    const bool exv = getenv("DSSS_EX_VERBOSE") != nullptr && any_pending;
+    double tv_issue = 0, tv_sync = 0, tv_wait = 0; int tv_n = 0;
+    auto tv_now = [] { return std::chrono::steady_clock::now(); };
     for (int b0 = 0, bk = 0; b0 < n; b0 += B, ++bk) {
         const int nb = std::min(B, n - b0);
+        const auto tv0 = tv_now();
         if (any_pending) {
             if (b0 + B < n) HIPCHK(c, upload_batch(b0 + B, up_ev[(bk + 1) & 1]));      // next batch's images start moving now
             HIPCHK(c, hipStreamWaitEvent(st, up_ev[bk & 1], 0));                       // this batch's images are in HBM before its kernels read them
@@ -1251,7 +1255,12 @@ static int extract_frames_impl(dsss_ctx* c, const int* ids, int n, bool keep_tap
         if (b0 + B >= n) { const int rb = dsss_bboxes_enqueue(c); if (rb) return rb; }      // the geo boxes the matcher will ask for ride on this batch's synchronisation
         HIPCHK(c, hipMemcpyAsync(h_err, d_errs, sizeof(int) * nb, hipMemcpyDeviceToHost, st));
         HIPCHK(c, hipMemcpyAsync(h_nkp, c->nkp_dev, sizeof(int) * c->max_frames, hipMemcpyDeviceToHost, st));
+        const auto tv1 = tv_now();
+        if (exv && any_pending) { (void)hipEventSynchronize(up_ev[bk & 1]); }
+        const auto tv2 = tv_now();
         HIPCHK(c, hipStreamSynchronize(st));         // one synchronisation per batch of up to EX_BATCH frames
+        if (exv) { const auto tv3 = tv_now(); auto us = [](auto a, auto b) { return std::chrono::duration<double, std::micro>(b - a).count(); };
+                   tv_issue += us(tv0, tv1); tv_wait += us(tv1, tv2); tv_sync += us(tv2, tv3); ++tv_n; }
         for (int s = 0; s < nb; ++s) {
             dsss_frame& f = c->frames[ids[b0 + s]];
             if (h_err[s]) DSSS_FAIL(c, DSSS_E_CAPACITY, "frame %d: extraction capacity exceeded (code %d; 7 = FAST candidates, else quadtree lists)", ids[b0 + s], h_err[s]);
@@ -1280,6 +1289,7 @@ static int extract_frames_impl(dsss_ctx* c, const int* ids, int n, bool keep_tap
             }
         }
     }
+    if (exv && tv_n) fprintf(stderr, "[dsss extract] %d batches of %d: per batch host issue %.0f us, wait for the batch's upload %.0f us, kernels after it %.0f us\n", tv_n, B, tv_issue / tv_n, tv_wait / tv_n, tv_sync / tv_n);
     return DSSS_OK;
 }
 
