@@ -29,7 +29,7 @@
 
 typedef unsigned short u16x2_s __attribute__((ext_vector_type(2)));
 
-__global__ __launch_bounds__(256) void sift_desc_kernel(const ex_frame* __restrict__ frs, const float* __restrict__ wtab)
+__global__ __launch_bounds__(256) void sift_desc_kernel(const ex_frame* __restrict__ frs, const float* __restrict__ wtab, int* __restrict__ dbg, int dbg_kcap)
 {
     __shared__ __attribute__((aligned(16))) uint8_t sP[RW * RS];
     __shared__ __attribute__((aligned(16))) uint16_t sH[GW * HSS];       // (later: the list of the window's live samples)
@@ -156,7 +156,7 @@ __global__ __launch_bounds__(256) void sift_desc_kernel(const ex_frame* __restri
         const float dx = (float)((int)b[1] - (int)b[-1]);
         const float dy = (float)((int)b[-GS] - (int)b[GS]);
         const float Ori = fast_atan2_dev(dy, dx);
-        const float Mag = __fsqrt_rn(dx * dx + dy * dy);
+        const float Mag = sqrtf(dx * dx + dy * dy);      // (sqrtf, correctly rounded under hipcc's default -fhip-fp32-correctly-rounded-divide-sqrt; __fsqrt_rn is the bare v_sqrt_f32: 1 ulp)
         float obin = (Ori - ori) * bins_per_deg;
         const float mag = Mag * wtab[i * i + j * j];
         const int r0 = __float2int_rd(rbin), c0 = __float2int_rd(cbin);
@@ -190,6 +190,7 @@ __global__ __launch_bounds__(256) void sift_desc_kernel(const ex_frame* __restri
         h = sHist[idx + o];
         if (o < 2) h += sHist[idx + 8 + o];
     }
+    if (dbg && tid < 128) dbg[((size_t)blockIdx.y * dbg_kcap + k) * 128 + tid] = (int)h;
     unsigned long long s = (unsigned long long)(h * h);
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) s += __shfl_xor(s, o, 64);
@@ -216,5 +217,20 @@ __global__ __launch_bounds__(256) void sift_desc_kernel(const ex_frame* __restri
 
 void dsss_launch_sift_desc(dsss_ctx* c, hipStream_t st, const ex_frame* d_exf, int kcap, int nb)
 {
-    hipLaunchKernelGGL(sift_desc_kernel, dim3(kcap, nb), dim3(256), 0, st, d_exf, c->sift_w);
+    // DSSS_SIFT_HIST_DUMP=<file> (diagnostic, tests/test_gpu_sift.py): the raw 2^-12 fixed-point histograms of every pre-filter keypoint of the
+    // batch, int32[nb][kcap][128], written after the launch -- the parity bar UNDER the rounded bytes (a one-unit difference in one of a
+    // keypoint's 13 000 rounded shares moves an output byte only once in a few thousand keypoints: the bare v_sqrt_f32 behind __fsqrt_rn did)
+    int* dbg = nullptr;
+    const char* dump = getenv("DSSS_SIFT_HIST_DUMP");
+    if (dump && hipMalloc(&dbg, (size_t)nb * kcap * 128 * sizeof(int)) != hipSuccess) { (void)hipGetLastError(); dbg = nullptr; }
+    if (dbg) (void)hipMemsetAsync(dbg, 0, (size_t)nb * kcap * 128 * sizeof(int), st);
+    hipLaunchKernelGGL(sift_desc_kernel, dim3(kcap, nb), dim3(256), 0, st, d_exf, c->sift_w, dbg, kcap);
+    if (dbg) {
+        std::vector<int> h((size_t)nb * kcap * 128);
+        if (hipStreamSynchronize(st) == hipSuccess && hipMemcpy(h.data(), dbg, h.size() * sizeof(int), hipMemcpyDeviceToHost) == hipSuccess) {
+            FILE* fp = fopen(dump, "wb");
+            if (fp) { fwrite(h.data(), sizeof(int), h.size(), fp); fclose(fp); }
+        }
+        hipFree(dbg);
+    }
 }

@@ -78,7 +78,7 @@ def test_config_C2_full_pipeline_vs_oracle(orc):
 
 
 
-def _every_stage_vs_oracle(orc, F, N, M, seed, nfeatures=None, oracle_lm=False, min_active=300, min_lc=30000, min_edges=5000, oracle_lm_full=False):
+def _every_stage_vs_oracle(orc, F, N, M, seed, nfeatures=None, oracle_lm=False, min_active=300, min_lc=30000, min_edges=5000, oracle_lm_full=False, sift=False):
     """One survey through the whole pipeline and, stage by stage, through the oracle (its frames, pairs and mini-LMs on a thread pool:
     the C calls release the GIL): features of every frame bit-exact (geo samples included), rows and kp7 of every active pair bit-exact
     and every inactive pair empty in the oracle too, every mini-LM (same iteration count, relative pose 1e-9), the selected loop-closure
@@ -93,6 +93,15 @@ def _every_stage_vs_oracle(orc, F, N, M, seed, nfeatures=None, oracle_lm=False, 
     raws = [sv.frame(f) for f in range(F)]
     ins = [sv.inputs(f) for f in range(F)]
     pipe = Pipeline(F, nfeatures=nfeatures)
+    pm = None
+    if sift:            # the 128-float rows of the SIFT call site next to the ORB ones, and the matcher's L2 branch on them
+        from diasss_amd import capi
+        mp0_, op0_, mt0_, pg0_ = pipe.ctx.default_params()
+        if nfeatures is not None:
+            op0_.nfeatures = int(nfeatures)
+        op0_.descriptor = capi.DESC_SIFT128; mt0_.use_l2 = 2
+        pipe.ctx.set_params(orb=op0_, match=mt0_)
+        pm = orc.match_params(); pm.use_l2 = 2
     g_poses, g_stats = pipe.run(raws, [i[0] for i in ins], [i[1] for i in ins], [i[2] for i in ins])
     g_poses = g_poses.copy(); g_stats = np.array(g_stats)
     po = None
@@ -104,6 +113,9 @@ def _every_stage_vs_oracle(orc, F, N, M, seed, nfeatures=None, oracle_lm=False, 
 
     def o_frame(f):
         pose, alt, gr = ins[f]
+        if sift:
+            kps, desc, _, _, d128 = orc.detect_feature(raws[f].cpu().numpy(), None, po, sift=True)
+            return dict(pose=pose, alt=alt, gr=gr, kps=kps, desc=desc, d128=d128, geo=orc.geo_at_kps(pose, gr, M, kps), bb=orc.geo_bbox(pose, gr, M))
         kps, desc, _, _ = orc.detect_feature(raws[f].cpu().numpy(), None, po)
         return dict(pose=pose, alt=alt, gr=gr, kps=kps, desc=desc, geo=orc.geo_at_kps(pose, gr, M, kps), bb=orc.geo_bbox(pose, gr, M))
     fr = list(pool.map(o_frame, range(F)))
@@ -116,6 +128,8 @@ def _every_stage_vs_oracle(orc, F, N, M, seed, nfeatures=None, oracle_lm=False, 
         for fld in ("x", "y", "angle", "response", "octave"):
             assert (k[fld] == o["kps"][fld]).all(), "frame %d %s" % (f, fld)
         assert (g == o["geo"]).all(), "frame %d geo" % f
+        if sift:
+            assert (pipe.ctx.features_get_sift(f, cap=cap) == o["d128"].astype(np.float32)).all(), "frame %d: SIFT rows" % f
         nkp += len(k)
     src, tgt = all_pairs(F)
     t0 = time.time()
@@ -123,7 +137,8 @@ def _every_stage_vs_oracle(orc, F, N, M, seed, nfeatures=None, oracle_lm=False, 
     def o_pair(p):
         i, j = int(src[p]), int(tgt[p])
         a, b = fr[i], fr[j]
-        rows = orc.robust_matching(i, j, N, N, a["kps"], a["desc"], a["geo"], a["bb"], b["kps"], b["desc"], b["geo"], b["bb"])
+        dk = "d128" if sift else "desc"
+        rows = orc.robust_matching(i, j, N, N, a["kps"], a[dk], a["geo"], a["bb"], b["kps"], b[dk], b["geo"], b["bb"], pm)
         kp7 = orc.get_kps_pairs(rows, j, a["alt"], a["gr"], b["alt"], b["gr"])
         return rows, kp7, orc.lc_solve(kp7, a["pose"], a["alt"], a["gr"], M, b["pose"], b["alt"], b["gr"], M)
     res = list(pool.map(o_pair, range(len(src))))
@@ -209,6 +224,14 @@ def test_config_C3_full_size_every_stage_vs_oracle(orc):
     included: the oracle's OBJECTIVE at the device's initial estimate and at its answer, and (round 6) the oracle's own LM on the
     full graph -- same iterations, same objective, the trajectory at the optimum within 1e-6."""
     _every_stage_vs_oracle(orc, 200, 2000, 1024, 20240601 + 1, oracle_lm_full=True)
+
+
+def test_config_C3_full_size_sift_mode_every_stage_vs_oracle(orc):
+    """SURVEY 8f N4 at the size of BASELINE config 3: the same survey with `dsss_orb_params.descriptor = DSSS_DESC_SIFT128` and the matcher's L2 branch
+    on the 128-float rows (`use_l2 = 2`) -- ORBextractor.cpp:1043-1047,1098 + FEAmatcher.cpp:106-139 as intended.  Every frame's rows bit-exact against
+    oracle/orc_sift.c (316 k keypoints), rows / kp7 of every active pair bit-exact against the oracle's L2 matcher, every mini-LM, the selected edges,
+    and the pose graph against the oracle's objective."""
+    _every_stage_vs_oracle(orc, 200, 2000, 1024, 20240601 + 1, sift=True)
 
 
 def test_config_C5_shaped_survey_every_stage_vs_oracle(orc):

@@ -53,6 +53,45 @@ def test_sift_rows_bit_exact_vs_oracle(ctx, orc, shape, kw):
         assert (d128.max(1) > 0).all() and len(np.unique(kps["octave"])) >= 3
 
 
+def test_sift_histograms_identical_under_the_rounded_bytes(ctx, orc, tmp_path, monkeypatch):
+    """The 128 output bytes hide a one-unit difference in the 2^-12 fixed-point histogram almost always (it moves a byte once in a few thousand
+    keypoints: that is how the full-size C3 test caught a 1-ulp square root).  DSSS_SIFT_HIST_DUMP hands out the raw int32 histograms of every
+    PRE-FILTER keypoint: compared one by one with orc_sift_hist on the oracle's blurred pyramid -- every one of ~13 000 rounded shares per
+    keypoint summed to the same integers."""
+    import ctypes as C
+    from diasss_amd.synth import Survey
+    N, M = 1200, 800
+    sv = Survey(2, N, M, seed=41)
+    _sift_mode(ctx)
+    raw = sv.frame(1).numpy(); pose, alt, gr = sv.inputs(1)
+    dump = str(tmp_path / "hist.bin")
+    monkeypatch.setenv("DSSS_SIFT_HIST_DUMP", dump)
+    ctx.frame_set(0, raw, N, M, pose, alt, gr); ctx.extract(0)
+    monkeypatch.delenv("DSSS_SIFT_HIST_DUMP")
+    H = np.fromfile(dump, np.int32).reshape(-1, 128)
+    norm = orc.normalize(raw)
+    kps, desc, d128 = orc.orb_extract_sift(norm)                  # pre-filter keypoints, the order of the device's list
+    assert 500 < len(kps) <= len(H)
+    p = orc.orb_params()
+    lr = (C.c_int * 8)(); lc = (C.c_int * 8)()
+    orc.lib().orc_orb_level_sizes(N, M, C.byref(p), lr, lc)
+    pyr = [norm]
+    for l in range(1, p.nlevels):
+        nxt = np.zeros((lr[l], lc[l]), np.uint8)
+        orc.lib().orc_resize_linear_u8(orc.u8(pyr[-1]), pyr[-1].shape[0], pyr[-1].shape[1], orc.u8(nxt), lr[l], lc[l]); pyr.append(nxt)
+    blur = [orc.blur13(im) for im in pyr]
+    bad = 0
+    for i in range(len(kps)):
+        l = int(kps["octave"][i]); s = np.float32(1.0)
+        for _ in range(l):
+            s = np.float32(s * np.float32(1.2))
+        x = kps["x"][i] / s if l else kps["x"][i]; y = kps["y"][i] / s if l else kps["y"][i]
+        h = orc.sift_hist(blur[l], int(round(float(x))), int(round(float(y))), float(kps["angle"][i]))
+        bad += int((H[i] != h).any())
+    assert bad == 0, "%d of %d keypoints have another histogram" % (bad, len(kps))
+    assert (H[len(kps):] == 0).all()
+
+
 def test_sift_extract_many_equals_single_and_mode_switch(ctx, orc):
     """the batched entry point (eager start by dsss_frames_set included) gives the same rows; switching the mode off drops them"""
     from diasss_amd.synth import Survey
