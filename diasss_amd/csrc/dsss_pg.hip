@@ -426,7 +426,7 @@ static int pg_solve_impl(dsss_ctx* c, const double* dr6, int total, const dsss_l
         return DSSS_OK;
     };
     auto error_of = [&](const pose_t* Xd, double* out) -> int {
-        hipLaunchKernelGGL(pg_linearize_kernel, dim3(nblk), dim3(256), 0, st, n, ne, Xd, d_meas, W, d_ea, d_eb, d_eo, d_emeas, d_ew, (double*)nullptr, (double*)nullptr, d_part, mp0, mp1);
+        hipLaunchKernelGGL(pg_linearize_kernel<false>, dim3(nblk), dim3(256), 0, st, n, ne, Xd, d_meas, W, d_ea, d_eb, d_eo, d_emeas, d_ew, (double*)nullptr, (double*)nullptr, d_part, mp0, mp1);
         hipLaunchKernelGGL(pg_final_sum_kernel, dim3(1), dim3(256), 0, st, d_part, nblk, 0.5, d_scal);
         double h3[3]; int f0 = 0;
         HCK(hipMemsetAsync(d_fail, 0, sizeof(int), st));
@@ -485,7 +485,7 @@ static int pg_solve_impl(dsss_ctx* c, const double* dr6, int total, const dsss_l
     const bool will_iterate = err > 0 && c->pg.max_iters > 0;
     bool pre_lin = false, pre_chain = false;
     if (will_iterate) {                              // first linearisation and the chain part of the first trial, before the analysis is in
-        hipLaunchKernelGGL(pg_linearize_kernel, dim3(nblk), dim3(256), 0, st, n, ne, d_X, d_meas, W, d_ea, d_eb, d_eo, d_emeas, d_ew, d_r, d_Ji, d_part, mp0, mp1);
+        hipLaunchKernelGGL(pg_linearize_kernel<true>, dim3(nblk), dim3(256), 0, st, n, ne, d_X, d_meas, W, d_ea, d_eb, d_eo, d_emeas, d_ew, d_r, d_Ji, d_part, mp0, mp1);
         hipLaunchKernelGGL(pg_final_sum_kernel, dim3(1), dim3(256), 0, st, d_part, nblk, 0.5, d_scal);
         HCK(hipMemcpyAsync(d_scal + 3, &lambda, sizeof(double), hipMemcpyHostToDevice, st));
         chain_part();
@@ -674,7 +674,7 @@ static int pg_solve_impl(dsss_ctx* c, const double* dr6, int total, const dsss_l
         cur = err;
         double oldLin = err;                                                   // linear error at delta = 0 == the error at X (same sum, already global)
         if (!pre_lin) {
-            hipLaunchKernelGGL(pg_linearize_kernel, dim3(nblk), dim3(256), 0, st, n, ne, d_X, d_meas, W, d_ea, d_eb, d_eo, d_emeas, d_ew, d_r, d_Ji, d_part, mp0, mp1);
+            hipLaunchKernelGGL(pg_linearize_kernel<true>, dim3(nblk), dim3(256), 0, st, n, ne, d_X, d_meas, W, d_ea, d_eb, d_eo, d_emeas, d_ew, d_r, d_Ji, d_part, mp0, mp1);
             hipLaunchKernelGGL(pg_final_sum_kernel, dim3(1), dim3(256), 0, st, d_part, nblk, 0.5, d_scal);
         }
         pre_lin = false;
@@ -746,7 +746,7 @@ static int pg_solve_impl(dsss_ctx* c, const double* dr6, int total, const dsss_l
             ++nfact;
             // X and Xn swap between trials, so these two stay outside the captured graph
             hipLaunchKernelGGL(pg_retract_kernel, dim3((n + 255) / 256), dim3(256), 0, st, n, d_X, d_delta, d_Xn);
-            hipLaunchKernelGGL(pg_linearize_kernel, dim3(nblk), dim3(256), 0, st, n, ne, d_Xn, d_meas, W, d_ea, d_eb, d_eo, d_emeas, d_ew, d_r2, d_Ji2, d_part, mp0, mp1);
+            hipLaunchKernelGGL(pg_linearize_kernel<true>, dim3(nblk), dim3(256), 0, st, n, ne, d_Xn, d_meas, W, d_ea, d_eb, d_eo, d_emeas, d_ew, d_r2, d_Ji2, d_part, mp0, mp1);
             hipLaunchKernelGGL(pg_final_sum_kernel, dim3(1), dim3(256), 0, st, d_part, nblk, 0.5, d_scal + 2);
             HCK(hipGetLastError());
             double h[3]; int failed = 0;

@@ -8,32 +8,51 @@
 // factor k < n: k == 0 prior on X0 (measurement DR0), else Between(X_{k-1}, X_k); factor n + e: LC edge e.
 // r = whitened residual, Ji = whitened Jacobian wrt the first pose (-W Ad(h^-1)); the Jacobian wrt the second
 // pose is W itself (BetweenFactor with GTSAM_SLOW_BUT_CORRECT_BETWEENFACTOR off, PriorFactor H = I).
-__device__ inline void factor_eval(int k, int n, const pose_t* X, const pose_t* meas, const pg_weights& W,
-                                   const int* ea, const int* eb, const pose_t* emeas, const double* ew,
-                                   double* r, double* Ji)
+// WJ is a template parameter and the arrays are indexed by unrolled loops only: r and Ji stay in registers (with a run-time `Ji != nullptr` the
+// compiler kept the 36 + 2 doubles in 304 bytes of private memory per thread -- 125 MB of scratch traffic per launch at C3, the reason the
+// kernel wrote 243 MB for 138 MB of residuals and Jacobians).  Same operations in the same order: same bits.
+template <bool WJ>
+__device__ __forceinline__ void factor_eval(int k, int n, const pose_t* X, const pose_t* meas, const pg_weights& W,
+                                            const int* ea, const int* eb, const pose_t* emeas, const double* ew,
+                                            double (&r)[6], double (&Ji)[36])
 {
     double xi[6];
     if (k == 0) {
         pose_t d;
         pose_between(&meas[0], &X[0], &d);
         pose_log(&d, xi);
+#pragma unroll
         for (int a = 0; a < 6; ++a) r[a] = xi[a] * W.prior[a];
-        if (Ji) for (int a = 0; a < 36; ++a) Ji[a] = 0.0;
+        if (WJ) {
+#pragma unroll
+            for (int a = 0; a < 36; ++a) Ji[a] = 0.0;
+        }
         return;
     }
-    int i, j; const pose_t* m; const double* w;
-    if (k < n) { i = k - 1; j = k; m = &meas[k]; w = W.odo; }
-    else { const int e = k - n; i = ea[e]; j = eb[e]; m = &emeas[e]; w = ew + (size_t)e * 6; }
+    int i, j; const pose_t* m; double w[6];
+    if (k < n) {
+        i = k - 1; j = k; m = &meas[k];
+#pragma unroll
+        for (int a = 0; a < 6; ++a) w[a] = W.odo[a];
+    } else {
+        const int e = k - n; i = ea[e]; j = eb[e]; m = &emeas[e];
+#pragma unroll
+        for (int a = 0; a < 6; ++a) w[a] = ew[(size_t)e * 6 + a];
+    }
     pose_t h, er;
     pose_between(&X[i], &X[j], &h);
     pose_between(m, &h, &er);
     pose_log(&er, xi);
+#pragma unroll
     for (int a = 0; a < 6; ++a) r[a] = xi[a] * w[a];
-    if (Ji) {
+    if (WJ) {
         pose_t hi; double Ad[36];
         pose_inverse(&h, &hi);
         pose_adjoint(&hi, Ad);
-        for (int a = 0; a < 6; ++a) for (int b = 0; b < 6; ++b) Ji[a * 6 + b] = -Ad[a * 6 + b] * w[a];
+#pragma unroll
+        for (int a = 0; a < 6; ++a)
+#pragma unroll
+            for (int b = 0; b < 6; ++b) Ji[a * 6 + b] = -Ad[a * 6 + b] * w[a];
     }
 }
 
@@ -58,6 +77,7 @@ __device__ inline bool pg_owned_factor(int k, int n, const int* __restrict__ eo,
     const int p = k < n ? k : eo[k - n];
     return p >= mp0 && p < mp1;
 }
+template <bool WJ>        // WJ: residuals AND Jacobians (r, Ji both given); otherwise the error alone (r, Ji null)
 __global__ __launch_bounds__(256) void pg_linearize_kernel(int n, int ne, const pose_t* __restrict__ X, const pose_t* __restrict__ meas,
                                                            pg_weights W, const int* __restrict__ ea, const int* __restrict__ eb, const int* __restrict__ eo,
                                                            const pose_t* __restrict__ emeas, const double* __restrict__ ew,
@@ -74,10 +94,11 @@ __global__ __launch_bounds__(256) void pg_linearize_kernel(int n, int ne, const 
     const bool own = k < n + ne && pg_owned_factor(k, n, eo, mp0, mp1);
     double rr[6], J[36];
     if (own) {
-        factor_eval(k, n, X, meas, W, ea, eb, emeas, ew, rr, Ji ? J : nullptr);
-        for (int a = 0; a < 6; ++a) { e2 += rr[a] * rr[a]; if (r) r[(size_t)k * 6 + a] = rr[a]; }
+        factor_eval<WJ>(k, n, X, meas, W, ea, eb, emeas, ew, rr, J);
+#pragma unroll
+        for (int a = 0; a < 6; ++a) { e2 += rr[a] * rr[a]; if (WJ) r[(size_t)k * 6 + a] = rr[a]; }
     }
-    if (Ji) {                                                   // (uniform over the grid)
+    if (WJ) {
         const unsigned long long owned = __ballot(own);
         const size_t k0 = (size_t)(blockIdx.x * 256 + wv * 64);   // first factor of this wavefront
         double* __restrict__ sj = s_j[wv];
@@ -101,6 +122,9 @@ __global__ __launch_bounds__(256) void pg_linearize_kernel(int n, int ne, const 
     const double s = block_sum256(e2, s_w);
     if (threadIdx.x == 0) partial[blockIdx.x] = s;
 }
+
+template __global__ void pg_linearize_kernel<false>(int, int, const pose_t* __restrict__, const pose_t* __restrict__, pg_weights, const int* __restrict__, const int* __restrict__, const int* __restrict__, const pose_t* __restrict__, const double* __restrict__, double* __restrict__, double* __restrict__, double* __restrict__, int, int);
+template __global__ void pg_linearize_kernel<true>(int, int, const pose_t* __restrict__, const pose_t* __restrict__, pg_weights, const int* __restrict__, const int* __restrict__, const int* __restrict__, const pose_t* __restrict__, const double* __restrict__, double* __restrict__, double* __restrict__, double* __restrict__, int, int);
 
 __global__ __launch_bounds__(256) void pg_final_sum_kernel(const double* __restrict__ partial, int n, double scale, double* __restrict__ out)
 {

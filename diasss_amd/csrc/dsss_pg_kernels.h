@@ -35,7 +35,7 @@ struct pg_child { const double* U; const double* g; long long relptr; int cld, c
 #define RNG_PER_THREAD 16
 
 // ---- dsss_pg_chain.hip
-__global__ void pg_linearize_kernel(int n, int ne, const pose_t* __restrict__ X, const pose_t* __restrict__ meas, pg_weights W, const int* __restrict__ ea, const int* __restrict__ eb, const int* __restrict__ eo, const pose_t* __restrict__ emeas, const double* __restrict__ ew, double* __restrict__ r, double* __restrict__ Ji, double* __restrict__ partial, int mp0, int mp1);
+template <bool WJ> __global__ void pg_linearize_kernel(int n, int ne, const pose_t* __restrict__ X, const pose_t* __restrict__ meas, pg_weights W, const int* __restrict__ ea, const int* __restrict__ eb, const int* __restrict__ eo, const pose_t* __restrict__ emeas, const double* __restrict__ ew, double* __restrict__ r, double* __restrict__ Ji, double* __restrict__ partial, int mp0, int mp1);
 __global__ void pg_final_sum_kernel(const double* __restrict__ partial, int n, double scale, double* __restrict__ out);
 __global__ void pg_assemble_kernel(int n, pg_weights W, const double* __restrict__ r, const double* __restrict__ Ji, const int* __restrict__ adj_ptr, const int* __restrict__ adj_edge, const double* __restrict__ ew, const double* __restrict__ lambda_ptr, double* __restrict__ D, double* __restrict__ C, double* __restrict__ g, const int* __restrict__ eo, int mp0, int mp1, const int* __restrict__ plist, int np);
 template <bool FROMJ> __global__ void pg_segment_kernel(int nseg, const int* __restrict__ seg_order, const int* __restrict__ sep_pose, const double* __restrict__ D, const double* __restrict__ C, const double* __restrict__ g, double* __restrict__ E, double* __restrict__ Dl, double* __restrict__ gi, double* __restrict__ segDL, double* __restrict__ segDR, double* __restrict__ segGL, double* __restrict__ segGR, double* __restrict__ segS, int* __restrict__ fail, int mp0, int mp1, const double* __restrict__ rf, const double* __restrict__ Jf, pg_weights W, const double* __restrict__ lambda_ptr);
