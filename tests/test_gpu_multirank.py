@@ -24,9 +24,19 @@ def _survey(F=6):
     return F, raws, poses, alts, grs
 
 
-def _reference(F, raws, poses, alts, grs):
+def _sift_mode(pipe):
+    """the 128-float rows + the L2 matcher on them (DSSS_DESC_SIFT128, use_l2 = 2)"""
+    from diasss_amd import capi
+    mp_, op_, mt_, pg_ = pipe.ctx.default_params()
+    op_.descriptor = capi.DESC_SIFT128; mt_.use_l2 = 2
+    pipe.ctx.set_params(orb=op_, match=mt_)
+
+
+def _reference(F, raws, poses, alts, grs, sift=False):
     from diasss_amd.pipeline import Pipeline
     pipe = Pipeline(F, device=0)
+    if sift:
+        _sift_mode(pipe)
     ref, ref_stats = pipe.run(raws, poses, alts, grs)
     ref = ref.copy()
     n_edges = len(pipe.ctx.posegraph_select(F))
@@ -90,6 +100,8 @@ def _worker(rank, world, port, q, backend):
     mine = set(shard_frames(F, rank, world))
     raws = [r if f in mine else None for f, r in enumerate(raws)]
     pipe = Pipeline(F, device=0, rank=rank, world=world, dist=dist, force_collectives=True)
+    if os.environ.get("DSSS_TEST_SIFT") == "1":
+        _sift_mode(pipe)
     if backend == "nccl":
         pipe.ctx.set_pg_partitions(3)                               # one RCCL rank, three partitions: the all-reduce runs on real buffers
     out, stats = pipe.run(raws, poses, alts, grs)
@@ -121,6 +133,19 @@ def test_ranks_over_gloo_equal_single_rank(world):
         assert cs[1] == world and cs[3] > 0 and cs[2] > 0           # all-reduces happened, bytes counted
     for r in range(1, world):
         assert (res[0][1] == res[r][1]).all()                       # every rank ends with the same bits
+
+
+def test_ranks_over_gloo_in_sift_mode(monkeypatch):
+    """the sharded pipeline with DSSS_DESC_SIFT128: the feature all-gather carries the 128-byte rows, every rank matches its pairs by L2 on them"""
+    F, raws, poses, alts, grs = _survey()
+    ref, ref_stats, n_edges = _reference(F, raws, poses, alts, grs, sift=True)
+    ref0, _, n0 = _reference(F, raws, poses, alts, grs)
+    assert n_edges > 10 and (n_edges != n0 or np.abs(ref - ref0).max() > 1e-9)      # (another matcher: another set of loop closures)
+    monkeypatch.setenv("DSSS_TEST_SIFT", "1")                      # (the spawned ranks inherit it)
+    res = _run(2, "gloo", 29300 + os.getpid() % 500)
+    for rank, out, stats, repro, cs in res:
+        assert stats[0] == ref_stats[0] and np.abs(out - ref).max() < 1e-9 and repro
+    assert (res[0][1] == res[1][1]).all()
 
 
 def test_rccl_one_rank_communicator():
