@@ -1163,16 +1163,17 @@ static int pg_update_impl(dsss_ctx* c, int nframes, int window_frames, double* p
     if (!frozen.empty()) {
         HIPCHK(c, hipSetDevice(c->device));
         // X_0 (the window's first pose) and the frozen end points: one gather out of the warm buffer
+        // (scratch out of the solver's arena, which is idle between solves: no allocation per update)
         std::vector<int> idx(frozen); idx.push_back(p0);
+        pg_dev gv;
         int* d_idx = nullptr; pose_t* d_g = nullptr;
-        HIPCHK(c, hipMalloc(&d_idx, idx.size() * sizeof(int)));
-        hipError_t e = hipMalloc(&d_g, idx.size() * sizeof(pose_t));
+        int rg = gv.alloc(c, &d_idx, idx.size()); if (rg) return rg;
+        rg = gv.alloc(c, &d_g, idx.size()); if (rg) { gv.release(); return rg; }
         std::vector<pose_t> g(idx.size());
-        if (e == hipSuccess) e = hipMemcpyAsync(d_idx, idx.data(), idx.size() * sizeof(int), hipMemcpyHostToDevice, c->stream);
+        hipError_t e = hipMemcpyAsync(d_idx, idx.data(), idx.size() * sizeof(int), hipMemcpyHostToDevice, c->stream);
         if (e == hipSuccess) { hipLaunchKernelGGL(pg_gather_pose_kernel, dim3(((int)idx.size() + 255) / 256), dim3(256), 0, c->stream, (int)idx.size(), d_idx, static_cast<const pose_t*>(c->pg_warm), d_g); e = hipGetLastError(); }
         if (e == hipSuccess) e = hipMemcpyAsync(g.data(), d_g, g.size() * sizeof(pose_t), hipMemcpyDeviceToHost, c->stream);
-        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-        hipFree(d_idx); hipFree(d_g);
+        gv.release();                                       // (synchronises the stream: the poses are on the host, the arena is free again)
         HIPCHK(c, e);
         pose_t X0inv; pose_inverse(&g.back(), &X0inv);
         for (dsss_lc_edge& w : we) {
