@@ -1144,10 +1144,13 @@ static int pg_update_impl(dsss_ctx* c, int nframes, int window_frames, double* p
     // them.  Loop closures inside the window keep their form; one from a frozen pose a into the window becomes a BetweenFactor from the
     // window's pinned first pose with the measurement X_0^-1 X_a rel -- exactly the same residual, since X_a = X_0 (X_0^-1 X_a) with both
     // factors frozen (error = Log(rel^-1 X_a^-1 X_b) = Log((X_0^-1 X_a rel)^-1 X_0^-1 X_b)); closures between two frozen poses drop out.
-    const int f0 = window_frames > 0 ? std::max(0, nframes - window_frames) : 0;
+    int f0 = window_frames > 0 ? std::max(0, nframes - window_frames) : 0;
     int p0 = 0;
     for (int f = 0; f < f0; ++f) p0 += c->frames[f].N;
-    if (f0 == 0 || c->pg_warm_n <= p0) {                // no frozen part yet (or nothing to condition on): the whole graph
+    // the window's first ping anchors it and needs an estimate: a window that starts in frames no update has covered yet (a new frame with
+    // window_frames = 1; several new frames at once) is extended backwards to the last frame that has one
+    while (f0 > 0 && c->pg_warm_n <= p0) { --f0; p0 -= c->frames[f0].N; }
+    if (f0 == 0) {                                       // no frozen part (yet): the whole graph
         c->pg_online = true; c->pg_win_f0 = 0; c->pg_win_p0 = 0;
         const int rc = pg_solve_impl(c, nullptr, (int)total, c->pg_inc_edges.data(), (int)c->pg_inc_edges.size(), poses12, stats4, rpy6, nframes);
         c->pg_online = false;

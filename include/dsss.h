@@ -220,8 +220,9 @@ int dsss_posegraph_update(dsss_ctx*, int nframes, double* poses12_host, double* 
  * re-factorises the whole graph, O(F) per update, O(F^2) over a survey).  The frozen part is NOT revisited: what iSAM2 does for variables
  * below its relinearisation threshold (optimizer.cpp:134-137) done by age -- a later dsss_posegraph_update (global, warm-started from these
  * estimates: one or two LM trials) gives the batch optimum, which is all the reference ever reads (calculateEstimate after the loop, :279).
- * poses12_host / rpy6_host (either may be NULL: nothing is downloaded) receive ALL pings of frames 0 .. nframes-1.  Falls back to the global
- * form while there is no frozen part (nframes <= window_frames).  Loop closures must end in the later ping (the pipeline's do).          */
+* poses12_host / rpy6_host (either may be NULL: nothing is downloaded) receive ALL pings of frames 0 .. nframes-1.  Falls back to the global
+ * form while there is no frozen part (nframes <= window_frames); a window that would start in frames no update has covered (window_frames = 1:
+ * the new frame alone) is extended backwards to the last frame that has an estimate, which anchors it.  Loop closures must end in the later ping (the pipeline's do).          */
 int dsss_posegraph_update_window(dsss_ctx*, int nframes, int window_frames, double* poses12_host, double* rpy6_host, double* stats4_host);
 int dsss_posegraph_reset(dsss_ctx*);
 int dsss_posegraph_online_edges(dsss_ctx*);      /* loop closures accumulated so far (>= 0) */

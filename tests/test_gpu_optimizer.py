@@ -312,3 +312,42 @@ def test_incremental_window_updates(orc):
     assert abs(e_o - e_t) <= 1e-9 * e_t and np.abs(tight_o[:, 9:] - tight_b[:, 9:]).max() < 1e-7
     pipe.close()
 
+
+def test_window_update_edge_cases(ctx, orc, survey):
+    """dsss_posegraph_update_window at its borders: a window that covers the whole survey IS the global update (same bits); a window of one
+    frame; an update that brings no new loop closures; window_frames < 1 is refused"""
+    from diasss_amd import capi
+    F, N = survey["F"], survey["N"]
+    src, tgt = survey["src"], survey["tgt"]
+    kp7 = [ctx.match_kp7(p) for p in range(len(src))]
+
+    def feed(j):
+        pj = [p for p in range(len(src)) if tgt[p] == j and len(kp7[p])]
+        if pj:
+            ctx.lc_solve_pairs([src[p] for p in pj], [tgt[p] for p in pj], [kp7[p] for p in pj])
+    try:
+        ctx.posegraph_reset()
+        for j in range(F):
+            feed(j)
+            g_out, _, g_st = ctx.posegraph_update(j + 1, (j + 1) * N)
+        ctx.posegraph_reset()
+        for j in range(F):
+            feed(j)
+            w_out, w_st = ctx.posegraph_update_window(j + 1, (j + 1) * N, F + 3)      # never a frozen part: the global path
+        assert (w_out == g_out).all() and (w_st == g_st).all()
+        ctx.posegraph_reset()
+        for j in range(F):
+            feed(j)
+            o1, s1 = ctx.posegraph_update_window(j + 1, (j + 1) * N, 1)               # one frame at a time, everything before it frozen
+        assert o1.shape == (F * N, 12) and np.isfinite(o1).all()
+        dr = np.concatenate([f["pose"] for f in survey["fr"]])
+        edges = ctx.posegraph_select(F)
+        # (frozen frames never move again: further from the optimum than a wider window, but a sane trajectory -- within 2 m of the batch one on this survey)
+        assert np.abs(o1[:, 9:] - g_out[:, 9:]).max() < 2.0
+        again, s2 = ctx.posegraph_update_window(F, F * N, 2)                           # nothing new: at most one accepted step, nothing moves far
+        assert s2[0] <= 2 and np.abs(again - o1)[: (F - 2) * N].max() == 0             # ... and the frozen part is bit for bit what it was
+        with pytest.raises(capi.DsssError):
+            ctx.posegraph_update_window(F, F * N, 0)
+    finally:
+        ctx.posegraph_reset()
+

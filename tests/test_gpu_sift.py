@@ -232,3 +232,26 @@ def test_pipeline_in_sift_mode_vs_oracle(orc):
     o_poses, o_stats = orc.pg_solve(np.concatenate([i[0] for i in ins]), edges)
     assert o_stats[0] == g_stats[0] and np.abs(g_poses - o_poses).max() < 1e-6
     pipe.close()
+
+
+def test_sift_mode_on_frames_without_keypoints(ctx, orc):
+    """a flat frame (no FAST corner anywhere) and a frame whose keypoints all fall under the mask: zero rows, no fault; matching such frames in
+    L2-128 mode gives empty rows"""
+    from tests import helpers as H
+    N, M = 700, 480
+    _sift_mode(ctx)
+    pose, alt, gr = H.track(N, M, 0, seed=3)
+    flat = np.full((N, M), 7.0)
+    ctx.frame_set(0, flat, N, M, pose, alt, gr)
+    assert ctx.extract(0) == 0
+    assert ctx.features_get_sift(0).shape == (0, 128)
+    rng = np.random.default_rng(1)
+    speck = rng.rayleigh(1.0, (N, M))
+    pose2 = pose.copy(); pose2[:, 4] += 0.3
+    ctx.frame_set(2, speck, N, M, pose2, alt, gr)
+    n2 = ctx.extract(2)
+    o = orc.detect_feature(speck, sift=True)
+    assert n2 == len(o[0]) and (ctx.features_get_sift(2) == o[4].astype(np.float32)).all()
+    ctx.match_pairs([0], [2])
+    assert len(ctx.match_rows(0)) == 0
+
