@@ -487,18 +487,22 @@ int dsss_frames_set(dsss_ctx* c, int n, const int* ids, const double* const* raw
         rc = frame_submit(c, ids[i], raw ? raw[i] : nullptr, false); if (rc) return rc;
     }
     HIPCHK(c, hipEventRecord(c->xev[0], c->stream));        // whatever is queued so far may still read the buffer's previous contents
+    const auto t1 = std::chrono::steady_clock::now();
     if (raw) dsss_extract_eager(c, ids, n);
+    const auto t2 = std::chrono::steady_clock::now();
     const int T_env = getenv("DSSS_FS_THREADS") ? atoi(getenv("DSSS_FS_THREADS")) : 0;
     const int T = T_env > 0 ? T_env : (n >= 16 ? 4 : 1);       // (eight threads were slower than four: the pointer-attribute queries of frame_fill serialise)
     std::vector<hipError_t> errs(T, hipSuccess);
     auto work = [&](int t) { for (int i = t; i < n; i += T) { const hipError_t e = frame_fill(c, ids[i], G.h + off[i], pose6[i], alt[i], grange[i]); if (e != hipSuccess) errs[t] = e; } };
     dsss_pool_run(T, work);
     for (int t = 0; t < T; ++t) if (errs[t] != hipSuccess) { c->ex_eager_valid = false; HIPCHK(c, errs[t]); }
+    const auto t3 = std::chrono::steady_clock::now();
     HIPCHK(c, hipStreamWaitEvent(c->xs[1], c->xev[0], 0));
     HIPCHK(c, hipMemcpyAsync(G.d, G.h, total * sizeof(double), hipMemcpyHostToDevice, c->xs[1]));
     HIPCHK(c, hipEventRecord(G.ev, c->xs[1]));
     HIPCHK(c, hipStreamWaitEvent(c->stream, G.ev, 0));      // every later consumer of the geometry is ordered behind the upload
-    if (getenv("DSSS_EX_VERBOSE")) fprintf(stderr, "[dsss frames_set] %d frames in %.1f us\n", n, std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count());
+    if (getenv("DSSS_EX_VERBOSE")) { auto us = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::micro>(b - a).count(); };
+        fprintf(stderr, "[dsss frames_set] %d frames in %.1f us: bookkeeping %.1f, eager extraction queued %.1f, geometry packed (%d threads) %.1f, upload queued %.1f\n", n, us(t0, std::chrono::steady_clock::now()), us(t0, t1), us(t1, t2), T, us(t2, t3), us(t3, std::chrono::steady_clock::now())); }
     return DSSS_OK;
 }
 

@@ -1079,7 +1079,9 @@ static int extract_frames_impl(dsss_ctx* c, const int* ids, int n, bool keep_tap
         slot_bytes = std::max(slot_bytes, Ls[i].total);
     }
     // slots of one batch share one scratch allocation: bound it (24 GB) instead of the frame count alone
-    int B = (int)std::max<size_t>(1, std::min<size_t>(std::min(n, EX_BATCH), ((size_t)24 << 30) / std::max<size_t>(slot_bytes, 1)));
+    // (DSSS_EX_SCRATCH_GB: tools/emulate_ranks.py puts the contexts of EIGHT ranks on one device)
+    const size_t scratch_gb = getenv("DSSS_EX_SCRATCH_GB") ? (size_t)std::max(1, atoi(getenv("DSSS_EX_SCRATCH_GB"))) : 24;
+    int B = (int)std::max<size_t>(1, std::min<size_t>(std::min(n, EX_BATCH), (scratch_gb << 30) / std::max<size_t>(slot_bytes, 1)));
     // frames whose page-locked host image has not been uploaded yet: smaller batches, the upload of batch k+1 runs on the copy
     // stream (xs[1]) under the kernels of batch k (PCIe: 16 B per pixel against ~6 ns of kernels per pixel, so the copies set the pace)
     bool any_pending = false;
@@ -1316,16 +1318,17 @@ static int extract_frames(dsss_ctx* c, const int* ids, int n, bool keep_taps)
 void dsss_extract_eager(dsss_ctx* c, const int* ids, int n)
 {
     c->ex_eager_valid = false;
-    if (n <= 0 || n > EX_BATCH) return;
+    const bool exv = getenv("DSSS_EX_VERBOSE") != nullptr;
+    if (n <= 0 || n > EX_BATCH) { if (exv) fprintf(stderr, "[dsss extract] no early start: %d frames in the call\n", n); return; }
     std::vector<int> mine;
     for (int i = 0; i < n; ++i) {
         const dsss_frame& f = c->frames[ids[i]];
         if (!f.has_raw) continue;                    // (a rank sets every frame's geometry and the images of its own)
-        if (f.raw_pending) return;                   // host-resident images are streamed in by the batch loop of the full path
+        if (f.raw_pending) { if (exv) fprintf(stderr, "[dsss extract] no early start: frame %d is still in host memory\n", ids[i]); return; }      // host-resident images are streamed in by the batch loop of the full path
         mine.push_back(ids[i]);
     }
     if (mine.empty()) return;
-    if (extract_frames_impl(c, mine.data(), (int)mine.size(), false, 1) != DSSS_OK) { (void)hipGetLastError(); return; }      // (the full path will report what is wrong)
+    if (extract_frames_impl(c, mine.data(), (int)mine.size(), false, 1) != DSSS_OK) { if (exv) fprintf(stderr, "[dsss extract] no early start: %s\n", c->err.c_str()); (void)hipGetLastError(); return; }      // (the full path will report what is wrong)
     c->ex_eager_ids.swap(mine); c->ex_eager_op = c->op; c->ex_eager_mp = c->mp; c->ex_eager_valid = true;
 }
 

@@ -240,6 +240,21 @@ static int pg_solve_impl(dsss_ctx* c, const double* dr6, int total, const dsss_l
     bool bottom_signalled = false;
     // (Rounds 4 - 5 also had the ordering on the device, dsss_pg_nd.hip: coordinate medians only.  The chain-order cut of round 5 -- 12 panel
     // levels instead of 29 at C3 -- exists on the host only, the device kernels were off by default from then on and were removed in round 6.)
+    // RANK-LOCAL ANALYSIS (round 6; several ranks).  Rounds 2 - 5 had every rank order and analyse the WHOLE reduced graph -- 2.6 ms of serial
+    // host work per solve at C3 whatever the number of GPUs, and arenas for everybody's fronts.  Now a rank analyses its OWN separators plus
+    // the interface: I = the separators with a neighbour on a higher rank (exactly the nodes whose diagonal blocks take contributions from
+    // two ranks -- the ownership rule of the numeric phase; every edge between two ranks has its lower end in I, so without I the ranks'
+    // interiors do not touch).  Every rank holds all edges, so every rank finds the same I.  The local graph is ordered by the nested
+    // dissection with I PRESCRIBED last as one dense front (pg_sym_opts::iface_last): a rank eliminates its interior, what is left on I
+    // is its share of the reduced Hessian, the ranks' interface fronts -- identical in layout -- are summed IN PLACE by the all-reduce, and
+    // every rank factorises the sum and substitutes back into its interior.  No structure is exchanged at all.  Kernels index separators
+    // and values globally (chain order), so the local tables are translated once: perm_g / dest_g / ifslot_g / ifsep_g and the fronts'
+    // value references.  A dense interface of more than PG_LOCAL_IFACE_MAX nodes (or DSSS_PG_LOCAL=0) keeps the replicated analysis with
+    // its interface TREE; so does one rank holding several partitions (world == 1: the tests of the partition logic).
+    bool local = false;
+    std::vector<int> perm_g, dest_g, ifslot_g, ifsep_g, loc_of, glob_of, ledge_g;
+    std::vector<std::pair<int, int>> ledges;
+    std::vector<double> cxl, cyl;
     std::thread sym_thread([&] {
         pg_sym_opts opt; opt.threads = sym_threads(ns);
         opt.on_bottom_ready = [&] { bottom_signalled = true; bottom_prom.set_value(); };
@@ -250,10 +265,47 @@ static int pg_solve_impl(dsss_ctx* c, const double* dr6, int total, const dsss_l
         for (int e = 0; e < ne; ++e) redges.push_back({ sidx(ea[e]), sidx(eb[e]) });
         const double bin_cost = getenv("DSSS_PG_BIN_COST") ? atof(getenv("DSSS_PG_BIN_COST")) : 600;   // ~ update-list iterations + 20 per column; measured optimum at C3 (500-700)
         opt.bin_cost = bin_cost; pg_sym_opts_env(opt);
-        pg_symbolic(ns, redges, nseg, cx.data(), cy.data(), nparts > 1 ? sym_part.data() : nullptr, nparts, opt, S);
-        // launch lists: this rank's interior fronts, then (after the all-reduce) the replicated interface fronts
-        pg_build_schedule(S, part_lo, part_hi, SO);
-        if (nparts > 1) pg_build_schedule(S, -1, 0, SI);
+        if (world > 1 && !(getenv("DSSS_PG_LOCAL") && atoi(getenv("DSSS_PG_LOCAL")) == 0)) {
+            std::vector<int> rank_of_part(nparts, 0);
+            for (int r = 0; r < world; ++r) for (int p = (int)((long long)nparts * r / world); p < (int)((long long)nparts * (r + 1) / world); ++p) rank_of_part[p] = r;
+            std::vector<char> isif(ns, 0);
+            for (const auto& e : redges) {
+                const int ra = rank_of_part[sym_part[e.first]], rb = rank_of_part[sym_part[e.second]];
+                if (ra < rb) isif[e.first] = 1; else if (rb < ra) isif[e.second] = 1;
+            }
+            int nif_l = 0; for (int k = 0; k < ns; ++k) nif_l += isif[k];
+            if (nif_l <= PG_LOCAL_IFACE_MAX) {
+                local = true;
+                loc_of.assign(ns, -1);
+                for (int k = 0; k < ns; ++k)
+                    if (isif[k] || rank_of_part[sym_part[k]] == rank) { loc_of[k] = (int)glob_of.size(); if (isif[k]) opt.iface_last.push_back(loc_of[k]); glob_of.push_back(k); }
+                for (size_t g = 0; g < redges.size(); ++g) {
+                    const int a = loc_of[redges[g].first], b = loc_of[redges[g].second];
+                    if (a >= 0 && b >= 0 && a != b) { ledges.push_back({ a, b }); ledge_g.push_back((int)g); }
+                }
+            }
+        }
+        if (local) {
+            const int nsl = (int)glob_of.size();
+            cxl.resize(nsl); cyl.resize(nsl);
+            opt.before_order = [&] { coords_fut.wait(); for (size_t i = 0; i < glob_of.size(); ++i) { cxl[i] = cx[glob_of[i]]; cyl[i] = cy[glob_of[i]]; } };
+            opt.on_bottom_ready = nullptr; opt.on_lists_ready = nullptr;      // (nothing goes up early: the tables below come last)
+            opt.threads = sym_threads(nsl);
+            pg_symbolic(nsl, ledges, 0, cxl.data(), cyl.data(), nullptr, 1, opt, S);
+            pg_build_schedule(S, 0, 1, SO);
+            pg_build_schedule(S, -1, 0, SI);
+            const int nval_g = ns + (int)redges.size();
+            perm_g.assign(ns, -1); dest_g.assign(nval_g, -1); ifslot_g.assign(ns, -1);
+            for (int i = 0; i < nsl; ++i) { perm_g[glob_of[i]] = S.perm[i]; dest_g[glob_of[i]] = S.dest_bin[i]; }
+            for (size_t le = 0; le < ledges.size(); ++le) dest_g[ns + ledge_g[le]] = S.dest_bin[nsl + le];
+            for (int& v : S.fa_src) v = v >= S.nval ? nval_g + (v - S.nval) : (v < nsl ? glob_of[v] : ns + ledge_g[v - nsl]);
+            for (size_t q = 0; q < S.iface_seps.size(); ++q) { const int k = glob_of[S.iface_seps[q]]; ifsep_g.push_back(k); ifslot_g[k] = (int)q; }
+        } else {
+            pg_symbolic(ns, redges, nseg, cx.data(), cy.data(), nparts > 1 ? sym_part.data() : nullptr, nparts, opt, S);
+            // launch lists: this rank's interior fronts, then (after the all-reduce) the replicated interface fronts
+            pg_build_schedule(S, part_lo, part_hi, SO);
+            if (nparts > 1) pg_build_schedule(S, -1, 0, SI);
+        }
         if (!lists_signalled) lists_prom.set_value();
         if (!bottom_signalled) bottom_prom.set_value();      // (several partitions: nothing is ready early)
     });
@@ -507,6 +559,7 @@ static int pg_solve_impl(dsss_ctx* c, const double* dr6, int total, const dsss_l
     bool lists_done = false;
     auto upload_lists = [&]() -> int {
         nnzL = S.rowidx.size();
+        const int ns = S.ns;                                     // (the analysed graph: this rank's own in the rank-local mode)
         int rc2 = DSSS_OK;
         char* d_binned = nullptr; int* d_rootof = nullptr;
         dv.later(&d_colptr, S.colptr); dv.later(&d_rowidx, S.rowidx); dv.later(&d_binned, S.binned); dv.later(&d_rootof, S.root_of);
@@ -542,27 +595,29 @@ static int pg_solve_impl(dsss_ctx* c, const double* dr6, int total, const dsss_l
         return DSSS_OK;
     };
     auto upload_bottom = [&]() -> int {
-        nnzL = S.rowidx.size(); nval = (int)S.dest_bin.size();
+        nnzL = S.rowidx.size(); nval = local ? (int)dest_g.size() : (int)S.dest_bin.size();
         ncv = S.comm_vals.size(); nif = S.iface_seps.size();
         comm_total = ncv * 36 + nif * 6 + (size_t)S.comm_doubles + 8;
         int rc2 = DSSS_OK;
         if (!lists_done && (rc2 = upload_lists())) return rc2;
-        dv.later(&d_perm, S.perm);
+        dv.later(&d_perm, local ? perm_g : S.perm);
         if ((rc2 = dv.alloc(c, &d_L, nnzL * 36))) return rc2;
         if ((rc2 = dv.alloc(c, &d_ubin, (size_t)S.ubin_doubles))) return rc2;
         // value array of the fronts; its tail IS the buffer the all-reduce sums: [interface values | interface right-hand sides |
         // update matrices that cross into the interface | 8 scalars]
         if ((rc2 = dv.alloc(c, &d_aval, (size_t)nval * 36 + comm_total))) return rc2;
         d_comm = d_aval + (size_t)nval * 36; d_avalif = d_comm; d_xif = d_comm + ncv * 36; d_commU = d_xif + nif * 6;
-        ifslot.assign(ns, -1); for (size_t q = 0; q < nif; ++q) ifslot[S.iface_seps[q]] = (int)q;
-        dv.later(&d_ifslot, ifslot); dv.later(&d_ifsep, S.iface_seps);
+        if (local) ifslot.swap(ifslot_g);
+        else { ifslot.assign(ns, -1); for (size_t q = 0; q < nif; ++q) ifslot[S.iface_seps[q]] = (int)q; }
+        dv.later(&d_ifslot, ifslot); dv.later(&d_ifsep, local ? ifsep_g : S.iface_seps);
         dv.later(&d_binptr, S.binptr); dv.later(&d_bincols, S.bincols); dv.later(&d_binperm, S.bin_perm);
-        dv.later(&d_dest, S.dest_bin);
+        dv.later(&d_dest, local ? dest_g : S.dest_bin);
         dv.later(&d_binroot_ptr, S.binroot_ptr); dv.later(&d_binroot_idx, S.binroot_idx); dv.later(&d_broot_b, S.broot_b); dv.later(&d_broot_uoff, S.broot_uoff);
         dv.later(&d_broot_of_col, S.broot_of_col);
         if ((rc2 = dv.flush(c, st))) return rc2;
         // this rank's bins are one contiguous range (bins never straddle partitions, partitions are ascending in the order)
-        { const int nb_all = (int)S.binptr.size() - 1; bin_lo = 0; while (bin_lo < nb_all && S.bin_part[bin_lo] < part_lo) ++bin_lo; bin_hi = bin_lo; while (bin_hi < nb_all && S.bin_part[bin_hi] < part_hi) ++bin_hi; }
+        { const int nb_all = (int)S.binptr.size() - 1, sel_lo = local ? 0 : part_lo, sel_hi = local ? 1 : part_hi;
+          bin_lo = 0; while (bin_lo < nb_all && S.bin_part[bin_lo] < sel_lo) ++bin_lo; bin_hi = bin_lo; while (bin_hi < nb_all && S.bin_part[bin_hi] < sel_hi) ++bin_hi; }
         nbins = bin_hi - bin_lo;
         return DSSS_OK;
     };
@@ -593,11 +648,16 @@ static int pg_solve_impl(dsss_ctx* c, const double* dr6, int total, const dsss_l
     if (!early_bottom) TRY(upload_bottom());
     else if (c->prof.on) c->prof.work[DSSS_K_PG_SUBTREE] += std::max(0.0, S.flops_factor - S.flops_fronts);
     if (verbose)
-        fprintf(stderr, "[dsss pg] rank %d/%d parts %d (own %d..%d, poses %d..%d)  poses %d  LC edges %d  separators %d (interface %zu)  nnz(L) blocks %zu  bins %d (%d cols)  fronts %d (largest %d block rows, arena %.0f MB)  panels %d in %d levels  all-reduce %.1f MB\n",
-                rank, world, nparts, part_lo, part_hi, mp0, mp1, n, ne, ns, S.iface_seps.size(), nnzL, (int)S.binptr.size() - 1, (int)S.bincols.size(), nfr, S.max_front_n, S.front_doubles * 8e-6, npan, S.nlev,
+        fprintf(stderr, "[dsss pg] rank %d/%d parts %d (own %d..%d, poses %d..%d)  %s analysis of %d separators  poses %d  LC edges %d  separators %d (interface %zu)  nnz(L) blocks %zu  bins %d (%d cols)  fronts %d (largest %d block rows, arena %.0f MB)  panels %d in %d levels  all-reduce %.1f MB\n",
+                rank, world, nparts, part_lo, part_hi, mp0, mp1, local ? "rank-local" : "replicated", S.ns, n, ne, ns, S.iface_seps.size(), nnzL, (int)S.binptr.size() - 1, (int)S.bincols.size(), nfr, S.max_front_n, S.front_doubles * 8e-6, npan, S.nlev,
                 (S.comm_doubles + 36.0 * S.comm_vals.size() + 6.0 * S.iface_seps.size()) * 8e-6);
 
-    TRY(dv.alloc(c, &d_F, (size_t)S.front_doubles)); TRY(dv.alloc(c, &d_R, (size_t)S.frhs_doubles));
+    // rank-local mode: the interface front is the LAST front of the arena and its right-hand side sits directly behind it, so that one
+    // all-reduce sums both in place
+    const int f_if = local && !S.iface_seps.empty() ? nfr - 1 : -1;
+    const size_t if_ld = f_if >= 0 ? (size_t)S.f_ld[f_if] : 0, if_count = if_ld * if_ld + if_ld;
+    if (f_if >= 0 && (S.f_part[f_if] != -1 || S.f_off[f_if] + (long long)(if_ld * if_ld) != S.front_doubles)) { abandon(); DSSS_FAIL(c, DSSS_E_STATE, "pose-graph analysis: the interface front is not the last one"); }
+    TRY(dv.alloc(c, &d_F, (size_t)S.front_doubles + if_ld)); TRY(dv.alloc(c, &d_R, (size_t)S.frhs_doubles));
     const int rsu_max = PG_RSU_MAX_TILES;               // levels with more tiles run the row solve and the trailing update as two launches
     const bool use_rsu = true;
     const int rsu32_max = PG_RSU32_MAX_TILES;           // levels with at most this many 64 x 64 tiles run them as 32 x 32 quarters
@@ -620,6 +680,7 @@ static int pg_solve_impl(dsss_ctx* c, const double* dr6, int total, const dsss_l
             pg_front& d = FD[f];
             d.off = S.f_off[f]; d.roff = S.f_roff[f]; d.ld = S.f_ld[f]; d.n6 = 6 * S.f_n[f]; d.s6 = 6 * S.f_s[f]; d.c0 = S.f_c0[f];
             d.rowptr = S.f_rowptr[f]; d.pan0 = S.f_pan0[f]; d.ch0 = S.ch_ptr[f]; d.ch1 = S.ch_ptr[f + 1]; d.fa0 = S.fa_ptr[f]; d.fa1 = S.fa_ptr[f + 1];
+            if (f == f_if) d.roff = (d_F + S.front_doubles) - d_R;      // (both come out of the solver's one arena)
         }
         for (size_t q = 0; q < CH.size(); ++q) {
             pg_child& d = CH[q]; d.relptr = S.ch_relptr[q];
@@ -687,9 +748,10 @@ static int pg_solve_impl(dsss_ctx* c, const double* dr6, int total, const dsss_l
                 if (!pre_bins) bottom_trial(std::max(0.0, S.flops_factor - S.flops_fronts));
                 pre_bins = false;
                 // fronts, level by level: assemble the fronts that start here, then one panel step of every active front
-                auto run_levels = [&](const pg_sched& H, const dsched& Dv) {
+                // part: 0 everything, 1 the assemblies only, 2 everything but the assemblies (rank-local mode: the all-reduce sits between the two)
+                auto run_levels = [&](const pg_sched& H, const dsched& Dv, int part = 0) {
                     for (int l = 0; l < H.nlev; ++l) {
-                        const int nas = H.asmrow_ptr[l + 1] - H.asmrow_ptr[l], nit = H.lv_ptr[l + 1] - H.lv_ptr[l], ntl = H.tile_ptr[l + 1] - H.tile_ptr[l];
+                        const int nas = part == 2 ? 0 : H.asmrow_ptr[l + 1] - H.asmrow_ptr[l], nit = part == 1 ? 0 : H.lv_ptr[l + 1] - H.lv_ptr[l], ntl = H.tile_ptr[l + 1] - H.tile_ptr[l];
                         const int* itf = Dv.lv_front + H.lv_ptr[l]; const int* its = Dv.lv_step + H.lv_ptr[l];
                         if (nas > 0) { dsss_scope s2(c, DSSS_K_PG_ASM);
                             hipLaunchKernelGGL(pg_front_asm_kernel, dim3(nas), dim3(256), 0, st, Dv.asm_front + H.asmrow_ptr[l], Dv.asm_row + H.asmrow_ptr[l], d_FD, d_CH, d_rel, d_xr_ptr, d_xr_child, d_xr_row,
@@ -723,7 +785,20 @@ static int pg_solve_impl(dsss_ctx* c, const double* dr6, int total, const dsss_l
                     }
                 };
                 run_levels(SO, DO);
-                if (nparts > 1) {
+                if (local) {
+                    // rank-local analysis: this rank's share of the reduced Hessian on the interface IS its interface front -- its own original
+                    // values and right-hand sides plus the update matrices of its interior, assembled as any front is -- and the all-reduce
+                    // sums the fronts (and the right-hand sides behind them) in place; then every rank factorises the sum
+                    if (f_if >= 0) {
+                        hipLaunchKernelGGL(pg_comm_xif_kernel, dim3(((int)nif + 255) / 256), dim3(256), 0, st, (int)nif, d_ifsep, d_perm, d_xif, d_x);
+                        hipMemsetAsync(d_F + S.f_off[f_if], 0, if_count * sizeof(double), st);      // (the assembly writes the lower block triangle only)
+                        run_levels(SI, DI, 1);
+                        { dsss_scope s8(c, DSSS_K_PG_COMM, (double)if_count * 8);
+                          int rc2 = dsss_comm_allreduce(c, d_F + S.f_off[f_if], if_count, st); if (rc2) { abandon(); return rc2; } }
+                        run_levels(SI, DI, 2);
+                        run_levels_bwd(SI, DI);
+                    }
+                } else if (nparts > 1) {
                     // the reduced Hessian on the interface: this rank's update matrices next to its share of the interface values and
                     // right-hand sides, summed over the ranks by ONE all-reduce; then the small replicated interface factorisation
                     if (n_pack > 0) hipLaunchKernelGGL(pg_comm_pack_kernel, dim3(n_pack), dim3(256), 0, st, d_pk_child, d_pk_row, d_PK);

@@ -630,6 +630,7 @@ __global__ __launch_bounds__(256) void pg_sep_delta_kernel(int ns, const int* __
     const int k = blockIdx.x * 256 + threadIdx.x;
     if (k >= ns) return;
     const int src = perm ? perm[k] : k;
+    if (src < 0) return;                                     // (rank-local analysis: another rank's interior separator -- not solved here, not read here)
     for (int a = 0; a < 6; ++a) delta[(size_t)sep_pose[k] * 6 + a] = x[(size_t)src * 6 + a];
 }
 

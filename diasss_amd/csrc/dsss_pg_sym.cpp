@@ -491,13 +491,35 @@ void pg_symbolic(int ns, const std::vector<std::pair<int, int>>& edges, int ncha
         adj_ptr[ns] = w;
         adj_idx.resize(w);
     }
+    const int nlast = (int)opt.iface_last.size();
+    if (nlast > 0) {
+        // the prescribed interface is a clique: every interface row gets all the other interface nodes (merged into its sorted row)
+        std::vector<int> ap(ns + 1, 0), ai;
+        std::vector<char> is_last(ns, 0);
+        for (int v : opt.iface_last) is_last[v] = 1;
+        ai.reserve(adj_idx.size() + (size_t)nlast * nlast);
+        for (int v = 0; v < ns; ++v) {
+            ap[v] = (int)ai.size();
+            if (!is_last[v]) { ai.insert(ai.end(), adj_idx.begin() + adj_ptr[v], adj_idx.begin() + adj_ptr[v + 1]); continue; }
+            int q = adj_ptr[v]; const int qe = adj_ptr[v + 1]; int w2 = 0;
+            while (q < qe || w2 < nlast) {
+                const int a = q < qe ? adj_idx[q] : (1 << 30), b = w2 < nlast ? opt.iface_last[w2] : (1 << 30);
+                if (a < b) { ai.push_back(a); ++q; }
+                else { if (b != v) ai.push_back(b); ++w2; if (a == b) ++q; }
+            }
+        }
+        ap[ns] = (int)ai.size();
+        adj_ptr.swap(ap); adj_idx.swap(ai);
+    }
     if (opt.before_order) opt.before_order();
     const auto q0a = tnow();
     std::vector<nd_tree> pool; std::mutex mu;
     std::vector<char> iface(ns, 0);
     int root = -1;
     {
-        std::vector<int> nodes(ns); std::iota(nodes.begin(), nodes.end(), 0);
+        std::vector<int> nodes; nodes.reserve(ns);
+        for (int v : opt.iface_last) iface[v] = 1;
+        for (int v = 0; v < ns; ++v) if (!iface[v]) nodes.push_back(v);
         std::vector<char> side(ns, 0), side2(ns, 0);
         S.order.reserve(ns);
         std::vector<char> forced(ns, 0);
@@ -507,6 +529,12 @@ void pg_symbolic(int ns, const std::vector<std::pair<int, int>>& edges, int ncha
         for (auto& a : nd_ns) a = 0;
         nd_ctx C{ adj_ptr.data(), adj_idx.data(), cx, cy, side.data(), side2.data(), opt.leaf, opt.nd_both_axes, opt.nd_geo_first, S.nparts > 1 ? part : nullptr, iface.data(), forced.data(), &pool, &mu, tv ? nd_ns : nullptr, opt.nd_index_cuts != 0, pos_scratch.data(), T };
         root = nd_order(nodes, C, S.order, 0);
+        if (nlast > 0) {        // the prescribed interface behind everything else; in the tree of ranges: a root whose second half is empty
+            for (int v : opt.iface_last) S.order.push_back(v);
+            pool.push_back({ -1, -1, 0 });
+            pool.push_back({ root, (int)pool.size() - 1, ns });
+            root = (int)pool.size() - 1;
+        }
         if (tv) fprintf(stderr, "[dsss pg symbolic] nd_order thread-time: candidates %.2f ms, final boundary %.2f ms, leaves %.2f ms\n", nd_ns[1] / 1e6, nd_ns[2] / 1e6, nd_ns[4] / 1e6);
     }
     const auto q1 = tnow();
@@ -901,7 +929,7 @@ void pg_symbolic(int ns, const std::vector<std::pair<int, int>>& edges, int ncha
             for (int c = S.ch_ptr[f]; c < S.ch_ptr[f + 1]; ++c) {
                 const int kind = S.ch_kind[c], id = S.ch_id[c];
                 const int cp = kind ? S.col_part[S.broot[id]] : S.f_part[id];
-                if (cp < 0) continue;
+                if (cp < 0 || nlast > 0) continue;               // (rank-local analysis: the interface front is summed whole, its children stay where they are)
                 const long long n6 = 6LL * (kind ? S.broot_b[id] : S.f_n[id] - S.f_s[id]);
                 S.comm_kind.push_back(kind); S.comm_id.push_back(id); S.comm_part.push_back(cp); S.comm_off.push_back(o);
                 o += n6 * n6 + n6; o = (o + 31) & ~31LL;
@@ -910,7 +938,7 @@ void pg_symbolic(int ns, const std::vector<std::pair<int, int>>& edges, int ncha
         S.comm_doubles = o;
         // original values of interface fronts and the interface separators
         S.nval = nval;
-        if (S.nparts > 1) {
+        if (S.nparts > 1 || nlast > 0) {
             std::vector<int> slot_of(nval, -1);
             for (int f = 0; f < nf; ++f) {
                 if (S.f_part[f] >= 0) continue;
@@ -1135,6 +1163,41 @@ extern "C" int dsss_host_pg_solve(int ns, const int32_t* edge_a, const int32_t* 
     if (stats8) {
         stats8[0] = S.nnzL; stats8[1] = (int64_t)S.f_c0.size(); stats8[2] = S.npanels; stats8[3] = S.nlev;
         stats8[4] = S.front_doubles; stats8[5] = S.comm_doubles; stats8[6] = (int64_t)S.bincols.size(); stats8[7] = S.max_front_n;
+    }
+    return rc == 0 ? DSSS_OK : (rc == -1 ? DSSS_E_NUMERIC : DSSS_E_STATE);
+}
+
+// the same with a PRESCRIBED interface (pg_sym_opts::iface_last): the analysis one rank of several runs on its own separators + the
+// interface nodes.  Any edge list (no chain prefix); iface_last ascending.
+extern "C" int dsss_host_pg_solve_local(int ns, const int32_t* edge_a, const int32_t* edge_b, int nedges, const double* cx, const double* cy,
+                                        const int32_t* iface_last, int nlast, const double* aval, const double* rhs, double* x, int64_t* stats8)
+{
+    if (ns < 1 || nedges < 0 || (nedges > 0 && (!edge_a || !edge_b)) || !cx || !cy || nlast < 0 || nlast > ns || (nlast > 0 && !iface_last) || !x || !aval || !rhs) return DSSS_E_ARG;
+    std::vector<std::pair<int, int>> edges(nedges);
+    for (int e = 0; e < nedges; ++e) {
+        edges[e] = { edge_a[e], edge_b[e] };
+        if (edge_a[e] < 0 || edge_a[e] >= ns || edge_b[e] < 0 || edge_b[e] >= ns || edge_a[e] == edge_b[e]) return DSSS_E_ARG;
+    }
+    pg_sym S; pg_sym_opts opt;
+    if (getenv("DSSS_PG_BIN_COST")) opt.bin_cost = atof(getenv("DSSS_PG_BIN_COST"));
+    pg_sym_opts_env(opt);
+    for (int q = 0; q < nlast; ++q) {
+        if (iface_last[q] < 0 || iface_last[q] >= ns || (q > 0 && iface_last[q] <= iface_last[q - 1])) return DSSS_E_ARG;
+        opt.iface_last.push_back(iface_last[q]);
+    }
+    pg_symbolic(ns, edges, 0, cx, cy, nullptr, 1, opt, S);
+    // the interface is the LAST front, dense over exactly the prescribed nodes
+    if (nlast > 0) {
+        const int nf = (int)S.f_c0.size();
+        if (nf < 1 || S.f_part[nf - 1] != -1 || S.f_s[nf - 1] != nlast || S.f_n[nf - 1] != nlast || S.f_c0[nf - 1] != ns - nlast) return DSSS_E_STATE;
+        for (int f = 0; f + 1 < nf; ++f) if (S.f_part[f] < 0) return DSSS_E_STATE;
+        for (int q = 0; q < nlast; ++q) if (S.order[ns - nlast + q] != iface_last[q] || (int)S.iface_seps.size() != nlast || S.iface_seps[q] != iface_last[q]) return DSSS_E_STATE;
+        if (!S.comm_kind.empty()) return DSSS_E_STATE;
+    }
+    const int rc = pg_host_solve(S, nedges, edges, aval, rhs, x);
+    if (stats8) {
+        stats8[0] = S.nnzL; stats8[1] = (int64_t)S.f_c0.size(); stats8[2] = S.npanels; stats8[3] = S.nlev;
+        stats8[4] = S.front_doubles; stats8[5] = (int64_t)S.comm_vals.size(); stats8[6] = (int64_t)S.bincols.size(); stats8[7] = S.max_front_n;
     }
     return rc == 0 ? DSSS_OK : (rc == -1 ? DSSS_E_NUMERIC : DSSS_E_STATE);
 }

@@ -129,6 +129,11 @@ struct pg_sym_opts {
     std::function<void()> on_lists_ready;
     bool lists_on_device = false;                // the caller builds the update lists, the update-map offsets and the root-boundary indices of the bins itself (dsss_pg.hip: on the device); rlptr .. anc_rel stay empty
     std::function<void()> before_order;          // called once the adjacency is built, before the first use of the coordinates (which may still be on their way)
+    // RANK-LOCAL analysis (dsss_pg.hip, several ranks): the graph handed in is one rank's own separators plus the INTERFACE nodes listed
+    // here (ascending node ids).  They are eliminated last, in this order, as ONE dense front whatever their edges (every rank lays the
+    // interface out the same way: the front is summed over the ranks as it is); the nested dissection orders the other nodes only.
+    // Their columns get col_part -1, their values the interface codes of dest_bin; no update matrix is packed for a collective.
+    std::vector<int> iface_last;
 };
 
 void pg_sym_opts_env(pg_sym_opts& opt);    // DSSS_PG_ND_BOTH / DSSS_PG_LEAF overrides (analysis knobs kept for tools/pg_sweep.sh)

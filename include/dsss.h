@@ -242,6 +242,11 @@ int dsss_posegraph_solve_edges(dsss_ctx*, const double* dr6, int total, const ds
  * front arena doubles, comm doubles, binned columns, largest front (block rows).                                          */
 int dsss_host_pg_solve(int ns, const int32_t* edge_a, const int32_t* edge_b, int nedges, const double* cx, const double* cy,
                        const int32_t* part, int nparts, const double* aval36, const double* rhs6, double* x6_host, int64_t* stats8);
+/* the same for the analysis ONE RANK of several runs (dsss_pg.hip, rank-local mode): its own variables plus the interface
+ * variables iface_last (ascending), which are eliminated last as one dense front whatever their edges.  Any edge list (no
+ * chain prefix).  stats8[5]: original values that land in the interface front.                                            */
+int dsss_host_pg_solve_local(int ns, const int32_t* edge_a, const int32_t* edge_b, int nedges, const double* cx, const double* cy,
+                             const int32_t* iface_last, int nlast, const double* aval36, const double* rhs6, double* x6_host, int64_t* stats8);
 
 /* ------------------------------------------------------------------ instrumentation
  * accumulated GPU time (ms, HIP events on the context stream) and launch count per kernel family        */

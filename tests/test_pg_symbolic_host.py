@@ -147,6 +147,70 @@ def test_partitioned_analysis_keeps_the_ownership_invariant(monkeypatch):
         assert st[5] > 0
 
 
+def _solve_local(ea, eb, aval, rhs, cx, cy, last):
+    from diasss_amd import capi
+    L = capi.lib()
+    ns = len(rhs)
+    x = np.zeros((ns, 6)); st = np.zeros(8, np.int64)
+    last = np.ascontiguousarray(last, np.int32)
+    p = lambda a: a.ctypes.data_as(C.c_void_p)
+    rc = L.dsss_host_pg_solve_local(ns, p(ea), p(eb), len(ea), p(cx), p(cy), p(last), len(last),
+                                    p(np.ascontiguousarray(aval)), p(np.ascontiguousarray(rhs)), p(x), p(st))
+    return rc, x, st
+
+
+@pytest.mark.parametrize("case", ["none", "few", "scattered", "all_but_one", "rank_view"])
+def test_host_solve_with_a_prescribed_interface(case, monkeypatch):
+    """The analysis ONE RANK of several runs (dsss_pg.hip, rank-local mode; pg_sym_opts::iface_last): the listed interface nodes are
+    eliminated last as one dense front whatever their edges (checked inside dsss_host_pg_solve_local: last front, exactly these
+    columns in this order, no packed update matrices), everything else is ordered by the nested dissection; the solve stays exact.
+    `rank_view`: the graph rank 1 of 3 sees -- its own legs + the interface nodes of the whole survey, which are isolated from
+    each other and from the chain except through its own nodes."""
+    monkeypatch.setenv("DSSS_PG_BIN_COST", "200")
+    legs, per_leg = 9, 40
+    ns, chords, cx, cy = _lawnmower(legs, per_leg, 41, density=0.7)
+    ea, eb, aval, rhs, A = _system(ns, chords, 43)
+    rng = np.random.default_rng(5)
+    if case == "rank_view":
+        part = np.arange(ns) // per_leg * 3 // legs
+        forced = np.zeros(ns, bool)
+        for a, b in zip(ea, eb):
+            if part[a] < part[b]: forced[a] = True
+            if part[b] < part[a]: forced[b] = True
+        keep = forced | (part == 1)
+        loc = -np.ones(ns, int); loc[keep] = np.arange(keep.sum())
+        sel = [e for e in range(len(ea)) if keep[ea[e]] and keep[eb[e]]]
+        nl = int(keep.sum())
+        ea2 = np.array([loc[ea[e]] for e in sel], np.int32); eb2 = np.array([loc[eb[e]] for e in sel], np.int32)
+        aval2 = np.concatenate([aval[:ns][keep], aval[ns:][sel]])
+        A2 = np.zeros((6 * nl, 6 * nl))
+        for k in range(nl):
+            A2[6 * k:6 * k + 6, 6 * k:6 * k + 6] = aval2[k].reshape(6, 6)
+        for e in range(len(sel)):
+            B = aval2[nl + e].reshape(6, 6); a, b = ea2[e], eb2[e]
+            A2[6 * a:6 * a + 6, 6 * b:6 * b + 6] += B; A2[6 * b:6 * b + 6, 6 * a:6 * a + 6] += B.T
+        last = loc[np.nonzero(forced)[0]]
+        assert 0 < len(last) < nl - 10
+        rhs2 = rhs[keep]
+        ref = np.linalg.solve(A2, rhs2.ravel()).reshape(nl, 6)
+        rc, x, st = _solve_local(ea2, eb2, aval2, rhs2, cx[keep], cy[keep], last)
+        assert rc == 0 and np.abs(x - ref).max() < 1e-10 * max(1.0, np.abs(ref).max())
+        assert st[5] >= len(last) and st[6] > 0                  # interface values exist (at least the diagonals); bins too
+        return
+    last = {"none": [], "few": [17, 18, 200], "scattered": sorted(rng.choice(ns, 40, replace=False).tolist()),
+            "all_but_one": [k for k in range(ns) if k != 77]}[case]
+    ref = np.linalg.solve(A, rhs.ravel()).reshape(ns, 6)
+    rc, x, st = _solve_local(ea, eb, aval, rhs, cx, cy, last)
+    assert rc == 0, rc
+    assert np.abs(x - ref).max() < 1e-10 * max(1.0, np.abs(ref).max())
+    if last:
+        assert st[7] >= len(last)
+    # not ascending / out of range: refused
+    if case == "few":
+        assert _solve_local(ea, eb, aval, rhs, cx, cy, [18, 17])[0] != 0
+        assert _solve_local(ea, eb, aval, rhs, cx, cy, [ns])[0] != 0
+
+
 def test_host_solver_under_thread_sanitizer():
     """the analysis runs its parallel phases on a process-wide worker pool (spin-then-sleep workers, stolen-back tasks):
     three threads solve different graphs at once under -fsanitize=thread (tools/sanitize/run.sh; ASan/UBSan: `run.sh asan`)"""
