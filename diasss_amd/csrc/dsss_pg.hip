@@ -233,7 +233,7 @@ static int pg_solve_impl(dsss_ctx* c, const double* dr6, int total, const dsss_l
     pg_sym S;
     pg_sched SO, SI;
     std::vector<int> sym_part(ns);
-    for (int k = 0; k < ns; ++k) sym_part[k] = (int)(std::upper_bound(pbound.begin(), pbound.end(), sep_pose[k]) - pbound.begin()) - 1;
+    { int p = 0; for (int k = 0; k < ns; ++k) { while (p + 1 < nparts && sep_pose[k] >= pbound[p + 1]) ++p; sym_part[k] = p; } }      // (the separators ascend: one sweep)
     std::promise<void> bottom_prom; std::future<void> bottom_fut = bottom_prom.get_future();
     std::promise<void> lists_prom; std::future<void> lists_fut = lists_prom.get_future(); bool lists_signalled = false;
     std::promise<void> coords_prom; std::future<void> coords_fut = coords_prom.get_future();
@@ -357,14 +357,25 @@ static int pg_solve_impl(dsss_ctx* c, const double* dr6, int total, const dsss_l
         coords_guard.set();
     }
     emeas.resize(ne); ew.resize((size_t)ne * 6);
-    for (int e = 0; e < ne; ++e) {                  // measurements and weights of the loop closures (the analysis is running and has its coordinates)
-        for (int k = 0; k < 9; ++k) emeas[e].R[k] = edges[e].rel[k];
-        for (int k = 0; k < 3; ++k) emeas[e].t[k] = edges[e].rel[9 + k];
-        for (int k = 0; k < 6; ++k) {
-            if (!(edges[e].var[k] > 0) || !std::isfinite(edges[e].var[k])) { abandon(); DSSS_FAIL(c, DSSS_E_NUMERIC, "LC edge %d: variance %d is not finite and positive", e, k); }
-            ew[(size_t)e * 6 + k] = 1.0 / std::sqrt(edges[e].var[k]);
+    {   // measurements and weights of the loop closures (the analysis is running and has its coordinates); large edge sets by ranges, as above
+        const int TE = ne >= 65536 ? 4 : 1;
+        std::vector<int> bad_var(TE, -1), bad_rel(TE, -1);
+        dsss_pool_run(TE, [&](int t) {
+            const int e0 = (int)((long long)ne * t / TE), e1 = (int)((long long)ne * (t + 1) / TE);
+            for (int e = e0; e < e1; ++e) {
+                for (int k = 0; k < 9; ++k) emeas[e].R[k] = edges[e].rel[k];
+                for (int k = 0; k < 3; ++k) emeas[e].t[k] = edges[e].rel[9 + k];
+                for (int k = 0; k < 6; ++k) {
+                    if ((!(edges[e].var[k] > 0) || !std::isfinite(edges[e].var[k])) && bad_var[t] < 0) bad_var[t] = e * 6 + k;
+                    ew[(size_t)e * 6 + k] = 1.0 / std::sqrt(edges[e].var[k]);
+                }
+                for (int k = 0; k < 12; ++k) if (!std::isfinite(edges[e].rel[k]) && bad_rel[t] < 0) bad_rel[t] = e;
+            }
+        });
+        for (int t = 0; t < TE; ++t) {
+            if (bad_var[t] >= 0) { abandon(); DSSS_FAIL(c, DSSS_E_NUMERIC, "LC edge %d: variance %d is not finite and positive", bad_var[t] / 6, bad_var[t] % 6); }
+            if (bad_rel[t] >= 0) { abandon(); DSSS_FAIL(c, DSSS_E_NUMERIC, "LC edge %d: relative pose is not finite", bad_rel[t]); }
         }
-        for (int k = 0; k < 12; ++k) if (!std::isfinite(edges[e].rel[k])) { abandon(); DSSS_FAIL(c, DSSS_E_NUMERIC, "LC edge %d: relative pose is not finite", e); }
     }
     // level-1 chain = true separators merged with the chunk ends 0, chunk, 2 chunk ...; segment orders: only the device reads them
     const double t_m0 = ms_since(T0);
@@ -1083,7 +1094,6 @@ int dsss_posegraph_solve(dsss_ctx* c, int nframes, double* poses12, double* rpy6
         c->pg_edges_cap = ecap;
     }
     dsss_lc_edge* edges_p = static_cast<dsss_lc_edge*>(c->pg_edges_host);
-    std::vector<dsss_lc_edge> edges;              // only used when the edges of several ranks are merged
     int ne = 0;
     const double t_dr = ms(t0);
     const auto t1 = std::chrono::steady_clock::now();
@@ -1112,16 +1122,16 @@ int dsss_posegraph_solve(dsss_ctx* c, int nframes, double* poses12, double* rpy6
         if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
         HIPCHK(c, e);
         // (round 5) the records travel as they are: ONE all-gather of equal slices (the largest rank's count of 152-byte records), own
-        // slice in place, the gathered block straight into page-locked memory and from there rank by rank into the edge list.  Ranks own
-        // ascending blocks of target frames and every rank's edges ascend in the target pose: the concatenation IS the reference's loop
-        // order (checked; sorted only if a caller's pair list broke that).  Rounds 2 - 4 packed twenty doubles per edge into a zero-padded
-        // vector on the host, summed it over the ranks and sorted the result: 75 of a rank's 355 ms per C5 step.
+        // slice in place.  Ranks own ascending blocks of target frames and every rank's edges ascend in the target pose: the
+        // concatenation IS the reference's loop order (checked; sorted only if a caller's pair list broke that).  (Round 6) the slices are
+        // closed up ON THE DEVICE and come back as one copy into page-locked memory, which is the edge list: rounds 2 - 5 copied them rank by
+        // rank into a fresh vector -- at C5 53 MB of first-touch page faults, 15 of a rank's 20 ms here.  Rounds 2 - 4 packed twenty doubles
+        // per edge into a zero-padded vector on the host, summed it over the ranks and sorted the result: 75 of a rank's 355 ms per C5 step.
         size_t tot = 0, maxc = 0;
         for (int r = 0; r < world; ++r) { tot += (size_t)cnt[r]; maxc = std::max(maxc, (size_t)cnt[r]); }
-        edges.resize(std::max<size_t>(tot, 1));
         if (tot > 0) {
             const size_t slice = maxc * sizeof(dsss_lc_edge), all = slice * (size_t)world;
-            rc = xch((all + sizeof(double) - 1) / sizeof(double)); if (rc) return rc;
+            rc = xch((2 * all + sizeof(double) - 1) / sizeof(double)); if (rc) return rc;
             if (c->xch_host_cap < all) {
                 if (c->xch_host) hipHostFree(c->xch_host);
                 c->xch_host = nullptr; c->xch_host_cap = 0;
@@ -1129,24 +1139,25 @@ int dsss_posegraph_solve(dsss_ctx* c, int nframes, double* poses12, double* rpy6
                 c->xch_host_cap = all + all / 2;
             }
             char* d_all = reinterpret_cast<char*>(c->xch_dev);
+            char* d_cmp = d_all + all;
             e = hipSuccess;
             if (ne > 0) e = hipMemcpyAsync(d_all + slice * (size_t)rank, edges_p, (size_t)ne * sizeof(dsss_lc_edge), hipMemcpyHostToDevice, c->stream);
             if (e == hipSuccess) { rc = dsss_comm_allgather(c, d_all, slice, c->stream); if (rc) return rc; }
-            if (e == hipSuccess) e = hipMemcpyAsync(c->xch_host, d_all, all, hipMemcpyDeviceToHost, c->stream);
-            if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-            HIPCHK(c, e);
             size_t w = 0;
-            for (int r = 0; r < world; ++r) {
+            for (int r = 0; r < world && e == hipSuccess; ++r) {
                 const size_t k = (size_t)cnt[r];
-                if (k) memcpy(edges.data() + w, static_cast<const char*>(c->xch_host) + slice * (size_t)r, k * sizeof(dsss_lc_edge));
+                if (k) e = hipMemcpyAsync(d_cmp + w * sizeof(dsss_lc_edge), d_all + slice * (size_t)r, k * sizeof(dsss_lc_edge), hipMemcpyDeviceToDevice, c->stream);
                 w += k;
             }
+            if (e == hipSuccess) e = hipMemcpyAsync(c->xch_host, d_cmp, tot * sizeof(dsss_lc_edge), hipMemcpyDeviceToHost, c->stream);
+            if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+            HIPCHK(c, e);
+            edges_p = static_cast<dsss_lc_edge*>(c->xch_host);
         }
         ne = (int)tot;
         bool ascending = true;
-        for (int i = 1; i < ne && ascending; ++i) ascending = edges[i - 1].b <= edges[i].b;
-        if (!ascending) std::stable_sort(edges.begin(), edges.begin() + ne, [](const dsss_lc_edge& x, const dsss_lc_edge& y) { return x.b < y.b; });
-        edges_p = edges.data();
+        for (int i = 1; i < ne && ascending; ++i) ascending = edges_p[i - 1].b <= edges_p[i].b;
+        if (!ascending) std::stable_sort(edges_p, edges_p + ne, [](const dsss_lc_edge& x, const dsss_lc_edge& y) { return x.b < y.b; });
     }
     const double t_sel = ms(t1);
     const auto t2 = std::chrono::steady_clock::now();

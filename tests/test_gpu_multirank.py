@@ -135,6 +135,25 @@ def test_ranks_over_gloo_equal_single_rank(world):
         assert (res[0][1] == res[r][1]).all()                       # every rank ends with the same bits
 
 
+def test_ranks_with_the_replicated_analysis(monkeypatch):
+    """Round 6 made the RANK-LOCAL analysis the default on several ranks (a rank orders and analyses its own separators + the interface,
+    which is one dense front summed in place; dsss_pg.hip).  The replicated analysis of rounds 2 - 5 -- every rank analyses the whole
+    graph, the interface is a tree, update matrices are packed for the all-reduce -- stays as the fall-back for interfaces of more than
+    PG_LOCAL_IFACE_MAX separators and is selected here by DSSS_PG_LOCAL=0 (the spawned ranks inherit it): same trajectory, fewer or more
+    bytes summed."""
+    F, raws, poses, alts, grs = _survey()
+    ref, ref_stats, n_edges = _reference(F, raws, poses, alts, grs)
+    loc = _run(2, "gloo", 29100 + os.getpid() % 400)
+    monkeypatch.setenv("DSSS_PG_LOCAL", "0")
+    rep = _run(2, "gloo", 29500 + os.getpid() % 400)
+    for res in (loc, rep):
+        for rank, out, stats, repro, cs in res:
+            assert stats[0] == ref_stats[0] and np.abs(out - ref).max() < 1e-9 and repro
+        assert (res[0][1] == res[1][1]).all()
+    assert np.abs(loc[0][1] - rep[0][1]).max() < 1e-9
+    assert loc[0][4][2] != rep[0][4][2]                            # (bytes through the collectives: the two modes sum different buffers)
+
+
 def test_ranks_over_gloo_in_sift_mode(monkeypatch):
     """the sharded pipeline with DSSS_DESC_SIFT128: the feature all-gather carries the 128-byte rows, every rank matches its pairs by L2 on them"""
     F, raws, poses, alts, grs = _survey()
