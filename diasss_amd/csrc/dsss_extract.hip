@@ -1079,9 +1079,9 @@ static int extract_frames_impl(dsss_ctx* c, const int* ids, int n, bool keep_tap
         slot_bytes = std::max(slot_bytes, Ls[i].total);
     }
     // slots of one batch share one scratch allocation: bound it (24 GB) instead of the frame count alone
-    // (DSSS_EX_SCRATCH_GB: tools/emulate_ranks.py puts the contexts of EIGHT ranks on one device)
-    const size_t scratch_gb = getenv("DSSS_EX_SCRATCH_GB") ? (size_t)std::max(1, atoi(getenv("DSSS_EX_SCRATCH_GB"))) : 24;
-    int B = (int)std::max<size_t>(1, std::min<size_t>(std::min(n, EX_BATCH), (scratch_gb << 30) / std::max<size_t>(slot_bytes, 1)));
+    // (DSSS_EX_SCRATCH_MB: tools/emulate_ranks.py puts the contexts of EIGHT ranks on one device)
+    const size_t scratch_mb = getenv("DSSS_EX_SCRATCH_MB") ? (size_t)std::max(1, atoi(getenv("DSSS_EX_SCRATCH_MB"))) : 24576;
+    int B = (int)std::max<size_t>(1, std::min<size_t>(std::min(n, EX_BATCH), (scratch_mb << 20) / std::max<size_t>(slot_bytes, 1)));
     // frames whose page-locked host image has not been uploaded yet: smaller batches, the upload of batch k+1 runs on the copy
     // stream (xs[1]) under the kernels of batch k (PCIe: 16 B per pixel against ~6 ns of kernels per pixel, so the copies set the pace)
     bool any_pending = false;

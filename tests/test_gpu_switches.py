@@ -1,6 +1,6 @@
 """GPU: every DSSS_* environment switch that selects another code path of the product is held to the default path's result.
 
-Round 5 pruned the experiment surface to ten switches (DESIGN.md names each): two print diagnostics (DSSS_PG_VERBOSE, DSSS_EX_VERBOSE), the
+Round 5 pruned the experiment surface to ten switches (DESIGN.md names each; round 6 added DSSS_PG_LOCAL -- tests/test_gpu_multirank.py -- and DSSS_EX_SCRATCH_MB): two print diagnostics (DSSS_PG_VERBOSE, DSSS_EX_VERBOSE), the
 others are read per call, so one process can flip them.  Paths that run the SAME arithmetic in another arrangement (ordering on the host,
 other thread counts, other upload batch, the all-pairs matcher) must reproduce the default's bits; knobs that change the ELIMINATION ORDER
 (bin size, dissection leaf and both-axes threshold) must reproduce it to rounding, with the same LM path."""
@@ -14,7 +14,8 @@ pytestmark = pytest.mark.gpu
 SAME_BITS_PG = [("DSSS_SYM_THREADS", "1"), ("DSSS_SYM_THREADS", "5")]
 SAME_OPTIMUM_PG = [("DSSS_PG_BIN_COST", "300"), ("DSSS_PG_BIN_COST", "1200"), ("DSSS_PG_ND_BOTH", "1000000"), ("DSSS_PG_LEAF", "12"),
                    ("DSSS_PG_ND_INDEX", "0")]       # coordinate medians only: the ordering of rounds 2 - 4 (no chain-order cut candidate)
-SAME_BITS_EX = [("DSSS_EX_UPLOAD_BATCH", "1"), ("DSSS_EX_UPLOAD_BATCH", "3"), ("DSSS_FS_THREADS", "1")]
+SAME_BITS_EX = [("DSSS_EX_UPLOAD_BATCH", "1"), ("DSSS_EX_UPLOAD_BATCH", "3"), ("DSSS_FS_THREADS", "1"),
+                ("DSSS_EX_SCRATCH_MB", "1"), ("DSSS_EX_SCRATCH_MB", "40")]      # batches of one frame / of a few (the default bound, 24 GB, holds all five)
 
 
 class _env:

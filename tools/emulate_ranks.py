@@ -106,7 +106,7 @@ def record(wl, seed, world, device=0):
     F = wl["F"]
     big = is_big(wl)
     if big and world > 4:                                    # the extraction scratch of one context is bounded at 24 GB: eight of them plus 65 GB of frames do not fit one device
-        os.environ.setdefault("DSSS_EX_SCRATCH_GB", str(max(2, 64 // world)))
+        os.environ.setdefault("DSSS_EX_SCRATCH_MB", str(max(2048, 65536 // world)))
     raws, poses, alts, grs = inputs(wl, seed, "cuda:%d" % device, set(range(F)))
     ls = LockStep(world)
     pipes = []
