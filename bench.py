@@ -479,6 +479,32 @@ def main():
             p.close()
     h_raws = None
 
+    # ---- side leg on several GPUs: ONE WHOLE SURVEY PER GPU, no communication -- what DESIGN.md section 4 "Ranks" recommends for throughput (a
+    # fleet's surveys are independent; the sharded step above is the latency of ONE survey and is what `value` reports).  Every rank makes the
+    # whole survey (3.3 GB at C3), runs it through a context of its own outside the communicator, and the aggregate is all ranks' frames over
+    # the slowest rank's time.  Never fatal: a failure here leaves the line without the leg.
+    replicas = None
+    if (world > 1 or force_comm) and not args.no_side_legs and not big:
+        try:
+            all_raws = [raws[f] if raws[f] is not None else sv.frame(f) for f in range(F)]
+            solo = Pipeline(F, device=local_rank, nfeatures=wl.get("nfeatures"))
+            solo_survey = solo.prepare(all_raws, poses, alts, grs)
+            for _ in range(max(1, args.warmup)):
+                solo.run(solo_survey)
+            solo.ctx.sync(); barrier()
+            t4 = time.perf_counter()
+            for _ in range(args.steps):
+                solo.run(solo_survey)
+            solo.ctx.sync(); barrier()
+            dt4 = time.perf_counter() - t4
+            if world > 1:
+                t = torch.tensor([dt4], dtype=torch.float64, device="cuda"); dist.all_reduce(t, op=dist.ReduceOp.MAX); dt4 = float(t.item())
+            solo.close(); del all_raws
+            replicas = {"value": world * F * args.steps / dt4, "unit": "frames/s", "surveys": world, "ms_per_step": 1e3 * dt4 / args.steps, "scaling": "weak",
+                        "note": "one whole survey per GPU, no collective in the data path: the throughput arrangement; `value` above is ONE survey sharded over the GPUs (strong scaling, its latency)"}
+        except Exception as e:                          # (the main line must not depend on this leg)
+            replicas = {"error": "%s: %s" % (type(e).__name__, e)}
+
     if rank == 0:
         out = {
             "metric": "sonar frames/sec end-to-end (extract+match+LM solve)",
@@ -495,6 +521,8 @@ def main():
             "roofline": roof, "roofline_stages": roof_groups, "roofline_all_kernels": roof_all, "breakdown_ms": breakdown, "work_per_step": work, "pcie_inclusive": pcie, "throughput_surveys_in_flight": inflight,
             "match_allpairs": match_allpairs, "sift128": sift_leg,
         }
+        if replicas is not None:
+            out["throughput_one_survey_per_gpu"] = replicas
         if crit is not None:      # the dependent-chain floor belongs to the factorisation stage; the headline carries it when that stage IS the headline
             if roof_groups and roof_groups.get("pg_factor"):
                 out["roofline_stages"] = dict(roof_groups, pg_factor=dict(roof_groups["pg_factor"], critical_path_floor_ms=crit["ms_per_step"], critical_path=crit))
