@@ -301,7 +301,33 @@ static int pg_solve_impl(dsss_ctx* c, const double* dr6, int total, const dsss_l
             for (int& v : S.fa_src) v = v >= S.nval ? nval_g + (v - S.nval) : (v < nsl ? glob_of[v] : ns + ledge_g[v - nsl]);
             for (size_t q = 0; q < S.iface_seps.size(); ++q) { const int k = glob_of[S.iface_seps[q]]; ifsep_g.push_back(k); ifslot_g[k] = (int)q; }
         } else {
-            pg_symbolic(ns, redges, nseg, cx.data(), cy.data(), nparts > 1 ? sym_part.data() : nullptr, nparts, opt, S);
+            // ONE rank, one partition: the analysis BY PARTS (pg_symbolic_parts, round 6).  The phases of pg_symbolic gain nothing from threads at
+            // C3's size (one thread 4.0 ms, eight 3.4: a dozen fork / joins around 0.1 - 0.3 ms of work each), whole parts do: the chain order is
+            // cut into K parts where few loop closures cross (the gap with the fewest spanning loop closures within a third of a part of the
+            // equal-count position: one difference array over the separators prices them all), every part is ordered and analysed on its own
+            // thread with the interface between the parts as the last dense front, and the tables are joined.
+            bool by_parts = false;
+            int K = getenv("DSSS_PG_PARTS_ANALYSIS") ? atoi(getenv("DSSS_PG_PARTS_ANALYSIS")) : (ns >= 6000 ? std::min(16, std::max(2, ns / 2800)) : 0);
+            if (nparts == 1 && K >= 2 && ne > 0) {
+                K = std::min(K, ns / 8);
+                std::vector<int> cross(ns + 1, 0), vpart(ns, 0);
+                for (size_t g = (size_t)ns - 1; g < redges.size(); ++g) { const int lo = std::min(redges[g].first, redges[g].second), hi = std::max(redges[g].first, redges[g].second); cross[lo + 1]++; cross[hi + 1]--; }
+                for (int k = 1; k <= ns; ++k) cross[k] += cross[k - 1];      // cross[g]: loop closures that span the gap between separators g - 1 and g
+                int prev = 0, p_cur = 0;
+                std::vector<int> starts;
+                for (int p = 1; p < K; ++p) {
+                    const int target = (int)((long long)ns * p / K), width = ns / K / 3;
+                    int best = -1, bcost = 1 << 30, bdist = 0;
+                    for (int g = std::max(target - width, prev + 1); g <= std::min(target + width, ns - 1); ++g) {
+                        const int d = std::abs(g - target);
+                        if (cross[g] < bcost || (cross[g] == bcost && d < bdist)) { bcost = cross[g]; bdist = d; best = g; }
+                    }
+                    if (best > prev && bcost <= PG_PARTS_CUT_MAX) { starts.push_back(best); prev = best; }      // (an expensive boundary is left out: its two parts stay one)
+                }
+                for (int k = 0; k < ns; ++k) { while (p_cur < (int)starts.size() && k >= starts[p_cur]) ++p_cur; vpart[k] = p_cur; }
+                if (!starts.empty()) by_parts = pg_symbolic_parts(ns, redges, nseg, cx.data(), cy.data(), vpart.data(), (int)starts.size() + 1, PG_PARTS_IFACE_MAX, opt, S);
+            }
+            if (!by_parts) pg_symbolic(ns, redges, nseg, cx.data(), cy.data(), nparts > 1 ? sym_part.data() : nullptr, nparts, opt, S);
             // launch lists: this rank's interior fronts, then (after the all-reduce) the replicated interface fronts
             pg_build_schedule(S, part_lo, part_hi, SO);
             if (nparts > 1) pg_build_schedule(S, -1, 0, SI);

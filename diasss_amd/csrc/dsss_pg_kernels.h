@@ -31,6 +31,8 @@ struct pg_child { const double* U; const double* g; long long relptr; int cld, c
 #define PG_BWD2_LD 97
 #define PG_BWD2_SX 8192                         // rows of x2 the LDS stages; taller fronts read x2 through the row map
 #define PG_BWD_SPLIT 2048
+#define PG_PARTS_CUT_MAX 12                          // ... and a boundary between two parts may be spanned by at most this many loop closures (every one puts a separator into the interface)
+#define PG_PARTS_IFACE_MAX 256                       // one rank analysed by parts (pg_symbolic_parts): the interface between the parts, one dense front, at most this many separators
 #define PG_LOCAL_IFACE_MAX 160                       // rank-local analysis (dsss_pg.hip): the interface is ONE dense front of at most this many separators (960 scalar columns, 7.4 MB summed per trial); beyond, the replicated analysis with its interface tree
 #define PG_BWD_RC 512
 #define RNG_PER_THREAD 16

@@ -456,6 +456,70 @@ void col_structs(const cs_ctx& C, int t, int lo, int size, std::vector<std::pair
 
 } // namespace
 
+
+namespace {
+// panel levels of the fronts (children have smaller indices than their parents)
+void sym_levels(pg_sym& S)
+{
+    const int nf = (int)S.f_c0.size();
+    // schedule: a front starts one level after its last child front has finished; panel steps are consecutive levels
+    S.f_level0.assign(nf, 0); S.f_npan.resize(nf); S.f_pan0.resize(nf);
+    int maxl = -1, np = 0;
+    for (int f = 0; f < nf; ++f) {
+        S.f_npan[f] = (S.f_s[f] + PG_PW - 1) / PG_PW; S.f_pan0[f] = np; np += S.f_npan[f];
+        int l0 = 0;
+        for (int c = S.ch_ptr[f]; c < S.ch_ptr[f + 1]; ++c) if (!S.ch_kind[c]) { const int g = S.ch_id[c]; l0 = std::max(l0, S.f_level0[g] + S.f_npan[g]); }
+        S.f_level0[f] = l0; maxl = std::max(maxl, l0 + S.f_npan[f] - 1);
+    }
+    S.npanels = np; S.nlev = maxl + 1;
+    S.lv_ptr.assign(S.nlev + 1, 0); S.asm_ptr.assign(S.nlev + 1, 0);
+    for (int f = 0; f < nf; ++f) { S.asm_ptr[S.f_level0[f] + 1]++; for (int k = 0; k < S.f_npan[f]; ++k) S.lv_ptr[S.f_level0[f] + k + 1]++; }
+    for (int l = 0; l < S.nlev; ++l) { S.lv_ptr[l + 1] += S.lv_ptr[l]; S.asm_ptr[l + 1] += S.asm_ptr[l]; }
+    S.lv_front.resize(np); S.lv_step.resize(np); S.asm_front.resize(nf);
+    {
+        std::vector<int> fp(S.lv_ptr.begin(), S.lv_ptr.end() - 1), fq(S.asm_ptr.begin(), S.asm_ptr.end() - 1);
+        for (int f = 0; f < nf; ++f) {
+            S.asm_front[fq[S.f_level0[f]]++] = f;
+            for (int k = 0; k < S.f_npan[f]; ++k) { const int at = fp[S.f_level0[f] + k]++; S.lv_front[at] = f; S.lv_step[at] = k; }
+        }
+    }
+}
+
+// per-row views of the fronts for the assembly kernel
+void sym_row_views(pg_sym& S, int T)
+{
+    const int nf = (int)S.f_c0.size();
+    // ---- per-row views for the assembly, work items of the assembly and of the trailing update
+    {
+        const int nrows_all = S.f_rowptr[nf];
+        S.fa_rowptr.assign(nrows_all + 1, 0);
+        S.xr_ptr.assign(nrows_all + 1, 0);
+        // (a front's block rows are its own range of both views: counts and fills run by ranges of fronts, the two prefix sums between them
+        // are one pass each)
+        par_ranges(nf, T, [&](int, int lo, int hi) {
+            for (int f = lo; f < hi; ++f) {
+                for (int e = S.fa_ptr[f]; e < S.fa_ptr[f + 1]; ++e) S.fa_rowptr[S.f_rowptr[f] + S.fa_row[e] + 1]++;
+                for (int c = S.ch_ptr[f]; c < S.ch_ptr[f + 1]; ++c) { const long long r0 = S.ch_relptr[c], r1 = S.ch_relptr[c + 1]; for (long long q = r0; q < r1; ++q) S.xr_ptr[S.f_rowptr[f] + S.rel[q] + 1]++; }
+            }
+        });
+        // entries are sorted by (front, row): the CSR offsets are global positions in fa_*
+        for (int i = 0; i < nrows_all; ++i) { S.fa_rowptr[i + 1] += S.fa_rowptr[i]; S.xr_ptr[i + 1] += S.xr_ptr[i]; }
+        S.xr_child.resize(S.xr_ptr[nrows_all]); S.xr_row.resize(S.xr_ptr[nrows_all]);
+        par_ranges(nf, T, [&](int, int lo, int hi) {
+            std::vector<int> fp;
+            for (int f = lo; f < hi; ++f) {
+                const int r0f = S.f_rowptr[f], nr = S.f_n[f];
+                fp.assign(S.xr_ptr.begin() + r0f, S.xr_ptr.begin() + r0f + nr);
+                for (int c = S.ch_ptr[f]; c < S.ch_ptr[f + 1]; ++c) {                                   // children in their fixed order
+                    const long long r0 = S.ch_relptr[c], r1 = S.ch_relptr[c + 1];
+                    for (long long q = r0; q < r1; ++q) { const int at = fp[S.rel[q]]++; S.xr_child[at] = c; S.xr_row[at] = (int)(q - r0); }
+                }
+            }
+        });
+    }
+}
+} // namespace
+
 void pg_symbolic(int ns, const std::vector<std::pair<int, int>>& edges, int nchain, const double* cx, const double* cy,
                  const int* part, int nparts, const pg_sym_opts& opt, pg_sym& S)
 {
@@ -627,6 +691,7 @@ void pg_symbolic(int ns, const std::vector<std::pair<int, int>>& edges, int ncha
                 fill += sub_cost[r]; bin_of_root[r] = nbins - 1; bin_fill.back() = fill;
             }
             // launch order: descending work inside every rank's (contiguous) range of bins; ties keep the bin order
+            S.bin_work = bin_fill;
             S.bin_perm.resize(nbins);
             for (int b = 0; b < nbins; ++b) S.bin_perm[b] = b;
             for (int b0 = 0; b0 < nbins;) {
@@ -860,27 +925,7 @@ void pg_symbolic(int ns, const std::vector<std::pair<int, int>>& edges, int ncha
         });
     }
     const auto fC = tnow();
-    // ---- schedule: a front starts one level after its last child front has finished; panel steps are consecutive levels
-    S.f_level0.assign(nf, 0); S.f_npan.resize(nf); S.f_pan0.resize(nf);
-    int maxl = -1, np = 0;
-    for (int f = 0; f < nf; ++f) {
-        S.f_npan[f] = (S.f_s[f] + PG_PW - 1) / PG_PW; S.f_pan0[f] = np; np += S.f_npan[f];
-        int l0 = 0;
-        for (int c = S.ch_ptr[f]; c < S.ch_ptr[f + 1]; ++c) if (!S.ch_kind[c]) { const int g = S.ch_id[c]; l0 = std::max(l0, S.f_level0[g] + S.f_npan[g]); }
-        S.f_level0[f] = l0; maxl = std::max(maxl, l0 + S.f_npan[f] - 1);
-    }
-    S.npanels = np; S.nlev = maxl + 1;
-    S.lv_ptr.assign(S.nlev + 1, 0); S.asm_ptr.assign(S.nlev + 1, 0);
-    for (int f = 0; f < nf; ++f) { S.asm_ptr[S.f_level0[f] + 1]++; for (int k = 0; k < S.f_npan[f]; ++k) S.lv_ptr[S.f_level0[f] + k + 1]++; }
-    for (int l = 0; l < S.nlev; ++l) { S.lv_ptr[l + 1] += S.lv_ptr[l]; S.asm_ptr[l + 1] += S.asm_ptr[l]; }
-    S.lv_front.resize(np); S.lv_step.resize(np); S.asm_front.resize(nf);
-    {
-        std::vector<int> fp(S.lv_ptr.begin(), S.lv_ptr.end() - 1), fq(S.asm_ptr.begin(), S.asm_ptr.end() - 1);
-        for (int f = 0; f < nf; ++f) {
-            S.asm_front[fq[S.f_level0[f]]++] = f;
-            for (int k = 0; k < S.f_npan[f]; ++k) { const int at = fp[S.f_level0[f] + k]++; S.lv_front[at] = f; S.lv_step[at] = k; }
-        }
-    }
+    sym_levels(S);
     if (tv && atoi(getenv("DSSS_PG_VERBOSE")) >= 2) {      // critical path of the schedule, root first
         int f = -1;
         for (int g = 0; g < nf; ++g) if (S.f_level0[g] + S.f_npan[g] == S.nlev) f = g;
@@ -892,34 +937,7 @@ void pg_symbolic(int ns, const std::vector<std::pair<int, int>>& edges, int ncha
         }
     }
     const auto fD = tnow();
-    // ---- per-row views for the assembly, work items of the assembly and of the trailing update
-    {
-        const int nrows_all = S.f_rowptr[nf];
-        S.fa_rowptr.assign(nrows_all + 1, 0);
-        S.xr_ptr.assign(nrows_all + 1, 0);
-        // (a front's block rows are its own range of both views: counts and fills run by ranges of fronts, the two prefix sums between them
-        // are one pass each)
-        par_ranges(nf, T, [&](int, int lo, int hi) {
-            for (int f = lo; f < hi; ++f) {
-                for (int e = S.fa_ptr[f]; e < S.fa_ptr[f + 1]; ++e) S.fa_rowptr[S.f_rowptr[f] + S.fa_row[e] + 1]++;
-                for (int c = S.ch_ptr[f]; c < S.ch_ptr[f + 1]; ++c) { const long long r0 = S.ch_relptr[c], r1 = S.ch_relptr[c + 1]; for (long long q = r0; q < r1; ++q) S.xr_ptr[S.f_rowptr[f] + S.rel[q] + 1]++; }
-            }
-        });
-        // entries are sorted by (front, row): the CSR offsets are global positions in fa_*
-        for (int i = 0; i < nrows_all; ++i) { S.fa_rowptr[i + 1] += S.fa_rowptr[i]; S.xr_ptr[i + 1] += S.xr_ptr[i]; }
-        S.xr_child.resize(S.xr_ptr[nrows_all]); S.xr_row.resize(S.xr_ptr[nrows_all]);
-        par_ranges(nf, T, [&](int, int lo, int hi) {
-            std::vector<int> fp;
-            for (int f = lo; f < hi; ++f) {
-                const int r0f = S.f_rowptr[f], nr = S.f_n[f];
-                fp.assign(S.xr_ptr.begin() + r0f, S.xr_ptr.begin() + r0f + nr);
-                for (int c = S.ch_ptr[f]; c < S.ch_ptr[f + 1]; ++c) {                                   // children in their fixed order
-                    const long long r0 = S.ch_relptr[c], r1 = S.ch_relptr[c + 1];
-                    for (long long q = r0; q < r1; ++q) { const int at = fp[S.rel[q]]++; S.xr_child[at] = c; S.xr_row[at] = (int)(q - r0); }
-                }
-            }
-        });
-    }
+    sym_row_views(S, T);
     const auto fE = tnow();
     // ---- children that cross from a rank's interior into the interface
     {
@@ -940,7 +958,7 @@ void pg_symbolic(int ns, const std::vector<std::pair<int, int>>& edges, int ncha
         S.nval = nval;
         if (S.nparts > 1 || nlast > 0) {
             std::vector<int> slot_of(nval, -1);
-            for (int f = 0; f < nf; ++f) {
+            for (int f = 0; f < nf && !opt.iface_plain; ++f) {
                 if (S.f_part[f] >= 0) continue;
                 for (int e = S.fa_ptr[f]; e < S.fa_ptr[f + 1]; ++e) {
                     const int v = S.fa_src[e];
@@ -1198,6 +1216,223 @@ extern "C" int dsss_host_pg_solve_local(int ns, const int32_t* edge_a, const int
     if (stats8) {
         stats8[0] = S.nnzL; stats8[1] = (int64_t)S.f_c0.size(); stats8[2] = S.npanels; stats8[3] = S.nlev;
         stats8[4] = S.front_doubles; stats8[5] = (int64_t)S.comm_vals.size(); stats8[6] = (int64_t)S.bincols.size(); stats8[7] = S.max_front_n;
+    }
+    return rc == 0 ? DSSS_OK : (rc == -1 ? DSSS_E_NUMERIC : DSSS_E_STATE);
+}
+
+// ------------------------------------------------------------------ one rank analysed by parts (dsss_pg_sym.h)
+bool pg_symbolic_parts(int ns, const std::vector<std::pair<int, int>>& edges, int nchain, const double* cx, const double* cy,
+                       const int* part, int K, int max_iface, const pg_sym_opts& opt, pg_sym& G)
+{
+    (void)nchain;
+    const bool tv = getenv("DSSS_PG_VERBOSE") != nullptr;
+    const auto q0 = std::chrono::steady_clock::now();
+    auto ms_since = [](std::chrono::steady_clock::time_point a) { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - a).count(); };
+    // the interface: nodes with a neighbour in a higher part (every edge between two parts has its lower end here)
+    std::vector<char> isif(ns, 0);
+    for (const auto& e : edges) { const int pa = part[e.first], pb = part[e.second]; if (pa < pb) isif[e.first] = 1; else if (pb < pa) isif[e.second] = 1; }
+    std::vector<int> I, iidx(ns, -1);
+    for (int k = 0; k < ns; ++k) if (isif[k]) { iidx[k] = (int)I.size(); I.push_back(k); }
+    const int nif = (int)I.size();
+    if (nif > max_iface || K < 2) return false;
+    struct part_t {
+        pg_sym S; std::vector<int> glob_of, ledge_g; std::vector<std::pair<int, int>> ledges; std::vector<double> cx, cy; std::vector<int> loc_of;
+        int nint = 0, nfi = 0;                                     // interior columns, interior fronts
+        long long c0 = 0, nnz0 = 0, f0 = 0, b0 = 0, br0 = 0, ch0 = 0, rel0 = 0, fa0 = 0, fd0 = 0, fr0 = 0, ub0 = 0, bc0 = 0, rl0 = 0, frow0 = 0;
+        long long nnz = 0, nchI = 0, nrelI = 0, nfaI = 0, nrows = 0;   // interior: factor blocks, children, rel entries, original entries, front rows
+    };
+    std::vector<part_t> P(K);
+    if (opt.before_order) opt.before_order();                      // (the coordinates: every part needs its own copy before it orders)
+    const double t_pre = ms_since(q0);
+    // ---- phase 1: every part on its own
+    dsss_pool_run(K, [&](int p) {
+        part_t& Q = P[p];
+        Q.loc_of.assign(ns, -1);
+        pg_sym_opts o = opt;
+        o.threads = 1; o.before_order = nullptr; o.on_bottom_ready = nullptr; o.on_lists_ready = nullptr; o.iface_plain = true; o.iface_last.clear();
+        for (int k = 0; k < ns; ++k)
+            if (isif[k] || part[k] == p) { Q.loc_of[k] = (int)Q.glob_of.size(); if (isif[k]) o.iface_last.push_back(Q.loc_of[k]); Q.glob_of.push_back(k); }
+        for (size_t g = 0; g < edges.size(); ++g) {
+            const int a = Q.loc_of[edges[g].first], b = Q.loc_of[edges[g].second];
+            if (a >= 0 && b >= 0 && a != b) { Q.ledges.push_back({ a, b }); Q.ledge_g.push_back((int)g); }
+        }
+        const int nsl = (int)Q.glob_of.size();
+        Q.cx.resize(nsl); Q.cy.resize(nsl);
+        for (int i = 0; i < nsl; ++i) { Q.cx[i] = cx[Q.glob_of[i]]; Q.cy[i] = cy[Q.glob_of[i]]; }
+        pg_symbolic(nsl, Q.ledges, 0, Q.cx.data(), Q.cy.data(), nullptr, 1, o, Q.S);
+        Q.nint = nsl - nif;
+    });
+    const double t_parts = ms_since(q0);
+    // ---- offsets of every index space
+    long long c0 = 0, nnz0 = 0, f0 = 0, b0 = 0, br0 = 0, ch0 = 0, rel0 = 0, fa0 = 0, fd0 = 0, fr0 = 0, ub0 = 0, bc0 = 0, rl0 = 0, frow0 = 0;
+    for (int p = 0; p < K; ++p) {
+        part_t& Q = P[p]; const pg_sym& S = Q.S;
+        const int nf = (int)S.f_c0.size();
+        if (nif > 0 && (nf < 1 || S.f_part[nf - 1] != -1 || S.f_s[nf - 1] != nif || S.f_n[nf - 1] != nif || S.f_c0[nf - 1] != Q.nint)) return false;      // (the interface must be the last, dense front of every part)
+        Q.nfi = nif > 0 ? nf - 1 : nf;
+        Q.nnz = S.colptr[Q.nint];
+        Q.nchI = S.ch_ptr[Q.nfi]; Q.nrelI = S.ch_relptr[Q.nchI]; Q.nfaI = S.fa_ptr[Q.nfi]; Q.nrows = S.f_rowptr[Q.nfi];
+        Q.c0 = c0; Q.nnz0 = nnz0; Q.f0 = f0; Q.b0 = b0; Q.br0 = br0; Q.ch0 = ch0; Q.rel0 = rel0; Q.fa0 = fa0; Q.fd0 = fd0; Q.fr0 = fr0; Q.ub0 = ub0; Q.bc0 = bc0; Q.rl0 = rl0; Q.frow0 = frow0;
+        c0 += Q.nint; nnz0 += Q.nnz; f0 += Q.nfi; b0 += (long long)S.binptr.size() - 1; br0 += (long long)S.broot.size(); ch0 += Q.nchI; rel0 += Q.nrelI; fa0 += Q.nfaI;
+        fd0 += Q.nfi < nf ? S.f_off[Q.nfi] : S.front_doubles; fr0 += Q.nfi < nf ? S.f_roff[Q.nfi] : S.frhs_doubles; ub0 += S.ubin_doubles; bc0 += (long long)S.bincols.size();
+        rl0 += S.rlptr.empty() ? 0 : S.rlptr[Q.nint]; frow0 += Q.nrows;
+    }
+    const int cI = (int)c0, nfG = (int)f0 + (nif > 0 ? 1 : 0), nbG = (int)b0, nbrG = (int)br0;
+    const long long nnzI = (long long)nif * (nif + 1) / 2, nnzG = nnz0 + nnzI;
+    // children / rel / original entries of the interface front: the parts' own, behind each other
+    long long chI = 0, relI = 0;
+    std::vector<long long> chI0(K, 0), relI0(K, 0);
+    for (int p = 0; p < K; ++p) {
+        const pg_sym& S = P[p].S;
+        chI0[p] = chI; relI0[p] = relI;
+        if (nif > 0) { chI += S.ch_ptr[P[p].nfi + 1] - S.ch_ptr[P[p].nfi]; relI += S.ch_relptr[S.ch_ptr[P[p].nfi + 1]] - S.ch_relptr[S.ch_ptr[P[p].nfi]]; }
+    }
+    const long long faI = nif > 0 ? P[0].S.fa_ptr[P[0].nfi + 1] - P[0].S.fa_ptr[P[0].nfi] : 0;
+    const bool host_lists = !opt.lists_on_device;
+    G = pg_sym();
+    G.ns = ns; G.nparts = 1;
+    G.nval = ns + (int)edges.size();
+    G.perm.assign(ns, -1); G.order.assign(ns, -1);
+    G.colptr.assign(ns + 1, 0); G.rowidx.resize(nnzG); G.parent.assign(ns, -1); G.col_part.assign(ns, 0);
+    G.binned.assign(ns, 0); G.root_of.assign(ns, -1); G.broot_of_col.assign(ns, -1); G.front_of_col.assign(ns, -1);
+    G.binptr.assign(nbG + 1, 0); G.bincols.resize(bc0); G.bin_part.assign(nbG, 0); G.bin_work.resize(nbG); G.bin_perm.resize(nbG);
+    G.broot.resize(nbrG); G.broot_b.resize(nbrG); G.broot_uoff.resize(nbrG); G.binroot_ptr.assign(nbG + 1, 0); G.binroot_idx.resize(nbrG);
+    G.ubin_doubles = ub0;
+    if (host_lists) { G.rlptr.assign(ns + 1, 0); G.rlcol.resize(rl0); G.rlpos.resize(rl0); G.rlrow.resize(rl0); G.anc_first.assign(ns, 0); G.anc_rel.assign(nnzG, -1); }
+    G.f_c0.resize(nfG); G.f_s.resize(nfG); G.f_n.resize(nfG); G.f_ld.resize(nfG); G.f_off.resize(nfG); G.f_roff.resize(nfG); G.f_parent.assign(nfG, -1); G.f_part.assign(nfG, 0);
+    G.f_rowptr.assign(nfG + 1, 0); G.f_rows.resize(frow0 + nif);
+    G.ch_ptr.assign(nfG + 1, 0); G.ch_kind.resize(ch0 + chI); G.ch_id.resize(ch0 + chI); G.ch_relptr.assign(ch0 + chI + 1, 0); G.rel.resize(rel0 + relI);
+    G.fa_ptr.assign(nfG + 1, 0); G.fa_src.resize(fa0 + faI); G.fa_row.resize(fa0 + faI); G.fa_col.resize(fa0 + faI); G.fa_tr.resize(fa0 + faI);
+    G.dest_bin.assign(G.nval, -1);
+    // ---- phase 2: every part writes its share of the joined tables
+    dsss_pool_run(K, [&](int p) {
+        const part_t& Q = P[p]; const pg_sym& S = Q.S;
+        const int nint = Q.nint;
+        auto colmap = [&](int j) { return j < nint ? (int)Q.c0 + j : cI + (j - nint); };
+        auto valmap = [&](int v) { const int nsl = (int)Q.glob_of.size(); return v < nsl ? Q.glob_of[v] : ns + Q.ledge_g[v - nsl]; };
+        for (int j = 0; j < nint; ++j) {
+            const int c = (int)Q.c0 + j, v = Q.glob_of[S.order[j]];
+            G.order[c] = v; G.perm[v] = c;
+            const int b = S.colptr[j], m = S.colptr[j + 1] - b;
+            G.colptr[c + 1] = m;                                                  // (sizes now, the prefix sum below)
+            int* out = G.rowidx.data() + Q.nnz0 + b;
+            for (int q = 0; q < m; ++q) out[q] = colmap(S.rowidx[b + q]);
+            G.parent[c] = S.parent[j] >= 0 ? colmap(S.parent[j]) : -1;
+            G.binned[c] = S.binned[j];
+            G.root_of[c] = S.root_of[j] >= 0 ? (int)Q.c0 + S.root_of[j] : -1;
+            G.broot_of_col[c] = S.broot_of_col.empty() || S.broot_of_col[j] < 0 ? -1 : (int)Q.br0 + S.broot_of_col[j];
+            G.front_of_col[c] = S.front_of_col[j] < 0 ? -1 : (S.front_of_col[j] >= Q.nfi ? nfG - 1 : (int)Q.f0 + S.front_of_col[j]);
+            if (host_lists) {
+                G.rlptr[c + 1] = S.rlptr[j + 1] - S.rlptr[j];
+                for (int t = S.rlptr[j]; t < S.rlptr[j + 1]; ++t) { const long long at = Q.rl0 + t; G.rlcol[at] = (int)Q.c0 + S.rlcol[t]; G.rlpos[at] = (int)(Q.nnz0 + S.rlpos[t]); G.rlrow[at] = (int)Q.c0 + S.rlrow[t]; }
+                G.anc_first[c] = S.anc_first[j];
+                for (int q = 0; q < m; ++q) G.anc_rel[Q.nnz0 + b + q] = S.anc_rel[b + q];
+            }
+        }
+        // bins and their roots
+        const int nb = (int)S.binptr.size() - 1;
+        for (int b = 0; b < nb; ++b) {
+            G.binptr[Q.b0 + b + 1] = S.binptr[b + 1] - S.binptr[b];
+            G.bin_work[Q.b0 + b] = S.bin_work[b];
+            G.binroot_ptr[Q.b0 + b + 1] = S.binroot_ptr[b + 1] - S.binroot_ptr[b];
+        }
+        for (size_t i = 0; i < S.bincols.size(); ++i) G.bincols[Q.bc0 + i] = (int)Q.c0 + S.bincols[i];
+        for (size_t i = 0; i < S.broot.size(); ++i) {
+            G.broot[Q.br0 + i] = (int)Q.c0 + S.broot[i]; G.broot_b[Q.br0 + i] = S.broot_b[i]; G.broot_uoff[Q.br0 + i] = Q.ub0 + S.broot_uoff[i];
+            G.binroot_idx[Q.br0 + i] = (int)Q.br0 + S.binroot_idx[i];
+        }
+        // interior fronts
+        for (int f = 0; f < Q.nfi; ++f) {
+            const int g = (int)Q.f0 + f;
+            G.f_c0[g] = (int)Q.c0 + S.f_c0[f]; G.f_s[g] = S.f_s[f]; G.f_n[g] = S.f_n[f]; G.f_ld[g] = S.f_ld[f];
+            G.f_off[g] = Q.fd0 + S.f_off[f]; G.f_roff[g] = Q.fr0 + S.f_roff[f];
+            G.f_parent[g] = S.f_parent[f] < 0 ? -1 : (S.f_parent[f] >= Q.nfi ? nfG - 1 : (int)Q.f0 + S.f_parent[f]);
+            G.f_rowptr[g + 1] = S.f_n[f];
+            int* out = G.f_rows.data() + Q.frow0 + S.f_rowptr[f];
+            for (int q = 0; q < S.f_n[f]; ++q) out[q] = colmap(S.f_rows[S.f_rowptr[f] + q]);
+            G.ch_ptr[g + 1] = S.ch_ptr[f + 1] - S.ch_ptr[f];
+            G.fa_ptr[g + 1] = S.fa_ptr[f + 1] - S.fa_ptr[f];
+        }
+        auto put_children = [&](int c_lo, int c_hi, long long at, long long rel_at) {
+            for (int c = c_lo; c < c_hi; ++c, ++at) {
+                G.ch_kind[at] = S.ch_kind[c]; G.ch_id[at] = S.ch_kind[c] ? (int)Q.br0 + S.ch_id[c] : (int)Q.f0 + S.ch_id[c];
+                const long long r0 = S.ch_relptr[c], r1 = S.ch_relptr[c + 1];
+                G.ch_relptr[at + 1] = r1 - r0;                                    // (sizes now, the prefix sum below)
+                for (long long q = r0; q < r1; ++q) G.rel[rel_at + (q - r0)] = S.rel[q];
+                rel_at += r1 - r0;
+            }
+        };
+        put_children(0, (int)Q.nchI, Q.ch0, Q.rel0);
+        if (nif > 0) put_children(S.ch_ptr[Q.nfi], S.ch_ptr[Q.nfi + 1], ch0 + chI0[p], rel0 + relI0[p]);
+        auto put_entries = [&](int e_lo, int e_hi, long long at) {
+            for (int e = e_lo; e < e_hi; ++e, ++at) { G.fa_src[at] = valmap(S.fa_src[e]); G.fa_row[at] = S.fa_row[e]; G.fa_col[at] = S.fa_col[e]; G.fa_tr[at] = S.fa_tr[e]; }
+        };
+        put_entries(0, (int)Q.nfaI, Q.fa0);
+        if (nif > 0 && p == 0) put_entries(S.fa_ptr[Q.nfi], S.fa_ptr[Q.nfi + 1], fa0);      // (the interface's own values: every part lists them all, one copy counts)
+        // destinations of the values whose column is one of this part's interior columns (the interface's own stay -1: front)
+        for (int v = 0; v < (int)S.dest_bin.size(); ++v) if (S.dest_bin[v] >= 0) G.dest_bin[valmap(v)] = (int)(((Q.nnz0 + (S.dest_bin[v] >> 1)) << 1) | (S.dest_bin[v] & 1));
+    });
+    // ---- the interface columns and their front; prefix sums; orders
+    for (int i = 0; i < nif; ++i) { const int c = cI + i; G.order[c] = I[i]; G.perm[I[i]] = c; G.colptr[c + 1] = nif - i; G.parent[c] = i + 1 < nif ? c + 1 : -1; G.front_of_col[c] = nfG - 1; }
+    for (int c = 0; c < ns; ++c) G.colptr[c + 1] += G.colptr[c];
+    { long long at = nnz0; for (int i = 0; i < nif; ++i) for (int r = i; r < nif; ++r) G.rowidx[at++] = cI + r; }
+    G.nnzL = nnzG;
+    for (int b = 0; b < nbG; ++b) { G.binptr[b + 1] += G.binptr[b]; G.binroot_ptr[b + 1] += G.binroot_ptr[b]; }
+    if (host_lists) {
+        for (int c = 0; c < ns; ++c) G.rlptr[c + 1] += G.rlptr[c];
+        G.mapptr.assign(ns + 1, 0);
+        for (int c = 0; c < ns; ++c) G.mapptr[c + 1] = G.mapptr[c] + (long long)(G.rlptr[c + 1] - G.rlptr[c]) * (long long)(G.colptr[c + 1] - G.colptr[c]);
+    }
+    for (int b = 0; b < nbG; ++b) G.bin_perm[b] = b;
+    std::stable_sort(G.bin_perm.begin(), G.bin_perm.end(), [&](int x, int y) { return G.bin_work[x] > G.bin_work[y]; });
+    if (nif > 0) {
+        const int g = nfG - 1, ld = (6 * nif + 15) & ~15;
+        G.f_c0[g] = cI; G.f_s[g] = nif; G.f_n[g] = nif; G.f_ld[g] = ld; G.f_off[g] = fd0; G.f_roff[g] = fr0; G.f_parent[g] = -1;
+        G.f_rowptr[g + 1] = nif;
+        for (int i = 0; i < nif; ++i) G.f_rows[frow0 + i] = cI + i;
+        G.ch_ptr[g + 1] = (int)chI; G.fa_ptr[g + 1] = (int)faI;
+        G.front_doubles = fd0 + (long long)ld * ld; G.frhs_doubles = fr0 + ld;
+    } else { G.front_doubles = fd0; G.frhs_doubles = fr0; }
+    for (int f = 0; f < nfG; ++f) { G.f_rowptr[f + 1] += G.f_rowptr[f]; G.ch_ptr[f + 1] += G.ch_ptr[f]; G.fa_ptr[f + 1] += G.fa_ptr[f]; }
+    for (size_t c = 0; c + 1 < G.ch_relptr.size(); ++c) G.ch_relptr[c + 1] += G.ch_relptr[c];
+    // statistics: the parts counted the interface columns once each
+    double if_cols = 0, if_front = 0;
+    for (int i = 0; i < nif; ++i) { const double m = nif - 1 - i; if_cols += 36.0 * 6.0 * (m * m + 3 * m) + 72.0; if_front += 216.0 * (m * m + 3 * m) + 72.0; }
+    for (int p = 0; p < K; ++p) { G.flops_factor += P[p].S.flops_factor - if_cols; G.flops_fronts += P[p].S.flops_fronts - (nif > 0 ? if_front : 0); }
+    G.flops_factor += if_cols; G.flops_fronts += nif > 0 ? if_front : 0;
+    for (int f = 0; f < nfG; ++f) G.max_front_n = std::max(G.max_front_n, G.f_n[f]);
+    const double t_join = ms_since(q0);
+    if (opt.on_lists_ready) opt.on_lists_ready();
+    if (opt.on_bottom_ready) opt.on_bottom_ready();
+    sym_levels(G);
+    sym_row_views(G, std::max(1, opt.threads));
+    if (tv) fprintf(stderr, "[dsss pg symbolic] %d parts + an interface of %d: interface and coordinates %.2f ms, the parts (largest %d separators) %.2f ms, joined %.2f ms, levels and row views %.2f ms | ns %d nnzL %lld bins %d fronts %d (max %d rows) panels %d levels %d front arena %.1f MB\n",
+                    K, nif, t_pre, [&] { int m = 0; for (auto& q : P) m = std::max(m, (int)q.glob_of.size()); return m; }(), t_parts - t_pre, t_join - t_parts, ms_since(q0) - t_join, ns, G.nnzL,
+                    nbG, nfG, G.max_front_n, G.npanels, G.nlev, G.front_doubles * 8e-6);
+    return true;
+}
+
+// host twin entry: one rank analysed by K parts of equal size in the chain order (CPU test-suite)
+extern "C" int dsss_host_pg_solve_parts(int ns, const int32_t* edge_a, const int32_t* edge_b, int nedges, const double* cx, const double* cy,
+                                        int K, const double* aval, const double* rhs, double* x, int64_t* stats8)
+{
+    if (ns < 1 || nedges < ns - 1 || !edge_a || !edge_b || !cx || !cy || K < 2 || !x || !aval || !rhs) return DSSS_E_ARG;
+    std::vector<std::pair<int, int>> edges(nedges);
+    for (int e = 0; e < nedges; ++e) {
+        edges[e] = { edge_a[e], edge_b[e] };
+        if (edge_a[e] < 0 || edge_a[e] >= ns || edge_b[e] < 0 || edge_b[e] >= ns) return DSSS_E_ARG;
+        if (e < ns - 1 && (edge_a[e] != e || edge_b[e] != e + 1)) return DSSS_E_ARG;
+    }
+    pg_sym S; pg_sym_opts opt;
+    if (getenv("DSSS_PG_BIN_COST")) opt.bin_cost = atof(getenv("DSSS_PG_BIN_COST"));
+    pg_sym_opts_env(opt);
+    std::vector<int> part(ns);
+    for (int k = 0; k < ns; ++k) part[k] = (int)((long long)k * K / ns);
+    if (!pg_symbolic_parts(ns, edges, ns - 1, cx, cy, part.data(), K, ns, opt, S)) return DSSS_E_STATE;
+    const int rc = pg_host_solve(S, nedges - (ns - 1), edges, aval, rhs, x);
+    if (stats8) {
+        stats8[0] = S.nnzL; stats8[1] = (int64_t)S.f_c0.size(); stats8[2] = S.npanels; stats8[3] = S.nlev;
+        stats8[4] = S.front_doubles; stats8[5] = 0; stats8[6] = (int64_t)S.bincols.size(); stats8[7] = S.max_front_n;
     }
     return rc == 0 ? DSSS_OK : (rc == -1 ? DSSS_E_NUMERIC : DSSS_E_STATE);
 }

@@ -38,6 +38,7 @@ struct pg_sym {
     std::vector<char> binned;
     std::vector<int> binptr, bincols;   // columns of every bin, ascending
     std::vector<int> bin_part;          // rank of every bin
+    std::vector<double> bin_work;       // work of every bin (the packing's estimate; pg_symbolic_parts orders the bins of all parts by it)
     std::vector<int> bin_perm;          // launch order of the bins: within every rank's range by descending work (the kernel's time is its longest
                                         // bin plus whatever starts late: long bins first, the short ones fill in behind them)
     std::vector<int> rlptr, rlcol, rlpos, rlrow;   // per target column: source columns k < j with L(j,k) != 0 and the position of that block (binned targets only)
@@ -134,6 +135,7 @@ struct pg_sym_opts {
     // interface out the same way: the front is summed over the ranks as it is); the nested dissection orders the other nodes only.
     // Their columns get col_part -1, their values the interface codes of dest_bin; no update matrix is packed for a collective.
     std::vector<int> iface_last;
+    bool iface_plain = false;           // with iface_last: the interface values stay ordinary values of the value array (no summed slots): one rank analysing by parts (pg_symbolic_parts)
 };
 
 void pg_sym_opts_env(pg_sym_opts& opt);    // DSSS_PG_ND_BOTH / DSSS_PG_LEAF overrides (analysis knobs kept for tools/pg_sweep.sh)
@@ -142,6 +144,15 @@ void pg_sym_opts_env(pg_sym_opts& opt);    // DSSS_PG_ND_BOTH / DSSS_PG_LEAF ove
 // part[k] (may be null): rank that owns separator k, non-decreasing in k.  cx, cy: DR positions of the separators.
 void pg_symbolic(int ns, const std::vector<std::pair<int, int>>& edges, int nchain, const double* cx, const double* cy,
                  const int* part, int nparts, const pg_sym_opts& opt, pg_sym& S);
+
+// ONE rank, analysed BY PARTS (round 6).  part[k]: part of separator k, non-decreasing, K parts.  The interface -- the separators with a
+// neighbour in a higher part -- is prescribed as the last, dense front; every part's own separators + the interface are ordered and analysed
+// independently of the other parts, all parts at the same time on the worker pool, and the results are joined into ONE ordinary
+// single-partition pg_sym (columns [part 0][part 1]...[interface], arenas and index spaces behind each other, the interface front taking
+// the children of all parts).  The phases of pg_symbolic do not speed up with threads at C3's size (a dozen fork / joins of 0.1 ms of work
+// each: one thread 4.0 ms, eight 3.4); whole parts do.  Returns false (S untouched) when the interface is wider than max_iface separators.
+bool pg_symbolic_parts(int ns, const std::vector<std::pair<int, int>>& edges, int nchain, const double* cx, const double* cy,
+                       const int* part, int K, int max_iface, const pg_sym_opts& opt, pg_sym& S);
 
 // Host twin of the numeric phase, used by the CPU test-suite only (the product path is dsss_pg.hip): factorises the matrix
 // given by `aval` (36 doubles per value index, see dest_bin) and solves for `rhs` (6 per separator, chain order).  Returns 0

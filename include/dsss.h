@@ -247,6 +247,11 @@ int dsss_host_pg_solve(int ns, const int32_t* edge_a, const int32_t* edge_b, int
  * chain prefix).  stats8[5]: original values that land in the interface front.                                            */
 int dsss_host_pg_solve_local(int ns, const int32_t* edge_a, const int32_t* edge_b, int nedges, const double* cx, const double* cy,
                              const int32_t* iface_last, int nlast, const double* aval36, const double* rhs6, double* x6_host, int64_t* stats8);
+/* the same for ONE rank analysed BY PARTS (pg_symbolic_parts: K parts of equal size in the chain order, each ordered and analysed on
+ * its own with the interface between the parts as the last, dense front, the results joined into one set of tables); the first
+ * ns-1 edges must be the chain.                                                                                               */
+int dsss_host_pg_solve_parts(int ns, const int32_t* edge_a, const int32_t* edge_b, int nedges, const double* cx, const double* cy,
+                             int K, const double* aval36, const double* rhs6, double* x6_host, int64_t* stats8);
 
 /* ------------------------------------------------------------------ instrumentation
  * accumulated GPU time (ms, HIP events on the context stream) and launch count per kernel family        */

@@ -13,7 +13,8 @@ pytestmark = pytest.mark.gpu
 
 SAME_BITS_PG = [("DSSS_SYM_THREADS", "1"), ("DSSS_SYM_THREADS", "5")]
 SAME_OPTIMUM_PG = [("DSSS_PG_BIN_COST", "300"), ("DSSS_PG_BIN_COST", "1200"), ("DSSS_PG_ND_BOTH", "1000000"), ("DSSS_PG_LEAF", "12"),
-                   ("DSSS_PG_ND_INDEX", "0")]       # coordinate medians only: the ordering of rounds 2 - 4 (no chain-order cut candidate)
+                   ("DSSS_PG_ND_INDEX", "0"),       # coordinate medians only: the ordering of rounds 2 - 4 (no chain-order cut candidate)
+                   ("DSSS_PG_PARTS_ANALYSIS", "0"), ("DSSS_PG_PARTS_ANALYSIS", "3"), ("DSSS_PG_PARTS_ANALYSIS", "16")]      # the analysis as ONE graph (rounds 1 - 5) / by 3 / by 16 parts (round 6; default: by the size of the graph)
 SAME_BITS_EX = [("DSSS_EX_UPLOAD_BATCH", "1"), ("DSSS_EX_UPLOAD_BATCH", "3"), ("DSSS_FS_THREADS", "1"),
                 ("DSSS_EX_SCRATCH_MB", "1"), ("DSSS_EX_SCRATCH_MB", "40")]      # batches of one frame / of a few (the default bound, 24 GB, holds all five)
 

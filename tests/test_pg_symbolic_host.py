@@ -211,6 +211,45 @@ def test_host_solve_with_a_prescribed_interface(case, monkeypatch):
         assert _solve_local(ea, eb, aval, rhs, cx, cy, [ns])[0] != 0
 
 
+@pytest.mark.parametrize("case,K", [("chain", 2), ("chain", 5), ("random", 3), ("lawnmower", 2), ("lawnmower", 4), ("lawnmower_big", 8), ("lawnmower_big", 16)])
+def test_host_solve_analysed_by_parts(case, K, monkeypatch):
+    """ONE rank, analysed by parts (pg_symbolic_parts, round 6): K parts of the chain order are ordered and analysed independently -- all
+    at the same time on the worker pool -- with the interface between the parts as the last dense front, and the K sets of tables are joined
+    into one (columns, factor positions, bins, roots, fronts, children, original entries, destinations: every index space behind the
+    previous part's).  The joined tables must solve the system exactly as the dense solver does, and twice the same way."""
+    monkeypatch.setenv("DSSS_PG_BIN_COST", "200")
+    if case == "chain":
+        ns, chords = 60, []
+        cx = np.arange(ns, dtype=float); cy = np.zeros(ns)
+    elif case == "random":
+        ns = 120
+        rng = np.random.default_rng(3)
+        chords = [(int(a), int(b)) for a, b in rng.integers(0, ns, (150, 2)) if abs(a - b) > 1]
+        chords = list({(min(a, b), max(a, b)) for a, b in chords})
+        cx = rng.uniform(0, 10, ns); cy = rng.uniform(0, 10, ns)
+    elif case == "lawnmower":
+        ns, chords, cx, cy = _lawnmower(6, 40, 5)
+    else:
+        ns, chords, cx, cy = _lawnmower(16, 90, 6)
+    ea, eb, aval, rhs, A = _system(ns, chords, 7)
+    ref = np.linalg.solve(A, rhs.ravel()).reshape(ns, 6)
+    from diasss_amd import capi
+    L = capi.lib()
+    p = lambda a: a.ctypes.data_as(C.c_void_p)
+
+    def run():
+        x = np.zeros((ns, 6)); st = np.zeros(8, np.int64)
+        rc = L.dsss_host_pg_solve_parts(ns, p(ea), p(eb), len(ea), p(cx), p(cy), K, p(np.ascontiguousarray(aval)), p(np.ascontiguousarray(rhs)), p(x), p(st))
+        assert rc == 0, rc
+        return x, st
+    x, st = run()
+    assert np.abs(x - ref).max() < 1e-10 * max(1.0, np.abs(ref).max())
+    x2, st2 = run()
+    assert np.array_equal(x, x2) and np.array_equal(st, st2)     # deterministic whatever the threads do
+    if case == "lawnmower_big":
+        assert st[1] > 3 and st[6] > 0 and st[3] >= 2            # fronts, binned columns and several levels all occur
+
+
 def test_host_solver_under_thread_sanitizer():
     """the analysis runs its parallel phases on a process-wide worker pool (spin-then-sleep workers, stolen-back tasks):
     three threads solve different graphs at once under -fsanitize=thread (tools/sanitize/run.sh; ASan/UBSan: `run.sh asan`)"""
