@@ -322,7 +322,7 @@ static int pg_solve_impl(dsss_ctx* c, const double* dr6, int total, const dsss_l
                         const int d = std::abs(g - target);
                         if (cross[g] < bcost || (cross[g] == bcost && d < bdist)) { bcost = cross[g]; bdist = d; best = g; }
                     }
-                    if (best > prev && bcost <= PG_PARTS_CUT_MAX) { starts.push_back(best); prev = best; }      // (an expensive boundary is left out: its two parts stay one)
+                    if (best > prev && bcost <= std::max(PG_PARTS_CUT_MAX, ns / 16384)) { starts.push_back(best); prev = best; }      // (an expensive boundary is left out: its two parts stay one)
                 }
                 for (int k = 0; k < ns; ++k) { while (p_cur < (int)starts.size() && k >= starts[p_cur]) ++p_cur; vpart[k] = p_cur; }
                 if (!starts.empty()) by_parts = pg_symbolic_parts(ns, redges, nseg, cx.data(), cy.data(), vpart.data(), (int)starts.size() + 1, PG_PARTS_IFACE_MAX, opt, S);

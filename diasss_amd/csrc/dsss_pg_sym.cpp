@@ -1249,7 +1249,8 @@ bool pg_symbolic_parts(int ns, const std::vector<std::pair<int, int>>& edges, in
         part_t& Q = P[p];
         Q.loc_of.assign(ns, -1);
         pg_sym_opts o = opt;
-        o.threads = 1; o.before_order = nullptr; o.on_bottom_ready = nullptr; o.on_lists_ready = nullptr; o.iface_plain = true; o.iface_last.clear();
+        o.threads = ns >= 131072 ? std::max(1, opt.threads / K) : 1;      // (a part of a C5-size graph is itself large enough for ranges; at C3's size forks cost what they gain)
+        o.before_order = nullptr; o.on_bottom_ready = nullptr; o.on_lists_ready = nullptr; o.iface_plain = true; o.iface_last.clear();
         for (int k = 0; k < ns; ++k)
             if (isif[k] || part[k] == p) { Q.loc_of[k] = (int)Q.glob_of.size(); if (isif[k]) o.iface_last.push_back(Q.loc_of[k]); Q.glob_of.push_back(k); }
         for (size_t g = 0; g < edges.size(); ++g) {

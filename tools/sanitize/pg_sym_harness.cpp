@@ -11,6 +11,8 @@ extern "C" int dsss_host_pg_solve(int ns, const int32_t* edge_a, const int32_t* 
                                   const int32_t* part, int nparts, const double* aval36, const double* rhs6, double* x6_host, int64_t* stats8);
 extern "C" int dsss_host_pg_solve_local(int ns, const int32_t* edge_a, const int32_t* edge_b, int nedges, const double* cx, const double* cy,
                                         const int32_t* iface_last, int nlast, const double* aval36, const double* rhs6, double* x6_host, int64_t* stats8);
+extern "C" int dsss_host_pg_solve_parts(int ns, const int32_t* edge_a, const int32_t* edge_b, int nedges, const double* cx, const double* cy,
+                                        int K, const double* aval36, const double* rhs6, double* x6_host, int64_t* stats8);
 static void run(unsigned seed, int ns, int nlc, int reps)
 {
     unsigned long long lcg = seed * 2654435761ull + 1; auto rnd = [&]() { lcg = lcg * 6364136223846793005ull + 1442695040888963407ull; return (int)((lcg >> 33) & 0x7fffffff); };
@@ -47,6 +49,16 @@ static void run(unsigned seed, int ns, int nlc, int reps)
     double dmax = 0; for (size_t i = 0; i < x.size(); ++i) dmax = fmax(dmax, fabs(x[i] - x2[i]));
     if (!(dmax < 1e-9)) { printf("prescribed interface: solutions differ by %g\n", dmax); exit(1); }
     printf("seed %u ok with a prescribed interface of %zu nodes (max difference %.1e)\n", seed, last.size(), dmax);
+    // one rank analysed by parts (round 6): the parts run at the same time on the pool, then write their shares of the joined tables
+    for (int K : { 3, 8 }) {
+        std::vector<double> x3((size_t)ns * 6);
+        int64_t st3[8];
+        const int rc3 = dsss_host_pg_solve_parts(ns, ea.data(), eb.data(), ne, cx.data(), cy.data(), K, aval.data(), rhs.data(), x3.data(), st3);
+        if (rc3) { printf("parts rc %d\n", rc3); exit(1); }
+        double d3 = 0; for (size_t i = 0; i < x.size(); ++i) d3 = fmax(d3, fabs(x[i] - x3[i]));
+        if (!(d3 < 1e-9)) { printf("analysis by %d parts: solutions differ by %g\n", K, d3); exit(1); }
+    }
+    printf("seed %u ok analysed by 3 and by 8 parts\n", seed);
 }
 // analysis only (x = NULL) of a graph beyond 65 536 separators: the passes of the ordering that run by ranges of a large node set (round 5:
 // key copies, histograms, marks, counts; the difference array of the chain-order cut with relaxed atomic adds)
