@@ -525,7 +525,7 @@ void pg_symbolic(int ns, const std::vector<std::pair<int, int>>& edges, int ncha
 {
     S = pg_sym();
     S.ns = ns; S.nparts = std::max(1, nparts);
-    const bool tv = getenv("DSSS_PG_VERBOSE") != nullptr;
+    const bool tv = getenv("DSSS_PG_VERBOSE") != nullptr && !opt.to_be_joined;      // (the parts of pg_symbolic_parts report together)
     auto tnow = [] { return std::chrono::steady_clock::now(); };
     auto tms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
     const auto q0 = tnow();
@@ -925,8 +925,8 @@ void pg_symbolic(int ns, const std::vector<std::pair<int, int>>& edges, int ncha
         });
     }
     const auto fC = tnow();
-    sym_levels(S);
-    if (tv && atoi(getenv("DSSS_PG_VERBOSE")) >= 2) {      // critical path of the schedule, root first
+    if (!opt.to_be_joined) sym_levels(S);
+    if (tv && atoi(getenv("DSSS_PG_VERBOSE")) >= 2 && !opt.to_be_joined) {      // critical path of the schedule, root first
         int f = -1;
         for (int g = 0; g < nf; ++g) if (S.f_level0[g] + S.f_npan[g] == S.nlev) f = g;
         while (f >= 0) {
@@ -937,7 +937,7 @@ void pg_symbolic(int ns, const std::vector<std::pair<int, int>>& edges, int ncha
         }
     }
     const auto fD = tnow();
-    sym_row_views(S, T);
+    if (!opt.to_be_joined) sym_row_views(S, T);
     const auto fE = tnow();
     // ---- children that cross from a rank's interior into the interface
     {
@@ -1250,7 +1250,7 @@ bool pg_symbolic_parts(int ns, const std::vector<std::pair<int, int>>& edges, in
         Q.loc_of.assign(ns, -1);
         pg_sym_opts o = opt;
         o.threads = ns >= 131072 ? std::max(1, opt.threads / K) : 1;      // (a part of a C5-size graph is itself large enough for ranges; at C3's size forks cost what they gain)
-        o.before_order = nullptr; o.on_bottom_ready = nullptr; o.on_lists_ready = nullptr; o.iface_plain = true; o.iface_last.clear();
+        o.before_order = nullptr; o.on_bottom_ready = nullptr; o.on_lists_ready = nullptr; o.iface_plain = true; o.to_be_joined = true; o.iface_last.clear();
         for (int k = 0; k < ns; ++k)
             if (isif[k] || part[k] == p) { Q.loc_of[k] = (int)Q.glob_of.size(); if (isif[k]) o.iface_last.push_back(Q.loc_of[k]); Q.glob_of.push_back(k); }
         for (size_t g = 0; g < edges.size(); ++g) {
@@ -1407,6 +1407,7 @@ bool pg_symbolic_parts(int ns, const std::vector<std::pair<int, int>>& edges, in
     if (opt.on_bottom_ready) opt.on_bottom_ready();
     sym_levels(G);
     sym_row_views(G, std::max(1, opt.threads));
+    if (tv) { fprintf(stderr, "[dsss pg symbolic] separators per part:"); for (auto& q : P) fprintf(stderr, " %d", q.nint); fprintf(stderr, "\n"); }
     if (tv) fprintf(stderr, "[dsss pg symbolic] %d parts + an interface of %d: interface and coordinates %.2f ms, the parts (largest %d separators) %.2f ms, joined %.2f ms, levels and row views %.2f ms | ns %d nnzL %lld bins %d fronts %d (max %d rows) panels %d levels %d front arena %.1f MB\n",
                     K, nif, t_pre, [&] { int m = 0; for (auto& q : P) m = std::max(m, (int)q.glob_of.size()); return m; }(), t_parts - t_pre, t_join - t_parts, ms_since(q0) - t_join, ns, G.nnzL,
                     nbG, nfG, G.max_front_n, G.npanels, G.nlev, G.front_doubles * 8e-6);

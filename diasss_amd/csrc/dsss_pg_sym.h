@@ -135,6 +135,7 @@ struct pg_sym_opts {
     // interface out the same way: the front is summed over the ranks as it is); the nested dissection orders the other nodes only.
     // Their columns get col_part -1, their values the interface codes of dest_bin; no update matrix is packed for a collective.
     std::vector<int> iface_last;
+    bool to_be_joined = false;          // pg_symbolic_parts: the panel levels and the per-row views of the fronts are built once, on the joined tables
     bool iface_plain = false;           // with iface_last: the interface values stay ordinary values of the value array (no summed slots): one rank analysing by parts (pg_symbolic_parts)
 };
 
