@@ -1242,7 +1242,7 @@ bool pg_symbolic_parts(int ns, const std::vector<std::pair<int, int>>& edges, in
         long long nnz = 0, nchI = 0, nrelI = 0, nfaI = 0, nrows = 0;   // interior: factor blocks, children, rel entries, original entries, front rows
     };
     std::vector<part_t> P(K);
-    if (opt.before_order) opt.before_order();                      // (the coordinates: every part needs its own copy before it orders)
+    std::once_flag coords_once;                                    // (the coordinates may still be on their way: the parts build their graphs first, ONE of them waits, the others behind it)
     const double t_pre = ms_since(q0);
     // ---- phase 1: every part on its own
     dsss_pool_run(K, [&](int p) {
@@ -1259,6 +1259,7 @@ bool pg_symbolic_parts(int ns, const std::vector<std::pair<int, int>>& edges, in
         }
         const int nsl = (int)Q.glob_of.size();
         Q.cx.resize(nsl); Q.cy.resize(nsl);
+        std::call_once(coords_once, [&] { if (opt.before_order) opt.before_order(); });
         for (int i = 0; i < nsl; ++i) { Q.cx[i] = cx[Q.glob_of[i]]; Q.cy[i] = cy[Q.glob_of[i]]; }
         pg_symbolic(nsl, Q.ledges, 0, Q.cx.data(), Q.cy.data(), nullptr, 1, o, Q.S);
         Q.nint = nsl - nif;
@@ -1408,7 +1409,7 @@ bool pg_symbolic_parts(int ns, const std::vector<std::pair<int, int>>& edges, in
     sym_levels(G);
     sym_row_views(G, std::max(1, opt.threads));
     if (tv) { fprintf(stderr, "[dsss pg symbolic] separators per part:"); for (auto& q : P) fprintf(stderr, " %d", q.nint); fprintf(stderr, "\n"); }
-    if (tv) fprintf(stderr, "[dsss pg symbolic] %d parts + an interface of %d: interface and coordinates %.2f ms, the parts (largest %d separators) %.2f ms, joined %.2f ms, levels and row views %.2f ms | ns %d nnzL %lld bins %d fronts %d (max %d rows) panels %d levels %d front arena %.1f MB\n",
+    if (tv) fprintf(stderr, "[dsss pg symbolic] %d parts + an interface of %d: interface %.2f ms, the parts (their graphs, the wait for the coordinates, the analyses; largest %d separators) %.2f ms, joined %.2f ms, levels and row views %.2f ms | ns %d nnzL %lld bins %d fronts %d (max %d rows) panels %d levels %d front arena %.1f MB\n",
                     K, nif, t_pre, [&] { int m = 0; for (auto& q : P) m = std::max(m, (int)q.glob_of.size()); return m; }(), t_parts - t_pre, t_join - t_parts, ms_since(q0) - t_join, ns, G.nnzL,
                     nbG, nfG, G.max_front_n, G.npanels, G.nlev, G.front_doubles * 8e-6);
     return true;
