@@ -307,7 +307,8 @@ static int pg_solve_impl(dsss_ctx* c, const double* dr6, int total, const dsss_l
             // equal-count position: one difference array over the separators prices them all), every part is ordered and analysed on its own
             // thread with the interface between the parts as the last dense front, and the tables are joined.
             bool by_parts = false;
-            int K = getenv("DSSS_PG_PARTS_ANALYSIS") ? atoi(getenv("DSSS_PG_PARTS_ANALYSIS")) : (ns >= 6000 ? std::min(16, std::max(2, ns / 2800)) : 0);
+            // (parts of about a thousand separators, at most 8, up to C3's size -- C2: 3 292 separators in 3 parts, step 7.6 -> 6.6 ms --; 16 from 64 k separators on)
+            int K = getenv("DSSS_PG_PARTS_ANALYSIS") ? atoi(getenv("DSSS_PG_PARTS_ANALYSIS")) : (ns >= 1500 ? (ns < 65536 ? std::min(8, std::max(2, ns / 1000)) : 16) : 0);
             if (nparts == 1 && K >= 2 && ne > 0) {
                 K = std::min(K, ns / 8);
                 std::vector<int> cross(ns + 1, 0), vpart(ns, 0);
