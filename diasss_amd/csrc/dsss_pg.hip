@@ -309,6 +309,7 @@ static int pg_solve_impl(dsss_ctx* c, const double* dr6, int total, const dsss_l
             bool by_parts = false;
             // (parts of about a thousand separators, at most 8, up to C3's size -- C2: 3 292 separators in 3 parts, step 7.6 -> 6.6 ms --; 16 from 64 k separators on)
             int K = getenv("DSSS_PG_PARTS_ANALYSIS") ? atoi(getenv("DSSS_PG_PARTS_ANALYSIS")) : (ns >= 1500 ? (ns < 65536 ? std::min(8, std::max(2, ns / 1000)) : 16) : 0);
+            if (!getenv("DSSS_PG_PARTS_ANALYSIS")) { const int hw = (int)std::thread::hardware_concurrency(); K = hw >= 4 ? std::min(K, hw) : 0; }      // (the parts need threads of their own: on a host with fewer than four the one graph is the shorter analysis)
             if (nparts == 1 && K >= 2 && ne > 0) {
                 K = std::min(K, ns / 8);
                 std::vector<int> cross(ns + 1, 0), vpart(ns, 0);
