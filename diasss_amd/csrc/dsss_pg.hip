@@ -290,6 +290,9 @@ static int pg_solve_impl(dsss_ctx* c, const double* dr6, int total, const dsss_l
             cxl.resize(nsl); cyl.resize(nsl);
             opt.before_order = [&] { coords_fut.wait(); for (size_t i = 0; i < glob_of.size(); ++i) { cxl[i] = cx[glob_of[i]]; cyl[i] = cy[glob_of[i]]; } };
             opt.on_bottom_ready = nullptr; opt.on_lists_ready = nullptr;      // (nothing goes up early: the tables below come last)
+            // a rank's share of the bins leaves most of the chip empty, and the bins kernel lasts as long as its longest bin: shorter bins, more
+            // of the tree in the fronts (the slowest rank of 8 at C3: 12.2 -> 11.5 ms; on one GPU, where 877 bins fill the chip, 600 is the optimum)
+            if (!getenv("DSSS_PG_BIN_COST") && nsl < 16384) opt.bin_cost = 120;      // (a rank of C5 has thousands of bins of its own: the one-GPU optimum holds there)
             opt.threads = sym_threads(nsl);
             pg_symbolic(nsl, ledges, 0, cxl.data(), cyl.data(), nullptr, 1, opt, S);
             pg_build_schedule(S, 0, 1, SO);
